@@ -1,0 +1,96 @@
+"""CPU tier: pins the numpy oracle (oracle/t2l_oracle.py) against golden vectors produced by running the
+imported reference (oracle/gen_golden.py). Tolerances are stated per check."""
+import numpy as np
+
+from oracle import t2l_oracle as O
+from text2loc_amd import synth
+
+
+def _cells(g):
+    return {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+
+
+def test_object_reductions_match_reference(golden):
+    g = golden("objects_reduce")
+    cells = synth.make_cells(int(g["n_cells"]), seed=int(g["cell_seed"]), with_pn_feat=True)
+    n = int(g["n_objects"])
+    for i, (b, o, label, xyz, rgb) in enumerate(synth.make_object_points(cells, int(g["cell_seed"]))):
+        if i >= n:
+            break
+        crgb, cidx, center, npts = O.object_reductions(xyz, rgb, synth.COLORS)
+        assert np.array_equal(crgb, g["color_rgb"][i])  # bit-exact: same numpy reductions
+        # the reference stores COLOR_NAMES.index(name): first occurrence of the duplicate "gray" (cells.py:94)
+        assert synth.COLOR_NAMES.index(synth.COLOR_NAMES[cidx]) == g["color_table_index"][i]
+        assert synth.color_name_to_embed_index(cidx) == g["color_embed_index"][i]
+        assert np.array_equal(center, g["center"][i])
+        assert npts == g["n_pts"][i]
+        assert synth.KNOWN_CLASS.index(label) + 1 == g["class_index"][i]
+
+
+def test_encoder_embed_mode(golden):
+    g = golden("encoder_embed")
+    sd = synth.make_object_branch_weights(int(g["weight_seed"]))
+    out, feats, _ = O.encode_cells(_cells(g), sd, class_embed=True, color_embed=True, return_stages=True)
+    # fp32 vs torch-CPU fp32: tolerance 2e-5 absolute on O(1) features, 1e-5 on unit-norm embeddings
+    assert np.abs(feats - g["object_features"]).max() < 2e-5
+    assert np.abs(out - g["cell_embeddings"]).max() < 1e-5
+
+
+def test_encoder_published_mode_downstream_of_pointnet(golden):
+    g = golden("encoder_pn")
+    sd = synth.make_object_branch_weights(int(g["weight_seed"]))
+    cells = _cells(g)
+    cells["pn_feat"] = synth.make_cells(int(g["n_cells"]), seed=int(g["cell_seed"]), with_pn_feat=True)["pn_feat"]
+    out, feats, _ = O.encode_cells(cells, sd, class_embed=False, color_embed=False, return_stages=True)
+    assert np.abs(feats - g["object_features"]).max() < 2e-5
+    assert np.abs(out - g["cell_embeddings"]).max() < 1e-5
+
+
+def test_e2e_cells_then_retrieval(golden):
+    g = golden("retrieval_e2e")
+    sd = synth.make_object_branch_weights(int(g["weight_seed"]))
+    enc = O.encode_cells(_cells(g), sd, class_embed=True, color_embed=True)
+    assert np.abs(enc - g["cell_encodings"]).max() < 1e-5
+    k = int(g["top_k"].max())
+    idx, sc = O.retrieve_topk(g["cell_encodings"], g["text_encodings"], k)
+    assert np.array_equal(idx, g["top_rows"])  # integer-exact
+    assert np.abs(sc - g["top_scores"]).max() < 1e-12  # float64 dot, summation order may differ
+    centers = 0.5 * (g["cell_bbox_w"][:, 0:2] + g["cell_bbox_w"][:, 3:5])
+    acc, close = O.eval_accuracies(idx, g["db_cell_ids"], g["query_cell_ids"], g["query_pose_w"][:, 0:2], centers,
+                                   float(g["cell_size"]), list(g["top_k"]))
+    assert np.array_equal(np.array([acc[k] for k in g["top_k"]]), g["acc"])
+    assert np.array_equal(np.array([close[k] for k in g["top_k"]]), g["acc_close"])
+    scene = np.array([c.split("_")[0] for c in g["db_cell_ids"]])
+    qscene = np.array([c.split("_")[0] for c in g["query_cell_ids"]])
+    at = O.coarse_pose_accuracies(idx, g["query_pose_w"][:, 0:2], qscene, g["cell_bbox_w"][:, 0:2], scene,
+                                  float(g["cell_size"]), list(g["top_k"]), list(g["threshs"]))
+    got = np.array([[at[k][t] for t in g["threshs"]] for k in g["top_k"]])
+    assert np.array_equal(got, g["acc_thresh"])
+
+
+def test_retrieval_big_integer_exact(golden):
+    g = golden("retrieval_big")
+    db, q, target = synth.make_retrieval_problem(int(g["n_cells"]), int(g["n_queries"]), seed=int(g["seed"]),
+                                                 noise=float(g["noise"]))
+    assert np.array_equal(target, g["target"])
+    idx, sc = O.retrieve_topk(db, q, int(g["k"]))
+    assert np.array_equal(idx, g["top_rows"])
+    assert np.abs(sc - g["top_scores"]).max() < 1e-12
+    hit = [(target[:, None] == idx[:, :k]).any(axis=1).mean() for k in g["top_k"]]
+    assert np.allclose(hit, g["acc"])
+
+
+def test_contrastive_loss_and_grads(golden):
+    g = golden("loss")
+    loss, ga, gp = O.contrastive_loss(g["anchor"], g["positive"], float(g["temperature"]))
+    assert abs(loss - float(g["loss"])) < 1e-6
+    assert np.abs(ga - g["grad_anchor"]).max() < 1e-6
+    assert np.abs(gp - g["grad_positive"]).max() < 1e-6
+
+
+def test_text_head(golden):
+    g = golden("text_head")
+    sd = synth.make_language_head_weights(int(g["weight_seed"]))
+    hidden = synth.make_t5_hidden(6 * int(g["batch"]), int(g["n_tokens"]), seed=int(g["hidden_seed"]))
+    out = O.text_head(hidden, sd, int(g["batch"]))
+    assert np.abs(out - g["text_embeddings"]).max() < 2e-5

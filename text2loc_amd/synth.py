@@ -1,0 +1,208 @@
+"""Seeded synthetic inputs and weights for the coarse-retrieval hot path.
+
+No KITTI360Pose data, checkpoints or T5 weights exist in this environment, so tests, the bench,
+``smoke()`` and the golden-fixture generator all draw from the generators below (numpy PCG64
+streams, stable across platforms). The distributions follow SURVEY.md §8(d):
+
+* cells: n_i ~ U{6..35} objects (exercises the >28 truncation), per object a class index 1..22,
+  mean rgb U[0,1]^3, centre U[0,1]^3, point count ~ clipped log-normal matched to the statistics the
+  reference hard-codes in ``models/object_encoder.py:43-44`` (mean 1826.68, std 2516.89);
+* weights: one array per ``state_dict`` key of the reference's coarse model (key names and shapes
+  per SURVEY.md §8(b)), BatchNorm running statistics perturbed so that BN folding is exercised;
+* retrieval embeddings: unit-normalised N(0,1)^256 rows with one planted positive per query.
+
+Nothing here is on the product compute path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# Table values follow datapreparation/kitti360pose/utils.py:48-69 (class names, alphabetical) and
+# :210-231 (8 fitted colour centres / their names; 'gray' appears twice in the reference).
+KNOWN_CLASS = [
+    "box", "bridge", "building", "fence", "garage", "guard rail", "lamp", "pad", "parking", "pole",
+    "road", "sidewalk", "smallpole", "stop", "terrain", "traffic light", "traffic sign",
+    "trash bin", "tunnel", "vegetation", "vending machine", "wall",
+]
+COLOR_NAMES = ["dark-green", "gray", "gray-green", "bright-gray", "gray", "black", "green", "beige"]
+COLORS = np.array(
+    [
+        [47.2579917, 49.75368454, 42.4153065],
+        [136.32696657, 136.95241796, 126.02741229],
+        [87.49822126, 91.69058836, 80.14558512],
+        [213.91030679, 216.25033052, 207.24611073],
+        [110.39218852, 112.91977458, 103.68638249],
+        [27.47505158, 28.43996795, 25.16840296],
+        [66.65951839, 70.22342483, 60.20395996],
+        [171.00852191, 170.05737735, 155.00130334],
+    ]
+) / 255.0
+
+NUM_MEAN = 1826.6844940968194  # models/object_encoder.py:43
+NUM_STD = 2516.8905096993817  # models/object_encoder.py:44
+
+
+# ----------------------------------------------------------------------------------------------
+# weights
+# ----------------------------------------------------------------------------------------------
+def _linear(rng, out_f, in_f, prefix, sd):
+    b = 1.0 / np.sqrt(in_f)
+    sd[prefix + ".weight"] = rng.uniform(-b, b, size=(out_f, in_f)).astype(np.float32)
+    sd[prefix + ".bias"] = rng.uniform(-b, b, size=(out_f,)).astype(np.float32)
+
+
+def _bn(rng, c, prefix, sd):
+    sd[prefix + ".weight"] = rng.uniform(0.5, 1.5, size=(c,)).astype(np.float32)
+    sd[prefix + ".bias"] = (0.1 * rng.standard_normal(c)).astype(np.float32)
+    sd[prefix + ".running_mean"] = (0.3 * rng.standard_normal(c)).astype(np.float32)
+    sd[prefix + ".running_var"] = rng.uniform(0.5, 2.0, size=(c,)).astype(np.float32)
+    sd[prefix + ".num_batches_tracked"] = np.array(100, dtype=np.int64)
+
+
+def _mlp(rng, channels, prefix, sd, last_relu=True):
+    """Key layout of the reference's get_mlp / get_mlp2 (models/language_encoder.py:16-74):
+    ``{prefix}.{layer}.0`` = Linear, ``{prefix}.{layer}.1`` = BatchNorm1d."""
+    for i in range(1, len(channels)):
+        _linear(rng, channels[i], channels[i - 1], f"{prefix}.{i - 1}.0", sd)
+        _bn(rng, channels[i], f"{prefix}.{i - 1}.1", sd)
+
+
+def _encoder_layer(rng, d, ff, prefix, sd):
+    """Key layout of torch.nn.TransformerEncoderLayer (post-norm, as the reference uses it)."""
+    b = np.sqrt(6.0 / (d + 3 * d))
+    sd[prefix + ".self_attn.in_proj_weight"] = rng.uniform(-b, b, size=(3 * d, d)).astype(np.float32)
+    sd[prefix + ".self_attn.in_proj_bias"] = (0.02 * rng.standard_normal(3 * d)).astype(np.float32)
+    _linear(rng, d, d, prefix + ".self_attn.out_proj", sd)
+    _linear(rng, ff, d, prefix + ".linear1", sd)
+    _linear(rng, d, ff, prefix + ".linear2", sd)
+    for n in ("norm1", "norm2"):
+        sd[f"{prefix}.{n}.weight"] = rng.uniform(0.8, 1.2, size=(d,)).astype(np.float32)
+        sd[f"{prefix}.{n}.bias"] = (0.05 * rng.standard_normal(d)).astype(np.float32)
+
+
+def make_object_branch_weights(seed: int = 0, embed_dim: int = 256, num_layers: int = 2,
+                               use_features=("class", "color", "position", "num")) -> dict:
+    """state_dict (numpy) of the 3D-submap branch: ``object_encoder.*`` (minus PointNet++) and
+    ``obj_inter_module.*``. Shapes: models/object_encoder.py:28-64, models/cell_retrieval.py:35."""
+    rng = np.random.default_rng([seed, 0xC311])
+    sd: dict = {}
+    d = embed_dim
+    emb = rng.standard_normal((len(KNOWN_CLASS) + 1, d)).astype(np.float32)
+    emb[0] = 0.0  # padding_idx=0 row (object_encoder.py:33)
+    sd["object_encoder.class_embedding.weight"] = emb
+    # known_colors dict has 7 distinct names + "<unk>" = 8 rows (object_encoder.py:35-37)
+    cemb = rng.standard_normal((len(set(COLOR_NAMES)) + 1, d)).astype(np.float32)
+    cemb[0] = 0.0
+    sd["object_encoder.color_embedding.weight"] = cemb
+    _mlp(rng, [3, 64, d], "object_encoder.pos_encoder", sd)
+    _mlp(rng, [3, 64, d], "object_encoder.color_encoder", sd)
+    _mlp(rng, [1, 64, d], "object_encoder.num_encoder", sd)
+    _mlp(rng, [256, d], "object_encoder.mlp_pointnet", sd)
+    _mlp(rng, [len(use_features) * d, d], "object_encoder.mlp_merge", sd)
+    for layer in range(num_layers):
+        _encoder_layer(rng, d, 2 * d, f"obj_inter_module.{layer}", sd)
+    return sd
+
+
+def make_language_head_weights(seed: int = 0, embed_dim: int = 256, t5_dim: int = 1024) -> dict:
+    """state_dict (numpy) of the text head after T5 (models/language_encoder.py:95-101)."""
+    rng = np.random.default_rng([seed, 0x7E47])
+    sd: dict = {}
+    _encoder_layer(rng, t5_dim, 4 * t5_dim, "language_encoder.intra_module.0", sd)
+    _mlp(rng, [t5_dim, embed_dim], "language_encoder.inter_mlp", sd)
+    _encoder_layer(rng, embed_dim, 4 * embed_dim, "language_encoder.inter_module.0", sd)
+    return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# cells (packed per-object features; the reference derives these from Object3d point sets)
+# ----------------------------------------------------------------------------------------------
+def nearest_color_index(rgb_mean: np.ndarray) -> np.ndarray:
+    """Index into COLORS of the nearest centre (datapreparation/kitti360pose/imports.py:33-38)."""
+    rgb_mean = np.atleast_2d(rgb_mean)
+    d = np.linalg.norm(rgb_mean[:, None, :] - COLORS[None, :, :], axis=2)
+    return np.argmin(d, axis=1)
+
+
+def color_name_to_embed_index(color_table_index: np.ndarray) -> np.ndarray:
+    """COLORS index -> row of ``color_embedding``: the reference builds
+    ``{name: i for i, name in enumerate(COLOR_NAMES)}`` (object_encoder.py:35) so the duplicate
+    'gray' maps both 1 and 4 to 4, and 'dark-green' -> 0 (the padding row)."""
+    name_to_idx = {c: i for i, c in enumerate(COLOR_NAMES)}
+    lut = np.array([name_to_idx[c] for c in COLOR_NAMES], dtype=np.int32)
+    return lut[np.asarray(color_table_index)]
+
+
+def make_cells(n_cells: int, seed: int = 0, min_obj: int = 6, max_obj: int = 35,
+               with_pn_feat: bool = False) -> dict:
+    """Packed SoA description of ``n_cells`` synthetic cells.
+
+    Returns a dict with ``counts i32[B]``, ``offsets i32[B+1]`` and per-object arrays
+    ``class_idx i32``, ``color_idx i32`` (row of color_embedding), ``rgb f32[.,3]``,
+    ``center f32[.,3]``, ``n_pts f32`` and optionally ``pn_feat f32[.,256]``.
+    """
+    rng = np.random.default_rng([seed, 0xCE11])
+    counts = rng.integers(min_obj, max_obj + 1, size=n_cells).astype(np.int32)
+    offsets = np.zeros(n_cells + 1, dtype=np.int32)
+    np.cumsum(counts, out=offsets[1:])
+    total = int(offsets[-1])
+    class_idx = rng.integers(1, len(KNOWN_CLASS) + 1, size=total).astype(np.int32)
+    rgb = rng.uniform(0.0, 1.0, size=(total, 3))
+    center = rng.uniform(0.0, 1.0, size=(total, 3))
+    # log-normal with the mean/std hard-coded in the reference
+    sigma2 = np.log(1.0 + (NUM_STD / NUM_MEAN) ** 2)
+    mu = np.log(NUM_MEAN) - 0.5 * sigma2
+    n_pts = np.clip(np.round(rng.lognormal(mu, np.sqrt(sigma2), size=total)), 25, 60000)
+    out = {
+        "counts": counts,
+        "offsets": offsets,
+        "class_idx": class_idx,
+        "color_idx": color_name_to_embed_index(nearest_color_index(rgb)).astype(np.int32),
+        "rgb": rgb.astype(np.float32),
+        "center": center.astype(np.float32),
+        "n_pts": n_pts.astype(np.float32),
+    }
+    if with_pn_feat:
+        out["pn_feat"] = np.abs(rng.standard_normal((total, 256))).astype(np.float32)
+    return out
+
+
+def make_object_points(cells: dict, seed: int = 0):
+    """Yield (cell, obj_in_cell, label, xyz f64[n,3], rgb f32[n,3]) point sets whose statistics follow
+    ``cells``: stands in for the raw ``Object3d.xyz/.rgb`` the reference reduces on the host
+    (datapreparation/kitti360pose/imports.py:28-41)."""
+    rng = np.random.default_rng([seed, 0x0B7])
+    for b in range(len(cells["counts"])):
+        lo, hi = int(cells["offsets"][b]), int(cells["offsets"][b + 1])
+        for o in range(lo, hi):
+            n = int(cells["n_pts"][o])
+            xyz = cells["center"][o].astype(np.float64) + 0.02 * rng.standard_normal((n, 3))
+            rgb = np.clip(cells["rgb"][o].astype(np.float64) + 0.05 * rng.standard_normal((n, 3)), 0, 1)
+            yield b, o - lo, KNOWN_CLASS[int(cells["class_idx"][o]) - 1], xyz, rgb.astype(np.float32)
+
+
+def make_t5_hidden(n_sentences: int, n_tokens: int, dim: int = 1024, seed: int = 0) -> np.ndarray:
+    """Stand-in for a frozen T5 encoder's last_hidden_state f32[n_sentences, n_tokens, dim]."""
+    rng = np.random.default_rng([seed, 0x75])
+    return (0.2 * rng.standard_normal((n_sentences, n_tokens, dim))).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+# retrieval embeddings
+# ----------------------------------------------------------------------------------------------
+def unit_rows(x: np.ndarray) -> np.ndarray:
+    n = np.linalg.norm(x, axis=1, keepdims=True)
+    return x / np.maximum(n, 1e-12)
+
+
+def make_retrieval_problem(n_cells: int, n_queries: int, dim: int = 256, seed: int = 0,
+                           noise: float = 0.5):
+    """DB ``f32[N,dim]`` unit rows and queries ``f32[Q,dim]`` with a planted positive per query
+    (``t_q = normalize(c_pi(q) + noise * unit-noise)``).
+    Returns (db, queries, target_row i64[Q])."""
+    rng = np.random.default_rng([seed, 0x5EA7])
+    db = unit_rows(rng.standard_normal((n_cells, dim))).astype(np.float32)
+    target = rng.integers(0, n_cells, size=n_queries)
+    nz = unit_rows(rng.standard_normal((n_queries, dim)))
+    q = unit_rows(db[target].astype(np.float64) + noise * nz).astype(np.float32)
+    return db, q, target.astype(np.int64)
