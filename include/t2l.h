@@ -1,0 +1,157 @@
+/*
+ * t2l.h — C ABI of the MI355X-native coarse-retrieval engine for Text2Loc (libt2l.so).
+ *
+ * The reference (Yan-Xia/Text2Loc) has NO plugin/operator/FFI layer: its boundary for this path is the
+ * duck-typed Python surface consumed by training/coarse.py:63-157 (eval_epoch) and
+ * evaluation/pipeline.py:41-87 (run_coarse). This header is the library a binding for that surface
+ * loads; text2loc_amd/engine.py is the ctypes binding, text2loc_amd/cell_retrieval.py and
+ * text2loc_amd/coarse.py mirror the reference's Python names on top of it.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative T2L_E* code on error; the message is available
+ *     from t2l_last_error(ctx). Nothing throws across the boundary.
+ *   - "dev" pointers are device (HBM) pointers on the context's GPU, "host" pointers are host memory.
+ *     All buffers are caller-allocated and caller-owned; the library copies what it keeps.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream). Calls are asynchronous on
+ *     that stream unless stated otherwise. A context is not thread-safe: the reference is a single
+ *     thread / single process per device, and so is this (one process per GPU; shards meet in RCCL).
+ *   - row ids are int32 (N < 2^31) and GLOBAL: local row + the shard's row_offset (t2l_db_set).
+ *   - embed dim is fixed at 256 (coarse_embed_dim of the published config, README.md:87-99).
+ */
+#ifndef T2L_H_
+#define T2L_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2L_ABI_VERSION 1
+#define T2L_EMBED_DIM 256
+#define T2L_OBJECT_SIZE 28 /* args.object_size, models/cell_retrieval.py:32 */
+#define T2L_MAX_TOPK 26    /* max(top_k) supported by the fused search (eval default is 10) */
+
+enum {
+  T2L_OK = 0,
+  T2L_EINVAL = -1,  /* bad argument (shape, K, null pointer, unknown name) */
+  T2L_ESTATE = -2,  /* call order: weights / database not loaded */
+  T2L_EHIP = -3,    /* a HIP runtime call failed (message carries hipGetErrorString) */
+  T2L_ENOMEM = -4
+};
+
+typedef struct t2l_ctx t2l_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+int t2l_abi_version(void);
+/* Replaces: model.to(device) (evaluation/pipeline.py:252). One context per GPU. */
+int t2l_create(t2l_ctx** out, int device_id);
+void t2l_destroy(t2l_ctx* ctx);
+const char* t2l_last_error(const t2l_ctx* ctx);
+
+/* ---- weights --------------------------------------------------------------------------------- */
+/* One fp32 tensor of the reference's checkpoint (torch.save'd state_dict, training/coarse.py:317-345),
+ * named by its state_dict key, e.g. "obj_inter_module.0.self_attn.in_proj_weight". */
+typedef struct {
+  const char* name;
+  const float* data; /* host, row-major, as stored by torch */
+  int64_t numel;
+} t2l_weight_desc;
+
+/* Feature switches of the 3D-submap branch (training/args.py:39-63): */
+typedef struct {
+  int32_t class_embed;   /* args.class_embed: 1 = class_embedding lookup, 0 = PointNet++ features2 -> mlp_pointnet */
+  int32_t color_embed;   /* args.color_embed: 1 = color_embedding lookup, 0 = color_encoder(mean rgb) */
+  int32_t use_class, use_color, use_position, use_num; /* args.use_features membership */
+  int32_t num_layers;    /* args.object_inter_module_num_layers (2) */
+  int32_t num_heads;     /* args.object_inter_module_num_heads (4) */
+} t2l_model_config;
+
+/* Replaces: CellRetrievalNetwork.load_state_dict(strict=False) (evaluation/pipeline.py:251) for the
+ * object branch. Folds eval-mode BatchNorm into the preceding Linear, re-lays weights out for the
+ * kernels and uploads them. Synchronous. Keys of other sub-modules (language_encoder.*, pointnet.*) are
+ * ignored; a missing REQUIRED key is T2L_EINVAL (stricter than strict=False on purpose: silent zero
+ * weights would void parity). */
+int t2l_load_weights(t2l_ctx* ctx, const t2l_weight_desc* w, int32_t n, const t2l_model_config* cfg);
+
+/* ---- cell encoding (a2+a4) ------------------------------------------------------------------- */
+/* Packed SoA replacement of List[List[Object3d]] (+ PointNet++ features2 when class_embed == 0).
+ * Per object o of cell b (offsets[b] <= o < offsets[b+1], dataset order):
+ *   class_idx  = known_classes.get(label, 0)            models/object_encoder.py:81
+ *   color_idx  = known_colors[get_color_text()]          models/object_encoder.py:83
+ *   rgb        = float32(mean rgb of the object's points)   imports.py:28-31, object_encoder.py:124-127
+ *   center     = float32(mean xyz)                          imports.py:40-41, object_encoder.py:133-134
+ *   n_pts      = float32(len(obj.xyz))                      object_encoder.py:141-143
+ *   pn_feat    = PointNet2(...).features2 of the object  [n_objects,256] (NULL when class_embed)   */
+typedef struct {
+  int32_t n_cells;
+  int32_t n_objects;
+  const int32_t* offsets;   /* dev i32[n_cells+1] */
+  const int32_t* class_idx; /* dev i32[n_objects] */
+  const int32_t* color_idx; /* dev i32[n_objects] */
+  const float* rgb;         /* dev f32[n_objects,3] */
+  const float* center;      /* dev f32[n_objects,3] */
+  const float* n_pts;       /* dev f32[n_objects] */
+  const float* pn_feat;     /* dev f32[n_objects,256] or NULL */
+} t2l_packed_cells;
+
+/* Replaces: CellRetrievalNetwork.encode_objects (models/cell_retrieval.py:65-110) in eval mode.
+ * out_emb: dev f32[n_cells,256], unit rows. Objects beyond the first 28 of a cell are ignored
+ * (cell_retrieval.py:94-98); the zero pad slots take part in attention and in the max-pool, as in
+ * the reference (no padding mask). */
+int t2l_encode_cells(t2l_ctx* ctx, const t2l_packed_cells* in, float* out_emb, void* stream);
+
+/* ---- database + search (a6) ------------------------------------------------------------------ */
+/* Replaces: the host array cell_encodings (training/coarse.py:81,105-113). Copies n_rows x 256 fp32
+ * rows (dev) into library-owned HBM. row_offset = global id of local row 0 (0 on a single GPU; the
+ * shard's first row when the DB is row-sharded over ranks). Synchronises the stream. */
+int t2l_db_set(t2l_ctx* ctx, const float* emb, int64_t n_rows, int64_t row_offset, void* stream);
+int64_t t2l_db_rows(const t2l_ctx* ctx);
+
+/* Replaces: the per-query loop `scores = cell_encodings @ text_encodings[q]; argsort(-scores)[:K]`
+ * (training/coarse.py:119-125). queries: dev f32[n_queries,256].
+ * out_idx:   dev i32[n_queries,K]  global row ids, best first; -1 where K > n_rows
+ * out_score: dev f64[n_queries,K]  float64 dot products of the f32 values (what the reference ranks by);
+ *                                  -inf where idx == -1. May be NULL.
+ * Result contract: identical to a float64 scan + stable descending sort (exact ties: lower row id
+ * first). Internally: f32 MFMA candidate scan -> float64 re-rank -> per-query certificate; queries
+ * whose certificate fails are re-done by an exact float64 scan on the device (no host round trip). */
+int t2l_search(t2l_ctx* ctx, const float* queries, int32_t n_queries, int32_t k, int32_t* out_idx,
+               double* out_score, void* stream);
+
+/* The ONE exchange step of the row-sharded database (new design; the reference is single-device):
+ * every rank searches its shard (global ids via row_offset), the per-rank [n_queries,k] results are
+ * all-gathered (RCCL over xGMI) into idx/score dev [parts][n_queries][k], and this merges them to the
+ * global top-k by (score desc, row id asc). parts * k <= 256. out_score may be NULL. */
+int t2l_merge_topk(t2l_ctx* ctx, const int32_t* idx, const double* score, int32_t parts, int32_t n_queries,
+                   int32_t k, int32_t* out_idx, double* out_score, void* stream);
+
+/* Number of queries of the LAST t2l_search that took the exact-scan fallback (synchronises). */
+int t2l_search_fallbacks(t2l_ctx* ctx, int32_t* out_count);
+
+/* ---- contrastive loss (a8) ------------------------------------------------------------------- */
+/* Replaces: ContrastiveLoss.forward (training/losses.py:269-283) and its autograd backward.
+ * anchor/positive: dev f32[batch,256] (need not be normalised: the loss re-normalises, :271-272).
+ * loss: dev f32[1]; grad_anchor/grad_positive: dev f32[batch,256] = d loss/d input, or NULL. batch <= 128. */
+int t2l_contrastive_loss(t2l_ctx* ctx, const float* anchor, const float* positive, int32_t batch,
+                         float temperature, float* loss, float* grad_anchor, float* grad_positive,
+                         void* stream);
+
+/* ---- knobs (tests / bench) ------------------------------------------------------------------- */
+/* "certify_eps_scale" (default 1.0): multiplies the f32 error bound of the search certificate; a huge
+ *     value forces every query through the exact fallback (used by the parity tests).
+ * "search_nsplit"     (default 0 = auto): DB row splits per query block in the scan kernel.
+ * "profile_events"    (default 0): record hipEvents around each kernel launch (t2l_kernel_stats). */
+int t2l_set_option(t2l_ctx* ctx, const char* name, double value);
+
+/* Per-kernel device time measured with hipEvent pairs recorded on the caller's stream around each launch
+ * (no synchronisation while recording; enabled by option "profile_events" = 1, off by default).
+ * Returns the average duration (ms) and the number of launches recorded since the previous call for
+ * name = "search_scan" | "search_rerank" | "encode_cells" | "contrastive_loss" (at most the last 512),
+ * then clears the record. Synchronises on the recorded events. */
+int t2l_kernel_stats(t2l_ctx* ctx, const char* name, float* out_avg_ms, int32_t* out_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T2L_H_ */

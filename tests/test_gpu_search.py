@@ -1,0 +1,158 @@
+"""GPU tier: the fused HIP search (through the C ABI) against the CPU oracle — integer-exact row ids."""
+import numpy as np
+import pytest
+
+from oracle import t2l_oracle as O
+from text2loc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    from text2loc_amd.engine import Engine
+
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _search(eng, db, q, k, row_offset=0):
+    import torch
+
+    eng.db_set(torch.from_numpy(np.ascontiguousarray(db)).cuda(), row_offset)
+    idx, sc = eng.search(torch.from_numpy(np.ascontiguousarray(q)).cuda(), k)
+    torch.cuda.synchronize()
+    return idx.cpu().numpy().astype(np.int64), sc.cpu().numpy()
+
+
+def test_golden_retrieval_big(eng, golden):
+    g = golden("retrieval_big")
+    db, q, _ = synth.make_retrieval_problem(int(g["n_cells"]), int(g["n_queries"]), seed=int(g["seed"]),
+                                            noise=float(g["noise"]))
+    idx, sc = _search(eng, db, q, int(g["k"]))
+    assert np.array_equal(idx, g["top_rows"])  # integer-exact vs the reference's own loop
+    assert np.abs(sc - g["top_scores"]).max() < 1e-12
+    assert eng.search_fallbacks() == 0
+
+
+def test_golden_e2e_ids(eng, golden):
+    g = golden("retrieval_e2e")
+    k = int(g["top_k"].max())
+    idx, sc = _search(eng, g["cell_encodings"], g["text_encodings"], k)
+    assert np.array_equal(idx, g["top_rows"])
+    assert np.abs(sc - g["top_scores"]).max() < 1e-12
+
+
+@pytest.mark.parametrize("n,q,k", [(1, 1, 1), (5, 3, 10), (31, 7, 5), (32, 128, 10), (33, 129, 10), (1000, 257, 26),
+                                   (4097, 64, 16), (11259, 300, 10)])
+def test_ragged_shapes_vs_oracle(eng, n, q, k):
+    db, qs, _ = synth.make_retrieval_problem(n, q, seed=100 + n, noise=2.0)
+    idx, sc = _search(eng, db, qs, k)
+    ridx, rsc = O.retrieve_topk(db, qs, k)
+    kk = ridx.shape[1]
+    assert np.array_equal(idx[:, :kk], ridx)
+    assert np.abs(sc[:, :kk] - rsc).max() < 1e-12
+    if kk < k:  # K > N: the tail is -1 / -inf
+        assert (idx[:, kk:] == -1).all() and np.isneginf(sc[:, kk:]).all()
+
+
+def test_exact_ties_lower_row_first(eng):
+    rng = np.random.default_rng(7)
+    base = synth.unit_rows(rng.standard_normal((40, 256))).astype(np.float32)
+    db = np.concatenate([base, base, base[:13]], axis=0)  # every row duplicated (some tripled)
+    q = synth.unit_rows(rng.standard_normal((50, 256))).astype(np.float32)
+    idx, sc = _search(eng, db, q, 10)
+    ridx, rsc = O.retrieve_topk(db, q, 10)
+    assert np.array_equal(idx, ridx)
+    assert np.abs(sc - rsc).max() < 1e-12
+
+
+def test_forced_fallback_matches(eng):
+    db, qs, _ = synth.make_retrieval_problem(3000, 40, seed=5, noise=2.0)
+    ridx, rsc = O.retrieve_topk(db, qs, 10)
+    eng.set_option("certify_eps_scale", 1e9)  # every certificate fails -> exact float64 scan kernel
+    try:
+        idx, sc = _search(eng, db, qs, 10)
+        assert eng.search_fallbacks() == 40
+    finally:
+        eng.set_option("certify_eps_scale", 1.0)
+    assert np.array_equal(idx, ridx)
+    assert np.abs(sc - rsc).max() < 1e-12
+
+
+def test_near_ties_are_certified_or_fall_back(eng):
+    # rows that differ by ~1e-7 in score: f32 cannot order them; the certificate must catch it
+    rng = np.random.default_rng(11)
+    q = synth.unit_rows(rng.standard_normal((8, 256))).astype(np.float32)
+    base = synth.unit_rows(rng.standard_normal((1, 256)))
+    db = (base + 1e-7 * rng.standard_normal((600, 256))).astype(np.float32)
+    idx, sc = _search(eng, db, q, 10)
+    ridx, rsc = O.retrieve_topk(db, q, 10)
+    assert np.array_equal(idx, ridx)
+    assert np.abs(sc - rsc).max() < 1e-12
+
+
+@pytest.mark.parametrize("nsplit", [1, 3, 8, 32])
+def test_nsplit_invariance(eng, nsplit):
+    db, qs, _ = synth.make_retrieval_problem(2500, 130, seed=9, noise=2.0)
+    ridx, _ = O.retrieve_topk(db, qs, 10)
+    eng.set_option("search_nsplit", nsplit)
+    try:
+        idx, _ = _search(eng, db, qs, 10)
+    finally:
+        eng.set_option("search_nsplit", 0)
+    assert np.array_equal(idx, ridx)
+
+
+def test_row_offset_and_logical_shards_merge(eng):
+    """8 logical shards on one GPU: per-shard top-k then the merge == unsharded result."""
+    from text2loc_amd.sharded import merge_topk, shard_bounds
+
+    db, qs, _ = synth.make_retrieval_problem(3001, 96, seed=3, noise=2.0)
+    ridx, rsc = O.retrieve_topk(db, qs, 10)
+    parts_i, parts_s = [], []
+    for r in range(8):
+        lo, hi = shard_bounds(len(db), 8, r)
+        i, s = _search(eng, db[lo:hi], qs, 10, row_offset=lo)
+        parts_i.append(i)
+        parts_s.append(s)
+    idx, sc = merge_topk(np.stack(parts_i), np.stack(parts_s), 10)
+    assert np.array_equal(idx, ridx)
+    assert np.abs(sc - rsc).max() < 1e-12
+
+
+def test_full_size_properties(eng):
+    """BASELINE config 2 size (N=11,259, Q=4,096): planted positives are retrieved, scores are sorted,
+    ids unique and in range, and a 256-query sample equals the oracle."""
+    db, qs, target = synth.make_retrieval_problem(11259, 4096, seed=1, noise=0.5)
+    idx, sc = _search(eng, db, qs, 10)
+    assert (idx[:, 0] == target).all()
+    assert (np.diff(sc, axis=1) <= 0).all()
+    assert ((idx >= 0) & (idx < 11259)).all()
+    assert all(len(set(r)) == 10 for r in idx[::64])
+    sel = np.arange(0, 4096, 16)
+    ridx, rsc = O.retrieve_topk(db, qs[sel], 10)
+    assert np.array_equal(idx[sel], ridx)
+    assert np.abs(sc[sel] - rsc).max() < 1e-12
+
+
+def test_hip_merge_kernel_vs_host_merge(eng):
+    import torch
+    from text2loc_amd.sharded import merge_topk_host
+
+    rng = np.random.default_rng(21)
+    P, Q, K = 8, 77, 10
+    idx = np.stack([np.sort(np.stack([rng.permutation(1000)[:K] for _ in range(Q)]) + 1000 * p, axis=1)
+                    for p in range(P)]).astype(np.int32)  # unique row ids, as shards are disjoint
+    sc = -np.sort(-rng.standard_normal((P, Q, K)), axis=2)
+    sc[3, :, 5:] = sc[3, :, 4:5]  # ties inside a shard
+    idx[5, :, 7:] = -1            # short shard
+    sc[5, :, 7:] = -np.inf
+    gi, gs = eng.merge_topk(torch.from_numpy(idx).cuda(), torch.from_numpy(sc).cuda())
+    torch.cuda.synchronize()
+    hi, hs = merge_topk_host(idx, sc, K)
+    assert np.array_equal(gi.cpu().numpy().astype(np.int64), hi)
+    assert np.array_equal(gs.cpu().numpy(), hs)

@@ -1,0 +1,209 @@
+// C ABI of libt2l.so (see include/t2l.h): context, database shard, options, timing.
+#include <string.h>
+
+#include "t2l_internal.h"
+
+namespace t2l {
+
+int fail(t2l_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+void event_begin(t2l_ctx* ctx, const char* name, hipStream_t s) {
+  if (!ctx->profile_events) return;
+  EventRing& e = ctx->events[name];
+  if (e.a.empty()) {
+    e.a.resize(kEventRing);
+    e.b.resize(kEventRing);
+    for (int i = 0; i < kEventRing; ++i) {
+      (void)hipEventCreate(&e.a[i]);
+      (void)hipEventCreate(&e.b[i]);
+    }
+  }
+  (void)hipEventRecord(e.a[e.head], s);
+}
+
+void event_end(t2l_ctx* ctx, const char* name, hipStream_t s) {
+  if (!ctx->profile_events) return;
+  EventRing& e = ctx->events[name];
+  (void)hipEventRecord(e.b[e.head], s);
+  e.head = (e.head + 1) % kEventRing;
+  if (e.count < kEventRing) ++e.count;
+}
+
+}  // namespace t2l
+
+using namespace t2l;
+
+extern "C" {
+
+int t2l_abi_version(void) { return T2L_ABI_VERSION; }
+
+int t2l_create(t2l_ctx** out, int device_id) {
+  if (!out) return T2L_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return T2L_EHIP;
+  if (hipSetDevice(device_id) != hipSuccess) return T2L_EHIP;
+  t2l_ctx* ctx = new t2l_ctx();
+  ctx->device = device_id;
+  if (hipMalloc(&ctx->db_norm_max, sizeof(float)) != hipSuccess ||
+      hipMalloc(&ctx->fb_count, sizeof(int32_t)) != hipSuccess) {
+    delete ctx;
+    return T2L_ENOMEM;
+  }
+  (void)hipMemset(ctx->db_norm_max, 0, sizeof(float));
+  (void)hipMemset(ctx->fb_count, 0, sizeof(int32_t));
+  *out = ctx;
+  return T2L_OK;
+}
+
+void t2l_destroy(t2l_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  free_weights(ctx);
+  for (void* p : {(void*)ctx->db, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->cand_idx,
+                  (void*)ctx->flags, (void*)ctx->fb_count})
+    if (p) (void)hipFree(p);
+  for (auto& kv : ctx->events) {
+    for (hipEvent_t ev : kv.second.a) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : kv.second.b) (void)hipEventDestroy(ev);
+  }
+  delete ctx;
+}
+
+const char* t2l_last_error(const t2l_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int t2l_load_weights(t2l_ctx* ctx, const t2l_weight_desc* w, int32_t n, const t2l_model_config* cfg) {
+  if (!ctx) return T2L_EINVAL;
+  if (!w || n <= 0 || !cfg) return fail(ctx, T2L_EINVAL, "t2l_load_weights: null/empty arguments");
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return load_weights_impl(ctx, w, n, cfg);
+}
+
+int t2l_encode_cells(t2l_ctx* ctx, const t2l_packed_cells* in, float* out_emb, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  if (!in || in->n_cells < 0 || in->n_objects < 0) return fail(ctx, T2L_EINVAL, "t2l_encode_cells: bad arguments");
+  if (in->n_cells == 0) return T2L_OK;
+  if (!out_emb || !in->offsets) return fail(ctx, T2L_EINVAL, "t2l_encode_cells: null buffer");
+  if (!ctx->enc) return fail(ctx, T2L_ESTATE, "t2l_encode_cells: weights not loaded (call t2l_load_weights)");
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return encode_impl(ctx, in, out_emb, (hipStream_t)stream);
+}
+
+int t2l_db_set(t2l_ctx* ctx, const float* emb, int64_t n_rows, int64_t row_offset, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  if (n_rows < 0 || (n_rows > 0 && !emb)) return fail(ctx, T2L_EINVAL, "t2l_db_set: bad arguments");
+  if (n_rows + row_offset >= (int64_t)INT32_MAX) return fail(ctx, T2L_EINVAL, "t2l_db_set: row ids must fit int32");
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t pad = (n_rows + kTileRows - 1) / kTileRows * kTileRows;
+  if (pad > ctx->db_cap) {
+    T2L_HIP(ctx, hipStreamSynchronize(s));
+    if (ctx->db) (void)hipFree(ctx->db);
+    ctx->db = nullptr;
+    ctx->db_cap = 0;
+    T2L_HIP(ctx, hipMalloc(&ctx->db, (size_t)pad * kD * sizeof(float)));
+    ctx->db_cap = pad;
+  }
+  ctx->db_rows = n_rows;
+  ctx->db_pad = pad;
+  ctx->row_offset = row_offset;
+  if (n_rows > 0) {
+    T2L_HIP(ctx, hipMemcpyAsync(ctx->db, emb, (size_t)n_rows * kD * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (pad > n_rows)
+      T2L_HIP(ctx, hipMemsetAsync(ctx->db + (size_t)n_rows * kD, 0, (size_t)(pad - n_rows) * kD * sizeof(float), s));
+  }
+  int rc = db_norm_impl(ctx, s);
+  if (rc != T2L_OK) return rc;
+  T2L_HIP(ctx, hipStreamSynchronize(s));
+  return T2L_OK;
+}
+
+int64_t t2l_db_rows(const t2l_ctx* ctx) { return ctx ? ctx->db_rows : -1; }
+
+int t2l_search(t2l_ctx* ctx, const float* queries, int32_t n_queries, int32_t k, int32_t* out_idx, double* out_score,
+               void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  if (n_queries < 0 || k < 1 || k > T2L_MAX_TOPK)
+    return fail(ctx, T2L_EINVAL, "t2l_search: need n_queries >= 0 and 1 <= k <= T2L_MAX_TOPK");
+  if (n_queries == 0) return T2L_OK;
+  if (!queries || !out_idx) return fail(ctx, T2L_EINVAL, "t2l_search: null buffer");
+  if (ctx->db_pad == 0 && ctx->db_rows == 0 && !ctx->db) {
+    // an empty shard is legal (ragged sharding); it answers -1 / -inf everywhere
+  }
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return search_impl(ctx, queries, n_queries, k, out_idx, out_score, (hipStream_t)stream);
+}
+
+int t2l_merge_topk(t2l_ctx* ctx, const int32_t* idx, const double* score, int32_t parts, int32_t n_queries, int32_t k,
+                   int32_t* out_idx, double* out_score, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  if (parts < 1 || n_queries < 0 || k < 1 || k > T2L_MAX_TOPK)
+    return fail(ctx, T2L_EINVAL, "t2l_merge_topk: bad parts / n_queries / k");
+  if (n_queries == 0) return T2L_OK;
+  if (!idx || !score || !out_idx) return fail(ctx, T2L_EINVAL, "t2l_merge_topk: null buffer");
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return merge_impl(ctx, idx, score, parts, n_queries, k, out_idx, out_score, (hipStream_t)stream);
+}
+
+int t2l_search_fallbacks(t2l_ctx* ctx, int32_t* out_count) {
+  if (!ctx || !out_count) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  T2L_HIP(ctx, hipDeviceSynchronize());
+  T2L_HIP(ctx, hipMemcpy(out_count, ctx->fb_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+  return T2L_OK;
+}
+
+int t2l_contrastive_loss(t2l_ctx* ctx, const float* anchor, const float* positive, int32_t batch, float temperature,
+                         float* loss, float* grad_anchor, float* grad_positive, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  if (batch < 1 || batch > 128 || !(temperature > 0.f))
+    return fail(ctx, T2L_EINVAL, "t2l_contrastive_loss: need 1 <= batch <= 128 and temperature > 0");
+  if (!anchor || !positive || !loss) return fail(ctx, T2L_EINVAL, "t2l_contrastive_loss: null buffer");
+  if ((grad_anchor == nullptr) != (grad_positive == nullptr))
+    return fail(ctx, T2L_EINVAL, "t2l_contrastive_loss: pass both gradients or neither");
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return loss_impl(ctx, anchor, positive, batch, temperature, loss, grad_anchor, grad_positive, (hipStream_t)stream);
+}
+
+int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
+  if (!ctx || !name) return T2L_EINVAL;
+  if (!strcmp(name, "certify_eps_scale")) {
+    if (!(value >= 0)) return fail(ctx, T2L_EINVAL, "certify_eps_scale must be >= 0");
+    ctx->eps_scale = value;
+  } else if (!strcmp(name, "search_nsplit")) {
+    if (value < 0 || value > kMaxParts / 2) return fail(ctx, T2L_EINVAL, "search_nsplit out of range [0,32]");
+    ctx->nsplit_override = (int)value;
+  } else if (!strcmp(name, "profile_events")) {
+    ctx->profile_events = value != 0;
+  } else {
+    return fail(ctx, T2L_EINVAL, std::string("unknown option: ") + name);
+  }
+  return T2L_OK;
+}
+
+int t2l_kernel_stats(t2l_ctx* ctx, const char* name, float* out_avg_ms, int32_t* out_count) {
+  if (!ctx || !name || !out_avg_ms || !out_count) return T2L_EINVAL;
+  *out_avg_ms = 0.f;
+  *out_count = 0;
+  auto it = ctx->events.find(name);
+  if (it == ctx->events.end() || it->second.count == 0) return T2L_OK;
+  EventRing& e = it->second;
+  double sum = 0.0;
+  for (int i = 0; i < e.count; ++i) {
+    const int slot = ((e.head - 1 - i) % kEventRing + kEventRing) % kEventRing;
+    T2L_HIP(ctx, hipEventSynchronize(e.b[slot]));
+    float ms = 0.f;
+    T2L_HIP(ctx, hipEventElapsedTime(&ms, e.a[slot], e.b[slot]));
+    sum += ms;
+  }
+  *out_avg_ms = (float)(sum / e.count);
+  *out_count = e.count;
+  e.count = 0;
+  return T2L_OK;
+}
+
+}  // extern "C"

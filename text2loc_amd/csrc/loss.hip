@@ -1,0 +1,191 @@
+// Symmetric InfoNCE of training/losses.py:255-283 (ContrastiveLoss), forward + analytic backward, as ONE
+// single-workgroup launch (the op is latency bound: 2*B^2*D = 2.1 MFLOP at B = 64).
+//
+//   ia_i = 1/|im_i|, ip_j = 1/|s_j|                                   losses.py:271-272
+//   sim  = (im @ s^T) * ia_i * ip_j            f32 MFMA 32x32x2      :274
+//   E    = exp(sim / T); R_i = sum_j E_ij; C_j = sum_i E_ij           :277-278 (no max-subtraction, as the reference)
+//   loss = mean_i( log C_i + log R_i - 2 sim_ii / T )                 == :280-281
+//   G    = dloss/dsim = (E_ij/C_j + E_ij/R_i - 2 delta_ij) / (T B)
+//   d im = ((G  @ s^) - im^ * rowdot) * ia ;  d s = ((G^T @ im^) - s^ * rowdot) * ip     (x^ = x/|x|)
+//
+// E/G lives in LDS ([Bp][Bp+1] f32, Bp = B rounded up to 32, B <= 128); operands stream from L2.
+#include "t2l_internal.h"
+
+namespace t2l {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float half_sum(float v) {  // sum over the 32 lanes that share lane>>5
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// One 32-row block of  out = ((M @ X^) - Y^ * rowdot) * iy   where M is G (transpose=false) or G^T.
+// X^ = x * ix (rows k), Y^ = y * iy (rows i). Result rows i0..i0+31, all 256 columns, one wave.
+__device__ __forceinline__ void grad_rowblock(const float* __restrict__ G, int ldg, bool transpose, int B, int i0,
+                                              const float* __restrict__ x, const float* __restrict__ ix,
+                                              const float* __restrict__ y, const float* __restrict__ iy,
+                                              float* __restrict__ out, int lane) {
+  const int col = lane & 31, half = lane >> 5;
+  f32x16 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const int gi = i0 + col;  // A-operand row of this lane
+  for (int k0 = 0; k0 < B; k0 += 2) {
+    const int k = k0 + half;
+    float a = 0.f, scale = 0.f;
+    if (k < B) {
+      a = transpose ? G[k * ldg + gi] : G[gi * ldg + k];
+      scale = ix[k];
+    }
+    const float* xr = x + (size_t)min(k, B - 1) * kD + col;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xr[32 * t] * scale, acc[t], 0, 0, 0);
+  }
+  // lane holds column 32*t + col, rows i0 + (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    const bool ok = row < B;
+    const float inv = ok ? iy[row] : 0.f;
+    const float* yr = y + (size_t)(ok ? row : 0) * kD + col;
+    float yv[8];
+    float part = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      yv[t] = yr[32 * t] * inv;
+      part += acc[t][r] * yv[t];
+    }
+    const float dot = half_sum(part);
+    if (ok) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) out[(size_t)row * kD + 32 * t + col] = (acc[t][r] - yv[t] * dot) * inv;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void contrastive_kernel(const float* __restrict__ im, const float* __restrict__ s,
+                                                             int B, float inv_t, float* __restrict__ loss,
+                                                             float* __restrict__ g_im, float* __restrict__ g_s) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Bp = (B + 31) / 32 * 32;
+  const int ldg = Bp + 1;
+  float* E = smem;                // [Bp][ldg]
+  float* ia = E + Bp * ldg;       // [Bp]
+  float* ip = ia + Bp;            // [Bp]
+  float* diag = ip + Bp;          // [Bp] sim_ii
+  float* R = diag + Bp;           // [Bp]
+  float* C = R + Bp;              // [Bp]
+  float* red = C + Bp;            // [4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+
+  for (int i = tid; i < Bp * ldg; i += 256) E[i] = 0.f;
+  for (int i = wave; i < Bp; i += 4) {  // inverse norms, one wave per row
+    float sa = 0.f, sp = 0.f;
+    if (i < B) {
+      const float4 a = reinterpret_cast<const float4*>(im + (size_t)i * kD)[lane];
+      const float4 p = reinterpret_cast<const float4*>(s + (size_t)i * kD)[lane];
+      sa = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+      sp = p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      sa += __shfl_xor(sa, off);
+      sp += __shfl_xor(sp, off);
+    }
+    if (lane == 0) {
+      ia[i] = i < B ? 1.f / sqrtf(sa) : 0.f;
+      ip[i] = i < B ? 1.f / sqrtf(sp) : 0.f;
+    }
+  }
+  __syncthreads();
+
+  // sim tiles (32x32), k permuted so that each lane streams one contiguous half row of each operand
+  const int nb = Bp / 32;
+  for (int tile = wave; tile < nb * nb; tile += 4) {
+    const int i0 = (tile / nb) * 32, j0 = (tile % nb) * 32;
+    const float4* ap = reinterpret_cast<const float4*>(im + (size_t)min(i0 + col, B - 1) * kD + half * 128);
+    const float4* pp = reinterpret_cast<const float4*>(s + (size_t)min(j0 + col, B - 1) * kD + half * 128);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+    for (int q = 0; q < 32; ++q) {
+      const float4 a = ap[q], p = pp[q];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, p.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, p.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, p.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, p.w, acc, 0, 0, 0);
+    }
+    const int j = j0 + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (i < B && j < B) {
+        const float sim = acc[r] * ia[i] * ip[j];
+        E[i * ldg + j] = __expf(sim * inv_t);
+        if (i == j) diag[i] = sim;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < Bp) {
+    float r = 0.f, c = 0.f;
+    for (int j = 0; j < B; ++j) {
+      r += E[tid * ldg + j];
+      c += E[j * ldg + tid];
+    }
+    R[tid] = r;
+    C[tid] = c;
+  }
+  __syncthreads();
+  {
+    float v = 0.f;
+    for (int i = tid; i < B; i += 256) v += __logf(C[i]) + __logf(R[i]) - 2.f * diag[i] * inv_t;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) red[wave] = v;
+  }
+  __syncthreads();
+  if (tid == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+  if (!g_im) return;
+
+  const float sc = inv_t / (float)B;
+  for (int e = tid; e < B * B; e += 256) {
+    const int i = e / B, j = e % B;
+    const float v = E[i * ldg + j];
+    E[i * ldg + j] = (v / C[j] + v / R[i] - (i == j ? 2.f : 0.f)) * sc;
+  }
+  __syncthreads();
+  for (int task = wave; task < 2 * nb; task += 4) {
+    const int i0 = (task % nb) * 32;
+    if (task < nb)
+      grad_rowblock(E, ldg, false, B, i0, s, ip, im, ia, g_im, lane);
+    else
+      grad_rowblock(E, ldg, true, B, i0, im, ia, s, ip, g_s, lane);
+  }
+}
+
+int loss_impl(t2l_ctx* ctx, const float* a, const float* p, int B, float temp, float* loss, float* ga, float* gp,
+              hipStream_t s) {
+  if (B > 128) return fail(ctx, T2L_EINVAL, "t2l_contrastive_loss: batch > 128 not supported by the fused kernel");
+  const int Bp = (B + 31) / 32 * 32;
+  const size_t lds = ((size_t)Bp * (Bp + 1) + 5 * Bp + 4) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&contrastive_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+    attr_done = true;
+  }
+  event_begin(ctx, "contrastive_loss", s);
+  hipLaunchKernelGGL(contrastive_kernel, dim3(1), dim3(256), lds, s, a, p, B, 1.0f / temp, loss, ga, gp);
+  event_end(ctx, "contrastive_loss", s);
+  T2L_HIP(ctx, hipGetLastError());
+  return T2L_OK;
+}
+
+}  // namespace t2l

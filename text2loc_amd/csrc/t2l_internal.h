@@ -1,0 +1,90 @@
+// Internal declarations shared by the HIP translation units of libt2l.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "t2l.h"
+
+namespace t2l {
+
+constexpr int kD = T2L_EMBED_DIM;   // 256
+constexpr int kS = T2L_OBJECT_SIZE; // 28 object slots per cell
+constexpr int kSP = 32;             // slots padded to one 32-row MFMA tile
+
+// ---- search geometry -------------------------------------------------------------------------
+constexpr int kTileRows = 32;                      // DB rows per LDS tile (one 32x32 MFMA row block)
+constexpr int kRowStrideF = kD + 4;                // LDS row stride in floats (1040 B): ds_read_b128 conflict-free
+constexpr int kTileFloats = kTileRows * kRowStrideF;
+constexpr int kQPerWave = 32;
+constexpr int kScanWaves = 4;
+constexpr int kQPerBlock = kQPerWave * kScanWaves; // 128 queries per workgroup
+constexpr int kStageCap = 32;                      // staged (score,row) slots per lane between compactions
+constexpr int kMaxParts = 64;                      // per-query candidate partitions (= 2 * nsplit) the re-rank merges
+
+// Per-kernel timing: a ring of hipEvent pairs recorded on the caller's stream (no sync when recording);
+// t2l_kernel_stats() reads them back after the caller's own synchronisation point.
+constexpr int kEventRing = 512;
+struct EventRing {
+  std::vector<hipEvent_t> a, b;
+  int head = 0;   // next slot
+  int count = 0;  // recorded since the last read (saturates at kEventRing)
+};
+
+struct EncoderWeights;  // encode.hip
+
+}  // namespace t2l
+
+struct t2l_ctx {
+  int device = 0;
+  std::string err;
+  // database shard
+  float* db = nullptr;       // [db_pad,256], rows >= db_rows are zero
+  int64_t db_rows = 0, db_pad = 0, db_cap = 0, row_offset = 0;
+  float* db_norm_max = nullptr;  // dev f32[1]: max row 2-norm (feeds the certificate's error bound)
+  // search workspace
+  float* cand_score = nullptr;
+  int32_t* cand_idx = nullptr;
+  int32_t* flags = nullptr;      // dev i32[Q]: 1 = certificate failed -> exact fallback
+  int32_t* fb_count = nullptr;   // dev i32[1]
+  size_t cand_cap = 0, flag_cap = 0;
+  // encoder
+  t2l::EncoderWeights* enc = nullptr;
+  // options
+  double eps_scale = 1.0;
+  int nsplit_override = 0;
+  bool profile_events = false;
+  std::unordered_map<std::string, t2l::EventRing> events;
+};
+
+namespace t2l {
+
+int fail(t2l_ctx* ctx, int code, const std::string& msg);
+
+#define T2L_HIP(ctx, expr)                                                                     \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return ::t2l::fail((ctx), T2L_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+void event_begin(t2l_ctx* ctx, const char* name, hipStream_t s);
+void event_end(t2l_ctx* ctx, const char* name, hipStream_t s);
+
+// search.hip
+int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s);
+int db_norm_impl(t2l_ctx* ctx, hipStream_t s);
+int merge_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int parts, int Q, int K, int32_t* out_idx,
+               double* out_score, hipStream_t s);
+// encode.hip
+int load_weights_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_model_config* cfg);
+int encode_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float* out, hipStream_t s);
+void free_weights(t2l_ctx* ctx);
+// loss.hip
+int loss_impl(t2l_ctx* ctx, const float* a, const float* p, int B, float temp, float* loss, float* ga, float* gp,
+              hipStream_t s);
+
+}  // namespace t2l

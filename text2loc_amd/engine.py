@@ -1,0 +1,227 @@
+"""ctypes binding of libt2l.so (include/t2l.h) — the only door between Python and the HIP kernels.
+
+PyTorch is used here for plumbing only: device allocations (``torch.empty(..., device='cuda')``), the
+current HIP stream handle and, in ``sharded.py``, ``torch.distributed`` (RCCL). No arithmetic of the
+hot path runs in PyTorch, and there is NO CPU fallback: importing this module without the built
+library, or calling it with CPU tensors, raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os.path as osp
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+EMBED_DIM = 256
+OBJECT_SIZE = 28
+MAX_TOPK = 26
+_LIB_PATH = osp.join(osp.dirname(osp.abspath(__file__)), "libt2l.so")
+
+
+class T2LError(RuntimeError):
+    pass
+
+
+class _WeightDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
+
+
+class _ModelConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("class_embed", "color_embed", "use_class", "use_color", "use_position",
+                                         "use_num", "num_layers", "num_heads")]
+
+
+class _PackedCells(C.Structure):
+    _fields_ = [("n_cells", C.c_int32), ("n_objects", C.c_int32), ("offsets", C.c_void_p), ("class_idx", C.c_void_p),
+                ("color_idx", C.c_void_p), ("rgb", C.c_void_p), ("center", C.c_void_p), ("n_pts", C.c_void_p),
+                ("pn_feat", C.c_void_p)]
+
+
+EXPORTS = {
+    "t2l_abi_version": (C.c_int, []),
+    "t2l_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "t2l_destroy": (None, [C.c_void_p]),
+    "t2l_last_error": (C.c_char_p, [C.c_void_p]),
+    "t2l_load_weights": (C.c_int, [C.c_void_p, C.POINTER(_WeightDesc), C.c_int32, C.POINTER(_ModelConfig)]),
+    "t2l_encode_cells": (C.c_int, [C.c_void_p, C.POINTER(_PackedCells), C.c_void_p, C.c_void_p]),
+    "t2l_db_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "t2l_db_rows": (C.c_int64, [C.c_void_p]),
+    "t2l_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "t2l_merge_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
+    "t2l_search_fallbacks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "t2l_contrastive_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "t2l_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "t2l_kernel_stats": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+}
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen libt2l.so and declare every symbol of include/t2l.h. Raises if the library is absent:
+    there is deliberately no fallback (build it with ``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not osp.exists(_LIB_PATH):
+        raise T2LError(f"{_LIB_PATH} is missing: the HIP extension is not built and there is no CPU fallback")
+    lib = C.CDLL(_LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _stream_ptr() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_ptr(t: Optional[torch.Tensor], dtype, name: str) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise T2LError(f"{name}: expected a CUDA (HIP) tensor; the engine has no CPU path")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise T2LError(f"{name}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+class Engine:
+    """One context per GPU (one process per GPU)."""
+
+    def __init__(self, device: Optional[int] = None):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise T2LError("no MI355X visible: the engine needs a GPU (there is no CPU fallback)")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        h = C.c_void_p()
+        rc = self.lib.t2l_create(C.byref(h), self.device)
+        if rc != 0:
+            raise T2LError(f"t2l_create failed with {rc}")
+        self._h = h
+        self._db_keepalive = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.t2l_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise T2LError(f"libt2l error {rc}: {self.lib.t2l_last_error(self._h).decode()}")
+
+    # ------------------------------------------------------------------ weights
+    def load_weights(self, state_dict: Dict[str, object], class_embed: bool, color_embed: bool,
+                     use_features=("class", "color", "position", "num"), num_layers: int = 2, num_heads: int = 4):
+        """state_dict: name -> torch.Tensor | np.ndarray (fp32), keys as in the reference checkpoint."""
+        keep, descs = [], []
+        for name, v in state_dict.items():
+            if not (name.startswith("object_encoder.") or name.startswith("obj_inter_module.")):
+                continue
+            if name.startswith("object_encoder.pointnet.") or name.endswith("num_batches_tracked"):
+                continue
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            keep.append(a)
+            descs.append(_WeightDesc(name.encode(), a.ctypes.data, a.size))
+        arr = (_WeightDesc * len(descs))(*descs)
+        cfg = _ModelConfig(int(class_embed), int(color_embed), int("class" in use_features),
+                           int("color" in use_features), int("position" in use_features), int("num" in use_features),
+                           int(num_layers), int(num_heads))
+        self._check(self.lib.t2l_load_weights(self._h, arr, len(descs), C.byref(cfg)))
+
+    # ------------------------------------------------------------------ cell encoding
+    def encode_cells(self, packed: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """packed: offsets i32[B+1], class_idx/color_idx i32[n], rgb/center f32[n,3], n_pts f32[n],
+        optional pn_feat f32[n,256] — all on the GPU. Returns f32[B,256] unit rows."""
+        offsets = packed["offsets"]
+        n_cells = int(offsets.numel()) - 1
+        n_obj = int(packed["n_pts"].numel()) if packed.get("n_pts") is not None else int(packed["class_idx"].numel())
+        out = torch.empty((max(n_cells, 0), EMBED_DIM), dtype=torch.float32, device=offsets.device)
+        if n_cells <= 0:
+            return out
+        pc = _PackedCells(
+            n_cells, n_obj, _dev_ptr(offsets, torch.int32, "offsets"),
+            _dev_ptr(packed.get("class_idx"), torch.int32, "class_idx"),
+            _dev_ptr(packed.get("color_idx"), torch.int32, "color_idx"),
+            _dev_ptr(packed.get("rgb"), torch.float32, "rgb"), _dev_ptr(packed.get("center"), torch.float32, "center"),
+            _dev_ptr(packed.get("n_pts"), torch.float32, "n_pts"),
+            _dev_ptr(packed.get("pn_feat"), torch.float32, "pn_feat"))
+        self._check(self.lib.t2l_encode_cells(self._h, C.byref(pc), out.data_ptr(), _stream_ptr()))
+        return out
+
+    # ------------------------------------------------------------------ database + search
+    def db_set(self, emb: torch.Tensor, row_offset: int = 0):
+        n = int(emb.shape[0])
+        if emb.dim() != 2 or emb.shape[1] != EMBED_DIM:
+            raise T2LError(f"db_set: expected [N,{EMBED_DIM}], got {tuple(emb.shape)}")
+        ptr = _dev_ptr(emb, torch.float32, "db") if n > 0 else None
+        self._check(self.lib.t2l_db_set(self._h, ptr, n, int(row_offset), _stream_ptr()))
+
+    @property
+    def db_rows(self) -> int:
+        return int(self.lib.t2l_db_rows(self._h))
+
+    def search(self, queries: torch.Tensor, k: int, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """Returns (idx i32[Q,k] global row ids best-first, scores f64[Q,k]); asynchronous on the current stream."""
+        if queries.dim() != 2 or queries.shape[1] != EMBED_DIM:
+            raise T2LError(f"search: expected [Q,{EMBED_DIM}], got {tuple(queries.shape)}")
+        Q = int(queries.shape[0])
+        if out is None:
+            idx = torch.empty((Q, k), dtype=torch.int32, device=queries.device)
+            sc = torch.empty((Q, k), dtype=torch.float64, device=queries.device)
+        else:
+            idx, sc = out
+        qp = _dev_ptr(queries, torch.float32, "queries") if Q > 0 else None
+        self._check(self.lib.t2l_search(self._h, qp, Q, int(k), _dev_ptr(idx, torch.int32, "out_idx"),
+                                        _dev_ptr(sc, torch.float64, "out_score"), _stream_ptr()))
+        return idx, sc
+
+    def merge_topk(self, idx: torch.Tensor, score: torch.Tensor):
+        """idx i32[P,Q,K], score f64[P,Q,K] (all-gathered per-shard results) -> (i32[Q,K], f64[Q,K])."""
+        P, Q, K = (int(x) for x in idx.shape)
+        out_i = torch.empty((Q, K), dtype=torch.int32, device=idx.device)
+        out_s = torch.empty((Q, K), dtype=torch.float64, device=idx.device)
+        self._check(self.lib.t2l_merge_topk(self._h, _dev_ptr(idx, torch.int32, "idx"),
+                                            _dev_ptr(score, torch.float64, "score"), P, Q, K, out_i.data_ptr(),
+                                            out_s.data_ptr(), _stream_ptr()))
+        return out_i, out_s
+
+    def search_fallbacks(self) -> int:
+        c = C.c_int32(0)
+        self._check(self.lib.t2l_search_fallbacks(self._h, C.byref(c)))
+        return int(c.value)
+
+    # ------------------------------------------------------------------ loss
+    def contrastive_loss(self, anchor: torch.Tensor, positive: torch.Tensor, temperature: float, need_grad=True):
+        B = int(anchor.shape[0])
+        loss = torch.empty((1,), dtype=torch.float32, device=anchor.device)
+        ga = torch.empty_like(anchor) if need_grad else None
+        gp = torch.empty_like(positive) if need_grad else None
+        self._check(self.lib.t2l_contrastive_loss(
+            self._h, _dev_ptr(anchor, torch.float32, "anchor"), _dev_ptr(positive, torch.float32, "positive"), B,
+            float(temperature), loss.data_ptr(), _dev_ptr(ga, torch.float32, "ga"), _dev_ptr(gp, torch.float32, "gp"),
+            _stream_ptr()))
+        return loss, ga, gp
+
+    # ------------------------------------------------------------------ knobs
+    def set_option(self, name: str, value: float):
+        self._check(self.lib.t2l_set_option(self._h, name.encode(), float(value)))
+
+    def kernel_stats(self, name: str):
+        """(average ms, launches) of kernel ``name`` since the last call (needs option profile_events=1)."""
+        ms, n = C.c_float(0), C.c_int32(0)
+        self._check(self.lib.t2l_kernel_stats(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)

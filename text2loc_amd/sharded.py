@@ -1,0 +1,88 @@
+"""Row-sharded database search across the GPUs of one node (new design — the reference is
+single-process, single-device: training/coarse.py:235, no torch.distributed call sites).
+
+One process per GPU. Rank r owns DB rows [lo_r, hi_r) (contiguous, read-only, resident in its HBM). Every
+rank holds all queries. A search is: local fused top-k on the shard (global row ids via ``row_offset``)
+-> ONE collective, ``all_gather`` of the per-rank [Q,K] (id, float64 score) pairs over RCCL/xGMI
+(Q*K*12 bytes per rank: latency bound, link bandwidth is irrelevant) -> merge on every rank by
+(score desc, id asc). Because every shard's list is already exact in float64, the merged top-k equals the
+unsharded result bit for bit. Cell encoding is embarrassingly parallel over cells: no collective.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+
+def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row shard of rank ``rank``: ceil(n/world) rows each, the tail shards may be short or empty."""
+    per = -(-n_rows // world)
+    lo = min(n_rows, rank * per)
+    return lo, min(n_rows, lo + per)
+
+
+def merge_topk_host(idx: np.ndarray, score: np.ndarray, k: int):
+    """Host restatement of the merge (numpy) — used by the CPU (gloo) tests of the N>1 logic and as the
+    checker of the HIP merge kernel. idx i[P,Q,K] (-1 = empty), score f64[P,Q,K]."""
+    P, Q, K = idx.shape
+    ids = idx.transpose(1, 0, 2).reshape(Q, P * K).astype(np.int64)
+    sc = score.transpose(1, 0, 2).reshape(Q, P * K).astype(np.float64).copy()
+    sc[ids < 0] = -np.inf
+    big = np.where(ids < 0, np.iinfo(np.int64).max, ids)
+    out_i = np.empty((Q, k), dtype=np.int64)
+    out_s = np.empty((Q, k), dtype=np.float64)
+    for q in range(Q):
+        order = np.lexsort((big[q], -sc[q]))[:k]
+        out_i[q], out_s[q] = ids[q, order], sc[q, order]
+    out_i[np.isneginf(out_s)] = -1
+    return out_i, out_s
+
+
+merge_topk = merge_topk_host  # name used by the tests
+
+
+class ShardedSearcher:
+    """search_fn(queries, k) -> (idx[Q,K] int32, score[Q,K] float64) on this rank's shard (global ids);
+    merge_fn(idx[P,Q,K], score[P,Q,K]) -> (idx[Q,K], score[Q,K]). With an ``Engine`` both default to the
+    HIP kernels; the CPU tests inject host stand-ins to exercise the collective plumbing under gloo."""
+
+    def __init__(self, engine=None, group=None, search_fn: Optional[Callable] = None,
+                 merge_fn: Optional[Callable] = None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.engine = engine
+        self.search_fn = search_fn or (lambda q, k: engine.search(q, k))
+        self.merge_fn = merge_fn or (lambda i, s: engine.merge_topk(i, s))
+
+    def set_db_shard(self, all_rows_or_shard, n_total: Optional[int] = None):
+        """Give either the full [N,256] matrix (this rank keeps its slice) or this rank's slice + n_total."""
+        if n_total is None:
+            n_total = int(all_rows_or_shard.shape[0])
+            lo, hi = shard_bounds(n_total, self.world, self.rank)
+            shard = all_rows_or_shard[lo:hi].contiguous()
+        else:
+            lo, hi = shard_bounds(n_total, self.world, self.rank)
+            shard = all_rows_or_shard
+            assert shard.shape[0] == hi - lo
+        self.lo, self.hi, self.n_total = lo, hi, n_total
+        if self.engine is not None:
+            self.engine.db_set(shard, row_offset=lo)
+        return lo, hi
+
+    def search(self, queries, k: int):
+        import torch
+
+        idx, sc = self.search_fn(queries, k)
+        if self.world == 1:
+            return idx, sc
+        Q = idx.shape[0]
+        all_i = torch.empty((self.world, Q, k), dtype=idx.dtype, device=idx.device)
+        all_s = torch.empty((self.world, Q, k), dtype=sc.dtype, device=sc.device)
+        self.dist.all_gather_into_tensor(all_i, idx.contiguous(), group=self.group)
+        self.dist.all_gather_into_tensor(all_s, sc.contiguous(), group=self.group)
+        return self.merge_fn(all_i, all_s)
