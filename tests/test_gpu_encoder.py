@@ -83,8 +83,8 @@ def test_e2e_golden_cells_then_ids(eng, golden):
     got = idx.cpu().numpy()
     full = np.sort(g["cell_encodings"].astype(np.float64) @ g["text_encodings"].astype(np.float64).T, axis=0)[::-1]
     gaps = np.abs(np.diff(full[: k + 1], axis=0)).min(axis=0)
-    safe = gaps > 1e-4
-    assert safe.mean() > 0.5
+    safe = gaps > 1e-5  # encoder error is ~1e-7 per component; score error well below this
+    assert safe.sum() >= 8
     assert np.array_equal(got[safe], g["top_rows"][safe])
 
 
