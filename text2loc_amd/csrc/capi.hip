@@ -49,12 +49,12 @@ int t2l_create(t2l_ctx** out, int device_id) {
   t2l_ctx* ctx = new t2l_ctx();
   ctx->device = device_id;
   if (hipMalloc(&ctx->db_norm_max, sizeof(float)) != hipSuccess ||
-      hipMalloc(&ctx->fb_count, sizeof(int32_t)) != hipSuccess) {
+      hipMalloc(&ctx->fb_count, 2 * sizeof(int32_t)) != hipSuccess) {
     delete ctx;
     return T2L_ENOMEM;
   }
   (void)hipMemset(ctx->db_norm_max, 0, sizeof(float));
-  (void)hipMemset(ctx->fb_count, 0, sizeof(int32_t));
+  (void)hipMemset(ctx->fb_count, 0, 2 * sizeof(int32_t));
   *out = ctx;
   return T2L_OK;
 }
@@ -64,8 +64,8 @@ void t2l_destroy(t2l_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   free_weights(ctx);
-  for (void* p : {(void*)ctx->db, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->cand_idx,
-                  (void*)ctx->flags, (void*)ctx->fb_count})
+  for (void* p : {(void*)ctx->db, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
+                  (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count})
     if (p) (void)hipFree(p);
   for (auto& kv : ctx->events) {
     for (hipEvent_t ev : kv.second.a) (void)hipEventDestroy(ev);

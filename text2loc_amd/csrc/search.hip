@@ -3,18 +3,22 @@
 // Replaces the host loop of training/coarse.py:119-125 — per query a float64 `cell_encodings @ t`
 // (N x 256) and a full argsort — by three launches on one stream, no host round trip:
 //
-//   scan_kernel    f32 MFMA (v_mfma_f32_32x32x2_f32, bit-exact f32 FMA chains) over [128 queries] x
-//                  [DB split]; every lane owns (1 query, half of each 32-row tile) and keeps a sorted
-//                  top-L list in registers; scores are never written to HBM.
-//   rerank_kernel  one wave per query: merges the 2*nsplit sorted lists to the f32 top-L, re-scores
-//                  those L rows in float64 (what the reference ranks by), orders them by
-//                  (score desc, row asc), and CERTIFIES the result: every row that was not re-scored
-//                  has f32 score <= g_L, so if  s64_K - g_L > eps(f32 error bound)  the top-K equals
-//                  the float64 ranking exactly.
-//   exact_kernel   only for queries whose certificate failed: float64 scan of the whole shard.
+//   scan_kernel      f32 MFMA (v_mfma_f32_32x32x2_f32, bit-exact f32 FMA chains) over [128 queries] x
+//                    [DB split]. A lane owns (1 query, half of each 32-row tile) and keeps its top-L as a
+//                    sorted register list of KEYS = f32 score with the low `code_bits` mantissa bits
+//                    replaced by the row's position inside the split, so one v_med3_f32 per list element
+//                    inserts a score branch-free, in the shadow of the serially dependent MFMA chain.
+//                    Scores are never written to HBM.
+//   rerank_kernel    one wave per query: merges the 2*nsplit sorted lists to the top-L keys, re-scores
+//                    those rows in float64 (what the reference ranks by), orders them by (score desc,
+//                    row asc) and CERTIFIES: every row that was not re-scored has key <= g, so
+//                    s64_K > g + key-truncation + f32-rounding bound  ==> the top-K equals the float64
+//                    ranking exactly.
+//   fallback_kernel  only for queries whose certificate failed: (stage 2) re-score ALL kept candidates in
+//                    float64 and certify against the lists' floors; (stage 3) float64 scan of the shard.
 //
-// Data layout in HBM: DB f32[n_pad,256] row-major (n_pad = n rounded up to 32, tail rows zero and
-// masked by row >= n); queries f32[Q,256]; candidates f32/i32 [Q][2*nsplit][L].
+// HBM layout: DB f32[n_pad,256] row-major (n_pad = n rounded up to 32, tail rows zero and masked by
+// row >= n); queries f32[Q,256]; candidate keys f32 [Q][nsplit][2][L].
 #include <float.h>
 #include <limits.h>
 
@@ -26,44 +30,76 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define T2L_NEG_INF (-__builtin_inff())
 
-// Sorted (descending) register list; x goes after equal elements, so among equal scores the one seen
-// first (lower row id within a lane's ascending scan) stays ahead.
-template <int L>
-__device__ __forceinline__ void list_insert(float (&s)[L], int (&id)[L], float x, int xi) {
-#pragma unroll
-  for (int i = L - 1; i >= 1; --i) {
-    const bool c_prev = x > s[i - 1];
-    const bool c_cur = x > s[i];
-    id[i] = c_prev ? id[i - 1] : (c_cur ? xi : id[i]);
-    s[i] = c_prev ? s[i - 1] : (c_cur ? x : s[i]);
+// Sorted (descending) register list of keys. Element I of the NEW list depends only on OLD values:
+// s'[I] = med3(s[I-1], s[I], x) for a descending s, s'[0] = max(s[0], x). Updating I = L-1 .. 0 in place
+// therefore needs no temporaries and no compares.
+template <int L, int I = L - 1>
+__device__ __forceinline__ void ins_key(float (&s)[L], float x) {
+  if constexpr (I == 0) {
+    s[0] = __builtin_amdgcn_fmed3f(s[0], x, __builtin_inff());  // max without a canonicalising extra op
+  } else {
+    s[I] = __builtin_amdgcn_fmed3f(s[I - 1], s[I], x);
+    ins_key<L, I - 1>(s, x);
   }
-  const bool c0 = x > s[0];
-  id[0] = c0 ? xi : id[0];
-  s[0] = c0 ? x : s[0];
+}
+
+__device__ __forceinline__ float make_key(float v, int mask, int code) {
+  return __int_as_float((__float_as_int(v) & mask) | code);
+}
+
+// One 32-row DB tile: 128 MFMAs into `cur` (D[db row][query]); after every 8th MFMA one score of the
+// PREVIOUS tile (`prev`) is turned into a key and inserted into the lane's list. The MFMA chain is
+// serially dependent (64-cycle issue = 64-cycle latency), so the ~L+3 VALU instructions per insertion ride
+// in its shadow when spread over the gaps (sched_group_barrier pins the interleave).
+template <int L, int S = 0>
+__device__ __forceinline__ void tile_mfma(const float* tb, const float (&qa)[128], f32x16& cur, const f32x16& prev,
+                                          int prev_row0, int n_rows, int mask, int prev_code0, float (&ls)[L],
+                                          float4 (&ab)[4]) {
+  if constexpr (S < 32) {
+    if constexpr (S == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // the 4 prologue LDS reads go first
+    const float4 a = ab[S & 3];
+    if constexpr (S + 4 < 32) ab[S & 3] = *reinterpret_cast<const float4*>(tb + 4 * (S + 4));
+    cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qa[4 * S + 0], cur, 0, 0, 0);
+    cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qa[4 * S + 1], cur, 0, 0, 0);
+    cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qa[4 * S + 2], cur, 0, 0, 0);
+    cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qa[4 * S + 3], cur, 0, 0, 0);
+    if constexpr ((S & 1) == 1) {  // 8 MFMAs issued since the last insertion
+      constexpr int r = S >> 1;
+      const int row = prev_row0 + (r & 3) + 8 * (r >> 2);
+      const float key = make_key(prev[r], mask, prev_code0 + r);
+      ins_key<L>(ls, row < n_rows ? key : T2L_NEG_INF);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, (L + 3 + 7) / 8, 0);  // its share of the insertion VALU
+    }
+    if constexpr (S + 4 < 32) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // the LDS prefetch
+    tile_mfma<L, S + 1>(tb, qa, cur, prev, prev_row0, n_rows, mask, prev_code0, ls, ab);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
-// scan: grid = n_qblocks * nsplit workgroups of 256 threads; block b -> split b % nsplit so that
-// with nsplit a multiple of 8 every XCD (b % 8) keeps re-reading the same DB split from its own L2.
-// LDS: 2 x [32 rows x 260 f32] DB tiles (glds double buffer) + per-lane candidate staging.
+// scan: grid = n_qblocks * nsplit workgroups of 256 threads; block b -> split b % nsplit so that with
+// nsplit a multiple of 8 every XCD (b % 8) keeps re-reading the same DB split from its own L2.
+// LDS: 2 x [32 rows x 260 f32] DB tiles (glds double buffer), shared by the 4 waves (4 x 32 queries).
 // ------------------------------------------------------------------------------------------------
 template <int L>
-__global__ __launch_bounds__(256, 1) void scan_kernel(const float* __restrict__ db, int n_rows, int n_tiles,
-                                                      const float* __restrict__ q, int Q, int nsplit,
-                                                      float* __restrict__ cand_s, int* __restrict__ cand_i) {
+__global__ __launch_bounds__(256, 2) void scan_kernel(const float* __restrict__ db, int n_rows, int n_tiles, int per,
+                                                      int code_bits, const float* __restrict__ q, int Q, int nsplit,
+                                                      float* __restrict__ cand, int32_t* __restrict__ fb_count, int zero_counts) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tiles = smem;
-  float* stage_s = smem + 2 * kTileFloats;
-  int* stage_i = reinterpret_cast<int*>(stage_s + kScanWaves * kStageCap * 64);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
   const int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
-  const int per = (n_tiles + nsplit - 1) / nsplit;
   const int t0 = sp * per;
   const int t1 = min(n_tiles, t0 + per);
   const int qrow = qb * kQPerBlock + wave * kQPerWave + col;
   const int qload = min(qrow, Q - 1);
+  const int mask = ~((1 << code_bits) - 1);
+  if (zero_counts && blockIdx.x == 0 && tid < 2) fb_count[tid] = 0;  // the re-rank / fallback kernels run after this one
 
   // B operand (queries), register resident for the whole scan. The MFMA sums over k in any order as
   // long as A and B agree: lane (col, half) owns k in [128*half, 128*half+128), one contiguous
@@ -82,16 +118,14 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(const float* __restrict__ 
   }
 
   float ls[L];
-  int li[L];
 #pragma unroll
-  for (int i = 0; i < L; ++i) {
-    ls[i] = T2L_NEG_INF;
-    li[i] = -1;
+  for (int i = 0; i < L; ++i) ls[i] = T2L_NEG_INF;
+  f32x16 accA, accB;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    accA[r] = T2L_NEG_INF;
+    accB[r] = T2L_NEG_INF;
   }
-  float tau = T2L_NEG_INF;
-  int cnt = 0;
-  float* my_s = stage_s + wave * kStageCap * 64 + lane;
-  int* my_i = stage_i + wave * kStageCap * 64 + lane;
 
   auto issue = [&](int t, int buf) {
     const float* src = db + (size_t)t * kTileRows * kD + lane * 4;
@@ -103,132 +137,126 @@ __global__ __launch_bounds__(256, 1) void scan_kernel(const float* __restrict__ 
                                        (__attribute__((address_space(3))) void*)(dst + row * kRowStrideF), 16, 0, 0);
     }
   };
-  auto compact = [&]() {
-    for (int slot = 0; __any(slot < cnt); ++slot) {
-      const bool ok = slot < cnt;
-      const float v = ok ? my_s[slot * 64] : T2L_NEG_INF;
-      const int vi = ok ? my_i[slot * 64] : -1;
-      list_insert<L>(ls, li, v, vi);
-    }
-    cnt = 0;
-    tau = ls[L - 1];
-  };
-
-  if (t0 < t1) issue(t0, 0);
-  for (int t = t0; t < t1; ++t) {
-    const int buf = (t - t0) & 1;
+  // D[row][col]: a lane holds query `col` and DB rows (r&3) + 8*(r>>2) + 4*half of the tile; the key's
+  // code is ((tile - t0) << 4) | r  (the row is rebuilt from it, `half` and the split in the re-rank).
+  auto step = [&](int t, int buf, f32x16& cur, const f32x16& prev) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile t landed for every wave; every wave is done reading buffer buf^1
     if (t + 1 < t1) issue(t + 1, buf ^ 1);
-
     const float* tb = tiles + buf * kTileFloats + col * kRowStrideF + half * 128;
-    f32x16 acc;
+    float4 ab[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i = 0; i < 4; ++i) ab[i] = *reinterpret_cast<const float4*>(tb + 4 * i);
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-      const float4 a = *reinterpret_cast<const float4*>(tb + 4 * s);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qa[4 * s + 0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qa[4 * s + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qa[4 * s + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qa[4 * s + 3], acc, 0, 0, 0);
-    }
-    // D[row][col]: this lane holds query `col`, DB rows (r&3) + 8*(r>>2) + 4*half of the tile.
-    const int row0 = t * kTileRows + 4 * half;
+    for (int r = 0; r < 16; ++r) cur[r] = 0.f;
+    tile_mfma<L>(tb, qa, cur, prev, (t - 1) * kTileRows + 4 * half, n_rows, mask, (t - 1 - t0) << 4, ls, ab);
+  };
+
+  if (t0 < t1) issue(t0, 0);
+  for (int t = t0; t < t1; t += 2) {
+    step(t, 0, accA, accB);  // while tile t multiplies, tile t-1's scores (accB) enter the list
+    if (t + 1 < t1) step(t + 1, 1, accB, accA);
+  }
+  if (t0 < t1) {  // the last tile's scores are still in registers
+    const int row0 = (t1 - 1) * kTileRows + 4 * half;
+    const int code0 = (t1 - 1 - t0) << 4;
+    if ((t1 - t0) & 1) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row0 + (r & 3) + 8 * (r >> 2);
-      const float v = acc[r];
-      if (v > tau && row < n_rows) {
-        my_s[cnt * 64] = v;
-        my_i[cnt * 64] = row;
-        ++cnt;
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        ins_key<L>(ls, row < n_rows ? make_key(accA[r], mask, code0 + r) : T2L_NEG_INF);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        ins_key<L>(ls, row < n_rows ? make_key(accB[r], mask, code0 + r) : T2L_NEG_INF);
       }
     }
-    if (__any(cnt > kStageCap - 16)) compact();
   }
-  compact();
 
   if (qrow < Q) {
-    const size_t base = (((size_t)qrow * nsplit + sp) * 2 + half) * L;
+    float4* out = reinterpret_cast<float4*>(cand + (((size_t)qrow * nsplit + sp) * 2 + half) * L);
 #pragma unroll
-    for (int i = 0; i < L; ++i) {
-      cand_s[base + i] = ls[i];
-      cand_i[base + i] = li[i];
-    }
+    for (int i = 0; i < L / 4; ++i) out[i] = make_float4(ls[4 * i], ls[4 * i + 1], ls[4 * i + 2], ls[4 * i + 3]);
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// rerank: one wave per query, 4 queries per 256-thread block.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool better(float s, int i, float bs, int bi) { return s > bs || (s == bs && i < bi); }
+// key -> local DB row. part = 2*split + half.
+__device__ __forceinline__ int key_row(float key, int part, int per, int code_bits) {
+  const int code = __float_as_int(key) & ((1 << code_bits) - 1);
+  const int r = code & 15;
+  return (((part >> 1) * per + (code >> 4)) << 5) + (r & 3) + 8 * (r >> 2) + 4 * (part & 1);
+}
 
+// float64 dot of DB row `row` with the query fragment held by the wave (lane owns dims 4*lane..4*lane+3)
+__device__ __forceinline__ double wave_dot64(const float* __restrict__ db, int row, const float4 qv, int lane) {
+  const float4 dv = reinterpret_cast<const float4*>(db + (size_t)row * kD)[lane];
+  double d = (double)dv.x * qv.x + (double)dv.y * qv.y + (double)dv.z * qv.z + (double)dv.w * qv.w;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off);
+  return d;
+}
+
+// bound on (float64 score - key) for any row whose key is <= g: truncation of `code_bits` mantissa bits
+// (relative 2^(code_bits-23), doubled for slack) plus the f32 dot-product rounding error eps32.
+__device__ __forceinline__ double key_slack(float g, int code_bits, double eps32) {
+  return fabs((double)g) * ldexp(1.0, code_bits - 22) + eps32;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rerank (stage 1): one wave per query, 4 queries per 256-thread block.
+// ------------------------------------------------------------------------------------------------
 template <int L>
 __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ db, const float* __restrict__ q, int Q,
-                                                     int K, int parts, const float* __restrict__ cand_s,
-                                                     const int* __restrict__ cand_i, int row_offset, float eps_rel,
+                                                     int K, int parts, int per, int code_bits,
+                                                     const float* __restrict__ cand, int row_offset, float eps_rel,
                                                      const float* __restrict__ db_norm_max,
                                                      int32_t* __restrict__ out_idx, double* __restrict__ out_score,
-                                                     int32_t* __restrict__ flags, int32_t* __restrict__ fb_count) {
+                                                     int32_t* __restrict__ flags) {
   const int lane = threadIdx.x & 63;
   const int qid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (qid >= Q) return;
 
-  // ---- merge the `parts` sorted lists into the f32 top-L (lane c ends up with the c-th best)
-  const size_t base = ((size_t)qid * parts + lane) * L;
+  // ---- merge the `parts` sorted key lists into the top-L (lane c ends up with the c-th best)
+  const float* mine = cand + ((size_t)qid * parts + min(lane, parts - 1)) * L;
   int ptr = 0;
-  float head_s = T2L_NEG_INF;
-  int head_i = INT_MAX;
-  if (lane < parts) {
-    head_s = cand_s[base];
-    head_i = cand_i[base];
-    if (head_i < 0) head_i = INT_MAX;
-  }
-  float my_s = T2L_NEG_INF;
-  int my_i = INT_MAX;
+  float head = lane < parts ? mine[0] : T2L_NEG_INF;
+  float my_key = T2L_NEG_INF;
+  int my_row = INT_MAX;
   for (int r = 0; r < L; ++r) {
-    float bs = head_s;
-    int bi = head_i;
+    float bk = head;
+    int bl = lane;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-      const float os = __shfl_xor(bs, off);
-      const int oi = __shfl_xor(bi, off);
-      if (better(os, oi, bs, bi)) {
-        bs = os;
-        bi = oi;
+      const float ok = __shfl_xor(bk, off);
+      const int ol = __shfl_xor(bl, off);
+      if (ok > bk || (ok == bk && ol < bl)) {
+        bk = ok;
+        bl = ol;
       }
     }
     if (lane == r) {
-      my_s = bs;
-      my_i = bi;
+      my_key = bk;
+      my_row = bk == T2L_NEG_INF ? INT_MAX : key_row(bk, bl, per, code_bits);
     }
-    if (bi != INT_MAX && head_i == bi) {  // the winner advances its list
+    if (lane == bl && bk != T2L_NEG_INF) {  // the winner advances its list
       ++ptr;
-      head_s = T2L_NEG_INF;
-      head_i = INT_MAX;
-      if (ptr < L) {
-        head_s = cand_s[base + ptr];
-        head_i = cand_i[base + ptr];
-        if (head_i < 0) head_i = INT_MAX;
-      }
+      head = ptr < L ? mine[ptr] : T2L_NEG_INF;
     }
   }
-  const float g_L = __shfl(my_s, L - 1);  // every row that is NOT re-scored has f32 score <= g_L
+  const float g = __shfl(my_key, L - 1);  // every row that is NOT re-scored has key <= g
 
-  // ---- float64 re-score of the L selected rows (products of f32 values are exact in f64)
+  // ---- float64 re-score of the selected rows (products of f32 values are exact in f64)
   const float4 qv = reinterpret_cast<const float4*>(q + (size_t)qid * kD)[lane];
   double qn = (double)qv.x * qv.x + (double)qv.y * qv.y + (double)qv.z * qv.z + (double)qv.w * qv.w;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) qn += __shfl_xor(qn, off);
   double my_d = -__builtin_inf();
   for (int c = 0; c < L; ++c) {
-    const int row = __shfl(my_i, c);
+    const int row = __shfl(my_row, c);
     if (row == INT_MAX) continue;  // wave-uniform
-    const float4 dv = reinterpret_cast<const float4*>(db + (size_t)row * kD)[lane];
-    double d = (double)dv.x * qv.x + (double)dv.y * qv.y + (double)dv.z * qv.z + (double)dv.w * qv.w;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off);
+    const double d = wave_dot64(db, row, qv, lane);
     if (lane == c) my_d = d;
   }
 
@@ -236,55 +264,46 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
   int rank = 0;
   for (int j = 0; j < L; ++j) {
     const double dj = __shfl(my_d, j);
-    const int ij = __shfl(my_i, j);
-    rank += (dj > my_d || (dj == my_d && ij < my_i)) ? 1 : 0;
+    const int ij = __shfl(my_row, j);
+    rank += (dj > my_d || (dj == my_d && ij < my_row)) ? 1 : 0;
   }
-  const bool valid = lane < L && my_i != INT_MAX;
+  const bool valid = lane < L && my_row != INT_MAX;
   if (lane < K) {
     out_idx[(size_t)qid * K + lane] = -1;
     if (out_score) out_score[(size_t)qid * K + lane] = -__builtin_inf();
   }
   if (valid && rank < K) {
-    out_idx[(size_t)qid * K + rank] = my_i + row_offset;
+    out_idx[(size_t)qid * K + rank] = my_row + row_offset;
     if (out_score) out_score[(size_t)qid * K + rank] = my_d;
   }
 
   // ---- certificate
-  const unsigned long long kth = __ballot(valid && rank == K - 1);
   bool certified = true;
-  if (g_L != T2L_NEG_INF) {
-    if (kth == 0ull) {
-      certified = false;  // cannot happen (>= K valid candidates whenever an L-th one exists); stay safe
-    } else {
+  if (g != T2L_NEG_INF) {  // an L-th candidate exists, so something may not have been re-scored
+    certified = false;
+    const unsigned long long kth = __ballot(valid && rank == K - 1);
+    if (K <= L && kth != 0ull) {
       const double dK = __shfl(my_d, __ffsll((long long)kth) - 1);
-      const double eps = (double)eps_rel * sqrt(qn) * (double)(*db_norm_max);
-      certified = (dK - (double)g_L) > eps;
+      const double eps32 = (double)eps_rel * sqrt(qn) * (double)(*db_norm_max);
+      certified = dK > (double)g + key_slack(g, code_bits, eps32);
     }
   }
-  if (lane == 0) {
-    flags[qid] = certified ? 0 : 1;
-    if (!certified) atomicAdd(fb_count, 1);
-  }
+  if (lane == 0) flags[qid] = certified ? 0 : 1;
 }
 
 // ------------------------------------------------------------------------------------------------
-// exact fallback: one workgroup per flagged query; float64 scan of every row + top-K selection.
+// fallback: one workgroup per flagged query.
+//   stage 2: float64 re-score of ALL kept candidates; rows that were dropped inside a lane have key <= that
+//            list's floor (its L-th key), so the certificate is against the largest floor.
+//   stage 3: exact float64 scan of the whole shard.
 // ------------------------------------------------------------------------------------------------
-template <int KMAX>
-__global__ __launch_bounds__(256) void exact_kernel(const float* __restrict__ db, int n_rows,
-                                                    const float* __restrict__ q, int K,
-                                                    const int32_t* __restrict__ flags, int row_offset,
-                                                    int32_t* __restrict__ out_idx, double* __restrict__ out_score) {
-  const int qid = blockIdx.x;
-  if (!flags[qid]) return;
-  __shared__ double qs[kD];
-  __shared__ double red_s[256];
-  __shared__ int red_i[256];
-  __shared__ int red_t[256];
-  const int tid = threadIdx.x;
-  qs[tid] = (double)q[(size_t)qid * kD + tid];
-  __syncthreads();
+constexpr int kMaxCand = kMaxParts * 32;  // parts * L upper bound
 
+template <int KMAX>
+__device__ void exact_scan(const float* __restrict__ db, int n_rows, const double* qs, int K, int row_offset,
+                           int32_t* __restrict__ out_idx, double* __restrict__ out_score, double* red_s, int* red_i,
+                           int* red_t) {
+  const int tid = threadIdx.x;
   double ls[KMAX];
   int li[KMAX];
 #pragma unroll
@@ -300,7 +319,7 @@ __global__ __launch_bounds__(256) void exact_kernel(const float* __restrict__ db
       d += (double)v.x * qs[4 * k] + (double)v.y * qs[4 * k + 1] + (double)v.z * qs[4 * k + 2] +
            (double)v.w * qs[4 * k + 3];
     }
-    if (d > ls[KMAX - 1]) {
+    if (d > ls[KMAX - 1]) {  // rows ascend per thread: strict > keeps the lower row ahead among equals
 #pragma unroll
       for (int i = KMAX - 1; i >= 1; --i) {
         const bool c_prev = d > ls[i - 1];
@@ -333,8 +352,8 @@ __global__ __launch_bounds__(256) void exact_kernel(const float* __restrict__ db
     const int win = red_t[0];
     if (tid == 0) {
       const bool ok = red_i[0] != INT_MAX;
-      out_idx[(size_t)qid * K + r] = ok ? red_i[0] + row_offset : -1;
-      if (out_score) out_score[(size_t)qid * K + r] = ok ? red_s[0] : -__builtin_inf();
+      out_idx[r] = ok ? red_i[0] + row_offset : -1;
+      if (out_score) out_score[r] = ok ? red_s[0] : -__builtin_inf();
     }
     if (tid == win) {  // pop the winner's head
 #pragma unroll
@@ -347,6 +366,111 @@ __global__ __launch_bounds__(256) void exact_kernel(const float* __restrict__ db
     }
     __syncthreads();
   }
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__ db, int n_rows,
+                                                       const float* __restrict__ q, int K, int parts, int per,
+                                                       int code_bits, const float* __restrict__ cand, int row_offset,
+                                                       float eps_rel, const float* __restrict__ db_norm_max,
+                                                       const int32_t* __restrict__ flags,
+                                                       int32_t* __restrict__ out_idx, double* __restrict__ out_score,
+                                                       int32_t* __restrict__ fb_count) {
+  const int qid = blockIdx.x;
+  if (!flags[qid]) return;
+  __shared__ double qs[kD];
+  __shared__ double cd[kMaxCand];
+  __shared__ int crow[kMaxCand];
+  __shared__ double red_s[256];
+  __shared__ int red_i[256];
+  __shared__ int red_t[256];
+  __shared__ float floor_max;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  qs[tid] = (double)q[(size_t)qid * kD + tid];
+
+  // ---- stage 2
+  const int total = parts * L;
+  const float* mine = cand + (size_t)qid * total;
+  const float4 qv = reinterpret_cast<const float4*>(q + (size_t)qid * kD)[lane];
+  for (int c = wave; c < total; c += 4) {
+    const float key = mine[c];  // wave-uniform
+    double d = -__builtin_inf();
+    int row = INT_MAX;
+    if (key != T2L_NEG_INF) {
+      row = key_row(key, c / L, per, code_bits);
+      d = wave_dot64(db, row, qv, lane);
+    }
+    if (lane == 0) {
+      cd[c] = d;
+      crow[c] = row;
+    }
+  }
+  if (tid == 0) {
+    float f = T2L_NEG_INF;
+    for (int p = 0; p < parts; ++p) f = fmaxf(f, mine[p * L + L - 1]);
+    floor_max = f;
+  }
+  __syncthreads();
+  // top-K of the candidates by (float64 score desc, row asc): K rounds of block arg-max
+  double dK = -__builtin_inf();
+  int found = 0;
+  for (int r = 0; r < K; ++r) {
+    double bs = -__builtin_inf();
+    int bi = INT_MAX, bc = -1;
+    for (int c = tid; c < total; c += 256) {
+      const double s = cd[c];
+      const int i = crow[c];
+      if (i != INT_MAX && (s > bs || (s == bs && i < bi))) {
+        bs = s;
+        bi = i;
+        bc = c;
+      }
+    }
+    red_s[tid] = bs;
+    red_i[tid] = bi;
+    red_t[tid] = bc;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+      if (tid < st) {
+        const double os = red_s[tid + st];
+        const int oi = red_i[tid + st];
+        if (os > red_s[tid] || (os == red_s[tid] && oi < red_i[tid])) {
+          red_s[tid] = os;
+          red_i[tid] = oi;
+          red_t[tid] = red_t[tid + st];
+        }
+      }
+      __syncthreads();
+    }
+    const bool ok = red_i[0] != INT_MAX;
+    if (ok) {
+      dK = red_s[0];
+      ++found;
+    }
+    const int win = red_t[0];
+    __syncthreads();
+    if (tid == 0) {
+      out_idx[(size_t)qid * K + r] = ok ? red_i[0] + row_offset : -1;
+      if (out_score) out_score[(size_t)qid * K + r] = ok ? red_s[0] : -__builtin_inf();
+      if (ok) crow[win] = INT_MAX;  // remove the winner
+    }
+    __syncthreads();
+  }
+  bool certified = floor_max == T2L_NEG_INF;  // no list is full: nothing was ever dropped
+  if (!certified && found == K) {
+    double qn = 0.0;
+    for (int k = 0; k < kD; ++k) qn += qs[k] * qs[k];
+    const double eps32 = (double)eps_rel * sqrt(qn) * (double)(*db_norm_max);
+    certified = dK > (double)floor_max + key_slack(floor_max, code_bits, eps32);
+  }
+  if (tid == 0) atomicAdd(&fb_count[1], 1);
+  if (certified) return;  // block-uniform
+
+  // ---- stage 3
+  if (tid == 0) atomicAdd(&fb_count[0], 1);
+  __syncthreads();
+  exact_scan<32>(db, n_rows, qs, K, row_offset, out_idx + (size_t)qid * K,
+                 out_score ? out_score + (size_t)qid * K : nullptr, red_s, red_i, red_t);
 }
 
 // max row 2-norm of the shard (bounds the f32 dot-product error in the certificate)
@@ -438,15 +562,13 @@ int db_norm_impl(t2l_ctx* ctx, hipStream_t s) {
   return T2L_OK;
 }
 
-static size_t scan_lds_bytes() {
-  return (size_t)2 * kTileFloats * sizeof(float) + (size_t)kScanWaves * kStageCap * 64 * 8;
-}
+static size_t scan_lds_bytes() { return (size_t)2 * kTileFloats * sizeof(float); }
 
 template <int L>
-static int launch_search(t2l_ctx* ctx, const float* q, int Q, int K, int nsplit, int32_t* out_idx, double* out_score,
+static int launch_search(t2l_ctx* ctx, const float* db, int n_rows, int row_offset, const float* q, int Q, int K,
+                         int nsplit, int per, int code_bits, int32_t* out_idx, double* out_score, bool first,
                          hipStream_t s) {
-  const int n_rows = (int)ctx->db_rows;
-  const int n_tiles = (int)(ctx->db_pad / kTileRows);
+  const int n_tiles = (n_rows + kTileRows - 1) / kTileRows;
   const int n_qblocks = (Q + kQPerBlock - 1) / kQPerBlock;
   const int parts = 2 * nsplit;
   const size_t lds = scan_lds_bytes();
@@ -457,58 +579,88 @@ static int launch_search(t2l_ctx* ctx, const float* q, int Q, int K, int nsplit,
     attr_done = true;
   }
   event_begin(ctx, "search_scan", s);
-  hipLaunchKernelGGL(scan_kernel<L>, dim3(n_qblocks * nsplit), dim3(256), lds, s, ctx->db, n_rows, n_tiles, q, Q,
-                     nsplit, ctx->cand_score, ctx->cand_idx);
+  hipLaunchKernelGGL(scan_kernel<L>, dim3(n_qblocks * nsplit), dim3(256), lds, s, db, n_rows, n_tiles, per, code_bits,
+                     q, Q, nsplit, ctx->cand_score, ctx->fb_count, first ? 1 : 0);
   event_end(ctx, "search_scan", s);
   T2L_HIP(ctx, hipGetLastError());
   // f32 dot-product error bound: gamma_n * |a||b| with n = 256 terms (+ slack for the MFMA's k order)
   const float eps_rel = (float)(ctx->eps_scale * (kD + 8) * 5.9604644775390625e-08);
   event_begin(ctx, "search_rerank", s);
-  hipLaunchKernelGGL(rerank_kernel<L>, dim3((Q + 3) / 4), dim3(256), 0, s, ctx->db, q, Q, K, parts, ctx->cand_score,
-                     ctx->cand_idx, (int)ctx->row_offset, eps_rel, ctx->db_norm_max, out_idx, out_score, ctx->flags,
-                     ctx->fb_count);
+  hipLaunchKernelGGL(rerank_kernel<L>, dim3((Q + 3) / 4), dim3(256), 0, s, db, q, Q, K, parts, per, code_bits,
+                     ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, out_idx, out_score, ctx->flags);
   T2L_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(exact_kernel<32>, dim3(Q), dim3(256), 0, s, ctx->db, n_rows, q, K, ctx->flags,
-                     (int)ctx->row_offset, out_idx, out_score);
+  hipLaunchKernelGGL(fallback_kernel<L>, dim3(Q), dim3(256), 0, s, db, n_rows, q, K, parts, per, code_bits,
+                     ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, ctx->flags, out_idx, out_score,
+                     ctx->fb_count);
   event_end(ctx, "search_rerank", s);
   T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;
 }
 
+// rows one scan launch can cover: 32 splits x 512 tiles (13 code bits) x 32 rows
+constexpr int kMaxPerTiles = 512;
+constexpr int kSegmentRows = (kMaxParts / 2) * kMaxPerTiles * kTileRows;
+
+static int grow(t2l_ctx* ctx, void** p, size_t* cap, size_t need_bytes) {
+  if (need_bytes <= *cap) return T2L_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  T2L_HIP(ctx, hipMalloc(p, need_bytes));
+  *cap = need_bytes;
+  return T2L_OK;
+}
+
 int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s) {
   if (Q == 0) return T2L_OK;
-  const int n_tiles = (int)(ctx->db_pad / kTileRows);
+  const int n_rows = (int)ctx->db_rows;
   const int n_qblocks = (Q + kQPerBlock - 1) / kQPerBlock;
-  int nsplit = ctx->nsplit_override;
-  if (nsplit <= 0) {
-    // >= 1 workgroup per CU (256 CUs); multiples of 8 keep a split on one XCD's L2
-    nsplit = (256 + n_qblocks - 1) / n_qblocks;
-    nsplit = ((nsplit + 7) / 8) * 8;
-  }
-  nsplit = max(1, min(nsplit, kMaxParts / 2));
-  nsplit = max(1, min(nsplit, max(1, n_tiles)));
   const int L = (K <= 10) ? 16 : 32;
-  const size_t need = (size_t)n_qblocks * kQPerBlock * 2 * nsplit * L;
-  if (need > ctx->cand_cap) {
-    if (ctx->cand_score) (void)hipFree(ctx->cand_score);
-    if (ctx->cand_idx) (void)hipFree(ctx->cand_idx);
-    ctx->cand_score = nullptr;
-    ctx->cand_idx = nullptr;
-    ctx->cand_cap = 0;
-    T2L_HIP(ctx, hipMalloc(&ctx->cand_score, need * sizeof(float)));
-    T2L_HIP(ctx, hipMalloc(&ctx->cand_idx, need * sizeof(int32_t)));
-    ctx->cand_cap = need;
+  const int n_seg = max(1, (n_rows + kSegmentRows - 1) / kSegmentRows);
+  if (n_seg * K > 256)
+    return fail(ctx, T2L_EINVAL, "t2l_search: shard too large (more than 256/k segments of 524,288 rows); shard the "
+                                 "database over more ranks");
+  int rc;
+  if ((rc = grow(ctx, (void**)&ctx->flags, &ctx->flag_cap, (size_t)Q * sizeof(int32_t))) != T2L_OK) return rc;
+  int32_t* seg_idx = out_idx;
+  double* seg_score = out_score;
+  if (n_seg > 1) {
+    if ((rc = grow(ctx, (void**)&ctx->seg_idx, &ctx->seg_idx_cap, (size_t)n_seg * Q * K * sizeof(int32_t))) != T2L_OK ||
+        (rc = grow(ctx, (void**)&ctx->seg_score, &ctx->seg_score_cap, (size_t)n_seg * Q * K * sizeof(double))) != T2L_OK)
+      return rc;
   }
-  if ((size_t)Q > ctx->flag_cap) {
-    if (ctx->flags) (void)hipFree(ctx->flags);
-    ctx->flags = nullptr;
-    ctx->flag_cap = 0;
-    T2L_HIP(ctx, hipMalloc(&ctx->flags, (size_t)Q * sizeof(int32_t)));
-    ctx->flag_cap = Q;
+  for (int seg = 0; seg < n_seg; ++seg) {
+    const int row0 = seg * kSegmentRows;
+    const int rows = min(kSegmentRows, n_rows - row0);
+    const int n_tiles = (max(rows, 0) + kTileRows - 1) / kTileRows;
+    int nsplit = ctx->nsplit_override;
+    if (nsplit <= 0) {
+      // 2 workgroups per CU (256 CUs); multiples of 8 keep a split on one XCD's L2
+      nsplit = (512 + n_qblocks - 1) / n_qblocks;
+      nsplit = ((nsplit + 7) / 8) * 8;
+    }
+    nsplit = max(1, min(nsplit, kMaxParts / 2));
+    nsplit = max(1, min(nsplit, max(1, n_tiles)));
+    nsplit = max(nsplit, (n_tiles + kMaxPerTiles - 1) / kMaxPerTiles);  // keep the key code within 13 bits
+    const int per = max(1, (n_tiles + nsplit - 1) / nsplit);
+    int code_bits = 4;
+    while ((1 << code_bits) < per * 16) ++code_bits;
+    const size_t need = (size_t)n_qblocks * kQPerBlock * 2 * nsplit * L * sizeof(float);
+    if ((rc = grow(ctx, (void**)&ctx->cand_score, &ctx->cand_cap, need)) != T2L_OK) return rc;
+    if (n_seg > 1) {
+      seg_idx = ctx->seg_idx + (size_t)seg * Q * K;
+      seg_score = ctx->seg_score + (size_t)seg * Q * K;
+    }
+    const float* db = ctx->db + (size_t)row0 * kD;
+    const int off = (int)ctx->row_offset + row0;
+    rc = (L == 16) ? launch_search<16>(ctx, db, max(rows, 0), off, q, Q, K, nsplit, per, code_bits, seg_idx,
+                                        seg_score, seg == 0, s)
+                   : launch_search<32>(ctx, db, max(rows, 0), off, q, Q, K, nsplit, per, code_bits, seg_idx,
+                                        seg_score, seg == 0, s);
+    if (rc != T2L_OK) return rc;
   }
-  T2L_HIP(ctx, hipMemsetAsync(ctx->fb_count, 0, sizeof(int32_t), s));
-  if (L == 16) return launch_search<16>(ctx, q, Q, K, nsplit, out_idx, out_score, s);
-  return launch_search<32>(ctx, q, Q, K, nsplit, out_idx, out_score, s);
+  if (n_seg > 1) return merge_impl(ctx, ctx->seg_idx, ctx->seg_score, n_seg, Q, K, out_idx, out_score, s);
+  return T2L_OK;
 }
 
 }  // namespace t2l

@@ -46,11 +46,12 @@ struct t2l_ctx {
   int64_t db_rows = 0, db_pad = 0, db_cap = 0, row_offset = 0;
   float* db_norm_max = nullptr;  // dev f32[1]: max row 2-norm (feeds the certificate's error bound)
   // search workspace
-  float* cand_score = nullptr;
-  int32_t* cand_idx = nullptr;
-  int32_t* flags = nullptr;      // dev i32[Q]: 1 = certificate failed -> exact fallback
-  int32_t* fb_count = nullptr;   // dev i32[1]
-  size_t cand_cap = 0, flag_cap = 0;
+  float* cand_score = nullptr;   // candidate keys [Q][2*nsplit][L]
+  int32_t* flags = nullptr;      // dev i32[Q]: 1 = first-stage certificate failed -> fallback kernel
+  int32_t* fb_count = nullptr;   // dev i32[2]: [0] exact-scan fallbacks, [1] stage-2 re-scores of the last search
+  int32_t* seg_idx = nullptr;    // per-segment results when the shard exceeds one scan launch
+  double* seg_score = nullptr;
+  size_t cand_cap = 0, flag_cap = 0, seg_idx_cap = 0, seg_score_cap = 0;  // bytes
   // encoder
   t2l::EncoderWeights* enc = nullptr;
   // options
