@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="dev: timing-only ablation of the scan kernel")
+    ap.add_argument("--nsplit", type=int, default=0, help="override the scan kernel's DB split count (0 = auto)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -78,6 +80,10 @@ def main():
     d_q = torch.from_numpy(qs).cuda()
     lo, hi = searcher.set_db_shard(d_db)
     eng.set_option("profile_events", 1)
+    if args.variant:
+        eng.set_option("scan_variant", args.variant)
+    if args.nsplit:
+        eng.set_option("search_nsplit", args.nsplit)
 
     def step():
         return searcher.search(d_q, TOPK)

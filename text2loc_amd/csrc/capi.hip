@@ -177,6 +177,8 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
   } else if (!strcmp(name, "search_nsplit")) {
     if (value < 0 || value > kMaxParts / 2) return fail(ctx, T2L_EINVAL, "search_nsplit out of range [0,32]");
     ctx->nsplit_override = (int)value;
+  } else if (!strcmp(name, "scan_variant")) {
+    ctx->scan_variant = (int)value;
   } else if (!strcmp(name, "profile_events")) {
     ctx->profile_events = value != 0;
   } else {

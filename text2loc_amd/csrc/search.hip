@@ -47,35 +47,40 @@ __device__ __forceinline__ float make_key(float v, int mask, int code) {
   return __int_as_float((__float_as_int(v) & mask) | code);
 }
 
-// One 32-row DB tile: 128 MFMAs into `cur` (D[db row][query]); after every 8th MFMA one score of the
-// PREVIOUS tile (`prev`) is turned into a key and inserted into the lane's list. The MFMA chain is
-// serially dependent (64-cycle issue = 64-cycle latency), so the ~L+3 VALU instructions per insertion ride
-// in its shadow when spread over the gaps (sched_group_barrier pins the interleave).
-template <int L, int S = 0>
-__device__ __forceinline__ void tile_mfma(const float* tb, const float (&qa)[128], f32x16& cur, const f32x16& prev,
-                                          int prev_row0, int n_rows, int mask, int prev_code0, float (&ls)[L],
-                                          float4 (&ab)[4]) {
+// One 32-row DB tile: 128 MFMAs (D[db row][query]) alternating between TWO accumulators (even / odd k
+// steps; their sum is the score) — back-to-back MFMAs on one accumulator forward the result only when they
+// are adjacent in the instruction stream, and any instruction between them costs the full write-back
+// latency, so the VALU work below needs two independent chains to hide behind. After every 8th MFMA one
+// score of the PREVIOUS tile is turned into a key and inserted into the lane's list: ~L+4 VALU instructions
+// spread over the gaps (sched_group_barrier pins the interleave).
+template <int L, int VAR, int S = 0>
+__device__ __forceinline__ void tile_mfma(const float* tb, const float (&qa)[128], f32x16& cur0, f32x16& cur1,
+                                          const f32x16& prev0, const f32x16& prev1, int prev_row0, int n_rows,
+                                          int mask, int prev_code0, float (&ls)[L], float4 (&ab)[4]) {
   if constexpr (S < 32) {
     if constexpr (S == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // the 4 prologue LDS reads go first
     const float4 a = ab[S & 3];
     if constexpr (S + 4 < 32) ab[S & 3] = *reinterpret_cast<const float4*>(tb + 4 * (S + 4));
-    cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qa[4 * S + 0], cur, 0, 0, 0);
-    cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qa[4 * S + 1], cur, 0, 0, 0);
-    cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qa[4 * S + 2], cur, 0, 0, 0);
-    cur = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qa[4 * S + 3], cur, 0, 0, 0);
+    cur0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qa[4 * S + 0], cur0, 0, 0, 0);
+    cur1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qa[4 * S + 1], cur1, 0, 0, 0);
+    cur0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qa[4 * S + 2], cur0, 0, 0, 0);
+    cur1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qa[4 * S + 3], cur1, 0, 0, 0);
     if constexpr ((S & 1) == 1) {  // 8 MFMAs issued since the last insertion
       constexpr int r = S >> 1;
       const int row = prev_row0 + (r & 3) + 8 * (r >> 2);
-      const float key = make_key(prev[r], mask, prev_code0 + r);
-      ins_key<L>(ls, row < n_rows ? key : T2L_NEG_INF);
+      const float key = make_key(prev0[r] + prev1[r], mask, prev_code0 + r);
+      if constexpr (VAR & 1)  // ablation: no list insertion
+        ls[r % L] = fmaxf(ls[r % L], key);
+      else
+        ins_key<L>(ls, row < n_rows ? key : T2L_NEG_INF);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // 1 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, (L + 3 + 7) / 8, 0);  // its share of the insertion VALU
+      __builtin_amdgcn_sched_group_barrier(0x002, (L + 4 + 7) / 8, 0);  // its share of the insertion VALU
     }
     if constexpr (S + 4 < 32) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // the LDS prefetch
-    tile_mfma<L, S + 1>(tb, qa, cur, prev, prev_row0, n_rows, mask, prev_code0, ls, ab);
+    tile_mfma<L, VAR, S + 1>(tb, qa, cur0, cur1, prev0, prev1, prev_row0, n_rows, mask, prev_code0, ls, ab);
   }
 }
 
@@ -84,8 +89,8 @@ __device__ __forceinline__ void tile_mfma(const float* tb, const float (&qa)[128
 // nsplit a multiple of 8 every XCD (b % 8) keeps re-reading the same DB split from its own L2.
 // LDS: 2 x [32 rows x 260 f32] DB tiles (glds double buffer), shared by the 4 waves (4 x 32 queries).
 // ------------------------------------------------------------------------------------------------
-template <int L>
-__global__ __launch_bounds__(256, 2) void scan_kernel(const float* __restrict__ db, int n_rows, int n_tiles, int per,
+template <int L, int VAR>
+__global__ __launch_bounds__(256, L == 16 ? 2 : 1) void scan_kernel(const float* __restrict__ db, int n_rows, int n_tiles, int per,
                                                       int code_bits, const float* __restrict__ q, int Q, int nsplit,
                                                       float* __restrict__ cand, int32_t* __restrict__ fb_count, int zero_counts) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -120,11 +125,11 @@ __global__ __launch_bounds__(256, 2) void scan_kernel(const float* __restrict__ 
   float ls[L];
 #pragma unroll
   for (int i = 0; i < L; ++i) ls[i] = T2L_NEG_INF;
-  f32x16 accA, accB;
+  f32x16 accA0, accA1, accB0, accB1;  // tile t (A) / tile t+1 (B), each as two partial sums
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    accA[r] = T2L_NEG_INF;
-    accB[r] = T2L_NEG_INF;
+    accA0[r] = accB0[r] = T2L_NEG_INF;
+    accA1[r] = accB1[r] = 0.f;
   }
 
   auto issue = [&](int t, int buf) {
@@ -139,23 +144,33 @@ __global__ __launch_bounds__(256, 2) void scan_kernel(const float* __restrict__ 
   };
   // D[row][col]: a lane holds query `col` and DB rows (r&3) + 8*(r>>2) + 4*half of the tile; the key's
   // code is ((tile - t0) << 4) | r  (the row is rebuilt from it, `half` and the split in the re-rank).
-  auto step = [&](int t, int buf, f32x16& cur, const f32x16& prev) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile t landed for every wave; every wave is done reading buffer buf^1
-    if (t + 1 < t1) issue(t + 1, buf ^ 1);
+  auto step = [&](int t, int buf, f32x16& cur0, f32x16& cur1, const f32x16& prev0, const f32x16& prev1) {
+    if constexpr (!(VAR & 2)) {  // (ablation bit 1: no tile streaming, every step re-reads the first tile)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // tile t landed for every wave; every wave is done reading buffer buf^1
+      if (t + 1 < t1) issue(t + 1, buf ^ 1);
+    }
     const float* tb = tiles + buf * kTileFloats + col * kRowStrideF + half * 128;
     float4 ab[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) ab[i] = *reinterpret_cast<const float4*>(tb + 4 * i);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cur[r] = 0.f;
-    tile_mfma<L>(tb, qa, cur, prev, (t - 1) * kTileRows + 4 * half, n_rows, mask, (t - 1 - t0) << 4, ls, ab);
+    for (int r = 0; r < 16; ++r) {
+      cur0[r] = 0.f;
+      cur1[r] = 0.f;
+    }
+    tile_mfma<L, VAR>(tb, qa, cur0, cur1, prev0, prev1, (t - 1) * kTileRows + 4 * half, n_rows, mask,
+                      (t - 1 - t0) << 4, ls, ab);
   };
 
   if (t0 < t1) issue(t0, 0);
+  if constexpr (VAR & 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   for (int t = t0; t < t1; t += 2) {
-    step(t, 0, accA, accB);  // while tile t multiplies, tile t-1's scores (accB) enter the list
-    if (t + 1 < t1) step(t + 1, 1, accB, accA);
+    step(t, 0, accA0, accA1, accB0, accB1);  // while tile t multiplies, tile t-1's scores (B) enter the list
+    if (t + 1 < t1) step(t + 1, (VAR & 2) ? 0 : 1, accB0, accB1, accA0, accA1);
   }
   if (t0 < t1) {  // the last tile's scores are still in registers
     const int row0 = (t1 - 1) * kTileRows + 4 * half;
@@ -164,13 +179,13 @@ __global__ __launch_bounds__(256, 2) void scan_kernel(const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2);
-        ins_key<L>(ls, row < n_rows ? make_key(accA[r], mask, code0 + r) : T2L_NEG_INF);
+        ins_key<L>(ls, row < n_rows ? make_key(accA0[r] + accA1[r], mask, code0 + r) : T2L_NEG_INF);
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2);
-        ins_key<L>(ls, row < n_rows ? make_key(accB[r], mask, code0 + r) : T2L_NEG_INF);
+        ins_key<L>(ls, row < n_rows ? make_key(accB0[r] + accB1[r], mask, code0 + r) : T2L_NEG_INF);
       }
     }
   }
@@ -564,6 +579,19 @@ int db_norm_impl(t2l_ctx* ctx, hipStream_t s) {
 
 static size_t scan_lds_bytes() { return (size_t)2 * kTileFloats * sizeof(float); }
 
+template <int L, int VAR>
+static void launch_scan(t2l_ctx* ctx, dim3 grid, size_t lds, hipStream_t s, const float* db, int n_rows, int n_tiles,
+                        int per, int code_bits, const float* q, int Q, int nsplit, int zero) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel<L, VAR>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((scan_kernel<L, VAR>), grid, dim3(256), lds, s, db, n_rows, n_tiles, per, code_bits, q, Q, nsplit,
+                     ctx->cand_score, ctx->fb_count, zero);
+}
+
 template <int L>
 static int launch_search(t2l_ctx* ctx, const float* db, int n_rows, int row_offset, const float* q, int Q, int K,
                          int nsplit, int per, int code_bits, int32_t* out_idx, double* out_score, bool first,
@@ -572,15 +600,14 @@ static int launch_search(t2l_ctx* ctx, const float* db, int n_rows, int row_offs
   const int n_qblocks = (Q + kQPerBlock - 1) / kQPerBlock;
   const int parts = 2 * nsplit;
   const size_t lds = scan_lds_bytes();
-  static bool attr_done = false;
-  if (!attr_done) {
-    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel<L>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
   event_begin(ctx, "search_scan", s);
-  hipLaunchKernelGGL(scan_kernel<L>, dim3(n_qblocks * nsplit), dim3(256), lds, s, db, n_rows, n_tiles, per, code_bits,
-                     q, Q, nsplit, ctx->cand_score, ctx->fb_count, first ? 1 : 0);
+  const dim3 grid(n_qblocks * nsplit);
+  switch (ctx->scan_variant) {  // 0 = product; 1..3 = timing-only ablations (wrong results by construction)
+    case 1: launch_scan<L, 1>(ctx, grid, lds, s, db, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+    case 2: launch_scan<L, 2>(ctx, grid, lds, s, db, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+    case 3: launch_scan<L, 3>(ctx, grid, lds, s, db, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+    default: launch_scan<L, 0>(ctx, grid, lds, s, db, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+  }
   event_end(ctx, "search_scan", s);
   T2L_HIP(ctx, hipGetLastError());
   // f32 dot-product error bound: gamma_n * |a||b| with n = 256 terms (+ slack for the MFMA's k order)

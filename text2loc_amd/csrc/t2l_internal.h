@@ -57,6 +57,7 @@ struct t2l_ctx {
   // options
   double eps_scale = 1.0;
   int nsplit_override = 0;
+  int scan_variant = 0;  // dev knob: timing-only ablations of the scan kernel
   bool profile_events = false;
   std::unordered_map<std::string, t2l::EventRing> events;
 };
