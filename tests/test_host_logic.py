@@ -1,0 +1,177 @@
+"""CPU tier: host-side logic of the drop-in surface — packer, accuracy bookkeeping of eval_epoch / run_coarse,
+the PyTorch text head, checkpoint key names — against the reference goldens. No GPU, no HIP compute calls."""
+import argparse
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import t2l_oracle as O
+from text2loc_amd import packing, synth
+
+
+class Obj:  # plain container duck-typing the reference's Object3d (xyz, rgb, label)
+    def __init__(self, label, xyz, rgb):
+        self.label, self.xyz, self.rgb = label, xyz, rgb
+
+
+def make_objects(cells, seed):
+    out = [[] for _ in range(len(cells["counts"]))]
+    for b, o, label, xyz, rgb in synth.make_object_points(cells, seed):
+        out[b].append(Obj(label, xyz, rgb))
+    return out
+
+
+def test_packer_matches_reference_inputs(golden):
+    g = golden("encoder_embed")
+    n_cells = 6
+    cells = synth.make_cells(int(g["n_cells"]), seed=int(g["cell_seed"]))
+    objs = make_objects(cells, int(g["cell_seed"]))[:n_cells]
+    p = packing.pack_cells(objs, packing.class_table(synth.KNOWN_CLASS))
+    hi = int(g["in_offsets"][n_cells])
+    assert np.array_equal(p["offsets"], g["in_offsets"][: n_cells + 1])
+    for k in ("class_idx", "color_idx", "rgb", "center", "n_pts"):
+        assert np.array_equal(p[k], g["in_" + k][:hi]), k  # bit-exact: same numpy reductions, same f32 cast
+
+
+def test_packer_unknown_label_and_gray_duplicate():
+    xyz = np.zeros((30, 3))
+    gray1 = np.tile(synth.COLORS[1], (30, 1)).astype(np.float32)  # nearest centre is index 1 ('gray')
+    p = packing.pack_cells([[Obj("spaceship", xyz, gray1)]], packing.class_table(synth.KNOWN_CLASS))
+    assert p["class_idx"][0] == 0  # known_classes.get(label, 0)
+    assert p["color_idx"][0] == 4  # {'gray': 4} wins in the reference's dict (object_encoder.py:35)
+    dark = np.tile(synth.COLORS[0], (30, 1)).astype(np.float32)
+    p = packing.pack_cells([[Obj("pole", xyz, dark)]], packing.class_table(synth.KNOWN_CLASS))
+    assert p["color_idx"][0] == 0 and p["class_idx"][0] == synth.KNOWN_CLASS.index("pole") + 1
+
+
+# ---------------------------------------------------------------------------------------------------------
+class StubCell:
+    def __init__(self, cid, bbox, size):
+        self.id, self.bbox_w, self.cell_size = str(cid), bbox, float(size)
+
+    def get_center(self):
+        return 0.5 * (self.bbox_w[0:3] + self.bbox_w[3:6])
+
+
+class StubPose:
+    def __init__(self, cell_id, pose_w):
+        self.cell_id, self.pose_w = str(cell_id), pose_w
+
+
+def stub_world(g):
+    cells = [StubCell(c, b, g["cell_size"]) for c, b in zip(g["db_cell_ids"], g["cell_bbox_w"])]
+    poses = [StubPose(c, p) for c, p in zip(g["query_cell_ids"], g["query_pose_w"])]
+
+    class CellDs:
+        def __init__(self):
+            self.cells = cells
+
+        def __len__(self):
+            return len(cells)
+
+        def __getitem__(self, i):
+            return {"cells": cells[i], "cell_ids": cells[i].id, "objects": i, "object_points": None}
+
+    class Ds:
+        all_cells, all_poses = cells, poses
+
+        def __len__(self):
+            return len(poses)
+
+        def __getitem__(self, i):
+            return {"texts": i, "cell_ids": poses[i].cell_id}
+
+        def get_cell_dataset(self):
+            return CellDs()
+
+    class Model:
+        embed_dim = 256
+
+        def eval(self):
+            pass
+
+        def encode_text(self, idx):
+            return torch.from_numpy(g["text_encodings"][np.array(idx)])
+
+        def encode_objects(self, idx, _):
+            return torch.from_numpy(g["cell_encodings"][np.array(idx)])
+
+    ds = Ds()
+    from text2loc_amd.coarse import collate_fn
+    dl = torch.utils.data.DataLoader(ds, batch_size=16, collate_fn=collate_fn, shuffle=False)
+    return Model(), dl
+
+
+def oracle_retrieve(cell_enc, text_enc, k):
+    return O.retrieve_topk(cell_enc.numpy(), text_enc.numpy(), k)
+
+
+def test_eval_epoch_and_run_coarse_bookkeeping_vs_reference(golden):
+    from text2loc_amd.coarse import eval_epoch, run_coarse
+
+    g = golden("retrieval_e2e")
+    model, dl = stub_world(g)
+    args = argparse.Namespace(ranking_loss="contrastive", top_k=[int(k) for k in g["top_k"]],
+                              threshs=[int(t) for t in g["threshs"]], batch_size=16)
+    acc, close, retr, ce, te, dists, scores = eval_epoch(model, dl, args, return_distance=True,
+                                                         retrieve=oracle_retrieve)
+    assert np.array_equal(np.array([acc[k] for k in args.top_k]), g["acc"])
+    assert np.array_equal(np.array([close[k] for k in args.top_k]), g["acc_close"])
+    ids = g["db_cell_ids"]
+    for q in range(len(retr)):
+        assert retr[q].dtype.kind == "U" and np.array_equal(retr[q], ids[g["top_rows"][q]])
+    assert np.abs(dists - g["top_dists"]).max() < 1e-9
+    assert np.abs(scores - g["top_scores"]).max() < 1e-12
+    assert ce.dtype == np.float64 and np.array_equal(ce, g["cell_encodings"].astype(np.float64))
+    retrievals, at = run_coarse(model, dl, args, retrieve=oracle_retrieve)
+    got = np.array([[at[k][t] for t in args.threshs] for k in args.top_k])
+    assert np.array_equal(got, g["acc_thresh"])
+    assert len(retrievals) == len(dl.dataset.all_poses)
+
+
+def test_text_head_matches_reference(golden):
+    from text2loc_amd.cell_retrieval import LanguageEncoder
+
+    g = golden("text_head")
+    B, L = int(g["batch"]), int(g["n_tokens"])
+    hidden = torch.from_numpy(synth.make_t5_hidden(6 * B, L, seed=int(g["hidden_seed"])))
+    enc = LanguageEncoder(256, fixed_embedding=True, intra_module_num_layers=1, inter_module_num_layers=1,
+                          llm_model=object(), tokenizer=None, input_dim=1024)
+    sd = {k[len("language_encoder."):]: torch.from_numpy(v) for k, v in
+          synth.make_language_head_weights(int(g["weight_seed"])).items()}
+    missing, unexpected = enc.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    enc.eval()
+    with torch.no_grad():
+        out = torch.nn.functional.normalize(enc.head(hidden, B)).numpy()
+    assert np.abs(out - g["text_embeddings"]).max() < 2e-5
+
+
+def test_checkpoint_key_names_match_the_reference_layout():
+    from text2loc_amd.cell_retrieval import CellRetrievalNetwork
+
+    args = argparse.Namespace(coarse_embed_dim=256, object_size=28, object_inter_module_num_heads=4,
+                              object_inter_module_num_layers=2, hungging_model=None, fixed_embedding=True,
+                              intra_module_num_layers=1, intra_module_num_heads=4, inter_module_num_layers=1,
+                              inter_module_num_heads=4, class_embed=True, color_embed=True,
+                              use_features=["class", "color", "position", "num"])
+    from text2loc_amd.cell_retrieval import LanguageEncoder
+    le = LanguageEncoder(256, fixed_embedding=True, intra_module_num_layers=1, inter_module_num_layers=1,
+                         llm_model=object(), input_dim=1024)
+    model = CellRetrievalNetwork(synth.KNOWN_CLASS, synth.COLOR_NAMES, args, language_encoder=le)
+    want = {k: v for k, v in synth.make_object_branch_weights(0).items()}
+    want.update(synth.make_language_head_weights(0))
+    have = model.state_dict()
+    for k, v in want.items():
+        assert k in have, k
+        assert tuple(have[k].shape) == tuple(np.asarray(v).shape), k
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in want.items()},
+                                                strict=True)
+    assert not missing and not unexpected
+    with pytest.raises(Exception, match="Not implemented"):
+        model.forward()
+    model.eval()
+    with pytest.raises(Exception, match="no CPU fallback|MI355X"):
+        model.encode_objects([[Obj("pole", np.zeros((30, 3)), np.zeros((30, 3), np.float32))]], [None])

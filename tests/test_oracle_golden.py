@@ -94,3 +94,22 @@ def test_text_head(golden):
     hidden = synth.make_t5_hidden(6 * int(g["batch"]), int(g["n_tokens"]), seed=int(g["hidden_seed"]))
     out = O.text_head(hidden, sd, int(g["batch"]))
     assert np.abs(out - g["text_embeddings"]).max() < 2e-5
+
+
+def test_c_oracle_retrieval_and_loss(golden):
+    """The plain-C restatement (oracle/t2l_oracle.c) against the same reference goldens."""
+    from oracle import c_oracle
+
+    g = golden("retrieval_big")
+    db, q, _ = synth.make_retrieval_problem(int(g["n_cells"]), int(g["n_queries"]), seed=int(g["seed"]),
+                                            noise=float(g["noise"]))
+    idx, sc = c_oracle.retrieve_topk(db, q[:128], int(g["k"]))
+    assert np.array_equal(idx, g["top_rows"][:128])
+    assert np.abs(sc - g["top_scores"][:128]).max() < 1e-12
+    e = golden("retrieval_e2e")
+    idx, sc = c_oracle.retrieve_topk(e["cell_encodings"], e["text_encodings"], int(e["top_k"].max()))
+    assert np.array_equal(idx, e["top_rows"])
+    l = golden("loss")
+    loss, ga, gp = c_oracle.contrastive_loss(l["anchor"], l["positive"], float(l["temperature"]))
+    assert abs(loss - float(l["loss"])) < 1e-6
+    assert np.abs(ga - l["grad_anchor"]).max() < 1e-6 and np.abs(gp - l["grad_positive"]).max() < 1e-6

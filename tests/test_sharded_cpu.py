@@ -1,0 +1,96 @@
+"""CPU tier: the N>1 path — shard bounds, host merge, and the all_gather plumbing of ShardedSearcher under
+gloo with world_size 2 (and 3, ragged/empty shards). The per-shard search is stood in by the oracle; on a GPU
+box the same class drives the HIP kernels (tests/test_gpu_search.py covers those)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import t2l_oracle as O
+from text2loc_amd import synth
+from text2loc_amd.sharded import merge_topk_host, shard_bounds
+
+
+@pytest.mark.parametrize("n,world", [(11259, 8), (10, 3), (3, 8), (0, 2), (64, 1)])
+def test_shard_bounds_partition_rows(n, world):
+    spans = [shard_bounds(n, world, r) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == n
+    for (a, b), (c, d) in zip(spans, spans[1:]):
+        assert b == c and a <= b and c <= d
+    assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= -(-n // world)
+
+
+def test_merge_topk_host_equals_unsharded():
+    db, qs, _ = synth.make_retrieval_problem(777, 40, seed=8, noise=2.0)
+    ridx, rsc = O.retrieve_topk(db, qs, 10)
+    parts_i, parts_s = [], []
+    for r in range(5):
+        lo, hi = shard_bounds(len(db), 5, r)
+        i, s = O.retrieve_topk(db[lo:hi], qs, 10)
+        parts_i.append(i + lo)
+        parts_s.append(s)
+    idx, sc = merge_topk_host(np.stack(parts_i), np.stack(parts_s), 10)
+    assert np.array_equal(idx, ridx) and np.abs(sc - rsc).max() < 1e-12
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_rows, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from text2loc_amd.sharded import ShardedSearcher
+
+    db, qs, _ = synth.make_retrieval_problem(n_rows, 33, seed=6, noise=2.0)
+    K = 10
+    state = {}
+
+    def search_fn(q, k):  # oracle stand-in for the HIP shard search: global ids, -1 / -inf padding
+        lo, hi = state["lo"], state["hi"]
+        i, s = O.retrieve_topk(db[lo:hi], q.numpy(), k) if hi > lo else (np.zeros((len(q), 0), np.int64),
+                                                                         np.zeros((len(q), 0)))
+        idx = np.full((len(q), k), -1, dtype=np.int32)
+        sc = np.full((len(q), k), -np.inf)
+        idx[:, : i.shape[1]] = i + lo
+        sc[:, : s.shape[1]] = s
+        return torch.from_numpy(idx), torch.from_numpy(sc)
+
+    def merge_fn(i, s):
+        a, b = merge_topk_host(i.numpy(), s.numpy(), K)
+        return torch.from_numpy(a), torch.from_numpy(b)
+
+    ss = ShardedSearcher(engine=None, search_fn=search_fn, merge_fn=merge_fn)
+    state["lo"], state["hi"] = ss.set_db_shard(torch.from_numpy(db))
+    idx, sc = ss.search(torch.from_numpy(qs), K)
+    ridx, rsc = O.retrieve_topk(db, qs, K)
+    kk = ridx.shape[1]
+    ok = np.array_equal(idx.numpy()[:, :kk], ridx) and np.abs(sc.numpy()[:, :kk] - rsc).max() < 1e-12  # BLAS order
+    out_q.put((rank, bool(ok), state["lo"], state["hi"]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_rows", [(2, 501), (3, 7)])
+def test_sharded_search_under_gloo(world, n_rows):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_rows, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res), res
+    spans = sorted((lo, hi) for _, _, lo, hi in res)
+    assert spans[0][0] == 0 and spans[-1][1] == n_rows

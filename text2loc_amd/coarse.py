@@ -1,0 +1,138 @@
+"""Drop-ins for ``training.coarse.eval_epoch`` (training/coarse.py:63-157) and
+``evaluation.pipeline.run_coarse`` / ``evaluation.coarse.run_coarse`` (evaluation/pipeline.py:41-87).
+
+Same arguments, same return structures — the difference is where the work runs:
+
+* cells are encoded by the fused HIP encoder and stay in HBM as the search database (no per-batch
+  ``.cpu().numpy()`` round trip, training/coarse.py:105-113);
+* the per-query ``float64 matvec + full argsort`` host loop (training/coarse.py:119-125) is ONE fused search on
+  the GPU (f32 MFMA scan -> float64 re-rank -> certificate), returning exactly the ids the float64 loop ranks;
+* hit@k / close@k / threshold accuracies (training/coarse.py:127-150, evaluation/utils.py:31-54) are
+  bookkeeping on [Q,K] integer arrays and run vectorised on the host.
+
+Datasets / dataloaders are duck-typed as in the reference: ``dataloader.dataset`` provides
+``get_cell_dataset()`` (-> ``.cells``, items with ``cell_ids, objects, object_points``), ``.all_poses``
+(``.pose_w``, ``.cell_id``) and ``.all_cells`` (``.id``, ``.cell_size``, ``.bbox_w``, ``.get_center()``);
+batches are dict-of-lists with ``texts`` and ``cell_ids``.
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+
+def collate_fn(data):
+    """dict-of-lists collate, as Kitti360BaseDataset.collate_fn (dataloading/kitti360pose/base.py:83-87)."""
+    return {key: [d[key] for d in data] for key in data[0].keys()}
+
+
+def _batches(dataset, batch_size):
+    n = len(dataset)
+    for lo in range(0, n, batch_size):
+        yield collate_fn([dataset[i] for i in range(lo, min(n, lo + batch_size))])
+
+
+def _engine_retrieve(model) -> Callable:
+    def retrieve(cell_enc: torch.Tensor, text_enc: torch.Tensor, k: int):
+        eng = model.engine()
+        eng.db_set(cell_enc.contiguous())
+        idx, sc = eng.search(text_enc.contiguous(), k)
+        return idx.cpu().numpy().astype(np.int64), sc.cpu().numpy()
+
+    return retrieve
+
+
+@torch.no_grad()
+def eval_epoch(model, dataloader, args, return_encodings: bool = False, return_distance: bool = False,
+               retrieve: Optional[Callable] = None):
+    """Returns (accuracies{k: float}, accuracies_close{k: float}, top_retrievals{q: ndarray['<U32'][max(top_k)]})
+    (+ encodings / dists / scores variants, training/coarse.py:152-157). ``retrieve`` replaces the search step
+    (tests of the host bookkeeping pass the oracle here); by default it is the model's HIP engine."""
+    assert args.ranking_loss != "triplet"  # as the reference (training/coarse.py:65)
+    model.eval()
+    dataset = dataloader.dataset
+    cells_dataset = dataset.get_cell_dataset()
+    cells = cells_dataset.cells
+    cell_size = cells[0].cell_size
+    max_k = int(np.max(args.top_k))
+    retrieve = retrieve or _engine_retrieve(model)
+
+    # ---- query side (text path stays on PyTorch)
+    t0 = time.time()
+    text_parts, query_cell_ids = [], []
+    for batch in dataloader:
+        text_parts.append(model.encode_text(batch["texts"]).detach().float())
+        query_cell_ids.extend(batch["cell_ids"])
+    text_enc = torch.cat(text_parts, dim=0)
+    print(f"Encoded {len(text_enc)} query texts in {time.time() - t0:0.2f}.")
+
+    # ---- database side: every cell once, resident on the device
+    cell_parts, db_cell_ids = [], []
+    for batch in _batches(cells_dataset, args.batch_size):
+        cell_parts.append(model.encode_objects(batch["objects"], batch["object_points"]).detach().float())
+        db_cell_ids.extend(batch["cell_ids"])
+    cell_enc = torch.cat(cell_parts, dim=0)
+    assert len(cell_enc) == len(dataset.all_cells)  # training/coarse.py:122
+    db_cell_ids = np.array(db_cell_ids, dtype="<U32")
+    query_cell_ids = np.array(query_cell_ids, dtype="<U32")
+
+    # ---- retrieval: identical to float64 `cell_encodings @ t` + stable descending argsort, first max(top_k)
+    top_idx, top_scores = retrieve(cell_enc, text_enc, max_k)
+
+    # ---- accuracies (host bookkeeping on [Q,K] arrays)
+    retrieved_ids = db_cell_ids[top_idx]  # [Q,K]
+    hits = retrieved_ids == query_cell_ids[:, None]
+    centers = np.array([c.get_center()[0:2] for c in cells], dtype=np.float64)
+    query_poses_w = np.array([p.pose_w[0:2] for p in dataset.all_poses], dtype=np.float64)
+    dists = np.linalg.norm(query_poses_w[:, None, :] - centers[top_idx], axis=2)  # [Q,K]
+    accuracies = {k: float(np.mean(hits[:, :k].any(axis=1))) for k in args.top_k}
+    accuracies_close = {k: float(np.mean((dists[:, :k] <= cell_size / 2).any(axis=1))) for k in args.top_k}
+    top_retrievals = {q: retrieved_ids[q] for q in range(len(retrieved_ids))}
+
+    if return_encodings or return_distance:
+        ce = cell_enc.cpu().numpy().astype(np.float64)
+        te = text_enc.cpu().numpy().astype(np.float64)
+        if return_encodings:
+            return accuracies, accuracies_close, top_retrievals, ce, te
+        return accuracies, accuracies_close, top_retrievals, ce, te, dists, top_scores
+    return accuracies, accuracies_close, top_retrievals
+
+
+def calc_sample_accuracies(pose, top_cells, pos_in_cells, top_k, threshs):
+    """evaluation/utils.py:31-54: world-xy error of the predicted position in each retrieved cell; retrievals
+    from another scene count as infinitely far."""
+    assert len(top_cells) == max(top_k) == len(pos_in_cells)
+    pred_w = np.array([c.bbox_w[0:2] + pos_in_cells[i, :] * c.cell_size for i, c in enumerate(top_cells)])
+    dists = np.linalg.norm(np.asarray(pose.pose_w)[0:2] - pred_w, axis=1)
+    scene = pose.cell_id.split("_")[0]
+    dists[np.array([c.id.split("_")[0] for c in top_cells]) != scene] = np.inf
+    return {k: {t: bool(np.min(dists[0:k]) <= t) for t in threshs} for k in top_k}
+
+
+@torch.no_grad()
+def run_coarse(model, dataloader, args, retrieve: Optional[Callable] = None):
+    """Returns (retrievals: List[ndarray of cell ids], accuracies{k:{t: float}}) as evaluation/pipeline.py:41-87."""
+    model.eval()
+    all_cells_dict = {cell.id: cell for cell in dataloader.dataset.all_cells}
+    acc, acc_close, retrievals = eval_epoch(model, dataloader, args, retrieve=retrieve)
+    retrievals = [retrievals[i] for i in range(len(retrievals))]
+    print("Retrieval Accs:")
+    print(acc)
+    print("Retrieval Accs Close:")
+    print(acc_close)
+    assert len(retrievals) == len(dataloader.dataset.all_poses)
+    accuracies = {k: {t: [] for t in args.threshs} for k in args.top_k}
+    for i, pose in enumerate(dataloader.dataset.all_poses):
+        top_cells = [all_cells_dict[cid] for cid in retrievals[i]]
+        pos_in_cells = 0.5 * np.ones((len(top_cells), 2))  # predict cell centres (pipeline.py:72)
+        accs = calc_sample_accuracies(pose, top_cells, pos_in_cells, args.top_k, args.threshs)
+        for k in args.top_k:
+            for t in args.threshs:
+                accuracies[k][t].append(accs[k][t])
+    for k in args.top_k:
+        for t in args.threshs:
+            accuracies[k][t] = float(np.mean(accuracies[k][t]))
+    return retrievals, accuracies

@@ -1,0 +1,95 @@
+"""Host-side packer: the reference's ``List[List[Object3d]]`` -> the engine's packed SoA (include/t2l.h).
+
+This is the build's counterpart of the Python loops inside ``ObjectEncoder.forward``
+(models/object_encoder.py:74-84,121-145): per object the class index, colour index, mean rgb, mean xyz
+and point count. The reference recomputes these reductions on every forward call (62 % of its
+``encode_objects`` wall time); here they are computed once per object and cached on it.
+
+Objects are duck-typed exactly like the reference's ``Object3d`` (datapreparation/kitti360pose/imports.py:
+8-83): ``.label``, ``.xyz [n,3]``, ``.rgb [n,3]``; if they carry the reference's own ``get_center`` /
+``get_color_rgb`` / ``get_color_text`` methods those are NOT called — the reductions below are this
+package's own (numpy, same formulas), so the packer works on plain containers too.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .synth import COLOR_NAMES, COLORS, KNOWN_CLASS  # data tables (utils.py:48-69,210-231)
+
+
+def class_table(known_classes: Sequence[str]) -> Dict[str, int]:
+    """known_classes -> index, 0 reserved for '<unk>'/padding (models/object_encoder.py:31-33)."""
+    t = {c: i + 1 for i, c in enumerate(known_classes)}
+    t["<unk>"] = 0
+    return t
+
+
+def color_table() -> Dict[str, int]:
+    """Colour name -> row of color_embedding. The reference ignores its ``known_colors`` argument and always
+    enumerates COLOR_NAMES (object_encoder.py:35-37): the duplicate 'gray' collapses 1 -> 4 and
+    'dark-green' shares row 0 with the padding index."""
+    t = {c: i for i, c in enumerate(COLOR_NAMES)}
+    t["<unk>"] = 0
+    return t
+
+
+def object_features(obj) -> tuple:
+    """(mean rgb f64[3], COLORS argmin, mean xyz f64[3], n_points) — imports.py:28-41, cached on the object."""
+    cached = getattr(obj, "_t2l_feat", None)
+    if cached is not None and cached[4] == (id(obj.xyz), id(obj.rgb)):
+        return cached[:4]
+    rgb = np.mean(obj.rgb, axis=0)
+    cidx = int(np.argmin(np.linalg.norm(rgb - COLORS, axis=1)))
+    center = np.mean(obj.xyz, axis=0)
+    out = (rgb, cidx, center, len(obj.xyz))
+    try:
+        obj._t2l_feat = out + ((id(obj.xyz), id(obj.rgb)),)
+    except Exception:
+        pass
+    return out
+
+
+def pack_cells(objects: List[List[object]], known_classes: Dict[str, int], known_colors: Optional[Dict[str, int]] = None,
+               pn_feat: Optional[Sequence[np.ndarray]] = None) -> Dict[str, np.ndarray]:
+    """objects: per cell, the cell's objects in dataset order. pn_feat: optional per-cell ``[n_i,256]`` arrays of
+    PointNet++ ``features2`` (needed when class_embed is off). Returns numpy arrays laid out as t2l_packed_cells."""
+    known_colors = known_colors or color_table()
+    counts = np.array([len(o) for o in objects], dtype=np.int32)
+    offsets = np.zeros(len(objects) + 1, dtype=np.int32)
+    np.cumsum(counts, out=offsets[1:])
+    total = int(offsets[-1])
+    class_idx = np.empty(total, dtype=np.int32)
+    color_idx = np.empty(total, dtype=np.int32)
+    rgb = np.empty((total, 3), dtype=np.float32)
+    center = np.empty((total, 3), dtype=np.float32)
+    n_pts = np.empty(total, dtype=np.float32)
+    i = 0
+    for objs in objects:
+        for o in objs:
+            c_rgb, cidx, c_xyz, n = object_features(o)
+            class_idx[i] = known_classes.get(o.label, 0)  # object_encoder.py:81
+            color_idx[i] = known_colors[COLOR_NAMES[cidx]]  # object_encoder.py:83
+            rgb[i] = c_rgb  # torch.tensor(..., dtype=torch.float), object_encoder.py:124-127
+            center[i] = c_xyz  # object_encoder.py:133-134
+            n_pts[i] = n  # object_encoder.py:141-143
+            i += 1
+    out = {"counts": counts, "offsets": offsets, "class_idx": class_idx, "color_idx": color_idx, "rgb": rgb,
+           "center": center, "n_pts": n_pts}
+    if pn_feat is not None:
+        feats = [np.asarray(f, dtype=np.float32).reshape(-1, 256) for f in pn_feat]
+        if [len(f) for f in feats] != counts.tolist():
+            raise ValueError("pn_feat must hold one [n_i,256] array per cell, matching the object counts")
+        out["pn_feat"] = np.concatenate(feats, axis=0) if feats else np.zeros((0, 256), np.float32)
+    return out
+
+
+def to_device(packed: Dict[str, np.ndarray], device) -> Dict[str, "torch.Tensor"]:
+    import torch
+
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(device, non_blocking=True) for k, v in packed.items()
+            if k != "counts"}
+
+
+__all__ = ["KNOWN_CLASS", "COLOR_NAMES", "class_table", "color_table", "object_features", "pack_cells", "to_device"]

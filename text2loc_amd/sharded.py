@@ -81,8 +81,9 @@ class ShardedSearcher:
         if self.world == 1:
             return idx, sc
         Q = idx.shape[0]
-        all_i = torch.empty((self.world, Q, k), dtype=idx.dtype, device=idx.device)
-        all_s = torch.empty((self.world, Q, k), dtype=sc.dtype, device=sc.device)
+        # rank-major concatenation along dim 0 (the layout both RCCL and gloo accept) == [world][Q][k]
+        all_i = torch.empty((self.world * Q, k), dtype=idx.dtype, device=idx.device)
+        all_s = torch.empty((self.world * Q, k), dtype=sc.dtype, device=sc.device)
         self.dist.all_gather_into_tensor(all_i, idx.contiguous(), group=self.group)
         self.dist.all_gather_into_tensor(all_s, sc.contiguous(), group=self.group)
-        return self.merge_fn(all_i, all_s)
+        return self.merge_fn(all_i.view(self.world, Q, k), all_s.view(self.world, Q, k))
