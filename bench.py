@@ -53,12 +53,58 @@ def cpu_baseline(db, qs, budget_s=12.0):
             "sample": f"{done} queries x N={len(db)} (float64 C@t + full argsort per query, numpy) in {dt:.1f}s"}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, written
+    by tools_pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, gfx950 correction per MI355X_MICROARCH.md).
+    None when no profile has been committed for this kernel name."""
+    try:
+        d = json.load(open(os.path.join(REPO, "profiles", "pmc_latest.json")))
+        return d[kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def secondary_measurements(eng):
+    """Outside the timed region: the fused cell encoder on the full 11,259-cell DB (cells/s, f32 MFMA TFLOP/s at the
+    algorithmic 60.33 MFLOP/cell + 0.67 MFLOP/object of SURVEY.md §8d) and the contrastive loss step (us)."""
+    out = {}
+    sd = synth.make_object_branch_weights(0)
+    eng.load_weights(sd, class_embed=True, color_embed=True)
+    cells = synth.make_cells(N_CELLS, seed=4)
+    packed = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cells.items() if k != "counts"}
+    for _ in range(2):
+        eng.encode_cells(packed)
+    eng.kernel_stats("encode_cells")
+    for _ in range(5):
+        eng.encode_cells(packed)
+    torch.cuda.synchronize()
+    ms, n = eng.kernel_stats("encode_cells")
+    kept = np.minimum(cells["counts"], 28).sum()
+    flops = N_CELLS * 60.33e6 + kept * 0.67e6
+    out["encode_cells"] = {"cells": N_CELLS, "kernel_ms": ms, "cells_per_s": N_CELLS / (ms * 1e-3),
+                           "tflops_algorithmic": flops / (ms * 1e-3) / 1e12, "peak_tflops": F32_MFMA_PEAK_TFLOPS,
+                           "frac": flops / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "launches_timed": n}
+    rng = np.random.default_rng(0)
+    a = torch.from_numpy(rng.standard_normal((64, 256)).astype(np.float32)).cuda()
+    p = torch.from_numpy(rng.standard_normal((64, 256)).astype(np.float32)).cuda()
+    for _ in range(3):
+        eng.contrastive_loss(a, p, 0.1)
+    eng.kernel_stats("contrastive_loss")
+    for _ in range(20):
+        eng.contrastive_loss(a, p, 0.1)
+    torch.cuda.synchronize()
+    ms, n = eng.kernel_stats("contrastive_loss")
+    out["contrastive_loss_b64_fwd_bwd_us"] = ms * 1e3
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the encoder / loss side measurements")
     ap.add_argument("--variant", type=int, default=0, help="dev: timing-only ablation of the scan kernel")
     ap.add_argument("--nsplit", type=int, default=0, help="override the scan kernel's DB split count (0 = auto)")
     args = ap.parse_args()
@@ -118,6 +164,9 @@ def main():
     parity = bool(np.array_equal(got[sel], ridx))
     recall1 = float((got[:, 0] == target).mean())
 
+    secondary = {}
+    if rank == 0 and world == 1 and not args.no_secondary:
+        secondary = secondary_measurements(eng)
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         n_local = hi - lo
@@ -136,9 +185,10 @@ def main():
                        "parallelism": f"db-row-shard x{world}" if world > 1 else "single-gpu"},
             "roofline": {"bound": "mfma", "kernel": "scan_kernel<16>", "achieved": achieved,
                          "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "kernel_ms": scan_ms, "launches_timed": scan_n,
+                         "traffic": pmc_traffic("t2l::scan_kernel<16, 0>"), "kernel_ms": scan_ms, "launches_timed": scan_n,
                          "flops_per_launch": flops},
             "kernels_ms": {"search_scan": scan_ms, "search_rerank+exact": rerank_ms},
+            "secondary": secondary,
             "parity": {"ids_equal_float64_oracle_on_sample": parity, "sample": int(len(sel)),
                        "recall_at_1_planted": recall1, "exact_fallback_queries_last_step": fallbacks},
         }

@@ -488,16 +488,24 @@ __global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__
                  out_score ? out_score + (size_t)qid * K : nullptr, red_s, red_i, red_t);
 }
 
-// max row 2-norm of the shard (bounds the f32 dot-product error in the certificate)
+// max row 2-norm of the shard (bounds the f32 dot-product error in the certificate); one atomic per workgroup
 __global__ __launch_bounds__(256) void db_norm_kernel(const float* __restrict__ db, int n_rows, float* out) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= n_rows) return;
-  const float4 v = reinterpret_cast<const float4*>(db + (size_t)row * kD)[lane];
-  float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float m = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < n_rows; row += gridDim.x * 4) {
+    const float4 v = reinterpret_cast<const float4*>(db + (size_t)row * kD)[lane];
+    float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-  if (lane == 0) atomicMax(reinterpret_cast<int*>(out), __float_as_int(sqrtf(s) * 1.0001f));
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    m = fmaxf(m, s);
+  }
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    atomicMax(reinterpret_cast<int*>(out), __float_as_int(sqrtf(m) * 1.0001f));  // non-negative floats order as ints
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -570,7 +578,7 @@ int merge_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int parts,
 int db_norm_impl(t2l_ctx* ctx, hipStream_t s) {
   T2L_HIP(ctx, hipMemsetAsync(ctx->db_norm_max, 0, sizeof(float), s));
   if (ctx->db_rows > 0) {
-    const int blocks = (int)((ctx->db_rows + 3) / 4);
+    const int blocks = (int)min((int64_t)1024, (ctx->db_rows + 3) / 4);
     hipLaunchKernelGGL(db_norm_kernel, dim3(blocks), dim3(256), 0, s, ctx->db, (int)ctx->db_rows, ctx->db_norm_max);
     T2L_HIP(ctx, hipGetLastError());
   }

@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Condense gpurun_out/prof_<tag>/ (written on the GPU box by tools_profile.sh) into committed summaries under
+profiles/: <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <tag>_pmc_summary.{md,json} (per-kernel PMC
+averages from the separate --pmc passes) and profiles/pmc_latest.json (read by bench.py for roofline.traffic)."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+shutil.copy(f"{src}/trace/t_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in sorted(os.listdir(src)):
+    f = f"{src}/{d}/p_counter_collection.csv"
+    if not os.path.exists(f):
+        continue
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+summary = {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"launches": len(next(iter(cs.values())))}
+           for k, cs in acc.items() if k.startswith("t2l::")}
+for k, s in summary.items():
+    if "FETCH_SIZE" in s:
+        # rocprofv3 FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x
+        # (MI355X_MICROARCH.md §HBM) -> doubled; WRITE_SIZE taken as is (uncalibrated).
+        s["hbm_bytes_per_launch"] = 2 * s["FETCH_SIZE"] * 1024 + s.get("WRITE_SIZE", 0.0) * 1024
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in s and "GRBM_GUI_ACTIVE" in s and s["GRBM_GUI_ACTIVE"] > 0:
+        cyc = s["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+        s["kernel_cycles"] = cyc
+        s["mfma_pipe_busy_frac"] = s["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc  # 1024 SIMDs
+json.dump(summary, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
+json.dump(summary, open("profiles/pmc_latest.json", "w"), indent=1, sort_keys=True)
+with open(f"profiles/{tag}_pmc_summary.md", "w") as f:
+    f.write(f"# PMC summary `{tag}` — rocprofv3 --pmc passes (separate runs) of `python bench.py --steps 20 --warmup 3`\n\n")
+    for k, s in sorted(summary.items()):
+        f.write(f"## {k}\n\n| counter | average per launch |\n|---|---|\n")
+        for c, v in sorted(s.items()):
+            f.write(f"| {c} | {v:,.3f} |\n")
+        f.write("\n")
+print(open(f"profiles/{tag}_pmc_summary.md").read()[:3000])
