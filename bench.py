@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the encoder / loss side measurements")
+    ap.add_argument("--mode", type=int, default=0, help="search_mode: 0 = split-bf16 specialised scan, 1 = f32 scan")
     ap.add_argument("--variant", type=int, default=0, help="dev: timing-only ablation of the scan kernel")
     ap.add_argument("--nsplit", type=int, default=0, help="override the scan kernel's DB split count (0 = auto)")
     args = ap.parse_args()
@@ -112,20 +113,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    ndev = torch.cuda.device_count()
+    dev = local % max(ndev, 1)  # one process per GPU; the modulo only matters for the 1-GPU dry run of the N>1 path
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("T2L_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" for the dry run
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     db, qs, target = synth.make_retrieval_problem(N_CELLS, N_QUERIES, DIM, seed=1, noise=0.5)
-    eng = Engine(local)
+    eng = Engine(dev)
     searcher = ShardedSearcher(eng)
     d_db = torch.from_numpy(db).cuda()
     d_q = torch.from_numpy(qs).cuda()
     lo, hi = searcher.set_db_shard(d_db)
     eng.set_option("profile_events", 1)
+    eng.set_option("search_mode", args.mode)
     if args.variant:
         eng.set_option("scan_variant", args.variant)
     if args.nsplit:

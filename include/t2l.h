@@ -140,6 +140,9 @@ int t2l_contrastive_loss(t2l_ctx* ctx, const float* anchor, const float* positiv
 /* ---- knobs (tests / bench) ------------------------------------------------------------------- */
 /* "certify_eps_scale" (default 1.0): multiplies the f32 error bound of the search certificate; a huge
  *     value forces every query through the exact fallback (used by the parity tests).
+ * "search_mode"       (default 0): 0 = split-bf16 (bf16x3) MFMA scan, 1 = exact-f32 MFMA scan; 2 / 3 = experimental
+ *     variants of 0 (wave-specialised; one wave per SIMD). All feed the same float64 re-rank + certificate, so the
+ *     RESULTS are identical; only the speed differs.
  * "search_nsplit"     (default 0 = auto): DB row splits per query block in the scan kernel.
  * "profile_events"    (default 0): record hipEvents around each kernel launch (t2l_kernel_stats). */
 int t2l_set_option(t2l_ctx* ctx, const char* name, double value);

@@ -8,13 +8,15 @@ from text2loc_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=[0, 1], ids=["bf16x3-specialised", "f32"])
+def eng(request):
+    """Both scan kernels feed the same float64 re-rank + certificate: every test runs against both."""
     import torch
     from text2loc_amd.engine import Engine
 
     assert torch.cuda.is_available(), "gpu tests need a GPU"
     e = Engine(0)
+    e.set_option("search_mode", request.param)
     yield e
     e.close()
 

@@ -64,7 +64,7 @@ void t2l_destroy(t2l_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   free_weights(ctx);
-  for (void* p : {(void*)ctx->db, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
+  for (void* p : {(void*)ctx->db, (void*)ctx->db_split, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
                   (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count})
     if (p) (void)hipFree(p);
   for (auto& kv : ctx->events) {
@@ -103,9 +103,12 @@ int t2l_db_set(t2l_ctx* ctx, const float* emb, int64_t n_rows, int64_t row_offse
   if (pad > ctx->db_cap) {
     T2L_HIP(ctx, hipStreamSynchronize(s));
     if (ctx->db) (void)hipFree(ctx->db);
+    if (ctx->db_split) (void)hipFree(ctx->db_split);
     ctx->db = nullptr;
+    ctx->db_split = nullptr;
     ctx->db_cap = 0;
     T2L_HIP(ctx, hipMalloc(&ctx->db, (size_t)pad * kD * sizeof(float)));
+    T2L_HIP(ctx, hipMalloc(&ctx->db_split, (size_t)pad * kD * sizeof(float)));
     ctx->db_cap = pad;
   }
   ctx->db_rows = n_rows;
@@ -177,6 +180,9 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
   } else if (!strcmp(name, "search_nsplit")) {
     if (value < 0 || value > kMaxParts / 2) return fail(ctx, T2L_EINVAL, "search_nsplit out of range [0,32]");
     ctx->nsplit_override = (int)value;
+  } else if (!strcmp(name, "search_mode")) {
+    if (value < 0 || value > 3) return fail(ctx, T2L_EINVAL, "search_mode must be 0..3");
+    ctx->search_mode = (int)value;
   } else if (!strcmp(name, "scan_variant")) {
     ctx->scan_variant = (int)value;
   } else if (!strcmp(name, "profile_events")) {

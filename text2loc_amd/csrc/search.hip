@@ -197,6 +197,382 @@ __global__ __launch_bounds__(256, L == 16 ? 2 : 1) void scan_kernel(const float*
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// scan2: wave-specialised scan on split-bf16 operands (the default path).
+//
+// Every f32 value x is stored as two bf16 planes hi = bf16(x), lo = bf16(x - hi); a product is formed as
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with f32 accumulation: |error| <= (2^-16 + 2^-18) * |a||b|
+// per dot product on top of the f32 accumulation bound — the same order as the key truncation, and covered
+// by the same certificate (the float64 re-rank decides the final order either way). 48 MFMAs of 32 cycles
+// per 32-row tile instead of 128 of 64 cycles: the matrix pipe is no longer the bound, the top-L selection
+// is — so the workgroup is 8 waves, 4 MFMA waves (32 queries each) + 4 selection waves. MFMA wave w hands
+// the 16 scores per lane of a finished tile to selection wave w+4 (same SIMD: its VALU runs beside the other
+// wave's MFMAs) through a double-buffered 4 KiB LDS slab; the selection waves also stream the DB tiles
+// (global_load_lds). One barrier per tile orders all three hand-offs.
+// DB layout for this kernel: bf16 [n_pad][2 planes][256] = 1 KiB per row, built once by split_db_kernel.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kSlabFloats = 16 * 64;  // one tile's scores of one MFMA wave: [r][lane]
+
+__device__ __forceinline__ unsigned bf16_rne_bits(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const unsigned h0 = bf16_rne_bits(x0), h1 = bf16_rne_bits(x1);
+  const unsigned l0 = bf16_rne_bits(x0 - __uint_as_float(h0 << 16)), l1 = bf16_rne_bits(x1 - __uint_as_float(h1 << 16));
+  hi = h0 | (h1 << 16);
+  lo = l0 | (l1 << 16);
+}
+__device__ __forceinline__ void split8(const float4 a, const float4 b, uint4& hi, uint4& lo) {
+  split_pair(a.x, a.y, hi.x, lo.x);
+  split_pair(a.z, a.w, hi.y, lo.y);
+  split_pair(b.x, b.y, hi.z, lo.z);
+  split_pair(b.z, b.w, hi.w, lo.w);
+}
+
+// f32 [rows][256] -> bf16 [rows][hi 256 | lo 256]
+__global__ __launch_bounds__(256) void split_db_kernel(const float* __restrict__ db, uint4* __restrict__ out, int rows) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;  // one thread = 8 consecutive floats
+  const int row = gid >> 5, c = gid & 31;
+  if (row >= rows) return;
+  const float4* src = reinterpret_cast<const float4*>(db + (size_t)row * kD + 8 * c);
+  uint4 hi, lo;
+  split8(src[0], src[1], hi, lo);
+  out[(size_t)row * 64 + c] = hi;
+  out[(size_t)row * 64 + 32 + c] = lo;
+}
+
+// 48 MFMAs of one tile (step S of 16), with one score of the previous tile written to the slab per step.
+template <int S = 0>
+__device__ __forceinline__ void tile_mfma_bf16(const char* tb, const uint4 (&qh)[16], const uint4 (&ql)[16], f32x16& cur,
+                                               const f32x16& prev, float* slab, uint4 (&ah)[2], uint4 (&al)[2]) {
+  if constexpr (S < 16) {
+    if constexpr (S == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // prologue LDS reads first
+    const uint4 a_hi = ah[S & 1], a_lo = al[S & 1];
+    if constexpr (S + 2 < 16) {
+      ah[S & 1] = *reinterpret_cast<const uint4*>(tb + 16 * (S + 2));
+      al[S & 1] = *reinterpret_cast<const uint4*>(tb + 512 + 16 * (S + 2));
+    }
+    const bf16x8 vh = __builtin_bit_cast(bf16x8, a_hi), vl = __builtin_bit_cast(bf16x8, a_lo);
+    cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, __builtin_bit_cast(bf16x8, qh[S]), cur, 0, 0, 0);
+    cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, __builtin_bit_cast(bf16x8, ql[S]), cur, 0, 0, 0);
+    cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, __builtin_bit_cast(bf16x8, qh[S]), cur, 0, 0, 0);
+    slab[S * 64] = prev[S];  // (iteration 0 writes zeros into a slab nobody reads yet)
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    if constexpr (S + 2 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    tile_mfma_bf16<S + 1>(tb, qh, ql, cur, prev, slab, ah, al);
+  }
+}
+
+template <int L, int VAR>
+__global__ __launch_bounds__(512, 2) void scan2_kernel(const uint4* __restrict__ dbs, int n_rows, int n_tiles, int per,
+                                                       int code_bits, const float* __restrict__ q, int Q, int nsplit,
+                                                       float* __restrict__ cand, int32_t* __restrict__ fb_count,
+                                                       int zero_counts) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tiles = smem;                       // 2 x [32 rows x 1040 B]
+  float* slabs = smem + 2 * kTileFloats;     // [4 waves][2][16][64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // MFMA wave and its selection wave share queries. VAR bit 3 (experiment): pair waves (2w, 2w+1) instead of (w, w+4)
+  const int role_w = (VAR & 8) ? (wave >> 1) : (wave & 3);
+  const bool is_mfma = (VAR & 8) ? !(wave & 1) : (wave < 4);
+  const int half = lane >> 5, col = lane & 31;
+  const int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
+  const int t0 = sp * per;
+  const int t1 = min(n_tiles, t0 + per);
+  const int nt = max(t1 - t0, 0);
+  const int qrow = qb * kQPerBlock + role_w * kQPerWave + col;
+  if (zero_counts && blockIdx.x == 0 && tid < 2) fb_count[tid] = 0;
+  float* my_slab = slabs + role_w * 2 * kSlabFloats + lane;
+
+  if (is_mfma) {
+    // ------------------------------------------------------------ MFMA role
+    uint4 qh[16], ql[16];
+    {
+      const float4* qp = reinterpret_cast<const float4*>(q + (size_t)min(qrow, Q - 1) * kD + half * 128);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) split8(qp[2 * s], qp[2 * s + 1], qh[s], ql[s]);
+    }
+    f32x16 accA, accB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accA[r] = accB[r] = 0.f;
+    auto step = [&](int it, int buf, f32x16& cur, const f32x16& prev) {
+      __syncthreads();
+      if (it < nt) {
+        const char* tb = reinterpret_cast<const char*>(tiles + buf * kTileFloats) + col * (kRowStrideF * 4) + half * 256;
+        uint4 ah[2], al[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ah[i] = *reinterpret_cast<const uint4*>(tb + 16 * i);
+          al[i] = *reinterpret_cast<const uint4*>(tb + 512 + 16 * i);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cur[r] = 0.f;
+        if constexpr (!(VAR & 2)) tile_mfma_bf16(tb, qh, ql, cur, prev, my_slab + ((it + 1) & 1) * kSlabFloats, ah, al);
+      } else if (it == nt && nt > 0) {  // drain: the last tile's scores
+#pragma unroll
+        for (int r = 0; r < 16; ++r) my_slab[((it - 1) & 1) * kSlabFloats + r * 64] = prev[r];
+      }
+    };
+    for (int it = 0; it < nt + 2; it += 2) {
+      step(it, 0, accA, accB);
+      step(it + 1, 1, accB, accA);
+    }
+  } else {
+    // ------------------------------------------------------------ selection + tile streaming role
+    const int mask = ~((1 << code_bits) - 1);
+    float ls[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) ls[i] = T2L_NEG_INF;
+    auto issue = [&](int t, int buf) {
+      const uint4* src = dbs + (size_t)t * kTileRows * 64 + lane;
+      float* dst = tiles + buf * kTileFloats;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = role_w * 8 + i;  // one wave-instruction moves one 1 KiB row (hi | lo planes) into LDS
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + row * 64),
+                                         (__attribute__((address_space(3))) void*)(dst + row * kRowStrideF), 16, 0, 0);
+      }
+    };
+    if (nt > 0) issue(t0, 0);
+    const int niter = (nt + 2 + 1) & ~1;  // the MFMA waves run an even number of iterations
+    for (int it = 0; it < niter; ++it) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile `it` has landed (this wave's rows)
+      __syncthreads();
+      if ((it + 1 < nt) && !(VAR & 4)) issue(t0 + it + 1, (it + 1) & 1);  // every wave is past its reads of that buffer
+      if (it >= 2 && it - 2 < nt) {
+        const int tl = it - 2;  // tile whose scores the MFMA wave wrote during iteration it-1
+        const float* slab = my_slab + (tl & 1) * kSlabFloats;
+        const int row0 = (t0 + tl) * kTileRows + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + (r & 3) + 8 * (r >> 2);
+          const float key = make_key(slab[r * 64], mask, (tl << 4) + r);
+          if constexpr (VAR & 1)
+            ls[r % L] = fmaxf(ls[r % L], key);
+          else
+            ins_key<L>(ls, row < n_rows ? key : T2L_NEG_INF);
+        }
+      }
+    }
+    if (qrow < Q) {
+      float4* out = reinterpret_cast<float4*>(cand + (((size_t)qrow * nsplit + sp) * 2 + half) * L);
+#pragma unroll
+      for (int i = 0; i < L / 4; ++i) out[i] = make_float4(ls[4 * i], ls[4 * i + 1], ls[4 * i + 2], ls[4 * i + 3]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scan3: split-bf16 scan with the selection interleaved in the SAME wave (measured on gfx950,
+// tools/mfma_valu_probe.hip: up to ~4-5 independent VALU instructions hide in the 32-cycle gap of a
+// bf16 32x32x16 MFMA when they sit in the issuing wave's own stream; a partner wave's VALU stream on the
+// same SIMD instead slows the MFMA wave by 20-40 cycles per MFMA, which is why scan2's wave specialisation
+// loses). Structure = scan_kernel (4 waves x 32 queries share the LDS tile), arithmetic = scan2's.
+// The row >= n_rows mask lives only in the epilogue: the one partial tile of a shard is the last tile of the
+// last split, whose scores are inserted after the loop.
+// ------------------------------------------------------------------------------------------------
+template <int L, int I = L - 1>
+__device__ __forceinline__ void ins_key_sat(float (&s)[L], float x, float pinf) {
+  if constexpr (I == 0) {
+    s[0] = __builtin_amdgcn_fmed3f(s[0], x, pinf);  // max(s0, x) as ONE op (pinf is a run-time +inf: no folding to
+  } else {                                          // the canonicalising v_max pair)
+    s[I] = __builtin_amdgcn_fmed3f(s[I - 1], s[I], x);
+    ins_key_sat<L, I - 1>(s, x, pinf);
+  }
+}
+
+// 48 MFMAs of a tile on ONE accumulator chain, 3 per k-step, with one score of the previous tile inserted per
+// k-step (measured: for the bf16 MFMA a single chain with ~6 interleaved VALU per MFMA beats two alternating
+// chains, which cost 32 more VGPRs and a spill at two waves per SIMD).
+template <int L, int VPM, int VAR, int S = 0>
+__device__ __forceinline__ void tile_mfma_bf16_sel(const char* tb, const uint4 (&qh)[16], const uint4 (&ql)[16],
+                                                   f32x16& cur, const f32x16& prev, int vmask, int code0, float pinf,
+                                                   float (&ls)[L], uint4 (&ah)[4], uint4 (&al)[4]) {
+  if constexpr (S < 16) {
+    if constexpr (S == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // prologue LDS reads first
+    const uint4 a_hi = ah[S & 3], a_lo = al[S & 3];
+    if constexpr (S + 4 < 16) {
+      ah[S & 3] = *reinterpret_cast<const uint4*>(tb + 16 * (S + 4));
+      al[S & 3] = *reinterpret_cast<const uint4*>(tb + 512 + 16 * (S + 4));
+    }
+    const bf16x8 vh = __builtin_bit_cast(bf16x8, a_hi), vl = __builtin_bit_cast(bf16x8, a_lo);
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, qh[S]), bl = __builtin_bit_cast(bf16x8, ql[S]);
+    if constexpr (VAR & 2) {
+      cur[S] += __builtin_bit_cast(uint4, vh).x * 1e-30f + __builtin_bit_cast(uint4, vl).y * 1e-30f;
+    } else {
+      cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, bh, cur, 0, 0, 0);
+      cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, bl, cur, 0, 0, 0);
+      cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, bh, cur, 0, 0, 0);
+    }
+    {  // score S of the previous tile enters the list: 2 + L VALU
+      const int code = __builtin_amdgcn_readfirstlane(code0 + S);
+      const float key = __int_as_float((__float_as_int(prev[S]) & vmask) | code);
+      if constexpr (VAR & 1)
+        ls[S % L] = __builtin_amdgcn_fmed3f(ls[S % L], key, pinf);
+      else
+        ins_key_sat<L>(ls, key, pinf);
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+    }
+    if constexpr (S + 4 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    tile_mfma_bf16_sel<L, VPM, VAR, S + 1>(tb, qh, ql, cur, prev, vmask, code0, pinf, ls, ah, al);
+  }
+}
+
+template <int L, int WPS, int VAR>
+__global__ __launch_bounds__(256, WPS) void scan3_kernel(const uint4* __restrict__ dbs, int n_rows, int n_tiles,
+                                                         int per, int code_bits, const float* __restrict__ q, int Q,
+                                                         int nsplit, float* __restrict__ cand,
+                                                         int32_t* __restrict__ fb_count, int zero_counts, float pinf) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tiles = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
+  const int t0 = sp * per;
+  const int t1 = min(n_tiles, t0 + per);
+  const int qrow = qb * kQPerBlock + wave * kQPerWave + col;
+  const int mask = ~((1 << code_bits) - 1);
+  int vmask = mask;
+  asm volatile("" : "+v"(vmask));  // keep the mask in a VGPR so key = v_and_or_b32(score, vmask, s_code) is one op
+  if (zero_counts && blockIdx.x == 0 && tid < 2) fb_count[tid] = 0;
+
+  uint4 qh[16], ql[16];
+  {
+    const float4* qp = reinterpret_cast<const float4*>(q + (size_t)min(qrow, Q - 1) * kD + half * 128);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) split8(qp[2 * s], qp[2 * s + 1], qh[s], ql[s]);
+  }
+  float ls[L];
+#pragma unroll
+  for (int i = 0; i < L; ++i) ls[i] = T2L_NEG_INF;
+  f32x16 accA, accB;  // tile t / tile t+1
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accA[r] = accB[r] = T2L_NEG_INF;  // "previous tile" of the first tile: no-op inserts
+
+  auto issue = [&](int t, int buf) {
+    const uint4* src = dbs + (size_t)t * kTileRows * 64 + lane;
+    float* dst = tiles + buf * kTileFloats;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = wave * 8 + i;  // one wave-instruction moves one 1 KiB row (hi | lo planes) into LDS
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + row * 64),
+                                       (__attribute__((address_space(3))) void*)(dst + row * kRowStrideF), 16, 0, 0);
+    }
+  };
+  auto step = [&](int t, int buf, f32x16& cur, const f32x16& prev) {
+    if constexpr (!(VAR & 4)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // tile t landed for every wave; every wave is done reading buffer buf^1
+      if (t + 1 < t1) issue(t + 1, buf ^ 1);
+    }
+    const char* tb = reinterpret_cast<const char*>(tiles + buf * kTileFloats) + col * (kRowStrideF * 4) + half * 256;
+    uint4 ah[4], al[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *reinterpret_cast<const uint4*>(tb + 16 * i);
+      al[i] = *reinterpret_cast<const uint4*>(tb + 512 + 16 * i);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cur[r] = 0.f;
+    constexpr int VPM = (L + 2 + 2) / 3;
+    tile_mfma_bf16_sel<L, VPM, VAR>(tb, qh, ql, cur, prev, vmask, (t - 1 - t0) << 4, pinf, ls, ah, al);
+  };
+
+  if (t0 < t1) issue(t0, 0);
+  if constexpr (VAR & 4) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  for (int t = t0; t < t1; t += 2) {
+    step(t, 0, accA, accB);
+    if (t + 1 < t1) step(t + 1, (VAR & 4) ? 0 : 1, accB, accA);
+  }
+  if (t0 < t1) {  // the last tile's scores are still in registers; only here can rows be >= n_rows
+    const int row0 = (t1 - 1) * kTileRows + 4 * half;
+    const int code0 = (t1 - 1 - t0) << 4;
+    if ((t1 - t0) & 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        ins_key<L>(ls, row < n_rows ? make_key(accA[r], mask, code0 + r) : T2L_NEG_INF);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        ins_key<L>(ls, row < n_rows ? make_key(accB[r], mask, code0 + r) : T2L_NEG_INF);
+      }
+    }
+  }
+  if (qrow < Q) {
+    float4* out = reinterpret_cast<float4*>(cand + (((size_t)qrow * nsplit + sp) * 2 + half) * L);
+#pragma unroll
+    for (int i = 0; i < L / 4; ++i) out[i] = make_float4(ls[4 * i], ls[4 * i + 1], ls[4 * i + 2], ls[4 * i + 3]);
+  }
+}
+
+// ---- wave-wide all-reduces on the VALU (DPP + v_permlane{16,32}_swap), no LDS traffic: __shfl_xor lowers to
+// ds_bpermute_b32, and the re-rank is shuffle-bound (hundreds of shuffles per query).
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+
+__device__ __forceinline__ float wave_max_f32(float v, float pinf) {  // every lane gets the maximum
+#define T2L_MAXSTEP(o) v = __builtin_amdgcn_fmed3f(v, (o), pinf)
+  T2L_MAXSTEP(__uint_as_float(dpp_u<kDppXor1>(__float_as_uint(v))));
+  T2L_MAXSTEP(__uint_as_float(dpp_u<kDppXor2>(__float_as_uint(v))));
+  T2L_MAXSTEP(__uint_as_float(dpp_u<kDppHalfMirror>(__float_as_uint(v))));
+  T2L_MAXSTEP(__uint_as_float(dpp_u<kDppMirror>(__float_as_uint(v))));
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __builtin_amdgcn_fmed3f(__uint_as_float(r[0]), __uint_as_float(r[1]), pinf);
+  }
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __builtin_amdgcn_fmed3f(__uint_as_float(r[0]), __uint_as_float(r[1]), pinf);
+  }
+#undef T2L_MAXSTEP
+  return v;
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  const unsigned long long b = __double_as_longlong(v);
+  const unsigned lo = dpp_u<CTRL>((unsigned)b), hi = dpp_u<CTRL>((unsigned)(b >> 32));
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {  // every lane gets the sum (fixed tree order)
+  v += dpp_d<kDppXor1>(v);
+  v += dpp_d<kDppXor2>(v);
+  v += dpp_d<kDppHalfMirror>(v);
+  v += dpp_d<kDppMirror>(v);
+  {
+    const unsigned long long b = __double_as_longlong(v);
+    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    v = __longlong_as_double(((unsigned long long)h[0] << 32) | l[0]) +
+        __longlong_as_double(((unsigned long long)h[1] << 32) | l[1]);
+  }
+  {
+    const unsigned long long b = __double_as_longlong(v);
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    v = __longlong_as_double(((unsigned long long)h[0] << 32) | l[0]) +
+        __longlong_as_double(((unsigned long long)h[1] << 32) | l[1]);
+  }
+  return v;
+}
+
 // key -> local DB row. part = 2*split + half.
 __device__ __forceinline__ int key_row(float key, int part, int per, int code_bits) {
   const int code = __float_as_int(key) & ((1 << code_bits) - 1);
@@ -228,58 +604,76 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
                                                      const float* __restrict__ cand, int row_offset, float eps_rel,
                                                      const float* __restrict__ db_norm_max,
                                                      int32_t* __restrict__ out_idx, double* __restrict__ out_score,
-                                                     int32_t* __restrict__ flags) {
+                                                     int32_t* __restrict__ flags, float pinf) {
   const int lane = threadIdx.x & 63;
   const int qid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (qid >= Q) return;
 
-  // ---- merge the `parts` sorted key lists into the top-L (lane c ends up with the c-th best)
-  const float* mine = cand + ((size_t)qid * parts + min(lane, parts - 1)) * L;
-  int ptr = 0;
-  float head = lane < parts ? mine[0] : T2L_NEG_INF;
+  // ---- every lane pulls its whole sorted key list into registers (one memory latency for the merge)
+  float lst[L];
+  {
+    const float4* mine = reinterpret_cast<const float4*>(cand + ((size_t)qid * parts + min(lane, parts - 1)) * L);
+#pragma unroll
+    for (int i = 0; i < L / 4; ++i) {
+      const float4 v = mine[i];
+      lst[4 * i] = v.x;
+      lst[4 * i + 1] = v.y;
+      lst[4 * i + 2] = v.z;
+      lst[4 * i + 3] = v.w;
+    }
+    if (lane >= parts) {
+#pragma unroll
+      for (int i = 0; i < L; ++i) lst[i] = T2L_NEG_INF;
+    }
+  }
+  const float4 qv = reinterpret_cast<const float4*>(q + (size_t)qid * kD)[lane];
+
+  // ---- merge the `parts` lists into the top-L keys: L rounds of wave arg-max over the list heads
   float my_key = T2L_NEG_INF;
   int my_row = INT_MAX;
+#pragma unroll 1
   for (int r = 0; r < L; ++r) {
-    float bk = head;
-    int bl = lane;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const float ok = __shfl_xor(bk, off);
-      const int ol = __shfl_xor(bl, off);
-      if (ok > bk || (ok == bk && ol < bl)) {
-        bk = ok;
-        bl = ol;
-      }
-    }
+    const float bk = wave_max_f32(lst[0], pinf);
+    const unsigned long long who = __ballot(lst[0] == bk);
+    const int bl = __ffsll((long long)who) - 1;  // equal keys: lowest part first
     if (lane == r) {
       my_key = bk;
       my_row = bk == T2L_NEG_INF ? INT_MAX : key_row(bk, bl, per, code_bits);
     }
-    if (lane == bl && bk != T2L_NEG_INF) {  // the winner advances its list
-      ++ptr;
-      head = ptr < L ? mine[ptr] : T2L_NEG_INF;
+    if (lane == bl) {  // the winner pops its head (register shift, no memory)
+#pragma unroll
+      for (int i = 0; i < L - 1; ++i) lst[i] = lst[i + 1];
+      lst[L - 1] = T2L_NEG_INF;
     }
   }
-  const float g = __shfl(my_key, L - 1);  // every row that is NOT re-scored has key <= g
+  const float g = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_key), L - 1));  // every row that is NOT re-scored has key <= g
 
-  // ---- float64 re-score of the selected rows (products of f32 values are exact in f64)
-  const float4 qv = reinterpret_cast<const float4*>(q + (size_t)qid * kD)[lane];
-  double qn = (double)qv.x * qv.x + (double)qv.y * qv.y + (double)qv.z * qv.z + (double)qv.w * qv.w;
+  // ---- float64 re-score of the selected rows (products of f32 values are exact in f64): all L row gathers are
+  // issued before the first reduction
+  const double qn =
+      wave_sum_f64((double)qv.x * qv.x + (double)qv.y * qv.y + (double)qv.z * qv.z + (double)qv.w * qv.w);
+  float4 rows[L];
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) qn += __shfl_xor(qn, off);
-  double my_d = -__builtin_inf();
   for (int c = 0; c < L; ++c) {
-    const int row = __shfl(my_row, c);
-    if (row == INT_MAX) continue;  // wave-uniform
-    const double d = wave_dot64(db, row, qv, lane);
-    if (lane == c) my_d = d;
+    const int row = __builtin_amdgcn_readlane(my_row, c);
+    rows[c] = reinterpret_cast<const float4*>(db + (size_t)(row == INT_MAX ? 0 : row) * kD)[lane];
+  }
+  double my_d = -__builtin_inf();
+#pragma unroll
+  for (int c = 0; c < L; ++c) {
+    const double d = wave_sum_f64((double)rows[c].x * qv.x + (double)rows[c].y * qv.y + (double)rows[c].z * qv.z +
+                                  (double)rows[c].w * qv.w);
+    if (lane == c && my_row != INT_MAX) my_d = d;
   }
 
   // ---- order by (float64 score desc, row asc); lane c computes its rank among the L
   int rank = 0;
+#pragma unroll
   for (int j = 0; j < L; ++j) {
-    const double dj = __shfl(my_d, j);
-    const int ij = __shfl(my_row, j);
+    const unsigned long long bj = __double_as_longlong(my_d);
+    const double dj = __longlong_as_double(((unsigned long long)__builtin_amdgcn_readlane((unsigned)(bj >> 32), j) << 32) |
+                                           (unsigned)__builtin_amdgcn_readlane((unsigned)bj, j));
+    const int ij = __builtin_amdgcn_readlane(my_row, j);
     rank += (dj > my_d || (dj == my_d && ij < my_row)) ? 1 : 0;
   }
   const bool valid = lane < L && my_row != INT_MAX;
@@ -385,14 +779,12 @@ __device__ void exact_scan(const float* __restrict__ db, int n_rows, const doubl
 
 template <int L>
 __global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__ db, int n_rows,
-                                                       const float* __restrict__ q, int K, int parts, int per,
+                                                       const float* __restrict__ q, int Q, int K, int parts, int per,
                                                        int code_bits, const float* __restrict__ cand, int row_offset,
                                                        float eps_rel, const float* __restrict__ db_norm_max,
                                                        const int32_t* __restrict__ flags,
                                                        int32_t* __restrict__ out_idx, double* __restrict__ out_score,
                                                        int32_t* __restrict__ fb_count) {
-  const int qid = blockIdx.x;
-  if (!flags[qid]) return;
   __shared__ double qs[kD];
   __shared__ double cd[kMaxCand];
   __shared__ int crow[kMaxCand];
@@ -401,6 +793,9 @@ __global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__
   __shared__ int red_t[256];
   __shared__ float floor_max;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int qid = blockIdx.x; qid < Q; qid += gridDim.x) {  // flagged queries are rare: few blocks sweep the flags
+  if (!flags[qid]) continue;
+  __syncthreads();
   qs[tid] = (double)q[(size_t)qid * kD + tid];
 
   // ---- stage 2
@@ -479,13 +874,14 @@ __global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__
     certified = dK > (double)floor_max + key_slack(floor_max, code_bits, eps32);
   }
   if (tid == 0) atomicAdd(&fb_count[1], 1);
-  if (certified) return;  // block-uniform
+  if (certified) continue;  // block-uniform
 
   // ---- stage 3
   if (tid == 0) atomicAdd(&fb_count[0], 1);
   __syncthreads();
   exact_scan<32>(db, n_rows, qs, K, row_offset, out_idx + (size_t)qid * K,
                  out_score ? out_score + (size_t)qid * K : nullptr, red_s, red_i, red_t);
+  }
 }
 
 // max row 2-norm of the shard (bounds the f32 dot-product error in the certificate); one atomic per workgroup
@@ -576,6 +972,12 @@ int merge_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int parts,
 }
 
 int db_norm_impl(t2l_ctx* ctx, hipStream_t s) {
+  if (ctx->db_pad > 0) {  // the bf16 hi/lo planes the default scan multiplies
+    const int threads = (int)ctx->db_pad * 32;
+    hipLaunchKernelGGL(split_db_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ctx->db, ctx->db_split,
+                       (int)ctx->db_pad);
+    T2L_HIP(ctx, hipGetLastError());
+  }
   T2L_HIP(ctx, hipMemsetAsync(ctx->db_norm_max, 0, sizeof(float), s));
   if (ctx->db_rows > 0) {
     const int blocks = (int)min((int64_t)1024, (ctx->db_rows + 3) / 4);
@@ -585,7 +987,6 @@ int db_norm_impl(t2l_ctx* ctx, hipStream_t s) {
   return T2L_OK;
 }
 
-static size_t scan_lds_bytes() { return (size_t)2 * kTileFloats * sizeof(float); }
 
 template <int L, int VAR>
 static void launch_scan(t2l_ctx* ctx, dim3 grid, size_t lds, hipStream_t s, const float* db, int n_rows, int n_tiles,
@@ -600,16 +1001,70 @@ static void launch_scan(t2l_ctx* ctx, dim3 grid, size_t lds, hipStream_t s, cons
                      ctx->cand_score, ctx->fb_count, zero);
 }
 
+static size_t scan_lds_bytes() { return (size_t)2 * kTileFloats * sizeof(float); }
+
+template <int L, int WPS, int VAR>
+static void launch_scan3(t2l_ctx* ctx, dim3 grid, hipStream_t s, const uint4* dbs, int n_rows, int n_tiles, int per,
+                         int code_bits, const float* q, int Q, int nsplit, int zero) {
+  const size_t lds = scan_lds_bytes();
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan3_kernel<L, WPS, VAR>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((scan3_kernel<L, WPS, VAR>), grid, dim3(256), lds, s, dbs, n_rows, n_tiles, per, code_bits, q, Q,
+                     nsplit, ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
+}
+
+template <int L, int VAR>
+static void launch_scan2(t2l_ctx* ctx, dim3 grid, hipStream_t s, const uint4* dbs, int n_rows, int n_tiles, int per,
+                         int code_bits, const float* q, int Q, int nsplit, int zero) {
+  const size_t lds = (size_t)(2 * kTileFloats + 4 * 2 * kSlabFloats) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan2_kernel<L, VAR>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((scan2_kernel<L, VAR>), grid, dim3(512), lds, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit,
+                     ctx->cand_score, ctx->fb_count, zero);
+}
+
 template <int L>
-static int launch_search(t2l_ctx* ctx, const float* db, int n_rows, int row_offset, const float* q, int Q, int K,
-                         int nsplit, int per, int code_bits, int32_t* out_idx, double* out_score, bool first,
-                         hipStream_t s) {
+static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, int n_rows, int row_offset, const float* q,
+                         int Q, int K, int nsplit, int per, int code_bits, int32_t* out_idx, double* out_score,
+                         bool first, hipStream_t s) {
   const int n_tiles = (n_rows + kTileRows - 1) / kTileRows;
   const int n_qblocks = (Q + kQPerBlock - 1) / kQPerBlock;
   const int parts = 2 * nsplit;
   const size_t lds = scan_lds_bytes();
   event_begin(ctx, "search_scan", s);
   const dim3 grid(n_qblocks * nsplit);
+  if (ctx->search_mode == 0) {
+    launch_scan3<L, 2, 0>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first);
+  } else if (ctx->search_mode == 3) {
+    switch (ctx->scan_variant) {
+      case 1: launch_scan3<L, 1, 1>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 2: launch_scan3<L, 1, 2>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 3: launch_scan3<L, 1, 3>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 4: launch_scan3<L, 1, 4>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 5: launch_scan3<L, 1, 5>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 6: launch_scan3<L, 1, 6>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 7: launch_scan3<L, 1, 7>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      default: launch_scan3<L, 1, 0>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+    }
+  } else if (ctx->search_mode == 2) {
+    switch (ctx->scan_variant) {  // 0 = product; others = timing-only ablations (wrong results by construction)
+      case 1: launch_scan2<L, 1>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 2: launch_scan2<L, 2>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 3: launch_scan2<L, 3>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 4: launch_scan2<L, 4>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 7: launch_scan2<L, 7>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 8: launch_scan2<L, 8>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      default: launch_scan2<L, 0>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+    }
+  } else
   switch (ctx->scan_variant) {  // 0 = product; 1..3 = timing-only ablations (wrong results by construction)
     case 1: launch_scan<L, 1>(ctx, grid, lds, s, db, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
     case 2: launch_scan<L, 2>(ctx, grid, lds, s, db, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
@@ -619,12 +1074,15 @@ static int launch_search(t2l_ctx* ctx, const float* db, int n_rows, int row_offs
   event_end(ctx, "search_scan", s);
   T2L_HIP(ctx, hipGetLastError());
   // f32 dot-product error bound: gamma_n * |a||b| with n = 256 terms (+ slack for the MFMA's k order)
-  const float eps_rel = (float)(ctx->eps_scale * (kD + 8) * 5.9604644775390625e-08);
+  // (+ the split-bf16 product error 2^-16 + 2^-18, rounded up, when the bf16x3 scan produced the keys)
+  const float eps_rel = (float)(ctx->eps_scale *
+                                ((kD + 8) * 5.9604644775390625e-08 + (ctx->search_mode != 1 ? 2.0e-5 : 0.0)));
   event_begin(ctx, "search_rerank", s);
   hipLaunchKernelGGL(rerank_kernel<L>, dim3((Q + 3) / 4), dim3(256), 0, s, db, q, Q, K, parts, per, code_bits,
-                     ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, out_idx, out_score, ctx->flags);
+                     ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, out_idx, out_score, ctx->flags,
+                     __builtin_inff());
   T2L_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(fallback_kernel<L>, dim3(Q), dim3(256), 0, s, db, n_rows, q, K, parts, per, code_bits,
+  hipLaunchKernelGGL(fallback_kernel<L>, dim3(min(Q, 512)), dim3(256), 0, s, db, n_rows, q, Q, K, parts, per, code_bits,
                      ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, ctx->flags, out_idx, out_score,
                      ctx->fb_count);
   event_end(ctx, "search_rerank", s);
@@ -670,8 +1128,9 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     const int n_tiles = (max(rows, 0) + kTileRows - 1) / kTileRows;
     int nsplit = ctx->nsplit_override;
     if (nsplit <= 0) {
-      // 2 workgroups per CU (256 CUs); multiples of 8 keep a split on one XCD's L2
-      nsplit = (512 + n_qblocks - 1) / n_qblocks;
+      // f32 scan: 2 workgroups (4 waves) per CU; bf16x3 scan: 1 workgroup (8 waves) per CU. 256 CUs.
+      // Multiples of 8 keep a split on one XCD's L2.
+      nsplit = ((ctx->search_mode >= 2 ? 256 : 512) + n_qblocks - 1) / n_qblocks;
       nsplit = ((nsplit + 7) / 8) * 8;
     }
     nsplit = max(1, min(nsplit, kMaxParts / 2));
@@ -687,10 +1146,11 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
       seg_score = ctx->seg_score + (size_t)seg * Q * K;
     }
     const float* db = ctx->db + (size_t)row0 * kD;
+    const uint4* dbs = ctx->db_split ? ctx->db_split + (size_t)row0 * 64 : nullptr;
     const int off = (int)ctx->row_offset + row0;
-    rc = (L == 16) ? launch_search<16>(ctx, db, max(rows, 0), off, q, Q, K, nsplit, per, code_bits, seg_idx,
+    rc = (L == 16) ? launch_search<16>(ctx, db, dbs, max(rows, 0), off, q, Q, K, nsplit, per, code_bits, seg_idx,
                                         seg_score, seg == 0, s)
-                   : launch_search<32>(ctx, db, max(rows, 0), off, q, Q, K, nsplit, per, code_bits, seg_idx,
+                   : launch_search<32>(ctx, db, dbs, max(rows, 0), off, q, Q, K, nsplit, per, code_bits, seg_idx,
                                         seg_score, seg == 0, s);
     if (rc != T2L_OK) return rc;
   }

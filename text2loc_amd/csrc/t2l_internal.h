@@ -43,6 +43,7 @@ struct t2l_ctx {
   std::string err;
   // database shard
   float* db = nullptr;       // [db_pad,256], rows >= db_rows are zero
+  uint4* db_split = nullptr; // bf16 [db_pad][hi 256 | lo 256] planes of the same rows (1 KiB per row)
   int64_t db_rows = 0, db_pad = 0, db_cap = 0, row_offset = 0;
   float* db_norm_max = nullptr;  // dev f32[1]: max row 2-norm (feeds the certificate's error bound)
   // search workspace
@@ -57,6 +58,7 @@ struct t2l_ctx {
   // options
   double eps_scale = 1.0;
   int nsplit_override = 0;
+  int search_mode = 0;   // 0 = wave-specialised split-bf16 scan (default), 1 = exact-f32 MFMA scan
   int scan_variant = 0;  // dev knob: timing-only ablations of the scan kernel
   bool profile_events = false;
   std::unordered_map<std::string, t2l::EventRing> events;
