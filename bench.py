@@ -9,8 +9,8 @@ searches its shard, one RCCL all_gather of the per-shard top-k, merge on every r
 work fixed).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the fused
-f32-MFMA scan; algorithmic FLOPs = 2*Q*N*D per launch / its hipEvent-measured duration vs the 157.3 TF f32
-MFMA peak) and `cpu_baseline` (the numpy oracle of training/coarse.py:119-125 timed on this host).
+f32-MFMA scan; algorithmic FLOPs = 2*Q*N*D per launch / its hipEvent-measured duration vs the dense MFMA peak of the
+dtype the scan multiplies in: bf16 2.5 PF for the default split-bf16 scan, 157.3 TF for --mode 1 = f32) and `cpu_baseline` (the numpy oracle of training/coarse.py:119-125 timed on this host).
 """
 import argparse
 import json
@@ -29,7 +29,8 @@ from text2loc_amd.engine import Engine  # noqa: E402
 from text2loc_amd.sharded import ShardedSearcher, shard_bounds  # noqa: E402
 
 N_CELLS, N_QUERIES, DIM, TOPK = 11259, 4096, 256, 10
-F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (AMD's 5 PF figure is 2:1 sparse)
 
 
 def cpu_baseline(db, qs, budget_s=12.0):
@@ -99,12 +100,15 @@ def secondary_measurements(eng):
 
 
 def main():
+    global N_CELLS, N_QUERIES
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the encoder / loss side measurements")
+    ap.add_argument("--cells", type=int, default=N_CELLS, help="dev: database rows (default = the BASELINE workload)")
+    ap.add_argument("--queries", type=int, default=N_QUERIES, help="dev: queries per step")
     ap.add_argument("--mode", type=int, default=0, help="search_mode: 0 = split-bf16 specialised scan, 1 = f32 scan")
     ap.add_argument("--variant", type=int, default=0, help="dev: timing-only ablation of the scan kernel")
     ap.add_argument("--nsplit", type=int, default=0, help="override the scan kernel's DB split count (0 = auto)")
@@ -126,6 +130,7 @@ def main():
             dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
+    N_CELLS, N_QUERIES = args.cells, args.queries
     db, qs, target = synth.make_retrieval_problem(N_CELLS, N_QUERIES, DIM, seed=1, noise=0.5)
     eng = Engine(dev)
     searcher = ShardedSearcher(eng)
@@ -180,20 +185,31 @@ def main():
         n_local = hi - lo
         flops = 2.0 * N_QUERIES * n_local * DIM  # algorithmic FLOPs of one scan launch on this rank's shard
         achieved = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+        if args.mode == 1:
+            kname, peak, dtype, mult = "scan_kernel<16, 0>", F32_MFMA_PEAK_TFLOPS, "f32", 1
+        else:
+            kname = {0: "scan3_kernel<16, 2, 0>", 2: "scan2_kernel<16, 0>", 3: "scan3_kernel<16, 1, 0>"}[args.mode]
+            peak, dtype, mult = BF16_MFMA_PEAK_TFLOPS, "bf16x3", 3
         out = {
             "metric": "coarse-retrieval queries/sec over 11k-cell DB, embed_dim=256; top-1/3/5 recall parity",
             "value": N_QUERIES * args.steps / elapsed,
             "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": dtype, "data": "synthetic",
             "config": {"workload": "KITTI360Pose-sized val DB: N=11259 cells x D=256 resident in HBM, Q=4096 "
                                    "precomputed text embeddings per step, top-10 (float64-exact ids)",
                        "n_cells": N_CELLS, "queries_per_step": N_QUERIES, "embed_dim": DIM, "top_k": TOPK,
+                       "arithmetic": ("split-bf16 MFMA candidate scan (f32 accumulate) -> float64 re-rank + certificate"
+                                      if args.mode != 1 else "f32 MFMA candidate scan -> float64 re-rank + certificate"),
                        "parallelism": f"db-row-shard x{world}" if world > 1 else "single-gpu"},
-            "roofline": {"bound": "mfma", "kernel": "scan_kernel<16>", "achieved": achieved,
-                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                         "traffic": pmc_traffic("t2l::scan_kernel<16, 0>"), "kernel_ms": scan_ms, "launches_timed": scan_n,
+            # achieved = ALGORITHMIC flops (2*Q*N*D) / kernel time. In the bf16x3 mode every f32 product is formed by 3
+            # bf16 MFMA products (hi*hi + hi*lo + lo*hi), so the matrix pipe executes 3x the algorithmic flops:
+            # `executed` / `frac_executed` give that view; `peak` is the dense MFMA peak of the dtype the pipe runs in.
+            "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved,
+                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "executed": achieved * mult, "frac_executed": achieved * mult / peak,
+                         "traffic": pmc_traffic("t2l::" + kname), "kernel_ms": scan_ms, "launches_timed": scan_n,
                          "flops_per_launch": flops},
             "kernels_ms": {"search_scan": scan_ms, "search_rerank+exact": rerank_ms},
             "secondary": secondary,

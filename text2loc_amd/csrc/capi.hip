@@ -49,12 +49,12 @@ int t2l_create(t2l_ctx** out, int device_id) {
   t2l_ctx* ctx = new t2l_ctx();
   ctx->device = device_id;
   if (hipMalloc(&ctx->db_norm_max, sizeof(float)) != hipSuccess ||
-      hipMalloc(&ctx->fb_count, 2 * sizeof(int32_t)) != hipSuccess) {
+      hipMalloc(&ctx->fb_count, 128 * sizeof(int32_t)) != hipSuccess) {
     delete ctx;
     return T2L_ENOMEM;
   }
   (void)hipMemset(ctx->db_norm_max, 0, sizeof(float));
-  (void)hipMemset(ctx->fb_count, 0, 2 * sizeof(int32_t));
+  (void)hipMemset(ctx->fb_count, 0, 128 * sizeof(int32_t));
   *out = ctx;
   return T2L_OK;
 }
@@ -150,6 +150,14 @@ int t2l_merge_topk(t2l_ctx* ctx, const int32_t* idx, const double* score, int32_
   if (!idx || !score || !out_idx) return fail(ctx, T2L_EINVAL, "t2l_merge_topk: null buffer");
   T2L_HIP(ctx, hipSetDevice(ctx->device));
   return merge_impl(ctx, idx, score, parts, n_queries, k, out_idx, out_score, (hipStream_t)stream);
+}
+
+// dev: phase cycle counters written by the instrumented scan variant (scan_variant 16/17): 4 waves x 5 phases
+int t2l_debug_counters(t2l_ctx* ctx, long long* out, int32_t n) {
+  if (!ctx || !out || n > 60) return T2L_EINVAL;
+  T2L_HIP(ctx, hipDeviceSynchronize());
+  T2L_HIP(ctx, hipMemcpy(out, ctx->fb_count + 4, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
+  return T2L_OK;
 }
 
 int t2l_search_fallbacks(t2l_ctx* ctx, int32_t* out_count) {

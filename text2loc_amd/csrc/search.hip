@@ -388,12 +388,27 @@ __device__ __forceinline__ void ins_key_sat(float (&s)[L], float x, float pinf) 
 // 48 MFMAs of a tile on ONE accumulator chain, 3 per k-step, with one score of the previous tile inserted per
 // k-step (measured: for the bf16 MFMA a single chain with ~6 interleaved VALU per MFMA beats two alternating
 // chains, which cost 32 more VGPRs and a spill at two waves per SIMD).
-template <int L, int VPM, int VAR, int S = 0>
+template <int L, int VPM, int VAR, int S, int S_END>
 __device__ __forceinline__ void tile_mfma_bf16_sel(const char* tb, const uint4 (&qh)[16], const uint4 (&ql)[16],
                                                    f32x16& cur, const f32x16& prev, int vmask, int code0, float pinf,
-                                                   float (&ls)[L], uint4 (&ah)[4], uint4 (&al)[4]) {
-  if constexpr (S < 16) {
+                                                   float (&ls)[L], uint4 (&ah)[4], uint4 (&al)[4],
+                                                   const uint4* gnext, float* lnext) {
+  if constexpr (S < S_END) {
     if constexpr (S == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // prologue LDS reads first
+    // VAR & 64: the 8 LDS-DMA rows of the NEXT tile are issued one per k-step inside the MFMA phase (each costs ~70
+    // issue cycles; in a burst after the barrier they also delay the first LDS reads by ~800 cycles)
+    if constexpr ((VAR & 64) != 0 && !(VAR & 4) && S < 8) {
+      // inline asm: the builtin makes hipcc wait vmcnt(0) before every later ds_read (it must assume the DMA's LDS
+      // write aliases it); the data is ordered by this kernel's own vmcnt(0) + barrier at the next tile boundary.
+      const unsigned lds_addr = __builtin_amdgcn_readfirstlane(
+          (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(lnext + S * kRowStrideF));
+      const uint4* g = gnext + S * 64;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(g), "s"(lds_addr)
+                   : "memory");
+    }
     const uint4 a_hi = ah[S & 3], a_lo = al[S & 3];
     if constexpr (S + 4 < 16) {
       ah[S & 3] = *reinterpret_cast<const uint4*>(tb + 16 * (S + 4));
@@ -422,7 +437,7 @@ __device__ __forceinline__ void tile_mfma_bf16_sel(const char* tb, const uint4 (
       __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
     }
     if constexpr (S + 4 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    tile_mfma_bf16_sel<L, VPM, VAR, S + 1>(tb, qh, ql, cur, prev, vmask, code0, pinf, ls, ah, al);
+    tile_mfma_bf16_sel<L, VPM, VAR, S + 1, S_END>(tb, qh, ql, cur, prev, vmask, code0, pinf, ls, ah, al, gnext, lnext);
   }
 }
 
@@ -433,6 +448,8 @@ __global__ __launch_bounds__(256, WPS) void scan3_kernel(const uint4* __restrict
                                                          int32_t* __restrict__ fb_count, int zero_counts, float pinf) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tiles = smem;
+  long long k0 = 0, k1 = 0, k2 = 0;
+  if constexpr (VAR & 16) k0 = __builtin_readcyclecounter();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
   const int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
@@ -467,11 +484,18 @@ __global__ __launch_bounds__(256, WPS) void scan3_kernel(const uint4* __restrict
                                        (__attribute__((address_space(3))) void*)(dst + row * kRowStrideF), 16, 0, 0);
     }
   };
+  long long tm[5] = {0, 0, 0, 0, 0};  // VAR & 16: cycles in [vmcnt wait, barrier, glds issue, first LDS reads, MFMA+select]
   auto step = [&](int t, int buf, f32x16& cur, const f32x16& prev) {
+    long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+    if constexpr (VAR & 16) c0 = __builtin_readcyclecounter();
     if constexpr (!(VAR & 4)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (VAR & 16) c1 = __builtin_readcyclecounter();
       __syncthreads();  // tile t landed for every wave; every wave is done reading buffer buf^1
-      if (t + 1 < t1) issue(t + 1, buf ^ 1);
+      if constexpr (VAR & 16) c2 = __builtin_readcyclecounter();
+      if constexpr (!(VAR & 64))
+        if (t + 1 < t1) issue(t + 1, buf ^ 1);
+      if constexpr (VAR & 16) c3 = __builtin_readcyclecounter();
     }
     const char* tb = reinterpret_cast<const char*>(tiles + buf * kTileFloats) + col * (kRowStrideF * 4) + half * 256;
     uint4 ah[4], al[4];
@@ -482,10 +506,33 @@ __global__ __launch_bounds__(256, WPS) void scan3_kernel(const uint4* __restrict
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) cur[r] = 0.f;
+    if constexpr (VAR & 16) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      c4 = __builtin_readcyclecounter();
+    }
     constexpr int VPM = (L + 2 + 2) / 3;
-    tile_mfma_bf16_sel<L, VPM, VAR>(tb, qh, ql, cur, prev, vmask, (t - 1 - t0) << 4, pinf, ls, ah, al);
+    {
+      // (past the last tile the interleaved DMA re-loads that tile into the idle buffer, which nobody reads)
+      const uint4* gnext = dbs + ((size_t)min(t + 1, t1 - 1) * kTileRows + wave * 8) * 64 + lane;
+      float* lnext = tiles + (buf ^ 1) * kTileFloats + (wave * 8) * kRowStrideF;
+      tile_mfma_bf16_sel<L, VPM, VAR, 0, 16>(tb, qh, ql, cur, prev, vmask, (t - 1 - t0) << 4, pinf, ls, ah, al, gnext,
+                                             lnext);
+    }
+    if constexpr (VAR & 16) {
+      asm volatile("" ::"v"(cur[0]));
+      const long long c5 = __builtin_readcyclecounter();
+      tm[0] += c1 - c0;
+      tm[1] += c2 - c1;
+      tm[2] += c3 - c2;
+      tm[3] += c4 - c3;
+      tm[4] += c5 - c4;
+    }
   };
 
+  if constexpr (VAR & 16) {
+    asm volatile("" ::"v"(qh[15].x), "v"(ql[15].w));
+    k1 = __builtin_readcyclecounter();
+  }
   if (t0 < t1) issue(t0, 0);
   if constexpr (VAR & 4) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -495,6 +542,7 @@ __global__ __launch_bounds__(256, WPS) void scan3_kernel(const uint4* __restrict
     step(t, 0, accA, accB);
     if (t + 1 < t1) step(t + 1, (VAR & 4) ? 0 : 1, accB, accA);
   }
+  if constexpr (VAR & 16) k2 = __builtin_readcyclecounter();
   if (t0 < t1) {  // the last tile's scores are still in registers; only here can rows be >= n_rows
     const int row0 = (t1 - 1) * kTileRows + 4 * half;
     const int code0 = (t1 - 1 - t0) << 4;
@@ -510,6 +558,20 @@ __global__ __launch_bounds__(256, WPS) void scan3_kernel(const uint4* __restrict
         const int row = row0 + (r & 3) + 8 * (r >> 2);
         ins_key<L>(ls, row < n_rows ? make_key(accB[r], mask, code0 + r) : T2L_NEG_INF);
       }
+    }
+  }
+  if constexpr (VAR & 16) {
+    if (blockIdx.x == 17 && lane == 0) {
+      for (int i = 0; i < 5; ++i) reinterpret_cast<long long*>(fb_count + 4)[wave * 5 + i] = tm[i];
+    }
+    // kernel-level stamps of wave 0 of 4 blocks: [start, after prologue, after loop, end]
+    const int slot = blockIdx.x == 0 ? 0 : blockIdx.x == 17 ? 1 : blockIdx.x == gridDim.x / 2 ? 2 : blockIdx.x == gridDim.x - 1 ? 3 : -1;
+    if (slot >= 0 && tid == 0) {
+      long long* o = reinterpret_cast<long long*>(fb_count + 4) + 20 + slot * 4;
+      o[0] = k0;
+      o[1] = k1;
+      o[2] = k2;
+      o[3] = __builtin_readcyclecounter();
     }
   }
   if (qrow < Q) {
@@ -1052,6 +1114,13 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, int n_
       case 5: launch_scan3<L, 1, 5>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
       case 6: launch_scan3<L, 1, 6>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
       case 7: launch_scan3<L, 1, 7>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 16: launch_scan3<L, 1, 16>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 17: launch_scan3<L, 2, 16>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 64: launch_scan3<L, 1, 64>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 65: launch_scan3<L, 2, 64>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 71: launch_scan3<L, 1, 71>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 67: launch_scan3<L, 1, 67>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
+      case 80: launch_scan3<L, 1, 80>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
       default: launch_scan3<L, 1, 0>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
     }
   } else if (ctx->search_mode == 2) {
