@@ -29,6 +29,7 @@ from text2loc_amd.engine import Engine  # noqa: E402
 from text2loc_amd.sharded import ShardedSearcher, shard_bounds  # noqa: E402
 
 N_CELLS, N_QUERIES, DIM, TOPK = 11259, 4096, 256, 10
+_QS = None
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (AMD's 5 PF figure is 2:1 sparse)
 
@@ -85,6 +86,19 @@ def secondary_measurements(eng):
     out["encode_cells"] = {"cells": N_CELLS, "kernel_ms": ms, "cells_per_s": N_CELLS / (ms * 1e-3),
                            "tflops_algorithmic": flops / (ms * 1e-3) / 1e12, "peak_tflops": F32_MFMA_PEAK_TFLOPS,
                            "frac": flops / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "launches_timed": n}
+    # latency of small query batches against the resident DB (the reference answers one query at a time)
+    lat = {}
+    for qn in (1, 64):
+        dq = torch.from_numpy(np.ascontiguousarray(_QS[:qn])).cuda()
+        for _ in range(10):
+            eng.search(dq, TOPK)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            eng.search(dq, TOPK)
+        torch.cuda.synchronize()
+        lat[f"q{qn}_us_per_call"] = (time.perf_counter() - t0) / 200 * 1e6
+    out["search_latency"] = lat
     rng = np.random.default_rng(0)
     a = torch.from_numpy(rng.standard_normal((64, 256)).astype(np.float32)).cuda()
     p = torch.from_numpy(rng.standard_normal((64, 256)).astype(np.float32)).cuda()
@@ -109,6 +123,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the encoder / loss side measurements")
     ap.add_argument("--cells", type=int, default=N_CELLS, help="dev: database rows (default = the BASELINE workload)")
     ap.add_argument("--queries", type=int, default=N_QUERIES, help="dev: queries per step")
+    ap.add_argument("--list-len", type=int, default=16, help="dev: per-lane candidate list length (12 or 16)")
     ap.add_argument("--mode", type=int, default=0, help="search_mode: 0 = split-bf16 specialised scan, 1 = f32 scan")
     ap.add_argument("--variant", type=int, default=0, help="dev: timing-only ablation of the scan kernel")
     ap.add_argument("--nsplit", type=int, default=0, help="override the scan kernel's DB split count (0 = auto)")
@@ -139,6 +154,7 @@ def main():
     lo, hi = searcher.set_db_shard(d_db)
     eng.set_option("profile_events", 1)
     eng.set_option("search_mode", args.mode)
+    eng.set_option("list_len", args.list_len)
     if args.variant:
         eng.set_option("scan_variant", args.variant)
     if args.nsplit:
@@ -171,7 +187,7 @@ def main():
 
     # parity spot check outside the timed region: ids of a query sample vs the float64 oracle
     from oracle import t2l_oracle as O
-    sel = np.arange(0, N_QUERIES, 32)
+    sel = np.arange(0, N_QUERIES, 32 if N_CELLS <= 100000 else max(1, N_QUERIES // 16))
     ridx, _ = O.retrieve_topk(db, qs[sel], TOPK)
     got = idx.cpu().numpy().astype(np.int64)
     parity = bool(np.array_equal(got[sel], ridx))
@@ -179,6 +195,8 @@ def main():
 
     secondary = {}
     if rank == 0 and world == 1 and not args.no_secondary:
+        global _QS
+        _QS = qs
         secondary = secondary_measurements(eng)
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
@@ -188,7 +206,8 @@ def main():
         if args.mode == 1:
             kname, peak, dtype, mult = "scan_kernel<16, 0>", F32_MFMA_PEAK_TFLOPS, "f32", 1
         else:
-            kname = {0: "scan3_kernel<16, 2, 0>", 2: "scan2_kernel<16, 0>", 3: "scan3_kernel<16, 1, 0>"}[args.mode]
+            kname = {0: "scan3_kernel<16, 2, 0, 4>", 2: "scan2_kernel<16, 0>", 3: "scan3_kernel<16, 1, 0, 4>",
+                     4: "scan3_kernel<16, 2, 0, 8>"}[args.mode]
             peak, dtype, mult = BF16_MFMA_PEAK_TFLOPS, "bf16x3", 3
         out = {
             "metric": "coarse-retrieval queries/sec over 11k-cell DB, embed_dim=256; top-1/3/5 recall parity",

@@ -189,8 +189,11 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     if (value < 0 || value > kMaxParts / 2) return fail(ctx, T2L_EINVAL, "search_nsplit out of range [0,32]");
     ctx->nsplit_override = (int)value;
   } else if (!strcmp(name, "search_mode")) {
-    if (value < 0 || value > 3) return fail(ctx, T2L_EINVAL, "search_mode must be 0..3");
+    if (value < 0 || value > 4) return fail(ctx, T2L_EINVAL, "search_mode must be 0..4");
     ctx->search_mode = (int)value;
+  } else if (!strcmp(name, "list_len")) {
+    if (value != 12 && value != 16) return fail(ctx, T2L_EINVAL, "list_len must be 12 or 16");
+    ctx->list_len = (int)value;
   } else if (!strcmp(name, "scan_variant")) {
     ctx->scan_variant = (int)value;
   } else if (!strcmp(name, "profile_events")) {

@@ -90,7 +90,7 @@ __device__ __forceinline__ void tile_mfma(const float* tb, const float (&qa)[128
 // LDS: 2 x [32 rows x 260 f32] DB tiles (glds double buffer), shared by the 4 waves (4 x 32 queries).
 // ------------------------------------------------------------------------------------------------
 template <int L, int VAR>
-__global__ __launch_bounds__(256, L == 16 ? 2 : 1) void scan_kernel(const float* __restrict__ db, int n_rows, int n_tiles, int per,
+__global__ __launch_bounds__(256, L <= 16 ? 2 : 1) void scan_kernel(const float* __restrict__ db, int n_rows, int n_tiles, int per,
                                                       int code_bits, const float* __restrict__ q, int Q, int nsplit,
                                                       float* __restrict__ cand, int32_t* __restrict__ fb_count, int zero_counts) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -388,7 +388,7 @@ __device__ __forceinline__ void ins_key_sat(float (&s)[L], float x, float pinf) 
 // 48 MFMAs of a tile on ONE accumulator chain, 3 per k-step, with one score of the previous tile inserted per
 // k-step (measured: for the bf16 MFMA a single chain with ~6 interleaved VALU per MFMA beats two alternating
 // chains, which cost 32 more VGPRs and a spill at two waves per SIMD).
-template <int L, int VPM, int VAR, int S, int S_END>
+template <int L, int VPM, int VAR, int NW, int S, int S_END>
 __device__ __forceinline__ void tile_mfma_bf16_sel(const char* tb, const uint4 (&qh)[16], const uint4 (&ql)[16],
                                                    f32x16& cur, const f32x16& prev, int vmask, int code0, float pinf,
                                                    float (&ls)[L], uint4 (&ah)[4], uint4 (&al)[4],
@@ -397,7 +397,7 @@ __device__ __forceinline__ void tile_mfma_bf16_sel(const char* tb, const uint4 (
     if constexpr (S == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // prologue LDS reads first
     // VAR & 64: the 8 LDS-DMA rows of the NEXT tile are issued one per k-step inside the MFMA phase (each costs ~70
     // issue cycles; in a burst after the barrier they also delay the first LDS reads by ~800 cycles)
-    if constexpr ((VAR & 64) != 0 && !(VAR & 4) && S < 8) {
+    if constexpr ((VAR & 64) != 0 && !(VAR & 4) && S < 32 / NW) {
       // inline asm: the builtin makes hipcc wait vmcnt(0) before every later ds_read (it must assume the DMA's LDS
       // write aliases it); the data is ordered by this kernel's own vmcnt(0) + barrier at the next tile boundary.
       const unsigned lds_addr = __builtin_amdgcn_readfirstlane(
@@ -437,12 +437,12 @@ __device__ __forceinline__ void tile_mfma_bf16_sel(const char* tb, const uint4 (
       __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
     }
     if constexpr (S + 4 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    tile_mfma_bf16_sel<L, VPM, VAR, S + 1, S_END>(tb, qh, ql, cur, prev, vmask, code0, pinf, ls, ah, al, gnext, lnext);
+    tile_mfma_bf16_sel<L, VPM, VAR, NW, S + 1, S_END>(tb, qh, ql, cur, prev, vmask, code0, pinf, ls, ah, al, gnext, lnext);
   }
 }
 
-template <int L, int WPS, int VAR>
-__global__ __launch_bounds__(256, WPS) void scan3_kernel(const uint4* __restrict__ dbs, int n_rows, int n_tiles,
+template <int L, int WPS, int VAR, int NW>
+__global__ __launch_bounds__(NW * 64, WPS) void scan3_kernel(const uint4* __restrict__ dbs, int n_rows, int n_tiles,
                                                          int per, int code_bits, const float* __restrict__ q, int Q,
                                                          int nsplit, float* __restrict__ cand,
                                                          int32_t* __restrict__ fb_count, int zero_counts, float pinf) {
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256, WPS) void scan3_kernel(const uint4* __restrict
   const int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
   const int t0 = sp * per;
   const int t1 = min(n_tiles, t0 + per);
-  const int qrow = qb * kQPerBlock + wave * kQPerWave + col;
+  const int qrow = qb * (NW * kQPerWave) + wave * kQPerWave + col;
   const int mask = ~((1 << code_bits) - 1);
   int vmask = mask;
   asm volatile("" : "+v"(vmask));  // keep the mask in a VGPR so key = v_and_or_b32(score, vmask, s_code) is one op
@@ -478,8 +478,8 @@ __global__ __launch_bounds__(256, WPS) void scan3_kernel(const uint4* __restrict
     const uint4* src = dbs + (size_t)t * kTileRows * 64 + lane;
     float* dst = tiles + buf * kTileFloats;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = wave * 8 + i;  // one wave-instruction moves one 1 KiB row (hi | lo planes) into LDS
+    for (int i = 0; i < 32 / NW; ++i) {
+      const int row = wave * (32 / NW) + i;  // one wave-instruction moves one 1 KiB row (hi | lo planes) into LDS
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + row * 64),
                                        (__attribute__((address_space(3))) void*)(dst + row * kRowStrideF), 16, 0, 0);
     }
@@ -513,10 +513,10 @@ __global__ __launch_bounds__(256, WPS) void scan3_kernel(const uint4* __restrict
     constexpr int VPM = (L + 2 + 2) / 3;
     {
       // (past the last tile the interleaved DMA re-loads that tile into the idle buffer, which nobody reads)
-      const uint4* gnext = dbs + ((size_t)min(t + 1, t1 - 1) * kTileRows + wave * 8) * 64 + lane;
-      float* lnext = tiles + (buf ^ 1) * kTileFloats + (wave * 8) * kRowStrideF;
-      tile_mfma_bf16_sel<L, VPM, VAR, 0, 16>(tb, qh, ql, cur, prev, vmask, (t - 1 - t0) << 4, pinf, ls, ah, al, gnext,
-                                             lnext);
+      const uint4* gnext = dbs + ((size_t)min(t + 1, t1 - 1) * kTileRows + wave * (32 / NW)) * 64 + lane;
+      float* lnext = tiles + (buf ^ 1) * kTileFloats + (wave * (32 / NW)) * kRowStrideF;
+      tile_mfma_bf16_sel<L, VPM, VAR, NW, 0, 16>(tb, qh, ql, cur, prev, vmask, (t - 1 - t0) << 4, pinf, ls, ah, al,
+                                                 gnext, lnext);
     }
     if constexpr (VAR & 16) {
       asm volatile("" ::"v"(cur[0]));
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256, WPS) void scan3_kernel(const uint4* __restrict
     }
   }
   if constexpr (VAR & 16) {
-    if (blockIdx.x == 17 && lane == 0) {
+    if (blockIdx.x == 17 && lane == 0 && wave < 4) {
       for (int i = 0; i < 5; ++i) reinterpret_cast<long long*>(fb_count + 4)[wave * 5 + i] = tm[i];
     }
     // kernel-level stamps of wave 0 of 4 blocks: [start, after prologue, after loop, end]
@@ -1065,17 +1065,17 @@ static void launch_scan(t2l_ctx* ctx, dim3 grid, size_t lds, hipStream_t s, cons
 
 static size_t scan_lds_bytes() { return (size_t)2 * kTileFloats * sizeof(float); }
 
-template <int L, int WPS, int VAR>
+template <int L, int WPS, int VAR, int NW = 4>
 static void launch_scan3(t2l_ctx* ctx, dim3 grid, hipStream_t s, const uint4* dbs, int n_rows, int n_tiles, int per,
                          int code_bits, const float* q, int Q, int nsplit, int zero) {
   const size_t lds = scan_lds_bytes();
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan3_kernel<L, WPS, VAR>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan3_kernel<L, WPS, VAR, NW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((scan3_kernel<L, WPS, VAR>), grid, dim3(256), lds, s, dbs, n_rows, n_tiles, per, code_bits, q, Q,
+  hipLaunchKernelGGL((scan3_kernel<L, WPS, VAR, NW>), grid, dim3(NW * 64), lds, s, dbs, n_rows, n_tiles, per, code_bits, q, Q,
                      nsplit, ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
 }
 
@@ -1098,12 +1098,15 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, int n_
                          int Q, int K, int nsplit, int per, int code_bits, int32_t* out_idx, double* out_score,
                          bool first, hipStream_t s) {
   const int n_tiles = (n_rows + kTileRows - 1) / kTileRows;
-  const int n_qblocks = (Q + kQPerBlock - 1) / kQPerBlock;
+  const int qpb = ctx->search_mode == 4 ? 2 * kQPerBlock : kQPerBlock;  // queries per workgroup
+  const int n_qblocks = (Q + qpb - 1) / qpb;
   const int parts = 2 * nsplit;
   const size_t lds = scan_lds_bytes();
   event_begin(ctx, "search_scan", s);
   const dim3 grid(n_qblocks * nsplit);
-  if (ctx->search_mode == 0) {
+  if (ctx->search_mode == 4) {  // 8 waves x 32 queries share each LDS tile: half the LDS-DMA bytes per MFMA
+    launch_scan3<L, 2, 0, 8>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first);
+  } else if (ctx->search_mode == 0) {
     launch_scan3<L, 2, 0>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first);
   } else if (ctx->search_mode == 3) {
     switch (ctx->scan_variant) {
@@ -1176,8 +1179,11 @@ static int grow(t2l_ctx* ctx, void** p, size_t* cap, size_t need_bytes) {
 int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s) {
   if (Q == 0) return T2L_OK;
   const int n_rows = (int)ctx->db_rows;
-  const int n_qblocks = (Q + kQPerBlock - 1) / kQPerBlock;
-  const int L = (K <= 10) ? 16 : 32;
+  const int qpb = ctx->search_mode == 4 ? 2 * kQPerBlock : kQPerBlock;
+  const int n_qblocks = (Q + qpb - 1) / qpb;
+  // per-lane list length: K + margin (the margin only has to absorb key-truncation ties; the certificate
+  // catches the rest). list_len option (dev): 12 trades a thinner margin for 22 % less selection work.
+  const int L = (K <= 10) ? ((ctx->list_len == 12 && K <= 10) ? 12 : 16) : 32;
   const int n_seg = max(1, (n_rows + kSegmentRows - 1) / kSegmentRows);
   if (n_seg * K > 256)
     return fail(ctx, T2L_EINVAL, "t2l_search: shard too large (more than 256/k segments of 524,288 rows); shard the "
@@ -1199,7 +1205,7 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     if (nsplit <= 0) {
       // f32 scan: 2 workgroups (4 waves) per CU; bf16x3 scan: 1 workgroup (8 waves) per CU. 256 CUs.
       // Multiples of 8 keep a split on one XCD's L2.
-      nsplit = ((ctx->search_mode >= 2 ? 256 : 512) + n_qblocks - 1) / n_qblocks;
+      nsplit = ((ctx->search_mode >= 2 ? 256 : 512) + n_qblocks - 1) / n_qblocks;  // modes 2-4: 1 WG per CU
       nsplit = ((nsplit + 7) / 8) * 8;
     }
     nsplit = max(1, min(nsplit, kMaxParts / 2));
@@ -1208,7 +1214,7 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     const int per = max(1, (n_tiles + nsplit - 1) / nsplit);
     int code_bits = 4;
     while ((1 << code_bits) < per * 16) ++code_bits;
-    const size_t need = (size_t)n_qblocks * kQPerBlock * 2 * nsplit * L * sizeof(float);
+    const size_t need = (size_t)n_qblocks * qpb * 2 * nsplit * L * sizeof(float);
     if ((rc = grow(ctx, (void**)&ctx->cand_score, &ctx->cand_cap, need)) != T2L_OK) return rc;
     if (n_seg > 1) {
       seg_idx = ctx->seg_idx + (size_t)seg * Q * K;
@@ -1217,7 +1223,9 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     const float* db = ctx->db + (size_t)row0 * kD;
     const uint4* dbs = ctx->db_split ? ctx->db_split + (size_t)row0 * 64 : nullptr;
     const int off = (int)ctx->row_offset + row0;
-    rc = (L == 16) ? launch_search<16>(ctx, db, dbs, max(rows, 0), off, q, Q, K, nsplit, per, code_bits, seg_idx,
+    rc = (L == 12) ? launch_search<12>(ctx, db, dbs, max(rows, 0), off, q, Q, K, nsplit, per, code_bits, seg_idx,
+                                        seg_score, seg == 0, s)
+       : (L == 16) ? launch_search<16>(ctx, db, dbs, max(rows, 0), off, q, Q, K, nsplit, per, code_bits, seg_idx,
                                         seg_score, seg == 0, s)
                    : launch_search<32>(ctx, db, dbs, max(rows, 0), off, q, Q, K, nsplit, per, code_bits, seg_idx,
                                         seg_score, seg == 0, s);

@@ -59,6 +59,7 @@ struct t2l_ctx {
   double eps_scale = 1.0;
   int nsplit_override = 0;
   int search_mode = 0;   // 0 = wave-specialised split-bf16 scan (default), 1 = exact-f32 MFMA scan
+  int list_len = 16;     // dev knob: per-lane top list length for K <= 10 (12 or 16)
   int scan_variant = 0;  // dev knob: timing-only ablations of the scan kernel
   bool profile_events = false;
   std::unordered_map<std::string, t2l::EventRing> events;

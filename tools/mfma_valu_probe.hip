@@ -28,13 +28,18 @@ __global__ __launch_bounds__(512, 2) void probe(float* out, long long* cyc, int 
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, l[0], (m & 1) ? acc1 : acc0, 0, 0, 0);
           if (m & 1) { acc1 = acc0; }
         } else {
-          if (m & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc1, 0, 0, 0);
+          if ((m & 1) && MODE != 4) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc1, 0, 0, 0);
           else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc0, 0, 0, 0);
         }
       }
       if (do_valu) {
+        if (MODE == 4 || MODE == 5) {  // the kernel's pattern: s'[i] = med3(s[i-1], s[i], x), i descending: independent ops
 #pragma unroll
-        for (int k = 0; k < K; ++k) l[(k + 1) & 15] = __builtin_amdgcn_fmed3f(l[k & 15], l[(k + 1) & 15], x);
+          for (int k = 0; k < K; ++k) l[15 - (k % 15)] = __builtin_amdgcn_fmed3f(l[14 - (k % 15)], l[15 - (k % 15)], x);
+        } else {
+#pragma unroll
+          for (int k = 0; k < K; ++k) l[(k + 1) & 15] = __builtin_amdgcn_fmed3f(l[k & 15], l[(k + 1) & 15], x);
+        }
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, K, 0);
@@ -69,6 +74,8 @@ int main() {
   run<6, 0>("same-wave bf16", 256); run<8, 0>("same-wave bf16", 256); run<12, 0>("same-wave bf16", 256);
   run<0, 1>("two-wave  bf16", 512); run<2, 1>("two-wave  bf16", 512); run<4, 1>("two-wave  bf16", 512);
   run<6, 1>("two-wave  bf16", 512); run<8, 1>("two-wave  bf16", 512); run<12, 1>("two-wave  bf16", 512);
+  run<0, 4>("1chain list   ", 256); run<4, 4>("1chain list   ", 256); run<6, 4>("1chain list   ", 256); run<8, 4>("1chain list   ", 256);
+  run<0, 5>("2chain list   ", 256); run<4, 5>("2chain list   ", 256); run<6, 5>("2chain list   ", 256); run<8, 5>("2chain list   ", 256);
   run<0, 3>("even/odd  bf16", 512); run<4, 3>("even/odd  bf16", 512); run<8, 3>("even/odd  bf16", 512); run<12, 3>("even/odd  bf16", 512);
   run<0, 2>("same-wave f32 ", 256); run<4, 2>("same-wave f32 ", 256); run<8, 2>("same-wave f32 ", 256); run<12, 2>("same-wave f32 ", 256);
   return 0;
