@@ -143,6 +143,8 @@ int t2l_contrastive_loss(t2l_ctx* ctx, const float* anchor, const float* positiv
  * "search_mode"       (default 0): 0 = split-bf16 (bf16x3) MFMA scan, 1 = exact-f32 MFMA scan; 2 / 3 = experimental
  *     variants of 0 (wave-specialised; one wave per SIMD). All feed the same float64 re-rank + certificate, so the
  *     RESULTS are identical; only the speed differs.
+ * "stream_min_rows"   (default 65536): batches of <= 64 queries against a shard of at least this many rows use the
+ *     HBM-streaming scan (every CU streams a disjoint DB slice once) instead of the batched scan.
  * "search_nsplit"     (default 0 = auto): DB row splits per query block in the scan kernel.
  * "profile_events"    (default 0): record hipEvents around each kernel launch (t2l_kernel_stats). */
 int t2l_set_option(t2l_ctx* ctx, const char* name, double value);

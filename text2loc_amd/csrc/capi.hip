@@ -191,6 +191,8 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
   } else if (!strcmp(name, "search_mode")) {
     if (value < 0 || value > 4) return fail(ctx, T2L_EINVAL, "search_mode must be 0..4");
     ctx->search_mode = (int)value;
+  } else if (!strcmp(name, "stream_min_rows")) {
+    ctx->stream_min_rows = (int)value;
   } else if (!strcmp(name, "list_len")) {
     if (value != 12 && value != 16) return fail(ctx, T2L_EINVAL, "list_len must be 12 or 16");
     ctx->list_len = (int)value;

@@ -1,0 +1,349 @@
+// Small query batches against a LARGE shard: the HBM-streaming form of the search (SURVEY.md §8d config 2').
+//
+// With few queries (<= 64) the arithmetic is far below the matrix pipe's capacity and the job is to pull the DB
+// through the chip once at HBM speed. The batched scan (search.hip) gives every 128-query block its own pass over
+// the DB and would leave most CUs idle here. This variant turns the decomposition around:
+//
+//   scanq_kernel       ALL waves of the chip hold the SAME (<= 32) queries as register-resident split-bf16 fragments
+//                      and each wave streams its OWN 32-row tiles HBM -> LDS (global_load_lds into a private 33 KiB
+//                      buffer, no workgroup barrier anywhere), multiplies them (3 x bf16 MFMA per product, as scan3)
+//                      and keeps per-lane sorted key lists. At the end a workgroup merges its 8 lists per query into
+//                      one (key, row) list: the candidate set is [32 queries][G workgroups][L].
+//   rerank_rows_kernel one workgroup per query: top-L of the G lists by key, float64 re-score, (score desc, row asc)
+//                      order, the same certificate as the batched path.
+//   exact_only_kernel  float64 scan of the shard for queries whose certificate failed.
+//
+// Algorithmic bytes per launch: the split-bf16 DB once = 1 KiB per row (+ G*32*L*8 B of candidates).
+#include "search_dev.h"
+
+namespace t2l {
+
+constexpr int kStreamQ = 32;  // queries per scanq launch
+
+template <int L>
+__global__ __launch_bounds__(256, 1) void scanq_kernel(const uint4* __restrict__ dbs, int n_rows, int n_tiles, int per,
+                                                       int code_bits, const float* __restrict__ q, int q0, int Q,
+                                                       float* __restrict__ cand_key, int* __restrict__ cand_row,
+                                                       float pinf) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int G = gridDim.x, wg = blockIdx.x;
+  float* tile = smem + wave * kTileFloats;  // this wave's private tile buffer
+  const int mask = ~((1 << code_bits) - 1);
+  int vmask = mask;
+  asm volatile("" : "+v"(vmask));
+
+  // every wave of the chip: the same 32 queries q0 .. q0+31 (clamped)
+  uint4 qh[16], ql[16];
+  {
+    const int qrow = min(q0 + col, Q - 1);
+    const float4* qp = reinterpret_cast<const float4*>(q + (size_t)qrow * kD + half * 128);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) split8(qp[2 * s], qp[2 * s + 1], qh[s], ql[s]);
+  }
+  float ls[L];
+#pragma unroll
+  for (int i = 0; i < L; ++i) ls[i] = T2L_NEG_INF;
+  f32x16 accA, accB;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accA[r] = accB[r] = T2L_NEG_INF;
+
+  // wave (wg, wave) owns tiles  (wg*per + j)*4 + wave,  j = 0 .. per-1  (interleaved so neighbours stream neighbours)
+  const int tbase = wg * per * 4 + wave;
+  auto tile_of = [&](int j) { return tbase + 4 * j; };
+  auto fetch = [&](int t) {
+    const uint4* src = dbs + (size_t)t * kTileRows * 64 + lane;
+#pragma unroll 8
+    for (int row = 0; row < kTileRows; ++row)  // one wave-instruction = one 1 KiB row (hi | lo planes)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + row * 64),
+                                       (__attribute__((address_space(3))) void*)(tile + row * kRowStrideF), 16, 0, 0);
+  };
+  const char* tb = reinterpret_cast<const char*>(tile) + col * (kRowStrideF * 4) + half * 256;
+  auto step = [&](int j, f32x16& cur, const f32x16& prev) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own tile has landed (no other wave touches it)
+    uint4 ah[4], al[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *reinterpret_cast<const uint4*>(tb + 16 * i);
+      al[i] = *reinterpret_cast<const uint4*>(tb + 512 + 16 * i);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cur[r] = 0.f;
+    constexpr int VPM = (L + 2 + 2) / 3;
+    tile_mfma_bf16_sel<L, VPM, 0, 4, 0, 16>(tb, qh, ql, cur, prev, vmask, (j - 1) << 4, pinf, ls, ah, al, nullptr,
+                                            nullptr);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all LDS reads of this tile are done: the buffer may refill
+  };
+  int nj = 0;
+  while (nj < per && tile_of(nj) < n_tiles) ++nj;  // tiles this wave really has
+  if (nj > 0) fetch(tile_of(0));
+  for (int j = 0; j < nj; j += 2) {
+    step(j, accA, accB);
+    if (j + 1 < nj) fetch(tile_of(j + 1));
+    if (j + 1 < nj) {
+      step(j + 1, accB, accA);
+      if (j + 2 < nj) fetch(tile_of(j + 2));
+    }
+  }
+  if (nj > 0) {  // the last tile's scores are still in registers; only the last tile of the shard can be partial
+    const int row0 = tile_of(nj - 1) * kTileRows + 4 * half;
+    const int code0 = (nj - 1) << 4;
+    if (nj & 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        ins_key<L>(ls, row < n_rows ? make_key(accA[r], mask, code0 + r) : T2L_NEG_INF);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        ins_key<L>(ls, row < n_rows ? make_key(accB[r], mask, code0 + r) : T2L_NEG_INF);
+      }
+    }
+  }
+
+  // ---- workgroup merge: 8 sorted lists per query (4 waves x 2 halves) -> one (key, row) list of L
+  __syncthreads();  // every wave is done with its tile buffer: reuse LDS
+  float* lists = smem;  // [32 queries][8 lists][L]
+#pragma unroll
+  for (int i = 0; i < L; ++i) lists[(col * 8 + wave * 2 + half) * L + i] = ls[i];
+  __syncthreads();
+  {
+    const int qi = tid >> 3, j = tid & 7;  // 8 consecutive lanes own the 8 lists of one query
+    const float* mine = lists + (qi * 8 + j) * L;
+    const int jw = j >> 1, jh = j & 1;     // list j came from wave jw, half jh
+    int ptr = 0;
+    float head = mine[0];
+    for (int r = 0; r < L; ++r) {
+      float bk = head;
+      int bj = j;
+#pragma unroll
+      for (int off = 4; off >= 1; off >>= 1) {
+        const float ok = __shfl_xor(bk, off);
+        const int oj = __shfl_xor(bj, off);
+        if (ok > bk || (ok == bk && oj < bj)) {
+          bk = ok;
+          bj = oj;
+        }
+      }
+      if (j == bj) {  // the winner emits and advances
+        int row = -1;
+        if (bk != T2L_NEG_INF) {
+          const int code = __float_as_int(bk) & ~mask;
+          const int rr = code & 15;
+          row = ((wg * per + (code >> 4)) * 4 + jw) * kTileRows + (rr & 3) + 8 * (rr >> 2) + 4 * jh;
+        }
+        const size_t o = ((size_t)qi * G + wg) * L + r;
+        cand_key[o] = bk;
+        cand_row[o] = row;
+        ++ptr;
+        head = ptr < L ? mine[ptr] : T2L_NEG_INF;
+      }
+    }
+  }
+}
+
+// One workgroup per query: G sorted (key,row) lists -> top-L by key -> float64 re-score -> order + certificate.
+template <int L>
+__global__ __launch_bounds__(256) void rerank_rows_kernel(const float* __restrict__ db, const float* __restrict__ q,
+                                                          int q0, int Q, int K, int G, int code_bits,
+                                                          const float* __restrict__ cand_key,
+                                                          const int* __restrict__ cand_row, int row_offset,
+                                                          float eps_rel, const float* __restrict__ db_norm_max,
+                                                          int32_t* __restrict__ out_idx, double* __restrict__ out_score,
+                                                          int32_t* __restrict__ flags, float pinf) {
+  const int qi = blockIdx.x, qid = q0 + qi;
+  if (qid >= Q) return;
+  __shared__ float sel_key[32];
+  __shared__ int sel_row[32];
+  __shared__ double sel_d[32];
+  __shared__ float red_k[4];
+  __shared__ int red_t[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // thread t walks the lists of workgroups t, t+256, ... merged on the fly: it keeps ONE current head
+  // (the best not-yet-taken key among its lists) by re-scanning its lists' heads (G/256 <= 4 lists per thread)
+  constexpr int MAXL = 4;
+  int ptr[MAXL];
+#pragma unroll
+  for (int i = 0; i < MAXL; ++i) ptr[i] = 0;
+  const float* keys = cand_key + (size_t)qi * G * L;
+  const int* rows = cand_row + (size_t)qi * G * L;
+  auto my_head = [&](int& which) {
+    float best = T2L_NEG_INF;
+    which = -1;
+#pragma unroll
+    for (int i = 0; i < MAXL; ++i) {
+      const int g = tid + 256 * i;
+      if (g < G && ptr[i] < L) {
+        const float k = keys[(size_t)g * L + ptr[i]];
+        if (k > best) {
+          best = k;
+          which = i;
+        }
+      }
+    }
+    return best;
+  };
+  int which;
+  float head = my_head(which);
+  for (int r = 0; r < L; ++r) {
+    const float wk = wave_max_f32(head, pinf);
+    const unsigned long long who = __ballot(head == wk);
+    if (lane == 0) {
+      red_k[wave] = wk;
+      red_t[wave] = wave * 64 + (__ffsll((long long)who) - 1);
+    }
+    __syncthreads();
+    float bk = red_k[0];
+    int bt = red_t[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (red_k[w] > bk) {
+        bk = red_k[w];
+        bt = red_t[w];
+      }
+    if (tid == bt) {
+      int row = INT_MAX;
+      if (bk != T2L_NEG_INF) {
+        const int g = tid + 256 * which;
+        row = rows[(size_t)g * L + ptr[which]];
+#pragma unroll
+        for (int i = 0; i < MAXL; ++i)
+          if (i == which) ++ptr[i];
+        head = my_head(which);
+      }
+      sel_key[r] = bk;
+      sel_row[r] = row < 0 ? INT_MAX : row;
+    }
+    __syncthreads();
+  }
+
+  // float64 re-score: wave w takes selected rows w, w+4, ...
+  const float4 qv = reinterpret_cast<const float4*>(q + (size_t)qid * kD)[lane];
+  const double qn = wave_sum_f64((double)qv.x * qv.x + (double)qv.y * qv.y + (double)qv.z * qv.z + (double)qv.w * qv.w);
+  for (int c = wave; c < L; c += 4) {
+    const int row = sel_row[c];
+    double d = -__builtin_inf();
+    if (row != INT_MAX) {
+      const float4 dv = reinterpret_cast<const float4*>(db + (size_t)row * kD)[lane];
+      d = wave_sum_f64((double)dv.x * qv.x + (double)dv.y * qv.y + (double)dv.z * qv.z + (double)dv.w * qv.w);
+    }
+    if (lane == 0) sel_d[c] = d;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const double my_d = lane < L ? sel_d[lane] : -__builtin_inf();
+    const int my_row = lane < L ? sel_row[lane] : INT_MAX;
+    int rank = 0;
+    for (int j = 0; j < L; ++j) {
+      const double dj = sel_d[j];
+      const int ij = sel_row[j];
+      rank += (dj > my_d || (dj == my_d && ij < my_row)) ? 1 : 0;
+    }
+    const bool valid = lane < L && my_row != INT_MAX;
+    if (lane < K) {
+      out_idx[(size_t)qid * K + lane] = -1;
+      if (out_score) out_score[(size_t)qid * K + lane] = -__builtin_inf();
+    }
+    if (valid && rank < K) {
+      out_idx[(size_t)qid * K + rank] = my_row + row_offset;
+      if (out_score) out_score[(size_t)qid * K + rank] = my_d;
+    }
+    const float g = sel_key[L - 1];
+    bool certified = true;
+    if (g != T2L_NEG_INF) {
+      certified = false;
+      const unsigned long long kth = __ballot(valid && rank == K - 1);
+      if (K <= L && kth != 0ull) {
+        const double dK = sel_d[__ffsll((long long)kth) - 1];
+        const double eps32 = (double)eps_rel * sqrt(qn) * (double)(*db_norm_max);
+        certified = dK > (double)g + key_slack(g, code_bits, eps32);
+      }
+    }
+    if (lane == 0) flags[qid] = certified ? 0 : 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void exact_only_kernel(const float* __restrict__ db, int n_rows,
+                                                         const float* __restrict__ q, int q0, int nq, int K,
+                                                         const int32_t* __restrict__ flags, int row_offset,
+                                                         int32_t* __restrict__ out_idx, double* __restrict__ out_score,
+                                                         int32_t* __restrict__ fb_count) {
+  __shared__ double qs[kD];
+  __shared__ double red_s[256];
+  __shared__ int red_i[256];
+  __shared__ int red_t[256];
+  for (int qid = q0 + blockIdx.x; qid < q0 + nq; qid += gridDim.x) {
+    if (!flags[qid]) continue;
+    __syncthreads();
+    qs[threadIdx.x] = (double)q[(size_t)qid * kD + threadIdx.x];
+    if (threadIdx.x == 0) atomicAdd(&fb_count[0], 1);
+    __syncthreads();
+    exact_scan<32>(db, n_rows, qs, K, row_offset, out_idx + (size_t)qid * K,
+                   out_score ? out_score + (size_t)qid * K : nullptr, red_s, red_i, red_t);
+  }
+}
+
+static int grow_buf(t2l_ctx* ctx, void** p, size_t* cap, size_t need_bytes) {
+  if (need_bytes <= *cap) return T2L_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  T2L_HIP(ctx, hipMalloc(p, need_bytes));
+  *cap = need_bytes;
+  return T2L_OK;
+}
+
+template <int L>
+static int stream_launch(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s) {
+  const int n_rows = (int)ctx->db_rows;
+  const int n_tiles = (int)(ctx->db_pad / kTileRows);
+  int G = 256;  // one workgroup (4 waves, 4 private tile buffers = 133 KB of LDS) per CU
+  while (G > 1 && (n_tiles + G * 4 - 1) / (G * 4) < 2) G >>= 1;
+  const int per = (n_tiles + G * 4 - 1) / (G * 4);
+  int code_bits = 4;
+  while ((1 << code_bits) < per * 16) ++code_bits;
+  if (code_bits > 13) return fail(ctx, T2L_EINVAL, "t2l_search: shard too large for one streaming launch (16.7M rows)");
+  int rc;
+  if ((rc = grow_buf(ctx, (void**)&ctx->cand_score, &ctx->cand_cap, (size_t)kStreamQ * G * L * sizeof(float))) != T2L_OK ||
+      (rc = grow_buf(ctx, (void**)&ctx->seg_idx, &ctx->seg_idx_cap, (size_t)kStreamQ * G * L * sizeof(int32_t))) != T2L_OK ||
+      (rc = grow_buf(ctx, (void**)&ctx->flags, &ctx->flag_cap, (size_t)Q * sizeof(int32_t))) != T2L_OK)
+    return rc;
+  const size_t lds = (size_t)4 * kTileFloats * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&scanq_kernel<L>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  const float eps_rel = (float)(ctx->eps_scale * ((kD + 8) * 5.9604644775390625e-08 + 2.0e-5));
+  T2L_HIP(ctx, hipMemsetAsync(ctx->fb_count, 0, 2 * sizeof(int32_t), s));
+  for (int q0 = 0; q0 < Q; q0 += kStreamQ) {
+    const int nq = min(kStreamQ, Q - q0);
+    event_begin(ctx, "search_scan", s);
+    hipLaunchKernelGGL(scanq_kernel<L>, dim3(G), dim3(256), lds, s, ctx->db_split, n_rows, n_tiles, per, code_bits, q, q0,
+                       Q, ctx->cand_score, ctx->seg_idx, __builtin_inff());
+    event_end(ctx, "search_scan", s);
+    T2L_HIP(ctx, hipGetLastError());
+    event_begin(ctx, "search_rerank", s);
+    hipLaunchKernelGGL(rerank_rows_kernel<L>, dim3(nq), dim3(256), 0, s, ctx->db, q, q0, Q, K, G, code_bits,
+                       ctx->cand_score, ctx->seg_idx, (int)ctx->row_offset, eps_rel, ctx->db_norm_max, out_idx, out_score,
+                       ctx->flags, __builtin_inff());
+    T2L_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(exact_only_kernel, dim3(min(nq, 32)), dim3(256), 0, s, ctx->db, n_rows, q, q0, nq, K, ctx->flags,
+                       (int)ctx->row_offset, out_idx, out_score, ctx->fb_count);
+    event_end(ctx, "search_rerank", s);
+    T2L_HIP(ctx, hipGetLastError());
+  }
+  return T2L_OK;
+}
+
+int search_stream_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s) {
+  if (K <= 10) return stream_launch<16>(ctx, q, Q, K, out_idx, out_score, s);
+  return stream_launch<32>(ctx, q, Q, K, out_idx, out_score, s);
+}
+
+}  // namespace t2l

@@ -34,7 +34,8 @@ struct EventRing {
   int count = 0;  // recorded since the last read (saturates at kEventRing)
 };
 
-struct EncoderWeights;  // encode.hip
+struct EncoderWeights;  int search_stream_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s);
+// encode.hip
 
 }  // namespace t2l
 
@@ -59,6 +60,7 @@ struct t2l_ctx {
   double eps_scale = 1.0;
   int nsplit_override = 0;
   int search_mode = 0;   // 0 = wave-specialised split-bf16 scan (default), 1 = exact-f32 MFMA scan
+  int stream_min_rows = 65536;  // shards at least this large answer batches of <= 64 queries with the streaming scan
   int list_len = 16;     // dev knob: per-lane top list length for K <= 10 (12 or 16)
   int scan_variant = 0;  // dev knob: timing-only ablations of the scan kernel
   bool profile_events = false;
@@ -84,6 +86,7 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
 int db_norm_impl(t2l_ctx* ctx, hipStream_t s);
 int merge_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int parts, int Q, int K, int32_t* out_idx,
                double* out_score, hipStream_t s);
+int search_stream_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s);
 // encode.hip
 int load_weights_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_model_config* cfg);
 int encode_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float* out, hipStream_t s);
