@@ -57,7 +57,7 @@ def cpu_baseline(db, qs, budget_s=12.0):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, written
-    by tools_pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, gfx950 correction per MI355X_MICROARCH.md).
+    by tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, gfx950 correction per MI355X_MICROARCH.md).
     None when no profile has been committed for this kernel name."""
     try:
         d = json.load(open(os.path.join(REPO, "profiles", "pmc_latest.json")))

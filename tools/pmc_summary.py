@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Condense gpurun_out/prof_<tag>/ (written on the GPU box by tools_profile.sh) into committed summaries under
+"""Condense gpurun_out/prof_<tag>/ (written on the GPU box by tools/profile.sh) into committed summaries under
 profiles/: <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the HEADLINE command), <tag>_secondary_
 kernel_stats.csv (side measurements), <tag>_pmc_summary.{md,json} (per-kernel PMC averages from the separate --pmc
 passes) and profiles/pmc_latest.json (read by bench.py for roofline.traffic). Kernels of the headline loop take their
@@ -48,7 +48,7 @@ for k, s in summary.items():
 json.dump(summary, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
 json.dump(summary, open("profiles/pmc_latest.json", "w"), indent=1, sort_keys=True)
 with open(f"profiles/{tag}_pmc_summary.md", "w") as f:
-    f.write(f"# PMC summary `{tag}` — rocprofv3 --pmc passes (separate runs; see tools_profile.sh)\n\n")
+    f.write(f"# PMC summary `{tag}` — rocprofv3 --pmc passes (separate runs; see tools/profile.sh)\n\n")
     for k, s in sorted(summary.items()):
         f.write(f"## {k}  ({s['source']})\n\n| counter | average per launch |\n|---|---|\n")
         for c, v in sorted(s.items()):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage (on the GPU box, from the repo root): bash tools_profile.sh <tag>
+# Usage (on the GPU box, from the repo root): bash tools/profile.sh <tag>
 # rocprofv3 of the HEADLINE command (bench.py without its side measurements, so per-kernel averages are those of the
 # timed loop) — kernel-trace stats + PMC passes in separate runs, as the MI355X guide prescribes — and one
 # kernel-trace + FETCH_SIZE/WRITE_SIZE pass of the side measurements (encoder, streaming scan, loss).
