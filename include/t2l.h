@@ -126,6 +126,13 @@ int t2l_search(t2l_ctx* ctx, const float* queries, int32_t n_queries, int32_t k,
 int t2l_merge_topk(t2l_ctx* ctx, const int32_t* idx, const double* score, int32_t parts, int32_t n_queries,
                    int32_t k, int32_t* out_idx, double* out_score, void* stream);
 
+/* Same exchange with ONE collective: t2l_pack_pairs turns a rank's (idx, score) [n_queries,k] into f64 [n_queries,k,2]
+ * records {score, (double)row id}; after the all-gather, t2l_merge_pairs merges dev f64 [parts][n_queries][k][2]. */
+int t2l_pack_pairs(t2l_ctx* ctx, const int32_t* idx, const double* score, int32_t n_queries, int32_t k, double* pairs,
+                   void* stream);
+int t2l_merge_pairs(t2l_ctx* ctx, const double* pairs, int32_t parts, int32_t n_queries, int32_t k, int32_t* out_idx,
+                    double* out_score, void* stream);
+
 /* Number of queries of the LAST t2l_search that took the exact-scan fallback (synchronises). */
 int t2l_search_fallbacks(t2l_ctx* ctx, int32_t* out_count);
 

@@ -159,6 +159,11 @@ def test_hip_merge_kernel_vs_host_merge(eng):
     hi, hs = merge_topk_host(idx, sc, K)
     assert np.array_equal(gi.cpu().numpy().astype(np.int64), hi)
     assert np.array_equal(gs.cpu().numpy(), hs)
+    # the packed single-collective form: pack per shard, stack (= all_gather), merge
+    pairs = torch.stack([eng.pack_pairs(torch.from_numpy(idx[p]).cuda(), torch.from_numpy(sc[p]).cuda()) for p in range(P)])
+    pi, ps = eng.merge_pairs(pairs)
+    assert np.array_equal(pi.cpu().numpy().astype(np.int64), hi)
+    assert np.array_equal(ps.cpu().numpy(), hs)
 
 
 @pytest.mark.parametrize("n,q,k", [(1, 1, 1), (33, 5, 10), (1000, 64, 10), (4097, 17, 26), (70001, 33, 10)])

@@ -152,6 +152,27 @@ int t2l_merge_topk(t2l_ctx* ctx, const int32_t* idx, const double* score, int32_
   return merge_impl(ctx, idx, score, parts, n_queries, k, out_idx, out_score, (hipStream_t)stream);
 }
 
+int t2l_pack_pairs(t2l_ctx* ctx, const int32_t* idx, const double* score, int32_t n_queries, int32_t k, double* pairs,
+                   void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  if (n_queries < 0 || k < 1) return fail(ctx, T2L_EINVAL, "t2l_pack_pairs: bad n_queries / k");
+  if (n_queries == 0) return T2L_OK;
+  if (!idx || !score || !pairs) return fail(ctx, T2L_EINVAL, "t2l_pack_pairs: null buffer");
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return pack_impl(ctx, idx, score, n_queries * k, pairs, (hipStream_t)stream);
+}
+
+int t2l_merge_pairs(t2l_ctx* ctx, const double* pairs, int32_t parts, int32_t n_queries, int32_t k, int32_t* out_idx,
+                    double* out_score, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  if (parts < 1 || n_queries < 0 || k < 1 || k > T2L_MAX_TOPK)
+    return fail(ctx, T2L_EINVAL, "t2l_merge_pairs: bad parts / n_queries / k");
+  if (n_queries == 0) return T2L_OK;
+  if (!pairs || !out_idx) return fail(ctx, T2L_EINVAL, "t2l_merge_pairs: null buffer");
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return merge_pairs_impl(ctx, pairs, parts, n_queries, k, out_idx, out_score, (hipStream_t)stream);
+}
+
 // dev: phase cycle counters written by the instrumented scan variant (scan_variant 16/17): 4 waves x 5 phases
 int t2l_debug_counters(t2l_ctx* ctx, long long* out, int32_t n) {
   if (!ctx || !out || n > 60) return T2L_EINVAL;

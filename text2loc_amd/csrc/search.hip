@@ -774,6 +774,53 @@ __global__ __launch_bounds__(256) void merge_kernel(const int32_t* __restrict__ 
   }
 }
 
+static int grow(t2l_ctx* ctx, void** p, size_t* cap, size_t need_bytes) {
+  if (need_bytes <= *cap) return T2L_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  T2L_HIP(ctx, hipMalloc(p, need_bytes));
+  *cap = need_bytes;
+  return T2L_OK;
+}
+
+// (score, row id) pairs as one f64[.,2] record (row ids are exact in f64): lets the sharded search exchange ONE buffer
+__global__ __launch_bounds__(256) void pack_pairs_kernel(const int32_t* __restrict__ idx, const double* __restrict__ score,
+                                                         int n, double* __restrict__ pairs) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    pairs[2 * i] = score[i];
+    pairs[2 * i + 1] = (double)idx[i];
+  }
+}
+__global__ __launch_bounds__(256) void unpack_pairs_kernel(const double* __restrict__ pairs, int n,
+                                                           int32_t* __restrict__ idx, double* __restrict__ score) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    score[i] = pairs[2 * i];
+    idx[i] = (int32_t)pairs[2 * i + 1];
+  }
+}
+
+int pack_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int n, double* pairs, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(pack_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, idx, score, n, pairs);
+  T2L_HIP(ctx, hipGetLastError());
+  return T2L_OK;
+}
+
+int merge_pairs_impl(t2l_ctx* ctx, const double* pairs, int parts, int Q, int K, int32_t* out_idx, double* out_score,
+                     hipStream_t s) {
+  const int n = parts * Q * K;
+  int rc;
+  if ((rc = grow(ctx, (void**)&ctx->seg_idx, &ctx->seg_idx_cap, (size_t)n * sizeof(int32_t))) != T2L_OK ||
+      (rc = grow(ctx, (void**)&ctx->seg_score, &ctx->seg_score_cap, (size_t)n * sizeof(double))) != T2L_OK)
+    return rc;
+  if (n > 0)
+    hipLaunchKernelGGL(unpack_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pairs, n, ctx->seg_idx, ctx->seg_score);
+  T2L_HIP(ctx, hipGetLastError());
+  return merge_impl(ctx, ctx->seg_idx, ctx->seg_score, parts, Q, K, out_idx, out_score, s);
+}
+
 int merge_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int parts, int Q, int K, int32_t* out_idx,
                double* out_score, hipStream_t s) {
   if (parts * K > 256) return fail(ctx, T2L_EINVAL, "t2l_merge_topk: parts * k must be <= 256");
@@ -914,16 +961,6 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, int n_
 // rows one scan launch can cover: 32 splits x 512 tiles (13 code bits) x 32 rows
 constexpr int kMaxPerTiles = 512;
 constexpr int kSegmentRows = (kMaxParts / 2) * kMaxPerTiles * kTileRows;
-
-static int grow(t2l_ctx* ctx, void** p, size_t* cap, size_t need_bytes) {
-  if (need_bytes <= *cap) return T2L_OK;
-  if (*p) (void)hipFree(*p);
-  *p = nullptr;
-  *cap = 0;
-  T2L_HIP(ctx, hipMalloc(p, need_bytes));
-  *cap = need_bytes;
-  return T2L_OK;
-}
 
 int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s) {
   if (Q == 0) return T2L_OK;

@@ -35,6 +35,9 @@ struct EventRing {
 };
 
 struct EncoderWeights;  int search_stream_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s);
+int pack_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int n, double* pairs, hipStream_t s);
+int merge_pairs_impl(t2l_ctx* ctx, const double* pairs, int parts, int Q, int K, int32_t* out_idx, double* out_score,
+                     hipStream_t s);
 // encode.hip
 
 }  // namespace t2l

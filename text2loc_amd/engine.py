@@ -51,6 +51,9 @@ EXPORTS = {
     "t2l_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_merge_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
+    "t2l_pack_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "t2l_merge_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
     "t2l_search_fallbacks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "t2l_contrastive_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -197,6 +200,23 @@ class Engine:
         self._check(self.lib.t2l_merge_topk(self._h, _dev_ptr(idx, torch.int32, "idx"),
                                             _dev_ptr(score, torch.float64, "score"), P, Q, K, out_i.data_ptr(),
                                             out_s.data_ptr(), _stream_ptr()))
+        return out_i, out_s
+
+    def pack_pairs(self, idx: torch.Tensor, score: torch.Tensor) -> torch.Tensor:
+        """(idx i32[Q,K], score f64[Q,K]) -> f64[Q,K,2] records {score, row id}: one buffer for one collective."""
+        Q, K = (int(x) for x in idx.shape)
+        pairs = torch.empty((Q, K, 2), dtype=torch.float64, device=idx.device)
+        self._check(self.lib.t2l_pack_pairs(self._h, _dev_ptr(idx, torch.int32, "idx"),
+                                            _dev_ptr(score, torch.float64, "score"), Q, K, pairs.data_ptr(), _stream_ptr()))
+        return pairs
+
+    def merge_pairs(self, pairs: torch.Tensor):
+        """pairs f64[P,Q,K,2] (all-gathered) -> (idx i32[Q,K], score f64[Q,K])."""
+        P, Q, K, _ = (int(x) for x in pairs.shape)
+        out_i = torch.empty((Q, K), dtype=torch.int32, device=pairs.device)
+        out_s = torch.empty((Q, K), dtype=torch.float64, device=pairs.device)
+        self._check(self.lib.t2l_merge_pairs(self._h, _dev_ptr(pairs, torch.float64, "pairs"), P, Q, K, out_i.data_ptr(),
+                                             out_s.data_ptr(), _stream_ptr()))
         return out_i, out_s
 
     def search_fallbacks(self) -> int:

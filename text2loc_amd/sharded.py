@@ -3,8 +3,8 @@ single-process, single-device: training/coarse.py:235, no torch.distributed call
 
 One process per GPU. Rank r owns DB rows [lo_r, hi_r) (contiguous, read-only, resident in its HBM). Every
 rank holds all queries. A search is: local fused top-k on the shard (global row ids via ``row_offset``)
--> ONE collective, ``all_gather`` of the per-rank [Q,K] (id, float64 score) pairs over RCCL/xGMI
-(Q*K*12 bytes per rank: latency bound, link bandwidth is irrelevant) -> merge on every rank by
+-> ONE collective, ``all_gather`` of the per-rank [Q,K] {float64 score, row id} records over RCCL/xGMI
+(Q*K*16 bytes per rank: latency bound, link bandwidth is irrelevant) -> merge on every rank by
 (score desc, id asc). Because every shard's list is already exact in float64, the merged top-k equals the
 unsharded result bit for bit. Cell encoding is embarrassingly parallel over cells: no collective.
 """
@@ -56,6 +56,7 @@ class ShardedSearcher:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.engine = engine
+        self._default_fns = search_fn is None and merge_fn is None
         self.search_fn = search_fn or (lambda q, k: engine.search(q, k))
         self.merge_fn = merge_fn or (lambda i, s: engine.merge_topk(i, s))
 
@@ -81,6 +82,12 @@ class ShardedSearcher:
         if self.world == 1:
             return idx, sc
         Q = idx.shape[0]
+        if self.engine is not None and self._default_fns:
+            # ONE collective: {score, row id} records (row ids are exact in float64), 16 B per candidate
+            pairs = self.engine.pack_pairs(idx, sc)
+            allp = torch.empty((self.world * Q, k, 2), dtype=torch.float64, device=pairs.device)
+            self.dist.all_gather_into_tensor(allp, pairs, group=self.group)
+            return self.engine.merge_pairs(allp.view(self.world, Q, k, 2))
         # rank-major concatenation along dim 0 (the layout both RCCL and gloo accept) == [world][Q][k]
         all_i = torch.empty((self.world * Q, k), dtype=idx.dtype, device=idx.device)
         all_s = torch.empty((self.world * Q, k), dtype=sc.dtype, device=sc.device)
