@@ -131,6 +131,30 @@ def secondary_measurements(eng):
         del big
     except Exception as e:  # the side measurement must never take the headline down
         out["hbm_stream"] = {"error": repr(e)}
+    # a1: per-object reductions over raw points (HBM-bound: 24 B per point, one pass)
+    try:
+        rs = np.random.default_rng(11)
+        n_pts = np.clip(np.round(rs.lognormal(6.98, 1.0, size=16000)), 25, 60000).astype(np.int64)
+        poff = np.zeros(len(n_pts) + 1, dtype=np.int64)
+        np.cumsum(n_pts, out=poff[1:])
+        total = int(poff[-1])
+        d_xyz = torch.rand((total, 3), device="cuda")
+        d_rgb = torch.rand((total, 3), device="cuda")
+        d_off = torch.from_numpy(poff).cuda()
+        rows = np.arange(8, dtype=np.int32)
+        for _ in range(2):
+            eng.reduce_objects(d_xyz, d_rgb, d_off, synth.COLORS, rows)
+        eng.kernel_stats("reduce_objects")
+        for _ in range(5):
+            eng.reduce_objects(d_xyz, d_rgb, d_off, synth.COLORS, rows)
+        torch.cuda.synchronize()
+        ms, n = eng.kernel_stats("reduce_objects")
+        out["reduce_objects"] = {"objects": len(n_pts), "points": total, "kernel_ms": ms,
+                                 "achieved_GBps": total * 24.0 / (ms * 1e-3) / 1e9, "peak_GBps": 8000.0,
+                                 "frac": total * 24.0 / (ms * 1e-3) / 1e9 / 8000.0, "launches_timed": n}
+        del d_xyz, d_rgb
+    except Exception as e:
+        out["reduce_objects"] = {"error": repr(e)}
     rng = np.random.default_rng(0)
     a = torch.from_numpy(rng.standard_normal((64, 256)).astype(np.float32)).cuda()
     p = torch.from_numpy(rng.standard_normal((64, 256)).astype(np.float32)).cuda()

@@ -74,6 +74,21 @@ typedef struct {
  * weights would void parity). */
 int t2l_load_weights(t2l_ctx* ctx, const t2l_weight_desc* w, int32_t n, const t2l_model_config* cfg);
 
+/* ---- per-object reductions over raw points (a1) ------------------------------------------------ */
+/* Replaces the host reductions the reference redoes inside every ObjectEncoder.forward call
+ * (datapreparation/kitti360pose/imports.py:28-41 via models/object_encoder.py:79-84,121-141):
+ *   out_rgb    = mean rgb of the object's points          Object3d.get_color_rgb
+ *   out_color  = color_rows[argmin_k ||mean rgb - color_centers[k]||]   Object3d.get_color_text -> known_colors[...]
+ *   out_center = mean xyz                                 Object3d.get_center
+ *   out_npts   = number of points                         len(obj.xyz)
+ * xyz, rgb: dev f32[n_points,3], the objects' points concatenated in object order; point_offsets: dev i64[n_objects+1].
+ * color_centers host f32[n_colors,3] (utils.py:210-224), color_rows host i32[n_colors] (row of color_embedding per centre,
+ * i.e. the reference's {name: i for i, name in enumerate(COLOR_NAMES)} applied to COLOR_NAMES), n_colors <= 16.
+ * Outputs are dev buffers in exactly the t2l_packed_cells layout. Sums are accumulated in float64. */
+int t2l_reduce_objects(t2l_ctx* ctx, const float* xyz, const float* rgb, const int64_t* point_offsets, int32_t n_objects,
+                       const float* color_centers, const int32_t* color_rows, int32_t n_colors, float* out_rgb,
+                       float* out_center, float* out_npts, int32_t* out_color_idx, void* stream);
+
 /* ---- cell encoding (a2+a4) ------------------------------------------------------------------- */
 /* Packed SoA replacement of List[List[Object3d]] (+ PointNet++ features2 when class_embed == 0).
  * Per object o of cell b (offsets[b] <= o < offsets[b+1], dataset order):
@@ -159,7 +174,7 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value);
 /* Per-kernel device time measured with hipEvent pairs recorded on the caller's stream around each launch
  * (no synchronisation while recording; enabled by option "profile_events" = 1, off by default).
  * Returns the average duration (ms) and the number of launches recorded since the previous call for
- * name = "search_scan" | "search_rerank" | "encode_cells" | "contrastive_loss" (at most the last 512),
+ * name = "search_scan" | "search_rerank" | "encode_cells" | "contrastive_loss" | "reduce_objects" (at most the last 512),
  * then clears the record. Synchronises on the recorded events. */
 int t2l_kernel_stats(t2l_ctx* ctx, const char* name, float* out_avg_ms, int32_t* out_count);
 

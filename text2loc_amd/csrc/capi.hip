@@ -93,6 +93,20 @@ int t2l_encode_cells(t2l_ctx* ctx, const t2l_packed_cells* in, float* out_emb, v
   return encode_impl(ctx, in, out_emb, (hipStream_t)stream);
 }
 
+int t2l_reduce_objects(t2l_ctx* ctx, const float* xyz, const float* rgb, const int64_t* point_offsets, int32_t n_objects,
+                       const float* color_centers, const int32_t* color_rows, int32_t n_colors, float* out_rgb,
+                       float* out_center, float* out_npts, int32_t* out_color_idx, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  if (n_objects < 0) return fail(ctx, T2L_EINVAL, "t2l_reduce_objects: n_objects < 0");
+  if (n_objects == 0) return T2L_OK;
+  if (!xyz || !rgb || !point_offsets || !color_centers || !color_rows || !out_rgb || !out_center || !out_npts ||
+      !out_color_idx)
+    return fail(ctx, T2L_EINVAL, "t2l_reduce_objects: null buffer");
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return reduce_impl(ctx, xyz, rgb, point_offsets, n_objects, color_centers, color_rows, n_colors, out_rgb, out_center,
+                     out_npts, out_color_idx, (hipStream_t)stream);
+}
+
 int t2l_db_set(t2l_ctx* ctx, const float* emb, int64_t n_rows, int64_t row_offset, void* stream) {
   if (!ctx) return T2L_EINVAL;
   if (n_rows < 0 || (n_rows > 0 && !emb)) return fail(ctx, T2L_EINVAL, "t2l_db_set: bad arguments");

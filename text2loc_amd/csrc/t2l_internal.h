@@ -38,6 +38,10 @@ struct EncoderWeights;  int search_stream_impl(t2l_ctx* ctx, const float* q, int
 int pack_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int n, double* pairs, hipStream_t s);
 int merge_pairs_impl(t2l_ctx* ctx, const double* pairs, int parts, int Q, int K, int32_t* out_idx, double* out_score,
                      hipStream_t s);
+// reduce.hip
+int reduce_impl(t2l_ctx* ctx, const float* xyz, const float* rgb, const int64_t* offsets, int n_objects,
+                const float* centers, const int32_t* rows, int n_colors, float* out_rgb, float* out_center,
+                float* out_npts, int32_t* out_color, hipStream_t s);
 // encode.hip
 
 }  // namespace t2l

@@ -46,6 +46,8 @@ EXPORTS = {
     "t2l_last_error": (C.c_char_p, [C.c_void_p]),
     "t2l_load_weights": (C.c_int, [C.c_void_p, C.POINTER(_WeightDesc), C.c_int32, C.POINTER(_ModelConfig)]),
     "t2l_encode_cells": (C.c_int, [C.c_void_p, C.POINTER(_PackedCells), C.c_void_p, C.c_void_p]),
+    "t2l_reduce_objects": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_db_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "t2l_db_rows": (C.c_int64, [C.c_void_p]),
     "t2l_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -144,6 +146,26 @@ class Engine:
                            int("color" in use_features), int("position" in use_features), int("num" in use_features),
                            int(num_layers), int(num_heads))
         self._check(self.lib.t2l_load_weights(self._h, arr, len(descs), C.byref(cfg)))
+
+    # ------------------------------------------------------------------ per-object reductions (a1)
+    def reduce_objects(self, xyz: torch.Tensor, rgb: torch.Tensor, point_offsets: torch.Tensor,
+                       color_centers: np.ndarray, color_rows: np.ndarray) -> Dict[str, torch.Tensor]:
+        """xyz, rgb f32[n_points,3] (GPU, objects concatenated), point_offsets i64[n_objects+1] (GPU) ->
+        dict(rgb f32[n,3], center f32[n,3], n_pts f32[n], color_idx i32[n]) on the GPU."""
+        n = int(point_offsets.numel()) - 1
+        dev = xyz.device
+        out = {"rgb": torch.empty((n, 3), dtype=torch.float32, device=dev),
+               "center": torch.empty((n, 3), dtype=torch.float32, device=dev),
+               "n_pts": torch.empty((n,), dtype=torch.float32, device=dev),
+               "color_idx": torch.empty((n,), dtype=torch.int32, device=dev)}
+        cc = np.ascontiguousarray(color_centers, dtype=np.float32)
+        cr = np.ascontiguousarray(color_rows, dtype=np.int32)
+        self._check(self.lib.t2l_reduce_objects(
+            self._h, _dev_ptr(xyz, torch.float32, "xyz"), _dev_ptr(rgb, torch.float32, "rgb"),
+            _dev_ptr(point_offsets, torch.int64, "point_offsets"), n, cc.ctypes.data, cr.ctypes.data, len(cr),
+            out["rgb"].data_ptr(), out["center"].data_ptr(), out["n_pts"].data_ptr(), out["color_idx"].data_ptr(),
+            _stream_ptr()))
+        return out
 
     # ------------------------------------------------------------------ cell encoding
     def encode_cells(self, packed: Dict[str, torch.Tensor]) -> torch.Tensor:

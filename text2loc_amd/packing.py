@@ -85,6 +85,31 @@ def pack_cells(objects: List[List[object]], known_classes: Dict[str, int], known
     return out
 
 
+def pack_cells_gpu(engine, objects: List[List[object]], known_classes: Dict[str, int],
+                   known_colors: Optional[Dict[str, int]] = None, device="cuda") -> Dict[str, "torch.Tensor"]:
+    """Same packed SoA as ``pack_cells`` but the per-object reductions over the raw points run on the GPU
+    (t2l_reduce_objects, one HBM pass over 24 B/point) instead of ~3 numpy reductions per object on the host.
+    The points are concatenated on the host once and copied over; class indices come from the labels."""
+    import torch
+
+    known_colors = known_colors or color_table()
+    flat = [o for objs in objects for o in objs]
+    counts = np.array([len(o) for o in objects], dtype=np.int32)
+    offsets = np.zeros(len(objects) + 1, dtype=np.int32)
+    np.cumsum(counts, out=offsets[1:])
+    npts = np.array([len(o.xyz) for o in flat], dtype=np.int64)
+    poff = np.zeros(len(flat) + 1, dtype=np.int64)
+    np.cumsum(npts, out=poff[1:])
+    xyz = np.concatenate([np.asarray(o.xyz, dtype=np.float32) for o in flat], axis=0) if flat else np.zeros((0, 3), np.float32)
+    rgb = np.concatenate([np.asarray(o.rgb, dtype=np.float32) for o in flat], axis=0) if flat else np.zeros((0, 3), np.float32)
+    rows = np.array([known_colors[c] for c in COLOR_NAMES], dtype=np.int32)
+    red = engine.reduce_objects(torch.from_numpy(xyz).to(device), torch.from_numpy(rgb).to(device),
+                                torch.from_numpy(poff).to(device), COLORS, rows)
+    red["offsets"] = torch.from_numpy(offsets).to(device)
+    red["class_idx"] = torch.from_numpy(np.array([known_classes.get(o.label, 0) for o in flat], dtype=np.int32)).to(device)
+    return red
+
+
 def to_device(packed: Dict[str, np.ndarray], device) -> Dict[str, "torch.Tensor"]:
     import torch
 
@@ -92,4 +117,5 @@ def to_device(packed: Dict[str, np.ndarray], device) -> Dict[str, "torch.Tensor"
             if k != "counts"}
 
 
-__all__ = ["KNOWN_CLASS", "COLOR_NAMES", "class_table", "color_table", "object_features", "pack_cells", "to_device"]
+__all__ = ["KNOWN_CLASS", "COLOR_NAMES", "class_table", "color_table", "object_features", "pack_cells",
+           "pack_cells_gpu", "to_device"]
