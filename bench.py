@@ -140,7 +140,7 @@ def secondary_measurements(eng):
         total = int(poff[-1])
         d_xyz = torch.rand((total, 3), device="cuda")
         d_rgb = torch.rand((total, 3), device="cuda")
-        d_off = torch.from_numpy(poff).cuda()
+        d_off = poff
         rows = np.arange(8, dtype=np.int32)
         for _ in range(2):
             eng.reduce_objects(d_xyz, d_rgb, d_off, synth.COLORS, rows)

@@ -81,7 +81,9 @@ int t2l_load_weights(t2l_ctx* ctx, const t2l_weight_desc* w, int32_t n, const t2
  *   out_color  = color_rows[argmin_k ||mean rgb - color_centers[k]||]   Object3d.get_color_text -> known_colors[...]
  *   out_center = mean xyz                                 Object3d.get_center
  *   out_npts   = number of points                         len(obj.xyz)
- * xyz, rgb: dev f32[n_points,3], the objects' points concatenated in object order; point_offsets: dev i64[n_objects+1].
+ * xyz, rgb: dev f32[n_points,3], the objects' points concatenated in object order; point_offsets: HOST i64[n_objects+1]
+ * (the caller knows the object sizes; the library cuts objects of more than 4096 points into runs so that the long
+ * tail of the size distribution does not serialise on one wave). Synchronises the stream once (upload of the run list).
  * color_centers host f32[n_colors,3] (utils.py:210-224), color_rows host i32[n_colors] (row of color_embedding per centre,
  * i.e. the reference's {name: i for i, name in enumerate(COLOR_NAMES)} applied to COLOR_NAMES), n_colors <= 16.
  * Outputs are dev buffers in exactly the t2l_packed_cells layout. Sums are accumulated in float64. */

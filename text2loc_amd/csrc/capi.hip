@@ -65,7 +65,7 @@ void t2l_destroy(t2l_ctx* ctx) {
   (void)hipDeviceSynchronize();
   free_weights(ctx);
   for (void* p : {(void*)ctx->db, (void*)ctx->db_split, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
-                  (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count})
+                  (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count, ctx->reduce_ws})
     if (p) (void)hipFree(p);
   for (auto& kv : ctx->events) {
     for (hipEvent_t ev : kv.second.a) (void)hipEventDestroy(ev);

@@ -150,9 +150,11 @@ class Engine:
     # ------------------------------------------------------------------ per-object reductions (a1)
     def reduce_objects(self, xyz: torch.Tensor, rgb: torch.Tensor, point_offsets: torch.Tensor,
                        color_centers: np.ndarray, color_rows: np.ndarray) -> Dict[str, torch.Tensor]:
-        """xyz, rgb f32[n_points,3] (GPU, objects concatenated), point_offsets i64[n_objects+1] (GPU) ->
-        dict(rgb f32[n,3], center f32[n,3], n_pts f32[n], color_idx i32[n]) on the GPU."""
-        n = int(point_offsets.numel()) - 1
+        """xyz, rgb f32[n_points,3] (GPU, objects concatenated), point_offsets i64[n_objects+1] (HOST: tensor or ndarray)
+        -> dict(rgb f32[n,3], center f32[n,3], n_pts f32[n], color_idx i32[n]) on the GPU."""
+        po = point_offsets.cpu().numpy() if isinstance(point_offsets, torch.Tensor) else np.asarray(point_offsets)
+        po = np.ascontiguousarray(po, dtype=np.int64)
+        n = int(po.size) - 1
         dev = xyz.device
         out = {"rgb": torch.empty((n, 3), dtype=torch.float32, device=dev),
                "center": torch.empty((n, 3), dtype=torch.float32, device=dev),
@@ -162,7 +164,7 @@ class Engine:
         cr = np.ascontiguousarray(color_rows, dtype=np.int32)
         self._check(self.lib.t2l_reduce_objects(
             self._h, _dev_ptr(xyz, torch.float32, "xyz"), _dev_ptr(rgb, torch.float32, "rgb"),
-            _dev_ptr(point_offsets, torch.int64, "point_offsets"), n, cc.ctypes.data, cr.ctypes.data, len(cr),
+            po.ctypes.data, n, cc.ctypes.data, cr.ctypes.data, len(cr),
             out["rgb"].data_ptr(), out["center"].data_ptr(), out["n_pts"].data_ptr(), out["color_idx"].data_ptr(),
             _stream_ptr()))
         return out

@@ -104,7 +104,7 @@ def pack_cells_gpu(engine, objects: List[List[object]], known_classes: Dict[str,
     rgb = np.concatenate([np.asarray(o.rgb, dtype=np.float32) for o in flat], axis=0) if flat else np.zeros((0, 3), np.float32)
     rows = np.array([known_colors[c] for c in COLOR_NAMES], dtype=np.int32)
     red = engine.reduce_objects(torch.from_numpy(xyz).to(device), torch.from_numpy(rgb).to(device),
-                                torch.from_numpy(poff).to(device), COLORS, rows)
+                                poff, COLORS, rows)
     red["offsets"] = torch.from_numpy(offsets).to(device)
     red["class_idx"] = torch.from_numpy(np.array([known_classes.get(o.label, 0) for o in flat], dtype=np.int32)).to(device)
     return red
