@@ -181,8 +181,18 @@ class CellRetrievalNetwork(nn.Module):
                 raise T2LError("class_embed is off: object_points must hold precomputed PointNet++ features2 "
                                "[n_i,256] per cell (PointNet++ kernels are not built yet)")
             pn = [p.detach().cpu().numpy() if isinstance(p, torch.Tensor) else np.asarray(p) for p in object_points]
+        eng = self.engine()
+        if any(getattr(o, "_t2l_feat", None) is None for objs in objects for o in objs):
+            # raw points not reduced yet: one HBM pass on the GPU (t2l_reduce_objects) instead of three numpy
+            # reductions per object on the host (what the reference redoes on every call)
+            packed = packing.pack_cells_gpu(eng, objects, self.object_encoder.known_classes,
+                                            self.object_encoder.known_colors, dev)
+            if pn is not None:
+                packed["pn_feat"] = torch.from_numpy(np.concatenate(
+                    [np.asarray(f, dtype=np.float32).reshape(-1, 256) for f in pn], axis=0)).to(dev)
+            return eng.encode_cells(packed)
         packed = packing.pack_cells(objects, self.object_encoder.known_classes, self.object_encoder.known_colors, pn)
-        return self.engine().encode_cells(packing.to_device(packed, dev))
+        return eng.encode_cells(packing.to_device(packed, dev))
 
     # ---- engine plumbing --------------------------------------------------------------------------------
     def engine(self) -> Engine:
