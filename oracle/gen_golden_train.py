@@ -1,0 +1,133 @@
+"""TEST INFRASTRUCTURE — build-container only.
+
+Golden vectors for SURVEY.md §8 row a9 / config 4 (one training step of the object branch): imports the
+upstream reference, runs ``model.train()`` -> ``encode_objects`` -> ``ContrastiveLoss(0.1)`` -> ``backward`` ->
+``optim.Adam.step`` (training/coarse.py:31-58,258) on B=64 seeded synthetic cells against a fixed [64,256] text
+batch, and writes ``tests/golden/train_step_{embed,pn}.npz`` (DATA only).
+
+Dropout: ``nn.TransformerEncoderLayer`` draws torch-RNG masks (p=0.1) in train mode, which no other
+implementation can reproduce; the goldens are taken with the four dropout sites of each layer set to p=0
+(attention probabilities, dropout, dropout1, dropout2). The dropout arithmetic itself is pinned separately by
+tests that feed the build's own counter-based masks to the float64 oracle.
+
+Parameter gradients are ~4.2 M floats; per tensor the fixture keeps the full array when it has <= 1024 elements,
+else 512 seeded samples + its L2 norm and sum.
+"""
+from __future__ import annotations
+
+import os
+import os.path as osp
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = osp.dirname(osp.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness as H  # noqa: E402
+
+H.setup_reference_imports()
+
+import torch  # noqa: E402
+
+from gen_golden import TablePointNet, TokenBatch, packed_from_objects, to_torch_sd  # noqa: E402
+from text2loc_amd import synth  # noqa: E402
+
+OUT = osp.join(H.REPO, "tests", "golden")
+torch.set_num_threads(4)
+N_SAMPLE = 512
+
+
+def sample_index(name: str, numel: int) -> np.ndarray:
+    """Deterministic sample positions of a flattened tensor (the tests call the same function)."""
+    seed = int.from_bytes(name.encode()[-8:].rjust(8, b"\0"), "little") % (2 ** 32)
+    return np.sort(np.random.default_rng([seed, numel]).choice(numel, size=min(N_SAMPLE, numel), replace=False))
+
+
+def pack_tensor(out: dict, tag: str, name: str, t: np.ndarray):
+    flat = np.asarray(t, dtype=np.float32).ravel()
+    if flat.size <= 1024:
+        out[f"{tag}/{name}"] = flat
+    else:
+        out[f"{tag}/{name}"] = flat[sample_index(name, flat.size)]
+    out[f"{tag}_norm/{name}"] = np.float64(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+    out[f"{tag}_sum/{name}"] = np.float64(flat.astype(np.float64).sum())
+
+
+def zero_dropout(model):
+    for layer in model.obj_inter_module:
+        layer.dropout.p = 0.0
+        layer.dropout1.p = 0.0
+        layer.dropout2.p = 0.0
+        layer.self_attn.dropout = 0.0
+
+
+def run(mode: str, hf_dir: str, pn_path: str):
+    from datapreparation.kitti360pose.utils import COLOR_NAMES, KNOWN_CLASS
+    from models.cell_retrieval import CellRetrievalNetwork
+    from training.losses import ContrastiveLoss
+
+    W_SEED, C_SEED, B, LR = 0, 3, 64, 1e-3
+    embed = mode == "embed"
+    sd_np = synth.make_object_branch_weights(W_SEED)
+    cells = synth.make_cells(B, seed=C_SEED, with_pn_feat=True)
+    objects = H.build_objects(cells, seed=C_SEED)
+    args = H.make_args(hf_dir, pn_path, class_embed=embed, color_embed=embed)
+    model = CellRetrievalNetwork(KNOWN_CLASS, COLOR_NAMES, args)
+    model.load_state_dict(to_torch_sd(sd_np), strict=False)
+    if not embed:
+        model.object_encoder.pointnet = TablePointNet(cells["pn_feat"], cells["offsets"])
+    zero_dropout(model)
+    model.train()
+    packed = packed_from_objects(model, objects)
+    toks = [None] * B if embed else [TokenBatch(i) for i in range(B)]
+
+    rng = np.random.default_rng([7, 0xA9])
+    anchor_np = rng.standard_normal((B, 256)).astype(np.float32)
+    anchor_np /= np.linalg.norm(anchor_np, axis=1, keepdims=True)
+    anchor = torch.from_numpy(anchor_np).requires_grad_(True)
+
+    names = [n for n, _ in model.named_parameters() if n.startswith(("object_encoder.", "obj_inter_module."))
+             and not n.startswith("object_encoder.pointnet")]
+    params = dict(model.named_parameters())
+    opt = torch.optim.Adam([params[n] for n in names], lr=LR)  # training/coarse.py:258
+    opt.zero_grad()
+    positive = model.encode_objects(objects, toks)
+    loss = ContrastiveLoss(temperature=0.1)(anchor, positive)  # training/coarse.py:52
+    loss.backward()
+
+    out = {"weight_seed": W_SEED, "cell_seed": C_SEED, "n_cells": B, "lr": LR, "temperature": 0.1,
+           "anchor": anchor_np, "positive": positive.detach().numpy(), "loss": np.float32(loss.item()),
+           "grad_anchor": anchor.grad.numpy()}
+    out.update({"in_" + k: v for k, v in packed.items()})
+    used = []
+    for n in names:
+        g = params[n].grad
+        if g is None:  # branches the mode does not touch (e.g. color_encoder in embed mode)
+            continue
+        used.append(n)
+        pack_tensor(out, "grad", n, g.numpy())
+    for n, b in model.named_buffers():
+        if n.startswith("object_encoder.") and not n.startswith("object_encoder.pointnet") and "running" in n:
+            out["buf/" + n] = b.numpy().copy()
+        if n.startswith("object_encoder.") and not n.startswith("object_encoder.pointnet") and n.endswith("num_batches_tracked"):
+            out["buf/" + n] = np.int64(b.item())
+    opt.step()
+    for n in used:
+        pack_tensor(out, "adam", n, params[n].detach().numpy())
+    out["used_params"] = np.array(used)
+    np.savez_compressed(osp.join(OUT, f"train_step_{mode}.npz"), **out)
+    print(mode, "loss", float(loss), "params with grad", len(used), "objects", int(packed["offsets"][-1]))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    tmp = tempfile.mkdtemp(prefix="t2l_golden_")
+    hf_dir = H.make_tiny_t5(osp.join(tmp, "t5tiny"))
+    pn_path = H.make_pointnet_ckpt(osp.join(tmp, "pointnet.pth"))
+    for mode in ("embed", "pn"):
+        run(mode, hf_dir, pn_path)
+
+
+if __name__ == "__main__":
+    main()

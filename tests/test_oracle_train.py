@@ -1,0 +1,135 @@
+"""CPU tier: the training-step oracle (oracle/t2l_oracle_train.py) against the goldens of the imported reference's
+``model.train()`` -> ``encode_objects`` -> ``ContrastiveLoss`` -> ``backward`` -> ``Adam.step`` run,
+and its analytic backward against central differences of its own forward (with the dropout masks on)."""
+import numpy as np
+import pytest
+
+from oracle import t2l_oracle as O
+from oracle import t2l_oracle_train as OT
+from text2loc_amd import synth
+
+
+def sample_index(name: str, numel: int, n_sample: int = 512) -> np.ndarray:
+    seed = int.from_bytes(name.encode()[-8:].rjust(8, b"\0"), "little") % (2 ** 32)
+    return np.sort(np.random.default_rng([seed, numel]).choice(numel, size=min(n_sample, numel), replace=False))
+
+
+def golden_view(g, tag, name, full):
+    """(expected, got) of one tensor: whole when small, else at the fixture's sample positions."""
+    flat = np.asarray(full, dtype=np.float64).ravel()
+    exp = g[f"{tag}/{name}"]
+    return exp, (flat if flat.size <= 1024 else flat[sample_index(name, flat.size)])
+
+
+def load_case(g, mode):
+    cells = synth.make_cells(int(g["n_cells"]), seed=int(g["cell_seed"]), with_pn_feat=True)
+    for k in ("class_idx", "color_idx", "rgb", "center", "n_pts", "offsets", "counts"):
+        cells[k] = g["in_" + k]  # exactly what the reference derived from its Object3d instances
+    sd = synth.make_object_branch_weights(int(g["weight_seed"]))
+    return cells, sd, mode == "embed"
+
+
+@pytest.mark.parametrize("mode", ["embed", "pn"])
+def test_train_step_oracle_matches_the_reference(golden, mode):
+    g = golden(f"train_step_{mode}")
+    cells, sd, embed = load_case(g, mode)
+    out0, _ = OT.encode_cells_train(cells, sd, embed, embed)
+    assert np.abs(out0 - g["positive"]).max() < 2e-6
+    loss, d_anchor, d_pos = O.contrastive_loss(g["anchor"], out0, float(g["temperature"]), dtype=np.float64)
+    assert abs(loss - float(g["loss"])) < 2e-6
+    assert np.abs(d_anchor - g["grad_anchor"]).max() < 1e-6
+    out, info = OT.encode_cells_train(cells, sd, embed, embed, grad_out=d_pos)
+    used = [str(n) for n in g["used_params"]]
+    assert sorted(used) == sorted(info["grads"].keys())
+    for n in used:
+        exp, got = golden_view(g, "grad", n, info["grads"][n])
+        rms = float(g[f"grad_norm/{n}"]) / np.sqrt(max(np.asarray(info["grads"][n]).size, 1))
+        # The reference runs in float32: one ReLU pre-activation within rounding of 0 flips sign between float32 and
+        # float64 (layer-1 hidden unit 192 in the embed case) and moves the upstream gradients by ~1e-3 of their rms;
+        # biases in front of a BatchNorm have true gradient 0 and carry ~1e-6 of float32 noise in the reference.
+        if n.startswith("object_encoder.") and n.endswith(".0.bias"):  # Linear bias in front of a BatchNorm
+            assert np.abs(got).max() < 1e-9 and np.abs(exp).max() < 1e-4, n
+            continue
+        err = np.abs(got - exp)
+        assert (err < 1e-2 * rms + 1e-5).mean() >= 0.95 and err.max() < 0.2 * rms + 1e-5, n
+        assert abs(np.sqrt((np.asarray(info["grads"][n]) ** 2).sum()) - float(g[f"grad_norm/{n}"])) < 2e-3 * float(g[f"grad_norm/{n}"]) + 2e-4, n
+    # the same restatement evaluated in float32 lands on the reference's own rounding where no ReLU sits in between
+    _, info32 = OT.encode_cells_train(cells, sd, embed, embed, grad_out=d_pos, dtype=np.float32)
+    for n in used:
+        if n.startswith(("obj_inter_module.1.linear2", "obj_inter_module.1.norm2")):  # downstream of every ReLU
+            exp, got = golden_view(g, "grad", n, info32["grads"][n])
+            rms = float(g[f"grad_norm/{n}"]) / np.sqrt(max(np.asarray(info32["grads"][n]).size, 1))
+            assert np.abs(got - exp).max() < 2e-4 * rms + 1e-7, n
+    # BatchNorm running statistics after the step
+    new = OT.bn_running_update(sd, info["bn_stats"])
+    n_buf = 0
+    for k in g.files:
+        if k.startswith("buf/"):
+            name = k[4:]
+            if name.rsplit(".", 1)[0] + ".running_mean" not in new:
+                assert np.allclose(g[k], sd[name]) or name.endswith("num_batches_tracked")  # untouched branch
+                continue
+            assert np.allclose(np.asarray(new[name], dtype=np.float64), g[k], rtol=2e-5, atol=2e-6), name
+            n_buf += 1
+    assert n_buf >= 9
+    # one Adam step from zero state, fed with the reference's own gradients (Adam's first step is lr*sign(g): feeding
+    # our gradients instead would compare the sign of float32 noise wherever the true gradient is 0)
+    for n in used:
+        flat = np.asarray(sd[n], dtype=np.float64).ravel()
+        p0 = flat if flat.size <= 1024 else flat[sample_index(n, flat.size)]
+        p1, _, _ = OT.adam_step(p0, g[f"grad/{n}"].astype(np.float64), 0.0, 0.0, 1, float(g["lr"]))
+        assert np.abs(p1 - g[f"adam/{n}"]).max() < 2e-7, n
+
+
+def test_backward_matches_central_differences_with_dropout():
+    B = 3
+    cells = synth.make_cells(B, seed=11, with_pn_feat=True, min_obj=3, max_obj=31)
+    sd = {k: np.asarray(v, dtype=np.float64) for k, v in synth.make_object_branch_weights(2).items()}
+    rng = np.random.default_rng(5)
+    gout = rng.standard_normal((B, 256))
+    for embed in (True, False):
+        kw = dict(p_drop=0.1, seed=1234)
+        out, info = OT.encode_cells_train(cells, sd, embed, embed, grad_out=gout, **kw)
+
+        def f(sd2):
+            o, _ = OT.encode_cells_train(cells, sd2, embed, embed, **kw)
+            return float((o * gout).sum())
+
+        names = sorted(info["grads"].keys())
+        checked = 0
+        for n in names:
+            w = sd[n]
+            for _ in range(2):
+                idx = tuple(rng.integers(0, s) for s in w.shape)
+                if "embedding" in n and idx[0] == 0:
+                    continue
+                h = 1e-6 * max(1.0, abs(w[idx]))
+                sd2 = dict(sd)
+                wp = w.copy(); wp[idx] += h; sd2[n] = wp
+                fp = f(sd2)
+                wm = w.copy(); wm[idx] -= h; sd2[n] = wm
+                fm = f(sd2)
+                num = (fp - fm) / (2 * h)
+                ana = np.asarray(info["grads"][n])[idx]
+                assert abs(num - ana) < 2e-4 * max(1.0, abs(num)) + 1e-6, (n, idx, num, ana)
+                checked += 1
+        assert checked > 60
+        if not embed:
+            dpn = info["grad_pn_feat"]
+            i, j = 4, 17
+            h = 1e-5
+            c2 = dict(cells); pf = cells["pn_feat"].astype(np.float64)
+            a = pf.copy(); a[i, j] += h; c2["pn_feat"] = a
+            fp = float((OT.encode_cells_train(c2, sd, embed, embed, **kw)[0] * gout).sum())
+            a = pf.copy(); a[i, j] -= h; c2["pn_feat"] = a
+            fm = float((OT.encode_cells_train(c2, sd, embed, embed, **kw)[0] * gout).sum())
+            assert abs((fp - fm) / (2 * h) - dpn[i, j]) < 1e-6
+
+
+def test_dropout_mask_statistics():
+    for p in (0.1, 0.5):
+        k = OT.dropout_keep(99, 3, 1 << 20, p)
+        assert abs(k.mean() - (1 - p)) < 2e-3
+        assert not np.array_equal(k, OT.dropout_keep(99, 4, 1 << 20, p))
+        assert not np.array_equal(k, OT.dropout_keep(100, 3, 1 << 20, p))
+    assert OT.dropout_keep(1, 1, 100, 0.0).all()
