@@ -161,6 +161,47 @@ int t2l_contrastive_loss(t2l_ctx* ctx, const float* anchor, const float* positiv
                          float temperature, float* loss, float* grad_anchor, float* grad_positive,
                          void* stream);
 
+/* ---- training step of the object branch (a9) --------------------------------------------------- */
+/* Replaces, for the object branch, the body of train_epoch (training/coarse.py:31-58): model.train() forward of
+ * CellRetrievalNetwork.encode_objects, loss.backward() through it, optimizer.zero_grad() / optim.Adam.step().
+ * The text branch (T5 + head) stays on PyTorch autograd; the two meet at the [batch,256] embeddings.
+ *
+ * One LIVE tensor of the model: the library reads parameters from `data` and accumulates (+=) gradients into `grad` on
+ * every backward — exactly torch's .data / .grad of the reference's nn.Parameters, bound by pointer, never copied.
+ * BatchNorm buffers ("...1.running_mean", "...1.running_var") are bound with grad = NULL and updated in place by the
+ * training-mode forward (momentum 0.1, unbiased batch variance); num_batches_tracked is an int64 the caller bumps. */
+typedef struct {
+  const char* name; /* state_dict key */
+  float* data;      /* dev f32[numel] */
+  float* grad;      /* dev f32[numel], or NULL for buffers */
+  int64_t numel;
+} t2l_train_tensor;
+
+/* Binds the tensors the configuration uses (same names t2l_load_weights takes; a missing one is T2L_EINVAL) and
+ * resets the optimizer state (Adam moments = 0, step = 0). Pointers must stay valid until the next bind. Synchronous. */
+int t2l_train_bind(t2l_ctx* ctx, const t2l_train_tensor* tensors, int32_t n, const t2l_model_config* cfg);
+
+/* encode_objects under model.train(): BatchNorm1d uses the statistics of THIS batch of objects (all objects of all
+ * cells, also those beyond slot 28) and updates the running buffers; the four dropout sites of every
+ * nn.TransformerEncoderLayer (attention probabilities, dropout1, feed-forward dropout, dropout2) drop with probability
+ * dropout_p (torch default 0.1) using counter-based masks: element i of site j is kept iff
+ * lowbias32(i*0x9E3779B1 + (seed ^ j*0x85EBCA77)) >> 8 >= dropout_p*2^24 (torch's own RNG stream is not reproducible
+ * outside torch; the mask function is part of this ABI so that a checker can replay it). Activations are kept inside
+ * the context until the next forward. `in` device arrays must stay valid until t2l_encode_cells_backward returns.
+ * out_emb: dev f32[n_cells,256]. */
+int t2l_encode_cells_train(t2l_ctx* ctx, const t2l_packed_cells* in, float dropout_p, uint32_t seed, float* out_emb,
+                           void* stream);
+
+/* loss.backward() through the forward above: grad_emb = d loss / d out_emb, dev f32[n_cells,256]. Parameter gradients
+ * are ADDED to the bound grad buffers (float atomics: summation order, hence the last bits, varies between runs).
+ * grad_pn_feat: dev f32[n_objects,256] receiving d loss / d pn_feat (class_embed == 0), or NULL. */
+int t2l_encode_cells_backward(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat, void* stream);
+
+/* optimizer.zero_grad() and torch.optim.Adam(lr, betas, eps).step() (no weight decay, no amsgrad — what
+ * training/coarse.py:258 constructs) over every bound tensor that has a gradient buffer. */
+int t2l_zero_grad(t2l_ctx* ctx, void* stream);
+int t2l_adam_step(t2l_ctx* ctx, float lr, float beta1, float beta2, float eps, void* stream);
+
 /* ---- knobs (tests / bench) ------------------------------------------------------------------- */
 /* "certify_eps_scale" (default 1.0): multiplies the f32 error bound of the search certificate; a huge
  *     value forces every query through the exact fallback (used by the parity tests).
@@ -176,7 +217,8 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value);
 /* Per-kernel device time measured with hipEvent pairs recorded on the caller's stream around each launch
  * (no synchronisation while recording; enabled by option "profile_events" = 1, off by default).
  * Returns the average duration (ms) and the number of launches recorded since the previous call for
- * name = "search_scan" | "search_rerank" | "encode_cells" | "contrastive_loss" | "reduce_objects" (at most the last 512),
+ * name = "search_scan" | "search_rerank" | "encode_cells" | "contrastive_loss" | "reduce_objects" | "train_forward" |
+ * "train_backward" | "adam_step" (at most the last 512),
  * then clears the record. Synchronises on the recorded events. */
 int t2l_kernel_stats(t2l_ctx* ctx, const char* name, float* out_avg_ms, int32_t* out_count);
 

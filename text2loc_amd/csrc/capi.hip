@@ -64,6 +64,7 @@ void t2l_destroy(t2l_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   free_weights(ctx);
+  free_train(ctx);
   for (void* p : {(void*)ctx->db, (void*)ctx->db_split, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
                   (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count, ctx->reduce_ws})
     if (p) (void)hipFree(p);
@@ -213,6 +214,39 @@ int t2l_contrastive_loss(t2l_ctx* ctx, const float* anchor, const float* positiv
     return fail(ctx, T2L_EINVAL, "t2l_contrastive_loss: pass both gradients or neither");
   T2L_HIP(ctx, hipSetDevice(ctx->device));
   return loss_impl(ctx, anchor, positive, batch, temperature, loss, grad_anchor, grad_positive, (hipStream_t)stream);
+}
+
+int t2l_train_bind(t2l_ctx* ctx, const t2l_train_tensor* tensors, int32_t n, const t2l_model_config* cfg) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return train_bind_impl(ctx, tensors, n, cfg);
+}
+
+int t2l_encode_cells_train(t2l_ctx* ctx, const t2l_packed_cells* in, float dropout_p, uint32_t seed, float* out_emb,
+                           void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return train_forward_impl(ctx, in, dropout_p, seed, out_emb, (hipStream_t)stream);
+}
+
+int t2l_encode_cells_backward(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return train_backward_impl(ctx, grad_emb, grad_pn_feat, (hipStream_t)stream);
+}
+
+int t2l_zero_grad(t2l_ctx* ctx, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return zero_grad_impl(ctx, (hipStream_t)stream);
+}
+
+int t2l_adam_step(t2l_ctx* ctx, float lr, float beta1, float beta2, float eps, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  if (!(lr >= 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f))
+    return fail(ctx, T2L_EINVAL, "t2l_adam_step: need lr >= 0, 0 <= beta < 1, eps >= 0");
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return adam_step_impl(ctx, lr, beta1, beta2, eps, (hipStream_t)stream);
 }
 
 int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {

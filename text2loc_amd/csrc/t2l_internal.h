@@ -34,7 +34,8 @@ struct EventRing {
   int count = 0;  // recorded since the last read (saturates at kEventRing)
 };
 
-struct EncoderWeights;  int search_stream_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s);
+struct EncoderWeights;
+int search_stream_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s);
 int pack_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int n, double* pairs, hipStream_t s);
 int merge_pairs_impl(t2l_ctx* ctx, const double* pairs, int parts, int Q, int K, int32_t* out_idx, double* out_score,
                      hipStream_t s);
@@ -65,6 +66,7 @@ struct t2l_ctx {
   size_t reduce_ws_cap = 0;
   // encoder
   t2l::EncoderWeights* enc = nullptr;
+  void* train = nullptr;         // t2l::TrainState (train.hip)
   // options
   double eps_scale = 1.0;
   int nsplit_override = 0;
@@ -100,6 +102,13 @@ int search_stream_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_
 int load_weights_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_model_config* cfg);
 int encode_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float* out, hipStream_t s);
 void free_weights(t2l_ctx* ctx);
+// train.hip
+int train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const t2l_model_config* cfg);
+int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32_t seed, float* out_emb, hipStream_t s);
+int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat, hipStream_t s);
+int adam_step_impl(t2l_ctx* ctx, float lr, float b1, float b2, float eps, hipStream_t s);
+int zero_grad_impl(t2l_ctx* ctx, hipStream_t s);
+void free_train(t2l_ctx* ctx);
 // loss.hip
 int loss_impl(t2l_ctx* ctx, const float* a, const float* p, int B, float temp, float* loss, float* ga, float* gp,
               hipStream_t s);

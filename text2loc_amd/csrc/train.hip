@@ -1,0 +1,506 @@
+// Training step of the object branch (training/coarse.py:31-58): host orchestration.
+//   t2l_train_bind              live parameter / gradient / BatchNorm-buffer pointers (no copies: the optimizer's tensors)
+//   t2l_encode_cells_train      CellRetrievalNetwork.encode_objects under model.train() (batch-statistics BatchNorm,
+//                               the four dropout sites of each TransformerEncoderLayer), activations kept for backward
+//   t2l_encode_cells_backward   what autograd does for that graph: gradients accumulated (+=) into the bound buffers
+//   t2l_adam_step / t2l_zero_grad   torch.optim.Adam defaults / optimizer.zero_grad()
+// Kernels: train_kernels.h.
+#include <math.h>
+#include <string.h>
+
+#include "t2l_internal.h"
+#include "train_kernels.h"
+
+namespace t2l {
+
+using namespace train;
+
+struct TTensor {
+  float* data = nullptr;
+  float* grad = nullptr;
+  int64_t numel = 0;
+};
+
+// One [Linear, BatchNorm1d, ReLU] block of get_mlp (models/language_encoder.py:16-41) with its saved activations.
+struct MlpLayer {
+  std::string prefix;  // e.g. "object_encoder.pos_encoder.1"
+  int cin = 0, cout = 0;
+  float *y = nullptr, *a = nullptr, *mean = nullptr, *rstd = nullptr;  // pre-BN, post-ReLU, batch statistics
+};
+struct Branch {
+  int kind = 0;  // 0 embedding lookup, 1 small MLP (K<=3 -> 64 -> 256), 2 PointNet-feature MLP (256 -> 256)
+  int slot = 0;  // 256-wide slot of the concatenated feature row
+  std::string table;          // kind 0
+  const int32_t* idx = nullptr;
+  const float* x = nullptr;   // kind 1/2 input
+  int k_in = 0, standardize = 0;
+  std::vector<MlpLayer> layers;
+  float* save_n = nullptr;
+};
+struct LayerSave {
+  std::string prefix;
+  const float* x_in = nullptr;
+  float *qkv = nullptr, *P = nullptr, *O = nullptr, *xhat1 = nullptr, *rstd1 = nullptr, *x1 = nullptr, *h = nullptr,
+        *hd = nullptr, *xhat2 = nullptr, *rstd2 = nullptr, *x2 = nullptr;
+};
+
+struct TrainState {
+  std::unordered_map<std::string, TTensor> t;
+  t2l_model_config cfg{};
+  std::vector<std::string> adam_names;
+  AdamTensor* d_tensors = nullptr;
+  AdamChunk* d_chunks = nullptr;
+  float* mv = nullptr;
+  int n_chunks = 0;
+  int64_t step = 0;
+  // workspace (bump-allocated per forward)
+  char* ws = nullptr;
+  size_t ws_cap = 0, ws_off = 0;
+  // the last forward
+  bool have_forward = false;
+  int M = 0, B = 0, T = 0, n_feat = 0;
+  const int32_t* offsets = nullptr;
+  std::vector<Branch> branches;
+  MlpLayer merge;
+  float *cat = nullptr, *X0 = nullptr, *save_nf = nullptr, *out = nullptr, *pool_n = nullptr;
+  int32_t* pool_arg = nullptr;
+  std::vector<LayerSave> layers;
+  uint32_t seed = 0;
+  float p = 0.f;
+};
+
+static TrainState* state(t2l_ctx* ctx) { return reinterpret_cast<TrainState*>(ctx->train); }
+
+void free_train(t2l_ctx* ctx) {
+  TrainState* st = state(ctx);
+  if (!st) return;
+  for (void* p : {(void*)st->d_tensors, (void*)st->d_chunks, (void*)st->mv, (void*)st->ws})
+    if (p) (void)hipFree(p);
+  delete st;
+  ctx->train = nullptr;
+}
+
+static Drop make_drop(uint32_t seed, int site, float p) {
+  Drop d;
+  d.key = seed ^ (uint32_t)((uint64_t)site * 0x85EBCA77ull);
+  d.thr = p > 0.f ? (uint32_t)((double)p * 16777216.0) : 0u;
+  d.scale = d.thr ? 1.0f / (1.0f - p) : 1.0f;
+  return d;
+}
+
+template <typename T>
+static T* bump(TrainState* st, size_t count) {
+  size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+  T* p = reinterpret_cast<T*>(st->ws + st->ws_off);
+  st->ws_off += bytes;
+  return p;
+}
+
+// ---- GEMM launchers -----------------------------------------------------------------------------------------
+// Y[M,N] = X[M,K] W[N,K]^T + b (relu)
+static void gemm_nt(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int relu, hipStream_t s) {
+  GemmArgs g{X, W, Y, b, M, N, K, K, K, N, relu, 0, K};
+  hipLaunchKernelGGL((gemm_kernel<true, true>), dim3(N / 64, (M + 63) / 64, 1), dim3(256), 0, s, g);
+}
+// dX[M,Kp] (+)= dY[M,N] W[N,Kp]
+static void gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kp, int accumulate, hipStream_t s) {
+  GemmArgs g{dY, W, dX, nullptr, M, Kp, N, N, Kp, Kp, 0, accumulate, N};
+  hipLaunchKernelGGL((gemm_kernel<true, false>), dim3(Kp / 64, (M + 63) / 64, 1), dim3(256), 0, s, g);
+}
+// dW[N,Kp] += dY[M,N]^T X[M,Kp]   (reduction over the M rows, split over grid.z, float atomics)
+static void gemm_tn(const float* dY, const float* X, float* dW, int M, int N, int Kp, hipStream_t s) {
+  const int tiles = (N / 64) * (Kp / 64);
+  int ksplit = std::max(1, std::min((M + 63) / 64, (512 + tiles - 1) / tiles));
+  int kchunk = (((M + ksplit - 1) / ksplit) + 15) & ~15;
+  ksplit = (M + kchunk - 1) / kchunk;
+  GemmArgs g{dY, X, dW, nullptr, N, Kp, M, N, Kp, Kp, 0, 1, kchunk};
+  hipLaunchKernelGGL((gemm_kernel<false, false>), dim3(Kp / 64, N / 64, ksplit), dim3(256), 0, s, g);
+}
+static void colsum(const float* X, int M, int N, float* out, hipStream_t s) {
+  const int rows = 128;
+  hipLaunchKernelGGL(colsum_kernel, dim3(N / 64, (M + rows - 1) / rows), dim3(256), 0, s, X, M, N, rows, out);
+}
+
+static int need(t2l_ctx* ctx, TrainState* st, const std::string& name, int64_t numel, bool with_grad, TTensor** out) {
+  auto it = st->t.find(name);
+  if (it == st->t.end()) return fail(ctx, T2L_EINVAL, "t2l_train_bind: missing tensor '" + name + "'");
+  if (it->second.numel != numel)
+    return fail(ctx, T2L_EINVAL, "t2l_train_bind: '" + name + "' has " + std::to_string(it->second.numel) + " elements, expected " +
+                                     std::to_string(numel));
+  if (with_grad && !it->second.grad) return fail(ctx, T2L_EINVAL, "t2l_train_bind: '" + name + "' needs a gradient buffer");
+  if (out) *out = &it->second;
+  return T2L_OK;
+}
+
+static const TTensor& T_(TrainState* st, const std::string& n) { return st->t.at(n); }
+
+// names + shapes of one get_mlp block
+static int check_mlp_layer(t2l_ctx* ctx, TrainState* st, const std::string& p, int cin, int cout, std::vector<std::string>& params) {
+  int rc;
+  if ((rc = need(ctx, st, p + ".0.weight", (int64_t)cin * cout, true, nullptr))) return rc;
+  if ((rc = need(ctx, st, p + ".0.bias", cout, true, nullptr))) return rc;
+  if ((rc = need(ctx, st, p + ".1.weight", cout, true, nullptr))) return rc;
+  if ((rc = need(ctx, st, p + ".1.bias", cout, true, nullptr))) return rc;
+  if ((rc = need(ctx, st, p + ".1.running_mean", cout, false, nullptr))) return rc;
+  if ((rc = need(ctx, st, p + ".1.running_var", cout, false, nullptr))) return rc;
+  for (const char* sfx : {".0.weight", ".0.bias", ".1.weight", ".1.bias"}) params.push_back(p + sfx);
+  return T2L_OK;
+}
+
+int train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const t2l_model_config* cfg) {
+  if (!tensors || n <= 0 || !cfg) return fail(ctx, T2L_EINVAL, "t2l_train_bind: null argument");
+  if (cfg->num_heads != kTH) return fail(ctx, T2L_EINVAL, "t2l_train_bind: the engine is built for 4 attention heads");
+  const int n_feat = (cfg->use_class != 0) + (cfg->use_color != 0) + (cfg->use_position != 0) + (cfg->use_num != 0);
+  if (n_feat < 2) return fail(ctx, T2L_EINVAL, "t2l_train_bind: training needs at least two of the class/color/position/num features");
+  free_train(ctx);
+  TrainState* st = new TrainState();
+  ctx->train = st;
+  st->cfg = *cfg;
+  st->n_feat = n_feat;
+  for (int i = 0; i < n; ++i) {
+    if (!tensors[i].name || !tensors[i].data) return fail(ctx, T2L_EINVAL, "t2l_train_bind: null name/data");
+    st->t[tensors[i].name] = TTensor{tensors[i].data, tensors[i].grad, tensors[i].numel};
+  }
+  std::vector<std::string>& P = st->adam_names;
+  const std::string oe = "object_encoder.";
+  int rc;
+  if (cfg->use_class) {
+    if (cfg->class_embed) {
+      auto it = st->t.find(oe + "class_embedding.weight");
+      if (it == st->t.end() || !it->second.grad || it->second.numel % kTD) return fail(ctx, T2L_EINVAL, "t2l_train_bind: class_embedding.weight");
+      P.push_back(oe + "class_embedding.weight");
+    } else if ((rc = check_mlp_layer(ctx, st, oe + "mlp_pointnet.0", 256, kTD, P))) return rc;
+  }
+  if (cfg->use_color) {
+    if (cfg->color_embed) {
+      auto it = st->t.find(oe + "color_embedding.weight");
+      if (it == st->t.end() || !it->second.grad || it->second.numel % kTD) return fail(ctx, T2L_EINVAL, "t2l_train_bind: color_embedding.weight");
+      P.push_back(oe + "color_embedding.weight");
+    } else {
+      if ((rc = check_mlp_layer(ctx, st, oe + "color_encoder.0", 3, 64, P))) return rc;
+      if ((rc = check_mlp_layer(ctx, st, oe + "color_encoder.1", 64, kTD, P))) return rc;
+    }
+  }
+  if (cfg->use_position) {
+    if ((rc = check_mlp_layer(ctx, st, oe + "pos_encoder.0", 3, 64, P))) return rc;
+    if ((rc = check_mlp_layer(ctx, st, oe + "pos_encoder.1", 64, kTD, P))) return rc;
+  }
+  if (cfg->use_num) {
+    if ((rc = check_mlp_layer(ctx, st, oe + "num_encoder.0", 1, 64, P))) return rc;
+    if ((rc = check_mlp_layer(ctx, st, oe + "num_encoder.1", 64, kTD, P))) return rc;
+  }
+  if ((rc = check_mlp_layer(ctx, st, oe + "mlp_merge.0", n_feat * kTD, kTD, P))) return rc;
+  for (int l = 0; l < cfg->num_layers; ++l) {
+    const std::string p = "obj_inter_module." + std::to_string(l);
+    const std::pair<const char*, int64_t> req[] = {
+        {".self_attn.in_proj_weight", 3 * kTD * kTD}, {".self_attn.in_proj_bias", 3 * kTD},
+        {".self_attn.out_proj.weight", kTD * kTD},    {".self_attn.out_proj.bias", kTD},
+        {".linear1.weight", 2 * kTD * kTD},           {".linear1.bias", 2 * kTD},
+        {".linear2.weight", 2 * kTD * kTD},           {".linear2.bias", kTD},
+        {".norm1.weight", kTD},                       {".norm1.bias", kTD},
+        {".norm2.weight", kTD},                       {".norm2.bias", kTD}};
+    for (auto& r : req) {
+      if ((rc = need(ctx, st, p + r.first, r.second, true, nullptr))) return rc;
+      P.push_back(p + r.first);
+    }
+  }
+  // Adam tables: moments zero-initialised, one chunk per 1,024 elements
+  std::vector<AdamTensor> ts;
+  std::vector<AdamChunk> cs;
+  int64_t total = 0;
+  for (auto& nme : P) total += st->t[nme].numel;
+  T2L_HIP(ctx, hipMalloc(&st->mv, sizeof(float) * 2 * (size_t)total));
+  T2L_HIP(ctx, hipMemset(st->mv, 0, sizeof(float) * 2 * (size_t)total));
+  int64_t off = 0;
+  for (auto& nme : P) {
+    const TTensor& t = st->t[nme];
+    ts.push_back(AdamTensor{t.data, t.grad, st->mv + off, st->mv + total + off, t.numel});
+    for (int64_t c = 0; c * 1024 < t.numel; ++c) cs.push_back(AdamChunk{(int32_t)ts.size() - 1, (int32_t)c});
+    off += t.numel;
+  }
+  st->n_chunks = (int)cs.size();
+  T2L_HIP(ctx, hipMalloc(&st->d_tensors, sizeof(AdamTensor) * ts.size()));
+  T2L_HIP(ctx, hipMalloc(&st->d_chunks, sizeof(AdamChunk) * cs.size()));
+  T2L_HIP(ctx, hipMemcpy(st->d_tensors, ts.data(), sizeof(AdamTensor) * ts.size(), hipMemcpyHostToDevice));
+  T2L_HIP(ctx, hipMemcpy(st->d_chunks, cs.data(), sizeof(AdamChunk) * cs.size(), hipMemcpyHostToDevice));
+  return T2L_OK;
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------
+static void mlp_layer_fwd(TrainState* st, MlpLayer& L, const float* x, int M, int small_k, int standardize, hipStream_t s) {
+  const TTensor& W = T_(st, L.prefix + ".0.weight");
+  const TTensor& b = T_(st, L.prefix + ".0.bias");
+  if (small_k)
+    hipLaunchKernelGGL(smallk_fwd_kernel, dim3((M * 64 + 255) / 256), dim3(256), 0, s, x, M, small_k, W.data, b.data, standardize,
+                       1826.6844940968194f, 2516.8905096993817f, L.y);
+  else
+    gemm_nt(x, W.data, b.data, L.y, M, L.cout, L.cin, 0, s);
+  hipLaunchKernelGGL(bn_fwd_kernel, dim3(L.cout / 16), dim3(256), 0, s, L.y, M, L.cout, T_(st, L.prefix + ".1.weight").data,
+                     T_(st, L.prefix + ".1.bias").data, T_(st, L.prefix + ".1.running_mean").data,
+                     T_(st, L.prefix + ".1.running_var").data, 0.1f, L.a, L.mean, L.rstd);
+}
+
+static MlpLayer make_layer(TrainState* st, const std::string& prefix, int cin, int cout, int M) {
+  MlpLayer L;
+  L.prefix = prefix;
+  L.cin = cin;
+  L.cout = cout;
+  L.y = bump<float>(st, (size_t)M * cout);
+  L.a = bump<float>(st, (size_t)M * cout);
+  L.mean = bump<float>(st, cout);
+  L.rstd = bump<float>(st, cout);
+  return L;
+}
+
+int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32_t seed, float* out_emb, hipStream_t s) {
+  TrainState* st = state(ctx);
+  if (!st) return fail(ctx, T2L_ESTATE, "t2l_encode_cells_train: call t2l_train_bind first");
+  if (!in || !out_emb || in->n_cells <= 0 || in->n_objects <= 1 || !in->offsets)
+    return fail(ctx, T2L_EINVAL, "t2l_encode_cells_train: bad arguments (BatchNorm batch statistics need >= 2 objects)");
+  if (!(p >= 0.f && p < 1.f)) return fail(ctx, T2L_EINVAL, "t2l_encode_cells_train: dropout_p must be in [0,1)");
+  const t2l_model_config& c = st->cfg;
+  if ((c.use_class && (c.class_embed ? !in->class_idx : !in->pn_feat)) || (c.use_color && (c.color_embed ? !in->color_idx : !in->rgb)) ||
+      (c.use_position && !in->center) || (c.use_num && !in->n_pts))
+    return fail(ctx, T2L_EINVAL, "t2l_encode_cells_train: a packed input the configuration needs is NULL");
+  const int M = in->n_objects, B = in->n_cells, T = B * kTS, Kc = st->n_feat * kTD;
+  if ((uint64_t)T * 2 * kTD >= (1ull << 32)) return fail(ctx, T2L_EINVAL, "t2l_encode_cells_train: batch too large for the dropout counters");
+  // workspace: generous closed-form bound, grown on demand
+  const size_t need_bytes =
+      sizeof(float) * ((size_t)M * (2 * Kc + 20 * kTD) + (size_t)T * kTD * 16 +
+                       (size_t)c.num_layers * ((size_t)T * (13 * kTD + 8) + (size_t)B * kTH * kTS * kTS) + (size_t)B * kTD * 4) +
+      (1 << 20);
+  if (need_bytes > st->ws_cap) {
+    if (st->ws) (void)hipFree(st->ws);
+    st->ws = nullptr;
+    st->ws_cap = 0;
+    T2L_HIP(ctx, hipMalloc(&st->ws, need_bytes));
+    st->ws_cap = need_bytes;
+  }
+  st->ws_off = 0;
+  st->have_forward = false;
+  st->M = M; st->B = B; st->T = T;
+  st->offsets = in->offsets;
+  st->seed = seed;
+  st->p = p;
+  st->branches.clear();
+  st->layers.clear();
+  event_begin(ctx, "train_forward", s);
+
+  st->cat = bump<float>(st, (size_t)M * Kc);
+  const std::string oe = "object_encoder.";
+  int slot = 0;
+  auto small_branch = [&](const std::string& name, const float* x, int k, int standardize) {
+    Branch br;
+    br.kind = 1; br.slot = slot++; br.x = x; br.k_in = k; br.standardize = standardize;
+    br.layers.push_back(make_layer(st, oe + name + ".0", k, 64, M));
+    br.layers.push_back(make_layer(st, oe + name + ".1", 64, kTD, M));
+    br.save_n = bump<float>(st, M);
+    mlp_layer_fwd(st, br.layers[0], x, M, k, standardize, s);
+    mlp_layer_fwd(st, br.layers[1], br.layers[0].a, M, 0, 0, s);
+    hipLaunchKernelGGL(rownorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, br.layers[1].a, (const int32_t*)nullptr, M,
+                       st->cat + br.slot * kTD, Kc, br.save_n);
+    st->branches.push_back(br);
+  };
+  auto embed_branch = [&](const std::string& table, const int32_t* idx) {
+    Branch br;
+    br.kind = 0; br.slot = slot++; br.table = oe + table; br.idx = idx;
+    br.save_n = bump<float>(st, M);
+    hipLaunchKernelGGL(rownorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, T_(st, br.table).data, idx, M, st->cat + br.slot * kTD, Kc,
+                       br.save_n);
+    st->branches.push_back(br);
+  };
+  if (c.use_class) {
+    if (c.class_embed) {
+      embed_branch("class_embedding.weight", in->class_idx);
+    } else {  // PointNet++ features2 -> mlp_pointnet (object_encoder.py:86-99,112)
+      Branch br;
+      br.kind = 2; br.slot = slot++; br.x = in->pn_feat; br.k_in = 256;
+      br.layers.push_back(make_layer(st, oe + "mlp_pointnet.0", 256, kTD, M));
+      br.save_n = bump<float>(st, M);
+      mlp_layer_fwd(st, br.layers[0], in->pn_feat, M, 0, 0, s);
+      hipLaunchKernelGGL(rownorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, br.layers[0].a, (const int32_t*)nullptr, M,
+                         st->cat + br.slot * kTD, Kc, br.save_n);
+      st->branches.push_back(br);
+    }
+  }
+  if (c.use_color) {
+    if (c.color_embed) embed_branch("color_embedding.weight", in->color_idx);
+    else small_branch("color_encoder", in->rgb, 3, 0);
+  }
+  if (c.use_position) small_branch("pos_encoder", in->center, 3, 0);
+  if (c.use_num) small_branch("num_encoder", in->n_pts, 1, 1);
+
+  st->merge = make_layer(st, oe + "mlp_merge.0", Kc, kTD, M);
+  mlp_layer_fwd(st, st->merge, st->cat, M, 0, 0, s);
+  st->X0 = bump<float>(st, (size_t)T * kTD);
+  st->save_nf = bump<float>(st, M);
+  hipLaunchKernelGGL(scatter_norm_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, st->merge.a, in->offsets, B, st->X0, st->save_nf);
+
+  float* tmp = bump<float>(st, (size_t)T * kTD);
+  const float* x = st->X0;
+  for (int l = 0; l < c.num_layers; ++l) {
+    LayerSave L;
+    L.prefix = "obj_inter_module." + std::to_string(l);
+    L.x_in = x;
+    L.qkv = bump<float>(st, (size_t)T * 3 * kTD);
+    L.P = bump<float>(st, (size_t)B * kTH * kTS * kTS);
+    L.O = bump<float>(st, (size_t)T * kTD);
+    L.xhat1 = bump<float>(st, (size_t)T * kTD);
+    L.rstd1 = bump<float>(st, T);
+    L.x1 = bump<float>(st, (size_t)T * kTD);
+    L.h = bump<float>(st, (size_t)T * 2 * kTD);
+    L.hd = p > 0.f ? bump<float>(st, (size_t)T * 2 * kTD) : L.h;
+    L.xhat2 = bump<float>(st, (size_t)T * kTD);
+    L.rstd2 = bump<float>(st, T);
+    L.x2 = bump<float>(st, (size_t)T * kTD);
+    gemm_nt(x, T_(st, L.prefix + ".self_attn.in_proj_weight").data, T_(st, L.prefix + ".self_attn.in_proj_bias").data, L.qkv, T, 3 * kTD, kTD, 0, s);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * kTH), dim3(256), 0, s, L.qkv, L.P, L.O, make_drop(seed, l * 4 + 0, p));
+    gemm_nt(L.O, T_(st, L.prefix + ".self_attn.out_proj.weight").data, T_(st, L.prefix + ".self_attn.out_proj.bias").data, tmp, T, kTD, kTD, 0, s);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, x, tmp, T, T_(st, L.prefix + ".norm1.weight").data,
+                       T_(st, L.prefix + ".norm1.bias").data, make_drop(seed, l * 4 + 1, p), L.x1, L.xhat1, L.rstd1);
+    gemm_nt(L.x1, T_(st, L.prefix + ".linear1.weight").data, T_(st, L.prefix + ".linear1.bias").data, L.h, T, 2 * kTD, kTD, 1, s);
+    if (p > 0.f) {
+      const size_t n = (size_t)T * 2 * kTD;
+      hipLaunchKernelGGL(drop_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, L.h, n, make_drop(seed, l * 4 + 2, p), L.hd);
+    }
+    gemm_nt(L.hd, T_(st, L.prefix + ".linear2.weight").data, T_(st, L.prefix + ".linear2.bias").data, tmp, T, kTD, 2 * kTD, 0, s);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, L.x1, tmp, T, T_(st, L.prefix + ".norm2.weight").data,
+                       T_(st, L.prefix + ".norm2.bias").data, make_drop(seed, l * 4 + 3, p), L.x2, L.xhat2, L.rstd2);
+    x = L.x2;
+    st->layers.push_back(L);
+  }
+  st->out = bump<float>(st, (size_t)B * kTD);
+  st->pool_n = bump<float>(st, B);
+  st->pool_arg = bump<int32_t>(st, (size_t)B * kTD);
+  hipLaunchKernelGGL(pool_norm_fwd_kernel, dim3(B), dim3(256), 0, s, x, st->out, st->pool_arg, st->pool_n);
+  T2L_HIP(ctx, hipMemcpyAsync(out_emb, st->out, sizeof(float) * (size_t)B * kTD, hipMemcpyDeviceToDevice, s));
+  event_end(ctx, "train_forward", s);
+  T2L_HIP(ctx, hipGetLastError());
+  if (st->ws_off > st->ws_cap) return fail(ctx, T2L_ENOMEM, "t2l_encode_cells_train: workspace bound exceeded (internal error)");
+  st->have_forward = true;
+  return T2L_OK;
+}
+
+// ---- backward --------------------------------------------------------------------------------------------------
+// d: gradient w.r.t. the block's ReLU output [M,cout] (overwritten); x: the block's input; dx (optional) receives d W.
+static void mlp_layer_bwd(TrainState* st, const MlpLayer& L, float* d, const float* x, int M, int small_k, int standardize, float* dx,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_kernel, dim3(L.cout / 16), dim3(256), 0, s, d, L.a, L.y, M, L.cout, T_(st, L.prefix + ".1.weight").data, L.mean,
+                     L.rstd, T_(st, L.prefix + ".1.weight").grad, T_(st, L.prefix + ".1.bias").grad);
+  colsum(d, M, L.cout, T_(st, L.prefix + ".0.bias").grad, s);
+  if (small_k) {
+    const int rows = 256;
+    hipLaunchKernelGGL(smallk_bwd_kernel, dim3((M + rows - 1) / rows), dim3(256), 0, s, x, M, small_k, d, standardize, 1826.6844940968194f,
+                       2516.8905096993817f, rows, T_(st, L.prefix + ".0.weight").grad);
+  } else {
+    gemm_tn(d, x, T_(st, L.prefix + ".0.weight").grad, M, L.cout, L.cin, s);
+    if (dx) gemm_nn(d, T_(st, L.prefix + ".0.weight").data, dx, M, L.cout, L.cin, 0, s);
+  }
+}
+
+int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat, hipStream_t s) {
+  TrainState* st = state(ctx);
+  if (!st || !st->have_forward) return fail(ctx, T2L_ESTATE, "t2l_encode_cells_backward: no forward pass to differentiate");
+  if (!grad_emb) return fail(ctx, T2L_EINVAL, "t2l_encode_cells_backward: null gradient");
+  const int M = st->M, B = st->B, T = st->T, Kc = st->n_feat * kTD;
+  const size_t mark = st->ws_off;
+  event_begin(ctx, "train_backward", s);
+  float* dcur = bump<float>(st, (size_t)T * kTD);
+  float* dA = bump<float>(st, (size_t)T * kTD);
+  float* dB = bump<float>(st, (size_t)T * kTD);
+  float* dC = bump<float>(st, (size_t)T * kTD);
+  float* dO = bump<float>(st, (size_t)T * kTD);
+  float* dH = bump<float>(st, (size_t)T * 2 * kTD);
+  float* dqkv = bump<float>(st, (size_t)T * 3 * kTD);
+  float* dfeat = bump<float>(st, (size_t)M * kTD);
+  float* dcat = bump<float>(st, (size_t)M * Kc);
+  float* d2 = bump<float>(st, (size_t)M * kTD);
+  float* d1 = bump<float>(st, (size_t)M * 64);
+  if (st->ws_off > st->ws_cap) {
+    st->ws_off = mark;
+    return fail(ctx, T2L_ENOMEM, "t2l_encode_cells_backward: workspace bound exceeded (internal error)");
+  }
+  const float* xl = st->layers.empty() ? st->X0 : st->layers.back().x2;
+  (void)xl;
+  hipLaunchKernelGGL(pool_norm_bwd_kernel, dim3(B), dim3(256), 0, s, grad_emb, st->out, st->pool_arg, st->pool_n, dcur);
+  const int ln_grid = std::min(256, (T + 3) / 4);
+  for (int l = (int)st->layers.size() - 1; l >= 0; --l) {
+    const LayerSave& L = st->layers[l];
+    auto W = [&](const char* n) -> const TTensor& { return T_(st, L.prefix + n); };
+    // norm2 + dropout2
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_grid), dim3(256), 0, s, dcur, L.xhat2, L.rstd2, T, W(".norm2.weight").data,
+                       make_drop(st->seed, l * 4 + 3, st->p), dA, dB, W(".norm2.weight").grad, W(".norm2.bias").grad);
+    // linear2
+    colsum(dB, T, kTD, W(".linear2.bias").grad, s);
+    gemm_tn(dB, L.hd, W(".linear2.weight").grad, T, kTD, 2 * kTD, s);
+    gemm_nn(dB, W(".linear2.weight").data, dH, T, kTD, 2 * kTD, 0, s);
+    {
+      const size_t n = (size_t)T * 2 * kTD;
+      hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dH, L.h, n,
+                         make_drop(st->seed, l * 4 + 2, st->p));
+    }
+    // linear1; dA (= dz2, the residual path) += dH W1
+    colsum(dH, T, 2 * kTD, W(".linear1.bias").grad, s);
+    gemm_tn(dH, L.x1, W(".linear1.weight").grad, T, 2 * kTD, kTD, s);
+    gemm_nn(dH, W(".linear1.weight").data, dA, T, 2 * kTD, kTD, 1, s);
+    // norm1 + dropout1
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_grid), dim3(256), 0, s, dA, L.xhat1, L.rstd1, T, W(".norm1.weight").data,
+                       make_drop(st->seed, l * 4 + 1, st->p), dC, dB, W(".norm1.weight").grad, W(".norm1.bias").grad);
+    // out_proj
+    colsum(dB, T, kTD, W(".self_attn.out_proj.bias").grad, s);
+    gemm_tn(dB, L.O, W(".self_attn.out_proj.weight").grad, T, kTD, kTD, s);
+    gemm_nn(dB, W(".self_attn.out_proj.weight").data, dO, T, kTD, kTD, 0, s);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * kTH), dim3(256), 0, s, L.qkv, L.P, dO, dqkv, make_drop(st->seed, l * 4 + 0, st->p));
+    // in_proj; dC (= dz1, the residual path) += dqkv Win
+    colsum(dqkv, T, 3 * kTD, W(".self_attn.in_proj_bias").grad, s);
+    gemm_tn(dqkv, L.x_in, W(".self_attn.in_proj_weight").grad, T, 3 * kTD, kTD, s);
+    gemm_nn(dqkv, W(".self_attn.in_proj_weight").data, dC, T, 3 * kTD, kTD, 1, s);
+    std::swap(dcur, dC);
+  }
+  // tokens -> objects, merge MLP
+  hipLaunchKernelGGL(scatter_norm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dcur, st->X0, st->save_nf, st->offsets, B, M, dfeat);
+  mlp_layer_bwd(st, st->merge, dfeat, st->cat, M, 0, 0, dcat, s);
+  for (const Branch& br : st->branches) {
+    const float* dslot = dcat + br.slot * kTD;
+    const float* yslot = st->cat + br.slot * kTD;
+    if (br.kind == 0) {
+      hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dslot, yslot, Kc, br.save_n, br.idx, M,
+                         T_(st, br.table).grad);
+      continue;
+    }
+    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dslot, yslot, Kc, br.save_n, (const int32_t*)nullptr, M, d2);
+    if (br.kind == 2) {
+      mlp_layer_bwd(st, br.layers[0], d2, br.x, M, 0, 0, grad_pn_feat, s);
+    } else {
+      mlp_layer_bwd(st, br.layers[1], d2, br.layers[0].a, M, 0, 0, d1, s);
+      mlp_layer_bwd(st, br.layers[0], d1, br.x, M, br.k_in, br.standardize, nullptr, s);
+    }
+  }
+  event_end(ctx, "train_backward", s);
+  st->ws_off = mark;
+  T2L_HIP(ctx, hipGetLastError());
+  return T2L_OK;
+}
+
+int adam_step_impl(t2l_ctx* ctx, float lr, float b1, float b2, float eps, hipStream_t s) {
+  TrainState* st = state(ctx);
+  if (!st) return fail(ctx, T2L_ESTATE, "t2l_adam_step: call t2l_train_bind first");
+  st->step += 1;
+  const float bc1 = (float)(1.0 - pow((double)b1, (double)st->step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)b2, (double)st->step));
+  event_begin(ctx, "adam_step", s);
+  hipLaunchKernelGGL(adam_kernel, dim3(st->n_chunks), dim3(256), 0, s, st->d_tensors, st->d_chunks, lr, b1, b2, eps, bc1, bc2s);
+  event_end(ctx, "adam_step", s);
+  T2L_HIP(ctx, hipGetLastError());
+  return T2L_OK;
+}
+
+int zero_grad_impl(t2l_ctx* ctx, hipStream_t s) {
+  TrainState* st = state(ctx);
+  if (!st) return fail(ctx, T2L_ESTATE, "t2l_zero_grad: call t2l_train_bind first");
+  hipLaunchKernelGGL(zero_kernel, dim3(st->n_chunks), dim3(256), 0, s, st->d_tensors, st->d_chunks);
+  T2L_HIP(ctx, hipGetLastError());
+  return T2L_OK;
+}
+
+}  // namespace t2l

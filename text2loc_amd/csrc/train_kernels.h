@@ -1,0 +1,624 @@
+// Device kernels of the object-branch TRAINING step: forward in model.train() mode with saved
+// activations, backward, Adam. gfx950 only. All arithmetic is f32 (the reference trains in f32); contractions run on
+// v_mfma_f32_32x32x2_f32. The step is small (B=64 cells -> 1,792 tokens, ~12 GFLOP fwd+bwd) and latency-bound, so the
+// kernels are modular (one per op of the autograd graph) rather than fused per cell like the eval encoder.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace t2l {
+namespace train {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTD = 256;    // embed dim
+constexpr int kTS = 28;     // object slots (tokens) per cell
+constexpr int kTH = 4;      // heads
+constexpr int kTHd = 64;    // head dim
+constexpr float kBnEps = 1e-5f, kLnEps = 1e-5f, kNormEps = 1e-12f;
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Counter-based dropout: keep element `idx` of site `site` iff the top 24 bits of lowbias32(idx*0x9E3779B1 + key) >= thr,
+// key = seed ^ site*0x85EBCA77, thr = p*2^24. oracle/t2l_oracle_train.py:dropout_keep is the same function.
+__device__ __forceinline__ bool keep_bit(uint32_t key, uint32_t idx, uint32_t thr) {
+  uint32_t x = idx * 0x9E3779B1u + key;
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return (x >> 8) >= thr;
+}
+struct Drop {
+  uint32_t key, thr;
+  float scale;  // 1/(1-p); thr == 0 -> identity
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// GEMM: C[M,N] (+)= A(m,k) B(k,n) (+ bias[n]) (relu). 64x64 tile per workgroup (4 waves, one 32x32 MFMA tile each),
+// BK = 16, operands staged k-major in LDS so that the MFMA operand reads are conflict-free.
+//   A_KC: A[m*lda + k] (k contiguous)  else A[k*lda + m]
+//   B_KC: B[n*ldb + k] (k contiguous)  else B[k*ldb + n]
+// Ragged dims: rows m >= M are skipped when A_KC; the reduction range [kb,ke) may end anywhere when both operands are
+// row-major over k (dW = dY^T X, reduction over tokens). N (and M when !A_KC) must be multiples of 64.
+// ---------------------------------------------------------------------------------------------------------------
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  int M, N, K, lda, ldb, ldc, relu, accumulate, kchunk;
+};
+
+constexpr int kGS = 96;  // LDS row stride (floats): 64 + 32 so the two k-halves of a wave hit disjoint banks
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  __shared__ float As[16 * kGS];
+  __shared__ float Bs[16 * kGS];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+  const int kb = blockIdx.z * g.kchunk, ke = min(g.K, kb + g.kchunk);
+  const int wm = w & 1, wn = w >> 1, col = lane & 31, kh = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float4 ra, rb;
+  auto load = [&](int kt) {
+    ra = make_float4(0.f, 0.f, 0.f, 0.f);
+    rb = ra;
+    if (A_KC) {
+      const int r = tid >> 2, k = kt + (tid & 3) * 4, m = m0 + r;
+      if (m < g.M && k < ke) ra = *reinterpret_cast<const float4*>(g.A + (size_t)m * g.lda + k);
+    } else {
+      const int k = kt + (tid >> 4), mq = (tid & 15) * 4;
+      if (k < ke) ra = *reinterpret_cast<const float4*>(g.A + (size_t)k * g.lda + m0 + mq);
+    }
+    if (B_KC) {
+      const int r = tid >> 2, k = kt + (tid & 3) * 4;
+      if (k < ke) rb = *reinterpret_cast<const float4*>(g.B + (size_t)(n0 + r) * g.ldb + k);
+    } else {
+      const int k = kt + (tid >> 4), nq = (tid & 15) * 4;
+      if (k < ke) rb = *reinterpret_cast<const float4*>(g.B + (size_t)k * g.ldb + n0 + nq);
+    }
+  };
+  auto store = [&]() {
+    if (A_KC) {
+      const int r = tid >> 2, kq = (tid & 3) * 4;
+      As[(kq + 0) * kGS + r] = ra.x;
+      As[(kq + 1) * kGS + r] = ra.y;
+      As[(kq + 2) * kGS + r] = ra.z;
+      As[(kq + 3) * kGS + r] = ra.w;
+    } else {
+      *reinterpret_cast<float4*>(&As[(tid >> 4) * kGS + (tid & 15) * 4]) = ra;
+    }
+    if (B_KC) {
+      const int r = tid >> 2, kq = (tid & 3) * 4;
+      Bs[(kq + 0) * kGS + r] = rb.x;
+      Bs[(kq + 1) * kGS + r] = rb.y;
+      Bs[(kq + 2) * kGS + r] = rb.z;
+      Bs[(kq + 3) * kGS + r] = rb.w;
+    } else {
+      *reinterpret_cast<float4*>(&Bs[(tid >> 4) * kGS + (tid & 15) * 4]) = rb;
+    }
+  };
+  if (kb < ke) load(kb);
+  for (int kt = kb; kt < ke; kt += 16) {
+    store();
+    __syncthreads();
+    if (kt + 16 < ke) load(kt + 16);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const float a = As[(2 * kk + kh) * kGS + wm * 32 + col];
+      const float b = Bs[(2 * kk + kh) * kGS + wn * 32 + col];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int cg = n0 + wn * 32 + col;
+  const float bv = (g.bias && blockIdx.z == 0) ? g.bias[cg] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+    if (row < g.M) {
+      float v = acc[r] + bv;
+      if (g.relu) v = fmaxf(v, 0.f);
+      float* dst = g.C + (size_t)row * g.ldc + cg;
+      if (g.accumulate)
+        unsafeAtomicAdd(dst, v);
+      else
+        *dst = v;
+    }
+  }
+}
+
+// out[n] += sum_m X[m*ld + n]   (bias gradients). grid (N/64, row chunks), 256 threads = 64 columns x 4 row lanes.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int ld, int rows_per_block,
+                                                     float* __restrict__ out) {
+  __shared__ float red[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  const int lo = blockIdx.y * rows_per_block, hi = min(M, lo + rows_per_block);
+  float s = 0.f;
+  for (int m = lo + g; m < hi; m += 4) s += X[(size_t)m * ld + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0) unsafeAtomicAdd(out + c, red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// first Linear of the small branches (K = 1 or 3 inputs -> 64): y[m][c] = b[c] + sum_k x[m][k] w[c][k]
+// standardize: x = (n_pts - mean)/std evaluated in f32 exactly as the reference's tensor expression
+// (models/object_encoder.py:141-144).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float small_in(const float* x, int m, int K, int k, int standardize, float mean, float stdv) {
+  float v = x[(size_t)m * K + k];
+  return standardize ? (v - mean) / stdv : v;
+}
+__global__ void smallk_fwd_kernel(const float* __restrict__ x, int M, int K, const float* __restrict__ w,
+                                  const float* __restrict__ b, int standardize, float mean, float stdv,
+                                  float* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * 64) return;
+  const int m = i >> 6, c = i & 63;
+  float s = b[c];
+  for (int k = 0; k < K; ++k) s += small_in(x, m, K, k, standardize, mean, stdv) * w[c * K + k];
+  y[i] = s;
+}
+// dW[c][k] += sum_m dy[m][c] x[m][k]   grid = row chunks, 256 threads = 64 channels x 4 row lanes
+__global__ __launch_bounds__(256) void smallk_bwd_kernel(const float* __restrict__ x, int M, int K,
+                                                         const float* __restrict__ dy, int standardize, float mean,
+                                                         float stdv, int rows_per_block, float* __restrict__ dW) {
+  __shared__ float red[3][256];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int lo = blockIdx.x * rows_per_block, hi = min(M, lo + rows_per_block);
+  float s[3] = {0.f, 0.f, 0.f};
+  for (int m = lo + g; m < hi; m += 4) {
+    const float d = dy[(size_t)m * 64 + c];
+    for (int k = 0; k < K; ++k) s[k] += d * small_in(x, m, K, k, standardize, mean, stdv);
+  }
+  for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = s[k];
+  __syncthreads();
+  if (g == 0)
+    for (int k = 0; k < K; ++k)
+      unsafeAtomicAdd(dW + c * K + k, red[k][c] + red[k][c + 64] + red[k][c + 128] + red[k][c + 192]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm1d in training mode (+ ReLU): batch statistics over the M rows, two-pass variance, running statistics
+// updated with the unbiased variance (momentum 0.1). One workgroup per 16 channels (16 x 16 threads).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bn_block_sum(float v, float* red) {  // sum over the 16 row lanes of each channel
+  const int cx = threadIdx.x & 15;
+  __syncthreads();
+  red[threadIdx.x] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += red[r * 16 + cx];
+  return s;
+}
+__global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ y, int M, int C,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                     float momentum, float* __restrict__ out, float* __restrict__ save_mean,
+                                                     float* __restrict__ save_rstd) {
+  __shared__ float red[256];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4, c = blockIdx.x * 16 + cx;
+  float s = 0.f;
+  for (int m = ry; m < M; m += 16) s += y[(size_t)m * C + c];
+  const float mean = bn_block_sum(s, red) / (float)M;
+  float q = 0.f;
+  for (int m = ry; m < M; m += 16) {
+    const float d = y[(size_t)m * C + c] - mean;
+    q += d * d;
+  }
+  const float var = bn_block_sum(q, red) / (float)M;
+  const float rstd = 1.0f / sqrtf(var + kBnEps);
+  const float ga = gamma[c], be = beta[c];
+  for (int m = ry; m < M; m += 16) out[(size_t)m * C + c] = fmaxf((y[(size_t)m * C + c] - mean) * rstd * ga + be, 0.f);
+  if (ry == 0) {
+    save_mean[c] = mean;
+    save_rstd[c] = rstd;
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * ((float)M / (float)max(M - 1, 1));
+  }
+}
+// d: gradient w.r.t. the ReLU output (in), overwritten with the gradient w.r.t. the Linear output y.
+__global__ __launch_bounds__(256) void bn_bwd_kernel(float* __restrict__ d, const float* __restrict__ out,
+                                                     const float* __restrict__ y, int M, int C,
+                                                     const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                     const float* __restrict__ save_rstd, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta) {
+  __shared__ float red[256];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4, c = blockIdx.x * 16 + cx;
+  const float mean = save_mean[c], rstd = save_rstd[c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int m = ry; m < M; m += 16) {
+    const size_t i = (size_t)m * C + c;
+    const float dv = out[i] > 0.f ? d[i] : 0.f;
+    s1 += dv;
+    s2 += dv * (y[i] - mean) * rstd;
+  }
+  s1 = bn_block_sum(s1, red);
+  s2 = bn_block_sum(s2, red);
+  const float k = gamma[c] * rstd / (float)M;
+  for (int m = ry; m < M; m += 16) {
+    const size_t i = (size_t)m * C + c;
+    const float dv = out[i] > 0.f ? d[i] : 0.f;
+    d[i] = k * ((float)M * dv - s1 - (y[i] - mean) * rstd * s2);
+  }
+  if (ry == 0) {
+    unsafeAtomicAdd(dgamma + c, s2);
+    unsafeAtomicAdd(dbeta + c, s1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// F.normalize over 256-wide rows: one wave per row, 4 floats per lane.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 norm_fwd(float4 v, float& n) {
+  n = fmaxf(sqrtf(wsum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w)), kNormEps);
+  return make_float4(v.x / n, v.y / n, v.z / n, v.w / n);
+}
+__device__ __forceinline__ float4 norm_bwd(float4 dy, float4 y, float n) {
+  if (n <= kNormEps) return make_float4(dy.x / kNormEps, dy.y / kNormEps, dy.z / kNormEps, dy.w / kNormEps);
+  const float t = wsum(dy.x * y.x + dy.y * y.y + dy.z * y.z + dy.w * y.w);
+  return make_float4((dy.x - y.x * t) / n, (dy.y - y.y * t) / n, (dy.z - y.z * t) / n, (dy.w - y.w * t) / n);
+}
+// src row = table[idx[m]] when idx != nullptr (embedding lookup) else src[m]; dst row stride ldd (a 256-wide slot of cat)
+__global__ void rownorm_fwd_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int M,
+                                   float* __restrict__ dst, int ldd, float* __restrict__ save_n) {
+  const int m = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (m >= M) return;
+  const size_t row = idx ? (size_t)idx[m] : (size_t)m;
+  const float4 v = *reinterpret_cast<const float4*>(src + row * kTD + lane * 4);
+  float n;
+  const float4 y = norm_fwd(v, n);
+  *reinterpret_cast<float4*>(dst + (size_t)m * ldd + lane * 4) = y;
+  if (lane == 0) save_n[m] = n;
+}
+// dx = normalize_bwd(dy, y, n). idx == nullptr: dx[m] written; else atomically added to dtable[idx[m]] (row 0 = padding_idx
+// never receives gradient, models/object_encoder.py:33,37).
+__global__ void rownorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int ld,
+                                   const float* __restrict__ save_n, const int32_t* __restrict__ idx, int M,
+                                   float* __restrict__ dx) {
+  const int m = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (m >= M) return;
+  const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)m * ld + lane * 4);
+  const float4 yy = *reinterpret_cast<const float4*>(y + (size_t)m * ld + lane * 4);
+  const float4 g = norm_bwd(d, yy, save_n[m]);
+  if (!idx) {
+    *reinterpret_cast<float4*>(dx + (size_t)m * kTD + lane * 4) = g;
+  } else if (idx[m] != 0) {
+    float* t = dx + (size_t)idx[m] * kTD + lane * 4;
+    unsafeAtomicAdd(t + 0, g.x);
+    unsafeAtomicAdd(t + 1, g.y);
+    unsafeAtomicAdd(t + 2, g.z);
+    unsafeAtomicAdd(t + 3, g.w);
+  }
+}
+// tokens: X0[b*28+s] = normalize(feats[offsets[b]+s]) for s < min(count,28), zeros otherwise (cell_retrieval.py:85-98)
+__global__ void scatter_norm_fwd_kernel(const float* __restrict__ feats, const int32_t* __restrict__ offsets, int B,
+                                        float* __restrict__ X0, float* __restrict__ save_n) {
+  const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (t >= B * kTS) return;
+  const int b = t / kTS, s = t - b * kTS;
+  const int lo = offsets[b], cnt = offsets[b + 1] - lo;
+  float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (s < cnt) {
+    float n;
+    y = norm_fwd(*reinterpret_cast<const float4*>(feats + (size_t)(lo + s) * kTD + lane * 4), n);
+    if (lane == 0) save_n[lo + s] = n;
+  }
+  *reinterpret_cast<float4*>(X0 + (size_t)t * kTD + lane * 4) = y;
+}
+// dfeats[o] = normalize_bwd(dX0[token of o]) for the kept objects, 0 for objects beyond slot 27
+__global__ void scatter_norm_bwd_kernel(const float* __restrict__ dX0, const float* __restrict__ X0,
+                                        const float* __restrict__ save_n, const int32_t* __restrict__ offsets, int B,
+                                        int M, float* __restrict__ dfeats) {
+  const int o = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (o >= M) return;
+  int lo = 0, hi = B;  // largest b with offsets[b] <= o
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (offsets[mid] <= o) lo = mid; else hi = mid;
+  }
+  const int s = o - offsets[lo];
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (s < kTS) {
+    const size_t t = (size_t)lo * kTS + s;
+    g = norm_bwd(*reinterpret_cast<const float4*>(dX0 + t * kTD + lane * 4),
+                 *reinterpret_cast<const float4*>(X0 + t * kTD + lane * 4), save_n[o]);
+  }
+  *reinterpret_cast<float4*>(dfeats + (size_t)o * kTD + lane * 4) = g;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// self-attention over the 28 slots of one cell, one workgroup per (cell, head). No padding mask (cell_retrieval.py:102).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kAS = kTHd + 1;  // LDS row stride of q/k/v tiles
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ P,
+                                                       float* __restrict__ O, Drop dr) {
+  __shared__ float q[kTS * kAS], k[kTS * kAS], v[kTS * kAS], p[kTS * (kTS + 1)];
+  const int b = blockIdx.x >> 2, h = blockIdx.x & 3, tid = threadIdx.x;
+  for (int i = tid; i < kTS * kTHd; i += 256) {
+    const int s = i >> 6, d = i & 63;
+    const float* base = qkv + (size_t)(b * kTS + s) * (3 * kTD) + h * kTHd + d;
+    q[s * kAS + d] = base[0];
+    k[s * kAS + d] = base[kTD];
+    v[s * kAS + d] = base[2 * kTD];
+  }
+  __syncthreads();
+  for (int e = tid; e < kTS * kTS; e += 256) {
+    const int i = e / kTS, j = e - i * kTS;
+    float s = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < kTHd; ++d) s += q[i * kAS + d] * k[j * kAS + d];
+    p[i * (kTS + 1) + j] = s * 0.125f;
+  }
+  __syncthreads();
+  if (tid < kTS) {
+    float* row = p + tid * (kTS + 1);
+    float mx = row[0];
+    for (int j = 1; j < kTS; ++j) mx = fmaxf(mx, row[j]);
+    float sum = 0.f;
+    for (int j = 0; j < kTS; ++j) {
+      row[j] = expf(row[j] - mx);
+      sum += row[j];
+    }
+    for (int j = 0; j < kTS; ++j) row[j] /= sum;
+  }
+  __syncthreads();
+  const size_t pbase = (size_t)blockIdx.x * kTS * kTS;
+  for (int e = tid; e < kTS * kTS; e += 256) {
+    const int i = e / kTS, j = e - i * kTS;
+    float pv = p[i * (kTS + 1) + j];
+    P[pbase + e] = pv;  // probabilities BEFORE dropout (softmax backward needs them)
+    if (dr.thr) pv = keep_bit(dr.key, (uint32_t)(pbase + e), dr.thr) ? pv * dr.scale : 0.f;
+    p[i * (kTS + 1) + j] = pv;
+  }
+  __syncthreads();
+  for (int e = tid; e < kTS * kTHd; e += 256) {
+    const int i = e >> 6, d = e & 63;
+    float s = 0.f;
+    for (int j = 0; j < kTS; ++j) s += p[i * (kTS + 1) + j] * v[j * kAS + d];
+    O[(size_t)(b * kTS + i) * kTD + h * kTHd + d] = s;
+  }
+}
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+                                                       const float* __restrict__ dO, float* __restrict__ dqkv, Drop dr) {
+  __shared__ float q[kTS * kAS], k[kTS * kAS], v[kTS * kAS], go[kTS * kAS];
+  __shared__ float p[kTS * (kTS + 1)], pd[kTS * (kTS + 1)], ds[kTS * (kTS + 1)];
+  const int b = blockIdx.x >> 2, h = blockIdx.x & 3, tid = threadIdx.x;
+  for (int i = tid; i < kTS * kTHd; i += 256) {
+    const int s = i >> 6, d = i & 63;
+    const float* base = qkv + (size_t)(b * kTS + s) * (3 * kTD) + h * kTHd + d;
+    q[s * kAS + d] = base[0];
+    k[s * kAS + d] = base[kTD];
+    v[s * kAS + d] = base[2 * kTD];
+    go[s * kAS + d] = dO[(size_t)(b * kTS + s) * kTD + h * kTHd + d];
+  }
+  const size_t pbase = (size_t)blockIdx.x * kTS * kTS;
+  for (int e = tid; e < kTS * kTS; e += 256) {
+    const int i = e / kTS, j = e - i * kTS;
+    const float pv = P[pbase + e];
+    const float m = dr.thr ? (keep_bit(dr.key, (uint32_t)(pbase + e), dr.thr) ? dr.scale : 0.f) : 1.f;
+    p[i * (kTS + 1) + j] = pv;
+    pd[i * (kTS + 1) + j] = pv * m;
+    ds[i * (kTS + 1) + j] = m;  // mask factor for now
+  }
+  __syncthreads();
+  // dV[j][d] = sum_i Pd[i][j] dO[i][d]
+  for (int e = tid; e < kTS * kTHd; e += 256) {
+    const int j = e >> 6, d = e & 63;
+    float s = 0.f;
+    for (int i = 0; i < kTS; ++i) s += pd[i * (kTS + 1) + j] * go[i * kAS + d];
+    dqkv[(size_t)(b * kTS + j) * (3 * kTD) + 2 * kTD + h * kTHd + d] = s;
+  }
+  // dP[i][j] = mask * sum_d dO[i][d] V[j][d]
+  for (int e = tid; e < kTS * kTS; e += 256) {
+    const int i = e / kTS, j = e - i * kTS;
+    float s = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < kTHd; ++d) s += go[i * kAS + d] * v[j * kAS + d];
+    ds[i * (kTS + 1) + j] *= s;
+  }
+  __syncthreads();
+  if (tid < kTS) {  // dS = P * (dP - sum_j dP*P) / sqrt(hd)
+    float t = 0.f;
+    for (int j = 0; j < kTS; ++j) t += ds[tid * (kTS + 1) + j] * p[tid * (kTS + 1) + j];
+    for (int j = 0; j < kTS; ++j)
+      ds[tid * (kTS + 1) + j] = p[tid * (kTS + 1) + j] * (ds[tid * (kTS + 1) + j] - t) * 0.125f;
+  }
+  __syncthreads();
+  for (int e = tid; e < kTS * kTHd; e += 256) {
+    const int i = e >> 6, d = e & 63;
+    float sq = 0.f, sk = 0.f;
+    for (int j = 0; j < kTS; ++j) {
+      sq += ds[i * (kTS + 1) + j] * k[j * kAS + d];  // dQ[i] = sum_j dS[i][j] K[j]
+      sk += ds[j * (kTS + 1) + i] * q[j * kAS + d];  // dK[i] = sum_j dS[j][i] Q[j]
+    }
+    float* base = dqkv + (size_t)(b * kTS + i) * (3 * kTD) + h * kTHd + d;
+    base[0] = sq;
+    base[kTD] = sk;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// out = LayerNorm(x + dropout(y)); one wave per token. Saves xhat and rstd.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y, int T,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, Drop dr,
+                              float* __restrict__ out, float* __restrict__ xhat, float* __restrict__ save_rstd) {
+  const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (t >= T) return;
+  const size_t o = (size_t)t * kTD + lane * 4;
+  float4 a = *reinterpret_cast<const float4*>(x + o);
+  float4 f = *reinterpret_cast<const float4*>(y + o);
+  if (dr.thr) {
+    f.x = keep_bit(dr.key, (uint32_t)o + 0, dr.thr) ? f.x * dr.scale : 0.f;
+    f.y = keep_bit(dr.key, (uint32_t)o + 1, dr.thr) ? f.y * dr.scale : 0.f;
+    f.z = keep_bit(dr.key, (uint32_t)o + 2, dr.thr) ? f.z * dr.scale : 0.f;
+    f.w = keep_bit(dr.key, (uint32_t)o + 3, dr.thr) ? f.w * dr.scale : 0.f;
+  }
+  a.x += f.x; a.y += f.y; a.z += f.z; a.w += f.w;
+  const float mu = wsum(a.x + a.y + a.z + a.w) * (1.f / kTD);
+  a.x -= mu; a.y -= mu; a.z -= mu; a.w -= mu;
+  const float var = wsum(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w) * (1.f / kTD);
+  const float rstd = 1.0f / sqrtf(var + kLnEps);
+  const float4 h = make_float4(a.x * rstd, a.y * rstd, a.z * rstd, a.w * rstd);
+  const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
+  const float4 be = *reinterpret_cast<const float4*>(beta + lane * 4);
+  *reinterpret_cast<float4*>(xhat + o) = h;
+  *reinterpret_cast<float4*>(out + o) = make_float4(h.x * g.x + be.x, h.y * g.y + be.y, h.z * g.z + be.z, h.w * g.w + be.w);
+  if (lane == 0) save_rstd[t] = rstd;
+}
+// dz = LN backward of dout; d_res = dz (gradient of the residual input), d_y = dz * dropout mask (gradient of y).
+// dgamma/dbeta: per-workgroup column partials, then atomics. grid = any; each workgroup strides over tokens.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ xhat,
+                                                     const float* __restrict__ save_rstd, int T,
+                                                     const float* __restrict__ gamma, Drop dr, float* __restrict__ d_res,
+                                                     float* __restrict__ d_y, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta) {
+  __shared__ float4 rg[256], rb[256];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
+  float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
+  for (int t = blockIdx.x * 4 + w; t < T; t += gridDim.x * 4) {
+    const size_t o = (size_t)t * kTD + lane * 4;
+    const float4 d = *reinterpret_cast<const float4*>(dout + o);
+    const float4 h = *reinterpret_cast<const float4*>(xhat + o);
+    ag.x += d.x * h.x; ag.y += d.y * h.y; ag.z += d.z * h.z; ag.w += d.w * h.w;
+    ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
+    const float4 dh = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+    const float m1 = wsum(dh.x + dh.y + dh.z + dh.w) * (1.f / kTD);
+    const float m2 = wsum(dh.x * h.x + dh.y * h.y + dh.z * h.z + dh.w * h.w) * (1.f / kTD);
+    const float rstd = save_rstd[t];
+    float4 dz = make_float4(rstd * (dh.x - m1 - h.x * m2), rstd * (dh.y - m1 - h.y * m2), rstd * (dh.z - m1 - h.z * m2),
+                            rstd * (dh.w - m1 - h.w * m2));
+    *reinterpret_cast<float4*>(d_res + o) = dz;
+    if (dr.thr) {
+      dz.x = keep_bit(dr.key, (uint32_t)o + 0, dr.thr) ? dz.x * dr.scale : 0.f;
+      dz.y = keep_bit(dr.key, (uint32_t)o + 1, dr.thr) ? dz.y * dr.scale : 0.f;
+      dz.z = keep_bit(dr.key, (uint32_t)o + 2, dr.thr) ? dz.z * dr.scale : 0.f;
+      dz.w = keep_bit(dr.key, (uint32_t)o + 3, dr.thr) ? dz.w * dr.scale : 0.f;
+    }
+    *reinterpret_cast<float4*>(d_y + o) = dz;
+  }
+  rg[threadIdx.x] = ag;
+  rb[threadIdx.x] = ab;
+  __syncthreads();
+  if (w == 0) {
+    for (int i = 1; i < 4; ++i) {
+      const float4 a = rg[lane + 64 * i], c = rb[lane + 64 * i];
+      ag.x += a.x; ag.y += a.y; ag.z += a.z; ag.w += a.w;
+      ab.x += c.x; ab.y += c.y; ab.z += c.z; ab.w += c.w;
+    }
+    float* pg = dgamma + lane * 4;
+    float* pb = dbeta + lane * 4;
+    unsafeAtomicAdd(pg + 0, ag.x); unsafeAtomicAdd(pg + 1, ag.y); unsafeAtomicAdd(pg + 2, ag.z); unsafeAtomicAdd(pg + 3, ag.w);
+    unsafeAtomicAdd(pb + 0, ab.x); unsafeAtomicAdd(pb + 1, ab.y); unsafeAtomicAdd(pb + 2, ab.z); unsafeAtomicAdd(pb + 3, ab.w);
+  }
+}
+
+// feed-forward hidden dropout: hd = h * mask (forward); dh = dhd * mask * (h > 0) (backward, in place)
+__global__ void drop_fwd_kernel(const float* __restrict__ h, size_t n, Drop dr, float* __restrict__ hd) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) hd[i] = keep_bit(dr.key, (uint32_t)i, dr.thr) ? h[i] * dr.scale : 0.f;
+}
+__global__ void relu_drop_bwd_kernel(float* __restrict__ d, const float* __restrict__ h, size_t n, Drop dr) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = h[i] > 0.f ? d[i] : 0.f;
+  if (dr.thr) v = keep_bit(dr.key, (uint32_t)i, dr.thr) ? v * dr.scale : 0.f;
+  d[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// max over the 28 slots (first maximal slot wins) + F.normalize: one workgroup (256 threads = columns) per cell
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+  v = wsum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void pool_norm_fwd_kernel(const float* __restrict__ X, float* __restrict__ out,
+                                                            int32_t* __restrict__ arg, float* __restrict__ save_n) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, c = threadIdx.x;
+  float mx = X[(size_t)b * kTS * kTD + c];
+  int am = 0;
+  for (int s = 1; s < kTS; ++s) {
+    const float v = X[((size_t)b * kTS + s) * kTD + c];
+    if (v > mx) { mx = v; am = s; }
+  }
+  const float n = fmaxf(sqrtf(block_sum256(mx * mx, red)), kNormEps);
+  out[(size_t)b * kTD + c] = mx / n;
+  arg[(size_t)b * kTD + c] = am;
+  if (c == 0) save_n[b] = n;
+}
+__global__ __launch_bounds__(256) void pool_norm_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ out,
+                                                            const int32_t* __restrict__ arg,
+                                                            const float* __restrict__ save_n, float* __restrict__ dX) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, c = threadIdx.x;
+  const float g = gout[(size_t)b * kTD + c], y = out[(size_t)b * kTD + c], n = save_n[b];
+  const float t = block_sum256(g * y, red);
+  const float d = n <= kNormEps ? g / kNormEps : (g - y * t) / n;
+  const int am = arg[(size_t)b * kTD + c];
+  for (int s = 0; s < kTS; ++s) dX[((size_t)b * kTS + s) * kTD + c] = (s == am) ? d : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// torch.optim.Adam (defaults: no weight decay, no amsgrad) over all bound tensors in ONE launch:
+// chunk table entry = (tensor, first element); 1,024 elements per workgroup.
+// ---------------------------------------------------------------------------------------------------------------
+struct AdamTensor {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t numel;
+};
+struct AdamChunk {
+  int32_t tensor;
+  int32_t first;  // element offset / 1024
+};
+__global__ __launch_bounds__(256) void adam_kernel(const AdamTensor* __restrict__ ts, const AdamChunk* __restrict__ cs,
+                                                   float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+  const AdamChunk c = cs[blockIdx.x];
+  const AdamTensor t = ts[c.tensor];
+  const int64_t base = (int64_t)c.first * 1024;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t i = base + j * 256 + threadIdx.x;
+    if (i < t.numel) {
+      const float g = t.g[i];
+      const float m = b1 * t.m[i] + (1.f - b1) * g;
+      const float v = b2 * t.v[i] + (1.f - b2) * g * g;
+      t.m[i] = m;
+      t.v[i] = v;
+      t.p[i] -= (lr / bc1) * m / (sqrtf(v) / bc2_sqrt + eps);
+    }
+  }
+}
+__global__ void zero_kernel(const AdamTensor* __restrict__ ts, const AdamChunk* __restrict__ cs) {
+  const AdamChunk c = cs[blockIdx.x];
+  const AdamTensor t = ts[c.tensor];
+  float* g = const_cast<float*>(t.g);
+  const int64_t base = (int64_t)c.first * 1024;
+  for (int j = 0; j < 4; ++j) {
+    const int64_t i = base + j * 256 + threadIdx.x;
+    if (i < t.numel) g[i] = 0.f;
+  }
+}
+
+}  // namespace train
+}  // namespace t2l

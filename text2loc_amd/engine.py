@@ -33,6 +33,10 @@ class _ModelConfig(C.Structure):
                                          "use_num", "num_layers", "num_heads")]
 
 
+class _TrainTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("grad", C.c_void_p), ("numel", C.c_int64)]
+
+
 class _PackedCells(C.Structure):
     _fields_ = [("n_cells", C.c_int32), ("n_objects", C.c_int32), ("offsets", C.c_void_p), ("class_idx", C.c_void_p),
                 ("color_idx", C.c_void_p), ("rgb", C.c_void_p), ("center", C.c_void_p), ("n_pts", C.c_void_p),
@@ -59,6 +63,11 @@ EXPORTS = {
     "t2l_search_fallbacks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "t2l_contrastive_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "t2l_train_bind": (C.c_int, [C.c_void_p, C.POINTER(_TrainTensor), C.c_int32, C.POINTER(_ModelConfig)]),
+    "t2l_encode_cells_train": (C.c_int, [C.c_void_p, C.POINTER(_PackedCells), C.c_float, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "t2l_encode_cells_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "t2l_zero_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "t2l_adam_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "t2l_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "t2l_kernel_stats": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
 }
@@ -188,6 +197,55 @@ class Engine:
             _dev_ptr(packed.get("pn_feat"), torch.float32, "pn_feat"))
         self._check(self.lib.t2l_encode_cells(self._h, C.byref(pc), out.data_ptr(), _stream_ptr()))
         return out
+
+    # ------------------------------------------------------------------ training step (a9)
+    def _packed_struct(self, packed: Dict[str, torch.Tensor]) -> "_PackedCells":
+        offsets = packed["offsets"]
+        n_cells = int(offsets.numel()) - 1
+        n_obj = int(packed["n_pts"].numel()) if packed.get("n_pts") is not None else int(packed["class_idx"].numel())
+        return _PackedCells(
+            n_cells, n_obj, _dev_ptr(offsets, torch.int32, "offsets"),
+            _dev_ptr(packed.get("class_idx"), torch.int32, "class_idx"),
+            _dev_ptr(packed.get("color_idx"), torch.int32, "color_idx"),
+            _dev_ptr(packed.get("rgb"), torch.float32, "rgb"), _dev_ptr(packed.get("center"), torch.float32, "center"),
+            _dev_ptr(packed.get("n_pts"), torch.float32, "n_pts"),
+            _dev_ptr(packed.get("pn_feat"), torch.float32, "pn_feat"))
+
+    def train_bind(self, tensors: Dict[str, Tuple[torch.Tensor, Optional[torch.Tensor]]], class_embed: bool,
+                   color_embed: bool, use_features=("class", "color", "position", "num"), num_layers: int = 2,
+                   num_heads: int = 4):
+        """tensors: state_dict key -> (live fp32 CUDA tensor, its gradient buffer or None for BatchNorm buffers).
+        The engine keeps the POINTERS (no copies): keep the tensors alive and re-bind if they are re-allocated."""
+        descs, keep = [], []
+        for name, (data, grad) in tensors.items():
+            keep.append((data, grad))
+            descs.append(_TrainTensor(name.encode(), _dev_ptr(data, torch.float32, name),
+                                      _dev_ptr(grad, torch.float32, name + ".grad"), data.numel()))
+        arr = (_TrainTensor * len(descs))(*descs)
+        cfg = _ModelConfig(int(class_embed), int(color_embed), int("class" in use_features),
+                           int("color" in use_features), int("position" in use_features), int("num" in use_features),
+                           int(num_layers), int(num_heads))
+        self._check(self.lib.t2l_train_bind(self._h, arr, len(descs), C.byref(cfg)))
+        self._train_keepalive = keep
+
+    def encode_cells_train(self, packed: Dict[str, torch.Tensor], dropout_p: float = 0.1, seed: int = 0) -> torch.Tensor:
+        pc = self._packed_struct(packed)
+        out = torch.empty((pc.n_cells, EMBED_DIM), dtype=torch.float32, device=packed["offsets"].device)
+        self._check(self.lib.t2l_encode_cells_train(self._h, C.byref(pc), float(dropout_p), int(seed) & 0xFFFFFFFF,
+                                                    out.data_ptr(), _stream_ptr()))
+        self._train_inputs = packed  # the device arrays must outlive the backward call
+        return out
+
+    def encode_cells_backward(self, grad_emb: torch.Tensor, grad_pn_feat: Optional[torch.Tensor] = None):
+        self._check(self.lib.t2l_encode_cells_backward(self._h, _dev_ptr(grad_emb, torch.float32, "grad_emb"),
+                                                       _dev_ptr(grad_pn_feat, torch.float32, "grad_pn_feat"),
+                                                       _stream_ptr()))
+
+    def zero_grad(self):
+        self._check(self.lib.t2l_zero_grad(self._h, _stream_ptr()))
+
+    def adam_step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
+        self._check(self.lib.t2l_adam_step(self._h, float(lr), float(beta1), float(beta2), float(eps), _stream_ptr()))
 
     # ------------------------------------------------------------------ database + search
     def db_set(self, emb: torch.Tensor, row_offset: int = 0):
