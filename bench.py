@@ -155,6 +155,51 @@ def secondary_measurements(eng):
         del d_xyz, d_rgb
     except Exception as e:
         out["reduce_objects"] = {"error": repr(e)}
+    # a9 / SURVEY.md §8d config 4: one training step of the object branch at B=64 (train-mode forward with dropout 0.1 ->
+    # contrastive loss -> backward -> Adam), text side supplied as a precomputed [64,256] batch
+    try:
+        cells64 = synth.make_cells(64, seed=9)
+        tens = {}
+        for k, v in sd.items():
+            if k.endswith("num_batches_tracked") or ".color_encoder." in k or ".mlp_pointnet." in k or ".pointnet." in k:
+                continue
+            t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda()
+            tens[k] = (t, None if "running_" in k else torch.zeros_like(t))
+        eng.train_bind(tens, class_embed=True, color_embed=True)
+        p64 = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cells64.items() if k != "counts"}
+        anchor = torch.nn.functional.normalize(torch.randn(64, 256, device="cuda"))
+
+        def train_step(i):
+            eng.zero_grad()
+            pos = eng.encode_cells_train(p64, dropout_p=0.1, seed=i)
+            loss, _, gp = eng.contrastive_loss(anchor, pos, 0.1)
+            eng.encode_cells_backward(gp)
+            eng.adam_step(1e-3)
+            return loss
+
+        for i in range(5):
+            train_step(i)
+        for nme in ("train_forward", "train_backward", "adam_step", "contrastive_loss"):
+            eng.kernel_stats(nme)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_steps = 50
+        for i in range(n_steps):
+            last = train_step(100 + i)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / n_steps
+        kept64 = int(np.minimum(cells64["counts"], 28).sum())
+        fl = 3.0 * (64 * 60.33e6 + kept64 * 0.67e6)  # forward + 2x for backward (dX and dW contractions)
+        out["train_step_b64"] = {"workload": "B=64 cells, %d objects, dropout 0.1, ContrastiveLoss(0.1), Adam" % int(cells64["offsets"][-1]),
+                                 "ms_per_step_wall": wall * 1e3,
+                                 "forward_ms": eng.kernel_stats("train_forward")[0],
+                                 "backward_ms": eng.kernel_stats("train_backward")[0],
+                                 "adam_ms": eng.kernel_stats("adam_step")[0],
+                                 "loss_ms": eng.kernel_stats("contrastive_loss")[0],
+                                 "steps_per_s": 1.0 / wall, "algorithmic_tflops": fl / wall / 1e12,
+                                 "final_loss": float(last)}
+    except Exception as e:
+        out["train_step_b64"] = {"error": repr(e)}
     rng = np.random.default_rng(0)
     a = torch.from_numpy(rng.standard_normal((64, 256)).astype(np.float32)).cuda()
     p = torch.from_numpy(rng.standard_normal((64, 256)).astype(np.float32)).cuda()

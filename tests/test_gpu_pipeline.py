@@ -113,6 +113,6 @@ def test_weights_resync_after_parameter_update():
         model.obj_inter_module[0].linear1.bias.add_(0.5)
     b = model.encode_objects(objs, [None] * 3).cpu().numpy()
     assert np.abs(a - b).max() > 1e-4  # the engine picked up the in-place update
-    model.train()
-    with pytest.raises(Exception, match="not built yet"):
-        model.encode_objects(objs, [None] * 3)
+    model.train()  # training mode is served by the engine's batch-statistics forward (tests/test_gpu_train_loop.py)
+    c = model.encode_objects(objs, [None] * 3)
+    assert c.requires_grad and c.shape == (3, 256)

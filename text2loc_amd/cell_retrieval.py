@@ -10,9 +10,12 @@ on the boundary that ``training.coarse.eval_epoch`` / ``evaluation.pipeline.run_
 
 The object branch's modules below are PARAMETER CONTAINERS only (so that checkpoints load and save with the
 reference's key names); their arithmetic runs in the HIP engine. The text branch stays on PyTorch, as the
-north star prescribes. Not built yet (DESIGN.md "out of scope / next"): training-mode forward+backward of the
-object branch (BatchNorm batch statistics) and PointNet++ itself — in the published feature mode
-(class_embed off) ``object_points`` must carry precomputed ``features2`` per cell.
+north star prescribes. Under ``model.train()`` ``encode_objects`` runs the engine's training-mode forward
+(batch-statistics BatchNorm, the TransformerEncoderLayers' dropout) and returns a tensor whose ``backward``
+runs the engine's backward kernels, which ADD into the ``.grad`` of these same nn.Parameters; step them with
+``text2loc_amd.optim.Adam`` (or any torch optimizer). Not built (DESIGN.md "out of scope / next"): PointNet++
+itself — in the published feature mode (class_embed off) ``object_points`` must carry precomputed ``features2``
+per cell (their gradient is returned when they require grad).
 """
 from __future__ import annotations
 
@@ -128,6 +131,32 @@ class LanguageEncoder(nn.Module):
         return next(self.inter_mlp.parameters()).device
 
 
+class _EncodeObjectsTrainFn(torch.autograd.Function):
+    """Training-mode encode_objects: forward and backward are HIP (t2l_encode_cells_train / _backward). Parameter
+    gradients do not flow through autograd: the engine adds them straight into the bound ``.grad`` buffers, so the
+    only differentiable input is ``pn_feat`` (``hook`` is a dummy leaf that makes autograd call ``backward``)."""
+
+    @staticmethod
+    def forward(ctx, hook, pn_feat, model, packed, p_drop, seed):
+        eng = model._engine
+        out = eng.encode_cells_train(packed, dropout_p=p_drop, seed=seed)
+        ctx.model = model
+        ctx.token = model._train_token = object()
+        ctx.need_pn = pn_feat is not None and pn_feat.requires_grad
+        ctx.pn_shape = None if pn_feat is None else pn_feat.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model = ctx.model
+        if model._train_token is not ctx.token:
+            raise T2LError("backward of a stale encode_objects call: the engine keeps the activations of the LAST "
+                           "training-mode forward only (the reference's loop does one forward per backward too)")
+        gpn = torch.empty(ctx.pn_shape, dtype=torch.float32, device=grad_out.device) if ctx.need_pn else None
+        model._engine.encode_cells_backward(grad_out.contiguous().float(), gpn)
+        return None, gpn, None, None, None, None
+
+
 class CellRetrievalNetwork(nn.Module):
     def __init__(self, known_classes: List[str], known_colors: List[str], args, language_encoder: Optional[nn.Module] = None):
         super().__init__()
@@ -150,6 +179,11 @@ class CellRetrievalNetwork(nn.Module):
             inter_module_num_heads=args.inter_module_num_heads)
         self._engine: Optional[Engine] = None
         self._weights_version = None
+        self._train_generation = 0   # bumped whenever the engine changes parameters/buffers behind torch's back
+        self._train_bound = None     # pointer set the engine's training path is bound to
+        self._train_grads = {}       # name -> persistent gradient buffer (kept when .grad is set to None)
+        self._train_token = None
+        self._train_hook = None
 
     # ---- reference surface ------------------------------------------------------------------------------
     def forward(self):
@@ -165,22 +199,112 @@ class CellRetrievalNetwork(nn.Module):
     def encode_text(self, descriptions):
         return F.normalize(self.language_encoder(descriptions))
 
-    @torch.no_grad()
     def encode_objects(self, objects, object_points=None):
-        if self.training:
-            raise T2LError("training-mode encode_objects (BatchNorm batch statistics + backward) is not built yet; "
-                           "call model.eval() — the engine implements the reference's eval path")
+        if self.training and torch.is_grad_enabled():
+            return self._encode_objects_train(objects, object_points)
+        with torch.no_grad():
+            return self._encode_objects_eval(objects, object_points)
+
+    def _pn_features(self, object_points, as_tensor: bool):
+        a = self.args
+        if not ("class" in a.use_features and not bool(getattr(a, "class_embed", False))):
+            return None
+        if object_points is None or any(p is None for p in object_points):
+            raise T2LError("class_embed is off: object_points must hold precomputed PointNet++ features2 "
+                           "[n_i,256] per cell (PointNet++ kernels are not built yet)")
+        if as_tensor:
+            return torch.cat([p if isinstance(p, torch.Tensor) else torch.as_tensor(np.asarray(p)) for p in object_points],
+                             dim=0).to(self.device, torch.float32).reshape(-1, 256)
+        return [p.detach().cpu().numpy() if isinstance(p, torch.Tensor) else np.asarray(p) for p in object_points]
+
+    # ---- training mode ----------------------------------------------------------------
+    def _train_tensors(self):
+        """state_dict key -> (live tensor, gradient buffer | None) for what the configuration uses."""
+        a = self.args
+        ce, co = bool(getattr(a, "class_embed", False)), bool(getattr(a, "color_embed", False))
+        skip = []
+        if "class" not in a.use_features or ce:
+            skip.append("object_encoder.mlp_pointnet.")
+        if "class" not in a.use_features or not ce:
+            skip.append("object_encoder.class_embedding.")
+        if "color" not in a.use_features or co:
+            skip.append("object_encoder.color_encoder.")
+        if "color" not in a.use_features or not co:
+            skip.append("object_encoder.color_embedding.")
+        if "position" not in a.use_features:
+            skip.append("object_encoder.pos_encoder.")
+        if "num" not in a.use_features:
+            skip.append("object_encoder.num_encoder.")
+        out = {}
+        for n, t in self.state_dict(keep_vars=True).items():
+            if not n.startswith(("object_encoder.", "obj_inter_module.")) or n.startswith(tuple(skip)):
+                continue
+            if n.endswith("num_batches_tracked"):
+                continue
+            if isinstance(t, nn.Parameter):
+                g = self._train_grads.get(n)
+                if g is None or g.shape != t.shape or g.device != t.device:
+                    g = self._train_grads[n] = torch.zeros_like(t.data)
+                if t.grad is None:
+                    t.grad = g  # hand the persistent buffer back (zero_grad(set_to_none=True) only drops the reference)
+                    g.zero_()
+                elif t.grad.data_ptr() != g.data_ptr():
+                    self._train_grads[n] = g = t.grad
+                out[n] = (t.data, g)
+            else:
+                out[n] = (t, None)
+        return out
+
+    def train_engine(self) -> Engine:
+        """The engine with the training path bound to the CURRENT parameter / gradient / buffer storage."""
+        dev = self.device
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        if self._engine is None or self._engine.device != idx:
+            self._engine = Engine(idx)
+            self._weights_version = None
+            self._train_bound = None
+        tensors = self._train_tensors()
+        key = tuple((n, d.data_ptr(), None if g is None else g.data_ptr()) for n, (d, g) in tensors.items())
+        if key != self._train_bound:
+            a = self.args
+            self._engine.train_bind(tensors, class_embed=bool(getattr(a, "class_embed", False)),
+                                    color_embed=bool(getattr(a, "color_embed", False)), use_features=tuple(a.use_features),
+                                    num_layers=a.object_inter_module_num_layers, num_heads=a.object_inter_module_num_heads)
+            self._train_bound = key
+        return self._engine
+
+    def _encode_objects_train(self, objects, object_points):
         dev = self.device
         if dev.type != "cuda":
             raise T2LError("encode_objects runs on the MI355X only (model.to('cuda')); there is no CPU fallback")
-        a = self.args
-        class_embed = bool(getattr(a, "class_embed", False))
-        pn = None
-        if "class" in a.use_features and not class_embed:
-            if object_points is None or any(p is None for p in object_points):
-                raise T2LError("class_embed is off: object_points must hold precomputed PointNet++ features2 "
-                               "[n_i,256] per cell (PointNet++ kernels are not built yet)")
-            pn = [p.detach().cpu().numpy() if isinstance(p, torch.Tensor) else np.asarray(p) for p in object_points]
+        eng = self.train_engine()
+        pn = self._pn_features(object_points, as_tensor=True)
+        if any(getattr(o, "_t2l_feat", None) is None for objs in objects for o in objs):
+            packed = packing.pack_cells_gpu(eng, objects, self.object_encoder.known_classes,
+                                            self.object_encoder.known_colors, dev)
+        else:
+            packed = packing.to_device(packing.pack_cells(objects, self.object_encoder.known_classes,
+                                                          self.object_encoder.known_colors, None), dev)
+        if pn is not None:
+            packed["pn_feat"] = pn.detach().contiguous()
+        layer = self.obj_inter_module[0] if len(self.obj_inter_module) else None
+        p_drop = float(layer.dropout.p) if layer is not None else 0.0  # nn.TransformerEncoderLayer default 0.1
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())       # torch.manual_seed governs the masks
+        if self._train_hook is None or self._train_hook.device != dev:
+            self._train_hook = torch.zeros(1, device=dev, requires_grad=True)
+        out = _EncodeObjectsTrainFn.apply(self._train_hook, pn, self, packed, p_drop, seed)
+        used = {k for k, _, _ in self._train_bound}
+        for name, m in self.named_modules():  # BatchNorm1d.train() side effect the engine does not see (int64)
+            if isinstance(m, nn.BatchNorm1d) and m.num_batches_tracked is not None and name + ".running_mean" in used:
+                m.num_batches_tracked += 1
+        self._train_generation += 1  # running statistics moved: the eval-path weights must be re-folded
+        return out
+
+    def _encode_objects_eval(self, objects, object_points=None):
+        dev = self.device
+        if dev.type != "cuda":
+            raise T2LError("encode_objects runs on the MI355X only (model.to('cuda')); there is no CPU fallback")
+        pn = self._pn_features(object_points, as_tensor=False)
         eng = self.engine()
         if any(getattr(o, "_t2l_feat", None) is None for objs in objects for o in objs):
             # raw points not reduced yet: one HBM pass on the GPU (t2l_reduce_objects) instead of three numpy
@@ -201,7 +325,8 @@ class CellRetrievalNetwork(nn.Module):
         if self._engine is None or self._engine.device != idx:
             self._engine = Engine(idx)
             self._weights_version = None
-        version = tuple((p.data_ptr(), p._version) for p in self._object_params())
+            self._train_bound = None
+        version = (self._train_generation,) + tuple((p.data_ptr(), p._version) for p in self._object_params())
         if version != self._weights_version:
             self.sync_weights()
             self._weights_version = version

@@ -29,6 +29,23 @@ def collate_fn(data):
     return {key: [d[key] for d in data] for key in data[0].keys()}
 
 
+def train_epoch(model, dataloader, args, optimizer, criterion):
+    """training/coarse.py:31-58 with the optimizer and criterion passed in (the reference reads them from module
+    globals): text branch on PyTorch autograd, object branch forward/backward in the engine, both meeting in the
+    contrastive loss kernel. Returns (mean loss, []) like the reference."""
+    model.train()
+    losses = []
+    for batch in dataloader:
+        optimizer.zero_grad()
+        anchor = model.encode_text(batch["texts"])
+        positive = model.encode_objects(batch["objects"], batch["object_points"])
+        loss = criterion(anchor, positive)  # "contrastive" ranking loss (training/args.py default)
+        loss.backward()
+        optimizer.step()
+        losses.append(loss.detach())
+    return float(torch.stack(losses).mean().item()) if losses else float("nan"), []
+
+
 def _batches(dataset, batch_size):
     n = len(dataset)
     for lo in range(0, n, batch_size):

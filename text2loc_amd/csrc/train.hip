@@ -51,6 +51,7 @@ struct TrainState {
   AdamTensor* d_tensors = nullptr;
   AdamChunk* d_chunks = nullptr;
   float* mv = nullptr;
+  double* bn_acc = nullptr;  // [2*1024] float64 partial sums of the BatchNorm stages
   int n_chunks = 0;
   int64_t step = 0;
   // workspace (bump-allocated per forward)
@@ -74,7 +75,7 @@ static TrainState* state(t2l_ctx* ctx) { return reinterpret_cast<TrainState*>(ct
 void free_train(t2l_ctx* ctx) {
   TrainState* st = state(ctx);
   if (!st) return;
-  for (void* p : {(void*)st->d_tensors, (void*)st->d_chunks, (void*)st->mv, (void*)st->ws})
+  for (void* p : {(void*)st->d_tensors, (void*)st->d_chunks, (void*)st->mv, (void*)st->ws, (void*)st->bn_acc})
     if (p) (void)hipFree(p);
   delete st;
   ctx->train = nullptr;
@@ -99,28 +100,23 @@ static T* bump(TrainState* st, size_t count) {
 // ---- GEMM launchers -----------------------------------------------------------------------------------------
 // Y[M,N] = X[M,K] W[N,K]^T + b (relu)
 static void gemm_nt(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int relu, hipStream_t s) {
-  GemmArgs g{X, W, Y, b, M, N, K, K, K, N, relu, 0, K};
+  GemmArgs g{X, W, Y, b, M, N, K, K, K, N, relu, 0, K, nullptr};
   hipLaunchKernelGGL((gemm_kernel<true, true>), dim3(N / 64, (M + 63) / 64, 1), dim3(256), 0, s, g);
 }
 // dX[M,Kp] (+)= dY[M,N] W[N,Kp]
 static void gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kp, int accumulate, hipStream_t s) {
-  GemmArgs g{dY, W, dX, nullptr, M, Kp, N, N, Kp, Kp, 0, accumulate, N};
+  GemmArgs g{dY, W, dX, nullptr, M, Kp, N, N, Kp, Kp, 0, accumulate, N, nullptr};
   hipLaunchKernelGGL((gemm_kernel<true, false>), dim3(Kp / 64, (M + 63) / 64, 1), dim3(256), 0, s, g);
 }
-// dW[N,Kp] += dY[M,N]^T X[M,Kp]   (reduction over the M rows, split over grid.z, float atomics)
-static void gemm_tn(const float* dY, const float* X, float* dW, int M, int N, int Kp, hipStream_t s) {
+// dW[N,Kp] += dY[M,N]^T X[M,Kp]   (reduction over the M rows, split over grid.z, float atomics);  db[N] += column sums of dY
+static void gemm_tn(const float* dY, const float* X, float* dW, float* db, int M, int N, int Kp, hipStream_t s) {
   const int tiles = (N / 64) * (Kp / 64);
   int ksplit = std::max(1, std::min((M + 63) / 64, (512 + tiles - 1) / tiles));
   int kchunk = (((M + ksplit - 1) / ksplit) + 15) & ~15;
   ksplit = (M + kchunk - 1) / kchunk;
-  GemmArgs g{dY, X, dW, nullptr, N, Kp, M, N, Kp, Kp, 0, 1, kchunk};
+  GemmArgs g{dY, X, dW, nullptr, N, Kp, M, N, Kp, Kp, 0, 1, kchunk, db};
   hipLaunchKernelGGL((gemm_kernel<false, false>), dim3(Kp / 64, N / 64, ksplit), dim3(256), 0, s, g);
 }
-static void colsum(const float* X, int M, int N, float* out, hipStream_t s) {
-  const int rows = 128;
-  hipLaunchKernelGGL(colsum_kernel, dim3(N / 64, (M + rows - 1) / rows), dim3(256), 0, s, X, M, N, rows, out);
-}
-
 static int need(t2l_ctx* ctx, TrainState* st, const std::string& name, int64_t numel, bool with_grad, TTensor** out) {
   auto it = st->t.find(name);
   if (it == st->t.end()) return fail(ctx, T2L_EINVAL, "t2l_train_bind: missing tensor '" + name + "'");
@@ -209,6 +205,7 @@ int train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const 
   std::vector<AdamChunk> cs;
   int64_t total = 0;
   for (auto& nme : P) total += st->t[nme].numel;
+  T2L_HIP(ctx, hipMalloc(&st->bn_acc, sizeof(double) * 2 * 1024));
   T2L_HIP(ctx, hipMalloc(&st->mv, sizeof(float) * 2 * (size_t)total));
   T2L_HIP(ctx, hipMemset(st->mv, 0, sizeof(float) * 2 * (size_t)total));
   int64_t off = 0;
@@ -235,8 +232,11 @@ static void mlp_layer_fwd(TrainState* st, MlpLayer& L, const float* x, int M, in
                        1826.6844940968194f, 2516.8905096993817f, L.y);
   else
     gemm_nt(x, W.data, b.data, L.y, M, L.cout, L.cin, 0, s);
-  hipLaunchKernelGGL(bn_fwd_kernel, dim3(L.cout / 16), dim3(256), 0, s, L.y, M, L.cout, T_(st, L.prefix + ".1.weight").data,
-                     T_(st, L.prefix + ".1.bias").data, T_(st, L.prefix + ".1.running_mean").data,
+  (void)hipMemsetAsync(st->bn_acc, 0, sizeof(double) * 2 * L.cout, s);
+  hipLaunchKernelGGL((bn_stats_kernel<0>), dim3(L.cout / 64, (M + kBnRows - 1) / kBnRows), dim3(256), 0, s, L.y, (const float*)nullptr,
+                     (const float*)nullptr, M, L.cout, (const float*)nullptr, (const float*)nullptr, st->bn_acc);
+  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)(((size_t)M * L.cout + 255) / 256)), dim3(256), 0, s, L.y, M, L.cout, st->bn_acc,
+                     T_(st, L.prefix + ".1.weight").data, T_(st, L.prefix + ".1.bias").data, T_(st, L.prefix + ".1.running_mean").data,
                      T_(st, L.prefix + ".1.running_var").data, 0.1f, L.a, L.mean, L.rstd);
 }
 
@@ -385,15 +385,17 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
 // d: gradient w.r.t. the block's ReLU output [M,cout] (overwritten); x: the block's input; dx (optional) receives d W.
 static void mlp_layer_bwd(TrainState* st, const MlpLayer& L, float* d, const float* x, int M, int small_k, int standardize, float* dx,
                           hipStream_t s) {
-  hipLaunchKernelGGL(bn_bwd_kernel, dim3(L.cout / 16), dim3(256), 0, s, d, L.a, L.y, M, L.cout, T_(st, L.prefix + ".1.weight").data, L.mean,
-                     L.rstd, T_(st, L.prefix + ".1.weight").grad, T_(st, L.prefix + ".1.bias").grad);
-  colsum(d, M, L.cout, T_(st, L.prefix + ".0.bias").grad, s);
+  (void)hipMemsetAsync(st->bn_acc, 0, sizeof(double) * 2 * L.cout, s);
+  hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(L.cout / 64, (M + kBnRows - 1) / kBnRows), dim3(256), 0, s, L.y, (const float*)d, (const float*)L.a,
+                     M, L.cout, (const float*)L.mean, (const float*)L.rstd, st->bn_acc);
+  hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((unsigned)(((size_t)M * L.cout + 255) / 256)), dim3(256), 0, s, d, L.a, L.y, M, L.cout, st->bn_acc,
+                     T_(st, L.prefix + ".1.weight").data, L.mean, L.rstd, T_(st, L.prefix + ".1.weight").grad, T_(st, L.prefix + ".1.bias").grad);
   if (small_k) {
-    const int rows = 256;
+    const int rows = 32;
     hipLaunchKernelGGL(smallk_bwd_kernel, dim3((M + rows - 1) / rows), dim3(256), 0, s, x, M, small_k, d, standardize, 1826.6844940968194f,
-                       2516.8905096993817f, rows, T_(st, L.prefix + ".0.weight").grad);
+                       2516.8905096993817f, rows, T_(st, L.prefix + ".0.weight").grad, T_(st, L.prefix + ".0.bias").grad);
   } else {
-    gemm_tn(d, x, T_(st, L.prefix + ".0.weight").grad, M, L.cout, L.cin, s);
+    gemm_tn(d, x, T_(st, L.prefix + ".0.weight").grad, T_(st, L.prefix + ".0.bias").grad, M, L.cout, L.cin, s);
     if (dx) gemm_nn(d, T_(st, L.prefix + ".0.weight").data, dx, M, L.cout, L.cin, 0, s);
   }
 }
@@ -423,7 +425,7 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   const float* xl = st->layers.empty() ? st->X0 : st->layers.back().x2;
   (void)xl;
   hipLaunchKernelGGL(pool_norm_bwd_kernel, dim3(B), dim3(256), 0, s, grad_emb, st->out, st->pool_arg, st->pool_n, dcur);
-  const int ln_grid = std::min(256, (T + 3) / 4);
+  const int ln_grid = std::min(64, (T + 3) / 4);  // few workgroups: each ends with 512 float atomics on the same addresses
   for (int l = (int)st->layers.size() - 1; l >= 0; --l) {
     const LayerSave& L = st->layers[l];
     auto W = [&](const char* n) -> const TTensor& { return T_(st, L.prefix + n); };
@@ -431,8 +433,7 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_grid), dim3(256), 0, s, dcur, L.xhat2, L.rstd2, T, W(".norm2.weight").data,
                        make_drop(st->seed, l * 4 + 3, st->p), dA, dB, W(".norm2.weight").grad, W(".norm2.bias").grad);
     // linear2
-    colsum(dB, T, kTD, W(".linear2.bias").grad, s);
-    gemm_tn(dB, L.hd, W(".linear2.weight").grad, T, kTD, 2 * kTD, s);
+    gemm_tn(dB, L.hd, W(".linear2.weight").grad, W(".linear2.bias").grad, T, kTD, 2 * kTD, s);
     gemm_nn(dB, W(".linear2.weight").data, dH, T, kTD, 2 * kTD, 0, s);
     {
       const size_t n = (size_t)T * 2 * kTD;
@@ -440,20 +441,17 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
                          make_drop(st->seed, l * 4 + 2, st->p));
     }
     // linear1; dA (= dz2, the residual path) += dH W1
-    colsum(dH, T, 2 * kTD, W(".linear1.bias").grad, s);
-    gemm_tn(dH, L.x1, W(".linear1.weight").grad, T, 2 * kTD, kTD, s);
+    gemm_tn(dH, L.x1, W(".linear1.weight").grad, W(".linear1.bias").grad, T, 2 * kTD, kTD, s);
     gemm_nn(dH, W(".linear1.weight").data, dA, T, 2 * kTD, kTD, 1, s);
     // norm1 + dropout1
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_grid), dim3(256), 0, s, dA, L.xhat1, L.rstd1, T, W(".norm1.weight").data,
                        make_drop(st->seed, l * 4 + 1, st->p), dC, dB, W(".norm1.weight").grad, W(".norm1.bias").grad);
     // out_proj
-    colsum(dB, T, kTD, W(".self_attn.out_proj.bias").grad, s);
-    gemm_tn(dB, L.O, W(".self_attn.out_proj.weight").grad, T, kTD, kTD, s);
+    gemm_tn(dB, L.O, W(".self_attn.out_proj.weight").grad, W(".self_attn.out_proj.bias").grad, T, kTD, kTD, s);
     gemm_nn(dB, W(".self_attn.out_proj.weight").data, dO, T, kTD, kTD, 0, s);
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * kTH), dim3(256), 0, s, L.qkv, L.P, dO, dqkv, make_drop(st->seed, l * 4 + 0, st->p));
     // in_proj; dC (= dz1, the residual path) += dqkv Win
-    colsum(dqkv, T, 3 * kTD, W(".self_attn.in_proj_bias").grad, s);
-    gemm_tn(dqkv, L.x_in, W(".self_attn.in_proj_weight").grad, T, 3 * kTD, kTD, s);
+    gemm_tn(dqkv, L.x_in, W(".self_attn.in_proj_weight").grad, W(".self_attn.in_proj_bias").grad, T, 3 * kTD, kTD, s);
     gemm_nn(dqkv, W(".self_attn.in_proj_weight").data, dC, T, 3 * kTD, kTD, 1, s);
     std::swap(dcur, dC);
   }
@@ -464,8 +462,9 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
     const float* dslot = dcat + br.slot * kTD;
     const float* yslot = st->cat + br.slot * kTD;
     if (br.kind == 0) {
-      hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dslot, yslot, Kc, br.save_n, br.idx, M,
-                         T_(st, br.table).grad);
+      const int rows = (int)(T_(st, br.table).numel / kTD);
+      if (rows > 1)
+        hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows - 1), dim3(256), 0, s, dslot, yslot, Kc, br.save_n, br.idx, M, T_(st, br.table).grad);
       continue;
     }
     hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dslot, yslot, Kc, br.save_n, (const int32_t*)nullptr, M, d2);

@@ -53,6 +53,7 @@ struct GemmArgs {
   float* C;
   const float* bias;
   int M, N, K, lda, ldb, ldc, relu, accumulate, kchunk;
+  float* colsum;  // !A_KC only: colsum[m] += sum_k A(m,k)  (bias gradient of the same dY), or nullptr
 };
 
 constexpr int kGS = 96;  // LDS row stride (floats): 64 + 32 so the two k-halves of a wave hit disjoint banks
@@ -107,11 +108,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       *reinterpret_cast<float4*>(&Bs[(tid >> 4) * kGS + (tid & 15) * 4]) = rb;
     }
   };
+  float csum = 0.f;
+  const bool do_colsum = !A_KC && g.colsum && blockIdx.x == 0;
   if (kb < ke) load(kb);
   for (int kt = kb; kt < ke; kt += 16) {
     store();
     __syncthreads();
     if (kt + 16 < ke) load(kt + 16);
+    if (do_colsum && tid < 64) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) csum += As[k * kGS + tid];
+    }
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       const float a = As[(2 * kk + kh) * kGS + wm * 32 + col];
@@ -120,6 +127,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
     __syncthreads();
   }
+  if (do_colsum && tid < 64) unsafeAtomicAdd(g.colsum + m0 + tid, csum);
   const int cg = n0 + wn * 32 + col;
   const float bv = (g.bias && blockIdx.z == 0) ? g.bias[cg] : 0.f;
 #pragma unroll
@@ -172,90 +180,112 @@ __global__ void smallk_fwd_kernel(const float* __restrict__ x, int M, int K, con
 // dW[c][k] += sum_m dy[m][c] x[m][k]   grid = row chunks, 256 threads = 64 channels x 4 row lanes
 __global__ __launch_bounds__(256) void smallk_bwd_kernel(const float* __restrict__ x, int M, int K,
                                                          const float* __restrict__ dy, int standardize, float mean,
-                                                         float stdv, int rows_per_block, float* __restrict__ dW) {
-  __shared__ float red[3][256];
+                                                         float stdv, int rows_per_block, float* __restrict__ dW,
+                                                         float* __restrict__ db) {
+  __shared__ float red[4][256];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int lo = blockIdx.x * rows_per_block, hi = min(M, lo + rows_per_block);
-  float s[3] = {0.f, 0.f, 0.f};
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
   for (int m = lo + g; m < hi; m += 4) {
     const float d = dy[(size_t)m * 64 + c];
+    s[3] += d;
     for (int k = 0; k < K; ++k) s[k] += d * small_in(x, m, K, k, standardize, mean, stdv);
   }
-  for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = s[k];
+  for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = s[k];
   __syncthreads();
-  if (g == 0)
+  if (g == 0) {
     for (int k = 0; k < K; ++k)
       unsafeAtomicAdd(dW + c * K + k, red[k][c] + red[k][c + 64] + red[k][c + 128] + red[k][c + 192]);
+    unsafeAtomicAdd(db + c, red[3][c] + red[3][c + 64] + red[3][c + 128] + red[3][c + 192]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// BatchNorm1d in training mode (+ ReLU): batch statistics over the M rows, two-pass variance, running statistics
-// updated with the unbiased variance (momentum 0.1). One workgroup per 16 channels (16 x 16 threads).
+// BatchNorm1d in training mode (+ ReLU). Two stages so that the whole chip takes part although there are only 64-1024
+// channels: (1) per (64 channels x 64 rows) workgroup partial sums, float64 atomics into acc[2*C]; (2) elementwise apply.
+// var = E[x^2] - mean^2 in float64 (inputs are f32; the cancellation is harmless there). Running statistics get the
+// unbiased variance (momentum 0.1), as torch does.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float bn_block_sum(float v, float* red) {  // sum over the 16 row lanes of each channel
-  const int cx = threadIdx.x & 15;
+constexpr int kBnRows = 64;
+// MODE 0: acc[c] += sum y, acc[C+c] += sum y^2.  MODE 1: dv = out>0 ? d : 0; acc[c] += sum dv, acc[C+c] += sum dv*xhat
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, const float* __restrict__ d,
+                                                       const float* __restrict__ out, int M, int C,
+                                                       const float* __restrict__ save_mean,
+                                                       const float* __restrict__ save_rstd, double* __restrict__ acc) {
+  __shared__ float r1[256], r2[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  const int lo = blockIdx.y * kBnRows, hi = min(M, lo + kBnRows);
+  float mean = 0.f, rstd = 0.f;
+  if (MODE == 1) {
+    mean = save_mean[c];
+    rstd = save_rstd[c];
+  }
+  float s1 = 0.f, s2 = 0.f;
+  for (int m = lo + g; m < hi; m += 4) {
+    const size_t i = (size_t)m * C + c;
+    if (MODE == 0) {
+      const float v = y[i];
+      s1 += v;
+      s2 += v * v;
+    } else {
+      const float dv = out[i] > 0.f ? d[i] : 0.f;
+      s1 += dv;
+      s2 += dv * (y[i] - mean) * rstd;
+    }
+  }
+  r1[threadIdx.x] = s1;
+  r2[threadIdx.x] = s2;
   __syncthreads();
-  red[threadIdx.x] = v;
-  __syncthreads();
-  float s = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) s += red[r * 16 + cx];
-  return s;
+  if (g == 0) {
+    const int t = threadIdx.x;
+    atomicAdd(acc + c, (double)r1[t] + (double)r1[t + 64] + (double)r1[t + 128] + (double)r1[t + 192]);
+    atomicAdd(acc + C + c, (double)r2[t] + (double)r2[t + 64] + (double)r2[t + 128] + (double)r2[t + 192]);
+  }
 }
-__global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ y, int M, int C,
-                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                     float momentum, float* __restrict__ out, float* __restrict__ save_mean,
-                                                     float* __restrict__ save_rstd) {
-  __shared__ float red[256];
-  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4, c = blockIdx.x * 16 + cx;
-  float s = 0.f;
-  for (int m = ry; m < M; m += 16) s += y[(size_t)m * C + c];
-  const float mean = bn_block_sum(s, red) / (float)M;
-  float q = 0.f;
-  for (int m = ry; m < M; m += 16) {
-    const float d = y[(size_t)m * C + c] - mean;
-    q += d * d;
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ y, int M, int C,
+                                                           const double* __restrict__ acc,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                           float momentum, float* __restrict__ out,
+                                                           float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < (size_t)M * C) {
+    const int c = (int)(i % C);
+    const double mean = acc[c] / M;
+    const double var = fmax(acc[C + c] / M - mean * mean, 0.0);
+    const float rstd = 1.0f / sqrtf((float)var + kBnEps);
+    out[i] = fmaxf((y[i] - (float)mean) * rstd * gamma[c] + beta[c], 0.f);
   }
-  const float var = bn_block_sum(q, red) / (float)M;
-  const float rstd = 1.0f / sqrtf(var + kBnEps);
-  const float ga = gamma[c], be = beta[c];
-  for (int m = ry; m < M; m += 16) out[(size_t)m * C + c] = fmaxf((y[(size_t)m * C + c] - mean) * rstd * ga + be, 0.f);
-  if (ry == 0) {
-    save_mean[c] = mean;
-    save_rstd[c] = rstd;
-    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
-    run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * ((float)M / (float)max(M - 1, 1));
-  }
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const double mean = acc[c] / M;
+      const double var = fmax(acc[C + c] / M - mean * mean, 0.0);
+      save_mean[c] = (float)mean;
+      save_rstd[c] = 1.0f / sqrtf((float)var + kBnEps);
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * ((double)M / (double)max(M - 1, 1)));
+    }
 }
 // d: gradient w.r.t. the ReLU output (in), overwritten with the gradient w.r.t. the Linear output y.
-__global__ __launch_bounds__(256) void bn_bwd_kernel(float* __restrict__ d, const float* __restrict__ out,
-                                                     const float* __restrict__ y, int M, int C,
-                                                     const float* __restrict__ gamma, const float* __restrict__ save_mean,
-                                                     const float* __restrict__ save_rstd, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta) {
-  __shared__ float red[256];
-  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4, c = blockIdx.x * 16 + cx;
-  const float mean = save_mean[c], rstd = save_rstd[c];
-  float s1 = 0.f, s2 = 0.f;
-  for (int m = ry; m < M; m += 16) {
-    const size_t i = (size_t)m * C + c;
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(float* __restrict__ d, const float* __restrict__ out,
+                                                           const float* __restrict__ y, int M, int C,
+                                                           const double* __restrict__ acc, const float* __restrict__ gamma,
+                                                           const float* __restrict__ save_mean,
+                                                           const float* __restrict__ save_rstd, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < (size_t)M * C) {
+    const int c = (int)(i % C);
+    const float rstd = save_rstd[c], s1 = (float)acc[c], s2 = (float)acc[C + c];
     const float dv = out[i] > 0.f ? d[i] : 0.f;
-    s1 += dv;
-    s2 += dv * (y[i] - mean) * rstd;
+    d[i] = gamma[c] * rstd / (float)M * ((float)M * dv - s1 - (y[i] - save_mean[c]) * rstd * s2);
   }
-  s1 = bn_block_sum(s1, red);
-  s2 = bn_block_sum(s2, red);
-  const float k = gamma[c] * rstd / (float)M;
-  for (int m = ry; m < M; m += 16) {
-    const size_t i = (size_t)m * C + c;
-    const float dv = out[i] > 0.f ? d[i] : 0.f;
-    d[i] = k * ((float)M * dv - s1 - (y[i] - mean) * rstd * s2);
-  }
-  if (ry == 0) {
-    unsafeAtomicAdd(dgamma + c, s2);
-    unsafeAtomicAdd(dbeta + c, s1);
-  }
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += 256) {
+      unsafeAtomicAdd(dgamma + c, (float)acc[C + c]);
+      unsafeAtomicAdd(dbeta + c, (float)acc[c]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -300,6 +330,31 @@ __global__ void rownorm_bwd_kernel(const float* __restrict__ dy, const float* __
     unsafeAtomicAdd(t + 1, g.y);
     unsafeAtomicAdd(t + 2, g.z);
     unsafeAtomicAdd(t + 3, g.w);
+  }
+}
+// Embedding-table gradient: one workgroup per table row r >= 1 (row 0 = padding_idx never receives gradient,
+// models/object_encoder.py:33,37); its 4 waves walk the objects, those with idx == r contribute normalize_bwd(dy).
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int ld,
+                                                        const float* __restrict__ save_n, const int32_t* __restrict__ idx,
+                                                        int M, float* __restrict__ dtable) {
+  __shared__ float4 red[256];
+  const int r = blockIdx.x + 1, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int m = w; m < M; m += 4) {
+    if (idx[m] != r) continue;  // wave-uniform
+    const float4 g = norm_bwd(*reinterpret_cast<const float4*>(dy + (size_t)m * ld + lane * 4),
+                              *reinterpret_cast<const float4*>(y + (size_t)m * ld + lane * 4), save_n[m]);
+    a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (w == 0) {
+    for (int i = 1; i < 4; ++i) {
+      const float4 b = red[lane + 64 * i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float* t = dtable + (size_t)r * kTD + lane * 4;
+    t[0] += a.x; t[1] += a.y; t[2] += a.z; t[3] += a.w;
   }
 }
 // tokens: X0[b*28+s] = normalize(feats[offsets[b]+s]) for s < min(count,28), zeros otherwise (cell_retrieval.py:85-98)
