@@ -44,6 +44,8 @@ struct LayerSave {
         *hd = nullptr, *xhat2 = nullptr, *rstd2 = nullptr, *x2 = nullptr;
 };
 
+constexpr int kBnSlots = 8;  // BatchNorm layers per pass: <= 2*3 small branches + pointnet mlp + merge
+
 struct TrainState {
   std::unordered_map<std::string, TTensor> t;
   t2l_model_config cfg{};
@@ -51,7 +53,8 @@ struct TrainState {
   AdamTensor* d_tensors = nullptr;
   AdamChunk* d_chunks = nullptr;
   float* mv = nullptr;
-  double* bn_acc = nullptr;  // [2*1024] float64 partial sums of the BatchNorm stages
+  double* bn_acc = nullptr;  // [kBnSlots][2*1024] float64 partial sums of the BatchNorm stages (one slot per BN pass)
+  int bn_slot = 0;
   int n_chunks = 0;
   int64_t step = 0;
   // workspace (bump-allocated per forward)
@@ -101,21 +104,21 @@ static T* bump(TrainState* st, size_t count) {
 // Y[M,N] = X[M,K] W[N,K]^T + b (relu)
 static void gemm_nt(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int relu, hipStream_t s) {
   GemmArgs g{X, W, Y, b, M, N, K, K, K, N, relu, 0, K, nullptr};
-  hipLaunchKernelGGL((gemm_kernel<true, true>), dim3(N / 64, (M + 63) / 64, 1), dim3(256), 0, s, g);
+  hipLaunchKernelGGL((gemm_kernel<true, true>), dim3(N / 32, (M + 31) / 32, 1), dim3(256), 0, s, g);
 }
 // dX[M,Kp] (+)= dY[M,N] W[N,Kp]
 static void gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kp, int accumulate, hipStream_t s) {
   GemmArgs g{dY, W, dX, nullptr, M, Kp, N, N, Kp, Kp, 0, accumulate, N, nullptr};
-  hipLaunchKernelGGL((gemm_kernel<true, false>), dim3(Kp / 64, (M + 63) / 64, 1), dim3(256), 0, s, g);
+  hipLaunchKernelGGL((gemm_kernel<true, false>), dim3(Kp / 32, (M + 31) / 32, 1), dim3(256), 0, s, g);
 }
 // dW[N,Kp] += dY[M,N]^T X[M,Kp]   (reduction over the M rows, split over grid.z, float atomics);  db[N] += column sums of dY
 static void gemm_tn(const float* dY, const float* X, float* dW, float* db, int M, int N, int Kp, hipStream_t s) {
-  const int tiles = (N / 64) * (Kp / 64);
-  int ksplit = std::max(1, std::min((M + 63) / 64, (512 + tiles - 1) / tiles));
-  int kchunk = (((M + ksplit - 1) / ksplit) + 15) & ~15;
+  const int tiles = (N / 32) * (Kp / 32);
+  int ksplit = std::max(1, std::min((M + 255) / 256, (1024 + tiles - 1) / tiles));  // >= 64 rows per wave, ~1k workgroups
+  int kchunk = (((M + ksplit - 1) / ksplit) + 63) & ~63;
   ksplit = (M + kchunk - 1) / kchunk;
   GemmArgs g{dY, X, dW, nullptr, N, Kp, M, N, Kp, Kp, 0, 1, kchunk, db};
-  hipLaunchKernelGGL((gemm_kernel<false, false>), dim3(Kp / 64, N / 64, ksplit), dim3(256), 0, s, g);
+  hipLaunchKernelGGL((gemm_kernel<false, false>), dim3(Kp / 32, N / 32, ksplit), dim3(256), 0, s, g);
 }
 static int need(t2l_ctx* ctx, TrainState* st, const std::string& name, int64_t numel, bool with_grad, TTensor** out) {
   auto it = st->t.find(name);
@@ -205,7 +208,7 @@ int train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const 
   std::vector<AdamChunk> cs;
   int64_t total = 0;
   for (auto& nme : P) total += st->t[nme].numel;
-  T2L_HIP(ctx, hipMalloc(&st->bn_acc, sizeof(double) * 2 * 1024));
+  T2L_HIP(ctx, hipMalloc(&st->bn_acc, sizeof(double) * 2 * 1024 * kBnSlots));
   T2L_HIP(ctx, hipMalloc(&st->mv, sizeof(float) * 2 * (size_t)total));
   T2L_HIP(ctx, hipMemset(st->mv, 0, sizeof(float) * 2 * (size_t)total));
   int64_t off = 0;
@@ -232,10 +235,10 @@ static void mlp_layer_fwd(TrainState* st, MlpLayer& L, const float* x, int M, in
                        1826.6844940968194f, 2516.8905096993817f, L.y);
   else
     gemm_nt(x, W.data, b.data, L.y, M, L.cout, L.cin, 0, s);
-  (void)hipMemsetAsync(st->bn_acc, 0, sizeof(double) * 2 * L.cout, s);
+  double* acc = st->bn_acc + (size_t)(st->bn_slot++ % kBnSlots) * 2048;
   hipLaunchKernelGGL((bn_stats_kernel<0>), dim3(L.cout / 64, (M + kBnRows - 1) / kBnRows), dim3(256), 0, s, L.y, (const float*)nullptr,
-                     (const float*)nullptr, M, L.cout, (const float*)nullptr, (const float*)nullptr, st->bn_acc);
-  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)(((size_t)M * L.cout + 255) / 256)), dim3(256), 0, s, L.y, M, L.cout, st->bn_acc,
+                     (const float*)nullptr, M, L.cout, (const float*)nullptr, (const float*)nullptr, acc);
+  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)(((size_t)M * L.cout + 255) / 256)), dim3(256), 0, s, L.y, M, L.cout, acc,
                      T_(st, L.prefix + ".1.weight").data, T_(st, L.prefix + ".1.bias").data, T_(st, L.prefix + ".1.running_mean").data,
                      T_(st, L.prefix + ".1.running_var").data, 0.1f, L.a, L.mean, L.rstd);
 }
@@ -285,6 +288,8 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
   st->branches.clear();
   st->layers.clear();
   event_begin(ctx, "train_forward", s);
+  st->bn_slot = 0;
+  T2L_HIP(ctx, hipMemsetAsync(st->bn_acc, 0, sizeof(double) * 2048 * kBnSlots, s));
 
   st->cat = bump<float>(st, (size_t)M * Kc);
   const std::string oe = "object_encoder.";
@@ -385,10 +390,10 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
 // d: gradient w.r.t. the block's ReLU output [M,cout] (overwritten); x: the block's input; dx (optional) receives d W.
 static void mlp_layer_bwd(TrainState* st, const MlpLayer& L, float* d, const float* x, int M, int small_k, int standardize, float* dx,
                           hipStream_t s) {
-  (void)hipMemsetAsync(st->bn_acc, 0, sizeof(double) * 2 * L.cout, s);
+  double* acc = st->bn_acc + (size_t)(st->bn_slot++ % kBnSlots) * 2048;
   hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(L.cout / 64, (M + kBnRows - 1) / kBnRows), dim3(256), 0, s, L.y, (const float*)d, (const float*)L.a,
-                     M, L.cout, (const float*)L.mean, (const float*)L.rstd, st->bn_acc);
-  hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((unsigned)(((size_t)M * L.cout + 255) / 256)), dim3(256), 0, s, d, L.a, L.y, M, L.cout, st->bn_acc,
+                     M, L.cout, (const float*)L.mean, (const float*)L.rstd, acc);
+  hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((unsigned)(((size_t)M * L.cout + 255) / 256)), dim3(256), 0, s, d, L.a, L.y, M, L.cout, acc,
                      T_(st, L.prefix + ".1.weight").data, L.mean, L.rstd, T_(st, L.prefix + ".1.weight").grad, T_(st, L.prefix + ".1.bias").grad);
   if (small_k) {
     const int rows = 32;
@@ -407,6 +412,8 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   const int M = st->M, B = st->B, T = st->T, Kc = st->n_feat * kTD;
   const size_t mark = st->ws_off;
   event_begin(ctx, "train_backward", s);
+  st->bn_slot = 0;
+  T2L_HIP(ctx, hipMemsetAsync(st->bn_acc, 0, sizeof(double) * 2048 * kBnSlots, s));
   float* dcur = bump<float>(st, (size_t)T * kTD);
   float* dA = bump<float>(st, (size_t)T * kTD);
   float* dB = bump<float>(st, (size_t)T * kTD);

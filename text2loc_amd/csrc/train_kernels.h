@@ -40,12 +40,16 @@ struct Drop {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// GEMM: C[M,N] (+)= A(m,k) B(k,n) (+ bias[n]) (relu). 64x64 tile per workgroup (4 waves, one 32x32 MFMA tile each),
-// BK = 16, operands staged k-major in LDS so that the MFMA operand reads are conflict-free.
+// GEMM: C[M,N] (+)= A(m,k) B(k,n) (+ bias[n]) (relu), f32 MFMA 32x32x2.
 //   A_KC: A[m*lda + k] (k contiguous)  else A[k*lda + m]
 //   B_KC: B[n*ldb + k] (k contiguous)  else B[k*ldb + n]
-// Ragged dims: rows m >= M are skipped when A_KC; the reduction range [kb,ke) may end anywhere when both operands are
-// row-major over k (dW = dY^T X, reduction over tokens). N (and M when !A_KC) must be multiples of 64.
+// These problems are small (M <= a few thousand tokens, N,K <= 1024) and live in L2, so the kernel is built for
+// PARALLELISM, not for operand reuse: one workgroup owns ONE 32x32 output tile and its four waves split the reduction
+// range four ways; every wave streams its operands straight from global memory into the MFMA operand registers — no
+// LDS staging, no barrier in the loop. The k index inside a 16-step is permuted (lane half kh owns k0+8*kh .. +7) so
+// that k-contiguous operands are two float4 loads per lane; any permutation is valid as long as A and B share it. The
+// four partial tiles meet in LDS once, at the end. M and the reduction range may be ragged; N must be a multiple of 32
+// (and M too when !A_KC).
 // ---------------------------------------------------------------------------------------------------------------
 struct GemmArgs {
   const float* A;
@@ -56,85 +60,78 @@ struct GemmArgs {
   float* colsum;  // !A_KC only: colsum[m] += sum_k A(m,k)  (bias gradient of the same dY), or nullptr
 };
 
-constexpr int kGS = 96;  // LDS row stride (floats): 64 + 32 so the two k-halves of a wave hit disjoint banks
+template <bool KC>
+__device__ __forceinline__ void gemm_load(const float* __restrict__ P, int ld, int row, bool row_ok, int k0, int kh, int kend,
+                                          float (&v)[8]) {
+  if (KC) {
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+    if (row_ok) {
+      const float* p = P + (size_t)row * ld + k0 + 8 * kh;
+      x = *reinterpret_cast<const float4*>(p);
+      y = *reinterpret_cast<const float4*>(p + 4);
+    }
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + 8 * kh + j;
+      v[j] = k < kend ? P[(size_t)k * ld + row] : 0.f;
+    }
+  }
+}
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  __shared__ float As[16 * kGS];
-  __shared__ float Bs[16 * kGS];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+  __shared__ float red[4 * 16 * 64];
+  __shared__ float cred[4 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, kh = lane >> 5;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
   const int kb = blockIdx.z * g.kchunk, ke = min(g.K, kb + g.kchunk);
-  const int wm = w & 1, wn = w >> 1, col = lane & 31, kh = lane >> 5;
+  const int slice = ((((ke - kb) + 3) / 4) + 15) & ~15;  // per-wave share of the reduction range, whole 16-steps
+  const int wk0 = kb + w * slice, wk1 = min(ke, wk0 + slice);
+  const bool a_ok = !A_KC || (m0 + i) < g.M;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float4 ra, rb;
-  auto load = [&](int kt) {
-    ra = make_float4(0.f, 0.f, 0.f, 0.f);
-    rb = ra;
-    if (A_KC) {
-      const int r = tid >> 2, k = kt + (tid & 3) * 4, m = m0 + r;
-      if (m < g.M && k < ke) ra = *reinterpret_cast<const float4*>(g.A + (size_t)m * g.lda + k);
-    } else {
-      const int k = kt + (tid >> 4), mq = (tid & 15) * 4;
-      if (k < ke) ra = *reinterpret_cast<const float4*>(g.A + (size_t)k * g.lda + m0 + mq);
-    }
-    if (B_KC) {
-      const int r = tid >> 2, k = kt + (tid & 3) * 4;
-      if (k < ke) rb = *reinterpret_cast<const float4*>(g.B + (size_t)(n0 + r) * g.ldb + k);
-    } else {
-      const int k = kt + (tid >> 4), nq = (tid & 15) * 4;
-      if (k < ke) rb = *reinterpret_cast<const float4*>(g.B + (size_t)k * g.ldb + n0 + nq);
-    }
-  };
-  auto store = [&]() {
-    if (A_KC) {
-      const int r = tid >> 2, kq = (tid & 3) * 4;
-      As[(kq + 0) * kGS + r] = ra.x;
-      As[(kq + 1) * kGS + r] = ra.y;
-      As[(kq + 2) * kGS + r] = ra.z;
-      As[(kq + 3) * kGS + r] = ra.w;
-    } else {
-      *reinterpret_cast<float4*>(&As[(tid >> 4) * kGS + (tid & 15) * 4]) = ra;
-    }
-    if (B_KC) {
-      const int r = tid >> 2, kq = (tid & 3) * 4;
-      Bs[(kq + 0) * kGS + r] = rb.x;
-      Bs[(kq + 1) * kGS + r] = rb.y;
-      Bs[(kq + 2) * kGS + r] = rb.z;
-      Bs[(kq + 3) * kGS + r] = rb.w;
-    } else {
-      *reinterpret_cast<float4*>(&Bs[(tid >> 4) * kGS + (tid & 15) * 4]) = rb;
-    }
-  };
-  float csum = 0.f;
+  float a[8], b[8], an[8], bn[8], csum = 0.f;
   const bool do_colsum = !A_KC && g.colsum && blockIdx.x == 0;
-  if (kb < ke) load(kb);
-  for (int kt = kb; kt < ke; kt += 16) {
-    store();
-    __syncthreads();
-    if (kt + 16 < ke) load(kt + 16);
-    if (do_colsum && tid < 64) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) csum += As[k * kGS + tid];
-    }
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      const float a = As[(2 * kk + kh) * kGS + wm * 32 + col];
-      const float b = Bs[(2 * kk + kh) * kGS + wn * 32 + col];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
-    __syncthreads();
+  if (wk0 < wk1) {
+    gemm_load<A_KC>(g.A, g.lda, m0 + i, a_ok, wk0, kh, wk1, a);
+    gemm_load<B_KC>(g.B, g.ldb, n0 + i, true, wk0, kh, wk1, b);
   }
-  if (do_colsum && tid < 64) unsafeAtomicAdd(g.colsum + m0 + tid, csum);
-  const int cg = n0 + wn * 32 + col;
-  const float bv = (g.bias && blockIdx.z == 0) ? g.bias[cg] : 0.f;
+  for (int k0 = wk0; k0 < wk1; k0 += 16) {
+    if (k0 + 16 < wk1) {
+      gemm_load<A_KC>(g.A, g.lda, m0 + i, a_ok, k0 + 16, kh, wk1, an);
+      gemm_load<B_KC>(g.B, g.ldb, n0 + i, true, k0 + 16, kh, wk1, bn);
+    }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+    for (int j = 0; j < 8; ++j) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+      if (do_colsum) csum += a[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a[j] = an[j];
+      b[j] = bn[j];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(w * 16 + r) * 64 + lane] = acc[r];
+  if (do_colsum) cred[w * 64 + lane] = csum;
+  __syncthreads();
+  if (do_colsum && tid < 32) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s += cred[q * 64 + tid] + cred[q * 64 + 32 + tid];
+    unsafeAtomicAdd(g.colsum + m0 + tid, s);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + 256 * q, r = e >> 6, l = e & 63;
+    const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), cg = n0 + (l & 31);
     if (row < g.M) {
-      float v = acc[r] + bv;
+      float v = red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l];
+      if (g.bias && blockIdx.z == 0) v += g.bias[cg];
       if (g.relu) v = fmaxf(v, 0.f);
       float* dst = g.C + (size_t)row * g.ldc + cg;
       if (g.accumulate)
@@ -143,19 +140,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         *dst = v;
     }
   }
-}
-
-// out[n] += sum_m X[m*ld + n]   (bias gradients). grid (N/64, row chunks), 256 threads = 64 columns x 4 row lanes.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int ld, int rows_per_block,
-                                                     float* __restrict__ out) {
-  __shared__ float red[256];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-  const int lo = blockIdx.y * rows_per_block, hi = min(M, lo + rows_per_block);
-  float s = 0.f;
-  for (int m = lo + g; m < hi; m += 4) s += X[(size_t)m * ld + c];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  if (g == 0) unsafeAtomicAdd(out + c, red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -338,13 +322,24 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ save_n, const int32_t* __restrict__ idx,
                                                         int M, float* __restrict__ dtable) {
   __shared__ float4 red[256];
+  __shared__ int list[2048];
+  __shared__ int cnt;
   const int r = blockIdx.x + 1, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int m = w; m < M; m += 4) {
-    if (idx[m] != r) continue;  // wave-uniform
-    const float4 g = norm_bwd(*reinterpret_cast<const float4*>(dy + (size_t)m * ld + lane * 4),
-                              *reinterpret_cast<const float4*>(y + (size_t)m * ld + lane * 4), save_n[m]);
-    a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+  for (int base = 0; base < M; base += 2048) {  // compact the matching objects of this chunk, then reduce only those
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    for (int m = base + threadIdx.x; m < min(M, base + 2048); m += 256)
+      if (idx[m] == r) list[atomicAdd(&cnt, 1)] = m;
+    __syncthreads();
+    const int n = cnt;
+    for (int i = w; i < n; i += 4) {
+      const int m = list[i];
+      const float4 g = norm_bwd(*reinterpret_cast<const float4*>(dy + (size_t)m * ld + lane * 4),
+                                *reinterpret_cast<const float4*>(y + (size_t)m * ld + lane * 4), save_n[m]);
+      a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+    }
+    __syncthreads();
   }
   red[threadIdx.x] = a;
   __syncthreads();
