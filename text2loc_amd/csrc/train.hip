@@ -468,13 +468,12 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   for (const Branch& br : st->branches) {
     const float* dslot = dcat + br.slot * kTD;
     const float* yslot = st->cat + br.slot * kTD;
+    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dslot, yslot, Kc, br.save_n, M, d2);
     if (br.kind == 0) {
       const int rows = (int)(T_(st, br.table).numel / kTD);
-      if (rows > 1)
-        hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows - 1), dim3(256), 0, s, dslot, yslot, Kc, br.save_n, br.idx, M, T_(st, br.table).grad);
+      if (rows > 1) hipLaunchKernelGGL(embed_sum_kernel, dim3(rows - 1, kEmbSplit), dim3(256), 0, s, d2, br.idx, M, T_(st, br.table).grad);
       continue;
     }
-    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dslot, yslot, Kc, br.save_n, (const int32_t*)nullptr, M, d2);
     if (br.kind == 2) {
       mlp_layer_bwd(st, br.layers[0], d2, br.x, M, 0, 0, grad_pn_feat, s);
     } else {

@@ -296,48 +296,38 @@ __global__ void rownorm_fwd_kernel(const float* __restrict__ src, const int32_t*
   *reinterpret_cast<float4*>(dst + (size_t)m * ldd + lane * 4) = y;
   if (lane == 0) save_n[m] = n;
 }
-// dx = normalize_bwd(dy, y, n). idx == nullptr: dx[m] written; else atomically added to dtable[idx[m]] (row 0 = padding_idx
-// never receives gradient, models/object_encoder.py:33,37).
+// dx[m] = normalize_bwd(dy[m], y[m], n[m])
 __global__ void rownorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int ld,
-                                   const float* __restrict__ save_n, const int32_t* __restrict__ idx, int M,
-                                   float* __restrict__ dx) {
+                                   const float* __restrict__ save_n, int M, float* __restrict__ dx) {
   const int m = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (m >= M) return;
   const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)m * ld + lane * 4);
   const float4 yy = *reinterpret_cast<const float4*>(y + (size_t)m * ld + lane * 4);
-  const float4 g = norm_bwd(d, yy, save_n[m]);
-  if (!idx) {
-    *reinterpret_cast<float4*>(dx + (size_t)m * kTD + lane * 4) = g;
-  } else if (idx[m] != 0) {
-    float* t = dx + (size_t)idx[m] * kTD + lane * 4;
-    unsafeAtomicAdd(t + 0, g.x);
-    unsafeAtomicAdd(t + 1, g.y);
-    unsafeAtomicAdd(t + 2, g.z);
-    unsafeAtomicAdd(t + 3, g.w);
-  }
+  *reinterpret_cast<float4*>(dx + (size_t)m * kTD + lane * 4) = norm_bwd(d, yy, save_n[m]);
 }
-// Embedding-table gradient: one workgroup per table row r >= 1 (row 0 = padding_idx never receives gradient,
-// models/object_encoder.py:33,37); its 4 waves walk the objects, those with idx == r contribute normalize_bwd(dy).
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int ld,
-                                                        const float* __restrict__ save_n, const int32_t* __restrict__ idx,
-                                                        int M, float* __restrict__ dtable) {
+// Embedding-table gradient, stage 2 (stage 1 = rownorm_bwd_kernel writing g[M,256] = normalize_bwd per object):
+// dtable[r] += sum over the objects with idx == r of g[m]. grid (table rows - 1, kEmbSplit): row 0 = padding_idx never
+// receives gradient (models/object_encoder.py:33,37). Each workgroup lists in LDS the matching objects with
+// m % kEmbSplit == blockIdx.y, its 4 waves add their rows (independent coalesced 1 KiB loads), then 256 float atomics.
+constexpr int kEmbSplit = 8;
+__global__ __launch_bounds__(256) void embed_sum_kernel(const float* __restrict__ g, const int32_t* __restrict__ idx, int M,
+                                                        float* __restrict__ dtable) {
   __shared__ float4 red[256];
   __shared__ int list[2048];
   __shared__ int cnt;
   const int r = blockIdx.x + 1, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int base = 0; base < M; base += 2048) {  // compact the matching objects of this chunk, then reduce only those
+  for (int base = 0; base < M; base += 2048) {
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
     for (int m = base + threadIdx.x; m < min(M, base + 2048); m += 256)
-      if (idx[m] == r) list[atomicAdd(&cnt, 1)] = m;
+      if (idx[m] == r && (m % kEmbSplit) == (int)blockIdx.y) list[atomicAdd(&cnt, 1)] = m;  // this workgroup's share
     __syncthreads();
     const int n = cnt;
+#pragma unroll 4
     for (int i = w; i < n; i += 4) {
-      const int m = list[i];
-      const float4 g = norm_bwd(*reinterpret_cast<const float4*>(dy + (size_t)m * ld + lane * 4),
-                                *reinterpret_cast<const float4*>(y + (size_t)m * ld + lane * 4), save_n[m]);
-      a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+      const float4 v = *reinterpret_cast<const float4*>(g + (size_t)list[i] * kTD + lane * 4);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
     __syncthreads();
   }
@@ -349,7 +339,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
     float* t = dtable + (size_t)r * kTD + lane * 4;
-    t[0] += a.x; t[1] += a.y; t[2] += a.z; t[3] += a.w;
+    unsafeAtomicAdd(t + 0, a.x); unsafeAtomicAdd(t + 1, a.y); unsafeAtomicAdd(t + 2, a.z); unsafeAtomicAdd(t + 3, a.w);
   }
 }
 // tokens: X0[b*28+s] = normalize(feats[offsets[b]+s]) for s < min(count,28), zeros otherwise (cell_retrieval.py:85-98)
