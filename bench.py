@@ -66,6 +66,62 @@ def pmc_traffic(kernel):
         return None
 
 
+def torch_train_step_ms(sd, cells64, anchor, steps=20):
+    """Same-GPU stock-library comparator for the training step: the identical graph in PyTorch eager (rocBLAS/MIOpen
+    kernels + autograd + torch.optim.Adam), dropout 0.1 — what the reference's train_epoch runs for the object branch."""
+    import argparse
+    import torch.nn.functional as F
+    from text2loc_amd.cell_retrieval import CellRetrievalNetwork
+
+    class _Txt(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        @property
+        def device(self):
+            return self.p.device
+
+    args = argparse.Namespace(coarse_embed_dim=256, object_size=28, object_inter_module_num_heads=4,
+                              object_inter_module_num_layers=2, class_embed=True, color_embed=True,
+                              use_features=["class", "color", "position", "num"])
+    m = CellRetrievalNetwork(synth.KNOWN_CLASS, synth.COLOR_NAMES, args, language_encoder=_Txt())
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    m = m.cuda().train()
+    oe = m.object_encoder
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cells64.items()}
+    B = len(cells64["counts"])
+    rows = torch.cat([torch.arange(min(int(c), 28)) + int(o) for c, o in zip(cells64["counts"], cells64["offsets"][:-1])]).cuda()
+    slots = torch.cat([torch.arange(min(int(c), 28)) + 28 * i for i, c in enumerate(cells64["counts"])]).cuda()
+    opt = torch.optim.Adam([p for n, p in m.named_parameters() if n.startswith(("object_encoder.", "obj_inter_module."))], lr=1e-3)
+
+    def step():
+        opt.zero_grad()
+        emb = [F.normalize(oe.class_embedding(t["class_idx"].long()), dim=-1),
+               F.normalize(oe.color_embedding(t["color_idx"].long()), dim=-1),
+               F.normalize(oe.pos_encoder(t["center"]), dim=-1),
+               F.normalize(oe.num_encoder((t["n_pts"].unsqueeze(-1) - 1826.6844940968194) / 2516.8905096993817), dim=-1)]
+        e = F.normalize(oe.mlp_merge(torch.cat(emb, dim=-1)), dim=-1)
+        x = torch.zeros(B * 28, 256, device="cuda").index_copy(0, slots, e[rows]).view(B, 28, 256).permute(1, 0, 2).contiguous()
+        for layer in m.obj_inter_module:
+            x = layer(x)
+        pos = F.normalize(x.max(dim=0)[0])
+        sim = anchor @ pos.t()
+        num, den = torch.exp(torch.diag(sim) / 0.1), torch.exp(sim / 0.1)
+        loss = torch.mean(-torch.log(num / den.sum(0)) - torch.log(num / den.sum(1)))
+        loss.backward()
+        opt.step()
+
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
 def secondary_measurements(eng):
     """Outside the timed region: the fused cell encoder on the full 11,259-cell DB (cells/s, f32 MFMA TFLOP/s at the
     algorithmic 60.33 MFLOP/cell + 0.67 MFLOP/object of SURVEY.md §8d) and the contrastive loss step (us)."""
@@ -86,6 +142,39 @@ def secondary_measurements(eng):
     out["encode_cells"] = {"cells": N_CELLS, "kernel_ms": ms, "cells_per_s": N_CELLS / (ms * 1e-3),
                            "tflops_algorithmic": flops / (ms * 1e-3) / 1e12, "peak_tflops": F32_MFMA_PEAK_TFLOPS,
                            "frac": flops / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "launches_timed": n}
+    # (ii) cold end-to-end = encode the N cells from packed features + build the DB + search Q queries;
+    # and the same-GPU stock-library comparator for the search (rocBLAS f32 GEMM + torch.topk, f32 scores only)
+    try:
+        dq_all = torch.from_numpy(np.ascontiguousarray(_QS)).cuda()
+        eng_c = Engine(eng.device)
+        eng_c.load_weights(sd, class_embed=True, color_embed=True)
+        for _ in range(2):
+            eng_c.db_set(eng_c.encode_cells(packed))
+            eng_c.search(dq_all, TOPK)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eng_c.db_set(eng_c.encode_cells(packed))
+            eng_c.search(dq_all, TOPK)
+        torch.cuda.synchronize()
+        cold = (time.perf_counter() - t0) / 3
+        out["cold_end_to_end"] = {"workload": f"encode {N_CELLS} cells + db_set + search {N_QUERIES} queries, top-{TOPK}",
+                                  "ms": cold * 1e3, "queries_per_s": N_QUERIES / cold}
+        eng_c.close()
+        d_db = eng.encode_cells(packed)
+        for _ in range(5):
+            torch.topk(dq_all @ d_db.t(), TOPK, dim=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            torch.topk(dq_all @ d_db.t(), TOPK, dim=1)
+        torch.cuda.synchronize()
+        tt = (time.perf_counter() - t0) / 50
+        out["torch_mm_topk_same_gpu"] = {"workload": "torch f32 [Q,256]@[256,N] (rocBLAS) + torch.topk(10): f32 ranking, not the "
+                                                     "reference's float64 ranking", "ms_per_step": tt * 1e3,
+                                         "queries_per_s": N_QUERIES / tt}
+    except Exception as e:
+        out["cold_end_to_end"] = {"error": repr(e)}
     # latency of small query batches against the resident DB (the reference answers one query at a time)
     lat = {}
     for qn in (1, 64):
@@ -198,6 +287,10 @@ def secondary_measurements(eng):
                                  "loss_ms": eng.kernel_stats("contrastive_loss")[0],
                                  "steps_per_s": 1.0 / wall, "algorithmic_tflops": fl / wall / 1e12,
                                  "final_loss": float(last)}
+        try:
+            out["train_step_b64"]["torch_eager_ms_per_step_same_gpu"] = torch_train_step_ms(sd, cells64, anchor)
+        except Exception as e:
+            out["train_step_b64"]["torch_eager_error"] = repr(e)
     except Exception as e:
         out["train_step_b64"] = {"error": repr(e)}
     rng = np.random.default_rng(0)
