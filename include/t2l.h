@@ -69,9 +69,10 @@ typedef struct {
 
 /* Replaces: CellRetrievalNetwork.load_state_dict(strict=False) (evaluation/pipeline.py:251) for the
  * object branch. Folds eval-mode BatchNorm into the preceding Linear, re-lays weights out for the
- * kernels and uploads them. Synchronous. Keys of other sub-modules (language_encoder.*, pointnet.*) are
- * ignored; a missing REQUIRED key is T2L_EINVAL (stricter than strict=False on purpose: silent zero
- * weights would void parity). */
+ * kernels and uploads them. Synchronous. Keys of other sub-modules (language_encoder.*) are ignored; a missing
+ * REQUIRED key is T2L_EINVAL (stricter than strict=False on purpose: silent zero weights would void parity).
+ * "object_encoder.pointnet.*" tensors are optional as a group: when present they are folded and packed for
+ * t2l_pointnet_features (the two classifier heads, unused on this path, are ignored). */
 int t2l_load_weights(t2l_ctx* ctx, const t2l_weight_desc* w, int32_t n, const t2l_model_config* cfg);
 
 /* ---- per-object reductions over raw points (a1) ------------------------------------------------ */
@@ -90,6 +91,21 @@ int t2l_load_weights(t2l_ctx* ctx, const t2l_weight_desc* w, int32_t n, const t2
 int t2l_reduce_objects(t2l_ctx* ctx, const float* xyz, const float* rgb, const int64_t* point_offsets, int32_t n_objects,
                        const float* color_centers, const int32_t* color_rows, int32_t n_colors, float* out_rgb,
                        float* out_center, float* out_npts, int32_t* out_color_idx, void* stream);
+
+/* ---- PointNet++ object backbone (a3), eval mode ------------------------------------------------ */
+/* Replaces: PointNet2.forward(...).features2 (models/pointcloud/pointnet2.py:66-100) as ObjectEncoder.forward calls it
+ * once per cell (models/object_encoder.py:92-95): three SetAbstraction layers (FPS 1/2, ball query r = .2/.3/.4 with at most
+ * 32 neighbours, PointConv = max over get_mlp(cat[x_j, pos_j - pos_i])), the global get_mlp + max, lin1/lin2 + ReLU.
+ * pos, rgb: dev f32[n_objects,256,3] — each object's 256 points as the reference's dataloader delivers them (FixedPoints(256)
+ * + NormalizeScale, dataloading/kitti360pose/utils.py:91-147); cell_offsets: HOST i32[n_cells+1] (objects per cell = per PyG
+ * batch, offsets[0] = 0); out_features2: dev f32[n_objects,256], ready to be t2l_packed_cells.pn_feat.
+ * PARITY UNPINNED: the arithmetic of this stage lives in torch_geometric / torch-cluster / torch-scatter, absent from the
+ * reference tree. Semantics here (oracle/t2l_oracle_pointnet.py): FPS starts at point 0 (the reference: random start) and
+ * breaks ties by lower index; the ball query keeps the first 32 source points in index order with d^2 < r^2; option
+ * "pointnet_pyg_self_loops" (default 1) reproduces PyG 1.7's PointConv(add_self_loops=True) on bipartite inputs, which adds
+ * the message of source node k of the cell's batch to centre k of the cell's batch. Synchronises the stream once. */
+int t2l_pointnet_features(t2l_ctx* ctx, const float* pos, const float* rgb, const int32_t* cell_offsets, int32_t n_cells,
+                          float* out_features2, void* stream);
 
 /* ---- cell encoding (a2+a4) ------------------------------------------------------------------- */
 /* Packed SoA replacement of List[List[Object3d]] (+ PointNet++ features2 when class_embed == 0).
@@ -211,6 +227,7 @@ int t2l_adam_step(t2l_ctx* ctx, float lr, float beta1, float beta2, float eps, v
  * "stream_min_rows"   (default 65536): batches of <= 64 queries against a shard of at least this many rows use the
  *     HBM-streaming scan (every CU streams a disjoint DB slice once) instead of the batched scan.
  * "search_nsplit"     (default 0 = auto): DB row splits per query block in the scan kernel.
+ * "pointnet_pyg_self_loops" (default 1): see t2l_pointnet_features.
  * "profile_events"    (default 0): record hipEvents around each kernel launch (t2l_kernel_stats). */
 int t2l_set_option(t2l_ctx* ctx, const char* name, double value);
 
@@ -218,7 +235,7 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value);
  * (no synchronisation while recording; enabled by option "profile_events" = 1, off by default).
  * Returns the average duration (ms) and the number of launches recorded since the previous call for
  * name = "search_scan" | "search_rerank" | "encode_cells" | "contrastive_loss" | "reduce_objects" | "train_forward" |
- * "train_backward" | "adam_step" (at most the last 512),
+ * "train_backward" | "adam_step" | "pointnet" (at most the last 512),
  * then clears the record. Synchronises on the recorded events. */
 int t2l_kernel_stats(t2l_ctx* ctx, const char* name, float* out_avg_ms, int32_t* out_count);
 

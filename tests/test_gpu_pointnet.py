@@ -1,0 +1,79 @@
+"""GPU tier: the PointNet++ object backbone through the C ABI against the build's own CPU restatement
+(oracle/t2l_oracle_pointnet.py). PARITY UNPINNED w.r.t. the reference: its arithmetic for this stage lives in absent
+third-party packages (see the oracle's header); these tests pin the kernels to the documented deterministic semantics."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import t2l_oracle as O
+from oracle import t2l_oracle_pointnet as OP
+from text2loc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from text2loc_amd.engine import Engine
+
+    e = Engine(0)
+    sd = synth.make_object_branch_weights(0)
+    sd.update(synth.make_pointnet_weights(0))
+    e.load_weights(sd, class_embed=False, color_embed=False)
+    e._sd = sd
+    yield e
+    e.close()
+
+
+def run(eng, cells, pos, rgb):
+    out = eng.pointnet_features(torch.from_numpy(pos).cuda(), torch.from_numpy(rgb).cuda(), cells["offsets"])
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("self_loops", [True, False])
+def test_features2_match_the_restatement(eng, self_loops):
+    cells = synth.make_cells(3, seed=1, min_obj=1, max_obj=5)
+    pos, rgb = synth.make_sampled_points(cells, 1)
+    eng.set_option("pointnet_pyg_self_loops", 1 if self_loops else 0)
+    got = run(eng, cells, pos, rgb)
+    eng.set_option("pointnet_pyg_self_loops", 1)
+    ref = OP.pointnet_features(pos, rgb, cells["offsets"], eng._sd, pyg_self_loops=self_loops)
+    assert got.shape == ref.shape == (int(cells["offsets"][-1]), 256)
+    assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
+    assert (ref > 0).mean() > 0.2  # not a dead network
+
+
+def test_degenerate_objects(eng):
+    """All points identical (every ball query saturates at 32, FPS ties everywhere) and a tiny cluster (1-neighbour balls)."""
+    cells = synth.make_cells(1, seed=3, min_obj=3, max_obj=3)
+    pos, rgb = synth.make_sampled_points(cells, 3)
+    pos[0] = 0.25
+    pos[1] = np.linspace(-1, 1, 256)[:, None].astype(np.float32) * np.array([1, 0, 0], np.float32)  # a line: sparse balls
+    got = run(eng, cells, pos, rgb)
+    ref = OP.pointnet_features(pos, rgb, cells["offsets"], eng._sd)
+    assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_published_mode_cell_embeddings_from_raw_points(eng):
+    """a3 -> a2 -> a4 chained on the GPU: points -> features2 -> mlp_pointnet ... -> cell embedding, vs the oracle chain."""
+    cells = synth.make_cells(4, seed=5, min_obj=2, max_obj=6)
+    pos, rgb = synth.make_sampled_points(cells, 5)
+    f2 = eng.pointnet_features(torch.from_numpy(pos).cuda(), torch.from_numpy(rgb).cuda(), cells["offsets"])
+    packed = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cells.items() if k != "counts"}
+    packed["pn_feat"] = f2
+    emb = eng.encode_cells(packed).cpu().numpy()
+    rc = dict(cells)
+    rc["pn_feat"] = OP.pointnet_features(pos, rgb, cells["offsets"], eng._sd)
+    ref = O.encode_cells(rc, eng._sd, False, False)
+    assert np.abs(emb - ref).max() < 1e-4
+
+
+def test_needs_pointnet_weights():
+    from text2loc_amd.engine import Engine, T2LError
+
+    e = Engine(0)
+    e.load_weights(synth.make_object_branch_weights(0), class_embed=True, color_embed=True)
+    with pytest.raises(T2LError, match="pointnet"):
+        e.pointnet_features(torch.zeros(1, 256, 3, device="cuda"), torch.zeros(1, 256, 3, device="cuda"), np.array([0, 1]))
+    e.close()

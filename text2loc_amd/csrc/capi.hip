@@ -65,6 +65,7 @@ void t2l_destroy(t2l_ctx* ctx) {
   (void)hipDeviceSynchronize();
   free_weights(ctx);
   free_train(ctx);
+  free_pointnet(ctx);
   for (void* p : {(void*)ctx->db, (void*)ctx->db_split, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
                   (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count, ctx->reduce_ws})
     if (p) (void)hipFree(p);
@@ -81,7 +82,15 @@ int t2l_load_weights(t2l_ctx* ctx, const t2l_weight_desc* w, int32_t n, const t2
   if (!ctx) return T2L_EINVAL;
   if (!w || n <= 0 || !cfg) return fail(ctx, T2L_EINVAL, "t2l_load_weights: null/empty arguments");
   T2L_HIP(ctx, hipSetDevice(ctx->device));
-  return load_weights_impl(ctx, w, n, cfg);
+  const int rc = load_weights_impl(ctx, w, n, cfg);
+  return rc ? rc : pointnet_load_impl(ctx, w, n);
+}
+
+int t2l_pointnet_features(t2l_ctx* ctx, const float* pos, const float* rgb, const int32_t* cell_offsets, int32_t n_cells,
+                          float* out_features2, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return pointnet_features_impl(ctx, pos, rgb, cell_offsets, n_cells, out_features2, (hipStream_t)stream);
 }
 
 int t2l_encode_cells(t2l_ctx* ctx, const t2l_packed_cells* in, float* out_emb, void* stream) {
@@ -267,6 +276,8 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     ctx->list_len = (int)value;
   } else if (!strcmp(name, "scan_variant")) {
     ctx->scan_variant = (int)value;
+  } else if (!strcmp(name, "pointnet_pyg_self_loops")) {
+    ctx->pn_self_loops = value != 0;
   } else if (!strcmp(name, "profile_events")) {
     ctx->profile_events = value != 0;
   } else {

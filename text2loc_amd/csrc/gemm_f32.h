@@ -1,0 +1,115 @@
+// f32 MFMA GEMM shared by the training step (train.hip) and the PointNet++ head (pointnet.hip). gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace t2l {
+namespace train {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------------------
+// GEMM: C[M,N] (+)= A(m,k) B(k,n) (+ bias[n]) (relu), f32 MFMA 32x32x2.
+//   A_KC: A[m*lda + k] (k contiguous)  else A[k*lda + m]
+//   B_KC: B[n*ldb + k] (k contiguous)  else B[k*ldb + n]
+// These problems are small (M <= a few thousand tokens, N,K <= 1024) and live in L2, so the kernel is built for
+// PARALLELISM, not for operand reuse: one workgroup owns ONE 32x32 output tile and its four waves split the reduction
+// range four ways; every wave streams its operands straight from global memory into the MFMA operand registers — no
+// LDS staging, no barrier in the loop. The k index inside a 16-step is permuted (lane half kh owns k0+8*kh .. +7) so
+// that k-contiguous operands are two float4 loads per lane; any permutation is valid as long as A and B share it. The
+// four partial tiles meet in LDS once, at the end. M and the reduction range may be ragged; N must be a multiple of 32
+// (and M too when !A_KC).
+// ---------------------------------------------------------------------------------------------------------------
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  int M, N, K, lda, ldb, ldc, relu, accumulate, kchunk;
+  float* colsum;  // !A_KC only: colsum[m] += sum_k A(m,k)  (bias gradient of the same dY), or nullptr
+};
+
+template <bool KC>
+__device__ __forceinline__ void gemm_load(const float* __restrict__ P, int ld, int row, bool row_ok, int k0, int kh, int kend,
+                                          float (&v)[8]) {
+  if (KC) {
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+    if (row_ok) {
+      const float* p = P + (size_t)row * ld + k0 + 8 * kh;
+      x = *reinterpret_cast<const float4*>(p);
+      y = *reinterpret_cast<const float4*>(p + 4);
+    }
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + 8 * kh + j;
+      v[j] = k < kend ? P[(size_t)k * ld + row] : 0.f;
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  __shared__ float red[4 * 16 * 64];
+  __shared__ float cred[4 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, kh = lane >> 5;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int kb = blockIdx.z * g.kchunk, ke = min(g.K, kb + g.kchunk);
+  const int slice = ((((ke - kb) + 3) / 4) + 15) & ~15;  // per-wave share of the reduction range, whole 16-steps
+  const int wk0 = kb + w * slice, wk1 = min(ke, wk0 + slice);
+  const bool a_ok = !A_KC || (m0 + i) < g.M;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float a[8], b[8], an[8], bn[8], csum = 0.f;
+  const bool do_colsum = !A_KC && g.colsum && blockIdx.x == 0;
+  if (wk0 < wk1) {
+    gemm_load<A_KC>(g.A, g.lda, m0 + i, a_ok, wk0, kh, wk1, a);
+    gemm_load<B_KC>(g.B, g.ldb, n0 + i, true, wk0, kh, wk1, b);
+  }
+  for (int k0 = wk0; k0 < wk1; k0 += 16) {
+    if (k0 + 16 < wk1) {
+      gemm_load<A_KC>(g.A, g.lda, m0 + i, a_ok, k0 + 16, kh, wk1, an);
+      gemm_load<B_KC>(g.B, g.ldb, n0 + i, true, k0 + 16, kh, wk1, bn);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+      if (do_colsum) csum += a[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a[j] = an[j];
+      b[j] = bn[j];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(w * 16 + r) * 64 + lane] = acc[r];
+  if (do_colsum) cred[w * 64 + lane] = csum;
+  __syncthreads();
+  if (do_colsum && tid < 32) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s += cred[q * 64 + tid] + cred[q * 64 + 32 + tid];
+    unsafeAtomicAdd(g.colsum + m0 + tid, s);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + 256 * q, r = e >> 6, l = e & 63;
+    const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), cg = n0 + (l & 31);
+    if (row < g.M) {
+      float v = red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l];
+      if (g.bias && blockIdx.z == 0) v += g.bias[cg];
+      if (g.relu) v = fmaxf(v, 0.f);
+      float* dst = g.C + (size_t)row * g.ldc + cg;
+      if (g.accumulate)
+        unsafeAtomicAdd(dst, v);
+      else
+        *dst = v;
+    }
+  }
+}
+
+}  // namespace train
+}  // namespace t2l

@@ -1,0 +1,492 @@
+// PointNet++ object backbone, eval mode: models/pointcloud/pointnet2.py:18-100 —
+//   3 x SetAbstraction (FPS 1/2, ball query r = .2/.3/.4 <= 32 neighbours, PointConv = max over get_mlp(cat[x_j, pos_j-pos_i]))
+//   -> GlobalAbstraction (get_mlp([259,512,1024]) + max over the 32 remaining points) -> lin1/lin2 + ReLU -> features2.
+// PARITY UNPINNED (third-party torch_geometric / torch-cluster arithmetic is absent from the reference tree): the
+// semantics are the deterministic ones spelled out in oracle/t2l_oracle_pointnet.py, which these kernels are tested
+// against. gfx950 only; f32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// One workgroup per object and level. FPS runs on one wave (DPP all-reduces, no LDS traffic in the loop). Every centre's
+// ball query is a wave-level ballot compaction ("first 32 in index order"). The two-layer edge MLP of a centre is one
+// 32-row tile (its <= 32 neighbours; empty slots repeat neighbour 0, harmless under max): layer 1 is computed TRANSPOSED
+// (features x neighbours) so that its MFMA output registers ARE the A operand of layer 2 — no LDS round trip between the
+// layers; BatchNorm and the Linear bias are folded on the host (bias rides on a constant-1 input column), weights are
+// pre-packed in operand order so every wave-level weight load is one coalesced 1 KiB line out of L2.
+#include <math.h>
+#include <string.h>
+
+#include "t2l_internal.h"
+#include "gemm_f32.h"
+
+namespace t2l {
+
+using train::f32x16;
+
+constexpr int kPnPts = 256;  // args.pointnet_numpoints
+
+struct PointNetWeights {
+  float4 *w1[3] = {}, *w2[3] = {};  // SA levels, packed
+  float* b2[3] = {};
+  float4 *ga1 = nullptr, *ga2 = nullptr;
+  float* gab2 = nullptr;
+  float *lin1w = nullptr, *lin1b = nullptr, *lin2w = nullptr, *lin2b = nullptr;
+  // workspace
+  char* ws = nullptr;
+  size_t ws_cap = 0;
+};
+
+void free_pointnet(t2l_ctx* ctx) {
+  PointNetWeights* P = reinterpret_cast<PointNetWeights*>(ctx->pn);
+  if (!P) return;
+  for (int l = 0; l < 3; ++l)
+    for (void* p : {(void*)P->w1[l], (void*)P->w2[l], (void*)P->b2[l]})
+      if (p) (void)hipFree(p);
+  for (void* p : {(void*)P->ga1, (void*)P->ga2, (void*)P->gab2, (void*)P->lin1w, (void*)P->lin1b, (void*)P->lin2w, (void*)P->lin2b, (void*)P->ws})
+    if (p) (void)hipFree(p);
+  delete P;
+  ctx->pn = nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host: fold BatchNorm, pack
+// ---------------------------------------------------------------------------------------------------------------
+using WMap = std::unordered_map<std::string, const t2l_weight_desc*>;
+
+// get_mlp block i of `prefix`: returns W' [cout][cin] and b' [cout] with eval-mode BatchNorm folded in
+static bool fold_block(const WMap& m, const std::string& prefix, int i, int cin, int cout, std::vector<float>& W, std::vector<float>& b) {
+  auto get = [&](const std::string& k, int64_t n) -> const float* {
+    auto it = m.find(prefix + "." + std::to_string(i) + k);
+    return (it == m.end() || it->second->numel != n) ? nullptr : it->second->data;
+  };
+  const float *w = get(".0.weight", (int64_t)cin * cout), *bb = get(".0.bias", cout), *g = get(".1.weight", cout), *be = get(".1.bias", cout),
+              *rm = get(".1.running_mean", cout), *rv = get(".1.running_var", cout);
+  if (!w || !bb || !g || !be || !rm || !rv) return false;
+  W.assign((size_t)cin * cout, 0.f);
+  b.assign(cout, 0.f);
+  for (int o = 0; o < cout; ++o) {
+    const float s = g[o] / sqrtf(rv[o] + 1e-5f);
+    for (int k = 0; k < cin; ++k) W[(size_t)o * cin + k] = w[(size_t)o * cin + k] * s;
+    b[o] = (bb[o] - rm[o]) * s + be[o];
+  }
+  return true;
+}
+
+// [rows/32][kp/8][64 lanes] float4: lane (i, kh) holds Wf[tile*32+i][kh*kp/2 + 4*s4 + 0..3]; Wf = [W | bias column | 0] of width kp
+static std::vector<float> pack_half_split(const std::vector<float>& W, const std::vector<float>* bias, int rows, int cin, int kp) {
+  std::vector<float> out((size_t)rows * kp, 0.f);
+  const int half = kp / 2;
+  for (int t = 0; t < rows / 32; ++t)
+    for (int s4 = 0; s4 < kp / 8; ++s4)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int c = 0; c < 4; ++c) {
+          const int row = t * 32 + (lane & 31), k = (lane >> 5) * half + 4 * s4 + c;
+          float v = 0.f;
+          if (k < cin) v = W[(size_t)row * cin + k];
+          else if (bias && k == cin) v = (*bias)[row];
+          out[(((size_t)t * (kp / 8) + s4) * 64 + lane) * 4 + c] = v;
+        }
+  return out;
+}
+// layer 2 of an SA block, B operand: [h2/32][h1/32][4][64] float4: lane (n, kh): W[nt*32+n][ft*32 + 8*rq + 4*kh + 0..3]
+static std::vector<float> pack_sa_l2(const std::vector<float>& W, int h2, int h1) {
+  std::vector<float> out((size_t)h2 * h1);
+  for (int nt = 0; nt < h2 / 32; ++nt)
+    for (int ft = 0; ft < h1 / 32; ++ft)
+      for (int rq = 0; rq < 4; ++rq)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int c = 0; c < 4; ++c)
+            out[((((size_t)nt * (h1 / 32) + ft) * 4 + rq) * 64 + lane) * 4 + c] =
+                W[(size_t)(nt * 32 + (lane & 31)) * h1 + ft * 32 + 8 * rq + 4 * (lane >> 5) + c];
+  return out;
+}
+
+template <typename T>
+static int upload(t2l_ctx* ctx, T** dst, const std::vector<float>& v) {
+  T2L_HIP(ctx, hipMalloc(dst, v.size() * sizeof(float)));
+  T2L_HIP(ctx, hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  return T2L_OK;
+}
+
+constexpr int kCin[3] = {3, 64, 128}, kH1[3] = {32, 128, 256}, kH2[3] = {64, 128, 256};
+constexpr int k1p(int cin) { return ((cin + 4 + 7) / 8) * 8; }  // [x | pos_j - pos_i | 1 | 0...] padded to 8
+
+// Returns T2L_OK with ctx->pn == nullptr when the state_dict carries no PointNet++ tensors at all.
+int pointnet_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n) {
+  free_pointnet(ctx);
+  const std::string p = "object_encoder.pointnet.";
+  WMap m;
+  for (int i = 0; i < n; ++i)
+    if (w[i].name && !strncmp(w[i].name, p.c_str(), p.size())) m[w[i].name] = &w[i];
+  if (m.empty()) return T2L_OK;
+  PointNetWeights* P = new PointNetWeights();
+  ctx->pn = P;
+  int rc;
+  std::vector<float> W, b;
+  for (int l = 0; l < 3; ++l) {
+    const std::string pre = p + "sa" + std::to_string(l + 1) + ".point_conv.local_nn";
+    if (!fold_block(m, pre, 0, kCin[l] + 3, kH1[l], W, b)) return fail(ctx, T2L_EINVAL, "t2l_load_weights: incomplete " + pre + ".0");
+    if ((rc = upload(ctx, &P->w1[l], pack_half_split(W, &b, kH1[l], kCin[l] + 3, k1p(kCin[l]))))) return rc;
+    if (!fold_block(m, pre, 1, kH1[l], kH2[l], W, b)) return fail(ctx, T2L_EINVAL, "t2l_load_weights: incomplete " + pre + ".1");
+    if ((rc = upload(ctx, &P->w2[l], pack_sa_l2(W, kH2[l], kH1[l])))) return rc;
+    if ((rc = upload(ctx, &P->b2[l], b))) return rc;
+  }
+  if (!fold_block(m, p + "ga.mlp", 0, 259, 512, W, b)) return fail(ctx, T2L_EINVAL, "t2l_load_weights: incomplete " + p + "ga.mlp.0");
+  if ((rc = upload(ctx, &P->ga1, pack_half_split(W, &b, 512, 259, 264)))) return rc;
+  if (!fold_block(m, p + "ga.mlp", 1, 512, 1024, W, b)) return fail(ctx, T2L_EINVAL, "t2l_load_weights: incomplete " + p + "ga.mlp.1");
+  if ((rc = upload(ctx, &P->ga2, pack_half_split(W, nullptr, 1024, 512, 512)))) return rc;
+  if ((rc = upload(ctx, &P->gab2, b))) return rc;
+  auto raw = [&](const char* name, int64_t numel, float** dst) -> int {
+    auto it = m.find(p + name);
+    if (it == m.end() || it->second->numel != numel) return fail(ctx, T2L_EINVAL, std::string("t2l_load_weights: missing ") + p + name);
+    return upload(ctx, dst, std::vector<float>(it->second->data, it->second->data + numel));
+  };
+  if ((rc = raw("lin1.weight", 512 * 1024, &P->lin1w)) || (rc = raw("lin1.bias", 512, &P->lin1b)) ||
+      (rc = raw("lin2.weight", 256 * 512, &P->lin2w)) || (rc = raw("lin2.bias", 256, &P->lin2b)))
+    return rc;
+  return T2L_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float d2_noFMA(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned pn_dpp(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+// all-reduce over the 64 lanes; OP(a,b) on unsigned
+#define PN_WAVE_REDUCE(NAME, OP)                                                                  \
+  __device__ __forceinline__ unsigned NAME(unsigned v) {                                          \
+    v = OP(v, pn_dpp<0xB1>(v));                                                                   \
+    v = OP(v, pn_dpp<0x4E>(v));                                                                   \
+    v = OP(v, pn_dpp<0x141>(v));                                                                  \
+    v = OP(v, pn_dpp<0x140>(v));                                                                  \
+    {                                                                                             \
+      const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);                        \
+      v = OP(r[0], r[1]);                                                                         \
+    }                                                                                             \
+    {                                                                                             \
+      const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);                        \
+      v = OP(r[0], r[1]);                                                                         \
+    }                                                                                             \
+    return v;                                                                                     \
+  }
+__device__ __forceinline__ unsigned pn_umax(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned pn_umin(unsigned a, unsigned b) { return a < b ? a : b; }
+PN_WAVE_REDUCE(wave_umax, pn_umax)
+PN_WAVE_REDUCE(wave_umin, pn_umin)
+
+// Edge MLP of one 32-row tile. xrow[e] = v[kh*K1P/2 + e] of this lane's row (lane&31), v = [x | dpos | 1 | 0].
+// Calls emit(nt, acc) for each 32-column tile of the layer-2 output (pre-bias): acc[r] = row (r&3)+8(r>>2)+4(lane>>5), col lane&31.
+template <int CIN, int H1, int H2, typename Emit>
+__device__ __forceinline__ void sa_mlp_tile(const float (&xrow)[k1p(CIN) / 2], const float4* __restrict__ w1, const float4* __restrict__ w2,
+                                            int lane, Emit&& emit) {
+  constexpr int K1P = k1p(CIN), S4 = K1P / 8, FT = H1 / 32, NT = H2 / 32;
+  f32x16 h1[FT];
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s4 = 0; s4 < S4; ++s4) {
+      const float4 w = w1[(ft * S4 + s4) * 64 + lane];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, xrow[4 * s4 + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, xrow[4 * s4 + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, xrow[4 * s4 + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, xrow[4 * s4 + 3], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h1[ft][r] = fmaxf(acc[r], 0.f);  // BatchNorm + bias folded; ReLU
+    __builtin_amdgcn_sched_barrier(0);  // keep the next tile's weight loads from being hoisted over this one (register pressure)
+  }
+#pragma unroll 1
+  for (int nt = 0; nt < NT; ++nt) {  // rolled: h1 (up to 128 VGPRs) + the input row already fill most of the register file
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const float4 w = w2[((nt * FT + ft) * 4 + rq) * 64 + lane];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h1[ft][4 * rq + 0], w.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h1[ft][4 * rq + 1], w.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h1[ft][4 * rq + 2], w.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h1[ft][4 * rq + 3], w.w, acc, 0, 0, 0);
+      }
+    }
+    emit(nt, acc);
+  }
+}
+
+// this lane's half of the input row [x(CIN) | dpos(3) | 1 | 0...]
+template <int CIN>
+__device__ __forceinline__ void build_xrow(const float* __restrict__ x, float dx, float dy, float dz, int kh, float (&xrow)[k1p(CIN) / 2]) {
+  constexpr int HALF = k1p(CIN) / 2;
+#pragma unroll
+  for (int e = 0; e < HALF; ++e) {
+    const int k = kh * HALF + e;
+    float v = 0.f;
+    if (k < CIN) v = x[k];
+    else if (k == CIN) v = dx;
+    else if (k == CIN + 1) v = dy;
+    else if (k == CIN + 2) v = dz;
+    else if (k == CIN + 3) v = 1.f;
+    xrow[e] = v;
+  }
+}
+
+struct SaParams {
+  const float* src_pos;  // [n_obj][NS][3]
+  const float* src_x;    // [n_obj][NS][CIN]
+  float* dst_pos;        // [n_obj][ND][3]
+  float* dst_x;          // [n_obj][ND][H2]
+  const int32_t* cell_base;  // [n_obj]: first object of the object's cell (PyG batch)
+  const float4* w1;
+  const float4* w2;
+  const float* b2;
+  float r2;
+  int self_loops;
+};
+
+template <int CIN, int H1, int H2, int NS>
+__global__ __launch_bounds__(256, 1) void pn_sa_kernel(SaParams P) {
+  constexpr int ND = NS / 2, XS = CIN + 4, PPL = NS / 64;
+  extern __shared__ float smem[];
+  float* spos = smem;                 // [NS][3]
+  float* sx = spos + NS * 3;          // [NS][XS]
+  float* dpos = sx + NS * XS;         // [ND][3]
+  float* selfm = dpos + ND * 3;       // [ND][H2]
+  int* sel = reinterpret_cast<int*>(selfm + ND * H2);  // [ND]
+  int* nbr = sel + ND;                // [4 waves][32]
+  const int o = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, kh = lane >> 5;
+  const float* gp = P.src_pos + (size_t)o * NS * 3;
+  const float* gx = P.src_x + (size_t)o * NS * CIN;
+  for (int i = tid; i < NS * 3; i += 256) spos[i] = gp[i];
+  for (int i = tid; i < NS * CIN; i += 256) sx[(i / CIN) * XS + (i % CIN)] = gx[i];
+  __syncthreads();
+
+  // ---- farthest point sampling, wave 0: selection order from point 0, lowest index on ties
+  if (w == 0) {
+    float mind[PPL], px[PPL], py[PPL], pz[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+      const int p = lane + 64 * q;
+      px[q] = spos[p * 3]; py[q] = spos[p * 3 + 1]; pz[q] = spos[p * 3 + 2];
+      mind[q] = 3.0e38f;
+    }
+    int last = 0;
+    if (lane == 0) sel[0] = 0;
+    for (int t = 1; t < ND; ++t) {
+      const float cx = spos[last * 3], cy = spos[last * 3 + 1], cz = spos[last * 3 + 2];
+      float best = -1.f;
+      int bi = 0;
+#pragma unroll
+      for (int q = 0; q < PPL; ++q) {
+        mind[q] = fminf(mind[q], d2_noFMA(px[q], py[q], pz[q], cx, cy, cz));
+        if (mind[q] > best) { best = mind[q]; bi = lane + 64 * q; }
+      }
+      const unsigned m = wave_umax(__float_as_uint(best));  // distances are >= 0: the bit pattern orders like the value
+      last = (int)wave_umin(__float_as_uint(best) == m ? (unsigned)bi : 0x7fffffffu);
+      if (lane == 0) sel[t] = last;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < ND * 3; i += 256) {
+    const float v = spos[sel[i / 3] * 3 + (i % 3)];
+    dpos[i] = v;
+    P.dst_pos[(size_t)o * ND * 3 + i] = v;
+  }
+  __syncthreads();
+
+  // ---- the extra (k -> k) messages of PyG's add_self_loops on the bipartite batch: centre k of the CELL's batch also
+  // hears source node k of the cell's batch (oracle/t2l_oracle_pointnet.py)
+  if (P.self_loops) {
+    const int cb = P.cell_base[o];
+    for (int tt = w; tt < ND / 32; tt += 4) {
+      const int t = tt * 32 + j;
+      const size_t k = (size_t)(o - cb) * ND + t;  // node index inside the cell's batch
+      const float* sp = P.src_pos + ((size_t)cb * NS + k) * 3;
+      float xrow[k1p(CIN) / 2];
+      build_xrow<CIN>(P.src_x + ((size_t)cb * NS + k) * CIN, sp[0] - dpos[t * 3], sp[1] - dpos[t * 3 + 1], sp[2] - dpos[t * 3 + 2], kh, xrow);
+      sa_mlp_tile<CIN, H1, H2>(xrow, P.w1, P.w2, lane, [&](int nt, const f32x16& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) selfm[(tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * H2 + nt * 32 + j] = acc[r];
+      });
+    }
+  } else {
+    for (int i = tid; i < ND * H2; i += 256) selfm[i] = -3.0e38f;
+  }
+  __syncthreads();
+
+  // ---- one 32-row tile per centre: ball query (first 32 in index order), edge MLP, max
+  for (int t = w; t < ND; t += 4) {
+    const float cx = dpos[t * 3], cy = dpos[t * 3 + 1], cz = dpos[t * 3 + 2];
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+      const int p = lane + 64 * q;
+      const bool in = d2_noFMA(spos[p * 3], spos[p * 3 + 1], spos[p * 3 + 2], cx, cy, cz) < P.r2;
+      const unsigned long long mask = __ballot(in);
+      const int rank = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+      if (in && rank < 32) nbr[w * 32 + rank] = p;
+      cnt += __popcll(mask);
+    }
+    cnt = min(cnt, 32);  // >= 1: the centre is one of the source points
+    const int nb = nbr[w * 32 + (j < cnt ? j : 0)];
+    float xrow[k1p(CIN) / 2];
+    build_xrow<CIN>(sx + nb * XS, spos[nb * 3] - cx, spos[nb * 3 + 1] - cy, spos[nb * 3 + 2] - cz, kh, xrow);
+    sa_mlp_tile<CIN, H1, H2>(xrow, P.w1, P.w2, lane, [&](int nt, const f32x16& acc) {
+      float m = acc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+      m = fmaxf(m, __shfl_xor(m, 32));
+      const int c = nt * 32 + j;
+      if (kh == 0) P.dst_x[((size_t)o * ND + t) * H2 + c] = fmaxf(fmaxf(m, selfm[t * H2 + c]) + P.b2[c], 0.f);
+    });
+  }
+}
+
+// GlobalAbstraction: get_mlp([259,512,1024]) over the 32 points of an object, max. One workgroup per object.
+constexpr int kGaK = 264, kGaXS = kGaK + 4, kGaH1 = 512, kGaHS = kGaH1 + 4, kGaH2 = 1024;
+__global__ __launch_bounds__(256, 1) void pn_ga_kernel(const float* __restrict__ pos3, const float* __restrict__ x3,
+                                                       const float4* __restrict__ w1, const float4* __restrict__ w2,
+                                                       const float* __restrict__ b2, float* __restrict__ f0) {
+  extern __shared__ float smem[];
+  float* X = smem;                 // [32][kGaXS]  rows = [x(256) | pos(3) | 1 | 0..]
+  float* Hd = X + 32 * kGaXS;      // [32][kGaHS]
+  const int o = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, kh = lane >> 5;
+  for (int i = tid; i < 32 * kGaK; i += 256) {
+    const int r = i / kGaK, k = i % kGaK;
+    float v = 0.f;
+    if (k < 256) v = x3[((size_t)o * 32 + r) * 256 + k];
+    else if (k < 259) v = pos3[((size_t)o * 32 + r) * 3 + (k - 256)];
+    else if (k == 259) v = 1.f;
+    X[r * kGaXS + k] = v;
+  }
+  __syncthreads();
+  // layer 1: 16 column tiles, 4 per wave; A = X (lane row j, k half kh), B = packed weights
+  for (int nt = w; nt < kGaH1 / 32; nt += 4) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* xr = X + j * kGaXS + kh * (kGaK / 2);
+#pragma unroll 3
+    for (int s4 = 0; s4 < kGaK / 8; ++s4) {
+      const float4 a = *reinterpret_cast<const float4*>(xr + 4 * s4);
+      const float4 b = w1[(nt * (kGaK / 8) + s4) * 64 + lane];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Hd[((r & 3) + 8 * (r >> 2) + 4 * kh) * kGaHS + nt * 32 + j] = fmaxf(acc[r], 0.f);
+  }
+  __syncthreads();
+  for (int nt = w; nt < kGaH2 / 32; nt += 4) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* hr = Hd + j * kGaHS + kh * (kGaH1 / 2);
+#pragma unroll 4
+    for (int s4 = 0; s4 < kGaH1 / 8; ++s4) {
+      const float4 a = *reinterpret_cast<const float4*>(hr + 4 * s4);
+      const float4 b = w2[(nt * (kGaH1 / 8) + s4) * 64 + lane];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    float m = acc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    if (kh == 0) f0[(size_t)o * kGaH2 + nt * 32 + j] = fmaxf(m + b2[nt * 32 + j], 0.f);
+  }
+}
+
+template <int CIN, int H1, int H2, int NS>
+static size_t sa_lds_bytes() {
+  constexpr int ND = NS / 2, XS = CIN + 4;
+  return sizeof(float) * (NS * 3 + NS * XS + ND * 3 + ND * H2) + sizeof(int) * (ND + 4 * 32);
+}
+
+template <int CIN, int H1, int H2, int NS>
+static hipError_t launch_sa(const SaParams& P, int n_obj, hipStream_t s) {
+  const size_t lds = sa_lds_bytes<CIN, H1, H2, NS>();
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_kernel<CIN, H1, H2, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS>), dim3(n_obj), dim3(256), lds, s, P);
+  return hipGetLastError();
+}
+
+int pointnet_features_impl(t2l_ctx* ctx, const float* pos, const float* rgb, const int32_t* cell_offsets, int n_cells, float* out,
+                           hipStream_t s) {
+  PointNetWeights* W = reinterpret_cast<PointNetWeights*>(ctx->pn);
+  if (!W) return fail(ctx, T2L_ESTATE, "t2l_pointnet_features: the loaded state_dict carried no object_encoder.pointnet.* tensors");
+  if (!pos || !rgb || !cell_offsets || !out || n_cells <= 0) return fail(ctx, T2L_EINVAL, "t2l_pointnet_features: null argument");
+  const int n_obj = cell_offsets[n_cells] - cell_offsets[0];
+  if (cell_offsets[0] != 0 || n_obj <= 0) return fail(ctx, T2L_EINVAL, "t2l_pointnet_features: cell_offsets must start at 0 and end at n_objects > 0");
+  std::vector<int32_t> base(n_obj);
+  for (int c = 0; c < n_cells; ++c) {
+    if (cell_offsets[c + 1] < cell_offsets[c]) return fail(ctx, T2L_EINVAL, "t2l_pointnet_features: cell_offsets must be non-decreasing");
+    for (int o = cell_offsets[c]; o < cell_offsets[c + 1]; ++o) base[o] = cell_offsets[c];
+  }
+  // level buffers for ALL objects (105 KB per object; 288 GB of HBM hold the whole KITTI360Pose DB at once)
+  const size_t per_obj = sizeof(float) * (128 * 3 + 128 * 64 + 64 * 3 + 64 * 128 + 32 * 3 + 32 * 256 + 1024 + 512) + sizeof(int32_t);
+  const size_t need = per_obj * (size_t)n_obj + 4096;
+  if (need > W->ws_cap) {
+    if (W->ws) (void)hipFree(W->ws);
+    W->ws = nullptr;
+    W->ws_cap = 0;
+    T2L_HIP(ctx, hipMalloc(&W->ws, need));
+    W->ws_cap = need;
+  }
+  float* p1 = reinterpret_cast<float*>(W->ws);
+  float* x1 = p1 + (size_t)n_obj * 128 * 3;
+  float* p2 = x1 + (size_t)n_obj * 128 * 64;
+  float* x2 = p2 + (size_t)n_obj * 64 * 3;
+  float* p3 = x2 + (size_t)n_obj * 64 * 128;
+  float* x3 = p3 + (size_t)n_obj * 32 * 3;
+  float* f0 = x3 + (size_t)n_obj * 32 * 256;
+  float* f1 = f0 + (size_t)n_obj * 1024;
+  int32_t* d_base = reinterpret_cast<int32_t*>(f1 + (size_t)n_obj * 512);
+  T2L_HIP(ctx, hipMemcpyAsync(d_base, base.data(), sizeof(int32_t) * n_obj, hipMemcpyHostToDevice, s));
+  T2L_HIP(ctx, hipStreamSynchronize(s));  // `base` is a host temporary
+  event_begin(ctx, "pointnet", s);
+  const float radii[3] = {0.2f, 0.3f, 0.4f};
+  SaParams P{pos, rgb, p1, x1, d_base, W->w1[0], W->w2[0], W->b2[0], radii[0] * radii[0], ctx->pn_self_loops};
+  T2L_HIP(ctx, (launch_sa<3, 32, 64, 256>(P, n_obj, s)));
+  P = SaParams{p1, x1, p2, x2, d_base, W->w1[1], W->w2[1], W->b2[1], radii[1] * radii[1], ctx->pn_self_loops};
+  T2L_HIP(ctx, (launch_sa<64, 128, 128, 128>(P, n_obj, s)));
+  P = SaParams{p2, x2, p3, x3, d_base, W->w1[2], W->w2[2], W->b2[2], radii[2] * radii[2], ctx->pn_self_loops};
+  T2L_HIP(ctx, (launch_sa<128, 256, 256, 64>(P, n_obj, s)));
+  {
+    const size_t lds = sizeof(float) * (32 * kGaXS + 32 * kGaHS);
+    static bool attr = false;
+    if (!attr) {
+      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr = true;
+    }
+    hipLaunchKernelGGL(pn_ga_kernel, dim3(n_obj), dim3(256), lds, s, p3, x3, W->ga1, W->ga2, W->gab2, f0);
+  }
+  {  // lin1 / lin2 + ReLU over all objects (pointnet2.py:86-89): plain GEMMs on the row-major torch weights
+    train::GemmArgs g{f0, W->lin1w, f1, W->lin1b, n_obj, 512, 1024, 1024, 1024, 512, 1, 0, 1024, nullptr};
+    hipLaunchKernelGGL((train::gemm_kernel<true, true>), dim3(512 / 32, (n_obj + 31) / 32, 1), dim3(256), 0, s, g);
+    train::GemmArgs h{f1, W->lin2w, out, W->lin2b, n_obj, 256, 512, 512, 512, 256, 1, 0, 512, nullptr};
+    hipLaunchKernelGGL((train::gemm_kernel<true, true>), dim3(256 / 32, (n_obj + 31) / 32, 1), dim3(256), 0, s, h);
+  }
+  event_end(ctx, "pointnet", s);
+  T2L_HIP(ctx, hipGetLastError());
+  return T2L_OK;
+}
+
+}  // namespace t2l

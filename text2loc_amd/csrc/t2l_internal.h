@@ -67,6 +67,8 @@ struct t2l_ctx {
   // encoder
   t2l::EncoderWeights* enc = nullptr;
   void* train = nullptr;         // t2l::TrainState (train.hip)
+  void* pn = nullptr;            // t2l::PointNetWeights (pointnet.hip), null when no pointnet.* tensors were loaded
+  int pn_self_loops = 1;         // PyG PointConv add_self_loops quirk on the bipartite batch (oracle/t2l_oracle_pointnet.py)
   // options
   double eps_scale = 1.0;
   int nsplit_override = 0;
@@ -109,6 +111,11 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
 int adam_step_impl(t2l_ctx* ctx, float lr, float b1, float b2, float eps, hipStream_t s);
 int zero_grad_impl(t2l_ctx* ctx, hipStream_t s);
 void free_train(t2l_ctx* ctx);
+// pointnet.hip
+int pointnet_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n);
+int pointnet_features_impl(t2l_ctx* ctx, const float* pos, const float* rgb, const int32_t* cell_offsets, int n_cells, float* out,
+                           hipStream_t s);
+void free_pointnet(t2l_ctx* ctx);
 // loss.hip
 int loss_impl(t2l_ctx* ctx, const float* a, const float* p, int B, float temp, float* loss, float* ga, float* gp,
               hipStream_t s);

@@ -50,6 +50,7 @@ EXPORTS = {
     "t2l_last_error": (C.c_char_p, [C.c_void_p]),
     "t2l_load_weights": (C.c_int, [C.c_void_p, C.POINTER(_WeightDesc), C.c_int32, C.POINTER(_ModelConfig)]),
     "t2l_encode_cells": (C.c_int, [C.c_void_p, C.POINTER(_PackedCells), C.c_void_p, C.c_void_p]),
+    "t2l_pointnet_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "t2l_reduce_objects": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_db_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
@@ -144,7 +145,7 @@ class Engine:
         for name, v in state_dict.items():
             if not (name.startswith("object_encoder.") or name.startswith("obj_inter_module.")):
                 continue
-            if name.startswith("object_encoder.pointnet.") or name.endswith("num_batches_tracked"):
+            if name.endswith("num_batches_tracked"):
                 continue
             a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
             a = np.ascontiguousarray(a, dtype=np.float32)
@@ -176,6 +177,20 @@ class Engine:
             po.ctypes.data, n, cc.ctypes.data, cr.ctypes.data, len(cr),
             out["rgb"].data_ptr(), out["center"].data_ptr(), out["n_pts"].data_ptr(), out["color_idx"].data_ptr(),
             _stream_ptr()))
+        return out
+
+    # ------------------------------------------------------------------ PointNet++ backbone (a3)
+    def pointnet_features(self, pos: torch.Tensor, rgb: torch.Tensor, cell_offsets) -> torch.Tensor:
+        """pos, rgb f32[n_objects,256,3] on the GPU, cell_offsets i32[n_cells+1] (HOST) -> features2 f32[n_objects,256]."""
+        co = cell_offsets.cpu().numpy() if isinstance(cell_offsets, torch.Tensor) else np.asarray(cell_offsets)
+        co = np.ascontiguousarray(co, dtype=np.int32)
+        n = int(pos.shape[0])
+        if pos.shape != (n, 256, 3) or rgb.shape != (n, 256, 3) or int(co[-1]) != n:
+            raise T2LError(f"pointnet_features: expected [n,256,3] points and offsets ending at n, got {tuple(pos.shape)}, "
+                           f"{tuple(rgb.shape)}, {int(co[-1])}")
+        out = torch.empty((n, EMBED_DIM), dtype=torch.float32, device=pos.device)
+        self._check(self.lib.t2l_pointnet_features(self._h, _dev_ptr(pos, torch.float32, "pos"), _dev_ptr(rgb, torch.float32, "rgb"),
+                                                   co.ctypes.data, len(co) - 1, out.data_ptr(), _stream_ptr()))
         return out
 
     # ------------------------------------------------------------------ cell encoding

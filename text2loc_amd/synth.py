@@ -104,6 +104,40 @@ def make_object_branch_weights(seed: int = 0, embed_dim: int = 256, num_layers: 
     return sd
 
 
+def make_pointnet_weights(seed: int = 0, n_classes: int = 22, n_colors: int = 8) -> dict:
+    """state_dict (numpy) of ``object_encoder.pointnet.*`` with the reference's key layout
+    (models/pointcloud/pointnet2.py:52-64): three SetAbstraction get_mlp's, the global get_mlp, lin1, lin2 and the
+    two (unused on this path) classifier heads."""
+    rng = np.random.default_rng([seed, 0x9A27])
+    sd: dict = {}
+    p = "object_encoder.pointnet."
+    _mlp(rng, [3 + 3, 32, 64], p + "sa1.point_conv.local_nn", sd)
+    _mlp(rng, [64 + 3, 128, 128], p + "sa2.point_conv.local_nn", sd)
+    _mlp(rng, [128 + 3, 256, 256], p + "sa3.point_conv.local_nn", sd)
+    _mlp(rng, [256 + 3, 512, 1024], p + "ga.mlp", sd)
+    _linear(rng, 512, 1024, p + "lin1", sd)
+    _linear(rng, 256, 512, p + "lin2", sd)
+    _linear(rng, n_classes, 256, p + "class_classifier", sd)
+    _linear(rng, n_colors, 256, p + "color_classifier", sd)
+    return sd
+
+
+def make_sampled_points(cells: dict, seed: int = 0, n_points: int = 256):
+    """(pos f32[total_objects, n_points, 3], rgb f32[total_objects, n_points, 3]): what the reference's dataloader hands
+    PointNet++ per object after FixedPoints(256) + NormalizeScale (dataloading/kitti360pose/utils.py:91-147,
+    training/coarse.py:182-193): positions centred and scaled into [-1,1]^3, colours in [0,1]. Objects are anisotropic
+    Gaussian blobs so that the 0.2/0.3/0.4 ball queries see anything from 1 to >32 neighbours."""
+    rng = np.random.default_rng([seed, 0xB10B])
+    total = int(cells["offsets"][-1])
+    scale = rng.uniform(0.05, 0.6, size=(total, 1, 3))
+    pos = rng.standard_normal((total, n_points, 3)) * scale
+    pos -= pos.mean(axis=1, keepdims=True)
+    pos /= np.abs(pos).max(axis=(1, 2), keepdims=True) / 0.999999
+    base = rng.uniform(0, 1, size=(total, 1, 3))
+    rgb = np.clip(base + 0.1 * rng.standard_normal((total, n_points, 3)), 0, 1)
+    return pos.astype(np.float32), rgb.astype(np.float32)
+
+
 def make_language_head_weights(seed: int = 0, embed_dim: int = 256, t5_dim: int = 1024) -> dict:
     """state_dict (numpy) of the text head after T5 (models/language_encoder.py:95-101)."""
     rng = np.random.default_rng([seed, 0x7E47])
