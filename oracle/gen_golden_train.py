@@ -127,6 +127,17 @@ def main():
     pn_path = H.make_pointnet_ckpt(osp.join(tmp, "pointnet.pth"))
     for mode in ("embed", "pn"):
         run(mode, hf_dir, pn_path)
+    # key layout of the reference's PointNet2 module (models/pointcloud/pointnet2.py:52-64) as its own constructor builds it
+    # (PointConv is an import shim that only holds ``local_nn``, the attribute name torch_geometric uses): names + shapes
+    import argparse
+
+    from models.pointcloud.pointnet2 import PointNet2
+
+    pn = PointNet2(22, 9, argparse.Namespace(pointnet_layers=3, pointnet_variation=0))
+    sd = pn.state_dict()
+    np.savez_compressed(osp.join(OUT, "pointnet_keys.npz"), names=np.array(list(sd.keys())),
+                        shapes=np.array([",".join(str(d) for d in v.shape) for v in sd.values()]))
+    print("pointnet_keys", len(sd))
 
 
 if __name__ == "__main__":

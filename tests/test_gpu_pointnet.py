@@ -77,3 +77,48 @@ def test_needs_pointnet_weights():
     with pytest.raises(T2LError, match="pointnet"):
         e.pointnet_features(torch.zeros(1, 256, 3, device="cuda"), torch.zeros(1, 256, 3, device="cuda"), np.array([0, 1]))
     e.close()
+
+
+def test_drop_in_published_mode_from_point_batches():
+    """CellRetrievalNetwork(class_embed off).encode_objects(objects, point batches): Object3d lists + the dataloader's
+    per-cell point batches in, cell embeddings out — PointNet++, object encoder and set transformer all in the engine."""
+    import argparse
+
+    from tests.test_host_logic import make_objects
+    from text2loc_amd import packing
+    from text2loc_amd.cell_retrieval import CellRetrievalNetwork
+
+    class Txt(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        @property
+        def device(self):
+            return self.p.device
+
+    args = argparse.Namespace(coarse_embed_dim=256, object_size=28, object_inter_module_num_heads=4,
+                              object_inter_module_num_layers=2, class_embed=False, color_embed=False,
+                              use_features=["class", "color", "position", "num"], pointnet_freeze=True)
+    cells = synth.make_cells(3, seed=9, min_obj=2, max_obj=5)
+    objects = make_objects(cells, 9)
+    model = CellRetrievalNetwork(synth.KNOWN_CLASS, synth.COLOR_NAMES, args, language_encoder=Txt())
+    sd = synth.make_object_branch_weights(2)
+    sd.update(synth.make_pointnet_weights(2, n_classes=len(synth.KNOWN_CLASS), n_colors=len(synth.COLOR_NAMES)))
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    model = model.to("cuda").eval()
+    batches = packing.sample_object_points(objects, 256, np.random.default_rng(0))
+    emb = model.encode_objects(objects, batches).cpu().numpy()
+    # the same chain through the restatements
+    pos = np.concatenate([b["pos"].reshape(-1, 256, 3) for b in batches])
+    rgb = np.concatenate([b["x"].reshape(-1, 256, 3) for b in batches])
+    for p in pos:  # NormalizeScale: centred, inside the unit cube
+        assert np.abs(p.mean(0)).max() < 1e-5 and 0.99 < np.abs(p).max() <= 1.0
+    packed = packing.pack_cells(objects, model.object_encoder.known_classes, model.object_encoder.known_colors)
+    packed["pn_feat"] = OP.pointnet_features(pos, rgb, packed["offsets"], sd)
+    ref = O.encode_cells(packed, sd, False, False)
+    assert np.abs(emb - ref).max() < 1e-4
+    # precomputed features2 remain accepted
+    feats = [torch.from_numpy(packed["pn_feat"][packed["offsets"][i]:packed["offsets"][i + 1]]) for i in range(3)]
+    emb2 = model.encode_objects(objects, feats).cpu().numpy()
+    assert np.abs(emb2 - ref).max() < 1e-4

@@ -163,6 +163,7 @@ def test_checkpoint_key_names_match_the_reference_layout():
     model = CellRetrievalNetwork(synth.KNOWN_CLASS, synth.COLOR_NAMES, args, language_encoder=le)
     want = {k: v for k, v in synth.make_object_branch_weights(0).items()}
     want.update(synth.make_language_head_weights(0))
+    want.update(synth.make_pointnet_weights(0, n_classes=len(synth.KNOWN_CLASS), n_colors=len(synth.COLOR_NAMES)))
     have = model.state_dict()
     for k, v in want.items():
         assert k in have, k
@@ -175,3 +176,15 @@ def test_checkpoint_key_names_match_the_reference_layout():
     model.eval()
     with pytest.raises(Exception, match="no CPU fallback|MI355X"):
         model.encode_objects([[Obj("pole", np.zeros((30, 3)), np.zeros((30, 3), np.float32))]], [None])
+
+
+def test_pointnet_parameter_names_match_the_reference_module(golden):
+    """object_encoder.pointnet.* of the mirror == state_dict of the reference's own PointNet2(22, 9, args) (names, shapes)."""
+    from text2loc_amd.cell_retrieval import PointNet2Params
+
+    g = golden("pointnet_keys")
+    want = {str(n): tuple(int(d) for d in str(s).split(",") if d) for n, s in zip(g["names"], g["shapes"])}
+    have = {k: tuple(v.shape) for k, v in PointNet2Params(22, 9).state_dict().items()}
+    assert have == want
+    sd = synth.make_pointnet_weights(0, n_classes=22, n_colors=9)
+    assert {k[len("object_encoder.pointnet."):]: tuple(np.asarray(v).shape) for k, v in sd.items()} == want

@@ -10,12 +10,13 @@ on the boundary that ``training.coarse.eval_epoch`` / ``evaluation.pipeline.run_
 
 The object branch's modules below are PARAMETER CONTAINERS only (so that checkpoints load and save with the
 reference's key names); their arithmetic runs in the HIP engine. The text branch stays on PyTorch, as the
-north star prescribes. Under ``model.train()`` ``encode_objects`` runs the engine's training-mode forward
+north star prescribes. PointNet++ (published feature mode) runs in the engine too when ``object_points`` carries the
+cells' point batches (parity unpinned, see oracle/t2l_oracle_pointnet.py). Under ``model.train()`` ``encode_objects`` runs the engine's training-mode forward
 (batch-statistics BatchNorm, the TransformerEncoderLayers' dropout) and returns a tensor whose ``backward``
 runs the engine's backward kernels, which ADD into the ``.grad`` of these same nn.Parameters; step them with
-``text2loc_amd.optim.Adam`` (or any torch optimizer). Not built (DESIGN.md "out of scope / next"): PointNet++
-itself — in the published feature mode (class_embed off) ``object_points`` must carry precomputed ``features2``
-per cell (their gradient is returned when they require grad).
+``text2loc_amd.optim.Adam`` (or any torch optimizer). PointNet++ is eval-only here (the ``--pointnet_freeze``
+setting): its backward is not built; precomputed ``features2`` passed as tensors that require grad do receive
+their gradient.
 """
 from __future__ import annotations
 
@@ -45,11 +46,48 @@ def get_mlp(channels: Sequence[int], add_batchnorm: bool = True, last_relu: bool
     return nn.Sequential(*blocks)
 
 
+class _PointConvParams(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.local_nn = get_mlp(channels)
+
+
+class _SetAbstractionParams(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.point_conv = _PointConvParams(channels)
+
+
+class _GlobalAbstractionParams(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.mlp = get_mlp(channels)
+
+
+class PointNet2Params(nn.Module):
+    """Parameters of models/pointcloud/pointnet2.py:52-64 under the same names (so that the published
+    ``pointnet_acc0.86_lr1_p256.pth`` / ``coarse.pth`` key layout loads); the arithmetic is t2l_pointnet_features."""
+
+    def __init__(self, num_classes: int, num_colors: int):
+        super().__init__()
+        self.sa1 = _SetAbstractionParams([3 + 3, 32, 64])
+        self.sa2 = _SetAbstractionParams([64 + 3, 128, 128])
+        self.sa3 = _SetAbstractionParams([128 + 3, 256, 256])
+        self.ga = _GlobalAbstractionParams([256 + 3, 512, 1024])
+        self.lin1 = nn.Linear(1024, 512)
+        self.lin2 = nn.Linear(512, 256)
+        self.class_classifier = nn.Linear(256, num_classes)
+        self.color_classifier = nn.Linear(256, num_colors)
+
+
 class ObjectEncoderParams(nn.Module):
     """Parameters of models/object_encoder.py:28-64 under the same names (PointNet++ sub-module excluded)."""
 
-    def __init__(self, embed_dim: int, known_classes: List[str], args):
+    def __init__(self, embed_dim: int, known_classes: List[str], args, known_colors: Optional[List[str]] = None):
         super().__init__()
+        self.pointnet = PointNet2Params(len(known_classes), len(known_colors) if known_colors is not None else 8)
+        if bool(getattr(args, "pointnet_freeze", True)):
+            self.pointnet.requires_grad_(False)
         self.known_classes = packing.class_table(known_classes)
         self.known_colors = packing.color_table()
         self.class_embedding = nn.Embedding(len(self.known_classes), embed_dim, padding_idx=0)
@@ -167,7 +205,7 @@ class CellRetrievalNetwork(nn.Module):
         if args.object_size != OBJECT_SIZE:
             raise T2LError(f"the engine is built for object_size={OBJECT_SIZE}, got {args.object_size}")
         self.object_size = args.object_size
-        self.object_encoder = ObjectEncoderParams(self.embed_dim, known_classes, args)
+        self.object_encoder = ObjectEncoderParams(self.embed_dim, known_classes, args, known_colors)
         self.obj_inter_module = nn.ModuleList([
             nn.TransformerEncoderLayer(self.embed_dim, args.object_inter_module_num_heads,
                                        dim_feedforward=2 * self.embed_dim)
@@ -205,17 +243,35 @@ class CellRetrievalNetwork(nn.Module):
         with torch.no_grad():
             return self._encode_objects_eval(objects, object_points)
 
-    def _pn_features(self, object_points, as_tensor: bool):
+    def _pn_features(self, object_points, eng: Engine):
+        """PointNet++ ``features2`` [n_objects,256] on the GPU for the published feature mode (class_embed off), or None.
+        ``object_points``: per cell EITHER a precomputed [n_i,256] feature array/tensor OR the cell's point batch as the
+        reference's dataloader builds it (a PyG ``Batch`` or anything with ``.pos`` / ``.x`` of shape [n_i*256,3], or a
+        dict with those keys) — then the engine's PointNet++ kernels run (t2l_pointnet_features, eval mode, no gradient:
+        the ``--pointnet_freeze`` setting)."""
         a = self.args
         if not ("class" in a.use_features and not bool(getattr(a, "class_embed", False))):
             return None
         if object_points is None or any(p is None for p in object_points):
-            raise T2LError("class_embed is off: object_points must hold precomputed PointNet++ features2 "
-                           "[n_i,256] per cell (PointNet++ kernels are not built yet)")
-        if as_tensor:
-            return torch.cat([p if isinstance(p, torch.Tensor) else torch.as_tensor(np.asarray(p)) for p in object_points],
-                             dim=0).to(self.device, torch.float32).reshape(-1, 256)
-        return [p.detach().cpu().numpy() if isinstance(p, torch.Tensor) else np.asarray(p) for p in object_points]
+            raise T2LError("class_embed is off: object_points must hold, per cell, PointNet++ features2 [n_i,256] or the "
+                           "cell's point batch (.pos/.x [n_i*256,3])")
+        dev = self.device
+
+        def field(p, name):
+            return p[name] if isinstance(p, dict) else getattr(p, name, None)
+
+        if all(field(p, "pos") is not None for p in object_points if not isinstance(p, (torch.Tensor, np.ndarray))) and \
+                not isinstance(object_points[0], (torch.Tensor, np.ndarray)):
+            if "color" not in a.use_features:  # ablation of the reference: void all colours (object_encoder.py:87-90)
+                xs = [torch.zeros_like(torch.as_tensor(field(p, "x"))) for p in object_points]
+            else:
+                xs = [torch.as_tensor(field(p, "x")) for p in object_points]
+            pos = torch.cat([torch.as_tensor(field(p, "pos")).reshape(-1, 256, 3) for p in object_points]).to(dev, torch.float32)
+            rgb = torch.cat([x.reshape(-1, 256, 3) for x in xs]).to(dev, torch.float32)
+            counts = [int(torch.as_tensor(field(p, "pos")).shape[0]) // 256 for p in object_points]
+            return eng.pointnet_features(pos.contiguous(), rgb.contiguous(), np.concatenate([[0], np.cumsum(counts)]).astype(np.int32))
+        return torch.cat([p if isinstance(p, torch.Tensor) else torch.as_tensor(np.asarray(p)) for p in object_points],
+                         dim=0).to(dev, torch.float32).reshape(-1, 256)
 
     # ---- training mode (SURVEY.md §8 a9) ----------------------------------------------------------------
     def _train_tensors(self):
@@ -231,6 +287,7 @@ class CellRetrievalNetwork(nn.Module):
             skip.append("object_encoder.color_encoder.")
         if "color" not in a.use_features or not co:
             skip.append("object_encoder.color_embedding.")
+        skip.append("object_encoder.pointnet.")  # frozen backbone: not part of the engine's training step
         if "position" not in a.use_features:
             skip.append("object_encoder.pos_encoder.")
         if "num" not in a.use_features:
@@ -278,7 +335,9 @@ class CellRetrievalNetwork(nn.Module):
         if dev.type != "cuda":
             raise T2LError("encode_objects runs on the MI355X only (model.to('cuda')); there is no CPU fallback")
         eng = self.train_engine()
-        pn = self._pn_features(object_points, as_tensor=True)
+        if self._weights_version is None and "class" in self.args.use_features and not bool(getattr(self.args, "class_embed", False)):
+            self.engine()  # the PointNet++ weights travel with the eval-path upload
+        pn = self._pn_features(object_points, eng)
         if any(getattr(o, "_t2l_feat", None) is None for objs in objects for o in objs):
             packed = packing.pack_cells_gpu(eng, objects, self.object_encoder.known_classes,
                                             self.object_encoder.known_colors, dev)
@@ -304,19 +363,21 @@ class CellRetrievalNetwork(nn.Module):
         dev = self.device
         if dev.type != "cuda":
             raise T2LError("encode_objects runs on the MI355X only (model.to('cuda')); there is no CPU fallback")
-        pn = self._pn_features(object_points, as_tensor=False)
         eng = self.engine()
+        pn = self._pn_features(object_points, eng)
         if any(getattr(o, "_t2l_feat", None) is None for objs in objects for o in objs):
             # raw points not reduced yet: one HBM pass on the GPU (t2l_reduce_objects) instead of three numpy
             # reductions per object on the host (what the reference redoes on every call)
             packed = packing.pack_cells_gpu(eng, objects, self.object_encoder.known_classes,
                                             self.object_encoder.known_colors, dev)
-            if pn is not None:
-                packed["pn_feat"] = torch.from_numpy(np.concatenate(
-                    [np.asarray(f, dtype=np.float32).reshape(-1, 256) for f in pn], axis=0)).to(dev)
-            return eng.encode_cells(packed)
-        packed = packing.pack_cells(objects, self.object_encoder.known_classes, self.object_encoder.known_colors, pn)
-        return eng.encode_cells(packing.to_device(packed, dev))
+        else:
+            packed = packing.to_device(packing.pack_cells(objects, self.object_encoder.known_classes,
+                                                          self.object_encoder.known_colors, None), dev)
+        if pn is not None:
+            if int(pn.shape[0]) != int(packed["offsets"][-1]):
+                raise T2LError("object_points must describe exactly the objects of each cell")
+            packed["pn_feat"] = pn.detach().contiguous()
+        return eng.encode_cells(packed)
 
     # ---- engine plumbing --------------------------------------------------------------------------------
     def engine(self) -> Engine:

@@ -110,6 +110,26 @@ def pack_cells_gpu(engine, objects: List[List[object]], known_classes: Dict[str,
     return red
 
 
+def sample_object_points(objects: List[List[object]], num: int = 256, rng: Optional[np.random.Generator] = None):
+    """Per cell, the point batch the reference's dataloader hands PointNet++ (dataloading/kitti360pose/utils.py:91-147 with
+    the eval transform of evaluation/pipeline.py:215-223): ``FixedPoints(num)`` — ``num`` indices drawn with replacement —
+    then ``NormalizeScale`` (centre on the mean, scale by 0.999999 / max|coordinate|). Returns a list of dicts
+    ``{"pos": f32[n_i*num,3], "x": f32[n_i*num,3]}`` (object-major), the duck type ``encode_objects`` accepts."""
+    rng = rng or np.random.default_rng()
+    out = []
+    for objs in objects:
+        pos, x = [], []
+        for o in objs:
+            xyz, rgb = np.asarray(o.xyz, dtype=np.float32), np.asarray(o.rgb, dtype=np.float32)
+            sel = rng.integers(0, len(xyz), size=num)
+            p = xyz[sel] - xyz[sel].mean(axis=0, keepdims=True)
+            p = p * (np.float32(0.999999) / max(float(np.abs(p).max()), 1e-12))
+            pos.append(p.astype(np.float32))
+            x.append(rgb[sel])
+        out.append({"pos": np.concatenate(pos, axis=0), "x": np.concatenate(x, axis=0)})
+    return out
+
+
 def to_device(packed: Dict[str, np.ndarray], device) -> Dict[str, "torch.Tensor"]:
     import torch
 
@@ -118,4 +138,4 @@ def to_device(packed: Dict[str, np.ndarray], device) -> Dict[str, "torch.Tensor"
 
 
 __all__ = ["KNOWN_CLASS", "COLOR_NAMES", "class_table", "color_table", "object_features", "pack_cells",
-           "pack_cells_gpu", "to_device"]
+           "pack_cells_gpu", "sample_object_points", "to_device"]
