@@ -244,6 +244,36 @@ def secondary_measurements(eng):
         del d_xyz, d_rgb
     except Exception as e:
         out["reduce_objects"] = {"error": repr(e)}
+    # a3: PointNet++ object backbone on raw 256-point objects (published feature mode): f32 MFMA edge MLPs,
+    # algorithmic ~376 MFLOP per object ("<=370 MFLOP/object")
+    try:
+        n_pc = 512
+        cells_p = synth.make_cells(n_pc, seed=13)
+        n_obj = int(cells_p["offsets"][-1])
+        pos_np, rgb_np = synth.make_sampled_points(cells_p, 13)
+        sd_pn = dict(sd)
+        sd_pn.update(synth.make_pointnet_weights(0))
+        eng_p = Engine(eng.device)
+        eng_p.set_option("profile_events", 1)
+        eng_p.load_weights(sd_pn, class_embed=False, color_embed=False)
+        d_pos, d_rgb = torch.from_numpy(pos_np).cuda(), torch.from_numpy(rgb_np).cuda()
+        for _ in range(2):
+            eng_p.pointnet_features(d_pos, d_rgb, cells_p["offsets"])
+        eng_p.kernel_stats("pointnet")
+        for _ in range(3):
+            f2 = eng_p.pointnet_features(d_pos, d_rgb, cells_p["offsets"])
+        torch.cuda.synchronize()
+        ms, n = eng_p.kernel_stats("pointnet")
+        # executed edge-MLP rows: (128+4)*32, (64+2)*32, (32+1)*32 per object, + global MLP + FC
+        fl = 2.0 * (132 * 32 * (8 * 32 + 32 * 64) + 66 * 32 * (72 * 128 + 128 * 128) + 33 * 32 * (136 * 256 + 256 * 256)
+                    + 32 * (264 * 512 + 512 * 1024) + 1024 * 512 + 512 * 256)
+        out["pointnet"] = {"objects": n_obj, "cells": n_pc, "kernel_ms": ms, "objects_per_s": n_obj / (ms * 1e-3),
+                           "tflops_executed": fl * n_obj / (ms * 1e-3) / 1e12, "peak_tflops": F32_MFMA_PEAK_TFLOPS,
+                           "frac": fl * n_obj / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "launches_timed": n,
+                           "parity": "self-consistent only (third-party reference arithmetic, unpinned)"}
+        eng_p.close()
+    except Exception as e:
+        out["pointnet"] = {"error": repr(e)}
     # a9 / SURVEY.md §8d config 4: one training step of the object branch at B=64 (train-mode forward with dropout 0.1 ->
     # contrastive loss -> backward -> Adam), text side supplied as a precomputed [64,256] batch
     try:
