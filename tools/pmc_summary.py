@@ -13,10 +13,11 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = f"gpurun_out/prof_{tag}"
-os.makedirs("profiles", exist_ok=True)
-shutil.copy(f"{src}/trace/t_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
+OUT = sys.argv[2] if len(sys.argv) > 2 else "profiles"  # on the GPU box: a directory under gpurun_out/ (raw traces exceed 64 MiB)
+os.makedirs(OUT, exist_ok=True)
+shutil.copy(f"{src}/trace/t_kernel_stats.csv", f"{OUT}/{tag}_kernel_stats.csv")
 if os.path.exists(f"{src}/sec_trace/t_kernel_stats.csv"):
-    shutil.copy(f"{src}/sec_trace/t_kernel_stats.csv", f"profiles/{tag}_secondary_kernel_stats.csv")
+    shutil.copy(f"{src}/sec_trace/t_kernel_stats.csv", f"{OUT}/{tag}_secondary_kernel_stats.csv")
 
 
 def collect(prefix):
@@ -45,9 +46,9 @@ for k, s in summary.items():
         cyc = s["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
         s["kernel_cycles"] = cyc
         s["mfma_pipe_busy_frac"] = s["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc  # 1024 SIMDs
-json.dump(summary, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
-json.dump(summary, open("profiles/pmc_latest.json", "w"), indent=1, sort_keys=True)
-with open(f"profiles/{tag}_pmc_summary.md", "w") as f:
+json.dump(summary, open(f"{OUT}/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
+json.dump(summary, open(f"{OUT}/pmc_latest.json", "w"), indent=1, sort_keys=True)
+with open(f"{OUT}/{tag}_pmc_summary.md", "w") as f:
     f.write(f"# PMC summary `{tag}` — rocprofv3 --pmc passes (separate runs; see tools/profile.sh)\n\n")
     for k, s in sorted(summary.items()):
         f.write(f"## {k}  ({s['source']})\n\n| counter | average per launch |\n|---|---|\n")

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Usage (on the GPU box, from the repo root): bash tools/profile.sh <tag>
+# Usage (on the GPU box, from the repo root): bash tools/profile.sh <tag>; python tools/pmc_summary.py <tag> gpurun_out/summary_<tag>; rm -rf gpurun_out/prof_<tag>
+# (the raw traces exceed the 64 MiB that travel back; copy gpurun_out/summary_<tag>/* into profiles/)
 # rocprofv3 of the HEADLINE command (bench.py without its side measurements, so per-kernel averages are those of the
 # timed loop) — kernel-trace stats + PMC passes in separate runs, as the MI355X guide prescribes — and one
 # kernel-trace + FETCH_SIZE/WRITE_SIZE pass of the side measurements (encoder, streaming scan, loss).
