@@ -122,3 +122,17 @@ def test_drop_in_published_mode_from_point_batches():
     feats = [torch.from_numpy(packed["pn_feat"][packed["offsets"][i]:packed["offsets"][i + 1]]) for i in range(3)]
     emb2 = model.encode_objects(objects, feats).cpu().numpy()
     assert np.abs(emb2 - ref).max() < 1e-4
+
+
+def test_argument_errors(eng):
+    from text2loc_amd.engine import T2LError
+
+    z = torch.zeros(2, 256, 3, device="cuda")
+    with pytest.raises(T2LError, match="offsets ending at n"):
+        eng.pointnet_features(z, z, np.array([0, 3]))
+    with pytest.raises(T2LError, match=r"\[n,256,3\]"):
+        eng.pointnet_features(torch.zeros(2, 128, 3, device="cuda"), z, np.array([0, 2]))
+    with pytest.raises(T2LError, match="non-decreasing"):
+        eng.pointnet_features(z, z, np.array([0, 3, 2]))
+    with pytest.raises(T2LError, match="CUDA"):
+        eng.pointnet_features(z.cpu(), z, np.array([0, 2]))

@@ -189,3 +189,43 @@ def test_train_step_matches_the_reference_run(eng, golden, mode):
         if ok.any():
             delta = (tensors[n][0] - b)[ok]
             assert torch.allclose(delta, -float(g["lr"]) * torch.sign(gr[ok]), rtol=2e-2, atol=1e-6), n
+
+
+def test_error_paths(eng):
+    from text2loc_amd.engine import Engine, T2LError
+
+    e = Engine(0)
+    cells = synth.make_cells(2, seed=1)
+    dcells = to_dev(cells, True)
+    with pytest.raises(T2LError, match="t2l_train_bind first"):
+        e.encode_cells_train(dcells, dropout_p=0.0, seed=0)
+    sd = synth.make_object_branch_weights(0)
+    tens = {}
+    for k, v in used_names(sd, True).items():
+        t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda()
+        tens[k] = (t, None if "running_" in k else torch.zeros_like(t))
+    broken = dict(tens)
+    del broken["obj_inter_module.1.norm2.bias"]
+    with pytest.raises(T2LError, match="missing tensor 'obj_inter_module.1.norm2.bias'"):
+        e.train_bind(broken, class_embed=True, color_embed=True)
+    broken = dict(tens)
+    w = broken["object_encoder.pos_encoder.1.0.weight"][0]
+    broken["object_encoder.pos_encoder.1.0.weight"] = (w[:100].contiguous(), torch.zeros_like(w[:100]))
+    with pytest.raises(T2LError, match="expected 16384"):
+        e.train_bind(broken, class_embed=True, color_embed=True)
+    broken = dict(tens)
+    broken["obj_inter_module.0.linear1.weight"] = (tens["obj_inter_module.0.linear1.weight"][0], None)
+    with pytest.raises(T2LError, match="needs a gradient buffer"):
+        e.train_bind(broken, class_embed=True, color_embed=True)
+    e.train_bind(tens, class_embed=True, color_embed=True)
+    with pytest.raises(T2LError, match="no forward pass"):
+        e.encode_cells_backward(torch.zeros(2, 256, device="cuda"))
+    with pytest.raises(T2LError, match=r"dropout_p must be in \[0,1\)"):
+        e.encode_cells_train(dcells, dropout_p=1.0, seed=0)
+    one = {k: (v[:1] if k != "offsets" else torch.tensor([0, 1], dtype=torch.int32, device="cuda")).contiguous()
+           for k, v in dcells.items()}
+    with pytest.raises(T2LError, match=">= 2 objects"):  # BatchNorm1d in training mode rejects a single row, as torch does
+        e.encode_cells_train(one, dropout_p=0.0, seed=0)
+    with pytest.raises(T2LError, match="at least two"):
+        e.train_bind(tens, class_embed=True, color_embed=True, use_features=("position",))
+    e.close()
