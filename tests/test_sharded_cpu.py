@@ -94,3 +94,44 @@ def test_sharded_search_under_gloo(world, n_rows):
     assert all(ok for _, ok, _, _ in res), res
     spans = sorted((lo, hi) for _, _, lo, hi in res)
     assert spans[0][0] == 0 and spans[-1][1] == n_rows
+
+
+def _qworker(rank, world, port, n_q, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from text2loc_amd.sharded import QueryShardedSearcher
+
+    db, qs, _ = synth.make_retrieval_problem(300, n_q, seed=4, noise=2.0)
+    K = 10
+
+    def search_fn(q, k):  # oracle stand-in for the HIP search over the replicated DB
+        i, s = O.retrieve_topk(db, q.numpy(), k)
+        return torch.from_numpy(i.astype(np.int32)), torch.from_numpy(s)
+
+    qs_ = QueryShardedSearcher(engine=None, search_fn=search_fn)
+    idx, sc = qs_.search(torch.from_numpy(qs), K)
+    ridx, rsc = O.retrieve_topk(db, qs, K)
+    ok = idx.shape == (n_q, K) and np.array_equal(idx.numpy(), ridx) and np.abs(sc.numpy() - rsc).max() < 1e-12
+    li, _ = qs_.search(torch.from_numpy(qs), K, gather=False)
+    lo, hi = shard_bounds(n_q, world, rank)
+    ok = ok and np.array_equal(li.numpy(), ridx[lo:hi])
+    out_q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_q", [(2, 33), (3, 2)])
+def test_query_sharded_search_under_gloo(world, n_q):
+    """replicated DB, split queries (ragged / empty query shards), results gathered to every rank"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_qworker, args=(r, world, port, n_q, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

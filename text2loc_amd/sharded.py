@@ -94,3 +94,45 @@ class ShardedSearcher:
         self.dist.all_gather_into_tensor(all_i, idx.contiguous(), group=self.group)
         self.dist.all_gather_into_tensor(all_s, sc.contiguous(), group=self.group)
         return self.merge_fn(all_i.view(self.world, Q, k), all_s.view(self.world, Q, k))
+
+
+class QueryShardedSearcher:
+    """The other way to use N GPUs when the whole DB fits every GPU (11,259 x 256 x 4 B = 11.5 MB does): the database
+    is REPLICATED, the QUERIES are split (rank r answers queries [r*ceil(Q/P), ...)), no exchange on the data path; one
+    optional ``all_gather`` hands every rank the complete [Q,K] result (what ``eval_epoch`` wants). Throughput scales with
+    the number of GPUs because every rank scans the full DB for 1/P of the queries, whereas row-sharding
+    (``ShardedSearcher``, the north-star layout, needed once the DB outgrows one GPU) makes every rank touch every query."""
+
+    def __init__(self, engine=None, group=None, search_fn: Optional[Callable] = None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.engine = engine
+        self.search_fn = search_fn or (lambda q, k: engine.search(q, k))
+
+    def set_db(self, all_rows):
+        if self.engine is not None:
+            self.engine.db_set(all_rows.contiguous(), row_offset=0)
+        return 0, int(all_rows.shape[0])
+
+    def search(self, queries, k: int, gather: bool = True):
+        import torch
+
+        Q = int(queries.shape[0])
+        lo, hi = shard_bounds(Q, self.world, self.rank)
+        per = -(-Q // self.world)
+        idx, sc = self.search_fn(queries[lo:hi].contiguous(), k) if hi > lo else (
+            torch.empty((0, k), dtype=torch.int32, device=queries.device), torch.empty((0, k), dtype=torch.float64, device=queries.device))
+        if self.world == 1 or not gather:
+            return idx, sc
+        pi = torch.full((per, k), -1, dtype=idx.dtype, device=idx.device)   # ragged tail -> fixed-size records
+        ps = torch.full((per, k), float("-inf"), dtype=sc.dtype, device=sc.device)
+        pi[: hi - lo], ps[: hi - lo] = idx, sc
+        all_i = torch.empty((self.world * per, k), dtype=idx.dtype, device=idx.device)
+        all_s = torch.empty((self.world * per, k), dtype=sc.dtype, device=sc.device)
+        self.dist.all_gather_into_tensor(all_i, pi, group=self.group)
+        self.dist.all_gather_into_tensor(all_s, ps, group=self.group)
+        return all_i[:Q], all_s[:Q]
