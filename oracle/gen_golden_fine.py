@@ -1,0 +1,103 @@
+"""TEST INFRASTRUCTURE — build-container only.
+
+Golden vectors for SURVEY.md §8 row f-1 (fine stage): imports the upstream reference and runs ``CrossMatch.forward``
+(models/cross_matcher.py:86-135) in eval mode on seeded synthetic (pose, top-k cell) samples shaped like an item of
+``Kitti360TopKDataset`` (dataloading/kitti360pose/eval.py:118-194): K=10 cells x pad_size=16 objects (short cells
+padded with ``Object3d.create_padding()``, long ones cut), 6 hints. The text branch is bypassed by feeding fixed hint
+encodings [K,6,128] (``model.language_encoder`` replaced by a table lookup): T5 stays out of the kernel path.
+Writes ``tests/golden/fine_{embed,pn}.npz`` (DATA only): packed per-object inputs exactly as the reference derives
+them (incl. its random padding objects), hint encodings, object encodings after F.normalize, offsets.
+"""
+from __future__ import annotations
+
+import os
+import os.path as osp
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = osp.dirname(osp.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness as H  # noqa: E402
+
+H.setup_reference_imports()
+
+import torch  # noqa: E402
+
+from gen_golden import TablePointNet, TokenBatch, packed_from_objects, to_torch_sd  # noqa: E402
+from text2loc_amd import synth  # noqa: E402
+
+OUT = osp.join(H.REPO, "tests", "golden")
+torch.set_num_threads(4)
+
+
+class HintTable(torch.nn.Module):
+    def __init__(self, table):
+        super().__init__()
+        self.table = torch.from_numpy(table)
+
+    def forward(self, hints):
+        return self.table[: len(hints)]
+
+
+def run(mode, hf_dir, pn_path):
+    from datapreparation.kitti360pose.imports import Object3d
+    from datapreparation.kitti360pose.utils import COLOR_NAMES, KNOWN_CLASS
+    from models.cross_matcher import CrossMatch
+
+    embed = mode == "embed"
+    W_SEED, C_SEED, K, PAD, NH = 0, 21, 10, 16, 6
+    args = H.make_args(hf_dir, pn_path, class_embed=embed, color_embed=embed, fine_embed_dim=128, fine_num_decoder_heads=4,
+                       fine_num_decoder_layers=2, fine_intra_module_num_layers=1, fine_intra_module_num_heads=4,
+                       pad_size=PAD, num_mentioned=NH)
+    model = CrossMatch(KNOWN_CLASS, COLOR_NAMES, args)
+    sd = synth.make_fine_weights(W_SEED)
+    missing, unexpected = model.load_state_dict(to_torch_sd(sd), strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith(("language_encoder.", "object_encoder.pointnet")) for k in missing), missing
+    model.eval()
+    # K cells with 6..35 objects -> cut to 16 / padded to 16 as Kitti360TopKDataset.load_pose_and_cell does
+    cells = synth.make_cells(K, seed=C_SEED, with_pn_feat=True, min_obj=6, max_obj=24)
+    objects = H.build_objects(cells, seed=C_SEED)
+    np.random.seed(1234)  # Object3d.create_padding draws np.random.rand(8,3)
+    padded, pn_rows = [], []
+    for i, objs in enumerate(objects):
+        objs = list(objs)[:PAD]
+        feats = cells["pn_feat"][cells["offsets"][i]:cells["offsets"][i] + len(objs)]
+        while len(objs) < PAD:
+            objs.append(Object3d.create_padding())
+            feats = np.concatenate([feats, np.abs(np.random.default_rng([C_SEED, i, len(objs)]).standard_normal((1, 256))).astype(np.float32)])
+        padded.append(objs)
+        pn_rows.append(feats.astype(np.float32))
+    pn_all = np.concatenate(pn_rows)
+    rng = np.random.default_rng([5, 0xF1])
+    hint_enc = rng.standard_normal((K, NH, 128)).astype(np.float32)
+    model.language_encoder = HintTable(hint_enc)
+    offsets16 = np.arange(0, K * PAD + 1, PAD, dtype=np.int32)
+    if not embed:
+        model.object_encoder.pointnet = TablePointNet(pn_all, offsets16)
+    toks = [None] * K if embed else [TokenBatch(i) for i in range(K)]
+    packed = packed_from_objects(model, padded)
+    with torch.no_grad():
+        enc, _ = model.object_encoder(padded, toks)
+        enc = torch.nn.functional.normalize(enc.reshape(K, PAD, 128), dim=-1)
+        off = model(padded, ["h"] * K, toks)
+    out = {"weight_seed": W_SEED, "cell_seed": C_SEED, "n_cells": K, "pad_size": PAD, "n_hints": NH, "hint_encodings": hint_enc,
+           "object_encodings": enc.numpy(), "offsets_out": off.numpy(), "in_pn_feat": pn_all}
+    out.update({"in_" + k: v for k, v in packed.items()})
+    np.savez_compressed(osp.join(OUT, f"fine_{mode}.npz"), **out)
+    print(mode, "offsets", off.numpy()[:3].round(4).tolist(), "pad objects", int((packed["class_idx"] == 0).sum()))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    tmp = tempfile.mkdtemp(prefix="t2l_golden_")
+    hf_dir = H.make_tiny_t5(osp.join(tmp, "t5tiny"))
+    pn_path = H.make_pointnet_ckpt(osp.join(tmp, "pointnet.pth"))
+    for mode in ("embed", "pn"):
+        run(mode, hf_dir, pn_path)
+
+
+if __name__ == "__main__":
+    main()

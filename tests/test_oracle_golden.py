@@ -1,6 +1,7 @@
 """CPU tier: pins the numpy oracle (oracle/t2l_oracle.py) against golden vectors produced by running the
 imported reference (oracle/gen_golden.py). Tolerances are stated per check."""
 import numpy as np
+import pytest
 
 from oracle import t2l_oracle as O
 from text2loc_amd import synth
@@ -113,3 +114,20 @@ def test_c_oracle_retrieval_and_loss(golden):
     loss, ga, gp = c_oracle.contrastive_loss(l["anchor"], l["positive"], float(l["temperature"]))
     assert abs(loss - float(l["loss"])) < 1e-6
     assert np.abs(ga - l["grad_anchor"]).max() < 1e-6 and np.abs(gp - l["grad_positive"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["embed", "pn"])
+def test_fine_stage_oracle_matches_reference_crossmatch(golden, mode):
+    """f-1: ObjectEncoder(128) + F.normalize, cascaded cross-attention decoder layers, offsets (cross_matcher.py:86-135)."""
+    from oracle import t2l_oracle_fine as OF
+    from text2loc_amd import synth
+
+    g = golden(f"fine_{mode}")
+    sd = synth.make_fine_weights(int(g["weight_seed"]))
+    cells = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    embed = mode == "embed"
+    enc = OF.fine_object_encodings(cells, sd, embed, embed, int(g["pad_size"]))
+    assert np.abs(enc - g["object_encodings"]).max() < 2e-6
+    off = OF.cross_match(g["object_encodings"], g["hint_encodings"], sd)
+    assert off.shape == (int(g["n_cells"]), 2)
+    assert np.abs(off - g["offsets_out"]).max() < 2e-5

@@ -138,6 +138,34 @@ def make_sampled_points(cells: dict, seed: int = 0, n_points: int = 256):
     return pos.astype(np.float32), rgb.astype(np.float32)
 
 
+def _decoder_layer(rng, d, ff, prefix, sd):
+    """Key layout of torch.nn.TransformerDecoderLayer (post-norm): self_attn, multihead_attn, linear1/2, norm1-3."""
+    b = np.sqrt(6.0 / (d + 3 * d))
+    for att in ("self_attn", "multihead_attn"):
+        sd[f"{prefix}.{att}.in_proj_weight"] = rng.uniform(-b, b, size=(3 * d, d)).astype(np.float32)
+        sd[f"{prefix}.{att}.in_proj_bias"] = (0.02 * rng.standard_normal(3 * d)).astype(np.float32)
+        _linear(rng, d, d, f"{prefix}.{att}.out_proj", sd)
+    _linear(rng, ff, d, prefix + ".linear1", sd)
+    _linear(rng, d, ff, prefix + ".linear2", sd)
+    for n in ("norm1", "norm2", "norm3"):
+        sd[f"{prefix}.{n}.weight"] = rng.uniform(0.8, 1.2, size=(d,)).astype(np.float32)
+        sd[f"{prefix}.{n}.bias"] = (0.05 * rng.standard_normal(d)).astype(np.float32)
+
+
+def make_fine_weights(seed: int = 0, embed_dim: int = 128, num_layers: int = 2) -> dict:
+    """state_dict (numpy) of the fine-stage ``CrossMatch`` without its text branch (models/cross_matcher.py:55-84):
+    ``object_encoder.*`` at fine_embed_dim, ``cross_objects.{i}.*`` / ``cross_hints.{i}.*`` decoder layers, ``mlp_offsets``."""
+    sd = {k: v for k, v in make_object_branch_weights(seed + 101, embed_dim=embed_dim, num_layers=0).items()
+          if k.startswith("object_encoder.")}
+    rng = np.random.default_rng([seed, 0xF17E])
+    for i in range(num_layers):
+        _decoder_layer(rng, embed_dim, 4 * embed_dim, f"cross_hints.{i}", sd)
+        _decoder_layer(rng, embed_dim, 4 * embed_dim, f"cross_objects.{i}", sd)
+    _linear(rng, embed_dim // 2, embed_dim, "mlp_offsets.0", sd)
+    _linear(rng, 2, embed_dim // 2, "mlp_offsets.2", sd)
+    return sd
+
+
 def make_language_head_weights(seed: int = 0, embed_dim: int = 256, t5_dim: int = 1024) -> dict:
     """state_dict (numpy) of the text head after T5 (models/language_encoder.py:95-101)."""
     rng = np.random.default_rng([seed, 0x7E47])
