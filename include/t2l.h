@@ -177,6 +177,29 @@ int t2l_contrastive_loss(t2l_ctx* ctx, const float* anchor, const float* positiv
                          float temperature, float* loss, float* grad_anchor, float* grad_positive,
                          void* stream);
 
+/* ---- fine stage (f-1): CrossMatch downstream of the text branch, eval mode ---------------------- */
+/* Replaces CrossMatch.load_state_dict for everything except language_encoder.* (evaluation/pipeline.py:258-262): tensors named
+ * as in the reference's fine checkpoint — object_encoder.* at fine_embed_dim = 128 (models/cross_matcher.py:57),
+ * cross_objects.{i}.* / cross_hints.{i}.* (nn.TransformerDecoderLayer: self_attn, multihead_attn, linear1/2, norm1-3),
+ * mlp_offsets.{0,2}.*. cfg: class_embed / color_embed / use_* as for the coarse model; num_layers =
+ * args.fine_num_decoder_layers (1..4), num_heads = args.fine_num_decoder_heads (4). Synchronous. */
+int t2l_fine_load_weights(t2l_ctx* ctx, const t2l_weight_desc* w, int32_t n, const t2l_model_config* cfg);
+
+/* Replaces the 3D-submap branch of CrossMatch.forward (models/cross_matcher.py:97-104): ObjectEncoder.forward on the
+ * padded cells + reshape + F.normalize. `in`: every cell holds EXACTLY pad_size = 16 objects (cut / padded on the host as
+ * Kitti360TopKDataset.load_pose_and_cell does, dataloading/kitti360pose/eval.py:147-156), n_objects = 16 * n_cells.
+ * out_desc: dev f32[n_cells,16,128]. The descriptors depend on the cell only: compute them once per database cell. */
+int t2l_fine_encode_objects(t2l_ctx* ctx, const t2l_packed_cells* in, float* out_desc, void* stream);
+
+/* Replaces the CCAT module + offset head of CrossMatch.forward (models/cross_matcher.py:106-131) for n_pairs (query, cell)
+ * pairs in ONE launch (the reference: one Python-level forward per query, evaluation/pipeline.py:113-116):
+ *   for i: obj = cross_objects[i](obj, hints); hints = cross_hints[i](hints, obj);  offsets = mlp_offsets(max over hints)
+ * cell_desc: dev f32[*,16,128] (t2l_fine_encode_objects); hint_desc: dev f32[*,n_hints,128] = LanguageEncoder(is_fine)
+ * output of the PyTorch text branch; cell_index / hint_index: dev i32[n_pairs] rows of those tables for each pair, or NULL
+ * for the identity (pair p uses row p). out_offsets: dev f32[n_pairs,2] = the pose estimate inside the cell, in [0,1]^2. */
+int t2l_fine_match(t2l_ctx* ctx, const float* cell_desc, const int32_t* cell_index, const float* hint_desc,
+                   const int32_t* hint_index, int32_t n_pairs, int32_t n_hints, float* out_offsets, void* stream);
+
 /* ---- training step of the object branch (a9) --------------------------------------------------- */
 /* Replaces, for the object branch, the body of train_epoch (training/coarse.py:31-58): model.train() forward of
  * CellRetrievalNetwork.encode_objects, loss.backward() through it, optimizer.zero_grad() / optim.Adam.step().
@@ -235,7 +258,7 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value);
  * (no synchronisation while recording; enabled by option "profile_events" = 1, off by default).
  * Returns the average duration (ms) and the number of launches recorded since the previous call for
  * name = "search_scan" | "search_rerank" | "encode_cells" | "contrastive_loss" | "reduce_objects" | "train_forward" |
- * "train_backward" | "adam_step" | "pointnet" (at most the last 512),
+ * "train_backward" | "adam_step" | "pointnet" | "fine_objects" | "fine_match" (at most the last 512),
  * then clears the record. Synchronises on the recorded events. */
 int t2l_kernel_stats(t2l_ctx* ctx, const char* name, float* out_avg_ms, int32_t* out_count);
 

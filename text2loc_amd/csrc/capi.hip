@@ -66,6 +66,7 @@ void t2l_destroy(t2l_ctx* ctx) {
   free_weights(ctx);
   free_train(ctx);
   free_pointnet(ctx);
+  free_fine(ctx);
   for (void* p : {(void*)ctx->db, (void*)ctx->db_split, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
                   (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count, ctx->reduce_ws})
     if (p) (void)hipFree(p);
@@ -223,6 +224,25 @@ int t2l_contrastive_loss(t2l_ctx* ctx, const float* anchor, const float* positiv
     return fail(ctx, T2L_EINVAL, "t2l_contrastive_loss: pass both gradients or neither");
   T2L_HIP(ctx, hipSetDevice(ctx->device));
   return loss_impl(ctx, anchor, positive, batch, temperature, loss, grad_anchor, grad_positive, (hipStream_t)stream);
+}
+
+int t2l_fine_load_weights(t2l_ctx* ctx, const t2l_weight_desc* w, int32_t n, const t2l_model_config* cfg) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return fine_load_impl(ctx, w, n, cfg);
+}
+
+int t2l_fine_encode_objects(t2l_ctx* ctx, const t2l_packed_cells* in, float* out_desc, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return fine_encode_impl(ctx, in, out_desc, (hipStream_t)stream);
+}
+
+int t2l_fine_match(t2l_ctx* ctx, const float* cell_desc, const int32_t* cell_index, const float* hint_desc,
+                   const int32_t* hint_index, int32_t n_pairs, int32_t n_hints, float* out_offsets, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return fine_match_impl(ctx, cell_desc, cell_index, hint_desc, hint_index, n_pairs, n_hints, out_offsets, (hipStream_t)stream);
 }
 
 int t2l_train_bind(t2l_ctx* ctx, const t2l_train_tensor* tensors, int32_t n, const t2l_model_config* cfg) {

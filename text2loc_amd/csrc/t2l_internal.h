@@ -68,6 +68,7 @@ struct t2l_ctx {
   t2l::EncoderWeights* enc = nullptr;
   void* train = nullptr;         // t2l::TrainState (train.hip)
   void* pn = nullptr;            // t2l::PointNetWeights (pointnet.hip), null when no pointnet.* tensors were loaded
+  void* fine = nullptr;          // t2l::FineWeights (fine.hip)
   int pn_self_loops = 1;         // PyG PointConv add_self_loops quirk on the bipartite batch (oracle/t2l_oracle_pointnet.py)
   // options
   double eps_scale = 1.0;
@@ -116,6 +117,12 @@ int pointnet_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n);
 int pointnet_features_impl(t2l_ctx* ctx, const float* pos, const float* rgb, const int32_t* cell_offsets, int n_cells, float* out,
                            hipStream_t s);
 void free_pointnet(t2l_ctx* ctx);
+// fine.hip
+int fine_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_model_config* cfg);
+int fine_encode_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float* out, hipStream_t s);
+int fine_match_impl(t2l_ctx* ctx, const float* cell_desc, const int32_t* cell_index, const float* hint_desc, const int32_t* hint_index,
+                    int n_pairs, int n_hints, float* out, hipStream_t s);
+void free_fine(t2l_ctx* ctx);
 // loss.hip
 int loss_impl(t2l_ctx* ctx, const float* a, const float* p, int B, float temp, float* loss, float* ga, float* gp,
               hipStream_t s);

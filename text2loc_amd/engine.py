@@ -64,6 +64,10 @@ EXPORTS = {
     "t2l_search_fallbacks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "t2l_contrastive_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "t2l_fine_load_weights": (C.c_int, [C.c_void_p, C.POINTER(_WeightDesc), C.c_int32, C.POINTER(_ModelConfig)]),
+    "t2l_fine_encode_objects": (C.c_int, [C.c_void_p, C.POINTER(_PackedCells), C.c_void_p, C.c_void_p]),
+    "t2l_fine_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                 C.c_void_p]),
     "t2l_train_bind": (C.c_int, [C.c_void_p, C.POINTER(_TrainTensor), C.c_int32, C.POINTER(_ModelConfig)]),
     "t2l_encode_cells_train": (C.c_int, [C.c_void_p, C.POINTER(_PackedCells), C.c_float, C.c_uint32, C.c_void_p, C.c_void_p]),
     "t2l_encode_cells_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -211,6 +215,47 @@ class Engine:
             _dev_ptr(packed.get("n_pts"), torch.float32, "n_pts"),
             _dev_ptr(packed.get("pn_feat"), torch.float32, "pn_feat"))
         self._check(self.lib.t2l_encode_cells(self._h, C.byref(pc), out.data_ptr(), _stream_ptr()))
+        return out
+
+    # ------------------------------------------------------------------ fine stage (f-1)
+    def fine_load_weights(self, state_dict: Dict[str, object], class_embed: bool, color_embed: bool,
+                          use_features=("class", "color", "position", "num"), num_layers: int = 2, num_heads: int = 4):
+        keep, descs = [], []
+        for name, v in state_dict.items():
+            if name.startswith(("language_encoder.", "object_encoder.pointnet.")) or name.endswith("num_batches_tracked"):
+                continue
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            keep.append(a)
+            descs.append(_WeightDesc(name.encode(), a.ctypes.data, a.size))
+        arr = (_WeightDesc * len(descs))(*descs)
+        cfg = _ModelConfig(int(class_embed), int(color_embed), int("class" in use_features), int("color" in use_features),
+                           int("position" in use_features), int("num" in use_features), int(num_layers), int(num_heads))
+        self._check(self.lib.t2l_fine_load_weights(self._h, arr, len(descs), C.byref(cfg)))
+
+    def fine_encode_objects(self, packed: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """packed cells of exactly 16 objects each -> f32[n_cells,16,128] unit-row object descriptors."""
+        pc = self._packed_struct(packed)
+        out = torch.empty((pc.n_cells, 16, 128), dtype=torch.float32, device=packed["offsets"].device)
+        self._check(self.lib.t2l_fine_encode_objects(self._h, C.byref(pc), out.data_ptr(), _stream_ptr()))
+        return out
+
+    def fine_match(self, cell_desc: torch.Tensor, hint_desc: torch.Tensor, cell_index: Optional[torch.Tensor] = None,
+                   hint_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """cell_desc f32[*,16,128], hint_desc f32[*,n_hints,128], optional i32[n_pairs] row indices -> offsets f32[n_pairs,2]."""
+        n_pairs = int(cell_index.numel()) if cell_index is not None else int(cell_desc.shape[0])
+        if hint_index is not None and int(hint_index.numel()) != n_pairs:
+            raise T2LError("fine_match: cell_index and hint_index must have one entry per pair")
+        if cell_index is None and hint_index is None and int(hint_desc.shape[0]) != n_pairs:
+            raise T2LError("fine_match: without index arrays cell_desc and hint_desc must have one row block per pair")
+        if cell_desc.shape[1:] != (16, 128) or hint_desc.shape[2] != 128:
+            raise T2LError(f"fine_match: expected [*,16,128] and [*,n_hints,128], got {tuple(cell_desc.shape)}, {tuple(hint_desc.shape)}")
+        out = torch.empty((n_pairs, 2), dtype=torch.float32, device=cell_desc.device)
+        self._check(self.lib.t2l_fine_match(self._h, _dev_ptr(cell_desc, torch.float32, "cell_desc"),
+                                            _dev_ptr(cell_index, torch.int32, "cell_index"),
+                                            _dev_ptr(hint_desc, torch.float32, "hint_desc"),
+                                            _dev_ptr(hint_index, torch.int32, "hint_index"), n_pairs, int(hint_desc.shape[1]),
+                                            out.data_ptr(), _stream_ptr()))
         return out
 
     # ------------------------------------------------------------------ training step (a9)
