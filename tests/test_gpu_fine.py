@@ -82,3 +82,125 @@ def test_feature_subsets_and_errors(eng):
     broken = {k: v for k, v in sd.items() if k != "cross_hints.1.norm3.bias"}
     with pytest.raises(T2LError, match="cross_hints.1.norm3.bias"):
         eng.fine_load_weights(broken, class_embed=True, color_embed=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the drop-in surface: CrossMatch.forward and run_fine
+# ---------------------------------------------------------------------------------------------------------------
+class HintTable(torch.nn.Module):
+    """Text-branch stand-in: the hint encodings of pose i are row i of a table; the pose index rides in the hint text."""
+
+    def __init__(self, table):
+        super().__init__()
+        self.table = torch.nn.Parameter(torch.from_numpy(table), requires_grad=False)
+
+    def forward(self, texts):
+        import re
+
+        idx = [int(re.search(r"q(\d+)x", t).group(1)) for t in texts]
+        return self.table[torch.as_tensor(idx, device=self.table.device)]
+
+
+def _fine_args(embed):
+    import argparse
+
+    return argparse.Namespace(fine_embed_dim=128, fine_num_decoder_heads=4, fine_num_decoder_layers=2, pad_size=16, num_mentioned=6,
+                              fine_intra_module_num_layers=1, fine_intra_module_num_heads=4, hungging_model=None,
+                              fixed_embedding=True, class_embed=embed, color_embed=embed, pointnet_freeze=True,
+                              use_features=["class", "color", "position", "num"], top_k=[1, 3, 5], threshs=[5, 10, 15])
+
+
+@pytest.mark.parametrize("embed", [True, False])
+def test_crossmatch_forward_and_run_fine_drop_in(embed):
+    from tests.test_host_logic import StubCell, make_objects
+    from text2loc_amd import packing
+    from text2loc_amd.coarse import calc_sample_accuracies
+    from text2loc_amd.cross_matcher import CrossMatch, pad_objects, run_fine
+
+    args = _fine_args(embed)
+    n_cells, Q, K = 12, 9, 5
+    cells_np = synth.make_cells(n_cells, seed=31, min_obj=4, max_obj=22)
+    objects = make_objects(cells_np, 31)
+    rng = np.random.default_rng(3)
+    table = rng.standard_normal((Q, 6, 128)).astype(np.float32)
+    model = CrossMatch(synth.KNOWN_CLASS, synth.COLOR_NAMES, args, language_encoder=HintTable(table))
+    sd = synth.make_fine_weights(5)
+    sd.update(synth.make_pointnet_weights(5, n_classes=len(synth.KNOWN_CLASS), n_colors=len(synth.COLOR_NAMES)))
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.startswith("language_encoder.") for k in missing), (missing, unexpected)
+    model = model.to("cuda").eval()
+
+    pts_rng = np.random.default_rng(8)
+    pts_cache = {}
+
+    def points_fn(padded_cells):  # deterministic per padded cell: sample once, reuse
+        out = []
+        for objs in padded_cells:
+            key = id(objs[0])
+            if key not in pts_cache:
+                pts_cache[key] = packing.sample_object_points([objs], 256, pts_rng)[0]
+            out.append(pts_cache[key])
+        return out
+
+    # ---- forward(): one (pose, cell) pair per entry, as the reference's run_fine calls it
+    padded = [pad_objects(o) for o in objects[:K]]
+    pts = None if embed else points_fn(padded)
+    off = model(padded, ["The pose is north of a red q2x."] * K, pts).cpu().numpy()
+    packed = packing.pack_cells(padded, model.object_encoder.known_classes, model.object_encoder.known_colors)
+    if not embed:
+        from oracle import t2l_oracle_pointnet as OP
+
+        pos = np.concatenate([p["pos"].reshape(-1, 256, 3) for p in pts])
+        rgb = np.concatenate([p["x"].reshape(-1, 256, 3) for p in pts])
+        packed["pn_feat"] = OP.pointnet_features(pos, rgb, packed["offsets"], sd)
+    ref_desc = OF.fine_object_encodings(packed, sd, embed, embed)
+    ref = OF.cross_match(ref_desc, np.repeat(table[2:3], K, axis=0), sd)
+    assert off.shape == (K, 2) and np.abs(off - ref).max() < 1e-4
+
+    # ---- run_fine(): all poses x top-k cells in one launch, accuracies as evaluation/pipeline.py:160-204
+    class D:
+        def __init__(self, i):
+            self.direction, self.object_color_text, self.object_label = "north", "red", f"q{i}x"
+
+    class Pose:
+        def __init__(self, i, cell):
+            self.descriptions = [D(i)]
+            self.cell_id = cell.id
+            self.pose_w = np.array([*(cell.bbox_w[0:2] + rng.uniform(0, 1, 2) * cell.cell_size), 0.0])
+
+    stub_cells = []
+    for i in range(n_cells):
+        lo = np.array([15.0 * (i % 4), 15.0 * (i // 4), 0.0])
+        c = StubCell(f"sceneA_{i:03d}", np.concatenate([lo, lo + 30.0]), 30.0)
+        c.objects = objects[i]
+        stub_cells.append(c)
+    retr = [np.array([stub_cells[j].id for j in rng.choice(n_cells, size=5, replace=False)]) for _ in range(Q)]
+    poses = [Pose(i, stub_cells[int(np.where([c.id == retr[i][0] for c in stub_cells])[0][0])]) for i in range(Q)]
+
+    class Ds:
+        all_poses, all_cells = poses, stub_cells
+
+    class Dl:
+        dataset = Ds()
+
+    acc = run_fine(model, retr, Dl(), args, None, object_points_fn=None if embed else points_fn)
+    # the same through the oracle
+    cd = {c.id: c for c in stub_cells}
+    exp = {k: {t: [] for t in args.threshs} for k in args.top_k}
+    for i, pose in enumerate(poses):
+        pc = [pad_objects(cd[cid].objects) for cid in retr[i]]
+        pk = packing.pack_cells(pc, model.object_encoder.known_classes, model.object_encoder.known_colors)
+        if not embed:
+            # run_fine pads every distinct cell once; reproduce its point batches through the same cache keys is not
+            # possible here (new pad objects), so compare accuracies only in the embed mode and offsets' shape otherwise
+            continue
+        o = OF.cross_match(OF.fine_object_encodings(pk, sd, True, True), np.repeat(table[i:i + 1], 5, axis=0), sd)
+        a = calc_sample_accuracies(pose, [cd[cid] for cid in retr[i]], o, args.top_k, args.threshs)
+        for k in args.top_k:
+            for t in args.threshs:
+                exp[k][t].append(a[k][t])
+    assert set(acc.keys()) == set(args.top_k) and all(0.0 <= acc[k][t] <= 1.0 for k in args.top_k for t in args.threshs)
+    if embed:
+        for k in args.top_k:
+            for t in args.threshs:
+                assert abs(acc[k][t] - float(np.mean(exp[k][t]))) < 1e-9, (k, t)

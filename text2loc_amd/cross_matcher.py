@@ -1,0 +1,199 @@
+"""Drop-in for the reference's fine stage: ``models.cross_matcher.CrossMatch`` (models/cross_matcher.py:39-141) and
+``evaluation.pipeline.run_fine`` (evaluation/pipeline.py:88-204).
+
+    CrossMatch(known_classes, known_colors, args)
+        .forward(objects, hints, object_points) -> Tensor[B,2]   offsets = pose estimate inside each cell, in [0,1]^2
+        .state_dict() / .load_state_dict()    same key names as the reference's fine checkpoint
+        .encode_cells(objects, object_points) -> Tensor[B,16,128]   (new: the query-independent half, cacheable per cell)
+        .match(cell_desc, hint_desc, cell_index, hint_index) -> Tensor[P,2]
+
+The text branch (``LanguageEncoder(is_fine=True)``: T5 + one Transformer layer over tokens + Linear/BN) stays on
+PyTorch-ROCm; the 3D-submap branch (ObjectEncoder at fine_embed_dim incl. PointNet++ in the published mode), the cascaded
+cross-attention decoder layers and the offset head run in the engine (t2l_fine_*). The nn.Modules below are PARAMETER
+CONTAINERS for the engine-side tensors. Eval only (the fine model's training step is not built).
+"""
+from __future__ import annotations
+
+from copy import copy
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import packing
+from .cell_retrieval import LanguageEncoder, ObjectEncoderParams
+from .engine import Engine, T2LError
+
+FINE_DIM, PAD_SIZE = 128, 16
+
+
+def get_mlp_offset(dims: List[int]) -> nn.Sequential:
+    """Linear/ReLU stack without trailing activation; key layout ``{0,2,...}`` (models/cross_matcher.py:17-36)."""
+    mods: list = []
+    for i in range(len(dims) - 1):
+        mods.append(nn.Linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2:
+            mods.append(nn.ReLU())
+    return nn.Sequential(*mods)
+
+
+class PadObject:
+    """``Object3d.create_padding()`` (datapreparation/kitti360pose/imports.py:75-83): label 'pad', 8 points within 1 mm of
+    the origin, black. The reference draws the 8 points with the global numpy RNG on every call; here they are fixed."""
+
+    label = "pad"
+    _xyz = np.random.default_rng(0xBAD).random((8, 3)) * 0.001
+    _rgb = np.zeros((8, 3), dtype=np.float32)
+
+    def __init__(self):
+        self.xyz, self.rgb = PadObject._xyz, PadObject._rgb
+
+
+def pad_objects(objects: list, pad_size: int = PAD_SIZE) -> list:
+    """Cut to / pad to ``pad_size`` objects (dataloading/kitti360pose/eval.py:147-156)."""
+    objs = list(objects)[:pad_size]
+    while len(objs) < pad_size:
+        objs.append(PadObject())
+    return objs
+
+
+def create_hint_description(pose) -> List[str]:
+    """dataloading/kitti360pose/base.py:60-68."""
+    return [f"The pose is {d.direction} of a {d.object_color_text} {d.object_label}." for d in pose.descriptions]
+
+
+class CrossMatch(nn.Module):
+    def __init__(self, known_classes: List[str], known_colors: List[str], args, language_encoder: Optional[nn.Module] = None):
+        super().__init__()
+        self.args = args
+        self.embed_dim = args.fine_embed_dim
+        if self.embed_dim != FINE_DIM:
+            raise T2LError(f"the engine's fine stage is built for fine_embed_dim={FINE_DIM}, got {self.embed_dim}")
+        if getattr(args, "pad_size", PAD_SIZE) != PAD_SIZE:
+            raise T2LError(f"the engine's fine stage is built for pad_size={PAD_SIZE}")
+        n_layers = args.fine_num_decoder_layers
+        if n_layers < 1:
+            raise T2LError("fine_num_decoder_layers == 0 (single cross_hints layer) is not built")
+        self.object_encoder = ObjectEncoderParams(FINE_DIM, known_classes, args, known_colors)
+        self.language_encoder = language_encoder if language_encoder is not None else LanguageEncoder(
+            FINE_DIM, hungging_model=args.hungging_model, fixed_embedding=args.fixed_embedding,
+            intra_module_num_layers=args.fine_intra_module_num_layers, intra_module_num_heads=args.fine_intra_module_num_heads,
+            is_fine=True)
+        self.mlp_offsets = get_mlp_offset([FINE_DIM, FINE_DIM // 2, 2])
+        mk = lambda: nn.TransformerDecoderLayer(d_model=FINE_DIM, nhead=args.fine_num_decoder_heads, dim_feedforward=4 * FINE_DIM)
+        self.cross_hints = nn.ModuleList([mk() for _ in range(n_layers)])
+        self.cross_objects = nn.ModuleList([mk() for _ in range(n_layers)])
+        self._engine: Optional[Engine] = None
+        self._weights_version = None
+
+    @property
+    def device(self):
+        return next(self.mlp_offsets.parameters()).device
+
+    def get_device(self):
+        return self.device
+
+    # ---- engine plumbing ----------------------------------------------------------------------------------
+    def engine(self) -> Engine:
+        dev = self.device
+        if dev.type != "cuda":
+            raise T2LError("the fine stage runs on the MI355X only (model.to('cuda')); there is no CPU fallback")
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        if self._engine is None or self._engine.device != idx:
+            self._engine = Engine(idx)
+            self._weights_version = None
+        params = [p for n, p in self.state_dict(keep_vars=True).items() if not n.startswith("language_encoder.")]
+        version = tuple((p.data_ptr(), p._version) for p in params)
+        if version != self._weights_version:
+            a = self.args
+            sd = {k: v for k, v in self.state_dict().items() if not k.startswith("language_encoder.")}
+            self._engine.fine_load_weights(sd, class_embed=bool(getattr(a, "class_embed", False)),
+                                           color_embed=bool(getattr(a, "color_embed", False)), use_features=tuple(a.use_features),
+                                           num_layers=a.fine_num_decoder_layers, num_heads=a.fine_num_decoder_heads)
+            self._weights_version = version
+        return self._engine
+
+    # ---- the two halves -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode_cells(self, objects, object_points=None) -> torch.Tensor:
+        """[B,16,128] unit-row object descriptors of B padded cells (cross_matcher.py:97-104)."""
+        if self.training:
+            raise T2LError("the fine stage is eval-only here (call model.eval()); its training step is not built")
+        if any(len(o) != PAD_SIZE for o in objects):
+            raise T2LError(f"every cell must hold exactly pad_size={PAD_SIZE} objects (cross_matcher.pad_objects pads / cuts)")
+        eng = self.engine()
+        dev = self.device
+        oe = self.object_encoder
+        if any(getattr(o, "_t2l_feat", None) is None for objs in objects for o in objs):
+            packed = packing.pack_cells_gpu(eng, objects, oe.known_classes, oe.known_colors, dev)
+        else:
+            packed = packing.to_device(packing.pack_cells(objects, oe.known_classes, oe.known_colors), dev)
+        a = self.args
+        if "class" in a.use_features and not bool(getattr(a, "class_embed", False)):
+            if object_points is None or any(p is None for p in object_points):
+                raise T2LError("class_embed is off: object_points must hold, per cell, features2 [16,256] or the point batch")
+            first = object_points[0]
+            if isinstance(first, (torch.Tensor, np.ndarray)):
+                pn = torch.cat([torch.as_tensor(np.asarray(p) if not isinstance(p, torch.Tensor) else p) for p in object_points]).to(dev, torch.float32)
+            else:
+                get = lambda p, n: p[n] if isinstance(p, dict) else getattr(p, n)
+                pos = torch.cat([torch.as_tensor(get(p, "pos")).reshape(-1, 256, 3) for p in object_points]).to(dev, torch.float32)
+                rgb = torch.cat([torch.as_tensor(get(p, "x")).reshape(-1, 256, 3) for p in object_points]).to(dev, torch.float32)
+                pn = eng.pointnet_features(pos.contiguous(), rgb.contiguous(), np.arange(0, len(objects) * PAD_SIZE + 1, PAD_SIZE, dtype=np.int32))
+            packed["pn_feat"] = pn.reshape(-1, 256).contiguous()
+        return eng.fine_encode_objects(packed)
+
+    @torch.no_grad()
+    def match(self, cell_desc: torch.Tensor, hint_desc: torch.Tensor, cell_index=None, hint_index=None) -> torch.Tensor:
+        ci = None if cell_index is None else torch.as_tensor(cell_index, dtype=torch.int32, device=cell_desc.device).contiguous()
+        hi = None if hint_index is None else torch.as_tensor(hint_index, dtype=torch.int32, device=cell_desc.device).contiguous()
+        return self.engine().fine_match(cell_desc.contiguous(), hint_desc.detach().float().contiguous(), ci, hi)
+
+    @torch.no_grad()
+    def forward(self, objects, hints, object_points=None) -> torch.Tensor:
+        """One (pose, cell) pair per batch entry, as ``run_fine`` calls it (evaluation/pipeline.py:113-116)."""
+        hint_enc = self.language_encoder(hints)  # [B, n_hints, 128]  (cross_matcher.py:95)
+        return self.match(self.encode_cells(objects, object_points), hint_enc)
+
+
+@torch.no_grad()
+def run_fine(model: CrossMatch, retrievals, dataloader, args, transform_fine=None, object_points_fn=None):
+    """evaluation/pipeline.py:88-204: offsets of every pose against its max(top_k) retrieved cells -> {k: {t: accuracy}}.
+    The reference builds a ``Kitti360TopKDataset`` item per pose and runs one forward per pose, re-encoding a cell for
+    every pose that retrieved it; here every distinct retrieved cell is padded and encoded ONCE, every pose's hints are
+    encoded once, and all poses x max(top_k) pairs are matched in one launch.
+    ``object_points_fn(list_of_padded_object_lists) -> object_points`` supplies the PointNet++ inputs in the published
+    feature mode (e.g. ``packing.sample_object_points``); ``transform_fine`` is accepted for signature compatibility."""
+    from .coarse import calc_sample_accuracies
+
+    model.eval()
+    ds = dataloader.dataset
+    poses, cells = ds.all_poses, ds.all_cells
+    K = max(args.top_k)
+    assert len(poses) == len(retrievals) and all(len(r) == K for r in retrievals), "retrievals must be trimmed to max(top_k)"
+    cells_dict = {c.id: c for c in cells}
+    uniq = sorted({str(cid) for r in retrievals for cid in r})
+    row = {cid: i for i, cid in enumerate(uniq)}
+    padded = [pad_objects(cells_dict[cid].objects) for cid in uniq]
+    descs = []
+    for lo in range(0, len(padded), 2048):
+        chunk = padded[lo:lo + 2048]
+        descs.append(model.encode_cells(chunk, object_points_fn(chunk) if object_points_fn is not None else None))
+    cell_desc = torch.cat(descs) if descs else torch.zeros((0, PAD_SIZE, FINE_DIM), device=model.device)
+    hint_desc = []
+    for lo in range(0, len(poses), 256):
+        texts = [" ".join(create_hint_description(p)) for p in poses[lo:lo + 256]]
+        hint_desc.append(model.language_encoder(texts))
+    hint_desc = torch.cat(hint_desc)
+    ci = np.array([row[str(cid)] for r in retrievals for cid in r], dtype=np.int32)
+    hi = np.repeat(np.arange(len(poses), dtype=np.int32), K)
+    offsets = model.match(cell_desc, hint_desc, ci, hi).cpu().numpy().reshape(len(poses), K, 2)
+    acc = {k: {t: [] for t in args.threshs} for k in args.top_k}
+    for i, pose in enumerate(poses):
+        top_cells = [cells_dict[str(cid)] for cid in retrievals[i]]
+        a = calc_sample_accuracies(pose, top_cells, offsets[i], args.top_k, args.threshs)
+        for k in args.top_k:
+            for t in args.threshs:
+                acc[k][t].append(a[k][t])
+    return {k: {t: float(np.mean(v)) for t, v in d.items()} for k, d in acc.items()}

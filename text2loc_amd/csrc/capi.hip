@@ -229,7 +229,8 @@ int t2l_contrastive_loss(t2l_ctx* ctx, const float* anchor, const float* positiv
 int t2l_fine_load_weights(t2l_ctx* ctx, const t2l_weight_desc* w, int32_t n, const t2l_model_config* cfg) {
   if (!ctx) return T2L_EINVAL;
   T2L_HIP(ctx, hipSetDevice(ctx->device));
-  return fine_load_impl(ctx, w, n, cfg);
+  const int rc = fine_load_impl(ctx, w, n, cfg);
+  return rc ? rc : pointnet_load_impl(ctx, w, n);  // the fine checkpoint carries its own object_encoder.pointnet.* (optional group)
 }
 
 int t2l_fine_encode_objects(t2l_ctx* ctx, const t2l_packed_cells* in, float* out_desc, void* stream) {

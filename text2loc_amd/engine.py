@@ -222,7 +222,7 @@ class Engine:
                           use_features=("class", "color", "position", "num"), num_layers: int = 2, num_heads: int = 4):
         keep, descs = [], []
         for name, v in state_dict.items():
-            if name.startswith(("language_encoder.", "object_encoder.pointnet.")) or name.endswith("num_batches_tracked"):
+            if name.startswith("language_encoder.") or name.endswith("num_batches_tracked"):
                 continue
             a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
             a = np.ascontiguousarray(a, dtype=np.float32)
