@@ -274,6 +274,40 @@ def secondary_measurements(eng):
         eng_p.close()
     except Exception as e:
         out["pointnet"] = {"error": repr(e)}
+    # f-1: fine stage on the coarse result — descriptors of all 11,259 database cells once, then Q x top-10 (pose, cell) pairs
+    try:
+        sd_f = synth.make_fine_weights(0)
+        eng_f = Engine(eng.device)
+        eng_f.set_option("profile_events", 1)
+        eng_f.fine_load_weights(sd_f, class_embed=True, color_embed=True)
+        cells16 = synth.make_cells(N_CELLS, seed=17, min_obj=16, max_obj=16)
+        p16 = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cells16.items() if k != "counts"}
+        for _ in range(2):
+            desc = eng_f.fine_encode_objects(p16)
+        eng_f.kernel_stats("fine_objects")
+        for _ in range(3):
+            desc = eng_f.fine_encode_objects(p16)
+        torch.cuda.synchronize()
+        ms_obj, _ = eng_f.kernel_stats("fine_objects")
+        rs = np.random.default_rng(3)
+        hints = torch.from_numpy(rs.standard_normal((N_QUERIES, 6, 128)).astype(np.float32)).cuda()
+        ci = torch.from_numpy(rs.integers(0, N_CELLS, size=N_QUERIES * TOPK).astype(np.int32)).cuda()
+        hi = torch.arange(N_QUERIES, dtype=torch.int32, device="cuda").repeat_interleave(TOPK).contiguous()
+        for _ in range(2):
+            eng_f.fine_match(desc, hints, ci, hi)
+        eng_f.kernel_stats("fine_match")
+        for _ in range(3):
+            eng_f.fine_match(desc, hints, ci, hi)
+        torch.cuda.synchronize()
+        ms_m, _ = eng_f.kernel_stats("fine_match")
+        n_pairs = N_QUERIES * TOPK
+        out["fine_stage"] = {"workload": f"{N_CELLS} padded cells x 16 objects -> descriptors; {N_QUERIES} queries x top-{TOPK} = {n_pairs} pairs",
+                             "objects_kernel_ms": ms_obj, "match_kernel_ms": ms_m, "pairs_per_s": n_pairs / (ms_m * 1e-3),
+                             "queries_per_s": N_QUERIES / (ms_m * 1e-3), "tflops_match": 23.0e6 * n_pairs / (ms_m * 1e-3) / 1e12,
+                             "arithmetic": "f32 VALU (first version)"}
+        eng_f.close()
+    except Exception as e:
+        out["fine_stage"] = {"error": repr(e)}
     # a9 / SURVEY.md §8d config 4: one training step of the object branch at B=64 (train-mode forward with dropout 0.1 ->
     # contrastive loss -> backward -> Adam), text side supplied as a precomputed [64,256] batch
     try:

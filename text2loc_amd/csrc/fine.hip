@@ -251,9 +251,12 @@ __device__ void f_attention(const float* q, int ldq, int qc, const float* kv, in
   __syncthreads();
 }
 
-// nn.TransformerDecoderLayer (post-norm, ReLU, eval, no masks): x [T] (LDS, stride kFS) attends itself, then mem [S]
-__device__ void f_decoder(float* x, int T, const float* mem, int S, const FDecoder D, float* qkv /*[16][388]*/, float* att /*[16][kFS]*/,
-                          float* prob, float* hid /*[16][516]*/) {
+// nn.TransformerDecoderLayer (post-norm, ReLU, eval, no masks): x [T] (LDS, stride kFS) attends itself, then mem [S].
+// big: [16][516] floats, holds q|k|v (stride 388) during the attentions and the feed-forward hidden (stride 516) afterwards;
+// att / tmp: [16][kFS] temporaries.
+__device__ void f_decoder(float* x, int T, const float* mem, int S, const FDecoder D, float* big, float* att, float* prob, float* tmp) {
+  float* qkv = big;
+  float* hid = tmp;
   const int T8 = (T + 7) / 8;
   f_linear(x, kFS, T8, D.sa_in, kFD, 3 * kFD, qkv, 388, 0, false);
   __syncthreads();
@@ -307,9 +310,9 @@ __device__ void f_decoder(float* x, int T, const float* mem, int S, const FDecod
   __syncthreads();
   f_add_ln(x, att, kFS, T, D.g2, D.b2);
   __syncthreads();
-  f_linear(x, kFS, T8, D.l1, kFD, 4 * kFD, hid, 516, 0, true);
+  f_linear(x, kFS, T8, D.l1, kFD, 4 * kFD, big, 516, 0, true);
   __syncthreads();
-  f_linear(hid, 516, T8, D.l2, 4 * kFD, kFD, att, kFS, 0, false);
+  f_linear(big, 516, T8, D.l2, 4 * kFD, kFD, att, kFS, 0, false);
   __syncthreads();
   f_add_ln(x, att, kFS, T, D.g3, D.b3);
   __syncthreads();
@@ -375,16 +378,16 @@ __global__ __launch_bounds__(256) void fine_objects_kernel(FineParams P, t2l_pac
 }
 
 // One workgroup per (query, cell) pair.
-__global__ __launch_bounds__(256) void fine_match_kernel(FineParams P, const float* __restrict__ cell_desc, const int32_t* __restrict__ cell_index,
+__global__ __launch_bounds__(256, 2) void fine_match_kernel(FineParams P, const float* __restrict__ cell_desc, const int32_t* __restrict__ cell_index,
                                                          const float* __restrict__ hint_desc, const int32_t* __restrict__ hint_index,
                                                          int n_hints, float* __restrict__ out) {
   extern __shared__ float sm[];
   float* d0 = sm;                          // [16][kFS]
   float* d1 = d0 + kFObj * kFS;            // [8][kFS]
-  float* qkv = d1 + kFHintMax * kFS;       // [16][388]
-  float* att = qkv + kFObj * 388;          // [16][kFS]
-  float* hid = att + kFObj * kFS;          // [16][516]
-  float* prob = hid + kFObj * 516;         // [4][16][16]
+  float* big = d1 + kFHintMax * kFS;       // [16][516]: q|k|v during the attentions, feed-forward hidden afterwards
+  float* att = big + kFObj * 516;          // [16][kFS]
+  float* tmp = att + kFObj * kFS;          // [16][kFS]
+  float* prob = tmp + kFObj * kFS;         // [4][16][16]
   float* pooled = prob + kFHeads * 16 * 16;  // [128]
   float* h64 = pooled + kFD;               // [64]
   const int pair = blockIdx.x, tid = threadIdx.x;
@@ -394,8 +397,8 @@ __global__ __launch_bounds__(256) void fine_match_kernel(FineParams P, const flo
   for (int i = tid; i < kFHintMax * kFD; i += 256) d1[(i / kFD) * kFS + (i % kFD)] = (i / kFD) < n_hints ? hd[i] : 0.f;
   __syncthreads();
   for (int l = 0; l < P.n_layers; ++l) {  // cross_matcher.py:114-118
-    f_decoder(d0, kFObj, d1, n_hints, P.obj[l], qkv, att, prob, hid);
-    f_decoder(d1, n_hints, d0, kFObj, P.hint[l], qkv, att, prob, hid);
+    f_decoder(d0, kFObj, d1, n_hints, P.obj[l], big, att, prob, tmp);
+    f_decoder(d1, n_hints, d0, kFObj, P.hint[l], big, att, prob, tmp);
   }
   if (tid < kFD) {  // desc1.max(dim=0) over the hints
     float m = d1[tid];
@@ -440,7 +443,7 @@ int fine_match_impl(t2l_ctx* ctx, const float* cell_desc, const int32_t* cell_in
   if (!cell_desc || !hint_desc || !out || n_pairs < 0) return fail(ctx, T2L_EINVAL, "t2l_fine_match: null argument");
   if (n_hints < 1 || n_hints > kFHintMax) return fail(ctx, T2L_EINVAL, "t2l_fine_match: 1 <= n_hints <= 8");
   if (n_pairs == 0) return T2L_OK;
-  const size_t lds = sizeof(float) * (kFObj * kFS + kFHintMax * kFS + kFObj * 388 + kFObj * kFS + kFObj * 516 + kFHeads * 16 * 16 + kFD + 64);
+  const size_t lds = sizeof(float) * (kFObj * kFS + kFHintMax * kFS + kFObj * 516 + 2 * kFObj * kFS + kFHeads * 16 * 16 + kFD + 64);  // 67.5 KB: two pairs per CU
   static bool attr = false;
   if (!attr) {
     T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fine_match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
