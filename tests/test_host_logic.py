@@ -188,3 +188,24 @@ def test_pointnet_parameter_names_match_the_reference_module(golden):
     assert have == want
     sd = synth.make_pointnet_weights(0, n_classes=22, n_colors=9)
     assert {k[len("object_encoder.pointnet."):]: tuple(np.asarray(v).shape) for k, v in sd.items()} == want
+
+
+def test_crossmatch_mirror_has_the_reference_key_layout():
+    """The fine model's parameter names/shapes == synth.make_fine_weights, whose names the reference's own CrossMatch accepted
+    with no unexpected key (oracle/gen_golden_fine.py asserts that when the goldens are generated)."""
+    from text2loc_amd.cross_matcher import CrossMatch, pad_objects
+
+    args = argparse.Namespace(fine_embed_dim=128, fine_num_decoder_heads=4, fine_num_decoder_layers=2, pad_size=16,
+                              fine_intra_module_num_layers=1, fine_intra_module_num_heads=4, hungging_model=None,
+                              fixed_embedding=True, class_embed=True, color_embed=True,
+                              use_features=["class", "color", "position", "num"])
+    model = CrossMatch(synth.KNOWN_CLASS, synth.COLOR_NAMES, args, language_encoder=torch.nn.Identity())
+    have = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    for k, v in synth.make_fine_weights(0).items():
+        assert have.get(k) == tuple(np.asarray(v).shape), k
+    objs = pad_objects([Obj("pole", np.zeros((30, 3)), np.zeros((30, 3), np.float32))] * 3)
+    assert len(objs) == 16 and objs[3].label == "pad" and objs[3].xyz.shape == (8, 3) and float(np.abs(objs[3].xyz).max()) < 1e-3
+    assert len(pad_objects(objs * 2)) == 16
+    with pytest.raises(Exception, match="MI355X|no CPU fallback"):
+        model.eval()
+        model.encode_cells([objs])
