@@ -184,39 +184,56 @@ template <int CIN, int H1, int H2, typename Emit>
 __device__ __forceinline__ void sa_mlp_tile(const float (&xrow)[k1p(CIN) / 2], const float4* __restrict__ w1, const float4* __restrict__ w2,
                                             int lane, Emit&& emit) {
   constexpr int K1P = k1p(CIN), S4 = K1P / 8, FT = H1 / 32, NT = H2 / 32;
+  // One wave per SIMD (the register file holds h1 + the input row), so the L2 latency of the weight stream is hidden by an
+  // explicit ring of PF float4 loads in flight (PF x 4 MFMAs = PF x 256 cycles of lookahead), not by other waves.
+  constexpr int PF = 4;
   f32x16 h1[FT];
+  {
+    constexpr int STEPS = FT * S4;
+    float4 ring[PF];
 #pragma unroll
-  for (int ft = 0; ft < FT; ++ft) {
+    for (int i = 0; i < PF; ++i) ring[i] = w1[(i < STEPS ? i : 0) * 64 + lane];
     f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int step = 0; step < STEPS; ++step) {
+      const int ft = step / S4, s4 = step % S4;
+      if (s4 == 0) {
 #pragma unroll
-    for (int s4 = 0; s4 < S4; ++s4) {
-      const float4 w = w1[(ft * S4 + s4) * 64 + lane];
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      }
+      const float4 w = ring[step % PF];
+      if (step + PF < STEPS) ring[step % PF] = w1[(step + PF) * 64 + lane];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, xrow[4 * s4 + 0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, xrow[4 * s4 + 1], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, xrow[4 * s4 + 2], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, xrow[4 * s4 + 3], acc, 0, 0, 0);
-    }
+      __builtin_amdgcn_sched_barrier(0);  // keep the ring's distance: no further hoisting of loads (register pressure)
+      if (s4 == S4 - 1) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) h1[ft][r] = fmaxf(acc[r], 0.f);  // BatchNorm + bias folded; ReLU
-    __builtin_amdgcn_sched_barrier(0);  // keep the next tile's weight loads from being hoisted over this one (register pressure)
+        for (int r = 0; r < 16; ++r) h1[ft][r] = fmaxf(acc[r], 0.f);  // BatchNorm + bias folded; ReLU
+      }
+    }
   }
 #pragma unroll 1
   for (int nt = 0; nt < NT; ++nt) {  // rolled: h1 (up to 128 VGPRs) + the input row already fill most of the register file
+    constexpr int STEPS = FT * 4;
+    const float4* wp = w2 + (size_t)nt * STEPS * 64 + lane;
+    float4 ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) ring[i] = wp[(i < STEPS ? i : 0) * 64];
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int ft = 0; ft < FT; ++ft) {
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const float4 w = w2[((nt * FT + ft) * 4 + rq) * 64 + lane];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h1[ft][4 * rq + 0], w.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h1[ft][4 * rq + 1], w.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h1[ft][4 * rq + 2], w.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h1[ft][4 * rq + 3], w.w, acc, 0, 0, 0);
-      }
+    for (int step = 0; step < STEPS; ++step) {
+      const int ft = step / 4, rq = step % 4;
+      const float4 w = ring[step % PF];
+      if (step + PF < STEPS) ring[step % PF] = wp[(step + PF) * 64];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h1[ft][4 * rq + 0], w.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h1[ft][4 * rq + 1], w.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h1[ft][4 * rq + 2], w.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h1[ft][4 * rq + 3], w.w, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     emit(nt, acc);
   }
@@ -350,6 +367,31 @@ __global__ __launch_bounds__(256, 1) void pn_sa_kernel(SaParams P) {
   }
 }
 
+// acc += A[32 x 8*S4] (this lane's row half, LDS, float4 per 4 k-steps) * B (packed weights, global: wp[s4*64], lane folded in),
+// with 4 weight loads in flight (one wave per SIMD: the L2 latency has to be hidden inside the wave)
+template <int S4>
+__device__ __forceinline__ void ga_dot(const float* __restrict__ ar, const float4* __restrict__ wp, f32x16& acc) {
+  float4 b0 = wp[0], b1 = wp[64 * (1 < S4 ? 1 : 0)], b2 = wp[64 * (2 < S4 ? 2 : 0)], b3 = wp[64 * (3 < S4 ? 3 : 0)];
+#define GA_STEP(B, S)                                                                         \
+  {                                                                                           \
+    const float4 a = *reinterpret_cast<const float4*>(ar + 4 * (S));                          \
+    const float4 w = B;                                                                       \
+    if ((S) + 4 < S4) B = wp[64 * ((S) + 4)];                                                 \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc, 0, 0, 0);                       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc, 0, 0, 0);                       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc, 0, 0, 0);                       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);                       \
+  }
+  int s = 0;
+  for (; s + 4 <= S4; s += 4) {
+    GA_STEP(b0, s) GA_STEP(b1, s + 1) GA_STEP(b2, s + 2) GA_STEP(b3, s + 3)
+  }
+  if (s < S4) GA_STEP(b0, s)
+  if (s + 1 < S4) GA_STEP(b1, s + 1)
+  if (s + 2 < S4) GA_STEP(b2, s + 2)
+#undef GA_STEP
+}
+
 // GlobalAbstraction: get_mlp([259,512,1024]) over the 32 points of an object, max. One workgroup per object.
 constexpr int kGaK = 264, kGaXS = kGaK + 4, kGaH1 = 512, kGaHS = kGaH1 + 4, kGaH2 = 1024;
 __global__ __launch_bounds__(256, 1) void pn_ga_kernel(const float* __restrict__ pos3, const float* __restrict__ x3,
@@ -374,15 +416,7 @@ __global__ __launch_bounds__(256, 1) void pn_ga_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* xr = X + j * kGaXS + kh * (kGaK / 2);
-#pragma unroll 3
-    for (int s4 = 0; s4 < kGaK / 8; ++s4) {
-      const float4 a = *reinterpret_cast<const float4*>(xr + 4 * s4);
-      const float4 b = w1[(nt * (kGaK / 8) + s4) * 64 + lane];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-    }
+    ga_dot<kGaK / 8>(xr, w1 + (size_t)nt * (kGaK / 8) * 64 + lane, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) Hd[((r & 3) + 8 * (r >> 2) + 4 * kh) * kGaHS + nt * 32 + j] = fmaxf(acc[r], 0.f);
   }
@@ -392,15 +426,7 @@ __global__ __launch_bounds__(256, 1) void pn_ga_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* hr = Hd + j * kGaHS + kh * (kGaH1 / 2);
-#pragma unroll 4
-    for (int s4 = 0; s4 < kGaH1 / 8; ++s4) {
-      const float4 a = *reinterpret_cast<const float4*>(hr + 4 * s4);
-      const float4 b = w2[(nt * (kGaH1 / 8) + s4) * 64 + lane];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-    }
+    ga_dot<kGaH1 / 8>(hr, w2 + (size_t)nt * (kGaH1 / 8) * 64 + lane, acc);
     float m = acc[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
