@@ -381,9 +381,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the encoder / loss side measurements")
     ap.add_argument("--cells", type=int, default=N_CELLS, help="dev: database rows (default = the BASELINE workload)")
     ap.add_argument("--queries", type=int, default=N_QUERIES, help="dev: queries per step")
-    ap.add_argument("--list-len", type=int, default=16, help="dev: per-lane candidate list length (12 or 16)")
     ap.add_argument("--mode", type=int, default=0, help="search_mode: 0 = split-bf16 specialised scan, 1 = f32 scan")
-    ap.add_argument("--variant", type=int, default=0, help="dev: timing-only ablation of the scan kernel")
     ap.add_argument("--nsplit", type=int, default=0, help="override the scan kernel's DB split count (0 = auto)")
     args = ap.parse_args()
 
@@ -412,9 +410,6 @@ def main():
     lo, hi = searcher.set_db_shard(d_db)
     eng.set_option("profile_events", 1)
     eng.set_option("search_mode", args.mode)
-    eng.set_option("list_len", args.list_len)
-    if args.variant:
-        eng.set_option("scan_variant", args.variant)
     if args.nsplit:
         eng.set_option("search_nsplit", args.nsplit)
 
@@ -487,11 +482,9 @@ def main():
         flops = 2.0 * N_QUERIES * n_local * DIM  # algorithmic FLOPs of one scan launch on this rank's shard
         achieved = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
         if args.mode == 1:
-            kname, peak, dtype, mult = "scan_kernel<16, 0>", F32_MFMA_PEAK_TFLOPS, "f32", 1
+            kname, peak, dtype, mult = "scan_kernel<16>", F32_MFMA_PEAK_TFLOPS, "f32", 1
         else:
-            kname = {0: "scan3_kernel<16, 2, 0, 4>", 2: "scan2_kernel<16, 0>", 3: "scan3_kernel<16, 1, 0, 4>",
-                     4: "scan3_kernel<16, 2, 0, 8>"}[args.mode]
-            peak, dtype, mult = BF16_MFMA_PEAK_TFLOPS, "bf16x3", 3
+            kname, peak, dtype, mult = "scan3_kernel<16>", BF16_MFMA_PEAK_TFLOPS, "bf16x3", 3
         out = {
             "metric": "coarse-retrieval queries/sec over 11k-cell DB, embed_dim=256; top-1/3/5 recall parity",
             "value": N_QUERIES * args.steps / elapsed,

@@ -198,14 +198,6 @@ int t2l_merge_pairs(t2l_ctx* ctx, const double* pairs, int32_t parts, int32_t n_
   return merge_pairs_impl(ctx, pairs, parts, n_queries, k, out_idx, out_score, (hipStream_t)stream);
 }
 
-// dev: phase cycle counters written by the instrumented scan variant (scan_variant 16/17): 4 waves x 5 phases
-int t2l_debug_counters(t2l_ctx* ctx, long long* out, int32_t n) {
-  if (!ctx || !out || n > 60) return T2L_EINVAL;
-  T2L_HIP(ctx, hipDeviceSynchronize());
-  T2L_HIP(ctx, hipMemcpy(out, ctx->fb_count + 4, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
-  return T2L_OK;
-}
-
 int t2l_search_fallbacks(t2l_ctx* ctx, int32_t* out_count) {
   if (!ctx || !out_count) return T2L_EINVAL;
   T2L_HIP(ctx, hipSetDevice(ctx->device));
@@ -288,15 +280,10 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     if (value < 0 || value > kMaxParts / 2) return fail(ctx, T2L_EINVAL, "search_nsplit out of range [0,32]");
     ctx->nsplit_override = (int)value;
   } else if (!strcmp(name, "search_mode")) {
-    if (value < 0 || value > 4) return fail(ctx, T2L_EINVAL, "search_mode must be 0..4");
+    if (value != 0 && value != 1) return fail(ctx, T2L_EINVAL, "search_mode must be 0 (split-bf16 scan) or 1 (f32 scan)");
     ctx->search_mode = (int)value;
   } else if (!strcmp(name, "stream_min_rows")) {
     ctx->stream_min_rows = (int)value;
-  } else if (!strcmp(name, "list_len")) {
-    if (value != 12 && value != 16) return fail(ctx, T2L_EINVAL, "list_len must be 12 or 16");
-    ctx->list_len = (int)value;
-  } else if (!strcmp(name, "scan_variant")) {
-    ctx->scan_variant = (int)value;
   } else if (!strcmp(name, "pointnet_pyg_self_loops")) {
     ctx->pn_self_loops = value != 0;
   } else if (!strcmp(name, "profile_events")) {

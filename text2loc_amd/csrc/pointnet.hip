@@ -21,7 +21,6 @@ namespace t2l {
 
 using train::f32x16;
 
-constexpr int kPnPts = 256;  // args.pointnet_numpoints
 
 struct PointNetWeights {
   float4 *w1[3] = {}, *w2[3] = {};  // SA levels, packed

@@ -33,7 +33,7 @@ namespace t2l {
 // latency, so the VALU work below needs two independent chains to hide behind. After every 8th MFMA one
 // score of the PREVIOUS tile is turned into a key and inserted into the lane's list: ~L+4 VALU instructions
 // spread over the gaps (sched_group_barrier pins the interleave).
-template <int L, int VAR, int S = 0>
+template <int L, int S = 0>
 __device__ __forceinline__ void tile_mfma(const float* tb, const float (&qa)[128], f32x16& cur0, f32x16& cur1,
                                           const f32x16& prev0, const f32x16& prev1, int prev_row0, int n_rows,
                                           int mask, int prev_code0, float (&ls)[L], float4 (&ab)[4]) {
@@ -49,10 +49,7 @@ __device__ __forceinline__ void tile_mfma(const float* tb, const float (&qa)[128
       constexpr int r = S >> 1;
       const int row = prev_row0 + (r & 3) + 8 * (r >> 2);
       const float key = make_key(prev0[r] + prev1[r], mask, prev_code0 + r);
-      if constexpr (VAR & 1)  // ablation: no list insertion
-        ls[r % L] = fmaxf(ls[r % L], key);
-      else
-        ins_key<L>(ls, row < n_rows ? key : T2L_NEG_INF);
+      ins_key<L>(ls, row < n_rows ? key : T2L_NEG_INF);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -60,7 +57,7 @@ __device__ __forceinline__ void tile_mfma(const float* tb, const float (&qa)[128
       __builtin_amdgcn_sched_group_barrier(0x002, (L + 4 + 7) / 8, 0);  // its share of the insertion VALU
     }
     if constexpr (S + 4 < 32) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // the LDS prefetch
-    tile_mfma<L, VAR, S + 1>(tb, qa, cur0, cur1, prev0, prev1, prev_row0, n_rows, mask, prev_code0, ls, ab);
+    tile_mfma<L, S + 1>(tb, qa, cur0, cur1, prev0, prev1, prev_row0, n_rows, mask, prev_code0, ls, ab);
   }
 }
 
@@ -69,7 +66,7 @@ __device__ __forceinline__ void tile_mfma(const float* tb, const float (&qa)[128
 // nsplit a multiple of 8 every XCD (b % 8) keeps re-reading the same DB split from its own L2.
 // LDS: 2 x [32 rows x 260 f32] DB tiles (glds double buffer), shared by the 4 waves (4 x 32 queries).
 // ------------------------------------------------------------------------------------------------
-template <int L, int VAR>
+template <int L>
 __global__ __launch_bounds__(256, L <= 16 ? 2 : 1) void scan_kernel(const float* __restrict__ db, int n_rows, int n_tiles, int per,
                                                       int code_bits, const float* __restrict__ q, int Q, int nsplit,
                                                       float* __restrict__ cand, int32_t* __restrict__ fb_count, int zero_counts) {
@@ -125,11 +122,9 @@ __global__ __launch_bounds__(256, L <= 16 ? 2 : 1) void scan_kernel(const float*
   // D[row][col]: a lane holds query `col` and DB rows (r&3) + 8*(r>>2) + 4*half of the tile; the key's
   // code is ((tile - t0) << 4) | r  (the row is rebuilt from it, `half` and the split in the re-rank).
   auto step = [&](int t, int buf, f32x16& cur0, f32x16& cur1, const f32x16& prev0, const f32x16& prev1) {
-    if constexpr (!(VAR & 2)) {  // (ablation bit 1: no tile streaming, every step re-reads the first tile)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();  // tile t landed for every wave; every wave is done reading buffer buf^1
-      if (t + 1 < t1) issue(t + 1, buf ^ 1);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile t landed for every wave; every wave is done reading buffer buf^1
+    if (t + 1 < t1) issue(t + 1, buf ^ 1);
     const float* tb = tiles + buf * kTileFloats + col * kRowStrideF + half * 128;
     float4 ab[4];
 #pragma unroll
@@ -139,18 +134,14 @@ __global__ __launch_bounds__(256, L <= 16 ? 2 : 1) void scan_kernel(const float*
       cur0[r] = 0.f;
       cur1[r] = 0.f;
     }
-    tile_mfma<L, VAR>(tb, qa, cur0, cur1, prev0, prev1, (t - 1) * kTileRows + 4 * half, n_rows, mask,
+    tile_mfma<L>(tb, qa, cur0, cur1, prev0, prev1, (t - 1) * kTileRows + 4 * half, n_rows, mask,
                       (t - 1 - t0) << 4, ls, ab);
   };
 
   if (t0 < t1) issue(t0, 0);
-  if constexpr (VAR & 2) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
   for (int t = t0; t < t1; t += 2) {
     step(t, 0, accA0, accA1, accB0, accB1);  // while tile t multiplies, tile t-1's scores (B) enter the list
-    if (t + 1 < t1) step(t + 1, (VAR & 2) ? 0 : 1, accB0, accB1, accA0, accA1);
+    if (t + 1 < t1) step(t + 1, 1, accB0, accB1, accA0, accA1);
   }
   if (t0 < t1) {  // the last tile's scores are still in registers
     const int row0 = (t1 - 1) * kTileRows + 4 * half;
@@ -178,17 +169,13 @@ __global__ __launch_bounds__(256, L <= 16 ? 2 : 1) void scan_kernel(const float*
 }
 
 // ------------------------------------------------------------------------------------------------
-// scan2: wave-specialised scan on split-bf16 operands (the default path).
+// Split-bf16 operands (the default scan, scan3_kernel below).
 //
 // Every f32 value x is stored as two bf16 planes hi = bf16(x), lo = bf16(x - hi); a product is formed as
 // hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with f32 accumulation: |error| <= (2^-16 + 2^-18) * |a||b|
 // per dot product on top of the f32 accumulation bound — the same order as the key truncation, and covered
 // by the same certificate (the float64 re-rank decides the final order either way). 48 MFMAs of 32 cycles
-// per 32-row tile instead of 128 of 64 cycles: the matrix pipe is no longer the bound, the top-L selection
-// is — so the workgroup is 8 waves, 4 MFMA waves (32 queries each) + 4 selection waves. MFMA wave w hands
-// the 16 scores per lane of a finished tile to selection wave w+4 (same SIMD: its VALU runs beside the other
-// wave's MFMAs) through a double-buffered 4 KiB LDS slab; the selection waves also stream the DB tiles
-// (global_load_lds). One barrier per tile orders all three hand-offs.
+// per 32-row tile instead of 128 of 64 cycles.
 // DB layout for this kernel: bf16 [n_pad][2 planes][256] = 1 KiB per row, built once by split_db_kernel.
 // ------------------------------------------------------------------------------------------------
 // f32 [rows][256] -> bf16 [rows][hi 256 | lo 256]
@@ -203,153 +190,29 @@ __global__ __launch_bounds__(256) void split_db_kernel(const float* __restrict__
   out[(size_t)row * 64 + 32 + c] = lo;
 }
 
-// 48 MFMAs of one tile (step S of 16), with one score of the previous tile written to the slab per step.
-template <int S = 0>
-__device__ __forceinline__ void tile_mfma_bf16(const char* tb, const uint4 (&qh)[16], const uint4 (&ql)[16], f32x16& cur,
-                                               const f32x16& prev, float* slab, uint4 (&ah)[2], uint4 (&al)[2]) {
-  if constexpr (S < 16) {
-    if constexpr (S == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // prologue LDS reads first
-    const uint4 a_hi = ah[S & 1], a_lo = al[S & 1];
-    if constexpr (S + 2 < 16) {
-      ah[S & 1] = *reinterpret_cast<const uint4*>(tb + 16 * (S + 2));
-      al[S & 1] = *reinterpret_cast<const uint4*>(tb + 512 + 16 * (S + 2));
-    }
-    const bf16x8 vh = __builtin_bit_cast(bf16x8, a_hi), vl = __builtin_bit_cast(bf16x8, a_lo);
-    cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, __builtin_bit_cast(bf16x8, qh[S]), cur, 0, 0, 0);
-    cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, __builtin_bit_cast(bf16x8, ql[S]), cur, 0, 0, 0);
-    cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, __builtin_bit_cast(bf16x8, qh[S]), cur, 0, 0, 0);
-    slab[S * 64] = prev[S];  // (iteration 0 writes zeros into a slab nobody reads yet)
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-    if constexpr (S + 2 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-    tile_mfma_bf16<S + 1>(tb, qh, ql, cur, prev, slab, ah, al);
-  }
-}
-
-template <int L, int VAR>
-__global__ __launch_bounds__(512, 2) void scan2_kernel(const uint4* __restrict__ dbs, int n_rows, int n_tiles, int per,
-                                                       int code_bits, const float* __restrict__ q, int Q, int nsplit,
-                                                       float* __restrict__ cand, int32_t* __restrict__ fb_count,
-                                                       int zero_counts) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* tiles = smem;                       // 2 x [32 rows x 1040 B]
-  float* slabs = smem + 2 * kTileFloats;     // [4 waves][2][16][64]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // MFMA wave and its selection wave share queries. VAR bit 3 (experiment): pair waves (2w, 2w+1) instead of (w, w+4)
-  const int role_w = (VAR & 8) ? (wave >> 1) : (wave & 3);
-  const bool is_mfma = (VAR & 8) ? !(wave & 1) : (wave < 4);
-  const int half = lane >> 5, col = lane & 31;
-  const int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
-  const int t0 = sp * per;
-  const int t1 = min(n_tiles, t0 + per);
-  const int nt = max(t1 - t0, 0);
-  const int qrow = qb * kQPerBlock + role_w * kQPerWave + col;
-  if (zero_counts && blockIdx.x == 0 && tid < 2) fb_count[tid] = 0;
-  float* my_slab = slabs + role_w * 2 * kSlabFloats + lane;
-
-  if (is_mfma) {
-    // ------------------------------------------------------------ MFMA role
-    uint4 qh[16], ql[16];
-    {
-      const float4* qp = reinterpret_cast<const float4*>(q + (size_t)min(qrow, Q - 1) * kD + half * 128);
-#pragma unroll
-      for (int s = 0; s < 16; ++s) split8(qp[2 * s], qp[2 * s + 1], qh[s], ql[s]);
-    }
-    f32x16 accA, accB;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accA[r] = accB[r] = 0.f;
-    auto step = [&](int it, int buf, f32x16& cur, const f32x16& prev) {
-      __syncthreads();
-      if (it < nt) {
-        const char* tb = reinterpret_cast<const char*>(tiles + buf * kTileFloats) + col * (kRowStrideF * 4) + half * 256;
-        uint4 ah[2], al[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          ah[i] = *reinterpret_cast<const uint4*>(tb + 16 * i);
-          al[i] = *reinterpret_cast<const uint4*>(tb + 512 + 16 * i);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cur[r] = 0.f;
-        if constexpr (!(VAR & 2)) tile_mfma_bf16(tb, qh, ql, cur, prev, my_slab + ((it + 1) & 1) * kSlabFloats, ah, al);
-      } else if (it == nt && nt > 0) {  // drain: the last tile's scores
-#pragma unroll
-        for (int r = 0; r < 16; ++r) my_slab[((it - 1) & 1) * kSlabFloats + r * 64] = prev[r];
-      }
-    };
-    for (int it = 0; it < nt + 2; it += 2) {
-      step(it, 0, accA, accB);
-      step(it + 1, 1, accB, accA);
-    }
-  } else {
-    // ------------------------------------------------------------ selection + tile streaming role
-    const int mask = ~((1 << code_bits) - 1);
-    float ls[L];
-#pragma unroll
-    for (int i = 0; i < L; ++i) ls[i] = T2L_NEG_INF;
-    auto issue = [&](int t, int buf) {
-      const uint4* src = dbs + (size_t)t * kTileRows * 64 + lane;
-      float* dst = tiles + buf * kTileFloats;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = role_w * 8 + i;  // one wave-instruction moves one 1 KiB row (hi | lo planes) into LDS
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + row * 64),
-                                         (__attribute__((address_space(3))) void*)(dst + row * kRowStrideF), 16, 0, 0);
-      }
-    };
-    if (nt > 0) issue(t0, 0);
-    const int niter = (nt + 2 + 1) & ~1;  // the MFMA waves run an even number of iterations
-    for (int it = 0; it < niter; ++it) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile `it` has landed (this wave's rows)
-      __syncthreads();
-      if ((it + 1 < nt) && !(VAR & 4)) issue(t0 + it + 1, (it + 1) & 1);  // every wave is past its reads of that buffer
-      if (it >= 2 && it - 2 < nt) {
-        const int tl = it - 2;  // tile whose scores the MFMA wave wrote during iteration it-1
-        const float* slab = my_slab + (tl & 1) * kSlabFloats;
-        const int row0 = (t0 + tl) * kTileRows + 4 * half;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row0 + (r & 3) + 8 * (r >> 2);
-          const float key = make_key(slab[r * 64], mask, (tl << 4) + r);
-          if constexpr (VAR & 1)
-            ls[r % L] = fmaxf(ls[r % L], key);
-          else
-            ins_key<L>(ls, row < n_rows ? key : T2L_NEG_INF);
-        }
-      }
-    }
-    if (qrow < Q) {
-      float4* out = reinterpret_cast<float4*>(cand + (((size_t)qrow * nsplit + sp) * 2 + half) * L);
-#pragma unroll
-      for (int i = 0; i < L / 4; ++i) out[i] = make_float4(ls[4 * i], ls[4 * i + 1], ls[4 * i + 2], ls[4 * i + 3]);
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // scan3: split-bf16 scan with the selection interleaved in the SAME wave (measured on gfx950,
 // tools/mfma_valu_probe.hip: up to ~4-5 independent VALU instructions hide in the 32-cycle gap of a
 // bf16 32x32x16 MFMA when they sit in the issuing wave's own stream; a partner wave's VALU stream on the
-// same SIMD instead slows the MFMA wave by 20-40 cycles per MFMA, which is why scan2's wave specialisation
-// loses). Structure = scan_kernel (4 waves x 32 queries share the LDS tile), arithmetic = scan2's.
+// same SIMD instead slows the MFMA wave by 20-40 cycles per MFMA, which is why a wave-specialised variant —
+// MFMA waves handing scores to selection waves through LDS — measured slower, 93 vs 81 us, and was dropped).
+// Structure = scan_kernel (4 waves x 32 queries share the LDS tile), arithmetic = split-bf16.
 // The row >= n_rows mask lives only in the epilogue: the one partial tile of a shard is the last tile of the
 // last split, whose scores are inserted after the loop.
 // ------------------------------------------------------------------------------------------------
-template <int L, int WPS, int VAR, int NW>
-__global__ __launch_bounds__(NW * 64, WPS) void scan3_kernel(const uint4* __restrict__ dbs, int n_rows, int n_tiles,
+template <int L>
+__global__ __launch_bounds__(kScanWaves * 64, 2) void scan3_kernel(const uint4* __restrict__ dbs, int n_rows, int n_tiles,
                                                          int per, int code_bits, const float* __restrict__ q, int Q,
                                                          int nsplit, float* __restrict__ cand,
                                                          int32_t* __restrict__ fb_count, int zero_counts, float pinf) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tiles = smem;
-  long long k0 = 0, k1 = 0, k2 = 0;
-  if constexpr (VAR & 16) k0 = __builtin_readcyclecounter();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
   const int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
   const int t0 = sp * per;
   const int t1 = min(n_tiles, t0 + per);
-  const int qrow = qb * (NW * kQPerWave) + wave * kQPerWave + col;
+  const int qrow = qb * (kScanWaves * kQPerWave) + wave * kQPerWave + col;
   const int mask = ~((1 << code_bits) - 1);
   int vmask = mask;
   asm volatile("" : "+v"(vmask));  // keep the mask in a VGPR so key = v_and_or_b32(score, vmask, s_code) is one op
@@ -372,25 +235,16 @@ __global__ __launch_bounds__(NW * 64, WPS) void scan3_kernel(const uint4* __rest
     const uint4* src = dbs + (size_t)t * kTileRows * 64 + lane;
     float* dst = tiles + buf * kTileFloats;
 #pragma unroll
-    for (int i = 0; i < 32 / NW; ++i) {
-      const int row = wave * (32 / NW) + i;  // one wave-instruction moves one 1 KiB row (hi | lo planes) into LDS
+    for (int i = 0; i < 32 / kScanWaves; ++i) {
+      const int row = wave * (32 / kScanWaves) + i;  // one wave-instruction moves one 1 KiB row (hi | lo planes) into LDS
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + row * 64),
                                        (__attribute__((address_space(3))) void*)(dst + row * kRowStrideF), 16, 0, 0);
     }
   };
-  long long tm[5] = {0, 0, 0, 0, 0};  // VAR & 16: cycles in [vmcnt wait, barrier, glds issue, first LDS reads, MFMA+select]
   auto step = [&](int t, int buf, f32x16& cur, const f32x16& prev) {
-    long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
-    if constexpr (VAR & 16) c0 = __builtin_readcyclecounter();
-    if constexpr (!(VAR & 4)) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if constexpr (VAR & 16) c1 = __builtin_readcyclecounter();
-      __syncthreads();  // tile t landed for every wave; every wave is done reading buffer buf^1
-      if constexpr (VAR & 16) c2 = __builtin_readcyclecounter();
-      if constexpr (!(VAR & 64))
-        if (t + 1 < t1) issue(t + 1, buf ^ 1);
-      if constexpr (VAR & 16) c3 = __builtin_readcyclecounter();
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile t landed for every wave; every wave is done reading buffer buf^1
+    if (t + 1 < t1) issue(t + 1, buf ^ 1);
     const char* tb = reinterpret_cast<const char*>(tiles + buf * kTileFloats) + col * (kRowStrideF * 4) + half * 256;
     uint4 ah[4], al[4];
 #pragma unroll
@@ -400,43 +254,15 @@ __global__ __launch_bounds__(NW * 64, WPS) void scan3_kernel(const uint4* __rest
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) cur[r] = 0.f;
-    if constexpr (VAR & 16) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      c4 = __builtin_readcyclecounter();
-    }
     constexpr int VPM = (L + 2 + 2) / 3;
-    {
-      // (past the last tile the interleaved DMA re-loads that tile into the idle buffer, which nobody reads)
-      const uint4* gnext = dbs + ((size_t)min(t + 1, t1 - 1) * kTileRows + wave * (32 / NW)) * 64 + lane;
-      float* lnext = tiles + (buf ^ 1) * kTileFloats + (wave * (32 / NW)) * kRowStrideF;
-      tile_mfma_bf16_sel<L, VPM, VAR, NW, 0, 16>(tb, qh, ql, cur, prev, vmask, (t - 1 - t0) << 4, pinf, ls, ah, al,
-                                                 gnext, lnext);
-    }
-    if constexpr (VAR & 16) {
-      asm volatile("" ::"v"(cur[0]));
-      const long long c5 = __builtin_readcyclecounter();
-      tm[0] += c1 - c0;
-      tm[1] += c2 - c1;
-      tm[2] += c3 - c2;
-      tm[3] += c4 - c3;
-      tm[4] += c5 - c4;
-    }
+    tile_mfma_bf16_sel<L, VPM, 0, 16>(tb, qh, ql, cur, prev, vmask, (t - 1 - t0) << 4, pinf, ls, ah, al);
   };
 
-  if constexpr (VAR & 16) {
-    asm volatile("" ::"v"(qh[15].x), "v"(ql[15].w));
-    k1 = __builtin_readcyclecounter();
-  }
   if (t0 < t1) issue(t0, 0);
-  if constexpr (VAR & 4) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
   for (int t = t0; t < t1; t += 2) {
     step(t, 0, accA, accB);
-    if (t + 1 < t1) step(t + 1, (VAR & 4) ? 0 : 1, accB, accA);
+    if (t + 1 < t1) step(t + 1, 1, accB, accA);
   }
-  if constexpr (VAR & 16) k2 = __builtin_readcyclecounter();
   if (t0 < t1) {  // the last tile's scores are still in registers; only here can rows be >= n_rows
     const int row0 = (t1 - 1) * kTileRows + 4 * half;
     const int code0 = (t1 - 1 - t0) << 4;
@@ -452,20 +278,6 @@ __global__ __launch_bounds__(NW * 64, WPS) void scan3_kernel(const uint4* __rest
         const int row = row0 + (r & 3) + 8 * (r >> 2);
         ins_key<L>(ls, row < n_rows ? make_key(accB[r], mask, code0 + r) : T2L_NEG_INF);
       }
-    }
-  }
-  if constexpr (VAR & 16) {
-    if (blockIdx.x == 17 && lane == 0 && wave < 4) {
-      for (int i = 0; i < 5; ++i) reinterpret_cast<long long*>(fb_count + 4)[wave * 5 + i] = tm[i];
-    }
-    // kernel-level stamps of wave 0 of 4 blocks: [start, after prologue, after loop, end]
-    const int slot = blockIdx.x == 0 ? 0 : blockIdx.x == 17 ? 1 : blockIdx.x == gridDim.x / 2 ? 2 : blockIdx.x == gridDim.x - 1 ? 3 : -1;
-    if (slot >= 0 && tid == 0) {
-      long long* o = reinterpret_cast<long long*>(fb_count + 4) + 20 + slot * 4;
-      o[0] = k0;
-      o[1] = k1;
-      o[2] = k2;
-      o[3] = __builtin_readcyclecounter();
     }
   }
   if (qrow < Q) {
@@ -846,47 +658,33 @@ int db_norm_impl(t2l_ctx* ctx, hipStream_t s) {
 }
 
 
-template <int L, int VAR>
+template <int L>
 static void launch_scan(t2l_ctx* ctx, dim3 grid, size_t lds, hipStream_t s, const float* db, int n_rows, int n_tiles,
                         int per, int code_bits, const float* q, int Q, int nsplit, int zero) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel<L, VAR>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((scan_kernel<L, VAR>), grid, dim3(256), lds, s, db, n_rows, n_tiles, per, code_bits, q, Q, nsplit,
+  hipLaunchKernelGGL((scan_kernel<L>), grid, dim3(256), lds, s, db, n_rows, n_tiles, per, code_bits, q, Q, nsplit,
                      ctx->cand_score, ctx->fb_count, zero);
 }
 
 static size_t scan_lds_bytes() { return (size_t)2 * kTileFloats * sizeof(float); }
 
-template <int L, int WPS, int VAR, int NW = 4>
+template <int L>
 static void launch_scan3(t2l_ctx* ctx, dim3 grid, hipStream_t s, const uint4* dbs, int n_rows, int n_tiles, int per,
                          int code_bits, const float* q, int Q, int nsplit, int zero) {
   const size_t lds = scan_lds_bytes();
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan3_kernel<L, WPS, VAR, NW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan3_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((scan3_kernel<L, WPS, VAR, NW>), grid, dim3(NW * 64), lds, s, dbs, n_rows, n_tiles, per, code_bits, q, Q,
+  hipLaunchKernelGGL((scan3_kernel<L>), grid, dim3(kScanWaves * 64), lds, s, dbs, n_rows, n_tiles, per, code_bits, q, Q,
                      nsplit, ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
-}
-
-template <int L, int VAR>
-static void launch_scan2(t2l_ctx* ctx, dim3 grid, hipStream_t s, const uint4* dbs, int n_rows, int n_tiles, int per,
-                         int code_bits, const float* q, int Q, int nsplit, int zero) {
-  const size_t lds = (size_t)(2 * kTileFloats + 4 * 2 * kSlabFloats) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan2_kernel<L, VAR>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((scan2_kernel<L, VAR>), grid, dim3(512), lds, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit,
-                     ctx->cand_score, ctx->fb_count, zero);
 }
 
 template <int L>
@@ -894,51 +692,14 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, int n_
                          int Q, int K, int nsplit, int per, int code_bits, int32_t* out_idx, double* out_score,
                          bool first, hipStream_t s) {
   const int n_tiles = (n_rows + kTileRows - 1) / kTileRows;
-  const int qpb = ctx->search_mode == 4 ? 2 * kQPerBlock : kQPerBlock;  // queries per workgroup
-  const int n_qblocks = (Q + qpb - 1) / qpb;
+  const int n_qblocks = (Q + kQPerBlock - 1) / kQPerBlock;
   const int parts = 2 * nsplit;
-  const size_t lds = scan_lds_bytes();
   event_begin(ctx, "search_scan", s);
   const dim3 grid(n_qblocks * nsplit);
-  if (ctx->search_mode == 4) {  // 8 waves x 32 queries share each LDS tile: half the LDS-DMA bytes per MFMA
-    launch_scan3<L, 2, 0, 8>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first);
-  } else if (ctx->search_mode == 0) {
-    launch_scan3<L, 2, 0>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first);
-  } else if (ctx->search_mode == 3) {
-    switch (ctx->scan_variant) {
-      case 1: launch_scan3<L, 1, 1>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 2: launch_scan3<L, 1, 2>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 3: launch_scan3<L, 1, 3>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 4: launch_scan3<L, 1, 4>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 5: launch_scan3<L, 1, 5>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 6: launch_scan3<L, 1, 6>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 7: launch_scan3<L, 1, 7>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 16: launch_scan3<L, 1, 16>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 17: launch_scan3<L, 2, 16>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 64: launch_scan3<L, 1, 64>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 65: launch_scan3<L, 2, 64>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 71: launch_scan3<L, 1, 71>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 67: launch_scan3<L, 1, 67>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 80: launch_scan3<L, 1, 80>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      default: launch_scan3<L, 1, 0>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-    }
-  } else if (ctx->search_mode == 2) {
-    switch (ctx->scan_variant) {  // 0 = product; others = timing-only ablations (wrong results by construction)
-      case 1: launch_scan2<L, 1>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 2: launch_scan2<L, 2>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 3: launch_scan2<L, 3>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 4: launch_scan2<L, 4>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 7: launch_scan2<L, 7>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      case 8: launch_scan2<L, 8>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-      default: launch_scan2<L, 0>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-    }
-  } else
-  switch (ctx->scan_variant) {  // 0 = product; 1..3 = timing-only ablations (wrong results by construction)
-    case 1: launch_scan<L, 1>(ctx, grid, lds, s, db, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-    case 2: launch_scan<L, 2>(ctx, grid, lds, s, db, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-    case 3: launch_scan<L, 3>(ctx, grid, lds, s, db, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-    default: launch_scan<L, 0>(ctx, grid, lds, s, db, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first); break;
-  }
+  if (ctx->search_mode == 0)  // split-bf16 MFMA scan (default)
+    launch_scan3<L>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first);
+  else  // exact-f32 MFMA scan
+    launch_scan<L>(ctx, grid, scan_lds_bytes(), s, db, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first);
   event_end(ctx, "search_scan", s);
   T2L_HIP(ctx, hipGetLastError());
   // f32 dot-product error bound: gamma_n * |a||b| with n = 256 terms (+ slack for the MFMA's k order)
@@ -968,11 +729,11 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
   // few queries against a large shard: stream the DB once through every CU (search_stream.hip)
   if (Q <= 64 && n_rows >= ctx->stream_min_rows && n_rows > 0 && ctx->search_mode == 0 && ctx->nsplit_override == 0)
     return search_stream_impl(ctx, q, Q, K, out_idx, out_score, s);
-  const int qpb = ctx->search_mode == 4 ? 2 * kQPerBlock : kQPerBlock;
+  const int qpb = kQPerBlock;
   const int n_qblocks = (Q + qpb - 1) / qpb;
   // per-lane list length: K + margin (the margin only has to absorb key-truncation ties; the certificate
-  // catches the rest). list_len option (dev): 12 trades a thinner margin for 22 % less selection work.
-  const int L = (K <= 10) ? ((ctx->list_len == 12 && K <= 10) ? 12 : 16) : 32;
+  // catches the rest). (L = 12 was measured: 9 % less scan time, but second-stage re-scores multiply: slower overall.)
+  const int L = (K <= 10) ? 16 : 32;
   const int n_seg = max(1, (n_rows + kSegmentRows - 1) / kSegmentRows);
   if (n_seg * K > 256)
     return fail(ctx, T2L_EINVAL, "t2l_search: shard too large (more than 256/k segments of 524,288 rows); shard the "
@@ -992,9 +753,8 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     const int n_tiles = (max(rows, 0) + kTileRows - 1) / kTileRows;
     int nsplit = ctx->nsplit_override;
     if (nsplit <= 0) {
-      // f32 scan: 2 workgroups (4 waves) per CU; bf16x3 scan: 1 workgroup (8 waves) per CU. 256 CUs.
-      // Multiples of 8 keep a split on one XCD's L2.
-      nsplit = ((ctx->search_mode >= 2 ? 256 : 512) + n_qblocks - 1) / n_qblocks;  // modes 2-4: 1 WG per CU
+      // 2 workgroups (4 waves) per CU x 256 CUs; multiples of 8 keep a split on one XCD's L2.
+      nsplit = (512 + n_qblocks - 1) / n_qblocks;
       nsplit = ((nsplit + 7) / 8) * 8;
     }
     nsplit = max(1, min(nsplit, kMaxParts / 2));
@@ -1012,12 +772,10 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     const float* db = ctx->db + (size_t)row0 * kD;
     const uint4* dbs = ctx->db_split ? ctx->db_split + (size_t)row0 * 64 : nullptr;
     const int off = (int)ctx->row_offset + row0;
-    rc = (L == 12) ? launch_search<12>(ctx, db, dbs, max(rows, 0), off, q, Q, K, nsplit, per, code_bits, seg_idx,
-                                        seg_score, seg == 0, s)
-       : (L == 16) ? launch_search<16>(ctx, db, dbs, max(rows, 0), off, q, Q, K, nsplit, per, code_bits, seg_idx,
-                                        seg_score, seg == 0, s)
+    rc = (L == 16) ? launch_search<16>(ctx, db, dbs, max(rows, 0), off, q, Q, K, nsplit, per, code_bits, seg_idx,
+                                       seg_score, seg == 0, s)
                    : launch_search<32>(ctx, db, dbs, max(rows, 0), off, q, Q, K, nsplit, per, code_bits, seg_idx,
-                                        seg_score, seg == 0, s);
+                                       seg_score, seg == 0, s);
     if (rc != T2L_OK) return rc;
   }
   if (n_seg > 1) return merge_impl(ctx, ctx->seg_idx, ctx->seg_score, n_seg, Q, K, out_idx, out_score, s);

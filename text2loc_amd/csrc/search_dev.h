@@ -31,7 +31,6 @@ __device__ __forceinline__ float make_key(float v, int mask, int code) {
 
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int kSlabFloats = 16 * 64;  // one tile's scores of one MFMA wave: [r][lane]
 
 __device__ __forceinline__ unsigned bf16_rne_bits(float x) {
   const unsigned u = __float_as_uint(x);
@@ -63,28 +62,14 @@ __device__ __forceinline__ void ins_key_sat(float (&s)[L], float x, float pinf) 
 
 // 48 MFMAs of a tile on ONE accumulator chain, 3 per k-step, with one score of the previous tile inserted per
 // k-step (measured: for the bf16 MFMA a single chain with ~6 interleaved VALU per MFMA beats two alternating
-// chains, which cost 32 more VGPRs and a spill at two waves per SIMD).
-template <int L, int VPM, int VAR, int NW, int S, int S_END>
+// chains, which cost 32 more VGPRs and a spill at two waves per SIMD; issuing the next tile's LDS-DMA rows one per
+// k-step inside this phase instead of in a burst after the barrier was also measured: no net gain).
+template <int L, int VPM, int S, int S_END>
 __device__ __forceinline__ void tile_mfma_bf16_sel(const char* tb, const uint4 (&qh)[16], const uint4 (&ql)[16],
                                                    f32x16& cur, const f32x16& prev, int vmask, int code0, float pinf,
-                                                   float (&ls)[L], uint4 (&ah)[4], uint4 (&al)[4],
-                                                   const uint4* gnext, float* lnext) {
+                                                   float (&ls)[L], uint4 (&ah)[4], uint4 (&al)[4]) {
   if constexpr (S < S_END) {
     if constexpr (S == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // prologue LDS reads first
-    // VAR & 64: the 8 LDS-DMA rows of the NEXT tile are issued one per k-step inside the MFMA phase (each costs ~70
-    // issue cycles; in a burst after the barrier they also delay the first LDS reads by ~800 cycles)
-    if constexpr ((VAR & 64) != 0 && !(VAR & 4) && S < 32 / NW) {
-      // inline asm: the builtin makes hipcc wait vmcnt(0) before every later ds_read (it must assume the DMA's LDS
-      // write aliases it); the data is ordered by this kernel's own vmcnt(0) + barrier at the next tile boundary.
-      const unsigned lds_addr = __builtin_amdgcn_readfirstlane(
-          (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(lnext + S * kRowStrideF));
-      const uint4* g = gnext + S * 64;
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep)
-                   : "v"(g), "s"(lds_addr)
-                   : "memory");
-    }
     const uint4 a_hi = ah[S & 3], a_lo = al[S & 3];
     if constexpr (S + 4 < 16) {
       ah[S & 3] = *reinterpret_cast<const uint4*>(tb + 16 * (S + 4));
@@ -92,20 +77,13 @@ __device__ __forceinline__ void tile_mfma_bf16_sel(const char* tb, const uint4 (
     }
     const bf16x8 vh = __builtin_bit_cast(bf16x8, a_hi), vl = __builtin_bit_cast(bf16x8, a_lo);
     const bf16x8 bh = __builtin_bit_cast(bf16x8, qh[S]), bl = __builtin_bit_cast(bf16x8, ql[S]);
-    if constexpr (VAR & 2) {
-      cur[S] += __builtin_bit_cast(uint4, vh).x * 1e-30f + __builtin_bit_cast(uint4, vl).y * 1e-30f;
-    } else {
-      cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, bh, cur, 0, 0, 0);
-      cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, bl, cur, 0, 0, 0);
-      cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, bh, cur, 0, 0, 0);
-    }
+    cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, bh, cur, 0, 0, 0);
+    cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, bl, cur, 0, 0, 0);
+    cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, bh, cur, 0, 0, 0);
     {  // score S of the previous tile enters the list: 2 + L VALU
       const int code = __builtin_amdgcn_readfirstlane(code0 + S);
       const float key = __int_as_float((__float_as_int(prev[S]) & vmask) | code);
-      if constexpr (VAR & 1)
-        ls[S % L] = __builtin_amdgcn_fmed3f(ls[S % L], key, pinf);
-      else
-        ins_key_sat<L>(ls, key, pinf);
+      ins_key_sat<L>(ls, key, pinf);
     }
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
@@ -113,7 +91,7 @@ __device__ __forceinline__ void tile_mfma_bf16_sel(const char* tb, const uint4 (
       __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
     }
     if constexpr (S + 4 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    tile_mfma_bf16_sel<L, VPM, VAR, NW, S + 1, S_END>(tb, qh, ql, cur, prev, vmask, code0, pinf, ls, ah, al, gnext, lnext);
+    tile_mfma_bf16_sel<L, VPM, S + 1, S_END>(tb, qh, ql, cur, prev, vmask, code0, pinf, ls, ah, al);
   }
 }
 

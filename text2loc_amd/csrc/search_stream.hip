@@ -71,8 +71,7 @@ __global__ __launch_bounds__(256, 1) void scanq_kernel(const uint4* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) cur[r] = 0.f;
     constexpr int VPM = (L + 2 + 2) / 3;
-    tile_mfma_bf16_sel<L, VPM, 0, 4, 0, 16>(tb, qh, ql, cur, prev, vmask, (j - 1) << 4, pinf, ls, ah, al, nullptr,
-                                            nullptr);
+    tile_mfma_bf16_sel<L, VPM, 0, 16>(tb, qh, ql, cur, prev, vmask, (j - 1) << 4, pinf, ls, ah, al);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all LDS reads of this tile are done: the buffer may refill
   };
   int nj = 0;

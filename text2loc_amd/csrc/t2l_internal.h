@@ -58,7 +58,7 @@ struct t2l_ctx {
   // search workspace
   float* cand_score = nullptr;   // candidate keys [Q][2*nsplit][L]
   int32_t* flags = nullptr;      // dev i32[Q]: 1 = first-stage certificate failed -> fallback kernel
-  int32_t* fb_count = nullptr;   // dev i32[2]: [0] exact-scan fallbacks, [1] stage-2 re-scores of the last search
+  int32_t* fb_count = nullptr;   // dev i32[128] (2 used): [0] exact-scan fallbacks, [1] stage-2 re-scores of the last search
   int32_t* seg_idx = nullptr;    // per-segment results when the shard exceeds one scan launch
   double* seg_score = nullptr;
   size_t cand_cap = 0, flag_cap = 0, seg_idx_cap = 0, seg_score_cap = 0;  // bytes
@@ -73,10 +73,8 @@ struct t2l_ctx {
   // options
   double eps_scale = 1.0;
   int nsplit_override = 0;
-  int search_mode = 0;   // 0 = wave-specialised split-bf16 scan (default), 1 = exact-f32 MFMA scan
+  int search_mode = 0;   // 0 = split-bf16 MFMA scan (default), 1 = exact-f32 MFMA scan
   int stream_min_rows = 65536;  // shards at least this large answer batches of <= 64 queries with the streaming scan
-  int list_len = 16;     // dev knob: per-lane top list length for K <= 10 (12 or 16)
-  int scan_variant = 0;  // dev knob: timing-only ablations of the scan kernel
   bool profile_events = false;
   std::unordered_map<std::string, t2l::EventRing> events;
 };
