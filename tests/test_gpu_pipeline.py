@@ -116,3 +116,43 @@ def test_weights_resync_after_parameter_update():
     model.train()  # training mode is served by the engine's batch-statistics forward (tests/test_gpu_train_loop.py)
     c = model.encode_objects(objs, [None] * 3)
     assert c.requires_grad and c.shape == (3, 256)
+
+
+def test_cell_database_build_save_load_search(golden, tmp_path):
+    """f-2: encode once -> file -> HBM; retrieval through the persisted database equals eval_epoch's."""
+    from text2loc_amd.cell_retrieval import CellRetrievalNetwork
+    from text2loc_amd.db import CellDatabase
+
+    g = golden("retrieval_e2e")
+    args = _args(top_k=[int(k) for k in g["top_k"]])
+    cells_np = synth.make_cells(int(g["n_cells"]), seed=int(g["cell_seed"]))
+    objects = make_objects(cells_np, int(g["cell_seed"]))
+    model = CellRetrievalNetwork(synth.KNOWN_CLASS, synth.COLOR_NAMES, args, language_encoder=PresetText(g["text_encodings"]))
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in
+                           synth.make_object_branch_weights(int(g["weight_seed"])).items()}, strict=False)
+    model = model.to("cuda").eval()
+    cells = [StubCell(c, b, g["cell_size"]) for c, b in zip(g["db_cell_ids"], g["cell_bbox_w"])]
+
+    class CellDs:
+        def __len__(self):
+            return len(cells)
+
+        def __getitem__(self, i):
+            return {"cells": cells[i], "cell_ids": cells[i].id, "objects": objects[i], "object_points": None}
+
+    db = CellDatabase.build(model, CellDs(), batch_size=20)
+    assert len(db) == 64 and db.embeddings.shape == (64, 256) and db.bbox_w.shape == (64, 6)
+    assert np.abs(db.embeddings - g["cell_encodings"]).max() < 1e-4
+    path = str(tmp_path / "cells.t2ldb.npz")
+    db.save(path)
+    db2 = CellDatabase.load(path)
+    assert np.array_equal(db2.cell_ids, db.cell_ids) and np.array_equal(db2.embeddings, db.embeddings)
+    assert db2.meta["class_embed"] is True and db2.fine_desc is None
+    from oracle import t2l_oracle as O
+
+    t = torch.from_numpy(g["text_encodings"]).cuda()
+    idx, sc = db2.search(model.engine(), t, 5)
+    ridx, rsc = O.retrieve_topk(db2.embeddings, g["text_encodings"], 5)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), ridx) and np.abs(sc.cpu().numpy() - rsc).max() < 1e-12
+    with pytest.raises(ValueError, match="unique"):
+        CellDatabase(["a", "a"], np.zeros((2, 256), np.float32))
