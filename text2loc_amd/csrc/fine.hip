@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include "t2l_internal.h"
+#include "mfma32.h"
 
 namespace t2l {
 
@@ -26,8 +27,12 @@ struct FLinear {
   const float* wt;  // [K][N] (transposed, BatchNorm folded where one follows)
   const float* b;   // [N]
 };
+struct FPacked {
+  const float4* w;  // half-split MFMA packing of W[N][K] (mfma32.h)
+  const float* b;   // [N]
+};
 struct FDecoder {
-  FLinear sa_in, sa_out, ca_in, ca_out, l1, l2;
+  FPacked sa_in, sa_out, ca_in, ca_out, l1, l2;
   const float *g1, *b1, *g2, *b2, *g3, *b3;
 };
 struct FineParams {
@@ -89,6 +94,17 @@ static int flinear(t2l_ctx* ctx, FineWeights* W, const WMap& m, const std::strin
   if ((rc = fupload(ctx, W, wt, &out->wt))) return rc;
   return fupload(ctx, W, bb, &out->b);
 }
+// Linear [N,K] as stored by torch -> half-split MFMA packing + bias (decoder layers: no BatchNorm)
+static int fpacked(t2l_ctx* ctx, FineWeights* W, const WMap& m, const std::string& wname, const std::string& bname, int K, int N, FPacked* out) {
+  const float *w = fget(m, wname, (int64_t)N * K), *b = fget(m, bname, N);
+  if (!w || !b) return fail(ctx, T2L_EINVAL, "t2l_fine_load_weights: missing or mis-shaped '" + wname + "'");
+  const std::vector<float> packed = pack_half_split(std::vector<float>(w, w + (size_t)N * K), nullptr, N, K, K);
+  const float* d = nullptr;
+  int rc;
+  if ((rc = fupload(ctx, W, packed, &d))) return rc;
+  out->w = reinterpret_cast<const float4*>(d);
+  return fupload(ctx, W, std::vector<float>(b, b + N), &out->b);
+}
 static int fraw(t2l_ctx* ctx, FineWeights* W, const WMap& m, const std::string& k, int64_t n, const float** dst) {
   const float* p = fget(m, k, n);
   if (!p) return fail(ctx, T2L_EINVAL, "t2l_fine_load_weights: missing or mis-shaped '" + k + "'");
@@ -132,24 +148,16 @@ int fine_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_mode
   if (P.use_num && ((rc = flinear(ctx, W, m, oe + "num_encoder.0.0", oe + "num_encoder.0.1", 1, 64, &P.num1)) ||
                     (rc = flinear(ctx, W, m, oe + "num_encoder.1.0", oe + "num_encoder.1.1", 64, kFD, &P.num2)))) return rc;
   if ((rc = flinear(ctx, W, m, oe + "mlp_merge.0.0", oe + "mlp_merge.0.1", P.n_feat * kFD, kFD, &P.merge))) return rc;
-  // nn.MultiheadAttention stores in_proj_weight / in_proj_bias without a sub-module: adapt the names
-  auto inproj = [&](const std::string& p, FLinear* out) -> int {
-    const float *wq = fget(m, p + ".in_proj_weight", 3 * kFD * kFD), *bq = fget(m, p + ".in_proj_bias", 3 * kFD);
-    if (!wq || !bq) return fail(ctx, T2L_EINVAL, "t2l_fine_load_weights: missing or mis-shaped '" + p + ".in_proj_weight'");
-    std::vector<float> wt((size_t)kFD * 3 * kFD);
-    for (int nn = 0; nn < 3 * kFD; ++nn)
-      for (int k = 0; k < kFD; ++k) wt[(size_t)k * 3 * kFD + nn] = wq[(size_t)nn * kFD + k];
-    int r;
-    if ((r = fupload(ctx, W, wt, &out->wt))) return r;
-    return fupload(ctx, W, std::vector<float>(bq, bq + 3 * kFD), &out->b);
-  };
   for (int l = 0; l < P.n_layers; ++l)
     for (int which = 0; which < 2; ++which) {
       const std::string p = std::string(which ? "cross_hints." : "cross_objects.") + std::to_string(l);
       FDecoder& D = which ? P.hint[l] : P.obj[l];
-      if ((rc = inproj(p + ".self_attn", &D.sa_in)) || (rc = flinear(ctx, W, m, p + ".self_attn.out_proj", "", kFD, kFD, &D.sa_out)) ||
-          (rc = inproj(p + ".multihead_attn", &D.ca_in)) || (rc = flinear(ctx, W, m, p + ".multihead_attn.out_proj", "", kFD, kFD, &D.ca_out)) ||
-          (rc = flinear(ctx, W, m, p + ".linear1", "", kFD, 4 * kFD, &D.l1)) || (rc = flinear(ctx, W, m, p + ".linear2", "", 4 * kFD, kFD, &D.l2)) ||
+      if ((rc = fpacked(ctx, W, m, p + ".self_attn.in_proj_weight", p + ".self_attn.in_proj_bias", kFD, 3 * kFD, &D.sa_in)) ||
+          (rc = fpacked(ctx, W, m, p + ".self_attn.out_proj.weight", p + ".self_attn.out_proj.bias", kFD, kFD, &D.sa_out)) ||
+          (rc = fpacked(ctx, W, m, p + ".multihead_attn.in_proj_weight", p + ".multihead_attn.in_proj_bias", kFD, 3 * kFD, &D.ca_in)) ||
+          (rc = fpacked(ctx, W, m, p + ".multihead_attn.out_proj.weight", p + ".multihead_attn.out_proj.bias", kFD, kFD, &D.ca_out)) ||
+          (rc = fpacked(ctx, W, m, p + ".linear1.weight", p + ".linear1.bias", kFD, 4 * kFD, &D.l1)) ||
+          (rc = fpacked(ctx, W, m, p + ".linear2.weight", p + ".linear2.bias", 4 * kFD, kFD, &D.l2)) ||
           (rc = fraw(ctx, W, m, p + ".norm1.weight", kFD, &D.g1)) || (rc = fraw(ctx, W, m, p + ".norm1.bias", kFD, &D.b1)) ||
           (rc = fraw(ctx, W, m, p + ".norm2.weight", kFD, &D.g2)) || (rc = fraw(ctx, W, m, p + ".norm2.bias", kFD, &D.b2)) ||
           (rc = fraw(ctx, W, m, p + ".norm3.weight", kFD, &D.g3)) || (rc = fraw(ctx, W, m, p + ".norm3.bias", kFD, &D.b3)))
@@ -222,19 +230,45 @@ __device__ void f_add_ln(float* x, const float* a, int ld, int T, const float* _
     x[t * ld + lane + 64] = d1 * rstd * g[lane + 64] + b[lane + 64];
   }
 }
-// multi-head attention: q [T][ldq] (cols qc..), k/v [S][ldk] (cols kc.. / vc..), 4 heads x 32 -> o [T][ldo]. prob: [4][16][16] scratch
-__device__ void f_attention(const float* q, int ldq, int qc, const float* kv, int ldk, int kc, int vc, int T, int S, float* prob, float* o, int ldo) {
+// out[32 rows][(nt - nt0)*32 + n] = act(bias[nt*32+n] + sum_k A[row][k] W[nt*32+n][k]) for the column tiles nt0 <= nt < nt1; the four
+// waves take tiles round-robin. A: LDS [32][lda]; W: half-split packing (mfma32.h) streamed from L2 with a prefetch ring.
+template <int K>
+__device__ __forceinline__ void f_mm32(const float* __restrict__ A, int lda, const FPacked L, int nt0, int nt1, float* __restrict__ out, int ldo,
+                                       bool relu) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 31, kh = lane >> 5;
+  for (int nt = nt0 + w; nt < nt1; nt += 4) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    mm32_dot<K / 8>(A + j * lda + kh * (K / 2), L.w + (size_t)nt * (K / 8) * 64 + lane, acc);
+    const float bv = L.b[nt * 32 + j];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = acc[r] + bv;
+      out[((r & 3) + 8 * (r >> 2) + 4 * kh) * ldo + (nt - nt0) * 32 + j] = relu ? fmaxf(v, 0.f) : v;
+    }
+  }
+}
+
+// multi-head attention for the kPairs pairs of a workgroup: queries of pair p are rows qbase*p + i (i < T) of q (cols qc..),
+// keys / values rows kbase*p + j (j < S) of kv (cols kc.. / vc..); 4 heads x 32. prob: [kPairs][4][16][16] scratch.
+constexpr int kPairs = 2;
+__device__ void f_attention(const float* q, int ldq, int qc, int qbase, const float* kv, int ldk, int kc, int vc, int kbase, int T, int S,
+                            float* prob, float* o, int ldo) {
   const float scale = 0.17677669529663687f;  // 1/sqrt(32)
-  for (int e = threadIdx.x; e < kFHeads * T * S; e += 256) {
-    const int h = e / (T * S), r = e % (T * S), i = r / S, j = r % S;
+  for (int e = threadIdx.x; e < kPairs * kFHeads * T * S; e += 256) {
+    const int p = e / (kFHeads * T * S), r0 = e % (kFHeads * T * S), h = r0 / (T * S), r = r0 % (T * S), i = r / S, j = r % S;
+    const float* qr = q + (qbase * p + i) * ldq + qc + h * kFHd;
+    const float* kr = kv + (kbase * p + j) * ldk + kc + h * kFHd;
     float s = 0.f;
 #pragma unroll 8
-    for (int d = 0; d < kFHd; ++d) s += q[i * ldq + qc + h * kFHd + d] * kv[j * ldk + kc + h * kFHd + d];
-    prob[(h * 16 + i) * 16 + j] = s * scale;
+    for (int d = 0; d < kFHd; ++d) s += qr[d] * kr[d];
+    prob[((p * kFHeads + h) * 16 + i) * 16 + j] = s * scale;
   }
   __syncthreads();
-  if (threadIdx.x < kFHeads * T) {
-    float* row = prob + ((threadIdx.x / T) * 16 + (threadIdx.x % T)) * 16;
+  if (threadIdx.x < kPairs * kFHeads * T) {
+    const int p = threadIdx.x / (kFHeads * T), r = threadIdx.x % (kFHeads * T);
+    float* row = prob + ((p * kFHeads + r / T) * 16 + (r % T)) * 16;
     float mx = row[0];
     for (int j = 1; j < S; ++j) mx = fmaxf(mx, row[j]);
     float sum = 0.f;
@@ -242,79 +276,42 @@ __device__ void f_attention(const float* q, int ldq, int qc, const float* kv, in
     for (int j = 0; j < S; ++j) row[j] /= sum;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < T * kFD; e += 256) {
-    const int i = e / kFD, c = e % kFD, h = c / kFHd;
+  for (int e = threadIdx.x; e < kPairs * T * kFD; e += 256) {
+    const int p = e / (T * kFD), r = e % (T * kFD), i = r / kFD, c = r % kFD, h = c / kFHd;
+    const float* pr = prob + ((p * kFHeads + h) * 16 + i) * 16;
     float s = 0.f;
-    for (int j = 0; j < S; ++j) s += prob[(h * 16 + i) * 16 + j] * kv[j * ldk + vc + c];
-    o[i * ldo + c] = s;
+    for (int j = 0; j < S; ++j) s += pr[j] * kv[(kbase * p + j) * ldk + vc + c];
+    o[(qbase * p + i) * ldo + c] = s;
   }
   __syncthreads();
 }
 
-// nn.TransformerDecoderLayer (post-norm, ReLU, eval, no masks): x [T] (LDS, stride kFS) attends itself, then mem [S].
-// big: [16][516] floats, holds q|k|v (stride 388) during the attentions and the feed-forward hidden (stride 516) afterwards;
-// att / tmp: [16][kFS] temporaries.
-__device__ void f_decoder(float* x, int T, const float* mem, int S, const FDecoder D, float* big, float* att, float* prob, float* tmp) {
-  float* qkv = big;
-  float* hid = tmp;
-  const int T8 = (T + 7) / 8;
-  f_linear(x, kFS, T8, D.sa_in, kFD, 3 * kFD, qkv, 388, 0, false);
+// nn.TransformerDecoderLayer (post-norm, ReLU, eval, no masks) for kPairs pairs at once. x: 32-row token buffer (LDS, stride
+// kFS) whose pair p occupies rows xbase*p .. +T-1 (the other rows ride along: every step is row-wise or reads only the valid
+// rows); mem: the other side's buffer (rows mbase*p .. +S-1). big [32][516]: q|k|v (stride 388), later the feed-forward hidden
+// (stride 516); att, tmp: [32][kFS].
+__device__ void f_decoder(float* x, int xbase, int T, int xrows, const float* mem, int mbase, int S, const FDecoder D, float* big, float* att,
+                          float* prob, float* tmp) {
+  f_mm32<kFD>(x, kFS, D.sa_in, 0, 12, big, 388, false);
   __syncthreads();
-  f_attention(qkv, 388, 0, qkv, 388, kFD, 2 * kFD, T, T, prob, att, kFS);
-  f_linear(att, kFS, T8, D.sa_out, kFD, kFD, hid, kFS, 0, false);
+  f_attention(big, 388, 0, xbase, big, 388, kFD, 2 * kFD, xbase, T, T, prob, att, kFS);
+  f_mm32<kFD>(att, kFS, D.sa_out, 0, 4, tmp, kFS, false);
   __syncthreads();
-  f_add_ln(x, hid, kFS, T, D.g1, D.b1);
+  f_add_ln(x, tmp, kFS, xrows, D.g1, D.b1);
   __syncthreads();
-  // cross attention: q from x (first 128 columns of in_proj), k/v from mem (columns 128..383)
-  FLinear qproj{D.ca_in.wt, D.ca_in.b};
-  {  // q = x Wq: the [K][3D] transposed layout makes the first D output columns the query projection
-    for (int item = threadIdx.x; item < kFD * T8; item += 256) {
-      const int n = item % kFD, tg = item / kFD;
-      float acc[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = qproj.b[n];
-      for (int k = 0; k < kFD; k += 4) {
-        const float w0 = qproj.wt[(size_t)(k + 0) * 3 * kFD + n], w1 = qproj.wt[(size_t)(k + 1) * 3 * kFD + n],
-                    w2 = qproj.wt[(size_t)(k + 2) * 3 * kFD + n], w3 = qproj.wt[(size_t)(k + 3) * 3 * kFD + n];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float4 v = *reinterpret_cast<const float4*>(x + (tg * 8 + j) * kFS + k);
-          acc[j] += v.x * w0 + v.y * w1 + v.z * w2 + v.w * w3;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) att[(tg * 8 + j) * kFS + n] = acc[j];
-    }
-    const int S8 = (S + 7) / 8;
-    for (int item = threadIdx.x; item < 2 * kFD * S8; item += 256) {
-      const int n = item % (2 * kFD), tg = item / (2 * kFD);
-      float acc[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = qproj.b[kFD + n];
-      for (int k = 0; k < kFD; k += 4) {
-        const float w0 = qproj.wt[(size_t)(k + 0) * 3 * kFD + kFD + n], w1 = qproj.wt[(size_t)(k + 1) * 3 * kFD + kFD + n],
-                    w2 = qproj.wt[(size_t)(k + 2) * 3 * kFD + kFD + n], w3 = qproj.wt[(size_t)(k + 3) * 3 * kFD + kFD + n];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float4 v = *reinterpret_cast<const float4*>(mem + (tg * 8 + j) * kFS + k);
-          acc[j] += v.x * w0 + v.y * w1 + v.z * w2 + v.w * w3;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) qkv[(tg * 8 + j) * 388 + n] = acc[j];
-    }
-  }
+  f_mm32<kFD>(x, kFS, D.ca_in, 0, 4, att, kFS, false);      // q  = x   Wq   (in_proj rows 0..127)
+  f_mm32<kFD>(mem, kFS, D.ca_in, 4, 12, big, 388, false);   // k|v = mem Wkv  (in_proj rows 128..383) -> big cols 0..255
   __syncthreads();
-  f_attention(att, kFS, 0, qkv, 388, 0, kFD, T, S, prob, hid, kFS);
-  f_linear(hid, kFS, T8, D.ca_out, kFD, kFD, att, kFS, 0, false);
+  f_attention(att, kFS, 0, xbase, big, 388, 0, kFD, mbase, T, S, prob, tmp, kFS);
+  f_mm32<kFD>(tmp, kFS, D.ca_out, 0, 4, att, kFS, false);
   __syncthreads();
-  f_add_ln(x, att, kFS, T, D.g2, D.b2);
+  f_add_ln(x, att, kFS, xrows, D.g2, D.b2);
   __syncthreads();
-  f_linear(x, kFS, T8, D.l1, kFD, 4 * kFD, big, 516, 0, true);
+  f_mm32<kFD>(x, kFS, D.l1, 0, 16, big, 516, true);
   __syncthreads();
-  f_linear(big, 516, T8, D.l2, 4 * kFD, kFD, att, kFS, 0, false);
+  f_mm32<4 * kFD>(big, 516, D.l2, 0, 4, att, kFS, false);
   __syncthreads();
-  f_add_ln(x, att, kFS, T, D.g3, D.b3);
+  f_add_ln(x, att, kFS, xrows, D.g3, D.b3);
   __syncthreads();
 }
 
@@ -377,45 +374,58 @@ __global__ __launch_bounds__(256) void fine_objects_kernel(FineParams P, t2l_pac
   for (int i = tid; i < kFObj * kFD; i += 256) out[(size_t)cell * kFObj * kFD + i] = res[(i / kFD) * kFS + (i % kFD)];
 }
 
-// One workgroup per (query, cell) pair.
-__global__ __launch_bounds__(256, 2) void fine_match_kernel(FineParams P, const float* __restrict__ cell_desc, const int32_t* __restrict__ cell_index,
-                                                         const float* __restrict__ hint_desc, const int32_t* __restrict__ hint_index,
-                                                         int n_hints, float* __restrict__ out) {
+// One workgroup per kPairs = 2 (query, cell) pairs: the 2 x 16 object tokens fill one 32-row MFMA tile, the 2 x 6 hint tokens
+// sit at rows 8p..8p+5 of a second one (its other rows are zero / ignored). All token-wise linears run on f32 MFMA tiles
+// (f_mm32); attention (16x6 / 16x16 / 6x6 / 6x16 per head), LayerNorm and the offset head stay on the vector ALU.
+__global__ __launch_bounds__(256, 1) void fine_match_kernel(FineParams P, const float* __restrict__ cell_desc, const int32_t* __restrict__ cell_index,
+                                                            const float* __restrict__ hint_desc, const int32_t* __restrict__ hint_index,
+                                                            int n_pairs, int n_hints, float* __restrict__ out) {
   extern __shared__ float sm[];
-  float* d0 = sm;                          // [16][kFS]
-  float* d1 = d0 + kFObj * kFS;            // [8][kFS]
-  float* big = d1 + kFHintMax * kFS;       // [16][516]: q|k|v during the attentions, feed-forward hidden afterwards
-  float* att = big + kFObj * 516;          // [16][kFS]
-  float* tmp = att + kFObj * kFS;          // [16][kFS]
-  float* prob = tmp + kFObj * kFS;         // [4][16][16]
-  float* pooled = prob + kFHeads * 16 * 16;  // [128]
-  float* h64 = pooled + kFD;               // [64]
-  const int pair = blockIdx.x, tid = threadIdx.x;
-  const float* cd = cell_desc + (size_t)(cell_index ? cell_index[pair] : pair) * kFObj * kFD;
-  const float* hd = hint_desc + (size_t)(hint_index ? hint_index[pair] : pair) * n_hints * kFD;
-  for (int i = tid; i < kFObj * kFD; i += 256) d0[(i / kFD) * kFS + (i % kFD)] = cd[i];
-  for (int i = tid; i < kFHintMax * kFD; i += 256) d1[(i / kFD) * kFS + (i % kFD)] = (i / kFD) < n_hints ? hd[i] : 0.f;
+  float* d0 = sm;                  // [32][kFS] objects: pair p at rows 16p..
+  float* d1 = d0 + 32 * kFS;       // [32][kFS] hints:   pair p at rows 8p..8p+n_hints-1
+  float* big = d1 + 32 * kFS;      // [32][516]
+  float* att = big + 32 * 516;     // [32][kFS]
+  float* tmp = att + 32 * kFS;     // [32][kFS]
+  float* prob = tmp + 32 * kFS;    // [kPairs][4][16][16]
+  float* pooled = prob + kPairs * kFHeads * 256;  // [kPairs][128]
+  float* h64 = pooled + kPairs * kFD;             // [kPairs][64]
+  const int tid = threadIdx.x, pair0 = blockIdx.x * kPairs;
+  for (int i = tid; i < 32 * kFD; i += 256) {
+    const int row = i / kFD, c = i % kFD, p = row >> 4;
+    const int pair = min(pair0 + p, n_pairs - 1);  // an odd tail pair is duplicated (its second copy is not written back)
+    d0[row * kFS + c] = cell_desc[(size_t)(cell_index ? cell_index[pair] : pair) * kFObj * kFD + (row & 15) * kFD + c];
+    const int hp = row >> 3, hr = row & 7;
+    float v = 0.f;
+    if (hp < kPairs && hr < n_hints) {
+      const int hpair = min(pair0 + hp, n_pairs - 1);
+      v = hint_desc[((size_t)(hint_index ? hint_index[hpair] : hpair) * n_hints + hr) * kFD + c];
+    }
+    d1[row * kFS + c] = v;
+  }
   __syncthreads();
   for (int l = 0; l < P.n_layers; ++l) {  // cross_matcher.py:114-118
-    f_decoder(d0, kFObj, d1, n_hints, P.obj[l], big, att, prob, tmp);
-    f_decoder(d1, n_hints, d0, kFObj, P.hint[l], big, att, prob, tmp);
+    f_decoder(d0, 16, kFObj, 32, d1, 8, n_hints, P.obj[l], big, att, prob, tmp);
+    f_decoder(d1, 8, n_hints, 16, d0, 16, kFObj, P.hint[l], big, att, prob, tmp);
   }
-  if (tid < kFD) {  // desc1.max(dim=0) over the hints
-    float m = d1[tid];
-    for (int t = 1; t < n_hints; ++t) m = fmaxf(m, d1[t * kFS + tid]);
-    pooled[tid] = m;
-  }
-  __syncthreads();
-  if (tid < 64) {
-    float s = P.off0.b[tid];
-    for (int k = 0; k < kFD; ++k) s += pooled[k] * P.off0.wt[k * 64 + tid];
-    h64[tid] = fmaxf(s, 0.f);
+  {  // desc1.max(dim=0) over the hints, then mlp_offsets (cross_matcher.py:128-131)
+    const int p = tid >> 7, c = tid & 127;
+    float m = d1[(8 * p) * kFS + c];
+    for (int t = 1; t < n_hints; ++t) m = fmaxf(m, d1[(8 * p + t) * kFS + c]);
+    pooled[p * kFD + c] = m;
   }
   __syncthreads();
-  if (tid < 2) {
-    float s = P.off2.b[tid];
-    for (int k = 0; k < 64; ++k) s += h64[k] * P.off2.wt[k * 2 + tid];
-    out[(size_t)pair * 2 + tid] = s;
+  if (tid < kPairs * 64) {
+    const int p = tid >> 6, n = tid & 63;
+    float s = P.off0.b[n];
+    for (int k = 0; k < kFD; ++k) s += pooled[p * kFD + k] * P.off0.wt[k * 64 + n];
+    h64[p * 64 + n] = fmaxf(s, 0.f);
+  }
+  __syncthreads();
+  if (tid < kPairs * 2) {
+    const int p = tid >> 1, n = tid & 1;
+    float s = P.off2.b[n];
+    for (int k = 0; k < 64; ++k) s += h64[p * 64 + k] * P.off2.wt[k * 2 + n];
+    if (pair0 + p < n_pairs) out[(size_t)(pair0 + p) * 2 + n] = s;
   }
 }
 
@@ -443,14 +453,15 @@ int fine_match_impl(t2l_ctx* ctx, const float* cell_desc, const int32_t* cell_in
   if (!cell_desc || !hint_desc || !out || n_pairs < 0) return fail(ctx, T2L_EINVAL, "t2l_fine_match: null argument");
   if (n_hints < 1 || n_hints > kFHintMax) return fail(ctx, T2L_EINVAL, "t2l_fine_match: 1 <= n_hints <= 8");
   if (n_pairs == 0) return T2L_OK;
-  const size_t lds = sizeof(float) * (kFObj * kFS + kFHintMax * kFS + kFObj * 516 + 2 * kFObj * kFS + kFHeads * 16 * 16 + kFD + 64);  // 67.5 KB: two pairs per CU
+  const size_t lds = sizeof(float) * (4 * 32 * kFS + 32 * 516 + kPairs * kFHeads * 256 + kPairs * kFD + kPairs * 64);  // 143 KB
   static bool attr = false;
   if (!attr) {
     T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fine_match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
   event_begin(ctx, "fine_match", s);
-  hipLaunchKernelGGL(fine_match_kernel, dim3(n_pairs), dim3(256), lds, s, W->p, cell_desc, cell_index, hint_desc, hint_index, n_hints, out);
+  hipLaunchKernelGGL(fine_match_kernel, dim3((n_pairs + kPairs - 1) / kPairs), dim3(256), lds, s, W->p, cell_desc, cell_index, hint_desc, hint_index,
+                     n_pairs, n_hints, out);
   event_end(ctx, "fine_match", s);
   T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;

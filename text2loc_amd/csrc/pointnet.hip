@@ -16,6 +16,7 @@
 
 #include "t2l_internal.h"
 #include "gemm_f32.h"
+#include "mfma32.h"
 
 namespace t2l {
 
@@ -69,22 +70,6 @@ static bool fold_block(const WMap& m, const std::string& prefix, int i, int cin,
   return true;
 }
 
-// [rows/32][kp/8][64 lanes] float4: lane (i, kh) holds Wf[tile*32+i][kh*kp/2 + 4*s4 + 0..3]; Wf = [W | bias column | 0] of width kp
-static std::vector<float> pack_half_split(const std::vector<float>& W, const std::vector<float>* bias, int rows, int cin, int kp) {
-  std::vector<float> out((size_t)rows * kp, 0.f);
-  const int half = kp / 2;
-  for (int t = 0; t < rows / 32; ++t)
-    for (int s4 = 0; s4 < kp / 8; ++s4)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int c = 0; c < 4; ++c) {
-          const int row = t * 32 + (lane & 31), k = (lane >> 5) * half + 4 * s4 + c;
-          float v = 0.f;
-          if (k < cin) v = W[(size_t)row * cin + k];
-          else if (bias && k == cin) v = (*bias)[row];
-          out[(((size_t)t * (kp / 8) + s4) * 64 + lane) * 4 + c] = v;
-        }
-  return out;
-}
 // layer 2 of an SA block, B operand: [h2/32][h1/32][4][64] float4: lane (n, kh): W[nt*32+n][ft*32 + 8*rq + 4*kh + 0..3]
 static std::vector<float> pack_sa_l2(const std::vector<float>& W, int h2, int h1) {
   std::vector<float> out((size_t)h2 * h1);
@@ -366,31 +351,6 @@ __global__ __launch_bounds__(256, 1) void pn_sa_kernel(SaParams P) {
   }
 }
 
-// acc += A[32 x 8*S4] (this lane's row half, LDS, float4 per 4 k-steps) * B (packed weights, global: wp[s4*64], lane folded in),
-// with 4 weight loads in flight (one wave per SIMD: the L2 latency has to be hidden inside the wave)
-template <int S4>
-__device__ __forceinline__ void ga_dot(const float* __restrict__ ar, const float4* __restrict__ wp, f32x16& acc) {
-  float4 b0 = wp[0], b1 = wp[64 * (1 < S4 ? 1 : 0)], b2 = wp[64 * (2 < S4 ? 2 : 0)], b3 = wp[64 * (3 < S4 ? 3 : 0)];
-#define GA_STEP(B, S)                                                                         \
-  {                                                                                           \
-    const float4 a = *reinterpret_cast<const float4*>(ar + 4 * (S));                          \
-    const float4 w = B;                                                                       \
-    if ((S) + 4 < S4) B = wp[64 * ((S) + 4)];                                                 \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc, 0, 0, 0);                       \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc, 0, 0, 0);                       \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc, 0, 0, 0);                       \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);                       \
-  }
-  int s = 0;
-  for (; s + 4 <= S4; s += 4) {
-    GA_STEP(b0, s) GA_STEP(b1, s + 1) GA_STEP(b2, s + 2) GA_STEP(b3, s + 3)
-  }
-  if (s < S4) GA_STEP(b0, s)
-  if (s + 1 < S4) GA_STEP(b1, s + 1)
-  if (s + 2 < S4) GA_STEP(b2, s + 2)
-#undef GA_STEP
-}
-
 // GlobalAbstraction: get_mlp([259,512,1024]) over the 32 points of an object, max. One workgroup per object.
 constexpr int kGaK = 264, kGaXS = kGaK + 4, kGaH1 = 512, kGaHS = kGaH1 + 4, kGaH2 = 1024;
 __global__ __launch_bounds__(256, 1) void pn_ga_kernel(const float* __restrict__ pos3, const float* __restrict__ x3,
@@ -415,7 +375,7 @@ __global__ __launch_bounds__(256, 1) void pn_ga_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* xr = X + j * kGaXS + kh * (kGaK / 2);
-    ga_dot<kGaK / 8>(xr, w1 + (size_t)nt * (kGaK / 8) * 64 + lane, acc);
+    mm32_dot<kGaK / 8>(xr, w1 + (size_t)nt * (kGaK / 8) * 64 + lane, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) Hd[((r & 3) + 8 * (r >> 2) + 4 * kh) * kGaHS + nt * 32 + j] = fmaxf(acc[r], 0.f);
   }
@@ -425,7 +385,7 @@ __global__ __launch_bounds__(256, 1) void pn_ga_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float* hr = Hd + j * kGaHS + kh * (kGaH1 / 2);
-    ga_dot<kGaH1 / 8>(hr, w2 + (size_t)nt * (kGaH1 / 8) * 64 + lane, acc);
+    mm32_dot<kGaH1 / 8>(hr, w2 + (size_t)nt * (kGaH1 / 8) * 64 + lane, acc);
     float m = acc[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
