@@ -203,9 +203,25 @@ __device__ void f_linear(const float* __restrict__ x, int ldx, int T8, const FLi
   }
 }
 
+// all-reduce sum over the 64 lanes on the VALU (DPP + v_permlane swaps): __shfl_xor lowers to ds_bpermute_b32, six dependent
+// LDS round trips per sum, and LayerNorm needs two sums per token row
+template <int CTRL>
+__device__ __forceinline__ float f_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float f_wsum(float v) {
-#pragma unroll
-  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  v += f_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += f_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += f_dpp<0x141>(v);  // row_half_mirror
+  v += f_dpp<0x140>(v);  // row_mirror
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
   return v;
 }
 // rows t < T of x (128 wide): x = normalize(x) (F.normalize, eps 1e-12); one wave per row
@@ -261,8 +277,11 @@ __device__ void f_attention(const float* q, int ldq, int qc, int qbase, const fl
     const float* qr = q + (qbase * p + i) * ldq + qc + h * kFHd;
     const float* kr = kv + (kbase * p + j) * ldk + kc + h * kFHd;
     float s = 0.f;
-#pragma unroll 8
-    for (int d = 0; d < kFHd; ++d) s += qr[d] * kr[d];
+#pragma unroll
+    for (int d = 0; d < kFHd; d += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(qr + d), b = *reinterpret_cast<const float4*>(kr + d);
+      s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
     prob[((p * kFHeads + h) * 16 + i) * 16 + j] = s * scale;
   }
   __syncthreads();
