@@ -69,9 +69,25 @@ struct EncoderWeights {
 };
 
 // ---- device helpers ----------------------------------------------------------------------------
+// all-reduce sum over the 64 lanes on the VALU (DPP + v_permlane swaps): __shfl_xor lowers to ds_bpermute_b32 — six dependent
+// LDS round trips per sum
+template <int CTRL>
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  v += wave_sum_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += wave_sum_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += wave_sum_dpp<0x141>(v);  // row_half_mirror
+  v += wave_sum_dpp<0x140>(v);  // row_mirror
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
   return v;
 }
 
