@@ -267,7 +267,13 @@ def secondary_measurements(eng):
         # executed edge-MLP rows: (128+4)*32, (64+2)*32, (32+1)*32 per object, + global MLP + FC
         fl = 2.0 * (132 * 32 * (8 * 32 + 32 * 64) + 66 * 32 * (72 * 128 + 128 * 128) + 33 * 32 * (136 * 256 + 256 * 256)
                     + 32 * (264 * 512 + 512 * 1024) + 1024 * 512 + 512 * 256)
+        # spot check outside the timed region: the first two cells (their objects only see each other) vs the restatement
+        from oracle import t2l_oracle_pointnet as OP
+        n2 = int(cells_p["offsets"][2])
+        ref2 = OP.pointnet_features(pos_np[:n2], rgb_np[:n2], cells_p["offsets"][:3], sd_pn)
+        pn_err = float(np.abs(f2[:n2].cpu().numpy() - ref2).max())
         out["pointnet"] = {"objects": n_obj, "cells": n_pc, "kernel_ms": ms, "objects_per_s": n_obj / (ms * 1e-3),
+                           "max_abs_err_vs_restatement_on_sample": pn_err, "sample_objects": n2,
                            "tflops_executed": fl * n_obj / (ms * 1e-3) / 1e12, "peak_tflops": F32_MFMA_PEAK_TFLOPS,
                            "frac": fl * n_obj / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, "launches_timed": n,
                            "parity": "self-consistent only (third-party reference arithmetic, unpinned)"}
@@ -313,7 +319,12 @@ def secondary_measurements(eng):
             off = eng_f.fine_match(desc, hints, top_idx.reshape(-1).contiguous(), hi)
         torch.cuda.synchronize()
         pipe = (time.perf_counter() - t0) / 3
-        out["fine_stage"] = {"coarse_plus_fine_ms": pipe * 1e3, "coarse_plus_fine_queries_per_s": N_QUERIES / pipe,"workload": f"{N_CELLS} padded cells x 16 objects -> descriptors; {N_QUERIES} queries x top-{TOPK} = {n_pairs} pairs",
+        from oracle import t2l_oracle_fine as OF
+        sel = np.arange(0, n_pairs, n_pairs // 8)[:8]
+        ci_h, hi_h = top_idx.reshape(-1).cpu().numpy()[sel], hi.cpu().numpy()[sel]
+        ref_off = OF.cross_match(OF.fine_object_encodings(cells16, sd_f, True, True)[ci_h], hints.cpu().numpy()[hi_h], sd_f)
+        fine_err = float(np.abs(off.cpu().numpy()[sel] - ref_off).max())
+        out["fine_stage"] = {"max_abs_err_vs_oracle_on_sample": fine_err, "coarse_plus_fine_ms": pipe * 1e3, "coarse_plus_fine_queries_per_s": N_QUERIES / pipe,"workload": f"{N_CELLS} padded cells x 16 objects -> descriptors; {N_QUERIES} queries x top-{TOPK} = {n_pairs} pairs",
                              "objects_kernel_ms": ms_obj, "match_kernel_ms": ms_m, "pairs_per_s": n_pairs / (ms_m * 1e-3),
                              "queries_per_s": N_QUERIES / (ms_m * 1e-3), "tflops_match": 23.0e6 * n_pairs / (ms_m * 1e-3) / 1e12,
                              "arithmetic": "f32 MFMA token linears (2 pairs per workgroup), VALU attention / LayerNorm"}
