@@ -25,15 +25,9 @@ namespace t2l {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kLdX = kD + 4;        // 260
-constexpr int kLdQ = 3 * kD + 4;    // 772  (qkv / ff / o buffer)
-constexpr int kLdF = 4 * kD + 4;    // 1028 (concatenated features)
+constexpr int kLdX = kD + 4;        // 260: row stride of every 256-wide LDS buffer
 constexpr int kLdH = 64 + 4;        // 68   (hidden layer of the small MLPs)
 constexpr int kXFloats = kSP * kLdX;
-constexpr int kQFloats = kSP * kLdQ;
-constexpr int kHFloats = kSP * kLdH;
-// feats [32][1028] is overlaid on (qkv, x): 32*1028 <= 32*772 + 32*260
-static_assert(kSP * kLdF <= kQFloats + kXFloats, "feature overlay must fit");
 constexpr float kNumMean = 1826.6844940968194f;  // models/object_encoder.py:43
 constexpr float kNumStd = 2516.8905096993817f;   // models/object_encoder.py:44
 
@@ -56,7 +50,7 @@ struct EncParams {
   SmallMlp pos, color, num;
   const float4* pn_wp;     // mlp_pointnet packed (N=256,K=256)
   const float* pn_b;
-  const float4* merge_wp;  // packed (N=256, K=256*nfeat)
+  const float4* merge_wp;  // nfeat consecutive packings (N=256, K=256), one per 256-wide feature slot
   const float* merge_b;
   LayerW layer[4];
   int num_layers;
@@ -133,6 +127,26 @@ __device__ __forceinline__ void gemm32(const float* __restrict__ A, int lda, int
   }
 }
 
+// acc0 += A * W0^T, acc1 += A * W1^T over qn packed k-steps (8 k each): A = this lane's LDS row half (arow), W0 / W1 =
+// packed weight tiles already offset to their first step and to this lane. The caller owns initialisation and epilogue.
+__device__ __forceinline__ void mm_pair(const float* __restrict__ arow, int qn, const float4* __restrict__ w0,
+                                        const float4* __restrict__ w1, f32x16& acc0, f32x16& acc1) {
+#pragma unroll 4
+  for (int q = 0; q < qn; ++q) {
+    const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q);
+    const float4 b0 = w0[q * 64];
+    const float4 b1 = w1[q * 64];
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+  }
+}
+
 // F.normalize over 256 columns of `rows` rows starting at buf (row stride ld); rows >= nvalid are zeroed.
 __device__ __forceinline__ void normalize_rows(float* buf, int ld, int nvalid, int wave, int lane) {
   for (int i = wave; i < kSP; i += 4) {
@@ -178,7 +192,7 @@ __device__ __forceinline__ void layer_norm_rows(float* x, const float* __restric
 // One feature branch through get_mlp([in,64,256]): hidden layer on the VALU (K = 1 or 3), 64->256 on MFMA.
 template <int IN>
 __device__ __forceinline__ void small_mlp(const SmallMlp& m, const float* __restrict__ in /* [nobj][IN] global */,
-                                          bool is_num, int nobj, float* hbuf, float* dst /* feats slot */, int tid,
+                                          bool is_num, int nobj, float* hbuf, float* dst /* [32][kLdX] */, int tid,
                                           int wave, int lane) {
   // hidden: 32 objects x 64 units, 8 per thread
   for (int e = tid; e < kSP * 64; e += 256) {
@@ -199,19 +213,27 @@ __device__ __forceinline__ void small_mlp(const SmallMlp& m, const float* __rest
   __syncthreads();
   const float* b2 = m.b2;
   gemm32(hbuf, kLdH, 64, m.w2p, kD, wave, lane,
-         [&](int, int, int row, int col, float v) { dst[row * kLdF + col] = fmaxf(v + b2[col], 0.f); });
+         [&](int, int, int row, int col, float v) { dst[row * kLdX + col] = fmaxf(v + b2[col], 0.f); });
   __syncthreads();
-  normalize_rows(dst, kLdF, nobj, wave, lane);
+  normalize_rows(dst, kLdX, nobj, wave, lane);
 }
 
-__global__ __launch_bounds__(256, 1) void encode_cells_kernel(EncParams P, t2l_packed_cells in,
+// LDS: x [32][260] + buf [32][260] = 66.6 KB, so TWO cells are in flight per CU (while one workgroup sits in a barrier, a
+// LayerNorm or a softmax, the other one keeps the MFMA pipe busy). What makes that fit:
+//  * the concatenated features never exist: every 256-wide slot is produced in `buf` and immediately contracted with its
+//    256-column slice of the merge weight into register accumulators;
+//  * q, k, v never touch LDS: head h = wave h computes q_h^T and k_h^T TRANSPOSED (A = packed weights, B = the x rows) and
+//    v_h straight (A = x rows, B = packed weights); in those MFMA output layouts k_h^T / q_h^T registers ARE the A / B
+//    operands of S^T = K Q^T and the v_h registers ARE the B operand of P V, so the whole head runs from registers;
+//  * the feed-forward hidden layer goes through `buf` in two halves of 256 units (chosen as the units that one half of the
+//    half-split weight packing covers), the second Linear accumulating over both halves in registers.
+__global__ __launch_bounds__(256, 2) void encode_cells_kernel(EncParams P, t2l_packed_cells in,
                                                               float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* qkv = smem;                 // [32][772]
-  float* x = smem + kQFloats;        // [32][260]
-  float* hbuf = x + kXFloats;        // [32][68]
-  float* red = hbuf + kHFloats;      // [8]
-  float* feats = smem;               // [32][1028] overlay on (qkv, x), only before x exists
+  float* x = smem;                   // [32][260] token buffer; scratch (small-MLP hidden / features2 staging) before it is live
+  float* buf = x + kXFloats;         // [32][260] feature slot -> attention output -> feed-forward hidden half
+  float* red = buf + kXFloats;       // [8]
+  float* hbuf = x;                   // [32][68]  overlay on x (feature phase only)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
@@ -219,10 +241,29 @@ __global__ __launch_bounds__(256, 1) void encode_cells_kernel(EncParams P, t2l_p
   const int obj0 = in.offsets[cell];
   const int nobj = min(in.offsets[cell + 1] - obj0, kS);  // objects beyond 28 are dropped (cell_retrieval.py:94-98)
 
-  // ------------------------------------------------------------------ per-object features
+  // ------------------------------------------------------------------ per-object features, merged slot by slot
+  f32x16 keep0, keep1;  // merge output tiles (wave, wave + 4)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) keep0[r] = keep1[r] = 0.f;
   int slot = 0;
+  auto merge_slot = [&]() {  // buf holds slot `slot` (normalised rows): keep += buf @ Wmerge[:, 256*slot : 256*slot+256]^T
+    __syncthreads();
+    if (P.nfeat > 1) {
+      const float4* wp = P.merge_wp + (size_t)slot * (kD * kD / 4);
+      mm_pair(buf + col * kLdX + half * 128, kD / 8, wp + (size_t)wave * (kD / 8) * 64 + lane,
+              wp + (size_t)(wave + 4) * (kD / 8) * 64 + lane, keep0, keep1);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        keep0[r] = buf[row * kLdX + wave * 32 + col];
+        keep1[r] = buf[row * kLdX + (wave + 4) * 32 + col];
+      }
+    }
+    ++slot;
+    __syncthreads();  // every wave is done reading buf (and the x-region scratch) before the next slot rewrites them
+  };
   if (P.use_class) {
-    float* dst = feats + slot * kD;
     if (P.class_embed) {  // object_encoder.py:103-110 (table rows pre-normalised on the host)
       for (int o = 0; o < kSP; ++o) {
         float v = 0.f;
@@ -230,27 +271,25 @@ __global__ __launch_bounds__(256, 1) void encode_cells_kernel(EncParams P, t2l_p
           const int ci = min(max(in.class_idx[obj0 + o], 0), P.n_class - 1);
           v = P.class_tab[ci * kD + tid];
         }
-        dst[o * kLdF + tid] = v;
+        buf[o * kLdX + tid] = v;
       }
     } else {  // object_encoder.py:86-99,112: features2 -> mlp_pointnet -> normalize
-      float* stage = feats + 3 * kD;  // park features2 in the last feature slot (rewritten later)
+      float* stage = x;  // park features2 in the (not yet live) token buffer
       for (int o = wave; o < kSP; o += 4) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (o < nobj) v = reinterpret_cast<const float4*>(in.pn_feat + (size_t)(obj0 + o) * kD)[lane];
-        reinterpret_cast<float4*>(stage + o * kLdF)[lane] = v;
+        reinterpret_cast<float4*>(stage + o * kLdX)[lane] = v;
       }
       __syncthreads();
       const float* pb = P.pn_b;
-      gemm32(stage, kLdF, kD, P.pn_wp, kD, wave, lane,
-             [&](int, int, int row, int c, float v) { dst[row * kLdF + c] = fmaxf(v + pb[c], 0.f); });
+      gemm32(stage, kLdX, kD, P.pn_wp, kD, wave, lane,
+             [&](int, int, int row, int c, float v) { buf[row * kLdX + c] = fmaxf(v + pb[c], 0.f); });
       __syncthreads();
-      normalize_rows(dst, kLdF, nobj, wave, lane);
+      normalize_rows(buf, kLdX, nobj, wave, lane);
     }
-    ++slot;
-    __syncthreads();
+    merge_slot();
   }
   if (P.use_color) {
-    float* dst = feats + slot * kD;
     if (P.color_embed) {  // object_encoder.py:116-120
       for (int o = 0; o < kSP; ++o) {
         float v = 0.f;
@@ -258,46 +297,30 @@ __global__ __launch_bounds__(256, 1) void encode_cells_kernel(EncParams P, t2l_p
           const int ci = min(max(in.color_idx[obj0 + o], 0), P.n_color - 1);
           v = P.color_tab[ci * kD + tid];
         }
-        dst[o * kLdF + tid] = v;
+        buf[o * kLdX + tid] = v;
       }
     } else {  // object_encoder.py:121-128
-      small_mlp<3>(P.color, in.rgb + (size_t)obj0 * 3, false, nobj, hbuf, dst, tid, wave, lane);
+      small_mlp<3>(P.color, in.rgb + (size_t)obj0 * 3, false, nobj, hbuf, buf, tid, wave, lane);
     }
-    ++slot;
-    __syncthreads();
+    merge_slot();
   }
   if (P.use_pos) {  // object_encoder.py:130-136
-    small_mlp<3>(P.pos, in.center + (size_t)obj0 * 3, false, nobj, hbuf, feats + slot * kD, tid, wave, lane);
-    ++slot;
-    __syncthreads();
+    small_mlp<3>(P.pos, in.center + (size_t)obj0 * 3, false, nobj, hbuf, buf, tid, wave, lane);
+    merge_slot();
   }
   if (P.use_num) {  // object_encoder.py:138-145
-    small_mlp<1>(P.num, in.n_pts + obj0, true, nobj, hbuf, feats + slot * kD, tid, wave, lane);
-    ++slot;
-    __syncthreads();
+    small_mlp<1>(P.num, in.n_pts + obj0, true, nobj, hbuf, buf, tid, wave, lane);
+    merge_slot();
   }
-
-  // ------------------------------------------------------------------ merge (object_encoder.py:148-149) + normalize (cell_retrieval.py:92)
+  // merge epilogue (object_encoder.py:148-149: Linear+BN folded, ReLU) + normalize (cell_retrieval.py:92)
   {
-    float keep[2][16];
-    if (P.nfeat > 1) {
-      const float* mb = P.merge_b;
-      gemm32(feats, kLdF, P.nfeat * kD, P.merge_wp, kD, wave, lane,
-             [&](int t, int r, int, int c, float v) { keep[t][r] = fmaxf(v + mb[c], 0.f); });
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        keep[0][r] = feats[row * kLdF + wave * 32 + col];
-        keep[1][r] = feats[row * kLdF + (wave + 4) * 32 + col];
-      }
-    }
-    __syncthreads();  // every wave is done reading feats; x may now be written over its tail
+    const float* mb = P.merge_b;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      x[row * kLdX + wave * 32 + col] = keep[0][r];
-      x[row * kLdX + (wave + 4) * 32 + col] = keep[1][r];
+      const int c0 = wave * 32 + col, c1 = (wave + 4) * 32 + col;
+      x[row * kLdX + c0] = P.nfeat > 1 ? fmaxf(keep0[r] + mb[c0], 0.f) : keep0[r];
+      x[row * kLdX + c1] = P.nfeat > 1 ? fmaxf(keep1[r] + mb[c1], 0.f) : keep1[r];
     }
   }
   __syncthreads();
@@ -307,28 +330,56 @@ __global__ __launch_bounds__(256, 1) void encode_cells_kernel(EncParams P, t2l_p
   // ------------------------------------------------------------------ set transformer (cell_retrieval.py:101-103)
   for (int l = 0; l < P.num_layers; ++l) {
     const LayerW& W = P.layer[l];
-    {  // qkv = x @ in_proj^T + b
-      const float* b = W.in_b;
-      gemm32(x, kLdX, kD, W.in_wp, 3 * kD, wave, lane,
-             [&](int, int, int row, int c, float v) { qkv[row * kLdQ + c] = v + b[c]; });
-    }
-    __syncthreads();
-    {  // head h = wave: S^T[j][i] = k_j . q_i ; softmax over keys j in-lane ; o = P v
+    {  // head h = wave, registers only
       const int h = wave;
-      const float* kr = qkv + col * kLdQ + kD + h * 64 + half * 32;
-      const float* qr = qkv + col * kLdQ + h * 64 + half * 32;
+      constexpr int QN = kD / 8;  // 32 packed k-steps
+      const float* xr = x + col * kLdX + half * 128;
+      const float4* wq0 = W.in_wp + (size_t)(2 * h) * QN * 64 + lane;
+      const float4* wq1 = W.in_wp + (size_t)(2 * h + 1) * QN * 64 + lane;
+      const float4* wk0 = W.in_wp + (size_t)(8 + 2 * h) * QN * 64 + lane;
+      const float4* wk1 = W.in_wp + (size_t)(9 + 2 * h) * QN * 64 + lane;
+      const float4* wv0 = W.in_wp + (size_t)(16 + 2 * h) * QN * 64 + lane;
+      const float4* wv1 = W.in_wp + (size_t)(17 + 2 * h) * QN * 64 + lane;
+      f32x16 qT0, qT1, kT0, kT1, v0, v1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) qT0[r] = qT1[r] = kT0[r] = kT1[r] = v0[r] = v1[r] = 0.f;
+#pragma unroll 2
+      for (int q = 0; q < QN; ++q) {
+        const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * q);
+        const float4 a0 = wq0[q * 64], a1 = wq1[q * 64], c0 = wk0[q * 64], c1 = wk1[q * 64], e0 = wv0[q * 64], e1 = wv1[q * 64];
+#define T2L_QKV(C)                                                            \
+  qT0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.C, xv.C, qT0, 0, 0, 0);       \
+  qT1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.C, xv.C, qT1, 0, 0, 0);       \
+  kT0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c0.C, xv.C, kT0, 0, 0, 0);       \
+  kT1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1.C, xv.C, kT1, 0, 0, 0);       \
+  v0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.C, e0.C, v0, 0, 0, 0);         \
+  v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.C, e1.C, v1, 0, 0, 0);
+        T2L_QKV(x) T2L_QKV(y) T2L_QKV(z) T2L_QKV(w)
+#undef T2L_QKV
+      }
+      {  // in_proj bias: q^T / k^T rows are features (register index), v columns are features (lane)
+        const float* ib = W.in_b;
+        const float bv0 = ib[2 * kD + h * 64 + col], bv1 = ib[2 * kD + h * 64 + 32 + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
+          qT0[r] += ib[h * 64 + f];
+          qT1[r] += ib[h * 64 + 32 + f];
+          kT0[r] += ib[kD + h * 64 + f];
+          kT1[r] += ib[kD + h * 64 + 32 + f];
+          v0[r] += bv0;
+          v1[r] += bv1;
+        }
+      }
+      // S^T[j][i] = k_j . q_i: k_h^T (token j = lane col, feature pair (f, f+4) = the two lane halves) is the A operand,
+      // q_h^T the B operand, one MFMA per register
       f32x16 st;
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float4 a = *reinterpret_cast<const float4*>(kr + 4 * q);
-        const float4 b = *reinterpret_cast<const float4*>(qr + 4 * q);
-        st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, st, 0, 0, 0);
-        st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, st, 0, 0, 0);
-        st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, st, 0, 0, 0);
-        st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, st, 0, 0, 0);
-      }
+      for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kT0[r], qT0[r], st, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kT1[r], qT1[r], st, 0, 0, 0);
       // lane: query i = col, keys j = (r&3) + 8*(r>>2) + 4*half ; keys >= 28 are the dead rows
       float m = -__builtin_inff();
 #pragma unroll
@@ -346,48 +397,67 @@ __global__ __launch_bounds__(256, 1) void encode_cells_kernel(EncParams P, t2l_p
       }
       sum += __shfl_xor(sum, 32);
       const float inv = 1.f / sum;
-      // o[i][n] = sum_j P[i][j] v[j][n]: MFMA step r pairs keys jA(r) (half 0) and jA(r)+4 (half 1)
+      // o[i][n] = sum_j P[i][j] v[j][n]: P (lane = query i, register = key j) is the A operand, v_h registers (lane = column n,
+      // register = key j) the B operand
       f32x16 o0, o1;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        o0[r] = 0.f;
-        o1[r] = 0.f;
-      }
-      const float* vb = qkv + 2 * kD + h * 64 + col;
+      for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
         const float p = st[r] * inv;
-        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p, vb[j * kLdQ], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p, vb[j * kLdQ + 32], o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p, v0[r], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p, v1[r], o1, 0, 0, 0);
       }
-      // o_h overwrites this head's own q columns (q_h is dead once S is formed)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-        qkv[i * kLdQ + h * 64 + col] = o0[r];
-        qkv[i * kLdQ + h * 64 + 32 + col] = o1[r];
+        buf[i * kLdX + h * 64 + col] = o0[r];
+        buf[i * kLdX + h * 64 + 32 + col] = o1[r];
       }
     }
     __syncthreads();
     {  // x = LN1(x + o @ out_proj^T + b)
       const float* b = W.out_b;
-      gemm32(qkv, kLdQ, kD, W.out_wp, kD, wave, lane,
+      gemm32(buf, kLdX, kD, W.out_wp, kD, wave, lane,
              [&](int, int, int row, int c, float v) { x[row * kLdX + c] += v + b[c]; });
     }
     __syncthreads();
     layer_norm_rows(x, W.ln1_w, W.ln1_b, wave, lane);
     __syncthreads();
-    {  // ff = relu(x @ W1^T + b1)  -> qkv buffer
-      const float* b = W.ff1_b;
-      gemm32(x, kLdX, kD, W.ff1_wp, 2 * kD, wave, lane,
-             [&](int, int, int row, int c, float v) { qkv[row * kLdQ + c] = fmaxf(v + b[c], 0.f); });
-    }
-    __syncthreads();
-    {  // x = LN2(x + ff @ W2^T + b2)
-      const float* b = W.ff2_b;
-      gemm32(qkv, kLdQ, 2 * kD, W.ff2_wp, kD, wave, lane,
-             [&](int, int, int row, int c, float v) { x[row * kLdX + c] += v + b[c]; });
+    {  // x = LN2(x + relu(x W1^T + b1) W2^T + b2), hidden units in two halves through buf
+      f32x16 acc0, acc1;  // output tiles (wave, wave + 4)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+      const float* b1 = W.ff1_b;
+      for (int hf = 0; hf < 2; ++hf) {
+        // half hf = hidden units [128 hf, 128 hf + 128) and [256 + 128 hf, 256 + 128 hf + 128): exactly what k-steps
+        // [32 hf, 32 hf + 32) of the half-split packing of W2 (K = 512) cover
+        const int tA = 4 * hf + wave, tB = 8 + 4 * hf + wave;
+        f32x16 h0, h1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h0[r] = h1[r] = 0.f;
+        mm_pair(x + col * kLdX + half * 128, kD / 8, W.ff1_wp + (size_t)tA * (kD / 8) * 64 + lane,
+                W.ff1_wp + (size_t)tB * (kD / 8) * 64 + lane, h0, h1);
+        if (hf) __syncthreads();  // every wave has consumed the first half from buf
+        const float bA = b1[tA * 32 + col], bB = b1[tB * 32 + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          buf[row * kLdX + 32 * wave + col] = fmaxf(h0[r] + bA, 0.f);
+          buf[row * kLdX + 128 + 32 * wave + col] = fmaxf(h1[r] + bB, 0.f);
+        }
+        __syncthreads();
+        mm_pair(buf + col * kLdX + half * 128, kD / 8, W.ff2_wp + ((size_t)wave * (2 * kD / 8) + 32 * hf) * 64 + lane,
+                W.ff2_wp + ((size_t)(wave + 4) * (2 * kD / 8) + 32 * hf) * 64 + lane, acc0, acc1);
+      }
+      const float* b2 = W.ff2_b;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int c0 = wave * 32 + col, c1 = (wave + 4) * 32 + col;
+        x[row * kLdX + c0] += acc0[r] + b2[c0];
+        x[row * kLdX + c1] += acc1[r] + b2[c1];
+      }
     }
     __syncthreads();
     layer_norm_rows(x, W.ln2_w, W.ln2_b, wave, lane);
@@ -548,7 +618,17 @@ int load_weights_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_m
   if (nfeat > 1) {
     std::vector<float> W, b;
     if (!fold(ctx, m, oe + "mlp_merge.0.0", oe + "mlp_merge.0.1", kD, nfeat * kD, &W, &b, &rc)) return rc;
-    merge_wp = blob.add(pack(W, kD, nfeat * kD));
+    {  // one (N=256, K=256) packing per feature slot, consecutive
+      std::vector<float> all;
+      for (int sl = 0; sl < nfeat; ++sl) {
+        std::vector<float> Ws((size_t)kD * kD);
+        for (int n = 0; n < kD; ++n)
+          for (int k = 0; k < kD; ++k) Ws[(size_t)n * kD + k] = W[(size_t)n * nfeat * kD + sl * kD + k];
+        const std::vector<float> ps = pack(Ws, kD, kD);
+        all.insert(all.end(), ps.begin(), ps.end());
+      }
+      merge_wp = blob.add(all);
+    }
     merge_b = blob.add(b);
   }
   struct LOff {
@@ -629,7 +709,7 @@ int encode_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float* out, hipStream_
   if ((P.use_class && P.class_embed && !in->class_idx) || (P.use_color && P.color_embed && !in->color_idx) ||
       (P.use_color && !P.color_embed && !in->rgb) || (P.use_pos && !in->center) || (P.use_num && !in->n_pts))
     return fail(ctx, T2L_EINVAL, "t2l_encode_cells: a per-object input required by the loaded config is NULL");
-  const size_t lds = (size_t)(kQFloats + kXFloats + kHFloats + 8) * sizeof(float);
+  const size_t lds = (size_t)(2 * kXFloats + 8) * sizeof(float);  // 66.6 KB: two cells per CU
   static bool attr_done = false;
   if (!attr_done) {
     T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_cells_kernel),
