@@ -6,9 +6,9 @@
 // The reference runs one Python-level forward per query over its top-k cells (evaluation/pipeline.py:113-116) and
 // re-encodes the same cells for every query that retrieved them; here the per-cell object descriptors are computed
 // once per database cell and the pairs are ONE launch (one workgroup per pair, everything LDS-resident).
-// First version: f32 VALU contractions (tokens per pair: 16 objects / 6 hints, d = 128 — 23 MFLOP per pair, the
-// problem is tiny and latency-bound); BatchNorm folded on the host, weights stored transposed [K][N] so that the
-// threads of a wave read consecutive output columns.
+// The match kernel runs every token-wise Linear on f32 MFMA tiles and each attention block from registers (see
+// f_attention_regs); the per-cell object encoder (1.1 ms for the whole database, once) contracts on the vector ALU with
+// weights stored transposed [K][N]. BatchNorm is folded on the host.
 #include <math.h>
 #include <string.h>
 
@@ -234,11 +234,13 @@ __device__ void f_normalize_rows(float* x, int ld, int T, int width = kFD) {
     for (int c = lane; c < width; c += 64) x[t * ld + c] /= n;
   }
 }
-// x[t] = LayerNorm(x[t] + a[t]) * g + b  for t < T
-__device__ void f_add_ln(float* x, const float* a, int ld, int T, const float* __restrict__ g, const float* __restrict__ b) {
+constexpr int kPairs = 2;  // pairs per workgroup: their 2 x 16 object tokens fill one 32-row MFMA tile
+
+// x[t] = LayerNorm(x[t]) * g + b for t < T (in place; one wave per row)
+__device__ void f_ln_rows(float* x, int ld, int T, const float* __restrict__ g, const float* __restrict__ b) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int t = w; t < T; t += 4) {
-    const float v0 = x[t * ld + lane] + a[t * ld + lane], v1 = x[t * ld + lane + 64] + a[t * ld + lane + 64];
+    const float v0 = x[t * ld + lane], v1 = x[t * ld + lane + 64];
     const float mu = f_wsum(v0 + v1) * (1.f / kFD);
     const float d0 = v0 - mu, d1 = v1 - mu;
     const float rstd = 1.0f / sqrtf(f_wsum(d0 * d0 + d1 * d1) * (1.f / kFD) + 1e-5f);
@@ -246,91 +248,139 @@ __device__ void f_add_ln(float* x, const float* a, int ld, int T, const float* _
     x[t * ld + lane + 64] = d1 * rstd * g[lane + 64] + b[lane + 64];
   }
 }
-// out[32 rows][(nt - nt0)*32 + n] = act(bias[nt*32+n] + sum_k A[row][k] W[nt*32+n][k]) for the column tiles nt0 <= nt < nt1; the four
-// waves take tiles round-robin. A: LDS [32][lda]; W: half-split packing (mfma32.h) streamed from L2 with a prefetch ring.
-template <int K>
-__device__ __forceinline__ void f_mm32(const float* __restrict__ A, int lda, const FPacked L, int nt0, int nt1, float* __restrict__ out, int ldo,
-                                       bool relu) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 31, kh = lane >> 5;
-  for (int nt = nt0 + w; nt < nt1; nt += 4) {
+
+// Which rows of a 32-row token tile belong together: pair p owns rows (p << shift) .. + count - 1 of the first `rows` rows.
+struct TileGroups {
+  int shift, count, rows;
+};
+
+// One attention block of nn.TransformerDecoderLayer for the kPairs pairs of the tile, head h = wave, REGISTERS ONLY:
+// q_h^T (from the x tile) and k_h^T (from the mem tile) are computed transposed (A = packed in_proj rows, B = token rows),
+// v_h straight (A = mem token rows, B = packed rows); in those MFMA output layouts k_h^T / q_h^T are the A / B operands of
+// S^T = K Q^T and v_h is the B operand of P V (the trick of encode.hip). Keys of another pair (or padding rows) are masked.
+// Writes o_h (32 rows x 32 columns) into obuf[:, 32 h ..]. x == mem for self-attention.
+__device__ __forceinline__ void f_attention_regs(const float* __restrict__ x, TileGroups gx, const float* __restrict__ mem, TileGroups gm,
+                                                 const FPacked in_proj, float* __restrict__ obuf) {
+  const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
+  constexpr int QN = kFD / 8;  // 16 packed k-steps
+  const float* xr = x + col * kFS + half * (kFD / 2);
+  const float* mr = mem + col * kFS + half * (kFD / 2);
+  const float4* wq = in_proj.w + (size_t)h * QN * 64 + lane;
+  const float4* wk = in_proj.w + (size_t)(4 + h) * QN * 64 + lane;
+  const float4* wv = in_proj.w + (size_t)(8 + h) * QN * 64 + lane;
+  f32x16 qT, kT, v;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) qT[r] = kT[r] = v[r] = 0.f;
+#pragma unroll 4
+  for (int q = 0; q < QN; ++q) {
+    const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * q);
+    const float4 mv = *reinterpret_cast<const float4*>(mr + 4 * q);
+    const float4 a = wq[q * 64], c = wk[q * 64], e = wv[q * 64];
+#define T2L_F_QKV(C)                                                        \
+  qT = __builtin_amdgcn_mfma_f32_32x32x2f32(a.C, xv.C, qT, 0, 0, 0);        \
+  kT = __builtin_amdgcn_mfma_f32_32x32x2f32(c.C, mv.C, kT, 0, 0, 0);        \
+  v = __builtin_amdgcn_mfma_f32_32x32x2f32(mv.C, e.C, v, 0, 0, 0);
+    T2L_F_QKV(x) T2L_F_QKV(y) T2L_F_QKV(z) T2L_F_QKV(w)
+#undef T2L_F_QKV
+  }
+  {
+    const float* ib = in_proj.b;
+    const float bv = ib[2 * kFD + h * kFHd + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
+      qT[r] += ib[h * kFHd + f];
+      kT[r] += ib[kFD + h * kFHd + f];
+      v[r] += bv;
+    }
+  }
+  f32x16 st;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kT[r], qT[r], st, 0, 0, 0);
+  // lane: query i = col, keys j = (r&3) + 8*(r>>2) + 4*half
+  const int gi = col >> gx.shift;
+  float m = -__builtin_inff();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
+    const bool ok = (j >> gm.shift) == gi && (j & ((1 << gm.shift) - 1)) < gm.count && j < gm.rows;
+    st[r] = ok ? st[r] * 0.17677669529663687f : -__builtin_inff();  // 1/sqrt(32)
+    m = fmaxf(m, st[r]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 32));
+  const bool any = m > -__builtin_inff();  // rows that are nobody's query (tile padding) see no key at all
+  float sum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    st[r] = any ? __expf(st[r] - m) : 0.f;
+    sum += st[r];
+  }
+  sum += __shfl_xor(sum, 32);
+  const float inv = any ? 1.f / sum : 0.f;
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(st[r] * inv, v[r], o, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) obuf[((r & 3) + 8 * (r >> 2) + 4 * half) * kFS + h * kFHd + col] = o[r];
+}
+
+// x += A @ W^T + b for a 128 -> 128 Linear (out_proj): one 32-column tile per wave
+__device__ __forceinline__ void f_proj_add(const float* __restrict__ A, const FPacked L, float* __restrict__ x) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  mm32_dot<kFD / 8>(A + col * kFS + half * (kFD / 2), L.w + (size_t)w * (kFD / 8) * 64 + lane, acc);
+  const float bv = L.b[w * 32 + col];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[((r & 3) + 8 * (r >> 2) + 4 * half) * kFS + w * 32 + col] += acc[r] + bv;
+}
+
+// nn.TransformerDecoderLayer (post-norm, ReLU, eval, no masks) for the kPairs pairs of a workgroup. x / mem: 32-row token
+// tiles (LDS, stride kFS); buf: one more 32 x 128 tile (attention output, then the feed-forward hidden in four quarters).
+__device__ void f_decoder(float* x, TileGroups gx, const float* mem, TileGroups gm, const FDecoder D, float* buf) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
+  f_attention_regs(x, gx, x, gx, D.sa_in, buf);
+  __syncthreads();
+  f_proj_add(buf, D.sa_out, x);
+  __syncthreads();
+  f_ln_rows(x, kFS, gx.rows, D.g1, D.b1);
+  __syncthreads();
+  f_attention_regs(x, gx, mem, gm, D.ca_in, buf);
+  __syncthreads();
+  f_proj_add(buf, D.ca_out, x);
+  __syncthreads();
+  f_ln_rows(x, kFS, gx.rows, D.g2, D.b2);
+  __syncthreads();
+  {  // feed-forward 128 -> 512 -> 128: the hidden layer passes through buf in four quarters of 128 units — the units that
+     // k-steps [16 q, 16 q + 16) of the half-split packing of W2 (K = 512) cover — W2's product accumulates in registers
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    mm32_dot<K / 8>(A + j * lda + kh * (K / 2), L.w + (size_t)nt * (K / 8) * 64 + lane, acc);
-    const float bv = L.b[nt * 32 + j];
+    for (int qtr = 0; qtr < 4; ++qtr) {
+      // quarter = hidden tiles {2 qtr, 2 qtr + 1} (buf columns 0..63) and {8 + 2 qtr, 9 + 2 qtr} (columns 64..127)
+      const int tile = (w < 2 ? 2 * qtr + w : 8 + 2 * qtr + (w - 2));
+      f32x16 hh;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float v = acc[r] + bv;
-      out[((r & 3) + 8 * (r >> 2) + 4 * kh) * ldo + (nt - nt0) * 32 + j] = relu ? fmaxf(v, 0.f) : v;
-    }
-  }
-}
-
-// multi-head attention for the kPairs pairs of a workgroup: queries of pair p are rows qbase*p + i (i < T) of q (cols qc..),
-// keys / values rows kbase*p + j (j < S) of kv (cols kc.. / vc..); 4 heads x 32. prob: [kPairs][4][16][16] scratch.
-constexpr int kPairs = 2;
-__device__ void f_attention(const float* q, int ldq, int qc, int qbase, const float* kv, int ldk, int kc, int vc, int kbase, int T, int S,
-                            float* prob, float* o, int ldo) {
-  const float scale = 0.17677669529663687f;  // 1/sqrt(32)
-  for (int e = threadIdx.x; e < kPairs * kFHeads * T * S; e += 256) {
-    const int p = e / (kFHeads * T * S), r0 = e % (kFHeads * T * S), h = r0 / (T * S), r = r0 % (T * S), i = r / S, j = r % S;
-    const float* qr = q + (qbase * p + i) * ldq + qc + h * kFHd;
-    const float* kr = kv + (kbase * p + j) * ldk + kc + h * kFHd;
-    float s = 0.f;
+      for (int r = 0; r < 16; ++r) hh[r] = 0.f;
+      mm32_dot<kFD / 8>(x + col * kFS + half * (kFD / 2), D.l1.w + (size_t)tile * (kFD / 8) * 64 + lane, hh);
+      if (qtr) __syncthreads();  // every wave has consumed the previous quarter
+      const float bv = D.l1.b[tile * 32 + col];
 #pragma unroll
-    for (int d = 0; d < kFHd; d += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(qr + d), b = *reinterpret_cast<const float4*>(kr + d);
-      s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+      for (int r = 0; r < 16; ++r) buf[((r & 3) + 8 * (r >> 2) + 4 * half) * kFS + w * 32 + col] = fmaxf(hh[r] + bv, 0.f);
+      __syncthreads();
+      mm32_dot<kFD / 8>(buf + col * kFS + half * (kFD / 2), D.l2.w + ((size_t)w * (4 * kFD / 8) + 16 * qtr) * 64 + lane, acc);
     }
-    prob[((p * kFHeads + h) * 16 + i) * 16 + j] = s * scale;
+    const float bv = D.l2.b[w * 32 + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[((r & 3) + 8 * (r >> 2) + 4 * half) * kFS + w * 32 + col] += acc[r] + bv;
   }
   __syncthreads();
-  if (threadIdx.x < kPairs * kFHeads * T) {
-    const int p = threadIdx.x / (kFHeads * T), r = threadIdx.x % (kFHeads * T);
-    float* row = prob + ((p * kFHeads + r / T) * 16 + (r % T)) * 16;
-    float mx = row[0];
-    for (int j = 1; j < S; ++j) mx = fmaxf(mx, row[j]);
-    float sum = 0.f;
-    for (int j = 0; j < S; ++j) { row[j] = expf(row[j] - mx); sum += row[j]; }
-    for (int j = 0; j < S; ++j) row[j] /= sum;
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < kPairs * T * kFD; e += 256) {
-    const int p = e / (T * kFD), r = e % (T * kFD), i = r / kFD, c = r % kFD, h = c / kFHd;
-    const float* pr = prob + ((p * kFHeads + h) * 16 + i) * 16;
-    float s = 0.f;
-    for (int j = 0; j < S; ++j) s += pr[j] * kv[(kbase * p + j) * ldk + vc + c];
-    o[(qbase * p + i) * ldo + c] = s;
-  }
-  __syncthreads();
-}
-
-// nn.TransformerDecoderLayer (post-norm, ReLU, eval, no masks) for kPairs pairs at once. x: 32-row token buffer (LDS, stride
-// kFS) whose pair p occupies rows xbase*p .. +T-1 (the other rows ride along: every step is row-wise or reads only the valid
-// rows); mem: the other side's buffer (rows mbase*p .. +S-1). big [32][516]: q|k|v (stride 388), later the feed-forward hidden
-// (stride 516); att, tmp: [32][kFS].
-__device__ void f_decoder(float* x, int xbase, int T, int xrows, const float* mem, int mbase, int S, const FDecoder D, float* big, float* att,
-                          float* prob, float* tmp) {
-  f_mm32<kFD>(x, kFS, D.sa_in, 0, 12, big, 388, false);
-  __syncthreads();
-  f_attention(big, 388, 0, xbase, big, 388, kFD, 2 * kFD, xbase, T, T, prob, att, kFS);
-  f_mm32<kFD>(att, kFS, D.sa_out, 0, 4, tmp, kFS, false);
-  __syncthreads();
-  f_add_ln(x, tmp, kFS, xrows, D.g1, D.b1);
-  __syncthreads();
-  f_mm32<kFD>(x, kFS, D.ca_in, 0, 4, att, kFS, false);      // q  = x   Wq   (in_proj rows 0..127)
-  f_mm32<kFD>(mem, kFS, D.ca_in, 4, 12, big, 388, false);   // k|v = mem Wkv  (in_proj rows 128..383) -> big cols 0..255
-  __syncthreads();
-  f_attention(att, kFS, 0, xbase, big, 388, 0, kFD, mbase, T, S, prob, tmp, kFS);
-  f_mm32<kFD>(tmp, kFS, D.ca_out, 0, 4, att, kFS, false);
-  __syncthreads();
-  f_add_ln(x, att, kFS, xrows, D.g2, D.b2);
-  __syncthreads();
-  f_mm32<kFD>(x, kFS, D.l1, 0, 16, big, 516, true);
-  __syncthreads();
-  f_mm32<4 * kFD>(big, 516, D.l2, 0, 4, att, kFS, false);
-  __syncthreads();
-  f_add_ln(x, att, kFS, xrows, D.g3, D.b3);
+  f_ln_rows(x, kFS, gx.rows, D.g3, D.b3);
   __syncthreads();
 }
 
@@ -394,20 +444,17 @@ __global__ __launch_bounds__(256) void fine_objects_kernel(FineParams P, t2l_pac
 }
 
 // One workgroup per kPairs = 2 (query, cell) pairs: the 2 x 16 object tokens fill one 32-row MFMA tile, the 2 x 6 hint tokens
-// sit at rows 8p..8p+5 of a second one (its other rows are zero / ignored). All token-wise linears run on f32 MFMA tiles
-// (f_mm32); attention (16x6 / 16x16 / 6x6 / 6x16 per head), LayerNorm and the offset head stay on the vector ALU.
-__global__ __launch_bounds__(256, 1) void fine_match_kernel(FineParams P, const float* __restrict__ cell_desc, const int32_t* __restrict__ cell_index,
+// sit at rows 8p..8p+5 of a second one (its other rows are zero / ignored). Three 32 x 128 LDS tiles (52 KB): three
+// workgroups per CU.
+__global__ __launch_bounds__(256, 3) void fine_match_kernel(FineParams P, const float* __restrict__ cell_desc, const int32_t* __restrict__ cell_index,
                                                             const float* __restrict__ hint_desc, const int32_t* __restrict__ hint_index,
                                                             int n_pairs, int n_hints, float* __restrict__ out) {
   extern __shared__ float sm[];
   float* d0 = sm;                  // [32][kFS] objects: pair p at rows 16p..
   float* d1 = d0 + 32 * kFS;       // [32][kFS] hints:   pair p at rows 8p..8p+n_hints-1
-  float* big = d1 + 32 * kFS;      // [32][516]
-  float* att = big + 32 * 516;     // [32][kFS]
-  float* tmp = att + 32 * kFS;     // [32][kFS]
-  float* prob = tmp + 32 * kFS;    // [kPairs][4][16][16]
-  float* pooled = prob + kPairs * kFHeads * 256;  // [kPairs][128]
-  float* h64 = pooled + kPairs * kFD;             // [kPairs][64]
+  float* buf = d1 + 32 * kFS;      // [32][kFS]
+  float* pooled = buf + 32 * kFS;  // [kPairs][128]
+  float* h64 = pooled + kPairs * kFD;  // [kPairs][64]
   const int tid = threadIdx.x, pair0 = blockIdx.x * kPairs;
   for (int i = tid; i < 32 * kFD; i += 256) {
     const int row = i / kFD, c = i % kFD, p = row >> 4;
@@ -422,9 +469,10 @@ __global__ __launch_bounds__(256, 1) void fine_match_kernel(FineParams P, const 
     d1[row * kFS + c] = v;
   }
   __syncthreads();
+  const TileGroups gobj{4, kFObj, 32}, ghint{3, n_hints, 16};
   for (int l = 0; l < P.n_layers; ++l) {  // cross_matcher.py:114-118
-    f_decoder(d0, 16, kFObj, 32, d1, 8, n_hints, P.obj[l], big, att, prob, tmp);
-    f_decoder(d1, 8, n_hints, 16, d0, 16, kFObj, P.hint[l], big, att, prob, tmp);
+    f_decoder(d0, gobj, d1, ghint, P.obj[l], buf);
+    f_decoder(d1, ghint, d0, gobj, P.hint[l], buf);
   }
   {  // desc1.max(dim=0) over the hints, then mlp_offsets (cross_matcher.py:128-131)
     const int p = tid >> 7, c = tid & 127;
@@ -472,7 +520,7 @@ int fine_match_impl(t2l_ctx* ctx, const float* cell_desc, const int32_t* cell_in
   if (!cell_desc || !hint_desc || !out || n_pairs < 0) return fail(ctx, T2L_EINVAL, "t2l_fine_match: null argument");
   if (n_hints < 1 || n_hints > kFHintMax) return fail(ctx, T2L_EINVAL, "t2l_fine_match: 1 <= n_hints <= 8");
   if (n_pairs == 0) return T2L_OK;
-  const size_t lds = sizeof(float) * (4 * 32 * kFS + 32 * 516 + kPairs * kFHeads * 256 + kPairs * kFD + kPairs * 64);  // 143 KB
+  const size_t lds = sizeof(float) * (3 * 32 * kFS + kPairs * kFD + kPairs * 64);  // 52 KB: three workgroups per CU
   static bool attr = false;
   if (!attr) {
     T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fine_match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
