@@ -351,14 +351,17 @@ __global__ __launch_bounds__(256, 1) void pn_sa_kernel(SaParams P) {
   }
 }
 
-// GlobalAbstraction: get_mlp([259,512,1024]) over the 32 points of an object, max. One workgroup per object.
-constexpr int kGaK = 264, kGaXS = kGaK + 4, kGaH1 = 512, kGaHS = kGaH1 + 4, kGaH2 = 1024;
-__global__ __launch_bounds__(256, 1) void pn_ga_kernel(const float* __restrict__ pos3, const float* __restrict__ x3,
+// GlobalAbstraction: get_mlp([259,512,1024]) over the 32 points of an object, max. One workgroup per object. The 512-wide
+// hidden layer passes through LDS in two halves of 256 units (the units k-steps [32 hf, 32 hf + 32) of the half-split
+// packing of the second Linear cover) while the 1024 outputs (8 column tiles per wave) accumulate in registers:
+// 68 KB of LDS instead of 100 KB, two objects per CU.
+constexpr int kGaK = 264, kGaXS = kGaK + 4, kGaH1 = 512, kGaHS = 256 + 4, kGaH2 = 1024;
+__global__ __launch_bounds__(256, 2) void pn_ga_kernel(const float* __restrict__ pos3, const float* __restrict__ x3,
                                                        const float4* __restrict__ w1, const float4* __restrict__ w2,
                                                        const float* __restrict__ b2, float* __restrict__ f0) {
   extern __shared__ float smem[];
   float* X = smem;                 // [32][kGaXS]  rows = [x(256) | pos(3) | 1 | 0..]
-  float* Hd = X + 32 * kGaXS;      // [32][kGaHS]
+  float* Hd = X + 32 * kGaXS;      // [32][kGaHS]  one half of the hidden layer
   const int o = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, kh = lane >> 5;
   for (int i = tid; i < 32 * kGaK; i += 256) {
     const int r = i / kGaK, k = i % kGaK;
@@ -369,28 +372,65 @@ __global__ __launch_bounds__(256, 1) void pn_ga_kernel(const float* __restrict__
     X[r * kGaXS + k] = v;
   }
   __syncthreads();
-  // layer 1: 16 column tiles, 4 per wave; A = X (lane row j, k half kh), B = packed weights
-  for (int nt = w; nt < kGaH1 / 32; nt += 4) {
-    f32x16 acc;
+  f32x16 acc[8];  // output column tiles w, w + 4, ..., w + 28
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* xr = X + j * kGaXS + kh * (kGaK / 2);
-    mm32_dot<kGaK / 8>(xr, w1 + (size_t)nt * (kGaK / 8) * 64 + lane, acc);
+  for (int t = 0; t < 8; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Hd[((r & 3) + 8 * (r >> 2) + 4 * kh) * kGaHS + nt * 32 + j] = fmaxf(acc[r], 0.f);
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (int hf = 0; hf < 2; ++hf) {
+    // layer 1, this half: hidden tiles 4 hf + w -> Hd columns 32 w.., and 8 + 4 hf + w -> Hd columns 128 + 32 w..
+    f32x16 h[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h[0][r] = h[1][r] = 0.f;
+    {  // the two tiles share every A fragment
+      const float* xr = X + j * kGaXS + kh * (kGaK / 2);
+      const float4* wa = w1 + (size_t)(4 * hf + w) * (kGaK / 8) * 64 + lane;
+      const float4* wb = w1 + (size_t)(8 + 4 * hf + w) * (kGaK / 8) * 64 + lane;
+#pragma unroll 3
+      for (int q = 0; q < kGaK / 8; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(xr + 4 * q);
+        const float4 b0 = wa[q * 64], b1 = wb[q * 64];
+        h[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, h[0], 0, 0, 0);
+        h[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, h[1], 0, 0, 0);
+        h[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, h[0], 0, 0, 0);
+        h[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, h[1], 0, 0, 0);
+        h[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, h[0], 0, 0, 0);
+        h[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, h[1], 0, 0, 0);
+        h[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, h[0], 0, 0, 0);
+        h[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, h[1], 0, 0, 0);
+      }
+    }
+    if (hf) __syncthreads();  // every wave has consumed the first half
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Hd[((r & 3) + 8 * (r >> 2) + 4 * kh) * kGaHS + 128 * u + 32 * w + j] = fmaxf(h[u][r], 0.f);
+    __syncthreads();
+    {  // layer 2 partial: the 8 column tiles of this wave share every A fragment (one LDS read, 8 weight loads, 32 MFMAs)
+      const float* hr = Hd + j * kGaHS + kh * 128;
+      const float4* wp = w2 + ((size_t)w * (kGaH1 / 8) + 32 * hf) * 64 + lane;
+#pragma unroll 2
+      for (int q = 0; q < 32; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(hr + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float4 b = wp[((size_t)4 * t * (kGaH1 / 8) + q) * 64];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+        }
+      }
+    }
   }
-  __syncthreads();
-  for (int nt = w; nt < kGaH2 / 32; nt += 4) {
-    f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* hr = Hd + j * kGaHS + kh * (kGaH1 / 2);
-    mm32_dot<kGaH1 / 8>(hr, w2 + (size_t)nt * (kGaH1 / 8) * 64 + lane, acc);
-    float m = acc[0];
+  for (int t = 0; t < 8; ++t) {
+    float m = acc[t][0];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[t][r]);
     m = fmaxf(m, __shfl_xor(m, 32));
-    if (kh == 0) f0[(size_t)o * kGaH2 + nt * 32 + j] = fmaxf(m + b2[nt * 32 + j], 0.f);
+    const int c = (w + 4 * t) * 32 + j;
+    if (kh == 0) f0[(size_t)o * kGaH2 + c] = fmaxf(m + b2[c], 0.f);
   }
 }
 
