@@ -92,6 +92,17 @@ int t2l_reduce_objects(t2l_ctx* ctx, const float* xyz, const float* rgb, const i
                        const float* color_centers, const int32_t* color_rows, int32_t n_colors, float* out_rgb,
                        float* out_center, float* out_npts, int32_t* out_color_idx, void* stream);
 
+/* ---- point batches for PointNet++ (a3, dataloader side) ------------------------------------------ */
+/* Replaces: batch_object_points(objects, transform) with transform = Compose([FixedPoints(256), NormalizeScale()])
+ * (dataloading/kitti360pose/utils.py:91-147, evaluation/pipeline.py:215-223), which the reference runs per object on the host
+ * inside the dataloader: 256 point indices drawn with replacement, positions centred on the mean of the sample and scaled by
+ * 0.999999 / max |coordinate|, colours gathered. xyz, rgb: dev f32[n_points,3] (objects concatenated);
+ * point_offsets: DEV i64[n_objects+1]; out_pos / out_rgb: dev f32[n_objects,256,3] — the inputs of t2l_pointnet_features.
+ * Sampling is counter-based (the reference uses numpy's global RNG: equal in distribution, not in the draw): index j of
+ * object o is floor(u * n_o) with u = (lowbias32(j * 0x9E3779B1 + (seed ^ o * 0x85EBCA77)) >> 8) / 2^24. */
+int t2l_sample_object_points(t2l_ctx* ctx, const float* xyz, const float* rgb, const int64_t* point_offsets, int32_t n_objects,
+                             uint32_t seed, float* out_pos, float* out_rgb, void* stream);
+
 /* ---- PointNet++ object backbone (a3), eval mode ------------------------------------------------ */
 /* Replaces: PointNet2.forward(...).features2 (models/pointcloud/pointnet2.py:66-100) as ObjectEncoder.forward calls it
  * once per cell (models/object_encoder.py:92-95): three SetAbstraction layers (FPS 1/2, ball query r = .2/.3/.4 with at most

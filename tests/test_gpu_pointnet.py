@@ -118,6 +118,14 @@ def test_drop_in_published_mode_from_point_batches():
     packed["pn_feat"] = OP.pointnet_features(pos, rgb, packed["offsets"], sd)
     ref = O.encode_cells(packed, sd, False, False)
     assert np.abs(emb - ref).max() < 1e-4
+    # point batches sampled on the GPU feed the same path (different draw, so compare with the restatement on those batches)
+    gb = packing.sample_object_points_gpu(model.engine(), objects, "cuda", seed=5)
+    emb_g = model.encode_objects(objects, gb).cpu().numpy()
+    pos_g = np.concatenate([b["pos"].cpu().numpy().reshape(-1, 256, 3) for b in gb])
+    rgb_g = np.concatenate([b["x"].cpu().numpy().reshape(-1, 256, 3) for b in gb])
+    packed_g = dict(packed)
+    packed_g["pn_feat"] = OP.pointnet_features(pos_g, rgb_g, packed["offsets"], sd)
+    assert np.abs(emb_g - O.encode_cells(packed_g, sd, False, False)).max() < 1e-4
     # precomputed features2 remain accepted
     feats = [torch.from_numpy(packed["pn_feat"][packed["offsets"][i]:packed["offsets"][i + 1]]) for i in range(3)]
     emb2 = model.encode_objects(objects, feats).cpu().numpy()
@@ -136,3 +144,23 @@ def test_argument_errors(eng):
         eng.pointnet_features(z, z, np.array([0, 3, 2]))
     with pytest.raises(T2LError, match="CUDA"):
         eng.pointnet_features(z.cpu(), z, np.array([0, 2]))
+
+
+def test_point_batches_sampled_on_the_gpu(eng):
+    """FixedPoints(256) + NormalizeScale on the GPU vs the numpy restatement (same counter-based draw), then straight into PointNet++."""
+    rs = np.random.default_rng(4)
+    n_pts = np.array([8, 25, 300, 4000, 61], dtype=np.int64)
+    poff = np.concatenate([[0], np.cumsum(n_pts)]).astype(np.int64)
+    xyz = (rs.standard_normal((int(poff[-1]), 3)) * 3 + 10).astype(np.float32)
+    rgb = rs.uniform(0, 1, size=(int(poff[-1]), 3)).astype(np.float32)
+    pos, col = eng.sample_object_points(torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda(), torch.from_numpy(poff).cuda(), seed=77)
+    rpos, rcol = OP.sample_object_points(xyz, rgb, poff, 77)
+    assert np.array_equal(col.cpu().numpy(), rcol)  # same indices
+    assert np.abs(pos.cpu().numpy() - rpos).max() < 2e-6
+    p = pos.cpu().numpy()
+    assert np.abs(p.mean(axis=1)).max() < 1e-5 and np.all(np.abs(p).max(axis=(1, 2)) <= 1.0) and np.all(np.abs(p).max(axis=(1, 2)) > 0.9999)
+    pos2, _ = eng.sample_object_points(torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda(), torch.from_numpy(poff).cuda(), seed=78)
+    assert not torch.equal(pos, pos2)
+    f2 = eng.pointnet_features(pos, col, np.array([0, 2, 5]))
+    ref = OP.pointnet_features(rpos, rcol, np.array([0, 2, 5]), eng._sd)
+    assert np.abs(f2.cpu().numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())

@@ -87,6 +87,13 @@ int t2l_load_weights(t2l_ctx* ctx, const t2l_weight_desc* w, int32_t n, const t2
   return rc ? rc : pointnet_load_impl(ctx, w, n);
 }
 
+int t2l_sample_object_points(t2l_ctx* ctx, const float* xyz, const float* rgb, const int64_t* point_offsets, int32_t n_objects,
+                             uint32_t seed, float* out_pos, float* out_rgb, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return sample_points_impl(ctx, xyz, rgb, point_offsets, n_objects, seed, out_pos, out_rgb, (hipStream_t)stream);
+}
+
 int t2l_pointnet_features(t2l_ctx* ctx, const float* pos, const float* rgb, const int32_t* cell_offsets, int32_t n_cells,
                           float* out_features2, void* stream) {
   if (!ctx) return T2L_EINVAL;

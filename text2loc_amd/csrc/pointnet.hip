@@ -434,6 +434,57 @@ __global__ __launch_bounds__(256, 2) void pn_ga_kernel(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The point batches PointNet++ eats, built on the GPU from the raw object points: FixedPoints(256) — 256 indices drawn
+// with replacement — then NormalizeScale (centre on the mean of the sampled points, scale by 0.999999 / max |coordinate|):
+// torch_geometric.transforms as the reference composes them (evaluation/pipeline.py:215-223) and applies them per object
+// on the host (dataloading/kitti360pose/utils.py:138-143). The reference draws from numpy's global RNG; here index j of
+// object o is floor(u * n) with u = the top 24 bits of lowbias32(j * 0x9E3779B1 + (seed ^ o * 0x85EBCA77)) / 2^24.
+// One workgroup per object, one thread per sampled point.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_points_kernel(const float* __restrict__ xyz, const float* __restrict__ rgb,
+                                                            const int64_t* __restrict__ offsets, uint32_t seed,
+                                                            float* __restrict__ out_pos, float* __restrict__ out_rgb) {
+  __shared__ float red[4][4];
+  const int o = blockIdx.x, j = threadIdx.x, lane = j & 63, w = j >> 6;
+  const int64_t p0 = offsets[o];
+  const uint32_t n = (uint32_t)(offsets[o + 1] - p0);
+  uint32_t x = (uint32_t)j * 0x9E3779B1u + (seed ^ ((uint32_t)o * 0x85EBCA77u));
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  const uint32_t idx = (uint32_t)(((uint64_t)(x >> 8) * n) >> 24);
+  const float* src = xyz + (size_t)(p0 + idx) * 3;
+  float px = src[0], py = src[1], pz = src[2];
+  const float* col = rgb + (size_t)(p0 + idx) * 3;
+  const size_t ob = ((size_t)o * 256 + j) * 3;
+  out_rgb[ob] = col[0]; out_rgb[ob + 1] = col[1]; out_rgb[ob + 2] = col[2];
+  float sx = px, sy = py, sz = pz;
+#pragma unroll
+  for (int off = 32; off; off >>= 1) { sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); sz += __shfl_xor(sz, off); }
+  if (lane == 0) { red[w][0] = sx; red[w][1] = sy; red[w][2] = sz; }
+  __syncthreads();
+  const float mx = (red[0][0] + red[1][0] + red[2][0] + red[3][0]) * (1.f / 256.f);
+  const float my = (red[0][1] + red[1][1] + red[2][1] + red[3][1]) * (1.f / 256.f);
+  const float mz = (red[0][2] + red[1][2] + red[2][2] + red[3][2]) * (1.f / 256.f);
+  px -= mx; py -= my; pz -= mz;
+  float m = fmaxf(fmaxf(fabsf(px), fabsf(py)), fabsf(pz));
+#pragma unroll
+  for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  __syncthreads();
+  if (lane == 0) red[w][3] = m;
+  __syncthreads();
+  const float scale = (1.0f / fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3]))) * 0.999999f;
+  out_pos[ob] = px * scale; out_pos[ob + 1] = py * scale; out_pos[ob + 2] = pz * scale;
+}
+
+int sample_points_impl(t2l_ctx* ctx, const float* xyz, const float* rgb, const int64_t* point_offsets_dev, int n_objects, uint32_t seed,
+                       float* out_pos, float* out_rgb, hipStream_t s) {
+  if (!xyz || !rgb || !point_offsets_dev || !out_pos || !out_rgb) return fail(ctx, T2L_EINVAL, "t2l_sample_object_points: null argument");
+  if (n_objects <= 0) return n_objects == 0 ? T2L_OK : fail(ctx, T2L_EINVAL, "t2l_sample_object_points: n_objects < 0");
+  hipLaunchKernelGGL(sample_points_kernel, dim3(n_objects), dim3(256), 0, s, xyz, rgb, point_offsets_dev, seed, out_pos, out_rgb);
+  T2L_HIP(ctx, hipGetLastError());
+  return T2L_OK;
+}
+
 template <int CIN, int H1, int H2, int NS>
 static size_t sa_lds_bytes() {
   constexpr int ND = NS / 2, XS = CIN + 4;

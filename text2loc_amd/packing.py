@@ -130,6 +130,28 @@ def sample_object_points(objects: List[List[object]], num: int = 256, rng: Optio
     return out
 
 
+def sample_object_points_gpu(engine, objects: List[List[object]], device="cuda", seed: int = 0):
+    """``sample_object_points`` on the GPU (t2l_sample_object_points): the raw points are concatenated and copied over once,
+    FixedPoints(256) + NormalizeScale run as one kernel (counter-based draw, so equal to the host sampler in distribution,
+    not in the indices). Returns the same per-cell ``{"pos", "x"}`` batches, as CUDA tensors."""
+    import torch
+
+    flat = [o for objs in objects for o in objs]
+    npts = np.array([len(o.xyz) for o in flat], dtype=np.int64)
+    poff = np.zeros(len(flat) + 1, dtype=np.int64)
+    np.cumsum(npts, out=poff[1:])
+    xyz = np.concatenate([np.asarray(o.xyz, dtype=np.float32) for o in flat], axis=0)
+    rgb = np.concatenate([np.asarray(o.rgb, dtype=np.float32) for o in flat], axis=0)
+    pos, col = engine.sample_object_points(torch.from_numpy(xyz).to(device), torch.from_numpy(rgb).to(device),
+                                           torch.from_numpy(poff).to(device), seed)
+    out, lo = [], 0
+    for objs in objects:
+        hi = lo + len(objs)
+        out.append({"pos": pos[lo:hi].reshape(-1, 3), "x": col[lo:hi].reshape(-1, 3)})
+        lo = hi
+    return out
+
+
 def to_device(packed: Dict[str, np.ndarray], device) -> Dict[str, "torch.Tensor"]:
     import torch
 
@@ -138,4 +160,4 @@ def to_device(packed: Dict[str, np.ndarray], device) -> Dict[str, "torch.Tensor"
 
 
 __all__ = ["KNOWN_CLASS", "COLOR_NAMES", "class_table", "color_table", "object_features", "pack_cells",
-           "pack_cells_gpu", "sample_object_points", "to_device"]
+           "pack_cells_gpu", "sample_object_points", "sample_object_points_gpu", "to_device"]
