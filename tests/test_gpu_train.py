@@ -121,8 +121,10 @@ def test_gradients_accumulate_and_zero_grad(eng):
     one = {n: t[1].clone() for n, t in tensors.items() if t[1] is not None}
     eng.encode_cells_backward(g)  # a second backward through the same graph adds, like autograd with retain_graph
     for n, t in tensors.items():
-        if t[1] is not None:  # float atomics: the summation order differs between the two passes
-            assert torch.allclose(t[1], 2 * one[n], rtol=1e-3, atol=1e-3 * float(one[n].abs().max()) + 1e-6), n
+        if t[1] is not None:
+            # float atomics: the summation order differs between the two passes; gradients that are exactly 0 in exact
+            # arithmetic (Linear biases in front of a BatchNorm, key biases) are pure cancellation noise of ~1e-6
+            assert torch.allclose(t[1], 2 * one[n], rtol=1e-3, atol=1e-3 * float(one[n].abs().max()) + 2e-5), n
     eng.zero_grad()
     torch.cuda.synchronize()
     assert all(float(t[1].abs().max()) == 0.0 for t in tensors.values() if t[1] is not None)
