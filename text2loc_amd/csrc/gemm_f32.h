@@ -62,26 +62,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float a[8], b[8], an[8], bn[8], csum = 0.f;
+  // operand ring, kRing 16-steps deep: a wave's share of the reduction is short (4-16 steps) and every step's operands come
+  // from L2 (~1 us away), so the loads of several steps have to be in flight at once — nothing else hides that latency
+  constexpr int kRing = 4;
+  float a[kRing][8], b[kRing][8], csum = 0.f;
   const bool do_colsum = !A_KC && g.colsum && blockIdx.x == 0;
-  if (wk0 < wk1) {
-    gemm_load<A_KC>(g.A, g.lda, m0 + i, a_ok, wk0, kh, wk1, a);
-    gemm_load<B_KC>(g.B, g.ldb, n0 + i, true, wk0, kh, wk1, b);
-  }
-  for (int k0 = wk0; k0 < wk1; k0 += 16) {
-    if (k0 + 16 < wk1) {
-      gemm_load<A_KC>(g.A, g.lda, m0 + i, a_ok, k0 + 16, kh, wk1, an);
-      gemm_load<B_KC>(g.B, g.ldb, n0 + i, true, k0 + 16, kh, wk1, bn);
-    }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
-      if (do_colsum) csum += a[j];
+  for (int d = 0; d < kRing; ++d)
+    if (wk0 + 16 * d < wk1) {
+      gemm_load<A_KC>(g.A, g.lda, m0 + i, a_ok, wk0 + 16 * d, kh, wk1, a[d]);
+      gemm_load<B_KC>(g.B, g.ldb, n0 + i, true, wk0 + 16 * d, kh, wk1, b[d]);
     }
+  for (int k0 = wk0; k0 < wk1; k0 += 16 * kRing) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      a[j] = an[j];
-      b[j] = bn[j];
+    for (int d = 0; d < kRing; ++d) {
+      if (k0 + 16 * d < wk1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][j], b[d][j], acc, 0, 0, 0);
+          if (do_colsum) csum += a[d][j];
+        }
+        if (k0 + 16 * (d + kRing) < wk1) {  // refill this slot with the step one ring ahead
+          gemm_load<A_KC>(g.A, g.lda, m0 + i, a_ok, k0 + 16 * (d + kRing), kh, wk1, a[d]);
+          gemm_load<B_KC>(g.B, g.ldb, n0 + i, true, k0 + 16 * (d + kRing), kh, wk1, b[d]);
+        }
+      }
     }
   }
 #pragma unroll
