@@ -15,10 +15,32 @@ namespace t2l {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float half_sum(float v) {  // sum over the 32 lanes that share lane>>5
-#pragma unroll
-  for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+template <int CTRL>
+__device__ __forceinline__ float loss_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {  // all-reduce over the 64 lanes on the VALU
+  v += loss_dpp<0xB1>(v);
+  v += loss_dpp<0x4E>(v);
+  v += loss_dpp<0x141>(v);
+  v += loss_dpp<0x140>(v);
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
   return v;
+}
+__device__ __forceinline__ float half_sum(float v) {  // sum over the 32 lanes that share lane>>5 (DPP, no LDS traffic)
+  v += loss_dpp<0xB1>(v);
+  v += loss_dpp<0x4E>(v);
+  v += loss_dpp<0x141>(v);
+  v += loss_dpp<0x140>(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // One 32-row block of  out = ((M @ X^) - Y^ * rowdot) * iy   where M is G (transpose=false) or G^T.
@@ -34,6 +56,7 @@ __device__ __forceinline__ void grad_rowblock(const float* __restrict__ G, int l
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   const int gi = i0 + col;  // A-operand row of this lane
+#pragma unroll 8  // the operands of 8 steps in flight: every step's loads come from L2 and nothing else hides their latency
   for (int k0 = 0; k0 < B; k0 += 2) {
     const int k = k0 + half;
     float a = 0.f, scale = 0.f;
@@ -84,6 +107,7 @@ __global__ __launch_bounds__(256, 1) void contrastive_kernel(const float* __rest
   const int col = lane & 31, half = lane >> 5;
 
   for (int i = tid; i < Bp * ldg; i += 256) E[i] = 0.f;
+#pragma unroll 4  // four rows' loads in flight per wave; the sums run on DPP (a __shfl_xor tree is 6 dependent LDS round trips)
   for (int i = wave; i < Bp; i += 4) {  // inverse norms, one wave per row
     float sa = 0.f, sp = 0.f;
     if (i < B) {
@@ -92,11 +116,8 @@ __global__ __launch_bounds__(256, 1) void contrastive_kernel(const float* __rest
       sa = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
       sp = p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      sa += __shfl_xor(sa, off);
-      sp += __shfl_xor(sp, off);
-    }
+    sa = wave_sum_f32(sa);
+    sp = wave_sum_f32(sp);
     if (lane == 0) {
       ia[i] = i < B ? 1.f / sqrtf(sa) : 0.f;
       ip[i] = i < B ? 1.f / sqrtf(sp) : 0.f;
