@@ -405,7 +405,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the encoder / loss side measurements")
     ap.add_argument("--cells", type=int, default=N_CELLS, help="dev: database rows (default = the BASELINE workload)")
     ap.add_argument("--queries", type=int, default=N_QUERIES, help="dev: queries per step")
-    ap.add_argument("--mode", type=int, default=0, help="search_mode: 0 = split-bf16 specialised scan, 1 = f32 scan")
+    ap.add_argument("--mode", type=int, default=0,
+                    help="search_mode: 0 = wide split-bf16 scan (default), 1 = f32 scan, 2 = narrow split-bf16 scan")
+    ap.add_argument("--nbuf", type=int, default=0, help="LDS tile buffers of the wide scan (3 or 4; 0 = library default)")
     ap.add_argument("--nsplit", type=int, default=0, help="override the scan kernel's DB split count (0 = auto)")
     args = ap.parse_args()
 
@@ -434,6 +436,8 @@ def main():
     lo, hi = searcher.set_db_shard(d_db)
     eng.set_option("profile_events", 1)
     eng.set_option("search_mode", args.mode)
+    if args.nbuf:
+        eng.set_option("wide_nbuf", args.nbuf)
     if args.nsplit:
         eng.set_option("search_nsplit", args.nsplit)
 
@@ -508,7 +512,8 @@ def main():
         if args.mode == 1:
             kname, peak, dtype, mult = "scan_kernel<16>", F32_MFMA_PEAK_TFLOPS, "f32", 1
         else:
-            kname, peak, dtype, mult = "scan3_kernel<16>", BF16_MFMA_PEAK_TFLOPS, "bf16x3", 3
+            kname = "scan3_kernel<16>" if args.mode == 2 else "scanw_kernel<8, %d>" % (args.nbuf or 4)
+            peak, dtype, mult = BF16_MFMA_PEAK_TFLOPS, "bf16x3", 3
         out = {
             "metric": "coarse-retrieval queries/sec over 11k-cell DB, embed_dim=256; top-1/3/5 recall parity",
             "value": N_QUERIES * args.steps / elapsed,

@@ -8,9 +8,9 @@ from text2loc_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["bf16x3-specialised", "f32"])
+@pytest.fixture(scope="module", params=[0, 1, 2], ids=["bf16x3-wide", "f32", "bf16x3-narrow"])
 def eng(request):
-    """Both scan kernels feed the same float64 re-rank + certificate: every test runs against both."""
+    """All scan kernels feed the same float64 re-rank + certificate: every test runs against each."""
     import torch
     from text2loc_amd.engine import Engine
 

@@ -287,8 +287,12 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     if (value < 0 || value > kMaxParts / 2) return fail(ctx, T2L_EINVAL, "search_nsplit out of range [0,32]");
     ctx->nsplit_override = (int)value;
   } else if (!strcmp(name, "search_mode")) {
-    if (value != 0 && value != 1) return fail(ctx, T2L_EINVAL, "search_mode must be 0 (split-bf16 scan) or 1 (f32 scan)");
+    if (value != 0 && value != 1 && value != 2)
+      return fail(ctx, T2L_EINVAL, "search_mode must be 0 (wide split-bf16 scan), 1 (f32 scan) or 2 (narrow split-bf16 scan)");
     ctx->search_mode = (int)value;
+  } else if (!strcmp(name, "wide_nbuf")) {
+    if (value != 3 && value != 4) return fail(ctx, T2L_EINVAL, "wide_nbuf must be 3 or 4");
+    ctx->wide_nbuf = (int)value;
   } else if (!strcmp(name, "stream_min_rows")) {
     ctx->stream_min_rows = (int)value;
   } else if (!strcmp(name, "pointnet_pyg_self_loops")) {
@@ -323,3 +327,4 @@ int t2l_kernel_stats(t2l_ctx* ctx, const char* name, float* out_avg_ms, int32_t*
 }
 
 }  // extern "C"
+

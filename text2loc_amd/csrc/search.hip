@@ -67,7 +67,7 @@ __device__ __forceinline__ void tile_mfma(const float* tb, const float (&qa)[128
 // LDS: 2 x [32 rows x 260 f32] DB tiles (glds double buffer), shared by the 4 waves (4 x 32 queries).
 // ------------------------------------------------------------------------------------------------
 template <int L>
-__global__ __launch_bounds__(256, L <= 16 ? 2 : 1) void scan_kernel(const float* __restrict__ db, int n_rows, int n_tiles, int per,
+__global__ __launch_bounds__(256, L <= 16 ? 2 : 1) void scan_kernel(const float* __restrict__ db, int n_rows, int n_tiles,
                                                       int code_bits, const float* __restrict__ q, int Q, int nsplit,
                                                       float* __restrict__ cand, int32_t* __restrict__ fb_count, int zero_counts) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -76,8 +76,7 @@ __global__ __launch_bounds__(256, L <= 16 ? 2 : 1) void scan_kernel(const float*
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
   const int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
-  const int t0 = sp * per;
-  const int t1 = min(n_tiles, t0 + per);
+  const int nt = sp < n_tiles ? (n_tiles - sp + nsplit - 1) / nsplit : 0;  // this split's tiles: sp, sp + nsplit, ...
   const int qrow = qb * kQPerBlock + wave * kQPerWave + col;
   const int qload = min(qrow, Q - 1);
   const int mask = ~((1 << code_bits) - 1);
@@ -109,22 +108,20 @@ __global__ __launch_bounds__(256, L <= 16 ? 2 : 1) void scan_kernel(const float*
     accA1[r] = accB1[r] = 0.f;
   }
 
-  auto issue = [&](int t, int buf) {
-    const float* src = db + (size_t)t * kTileRows * kD + lane * 4;
-    float* dst = tiles + buf * kTileFloats;
+  const int uwave = uniform_wave_id();
+  auto issue = [&](int j, int buf) {
+    const float* src = db + ((size_t)(sp + j * nsplit) * kTileRows + uwave * 8) * kD;
+    const unsigned dst = lds_addr_of(tiles + buf * kTileFloats + uwave * 8 * kRowStrideF);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = wave * 8 + i;  // one wave-instruction moves one 1 KiB DB row into LDS
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + row * kD),
-                                       (__attribute__((address_space(3))) void*)(dst + row * kRowStrideF), 16, 0, 0);
-    }
+    for (int i = 0; i < 8; ++i)  // one wave-instruction moves one 1 KiB DB row into LDS
+      lds_dma_row(dst + i * (kRowStrideF * 4), lane * 16, src + i * kD);
   };
   // D[row][col]: a lane holds query `col` and DB rows (r&3) + 8*(r>>2) + 4*half of the tile; the key's
-  // code is ((tile - t0) << 4) | r  (the row is rebuilt from it, `half` and the split in the re-rank).
-  auto step = [&](int t, int buf, f32x16& cur0, f32x16& cur1, const f32x16& prev0, const f32x16& prev1) {
+  // code is (j << 4) | r for the split's j-th tile (the row is rebuilt from it, `half` and the split in the re-rank).
+  auto step = [&](int j, int buf, f32x16& cur0, f32x16& cur1, const f32x16& prev0, const f32x16& prev1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile t landed for every wave; every wave is done reading buffer buf^1
-    if (t + 1 < t1) issue(t + 1, buf ^ 1);
+    __syncthreads();  // tile j landed for every wave; every wave is done reading buffer buf^1
+    if (j + 1 < nt) issue(j + 1, buf ^ 1);
     const float* tb = tiles + buf * kTileFloats + col * kRowStrideF + half * 128;
     float4 ab[4];
 #pragma unroll
@@ -134,19 +131,19 @@ __global__ __launch_bounds__(256, L <= 16 ? 2 : 1) void scan_kernel(const float*
       cur0[r] = 0.f;
       cur1[r] = 0.f;
     }
-    tile_mfma<L>(tb, qa, cur0, cur1, prev0, prev1, (t - 1) * kTileRows + 4 * half, n_rows, mask,
-                      (t - 1 - t0) << 4, ls, ab);
+    tile_mfma<L>(tb, qa, cur0, cur1, prev0, prev1, (sp + (j - 1) * nsplit) * kTileRows + 4 * half, n_rows, mask,
+                      (j - 1) << 4, ls, ab);
   };
 
-  if (t0 < t1) issue(t0, 0);
-  for (int t = t0; t < t1; t += 2) {
-    step(t, 0, accA0, accA1, accB0, accB1);  // while tile t multiplies, tile t-1's scores (B) enter the list
-    if (t + 1 < t1) step(t + 1, 1, accB0, accB1, accA0, accA1);
+  if (nt > 0) issue(0, 0);
+  for (int j = 0; j < nt; j += 2) {
+    step(j, 0, accA0, accA1, accB0, accB1);  // while tile j multiplies, tile j-1's scores (B) enter the list
+    if (j + 1 < nt) step(j + 1, 1, accB0, accB1, accA0, accA1);
   }
-  if (t0 < t1) {  // the last tile's scores are still in registers
-    const int row0 = (t1 - 1) * kTileRows + 4 * half;
-    const int code0 = (t1 - 1 - t0) << 4;
-    if ((t1 - t0) & 1) {
+  if (nt > 0) {  // the last tile's scores are still in registers
+    const int row0 = (sp + (nt - 1) * nsplit) * kTileRows + 4 * half;
+    const int code0 = (nt - 1) << 4;
+    if (nt & 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2);
@@ -202,7 +199,7 @@ __global__ __launch_bounds__(256) void split_db_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------
 template <int L>
 __global__ __launch_bounds__(kScanWaves * 64, 2) void scan3_kernel(const uint4* __restrict__ dbs, int n_rows, int n_tiles,
-                                                         int per, int code_bits, const float* __restrict__ q, int Q,
+                                                         int code_bits, const float* __restrict__ q, int Q,
                                                          int nsplit, float* __restrict__ cand,
                                                          int32_t* __restrict__ fb_count, int zero_counts, float pinf) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -210,8 +207,7 @@ __global__ __launch_bounds__(kScanWaves * 64, 2) void scan3_kernel(const uint4* 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
   const int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
-  const int t0 = sp * per;
-  const int t1 = min(n_tiles, t0 + per);
+  const int nt = sp < n_tiles ? (n_tiles - sp + nsplit - 1) / nsplit : 0;
   const int qrow = qb * (kScanWaves * kQPerWave) + wave * kQPerWave + col;
   const int mask = ~((1 << code_bits) - 1);
   int vmask = mask;
@@ -231,20 +227,19 @@ __global__ __launch_bounds__(kScanWaves * 64, 2) void scan3_kernel(const uint4* 
 #pragma unroll
   for (int r = 0; r < 16; ++r) accA[r] = accB[r] = T2L_NEG_INF;  // "previous tile" of the first tile: no-op inserts
 
-  auto issue = [&](int t, int buf) {
-    const uint4* src = dbs + (size_t)t * kTileRows * 64 + lane;
-    float* dst = tiles + buf * kTileFloats;
+  const int uwave = uniform_wave_id();
+  auto issue = [&](int j, int buf) {
+    constexpr int kRowsPerWave = 32 / kScanWaves;
+    const uint4* src = dbs + ((size_t)(sp + j * nsplit) * kTileRows + uwave * kRowsPerWave) * 64;
+    const unsigned dst = lds_addr_of(tiles + buf * kTileFloats + uwave * kRowsPerWave * kRowStrideF);
 #pragma unroll
-    for (int i = 0; i < 32 / kScanWaves; ++i) {
-      const int row = wave * (32 / kScanWaves) + i;  // one wave-instruction moves one 1 KiB row (hi | lo planes) into LDS
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + row * 64),
-                                       (__attribute__((address_space(3))) void*)(dst + row * kRowStrideF), 16, 0, 0);
-    }
+    for (int i = 0; i < kRowsPerWave; ++i)  // one wave-instruction moves one 1 KiB row (hi | lo planes) into LDS
+      lds_dma_row(dst + i * (kRowStrideF * 4), lane * 16, src + i * 64);
   };
-  auto step = [&](int t, int buf, f32x16& cur, const f32x16& prev) {
+  auto step = [&](int j, int buf, f32x16& cur, const f32x16& prev) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile t landed for every wave; every wave is done reading buffer buf^1
-    if (t + 1 < t1) issue(t + 1, buf ^ 1);
+    __syncthreads();  // tile j landed for every wave; every wave is done reading buffer buf^1
+    if (j + 1 < nt) issue(j + 1, buf ^ 1);
     const char* tb = reinterpret_cast<const char*>(tiles + buf * kTileFloats) + col * (kRowStrideF * 4) + half * 256;
     uint4 ah[4], al[4];
 #pragma unroll
@@ -255,18 +250,18 @@ __global__ __launch_bounds__(kScanWaves * 64, 2) void scan3_kernel(const uint4* 
 #pragma unroll
     for (int r = 0; r < 16; ++r) cur[r] = 0.f;
     constexpr int VPM = (L + 2 + 2) / 3;
-    tile_mfma_bf16_sel<L, VPM, 0, 16>(tb, qh, ql, cur, prev, vmask, (t - 1 - t0) << 4, pinf, ls, ah, al);
+    tile_mfma_bf16_sel<L, VPM, 0, 16>(tb, qh, ql, cur, prev, vmask, (j - 1) << 4, pinf, ls, ah, al);
   };
 
-  if (t0 < t1) issue(t0, 0);
-  for (int t = t0; t < t1; t += 2) {
-    step(t, 0, accA, accB);
-    if (t + 1 < t1) step(t + 1, 1, accB, accA);
+  if (nt > 0) issue(0, 0);
+  for (int j = 0; j < nt; j += 2) {
+    step(j, 0, accA, accB);
+    if (j + 1 < nt) step(j + 1, 1, accB, accA);
   }
-  if (t0 < t1) {  // the last tile's scores are still in registers; only here can rows be >= n_rows
-    const int row0 = (t1 - 1) * kTileRows + 4 * half;
-    const int code0 = (t1 - 1 - t0) << 4;
-    if ((t1 - t0) & 1) {
+  if (nt > 0) {  // the last tile's scores are still in registers; only here can rows be >= n_rows
+    const int row0 = (sp + (nt - 1) * nsplit) * kTileRows + 4 * half;
+    const int code0 = (nt - 1) << 4;
+    if (nt & 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2);
@@ -288,11 +283,141 @@ __global__ __launch_bounds__(kScanWaves * 64, 2) void scan3_kernel(const uint4* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// scanw: the wide split-bf16 scan — ONE workgroup (4 waves = one wave per SIMD) per CU, 64 queries per wave.
+//
+// Why: at 32 queries per wave the LDS feeds the MFMAs at 2/3 of a 16-byte read per MFMA, i.e. 83 % of a CU's LDS
+// bandwidth at the full MFMA rate, and scan3 hides its barrier / DMA-issue / first-read phases behind a second
+// wave on the same SIMD whose VALU stream slows the first wave's MFMAs (measured; scan3 reaches 40 % MFMA busy).
+// Here a wave holds two query fragments (256 operand registers; the unified 512-entry file of a single wave per
+// SIMD), every DB fragment read feeds 6 MFMAs on two independent accumulator chains, and everything else is
+// software-pipelined INSIDE the one wave: the fragment ring runs across the tile boundary, the tile NBUF-1 ahead
+// is DMA'd while the current one multiplies, the previous tile's scores enter the per-lane lists in the MFMA
+// shadow. One barrier per tile, placed where nothing waits on it (the tile it releases landed a tile-time ago).
+//   grid = ceil(Q/256) * nsplit; block b -> split b % nsplit (tiles sp, sp + nsplit, ...); LDS NBUF x 33 KiB.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWideQPerWave = 64;
+constexpr int kWideQPerBlock = 4 * kWideQPerWave;
+
+template <int LL, int NBUF>
+__global__ __launch_bounds__(256, 1) void scanw_kernel(const uint4* __restrict__ dbs, int n_rows, int n_tiles, int code_bits,
+                                                       const float* __restrict__ q, int Q, int nsplit,
+                                                       float* __restrict__ cand, int32_t* __restrict__ fb_count,
+                                                       int zero_counts, float pinf) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, col = lane & 31;
+  const int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
+  const int nt = sp < n_tiles ? (n_tiles - sp + nsplit - 1) / nsplit : 0;
+  const int qrow0 = qb * kWideQPerBlock + wave * kWideQPerWave + col, qrow1 = qrow0 + 32;
+  const int mask = ~((1 << code_bits) - 1);
+  int vmask = mask;
+  asm volatile("" : "+v"(vmask));
+  if (zero_counts && blockIdx.x == 0 && tid < 2) fb_count[tid] = 0;
+  if (nt == 0) return;  // (the host never launches an empty split)
+  const int uwave = uniform_wave_id();
+
+  // LDS-DMA of this wave's 8 rows of the split's j-th tile (clamped: the pipeline over-issues NBUF-1 tiles at the end,
+  // into buffers nobody reads any more; the final s_waitcnt keeps them from outliving the workgroup)
+  auto dma_of = [&](int j, int buf) {
+    const int tile = sp + min(j, nt - 1) * nsplit;
+    WideDma d;
+    d.src = reinterpret_cast<const char*>(dbs) + ((size_t)tile * kTileRows + uwave * 8) * 1024;
+    d.dst = lds_addr_of(smem + buf * kTileFloats + uwave * 8 * kRowStrideF);
+    d.lane16 = lane * 16;
+    return d;
+  };
+#pragma unroll
+  for (int b = 0; b < NBUF - 1; ++b) {
+    const WideDma d = dma_of(b, b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d.row(i);
+  }
+
+  u32x4 qh0[16], ql0[16], qh1[16], ql1[16];  // 256 AGPRs
+  {
+    const float4* qp0 = reinterpret_cast<const float4*>(q + (size_t)min(qrow0, Q - 1) * kD + half * 128);
+    const float4* qp1 = reinterpret_cast<const float4*>(q + (size_t)min(qrow1, Q - 1) * kD + half * 128);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      uint4 h, l;
+      split8(qp0[2 * s], qp0[2 * s + 1], h, l);
+      qh0[s] = pin_agpr(as_u32x4(h));
+      ql0[s] = pin_agpr(as_u32x4(l));
+      split8(qp1[2 * s], qp1[2 * s + 1], h, l);
+      qh1[s] = pin_agpr(as_u32x4(h));
+      ql1[s] = pin_agpr(as_u32x4(l));
+    }
+  }
+  WideLists<LL> w;
+#pragma unroll
+  for (int i = 0; i < LL; ++i) w.ls0[i] = w.ls1[i] = T2L_NEG_INF;
+  w.key0 = w.key1 = T2L_NEG_INF;
+  f32x16 accA0, accA1, accB0, accB1;  // tile j / tile j+1, per query group
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accA0[r] = accA1[r] = accB0[r] = accB1[r] = T2L_NEG_INF;
+
+  const int lane_off = col * (kRowStrideF * 4) + half * 256;
+  const char* lbase = reinterpret_cast<const char*>(smem) + lane_off;
+  u32x4 ah[4], al[4];
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(8 * (NBUF - 2)) : "memory");  // tile 0 landed for every wave
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ah[i] = *reinterpret_cast<const u32x4*>(lbase + 16 * i);
+    al[i] = *reinterpret_cast<const u32x4*>(lbase + 512 + 16 * i);
+  }
+
+  int buf = 0;  // buffer of tile j; tile j+1 is in buf+1, the DMA target (tile j+NBUF-1) is buf-1 (mod NBUF)
+  auto step = [&](int j, f32x16& cur0, f32x16& cur1, const f32x16& prev0, const f32x16& prev1) {
+    const int nbuf = buf + 1 == NBUF ? 0 : buf + 1;
+    const int dbuf = buf == 0 ? NBUF - 1 : buf - 1;
+    const char* tb = lbase + buf * (kTileFloats * 4);
+    const char* tbn = lbase + nbuf * (kTileFloats * 4);
+    const WideDma d = dma_of(j + NBUF - 1, dbuf);
+    tilew_steps<LL, 0, 12>(tb, tbn, qh0, ql0, qh1, ql1, cur0, cur1, prev0, prev1, vmask, (j - 1) << 4, pinf, w, ah, al, d);
+    // tile j+1 (issued NBUF-2 tiles ago) has landed for this wave; after the barrier it has for every wave, and every
+    // wave is past its last read of tile j-1, whose buffer the DMA below refills
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(8 * (NBUF - 3)) : "memory");
+    tilew_steps<LL, 12, 16>(tb, tbn, qh0, ql0, qh1, ql1, cur0, cur1, prev0, prev1, vmask, (j - 1) << 4, pinf, w, ah, al, d);
+    buf = nbuf;
+  };
+  for (int j = 0; j < nt; j += 2) {
+    step(j, accA0, accA1, accB0, accB1);
+    if (j + 1 < nt) step(j + 1, accB0, accB1, accA0, accA1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // over-issued DMA rows must not land in LDS after the workgroup is gone
+
+  {  // the last tile's scores are still in registers; only here can rows be >= n_rows
+    const int row0 = (sp + (nt - 1) * nsplit) * kTileRows + 4 * half;
+    const int code0 = (nt - 1) << 4;
+    const bool odd = nt & 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool ok = row0 + (r & 3) + 8 * (r >> 2) < n_rows;
+      const float s0 = odd ? accA0[r] : accB0[r], s1 = odd ? accA1[r] : accB1[r];
+      ins_key<LL>(w.ls0, ok ? make_key(s0, mask, code0 + r) : T2L_NEG_INF);
+      ins_key<LL>(w.ls1, ok ? make_key(s1, mask, code0 + r) : T2L_NEG_INF);
+    }
+  }
+  const int part = 2 * sp + half, parts = 2 * nsplit;
+  if (qrow0 < Q) {
+    float4* out = reinterpret_cast<float4*>(cand + ((size_t)qrow0 * parts + part) * LL);
+#pragma unroll
+    for (int i = 0; i < LL / 4; ++i) out[i] = make_float4(w.ls0[4 * i], w.ls0[4 * i + 1], w.ls0[4 * i + 2], w.ls0[4 * i + 3]);
+  }
+  if (qrow1 < Q) {
+    float4* out = reinterpret_cast<float4*>(cand + ((size_t)qrow1 * parts + part) * LL);
+#pragma unroll
+    for (int i = 0; i < LL / 4; ++i) out[i] = make_float4(w.ls1[4 * i], w.ls1[4 * i + 1], w.ls1[4 * i + 2], w.ls1[4 * i + 3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // rerank (stage 1): one wave per query, 4 queries per 256-thread block.
 // ------------------------------------------------------------------------------------------------
-template <int L>
+// LL = length of the per-lane lists the scan wrote, L = rows re-scored per query (LL <= L).
+template <int LL, int L>
 __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ db, const float* __restrict__ q, int Q,
-                                                     int K, int parts, int per, int code_bits,
+                                                     int K, int parts, int code_bits,
                                                      const float* __restrict__ cand, int row_offset, float eps_rel,
                                                      const float* __restrict__ db_norm_max,
                                                      int32_t* __restrict__ out_idx, double* __restrict__ out_score,
@@ -302,11 +427,11 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
   if (qid >= Q) return;
 
   // ---- every lane pulls its whole sorted key list into registers (one memory latency for the merge)
-  float lst[L];
+  float lst[LL];
   {
-    const float4* mine = reinterpret_cast<const float4*>(cand + ((size_t)qid * parts + min(lane, parts - 1)) * L);
+    const float4* mine = reinterpret_cast<const float4*>(cand + ((size_t)qid * parts + min(lane, parts - 1)) * LL);
 #pragma unroll
-    for (int i = 0; i < L / 4; ++i) {
+    for (int i = 0; i < LL / 4; ++i) {
       const float4 v = mine[i];
       lst[4 * i] = v.x;
       lst[4 * i + 1] = v.y;
@@ -315,9 +440,11 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
     }
     if (lane >= parts) {
 #pragma unroll
-      for (int i = 0; i < L; ++i) lst[i] = T2L_NEG_INF;
+      for (int i = 0; i < LL; ++i) lst[i] = T2L_NEG_INF;
     }
   }
+  // a FULL list dropped rows inside its lane: all of them have key <= its floor (-inf when nothing was dropped)
+  const float floor_max = wave_max_f32(lst[LL - 1], pinf);
   const float4 qv = reinterpret_cast<const float4*>(q + (size_t)qid * kD)[lane];
 
   // ---- merge the `parts` lists into the top-L keys: L rounds of wave arg-max over the list heads
@@ -330,15 +457,17 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
     const int bl = __ffsll((long long)who) - 1;  // equal keys: lowest part first
     if (lane == r) {
       my_key = bk;
-      my_row = bk == T2L_NEG_INF ? INT_MAX : key_row(bk, bl, per, code_bits);
+      my_row = bk == T2L_NEG_INF ? INT_MAX : key_row(bk, bl, parts >> 1, code_bits);
     }
     if (lane == bl) {  // the winner pops its head (register shift, no memory)
 #pragma unroll
-      for (int i = 0; i < L - 1; ++i) lst[i] = lst[i + 1];
-      lst[L - 1] = T2L_NEG_INF;
+      for (int i = 0; i < LL - 1; ++i) lst[i] = lst[i + 1];
+      lst[LL - 1] = T2L_NEG_INF;
     }
   }
-  const float g = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_key), L - 1));  // every row that is NOT re-scored has key <= g
+  // every row that is NOT re-scored has key <= g: kept rows lie at or below the L-th merged key, rows dropped inside a
+  // lane at or below that lane's floor (with LL == L a floor above the L-th key cannot happen; with LL < L it can)
+  const float g = fmaxf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_key), L - 1)), floor_max);
 
   // ---- float64 re-score of the selected rows (products of f32 values are exact in f64): all L row gathers are
   // issued before the first reduction
@@ -402,7 +531,7 @@ constexpr int kMaxCand = kMaxParts * 32;  // parts * L upper bound
 
 template <int L>
 __global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__ db, int n_rows,
-                                                       const float* __restrict__ q, int Q, int K, int parts, int per,
+                                                       const float* __restrict__ q, int Q, int K, int parts,
                                                        int code_bits, const float* __restrict__ cand, int row_offset,
                                                        float eps_rel, const float* __restrict__ db_norm_max,
                                                        const int32_t* __restrict__ flags,
@@ -430,7 +559,7 @@ __global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__
     double d = -__builtin_inf();
     int row = INT_MAX;
     if (key != T2L_NEG_INF) {
-      row = key_row(key, c / L, per, code_bits);
+      row = key_row(key, c / L, parts >> 1, code_bits);
       d = wave_dot64(db, row, qv, lane);
     }
     if (lane == 0) {
@@ -658,60 +787,65 @@ int db_norm_impl(t2l_ctx* ctx, hipStream_t s) {
 }
 
 
-template <int L>
-static void launch_scan(t2l_ctx* ctx, dim3 grid, size_t lds, hipStream_t s, const float* db, int n_rows, int n_tiles,
-                        int per, int code_bits, const float* q, int Q, int nsplit, int zero) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((scan_kernel<L>), grid, dim3(256), lds, s, db, n_rows, n_tiles, per, code_bits, q, Q, nsplit,
-                     ctx->cand_score, ctx->fb_count, zero);
-}
-
 static size_t scan_lds_bytes() { return (size_t)2 * kTileFloats * sizeof(float); }
 
-template <int L>
-static void launch_scan3(t2l_ctx* ctx, dim3 grid, hipStream_t s, const uint4* dbs, int n_rows, int n_tiles, int per,
-                         int code_bits, const float* q, int Q, int nsplit, int zero) {
-  const size_t lds = scan_lds_bytes();
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan3_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((scan3_kernel<L>), grid, dim3(kScanWaves * 64), lds, s, dbs, n_rows, n_tiles, per, code_bits, q, Q,
-                     nsplit, ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
+template <typename Kern>
+static void allow_lds(Kern* kern, size_t lds) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-template <int L>
+// scan (by search_mode) -> re-rank -> fallback on one stream. LL = per-lane list length the scan keeps, L = rows the
+// re-rank re-scores per query.
+template <int LL, int L>
 static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, int n_rows, int row_offset, const float* q,
-                         int Q, int K, int nsplit, int per, int code_bits, int32_t* out_idx, double* out_score,
-                         bool first, hipStream_t s) {
+                         int Q, int K, int nsplit, int code_bits, int32_t* out_idx, double* out_score, bool first,
+                         hipStream_t s) {
   const int n_tiles = (n_rows + kTileRows - 1) / kTileRows;
-  const int n_qblocks = (Q + kQPerBlock - 1) / kQPerBlock;
   const int parts = 2 * nsplit;
+  const int zero = first;
   event_begin(ctx, "search_scan", s);
-  const dim3 grid(n_qblocks * nsplit);
-  if (ctx->search_mode == 0)  // split-bf16 MFMA scan (default)
-    launch_scan3<L>(ctx, grid, s, dbs, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first);
-  else  // exact-f32 MFMA scan
-    launch_scan<L>(ctx, grid, scan_lds_bytes(), s, db, n_rows, n_tiles, per, code_bits, q, Q, nsplit, first);
+  if (ctx->search_mode == 0) {  // wide split-bf16 MFMA scan (default): one workgroup per CU, 256 queries each
+    const dim3 grid((Q + kWideQPerBlock - 1) / kWideQPerBlock * nsplit);
+    if (ctx->wide_nbuf == 3) {
+      const size_t lds = (size_t)3 * kTileFloats * sizeof(float);
+      static bool once = (allow_lds(&scanw_kernel<LL, 3>, (size_t)3 * kTileFloats * sizeof(float)), true);
+      (void)once;
+      hipLaunchKernelGGL((scanw_kernel<LL, 3>), grid, dim3(256), lds, s, dbs, n_rows, n_tiles, code_bits, q, Q, nsplit,
+                         ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
+    } else {
+      const size_t lds = (size_t)4 * kTileFloats * sizeof(float);
+      static bool once = (allow_lds(&scanw_kernel<LL, 4>, (size_t)4 * kTileFloats * sizeof(float)), true);
+      (void)once;
+      hipLaunchKernelGGL((scanw_kernel<LL, 4>), grid, dim3(256), lds, s, dbs, n_rows, n_tiles, code_bits, q, Q, nsplit,
+                         ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
+    }
+  } else if constexpr (LL == L) {
+    const dim3 grid((Q + kQPerBlock - 1) / kQPerBlock * nsplit);
+    const size_t lds = scan_lds_bytes();
+    if (ctx->search_mode == 2) {  // split-bf16 scan, 32 queries per wave, two workgroups per CU
+      static bool once = (allow_lds(&scan3_kernel<L>, scan_lds_bytes()), true);
+      (void)once;
+      hipLaunchKernelGGL((scan3_kernel<L>), grid, dim3(kScanWaves * 64), lds, s, dbs, n_rows, n_tiles, code_bits, q, Q,
+                         nsplit, ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
+    } else {  // exact-f32 MFMA scan
+      static bool once = (allow_lds(&scan_kernel<L>, scan_lds_bytes()), true);
+      (void)once;
+      hipLaunchKernelGGL((scan_kernel<L>), grid, dim3(256), lds, s, db, n_rows, n_tiles, code_bits, q, Q, nsplit,
+                         ctx->cand_score, ctx->fb_count, zero);
+    }
+  }
   event_end(ctx, "search_scan", s);
   T2L_HIP(ctx, hipGetLastError());
   // f32 dot-product error bound: gamma_n * |a||b| with n = 256 terms (+ slack for the MFMA's k order)
-  // (+ the split-bf16 product error 2^-16 + 2^-18, rounded up, when the bf16x3 scan produced the keys)
+  // (+ the split-bf16 product error 2^-16 + 2^-18, rounded up, when a bf16x3 scan produced the keys)
   const float eps_rel = (float)(ctx->eps_scale *
                                 ((kD + 8) * 5.9604644775390625e-08 + (ctx->search_mode != 1 ? 2.0e-5 : 0.0)));
   event_begin(ctx, "search_rerank", s);
-  hipLaunchKernelGGL(rerank_kernel<L>, dim3((Q + 3) / 4), dim3(256), 0, s, db, q, Q, K, parts, per, code_bits,
+  hipLaunchKernelGGL((rerank_kernel<LL, L>), dim3((Q + 3) / 4), dim3(256), 0, s, db, q, Q, K, parts, code_bits,
                      ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, out_idx, out_score, ctx->flags,
                      __builtin_inff());
   T2L_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(fallback_kernel<L>, dim3(min(Q, 512)), dim3(256), 0, s, db, n_rows, q, Q, K, parts, per, code_bits,
+  hipLaunchKernelGGL(fallback_kernel<LL>, dim3(min(Q, 512)), dim3(256), 0, s, db, n_rows, q, Q, K, parts, code_bits,
                      ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, ctx->flags, out_idx, out_score,
                      ctx->fb_count);
   event_end(ctx, "search_rerank", s);
@@ -729,10 +863,11 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
   // few queries against a large shard: stream the DB once through every CU (search_stream.hip)
   if (Q <= 64 && n_rows >= ctx->stream_min_rows && n_rows > 0 && ctx->search_mode == 0 && ctx->nsplit_override == 0)
     return search_stream_impl(ctx, q, Q, K, out_idx, out_score, s);
-  const int qpb = kQPerBlock;
+  const bool wide = ctx->search_mode == 0;
+  const int qpb = wide ? kWideQPerBlock : kQPerBlock;
   const int n_qblocks = (Q + qpb - 1) / qpb;
-  // per-lane list length: K + margin (the margin only has to absorb key-truncation ties; the certificate
-  // catches the rest). (L = 12 was measured: 9 % less scan time, but second-stage re-scores multiply: slower overall.)
+  // rows re-scored per query: K + margin (the margin only has to absorb key-truncation ties; the certificate catches
+  // the rest). (L = 12 was measured: second-stage re-scores multiply.)
   const int L = (K <= 10) ? 16 : 32;
   const int n_seg = max(1, (n_rows + kSegmentRows - 1) / kSegmentRows);
   if (n_seg * K > 256)
@@ -753,8 +888,9 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     const int n_tiles = (max(rows, 0) + kTileRows - 1) / kTileRows;
     int nsplit = ctx->nsplit_override;
     if (nsplit <= 0) {
-      // 2 workgroups (4 waves) per CU x 256 CUs; multiples of 8 keep a split on one XCD's L2.
-      nsplit = (512 + n_qblocks - 1) / n_qblocks;
+      // fill 256 CUs with one (wide scan) or two workgroups each; multiples of 8 keep a split on one XCD's L2
+      const int want = wide ? 256 : 512;
+      nsplit = (want + n_qblocks - 1) / n_qblocks;
       nsplit = ((nsplit + 7) / 8) * 8;
     }
     nsplit = max(1, min(nsplit, kMaxParts / 2));
@@ -763,7 +899,12 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     const int per = max(1, (n_tiles + nsplit - 1) / nsplit);
     int code_bits = 4;
     while ((1 << code_bits) < per * 16) ++code_bits;
-    const size_t need = (size_t)n_qblocks * qpb * 2 * nsplit * L * sizeof(float);
+    // per-lane list length of the wide scan: the global top-L spreads over 2*nsplit lists (tiles are dealt round-robin
+    // to the splits, 4-row groups alternate between the lane halves), so 8 per list hold it unless more than 8 of a
+    // query's best 16 fall into ONE list — with >= 16 lists a ~1e-8 event on unstructured data; the certificate
+    // (floors of full lists) catches it and the fallback re-scores. Few lists (tiny shards): keep 16.
+    const int LL = !wide ? L : (L == 32 ? 32 : (2 * nsplit >= 16 ? 8 : 16));
+    const size_t need = (size_t)n_qblocks * qpb * 2 * nsplit * LL * sizeof(float);
     if ((rc = grow(ctx, (void**)&ctx->cand_score, &ctx->cand_cap, need)) != T2L_OK) return rc;
     if (n_seg > 1) {
       seg_idx = ctx->seg_idx + (size_t)seg * Q * K;
@@ -772,10 +913,10 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     const float* db = ctx->db + (size_t)row0 * kD;
     const uint4* dbs = ctx->db_split ? ctx->db_split + (size_t)row0 * 64 : nullptr;
     const int off = (int)ctx->row_offset + row0;
-    rc = (L == 16) ? launch_search<16>(ctx, db, dbs, max(rows, 0), off, q, Q, K, nsplit, per, code_bits, seg_idx,
-                                       seg_score, seg == 0, s)
-                   : launch_search<32>(ctx, db, dbs, max(rows, 0), off, q, Q, K, nsplit, per, code_bits, seg_idx,
-                                       seg_score, seg == 0, s);
+#define T2L_SEARCH(LLv, Lv) \
+  launch_search<LLv, Lv>(ctx, db, dbs, max(rows, 0), off, q, Q, K, nsplit, code_bits, seg_idx, seg_score, seg == 0, s)
+    rc = LL == 8 ? T2L_SEARCH(8, 16) : (L == 16 ? T2L_SEARCH(16, 16) : T2L_SEARCH(32, 32));
+#undef T2L_SEARCH
     if (rc != T2L_OK) return rc;
   }
   if (n_seg > 1) return merge_impl(ctx, ctx->seg_idx, ctx->seg_score, n_seg, Q, K, out_idx, out_score, s);

@@ -32,15 +32,15 @@ __device__ __forceinline__ float make_key(float v, int mask, int code) {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned bf16_rne_bits(float x) {
-  const unsigned u = __float_as_uint(x);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
+// x -> (hi, lo) bf16 pair with hi = RNE_bf16(x), lo = RNE_bf16(x - hi), two values per call packed low|high:
+// v_cvt_pk_bf16_f32 rounds both lanes in one instruction (5 VALU per pair instead of ~26 for integer rounding — the
+// query split in a scan's prologue is 64 x 8 values per lane and was 15 % of the whole kernel).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
-  const unsigned h0 = bf16_rne_bits(x0), h1 = bf16_rne_bits(x1);
-  const unsigned l0 = bf16_rne_bits(x0 - __uint_as_float(h0 << 16)), l1 = bf16_rne_bits(x1 - __uint_as_float(h1 << 16));
-  hi = h0 | (h1 << 16);
-  lo = l0 | (l1 << 16);
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+  const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xFFFF0000u);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0 - h0, x1 - h1}, bf16x2));
 }
 __device__ __forceinline__ void split8(const float4 a, const float4 b, uint4& hi, uint4& lo) {
   split_pair(a.x, a.y, hi.x, lo.x);
@@ -92,6 +92,131 @@ __device__ __forceinline__ void tile_mfma_bf16_sel(const char* tb, const uint4 (
     }
     if constexpr (S + 4 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     tile_mfma_bf16_sel<L, VPM, S + 1, S_END>(tb, qh, ql, cur, prev, vmask, code0, pinf, ls, ah, al);
+  }
+}
+
+
+// ---- LDS-DMA: global_load_lds_dwordx4, one wave-instruction moves 64 x 16 B = one 1 KiB DB row into LDS (M0 = the
+// row's LDS address, the hardware adds lane*16). Issued from inline asm ON PURPOSE: for the compiler's builtin,
+// SIInsertWaitcnts makes every later LDS read wait for vmcnt(0) ("may alias the DMA's LDS write"), i.e. the wave sits out
+// the whole L2 round trip of the NEXT tile before it touches the CURRENT one and the double buffer buys nothing
+// (visible in the ISA as `s_waitcnt vmcnt(0)` between the DMA burst and the first ds_read). The kernels order DMA
+// against LDS reads themselves: explicit s_waitcnt vmcnt(n) + s_barrier before a buffer is read.
+// `row_base` must be wave-uniform (SGPR pair).
+__device__ __forceinline__ void lds_dma_row(unsigned lds_row_addr, unsigned lane16, const void* row_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_row_addr), "v"(lane16), "s"(row_base)
+               : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ int uniform_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// ---- the wide tile body (scanw_kernel): a wave holds TWO 32-query fragments, so every DB fragment read from LDS
+// feeds 6 MFMAs (hi*hi, hi*lo, lo*hi for each query group) on two independent accumulator chains, and per k-step
+// one score of the previous tile of EACH group enters that group's list: 2*(1 + LL) VALU ops in the shadows of 6 MFMAs.
+//
+// Register plan (one wave per SIMD = the unified 512-entry file): the 64 query fragments fill ALL 256 AGPRs and are
+// read by the MFMAs in place; accumulators, key lists and the LDS fragment ring live in VGPRs where the VALU can
+// reach them. The compiler does not find that split by itself (it parks fragments in AGPRs and copies them back with
+// v_accvgpr_read before every use, and its sched_group_barrier solver then gives up and emits all MFMAs followed by
+// all insertions), so the MFMAs are inline asm with explicit register classes and the instruction order is written
+// out by hand: asm volatile keeps MFMAs / DMA / waits in program order, sched_barrier(0) pins the VALU and LDS
+// instructions between them. Inline-asm MFMAs are invisible to the hazard recogniser; by construction a score is
+// read by the VALU no earlier than two MFMA issues (64+ cycles) after the MFMA that wrote it, and accumulators
+// start from the constant-0 srcC form instead of being zeroed by the VALU.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void mfma_bf16_first(f32x16& acc, const u32x4& a, const u32x4& b_agpr) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b_agpr));
+}
+__device__ __forceinline__ void mfma_bf16_acc(f32x16& acc, const u32x4& a, const u32x4& b_agpr) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b_agpr));
+}
+__device__ __forceinline__ u32x4 pin_agpr(u32x4 v) {  // from here on the value lives in an AGPR tuple
+  u32x4 r;
+  asm volatile("" : "=a"(r) : "0"(v));
+  return r;
+}
+__device__ __forceinline__ u32x4 as_u32x4(const uint4 v) { return u32x4{v.x, v.y, v.z, v.w}; }
+
+struct WideDma {
+  const char* src;  // wave-uniform global address of row 8*wave of the tile
+  unsigned dst;     // LDS byte address of row 8*wave of the target buffer
+  unsigned lane16;  // lane * 16
+  __device__ __forceinline__ void row(int i) const { lds_dma_row(dst + i * (kRowStrideF * 4), lane16, src + i * 1024); }
+};
+
+template <int LL>
+struct WideLists {
+  float ls0[LL], ls1[LL];  // sorted key lists of the two query groups
+  float key0, key1;        // keys in flight
+};
+
+// VALU op O (of 2*LL + 2) of inserting score S of both groups: 0 = key0, 1..LL = list 0 from its tail to its head,
+// LL+1 = key1, LL+2..2LL+1 = list 1. Every list element reads OLD neighbours only, so the order tail -> head is in place.
+template <int LL, int S, int O>
+__device__ __forceinline__ void wide_sel_op(WideLists<LL>& w, const f32x16& prev0, const f32x16& prev1, int vmask, int code,
+                                            float pinf) {
+  if constexpr (O == 0) {
+    w.key0 = __int_as_float((__float_as_int(prev0[S]) & vmask) | code);
+  } else if constexpr (O <= LL) {
+    constexpr int I = LL - O;
+    if constexpr (I == 0) w.ls0[0] = __builtin_amdgcn_fmed3f(w.ls0[0], w.key0, pinf);
+    else w.ls0[I] = __builtin_amdgcn_fmed3f(w.ls0[I - 1], w.ls0[I], w.key0);
+  } else if constexpr (O == LL + 1) {
+    w.key1 = __int_as_float((__float_as_int(prev1[S]) & vmask) | code);
+  } else if constexpr (O <= 2 * LL + 1) {
+    constexpr int I = 2 * LL + 1 - O;
+    if constexpr (I == 0) w.ls1[0] = __builtin_amdgcn_fmed3f(w.ls1[0], w.key1, pinf);
+    else w.ls1[I] = __builtin_amdgcn_fmed3f(w.ls1[I - 1], w.ls1[I], w.key1);
+  }
+}
+template <int LL, int S, int O, int O_END>
+__device__ __forceinline__ void wide_sel_ops(WideLists<LL>& w, const f32x16& prev0, const f32x16& prev1, int vmask, int code,
+                                             float pinf) {
+  if constexpr (O < O_END && O < 2 * LL + 2) {
+    wide_sel_op<LL, S, O>(w, prev0, prev1, vmask, code, pinf);
+    wide_sel_ops<LL, S, O + 1, O_END>(w, prev0, prev1, vmask, code, pinf);
+  }
+}
+
+// k-steps [S, S_END) of one tile. Ring slot S&3 holds fragment S; the prefetch runs 4 k-steps ahead and crosses into the
+// NEXT tile's buffer (tbn) at S >= 12, where the wave also issues its 8 LDS-DMA rows of the tile NBUF-1 ahead.
+template <int LL, int S, int S_END>
+__device__ __forceinline__ void tilew_steps(const char* tb, const char* tbn, const u32x4 (&qh0)[16], const u32x4 (&ql0)[16],
+                                            const u32x4 (&qh1)[16], const u32x4 (&ql1)[16], f32x16& cur0, f32x16& cur1,
+                                            const f32x16& prev0, const f32x16& prev1, int vmask, int code0, float pinf,
+                                            WideLists<LL>& w, u32x4 (&ah)[4], u32x4 (&al)[4], const WideDma& dma) {
+  if constexpr (S < S_END) {
+    constexpr int VPM = (2 * LL + 2 + 5) / 6;
+    const u32x4 a_hi = ah[S & 3], a_lo = al[S & 3];
+    const char* nx = (S + 4 < 16) ? tb + 16 * (S + 4) : tbn + 16 * (S + 4 - 16);
+    const int code = __builtin_amdgcn_readfirstlane(code0 + S);
+#define T2L_GAP(e)                                                                         \
+  __builtin_amdgcn_sched_barrier(0);                                                   \
+  wide_sel_ops<LL, S, (e) * VPM, ((e) + 1) * VPM>(w, prev0, prev1, vmask, code, pinf); \
+  __builtin_amdgcn_sched_barrier(0)
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S == 0) mfma_bf16_first(cur0, a_hi, qh0[S]); else mfma_bf16_acc(cur0, a_hi, qh0[S]);
+    ah[S & 3] = *reinterpret_cast<const u32x4*>(nx);
+    T2L_GAP(0);
+    if constexpr (S == 0) mfma_bf16_first(cur1, a_hi, qh1[S]); else mfma_bf16_acc(cur1, a_hi, qh1[S]);
+    al[S & 3] = *reinterpret_cast<const u32x4*>(nx + 512);
+    T2L_GAP(1);
+    mfma_bf16_acc(cur0, a_hi, ql0[S]);
+    if constexpr (S >= 12) dma.row(2 * (S - 12));
+    T2L_GAP(2);
+    mfma_bf16_acc(cur1, a_hi, ql1[S]);
+    T2L_GAP(3);
+    mfma_bf16_acc(cur0, a_lo, qh0[S]);
+    if constexpr (S >= 12) dma.row(2 * (S - 12) + 1);
+    T2L_GAP(4);
+    mfma_bf16_acc(cur1, a_lo, qh1[S]);
+    T2L_GAP(5);
+#undef T2L_GAP
+    tilew_steps<LL, S + 1, S_END>(tb, tbn, qh0, ql0, qh1, ql1, cur0, cur1, prev0, prev1, vmask, code0, pinf, w, ah, al,
+                                  dma);
   }
 }
 
@@ -150,11 +275,12 @@ __device__ __forceinline__ double wave_sum_f64(double v) {  // every lane gets t
   return v;
 }
 
-// key -> local DB row. part = 2*split + half.
-__device__ __forceinline__ int key_row(float key, int part, int per, int code_bits) {
+// key -> local DB row. part = 2*split + half; split sp owns tiles sp, sp + nsplit, sp + 2*nsplit, ... (interleaved, so a
+// run of similar neighbouring rows spreads over all the per-lane lists instead of filling one).
+__device__ __forceinline__ int key_row(float key, int part, int nsplit, int code_bits) {
   const int code = __float_as_int(key) & ((1 << code_bits) - 1);
   const int r = code & 15;
-  return (((part >> 1) * per + (code >> 4)) << 5) + (r & 3) + 8 * (r >> 2) + 4 * (part & 1);
+  return (((code >> 4) * nsplit + (part >> 1)) << 5) + (r & 3) + 8 * (r >> 2) + 4 * (part & 1);
 }
 
 // float64 dot of DB row `row` with the query fragment held by the wave (lane owns dims 4*lane..4*lane+3)

@@ -73,7 +73,8 @@ struct t2l_ctx {
   // options
   double eps_scale = 1.0;
   int nsplit_override = 0;
-  int search_mode = 0;   // 0 = split-bf16 MFMA scan (default), 1 = exact-f32 MFMA scan
+  int search_mode = 0;   // 0 = wide split-bf16 MFMA scan (default), 1 = exact-f32 MFMA scan, 2 = narrow split-bf16 scan
+  int wide_nbuf = 4;     // LDS tile buffers of the wide scan (3 or 4)
   int stream_min_rows = 65536;  // shards at least this large answer batches of <= 64 queries with the streaming scan
   bool profile_events = false;
   std::unordered_map<std::string, t2l::EventRing> events;
