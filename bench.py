@@ -406,8 +406,7 @@ def main():
     ap.add_argument("--cells", type=int, default=N_CELLS, help="dev: database rows (default = the BASELINE workload)")
     ap.add_argument("--queries", type=int, default=N_QUERIES, help="dev: queries per step")
     ap.add_argument("--mode", type=int, default=0,
-                    help="search_mode: 0 = wide split-bf16 scan (default), 1 = f32 scan, 2 = narrow split-bf16 scan")
-    ap.add_argument("--nbuf", type=int, default=0, help="LDS tile buffers of the wide scan (3 or 4; 0 = library default)")
+                    help="search_mode: 0 = f16 scan (default), 1 = f32 scan, 2 = split-bf16 scan")
     ap.add_argument("--nsplit", type=int, default=0, help="override the scan kernel's DB split count (0 = auto)")
     args = ap.parse_args()
 
@@ -436,8 +435,6 @@ def main():
     lo, hi = searcher.set_db_shard(d_db)
     eng.set_option("profile_events", 1)
     eng.set_option("search_mode", args.mode)
-    if args.nbuf:
-        eng.set_option("wide_nbuf", args.nbuf)
     if args.nsplit:
         eng.set_option("search_nsplit", args.nsplit)
 
@@ -465,6 +462,7 @@ def main():
     scan_ms, scan_n = eng.kernel_stats("search_scan")
     rerank_ms, _ = eng.kernel_stats("search_rerank")
     fallbacks = eng.search_fallbacks()
+    rescored = eng.search_rescored()
 
     # parity spot check outside the timed region: ids of a query sample vs the float64 oracle
     from oracle import t2l_oracle as O
@@ -511,9 +509,10 @@ def main():
         achieved = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
         if args.mode == 1:
             kname, peak, dtype, mult = "scan_kernel<16>", F32_MFMA_PEAK_TFLOPS, "f32", 1
+        elif args.mode == 2:
+            kname, peak, dtype, mult = "scanw_kernel<8, 4>", BF16_MFMA_PEAK_TFLOPS, "bf16x3", 3
         else:
-            kname = "scan3_kernel<16>" if args.mode == 2 else "scanw_kernel<8, %d>" % (args.nbuf or 4)
-            peak, dtype, mult = BF16_MFMA_PEAK_TFLOPS, "bf16x3", 3
+            kname, peak, dtype, mult = "scanh_kernel<8>", BF16_MFMA_PEAK_TFLOPS, "f16", 1
         out = {
             "metric": "coarse-retrieval queries/sec over 11k-cell DB, embed_dim=256; top-1/3/5 recall parity",
             "value": N_QUERIES * args.steps / elapsed,
@@ -524,12 +523,14 @@ def main():
             "config": {"workload": "KITTI360Pose-sized val DB: N=11259 cells x D=256 resident in HBM, Q=4096 "
                                    "precomputed text embeddings per step, top-10 (float64-exact ids)",
                        "n_cells": N_CELLS, "queries_per_step": N_QUERIES, "embed_dim": DIM, "top_k": TOPK,
-                       "arithmetic": ("split-bf16 MFMA candidate scan (f32 accumulate) -> float64 re-rank + certificate"
-                                      if args.mode != 1 else "f32 MFMA candidate scan -> float64 re-rank + certificate"),
+                       "arithmetic": {0: "f16 MFMA candidate scan (power-of-two scaled operands, f32 accumulate)",
+                                      1: "f32 MFMA candidate scan",
+                                      2: "split-bf16 (3 MFMAs per product) candidate scan (f32 accumulate)"}[args.mode]
+                                     + " -> float64 re-rank + certificate (ids and scores are the float64 ranking)",
                        "parallelism": f"db-row-shard x{world}" if world > 1 else "single-gpu"},
-            # achieved = ALGORITHMIC flops (2*Q*N*D) / kernel time. In the bf16x3 mode every f32 product is formed by 3
-            # bf16 MFMA products (hi*hi + hi*lo + lo*hi), so the matrix pipe executes 3x the algorithmic flops:
-            # `executed` / `frac_executed` give that view; `peak` is the dense MFMA peak of the dtype the pipe runs in.
+            # achieved = ALGORITHMIC flops (2*Q*N*D) / kernel time; `peak` is the dense MFMA peak of the dtype the pipe runs
+            # in (f16 and bf16 share the 2.5 PF rate). In --mode 2 every product is 3 bf16 MFMA products (hi*hi + hi*lo +
+            # lo*hi): `executed` / `frac_executed` give the matrix pipe's view (mult = 1 for the f16 and f32 scans).
             "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "executed": achieved * mult, "frac_executed": achieved * mult / peak,
@@ -538,7 +539,8 @@ def main():
             "kernels_ms": {"search_scan": scan_ms, "search_rerank+exact": rerank_ms},
             "secondary": secondary,
             "parity": {"ids_equal_float64_oracle_on_sample": parity, "sample": int(len(sel)),
-                       "recall_at_1_planted": recall1, "exact_fallback_queries_last_step": fallbacks},
+                       "recall_at_1_planted": recall1, "exact_fallback_queries_last_step": fallbacks,
+                       "second_stage_rescored_queries_last_step": rescored},
         }
         if alt is not None:
             out["alt_query_sharded"] = alt

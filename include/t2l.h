@@ -179,6 +179,9 @@ int t2l_merge_pairs(t2l_ctx* ctx, const double* pairs, int32_t parts, int32_t n_
 
 /* Number of queries of the LAST t2l_search that took the exact-scan fallback (synchronises). */
 int t2l_search_fallbacks(t2l_ctx* ctx, int32_t* out_count);
+/* Number of queries of the LAST t2l_search whose first certificate failed and whose kept candidates were all re-scored in
+ * float64 (second stage; the exact-scan count above is a subset of these). Synchronises. */
+int t2l_search_rescored(t2l_ctx* ctx, int32_t* out_count);
 
 /* ---- contrastive loss (a8) ------------------------------------------------------------------- */
 /* Replaces: ContrastiveLoss.forward (training/losses.py:269-283) and its autograd backward.

@@ -8,7 +8,7 @@ from text2loc_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1, 2], ids=["bf16x3-wide", "f32", "bf16x3-narrow"])
+@pytest.fixture(scope="module", params=[0, 1, 2], ids=["f16", "f32", "bf16x3"])
 def eng(request):
     """All scan kernels feed the same float64 re-rank + certificate: every test runs against each."""
     import torch
@@ -17,6 +17,7 @@ def eng(request):
     assert torch.cuda.is_available(), "gpu tests need a GPU"
     e = Engine(0)
     e.set_option("search_mode", request.param)
+    e.scan_mode = request.param
     yield e
     e.close()
 
@@ -96,6 +97,59 @@ def test_near_ties_are_certified_or_fall_back(eng):
     ridx, rsc = O.retrieve_topk(db, q, 10)
     assert np.array_equal(idx, ridx)
     assert np.abs(sc - rsc).max() < 1e-12
+
+
+@pytest.mark.parametrize("db_scale,q_scale", [(1.0, 1.0), (3.0e-6, 1.0), (1.0, 7.0e4), (2.5e5, 1.0e-7), (1.0e-20, 1.0e20)])
+def test_scale_invariance(eng, db_scale, q_scale):
+    """The f16 scan rescales DB and queries by exact powers of two: ids must not depend on the magnitudes handed in."""
+    db, qs, _ = synth.make_retrieval_problem(3000, 200, seed=13, noise=2.0)
+    db = (db * np.float32(db_scale)).astype(np.float32)
+    qs = (qs * np.float32(q_scale)).astype(np.float32)
+    qs[5] *= np.float32(1e-3)  # per-query scales differ inside a batch
+    qs[6] *= np.float32(1e3)
+    db[17] *= np.float32(1e-4)  # a row far below the largest one
+    idx, sc = _search(eng, db, qs, 10)
+    ridx, rsc = O.retrieve_topk(db, qs, 10)
+    assert np.array_equal(idx, ridx)
+    assert np.abs(sc - rsc).max() <= 1e-12 * max(1.0, float(np.abs(rsc).max()))
+    if eng.scan_mode == 0 or max(abs(np.log10(db_scale)), abs(np.log10(q_scale))) < 11:
+        assert eng.search_fallbacks() == 0  # representable: nobody needed the exact scan
+    else:  # the f32 / split-bf16 scans multiply the raw values and hand magnitudes beyond 2^+-40 to the exact scan
+        assert eng.search_fallbacks() == len(qs)
+
+
+def test_unrepresentable_inputs_take_the_exact_scan(eng):
+    """Zero / denormal-sized queries (and a denormal-sized DB) have no f16 image: those queries are scanned exactly."""
+    db, qs, _ = synth.make_retrieval_problem(700, 12, seed=14, noise=2.0)
+    qs[3] = 0.0
+    qs[4] = (qs[4] * np.float32(1e-30)).astype(np.float32) * np.float32(1e-12)  # denormal magnitudes
+    idx, sc = _search(eng, db, qs, 10)
+    ridx, rsc = O.retrieve_topk(db, qs, 10)
+    keep = np.array([i for i in range(12) if i != 3])  # the zero query ties everywhere: compare it separately
+    assert np.array_equal(idx[keep], ridx[keep])
+    assert np.array_equal(idx[3], np.arange(10))  # all scores 0: (score desc, row asc)
+    assert np.abs(sc - rsc).max() < 1e-12
+    tiny = (db * np.float32(1e-30)).astype(np.float32) * np.float32(1e-14)  # every element denormal or zero
+    idx, _ = _search(eng, tiny, qs[:3], 10)
+    ridx, _ = O.retrieve_topk(tiny, qs[:3], 10)
+    from oracle import c_oracle
+    ridx, _ = c_oracle.retrieve_topk(tiny, qs[:3], 10)
+    assert np.array_equal(idx, ridx)
+
+
+def test_clustered_scores_use_the_second_stage(eng):
+    """Scores packed ~1e-4 apart: more rows than the re-rank re-scores sit inside the scan's error band, so the
+    certificate fails and the targeted float64 re-score (or the full one) decides — exactly."""
+    rng = np.random.default_rng(23)
+    q = synth.unit_rows(rng.standard_normal((40, 256))).astype(np.float32)
+    base = synth.unit_rows(rng.standard_normal((1, 256)))
+    db = synth.unit_rows(base + 2e-4 * rng.standard_normal((2000, 256))).astype(np.float32)
+    db[::7] = synth.unit_rows(rng.standard_normal((len(db[::7]), 256))).astype(np.float32)  # and unrelated rows between
+    idx, sc = _search(eng, db, q, 10)
+    ridx, rsc = O.retrieve_topk(db, q, 10)
+    assert np.array_equal(idx, ridx)
+    assert np.abs(sc - rsc).max() < 1e-12
+    assert eng.search_rescored() >= eng.search_fallbacks()
 
 
 @pytest.mark.parametrize("nsplit", [1, 3, 8, 32])

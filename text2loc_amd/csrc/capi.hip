@@ -48,12 +48,12 @@ int t2l_create(t2l_ctx** out, int device_id) {
   if (hipSetDevice(device_id) != hipSuccess) return T2L_EHIP;
   t2l_ctx* ctx = new t2l_ctx();
   ctx->device = device_id;
-  if (hipMalloc(&ctx->db_norm_max, sizeof(float)) != hipSuccess ||
+  if (hipMalloc(&ctx->db_norm_max, 2 * sizeof(float)) != hipSuccess ||
       hipMalloc(&ctx->fb_count, 128 * sizeof(int32_t)) != hipSuccess) {
     delete ctx;
     return T2L_ENOMEM;
   }
-  (void)hipMemset(ctx->db_norm_max, 0, sizeof(float));
+  (void)hipMemset(ctx->db_norm_max, 0, 2 * sizeof(float));
   (void)hipMemset(ctx->fb_count, 0, 128 * sizeof(int32_t));
   *out = ctx;
   return T2L_OK;
@@ -67,7 +67,7 @@ void t2l_destroy(t2l_ctx* ctx) {
   free_train(ctx);
   free_pointnet(ctx);
   free_fine(ctx);
-  for (void* p : {(void*)ctx->db, (void*)ctx->db_split, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
+  for (void* p : {(void*)ctx->db, (void*)ctx->db_split, (void*)ctx->db_half, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
                   (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count, ctx->reduce_ws})
     if (p) (void)hipFree(p);
   for (auto& kv : ctx->events) {
@@ -136,11 +136,14 @@ int t2l_db_set(t2l_ctx* ctx, const float* emb, int64_t n_rows, int64_t row_offse
     T2L_HIP(ctx, hipStreamSynchronize(s));
     if (ctx->db) (void)hipFree(ctx->db);
     if (ctx->db_split) (void)hipFree(ctx->db_split);
+    if (ctx->db_half) (void)hipFree(ctx->db_half);
     ctx->db = nullptr;
     ctx->db_split = nullptr;
+    ctx->db_half = nullptr;
     ctx->db_cap = 0;
     T2L_HIP(ctx, hipMalloc(&ctx->db, (size_t)pad * kD * sizeof(float)));
     T2L_HIP(ctx, hipMalloc(&ctx->db_split, (size_t)pad * kD * sizeof(float)));
+    T2L_HIP(ctx, hipMalloc(&ctx->db_half, (size_t)pad * kD * 2));
     ctx->db_cap = pad;
   }
   ctx->db_rows = n_rows;
@@ -210,6 +213,14 @@ int t2l_search_fallbacks(t2l_ctx* ctx, int32_t* out_count) {
   T2L_HIP(ctx, hipSetDevice(ctx->device));
   T2L_HIP(ctx, hipDeviceSynchronize());
   T2L_HIP(ctx, hipMemcpy(out_count, ctx->fb_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+  return T2L_OK;
+}
+
+int t2l_search_rescored(t2l_ctx* ctx, int32_t* out_count) {
+  if (!ctx || !out_count) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  T2L_HIP(ctx, hipDeviceSynchronize());
+  T2L_HIP(ctx, hipMemcpy(out_count, ctx->fb_count + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
   return T2L_OK;
 }
 
@@ -288,11 +299,8 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     ctx->nsplit_override = (int)value;
   } else if (!strcmp(name, "search_mode")) {
     if (value != 0 && value != 1 && value != 2)
-      return fail(ctx, T2L_EINVAL, "search_mode must be 0 (wide split-bf16 scan), 1 (f32 scan) or 2 (narrow split-bf16 scan)");
+      return fail(ctx, T2L_EINVAL, "search_mode must be 0 (f16 scan), 1 (f32 scan) or 2 (split-bf16 scan)");
     ctx->search_mode = (int)value;
-  } else if (!strcmp(name, "wide_nbuf")) {
-    if (value != 3 && value != 4) return fail(ctx, T2L_EINVAL, "wide_nbuf must be 3 or 4");
-    ctx->wide_nbuf = (int)value;
   } else if (!strcmp(name, "stream_min_rows")) {
     ctx->stream_min_rows = (int)value;
   } else if (!strcmp(name, "pointnet_pyg_self_loops")) {

@@ -22,6 +22,8 @@
 #include <float.h>
 #include <limits.h>
 
+#include <type_traits>
+
 #include "t2l_internal.h"
 #include "search_dev.h"
 
@@ -188,101 +190,6 @@ __global__ __launch_bounds__(256) void split_db_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// scan3: split-bf16 scan with the selection interleaved in the SAME wave (measured on gfx950,
-// tools/mfma_valu_probe.hip: up to ~4-5 independent VALU instructions hide in the 32-cycle gap of a
-// bf16 32x32x16 MFMA when they sit in the issuing wave's own stream; a partner wave's VALU stream on the
-// same SIMD instead slows the MFMA wave by 20-40 cycles per MFMA, which is why a wave-specialised variant —
-// MFMA waves handing scores to selection waves through LDS — measured slower, 93 vs 81 us, and was dropped).
-// Structure = scan_kernel (4 waves x 32 queries share the LDS tile), arithmetic = split-bf16.
-// The row >= n_rows mask lives only in the epilogue: the one partial tile of a shard is the last tile of the
-// last split, whose scores are inserted after the loop.
-// ------------------------------------------------------------------------------------------------
-template <int L>
-__global__ __launch_bounds__(kScanWaves * 64, 2) void scan3_kernel(const uint4* __restrict__ dbs, int n_rows, int n_tiles,
-                                                         int code_bits, const float* __restrict__ q, int Q,
-                                                         int nsplit, float* __restrict__ cand,
-                                                         int32_t* __restrict__ fb_count, int zero_counts, float pinf) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* tiles = smem;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, col = lane & 31;
-  const int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
-  const int nt = sp < n_tiles ? (n_tiles - sp + nsplit - 1) / nsplit : 0;
-  const int qrow = qb * (kScanWaves * kQPerWave) + wave * kQPerWave + col;
-  const int mask = ~((1 << code_bits) - 1);
-  int vmask = mask;
-  asm volatile("" : "+v"(vmask));  // keep the mask in a VGPR so key = v_and_or_b32(score, vmask, s_code) is one op
-  if (zero_counts && blockIdx.x == 0 && tid < 2) fb_count[tid] = 0;
-
-  uint4 qh[16], ql[16];
-  {
-    const float4* qp = reinterpret_cast<const float4*>(q + (size_t)min(qrow, Q - 1) * kD + half * 128);
-#pragma unroll
-    for (int s = 0; s < 16; ++s) split8(qp[2 * s], qp[2 * s + 1], qh[s], ql[s]);
-  }
-  float ls[L];
-#pragma unroll
-  for (int i = 0; i < L; ++i) ls[i] = T2L_NEG_INF;
-  f32x16 accA, accB;  // tile t / tile t+1
-#pragma unroll
-  for (int r = 0; r < 16; ++r) accA[r] = accB[r] = T2L_NEG_INF;  // "previous tile" of the first tile: no-op inserts
-
-  const int uwave = uniform_wave_id();
-  auto issue = [&](int j, int buf) {
-    constexpr int kRowsPerWave = 32 / kScanWaves;
-    const uint4* src = dbs + ((size_t)(sp + j * nsplit) * kTileRows + uwave * kRowsPerWave) * 64;
-    const unsigned dst = lds_addr_of(tiles + buf * kTileFloats + uwave * kRowsPerWave * kRowStrideF);
-#pragma unroll
-    for (int i = 0; i < kRowsPerWave; ++i)  // one wave-instruction moves one 1 KiB row (hi | lo planes) into LDS
-      lds_dma_row(dst + i * (kRowStrideF * 4), lane * 16, src + i * 64);
-  };
-  auto step = [&](int j, int buf, f32x16& cur, const f32x16& prev) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile j landed for every wave; every wave is done reading buffer buf^1
-    if (j + 1 < nt) issue(j + 1, buf ^ 1);
-    const char* tb = reinterpret_cast<const char*>(tiles + buf * kTileFloats) + col * (kRowStrideF * 4) + half * 256;
-    uint4 ah[4], al[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ah[i] = *reinterpret_cast<const uint4*>(tb + 16 * i);
-      al[i] = *reinterpret_cast<const uint4*>(tb + 512 + 16 * i);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) cur[r] = 0.f;
-    constexpr int VPM = (L + 2 + 2) / 3;
-    tile_mfma_bf16_sel<L, VPM, 0, 16>(tb, qh, ql, cur, prev, vmask, (j - 1) << 4, pinf, ls, ah, al);
-  };
-
-  if (nt > 0) issue(0, 0);
-  for (int j = 0; j < nt; j += 2) {
-    step(j, 0, accA, accB);
-    if (j + 1 < nt) step(j + 1, 1, accB, accA);
-  }
-  if (nt > 0) {  // the last tile's scores are still in registers; only here can rows be >= n_rows
-    const int row0 = (sp + (nt - 1) * nsplit) * kTileRows + 4 * half;
-    const int code0 = (nt - 1) << 4;
-    if (nt & 1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2);
-        ins_key<L>(ls, row < n_rows ? make_key(accA[r], mask, code0 + r) : T2L_NEG_INF);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2);
-        ins_key<L>(ls, row < n_rows ? make_key(accB[r], mask, code0 + r) : T2L_NEG_INF);
-      }
-    }
-  }
-  if (qrow < Q) {
-    float4* out = reinterpret_cast<float4*>(cand + (((size_t)qrow * nsplit + sp) * 2 + half) * L);
-#pragma unroll
-    for (int i = 0; i < L / 4; ++i) out[i] = make_float4(ls[4 * i], ls[4 * i + 1], ls[4 * i + 2], ls[4 * i + 3]);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // scanw: the wide split-bf16 scan — ONE workgroup (4 waves = one wave per SIMD) per CU, 64 queries per wave.
 //
 // Why: at 32 queries per wave the LDS feeds the MFMAs at 2/3 of a 16-byte read per MFMA, i.e. 83 % of a CU's LDS
@@ -412,6 +319,165 @@ __global__ __launch_bounds__(256, 1) void scanw_kernel(const uint4* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// scanh: the f16 scan (default) — the wide kernel's structure with ONE f16 MFMA per product instead of three bf16 ones.
+//
+// The scan only has to deliver candidates whose keys bound the scores of everything it drops; the float64 re-rank
+// decides the order and the certificate proves it. With exact power-of-two scaling (search_dev.h) the f16 operand
+// rounding costs |error| <= ~1e-3 |q||c| — 50x the split-bf16 bound, still far below the gap between the K-th and the
+// L-th best score of a real query, and a failed certificate only costs that query the float64 fallback.
+// A third of the MFMA work, half the DB bytes through L2/LDS (512 B per row), half the operand registers
+// (128 AGPRs), so the kernel is bound by the per-score selection VALU (9 ops) rather than by the matrix pipe.
+//   DB plane: f16 [n_pad][256] (scaled by 2^shift_db), built by half_db_kernel. LDS: 4 x 16 KiB tiles, unpadded rows,
+//   16-byte chunk c of row r stored at chunk c ^ r (the LDS-DMA lanes fetch the permuted chunks; ds_read_b128 of one
+//   k-step then hits every bank group exactly 4 times = full LDS rate).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void half_db_kernel(const float* __restrict__ db, const float* __restrict__ norms,
+                                                      uint4* __restrict__ out, int rows) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;  // one thread = 8 consecutive floats -> 16 bytes
+  const int row = gid >> 5, c = gid & 31;
+  if (row >= rows) return;
+  int shift;
+  half_shift_of(norms[1], shift);
+  const float4* src = reinterpret_cast<const float4*>(db + (size_t)row * kD + 8 * c);
+  const float4 a = src[0], b = src[1];
+  out[(size_t)row * 32 + c] = make_uint4(pack_f16x2(a.x, a.y, shift), pack_f16x2(a.z, a.w, shift),
+                                         pack_f16x2(b.x, b.y, shift), pack_f16x2(b.z, b.w, shift));
+}
+
+template <int LL>
+__global__ __launch_bounds__(256, 1) void scanh_kernel(const uint4* __restrict__ dbh, int n_rows, int n_tiles, int code_bits,
+                                                       const float* __restrict__ q, int Q, int nsplit,
+                                                       float* __restrict__ cand, int32_t* __restrict__ fb_count,
+                                                       int zero_counts, float pinf) {
+  constexpr int NBUF = 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int half = lane >> 5, col = lane & 31;
+  const int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
+  const int nt = sp < n_tiles ? (n_tiles - sp + nsplit - 1) / nsplit : 0;
+  const int uwave = uniform_wave_id();
+  const int qrow0 = qb * kWideQPerBlock + uwave * kWideQPerWave + col, qrow1 = qrow0 + 32;
+  const int mask = ~((1 << code_bits) - 1);
+  int vmask = mask;
+  asm volatile("" : "+v"(vmask));
+  if (zero_counts && blockIdx.x == 0 && tid < 2) fb_count[tid] = 0;
+  if (nt == 0) return;  // (the host never launches an empty split)
+
+  // ---- LDS-DMA plan: wave w moves row pairs 4w .. 4w+3 of a tile; lane l of piece i lands at LDS chunk l & 31 of row
+  // r = 2*(4w+i) + (l >> 5), which must hold global chunk (l & 31) ^ r of that row
+  unsigned doff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 2 * (4 * uwave + i) + half;
+    doff[i] = r * 512 + ((col ^ r) << 4);
+  }
+  const unsigned lds_base = lds_addr_of(smem);
+  auto dma_of = [&](int j, int buf) {
+    const int tile = sp + min(j, nt - 1) * nsplit;  // over-issue at the end is clamped (see scanw_kernel)
+    HalfDma d;
+    d.src = reinterpret_cast<const char*>(dbh) + (size_t)tile * kHalfTileBytes;
+    d.dst = lds_base + buf * kHalfTileBytes + uwave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d.off[i] = doff[i];
+    return d;
+  };
+#pragma unroll
+  for (int b = 0; b < NBUF - 1; ++b) {
+    const HalfDma d = dma_of(b, b);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d.piece(i);
+  }
+
+  // ---- queries: scale by the power of two that puts the largest |element| into [2^14, 2^15), round to f16, pin in AGPRs
+  u32x4 q0[16], q1[16];  // 128 AGPRs
+  auto load_group = [&](int qrow, u32x4 (&dst)[16]) {
+    const float4* qp = reinterpret_cast<const float4*>(q + (size_t)min(qrow, Q - 1) * kD + half * 128);
+    float4 v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = qp[i];
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      m = fmaxf(fmaxf(m, fabsf(v[i].x)), fabsf(v[i].y));
+      m = fmaxf(fmaxf(m, fabsf(v[i].z)), fabsf(v[i].w));
+    }
+    {  // the other half of the row lives in lane ^ 32
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+      m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    int shift;
+    half_shift_of(m, shift);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float4 a = v[2 * s], b = v[2 * s + 1];
+      dst[s] = pin_agpr(u32x4{pack_f16x2(a.x, a.y, shift), pack_f16x2(a.z, a.w, shift), pack_f16x2(b.x, b.y, shift),
+                              pack_f16x2(b.z, b.w, shift)});
+    }
+  };
+  load_group(qrow0, q0);
+  load_group(qrow1, q1);
+
+  WideLists<LL> w;
+#pragma unroll
+  for (int i = 0; i < LL; ++i) w.ls0[i] = w.ls1[i] = T2L_NEG_INF;
+  w.key0 = w.key1 = T2L_NEG_INF;
+  f32x16 accA0, accA1, accB0, accB1;  // tile j / tile j+1, per query group
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accA0[r] = accA1[r] = accB0[r] = accB1[r] = T2L_NEG_INF;
+
+  // lane (col, half) reads chunk half*16 + S of row col at k-step S: swizzled position (half*16 + S) ^ col
+  unsigned roff[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) roff[s] = col * 512 + ((((half << 4) + s) ^ col) << 4);
+  const char* lds0 = reinterpret_cast<const char*>(smem);
+  u32x4 ring[4];
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (NBUF - 2)) : "memory");  // tile 0 landed for every wave
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ring[i] = *reinterpret_cast<const u32x4*>(lds0 + roff[i]);
+
+  auto step = [&](auto buf_tag, int j, f32x16& cur0, f32x16& cur1, const f32x16& prev0, const f32x16& prev1) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    const HalfDma d = dma_of(j + NBUF - 1, (BUF + NBUF - 1) % NBUF);
+    tileh_steps<LL, 0, 12, BUF, NBUF>(lds0, roff, q0, q1, cur0, cur1, prev0, prev1, vmask, (j - 1) << 4, pinf, w, ring, d);
+    // tile j+1 (issued two tiles ago) has landed for this wave; after the barrier it has for every wave, and every wave
+    // is past its last read of tile j-1, whose buffer the DMA below refills
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (NBUF - 3)) : "memory");
+    tileh_steps<LL, 12, 16, BUF, NBUF>(lds0, roff, q0, q1, cur0, cur1, prev0, prev1, vmask, (j - 1) << 4, pinf, w, ring, d);
+  };
+  for (int j = 0; j < nt; j += 4) {
+    step(std::integral_constant<int, 0>{}, j, accA0, accA1, accB0, accB1);
+    if (j + 1 < nt) step(std::integral_constant<int, 1>{}, j + 1, accB0, accB1, accA0, accA1);
+    if (j + 2 < nt) step(std::integral_constant<int, 2>{}, j + 2, accA0, accA1, accB0, accB1);
+    if (j + 3 < nt) step(std::integral_constant<int, 3>{}, j + 3, accB0, accB1, accA0, accA1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // over-issued DMA pieces must not land in LDS after the workgroup is gone
+
+  {  // the last tile's scores are still in registers; only here can rows be >= n_rows
+    const int row0 = (sp + (nt - 1) * nsplit) * kTileRows + 4 * half;
+    const int code0 = (nt - 1) << 4;
+    const bool odd = nt & 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool ok = row0 + (r & 3) + 8 * (r >> 2) < n_rows;
+      const float s0 = odd ? accA0[r] : accB0[r], s1 = odd ? accA1[r] : accB1[r];
+      ins_key<LL>(w.ls0, ok ? make_key(s0, mask, code0 + r) : T2L_NEG_INF);
+      ins_key<LL>(w.ls1, ok ? make_key(s1, mask, code0 + r) : T2L_NEG_INF);
+    }
+  }
+  const int part = 2 * sp + half, parts = 2 * nsplit;
+  if (qrow0 < Q) {
+    float4* out = reinterpret_cast<float4*>(cand + ((size_t)qrow0 * parts + part) * LL);
+#pragma unroll
+    for (int i = 0; i < LL / 4; ++i) out[i] = make_float4(w.ls0[4 * i], w.ls0[4 * i + 1], w.ls0[4 * i + 2], w.ls0[4 * i + 3]);
+  }
+  if (qrow1 < Q) {
+    float4* out = reinterpret_cast<float4*>(cand + ((size_t)qrow1 * parts + part) * LL);
+#pragma unroll
+    for (int i = 0; i < LL / 4; ++i) out[i] = make_float4(w.ls1[4 * i], w.ls1[4 * i + 1], w.ls1[4 * i + 2], w.ls1[4 * i + 3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // rerank (stage 1): one wave per query, 4 queries per 256-thread block.
 // ------------------------------------------------------------------------------------------------
 // LL = length of the per-lane lists the scan wrote, L = rows re-scored per query (LL <= L).
@@ -419,7 +485,7 @@ template <int LL, int L>
 __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ db, const float* __restrict__ q, int Q,
                                                      int K, int parts, int code_bits,
                                                      const float* __restrict__ cand, int row_offset, float eps_rel,
-                                                     const float* __restrict__ db_norm_max,
+                                                     const float* __restrict__ db_norm_max, int half_mode,
                                                      int32_t* __restrict__ out_idx, double* __restrict__ out_score,
                                                      int32_t* __restrict__ flags, float pinf) {
   const int lane = threadIdx.x & 63;
@@ -507,18 +573,45 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
     if (out_score) out_score[(size_t)qid * K + rank] = my_d;
   }
 
-  // ---- certificate
+  // ---- certificate (keys of the f16 scan are true scores times 2^(shift_db + shift_q): undo that exactly)
+  double kscale = 1.0;
+  bool representable = true;
+  {
+    const float m = wave_max_f32(fmaxf(fmaxf(fabsf(qv.x), fabsf(qv.y)), fmaxf(fabsf(qv.z), fabsf(qv.w))), pinf);
+    int sq, sd;
+    representable = half_shift_of(m, sq);
+    representable = half_shift_of(db_norm_max[1], sd) && representable;
+    if (half_mode) {
+      kscale = ldexp(1.0, -(sq + sd));
+    } else {
+      // the f32 / split-bf16 scans multiply the raw values: their relative error bound needs every product that matters
+      // to stay a normal f32, which magnitudes within 2^-40 .. 2^40 guarantee with a wide margin
+      representable = representable && abs(sq - 14) <= 40 && abs(sd - 14) <= 40;
+    }
+  }
   bool certified = true;
+  float thr = T2L_NEG_INF;  // fallback: only rows with key >= thr can still reach the top-K
   if (g != T2L_NEG_INF) {  // an L-th candidate exists, so something may not have been re-scored
     certified = false;
     const unsigned long long kth = __ballot(valid && rank == K - 1);
     if (K <= L && kth != 0ull) {
       const double dK = __shfl(my_d, __ffsll((long long)kth) - 1);
       const double eps32 = (double)eps_rel * sqrt(qn) * (double)(*db_norm_max);
-      certified = dK > (double)g + key_slack(g, code_bits, eps32);
+      certified = dK > (double)g * kscale + key_slack(g, code_bits, eps32, kscale);
+      // a row with key k has score <= k*kscale + |k|*kscale*2^(cb-22) + eps32; with S = 2*(|dK|*2^(cb-22) + eps32) every
+      // key below (dK - S)/kscale is therefore below the current K-th best score dK (and the final K-th is >= dK)
+      const double S = 2.0 * (fabs(dK) * ldexp(1.0, code_bits - 22) + eps32);
+      const double t = (dK - S) / kscale;
+      thr = (float)t;
+      if ((double)thr > t) thr = __uint_as_float(__float_as_uint(thr) + (thr > 0.f ? -1 : 1));  // round down
+      if (!(fabs(t) < 3.0e38)) thr = T2L_NEG_INF;
     }
   }
-  if (lane == 0) flags[qid] = certified ? 0 : 1;
+  // 2 = the f16 operands of this query (or of the DB) were not representable: its keys mean nothing, scan exactly
+  if (lane == 0) {
+    flags[qid] = !representable ? 2 : (certified ? 0 : 1);
+    reinterpret_cast<float*>(flags + Q)[qid] = thr;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -533,7 +626,7 @@ template <int L>
 __global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__ db, int n_rows,
                                                        const float* __restrict__ q, int Q, int K, int parts,
                                                        int code_bits, const float* __restrict__ cand, int row_offset,
-                                                       float eps_rel, const float* __restrict__ db_norm_max,
+                                                       float eps_rel, const float* __restrict__ db_norm_max, int half_mode,
                                                        const int32_t* __restrict__ flags,
                                                        int32_t* __restrict__ out_idx, double* __restrict__ out_score,
                                                        int32_t* __restrict__ fb_count) {
@@ -544,86 +637,173 @@ __global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__
   __shared__ int red_i[256];
   __shared__ int red_t[256];
   __shared__ float floor_max;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ double stat_dk;
+  __shared__ int stat_found;
+  constexpr int kMaxSel = 96;
+  __shared__ int n_sel, sel_bad;
+  __shared__ int sel_c[kMaxSel];
+  const int tid = threadIdx.x;
   for (int qid = blockIdx.x; qid < Q; qid += gridDim.x) {  // flagged queries are rare: few blocks sweep the flags
-  if (!flags[qid]) continue;
+  const int flag = flags[qid];
+  if (!flag) continue;
   __syncthreads();
   qs[tid] = (double)q[(size_t)qid * kD + tid];
+  if (flag == 2) {  // keys are meaningless (see rerank_kernel): straight to the exact scan
+    if (tid == 0) {
+      atomicAdd(&fb_count[1], 1);
+      atomicAdd(&fb_count[0], 1);
+    }
+    __syncthreads();
+    exact_scan<32>(db, n_rows, qs, K, row_offset, out_idx + (size_t)qid * K,
+                   out_score ? out_score + (size_t)qid * K : nullptr, red_s, red_i, red_t);
+    continue;
+  }
 
-  // ---- stage 2
+  // ---- stage 2a: only the kept candidates whose key can still reach the top-K (key >= the threshold the re-rank left;
+  // typically a few more than the L it re-scored). Valid when no list's floor reaches the threshold (dropped rows are below
+  // it too) — then the result is exact by construction. One wave per selected row, coalesced 1 KiB gathers.
+  {
+    const int total_a = parts * L;
+    const float* keys = cand + (size_t)qid * total_a;
+    const float thr = reinterpret_cast<const float*>(flags + Q)[qid];
+    if (tid == 0) {
+      n_sel = 0;
+      sel_bad = 0;
+    }
+    __syncthreads();
+    for (int c = tid; c < total_a; c += 256) {
+      const float key = keys[c];
+      if (key != T2L_NEG_INF && key >= thr) {
+        const int i = atomicAdd(&n_sel, 1);
+        if (i < kMaxSel) sel_c[i] = c;
+      }
+      if ((c % L) == L - 1 && key != T2L_NEG_INF && key >= thr) sel_bad = 1;  // a full list's floor reaches the threshold
+    }
+    __syncthreads();
+    const int ns = n_sel;
+    if (thr != T2L_NEG_INF && !sel_bad && ns >= K && ns <= kMaxSel) {  // block-uniform
+      const int lane = tid & 63, wave = tid >> 6;
+      const float4 qv = reinterpret_cast<const float4*>(q + (size_t)qid * kD)[lane];
+      for (int i0 = wave * 8; i0 < ns; i0 += 32) {  // 8 row gathers in flight per wave
+        float4 rows[8];
+        int rid[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = sel_c[min(i0 + e, ns - 1)];
+          rid[e] = key_row(keys[c], c / L, parts >> 1, code_bits);
+          rows[e] = reinterpret_cast<const float4*>(db + (size_t)rid[e] * kD)[lane];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const double d = wave_sum_f64((double)rows[e].x * qv.x + (double)rows[e].y * qv.y + (double)rows[e].z * qv.z +
+                                        (double)rows[e].w * qv.w);
+          if (lane == 0 && i0 + e < ns) {
+            cd[i0 + e] = d;
+            crow[i0 + e] = rid[e];
+          }
+        }
+      }
+      __syncthreads();
+      if (tid < ns) {
+        const double d = cd[tid];
+        const int row = crow[tid];
+        int rank = 0;
+        for (int o = 0; o < ns; ++o) {
+          const double od = cd[o];
+          const int orow = crow[o];
+          rank += (od > d || (od == d && orow < row)) ? 1 : 0;
+        }
+        if (rank < K) {
+          out_idx[(size_t)qid * K + rank] = row + row_offset;
+          if (out_score) out_score[(size_t)qid * K + rank] = d;
+        }
+      }
+      if (tid == 0) atomicAdd(&fb_count[1], 1);
+      continue;
+    }
+  }
+
+  // ---- stage 2: one thread per kept candidate — float64 dot (query broadcast from LDS), then every candidate counts
+  // the candidates ahead of it by (score desc, row asc): its rank. No sorting rounds, two barriers.
   const int total = parts * L;
   const float* mine = cand + (size_t)qid * total;
-  const float4 qv = reinterpret_cast<const float4*>(q + (size_t)qid * kD)[lane];
-  for (int c = wave; c < total; c += 4) {
-    const float key = mine[c];  // wave-uniform
+  if (tid == 0) {
+    stat_dk = -__builtin_inf();
+    stat_found = 0;
+  }
+  __syncthreads();
+  int my_found = 0;
+  for (int c = tid; c < total; c += 256) {
+    const float key = mine[c];
     double d = -__builtin_inf();
     int row = INT_MAX;
     if (key != T2L_NEG_INF) {
       row = key_row(key, c / L, parts >> 1, code_bits);
-      d = wave_dot64(db, row, qv, lane);
+      const float4* rp = reinterpret_cast<const float4*>(db + (size_t)row * kD);
+      double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll 4
+      for (int k = 0; k < kD / 4; ++k) {
+        const float4 v = rp[k];
+        d0 += (double)v.x * qs[4 * k];
+        d1 += (double)v.y * qs[4 * k + 1];
+        d2 += (double)v.z * qs[4 * k + 2];
+        d3 += (double)v.w * qs[4 * k + 3];
+      }
+      d = (d0 + d1) + (d2 + d3);
+      ++my_found;
     }
-    if (lane == 0) {
-      cd[c] = d;
-      crow[c] = row;
-    }
+    cd[c] = d;
+    crow[c] = row;
   }
-  if (tid == 0) {
+  if (my_found) atomicAdd(&stat_found, my_found);
+  if (tid < 64) {  // largest floor of a full list (wave 0)
     float f = T2L_NEG_INF;
-    for (int p = 0; p < parts; ++p) f = fmaxf(f, mine[p * L + L - 1]);
-    floor_max = f;
+    for (int p = tid; p < parts; p += 64) f = fmaxf(f, mine[p * L + L - 1]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) f = fmaxf(f, __shfl_xor(f, off));
+    if (tid == 0) floor_max = f;
   }
   __syncthreads();
-  // top-K of the candidates by (float64 score desc, row asc): K rounds of block arg-max
-  double dK = -__builtin_inf();
-  int found = 0;
-  for (int r = 0; r < K; ++r) {
-    double bs = -__builtin_inf();
-    int bi = INT_MAX, bc = -1;
-    for (int c = tid; c < total; c += 256) {
-      const double s = cd[c];
-      const int i = crow[c];
-      if (i != INT_MAX && (s > bs || (s == bs && i < bi))) {
-        bs = s;
-        bi = i;
-        bc = c;
-      }
-    }
-    red_s[tid] = bs;
-    red_i[tid] = bi;
-    red_t[tid] = bc;
-    __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) {
-      if (tid < st) {
-        const double os = red_s[tid + st];
-        const int oi = red_i[tid + st];
-        if (os > red_s[tid] || (os == red_s[tid] && oi < red_i[tid])) {
-          red_s[tid] = os;
-          red_i[tid] = oi;
-          red_t[tid] = red_t[tid + st];
-        }
-      }
-      __syncthreads();
-    }
-    const bool ok = red_i[0] != INT_MAX;
-    if (ok) {
-      dK = red_s[0];
-      ++found;
-    }
-    const int win = red_t[0];
-    __syncthreads();
-    if (tid == 0) {
-      out_idx[(size_t)qid * K + r] = ok ? red_i[0] + row_offset : -1;
-      if (out_score) out_score[(size_t)qid * K + r] = ok ? red_s[0] : -__builtin_inf();
-      if (ok) crow[win] = INT_MAX;  // remove the winner
-    }
-    __syncthreads();
+  if (tid < K) {
+    out_idx[(size_t)qid * K + tid] = -1;
+    if (out_score) out_score[(size_t)qid * K + tid] = -__builtin_inf();
   }
+  __syncthreads();
+  for (int c = tid; c < total; c += 256) {
+    const int row = crow[c];
+    if (row == INT_MAX) continue;
+    const double d = cd[c];
+    int rank = 0;
+    for (int o = 0; o < total; ++o) {
+      const double od = cd[o];
+      const int orow = crow[o];
+      rank += (orow != INT_MAX && (od > d || (od == d && orow < row))) ? 1 : 0;
+    }
+    if (rank < K) {
+      out_idx[(size_t)qid * K + rank] = row + row_offset;
+      if (out_score) out_score[(size_t)qid * K + rank] = d;
+      if (rank == K - 1) stat_dk = d;
+    }
+  }
+  __syncthreads();
+  const double dK = stat_dk;
+  const int found = min(stat_found, K);
   bool certified = floor_max == T2L_NEG_INF;  // no list is full: nothing was ever dropped
   if (!certified && found == K) {
-    double qn = 0.0;
-    for (int k = 0; k < kD; ++k) qn += qs[k] * qs[k];
+    double qn = 0.0, qm = 0.0;
+    for (int k = 0; k < kD; ++k) {
+      qn += qs[k] * qs[k];
+      qm = fmax(qm, fabs(qs[k]));
+    }
+    double kscale = 1.0;
+    if (half_mode) {
+      int sq, sd;
+      half_shift_of((float)qm, sq);  // (float)qm is exact: qm is one of the query's f32 values
+      half_shift_of(db_norm_max[1], sd);
+      kscale = ldexp(1.0, -(sq + sd));
+    }
     const double eps32 = (double)eps_rel * sqrt(qn) * (double)(*db_norm_max);
-    certified = dK > (double)floor_max + key_slack(floor_max, code_bits, eps32);
+    certified = dK > (double)floor_max * kscale + key_slack(floor_max, code_bits, eps32, kscale);
   }
   if (tid == 0) atomicAdd(&fb_count[1], 1);
   if (certified) continue;  // block-uniform
@@ -637,22 +817,36 @@ __global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__
 }
 
 // max row 2-norm of the shard (bounds the f32 dot-product error in the certificate); one atomic per workgroup
+// out[0] = max row 2-norm (x 1.0001), out[1] = max |element| as raw bits (inf / NaN payloads order above every finite
+// value, so a non-finite DB is seen as such by half_shift_of)
 __global__ __launch_bounds__(256) void db_norm_kernel(const float* __restrict__ db, int n_rows, float* out) {
   __shared__ float red[4];
+  __shared__ int red_a[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float m = 0.f;
+  int am = 0;
   for (int row = blockIdx.x * 4 + wave; row < n_rows; row += gridDim.x * 4) {
     const float4 v = reinterpret_cast<const float4*>(db + (size_t)row * kD)[lane];
     float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    int a = max(max(__float_as_int(v.x) & 0x7fffffff, __float_as_int(v.y) & 0x7fffffff),
+                max(__float_as_int(v.z) & 0x7fffffff, __float_as_int(v.w) & 0x7fffffff));
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    for (int off = 32; off >= 1; off >>= 1) {
+      s += __shfl_xor(s, off);
+      a = max(a, __shfl_xor(a, off));
+    }
     m = fmaxf(m, s);
+    am = max(am, a);
   }
-  if (lane == 0) red[wave] = m;
+  if (lane == 0) {
+    red[wave] = m;
+    red_a[wave] = am;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     atomicMax(reinterpret_cast<int*>(out), __float_as_int(sqrtf(m) * 1.0001f));  // non-negative floats order as ints
+    atomicMax(reinterpret_cast<int*>(out) + 1, max(max(red_a[0], red_a[1]), max(red_a[2], red_a[3])));
   }
 }
 
@@ -771,16 +965,21 @@ int merge_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int parts,
 }
 
 int db_norm_impl(t2l_ctx* ctx, hipStream_t s) {
-  if (ctx->db_pad > 0) {  // the bf16 hi/lo planes the default scan multiplies
-    const int threads = (int)ctx->db_pad * 32;
+  const int threads = (int)ctx->db_pad * 32;
+  if (ctx->db_pad > 0) {  // the bf16 hi/lo planes (split-bf16 scan, streaming scan)
     hipLaunchKernelGGL(split_db_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ctx->db, ctx->db_split,
                        (int)ctx->db_pad);
     T2L_HIP(ctx, hipGetLastError());
   }
-  T2L_HIP(ctx, hipMemsetAsync(ctx->db_norm_max, 0, sizeof(float), s));
+  T2L_HIP(ctx, hipMemsetAsync(ctx->db_norm_max, 0, 2 * sizeof(float), s));
   if (ctx->db_rows > 0) {
     const int blocks = (int)min((int64_t)1024, (ctx->db_rows + 3) / 4);
     hipLaunchKernelGGL(db_norm_kernel, dim3(blocks), dim3(256), 0, s, ctx->db, (int)ctx->db_rows, ctx->db_norm_max);
+    T2L_HIP(ctx, hipGetLastError());
+  }
+  if (ctx->db_pad > 0) {  // the scaled f16 plane of the default scan (needs the max |element| from above)
+    hipLaunchKernelGGL(half_db_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ctx->db, ctx->db_norm_max, ctx->db_half,
+                       (int)ctx->db_pad);
     T2L_HIP(ctx, hipGetLastError());
   }
   return T2L_OK;
@@ -797,56 +996,50 @@ static void allow_lds(Kern* kern, size_t lds) {
 // scan (by search_mode) -> re-rank -> fallback on one stream. LL = per-lane list length the scan keeps, L = rows the
 // re-rank re-scores per query.
 template <int LL, int L>
-static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, int n_rows, int row_offset, const float* q,
-                         int Q, int K, int nsplit, int code_bits, int32_t* out_idx, double* out_score, bool first,
-                         hipStream_t s) {
+static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const uint4* dbh, int n_rows, int row_offset,
+                         const float* q, int Q, int K, int nsplit, int code_bits, int32_t* out_idx, double* out_score,
+                         bool first, hipStream_t s) {
   const int n_tiles = (n_rows + kTileRows - 1) / kTileRows;
   const int parts = 2 * nsplit;
   const int zero = first;
+  const int half_mode = ctx->search_mode == 0;
   event_begin(ctx, "search_scan", s);
-  if (ctx->search_mode == 0) {  // wide split-bf16 MFMA scan (default): one workgroup per CU, 256 queries each
+  if (ctx->search_mode == 0) {  // f16 MFMA scan (default): one workgroup per CU, 256 queries each
     const dim3 grid((Q + kWideQPerBlock - 1) / kWideQPerBlock * nsplit);
-    if (ctx->wide_nbuf == 3) {
-      const size_t lds = (size_t)3 * kTileFloats * sizeof(float);
-      static bool once = (allow_lds(&scanw_kernel<LL, 3>, (size_t)3 * kTileFloats * sizeof(float)), true);
-      (void)once;
-      hipLaunchKernelGGL((scanw_kernel<LL, 3>), grid, dim3(256), lds, s, dbs, n_rows, n_tiles, code_bits, q, Q, nsplit,
-                         ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
-    } else {
-      const size_t lds = (size_t)4 * kTileFloats * sizeof(float);
-      static bool once = (allow_lds(&scanw_kernel<LL, 4>, (size_t)4 * kTileFloats * sizeof(float)), true);
-      (void)once;
-      hipLaunchKernelGGL((scanw_kernel<LL, 4>), grid, dim3(256), lds, s, dbs, n_rows, n_tiles, code_bits, q, Q, nsplit,
-                         ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
-    }
-  } else if constexpr (LL == L) {
+    const size_t lds = (size_t)4 * kHalfTileBytes;
+    static bool once = (allow_lds(&scanh_kernel<LL>, (size_t)4 * kHalfTileBytes), true);
+    (void)once;
+    hipLaunchKernelGGL((scanh_kernel<LL>), grid, dim3(256), lds, s, dbh, n_rows, n_tiles, code_bits, q, Q, nsplit,
+                       ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
+  } else if (ctx->search_mode == 2) {  // split-bf16 MFMA scan, same structure, three MFMAs per product
+    const dim3 grid((Q + kWideQPerBlock - 1) / kWideQPerBlock * nsplit);
+    const size_t lds = (size_t)4 * kTileFloats * sizeof(float);
+    static bool once = (allow_lds(&scanw_kernel<LL, 4>, (size_t)4 * kTileFloats * sizeof(float)), true);
+    (void)once;
+    hipLaunchKernelGGL((scanw_kernel<LL, 4>), grid, dim3(256), lds, s, dbs, n_rows, n_tiles, code_bits, q, Q, nsplit,
+                       ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
+  } else if constexpr (LL == L) {  // exact-f32 MFMA scan
     const dim3 grid((Q + kQPerBlock - 1) / kQPerBlock * nsplit);
     const size_t lds = scan_lds_bytes();
-    if (ctx->search_mode == 2) {  // split-bf16 scan, 32 queries per wave, two workgroups per CU
-      static bool once = (allow_lds(&scan3_kernel<L>, scan_lds_bytes()), true);
-      (void)once;
-      hipLaunchKernelGGL((scan3_kernel<L>), grid, dim3(kScanWaves * 64), lds, s, dbs, n_rows, n_tiles, code_bits, q, Q,
-                         nsplit, ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
-    } else {  // exact-f32 MFMA scan
-      static bool once = (allow_lds(&scan_kernel<L>, scan_lds_bytes()), true);
-      (void)once;
-      hipLaunchKernelGGL((scan_kernel<L>), grid, dim3(256), lds, s, db, n_rows, n_tiles, code_bits, q, Q, nsplit,
-                         ctx->cand_score, ctx->fb_count, zero);
-    }
+    static bool once = (allow_lds(&scan_kernel<L>, scan_lds_bytes()), true);
+    (void)once;
+    hipLaunchKernelGGL((scan_kernel<L>), grid, dim3(256), lds, s, db, n_rows, n_tiles, code_bits, q, Q, nsplit,
+                       ctx->cand_score, ctx->fb_count, zero);
   }
   event_end(ctx, "search_scan", s);
   T2L_HIP(ctx, hipGetLastError());
-  // f32 dot-product error bound: gamma_n * |a||b| with n = 256 terms (+ slack for the MFMA's k order)
-  // (+ the split-bf16 product error 2^-16 + 2^-18, rounded up, when a bf16x3 scan produced the keys)
-  const float eps_rel = (float)(ctx->eps_scale *
-                                ((kD + 8) * 5.9604644775390625e-08 + (ctx->search_mode != 1 ? 2.0e-5 : 0.0)));
+  // f32 dot-product error bound: gamma_n * |a||b| with n = 256 terms (+ slack for the MFMA's k order), plus the operand
+  // rounding of the scan that produced the keys: f16 (RNE, both operands) 2^-10 + 2^-21 and 2^-20 for denormal
+  // elements, rounded up to 9.85e-4; split-bf16 2^-16 + 2^-18, rounded up to 2e-5; f32: none
+  const double operand_eps = ctx->search_mode == 0 ? 9.85e-4 : (ctx->search_mode == 2 ? 2.0e-5 : 0.0);
+  const float eps_rel = (float)(ctx->eps_scale * ((kD + 8) * 5.9604644775390625e-08 + operand_eps));
   event_begin(ctx, "search_rerank", s);
   hipLaunchKernelGGL((rerank_kernel<LL, L>), dim3((Q + 3) / 4), dim3(256), 0, s, db, q, Q, K, parts, code_bits,
-                     ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, out_idx, out_score, ctx->flags,
+                     ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, half_mode, out_idx, out_score, ctx->flags,
                      __builtin_inff());
   T2L_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(fallback_kernel<LL>, dim3(min(Q, 512)), dim3(256), 0, s, db, n_rows, q, Q, K, parts, code_bits,
-                     ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, ctx->flags, out_idx, out_score,
+                     ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, half_mode, ctx->flags, out_idx, out_score,
                      ctx->fb_count);
   event_end(ctx, "search_rerank", s);
   T2L_HIP(ctx, hipGetLastError());
@@ -863,7 +1056,7 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
   // few queries against a large shard: stream the DB once through every CU (search_stream.hip)
   if (Q <= 64 && n_rows >= ctx->stream_min_rows && n_rows > 0 && ctx->search_mode == 0 && ctx->nsplit_override == 0)
     return search_stream_impl(ctx, q, Q, K, out_idx, out_score, s);
-  const bool wide = ctx->search_mode == 0;
+  const bool wide = ctx->search_mode != 1;
   const int qpb = wide ? kWideQPerBlock : kQPerBlock;
   const int n_qblocks = (Q + qpb - 1) / qpb;
   // rows re-scored per query: K + margin (the margin only has to absorb key-truncation ties; the certificate catches
@@ -874,7 +1067,7 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     return fail(ctx, T2L_EINVAL, "t2l_search: shard too large (more than 256/k segments of 524,288 rows); shard the "
                                  "database over more ranks");
   int rc;
-  if ((rc = grow(ctx, (void**)&ctx->flags, &ctx->flag_cap, (size_t)Q * sizeof(int32_t))) != T2L_OK) return rc;
+  if ((rc = grow(ctx, (void**)&ctx->flags, &ctx->flag_cap, (size_t)2 * Q * sizeof(int32_t))) != T2L_OK) return rc;  // flags[Q] + f32 thresholds[Q]
   int32_t* seg_idx = out_idx;
   double* seg_score = out_score;
   if (n_seg > 1) {
@@ -912,9 +1105,10 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     }
     const float* db = ctx->db + (size_t)row0 * kD;
     const uint4* dbs = ctx->db_split ? ctx->db_split + (size_t)row0 * 64 : nullptr;
+    const uint4* dbh = ctx->db_half ? ctx->db_half + (size_t)row0 * 32 : nullptr;
     const int off = (int)ctx->row_offset + row0;
 #define T2L_SEARCH(LLv, Lv) \
-  launch_search<LLv, Lv>(ctx, db, dbs, max(rows, 0), off, q, Q, K, nsplit, code_bits, seg_idx, seg_score, seg == 0, s)
+  launch_search<LLv, Lv>(ctx, db, dbs, dbh, max(rows, 0), off, q, Q, K, nsplit, code_bits, seg_idx, seg_score, seg == 0, s)
     rc = LL == 8 ? T2L_SEARCH(8, 16) : (L == 16 ? T2L_SEARCH(16, 16) : T2L_SEARCH(32, 32));
 #undef T2L_SEARCH
     if (rc != T2L_OK) return rc;

@@ -221,6 +221,73 @@ __device__ __forceinline__ void tilew_steps(const char* tb, const char* tbn, con
 }
 
 
+// ---- f16 scan (scanh_kernel): ONE f16 MFMA per product. Inputs are scaled by exact powers of two so that the largest
+// |element| of the DB (resp. of each query) lands in [2^14, 2^15): no f16 overflow, and an element is f16-denormal only
+// below 2^-28 of the largest one, so whether the MFMA flushes denormals is irrelevant. shift = 14 - floor(log2(absmax));
+// a key is the true score times 2^(shift_db + shift_q). Products of f16 values are exact in f32, so the only error on top
+// of the f32 accumulation is the RNE rounding of the operands: |a.b - a'.b'| <= (2^-10 + 2^-21) |a||b|.
+// Inputs whose largest magnitude is 0 / denormal / inf / NaN or astronomically far from 1 (|shift| > kHalfShiftMax) get
+// shift 0 here and are sent to the exact float64 scan by the re-rank, which evaluates the same predicate.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr int kHalfShiftMax = 100;
+constexpr int kHalfTileBytes = kTileRows * 512;  // 32 rows x 256 f16, unpadded; chunk c of row r sits at chunk c ^ r
+
+__device__ __forceinline__ bool half_shift_of(float absmax, int& shift) {  // false = not representable (see above)
+  const int e = (int)((__float_as_uint(absmax) >> 23) & 0xffu) - 127;
+  shift = 14 - e;
+  const bool ok = shift >= -kHalfShiftMax && shift <= kHalfShiftMax;
+  if (!ok) shift = 0;
+  return ok;
+}
+__device__ __forceinline__ unsigned pack_f16x2(float x0, float x1, int shift) {  // RNE (v_cvt_pk_f16_f32) of x * 2^shift
+  return __builtin_bit_cast(unsigned,
+                            __builtin_convertvector(f32x2{__builtin_ldexpf(x0, shift), __builtin_ldexpf(x1, shift)}, f16x2));
+}
+
+__device__ __forceinline__ void mfma_f16_first(f32x16& acc, const u32x4& a, const u32x4& b_agpr) {
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b_agpr));
+}
+__device__ __forceinline__ void mfma_f16_acc(f32x16& acc, const u32x4& a, const u32x4& b_agpr) {
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b_agpr));
+}
+
+struct HalfDma {        // this wave's 4 LDS-DMA instructions of one tile (2 rows = 1 KiB each)
+  const char* src;      // wave-uniform global address of the tile
+  unsigned dst;         // LDS byte address of the wave's first row pair in the target buffer
+  unsigned off[4];      // per-lane global byte offsets: row and the chunk swizzle folded in
+  __device__ __forceinline__ void piece(int i) const { lds_dma_row(dst + i * 1024, off[i], src); }
+};
+
+// k-steps [S, S_END) of one f16 tile: per k-step one fragment read (ring of 4, crossing into the next tile's buffer at
+// S >= 12), two MFMAs (one per query group), the insertion of score S of the previous tile into both lists, and at
+// S >= 12 one LDS-DMA piece of the tile NBUF-1 ahead. BUF / NBUFS are compile-time: the buffer base is an immediate.
+template <int LL, int S, int S_END, int BUF, int NBUFS>
+__device__ __forceinline__ void tileh_steps(const char* lds0, const unsigned (&roff)[16], const u32x4 (&q0)[16],
+                                            const u32x4 (&q1)[16], f32x16& cur0, f32x16& cur1, const f32x16& prev0,
+                                            const f32x16& prev1, int vmask, int code0, float pinf, WideLists<LL>& w,
+                                            u32x4 (&ring)[4], const HalfDma& dma) {
+  if constexpr (S < S_END) {
+    constexpr int VPM = LL + 1;
+    constexpr int NXT = (BUF + 1) % NBUFS;
+    const u32x4 a = ring[S & 3];
+    const int code = __builtin_amdgcn_readfirstlane(code0 + S);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S == 0) mfma_f16_first(cur0, a, q0[S]); else mfma_f16_acc(cur0, a, q0[S]);
+    if constexpr (S + 4 < 16) ring[S & 3] = *reinterpret_cast<const u32x4*>(lds0 + roff[S + 4] + BUF * kHalfTileBytes);
+    else ring[S & 3] = *reinterpret_cast<const u32x4*>(lds0 + roff[S + 4 - 16] + NXT * kHalfTileBytes);
+    __builtin_amdgcn_sched_barrier(0);
+    wide_sel_ops<LL, S, 0, VPM>(w, prev0, prev1, vmask, code, pinf);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S == 0) mfma_f16_first(cur1, a, q1[S]); else mfma_f16_acc(cur1, a, q1[S]);
+    if constexpr (S >= 12) dma.piece(S - 12);
+    __builtin_amdgcn_sched_barrier(0);
+    wide_sel_ops<LL, S, VPM, 2 * VPM>(w, prev0, prev1, vmask, code, pinf);
+    __builtin_amdgcn_sched_barrier(0);
+    tileh_steps<LL, S + 1, S_END, BUF, NBUFS>(lds0, roff, q0, q1, cur0, cur1, prev0, prev1, vmask, code0, pinf, w, ring, dma);
+  }
+}
+
+
 // ---- wave-wide all-reduces on the VALU (DPP + v_permlane{16,32}_swap), no LDS traffic: __shfl_xor lowers to
 // ds_bpermute_b32, and the re-rank is shuffle-bound (hundreds of shuffles per query).
 template <int CTRL>
@@ -292,10 +359,11 @@ __device__ __forceinline__ double wave_dot64(const float* __restrict__ db, int r
   return d;
 }
 
-// bound on (float64 score - key) for any row whose key is <= g: truncation of `code_bits` mantissa bits
-// (relative 2^(code_bits-23), doubled for slack) plus the f32 dot-product rounding error eps32.
-__device__ __forceinline__ double key_slack(float g, int code_bits, double eps32) {
-  return fabs((double)g) * ldexp(1.0, code_bits - 22) + eps32;
+// bound on (float64 score - key * kscale) for any row whose key is <= g: truncation of `code_bits` mantissa bits
+// (relative 2^(code_bits-23), doubled for slack) plus the scan's arithmetic error eps32 (in true score units).
+// kscale = 1 except for the f16 scan, whose keys are scores times a power of two.
+__device__ __forceinline__ double key_slack(float g, int code_bits, double eps32, double kscale = 1.0) {
+  return fabs((double)g) * kscale * ldexp(1.0, code_bits - 22) + eps32;
 }
 
 

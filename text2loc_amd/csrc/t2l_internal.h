@@ -54,7 +54,8 @@ struct t2l_ctx {
   float* db = nullptr;       // [db_pad,256], rows >= db_rows are zero
   uint4* db_split = nullptr; // bf16 [db_pad][hi 256 | lo 256] planes of the same rows (1 KiB per row)
   int64_t db_rows = 0, db_pad = 0, db_cap = 0, row_offset = 0;
-  float* db_norm_max = nullptr;  // dev f32[1]: max row 2-norm (feeds the certificate's error bound)
+  uint4* db_half = nullptr;  // f16 [db_pad][256] plane of the same rows, scaled by a power of two (512 B per row)
+  float* db_norm_max = nullptr;  // dev f32[2]: max row 2-norm (feeds the certificate's error bound), max |element|
   // search workspace
   float* cand_score = nullptr;   // candidate keys [Q][2*nsplit][L]
   int32_t* flags = nullptr;      // dev i32[Q]: 1 = first-stage certificate failed -> fallback kernel
@@ -73,8 +74,7 @@ struct t2l_ctx {
   // options
   double eps_scale = 1.0;
   int nsplit_override = 0;
-  int search_mode = 0;   // 0 = wide split-bf16 MFMA scan (default), 1 = exact-f32 MFMA scan, 2 = narrow split-bf16 scan
-  int wide_nbuf = 4;     // LDS tile buffers of the wide scan (3 or 4)
+  int search_mode = 0;   // 0 = f16 MFMA scan (default), 1 = exact-f32 MFMA scan, 2 = split-bf16 MFMA scan
   int stream_min_rows = 65536;  // shards at least this large answer batches of <= 64 queries with the streaming scan
   bool profile_events = false;
   std::unordered_map<std::string, t2l::EventRing> events;

@@ -64,6 +64,7 @@ EXPORTS = {
     "t2l_merge_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     "t2l_search_fallbacks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "t2l_search_rescored": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "t2l_contrastive_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_fine_load_weights": (C.c_int, [C.c_void_p, C.POINTER(_WeightDesc), C.c_int32, C.POINTER(_ModelConfig)]),
@@ -377,6 +378,12 @@ class Engine:
     def search_fallbacks(self) -> int:
         c = C.c_int32(0)
         self._check(self.lib.t2l_search_fallbacks(self._h, C.byref(c)))
+        return int(c.value)
+
+    def search_rescored(self) -> int:
+        """Queries of the last search whose first certificate failed (all kept candidates re-scored in float64)."""
+        c = C.c_int32(0)
+        self._check(self.lib.t2l_search_rescored(self._h, C.byref(c)))
         return int(c.value)
 
     # ------------------------------------------------------------------ loss
