@@ -427,13 +427,16 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     N_CELLS, N_QUERIES = args.cells, args.queries
+    EVENT_EVERY = max(1, min(8, args.steps // 8))
     db, qs, target = synth.make_retrieval_problem(N_CELLS, N_QUERIES, DIM, seed=1, noise=0.5)
     eng = Engine(dev)
     searcher = ShardedSearcher(eng)
     d_db = torch.from_numpy(db).cuda()
     d_q = torch.from_numpy(qs).cuda()
     lo, hi = searcher.set_db_shard(d_db)
-    eng.set_option("profile_events", 1)
+    # hipEvents bracket every EVENT_EVERY-th launch of each kernel inside the timed region (4 records per step cost ~14 us
+    # of queue time beside a ~57 us step; the samples still come from the timed loop: `launches_timed` says how many)
+    eng.set_option("profile_events", EVENT_EVERY)
     eng.set_option("search_mode", args.mode)
     if args.nsplit:
         eng.set_option("search_nsplit", args.nsplit)
@@ -461,6 +464,7 @@ def main():
         elapsed = float(t.item())
     scan_ms, scan_n = eng.kernel_stats("search_scan")
     rerank_ms, _ = eng.kernel_stats("search_rerank")
+    eng.set_option("profile_events", 1)  # the side measurements below bracket every launch
     fallbacks = eng.search_fallbacks()
     rescored = eng.search_rescored()
 

@@ -264,11 +264,12 @@ int t2l_adam_step(t2l_ctx* ctx, float lr, float beta1, float beta2, float eps, v
  *     HBM-streaming scan (every CU streams a disjoint DB slice once) instead of the batched scan.
  * "search_nsplit"     (default 0 = auto): DB row splits per query block in the scan kernel.
  * "pointnet_pyg_self_loops" (default 1): see t2l_pointnet_features.
- * "profile_events"    (default 0): record hipEvents around each kernel launch (t2l_kernel_stats). */
+ * "profile_events"    (default 0): n >= 1 records hipEvents around every n-th launch of each kernel (t2l_kernel_stats);
+ *                     two records cost a few microseconds of queue time, which matters beside a 40 us kernel. */
 int t2l_set_option(t2l_ctx* ctx, const char* name, double value);
 
 /* Per-kernel device time measured with hipEvent pairs recorded on the caller's stream around each launch
- * (no synchronisation while recording; enabled by option "profile_events" = 1, off by default).
+ * (no synchronisation while recording; enabled by option "profile_events" >= 1, off by default).
  * Returns the average duration (ms) and the number of launches recorded since the previous call for
  * name = "search_scan" | "search_rerank" | "encode_cells" | "contrastive_loss" | "reduce_objects" | "train_forward" |
  * "train_backward" | "adam_step" | "pointnet" | "fine_objects" | "fine_match" (at most the last 512),

@@ -21,12 +21,15 @@ void event_begin(t2l_ctx* ctx, const char* name, hipStream_t s) {
       (void)hipEventCreate(&e.b[i]);
     }
   }
-  (void)hipEventRecord(e.a[e.head], s);
+  e.open = (e.calls++ % ctx->profile_events) == 0;
+  if (e.open) (void)hipEventRecord(e.a[e.head], s);
 }
 
 void event_end(t2l_ctx* ctx, const char* name, hipStream_t s) {
   if (!ctx->profile_events) return;
   EventRing& e = ctx->events[name];
+  if (!e.open) return;
+  e.open = false;
   (void)hipEventRecord(e.b[e.head], s);
   e.head = (e.head + 1) % kEventRing;
   if (e.count < kEventRing) ++e.count;
@@ -306,7 +309,8 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
   } else if (!strcmp(name, "pointnet_pyg_self_loops")) {
     ctx->pn_self_loops = value != 0;
   } else if (!strcmp(name, "profile_events")) {
-    ctx->profile_events = value != 0;
+    if (value < 0) return fail(ctx, T2L_EINVAL, "profile_events must be >= 0");
+    ctx->profile_events = (int)value;
   } else {
     return fail(ctx, T2L_EINVAL, std::string("unknown option: ") + name);
   }

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, L <= 16 ? 2 : 1) void scan_kernel(const float*
   const int qrow = qb * kQPerBlock + wave * kQPerWave + col;
   const int qload = min(qrow, Q - 1);
   const int mask = ~((1 << code_bits) - 1);
-  if (zero_counts && blockIdx.x == 0 && tid < 2) fb_count[tid] = 0;  // the re-rank / fallback kernels run after this one
+  if (blockIdx.x == 0 && tid < 3 && (zero_counts || tid == 2)) fb_count[tid] = 0;  // [2] = length of this launch's flagged list
 
   // B operand (queries), register resident for the whole scan. The MFMA sums over k in any order as
   // long as A and B agree: lane (col, half) owns k in [128*half, 128*half+128), one contiguous
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void scanw_kernel(const uint4* __restrict__
   const int mask = ~((1 << code_bits) - 1);
   int vmask = mask;
   asm volatile("" : "+v"(vmask));
-  if (zero_counts && blockIdx.x == 0 && tid < 2) fb_count[tid] = 0;
+  if (blockIdx.x == 0 && tid < 3 && (zero_counts || tid == 2)) fb_count[tid] = 0;
   if (nt == 0) return;  // (the host never launches an empty split)
   const int uwave = uniform_wave_id();
 
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, 1) void scanh_kernel(const uint4* __restrict__
   const int mask = ~((1 << code_bits) - 1);
   int vmask = mask;
   asm volatile("" : "+v"(vmask));
-  if (zero_counts && blockIdx.x == 0 && tid < 2) fb_count[tid] = 0;
+  if (blockIdx.x == 0 && tid < 3 && (zero_counts || tid == 2)) fb_count[tid] = 0;
   if (nt == 0) return;  // (the host never launches an empty split)
 
   // ---- LDS-DMA plan: wave w moves row pairs 4w .. 4w+3 of a tile; lane l of piece i lands at LDS chunk l & 31 of row
@@ -487,7 +487,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
                                                      const float* __restrict__ cand, int row_offset, float eps_rel,
                                                      const float* __restrict__ db_norm_max, int half_mode,
                                                      int32_t* __restrict__ out_idx, double* __restrict__ out_score,
-                                                     int32_t* __restrict__ flags, float pinf) {
+                                                     int32_t* __restrict__ flags, int32_t* __restrict__ fb_count,
+                                                     float pinf) {
   const int lane = threadIdx.x & 63;
   const int qid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (qid >= Q) return;
@@ -609,8 +610,10 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
   }
   // 2 = the f16 operands of this query (or of the DB) were not representable: its keys mean nothing, scan exactly
   if (lane == 0) {
-    flags[qid] = !representable ? 2 : (certified ? 0 : 1);
+    const int flag = !representable ? 2 : (certified ? 0 : 1);
+    flags[qid] = flag;
     reinterpret_cast<float*>(flags + Q)[qid] = thr;
+    if (flag) flags[2 * Q + atomicAdd(&fb_count[2], 1)] = qid;  // the fallback kernel walks this list
   }
 }
 
@@ -643,9 +646,10 @@ __global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__
   __shared__ int n_sel, sel_bad;
   __shared__ int sel_c[kMaxSel];
   const int tid = threadIdx.x;
-  for (int qid = blockIdx.x; qid < Q; qid += gridDim.x) {  // flagged queries are rare: few blocks sweep the flags
+  const int n_flagged = fb_count[2];  // queries the re-rank could not certify (usually none or a handful)
+  for (int fi = blockIdx.x; fi < n_flagged; fi += gridDim.x) {
+  const int qid = flags[2 * Q + fi];
   const int flag = flags[qid];
-  if (!flag) continue;
   __syncthreads();
   qs[tid] = (double)q[(size_t)qid * kD + tid];
   if (flag == 2) {  // keys are meaningless (see rerank_kernel): straight to the exact scan
@@ -1036,9 +1040,9 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
   event_begin(ctx, "search_rerank", s);
   hipLaunchKernelGGL((rerank_kernel<LL, L>), dim3((Q + 3) / 4), dim3(256), 0, s, db, q, Q, K, parts, code_bits,
                      ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, half_mode, out_idx, out_score, ctx->flags,
-                     __builtin_inff());
+                     ctx->fb_count, __builtin_inff());
   T2L_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(fallback_kernel<LL>, dim3(min(Q, 512)), dim3(256), 0, s, db, n_rows, q, Q, K, parts, code_bits,
+  hipLaunchKernelGGL(fallback_kernel<LL>, dim3(min(Q, 128)), dim3(256), 0, s, db, n_rows, q, Q, K, parts, code_bits,
                      ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, half_mode, ctx->flags, out_idx, out_score,
                      ctx->fb_count);
   event_end(ctx, "search_rerank", s);
@@ -1067,7 +1071,7 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     return fail(ctx, T2L_EINVAL, "t2l_search: shard too large (more than 256/k segments of 524,288 rows); shard the "
                                  "database over more ranks");
   int rc;
-  if ((rc = grow(ctx, (void**)&ctx->flags, &ctx->flag_cap, (size_t)2 * Q * sizeof(int32_t))) != T2L_OK) return rc;  // flags[Q] + f32 thresholds[Q]
+  if ((rc = grow(ctx, (void**)&ctx->flags, &ctx->flag_cap, (size_t)3 * Q * sizeof(int32_t))) != T2L_OK) return rc;  // flags[Q] + f32 thresholds[Q] + flagged list[Q]
   int32_t* seg_idx = out_idx;
   double* seg_score = out_score;
   if (n_seg > 1) {

@@ -32,6 +32,8 @@ struct EventRing {
   std::vector<hipEvent_t> a, b;
   int head = 0;   // next slot
   int count = 0;  // recorded since the last read (saturates at kEventRing)
+  int calls = 0;  // launches seen (option profile_events = n records every n-th)
+  bool open = false;
 };
 
 struct EncoderWeights;
@@ -76,7 +78,7 @@ struct t2l_ctx {
   int nsplit_override = 0;
   int search_mode = 0;   // 0 = f16 MFMA scan (default), 1 = exact-f32 MFMA scan, 2 = split-bf16 MFMA scan
   int stream_min_rows = 65536;  // shards at least this large answer batches of <= 64 queries with the streaming scan
-  bool profile_events = false;
+  int profile_events = 0;  // 0 off, n >= 1: record every n-th launch of each kernel
   std::unordered_map<std::string, t2l::EventRing> events;
 };
 
