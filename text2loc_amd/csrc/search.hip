@@ -512,7 +512,23 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
   }
   // a FULL list dropped rows inside its lane: all of them have key <= its floor (-inf when nothing was dropped)
   const float floor_max = wave_max_f32(lst[LL - 1], pinf);
-  const float4 qv = reinterpret_cast<const float4*>(q + (size_t)qid * kD)[lane];
+  // the query as float64, 16 elements per lane (dims 64 i + 4 seg + e: each load instruction reads 256 contiguous bytes
+  // per 16-lane row); the lanes of one row cover the 256 dims, the 4 rows hold copies
+  const int seg = lane & 15;
+  double qd[16];
+  float q_absmax = 0.f;
+  {
+    const float4* qp = reinterpret_cast<const float4*>(q + (size_t)qid * kD) + seg;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = qp[16 * i];
+      qd[4 * i] = (double)v.x;
+      qd[4 * i + 1] = (double)v.y;
+      qd[4 * i + 2] = (double)v.z;
+      qd[4 * i + 3] = (double)v.w;
+      q_absmax = fmaxf(fmaxf(fmaxf(q_absmax, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+  }
 
   // ---- merge the `parts` lists into the top-L keys: L rounds of wave arg-max over the list heads
   float my_key = T2L_NEG_INF;
@@ -536,22 +552,35 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
   // lane at or below that lane's floor (with LL == L a floor above the L-th key cannot happen; with LL < L it can)
   const float g = fmaxf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_key), L - 1)), floor_max);
 
-  // ---- float64 re-score of the selected rows (products of f32 values are exact in f64): all L row gathers are
-  // issued before the first reduction
-  const double qn =
-      wave_sum_f64((double)qv.x * qv.x + (double)qv.y * qv.y + (double)qv.z * qv.z + (double)qv.w * qv.w);
-  float4 rows[L];
+  // ---- float64 re-score of the selected rows (products of f32 values are exact in f64). Four rows at a time, one per
+  // 16-lane row of the wave: a lane multiplies 16 elements and the row sum is 4 DPP steps (a whole-wave reduction per
+  // row costs 3x the VALU). All gathers are issued before the first sum.
+  double qn = 0.0;
 #pragma unroll
-  for (int c = 0; c < L; ++c) {
-    const int row = __builtin_amdgcn_readlane(my_row, c);
-    rows[c] = reinterpret_cast<const float4*>(db + (size_t)(row == INT_MAX ? 0 : row) * kD)[lane];
+  for (int i = 0; i < 16; ++i) qn += qd[i] * qd[i];
+  qn = row16_sum_f64(qn);
+  float4 rows[L / 4][4];
+#pragma unroll
+  for (int p = 0; p < L / 4; ++p) {
+    const int row = __shfl(my_row, 4 * p + (lane >> 4));  // candidate 4p + g is re-scored by 16-lane row g
+    const float4* rp = reinterpret_cast<const float4*>(db + (size_t)(row == INT_MAX ? 0 : row) * kD) + seg;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rows[p][i] = rp[16 * i];
   }
   double my_d = -__builtin_inf();
 #pragma unroll
-  for (int c = 0; c < L; ++c) {
-    const double d = wave_sum_f64((double)rows[c].x * qv.x + (double)rows[c].y * qv.y + (double)rows[c].z * qv.z +
-                                  (double)rows[c].w * qv.w);
-    if (lane == c && my_row != INT_MAX) my_d = d;
+  for (int p = 0; p < L / 4; ++p) {
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      d0 += (double)rows[p][i].x * qd[4 * i];
+      d1 += (double)rows[p][i].y * qd[4 * i + 1];
+      d0 += (double)rows[p][i].z * qd[4 * i + 2];
+      d1 += (double)rows[p][i].w * qd[4 * i + 3];
+    }
+    const double d = row16_sum_f64(d0 + d1);
+    const double mine = __shfl(d, 16 * (lane & 3));  // lane c = 4p + g takes the sum of row g
+    if ((lane >> 2) == p && lane < L && my_row != INT_MAX) my_d = mine;
   }
 
   // ---- order by (float64 score desc, row asc); lane c computes its rank among the L
@@ -578,7 +607,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
   double kscale = 1.0;
   bool representable = true;
   {
-    const float m = wave_max_f32(fmaxf(fmaxf(fabsf(qv.x), fabsf(qv.y)), fmaxf(fabsf(qv.z), fabsf(qv.w))), pinf);
+    const float m = row16_max_f32(q_absmax);
     int sq, sd;
     representable = half_shift_of(m, sq);
     representable = half_shift_of(db_norm_max[1], sd) && representable;

@@ -342,6 +342,22 @@ __device__ __forceinline__ double wave_sum_f64(double v) {  // every lane gets t
   return v;
 }
 
+// all-reduce within each row of 16 lanes (the DPP row): every lane of the row gets the row's sum / maximum
+__device__ __forceinline__ double row16_sum_f64(double v) {
+  v += dpp_d<kDppXor1>(v);
+  v += dpp_d<kDppXor2>(v);
+  v += dpp_d<kDppHalfMirror>(v);
+  v += dpp_d<kDppMirror>(v);
+  return v;
+}
+__device__ __forceinline__ float row16_max_f32(float v) {
+  v = fmaxf(v, __uint_as_float(dpp_u<kDppXor1>(__float_as_uint(v))));
+  v = fmaxf(v, __uint_as_float(dpp_u<kDppXor2>(__float_as_uint(v))));
+  v = fmaxf(v, __uint_as_float(dpp_u<kDppHalfMirror>(__float_as_uint(v))));
+  v = fmaxf(v, __uint_as_float(dpp_u<kDppMirror>(__float_as_uint(v))));
+  return v;
+}
+
 // key -> local DB row. part = 2*split + half; split sp owns tiles sp, sp + nsplit, sp + 2*nsplit, ... (interleaved, so a
 // run of similar neighbouring rows spreads over all the per-lane lists instead of filling one).
 __device__ __forceinline__ int key_row(float key, int part, int nsplit, int code_bits) {
