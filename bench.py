@@ -188,10 +188,10 @@ def secondary_measurements(eng):
         torch.cuda.synchronize()
         lat[f"q{qn}_us_per_call"] = (time.perf_counter() - t0) / 200 * 1e6
     out["search_latency"] = lat
-    # HBM-streaming regime (SURVEY.md §8d config 2'): 32 queries against N = 1,048,576 rows (1 GiB of split-bf16 DB,
-    # 4x the Infinity Cache): algorithmic bytes = the DB once per launch
+    # HBM-streaming regime (SURVEY.md §8d config 2'): 32 queries against N = 2,097,152 rows (1 GiB of f16 DB plane,
+    # 4x the Infinity Cache): algorithmic bytes = that plane once per launch (512 B per row)
     try:
-        n_big = 1 << 20
+        n_big = 1 << 21
         rs = np.random.default_rng(7)
         big = rs.standard_normal((n_big, DIM), dtype=np.float32)
         big /= np.linalg.norm(big, axis=1, keepdims=True)
@@ -206,11 +206,11 @@ def secondary_measurements(eng):
             idx_b, _ = eng2.search(dq, TOPK)
         torch.cuda.synchronize()
         ms, n = eng2.kernel_stats("search_scan")
-        bytes_alg = n_big * 1024.0
+        bytes_alg = n_big * 512.0
         sel = [0, 13, 31]
         from oracle import c_oracle
         ridx, _ = c_oracle.retrieve_topk(big, _QS[sel], TOPK)
-        out["hbm_stream"] = {"workload": "N=1048576 rows, Q=32 per launch, top-10, scanq_kernel<16>", "kernel_ms": ms,
+        out["hbm_stream"] = {"workload": "N=2097152 rows (f16 plane 1 GiB), Q=32 per launch, top-10, scanq_kernel<16>", "kernel_ms": ms,
                              "algorithmic_bytes_per_launch": bytes_alg, "achieved_GBps": bytes_alg / (ms * 1e-3) / 1e9,
                              "peak_GBps": 8000.0, "frac": bytes_alg / (ms * 1e-3) / 1e9 / 8000.0,
                              "traffic": pmc_traffic("t2l::scanq_kernel<16>"), "launches_timed": n,

@@ -152,6 +152,34 @@ def test_clustered_scores_use_the_second_stage(eng):
     assert eng.search_rescored() >= eng.search_fallbacks()
 
 
+def test_auto_mode_leaves_the_f16_scan_on_packed_scores_and_returns(eng):
+    """Scores packed ~1e-4 apart: the f16 error band cannot separate anything, every query is flagged; the engine
+    reads that count back (no synchronisation of its own) and serves the next batches with the split-bf16 scan, then goes
+    back to the f16 scan once ordinary data would certify again. Results are exact throughout."""
+    import torch
+
+    if eng.scan_mode != 0:
+        pytest.skip("auto mode belongs to the default scan")
+    rng = np.random.default_rng(29)
+    q = synth.unit_rows(rng.standard_normal((64, 256))).astype(np.float32)
+    base = synth.unit_rows(rng.standard_normal((1, 256)))
+    packed = synth.unit_rows(base + 1e-3 * rng.standard_normal((3000, 256))).astype(np.float32)
+    ridx, rsc = O.retrieve_topk(packed, q, 10)
+    idx, sc = _search(eng, packed, q, 10)
+    assert np.array_equal(idx, ridx) and np.abs(sc - rsc).max() < 1e-12
+    first = eng.search_rescored()
+    assert first > len(q) // 8
+    idx, sc = _search(eng, packed, q, 10)  # the stand-in scan: its certificate holds
+    assert np.array_equal(idx, ridx) and np.abs(sc - rsc).max() < 1e-12
+    assert eng.search_rescored() < first
+    db, qs, _ = synth.make_retrieval_problem(3000, 64, seed=31, noise=2.0)
+    r2, _ = O.retrieve_topk(db, qs, 10)
+    for _ in range(3):  # ordinary data: one stand-in call reports "f16 would certify", the next ones are f16 again
+        idx, _ = _search(eng, db, qs, 10)
+        assert np.array_equal(idx, r2)
+    assert eng.search_fallbacks() == 0
+
+
 @pytest.mark.parametrize("nsplit", [1, 3, 8, 32])
 def test_nsplit_invariance(eng, nsplit):
     db, qs, _ = synth.make_retrieval_problem(2500, 130, seed=9, noise=2.0)

@@ -57,6 +57,10 @@ int t2l_create(t2l_ctx** out, int device_id) {
     return T2L_ENOMEM;
   }
   (void)hipMemset(ctx->db_norm_max, 0, 2 * sizeof(float));
+  if (hipHostMalloc((void**)&ctx->host_stat, 4 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess) {
+    memset(ctx->host_stat, 0, 4 * sizeof(int32_t));
+    if (hipHostGetDevicePointer((void**)&ctx->host_stat_dev, ctx->host_stat, 0) != hipSuccess) ctx->host_stat_dev = nullptr;
+  }
   (void)hipMemset(ctx->fb_count, 0, 128 * sizeof(int32_t));
   *out = ctx;
   return T2L_OK;
@@ -73,6 +77,7 @@ void t2l_destroy(t2l_ctx* ctx) {
   for (void* p : {(void*)ctx->db, (void*)ctx->db_split, (void*)ctx->db_half, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
                   (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count, ctx->reduce_ws})
     if (p) (void)hipFree(p);
+  if (ctx->host_stat) (void)hipHostFree(ctx->host_stat);
   for (auto& kv : ctx->events) {
     for (hipEvent_t ev : kv.second.a) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : kv.second.b) (void)hipEventDestroy(ev);
@@ -304,6 +309,9 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     if (value != 0 && value != 1 && value != 2)
       return fail(ctx, T2L_EINVAL, "search_mode must be 0 (f16 scan), 1 (f32 scan) or 2 (split-bf16 scan)");
     ctx->search_mode = (int)value;
+  } else if (!strcmp(name, "search_auto")) {
+    ctx->search_auto = value != 0;
+    if (!ctx->search_auto) ctx->escalated = false;
   } else if (!strcmp(name, "stream_min_rows")) {
     ctx->stream_min_rows = (int)value;
   } else if (!strcmp(name, "pointnet_pyg_self_loops")) {

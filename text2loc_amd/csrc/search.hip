@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, L <= 16 ? 2 : 1) void scan_kernel(const float*
   const int qrow = qb * kQPerBlock + wave * kQPerWave + col;
   const int qload = min(qrow, Q - 1);
   const int mask = ~((1 << code_bits) - 1);
-  if (blockIdx.x == 0 && tid < 3 && (zero_counts || tid == 2)) fb_count[tid] = 0;  // [2] = length of this launch's flagged list
+  if (blockIdx.x == 0 && tid < 4 && (zero_counts || tid >= 2)) fb_count[tid] = 0;  // [2] = length of this launch's flagged list
 
   // B operand (queries), register resident for the whole scan. The MFMA sums over k in any order as
   // long as A and B agree: lane (col, half) owns k in [128*half, 128*half+128), one contiguous
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void scanw_kernel(const uint4* __restrict__
   const int mask = ~((1 << code_bits) - 1);
   int vmask = mask;
   asm volatile("" : "+v"(vmask));
-  if (blockIdx.x == 0 && tid < 3 && (zero_counts || tid == 2)) fb_count[tid] = 0;
+  if (blockIdx.x == 0 && tid < 4 && (zero_counts || tid >= 2)) fb_count[tid] = 0;  // [3] = f16-probe count (rerank_kernel)
   if (nt == 0) return;  // (the host never launches an empty split)
   const int uwave = uniform_wave_id();
 
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, 1) void scanh_kernel(const uint4* __restrict__
   const int mask = ~((1 << code_bits) - 1);
   int vmask = mask;
   asm volatile("" : "+v"(vmask));
-  if (blockIdx.x == 0 && tid < 3 && (zero_counts || tid == 2)) fb_count[tid] = 0;
+  if (blockIdx.x == 0 && tid < 4 && (zero_counts || tid >= 2)) fb_count[tid] = 0;  // [3] = f16-probe count (rerank_kernel)
   if (nt == 0) return;  // (the host never launches an empty split)
 
   // ---- LDS-DMA plan: wave w moves row pairs 4w .. 4w+3 of a tile; lane l of piece i lands at LDS chunk l & 31 of row
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
                                                      const float* __restrict__ db_norm_max, int half_mode,
                                                      int32_t* __restrict__ out_idx, double* __restrict__ out_score,
                                                      int32_t* __restrict__ flags, int32_t* __restrict__ fb_count,
-                                                     float pinf) {
+                                                     float eps_rel_probe, float pinf) {
   const int lane = threadIdx.x & 63;
   const int qid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (qid >= Q) return;
@@ -628,6 +628,11 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
       const double dK = __shfl(my_d, __ffsll((long long)kth) - 1);
       const double eps32 = (double)eps_rel * sqrt(qn) * (double)(*db_norm_max);
       certified = dK > (double)g * kscale + key_slack(g, code_bits, eps32, kscale);
+      // while the split-bf16 scan stands in for the f16 scan on a DB that overwhelmed its certificate, count the queries
+      // the f16 error band would still flag: the host goes back to the f16 scan when they become rare
+      if (eps_rel_probe > 0.f && lane == 0 &&
+          !(dK > (double)g * kscale + key_slack(g, code_bits, (double)eps_rel_probe * sqrt(qn) * (double)(*db_norm_max), kscale)))
+        atomicAdd(&fb_count[3], 1);
       // a row with key k has score <= k*kscale + |k|*kscale*2^(cb-22) + eps32; with S = 2*(|dK|*2^(cb-22) + eps32) every
       // key below (dK - S)/kscale is therefore below the current K-th best score dK (and the final K-th is >= dK)
       const double S = 2.0 * (fabs(dK) * ldexp(1.0, code_bits - 22) + eps32);
@@ -661,7 +666,8 @@ __global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__
                                                        float eps_rel, const float* __restrict__ db_norm_max, int half_mode,
                                                        const int32_t* __restrict__ flags,
                                                        int32_t* __restrict__ out_idx, double* __restrict__ out_score,
-                                                       int32_t* __restrict__ fb_count) {
+                                                       int32_t* __restrict__ fb_count, int32_t* __restrict__ host_stat,
+                                                       int seq, int probe) {
   __shared__ double qs[kD];
   __shared__ double cd[kMaxCand];
   __shared__ int crow[kMaxCand];
@@ -676,6 +682,12 @@ __global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__
   __shared__ int sel_c[kMaxSel];
   const int tid = threadIdx.x;
   const int n_flagged = fb_count[2];  // queries the re-rank could not certify (usually none or a handful)
+  if (host_stat && blockIdx.x == 0 && threadIdx.x == 0) {  // report card for the host (mapped memory, read at a later call)
+    host_stat[1] = probe ? fb_count[3] : n_flagged;
+    host_stat[2] = Q;
+    __threadfence_system();
+    host_stat[0] = seq;
+  }
   for (int fi = blockIdx.x; fi < n_flagged; fi += gridDim.x) {
   const int qid = flags[2 * Q + fi];
   const int flag = flags[qid];
@@ -1035,16 +1047,17 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
   const int n_tiles = (n_rows + kTileRows - 1) / kTileRows;
   const int parts = 2 * nsplit;
   const int zero = first;
-  const int half_mode = ctx->search_mode == 0;
+  const int half_mode = ctx->eff_mode == 0;
+  const bool probing = ctx->search_mode == 0 && ctx->eff_mode == 2;  // standing in for the f16 scan (search_impl)
   event_begin(ctx, "search_scan", s);
-  if (ctx->search_mode == 0) {  // f16 MFMA scan (default): one workgroup per CU, 256 queries each
+  if (ctx->eff_mode == 0) {  // f16 MFMA scan (default): one workgroup per CU, 256 queries each
     const dim3 grid((Q + kWideQPerBlock - 1) / kWideQPerBlock * nsplit);
     const size_t lds = (size_t)4 * kHalfTileBytes;
     static bool once = (allow_lds(&scanh_kernel<LL>, (size_t)4 * kHalfTileBytes), true);
     (void)once;
     hipLaunchKernelGGL((scanh_kernel<LL>), grid, dim3(256), lds, s, dbh, n_rows, n_tiles, code_bits, q, Q, nsplit,
                        ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
-  } else if (ctx->search_mode == 2) {  // split-bf16 MFMA scan, same structure, three MFMAs per product
+  } else if (ctx->eff_mode == 2) {  // split-bf16 MFMA scan, same structure, three MFMAs per product
     const dim3 grid((Q + kWideQPerBlock - 1) / kWideQPerBlock * nsplit);
     const size_t lds = (size_t)4 * kTileFloats * sizeof(float);
     static bool once = (allow_lds(&scanw_kernel<LL, 4>, (size_t)4 * kTileFloats * sizeof(float)), true);
@@ -1064,16 +1077,17 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
   // f32 dot-product error bound: gamma_n * |a||b| with n = 256 terms (+ slack for the MFMA's k order), plus the operand
   // rounding of the scan that produced the keys: f16 (RNE, both operands) 2^-10 + 2^-21 and 2^-20 for denormal
   // elements, rounded up to 9.85e-4; split-bf16 2^-16 + 2^-18, rounded up to 2e-5; f32: none
-  const double operand_eps = ctx->search_mode == 0 ? 9.85e-4 : (ctx->search_mode == 2 ? 2.0e-5 : 0.0);
+  const double operand_eps = ctx->eff_mode == 0 ? 9.85e-4 : (ctx->eff_mode == 2 ? 2.0e-5 : 0.0);
   const float eps_rel = (float)(ctx->eps_scale * ((kD + 8) * 5.9604644775390625e-08 + operand_eps));
   event_begin(ctx, "search_rerank", s);
   hipLaunchKernelGGL((rerank_kernel<LL, L>), dim3((Q + 3) / 4), dim3(256), 0, s, db, q, Q, K, parts, code_bits,
                      ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, half_mode, out_idx, out_score, ctx->flags,
-                     ctx->fb_count, __builtin_inff());
+                     ctx->fb_count, probing ? (float)(ctx->eps_scale * ((kD + 8) * 5.9604644775390625e-08 + 9.85e-4)) : 0.f,
+                     __builtin_inff());
   T2L_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(fallback_kernel<LL>, dim3(min(Q, 128)), dim3(256), 0, s, db, n_rows, q, Q, K, parts, code_bits,
                      ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, half_mode, ctx->flags, out_idx, out_score,
-                     ctx->fb_count);
+                     ctx->fb_count, (half_mode || probing) ? ctx->host_stat_dev : nullptr, ++ctx->stat_seq, probing ? 1 : 0);
   event_end(ctx, "search_rerank", s);
   T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;
@@ -1089,7 +1103,21 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
   // few queries against a large shard: stream the DB once through every CU (search_stream.hip)
   if (Q <= 64 && n_rows >= ctx->stream_min_rows && n_rows > 0 && ctx->search_mode == 0 && ctx->nsplit_override == 0)
     return search_stream_impl(ctx, q, Q, K, out_idx, out_score, s);
-  const bool wide = ctx->search_mode != 1;
+  // the f16 scan's report card of an earlier call on this DB (see t2l_internal.h): more than 1 in 8 queries flagged ->
+  // the split-bf16 scan from now on
+  // ... and back when fewer than 1 in 16 would be (the stand-in counts them, rerank_kernel)
+  if (ctx->search_mode == 0 && ctx->search_auto && ctx->host_stat) {
+    const volatile int32_t* hs = ctx->host_stat;
+    const int done = hs[0];
+    if (done > ctx->stat_seen) {
+      ctx->stat_seen = done;
+      const int64_t flagged = hs[1], total = hs[2];
+      if (!ctx->escalated && flagged * 8 > total) ctx->escalated = true;
+      else if (ctx->escalated && flagged * 16 < total) ctx->escalated = false;
+    }
+  }
+  ctx->eff_mode = (ctx->search_mode == 0 && ctx->escalated) ? 2 : ctx->search_mode;
+  const bool wide = ctx->eff_mode != 1;
   const int qpb = wide ? kWideQPerBlock : kQPerBlock;
   const int n_qblocks = (Q + qpb - 1) / qpb;
   // rows re-scored per query: K + margin (the margin only has to absorb key-truncation ties; the certificate catches

@@ -60,42 +60,6 @@ __device__ __forceinline__ void ins_key_sat(float (&s)[L], float x, float pinf) 
   }
 }
 
-// 48 MFMAs of a tile on ONE accumulator chain, 3 per k-step, with one score of the previous tile inserted per
-// k-step (measured: for the bf16 MFMA a single chain with ~6 interleaved VALU per MFMA beats two alternating
-// chains, which cost 32 more VGPRs and a spill at two waves per SIMD; issuing the next tile's LDS-DMA rows one per
-// k-step inside this phase instead of in a burst after the barrier was also measured: no net gain).
-template <int L, int VPM, int S, int S_END>
-__device__ __forceinline__ void tile_mfma_bf16_sel(const char* tb, const uint4 (&qh)[16], const uint4 (&ql)[16],
-                                                   f32x16& cur, const f32x16& prev, int vmask, int code0, float pinf,
-                                                   float (&ls)[L], uint4 (&ah)[4], uint4 (&al)[4]) {
-  if constexpr (S < S_END) {
-    if constexpr (S == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // prologue LDS reads first
-    const uint4 a_hi = ah[S & 3], a_lo = al[S & 3];
-    if constexpr (S + 4 < 16) {
-      ah[S & 3] = *reinterpret_cast<const uint4*>(tb + 16 * (S + 4));
-      al[S & 3] = *reinterpret_cast<const uint4*>(tb + 512 + 16 * (S + 4));
-    }
-    const bf16x8 vh = __builtin_bit_cast(bf16x8, a_hi), vl = __builtin_bit_cast(bf16x8, a_lo);
-    const bf16x8 bh = __builtin_bit_cast(bf16x8, qh[S]), bl = __builtin_bit_cast(bf16x8, ql[S]);
-    cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, bh, cur, 0, 0, 0);
-    cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, bl, cur, 0, 0, 0);
-    cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, bh, cur, 0, 0, 0);
-    {  // score S of the previous tile enters the list: 2 + L VALU
-      const int code = __builtin_amdgcn_readfirstlane(code0 + S);
-      const float key = __int_as_float((__float_as_int(prev[S]) & vmask) | code);
-      ins_key_sat<L>(ls, key, pinf);
-    }
-#pragma unroll
-    for (int e = 0; e < 3; ++e) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-    }
-    if constexpr (S + 4 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    tile_mfma_bf16_sel<L, VPM, S + 1, S_END>(tb, qh, ql, cur, prev, vmask, code0, pinf, ls, ah, al);
-  }
-}
-
-
 // ---- LDS-DMA: global_load_lds_dwordx4, one wave-instruction moves 64 x 16 B = one 1 KiB DB row into LDS (M0 = the
 // row's LDS address, the hardware adds lane*16). Issued from inline asm ON PURPOSE: for the compiler's builtin,
 // SIInsertWaitcnts makes every later LDS read wait for vmcnt(0) ("may alias the DMA's LDS write"), i.e. the wave sits out

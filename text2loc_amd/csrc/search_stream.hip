@@ -1,46 +1,87 @@
 // Small query batches against a LARGE shard: the HBM-streaming form of the search (SURVEY.md §8d config 2').
 //
 // With few queries (<= 64) the arithmetic is far below the matrix pipe's capacity and the job is to pull the DB
-// through the chip once at HBM speed. The batched scan (search.hip) gives every 128-query block its own pass over
+// through the chip once at HBM speed. The batched scan (search.hip) gives every 256-query block its own pass over
 // the DB and would leave most CUs idle here. This variant turns the decomposition around:
 //
-//   scanq_kernel       ALL waves of the chip hold the SAME (<= 32) queries as register-resident split-bf16 fragments
-//                      and each wave streams its OWN 32-row tiles HBM -> LDS (global_load_lds into a private 33 KiB
-//                      buffer, no workgroup barrier anywhere), multiplies them (3 x bf16 MFMA per product, as scan3)
-//                      and keeps per-lane sorted key lists. At the end a workgroup merges its 8 lists per query into
-//                      one (key, row) list: the candidate set is [32 queries][G workgroups][L].
+//   scanq_kernel       ALL waves of the chip hold the SAME (<= 32) queries as register-resident f16 fragments (scaled by
+//                      a power of two, as scanh_kernel) and each wave streams its OWN 32-row tiles of the f16 DB plane
+//                      HBM -> LDS (LDS-DMA into a private 2 x 16 KiB double buffer: the next tile is in flight while the
+//                      current one multiplies; no workgroup barrier anywhere), one f16 MFMA per product, per-lane sorted
+//                      key lists. At the end a workgroup merges its 8 lists per query into one (key, row) list: the
+//                      candidate set is [32 queries][G workgroups][L].
 //   rerank_rows_kernel one workgroup per query: top-L of the G lists by key, float64 re-score, (score desc, row asc)
 //                      order, the same certificate as the batched path.
 //   exact_only_kernel  float64 scan of the shard for queries whose certificate failed.
 //
-// Algorithmic bytes per launch: the split-bf16 DB once = 1 KiB per row (+ G*32*L*8 B of candidates).
+// Algorithmic bytes per launch: the f16 DB plane once = 512 B per row (+ G*32*L*8 B of candidates).
 #include "search_dev.h"
 
 namespace t2l {
 
 constexpr int kStreamQ = 32;  // queries per scanq launch
 
+// 16 k-steps of one tile: fragment ring of 4 (within the tile), one MFMA and the insertion of one score of the previous
+// tile per k-step (1 + L VALU, pinned behind the MFMA)
+template <int L, int S>
+__device__ __forceinline__ void tileq_steps(const char* tb, const unsigned (&roff)[16], const u32x4 (&qf)[16], f32x16& cur,
+                                            const f32x16& prev, int vmask, int code0, float pinf, float (&ls)[L],
+                                            u32x4 (&ring)[4]) {
+  if constexpr (S < 16) {
+    const u32x4 a = ring[S & 3];
+    const int code = __builtin_amdgcn_readfirstlane(code0 + S);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S == 0) mfma_f16_first(cur, a, qf[S]); else mfma_f16_acc(cur, a, qf[S]);
+    if constexpr (S + 4 < 16) ring[S & 3] = *reinterpret_cast<const u32x4*>(tb + roff[S + 4]);
+    __builtin_amdgcn_sched_barrier(0);
+    ins_key_sat<L>(ls, __int_as_float((__float_as_int(prev[S]) & vmask) | code), pinf);
+    __builtin_amdgcn_sched_barrier(0);
+    tileq_steps<L, S + 1>(tb, roff, qf, cur, prev, vmask, code0, pinf, ls, ring);
+  }
+}
+
 template <int L>
-__global__ __launch_bounds__(256, 1) void scanq_kernel(const uint4* __restrict__ dbs, int n_rows, int n_tiles, int per,
+__global__ __launch_bounds__(256, 1) void scanq_kernel(const uint4* __restrict__ dbh, int n_rows, int n_tiles, int per,
                                                        int code_bits, const float* __restrict__ q, int q0, int Q,
                                                        float* __restrict__ cand_key, int* __restrict__ cand_row,
                                                        float pinf) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform_wave_id();
   const int half = lane >> 5, col = lane & 31;
   const int G = gridDim.x, wg = blockIdx.x;
-  float* tile = smem + wave * kTileFloats;  // this wave's private tile buffer
+  char* tiles = reinterpret_cast<char*>(smem) + wave * (2 * kHalfTileBytes);  // this wave's private double buffer
+  const unsigned tiles_lds = lds_addr_of(tiles);
   const int mask = ~((1 << code_bits) - 1);
   int vmask = mask;
   asm volatile("" : "+v"(vmask));
 
-  // every wave of the chip: the same 32 queries q0 .. q0+31 (clamped)
-  uint4 qh[16], ql[16];
+  // every wave of the chip: the same 32 queries q0 .. q0+31 (clamped), scaled and rounded to f16 like scanh_kernel
+  u32x4 qf[16];
   {
     const int qrow = min(q0 + col, Q - 1);
     const float4* qp = reinterpret_cast<const float4*>(q + (size_t)qrow * kD + half * 128);
+    float4 v[32];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) split8(qp[2 * s], qp[2 * s + 1], qh[s], ql[s]);
+    for (int i = 0; i < 32; ++i) v[i] = qp[i];
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      m = fmaxf(fmaxf(m, fabsf(v[i].x)), fabsf(v[i].y));
+      m = fmaxf(fmaxf(m, fabsf(v[i].z)), fabsf(v[i].w));
+    }
+    {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+      m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    int shift;
+    half_shift_of(m, shift);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float4 a = v[2 * s], b = v[2 * s + 1];
+      qf[s] = pin_agpr(u32x4{pack_f16x2(a.x, a.y, shift), pack_f16x2(a.z, a.w, shift), pack_f16x2(b.x, b.y, shift),
+                             pack_f16x2(b.z, b.w, shift)});
+    }
   }
   float ls[L];
 #pragma unroll
@@ -49,62 +90,62 @@ __global__ __launch_bounds__(256, 1) void scanq_kernel(const uint4* __restrict__
 #pragma unroll
   for (int r = 0; r < 16; ++r) accA[r] = accB[r] = T2L_NEG_INF;
 
+  // LDS tile layout as scanh_kernel: unpadded 512-byte rows, 16-byte chunk c of row r at chunk c ^ r. One LDS-DMA
+  // instruction moves two rows; lane l of piece i lands at chunk l & 31 of row 2i + (l >> 5).
+  unsigned doff[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = 2 * i + half;
+    doff[i] = r * 512 + ((col ^ r) << 4);
+  }
+  unsigned roff[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) roff[s] = col * 512 + ((((half << 4) + s) ^ col) << 4);
+
   // wave (wg, wave) owns tiles  (wg*per + j)*4 + wave,  j = 0 .. per-1  (interleaved so neighbours stream neighbours)
   const int tbase = wg * per * 4 + wave;
   auto tile_of = [&](int j) { return tbase + 4 * j; };
-  auto fetch = [&](int t) {
-    const uint4* src = dbs + (size_t)t * kTileRows * 64 + lane;
-#pragma unroll 8
-    for (int row = 0; row < kTileRows; ++row)  // one wave-instruction = one 1 KiB row (hi | lo planes)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + row * 64),
-                                       (__attribute__((address_space(3))) void*)(tile + row * kRowStrideF), 16, 0, 0);
+  auto fetch = [&](int t, int buf) {
+    const char* src = reinterpret_cast<const char*>(dbh) + (size_t)t * kHalfTileBytes;
+    const unsigned dst = tiles_lds + buf * kHalfTileBytes;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lds_dma_row(dst + i * 1024, doff[i], src);
   };
-  const char* tb = reinterpret_cast<const char*>(tile) + col * (kRowStrideF * 4) + half * 256;
-  auto step = [&](int j, f32x16& cur, const f32x16& prev) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own tile has landed (no other wave touches it)
-    uint4 ah[4], al[4];
+  auto step = [&](int j, int buf, bool more, f32x16& cur, const f32x16& prev) {
+    // tile j has landed (its 16 pieces are older than the 16 of tile j+1 that may still be in flight)
+    if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* tb = tiles + buf * kHalfTileBytes;
+    u32x4 ring[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ah[i] = *reinterpret_cast<const uint4*>(tb + 16 * i);
-      al[i] = *reinterpret_cast<const uint4*>(tb + 512 + 16 * i);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) cur[r] = 0.f;
-    constexpr int VPM = (L + 2 + 2) / 3;
-    tile_mfma_bf16_sel<L, VPM, 0, 16>(tb, qh, ql, cur, prev, vmask, (j - 1) << 4, pinf, ls, ah, al);
+    for (int i = 0; i < 4; ++i) ring[i] = *reinterpret_cast<const u32x4*>(tb + roff[i]);
+    tileq_steps<L, 0>(tb, roff, qf, cur, prev, vmask, (j - 1) << 4, pinf, ls, ring);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all LDS reads of this tile are done: the buffer may refill
   };
   int nj = 0;
   while (nj < per && tile_of(nj) < n_tiles) ++nj;  // tiles this wave really has
-  if (nj > 0) fetch(tile_of(0));
+  if (nj > 0) fetch(tile_of(0), 0);
   for (int j = 0; j < nj; j += 2) {
-    step(j, accA, accB);
-    if (j + 1 < nj) fetch(tile_of(j + 1));
+    if (j + 1 < nj) fetch(tile_of(j + 1), 1);  // buffer 1 was last read by tile j-1 (lgkmcnt(0) above)
+    step(j, 0, j + 1 < nj, accA, accB);
     if (j + 1 < nj) {
-      step(j + 1, accB, accA);
-      if (j + 2 < nj) fetch(tile_of(j + 2));
+      if (j + 2 < nj) fetch(tile_of(j + 2), 0);
+      step(j + 1, 1, j + 2 < nj, accB, accA);
     }
   }
   if (nj > 0) {  // the last tile's scores are still in registers; only the last tile of the shard can be partial
     const int row0 = tile_of(nj - 1) * kTileRows + 4 * half;
     const int code0 = (nj - 1) << 4;
-    if (nj & 1) {
+    const bool odd = nj & 1;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2);
-        ins_key<L>(ls, row < n_rows ? make_key(accA[r], mask, code0 + r) : T2L_NEG_INF);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2);
-        ins_key<L>(ls, row < n_rows ? make_key(accB[r], mask, code0 + r) : T2L_NEG_INF);
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + (r & 3) + 8 * (r >> 2);
+      ins_key<L>(ls, row < n_rows ? make_key(odd ? accA[r] : accB[r], mask, code0 + r) : T2L_NEG_INF);
     }
   }
 
   // ---- workgroup merge: 8 sorted lists per query (4 waves x 2 halves) -> one (key, row) list of L
-  __syncthreads();  // every wave is done with its tile buffer: reuse LDS
+  __syncthreads();  // every wave is done with its tile buffers: reuse LDS
   float* lists = smem;  // [32 queries][8 lists][L]
 #pragma unroll
   for (int i = 0; i < L; ++i) lists[(col * 8 + wave * 2 + half) * L + i] = ls[i];
@@ -252,6 +293,13 @@ __global__ __launch_bounds__(256) void rerank_rows_kernel(const float* __restric
       if (out_score) out_score[(size_t)qid * K + rank] = my_d;
     }
     const float g = sel_key[L - 1];
+    // keys are true scores times 2^(shift_db + shift_q) (f16 scan): undo that exactly; inputs without an f16 image are
+    // scanned exactly
+    int sq, sd;
+    const float m = wave_max_f32(fmaxf(fmaxf(fabsf(qv.x), fabsf(qv.y)), fmaxf(fabsf(qv.z), fabsf(qv.w))), pinf);
+    bool representable = half_shift_of(m, sq);
+    representable = half_shift_of(db_norm_max[1], sd) && representable;
+    const double kscale = ldexp(1.0, -(sq + sd));
     bool certified = true;
     if (g != T2L_NEG_INF) {
       certified = false;
@@ -259,10 +307,10 @@ __global__ __launch_bounds__(256) void rerank_rows_kernel(const float* __restric
       if (K <= L && kth != 0ull) {
         const double dK = sel_d[__ffsll((long long)kth) - 1];
         const double eps32 = (double)eps_rel * sqrt(qn) * (double)(*db_norm_max);
-        certified = dK > (double)g + key_slack(g, code_bits, eps32);
+        certified = dK > (double)g * kscale + key_slack(g, code_bits, eps32, kscale);
       }
     }
-    if (lane == 0) flags[qid] = certified ? 0 : 1;
+    if (lane == 0) flags[qid] = (certified && representable) ? 0 : 1;
   }
 }
 
@@ -300,7 +348,7 @@ template <int L>
 static int stream_launch(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s) {
   const int n_rows = (int)ctx->db_rows;
   const int n_tiles = (int)(ctx->db_pad / kTileRows);
-  int G = 256;  // one workgroup (4 waves, 4 private tile buffers = 133 KB of LDS) per CU
+  int G = 256;  // one workgroup (4 waves, 4 private 2 x 16 KiB tile buffers = 128 KiB of LDS) per CU
   while (G > 1 && (n_tiles + G * 4 - 1) / (G * 4) < 2) G >>= 1;
   const int per = (n_tiles + G * 4 - 1) / (G * 4);
   int code_bits = 4;
@@ -311,19 +359,19 @@ static int stream_launch(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* ou
       (rc = grow_buf(ctx, (void**)&ctx->seg_idx, &ctx->seg_idx_cap, (size_t)kStreamQ * G * L * sizeof(int32_t))) != T2L_OK ||
       (rc = grow_buf(ctx, (void**)&ctx->flags, &ctx->flag_cap, (size_t)Q * sizeof(int32_t))) != T2L_OK)
     return rc;
-  const size_t lds = (size_t)4 * kTileFloats * sizeof(float);
+  const size_t lds = (size_t)4 * 2 * kHalfTileBytes;
   static bool attr_done = false;
   if (!attr_done) {
     T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&scanq_kernel<L>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  const float eps_rel = (float)(ctx->eps_scale * ((kD + 8) * 5.9604644775390625e-08 + 2.0e-5));
+  const float eps_rel = (float)(ctx->eps_scale * ((kD + 8) * 5.9604644775390625e-08 + 9.85e-4));  // f16 operands (search.hip)
   T2L_HIP(ctx, hipMemsetAsync(ctx->fb_count, 0, 2 * sizeof(int32_t), s));
   for (int q0 = 0; q0 < Q; q0 += kStreamQ) {
     const int nq = min(kStreamQ, Q - q0);
     event_begin(ctx, "search_scan", s);
-    hipLaunchKernelGGL(scanq_kernel<L>, dim3(G), dim3(256), lds, s, ctx->db_split, n_rows, n_tiles, per, code_bits, q, q0,
+    hipLaunchKernelGGL(scanq_kernel<L>, dim3(G), dim3(256), lds, s, ctx->db_half, n_rows, n_tiles, per, code_bits, q, q0,
                        Q, ctx->cand_score, ctx->seg_idx, __builtin_inff());
     event_end(ctx, "search_scan", s);
     T2L_HIP(ctx, hipGetLastError());

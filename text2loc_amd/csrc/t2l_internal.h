@@ -77,6 +77,16 @@ struct t2l_ctx {
   double eps_scale = 1.0;
   int nsplit_override = 0;
   int search_mode = 0;   // 0 = f16 MFMA scan (default), 1 = exact-f32 MFMA scan, 2 = split-bf16 MFMA scan
+  // mode 0 watches how many queries of a batch its certificate sends to the second stage (the fallback kernel writes the
+  // count to mapped host memory; no stream operation, no synchronisation) and, when that is more than one in eight —
+  // scores packed tighter than the f16 error band — searches with the split-bf16 scan (50x tighter bound) until fewer than
+  // one in sixteen would be flagged again
+  int search_auto = 1;
+  int eff_mode = 0;           // the scan the current t2l_search call runs
+  bool escalated = false;     // the split-bf16 scan is standing in (it counts what the f16 band would still flag)
+  int32_t* host_stat = nullptr;      // mapped pinned host int32[4]: {sequence number of the last finished call, flagged, Q}
+  int32_t* host_stat_dev = nullptr;  // its device address
+  int stat_seq = 0, stat_seen = 0;
   int stream_min_rows = 65536;  // shards at least this large answer batches of <= 64 queries with the streaming scan
   int profile_events = 0;  // 0 off, n >= 1: record every n-th launch of each kernel
   std::unordered_map<std::string, t2l::EventRing> events;
