@@ -8,9 +8,10 @@ the timed region starts. With --gpus N the DB is row-sharded over the ranks (one
 searches its shard, one RCCL all_gather of the per-shard top-k, merge on every rank (strong scaling: total
 work fixed).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the fused
-f32-MFMA scan; algorithmic FLOPs = 2*Q*N*D per launch / its hipEvent-measured duration vs the dense MFMA peak of the
-dtype the scan multiplies in: bf16 2.5 PF for the default split-bf16 scan, 157.3 TF for --mode 1 = f32) and `cpu_baseline` (the numpy oracle of training/coarse.py:119-125 timed on this host).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the fused MFMA
+candidate scan; algorithmic FLOPs = 2*Q*N*D per launch / its hipEvent-measured duration vs the dense MFMA peak of the
+dtype the scan multiplies in: 2.5 PF for the default f16 scan and for --mode 2 = split-bf16, 157.3 TF for --mode 1 = f32)
+and `cpu_baseline` (the numpy oracle of training/coarse.py:119-125 timed on this host).
 """
 import argparse
 import json

@@ -258,8 +258,11 @@ int t2l_adam_step(t2l_ctx* ctx, float lr, float beta1, float beta2, float eps, v
 /* ---- knobs (tests / bench) ------------------------------------------------------------------- */
 /* "certify_eps_scale" (default 1.0): multiplies the f32 error bound of the search certificate; a huge
  *     value forces every query through the exact fallback (used by the parity tests).
- * "search_mode"       (default 0): 0 = split-bf16 (bf16x3) MFMA scan, 1 = exact-f32 MFMA scan. Both feed the same float64
- *     re-rank + certificate, so the RESULTS are identical; only the speed differs.
+ * "search_mode"       (default 0): 0 = f16 MFMA scan (operands scaled by exact powers of two), 1 = exact-f32 MFMA scan,
+ *     2 = split-bf16 (three bf16 MFMAs per product) scan. All feed the same float64 re-rank + certificate, so the RESULTS
+ *     are identical; only the speed differs.
+ * "search_auto"       (default 1): mode 0 only — when more than 1 in 8 queries of a batch fail the f16 certificate (scores
+ *     packed tighter than its error band) later searches use the split-bf16 scan until fewer than 1 in 16 would.
  * "stream_min_rows"   (default 65536): batches of <= 64 queries against a shard of at least this many rows use the
  *     HBM-streaming scan (every CU streams a disjoint DB slice once) instead of the batched scan.
  * "search_nsplit"     (default 0 = auto): DB row splits per query block in the scan kernel.
