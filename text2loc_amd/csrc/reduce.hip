@@ -38,7 +38,32 @@ __global__ __launch_bounds__(256) void reduce_partial_kernel(const float* __rest
   const WorkItem w = items[it];
   const int64_t p0 = w.begin, p1 = w.begin + w.count;
   double sx = 0, sy = 0, sz = 0, sr = 0, sg = 0, sb = 0;
-  for (int64_t p = p0 + lane; p < p1; p += 64) {
+  int64_t p = p0 + lane;
+  // four points per lane and array in flight (8 x 12-byte loads before the first add: a lone wave otherwise waits out every
+  // HBM round trip with 24 bytes per lane outstanding)
+  for (; p + 192 < p1; p += 256) {
+    float a[4][3], c[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* ap = xyz + (p + 64 * u) * 3;
+      const float* cp = rgb + (p + 64 * u) * 3;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        a[u][j] = ap[j];
+        c[u][j] = cp[j];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      sx += (double)a[u][0];
+      sy += (double)a[u][1];
+      sz += (double)a[u][2];
+      sr += (double)c[u][0];
+      sg += (double)c[u][1];
+      sb += (double)c[u][2];
+    }
+  }
+  for (; p < p1; p += 64) {
     const float* a = xyz + p * 3;
     const float* c = rgb + p * 3;
     sx += (double)a[0];
