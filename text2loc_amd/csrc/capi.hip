@@ -311,7 +311,10 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     ctx->search_mode = (int)value;
   } else if (!strcmp(name, "search_auto")) {
     ctx->search_auto = value != 0;
-    if (!ctx->search_auto) ctx->escalated = false;
+    if (!ctx->search_auto) {  // forget the state and every report of a search launched so far
+      ctx->escalated = false;
+      ctx->stat_seen = ctx->stat_seq;
+    }
   } else if (!strcmp(name, "stream_min_rows")) {
     ctx->stream_min_rows = (int)value;
   } else if (!strcmp(name, "pointnet_pyg_self_loops")) {
