@@ -34,11 +34,14 @@ def _take(cells, n_cells=None, n_objects=None):
     return out
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=[0, 1], ids=["split-f16", "f32"])
+def eng(request):
+    """Both encoder kernels (split-f16 MFMAs for the big contractions / everything on the f32 MFMA) against the same bars."""
     from text2loc_amd.engine import Engine
 
     e = Engine(0)
+    e.set_option("encoder_f32", request.param)
+    e.encoder_f32 = request.param
     yield e
     e.close()
 
@@ -53,6 +56,7 @@ def test_embed_mode_vs_reference_golden(eng, golden):
     eng.load_weights(sd, class_embed=True, color_embed=True)
     out = eng.encode_cells(_to_gpu(_cells(g))).cpu().numpy()
     err = np.abs(out - g["cell_embeddings"]).max()
+    print("embed-mode max err", err, "f32" if eng.encoder_f32 else "split-f16")
     assert err < TOL, err
 
 

@@ -309,6 +309,8 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     if (value != 0 && value != 1 && value != 2)
       return fail(ctx, T2L_EINVAL, "search_mode must be 0 (f16 scan), 1 (f32 scan) or 2 (split-bf16 scan)");
     ctx->search_mode = (int)value;
+  } else if (!strcmp(name, "encoder_f32")) {
+    ctx->encoder_f32 = value != 0;
   } else if (!strcmp(name, "search_auto")) {
     ctx->search_auto = value != 0;
     if (!ctx->search_auto) {  // forget the state and every report of a search launched so far

@@ -10,7 +10,14 @@
 //   x[28,256] zero padded -> 2 x TransformerEncoderLayer (post-norm, ReLU, NO padding mask: zero slots are
 //   attended to and attend) -> max over the 28 slots -> normalize.
 //
-// All contractions are f32 MFMA (v_mfma_f32_32x32x2_f32: exact f32 FMA chains; 1e-3 parity needs f32).
+// The big contractions (feature merge, q/k/v, out_proj, feed-forward: 97 % of the FLOPs) run as SPLIT-f16 on
+// v_mfma_f32_32x32x16_f16: every f32 value a is used as hi + lo with hi = f16(a), lo = f16(a - hi) (22 significand bits;
+// gfx950's MFMA honours f16 denormals, tools/ probe) and a product is hi*hi + hi*lo + lo*hi with f32 accumulation —
+// ~5e-7 relative, well inside the 1e-3 parity budget (measured 2e-6 on the goldens) at 1/5 of the matrix-pipe time of
+// v_mfma_f32_32x32x2_f32. Activations are split on the fly (20 VALU per 8 values), weights at load time. f16 overflows at
+// 65504: t2l_load_weights bounds every activation that enters a split GEMM from the weights (LayerNorm gain/bias,
+// row norms) and keeps the all-f32 kernel for models that could exceed it (option encoder_f32 forces it).
+// The attention core (S = K Q^T, P V) and the small MLPs stay on the f32 MFMA.
 // M = 32 rows = the 28 slots + 4 dead rows (masked out of the softmax keys and the max-pool).
 // Weights are BN-folded and re-laid out on the host into MFMA B-fragment order
 // [n_tile][k_step][lane][4] so every wave-level weight load is one coalesced 1 KiB line.
@@ -24,6 +31,8 @@
 namespace t2l {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kLdX = kD + 4;        // 260: row stride of every 256-wide LDS buffer
 constexpr int kLdH = 64 + 4;        // 68   (hidden layer of the small MLPs)
@@ -40,6 +49,7 @@ struct SmallMlp {  // get_mlp([in, 64, 256]) with BN folded (language_encoder.py
 
 struct LayerW {
   const float4 *in_wp, *out_wp, *ff1_wp, *ff2_wp;
+  const uint4 *in_hp, *out_hp, *ff1_hp, *ff2_hp;  // the same matrices as split-f16 fragments (pack_h)
   const float *in_b, *out_b, *ff1_b, *ff2_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
 };
 
@@ -49,12 +59,15 @@ struct EncParams {
   int n_class, n_color;
   SmallMlp pos, color, num;
   const float4* pn_wp;     // mlp_pointnet packed (N=256,K=256)
+  const uint4* pn_hp;
   const float* pn_b;
   const float4* merge_wp;  // nfeat consecutive packings (N=256, K=256), one per 256-wide feature slot
+  const uint4* merge_hp;
   const float* merge_b;
   LayerW layer[4];
   int num_layers;
   int class_embed, color_embed, use_class, use_color, use_pos, use_num, nfeat;
+  int split_ok;  // every activation entering a split-f16 GEMM is provably below the f16 range for these weights
 };
 
 struct EncoderWeights {
@@ -147,6 +160,67 @@ __device__ __forceinline__ void mm_pair(const float* __restrict__ arow, int qn, 
   }
 }
 
+// ---- split-f16 forms of gemm32 / mm_pair. Weights: [n_tile][K/16 steps][64 lanes][hi 16 B | lo 16 B], lane (i, kh) of
+// step s holds W[tile*32 + i][kh*K/2 + 8 s .. +7]; activations: the lane's LDS row half, 8 floats per step.
+struct HFrag {
+  f16x8 hi, lo;
+};
+__device__ __forceinline__ HFrag split_h(const float* __restrict__ p) {  // 8 consecutive floats (16-byte aligned)
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  const f32x8 v = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  HFrag f;
+  f.hi = __builtin_convertvector(v, f16x8);
+  f.lo = __builtin_convertvector(v - __builtin_convertvector(f.hi, f32x8), f16x8);
+  return f;
+}
+__device__ __forceinline__ HFrag load_h(const uint4* __restrict__ wp) {
+  HFrag f;
+  f.hi = __builtin_bit_cast(f16x8, wp[0]);
+  f.lo = __builtin_bit_cast(f16x8, wp[1]);
+  return f;
+}
+// acc += A * B with A, B split fragments (a = A operand, b = B operand of the MFMA)
+__device__ __forceinline__ void mfma_h3(f32x16& acc, const HFrag& a, const HFrag& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, acc, 0, 0, 0);
+}
+// acc0 += A * W0^T, acc1 += A * W1^T over `steps` k-steps of 16: arow = this lane's LDS row half, w0 / w1 = the two weight
+// tiles already offset to their first step and to this lane (2 uint4 per lane and step, 128 uint4 per step)
+__device__ __forceinline__ void mm_pair_h(const float* __restrict__ arow, int steps, const uint4* __restrict__ w0,
+                                          const uint4* __restrict__ w1, f32x16& acc0, f32x16& acc1) {
+#pragma unroll 2
+  for (int s = 0; s < steps; ++s) {
+    const HFrag a = split_h(arow + 8 * s);
+    const HFrag b0 = load_h(w0 + s * 128), b1 = load_h(w1 + s * 128);
+    mfma_h3(acc0, a, b0);
+    mfma_h3(acc1, a, b1);
+  }
+}
+template <typename Epi>
+__device__ __forceinline__ void gemm32_h(const float* __restrict__ A, int lda, int K, const uint4* __restrict__ Wp, int N,
+                                         int wave, int lane, Epi epi) {
+  const int col = lane & 31, half = lane >> 5;
+  const int steps = K >> 4;
+  const float* arow = A + col * lda + half * (K >> 1);
+  for (int p = 0; p < (N >> 8); ++p) {
+    const int nt0 = wave + 8 * p, nt1 = nt0 + 4;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc0[r] = 0.f;
+      acc1[r] = 0.f;
+    }
+    mm_pair_h(arow, steps, Wp + ((size_t)nt0 * steps * 64 + lane) * 2, Wp + ((size_t)nt1 * steps * 64 + lane) * 2, acc0, acc1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      epi(0, r, row, nt0 * 32 + col, acc0[r]);
+      epi(1, r, row, nt1 * 32 + col, acc1[r]);
+    }
+  }
+}
+
 // F.normalize over 256 columns of `rows` rows starting at buf (row stride ld); rows >= nvalid are zeroed.
 __device__ __forceinline__ void normalize_rows(float* buf, int ld, int nvalid, int wave, int lane) {
   for (int i = wave; i < kSP; i += 4) {
@@ -227,6 +301,7 @@ __device__ __forceinline__ void small_mlp(const SmallMlp& m, const float* __rest
 //    operands of S^T = K Q^T and the v_h registers ARE the B operand of P V, so the whole head runs from registers;
 //  * the feed-forward hidden layer goes through `buf` in two halves of 256 units (chosen as the units that one half of the
 //    half-split weight packing covers), the second Linear accumulating over both halves in registers.
+template <bool H>  // H: split-f16 MFMAs for the big contractions (see the file header); !H: everything on the f32 MFMA
 __global__ __launch_bounds__(256, 2) void encode_cells_kernel(EncParams P, t2l_packed_cells in,
                                                               float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -249,9 +324,15 @@ __global__ __launch_bounds__(256, 2) void encode_cells_kernel(EncParams P, t2l_p
   auto merge_slot = [&]() {  // buf holds slot `slot` (normalised rows): keep += buf @ Wmerge[:, 256*slot : 256*slot+256]^T
     __syncthreads();
     if (P.nfeat > 1) {
-      const float4* wp = P.merge_wp + (size_t)slot * (kD * kD / 4);
-      mm_pair(buf + col * kLdX + half * 128, kD / 8, wp + (size_t)wave * (kD / 8) * 64 + lane,
-              wp + (size_t)(wave + 4) * (kD / 8) * 64 + lane, keep0, keep1);
+      if constexpr (H) {
+        const uint4* hp = P.merge_hp + (size_t)slot * (kD * kD / 4);
+        mm_pair_h(buf + col * kLdX + half * 128, kD / 16, hp + ((size_t)wave * (kD / 16) * 64 + lane) * 2,
+                  hp + ((size_t)(wave + 4) * (kD / 16) * 64 + lane) * 2, keep0, keep1);
+      } else {
+        const float4* wp = P.merge_wp + (size_t)slot * (kD * kD / 4);
+        mm_pair(buf + col * kLdX + half * 128, kD / 8, wp + (size_t)wave * (kD / 8) * 64 + lane,
+                wp + (size_t)(wave + 4) * (kD / 8) * 64 + lane, keep0, keep1);
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -282,8 +363,9 @@ __global__ __launch_bounds__(256, 2) void encode_cells_kernel(EncParams P, t2l_p
       }
       __syncthreads();
       const float* pb = P.pn_b;
-      gemm32(stage, kLdX, kD, P.pn_wp, kD, wave, lane,
-             [&](int, int, int row, int c, float v) { buf[row * kLdX + c] = fmaxf(v + pb[c], 0.f); });
+      auto pn_epi = [&](int, int, int row, int c, float v) { buf[row * kLdX + c] = fmaxf(v + pb[c], 0.f); };
+      // (features2 is an input: its magnitude is not bounded by the weights, so this GEMM stays f32)
+      gemm32(stage, kLdX, kD, P.pn_wp, kD, wave, lane, pn_epi);
       __syncthreads();
       normalize_rows(buf, kLdX, nobj, wave, lane);
     }
@@ -343,6 +425,27 @@ __global__ __launch_bounds__(256, 2) void encode_cells_kernel(EncParams P, t2l_p
       f32x16 qT0, qT1, kT0, kT1, v0, v1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) qT0[r] = qT1[r] = kT0[r] = kT1[r] = v0[r] = v1[r] = 0.f;
+      if constexpr (H) {
+        // q_h^T, k_h^T: the packed weights are the A operand and the token rows the B operand; v_h straight. One split
+        // of the token fragment feeds all 18 MFMAs of the step.
+        constexpr int HS = kD / 16;
+        const uint4* hq0 = W.in_hp + ((size_t)(2 * h) * HS * 64 + lane) * 2;
+        const uint4* hq1 = W.in_hp + ((size_t)(2 * h + 1) * HS * 64 + lane) * 2;
+        const uint4* hk0 = W.in_hp + ((size_t)(8 + 2 * h) * HS * 64 + lane) * 2;
+        const uint4* hk1 = W.in_hp + ((size_t)(9 + 2 * h) * HS * 64 + lane) * 2;
+        const uint4* hv0 = W.in_hp + ((size_t)(16 + 2 * h) * HS * 64 + lane) * 2;
+        const uint4* hv1 = W.in_hp + ((size_t)(17 + 2 * h) * HS * 64 + lane) * 2;
+#pragma unroll 2
+        for (int s = 0; s < HS; ++s) {
+          const HFrag xf = split_h(xr + 8 * s);
+          mfma_h3(qT0, load_h(hq0 + s * 128), xf);
+          mfma_h3(qT1, load_h(hq1 + s * 128), xf);
+          mfma_h3(kT0, load_h(hk0 + s * 128), xf);
+          mfma_h3(kT1, load_h(hk1 + s * 128), xf);
+          mfma_h3(v0, xf, load_h(hv0 + s * 128));
+          mfma_h3(v1, xf, load_h(hv1 + s * 128));
+        }
+      } else {
 #pragma unroll 2
       for (int q = 0; q < QN; ++q) {
         const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * q);
@@ -356,6 +459,7 @@ __global__ __launch_bounds__(256, 2) void encode_cells_kernel(EncParams P, t2l_p
   v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.C, e1.C, v1, 0, 0, 0);
         T2L_QKV(x) T2L_QKV(y) T2L_QKV(z) T2L_QKV(w)
 #undef T2L_QKV
+      }
       }
       {  // in_proj bias: q^T / k^T rows are features (register index), v columns are features (lane)
         const float* ib = W.in_b;
@@ -418,8 +522,9 @@ __global__ __launch_bounds__(256, 2) void encode_cells_kernel(EncParams P, t2l_p
     __syncthreads();
     {  // x = LN1(x + o @ out_proj^T + b)
       const float* b = W.out_b;
-      gemm32(buf, kLdX, kD, W.out_wp, kD, wave, lane,
-             [&](int, int, int row, int c, float v) { x[row * kLdX + c] += v + b[c]; });
+      auto out_epi = [&](int, int, int row, int c, float v) { x[row * kLdX + c] += v + b[c]; };
+      if constexpr (H) gemm32_h(buf, kLdX, kD, W.out_hp, kD, wave, lane, out_epi);
+      else gemm32(buf, kLdX, kD, W.out_wp, kD, wave, lane, out_epi);
     }
     __syncthreads();
     layer_norm_rows(x, W.ln1_w, W.ln1_b, wave, lane);
@@ -436,8 +541,12 @@ __global__ __launch_bounds__(256, 2) void encode_cells_kernel(EncParams P, t2l_p
         f32x16 h0, h1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) h0[r] = h1[r] = 0.f;
-        mm_pair(x + col * kLdX + half * 128, kD / 8, W.ff1_wp + (size_t)tA * (kD / 8) * 64 + lane,
-                W.ff1_wp + (size_t)tB * (kD / 8) * 64 + lane, h0, h1);
+        if constexpr (H)
+          mm_pair_h(x + col * kLdX + half * 128, kD / 16, W.ff1_hp + ((size_t)tA * (kD / 16) * 64 + lane) * 2,
+                    W.ff1_hp + ((size_t)tB * (kD / 16) * 64 + lane) * 2, h0, h1);
+        else
+          mm_pair(x + col * kLdX + half * 128, kD / 8, W.ff1_wp + (size_t)tA * (kD / 8) * 64 + lane,
+                  W.ff1_wp + (size_t)tB * (kD / 8) * 64 + lane, h0, h1);
         if (hf) __syncthreads();  // every wave has consumed the first half from buf
         const float bA = b1[tA * 32 + col], bB = b1[tB * 32 + col];
 #pragma unroll
@@ -447,8 +556,13 @@ __global__ __launch_bounds__(256, 2) void encode_cells_kernel(EncParams P, t2l_p
           buf[row * kLdX + 128 + 32 * wave + col] = fmaxf(h1[r] + bB, 0.f);
         }
         __syncthreads();
-        mm_pair(buf + col * kLdX + half * 128, kD / 8, W.ff2_wp + ((size_t)wave * (2 * kD / 8) + 32 * hf) * 64 + lane,
-                W.ff2_wp + ((size_t)(wave + 4) * (2 * kD / 8) + 32 * hf) * 64 + lane, acc0, acc1);
+        if constexpr (H)  // K = 512: 32 steps per tile, half hf = steps [16 hf, 16 hf + 16)
+          mm_pair_h(buf + col * kLdX + half * 128, kD / 16,
+                    W.ff2_hp + (((size_t)wave * (2 * kD / 16) + 16 * hf) * 64 + lane) * 2,
+                    W.ff2_hp + (((size_t)(wave + 4) * (2 * kD / 16) + 16 * hf) * 64 + lane) * 2, acc0, acc1);
+        else
+          mm_pair(buf + col * kLdX + half * 128, kD / 8, W.ff2_wp + ((size_t)wave * (2 * kD / 8) + 32 * hf) * 64 + lane,
+                  W.ff2_wp + ((size_t)(wave + 4) * (2 * kD / 8) + 32 * hf) * 64 + lane, acc0, acc1);
       }
       const float* b2 = W.ff2_b;
 #pragma unroll
@@ -539,6 +653,42 @@ std::vector<float> pack(const std::vector<float>& W, int N, int K) {
   return p;
 }
 
+// W [N][K] row-major -> split-f16 fragments [N/32][K/16][64 lanes][hi 8 x f16 | lo 8 x f16] (bit patterns carried in a float
+// vector, 8 floats per lane and step): lane (i, kh) of step s holds W[nt*32+i][kh*K/2 + 8s .. +7], hi = f16(w) (RNE),
+// lo = f16(w - hi)
+std::vector<float> pack_h(const std::vector<float>& W, int N, int K) {
+  std::vector<float> p((size_t)N * K);
+  const int steps = K / 16;
+  uint16_t* out = reinterpret_cast<uint16_t*>(p.data());
+  for (int nt = 0; nt < N / 32; ++nt)
+    for (int st = 0; st < steps; ++st)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+          const float w = W[(size_t)(nt * 32 + (lane & 31)) * K + (lane >> 5) * (K / 2) + 8 * st + e];
+          const _Float16 hi = (_Float16)w;
+          const _Float16 lo = (_Float16)(w - (float)hi);
+          const size_t base = (((size_t)nt * steps + st) * 64 + lane) * 16;
+          memcpy(out + base + e, &hi, 2);
+          memcpy(out + base + 8 + e, &lo, 2);
+        }
+  return p;
+}
+
+float max_abs(const float* v, size_t n) {
+  float m = 0.f;
+  for (size_t i = 0; i < n; ++i) m = fmaxf(m, fabsf(v[i]));
+  return m;
+}
+float max_row_norm(const float* W, int rows, int cols) {
+  double m = 0.0;
+  for (int r = 0; r < rows; ++r) {
+    double ss = 0.0;
+    for (int c = 0; c < cols; ++c) ss += (double)W[(size_t)r * cols + c] * W[(size_t)r * cols + c];
+    m = fmax(m, sqrt(ss));
+  }
+  return (float)m;
+}
+
 std::vector<float> normalized_rows(const float* t, int rows) {
   std::vector<float> o((size_t)rows * kD);
   for (int r = 0; r < rows; ++r) {
@@ -587,7 +737,9 @@ int load_weights_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_m
   int rc = T2L_OK;
   Blob blob;
   const std::string oe = "object_encoder.";
-  size_t class_tab = 0, color_tab = 0, pn_wp = 0, pn_b = 0, merge_wp = 0, merge_b = 0;
+  size_t class_tab = 0, color_tab = 0, pn_wp = 0, pn_b = 0, merge_wp = 0, merge_hp = 0, merge_b = 0;
+  // split-f16 safety (file header): largest weight, and an upper bound on |activation| entering a split GEMM
+  float w_absmax = 0.f, act_bound = 1.f;  // merge inputs are unit rows
   int n_class = 0, n_color = 0;
   SmallOff pos{}, color{}, num{};
   if (cfg->use_class) {
@@ -601,6 +753,7 @@ int load_weights_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_m
       if (!fold(ctx, m, oe + "mlp_pointnet.0.0", oe + "mlp_pointnet.0.1", kD, kD, &W, &b, &rc)) return rc;
       pn_wp = blob.add(pack(W, kD, kD));
       pn_b = blob.add(b);
+      w_absmax = fmaxf(w_absmax, max_abs(W.data(), W.size()));
     }
   }
   if (cfg->use_color) {
@@ -619,29 +772,38 @@ int load_weights_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_m
     std::vector<float> W, b;
     if (!fold(ctx, m, oe + "mlp_merge.0.0", oe + "mlp_merge.0.1", kD, nfeat * kD, &W, &b, &rc)) return rc;
     {  // one (N=256, K=256) packing per feature slot, consecutive
-      std::vector<float> all;
+      std::vector<float> all, all_h;
       for (int sl = 0; sl < nfeat; ++sl) {
         std::vector<float> Ws((size_t)kD * kD);
         for (int n = 0; n < kD; ++n)
           for (int k = 0; k < kD; ++k) Ws[(size_t)n * kD + k] = W[(size_t)n * nfeat * kD + sl * kD + k];
         const std::vector<float> ps = pack(Ws, kD, kD);
         all.insert(all.end(), ps.begin(), ps.end());
+        const std::vector<float> ph = pack_h(Ws, kD, kD);
+        all_h.insert(all_h.end(), ph.begin(), ph.end());
       }
       merge_wp = blob.add(all);
+      merge_hp = blob.add(all_h);
+      w_absmax = fmaxf(w_absmax, max_abs(W.data(), W.size()));
     }
     merge_b = blob.add(b);
   }
   struct LOff {
     size_t in_wp, in_b, out_wp, out_b, ff1_wp, ff1_b, ff2_wp, ff2_b, ln1_w, ln1_b, ln2_w, ln2_b;
+    size_t in_hp, out_hp, ff1_hp, ff2_hp;
   } lo[4];
+  float x_norm = 1.f;  // bound on the 2-norm of a token row entering the layer (layer 0: unit rows or zero pads)
   for (int l = 0; l < cfg->num_layers; ++l) {
     const std::string p = "obj_inter_module." + std::to_string(l) + ".";
-    auto lin = [&](const std::string& wn, const std::string& bn, int out, int in, size_t* wp, size_t* bo) -> bool {
+    auto lin = [&](const std::string& wn, const std::string& bn, int out, int in, size_t* wp, size_t* hp, size_t* bo) -> bool {
       const float* W = need(ctx, m, p + wn, (int64_t)out * in, &rc);
       const float* b = need(ctx, m, p + bn, out, &rc);
       if (!W || !b) return false;
-      *wp = blob.add(pack(std::vector<float>(W, W + (size_t)out * in), out, in));
+      const std::vector<float> Wv(W, W + (size_t)out * in);
+      *wp = blob.add(pack(Wv, out, in));
+      *hp = blob.add(pack_h(Wv, out, in));
       *bo = blob.add(std::vector<float>(b, b + out));
+      w_absmax = fmaxf(w_absmax, max_abs(W, Wv.size()));
       return true;
     };
     auto vec = [&](const std::string& name, size_t* o) -> bool {
@@ -650,13 +812,28 @@ int load_weights_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_m
       *o = blob.add(std::vector<float>(v, v + kD));
       return true;
     };
-    if (!lin("self_attn.in_proj_weight", "self_attn.in_proj_bias", 3 * kD, kD, &lo[l].in_wp, &lo[l].in_b)) return rc;
-    if (!lin("self_attn.out_proj.weight", "self_attn.out_proj.bias", kD, kD, &lo[l].out_wp, &lo[l].out_b)) return rc;
-    if (!lin("linear1.weight", "linear1.bias", 2 * kD, kD, &lo[l].ff1_wp, &lo[l].ff1_b)) return rc;
-    if (!lin("linear2.weight", "linear2.bias", kD, 2 * kD, &lo[l].ff2_wp, &lo[l].ff2_b)) return rc;
+    if (!lin("self_attn.in_proj_weight", "self_attn.in_proj_bias", 3 * kD, kD, &lo[l].in_wp, &lo[l].in_hp, &lo[l].in_b)) return rc;
+    if (!lin("self_attn.out_proj.weight", "self_attn.out_proj.bias", kD, kD, &lo[l].out_wp, &lo[l].out_hp, &lo[l].out_b)) return rc;
+    if (!lin("linear1.weight", "linear1.bias", 2 * kD, kD, &lo[l].ff1_wp, &lo[l].ff1_hp, &lo[l].ff1_b)) return rc;
+    if (!lin("linear2.weight", "linear2.bias", kD, 2 * kD, &lo[l].ff2_wp, &lo[l].ff2_hp, &lo[l].ff2_b)) return rc;
     if (!vec("norm1.weight", &lo[l].ln1_w) || !vec("norm1.bias", &lo[l].ln1_b) || !vec("norm2.weight", &lo[l].ln2_w) ||
         !vec("norm2.bias", &lo[l].ln2_b))
       return rc;
+    {  // bounds on what enters this layer's split GEMMs (|LayerNorm(.)| <= sqrt(255) |gain| + |bias| per element)
+      const float* Wi = m.at(p + "self_attn.in_proj_weight")->data;
+      const float* bi = m.at(p + "self_attn.in_proj_bias")->data;
+      const float* W1 = m.at(p + "linear1.weight")->data;
+      const float* b1 = m.at(p + "linear1.bias")->data;
+      auto ln_elem = [&](const char* wn, const char* bn) {
+        return 16.f * max_abs(m.at(p + wn)->data, kD) + max_abs(m.at(p + bn)->data, kD);
+      };
+      act_bound = fmaxf(act_bound, x_norm);                                                                   // q/k/v input
+      act_bound = fmaxf(act_bound, x_norm * max_row_norm(Wi + (size_t)2 * kD * kD, kD, kD) + max_abs(bi + 2 * kD, kD));  // out_proj input: convex combinations of v
+      const float ln1 = ln_elem("norm1.weight", "norm1.bias");
+      act_bound = fmaxf(act_bound, ln1);                                                                      // linear1 input (element bound)
+      act_bound = fmaxf(act_bound, 16.f * ln1 * max_row_norm(W1, 2 * kD, kD) + max_abs(b1, 2 * kD));          // linear2 input
+      x_norm = 16.f * ln_elem("norm2.weight", "norm2.bias");                                                 // next layer's rows
+    }
   }
 
   free_weights(ctx);
@@ -682,14 +859,19 @@ int load_weights_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_m
   P.pos = sm(pos);
   P.color = sm(color);
   P.num = sm(num);
+  auto u4 = [&](size_t off) { return reinterpret_cast<const uint4*>(B + off); };
   P.pn_wp = f4(pn_wp);
+  P.pn_hp = nullptr;
   P.pn_b = B + pn_b;
   P.merge_wp = f4(merge_wp);
+  P.merge_hp = u4(merge_hp);
   P.merge_b = B + merge_b;
   for (int l = 0; l < cfg->num_layers; ++l)
     P.layer[l] = LayerW{f4(lo[l].in_wp),  f4(lo[l].out_wp), f4(lo[l].ff1_wp), f4(lo[l].ff2_wp),
+                        u4(lo[l].in_hp),  u4(lo[l].out_hp), u4(lo[l].ff1_hp), u4(lo[l].ff2_hp),
                         B + lo[l].in_b,   B + lo[l].out_b,  B + lo[l].ff1_b,  B + lo[l].ff2_b,
                         B + lo[l].ln1_w,  B + lo[l].ln1_b,  B + lo[l].ln2_w,  B + lo[l].ln2_b};
+  P.split_ok = (w_absmax < 3.0e4f && act_bound < 3.0e4f) ? 1 : 0;
   P.num_layers = cfg->num_layers;
   P.class_embed = cfg->class_embed;
   P.color_embed = cfg->color_embed;
@@ -712,12 +894,17 @@ int encode_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float* out, hipStream_
   const size_t lds = (size_t)(2 * kXFloats + 8) * sizeof(float);  // 66.6 KB: two cells per CU
   static bool attr_done = false;
   if (!attr_done) {
-    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_cells_kernel),
+    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_cells_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_cells_kernel<false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   event_begin(ctx, "encode_cells", s);
-  hipLaunchKernelGGL(encode_cells_kernel, dim3(in->n_cells), dim3(256), lds, s, P, *in, out);
+  if (P.split_ok && !ctx->encoder_f32)
+    hipLaunchKernelGGL(encode_cells_kernel<true>, dim3(in->n_cells), dim3(256), lds, s, P, *in, out);
+  else
+    hipLaunchKernelGGL(encode_cells_kernel<false>, dim3(in->n_cells), dim3(256), lds, s, P, *in, out);
   event_end(ctx, "encode_cells", s);
   T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;

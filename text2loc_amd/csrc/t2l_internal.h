@@ -81,6 +81,7 @@ struct t2l_ctx {
   // count to mapped host memory; no stream operation, no synchronisation) and, when that is more than one in eight —
   // scores packed tighter than the f16 error band — searches with the split-bf16 scan (50x tighter bound) until fewer than
   // one in sixteen would be flagged again
+  int encoder_f32 = 0;   // 1: the all-f32-MFMA encoder kernel even when the split-f16 one is safe (encode.hip)
   int search_auto = 1;
   int eff_mode = 0;           // the scan the current t2l_search call runs
   bool escalated = false;     // the split-bf16 scan is standing in (it counts what the f16 band would still flag)
