@@ -15,11 +15,14 @@ def to_dev(cells, embed):
     return {k: torch.from_numpy(np.ascontiguousarray(cells[k])).cuda() for k in keys}
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=[0, 1], ids=["split-f16", "f32"])
+def eng(request):
+    """Both match kernels (split-f16 MFMAs behind the norm guard / everything on the f32 MFMA) against the same bars."""
     from text2loc_amd.engine import Engine
 
     e = Engine(0)
+    e.set_option("encoder_f32", request.param)
+    e.all_f32 = request.param
     yield e
     e.close()
 
@@ -37,6 +40,28 @@ def test_crossmatch_matches_the_reference_run(eng, golden, mode):
     off = eng.fine_match(desc, torch.from_numpy(g["hint_encodings"]).cuda())
     torch.cuda.synchronize()
     assert np.abs(off.cpu().numpy() - g["offsets_out"]).max() < 5e-5
+
+
+def test_norm_guard_sends_large_rows_to_the_f32_kernel(eng):
+    """Hint rows far above the guard (2-norm 64) in SOME pairs: those workgroups are served by the f32 launch that follows the
+    split-f16 one, the others are not touched twice; every pair still matches the oracle."""
+    sd = synth.make_fine_weights(3)
+    eng.fine_load_weights(sd, class_embed=True, color_embed=True)
+    cells = synth.make_cells(6, seed=5, min_obj=16, max_obj=16)
+    desc = eng.fine_encode_objects(to_dev(cells, True))
+    ref_desc = OF.fine_object_encodings(cells, sd, True, True)
+    rng = np.random.default_rng(4)
+    Q = 9
+    hints = rng.standard_normal((Q, 6, 128)).astype(np.float32)
+    hints[2] *= 40.0   # row norms ~450
+    hints[7] *= 3.0e3  # ~34,000: beyond what f16 could hold after the projections
+    ci = rng.integers(0, 6, size=Q).astype(np.int32)
+    hi = np.arange(Q, dtype=np.int32)
+    off = eng.fine_match(desc, torch.from_numpy(hints).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(hi).cuda())
+    ref = OF.cross_match(ref_desc[ci], hints[hi], sd)
+    got = off.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < 5e-5 * max(1.0, float(np.abs(ref).max()))
 
 
 def test_pairs_by_index_and_ragged_hints(eng):

@@ -27,12 +27,11 @@
 #include <string.h>
 
 #include "t2l_internal.h"
+#include "mfma_h3.h"
 
 namespace t2l {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kLdX = kD + 4;        // 260: row stride of every 256-wide LDS buffer
 constexpr int kLdH = 64 + 4;        // 68   (hidden layer of the small MLPs)
@@ -160,31 +159,7 @@ __device__ __forceinline__ void mm_pair(const float* __restrict__ arow, int qn, 
   }
 }
 
-// ---- split-f16 forms of gemm32 / mm_pair. Weights: [n_tile][K/16 steps][64 lanes][hi 16 B | lo 16 B], lane (i, kh) of
-// step s holds W[tile*32 + i][kh*K/2 + 8 s .. +7]; activations: the lane's LDS row half, 8 floats per step.
-struct HFrag {
-  f16x8 hi, lo;
-};
-__device__ __forceinline__ HFrag split_h(const float* __restrict__ p) {  // 8 consecutive floats (16-byte aligned)
-  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-  const f32x8 v = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  HFrag f;
-  f.hi = __builtin_convertvector(v, f16x8);
-  f.lo = __builtin_convertvector(v - __builtin_convertvector(f.hi, f32x8), f16x8);
-  return f;
-}
-__device__ __forceinline__ HFrag load_h(const uint4* __restrict__ wp) {
-  HFrag f;
-  f.hi = __builtin_bit_cast(f16x8, wp[0]);
-  f.lo = __builtin_bit_cast(f16x8, wp[1]);
-  return f;
-}
-// acc += A * B with A, B split fragments (a = A operand, b = B operand of the MFMA)
-__device__ __forceinline__ void mfma_h3(f32x16& acc, const HFrag& a, const HFrag& b) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, acc, 0, 0, 0);
-}
+// ---- split-f16 forms of gemm32 / mm_pair (fragments and packing: mfma_h3.h)
 // acc0 += A * W0^T, acc1 += A * W1^T over `steps` k-steps of 16: arow = this lane's LDS row half, w0 / w1 = the two weight
 // tiles already offset to their first step and to this lane (2 uint4 per lane and step, 128 uint4 per step)
 __device__ __forceinline__ void mm_pair_h(const float* __restrict__ arow, int steps, const uint4* __restrict__ w0,
@@ -653,41 +628,9 @@ std::vector<float> pack(const std::vector<float>& W, int N, int K) {
   return p;
 }
 
-// W [N][K] row-major -> split-f16 fragments [N/32][K/16][64 lanes][hi 8 x f16 | lo 8 x f16] (bit patterns carried in a float
-// vector, 8 floats per lane and step): lane (i, kh) of step s holds W[nt*32+i][kh*K/2 + 8s .. +7], hi = f16(w) (RNE),
-// lo = f16(w - hi)
-std::vector<float> pack_h(const std::vector<float>& W, int N, int K) {
-  std::vector<float> p((size_t)N * K);
-  const int steps = K / 16;
-  uint16_t* out = reinterpret_cast<uint16_t*>(p.data());
-  for (int nt = 0; nt < N / 32; ++nt)
-    for (int st = 0; st < steps; ++st)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int e = 0; e < 8; ++e) {
-          const float w = W[(size_t)(nt * 32 + (lane & 31)) * K + (lane >> 5) * (K / 2) + 8 * st + e];
-          const _Float16 hi = (_Float16)w;
-          const _Float16 lo = (_Float16)(w - (float)hi);
-          const size_t base = (((size_t)nt * steps + st) * 64 + lane) * 16;
-          memcpy(out + base + e, &hi, 2);
-          memcpy(out + base + 8 + e, &lo, 2);
-        }
-  return p;
-}
-
-float max_abs(const float* v, size_t n) {
-  float m = 0.f;
-  for (size_t i = 0; i < n; ++i) m = fmaxf(m, fabsf(v[i]));
-  return m;
-}
-float max_row_norm(const float* W, int rows, int cols) {
-  double m = 0.0;
-  for (int r = 0; r < rows; ++r) {
-    double ss = 0.0;
-    for (int c = 0; c < cols; ++c) ss += (double)W[(size_t)r * cols + c] * W[(size_t)r * cols + c];
-    m = fmax(m, sqrt(ss));
-  }
-  return (float)m;
-}
+std::vector<float> pack_h(const std::vector<float>& W, int N, int K) { return pack_split_f16(W.data(), nullptr, N, K, K); }
+float max_abs(const float* v, size_t n) { return h3_max_abs(v, n); }
+float max_row_norm(const float* W, int rows, int cols) { return h3_max_row_norm(W, rows, cols); }
 
 std::vector<float> normalized_rows(const float* t, int rows) {
   std::vector<float> o((size_t)rows * kD);
@@ -871,7 +814,7 @@ int load_weights_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_m
                         u4(lo[l].in_hp),  u4(lo[l].out_hp), u4(lo[l].ff1_hp), u4(lo[l].ff2_hp),
                         B + lo[l].in_b,   B + lo[l].out_b,  B + lo[l].ff1_b,  B + lo[l].ff2_b,
                         B + lo[l].ln1_w,  B + lo[l].ln1_b,  B + lo[l].ln2_w,  B + lo[l].ln2_b};
-  P.split_ok = (w_absmax < 3.0e4f && act_bound < 3.0e4f) ? 1 : 0;
+  P.split_ok = (w_absmax < kSplitF16Safe && act_bound < kSplitF16Safe) ? 1 : 0;
   P.num_layers = cfg->num_layers;
   P.class_embed = cfg->class_embed;
   P.color_embed = cfg->color_embed;

@@ -6,14 +6,17 @@
 // The reference runs one Python-level forward per query over its top-k cells (evaluation/pipeline.py:113-116) and
 // re-encodes the same cells for every query that retrieved them; here the per-cell object descriptors are computed
 // once per database cell and the pairs are ONE launch (one workgroup per pair, everything LDS-resident).
-// The match kernel runs every token-wise Linear on f32 MFMA tiles and each attention block from registers (see
-// f_attention_regs); the per-cell object encoder (1.1 ms for the whole database, once) contracts on the vector ALU with
+// The match kernel runs every token-wise Linear on MFMA tiles — split-f16 (mfma_h3.h: hi*hi + hi*lo + lo*hi on the f16
+// MFMA, ~5e-7 relative, a fifth of the f32 MFMA's pipe time) when the weights bound the activations below the f16 range and
+// the workgroup's raw input rows pass a run-time norm guard, the f32 MFMA otherwise — and each attention block from
+// registers (see f_attention_regs); the per-cell object encoder (1.1 ms for the whole database, once) contracts on the vector ALU with
 // weights stored transposed [K][N]. BatchNorm is folded on the host.
 #include <math.h>
 #include <string.h>
 
 #include "t2l_internal.h"
 #include "mfma32.h"
+#include "mfma_h3.h"
 
 namespace t2l {
 
@@ -29,6 +32,7 @@ struct FLinear {
 };
 struct FPacked {
   const float4* w;  // half-split MFMA packing of W[N][K] (mfma32.h)
+  const uint4* h;   // the same matrix as split-f16 fragments (mfma_h3.h)
   const float* b;   // [N]
 };
 struct FDecoder {
@@ -44,16 +48,21 @@ struct FineParams {
   int n_layers;
   FDecoder obj[4], hint[4];
   FLinear off0, off2;
+  int split_ok;  // with input rows of 2-norm <= kFGuardNorm every activation entering a split-f16 product stays < 3e4
 };
+constexpr float kFGuardNorm = 64.f;  // run-time guard on the raw descriptor rows a workgroup loads (unit rows in the reference's pipeline)
 struct FineWeights {
   FineParams p{};
   std::vector<void*> blobs;
+  int32_t* wg_flags = nullptr;  // per-workgroup guard verdicts of the split-f16 match launch
+  size_t flag_cap = 0;
 };
 
 void free_fine(t2l_ctx* ctx) {
   FineWeights* W = reinterpret_cast<FineWeights*>(ctx->fine);
   if (!W) return;
   for (void* b : W->blobs) (void)hipFree(b);
+  if (W->wg_flags) (void)hipFree(W->wg_flags);
   delete W;
   ctx->fine = nullptr;
 }
@@ -103,6 +112,9 @@ static int fpacked(t2l_ctx* ctx, FineWeights* W, const WMap& m, const std::strin
   int rc;
   if ((rc = fupload(ctx, W, packed, &d))) return rc;
   out->w = reinterpret_cast<const float4*>(d);
+  const float* dh = nullptr;
+  if ((rc = fupload(ctx, W, pack_split_f16(w, nullptr, N, K, K), &dh))) return rc;
+  out->h = reinterpret_cast<const uint4*>(dh);
   return fupload(ctx, W, std::vector<float>(b, b + N), &out->b);
 }
 static int fraw(t2l_ctx* ctx, FineWeights* W, const WMap& m, const std::string& k, int64_t n, const float** dst) {
@@ -165,6 +177,36 @@ int fine_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_mode
     }
   if ((rc = flinear(ctx, W, m, "mlp_offsets.0", "", kFD, kFD / 2, &P.off0)) || (rc = flinear(ctx, W, m, "mlp_offsets.2", "", kFD / 2, 2, &P.off2)))
     return rc;
+  {  // split-f16 safety: bound every activation that enters a split product, given input rows of norm <= kFGuardNorm
+    const float sq = 11.32f;  // > sqrt(128): |LayerNorm(.)| <= sqrt(127) |gain| + |bias| per element, row norm <= sqrt(128) x that
+    float wmax = 0.f, amax = kFGuardNorm, n_obj = kFGuardNorm, n_hint = kFGuardNorm;
+    auto dec = [&](const std::string& p, float xn, float mn) -> float {  // returns the norm bound of the rows it leaves in x
+      auto W_ = [&](const char* k, int64_t n) { return fget(m, p + k, n); };
+      const float *sa = W_(".self_attn.in_proj_weight", 3 * kFD * kFD), *sab = W_(".self_attn.in_proj_bias", 3 * kFD);
+      const float *ca = W_(".multihead_attn.in_proj_weight", 3 * kFD * kFD), *cab = W_(".multihead_attn.in_proj_bias", 3 * kFD);
+      const float *l1 = W_(".linear1.weight", 4 * kFD * kFD), *l1b = W_(".linear1.bias", 4 * kFD);
+      for (const char* k : {".self_attn.in_proj_weight", ".self_attn.out_proj.weight", ".multihead_attn.in_proj_weight",
+                            ".multihead_attn.out_proj.weight", ".linear1.weight", ".linear2.weight"}) {
+        auto it = m.find(p + k);
+        wmax = fmaxf(wmax, h3_max_abs(it->second->data, (size_t)it->second->numel));
+      }
+      auto ln = [&](const char* g, const char* b) { return sq * h3_max_abs(W_(g, kFD), kFD) + h3_max_abs(W_(b, kFD), kFD); };
+      amax = fmaxf(amax, fmaxf(xn, mn));                                                                          // q/k/v inputs
+      amax = fmaxf(amax, xn * h3_max_row_norm(sa + (size_t)2 * kFD * kFD, kFD, kFD) + h3_max_abs(sab + 2 * kFD, kFD));  // self out_proj input
+      const float e1 = ln(".norm1.weight", ".norm1.bias");
+      amax = fmaxf(amax, e1);                                                                                     // cross-attention q input
+      amax = fmaxf(amax, mn * h3_max_row_norm(ca + (size_t)2 * kFD * kFD, kFD, kFD) + h3_max_abs(cab + 2 * kFD, kFD));  // cross out_proj input
+      const float e2 = ln(".norm2.weight", ".norm2.bias");
+      amax = fmaxf(amax, e2);                                                                                     // linear1 input
+      amax = fmaxf(amax, sq * e2 * h3_max_row_norm(l1, 4 * kFD, kFD) + h3_max_abs(l1b, 4 * kFD));                // linear2 input
+      return sq * ln(".norm3.weight", ".norm3.bias");
+    };
+    for (int l = 0; l < P.n_layers; ++l) {
+      n_obj = dec("cross_objects." + std::to_string(l), n_obj, n_hint);
+      n_hint = dec("cross_hints." + std::to_string(l), n_hint, n_obj);
+    }
+    P.split_ok = (wmax < kSplitF16Safe && amax < kSplitF16Safe) ? 1 : 0;
+  }
   return T2L_OK;
 }
 
@@ -259,6 +301,7 @@ struct TileGroups {
 // v_h straight (A = mem token rows, B = packed rows); in those MFMA output layouts k_h^T / q_h^T are the A / B operands of
 // S^T = K Q^T and v_h is the B operand of P V (the trick of encode.hip). Keys of another pair (or padding rows) are masked.
 // Writes o_h (32 rows x 32 columns) into obuf[:, 32 h ..]. x == mem for self-attention.
+template <bool H>
 __device__ __forceinline__ void f_attention_regs(const float* __restrict__ x, TileGroups gx, const float* __restrict__ mem, TileGroups gm,
                                                  const FPacked in_proj, float* __restrict__ obuf) {
   const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
@@ -271,6 +314,19 @@ __device__ __forceinline__ void f_attention_regs(const float* __restrict__ x, Ti
   f32x16 qT, kT, v;
 #pragma unroll
   for (int r = 0; r < 16; ++r) qT[r] = kT[r] = v[r] = 0.f;
+  if constexpr (H) {
+    constexpr int HS = kFD / 16;  // 8 steps of 16
+    const uint4* hq = in_proj.h + ((size_t)h * HS * 64 + lane) * 2;
+    const uint4* hk = in_proj.h + ((size_t)(4 + h) * HS * 64 + lane) * 2;
+    const uint4* hv = in_proj.h + ((size_t)(8 + h) * HS * 64 + lane) * 2;
+#pragma unroll 2
+    for (int st = 0; st < HS; ++st) {
+      const HFrag xf = split_h(xr + 8 * st), mf = split_h(mr + 8 * st);
+      mfma_h3(qT, load_h(hq + st * 128), xf);
+      mfma_h3(kT, load_h(hk + st * 128), mf);
+      mfma_h3(v, mf, load_h(hv + st * 128));
+    }
+  } else {
 #pragma unroll 4
   for (int q = 0; q < QN; ++q) {
     const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * q);
@@ -282,6 +338,7 @@ __device__ __forceinline__ void f_attention_regs(const float* __restrict__ x, Ti
   v = __builtin_amdgcn_mfma_f32_32x32x2f32(mv.C, e.C, v, 0, 0, 0);
     T2L_F_QKV(x) T2L_F_QKV(y) T2L_F_QKV(z) T2L_F_QKV(w)
 #undef T2L_F_QKV
+  }
   }
   {
     const float* ib = in_proj.b;
@@ -329,12 +386,14 @@ __device__ __forceinline__ void f_attention_regs(const float* __restrict__ x, Ti
 }
 
 // x += A @ W^T + b for a 128 -> 128 Linear (out_proj): one 32-column tile per wave
+template <bool H>
 __device__ __forceinline__ void f_proj_add(const float* __restrict__ A, const FPacked L, float* __restrict__ x) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  mm32_dot<kFD / 8>(A + col * kFS + half * (kFD / 2), L.w + (size_t)w * (kFD / 8) * 64 + lane, acc);
+  if constexpr (H) mm32_dot_h<kFD / 16>(A + col * kFS + half * (kFD / 2), L.h + ((size_t)w * (kFD / 16) * 64 + lane) * 2, acc);
+  else mm32_dot<kFD / 8>(A + col * kFS + half * (kFD / 2), L.w + (size_t)w * (kFD / 8) * 64 + lane, acc);
   const float bv = L.b[w * 32 + col];
 #pragma unroll
   for (int r = 0; r < 16; ++r) x[((r & 3) + 8 * (r >> 2) + 4 * half) * kFS + w * 32 + col] += acc[r] + bv;
@@ -342,17 +401,18 @@ __device__ __forceinline__ void f_proj_add(const float* __restrict__ A, const FP
 
 // nn.TransformerDecoderLayer (post-norm, ReLU, eval, no masks) for the kPairs pairs of a workgroup. x / mem: 32-row token
 // tiles (LDS, stride kFS); buf: one more 32 x 128 tile (attention output, then the feed-forward hidden in four quarters).
+template <bool H>
 __device__ void f_decoder(float* x, TileGroups gx, const float* mem, TileGroups gm, const FDecoder D, float* buf) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
-  f_attention_regs(x, gx, x, gx, D.sa_in, buf);
+  f_attention_regs<H>(x, gx, x, gx, D.sa_in, buf);
   __syncthreads();
-  f_proj_add(buf, D.sa_out, x);
+  f_proj_add<H>(buf, D.sa_out, x);
   __syncthreads();
   f_ln_rows(x, kFS, gx.rows, D.g1, D.b1);
   __syncthreads();
-  f_attention_regs(x, gx, mem, gm, D.ca_in, buf);
+  f_attention_regs<H>(x, gx, mem, gm, D.ca_in, buf);
   __syncthreads();
-  f_proj_add(buf, D.ca_out, x);
+  f_proj_add<H>(buf, D.ca_out, x);
   __syncthreads();
   f_ln_rows(x, kFS, gx.rows, D.g2, D.b2);
   __syncthreads();
@@ -367,13 +427,17 @@ __device__ void f_decoder(float* x, TileGroups gx, const float* mem, TileGroups 
       f32x16 hh;
 #pragma unroll
       for (int r = 0; r < 16; ++r) hh[r] = 0.f;
-      mm32_dot<kFD / 8>(x + col * kFS + half * (kFD / 2), D.l1.w + (size_t)tile * (kFD / 8) * 64 + lane, hh);
+      if constexpr (H) mm32_dot_h<kFD / 16>(x + col * kFS + half * (kFD / 2), D.l1.h + ((size_t)tile * (kFD / 16) * 64 + lane) * 2, hh);
+      else mm32_dot<kFD / 8>(x + col * kFS + half * (kFD / 2), D.l1.w + (size_t)tile * (kFD / 8) * 64 + lane, hh);
       if (qtr) __syncthreads();  // every wave has consumed the previous quarter
       const float bv = D.l1.b[tile * 32 + col];
 #pragma unroll
       for (int r = 0; r < 16; ++r) buf[((r & 3) + 8 * (r >> 2) + 4 * half) * kFS + w * 32 + col] = fmaxf(hh[r] + bv, 0.f);
       __syncthreads();
-      mm32_dot<kFD / 8>(buf + col * kFS + half * (kFD / 2), D.l2.w + ((size_t)w * (4 * kFD / 8) + 16 * qtr) * 64 + lane, acc);
+      if constexpr (H)  // K = 512: 32 steps per tile, quarter qtr = steps [8 qtr, 8 qtr + 8)
+        mm32_dot_h<kFD / 16>(buf + col * kFS + half * (kFD / 2), D.l2.h + (((size_t)w * (4 * kFD / 16) + 8 * qtr) * 64 + lane) * 2, acc);
+      else
+        mm32_dot<kFD / 8>(buf + col * kFS + half * (kFD / 2), D.l2.w + ((size_t)w * (4 * kFD / 8) + 16 * qtr) * 64 + lane, acc);
     }
     const float bv = D.l2.b[w * 32 + col];
 #pragma unroll
@@ -446,9 +510,15 @@ __global__ __launch_bounds__(256) void fine_objects_kernel(FineParams P, t2l_pac
 // One workgroup per kPairs = 2 (query, cell) pairs: the 2 x 16 object tokens fill one 32-row MFMA tile, the 2 x 6 hint tokens
 // sit at rows 8p..8p+5 of a second one (its other rows are zero / ignored). Three 32 x 128 LDS tiles (52 KB): three
 // workgroups per CU.
+// H = split-f16 MFMAs: a workgroup whose raw descriptor rows exceed kFGuardNorm writes wg_flags[block] = 1 and leaves; the
+// !H launch that follows (all-f32 MFMA) serves exactly those workgroups (wg_flags == nullptr: every workgroup).
+template <bool H>
 __global__ __launch_bounds__(256, 3) void fine_match_kernel(FineParams P, const float* __restrict__ cell_desc, const int32_t* __restrict__ cell_index,
                                                             const float* __restrict__ hint_desc, const int32_t* __restrict__ hint_index,
-                                                            int n_pairs, int n_hints, float* __restrict__ out) {
+                                                            int n_pairs, int n_hints, float* __restrict__ out, int32_t* __restrict__ wg_flags) {
+  if constexpr (!H) {
+    if (wg_flags && !wg_flags[blockIdx.x]) return;
+  }
   extern __shared__ float sm[];
   float* d0 = sm;                  // [32][kFS] objects: pair p at rows 16p..
   float* d1 = d0 + 32 * kFS;       // [32][kFS] hints:   pair p at rows 8p..8p+n_hints-1
@@ -469,10 +539,26 @@ __global__ __launch_bounds__(256, 3) void fine_match_kernel(FineParams P, const 
     d1[row * kFS + c] = v;
   }
   __syncthreads();
+  if constexpr (H) {  // guard: largest 2-norm of the 64 raw rows (NaN fails the comparison too)
+    const int w = tid >> 6, lane = tid & 63;
+    float worst = 0.f;
+    for (int t = w; t < 64; t += 4) {
+      const float* row = (t < 32 ? d0 + t * kFS : d1 + (t - 32) * kFS);
+      const float a = row[lane], b = row[lane + 64];
+      worst = fmaxf(worst, f_wsum(a * a + b * b));
+    }
+    if (lane == 0) h64[w] = worst;
+    __syncthreads();
+    const float ss = fmaxf(fmaxf(h64[0], h64[1]), fmaxf(h64[2], h64[3]));
+    const bool safe = ss <= kFGuardNorm * kFGuardNorm;
+    if (tid == 0) wg_flags[blockIdx.x] = safe ? 0 : 1;
+    if (!safe) return;  // block-uniform
+    __syncthreads();
+  }
   const TileGroups gobj{4, kFObj, 32}, ghint{3, n_hints, 16};
   for (int l = 0; l < P.n_layers; ++l) {  // cross_matcher.py:114-118
-    f_decoder(d0, gobj, d1, ghint, P.obj[l], buf);
-    f_decoder(d1, ghint, d0, gobj, P.hint[l], buf);
+    f_decoder<H>(d0, gobj, d1, ghint, P.obj[l], buf);
+    f_decoder<H>(d1, ghint, d0, gobj, P.hint[l], buf);
   }
   {  // desc1.max(dim=0) over the hints, then mlp_offsets (cross_matcher.py:128-131)
     const int p = tid >> 7, c = tid & 127;
@@ -523,12 +609,29 @@ int fine_match_impl(t2l_ctx* ctx, const float* cell_desc, const int32_t* cell_in
   const size_t lds = sizeof(float) * (3 * 32 * kFS + kPairs * kFD + kPairs * 64);  // 52 KB: three workgroups per CU
   static bool attr = false;
   if (!attr) {
-    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fine_match_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fine_match_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fine_match_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
+  const int n_wg = (n_pairs + kPairs - 1) / kPairs;
+  const bool split = W->p.split_ok && !ctx->encoder_f32;
+  if (split && (size_t)n_wg * sizeof(int32_t) > W->flag_cap) {
+    if (W->wg_flags) (void)hipFree(W->wg_flags);
+    W->wg_flags = nullptr;
+    W->flag_cap = 0;
+    T2L_HIP(ctx, hipMalloc(&W->wg_flags, (size_t)n_wg * sizeof(int32_t)));
+    W->flag_cap = (size_t)n_wg * sizeof(int32_t);
+  }
   event_begin(ctx, "fine_match", s);
-  hipLaunchKernelGGL(fine_match_kernel, dim3((n_pairs + kPairs - 1) / kPairs), dim3(256), lds, s, W->p, cell_desc, cell_index, hint_desc, hint_index,
-                     n_pairs, n_hints, out);
+  if (split) {
+    hipLaunchKernelGGL(fine_match_kernel<true>, dim3(n_wg), dim3(256), lds, s, W->p, cell_desc, cell_index, hint_desc, hint_index, n_pairs,
+                       n_hints, out, W->wg_flags);
+    hipLaunchKernelGGL(fine_match_kernel<false>, dim3(n_wg), dim3(256), lds, s, W->p, cell_desc, cell_index, hint_desc, hint_index, n_pairs,
+                       n_hints, out, W->wg_flags);  // only the workgroups the guard turned away
+  } else {
+    hipLaunchKernelGGL(fine_match_kernel<false>, dim3(n_wg), dim3(256), lds, s, W->p, cell_desc, cell_index, hint_desc, hint_index, n_pairs,
+                       n_hints, out, (int32_t*)nullptr);
+  }
   event_end(ctx, "fine_match", s);
   T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;
