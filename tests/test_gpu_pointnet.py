@@ -12,11 +12,14 @@ from text2loc_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=[0, 1], ids=["split-f16", "f32"])
+def eng(request):
+    """Both kernel sets (split-f16 MFMAs with the magnitude watch / everything on the f32 MFMA) against the same bars."""
     from text2loc_amd.engine import Engine
 
     e = Engine(0)
+    e.set_option("encoder_f32", request.param)
+    e.all_f32 = request.param
     sd = synth.make_object_branch_weights(0)
     sd.update(synth.make_pointnet_weights(0))
     e.load_weights(sd, class_embed=False, color_embed=False)
@@ -42,6 +45,20 @@ def test_features2_match_the_restatement(eng, self_loops):
     assert got.shape == ref.shape == (int(cells["offsets"][-1]), 256)
     assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
     assert (ref > 0).mean() > 0.2  # not a dead network
+
+
+def test_magnitude_watch_hands_large_objects_to_the_f32_kernels(eng):
+    """Colour values of ~1e5 in SOME objects leave the f16 range inside the split products: those objects are flagged and
+    recomputed by the f32 launches (flags are sticky down the levels), the others stay on the split kernels; all match."""
+    cells = synth.make_cells(2, seed=9, min_obj=3, max_obj=4)
+    pos, rgb = synth.make_sampled_points(cells, 9)
+    rgb = rgb.copy()
+    rgb[1] *= np.float32(2.0e5)   # beyond 65504 from the first layer on
+    rgb[4] *= np.float32(3.0e3)   # fits f16 as an input, overflows deeper in the MLP chain (or not at all): either way exact enough
+    got = run(eng, cells, pos, rgb)
+    ref = OP.pointnet_features(pos, rgb, cells["offsets"], eng._sd)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
 
 
 def test_degenerate_objects(eng):

@@ -37,9 +37,11 @@ __device__ __forceinline__ HFrag split_h(const float* __restrict__ p) {  // 8 co
   return f;
 }
 __device__ __forceinline__ HFrag load_h(const uint4* __restrict__ wp) {
+  // packed weights live in global memory: say so (a pointer that went through an opaque asm would otherwise load as flat_*)
+  const __attribute__((address_space(1))) uint4* gp = (const __attribute__((address_space(1))) uint4*)wp;
   HFrag f;
-  f.hi = __builtin_bit_cast(h3_f16x8, wp[0]);
-  f.lo = __builtin_bit_cast(h3_f16x8, wp[1]);
+  f.hi = __builtin_bit_cast(h3_f16x8, gp[0]);
+  f.lo = __builtin_bit_cast(h3_f16x8, gp[1]);
   return f;
 }
 // acc += A * B with A, B split fragments (a = A operand, b = B operand of the MFMA)

@@ -3,7 +3,12 @@
 //   -> GlobalAbstraction (get_mlp([259,512,1024]) + max over the 32 remaining points) -> lin1/lin2 + ReLU -> features2.
 // PARITY UNPINNED (third-party torch_geometric / torch-cluster arithmetic is absent from the reference tree): the
 // semantics are the deterministic ones spelled out in oracle/t2l_oracle_pointnet.py, which these kernels are tested
-// against. gfx950 only; f32 MFMA (v_mfma_f32_32x32x2_f32).
+// against. gfx950 only. The edge MLPs and the global MLP run as split-f16 MFMAs (mfma_h3.h: hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_f16, ~5e-7 relative, a fifth of the matrix-pipe time of v_mfma_f32_32x32x2_f32). There is no
+// normalisation between the levels, so no static bound on the activations is useful: the split kernels watch the
+// magnitude of everything that enters a split product and flag the object when it reaches 3e4 (or is not finite); the
+// all-f32-MFMA launch that follows every split launch recomputes exactly the flagged objects (flags are sticky down the
+// levels). Option encoder_f32 forces the f32 kernels.
 //
 // One workgroup per object and level. FPS runs on one wave (DPP all-reduces, no LDS traffic in the loop). Every centre's
 // ball query is a wave-level ballot compaction ("first 32 in index order"). The two-layer edge MLP of a centre is one
@@ -17,6 +22,7 @@
 #include "t2l_internal.h"
 #include "gemm_f32.h"
 #include "mfma32.h"
+#include "mfma_h3.h"
 
 namespace t2l {
 
@@ -24,6 +30,7 @@ using train::f32x16;
 
 
 struct PointNetWeights {
+  uint4 *w1h[3] = {}, *w2h[3] = {}, *ga1h = nullptr, *ga2h = nullptr;  // split-f16 packings of the same matrices
   float4 *w1[3] = {}, *w2[3] = {};  // SA levels, packed
   float* b2[3] = {};
   float4 *ga1 = nullptr, *ga2 = nullptr;
@@ -38,9 +45,9 @@ void free_pointnet(t2l_ctx* ctx) {
   PointNetWeights* P = reinterpret_cast<PointNetWeights*>(ctx->pn);
   if (!P) return;
   for (int l = 0; l < 3; ++l)
-    for (void* p : {(void*)P->w1[l], (void*)P->w2[l], (void*)P->b2[l]})
+    for (void* p : {(void*)P->w1[l], (void*)P->w2[l], (void*)P->b2[l], (void*)P->w1h[l], (void*)P->w2h[l]})
       if (p) (void)hipFree(p);
-  for (void* p : {(void*)P->ga1, (void*)P->ga2, (void*)P->gab2, (void*)P->lin1w, (void*)P->lin1b, (void*)P->lin2w, (void*)P->lin2b, (void*)P->ws})
+  for (void* p : {(void*)P->ga1h, (void*)P->ga2h, (void*)P->ga1, (void*)P->ga2, (void*)P->gab2, (void*)P->lin1w, (void*)P->lin1b, (void*)P->lin2w, (void*)P->lin2b, (void*)P->ws})
     if (p) (void)hipFree(p);
   delete P;
   ctx->pn = nullptr;
@@ -83,6 +90,28 @@ static std::vector<float> pack_sa_l2(const std::vector<float>& W, int h2, int h1
   return out;
 }
 
+// layer 2 of an SA block for the split-f16 path, B operand: [h2/32][h1/32][2][64 lanes][hi 16 B | lo 16 B]. The A operand of
+// MFMA m of feature tile ft is registers 8m..8m+7 of the layer-1 accumulator, i.e. features (r&3) + 8(r>>2) + 4 kh of the tile
+// for lane half kh: lane (n, kh) holds W[nt*32+n][ft*32 + that feature], r = 8m + e.
+static std::vector<float> pack_sa_l2_h(const std::vector<float>& W, int h2, int h1) {
+  std::vector<float> p((size_t)h2 * h1);
+  uint16_t* out = reinterpret_cast<uint16_t*>(p.data());
+  for (int nt = 0; nt < h2 / 32; ++nt)
+    for (int ft = 0; ft < h1 / 32; ++ft)
+      for (int mm = 0; mm < 2; ++mm)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 8; ++e) {
+            const int r = 8 * mm + e, f = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float w = W[(size_t)(nt * 32 + (lane & 31)) * h1 + ft * 32 + f];
+            const _Float16 hi = (_Float16)w;
+            const _Float16 lo = (_Float16)(w - (float)hi);
+            const size_t base = ((((size_t)nt * (h1 / 32) + ft) * 2 + mm) * 64 + lane) * 16;
+            memcpy(out + base + e, &hi, 2);
+            memcpy(out + base + 8 + e, &lo, 2);
+          }
+  return p;
+}
+
 template <typename T>
 static int upload(t2l_ctx* ctx, T** dst, const std::vector<float>& v) {
   T2L_HIP(ctx, hipMalloc(dst, v.size() * sizeof(float)));
@@ -92,6 +121,7 @@ static int upload(t2l_ctx* ctx, T** dst, const std::vector<float>& v) {
 
 constexpr int kCin[3] = {3, 64, 128}, kH1[3] = {32, 128, 256}, kH2[3] = {64, 128, 256};
 constexpr int k1p(int cin) { return ((cin + 4 + 7) / 8) * 8; }  // [x | pos_j - pos_i | 1 | 0...] padded to 8
+constexpr int k1ph(int cin) { return ((cin + 4 + 15) / 16) * 16; }  // the same row padded to 16 (split-f16 steps of 16)
 
 // Returns T2L_OK with ctx->pn == nullptr when the state_dict carries no PointNet++ tensors at all.
 int pointnet_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n) {
@@ -109,14 +139,18 @@ int pointnet_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n) {
     const std::string pre = p + "sa" + std::to_string(l + 1) + ".point_conv.local_nn";
     if (!fold_block(m, pre, 0, kCin[l] + 3, kH1[l], W, b)) return fail(ctx, T2L_EINVAL, "t2l_load_weights: incomplete " + pre + ".0");
     if ((rc = upload(ctx, &P->w1[l], pack_half_split(W, &b, kH1[l], kCin[l] + 3, k1p(kCin[l]))))) return rc;
+    if ((rc = upload(ctx, &P->w1h[l], pack_split_f16(W.data(), b.data(), kH1[l], kCin[l] + 3, k1ph(kCin[l]))))) return rc;
     if (!fold_block(m, pre, 1, kH1[l], kH2[l], W, b)) return fail(ctx, T2L_EINVAL, "t2l_load_weights: incomplete " + pre + ".1");
     if ((rc = upload(ctx, &P->w2[l], pack_sa_l2(W, kH2[l], kH1[l])))) return rc;
+    if ((rc = upload(ctx, &P->w2h[l], pack_sa_l2_h(W, kH2[l], kH1[l])))) return rc;
     if ((rc = upload(ctx, &P->b2[l], b))) return rc;
   }
   if (!fold_block(m, p + "ga.mlp", 0, 259, 512, W, b)) return fail(ctx, T2L_EINVAL, "t2l_load_weights: incomplete " + p + "ga.mlp.0");
   if ((rc = upload(ctx, &P->ga1, pack_half_split(W, &b, 512, 259, 264)))) return rc;
+  if ((rc = upload(ctx, &P->ga1h, pack_split_f16(W.data(), b.data(), 512, 259, 272)))) return rc;
   if (!fold_block(m, p + "ga.mlp", 1, 512, 1024, W, b)) return fail(ctx, T2L_EINVAL, "t2l_load_weights: incomplete " + p + "ga.mlp.1");
   if ((rc = upload(ctx, &P->ga2, pack_half_split(W, nullptr, 1024, 512, 512)))) return rc;
+  if ((rc = upload(ctx, &P->ga2h, pack_split_f16(W.data(), nullptr, 1024, 512, 512)))) return rc;
   if ((rc = upload(ctx, &P->gab2, b))) return rc;
   auto raw = [&](const char* name, int64_t numel, float** dst) -> int {
     auto it = m.find(p + name);
@@ -223,10 +257,116 @@ __device__ __forceinline__ void sa_mlp_tile(const float (&xrow)[k1p(CIN) / 2], c
   }
 }
 
+// 8 register values -> split fragment; amax tracks the largest magnitude that entered a split product
+__device__ __forceinline__ HFrag split_vals(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
+                                            float& amax) {
+  amax = fmaxf(fmaxf(fmaxf(amax, fabsf(v0)), fmaxf(fabsf(v1), fabsf(v2))), fmaxf(fmaxf(fabsf(v3), fabsf(v4)), fabsf(v5)));
+  amax = fmaxf(amax, fmaxf(fabsf(v6), fabsf(v7)));
+  const h3_f32x8 v = {v0, v1, v2, v3, v4, v5, v6, v7};
+  HFrag f;
+  f.hi = __builtin_convertvector(v, h3_f16x8);
+  f.lo = __builtin_convertvector(v - __builtin_convertvector(f.hi, h3_f32x8), h3_f16x8);
+  return f;
+}
+
+// The steps of the two layers as template recursions (the compiler does not unroll a 72-step loop with this body, and
+// run-time indices would put the fragment arrays into scratch memory).
+template <int STEP, int STEPS, int S, int PF, int FT>
+__device__ __forceinline__ void sa_l1_steps(HFrag (&ring)[PF], const uint4*& wp, f32x16& acc, const HFrag (&xf)[S], HFrag (&hf)[FT][2],
+                                            float& amax) {
+  if constexpr (STEP < STEPS) {
+    constexpr int ft = STEP / S, st = STEP % S;
+    if constexpr (st == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    }
+    const HFrag wf = ring[STEP % PF];
+    if constexpr (STEP + PF < STEPS) {
+      ring[STEP % PF] = load_h(wp);
+      wp += 128;
+      asm volatile("" : "+v"(wp));
+    }
+    mfma_h3(acc, wf, xf[st]);
+    __builtin_amdgcn_sched_barrier(0);  // keep the ring's distance: no further hoisting of loads (register pressure)
+    if constexpr (st == S - 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);  // BatchNorm + bias folded; ReLU
+      hf[ft][0] = split_vals(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7], amax);
+      hf[ft][1] = split_vals(acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15], amax);
+    }
+    sa_l1_steps<STEP + 1, STEPS, S, PF, FT>(ring, wp, acc, xf, hf, amax);
+  }
+}
+template <int STEP, int STEPS, int PF, int FT>
+__device__ __forceinline__ void sa_l2_steps(HFrag (&ring)[PF], const uint4*& wp, f32x16& acc, const HFrag (&hf)[FT][2], bool not_last_tile) {
+  if constexpr (STEP < STEPS) {
+    const HFrag wf = ring[STEP % PF];
+    if (not_last_tile || STEP + PF < STEPS) {  // the stream continues into the next output tile
+      ring[STEP % PF] = load_h(wp);
+      wp += 128;
+      asm volatile("" : "+v"(wp));
+    }
+    mfma_h3(acc, hf[STEP / 2][STEP % 2], wf);
+    __builtin_amdgcn_sched_barrier(0);
+    sa_l2_steps<STEP + 1, STEPS, PF, FT>(ring, wp, acc, hf, not_last_tile);
+  }
+}
+
+// sa_mlp_tile on split-f16 MFMAs. xrow: this lane's half of the row padded to k1ph(CIN). Layer 1 transposed (A = packed
+// weights, B = the row fragments, split once per tile); its accumulator registers 0..7 / 8..15 are the two A fragments of
+// layer 2 for that feature tile (pack_sa_l2_h orders the weights to match), split once and reused by all output tiles.
+template <int CIN, int H1, int H2, typename Emit>
+__device__ __forceinline__ void sa_mlp_tile_h(const float (&xrow)[k1ph(CIN) / 2], const uint4* __restrict__ w1, const uint4* __restrict__ w2,
+                                              int lane, float& amax, Emit&& emit) {
+  constexpr int S = k1ph(CIN) / 16, FT = H1 / 32, NT = H2 / 32;
+  HFrag xf[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+    xf[s] = split_vals(xrow[8 * s], xrow[8 * s + 1], xrow[8 * s + 2], xrow[8 * s + 3], xrow[8 * s + 4], xrow[8 * s + 5], xrow[8 * s + 6],
+                       xrow[8 * s + 7], amax);
+  // One wave per SIMD: the L2 latency of the weight stream is hidden by an explicit ring of PF fragment pairs in flight
+  // (PF x 3 MFMAs = PF x 96 cycles of look-ahead). The pointers run (opaque increments): with `base + constant` addressing
+  // the compiler materialises one 64-bit address per load (2 KiB apart, beyond the immediate offset) and hoists hundreds.
+  HFrag hf[FT][2];
+  {
+    constexpr int STEPS = FT * S, PF = STEPS < 4 ? STEPS : 4;
+    const uint4* wp = w1 + (size_t)lane * 2;
+    asm volatile("" : "+v"(wp));
+    HFrag ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      ring[i] = load_h(wp);
+      wp += 128;
+      asm volatile("" : "+v"(wp));
+    }
+    f32x16 acc;
+    sa_l1_steps<0, STEPS, S, PF, FT>(ring, wp, acc, xf, hf, amax);
+  }
+  {
+    constexpr int STEPS = FT * 2, PF = STEPS < 4 ? STEPS : 4;  // per output tile; STEPS is a multiple of PF
+    const uint4* wp = w2 + (size_t)lane * 2;
+    asm volatile("" : "+v"(wp));
+    HFrag ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      ring[i] = load_h(wp);
+      wp += 128;
+      asm volatile("" : "+v"(wp));
+    }
+#pragma unroll 1
+    for (int nt = 0; nt < NT; ++nt) {  // rolled: the split h1 (up to 128 VGPRs) + the row fragments already fill most of the file
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      sa_l2_steps<0, STEPS, PF, FT>(ring, wp, acc, hf, nt + 1 < NT);
+      emit(nt, acc);
+    }
+  }
+}
+
 // this lane's half of the input row [x(CIN) | dpos(3) | 1 | 0...]
-template <int CIN>
-__device__ __forceinline__ void build_xrow(const float* __restrict__ x, float dx, float dy, float dz, int kh, float (&xrow)[k1p(CIN) / 2]) {
-  constexpr int HALF = k1p(CIN) / 2;
+template <int CIN, int HALF>
+__device__ __forceinline__ void build_xrow(const float* __restrict__ x, float dx, float dy, float dz, int kh, float (&xrow)[HALF]) {
 #pragma unroll
   for (int e = 0; e < HALF; ++e) {
     const int k = kh * HALF + e;
@@ -251,11 +391,20 @@ struct SaParams {
   const float* b2;
   float r2;
   int self_loops;
+  const uint4* w1h;
+  const uint4* w2h;
+  int32_t* obj_flags;  // [n_obj]: 1 = this object's magnitudes left the split-f16 range (or were not finite): f32 launches only
 };
 
-template <int CIN, int H1, int H2, int NS>
+template <int CIN, int H1, int H2, int NS, bool H>
 __global__ __launch_bounds__(256, 1) void pn_sa_kernel(SaParams P) {
   constexpr int ND = NS / 2, XS = CIN + 4, PPL = NS / 64;
+  constexpr int HALF = (H ? k1ph(CIN) : k1p(CIN)) / 2;
+  if (P.obj_flags) {  // split launch: skip flagged objects; f32 launch: only flagged objects
+    const int flagged = P.obj_flags[blockIdx.x];
+    if (H ? flagged : !flagged) return;
+  }
+  float amax = 0.f;
   extern __shared__ float smem[];
   float* spos = smem;                 // [NS][3]
   float* sx = spos + NS * 3;          // [NS][XS]
@@ -311,12 +460,14 @@ __global__ __launch_bounds__(256, 1) void pn_sa_kernel(SaParams P) {
       const int t = tt * 32 + j;
       const size_t k = (size_t)(o - cb) * ND + t;  // node index inside the cell's batch
       const float* sp = P.src_pos + ((size_t)cb * NS + k) * 3;
-      float xrow[k1p(CIN) / 2];
-      build_xrow<CIN>(P.src_x + ((size_t)cb * NS + k) * CIN, sp[0] - dpos[t * 3], sp[1] - dpos[t * 3 + 1], sp[2] - dpos[t * 3 + 2], kh, xrow);
-      sa_mlp_tile<CIN, H1, H2>(xrow, P.w1, P.w2, lane, [&](int nt, const f32x16& acc) {
+      float xrow[HALF];
+      build_xrow<CIN, HALF>(P.src_x + ((size_t)cb * NS + k) * CIN, sp[0] - dpos[t * 3], sp[1] - dpos[t * 3 + 1], sp[2] - dpos[t * 3 + 2], kh, xrow);
+      auto keep = [&](int nt, const f32x16& acc) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) selfm[(tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * H2 + nt * 32 + j] = acc[r];
-      });
+      };
+      if constexpr (H) sa_mlp_tile_h<CIN, H1, H2>(xrow, P.w1h, P.w2h, lane, amax, keep);
+      else sa_mlp_tile<CIN, H1, H2>(xrow, P.w1, P.w2, lane, keep);
     }
   } else {
     for (int i = tid; i < ND * H2; i += 256) selfm[i] = -3.0e38f;
@@ -338,16 +489,21 @@ __global__ __launch_bounds__(256, 1) void pn_sa_kernel(SaParams P) {
     }
     cnt = min(cnt, 32);  // >= 1: the centre is one of the source points
     const int nb = nbr[w * 32 + (j < cnt ? j : 0)];
-    float xrow[k1p(CIN) / 2];
-    build_xrow<CIN>(sx + nb * XS, spos[nb * 3] - cx, spos[nb * 3 + 1] - cy, spos[nb * 3 + 2] - cz, kh, xrow);
-    sa_mlp_tile<CIN, H1, H2>(xrow, P.w1, P.w2, lane, [&](int nt, const f32x16& acc) {
+    float xrow[HALF];
+    build_xrow<CIN, HALF>(sx + nb * XS, spos[nb * 3] - cx, spos[nb * 3 + 1] - cy, spos[nb * 3 + 2] - cz, kh, xrow);
+    auto pool = [&](int nt, const f32x16& acc) {
       float m = acc[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
       m = fmaxf(m, __shfl_xor(m, 32));
       const int c = nt * 32 + j;
       if (kh == 0) P.dst_x[((size_t)o * ND + t) * H2 + c] = fmaxf(fmaxf(m, selfm[t * H2 + c]) + P.b2[c], 0.f);
-    });
+    };
+    if constexpr (H) sa_mlp_tile_h<CIN, H1, H2>(xrow, P.w1h, P.w2h, lane, amax, pool);
+    else sa_mlp_tile<CIN, H1, H2>(xrow, P.w1, P.w2, lane, pool);
+  }
+  if constexpr (H) {  // anything at or beyond 3e4 (or NaN: the comparison fails) entered a split product: hand the object over
+    if (!(amax < kSplitF16Safe)) P.obj_flags[o] = 1;
   }
 }
 
@@ -355,14 +511,24 @@ __global__ __launch_bounds__(256, 1) void pn_sa_kernel(SaParams P) {
 // hidden layer passes through LDS in two halves of 256 units (the units k-steps [32 hf, 32 hf + 32) of the half-split
 // packing of the second Linear cover) while the 1024 outputs (8 column tiles per wave) accumulate in registers:
 // 68 KB of LDS instead of 100 KB, two objects per CU.
-constexpr int kGaK = 264, kGaXS = kGaK + 4, kGaH1 = 512, kGaHS = 256 + 4, kGaH2 = 1024;
+constexpr int kGaH1 = 512, kGaHS = 256 + 4, kGaH2 = 1024;
+constexpr int ga_k(bool h) { return h ? 272 : 264; }  // [x(256) | pos(3) | 1 | 0..] padded to 8 (f32 steps) / 16 (split-f16 steps)
+template <bool H>
 __global__ __launch_bounds__(256, 2) void pn_ga_kernel(const float* __restrict__ pos3, const float* __restrict__ x3,
                                                        const float4* __restrict__ w1, const float4* __restrict__ w2,
-                                                       const float* __restrict__ b2, float* __restrict__ f0) {
+                                                       const uint4* __restrict__ w1h, const uint4* __restrict__ w2h,
+                                                       const float* __restrict__ b2, float* __restrict__ f0,
+                                                       int32_t* __restrict__ obj_flags) {
+  constexpr int kGaK = ga_k(H), kGaXS = kGaK + 4;
   extern __shared__ float smem[];
   float* X = smem;                 // [32][kGaXS]  rows = [x(256) | pos(3) | 1 | 0..]
   float* Hd = X + 32 * kGaXS;      // [32][kGaHS]  one half of the hidden layer
   const int o = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, kh = lane >> 5;
+  if (obj_flags) {
+    const int flagged = obj_flags[o];
+    if (H ? flagged : !flagged) return;
+  }
+  float amax = 0.f;
   for (int i = tid; i < 32 * kGaK; i += 256) {
     const int r = i / kGaK, k = i % kGaK;
     float v = 0.f;
@@ -370,6 +536,7 @@ __global__ __launch_bounds__(256, 2) void pn_ga_kernel(const float* __restrict__
     else if (k < 259) v = pos3[((size_t)o * 32 + r) * 3 + (k - 256)];
     else if (k == 259) v = 1.f;
     X[r * kGaXS + k] = v;
+    amax = fmaxf(amax, fabsf(v));
   }
   __syncthreads();
   f32x16 acc[8];  // output column tiles w, w + 4, ..., w + 28
@@ -382,7 +549,18 @@ __global__ __launch_bounds__(256, 2) void pn_ga_kernel(const float* __restrict__
     f32x16 h[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) h[0][r] = h[1][r] = 0.f;
-    {  // the two tiles share every A fragment
+    if constexpr (H) {  // the two tiles share every (split) A fragment
+      const float* xr = X + j * kGaXS + kh * (kGaK / 2);
+      constexpr int S = kGaK / 16;
+      const uint4* wa = w1h + ((size_t)(4 * hf + w) * S * 64 + lane) * 2;
+      const uint4* wb = w1h + ((size_t)(8 + 4 * hf + w) * S * 64 + lane) * 2;
+#pragma unroll 2
+      for (int st = 0; st < S; ++st) {
+        const HFrag a = split_h(xr + 8 * st);
+        mfma_h3(h[0], a, load_h(wa + st * 128));
+        mfma_h3(h[1], a, load_h(wb + st * 128));
+      }
+    } else {  // the two tiles share every A fragment
       const float* xr = X + j * kGaXS + kh * (kGaK / 2);
       const float4* wa = w1 + (size_t)(4 * hf + w) * (kGaK / 8) * 64 + lane;
       const float4* wb = w1 + (size_t)(8 + 4 * hf + w) * (kGaK / 8) * 64 + lane;
@@ -404,9 +582,22 @@ __global__ __launch_bounds__(256, 2) void pn_ga_kernel(const float* __restrict__
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Hd[((r & 3) + 8 * (r >> 2) + 4 * kh) * kGaHS + 128 * u + 32 * w + j] = fmaxf(h[u][r], 0.f);
+      for (int r = 0; r < 16; ++r) {
+        const float hv = fmaxf(h[u][r], 0.f);
+        Hd[((r & 3) + 8 * (r >> 2) + 4 * kh) * kGaHS + 128 * u + 32 * w + j] = hv;
+        amax = fmaxf(amax, hv);
+      }
     __syncthreads();
-    {  // layer 2 partial: the 8 column tiles of this wave share every A fragment (one LDS read, 8 weight loads, 32 MFMAs)
+    if constexpr (H) {  // layer 2 partial: 8 column tiles share every split A fragment; K = 512: half hf = steps [16 hf, 16 hf + 16)
+      const float* hr = Hd + j * kGaHS + kh * 128;
+      const uint4* wp = w2h + (((size_t)w * (kGaH1 / 16) + 16 * hf) * 64 + lane) * 2;
+#pragma unroll 2
+      for (int st = 0; st < 16; ++st) {
+        const HFrag a = split_h(hr + 8 * st);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) mfma_h3(acc[t], a, load_h(wp + ((size_t)4 * t * (kGaH1 / 16) + st) * 128));
+      }
+    } else {  // layer 2 partial: the 8 column tiles of this wave share every A fragment (one LDS read, 8 weight loads, 32 MFMAs)
       const float* hr = Hd + j * kGaHS + kh * 128;
       const float4* wp = w2 + ((size_t)w * (kGaH1 / 8) + 32 * hf) * 64 + lane;
 #pragma unroll 2
@@ -431,6 +622,9 @@ __global__ __launch_bounds__(256, 2) void pn_ga_kernel(const float* __restrict__
     m = fmaxf(m, __shfl_xor(m, 32));
     const int c = (w + 4 * t) * 32 + j;
     if (kh == 0) f0[(size_t)o * kGaH2 + c] = fmaxf(m + b2[c], 0.f);
+  }
+  if constexpr (H) {
+    if (!(amax < kSplitF16Safe)) obj_flags[o] = 1;
   }
 }
 
@@ -491,16 +685,23 @@ static size_t sa_lds_bytes() {
   return sizeof(float) * (NS * 3 + NS * XS + ND * 3 + ND * H2) + sizeof(int) * (ND + 4 * 32);
 }
 
+// split = true: the split-f16 launch over all objects (it skips flagged ones and flags new ones) followed by the f32 launch
+// that serves exactly the flagged objects; split = false: one f32 launch over everything (P.obj_flags must be null)
 template <int CIN, int H1, int H2, int NS>
-static hipError_t launch_sa(const SaParams& P, int n_obj, hipStream_t s) {
+static hipError_t launch_sa(const SaParams& P, int n_obj, bool split, hipStream_t s) {
   const size_t lds = sa_lds_bytes<CIN, H1, H2, NS>();
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_kernel<CIN, H1, H2, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_kernel<CIN, H1, H2, NS, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_kernel<CIN, H1, H2, NS, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr = true;
   }
-  hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS>), dim3(n_obj), dim3(256), lds, s, P);
+  if (split) hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, true>), dim3(n_obj), dim3(256), lds, s, P);
+  hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, false>), dim3(n_obj), dim3(256), lds, s, P);
   return hipGetLastError();
 }
 
@@ -517,7 +718,7 @@ int pointnet_features_impl(t2l_ctx* ctx, const float* pos, const float* rgb, con
     for (int o = cell_offsets[c]; o < cell_offsets[c + 1]; ++o) base[o] = cell_offsets[c];
   }
   // level buffers for ALL objects (105 KB per object; 288 GB of HBM hold the whole KITTI360Pose DB at once)
-  const size_t per_obj = sizeof(float) * (128 * 3 + 128 * 64 + 64 * 3 + 64 * 128 + 32 * 3 + 32 * 256 + 1024 + 512) + sizeof(int32_t);
+  const size_t per_obj = sizeof(float) * (128 * 3 + 128 * 64 + 64 * 3 + 64 * 128 + 32 * 3 + 32 * 256 + 1024 + 512) + 2 * sizeof(int32_t);
   const size_t need = per_obj * (size_t)n_obj + 4096;
   if (need > W->ws_cap) {
     if (W->ws) (void)hipFree(W->ws);
@@ -535,24 +736,30 @@ int pointnet_features_impl(t2l_ctx* ctx, const float* pos, const float* rgb, con
   float* f0 = x3 + (size_t)n_obj * 32 * 256;
   float* f1 = f0 + (size_t)n_obj * 1024;
   int32_t* d_base = reinterpret_cast<int32_t*>(f1 + (size_t)n_obj * 512);
+  const bool split = !ctx->encoder_f32;
+  int32_t* d_flags = split ? d_base + n_obj : nullptr;
+  if (split) T2L_HIP(ctx, hipMemsetAsync(d_flags, 0, sizeof(int32_t) * n_obj, s));
   T2L_HIP(ctx, hipMemcpyAsync(d_base, base.data(), sizeof(int32_t) * n_obj, hipMemcpyHostToDevice, s));
   T2L_HIP(ctx, hipStreamSynchronize(s));  // `base` is a host temporary
   event_begin(ctx, "pointnet", s);
   const float radii[3] = {0.2f, 0.3f, 0.4f};
-  SaParams P{pos, rgb, p1, x1, d_base, W->w1[0], W->w2[0], W->b2[0], radii[0] * radii[0], ctx->pn_self_loops};
-  T2L_HIP(ctx, (launch_sa<3, 32, 64, 256>(P, n_obj, s)));
-  P = SaParams{p1, x1, p2, x2, d_base, W->w1[1], W->w2[1], W->b2[1], radii[1] * radii[1], ctx->pn_self_loops};
-  T2L_HIP(ctx, (launch_sa<64, 128, 128, 128>(P, n_obj, s)));
-  P = SaParams{p2, x2, p3, x3, d_base, W->w1[2], W->w2[2], W->b2[2], radii[2] * radii[2], ctx->pn_self_loops};
-  T2L_HIP(ctx, (launch_sa<128, 256, 256, 64>(P, n_obj, s)));
+  SaParams P{pos, rgb, p1, x1, d_base, W->w1[0], W->w2[0], W->b2[0], radii[0] * radii[0], ctx->pn_self_loops, W->w1h[0], W->w2h[0], d_flags};
+  T2L_HIP(ctx, (launch_sa<3, 32, 64, 256>(P, n_obj, split, s)));
+  P = SaParams{p1, x1, p2, x2, d_base, W->w1[1], W->w2[1], W->b2[1], radii[1] * radii[1], ctx->pn_self_loops, W->w1h[1], W->w2h[1], d_flags};
+  T2L_HIP(ctx, (launch_sa<64, 128, 128, 128>(P, n_obj, split, s)));
+  P = SaParams{p2, x2, p3, x3, d_base, W->w1[2], W->w2[2], W->b2[2], radii[2] * radii[2], ctx->pn_self_loops, W->w1h[2], W->w2h[2], d_flags};
+  T2L_HIP(ctx, (launch_sa<128, 256, 256, 64>(P, n_obj, split, s)));
   {
-    const size_t lds = sizeof(float) * (32 * kGaXS + 32 * kGaHS);
+    const size_t lds_h = sizeof(float) * (32 * (ga_k(true) + 4) + 32 * kGaHS), lds_f = sizeof(float) * (32 * (ga_k(false) + 4) + 32 * kGaHS);
     static bool attr = false;
     if (!attr) {
-      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
+      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
       attr = true;
     }
-    hipLaunchKernelGGL(pn_ga_kernel, dim3(n_obj), dim3(256), lds, s, p3, x3, W->ga1, W->ga2, W->gab2, f0);
+    if (split)
+      hipLaunchKernelGGL(pn_ga_kernel<true>, dim3(n_obj), dim3(256), lds_h, s, p3, x3, W->ga1, W->ga2, W->ga1h, W->ga2h, W->gab2, f0, d_flags);
+    hipLaunchKernelGGL(pn_ga_kernel<false>, dim3(n_obj), dim3(256), lds_f, s, p3, x3, W->ga1, W->ga2, W->ga1h, W->ga2h, W->gab2, f0, d_flags);
   }
   {  // lin1 / lin2 + ReLU over all objects (pointnet2.py:86-89): plain GEMMs on the row-major torch weights
     train::GemmArgs g{f0, W->lin1w, f1, W->lin1b, n_obj, 512, 1024, 1024, 1024, 512, 1, 0, 1024, nullptr};
