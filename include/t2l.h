@@ -267,9 +267,10 @@ int t2l_adam_step(t2l_ctx* ctx, float lr, float beta1, float beta2, float eps, v
  *     HBM-streaming scan (every CU streams a disjoint DB slice once) instead of the batched scan.
  * "search_nsplit"     (default 0 = auto): DB row splits per query block in the scan kernel.
  * "pointnet_pyg_self_loops" (default 1): see t2l_pointnet_features.
- * "encoder_f32"       (default 0): 1 = run t2l_encode_cells entirely on the f32 MFMA. By default the big contractions use
- *     split-f16 MFMAs (hi*hi + hi*lo + lo*hi, ~5e-7 relative) whenever t2l_load_weights can bound every activation that
- *     enters them below the f16 range from the weights; otherwise the f32 kernel is used automatically.
+ * "encoder_f32"       (default 0): 1 = run t2l_encode_cells, t2l_pointnet_features and t2l_fine_match entirely on the f32
+ *     MFMA. By default their big contractions use split-f16 MFMAs (hi*hi + hi*lo + lo*hi, ~5e-7 relative) behind range
+ *     safeguards — bounds derived from the weights at load time (encoder, fine stage), a row-norm guard on the raw
+ *     descriptors (fine stage), a magnitude watch (PointNet++) — and whatever fails them is computed by the f32 kernels.
  * "profile_events"    (default 0): n >= 1 records hipEvents around every n-th launch of each kernel (t2l_kernel_stats);
  *                     two records cost a few microseconds of queue time, which matters beside a 40 us kernel. */
 int t2l_set_option(t2l_ctx* ctx, const char* name, double value);
