@@ -164,7 +164,7 @@ __device__ __forceinline__ void mm_pair(const float* __restrict__ arow, int qn, 
 // tiles already offset to their first step and to this lane (2 uint4 per lane and step, 128 uint4 per step)
 __device__ __forceinline__ void mm_pair_h(const float* __restrict__ arow, int steps, const uint4* __restrict__ w0,
                                           const uint4* __restrict__ w1, f32x16& acc0, f32x16& acc1) {
-#pragma unroll 2
+#pragma unroll 4
   for (int s = 0; s < steps; ++s) {
     const HFrag a = split_h(arow + 8 * s);
     const HFrag b0 = load_h(w0 + s * 128), b1 = load_h(w1 + s * 128);
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void encode_cells_kernel(EncParams P, t2l_p
         const uint4* hk1 = W.in_hp + ((size_t)(9 + 2 * h) * HS * 64 + lane) * 2;
         const uint4* hv0 = W.in_hp + ((size_t)(16 + 2 * h) * HS * 64 + lane) * 2;
         const uint4* hv1 = W.in_hp + ((size_t)(17 + 2 * h) * HS * 64 + lane) * 2;
-#pragma unroll 2
+#pragma unroll 4
         for (int s = 0; s < HS; ++s) {
           const HFrag xf = split_h(xr + 8 * s);
           mfma_h3(qT0, load_h(hq0 + s * 128), xf);

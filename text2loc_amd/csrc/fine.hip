@@ -319,7 +319,7 @@ __device__ __forceinline__ void f_attention_regs(const float* __restrict__ x, Ti
     const uint4* hq = in_proj.h + ((size_t)h * HS * 64 + lane) * 2;
     const uint4* hk = in_proj.h + ((size_t)(4 + h) * HS * 64 + lane) * 2;
     const uint4* hv = in_proj.h + ((size_t)(8 + h) * HS * 64 + lane) * 2;
-#pragma unroll 2
+#pragma unroll 4
     for (int st = 0; st < HS; ++st) {
       const HFrag xf = split_h(xr + 8 * st), mf = split_h(mr + 8 * st);
       mfma_h3(qT, load_h(hq + st * 128), xf);
