@@ -182,6 +182,36 @@ def test_auto_mode_leaves_the_f16_scan_on_packed_scores_and_returns(eng):
     assert eng.search_fallbacks() == 0
 
 
+def test_randomized_shapes_and_data_kinds(eng):
+    """24 random (N, Q, K, row offset) draws over plain / tightly clustered / rescaled / duplicated data: ids equal the oracle
+    (swaps only between float64-equal scores, where BLAS and the kernel may sum in different orders), scores to 1e-12."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(2024 + eng.scan_mode)
+    for _ in range(24):
+        n = int(rng.choice([1, 7, 31, 32, 33, 100, 257, 511, 1000, 2049, 5000, 11259]))
+        q = int(rng.choice([1, 2, 31, 64, 65, 255, 256, 257, 700]))
+        k = int(rng.choice([1, 3, 5, 10, 11, 26]))
+        kind = int(rng.integers(0, 4))
+        db, qs, _ = synth.make_retrieval_problem(n, q, seed=int(rng.integers(1 << 30)), noise=float(rng.choice([0.1, 0.5, 2.0])))
+        if kind == 1:
+            base = synth.unit_rows(rng.standard_normal((1, 256)))
+            db = synth.unit_rows(base + 10 ** rng.uniform(-4, -2) * rng.standard_normal((n, 256))).astype(np.float32)
+        elif kind == 2:
+            db = (db * np.float32(10 ** rng.uniform(-8, 8))).astype(np.float32)
+            qs = (qs * np.float32(10 ** rng.uniform(-8, 8))).astype(np.float32)
+        elif kind == 3 and n > 40:
+            db[n // 2:n // 2 + min(20, n // 4)] = db[:min(20, n // 4)]
+        off = int(rng.integers(0, 1000))
+        idx, sc = _search(eng, db, qs, k, row_offset=off)
+        ridx, rsc = (c_oracle if kind == 3 else O).retrieve_topk(db, qs, k)
+        kk = ridx.shape[1]
+        scale = max(1.0, float(np.abs(rsc).max()))
+        assert np.abs(sc[:, :kk] - rsc).max() <= 1e-12 * scale, (n, q, k, kind)
+        for a, b in np.argwhere(idx[:, :kk] != ridx + off):
+            assert abs(sc[a, b] - rsc[a, b]) <= 1e-13 * scale, (n, q, k, kind)
+
+
 @pytest.mark.parametrize("nsplit", [1, 3, 8, 32])
 def test_nsplit_invariance(eng, nsplit):
     db, qs, _ = synth.make_retrieval_problem(2500, 130, seed=9, noise=2.0)
