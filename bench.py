@@ -448,7 +448,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     N_CELLS, N_QUERIES = args.cells, args.queries
-    EVENT_EVERY = max(1, min(8, args.steps // 8))
+    EVENT_EVERY = max(1, min(8, args.steps))  # any 8 (or `steps`) consecutive launches contain one bracketed launch
     db, qs, target = synth.make_retrieval_problem(N_CELLS, N_QUERIES, DIM, seed=1, noise=0.5)
     eng = Engine(dev)
     searcher = ShardedSearcher(eng)
