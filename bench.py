@@ -469,6 +469,7 @@ def main():
         step()
     eng.kernel_stats("search_scan")
     eng.kernel_stats("search_rerank")
+    eng.set_option("profile_events", EVENT_EVERY)  # restart the sampling phase: the first timed step is a bracketed one
     if dist:
         dist.barrier()
     torch.cuda.synchronize()

@@ -324,6 +324,7 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
   } else if (!strcmp(name, "profile_events")) {
     if (value < 0) return fail(ctx, T2L_EINVAL, "profile_events must be >= 0");
     ctx->profile_events = (int)value;
+    for (auto& kv : ctx->events) kv.second.calls = 0;  // the next launch of every kernel is a bracketed one
   } else {
     return fail(ctx, T2L_EINVAL, std::string("unknown option: ") + name);
   }
