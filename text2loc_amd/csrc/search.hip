@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256, 1) void scanh_kernel(const uint4* __restrict__
   const int half = lane >> 5, col = lane & 31;
   // block -> (query block, split): consecutive blocks (= the 8 XCDs, round robin) take consecutive QUERY blocks, so an XCD's
   // L2 sees 1/8 of the queries but every DB split. The other order (split = b % nsplit, as the f32 / split-bf16 kernels) makes
-  // every XCD pull the whole 4 MB query matrix through the fabric during the prologue — 32 MB at HBM speed = 6 of its 8 us —
-  // to save DB traffic that is spread over the whole scan and prefetched three tiles ahead anyway.
+  // every XCD pull the whole 4 MB query matrix through the fabric during the prologue (32 MB in all) to save DB traffic that
+  // is spread over the whole scan and prefetched three tiles ahead anyway. Measured: 40.2 -> 39.2 us.
   const int n_qb = gridDim.x / nsplit;
   const int qb = blockIdx.x % n_qb, sp = blockIdx.x / n_qb;
   const int nt = sp < n_tiles ? (n_tiles - sp + nsplit - 1) / nsplit : 0;
