@@ -353,12 +353,7 @@ __global__ __launch_bounds__(256, 1) void scanh_kernel(const uint4* __restrict__
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int half = lane >> 5, col = lane & 31;
-  // block -> (query block, split): consecutive blocks (= the 8 XCDs, round robin) take consecutive QUERY blocks, so an XCD's
-  // L2 sees 1/8 of the queries but every DB split. The other order (split = b % nsplit, as the f32 / split-bf16 kernels) makes
-  // every XCD pull the whole 4 MB query matrix through the fabric during the prologue (32 MB in all) to save DB traffic that
-  // is spread over the whole scan and prefetched three tiles ahead anyway. Measured: 40.2 -> 39.2 us.
-  const int n_qb = gridDim.x / nsplit;
-  const int qb = blockIdx.x % n_qb, sp = blockIdx.x / n_qb;
+  const int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
   const int nt = sp < n_tiles ? (n_tiles - sp + nsplit - 1) / nsplit : 0;
   const int uwave = uniform_wave_id();
   const int qrow0 = qb * kWideQPerBlock + uwave * kWideQPerWave + col, qrow1 = qrow0 + 32;
