@@ -511,7 +511,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
     }
   }
   // a FULL list dropped rows inside its lane: all of them have key <= its floor (-inf when nothing was dropped)
-  const float floor_max = wave_max_f32(lst[LL - 1], pinf);
+  const float lane_floor = lst[LL - 1];
+  const float floor_max = wave_max_f32(lane_floor, pinf);
   // the query as float64, 16 elements per lane (dims 64 i + 4 seg + e: each load instruction reads 256 contiguous bytes
   // per 16-lane row); the lanes of one row cover the 256 dims, the 4 rows hold copies
   const int seg = lane & 15;
@@ -642,9 +643,69 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
       if (!(fabs(t) < 3.0e38)) thr = T2L_NEG_INF;
     }
   }
+  // ---- the usual way out of a failed certificate, without leaving the wave: the lists (what the merge left of them) are
+  // still in registers. If at most 16 more kept keys reach the threshold and no full list's floor does, re-scoring exactly
+  // those — same arithmetic as above, so equal rows keep bit-equal scores — makes the top-K exact by construction (the
+  // argument of the fallback kernel's stage 2a, which remains for the larger cases).
+  bool settled = false;
+  if (!certified && representable && thr != T2L_NEG_INF && L + 16 <= 64) {
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < LL; ++i) cnt += (lst[i] >= thr) ? 1 : 0;
+    int total = cnt;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off);
+    const bool bad = lane_floor != T2L_NEG_INF && lane_floor >= thr;  // this list dropped rows that could still matter
+    if (__ballot(bad) == 0ull && total <= 16) {
+      for (int e = 0; e < total; ++e) {  // the next best kept keys, in key order, into lanes L, L+1, ...
+        const float bk = wave_max_f32(lst[0], pinf);
+        const int bl = __ffsll((long long)__ballot(lst[0] == bk)) - 1;
+        if (lane == L + e) {
+          my_key = bk;
+          my_row = key_row(bk, bl, parts >> 1, code_bits);
+        }
+        if (lane == bl) {
+#pragma unroll
+          for (int i = 0; i < LL - 1; ++i) lst[i] = lst[i + 1];
+          lst[LL - 1] = T2L_NEG_INF;
+        }
+      }
+      for (int p = L / 4; p < (L + total + 3) / 4; ++p) {
+        const int row = __shfl(my_row, 4 * p + (lane >> 4));
+        const float4* rp = reinterpret_cast<const float4*>(db + (size_t)(row == INT_MAX ? 0 : row) * kD) + seg;
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 rv = rp[16 * i];
+          d0 += (double)rv.x * qd[4 * i];
+          d1 += (double)rv.y * qd[4 * i + 1];
+          d0 += (double)rv.z * qd[4 * i + 2];
+          d1 += (double)rv.w * qd[4 * i + 3];
+        }
+        const double d = row16_sum_f64(d0 + d1);
+        const double mine = __shfl(d, 16 * (lane & 3));
+        if ((lane >> 2) == p && lane < L + total && my_row != INT_MAX) my_d = mine;
+      }
+      int rank2 = 0;
+#pragma unroll
+      for (int j = 0; j < L + 16; ++j) {
+        const unsigned long long bj = __double_as_longlong(my_d);
+        const double dj = __longlong_as_double(((unsigned long long)__builtin_amdgcn_readlane((unsigned)(bj >> 32), j) << 32) |
+                                               (unsigned)__builtin_amdgcn_readlane((unsigned)bj, j));
+        const int ij = __builtin_amdgcn_readlane(my_row, j);
+        rank2 += (dj > my_d || (dj == my_d && ij < my_row)) ? 1 : 0;
+      }
+      if (lane < L + total && my_row != INT_MAX && rank2 < K) {
+        out_idx[(size_t)qid * K + rank2] = my_row + row_offset;
+        if (out_score) out_score[(size_t)qid * K + rank2] = my_d;
+      }
+      if (lane == 0) atomicAdd(&fb_count[1], 1);  // counted with the second-stage queries
+      settled = true;
+    }
+  }
   // 2 = the f16 operands of this query (or of the DB) were not representable: its keys mean nothing, scan exactly
   if (lane == 0) {
-    const int flag = !representable ? 2 : (certified ? 0 : 1);
+    const int flag = !representable ? 2 : ((certified || settled) ? 0 : 1);
     flags[qid] = flag;
     reinterpret_cast<float*>(flags + Q)[qid] = thr;
     if (flag) flags[2 * Q + atomicAdd(&fb_count[2], 1)] = qid;  // the fallback kernel walks this list
