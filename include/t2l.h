@@ -255,6 +255,14 @@ int t2l_encode_cells_backward(t2l_ctx* ctx, const float* grad_emb, float* grad_p
 int t2l_zero_grad(t2l_ctx* ctx, void* stream);
 int t2l_adam_step(t2l_ctx* ctx, float lr, float beta1, float beta2, float eps, void* stream);
 
+/* optimizer.state_dict() / load_state_dict() for the engine-stepped tensors (torch.optim.Adam keeps exp_avg / exp_avg_sq /
+ * step per parameter; here they live inside the library). numel (out, may be NULL) = total elements over the stepped
+ * tensors, concatenated in the order of t2l_train_bind's parameter walk (feature branches, mlp_merge, obj_inter_module.*).
+ * m == v == NULL: query numel and (set == 0) step only. Otherwise m, v: dev f32[numel]; set == 0 copies the moments out and
+ * writes *step, set != 0 copies them in and takes *step. A re-bind with an unchanged parameter list (same names and sizes,
+ * new pointers: model.to(), re-assigned .grad) keeps moments and step; a changed list starts from zero. */
+int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step, int64_t* numel, void* stream);
+
 /* ---- knobs (tests / bench) ------------------------------------------------------------------- */
 /* "certify_eps_scale" (default 1.0): multiplies the f32 error bound of the search certificate; a huge
  *     value forces every query through the exact fallback (used by the parity tests).

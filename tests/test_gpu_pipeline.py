@@ -79,22 +79,40 @@ def test_run_coarse_matches_the_reference_run(golden):
         def get_cell_dataset(self):
             return CellDs()
 
+    # the HOST packer (numpy, the reference's own arithmetic for the per-object means: imports.py:28-41) feeds the encoder,
+    # so the only difference to the reference run is the fused encoder's float32 round-off
+    from oracle import c_oracle
+    from text2loc_amd import packing
+
+    for objs in objects:
+        for o in objs:
+            packing.object_features(o)
     dl = torch.utils.data.DataLoader(Ds(), batch_size=16, collate_fn=collate_fn, shuffle=False)
     acc, close, retr, ce, te = eval_epoch(model, dl, args, return_encodings=True)
-    # GPU point reductions (float64 sums vs the reference's float32 numpy sums) + fused encoder vs the reference
-    assert np.abs(ce - g["cell_encodings"]).max() < 1e-4
-    # ids: equal to the reference's wherever its own top-(k+1) score gaps exceed the encoder round-off
-    k = max(args.top_k)
-    full = np.sort(g["cell_encodings"].astype(np.float64) @ g["text_encodings"].astype(np.float64).T, axis=0)[::-1]
-    safe = np.abs(np.diff(full[: k + 1], axis=0)).min(axis=0) > 1e-5
+    ref_ce = g["cell_encodings"].astype(np.float64)
+    assert np.abs(ce - ref_ce).max() < 2e-6
+    assert np.array_equal(te, g["text_encodings"].astype(np.float64))
     ids = g["db_cell_ids"]
-    assert safe.sum() >= 8
-    for q in np.nonzero(safe)[0]:
+    k = max(args.top_k)
+    # (1) EVERY query: the retrieved ids are exactly the float64 ranking of the embeddings the engine produced
+    ridx, _ = c_oracle.retrieve_topk(ce.astype(np.float32), te.astype(np.float32), k)
+    for q in range(len(retr)):
+        assert np.array_equal(retr[q], ids[ridx[q]])
+    # (2) and they are the REFERENCE's ids for every query whose reference ranking the encoder round-off cannot touch:
+    # a score moves by at most ||c - c_ref||_2 * ||t||_2, so two neighbours can swap only if their gap is below twice that
+    delta = np.linalg.norm(ce - ref_ce, axis=1).max() * np.linalg.norm(te, axis=1).max()
+    full = np.sort(ref_ce @ te.T, axis=0)[::-1]
+    decided = np.abs(np.diff(full[: k + 1], axis=0)).min(axis=0) > 2 * delta
+    assert decided.sum() >= 60, (decided.sum(), delta)
+    for q in np.nonzero(decided)[0]:
         assert np.array_equal(retr[q], ids[g["top_rows"][q]])
-    assert np.allclose([acc[kk] for kk in args.top_k], g["acc"], atol=2 / 64)
+    undecided = int((~decided).sum())
+    assert np.abs(np.array([acc[kk] for kk in args.top_k]) - g["acc"]).max() <= undecided / 64 + 1e-12
     retrievals, at = run_coarse(model, dl, args)
     got = np.array([[at[kk][t] for t in args.threshs] for kk in args.top_k])
-    assert np.abs(got - g["acc_thresh"]).max() <= 2 / 64
+    assert np.abs(got - g["acc_thresh"]).max() <= undecided / 64 + 1e-12
+    if undecided == 0 or all(np.array_equal(retr[q], ids[g["top_rows"][q]]) for q in range(64)):
+        assert np.array_equal(np.array([acc[kk] for kk in args.top_k]), g["acc"]) and np.array_equal(got, g["acc_thresh"])
     assert len(retrievals) == 64 and retrievals[0].dtype.kind == "U"
 
 

@@ -243,17 +243,18 @@ def test_row_offset_and_logical_shards_merge(eng):
 
 def test_full_size_properties(eng):
     """BASELINE config 2 size (N=11,259, Q=4,096): planted positives are retrieved, scores are sorted,
-    ids unique and in range, and a 256-query sample equals the oracle."""
+    ids unique and in range, and EVERY one of the 4,096 x 10 (id, score) pairs equals the float64 C oracle."""
+    from oracle import c_oracle
+
     db, qs, target = synth.make_retrieval_problem(11259, 4096, seed=1, noise=0.5)
     idx, sc = _search(eng, db, qs, 10)
     assert (idx[:, 0] == target).all()
     assert (np.diff(sc, axis=1) <= 0).all()
     assert ((idx >= 0) & (idx < 11259)).all()
     assert all(len(set(r)) == 10 for r in idx[::64])
-    sel = np.arange(0, 4096, 16)
-    ridx, rsc = O.retrieve_topk(db, qs[sel], 10)
-    assert np.array_equal(idx[sel], ridx)
-    assert np.abs(sc[sel] - rsc).max() < 1e-12
+    ridx, rsc = c_oracle.retrieve_topk(db, qs, 10)
+    assert np.array_equal(idx, ridx)
+    assert np.abs(sc - rsc).max() < 1e-12
 
 
 def test_hip_merge_kernel_vs_host_merge(eng):

@@ -209,3 +209,50 @@ def test_crossmatch_mirror_has_the_reference_key_layout():
     with pytest.raises(Exception, match="MI355X|no CPU fallback"):
         model.eval()
         model.encode_cells([objs])
+
+
+class _WsTokenizer:
+    """whitespace tokenizer with padding='longest' (id 0 = pad), the interface LanguageEncoder.forward uses"""
+
+    def __call__(self, sentences, return_tensors="pt", padding="longest"):
+        toks = [[(hash(w) % 97) + 1 for w in s.split()] for s in sentences]
+        L = max(len(t) for t in toks)
+        ids = torch.tensor([t + [0] * (L - len(t)) for t in toks])
+        return {"input_ids": ids, "attention_mask": (ids != 0).long()}
+
+
+class _EmbedLLM(torch.nn.Module):
+    """stand-in for the frozen T5 encoder: an embedding table; pad positions get a (non-zero) pad embedding, as T5's do"""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.table = torch.nn.Embedding(128, dim)
+
+    def forward(self, input_ids, attention_mask, output_attentions=False):
+        return argparse.Namespace(last_hidden_state=self.table(input_ids))
+
+
+def test_run_fine_hint_encoding_pads_per_pose_like_the_reference():
+    """evaluation/pipeline.py:113-116 calls the model once per pose, so padding='longest' pads to that pose's longest hint;
+    the intra module has no padding mask and max-pools over all positions. encode_pose_hints must reproduce the per-pose
+    result when it batches poses — a naive joint call does not."""
+    from text2loc_amd.cell_retrieval import LanguageEncoder
+    from text2loc_amd.cross_matcher import encode_pose_hints
+    from text2loc_amd.engine import T2LError
+
+    torch.manual_seed(0)
+    enc = LanguageEncoder(128, fixed_embedding=True, intra_module_num_layers=1, is_fine=True, llm_model=_EmbedLLM(64),
+                          tokenizer=_WsTokenizer(), input_dim=64).eval()
+    texts = ["The pose is north of a red car. The pose is on-top of a dark-green traffic light pole thing.",
+             "The pose is east of a box. The pose is west of a wall.",
+             "The pose is south of a blue building. The pose is north of a gray very long vegetation strip here.",
+             "The pose is west of a pole. The pose is east of a road."]
+    with torch.no_grad():
+        per_pose = torch.cat([enc([t]) for t in texts])
+        grouped = encode_pose_hints(enc, texts)
+        joint = enc(texts)
+    assert grouped.shape == (4, 2, 128)
+    assert torch.allclose(grouped, per_pose, atol=1e-6)
+    assert (joint - per_pose).abs().max() > 1e-4  # the pad length is part of the reference's result
+    with pytest.raises(T2LError, match="same number of sentences"):
+        enc(["One sentence.", "Two sentences. Here."])

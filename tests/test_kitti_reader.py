@@ -1,0 +1,88 @@
+"""CPU tier, row f-2 (pickle ingestion): text2loc_amd.kitti360pose reads the reference's on-disk format
+(dataloading/kitti360pose/base.py:40-48) with NO reference module importable — the fixture pickles were written by the
+reference's own Cell / Object3d / Pose / Description classes (oracle/gen_golden_dataset.py), the expected arrays by the
+reference's own Kitti360BaseDataset reading them back."""
+import os.path as osp
+import pickle
+import sys
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN
+
+BASE = osp.join(GOLDEN, "k360_tiny")
+
+
+def test_reference_modules_are_not_importable_here():
+    assert "datapreparation" not in sys.modules
+    with pytest.raises(ModuleNotFoundError):
+        pickle.load(open(osp.join(BASE, "cells", "2013_05_28_drive_0010_sync.pkl"), "rb"))  # what plain pickle would need
+
+
+def test_pickles_load_into_records_equal_to_the_reference_view(golden):
+    from text2loc_amd import kitti360pose as K
+
+    g = golden("k360_tiny")
+    for si, scene in enumerate(g["scenes"]):
+        p = f"s{si}_"
+        cells, poses = K.load_scene(BASE, str(scene))
+        assert all(isinstance(c, K.CellRecord) for c in cells) and all(isinstance(q, K.PoseRecord) for q in poses)
+        assert [c.id for c in cells] == g[p + "cell_ids"].tolist()
+        assert np.array_equal(np.array([c.bbox_w for c in cells]), g[p + "cell_bbox_w"])
+        assert np.array_equal(np.array([c.cell_size for c in cells], dtype=np.float64), g[p + "cell_size"])
+        assert np.array_equal(np.array([c.get_center() for c in cells]), g[p + "cell_center"])
+        assert [len(c.objects) for c in cells] == g[p + "obj_counts"].tolist()
+        flat = [o for c in cells for o in c.objects]
+        assert all(isinstance(o, K.ObjectRecord) for o in flat)
+        assert [o.label for o in flat] == g[p + "obj_label"].tolist()
+        assert [o.id for o in flat] == g[p + "obj_id"].tolist()
+        assert np.array_equal(np.concatenate([o.xyz for o in flat]), g[p + "obj_xyz"])
+        assert np.array_equal(np.concatenate([o.rgb for o in flat]), g[p + "obj_rgb"])
+        assert [o.get_color_text() for o in flat] == g[p + "obj_color_text"].tolist()
+        assert np.array_equal(np.array([o.get_center() for o in flat]), g[p + "obj_center"])
+        assert np.array_equal(np.array([q.pose_w for q in poses]), g[p + "pose_w"])
+        assert [q.cell_id for q in poses] == g[p + "pose_cell_id"].tolist()
+        hints = [h for q in poses for h in K.hint_sentences(q)]
+        assert hints == g[p + "hints"].tolist()
+        assert [len(q.descriptions) for q in poses] == g[p + "hints_per_pose"].tolist()
+
+
+def test_dataset_surface_feeds_the_packer_and_eval_bookkeeping(golden):
+    """Kitti360PoseDataset: all_cells / all_poses / items / cell-only dataset as eval_epoch and CellDatabase.build consume
+    them; the host packer's per-object features equal the reference's reductions stored in the fixture."""
+    from text2loc_amd import kitti360pose as K
+    from text2loc_amd import packing
+
+    g = golden("k360_tiny")
+    scenes = [str(s) for s in g["scenes"]]
+    ds = K.Kitti360PoseDataset(BASE, scenes, object_points="sample", seed=3)
+    n_cells = sum(len(g[f"s{i}_cell_ids"]) for i in range(len(scenes)))
+    n_poses = sum(len(g[f"s{i}_pose_w"]) for i in range(len(scenes)))
+    assert len(ds.all_cells) == n_cells and len(ds) == len(ds.all_poses) == n_poses
+    assert sorted(ds.get_known_classes()) == sorted(g["s0_known_classes"].tolist())
+    item = ds[0]
+    assert item["cell_ids"] == g["s0_pose_cell_id"][0] and item["cells"].id == item["cell_ids"]
+    assert item["texts"] == " ".join(g["s0_hints"][: int(g["s0_hints_per_pose"][0])].tolist())
+    n_obj = len(item["objects"])
+    assert item["object_points"]["pos"].shape == (n_obj * 256, 3) and item["object_points"]["x"].shape == (n_obj * 256, 3)
+    batch = K.Kitti360PoseDataset.collate_fn([ds[0], ds[1]])
+    assert set(batch) >= {"texts", "cell_ids", "objects", "object_points", "poses", "cells"} and len(batch["texts"]) == 2
+    cds = ds.get_cell_dataset()
+    assert len(cds) == n_cells and [cds[i]["cell_ids"] for i in range(n_cells)] == [c.id for c in ds.all_cells]
+    assert cds.cells is not None and cds[0]["cells"].cell_size == g["s0_cell_size"][0]
+    packed = packing.pack_cells([c.objects for c in ds.all_cells], packing.class_table(packing.KNOWN_CLASS))
+    centers = np.concatenate([g[f"s{i}_obj_center"] for i in range(len(scenes))])
+    assert np.array_equal(packed["center"], centers.astype(np.float32))
+    names = np.concatenate([g[f"s{i}_obj_color_text"] for i in range(len(scenes))])
+    assert packed["color_idx"].tolist() == [packing.color_table()[n] for n in names]
+    assert packed["n_pts"].tolist() == np.concatenate([g[f"s{i}_obj_npts"] for i in range(len(scenes))]).tolist()
+
+
+def test_unpickler_refuses_foreign_classes(tmp_path):
+    from text2loc_amd import kitti360pose as K
+
+    p = tmp_path / "evil.pkl"
+    pickle.dump(osp.join, open(p, "wb"))  # a global from a module outside the whitelist
+    with pytest.raises(pickle.UnpicklingError, match="refusing"):
+        K.load_pickle(str(p))

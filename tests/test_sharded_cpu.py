@@ -135,3 +135,33 @@ def test_query_sharded_search_under_gloo(world, n_q):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def _gworker(rank, world, port, n_rows, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from text2loc_amd.sharded import gather_rows
+
+    full = torch.arange(n_rows * 6, dtype=torch.float32).reshape(n_rows, 3, 2)  # stands for [pairs, ...] match results
+    lo, hi = shard_bounds(n_rows, world, rank)
+    got = gather_rows(full[lo:hi].clone(), n_rows)
+    out_q.put((rank, bool(torch.equal(got, full))))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_rows", [(2, 41), (3, 7), (3, 2), (2, 0)])
+def test_gather_rows_under_gloo(world, n_rows):
+    """the config-5 split of the fine stage: contiguous row blocks per rank (ragged / empty tails), one all_gather"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gworker, args=(r, world, port, n_rows, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

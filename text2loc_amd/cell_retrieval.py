@@ -143,6 +143,8 @@ class LanguageEncoder(nn.Module):
             x = layer(x)
         x = x.permute(1, 0, 2).contiguous().max(dim=1)[0]
         x = self.inter_mlp(x)
+        if x.shape[0] % batch_size:
+            raise T2LError(f"{x.shape[0]} sentences do not split evenly over {batch_size} descriptions")
         x = x.view(batch_size, x.shape[0] // batch_size, -1)
         if self.is_fine:
             return x
@@ -153,8 +155,15 @@ class LanguageEncoder(nn.Module):
 
     def forward(self, descriptions: List[str]) -> torch.Tensor:
         sentences: List[str] = []
+        per_desc = []
         for d in descriptions:
-            sentences.extend(self.split_sentences(d))
+            ss = self.split_sentences(d)
+            per_desc.append(len(ss))
+            sentences.extend(ss)
+        if len(set(per_desc)) > 1:
+            # the reference reshapes [n_sentences_total] -> [batch, n // batch] (language_encoder.py:113,138): ragged hint
+            # counts either crash there or silently hand sentences to the wrong description. Refuse them.
+            raise T2LError(f"every description of a batch must hold the same number of sentences, got {sorted(set(per_desc))}")
         inputs = self.tokenizer(sentences, return_tensors="pt", padding="longest")
         dev = self.device
         out = self.llm_model(input_ids=inputs["input_ids"].to(dev), attention_mask=inputs["attention_mask"].to(dev),
@@ -217,6 +226,7 @@ class CellRetrievalNetwork(nn.Module):
             inter_module_num_heads=args.inter_module_num_heads)
         self._engine: Optional[Engine] = None
         self._weights_version = None
+        self._pn_weights_version = None
         self._train_generation = 0   # bumped whenever the engine changes parameters/buffers behind torch's back
         self._train_bound = None     # pointer set the engine's training path is bound to
         self._train_grads = {}       # name -> persistent gradient buffer (kept when .grad is set to None)
@@ -319,6 +329,7 @@ class CellRetrievalNetwork(nn.Module):
         if self._engine is None or self._engine.device != idx:
             self._engine = Engine(idx)
             self._weights_version = None
+            self._pn_weights_version = None
             self._train_bound = None
         tensors = self._train_tensors()
         key = tuple((n, d.data_ptr(), None if g is None else g.data_ptr()) for n, (d, g) in tensors.items())
@@ -335,8 +346,11 @@ class CellRetrievalNetwork(nn.Module):
         if dev.type != "cuda":
             raise T2LError("encode_objects runs on the MI355X only (model.to('cuda')); there is no CPU fallback")
         eng = self.train_engine()
-        if self._weights_version is None and "class" in self.args.use_features and not bool(getattr(self.args, "class_embed", False)):
-            self.engine()  # the PointNet++ weights travel with the eval-path upload
+        if "class" in self.args.use_features and not bool(getattr(self.args, "class_embed", False)):
+            # the (frozen) PointNet++ weights travel with the eval-path upload: redo it whenever THEY changed
+            # (load_state_dict after the first call), not on every step's running-statistics bump
+            if self._pn_version() != self._pn_weights_version:
+                self.sync_weights()
         pn = self._pn_features(object_points, eng)
         if any(getattr(o, "_t2l_feat", None) is None for objs in objects for o in objs):
             packed = packing.pack_cells_gpu(eng, objects, self.object_encoder.known_classes,
@@ -345,6 +359,8 @@ class CellRetrievalNetwork(nn.Module):
             packed = packing.to_device(packing.pack_cells(objects, self.object_encoder.known_classes,
                                                           self.object_encoder.known_colors, None), dev)
         if pn is not None:
+            if int(pn.shape[0]) != int(packed["offsets"][-1]):
+                raise T2LError("object_points must describe exactly the objects of each cell")
             packed["pn_feat"] = pn.detach().contiguous()
         layer = self.obj_inter_module[0] if len(self.obj_inter_module) else None
         p_drop = float(layer.dropout.p) if layer is not None else 0.0  # nn.TransformerEncoderLayer default 0.1
@@ -386,6 +402,7 @@ class CellRetrievalNetwork(nn.Module):
         if self._engine is None or self._engine.device != idx:
             self._engine = Engine(idx)
             self._weights_version = None
+            self._pn_weights_version = None
             self._train_bound = None
         version = (self._train_generation,) + tuple((p.data_ptr(), p._version) for p in self._object_params())
         if version != self._weights_version:
@@ -398,9 +415,14 @@ class CellRetrievalNetwork(nn.Module):
             if n.startswith(("object_encoder.", "obj_inter_module.")):
                 yield p
 
+    def _pn_version(self):
+        return tuple((p.data_ptr(), p._version) for n, p in self.state_dict(keep_vars=True).items()
+                     if n.startswith("object_encoder.pointnet."))
+
     def sync_weights(self):
         """Fold BatchNorm, re-lay out and upload the object-branch weights (t2l_load_weights)."""
         a = self.args
+        self._pn_weights_version = self._pn_version()
         sd = {k: v for k, v in self.state_dict().items() if k.startswith(("object_encoder.", "obj_inter_module."))}
         self._engine.load_weights(sd, class_embed=bool(getattr(a, "class_embed", False)),
                                   color_embed=bool(getattr(a, "color_embed", False)),

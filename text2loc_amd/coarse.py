@@ -54,6 +54,10 @@ def _batches(dataset, batch_size):
 
 def _engine_retrieve(model) -> Callable:
     def retrieve(cell_enc: torch.Tensor, text_enc: torch.Tensor, k: int):
+        from .engine import MAX_TOPK
+
+        if k > MAX_TOPK:
+            raise ValueError(f"max(top_k)={k} exceeds the engine's T2L_MAX_TOPK={MAX_TOPK} (include/t2l.h)")
         eng = model.engine()
         eng.db_set(cell_enc.contiguous())
         idx, sc = eng.search(text_enc.contiguous(), k)
@@ -97,7 +101,12 @@ def eval_epoch(model, dataloader, args, return_encodings: bool = False, return_d
     query_cell_ids = np.array(query_cell_ids, dtype="<U32")
 
     # ---- retrieval: identical to float64 `cell_encodings @ t` + stable descending argsort, first max(top_k)
-    top_idx, top_scores = retrieve(cell_enc, text_enc, max_k)
+    # (a database smaller than max(top_k) yields that many columns, like the reference's `sorted_indices[0:max_k]`;
+    # the engine marks missing ranks with id -1, which must never be used as an index)
+    k_eff = min(max_k, len(cell_enc))
+    top_idx, top_scores = retrieve(cell_enc, text_enc, k_eff)
+    if (np.asarray(top_idx) < 0).any():
+        raise RuntimeError("retrieval returned an empty rank although k <= number of cells")
 
     # ---- accuracies (host bookkeeping on [Q,K] arrays)
     retrieved_ids = db_cell_ids[top_idx]  # [Q,K]
@@ -129,27 +138,40 @@ def calc_sample_accuracies(pose, top_cells, pos_in_cells, top_k, threshs):
     return {k: {t: bool(np.min(dists[0:k]) <= t) for t in threshs} for k in top_k}
 
 
+def sample_accuracies_batch(pose_xy, pose_scene, cell_bbox_xy, cell_size, cell_scene, pos_in_cells, top_k, threshs):
+    """``calc_sample_accuracies`` for all poses at once. pose_xy f64[Q,2], pose_scene / cell_scene str arrays [Q] / [Q,K],
+    cell_bbox_xy f64[Q,K,2], cell_size f64[Q,K], pos_in_cells f64[Q,K,2] -> {k: {t: bool[Q]}}."""
+    pred_w = cell_bbox_xy + pos_in_cells * cell_size[..., None]
+    dists = np.linalg.norm(pose_xy[:, None, :] - pred_w, axis=2)
+    dists = np.where(cell_scene != pose_scene[:, None], np.inf, dists)
+    return {k: {t: dists[:, :k].min(axis=1) <= t for t in threshs} for k in top_k}
+
+
+def _pose_cell_tables(poses, cells, retrievals):
+    """The arrays ``sample_accuracies_batch`` wants, gathered once per run from the duck-typed pose / cell objects."""
+    row = {str(c.id): i for i, c in enumerate(cells)}
+    bbox = np.array([np.asarray(c.bbox_w, dtype=np.float64)[0:2] for c in cells])
+    size = np.array([float(c.cell_size) for c in cells])
+    scene = np.array([str(c.id).split("_")[0] for c in cells])
+    ridx = np.array([[row[str(cid)] for cid in r] for r in retrievals], dtype=np.int64)
+    pose_xy = np.array([np.asarray(p.pose_w, dtype=np.float64)[0:2] for p in poses])
+    pose_scene = np.array([str(p.cell_id).split("_")[0] for p in poses])
+    return pose_xy, pose_scene, bbox[ridx], size[ridx], scene[ridx]
+
+
 @torch.no_grad()
 def run_coarse(model, dataloader, args, retrieve: Optional[Callable] = None):
-    """Returns (retrievals: List[ndarray of cell ids], accuracies{k:{t: float}}) as evaluation/pipeline.py:41-87."""
-    model.eval()
-    all_cells_dict = {cell.id: cell for cell in dataloader.dataset.all_cells}
-    acc, acc_close, retrievals = eval_epoch(model, dataloader, args, retrieve=retrieve)
-    retrievals = [retrievals[i] for i in range(len(retrievals))]
+    """Returns (retrievals: List[ndarray of cell ids], accuracies{k:{t: float}}) — the result contract of
+    evaluation/pipeline.py:41-87, computed for all poses at once on [Q,K] arrays instead of per pose."""
+    acc, acc_close, top = eval_epoch(model, dataloader, args, retrieve=retrieve)
     print("Retrieval Accs:")
     print(acc)
     print("Retrieval Accs Close:")
     print(acc_close)
-    assert len(retrievals) == len(dataloader.dataset.all_poses)
-    accuracies = {k: {t: [] for t in args.threshs} for k in args.top_k}
-    for i, pose in enumerate(dataloader.dataset.all_poses):
-        top_cells = [all_cells_dict[cid] for cid in retrievals[i]]
-        pos_in_cells = 0.5 * np.ones((len(top_cells), 2))  # predict cell centres (pipeline.py:72)
-        accs = calc_sample_accuracies(pose, top_cells, pos_in_cells, args.top_k, args.threshs)
-        for k in args.top_k:
-            for t in args.threshs:
-                accuracies[k][t].append(accs[k][t])
-    for k in args.top_k:
-        for t in args.threshs:
-            accuracies[k][t] = float(np.mean(accuracies[k][t]))
-    return retrievals, accuracies
+    ds = dataloader.dataset
+    retrievals = [top[i] for i in range(len(top))]
+    assert len(retrievals) == len(ds.all_poses)
+    pose_xy, pose_scene, bbox_xy, size, scene = _pose_cell_tables(ds.all_poses, ds.all_cells, retrievals)
+    centre = np.full(bbox_xy.shape, 0.5)  # the coarse-only estimate is the cell centre (pipeline.py:72)
+    ok = sample_accuracies_batch(pose_xy, pose_scene, bbox_xy, size, scene, centre, args.top_k, args.threshs)
+    return retrievals, {k: {t: float(np.mean(ok[k][t])) for t in args.threshs} for k in args.top_k}

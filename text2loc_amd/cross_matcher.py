@@ -158,6 +158,38 @@ class CrossMatch(nn.Module):
 
 
 @torch.no_grad()
+def encode_pose_hints(language_encoder, texts: List[str], max_batch: int = 256) -> torch.Tensor:
+    """Hint encodings [n_poses, n_hints, 128] of one text per pose, equal to what the reference's per-pose call produces.
+
+    The reference runs the model once per pose on ``max(top_k)`` copies of that pose's text (evaluation/pipeline.py:113-116,
+    dataloading/kitti360pose/eval.py:181-186), so ``padding='longest'`` pads to THAT pose's longest hint — and the
+    intra-module TransformerEncoderLayers have no padding mask and max-pool over every token position
+    (language_encoder.py:127-134), i.e. the pad length is part of the result. Poses are therefore batched only with
+    poses of the same (hint count, padded token length): inside such a group a joint call pads exactly like the
+    per-pose call. One tokenizer pass per pose decides the groups; the model runs once per group chunk."""
+    tok = getattr(language_encoder, "tokenizer", None)
+    split = getattr(language_encoder, "split_sentences", None)
+    if tok is None or split is None:  # injected encoders without a tokenizer (tests with a table): one call per pose
+        return torch.cat([language_encoder([t]) for t in texts]) if texts else torch.zeros((0, 0, FINE_DIM))
+    groups = {}
+    for i, t in enumerate(texts):
+        ss = split(t)
+        ids = tok(ss, return_tensors="pt", padding="longest")["input_ids"]
+        groups.setdefault((len(ss), int(ids.shape[1])), []).append(i)
+    if len({k[0] for k in groups}) > 1:
+        raise T2LError(f"poses carry different numbers of hints: {sorted({k[0] for k in groups})}")
+    out = None
+    for _, members in sorted(groups.items()):
+        for lo in range(0, len(members), max_batch):
+            sel = members[lo:lo + max_batch]
+            enc = language_encoder([texts[i] for i in sel])
+            if out is None:
+                out = torch.empty((len(texts),) + tuple(enc.shape[1:]), dtype=enc.dtype, device=enc.device)
+            out[torch.as_tensor(sel, device=enc.device)] = enc
+    return out if out is not None else torch.zeros((0, 0, FINE_DIM))
+
+
+@torch.no_grad()
 def run_fine(model: CrossMatch, retrievals, dataloader, args, transform_fine=None, object_points_fn=None):
     """evaluation/pipeline.py:88-204: offsets of every pose against its max(top_k) retrieved cells -> {k: {t: accuracy}}.
     The reference builds a ``Kitti360TopKDataset`` item per pose and runs one forward per pose, re-encoding a cell for
@@ -165,8 +197,6 @@ def run_fine(model: CrossMatch, retrievals, dataloader, args, transform_fine=Non
     encoded once, and all poses x max(top_k) pairs are matched in one launch.
     ``object_points_fn(list_of_padded_object_lists) -> object_points`` supplies the PointNet++ inputs in the published
     feature mode (e.g. ``packing.sample_object_points``); ``transform_fine`` is accepted for signature compatibility."""
-    from .coarse import calc_sample_accuracies
-
     model.eval()
     ds = dataloader.dataset
     poses, cells = ds.all_poses, ds.all_cells
@@ -175,25 +205,28 @@ def run_fine(model: CrossMatch, retrievals, dataloader, args, transform_fine=Non
     cells_dict = {c.id: c for c in cells}
     uniq = sorted({str(cid) for r in retrievals for cid in r})
     row = {cid: i for i, cid in enumerate(uniq)}
-    padded = [pad_objects(cells_dict[cid].objects) for cid in uniq]
+    # more than one process (one per GPU, torch.distributed initialised): the distinct cells and the (pose, cell) pairs are
+    # split across the ranks in contiguous blocks — no exchange inside either stage — and all-gathered once each
+    from .sharded import gather_rows, shard_bounds, world_rank
+
+    world, rank = world_rank()
+    c_lo, c_hi = shard_bounds(len(uniq), world, rank)
+    padded = [pad_objects(cells_dict[cid].objects) for cid in uniq[c_lo:c_hi]]
     descs = []
     for lo in range(0, len(padded), 2048):
         chunk = padded[lo:lo + 2048]
         descs.append(model.encode_cells(chunk, object_points_fn(chunk) if object_points_fn is not None else None))
     cell_desc = torch.cat(descs) if descs else torch.zeros((0, PAD_SIZE, FINE_DIM), device=model.device)
-    hint_desc = []
-    for lo in range(0, len(poses), 256):
-        texts = [" ".join(create_hint_description(p)) for p in poses[lo:lo + 256]]
-        hint_desc.append(model.language_encoder(texts))
-    hint_desc = torch.cat(hint_desc)
+    cell_desc = gather_rows(cell_desc, len(uniq))
+    hint_desc = encode_pose_hints(model.language_encoder, [" ".join(create_hint_description(p)) for p in poses])
     ci = np.array([row[str(cid)] for r in retrievals for cid in r], dtype=np.int32)
     hi = np.repeat(np.arange(len(poses), dtype=np.int32), K)
-    offsets = model.match(cell_desc, hint_desc, ci, hi).cpu().numpy().reshape(len(poses), K, 2)
-    acc = {k: {t: [] for t in args.threshs} for k in args.top_k}
-    for i, pose in enumerate(poses):
-        top_cells = [cells_dict[str(cid)] for cid in retrievals[i]]
-        a = calc_sample_accuracies(pose, top_cells, offsets[i], args.top_k, args.threshs)
-        for k in args.top_k:
-            for t in args.threshs:
-                acc[k][t].append(a[k][t])
-    return {k: {t: float(np.mean(v)) for t, v in d.items()} for k, d in acc.items()}
+    p_lo, p_hi = shard_bounds(len(ci), world, rank)
+    local = model.match(cell_desc, hint_desc, ci[p_lo:p_hi], hi[p_lo:p_hi]) if p_hi > p_lo else \
+        torch.zeros((0, 2), device=model.device)
+    offsets = gather_rows(local, len(ci)).cpu().numpy().reshape(len(poses), K, 2)
+    from .coarse import _pose_cell_tables, sample_accuracies_batch
+
+    pose_xy, pose_scene, bbox_xy, size, scene = _pose_cell_tables(poses, cells, retrievals)
+    ok = sample_accuracies_batch(pose_xy, pose_scene, bbox_xy, size, scene, offsets.astype(np.float64), args.top_k, args.threshs)
+    return {k: {t: float(np.mean(ok[k][t])) for t in args.threshs} for k in args.top_k}

@@ -297,6 +297,12 @@ int t2l_adam_step(t2l_ctx* ctx, float lr, float beta1, float beta2, float eps, v
   return adam_step_impl(ctx, lr, beta1, beta2, eps, (hipStream_t)stream);
 }
 
+int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step, int64_t* numel, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return adam_state_impl(ctx, set, m, v, step, numel, (hipStream_t)stream);
+}
+
 int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
   if (!ctx || !name) return T2L_EINVAL;
   if (!strcmp(name, "certify_eps_scale")) {

@@ -1158,9 +1158,23 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
 constexpr int kMaxPerTiles = 512;
 constexpr int kSegmentRows = (kMaxParts / 2) * kMaxPerTiles * kTileRows;
 
+// an empty shard (legal under ragged row-sharding: shard_bounds hands the tail ranks nothing) answers -1 / -inf everywhere
+__global__ __launch_bounds__(256) void empty_result_kernel(int n, int32_t* __restrict__ out_idx, double* __restrict__ out_score) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    out_idx[i] = -1;
+    if (out_score) out_score[i] = -__builtin_inf();
+  }
+}
+
 int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s) {
   if (Q == 0) return T2L_OK;
   const int n_rows = (int)ctx->db_rows;
+  if (n_rows <= 0) {  // no scan: the kernels below assume at least one tile per split
+    hipLaunchKernelGGL(empty_result_kernel, dim3((Q * K + 255) / 256), dim3(256), 0, s, Q * K, out_idx, out_score);
+    T2L_HIP(ctx, hipGetLastError());
+    return T2L_OK;
+  }
   // few queries against a large shard: stream the DB once through every CU (search_stream.hip)
   if (Q <= 64 && n_rows >= ctx->stream_min_rows && n_rows > 0 && ctx->search_mode == 0 && ctx->nsplit_override == 0)
     return search_stream_impl(ctx, q, Q, K, out_idx, out_score, s);

@@ -52,7 +52,8 @@ struct TrainState {
   std::vector<std::string> adam_names;
   AdamTensor* d_tensors = nullptr;
   AdamChunk* d_chunks = nullptr;
-  float* mv = nullptr;
+  float* mv = nullptr;       // [2][mv_total]: first moments of all Adam tensors (adam_names order), then second moments
+  int64_t mv_total = 0;
   double* bn_acc = nullptr;  // [kBnSlots][2*1024] float64 partial sums of the BatchNorm stages (one slot per BN pass)
   int bn_slot = 0;
   int n_chunks = 0;
@@ -151,6 +152,24 @@ int train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const 
   if (cfg->num_heads != kTH) return fail(ctx, T2L_EINVAL, "t2l_train_bind: the engine is built for 4 attention heads");
   const int n_feat = (cfg->use_class != 0) + (cfg->use_color != 0) + (cfg->use_position != 0) + (cfg->use_num != 0);
   if (n_feat < 2) return fail(ctx, T2L_EINVAL, "t2l_train_bind: training needs at least two of the class/color/position/num features");
+  // a re-bind (model.to(), an externally assigned .grad, ...) only moves POINTERS: the Adam moments and the bias-
+  // correction step of the previous binding carry over when the parameter list (names and sizes) is unchanged
+  TrainState* old = state(ctx);
+  std::vector<std::string> old_names;
+  std::vector<int64_t> old_numel;
+  float* old_mv = nullptr;
+  int64_t old_step = 0;
+  if (old) {
+    old_names = old->adam_names;
+    for (auto& nme : old_names) old_numel.push_back(old->t[nme].numel);
+    old_mv = old->mv;
+    old->mv = nullptr;  // survives free_train below
+    old_step = old->step;
+  }
+  struct MvGuard {
+    float* p;
+    ~MvGuard() { if (p) (void)hipFree(p); }
+  } guard{old_mv};
   free_train(ctx);
   TrainState* st = new TrainState();
   ctx->train = st;
@@ -211,6 +230,15 @@ int train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const 
   T2L_HIP(ctx, hipMalloc(&st->bn_acc, sizeof(double) * 2 * 1024 * kBnSlots));
   T2L_HIP(ctx, hipMalloc(&st->mv, sizeof(float) * 2 * (size_t)total));
   T2L_HIP(ctx, hipMemset(st->mv, 0, sizeof(float) * 2 * (size_t)total));
+  st->mv_total = total;
+  {
+    bool same = old_mv != nullptr && old_names == P;
+    for (size_t i = 0; same && i < P.size(); ++i) same = st->t[P[i]].numel == old_numel[i];
+    if (same) {
+      T2L_HIP(ctx, hipMemcpy(st->mv, old_mv, sizeof(float) * 2 * (size_t)total, hipMemcpyDeviceToDevice));
+      st->step = old_step;
+    }
+  }
   int64_t off = 0;
   for (auto& nme : P) {
     const TTensor& t = st->t[nme];
@@ -497,6 +525,28 @@ int adam_step_impl(t2l_ctx* ctx, float lr, float b1, float b2, float eps, hipStr
   hipLaunchKernelGGL(adam_kernel, dim3(st->n_chunks), dim3(256), 0, s, st->d_tensors, st->d_chunks, lr, b1, b2, eps, bc1, bc2s);
   event_end(ctx, "adam_step", s);
   T2L_HIP(ctx, hipGetLastError());
+  return T2L_OK;
+}
+
+int adam_state_impl(t2l_ctx* ctx, int set, float* m, float* v, int64_t* step, int64_t* numel, hipStream_t s) {
+  TrainState* st = state(ctx);
+  if (!st) return fail(ctx, T2L_ESTATE, "t2l_adam_state: call t2l_train_bind first");
+  if (numel) *numel = st->mv_total;
+  if (!m && !v) {  // size / step query
+    if (step && !set) *step = st->step;
+    return T2L_OK;
+  }
+  if (!m || !v || !step) return fail(ctx, T2L_EINVAL, "t2l_adam_state: pass m, v and step together");
+  const size_t bytes = sizeof(float) * (size_t)st->mv_total;
+  if (set) {
+    T2L_HIP(ctx, hipMemcpyAsync(st->mv, m, bytes, hipMemcpyDeviceToDevice, s));
+    T2L_HIP(ctx, hipMemcpyAsync(st->mv + st->mv_total, v, bytes, hipMemcpyDeviceToDevice, s));
+    st->step = *step;
+  } else {
+    T2L_HIP(ctx, hipMemcpyAsync(m, st->mv, bytes, hipMemcpyDeviceToDevice, s));
+    T2L_HIP(ctx, hipMemcpyAsync(v, st->mv + st->mv_total, bytes, hipMemcpyDeviceToDevice, s));
+    *step = st->step;
+  }
   return T2L_OK;
 }
 

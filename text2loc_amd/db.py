@@ -94,9 +94,12 @@ class CellDatabase:
     def to_engine(self, engine, device="cuda", lo: int = 0, hi: Optional[int] = None):
         """Upload rows [lo, hi) as the engine's database shard (global row ids start at lo)."""
         hi = len(self) if hi is None else hi
-        engine.db_set(torch.from_numpy(self.embeddings[lo:hi]).to(device), row_offset=lo)
+        engine.db_set(torch.from_numpy(self.embeddings[lo:hi]).to(device), row_offset=lo, owner=(self, lo, hi))
 
     def search(self, engine, text_embeddings: torch.Tensor, k: int):
-        if int(engine.db_rows) != len(self):
+        """Search the WHOLE database on ``engine``. The engine is shared (eval_epoch, other databases): residency is
+        decided by identity — the engine's ``db_owner`` token, replaced by every ``db_set`` — never by row count."""
+        own = engine.db_owner
+        if not (isinstance(own, tuple) and len(own) == 3 and own[0] is self and own[1] == 0 and own[2] == len(self)):
             self.to_engine(engine, text_embeddings.device)
         return engine.search(text_embeddings.contiguous().float(), k)

@@ -76,6 +76,8 @@ EXPORTS = {
     "t2l_encode_cells_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_zero_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
     "t2l_adam_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "t2l_adam_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                 C.c_void_p]),
     "t2l_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "t2l_kernel_stats": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
 }
@@ -127,7 +129,8 @@ class Engine:
         if rc != 0:
             raise T2LError(f"t2l_create failed with {rc}")
         self._h = h
-        self._db_keepalive = None
+        self.db_owner = None
+        self.db_generation = 0
 
     def close(self):
         if getattr(self, "_h", None):
@@ -321,8 +324,34 @@ class Engine:
     def adam_step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
         self._check(self.lib.t2l_adam_step(self._h, float(lr), float(beta1), float(beta2), float(eps), _stream_ptr()))
 
+    def adam_state(self):
+        """(exp_avg f32[n], exp_avg_sq f32[n], step) of the engine-stepped tensors, flat in bind order (GPU tensors)."""
+        n, step = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.t2l_adam_state(self._h, 0, None, None, C.byref(step), C.byref(n), _stream_ptr()))
+        dev = torch.device("cuda", self.device)
+        m = torch.empty((int(n.value),), dtype=torch.float32, device=dev)
+        v = torch.empty_like(m)
+        self._check(self.lib.t2l_adam_state(self._h, 0, m.data_ptr(), v.data_ptr(), C.byref(step), C.byref(n), _stream_ptr()))
+        return m, v, int(step.value)
+
+    def set_adam_state(self, m: torch.Tensor, v: torch.Tensor, step: int):
+        n, st = C.c_int64(0), C.c_int64(int(step))
+        self._check(self.lib.t2l_adam_state(self._h, 0, None, None, C.byref(C.c_int64(0)), C.byref(n), _stream_ptr()))
+        if int(m.numel()) != int(n.value) or int(v.numel()) != int(n.value):
+            raise T2LError(f"adam state of {int(m.numel())} elements does not match the bound tensors ({int(n.value)})")
+        dev = torch.device("cuda", self.device)
+        m = m.to(dev, torch.float32).contiguous()
+        v = v.to(dev, torch.float32).contiguous()
+        self._check(self.lib.t2l_adam_state(self._h, 1, m.data_ptr(), v.data_ptr(), C.byref(st), C.byref(n), _stream_ptr()))
+        torch.cuda.current_stream().synchronize()  # m, v may be temporaries
+
     # ------------------------------------------------------------------ database + search
-    def db_set(self, emb: torch.Tensor, row_offset: int = 0):
+    def db_set(self, emb: torch.Tensor, row_offset: int = 0, owner=None):
+        """Upload this rank's database shard. ``owner`` (any object) is remembered as ``db_owner`` so that callers sharing
+        the engine can tell WHOSE rows are resident (row counts alone do not: db.CellDatabase.search); every call without
+        one installs a fresh anonymous token, i.e. invalidates every earlier owner."""
+        self.db_owner = owner if owner is not None else object()
+        self.db_generation = getattr(self, "db_generation", 0) + 1
         n = int(emb.shape[0])
         if emb.dim() != 2 or emb.shape[1] != EMBED_DIM:
             raise T2LError(f"db_set: expected [N,{EMBED_DIM}], got {tuple(emb.shape)}")

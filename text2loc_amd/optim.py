@@ -48,3 +48,21 @@ class Adam(torch.optim.Optimizer):
                 dst["lr"], dst["betas"], dst["eps"] = src["lr"], src["betas"], src["eps"]
             self._torch.step()
         return loss
+
+    # ---- checkpoint / resume: the engine-side moments are part of the optimizer state -------------------------------
+    def state_dict(self):
+        sd = {"param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
+              "torch": self._torch.state_dict() if self._torch is not None else None, "t2l_engine": None}
+        if self._model.device.type == "cuda":
+            m, v, step = self._model.train_engine().adam_state()
+            sd["t2l_engine"] = {"exp_avg": m.cpu(), "exp_avg_sq": v.cpu(), "step": step}
+        return sd
+
+    def load_state_dict(self, sd):
+        for g, saved in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: v for k, v in saved.items() if k != "params"})
+        if self._torch is not None and sd.get("torch") is not None:
+            self._torch.load_state_dict(sd["torch"])
+        e = sd.get("t2l_engine")
+        if e is not None:
+            self._model.train_engine().set_adam_state(e["exp_avg"], e["exp_avg_sq"], int(e["step"]))

@@ -16,7 +16,7 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-from .synth import COLOR_NAMES, COLORS, KNOWN_CLASS  # data tables (utils.py:48-69,210-231)
+from .tables import COLOR_NAMES, COLORS, KNOWN_CLASS  # data tables (utils.py:48-69,210-231)
 
 
 def class_table(known_classes: Sequence[str]) -> Dict[str, int]:

@@ -42,6 +42,48 @@ def merge_topk_host(idx: np.ndarray, score: np.ndarray, k: int):
 merge_topk = merge_topk_host  # name used by the tests
 
 
+def _all_gather(dist, out, inp, group):
+    """``all_gather_into_tensor`` on the tensors' own device under RCCL ("nccl"); under gloo (CPU tests, and the
+    several-processes-on-one-GPU dry run of the engine path, where RCCL refuses duplicate devices) device tensors are
+    staged through the host."""
+    if inp.is_cuda and dist.get_backend(group) != "nccl":
+        h_out = out.new_empty(out.shape, device="cpu")
+        dist.all_gather_into_tensor(h_out, inp.cpu().contiguous(), group=group)
+        out.copy_(h_out)
+    else:
+        dist.all_gather_into_tensor(out, inp.contiguous(), group=group)
+
+
+def world_rank(group=None) -> Tuple[int, int]:
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def gather_rows(local, n_total: int, group=None):
+    """Embarrassingly parallel stages (cell encoding, the fine stage's (pose, cell) pairs — BASELINE config 5): rank r
+    computed rows ``shard_bounds(n_total, world, r)`` of a row-wise result; every rank gets all ``n_total`` rows back
+    through ONE all_gather of fixed-size blocks (the ragged tail is padded, then trimmed). No-op for a single process."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = world_rank(group)
+    if world == 1:
+        return local
+    lo, hi = shard_bounds(n_total, world, rank)
+    assert local.shape[0] == hi - lo, (local.shape, lo, hi)
+    per = -(-n_total // world)
+    block = local.new_zeros((per,) + tuple(local.shape[1:]))
+    block[: hi - lo] = local
+    out = local.new_empty((world * per,) + tuple(local.shape[1:]))
+    _all_gather(dist, out, block, group)
+    # shard r starts at row min(n, r*per) = its block's offset in the gathered buffer (every shard before the tail one is
+    # full), so the first n_total rows ARE the result in order
+    return out[:n_total]
+
+
 class ShardedSearcher:
     """search_fn(queries, k) -> (idx[Q,K] int32, score[Q,K] float64) on this rank's shard (global ids);
     merge_fn(idx[P,Q,K], score[P,Q,K]) -> (idx[Q,K], score[Q,K]). With an ``Engine`` both default to the
@@ -86,13 +128,13 @@ class ShardedSearcher:
             # ONE collective: {score, row id} records (row ids are exact in float64), 16 B per candidate
             pairs = self.engine.pack_pairs(idx, sc)
             allp = torch.empty((self.world * Q, k, 2), dtype=torch.float64, device=pairs.device)
-            self.dist.all_gather_into_tensor(allp, pairs, group=self.group)
+            _all_gather(self.dist, allp, pairs, self.group)
             return self.engine.merge_pairs(allp.view(self.world, Q, k, 2))
         # rank-major concatenation along dim 0 (the layout both RCCL and gloo accept) == [world][Q][k]
         all_i = torch.empty((self.world * Q, k), dtype=idx.dtype, device=idx.device)
         all_s = torch.empty((self.world * Q, k), dtype=sc.dtype, device=sc.device)
-        self.dist.all_gather_into_tensor(all_i, idx.contiguous(), group=self.group)
-        self.dist.all_gather_into_tensor(all_s, sc.contiguous(), group=self.group)
+        _all_gather(self.dist, all_i, idx, self.group)
+        _all_gather(self.dist, all_s, sc, self.group)
         return self.merge_fn(all_i.view(self.world, Q, k), all_s.view(self.world, Q, k))
 
 
@@ -133,6 +175,6 @@ class QueryShardedSearcher:
         pi[: hi - lo], ps[: hi - lo] = idx, sc
         all_i = torch.empty((self.world * per, k), dtype=idx.dtype, device=idx.device)
         all_s = torch.empty((self.world * per, k), dtype=sc.dtype, device=sc.device)
-        self.dist.all_gather_into_tensor(all_i, pi, group=self.group)
-        self.dist.all_gather_into_tensor(all_s, ps, group=self.group)
+        _all_gather(self.dist, all_i, pi, self.group)
+        _all_gather(self.dist, all_s, ps, self.group)
         return all_i[:Q], all_s[:Q]

@@ -17,26 +17,7 @@ from __future__ import annotations
 
 import numpy as np
 
-# Table values follow datapreparation/kitti360pose/utils.py:48-69 (class names, alphabetical) and
-# :210-231 (8 fitted colour centres / their names; 'gray' appears twice in the reference).
-KNOWN_CLASS = [
-    "box", "bridge", "building", "fence", "garage", "guard rail", "lamp", "pad", "parking", "pole",
-    "road", "sidewalk", "smallpole", "stop", "terrain", "traffic light", "traffic sign",
-    "trash bin", "tunnel", "vegetation", "vending machine", "wall",
-]
-COLOR_NAMES = ["dark-green", "gray", "gray-green", "bright-gray", "gray", "black", "green", "beige"]
-COLORS = np.array(
-    [
-        [47.2579917, 49.75368454, 42.4153065],
-        [136.32696657, 136.95241796, 126.02741229],
-        [87.49822126, 91.69058836, 80.14558512],
-        [213.91030679, 216.25033052, 207.24611073],
-        [110.39218852, 112.91977458, 103.68638249],
-        [27.47505158, 28.43996795, 25.16840296],
-        [66.65951839, 70.22342483, 60.20395996],
-        [171.00852191, 170.05737735, 155.00130334],
-    ]
-) / 255.0
+from .tables import COLOR_NAMES, COLORS, KNOWN_CLASS  # noqa: F401  (dataset constants live with the product)
 
 NUM_MEAN = 1826.6844940968194  # models/object_encoder.py:43
 NUM_STD = 2516.8905096993817  # models/object_encoder.py:44
@@ -268,3 +249,13 @@ def make_retrieval_problem(n_cells: int, n_queries: int, dim: int = 256, seed: i
     nz = unit_rows(rng.standard_normal((n_queries, dim)))
     q = unit_rows(db[target].astype(np.float64) + noise * nz).astype(np.float32)
     return db, q, target.astype(np.int64)
+
+
+def make_queries_for(db: np.ndarray, n_queries: int, seed: int = 0, noise: float = 0.5):
+    """Another batch of planted-positive queries for an existing DB (same recipe as ``make_retrieval_problem``).
+    Returns (queries f32[Q,dim], target_row i64[Q])."""
+    rng = np.random.default_rng([seed, 0xBA7C])
+    target = rng.integers(0, len(db), size=n_queries)
+    nz = unit_rows(rng.standard_normal((n_queries, db.shape[1])))
+    q = unit_rows(db[target].astype(np.float64) + noise * nz).astype(np.float32)
+    return q, target.astype(np.int64)
