@@ -260,7 +260,8 @@ int t2l_adam_step(t2l_ctx* ctx, float lr, float beta1, float beta2, float eps, v
  * tensors, concatenated in the order of t2l_train_bind's parameter walk (feature branches, mlp_merge, obj_inter_module.*).
  * m == v == NULL: query numel and (set == 0) step only. Otherwise m, v: dev f32[numel]; set == 0 copies the moments out and
  * writes *step, set != 0 copies them in and takes *step. A re-bind with an unchanged parameter list (same names and sizes,
- * new pointers: model.to(), re-assigned .grad) keeps moments and step; a changed list starts from zero. */
+ * new pointers: model.to(), re-assigned .grad) keeps moments and step IF option "train_keep_adam_state" is 1 at the time of
+ * the re-bind (default 0: every bind starts from zero moments — a different model may use the same names). */
 int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step, int64_t* numel, void* stream);
 
 /* ---- knobs (tests / bench) ------------------------------------------------------------------- */

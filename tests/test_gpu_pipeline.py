@@ -91,7 +91,7 @@ def test_run_coarse_matches_the_reference_run(golden):
     acc, close, retr, ce, te = eval_epoch(model, dl, args, return_encodings=True)
     ref_ce = g["cell_encodings"].astype(np.float64)
     assert np.abs(ce - ref_ce).max() < 2e-6
-    assert np.array_equal(te, g["text_encodings"].astype(np.float64))
+    assert np.abs(te - g["text_encodings"].astype(np.float64)).max() < 1e-6  # encode_text re-normalises the preset rows
     ids = g["db_cell_ids"]
     k = max(args.top_k)
     # (1) EVERY query: the retrieved ids are exactly the float64 ranking of the embeddings the engine produced

@@ -200,3 +200,61 @@ def test_train_epoch_runs_and_pn_feature_gradient_flows():
         a = model.encode_objects(objects[:B], pn)
         model.encode_objects(objects[:B], pn)
         a.sum().backward()
+
+
+def test_adam_state_survives_rebinds_and_checkpoints():
+    """The engine owns exp_avg / exp_avg_sq / step of the object branch: a re-bind of the same model (new .grad storage)
+    keeps them, and optimizer.state_dict() / load_state_dict() round-trip them (resume gives the same next step)."""
+    from text2loc_amd.cell_retrieval import CellRetrievalNetwork
+    from text2loc_amd.losses import ContrastiveLoss
+    from text2loc_amd.optim import Adam
+
+    B = 8
+    args = _args()
+    cells = synth.make_cells(B, seed=77)
+    objects = make_objects(cells, 77)
+    sd0 = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_object_branch_weights(6).items()}
+
+    def fresh():
+        m = CellRetrievalNetwork(synth.KNOWN_CLASS, synth.COLOR_NAMES, args, language_encoder=TableText(B, 5))
+        m.load_state_dict(sd0, strict=False)
+        for layer in m.obj_inter_module:
+            layer.dropout.p = layer.dropout1.p = layer.dropout2.p = 0.0
+            layer.self_attn.dropout = 0.0
+        return m.to("cuda").train()
+
+    crit = ContrastiveLoss(temperature=0.1)
+
+    def one_step(m, opt):
+        opt.zero_grad()
+        loss = crit(m.encode_text(list(range(B))), m.encode_objects(objects, None))
+        loss.backward()
+        opt.step()
+
+    model = fresh()
+    opt = Adam(model, lr=1e-3)
+    one_step(model, opt)
+    one_step(model, opt)
+    m2, v2, step2 = model.train_engine().adam_state()
+    assert step2 == 2 and float(v2.abs().max()) > 0
+    # re-bind: hand one parameter a NEW gradient buffer (what an external .grad assignment does)
+    p = model.obj_inter_module[0].linear1.weight
+    p.grad = torch.zeros_like(p)
+    eng = model.train_engine()
+    m2b, v2b, step2b = eng.adam_state()
+    assert step2b == 2 and torch.equal(m2, m2b) and torch.equal(v2, v2b)
+    # checkpoint after 2 steps -> resume in a new model/optimizer -> the third step matches the uninterrupted run
+    ckpt_model = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ckpt_opt = opt.state_dict()
+    one_step(model, opt)
+    want = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    resumed = fresh()
+    resumed.load_state_dict(ckpt_model)
+    opt_r = Adam(resumed, lr=1e-3)
+    opt_r.load_state_dict(ckpt_opt)
+    assert resumed.train_engine().adam_state()[2] == 2
+    one_step(resumed, opt_r)
+    for k in ("obj_inter_module.1.linear2.weight", "object_encoder.mlp_merge.0.0.weight", "object_encoder.class_embedding.weight"):
+        assert torch.allclose(resumed.state_dict()[k], want[k], rtol=0, atol=2e-6), k  # float atomics in the gradients
+    # a DIFFERENT model on a fresh engine starts from zero
+    assert fresh().train_engine().adam_state()[2] == 0

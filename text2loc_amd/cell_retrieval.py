@@ -335,6 +335,8 @@ class CellRetrievalNetwork(nn.Module):
         key = tuple((n, d.data_ptr(), None if g is None else g.data_ptr()) for n, (d, g) in tensors.items())
         if key != self._train_bound:
             a = self.args
+            # same model, moved storage (model.to(), re-assigned .grad): the optimizer state must survive the re-bind
+            self._engine.set_option("train_keep_adam_state", 1 if self._train_bound is not None else 0)
             self._engine.train_bind(tensors, class_embed=bool(getattr(a, "class_embed", False)),
                                     color_embed=bool(getattr(a, "color_embed", False)), use_features=tuple(a.use_features),
                                     num_layers=a.object_inter_module_num_layers, num_heads=a.object_inter_module_num_heads)

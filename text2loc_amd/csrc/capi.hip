@@ -1,4 +1,5 @@
 // C ABI of libt2l.so (see include/t2l.h): context, database shard, options, timing.
+#include <limits.h>
 #include <string.h>
 
 #include "t2l_internal.h"
@@ -224,6 +225,16 @@ int t2l_search_fallbacks(t2l_ctx* ctx, int32_t* out_count) {
   return T2L_OK;
 }
 
+#ifdef T2L_STAMPS
+int t2l_debug_stamps(t2l_ctx* ctx, long long* out8) {  // dev builds only: s_memrealtime stamps a kernel left in fb_count[16..]
+  T2L_HIP(ctx, hipDeviceSynchronize());
+  T2L_HIP(ctx, hipMemcpy(out8, ctx->fb_count + 16, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+  const long long init[8] = {0, 0, 0, 0, LLONG_MAX, 0, LLONG_MAX, 0};  // re-arm the min / max slots
+  T2L_HIP(ctx, hipMemcpy(ctx->fb_count + 16, init, sizeof(init), hipMemcpyHostToDevice));
+  return T2L_OK;
+}
+#endif
+
 int t2l_search_rescored(t2l_ctx* ctx, int32_t* out_count) {
   if (!ctx || !out_count) return T2L_EINVAL;
   T2L_HIP(ctx, hipSetDevice(ctx->device));
@@ -323,6 +334,13 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
       ctx->escalated = false;
       ctx->stat_seen = ctx->stat_seq;
     }
+  } else if (!strcmp(name, "search_pair_ll")) {
+    if (value != 5 && value != 6) return fail(ctx, T2L_EINVAL, "search_pair_ll must be 5 or 6");
+    ctx->pair_ll = (int)value;
+  } else if (!strcmp(name, "search_pair")) {
+    ctx->search_pair = value != 0;
+  } else if (!strcmp(name, "train_keep_adam_state")) {
+    ctx->train_keep_adam = value != 0;
   } else if (!strcmp(name, "stream_min_rows")) {
     ctx->stream_min_rows = (int)value;
   } else if (!strcmp(name, "pointnet_pyg_self_loops")) {

@@ -333,15 +333,18 @@ __global__ __launch_bounds__(256, 1) void scanw_kernel(const uint4* __restrict__
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void half_db_kernel(const float* __restrict__ db, const float* __restrict__ norms,
                                                       uint4* __restrict__ out, int rows) {
-  const int gid = blockIdx.x * 256 + threadIdx.x;  // one thread = 8 consecutive floats -> 16 bytes
-  const int row = gid >> 5, c = gid & 31;
+  // one thread = 8 consecutive floats of one row -> one 16-byte f16 chunk; consecutive threads take consecutive ROWS of one
+  // chunk column, i.e. consecutive 16-byte units of the tile-chunk-major plane (search_dev.h): coalesced writes
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int r = gid & 31, c = (gid >> 5) & 31, tile = gid >> 10;
+  const int row = tile * kTileRows + r;
   if (row >= rows) return;
   int shift;
   half_shift_of(norms[1], shift);
   const float4* src = reinterpret_cast<const float4*>(db + (size_t)row * kD + 8 * c);
   const float4 a = src[0], b = src[1];
-  out[(size_t)row * 32 + c] = make_uint4(pack_f16x2(a.x, a.y, shift), pack_f16x2(a.z, a.w, shift),
-                                         pack_f16x2(b.x, b.y, shift), pack_f16x2(b.z, b.w, shift));
+  out[gid] = make_uint4(pack_f16x2(a.x, a.y, shift), pack_f16x2(a.z, a.w, shift), pack_f16x2(b.x, b.y, shift),
+                        pack_f16x2(b.z, b.w, shift));
 }
 
 template <int LL>
@@ -363,22 +366,14 @@ __global__ __launch_bounds__(256, 1) void scanh_kernel(const uint4* __restrict__
   if (blockIdx.x == 0 && tid < 4 && (zero_counts || tid >= 2)) fb_count[tid] = 0;  // [3] = f16-probe count (rerank_kernel)
   if (nt == 0) return;  // (the host never launches an empty split)
 
-  // ---- LDS-DMA plan: wave w moves row pairs 4w .. 4w+3 of a tile; lane l of piece i lands at LDS chunk l & 31 of row
-  // r = 2*(4w+i) + (l >> 5), which must hold global chunk (l & 31) ^ r of that row
-  unsigned doff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = 2 * (4 * uwave + i) + half;
-    doff[i] = r * 512 + ((col ^ r) << 4);
-  }
+  // ---- LDS-DMA plan: wave w moves pieces 4w .. 4w+3 (1 KiB each, contiguous) of a tile: global image == LDS image
   const unsigned lds_base = lds_addr_of(smem);
   auto dma_of = [&](int j, int buf) {
     const int tile = sp + min(j, nt - 1) * nsplit;  // over-issue at the end is clamped (see scanw_kernel)
     HalfDma d;
-    d.src = reinterpret_cast<const char*>(dbh) + (size_t)tile * kHalfTileBytes;
+    d.src = reinterpret_cast<const char*>(dbh) + (size_t)tile * kHalfTileBytes + uwave * 4096;
     d.dst = lds_base + buf * kHalfTileBytes + uwave * 4096;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) d.off[i] = doff[i];
+    d.lane16 = lane * 16;
     return d;
   };
 #pragma unroll
@@ -425,24 +420,21 @@ __global__ __launch_bounds__(256, 1) void scanh_kernel(const uint4* __restrict__
 #pragma unroll
   for (int r = 0; r < 16; ++r) accA0[r] = accA1[r] = accB0[r] = accB1[r] = T2L_NEG_INF;
 
-  // lane (col, half) reads chunk half*16 + S of row col at k-step S: swizzled position (half*16 + S) ^ col
-  unsigned roff[16];
-#pragma unroll
-  for (int s = 0; s < 16; ++s) roff[s] = col * 512 + ((((half << 4) + s) ^ col) << 4);
-  const char* lds0 = reinterpret_cast<const char*>(smem);
+  // lane (col, half) reads chunk half*16 + S of row col at k-step S: lb + S*512 (tile-chunk-major, search_dev.h)
+  const char* lb = reinterpret_cast<const char*>(smem) + half * 8192 + col * 16;
   u32x4 ring[4];
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (NBUF - 2)) : "memory");  // tile 0 landed for every wave
 #pragma unroll
-  for (int i = 0; i < 4; ++i) ring[i] = *reinterpret_cast<const u32x4*>(lds0 + roff[i]);
+  for (int i = 0; i < 4; ++i) ring[i] = *reinterpret_cast<const u32x4*>(lb + i * 512);
 
   auto step = [&](auto buf_tag, int j, f32x16& cur0, f32x16& cur1, const f32x16& prev0, const f32x16& prev1) {
     constexpr int BUF = decltype(buf_tag)::value;
     const HalfDma d = dma_of(j + NBUF - 1, (BUF + NBUF - 1) % NBUF);
-    tileh_steps<LL, 0, 12, BUF, NBUF>(lds0, roff, q0, q1, cur0, cur1, prev0, prev1, vmask, (j - 1) << 4, pinf, w, ring, d);
+    tileh_steps<LL, 0, 12, BUF, NBUF>(lb, q0, q1, cur0, cur1, prev0, prev1, vmask, (j - 1) << 4, pinf, w, ring, d);
     // tile j+1 (issued two tiles ago) has landed for this wave; after the barrier it has for every wave, and every wave
     // is past its last read of tile j-1, whose buffer the DMA below refills
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (NBUF - 3)) : "memory");
-    tileh_steps<LL, 12, 16, BUF, NBUF>(lds0, roff, q0, q1, cur0, cur1, prev0, prev1, vmask, (j - 1) << 4, pinf, w, ring, d);
+    tileh_steps<LL, 12, 16, BUF, NBUF>(lb, q0, q1, cur0, cur1, prev0, prev1, vmask, (j - 1) << 4, pinf, w, ring, d);
   };
   for (int j = 0; j < nt; j += 4) {
     step(std::integral_constant<int, 0>{}, j, accA0, accA1, accB0, accB1);
@@ -478,6 +470,200 @@ __global__ __launch_bounds__(256, 1) void scanh_kernel(const uint4* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// scanp: the PAIRED f16 scan (default) — scanh's per-wave pipeline with TWO waves per SIMD (search_dev.h).
+//
+//   workgroup = 512 threads = 8 waves, 256 queries (waves w and w+4 hold the same 64), DB split sp of nsplit; wave w (< 4)
+//   scans the tiles of virtual split sp, wave w+4 those of sp + nsplit (of 2*nsplit: tile t belongs to virtual split
+//   t % (2*nsplit)), one tile each per STEP. A step's two tiles share an LDS slot (2 x 16 KiB); the ring holds NS slots and
+//   all 8 waves move every tile (4 LDS-DMA pieces per wave per step). One s_waitcnt + s_barrier per step.
+//   Per-lane lists of LL = 6 keys: 4 lists per (query, split) -> 64 lists per query at nsplit = 16, so the candidate set
+//   (384 keys) is larger than scanh's (32 x 8) at 7 instead of 9 selection VALU per score.
+//   Prologue: the 256 queries are converted COOPERATIVELY, once per workgroup: thread (query, quarter row) loads 64
+//   floats (64 staging registers instead of 128 per lane), the row maximum is a DPP quad reduction, the scaled f16 chunks
+//   go to LDS and every wave reads its 2 x 16 fragments back into AGPRs — two rounds of 128 queries (round = query group),
+//   64 KiB of LDS that the ring's later slots reuse.
+//   grid = ceil(Q/256) * nsplit; LDS 128 KiB.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+
+template <int LL, int NS>
+__global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__ dbt, int n_rows, int n_tiles, int code_bits,
+                                                       const float* __restrict__ q, int Q, int nsplit,
+                                                       float* __restrict__ cand, int32_t* __restrict__ fb_count,
+                                                       int zero_counts, float pinf) {
+  static_assert(NS == 4, "the step loop below is unrolled for a ring of 4 slots");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kSlotBytes = 2 * kHalfTileBytes;
+  constexpr unsigned kExchange = 2 * kSlotBytes;  // slots 2.. double as the query exchange area (64 KiB) in the prologue
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int half = lane >> 5, col = lane & 31;
+  const int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
+  const int uwave = uniform_wave_id();
+  const int quad = uwave >> 2, wq = uwave & 3;
+  const int vn = 2 * nsplit, vs = sp + quad * nsplit;                     // this wave's virtual split
+  const int nt = vs < n_tiles ? (n_tiles - vs + vn - 1) / vn : 0;         // its tiles: vs, vs + vn, ...
+  const int steps = sp < n_tiles ? (n_tiles - sp + vn - 1) / vn : 0;      // = nt of the first quad >= nt of the second
+  const int mask = ~((1 << code_bits) - 1);
+  int vmask = mask;
+  asm volatile("" : "+v"(vmask));
+  if (blockIdx.x == 0 && tid < 4 && (zero_counts || tid >= 2)) fb_count[tid] = 0;  // [3] = f16-probe count (rerank_kernel)
+  if (steps == 0) return;  // (the host never launches an empty split)
+#ifdef T2L_STAMPS
+#define T2L_STAMP(k)                                                                                                   \
+  if (tid == 0) {                                                                                                      \
+    const long long t_ = __builtin_amdgcn_s_memrealtime();                                                             \
+    if (blockIdx.x == 37) reinterpret_cast<long long*>(fb_count + 16)[k] = t_;                                         \
+    if (k == 0) atomicMin(reinterpret_cast<unsigned long long*>(fb_count + 16) + 4, (unsigned long long)t_);           \
+    if (k == 0) atomicMax(reinterpret_cast<unsigned long long*>(fb_count + 16) + 5, (unsigned long long)t_);           \
+    if (k == 3) atomicMin(reinterpret_cast<unsigned long long*>(fb_count + 16) + 6, (unsigned long long)t_);           \
+    if (k == 3) atomicMax(reinterpret_cast<unsigned long long*>(fb_count + 16) + 7, (unsigned long long)t_);           \
+  }
+#else
+#define T2L_STAMP(k)
+#endif
+  T2L_STAMP(0);
+
+  const unsigned lds_base = lds_addr_of(smem);
+  const unsigned lane16 = lane * 16;
+  // the wave's 4 LDS-DMA pieces of step i (2 tiles x pieces 2w, 2w+1) into slot `slot`; tiles past the end are clamped to
+  // the last tile (the pipeline over-issues, and the second quad may run one step more than it has tiles: nobody reads those)
+  auto dma_of = [&](int i, int slot) {
+    PairDma d;
+    const int t0 = min(sp + (2 * i) * nsplit, n_tiles - 1), t1 = min(sp + (2 * i + 1) * nsplit, n_tiles - 1);
+    d.src0 = reinterpret_cast<const char*>(dbt) + (size_t)t0 * kHalfTileBytes + uwave * 2048;
+    d.src1 = reinterpret_cast<const char*>(dbt) + (size_t)t1 * kHalfTileBytes + uwave * 2048;
+    d.dst = lds_base + slot * kSlotBytes + uwave * 2048;
+    d.lane16 = lane16;
+    return d;
+  };
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {  // steps 0 and 1 travel while the queries are converted
+    const PairDma d = dma_of(b, b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d.piece(e);
+  }
+
+  // ---- queries: round g converts query group g of every wave slot: local query ql = (wave slot, col) <-> global query
+  // qb*256 + slot*64 + g*32 + col; thread (ql, quarter) = (tid >> 2, tid & 3). LDS exchange rows are 512 B (one f16 query),
+  // 16-byte chunk c of row ql at chunk c ^ (ql & 31): conflict-free for the quarter-row writers and the fragment readers.
+  u32x4 q0[16], q1[16];  // 128 AGPRs
+  {
+    const int ql = tid >> 2, qt = tid & 3;
+    char* ex_w = reinterpret_cast<char*>(smem) + kExchange + ql * 512;
+    const char* ex_r = reinterpret_cast<const char*>(smem) + kExchange + (wq * 32 + col) * 512;
+    // BOTH rounds' loads are issued before anything waits on them (2 x 64 staging registers: what does not fit the 128
+    // VGPRs parks in the still-empty AGPRs): the prologue is latency-bound, one round trip instead of two
+    float4 v[2][16];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int qrow = min(qb * kWideQPerBlock + (ql >> 5) * kWideQPerWave + g * 32 + (ql & 31), Q - 1);
+      const float4* qp = reinterpret_cast<const float4*>(q + (size_t)qrow * kD + qt * 64);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[g][i] = qp[i];
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float m = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        m = fmaxf(fmaxf(m, fabsf(v[g][i].x)), fabsf(v[g][i].y));
+        m = fmaxf(fmaxf(m, fabsf(v[g][i].z)), fabsf(v[g][i].w));
+      }
+      m = fmaxf(m, dpp_f<kDppXor1>(m));  // the row's 4 quarters sit in 4 adjacent lanes
+      m = fmaxf(m, dpp_f<kDppXor2>(m));
+      int shift;
+      half_shift_of(m, shift);
+      if (g == 1) __syncthreads();  // every wave has read round 0's fragments: the exchange area may be overwritten
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 a = v[g][2 * j], b = v[g][2 * j + 1];
+        *reinterpret_cast<u32x4*>(ex_w + (((qt * 8 + j) ^ (ql & 31)) << 4)) =
+            u32x4{pack_f16x2(a.x, a.y, shift), pack_f16x2(a.z, a.w, shift), pack_f16x2(b.x, b.y, shift),
+                  pack_f16x2(b.z, b.w, shift)};
+      }
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const u32x4 f = *reinterpret_cast<const u32x4*>(ex_r + ((((half << 4) + s) ^ col) << 4));
+        if (g == 0) q0[s] = pin_agpr(f); else q1[s] = pin_agpr(f);
+      }
+    }
+    __syncthreads();  // the exchange area is free: it is slots 2.. of the tile ring from here on
+  }
+  T2L_STAMP(1);
+  {
+    const PairDma d = dma_of(2, 2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d.piece(e);
+  }
+
+  WideLists<LL> w;
+#pragma unroll
+  for (int i = 0; i < LL; ++i) w.ls0[i] = w.ls1[i] = T2L_NEG_INF;
+  w.key0 = w.key1 = T2L_NEG_INF;
+  f32x16 accA0, accA1, accB0, accB1;  // step i / step i+1, per query group
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accA0[r] = accA1[r] = accB0[r] = accB1[r] = T2L_NEG_INF;
+
+  lds_cptr lb0 = (lds_cptr)smem + quad * kHalfTileBytes + half * 8192 + col * 16;
+  lds_cptr lb1 = lb0 + 65536;
+  asm volatile("" : "+v"(lb1));  // opaque: otherwise every slot-2/3 fragment address (> the 16-bit ds offset) gets its own register
+  u32x4 ring[4];
+  // steps 0 and 1 landed for every wave before the query loads returned (vmcnt retires in order) and the barriers above
+  // published that; only step 2's pieces may be in flight
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ring[i] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(lb0 + i * 512);
+
+  auto step = [&](auto slot_tag, int i, f32x16& cur0, f32x16& cur1, const f32x16& prev0, const f32x16& prev1) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    const PairDma d = dma_of(i + NS - 1, (SLOT + NS - 1) % NS);
+    tilep_steps<LL, 0, 12, SLOT, NS>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, (i - 1) << 4, pinf, w, ring, d);
+    // step i+1 (issued two steps ago) has landed for this wave; after the barrier it has for every wave, and every wave
+    // is past its last read of step i-1, whose slot the DMA below refills
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (NS - 3)) : "memory");
+    tilep_steps<LL, 12, 16, SLOT, NS>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, (i - 1) << 4, pinf, w, ring, d);
+  };
+  for (int i = 0; i < steps; i += 4) {
+    step(std::integral_constant<int, 0>{}, i, accA0, accA1, accB0, accB1);
+    if (i + 1 < steps) step(std::integral_constant<int, 1>{}, i + 1, accB0, accB1, accA0, accA1);
+    if (i + 2 < steps) step(std::integral_constant<int, 2>{}, i + 2, accA0, accA1, accB0, accB1);
+    if (i + 3 < steps) step(std::integral_constant<int, 3>{}, i + 3, accB0, accB1, accA0, accA1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // over-issued DMA pieces must not land in LDS after the workgroup is gone
+  T2L_STAMP(2);
+
+  if (nt == steps) {  // the wave's last tile's scores are still in registers; only here can rows be >= n_rows. (A wave with
+                      // nt == steps - 1 ran its last step on a clamped tile: that step inserted the real last tile's scores.)
+    const int row0 = (vs + (nt - 1) * vn) * kTileRows + 4 * half;
+    const int code0 = (nt - 1) << 4;
+    const bool odd = nt & 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool ok = row0 + (r & 3) + 8 * (r >> 2) < n_rows;
+      const float s0 = odd ? accA0[r] : accB0[r], s1 = odd ? accA1[r] : accB1[r];
+      ins_key<LL>(w.ls0, ok ? make_key(s0, mask, code0 + r) : T2L_NEG_INF);
+      ins_key<LL>(w.ls1, ok ? make_key(s1, mask, code0 + r) : T2L_NEG_INF);
+    }
+  }
+  const int part = 2 * vs + half, parts = 2 * vn;
+  const int qrow0 = qb * kWideQPerBlock + wq * kWideQPerWave + col, qrow1 = qrow0 + 32;
+  if (qrow0 < Q) {
+    float* out = cand + ((size_t)qrow0 * parts + part) * LL;
+#pragma unroll
+    for (int i = 0; i < LL; ++i) out[i] = w.ls0[i];
+  }
+  if (qrow1 < Q) {
+    float* out = cand + ((size_t)qrow1 * parts + part) * LL;
+#pragma unroll
+    for (int i = 0; i < LL; ++i) out[i] = w.ls1[i];
+  }
+  T2L_STAMP(3);
+}
+
+// ------------------------------------------------------------------------------------------------
 // rerank (stage 1): one wave per query, 4 queries per 256-thread block.
 // ------------------------------------------------------------------------------------------------
 // LL = length of the per-lane lists the scan wrote, L = rows re-scored per query (LL <= L).
@@ -496,14 +682,17 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
   // ---- every lane pulls its whole sorted key list into registers (one memory latency for the merge)
   float lst[LL];
   {
-    const float4* mine = reinterpret_cast<const float4*>(cand + ((size_t)qid * parts + min(lane, parts - 1)) * LL);
+    const float* mine = cand + ((size_t)qid * parts + min(lane, parts - 1)) * LL;
+    if constexpr (LL % 2 == 0) {  // (LL = 6 lists are 24 bytes: 8-byte loads keep every list aligned)
 #pragma unroll
-    for (int i = 0; i < LL / 4; ++i) {
-      const float4 v = mine[i];
-      lst[4 * i] = v.x;
-      lst[4 * i + 1] = v.y;
-      lst[4 * i + 2] = v.z;
-      lst[4 * i + 3] = v.w;
+      for (int i = 0; i < LL / 2; ++i) {
+        const float2 v = reinterpret_cast<const float2*>(mine)[i];
+        lst[2 * i] = v.x;
+        lst[2 * i + 1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < LL; ++i) lst[i] = mine[i];
     }
     if (lane >= parts) {
 #pragma unroll
@@ -1104,14 +1293,23 @@ static void allow_lds(Kern* kern, size_t lds) {
 template <int LL, int L>
 static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const uint4* dbh, int n_rows, int row_offset,
                          const float* q, int Q, int K, int nsplit, int code_bits, int32_t* out_idx, double* out_score,
-                         bool first, hipStream_t s) {
+                         bool first, bool pair, hipStream_t s) {
   const int n_tiles = (n_rows + kTileRows - 1) / kTileRows;
   const int parts = 2 * nsplit;
   const int zero = first;
   const int half_mode = ctx->eff_mode == 0;
   const bool probing = ctx->search_mode == 0 && ctx->eff_mode == 2;  // standing in for the f16 scan (search_impl)
   event_begin(ctx, "search_scan", s);
-  if (ctx->eff_mode == 0) {  // f16 MFMA scan (default): one workgroup per CU, 256 queries each
+  if constexpr (LL <= 6) {  // paired f16 MFMA scan (default): one 512-thread workgroup per CU, 256 queries each; `nsplit`
+    // counts VIRTUAL splits here: the kernel takes physical ones (2 virtual splits per workgroup)
+    const dim3 grid((Q + kWideQPerBlock - 1) / kWideQPerBlock * (nsplit / 2));
+    const size_t lds = (size_t)4 * 2 * kHalfTileBytes;
+    static bool once = (allow_lds(&scanp_kernel<LL, 4>, (size_t)4 * 2 * kHalfTileBytes), true);
+    (void)once;
+    hipLaunchKernelGGL((scanp_kernel<LL, 4>), grid, dim3(512), lds, s, dbh, n_rows, n_tiles, code_bits, q, Q, nsplit / 2,
+                       ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
+  } else {
+  if (ctx->eff_mode == 0) {  // f16 MFMA scan, one wave per SIMD (tiny shards, k > 10): 256 queries per workgroup
     const dim3 grid((Q + kWideQPerBlock - 1) / kWideQPerBlock * nsplit);
     const size_t lds = (size_t)4 * kHalfTileBytes;
     static bool once = (allow_lds(&scanh_kernel<LL>, (size_t)4 * kHalfTileBytes), true);
@@ -1132,6 +1330,7 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
     (void)once;
     hipLaunchKernelGGL((scan_kernel<L>), grid, dim3(256), lds, s, db, n_rows, n_tiles, code_bits, q, Q, nsplit,
                        ctx->cand_score, ctx->fb_count, zero);
+  }
   }
   event_end(ctx, "search_scan", s);
   T2L_HIP(ctx, hipGetLastError());
@@ -1215,6 +1414,9 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     const int row0 = seg * kSegmentRows;
     const int rows = min(kSegmentRows, n_rows - row0);
     const int n_tiles = (max(rows, 0) + kTileRows - 1) / kTileRows;
+    // the paired scan (two waves per SIMD, scanp_kernel) serves the f16 mode whenever the shard gives every query at least
+    // 32 per-lane lists (>= 8 physical splits: 256+ rows); its splits below are VIRTUAL ones (two per workgroup)
+    const bool pair_ok = ctx->eff_mode == 0 && ctx->search_pair && L == 16 && n_tiles >= 16;
     int nsplit = ctx->nsplit_override;
     if (nsplit <= 0) {
       // fill 256 CUs with one (wide scan) or two workgroups each; multiples of 8 keep a split on one XCD's L2
@@ -1225,6 +1427,14 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     nsplit = max(1, min(nsplit, kMaxParts / 2));
     nsplit = max(1, min(nsplit, max(1, n_tiles)));
     nsplit = max(nsplit, (n_tiles + kMaxPerTiles - 1) / kMaxPerTiles);  // keep the key code within 13 bits
+    bool pair = pair_ok;
+    if (pair) {  // physical splits = workgroups per query block (<= 16), virtual = twice that
+      int phys = ctx->nsplit_override > 0 ? max(1, ctx->nsplit_override / 2) : min(16, nsplit);
+      phys = max(phys, (n_tiles + 2 * kMaxPerTiles - 1) / (2 * kMaxPerTiles));
+      phys = min(phys, 16);
+      if (2 * phys > n_tiles || 4 * phys < 32) pair = false;
+      else nsplit = 2 * phys;
+    }
     const int per = max(1, (n_tiles + nsplit - 1) / nsplit);
     int code_bits = 4;
     while ((1 << code_bits) < per * 16) ++code_bits;
@@ -1232,7 +1442,7 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     // to the splits, 4-row groups alternate between the lane halves), so 8 per list hold it unless more than 8 of a
     // query's best 16 fall into ONE list — with >= 16 lists a ~1e-8 event on unstructured data; the certificate
     // (floors of full lists) catches it and the fallback re-scores. Few lists (tiny shards): keep 16.
-    const int LL = !wide ? L : (L == 32 ? 32 : (2 * nsplit >= 16 ? 8 : 16));
+    const int LL = !wide ? L : (pair ? ctx->pair_ll : (L == 32 ? 32 : (2 * nsplit >= 16 ? 8 : 16)));
     const size_t need = (size_t)n_qblocks * qpb * 2 * nsplit * LL * sizeof(float);
     if ((rc = grow(ctx, (void**)&ctx->cand_score, &ctx->cand_cap, need)) != T2L_OK) return rc;
     if (n_seg > 1) {
@@ -1244,8 +1454,8 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     const uint4* dbh = ctx->db_half ? ctx->db_half + (size_t)row0 * 32 : nullptr;
     const int off = (int)ctx->row_offset + row0;
 #define T2L_SEARCH(LLv, Lv) \
-  launch_search<LLv, Lv>(ctx, db, dbs, dbh, max(rows, 0), off, q, Q, K, nsplit, code_bits, seg_idx, seg_score, seg == 0, s)
-    rc = LL == 8 ? T2L_SEARCH(8, 16) : (L == 16 ? T2L_SEARCH(16, 16) : T2L_SEARCH(32, 32));
+  launch_search<LLv, Lv>(ctx, db, dbs, dbh, max(rows, 0), off, q, Q, K, nsplit, code_bits, seg_idx, seg_score, seg == 0, pair, s)
+    rc = LL == 5 ? T2L_SEARCH(5, 16) : LL == 6 ? T2L_SEARCH(6, 16) : (LL == 8 ? T2L_SEARCH(8, 16) : (L == 16 ? T2L_SEARCH(16, 16) : T2L_SEARCH(32, 32)));
 #undef T2L_SEARCH
     if (rc != T2L_OK) return rc;
   }

@@ -194,7 +194,7 @@ __device__ __forceinline__ void tilew_steps(const char* tb, const char* tbn, con
 // shift 0 here and are sent to the exact float64 scan by the re-rank, which evaluates the same predicate.
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr int kHalfShiftMax = 100;
-constexpr int kHalfTileBytes = kTileRows * 512;  // 32 rows x 256 f16, unpadded; chunk c of row r sits at chunk c ^ r
+constexpr int kHalfTileBytes = kTileRows * 512;  // 32 rows x 256 f16 = 16 KiB, tile-chunk-major (below)
 
 __device__ __forceinline__ bool half_shift_of(float absmax, int& shift) {  // false = not representable (see above)
   const int e = (int)((__float_as_uint(absmax) >> 23) & 0xffu) - 127;
@@ -215,18 +215,25 @@ __device__ __forceinline__ void mfma_f16_acc(f32x16& acc, const u32x4& a, const 
   asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b_agpr));
 }
 
-struct HalfDma {        // this wave's 4 LDS-DMA instructions of one tile (2 rows = 1 KiB each)
-  const char* src;      // wave-uniform global address of the tile
-  unsigned dst;         // LDS byte address of the wave's first row pair in the target buffer
-  unsigned off[4];      // per-lane global byte offsets: row and the chunk swizzle folded in
-  __device__ __forceinline__ void piece(int i) const { lds_dma_row(dst + i * 1024, off[i], src); }
+// f16 DB plane, TILE-CHUNK-MAJOR: tile t (32 rows) is 16 KiB = [chunk c = 0..31][row r = 0..31][8 f16 = 16 B], chunk c
+// holding k in [8c, 8c+8). The LDS image of a tile IS its global image, so an LDS-DMA piece (1 KiB per wave-instruction)
+// is a straight contiguous copy (chunks 2p, 2p+1 of all 32 rows), and lane (col, half) reads its MFMA A fragment of
+// k-step S — chunk half*16 + S of row col — at  half*8192 + col*16 + S*512: one per-lane base register plus an
+// immediate, the 32 lanes of a half reading 512 contiguous bytes (conflict-free). (The row-major plane of round 1 needed
+// an XOR swizzle against bank conflicts: 16 per-lane LDS offsets + 4 per-lane DMA offsets in registers.)
+struct HalfDma {        // this wave's 4 LDS-DMA instructions of one tile (pieces 4w .. 4w+3, 1 KiB each)
+  const char* src;      // wave-uniform global address of the wave's first piece of the tile
+  unsigned dst;         // LDS byte address of that piece in the target buffer
+  unsigned lane16;      // lane * 16
+  __device__ __forceinline__ void piece(int i) const { lds_dma_row(dst + i * 1024, lane16, src + i * 1024); }
 };
 
 // k-steps [S, S_END) of one f16 tile: per k-step one fragment read (ring of 4, crossing into the next tile's buffer at
 // S >= 12), two MFMAs (one per query group), the insertion of score S of the previous tile into both lists, and at
-// S >= 12 one LDS-DMA piece of the tile NBUF-1 ahead. BUF / NBUFS are compile-time: the buffer base is an immediate.
+// S >= 12 one LDS-DMA piece of the tile NBUF-1 ahead. BUF / NBUFS are compile-time: every LDS offset is an immediate.
+// lb = LDS address of the lane's fragment of chunk-row 0 in buffer 0 (half*8192 + col*16 from the buffers' base).
 template <int LL, int S, int S_END, int BUF, int NBUFS>
-__device__ __forceinline__ void tileh_steps(const char* lds0, const unsigned (&roff)[16], const u32x4 (&q0)[16],
+__device__ __forceinline__ void tileh_steps(const char* lb, const u32x4 (&q0)[16],
                                             const u32x4 (&q1)[16], f32x16& cur0, f32x16& cur1, const f32x16& prev0,
                                             const f32x16& prev1, int vmask, int code0, float pinf, WideLists<LL>& w,
                                             u32x4 (&ring)[4], const HalfDma& dma) {
@@ -237,8 +244,8 @@ __device__ __forceinline__ void tileh_steps(const char* lds0, const unsigned (&r
     const int code = __builtin_amdgcn_readfirstlane(code0 + S);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (S == 0) mfma_f16_first(cur0, a, q0[S]); else mfma_f16_acc(cur0, a, q0[S]);
-    if constexpr (S + 4 < 16) ring[S & 3] = *reinterpret_cast<const u32x4*>(lds0 + roff[S + 4] + BUF * kHalfTileBytes);
-    else ring[S & 3] = *reinterpret_cast<const u32x4*>(lds0 + roff[S + 4 - 16] + NXT * kHalfTileBytes);
+    if constexpr (S + 4 < 16) ring[S & 3] = *reinterpret_cast<const u32x4*>(lb + (S + 4) * 512 + BUF * kHalfTileBytes);
+    else ring[S & 3] = *reinterpret_cast<const u32x4*>(lb + (S + 4 - 16) * 512 + NXT * kHalfTileBytes);
     __builtin_amdgcn_sched_barrier(0);
     wide_sel_ops<LL, S, 0, VPM>(w, prev0, prev1, vmask, code, pinf);
     __builtin_amdgcn_sched_barrier(0);
@@ -247,7 +254,59 @@ __device__ __forceinline__ void tileh_steps(const char* lds0, const unsigned (&r
     __builtin_amdgcn_sched_barrier(0);
     wide_sel_ops<LL, S, VPM, 2 * VPM>(w, prev0, prev1, vmask, code, pinf);
     __builtin_amdgcn_sched_barrier(0);
-    tileh_steps<LL, S + 1, S_END, BUF, NBUFS>(lds0, roff, q0, q1, cur0, cur1, prev0, prev1, vmask, code0, pinf, w, ring, dma);
+    tileh_steps<LL, S + 1, S_END, BUF, NBUFS>(lb, q0, q1, cur0, cur1, prev0, prev1, vmask, code0, pinf, w, ring, dma);
+  }
+}
+
+// ---- the paired scan (scanp_kernel): TWO waves per SIMD. The f16 scan is bound by the wave's own instruction issue (an
+// MFMA costs ~10 issue cycles and every VALU filler beyond 5 per MFMA gap 4 more: tools/mfma_agpr_probe.hip), not by
+// the matrix pipe; a second wave on the same SIMD issues its VALU / LDS / DMA work into exactly those gaps
+// (tools/pair_probe.hip: +20 % MFMA+9-filler throughput per SIMD, +12..21 % at 6-7 fillers). Waves w and w+4 of the
+// 512-thread workgroup hold the SAME 64 queries and take alternate tiles of the workgroup's DB split ("virtual splits"
+// sp and sp + nsplit of 2*nsplit), sharing one LDS ring of NS step-slots x 2 tiles.
+struct PairDma {        // this wave's 4 LDS-DMA pieces of one STEP (2 tiles x pieces 2w, 2w+1)
+  const char* src0;     // wave-uniform global addresses of the wave's first piece in the step's two tiles
+  const char* src1;
+  unsigned dst;         // LDS byte address of the wave's first piece in the slot's first tile buffer
+  unsigned lane16;
+  __device__ __forceinline__ void piece(int e) const {
+    lds_dma_row(dst + (e >> 1) * kHalfTileBytes + (e & 1) * 1024, lane16, ((e >> 1) ? src1 : src0) + (e & 1) * 1024);
+  }
+};
+
+// lb0 / lb1: the lane's fragment address (quad*16384 + half*8192 + col*16 from the ring base) for slots whose offset fits
+// the 16-bit immediate of ds_read (slots 0, 1) and lb0 + 65536 for the others
+typedef const __attribute__((address_space(3))) char* lds_cptr;  // explicit LDS pointer (32-bit): survives an opaque asm
+template <int SLOT, int CHUNK>
+__device__ __forceinline__ u32x4 pair_frag(lds_cptr lb0, lds_cptr lb1) {
+  constexpr int OFF = SLOT * 2 * kHalfTileBytes + CHUNK * 512;
+  typedef const __attribute__((address_space(3))) u32x4* frag_ptr;
+  if constexpr (OFF < 65536) return *reinterpret_cast<frag_ptr>(lb0 + OFF);
+  else return *reinterpret_cast<frag_ptr>(lb1 + (OFF - 65536));
+}
+
+template <int LL, int S, int S_END, int SLOT, int NS>
+__device__ __forceinline__ void tilep_steps(lds_cptr lb0, lds_cptr lb1, const u32x4 (&q0)[16], const u32x4 (&q1)[16],
+                                            f32x16& cur0, f32x16& cur1, const f32x16& prev0, const f32x16& prev1, int vmask,
+                                            int code0, float pinf, WideLists<LL>& w, u32x4 (&ring)[4], const PairDma& dma) {
+  if constexpr (S < S_END) {
+    constexpr int VPM = LL + 1;
+    constexpr int NXT = (SLOT + 1) % NS;
+    const u32x4 a = ring[S & 3];
+    const int code = __builtin_amdgcn_readfirstlane(code0 + S);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S == 0) mfma_f16_first(cur0, a, q0[S]); else mfma_f16_acc(cur0, a, q0[S]);
+    if constexpr (S + 4 < 16) ring[S & 3] = pair_frag<SLOT, S + 4>(lb0, lb1);
+    else ring[S & 3] = pair_frag<NXT, S + 4 - 16>(lb0, lb1);
+    __builtin_amdgcn_sched_barrier(0);
+    wide_sel_ops<LL, S, 0, VPM>(w, prev0, prev1, vmask, code, pinf);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S == 0) mfma_f16_first(cur1, a, q1[S]); else mfma_f16_acc(cur1, a, q1[S]);
+    if constexpr (S >= 12) dma.piece(S - 12);
+    __builtin_amdgcn_sched_barrier(0);
+    wide_sel_ops<LL, S, VPM, 2 * VPM>(w, prev0, prev1, vmask, code, pinf);
+    __builtin_amdgcn_sched_barrier(0);
+    tilep_steps<LL, S + 1, S_END, SLOT, NS>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, code0, pinf, w, ring, dma);
   }
 }
 

@@ -24,7 +24,7 @@ constexpr int kStreamQ = 32;  // queries per scanq launch
 // 16 k-steps of one tile: fragment ring of 4 (within the tile), one MFMA and the insertion of one score of the previous
 // tile per k-step (1 + L VALU, pinned behind the MFMA)
 template <int L, int S>
-__device__ __forceinline__ void tileq_steps(const char* tb, const unsigned (&roff)[16], const u32x4 (&qf)[16], f32x16& cur,
+__device__ __forceinline__ void tileq_steps(const char* tb, const u32x4 (&qf)[16], f32x16& cur,
                                             const f32x16& prev, int vmask, int code0, float pinf, float (&ls)[L],
                                             u32x4 (&ring)[4]) {
   if constexpr (S < 16) {
@@ -32,11 +32,11 @@ __device__ __forceinline__ void tileq_steps(const char* tb, const unsigned (&rof
     const int code = __builtin_amdgcn_readfirstlane(code0 + S);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (S == 0) mfma_f16_first(cur, a, qf[S]); else mfma_f16_acc(cur, a, qf[S]);
-    if constexpr (S + 4 < 16) ring[S & 3] = *reinterpret_cast<const u32x4*>(tb + roff[S + 4]);
+    if constexpr (S + 4 < 16) ring[S & 3] = *reinterpret_cast<const u32x4*>(tb + (S + 4) * 512);
     __builtin_amdgcn_sched_barrier(0);
     ins_key_sat<L>(ls, __int_as_float((__float_as_int(prev[S]) & vmask) | code), pinf);
     __builtin_amdgcn_sched_barrier(0);
-    tileq_steps<L, S + 1>(tb, roff, qf, cur, prev, vmask, code0, pinf, ls, ring);
+    tileq_steps<L, S + 1>(tb, qf, cur, prev, vmask, code0, pinf, ls, ring);
   }
 }
 
@@ -90,17 +90,10 @@ __global__ __launch_bounds__(256, 1) void scanq_kernel(const uint4* __restrict__
 #pragma unroll
   for (int r = 0; r < 16; ++r) accA[r] = accB[r] = T2L_NEG_INF;
 
-  // LDS tile layout as scanh_kernel: unpadded 512-byte rows, 16-byte chunk c of row r at chunk c ^ r. One LDS-DMA
-  // instruction moves two rows; lane l of piece i lands at chunk l & 31 of row 2i + (l >> 5).
-  unsigned doff[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int r = 2 * i + half;
-    doff[i] = r * 512 + ((col ^ r) << 4);
-  }
-  unsigned roff[16];
-#pragma unroll
-  for (int s = 0; s < 16; ++s) roff[s] = col * 512 + ((((half << 4) + s) ^ col) << 4);
+  // LDS tile image == global tile image (tile-chunk-major f16 plane, search_dev.h): 16 contiguous 1 KiB LDS-DMA pieces per
+  // tile; lane (col, half) reads chunk half*16 + S of row col at  half*8192 + col*16 + S*512.
+  const unsigned lane16 = lane * 16;
+  const int frag_off = half * 8192 + col * 16;
 
   // wave (wg, wave) owns tiles  (wg*per + j)*4 + wave,  j = 0 .. per-1  (interleaved so neighbours stream neighbours)
   const int tbase = wg * per * 4 + wave;
@@ -109,17 +102,17 @@ __global__ __launch_bounds__(256, 1) void scanq_kernel(const uint4* __restrict__
     const char* src = reinterpret_cast<const char*>(dbh) + (size_t)t * kHalfTileBytes;
     const unsigned dst = tiles_lds + buf * kHalfTileBytes;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) lds_dma_row(dst + i * 1024, doff[i], src);
+    for (int i = 0; i < 16; ++i) lds_dma_row(dst + i * 1024, lane16, src + i * 1024);
   };
   auto step = [&](int j, int buf, bool more, f32x16& cur, const f32x16& prev) {
     // tile j has landed (its 16 pieces are older than the 16 of tile j+1 that may still be in flight)
     if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const char* tb = tiles + buf * kHalfTileBytes;
+    const char* tb = tiles + buf * kHalfTileBytes + frag_off;
     u32x4 ring[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ring[i] = *reinterpret_cast<const u32x4*>(tb + roff[i]);
-    tileq_steps<L, 0>(tb, roff, qf, cur, prev, vmask, (j - 1) << 4, pinf, ls, ring);
+    for (int i = 0; i < 4; ++i) ring[i] = *reinterpret_cast<const u32x4*>(tb + i * 512);
+    tileq_steps<L, 0>(tb, qf, cur, prev, vmask, (j - 1) << 4, pinf, ls, ring);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all LDS reads of this tile are done: the buffer may refill
   };
   int nj = 0;

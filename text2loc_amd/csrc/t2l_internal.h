@@ -83,6 +83,9 @@ struct t2l_ctx {
   // one in sixteen would be flagged again
   int encoder_f32 = 0;   // 1: the all-f32-MFMA encoder kernel even when the split-f16 one is safe (encode.hip)
   int search_auto = 1;
+  int pair_ll = 6;       // per-lane list length of the paired scan (5 or 6)
+  int search_pair = 1;   // mode 0: 1 = the paired scan (two waves per SIMD, scanp_kernel), 0 = scanh_kernel (one wave per SIMD)
+  int train_keep_adam = 0;  // 1: t2l_train_bind keeps Adam moments + step when the parameter list is unchanged (a re-bind)
   int eff_mode = 0;           // the scan the current t2l_search call runs
   bool escalated = false;     // the split-bf16 scan is standing in (it counts what the f16 band would still flag)
   int32_t* host_stat = nullptr;      // mapped pinned host int32[4]: {sequence number of the last finished call, flagged, Q}

@@ -152,14 +152,15 @@ int train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const 
   if (cfg->num_heads != kTH) return fail(ctx, T2L_EINVAL, "t2l_train_bind: the engine is built for 4 attention heads");
   const int n_feat = (cfg->use_class != 0) + (cfg->use_color != 0) + (cfg->use_position != 0) + (cfg->use_num != 0);
   if (n_feat < 2) return fail(ctx, T2L_EINVAL, "t2l_train_bind: training needs at least two of the class/color/position/num features");
-  // a re-bind (model.to(), an externally assigned .grad, ...) only moves POINTERS: the Adam moments and the bias-
-  // correction step of the previous binding carry over when the parameter list (names and sizes) is unchanged
+  // a re-bind of the SAME model (model.to(), an externally assigned .grad, ...) only moves POINTERS: with option
+  // "train_keep_adam_state" set (the Python seam sets it for exactly that case) the Adam moments and the bias-correction
+  // step of the previous binding carry over when the parameter list (names and sizes) is unchanged
   TrainState* old = state(ctx);
   std::vector<std::string> old_names;
   std::vector<int64_t> old_numel;
   float* old_mv = nullptr;
   int64_t old_step = 0;
-  if (old) {
+  if (old && ctx->train_keep_adam) {
     old_names = old->adam_names;
     for (auto& nme : old_names) old_numel.push_back(old->t[nme].numel);
     old_mv = old->mv;
