@@ -310,3 +310,80 @@ def test_streaming_small_batch_path_vs_oracle(n, q, k):
         assert np.array_equal(idx2.cpu().numpy().astype(np.int64)[:, : r2.shape[1]], r2)
     finally:
         e.close()
+
+
+def _clustered_problem(n, q, spread, seed):
+    """rows = one direction + `spread`-sized perturbations (score gaps far below every scan's error band), queries = rows +
+    a quarter of that spread"""
+    rs = np.random.default_rng(seed)
+    base = synth.unit_rows(rs.standard_normal((1, 256)))
+    db = synth.unit_rows(base + spread * rs.standard_normal((n, 256))).astype(np.float32)
+    tgt = rs.integers(0, n, size=q)
+    qs = synth.unit_rows(db[tgt].astype(np.float64) + 0.25 * spread * rs.standard_normal((q, 256))).astype(np.float32)
+    return db, qs
+
+
+@pytest.mark.parametrize("n,q,k,spread", [(11259, 700, 10, 1e-3), (3000, 130, 5, 1e-4), (40, 33, 10, 1e-3), (5000, 64, 26, 1e-3)])
+def test_float64_mfma_exact_stage_on_clustered_database(n, q, k, spread):
+    """heavy mode (search_exact.hip): queries the certificates cannot settle are ranked by the float64 MFMA scan — ids and
+    scores must still be exactly the float64 ranking."""
+    import torch
+    from oracle import c_oracle
+    from text2loc_amd.engine import Engine
+
+    db, qs = _clustered_problem(n, q, spread, seed=n + q)
+    e = Engine(0)
+    try:
+        e.set_option("search_auto", 0)
+        e.set_option("search_heavy", 1)
+        e.set_option("profile_events", 1)
+        e.db_set(torch.from_numpy(db).cuda(), 3)
+        idx, sc = e.search(torch.from_numpy(qs).cuda(), k)
+        torch.cuda.synchronize()
+        ridx, rsc = c_oracle.retrieve_topk(db, qs, k)
+        assert np.array_equal(idx.cpu().numpy().astype(np.int64), ridx + 3)
+        assert np.abs(sc.cpu().numpy() - rsc).max() < 1e-12
+        assert e.search_fallbacks() > q // 2  # the exact stage really served them
+        assert e.kernel_stats("search_exact")[1] >= 1
+        # exact duplicates: more ties than the stage re-scores -> its certificate fails -> the VALU scan decides, lower row first
+        db2 = np.concatenate([db[:20]] * 3, axis=0)
+        e.db_set(torch.from_numpy(db2).cuda(), 0)
+        idx2, _ = e.search(torch.from_numpy(qs[:9]).cuda(), min(k, 10))
+        r2, _ = c_oracle.retrieve_topk(db2, qs[:9], min(k, 10))
+        assert np.array_equal(idx2.cpu().numpy().astype(np.int64), r2)
+    finally:
+        e.close()
+
+
+def test_auto_mode_moves_a_clustered_database_to_the_exact_stage():
+    """no option set: the report card of earlier calls switches the engine to the float64 MFMA stage, and back on friendly data"""
+    import torch
+    from oracle import c_oracle
+    from text2loc_amd.engine import Engine
+
+    db, qs = _clustered_problem(4000, 512, 1e-3, seed=9)
+    e = Engine(0)
+    try:
+        e.set_option("profile_events", 1)
+        e.db_set(torch.from_numpy(db).cuda())
+        dq = torch.from_numpy(qs).cuda()
+        ridx, _ = c_oracle.retrieve_topk(db, qs, 10)
+        for _ in range(8):
+            idx, _ = e.search(dq, 10)
+            torch.cuda.synchronize()
+            assert np.array_equal(idx.cpu().numpy().astype(np.int64), ridx)
+        assert e.kernel_stats("search_exact")[1] >= 1  # engaged within a few calls
+        db3, qs3, _ = synth.make_retrieval_problem(4000, 512, seed=3, noise=0.5)
+        e.db_set(torch.from_numpy(db3).cuda())
+        r3, _ = c_oracle.retrieve_topk(db3, qs3, 10)
+        for _ in range(8):
+            idx, _ = e.search(torch.from_numpy(qs3).cuda(), 10)
+            torch.cuda.synchronize()
+            assert np.array_equal(idx.cpu().numpy().astype(np.int64), r3)
+        e.kernel_stats("search_exact")
+        for _ in range(3):
+            e.search(torch.from_numpy(qs3).cuda(), 10)
+        torch.cuda.synchronize()
+        assert e.kernel_stats("search_exact")[1] == 0  # released again
+    finally:
+        e.close()

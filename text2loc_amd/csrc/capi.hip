@@ -58,8 +58,8 @@ int t2l_create(t2l_ctx** out, int device_id) {
     return T2L_ENOMEM;
   }
   (void)hipMemset(ctx->db_norm_max, 0, 2 * sizeof(float));
-  if (hipHostMalloc((void**)&ctx->host_stat, 4 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess) {
-    memset(ctx->host_stat, 0, 4 * sizeof(int32_t));
+  if (hipHostMalloc((void**)&ctx->host_stat, 8 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess) {
+    memset(ctx->host_stat, 0, 8 * sizeof(int32_t));
     if (hipHostGetDevicePointer((void**)&ctx->host_stat_dev, ctx->host_stat, 0) != hipSuccess) ctx->host_stat_dev = nullptr;
   }
   (void)hipMemset(ctx->fb_count, 0, 128 * sizeof(int32_t));
@@ -221,7 +221,9 @@ int t2l_search_fallbacks(t2l_ctx* ctx, int32_t* out_count) {
   if (!ctx || !out_count) return T2L_EINVAL;
   T2L_HIP(ctx, hipSetDevice(ctx->device));
   T2L_HIP(ctx, hipDeviceSynchronize());
-  T2L_HIP(ctx, hipMemcpy(out_count, ctx->fb_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+  int32_t c[8];
+  T2L_HIP(ctx, hipMemcpy(c, ctx->fb_count, sizeof(c), hipMemcpyDeviceToHost));
+  *out_count = c[0] + (c[7] - c[6]);  // float64 VALU scans + queries the float64 MFMA stage certified (search_exact.hip)
   return T2L_OK;
 }
 
@@ -332,8 +334,11 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     ctx->search_auto = value != 0;
     if (!ctx->search_auto) {  // forget the state and every report of a search launched so far
       ctx->escalated = false;
+      ctx->heavy = false;
       ctx->stat_seen = ctx->stat_seq;
     }
+  } else if (!strcmp(name, "search_heavy")) {  // force (1) / release (0) the float64 MFMA exact stage (tests)
+    ctx->heavy = value != 0;
   } else if (!strcmp(name, "search_pair_ll")) {
     if (value != 5 && value != 6) return fail(ctx, T2L_EINVAL, "search_pair_ll must be 5 or 6");
     ctx->pair_ll = (int)value;

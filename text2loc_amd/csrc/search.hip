@@ -35,6 +35,20 @@ namespace t2l {
 // latency, so the VALU work below needs two independent chains to hide behind. After every 8th MFMA one
 // score of the PREVIOUS tile is turned into a key and inserted into the lane's list: ~L+4 VALU instructions
 // spread over the gaps (sched_group_barrier pins the interleave).
+// fb_count (dev i32[128]), per t2l_search call: [0] queries that ended in a float64 VALU scan, [1] second-stage re-scores,
+// [2] length of the re-rank's flagged list, [3] f16-probe count (auto mode), [4] queries deferred to the float64 MFMA stage
+// (heavy mode), [5] = [0] + [4] of the PREVIOUS call (reported to the host by the fallback kernel), [6] queries the MFMA
+// stage could not certify, [7] queries it served. The first scan launch of a call (zero_counts) rolls them over.
+__device__ __forceinline__ void reset_counts(int32_t* fb_count, int zero_counts, int tid) {
+  if (tid == 0) {
+    if (zero_counts) {
+      fb_count[5] = fb_count[0] + fb_count[4];
+      fb_count[0] = fb_count[1] = fb_count[4] = fb_count[6] = fb_count[7] = 0;
+    }
+    fb_count[2] = fb_count[3] = 0;
+  }
+}
+
 template <int L, int S = 0>
 __device__ __forceinline__ void tile_mfma(const float* tb, const float (&qa)[128], f32x16& cur0, f32x16& cur1,
                                           const f32x16& prev0, const f32x16& prev1, int prev_row0, int n_rows,
@@ -82,7 +96,7 @@ __global__ __launch_bounds__(256, L <= 16 ? 2 : 1) void scan_kernel(const float*
   const int qrow = qb * kQPerBlock + wave * kQPerWave + col;
   const int qload = min(qrow, Q - 1);
   const int mask = ~((1 << code_bits) - 1);
-  if (blockIdx.x == 0 && tid < 4 && (zero_counts || tid >= 2)) fb_count[tid] = 0;  // [2] = length of this launch's flagged list
+  if (blockIdx.x == 0) reset_counts(fb_count, zero_counts, tid);
 
   // B operand (queries), register resident for the whole scan. The MFMA sums over k in any order as
   // long as A and B agree: lane (col, half) owns k in [128*half, 128*half+128), one contiguous
@@ -219,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void scanw_kernel(const uint4* __restrict__
   const int mask = ~((1 << code_bits) - 1);
   int vmask = mask;
   asm volatile("" : "+v"(vmask));
-  if (blockIdx.x == 0 && tid < 4 && (zero_counts || tid >= 2)) fb_count[tid] = 0;  // [3] = f16-probe count (rerank_kernel)
+  if (blockIdx.x == 0) reset_counts(fb_count, zero_counts, tid);
   if (nt == 0) return;  // (the host never launches an empty split)
   const int uwave = uniform_wave_id();
 
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(256, 1) void scanh_kernel(const uint4* __restrict__
   const int mask = ~((1 << code_bits) - 1);
   int vmask = mask;
   asm volatile("" : "+v"(vmask));
-  if (blockIdx.x == 0 && tid < 4 && (zero_counts || tid >= 2)) fb_count[tid] = 0;  // [3] = f16-probe count (rerank_kernel)
+  if (blockIdx.x == 0) reset_counts(fb_count, zero_counts, tid);
   if (nt == 0) return;  // (the host never launches an empty split)
 
   // ---- LDS-DMA plan: wave w moves pieces 4w .. 4w+3 (1 KiB each, contiguous) of a tile: global image == LDS image
@@ -509,7 +523,7 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
   const int mask = ~((1 << code_bits) - 1);
   int vmask = mask;
   asm volatile("" : "+v"(vmask));
-  if (blockIdx.x == 0 && tid < 4 && (zero_counts || tid >= 2)) fb_count[tid] = 0;  // [3] = f16-probe count (rerank_kernel)
+  if (blockIdx.x == 0) reset_counts(fb_count, zero_counts, tid);
   if (steps == 0) return;  // (the host never launches an empty split)
 #ifdef T2L_STAMPS
 #define T2L_STAMP(k)                                                                                                   \
@@ -917,7 +931,7 @@ __global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__
                                                        const int32_t* __restrict__ flags,
                                                        int32_t* __restrict__ out_idx, double* __restrict__ out_score,
                                                        int32_t* __restrict__ fb_count, int32_t* __restrict__ host_stat,
-                                                       int seq, int probe) {
+                                                       int seq, int probe, int stat_mode, int defer) {
   __shared__ double qs[kD];
   __shared__ double cd[kMaxCand];
   __shared__ int crow[kMaxCand];
@@ -935,7 +949,10 @@ __global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__
   if (host_stat && blockIdx.x == 0 && threadIdx.x == 0) {  // report card for the host (mapped memory, read at a later call)
     host_stat[1] = probe ? fb_count[3] : n_flagged;
     host_stat[2] = Q;
-    __threadfence_system();
+    host_stat[3] = fb_count[5];  // the PREVIOUS call's exact-stage queries (rolled over by this call's scan)
+    host_stat[4] = stat_mode;    // 1: [1] is an f16-certificate count the auto mode may act on
+    // (no system-scope fence before the sequence number: it would stall this kernel for a PCIe round trip, and the host
+    // only steers heuristics with these numbers — a report mixed from two calls is harmless)
     host_stat[0] = seq;
   }
   for (int fi = blockIdx.x; fi < n_flagged; fi += gridDim.x) {
@@ -944,6 +961,13 @@ __global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__
   __syncthreads();
   qs[tid] = (double)q[(size_t)qid * kD + tid];
   if (flag == 2) {  // keys are meaningless (see rerank_kernel): straight to the exact scan
+    if (defer) {    // heavy mode: the float64 VALU scan runs as its own launch (exact_list_kernel) behind the MFMA stage
+      if (tid == 0) {
+        atomicAdd(&fb_count[1], 1);
+        const_cast<int32_t*>(flags)[4 * Q + atomicAdd(&fb_count[6], 1)] = qid;
+      }
+      continue;
+    }
     if (tid == 0) {
       atomicAdd(&fb_count[1], 1);
       atomicAdd(&fb_count[0], 1);
@@ -1016,6 +1040,15 @@ __global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__
       if (tid == 0) atomicAdd(&fb_count[1], 1);
       continue;
     }
+  }
+
+  if (defer) {  // heavy mode (search_impl): this database defeats the certificates wholesale, so re-scoring every kept
+                // candidate (stage 2) would only add 256+ row gathers per query: hand the query to the float64 MFMA stage
+    if (tid == 0) {
+      atomicAdd(&fb_count[1], 1);
+      const_cast<int32_t*>(flags)[3 * Q + atomicAdd(&fb_count[4], 1)] = qid;
+    }
+    continue;
   }
 
   // ---- stage 2: one thread per kept candidate — float64 dot (query broadcast from LDS), then every candidate counts
@@ -1345,11 +1378,14 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
                      ctx->fb_count, probing ? (float)(ctx->eps_scale * ((kD + 8) * 5.9604644775390625e-08 + 9.85e-4)) : 0.f,
                      __builtin_inff());
   T2L_HIP(ctx, hipGetLastError());
+  // (an EMPTY launch of this kernel costs ~4.5 us whatever its grid: measured with 8 and with 128 workgroups)
   hipLaunchKernelGGL(fallback_kernel<LL>, dim3(min(Q, 128)), dim3(256), 0, s, db, n_rows, q, Q, K, parts, code_bits,
                      ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, half_mode, ctx->flags, out_idx, out_score,
-                     ctx->fb_count, (half_mode || probing) ? ctx->host_stat_dev : nullptr, ++ctx->stat_seq, probing ? 1 : 0);
+                     ctx->fb_count, ctx->host_stat_dev, ++ctx->stat_seq, probing ? 1 : 0, (half_mode || probing) ? 1 : 0,
+                     ctx->heavy ? 1 : 0);
   event_end(ctx, "search_rerank", s);
   T2L_HIP(ctx, hipGetLastError());
+  if (ctx->heavy) return exact_stage_impl(ctx, db, n_rows, row_offset, q, Q, K, out_idx, out_score, s);
   return T2L_OK;
 }
 
@@ -1380,14 +1416,23 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
   // the f16 scan's report card of an earlier call on this DB (see t2l_internal.h): more than 1 in 8 queries flagged ->
   // the split-bf16 scan from now on
   // ... and back when fewer than 1 in 16 would be (the stand-in counts them, rerank_kernel)
-  if (ctx->search_mode == 0 && ctx->search_auto && ctx->host_stat) {
+  // ... and its exact-stage count: when more than 1 in 64 queries of a call ended in the float64 scan, the database
+  // defeats the certificates wholesale ("heavy"): later calls defer those queries to the float64 MFMA stage
+  // (search_exact.hip) instead of the fallback kernel's VALU scan, until fewer than 1 in 256 need it
+  if (ctx->host_stat) {
     const volatile int32_t* hs = ctx->host_stat;
     const int done = hs[0];
     if (done > ctx->stat_seen) {
       ctx->stat_seen = done;
-      const int64_t flagged = hs[1], total = hs[2];
-      if (!ctx->escalated && flagged * 8 > total) ctx->escalated = true;
-      else if (ctx->escalated && flagged * 16 < total) ctx->escalated = false;
+      const int64_t flagged = hs[1], total = hs[2], exact_prev = hs[3];
+      if (ctx->search_mode == 0 && ctx->search_auto && hs[4]) {
+        if (!ctx->escalated && flagged * 8 > total) ctx->escalated = true;
+        else if (ctx->escalated && flagged * 16 < total) ctx->escalated = false;
+      }
+      if (ctx->search_auto) {
+        if (!ctx->heavy && exact_prev * 64 > total) ctx->heavy = true;
+        else if (ctx->heavy && exact_prev * 256 < total) ctx->heavy = false;
+      }
     }
   }
   ctx->eff_mode = (ctx->search_mode == 0 && ctx->escalated) ? 2 : ctx->search_mode;
@@ -1402,7 +1447,8 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     return fail(ctx, T2L_EINVAL, "t2l_search: shard too large (more than 256/k segments of 524,288 rows); shard the "
                                  "database over more ranks");
   int rc;
-  if ((rc = grow(ctx, (void**)&ctx->flags, &ctx->flag_cap, (size_t)3 * Q * sizeof(int32_t))) != T2L_OK) return rc;  // flags[Q] + f32 thresholds[Q] + flagged list[Q]
+  // flags[Q] + f32 thresholds[Q] + flagged list[Q] + deferred list[Q] + uncertified list[Q] (search_exact.hip)
+  if ((rc = grow(ctx, (void**)&ctx->flags, &ctx->flag_cap, (size_t)5 * Q * sizeof(int32_t))) != T2L_OK) return rc;
   int32_t* seg_idx = out_idx;
   double* seg_score = out_score;
   if (n_seg > 1) {
@@ -1416,7 +1462,8 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     const int n_tiles = (max(rows, 0) + kTileRows - 1) / kTileRows;
     // the paired scan (two waves per SIMD, scanp_kernel) serves the f16 mode whenever the shard gives every query at least
     // 32 per-lane lists (>= 8 physical splits: 256+ rows); its splits below are VIRTUAL ones (two per workgroup)
-    const bool pair_ok = ctx->eff_mode == 0 && ctx->search_pair && L == 16 && n_tiles >= 16;
+    // (small batches keep the one-wave-per-SIMD kernel: twice the workgroups, and its prologue is the shorter one)
+    const bool pair_ok = ctx->eff_mode == 0 && ctx->search_pair && L == 16 && n_tiles >= 16 && Q >= 256;
     int nsplit = ctx->nsplit_override;
     if (nsplit <= 0) {
       // fill 256 CUs with one (wide scan) or two workgroups each; multiples of 8 keep a split on one XCD's L2

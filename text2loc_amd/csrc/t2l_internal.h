@@ -87,8 +87,9 @@ struct t2l_ctx {
   int search_pair = 1;   // mode 0: 1 = the paired scan (two waves per SIMD, scanp_kernel), 0 = scanh_kernel (one wave per SIMD)
   int train_keep_adam = 0;  // 1: t2l_train_bind keeps Adam moments + step when the parameter list is unchanged (a re-bind)
   int eff_mode = 0;           // the scan the current t2l_search call runs
+  bool heavy = false;         // the database defeats the certificates: flagged queries go to the float64 MFMA stage
   bool escalated = false;     // the split-bf16 scan is standing in (it counts what the f16 band would still flag)
-  int32_t* host_stat = nullptr;      // mapped pinned host int32[4]: {sequence number of the last finished call, flagged, Q}
+  int32_t* host_stat = nullptr;      // mapped pinned host int32[8]: {sequence number of the last finished call, flagged, Q, previous exact-stage count, f16 stat}
   int32_t* host_stat_dev = nullptr;  // its device address
   int stat_seq = 0, stat_seen = 0;
   int stream_min_rows = 65536;  // shards at least this large answer batches of <= 64 queries with the streaming scan
@@ -116,6 +117,9 @@ int db_norm_impl(t2l_ctx* ctx, hipStream_t s);
 int merge_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int parts, int Q, int K, int32_t* out_idx,
                double* out_score, hipStream_t s);
 int search_stream_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s);
+// search_exact.hip
+int exact_stage_impl(t2l_ctx* ctx, const float* db, int n_rows, int row_offset, const float* q, int Q, int K, int32_t* out_idx,
+                     double* out_score, hipStream_t s);
 // encode.hip
 int load_weights_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_model_config* cfg);
 int encode_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float* out, hipStream_t s);
