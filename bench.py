@@ -509,6 +509,28 @@ def secondary_measurements(eng):
                                  "loss_ms": eng.kernel_stats("contrastive_loss")[0],
                                  "steps_per_s": 1.0 / wall, "algorithmic_tflops": fl / wall / 1e12,
                                  "final_loss": float(last)}
+        # BASELINE config 4 names bf16: the same step with option train_bf16 (GEMM operands rounded to bf16, f32 accumulation,
+        # everything else f32) — its time, and how far its embeddings / loss sit from the f32 step on identical inputs
+        try:
+            eng.set_option("train_bf16", 0)
+            pos32 = eng.encode_cells_train(p64, dropout_p=0.0, seed=1).clone()
+            l32 = float(eng.contrastive_loss(anchor, pos32, 0.1)[0])
+            eng.set_option("train_bf16", 1)
+            pos16 = eng.encode_cells_train(p64, dropout_p=0.0, seed=1).clone()
+            l16 = float(eng.contrastive_loss(anchor, pos16, 0.1)[0])
+            for i in range(5):
+                train_step(200 + i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_steps):
+                train_step(300 + i)
+            torch.cuda.synchronize()
+            out["train_step_b64"]["bf16_variant"] = {"ms_per_step_wall": (time.perf_counter() - t0) / n_steps * 1e3,
+                                                     "max_abs_embedding_diff_vs_f32": float((pos16 - pos32).abs().max()),
+                                                     "loss_f32": l32, "loss_bf16": l16}
+            eng.set_option("train_bf16", 0)
+        except Exception as e:
+            out["train_step_b64"]["bf16_variant"] = {"error": repr(e)}
         try:
             out["train_step_b64"]["torch_eager_ms_per_step_same_gpu"] = torch_train_step_ms(sd, cells64, anchor)
         except Exception as e:

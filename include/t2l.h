@@ -272,6 +272,13 @@ int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step,
  *     are identical; only the speed differs.
  * "search_auto"       (default 1): mode 0 only — when more than 1 in 8 queries of a batch fail the f16 certificate (scores
  *     packed tighter than its error band) later searches use the split-bf16 scan until fewer than 1 in 16 would.
+ * "train_bf16"        (default 0): 1 = the GEMMs of t2l_encode_cells_train / t2l_encode_cells_backward round their operands to
+ *     bf16 (RNE) and run on the bf16 MFMA with f32 accumulation; parameters, activations, BatchNorm / LayerNorm / softmax,
+ *     the loss and Adam stay f32 (what torch.autocast(bfloat16) keeps in f32 too). BASELINE config 4's "bf16".
+ * "search_pair"       (default 1): mode 0 only — 1 = the paired scan (two waves per SIMD), 0 = one wave per SIMD.
+ * "search_heavy"      (set by the engine, see search_auto): 1 = queries no certificate settles go to the float64 MFMA exact
+ *     stage instead of the fallback kernel's float64 VALU scan. With search_auto = 0 the caller may force it.
+ * "train_keep_adam_state" (default 0): see t2l_adam_state.
  * "stream_min_rows"   (default 65536): batches of <= 64 queries against a shard of at least this many rows use the
  *     HBM-streaming scan (every CU streams a disjoint DB slice once) instead of the batched scan.
  * "search_nsplit"     (default 0 = auto): DB row splits per query block in the scan kernel.

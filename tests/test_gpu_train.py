@@ -231,3 +231,44 @@ def test_error_paths(eng):
     with pytest.raises(T2LError, match="at least two"):
         e.train_bind(tens, class_embed=True, color_embed=True, use_features=("position",))
     e.close()
+
+
+@pytest.mark.parametrize("mode", ["embed", "pn"])
+def test_bf16_variant_tracks_the_reference_run(golden, mode):
+    """BASELINE config 4's "bf16": option train_bf16 rounds the GEMM operands to bf16 (f32 accumulation, everything else f32).
+    Against the reference's f32 train-step goldens the tolerances are bf16's: 2^-8 relative per operand, i.e. ~1e-2 on the
+    unit-norm embeddings' elements after the stack of layers, ~1e-2 relative on the loss, and gradient tensors that agree
+    in direction (cosine) and norm to a few percent."""
+    from text2loc_amd.engine import Engine
+
+    g = golden(f"train_step_{mode}")
+    cells, sd, embed = load_case(g, mode)
+    e = Engine(0)
+    try:
+        e.set_option("train_bf16", 1)
+        tensors = bind(e, sd, embed)
+        dcells = to_dev(cells, embed)
+        positive = e.encode_cells_train(dcells, dropout_p=0.0, seed=0)
+        err = np.abs(positive.cpu().numpy() - g["positive"]).max()
+        assert 1e-6 < err < 2e-2, err  # really bf16 (not the f32 path), and within bf16's reach
+        anchor = torch.from_numpy(g["anchor"]).cuda()
+        loss, ga, gp = e.contrastive_loss(anchor, positive, float(g["temperature"]))
+        assert abs(float(loss) - float(g["loss"])) < 2e-2 * abs(float(g["loss"]))
+        e.encode_cells_backward(gp)
+        torch.cuda.synchronize()
+        worst_cos, n_checked = 1.0, 0
+        for n in [str(x) for x in g["used_params"]]:
+            exp, got = golden_view(g, "grad", n, tensors[n][1].cpu().numpy())
+            ref_norm = float(g[f"grad_norm/{n}"])
+            if ref_norm < 1e-4 or got.shape != exp.shape or tensors[n][1].numel() < 4096:
+                continue  # zero-gradient tensors (Linear biases in front of BatchNorm), sampled views, and the small tensors
+                          # whose true gradient is a cancellation residue ([64,1] / [64,3] Linears in front of a BatchNorm)
+            cos = float((got * exp).sum() / (np.linalg.norm(got) * np.linalg.norm(exp) + 1e-30))
+            worst_cos = min(worst_cos, cos)
+            n_checked += 1
+            assert abs(float(np.linalg.norm(tensors[n][1].cpu().numpy())) - ref_norm) < 0.1 * ref_norm, n
+        assert n_checked >= 10 and worst_cos > 0.98, (n_checked, worst_cos)
+        e.adam_step(float(g["lr"]))
+        torch.cuda.synchronize()
+    finally:
+        e.close()

@@ -256,3 +256,19 @@ def test_run_fine_hint_encoding_pads_per_pose_like_the_reference():
     assert (joint - per_pose).abs().max() > 1e-4  # the pad length is part of the reference's result
     with pytest.raises(T2LError, match="same number of sentences"):
         enc(["One sentence.", "Two sentences. Here."])
+
+
+@pytest.mark.parametrize("name", ["pairwise", "hardest"])
+def test_other_ranking_losses_match_the_reference(golden, name):
+    """training/losses.py:178-253 (value + autograd gradients from the imported reference, oracle/gen_golden_losses.py)"""
+    from text2loc_amd.losses import HardestRankingLoss, PairwiseRankingLoss
+
+    g = golden("loss_ranking")
+    crit = {"pairwise": PairwiseRankingLoss, "hardest": HardestRankingLoss}[name](margin=float(g["margin"]))
+    a = torch.tensor(g["im"], requires_grad=True)
+    b = torch.tensor(g["s"], requires_grad=True)
+    loss = crit(a, b)
+    loss.backward()
+    assert abs(float(loss) - float(g[name + "_loss"])) < 1e-5 * max(1.0, abs(float(g[name + "_loss"])))
+    assert np.abs(a.grad.numpy() - g[name + "_grad_im"]).max() < 1e-6
+    assert np.abs(b.grad.numpy() - g[name + "_grad_s"]).max() < 1e-6

@@ -33,13 +33,17 @@ def train_epoch(model, dataloader, args, optimizer, criterion):
     """training/coarse.py:31-58 with the optimizer and criterion passed in (the reference reads them from module
     globals): text branch on PyTorch autograd, object branch forward/backward in the engine, both meeting in the
     contrastive loss kernel. Returns (mean loss, []) like the reference."""
+    if getattr(args, "ranking_loss", "contrastive") == "triplet":
+        # the reference's own triplet branch cannot run (it calls encode_objects with one argument, training/coarse.py:49,
+        # and eval_epoch asserts it away, :65); there is nothing to mirror
+        raise NotImplementedError("ranking_loss='triplet' is not runnable in the reference either (training/coarse.py:47-50)")
     model.train()
     losses = []
     for batch in dataloader:
         optimizer.zero_grad()
         anchor = model.encode_text(batch["texts"])
         positive = model.encode_objects(batch["objects"], batch["object_points"])
-        loss = criterion(anchor, positive)  # "contrastive" ranking loss (training/args.py default)
+        loss = criterion(anchor, positive)  # contrastive (fused kernel) | pairwise | hardest (text2loc_amd.losses)
         loss.backward()
         optimizer.step()
         losses.append(loss.detach())

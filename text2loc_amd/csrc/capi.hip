@@ -344,6 +344,8 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     ctx->pair_ll = (int)value;
   } else if (!strcmp(name, "search_pair")) {
     ctx->search_pair = value != 0;
+  } else if (!strcmp(name, "train_bf16")) {
+    ctx->train_bf16 = value != 0;
   } else if (!strcmp(name, "train_keep_adam_state")) {
     ctx->train_keep_adam = value != 0;
   } else if (!strcmp(name, "stream_min_rows")) {

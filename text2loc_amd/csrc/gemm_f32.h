@@ -27,7 +27,16 @@ struct GemmArgs {
   const float* bias;
   int M, N, K, lda, ldb, ldc, relu, accumulate, kchunk;
   float* colsum;  // !A_KC only: colsum[m] += sum_k A(m,k)  (bias gradient of the same dY), or nullptr
+  int bf16;       // 1: operands rounded to bf16 (RNE) on the fly, ONE v_mfma_f32_32x32x16_bf16 per 16-step instead of eight
+                  // v_mfma_f32_32x32x2_f32 — the "bf16" training variant of BASELINE config 4 (f32 accumulation, f32 master
+                  // weights, f32 everything else)
 };
+
+typedef __bf16 gemm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float gemm_f32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ gemm_bf16x8 gemm_to_bf16(const float (&v)[8]) {
+  return __builtin_convertvector(gemm_f32x8{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}, gemm_bf16x8);  // v_cvt_pk_bf16_f32
+}
 
 template <bool KC>
 __device__ __forceinline__ void gemm_load(const float* __restrict__ P, int ld, int row, bool row_ok, int k0, int kh, int kend,
@@ -77,10 +86,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int d = 0; d < kRing; ++d) {
       if (k0 + 16 * d < wk1) {
+        if (g.bf16) {  // (workgroup-uniform) lane (i, kh) holds k0 + 8*kh + j, j = 0..7: exactly the 32x32x16 operand layout
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gemm_to_bf16(a[d]), gemm_to_bf16(b[d]), acc, 0, 0, 0);
+          if (do_colsum) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][j], b[d][j], acc, 0, 0, 0);
-          if (do_colsum) csum += a[d][j];
+            for (int j = 0; j < 8; ++j) csum += a[d][j];  // the bias gradient stays an f32 sum
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][j], b[d][j], acc, 0, 0, 0);
+            if (do_colsum) csum += a[d][j];
+          }
         }
         if (k0 + 16 * (d + kRing) < wk1) {  // refill this slot with the step one ring ahead
           gemm_load<A_KC>(g.A, g.lda, m0 + i, a_ok, k0 + 16 * (d + kRing), kh, wk1, a[d]);

@@ -102,14 +102,15 @@ static T* bump(TrainState* st, size_t count) {
 }
 
 // ---- GEMM launchers -----------------------------------------------------------------------------------------
+static thread_local int tl_gemm_bf16 = 0;  // set from the context option "train_bf16" at the top of every forward / backward
 // Y[M,N] = X[M,K] W[N,K]^T + b (relu)
 static void gemm_nt(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int relu, hipStream_t s) {
-  GemmArgs g{X, W, Y, b, M, N, K, K, K, N, relu, 0, K, nullptr};
+  GemmArgs g{X, W, Y, b, M, N, K, K, K, N, relu, 0, K, nullptr, tl_gemm_bf16};
   hipLaunchKernelGGL((gemm_kernel<true, true>), dim3(N / 32, (M + 31) / 32, 1), dim3(256), 0, s, g);
 }
 // dX[M,Kp] (+)= dY[M,N] W[N,Kp]
 static void gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kp, int accumulate, hipStream_t s) {
-  GemmArgs g{dY, W, dX, nullptr, M, Kp, N, N, Kp, Kp, 0, accumulate, N, nullptr};
+  GemmArgs g{dY, W, dX, nullptr, M, Kp, N, N, Kp, Kp, 0, accumulate, N, nullptr, tl_gemm_bf16};
   hipLaunchKernelGGL((gemm_kernel<true, false>), dim3(Kp / 32, (M + 31) / 32, 1), dim3(256), 0, s, g);
 }
 // dW[N,Kp] += dY[M,N]^T X[M,Kp]   (reduction over the M rows, split over grid.z, float atomics);  db[N] += column sums of dY
@@ -118,7 +119,7 @@ static void gemm_tn(const float* dY, const float* X, float* dW, float* db, int M
   int ksplit = std::max(1, std::min((M + 255) / 256, (1024 + tiles - 1) / tiles));  // >= 64 rows per wave, ~1k workgroups
   int kchunk = (((M + ksplit - 1) / ksplit) + 63) & ~63;
   ksplit = (M + kchunk - 1) / kchunk;
-  GemmArgs g{dY, X, dW, nullptr, N, Kp, M, N, Kp, Kp, 0, 1, kchunk, db};
+  GemmArgs g{dY, X, dW, nullptr, N, Kp, M, N, Kp, Kp, 0, 1, kchunk, db, tl_gemm_bf16};
   hipLaunchKernelGGL((gemm_kernel<false, false>), dim3(Kp / 32, N / 32, ksplit), dim3(256), 0, s, g);
 }
 static int need(t2l_ctx* ctx, TrainState* st, const std::string& name, int64_t numel, bool with_grad, TTensor** out) {
@@ -298,7 +299,7 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
   if ((uint64_t)T * 2 * kTD >= (1ull << 32)) return fail(ctx, T2L_EINVAL, "t2l_encode_cells_train: batch too large for the dropout counters");
   // workspace: generous closed-form bound, grown on demand
   const size_t need_bytes =
-      sizeof(float) * ((size_t)M * (2 * Kc + 20 * kTD) + (size_t)T * kTD * 16 +
+      sizeof(float) * ((size_t)M * (2 * Kc + 26 * kTD) + (size_t)T * kTD * 18 +
                        (size_t)c.num_layers * ((size_t)T * (13 * kTD + 8) + (size_t)B * kTH * kTS * kTS) + (size_t)B * kTD * 4) +
       (1 << 20);
   if (need_bytes > st->ws_cap) {
@@ -308,6 +309,7 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
     T2L_HIP(ctx, hipMalloc(&st->ws, need_bytes));
     st->ws_cap = need_bytes;
   }
+  tl_gemm_bf16 = ctx->train_bf16;
   st->ws_off = 0;
   st->have_forward = false;
   st->M = M; st->B = B; st->T = T;
@@ -439,6 +441,7 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   if (!st || !st->have_forward) return fail(ctx, T2L_ESTATE, "t2l_encode_cells_backward: no forward pass to differentiate");
   if (!grad_emb) return fail(ctx, T2L_EINVAL, "t2l_encode_cells_backward: null gradient");
   const int M = st->M, B = st->B, T = st->T, Kc = st->n_feat * kTD;
+  tl_gemm_bf16 = ctx->train_bf16;
   const size_t mark = st->ws_off;
   event_begin(ctx, "train_backward", s);
   st->bn_slot = 0;
@@ -447,13 +450,18 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   float* dA = bump<float>(st, (size_t)T * kTD);
   float* dB = bump<float>(st, (size_t)T * kTD);
   float* dC = bump<float>(st, (size_t)T * kTD);
+  float* dB2 = bump<float>(st, (size_t)T * kTD);
   float* dO = bump<float>(st, (size_t)T * kTD);
   float* dH = bump<float>(st, (size_t)T * 2 * kTD);
   float* dqkv = bump<float>(st, (size_t)T * 3 * kTD);
   float* dfeat = bump<float>(st, (size_t)M * kTD);
   float* dcat = bump<float>(st, (size_t)M * Kc);
-  float* d2 = bump<float>(st, (size_t)M * kTD);
-  float* d1 = bump<float>(st, (size_t)M * 64);
+  float* d2s[4];
+  float* d1s[4];
+  for (int i = 0; i < 4; ++i) {  // one scratch pair per feature branch: the branches run side by side
+    d2s[i] = bump<float>(st, (size_t)M * kTD);
+    d1s[i] = bump<float>(st, (size_t)M * 64);
+  }
   if (st->ws_off > st->ws_cap) {
     st->ws_off = mark;
     return fail(ctx, T2L_ENOMEM, "t2l_encode_cells_backward: workspace bound exceeded (internal error)");
@@ -481,10 +489,10 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
     gemm_nn(dH, W(".linear1.weight").data, dA, T, 2 * kTD, kTD, 1, s);
     // norm1 + dropout1
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_grid), dim3(256), 0, s, dA, L.xhat1, L.rstd1, T, W(".norm1.weight").data,
-                       make_drop(st->seed, l * 4 + 1, st->p), dC, dB, W(".norm1.weight").grad, W(".norm1.bias").grad);
+                       make_drop(st->seed, l * 4 + 1, st->p), dC, dB2, W(".norm1.weight").grad, W(".norm1.bias").grad);
     // out_proj
-    gemm_tn(dB, L.O, W(".self_attn.out_proj.weight").grad, W(".self_attn.out_proj.bias").grad, T, kTD, kTD, s);
-    gemm_nn(dB, W(".self_attn.out_proj.weight").data, dO, T, kTD, kTD, 0, s);
+    gemm_tn(dB2, L.O, W(".self_attn.out_proj.weight").grad, W(".self_attn.out_proj.bias").grad, T, kTD, kTD, s);
+    gemm_nn(dB2, W(".self_attn.out_proj.weight").data, dO, T, kTD, kTD, 0, s);
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * kTH), dim3(256), 0, s, L.qkv, L.P, dO, dqkv, make_drop(st->seed, l * 4 + 0, st->p));
     // in_proj; dC (= dz1, the residual path) += dqkv Win
     gemm_tn(dqkv, L.x_in, W(".self_attn.in_proj_weight").grad, W(".self_attn.in_proj_bias").grad, T, 3 * kTD, kTD, s);
@@ -495,6 +503,8 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   hipLaunchKernelGGL(scatter_norm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dcur, st->X0, st->save_nf, st->offsets, B, M, dfeat);
   mlp_layer_bwd(st, st->merge, dfeat, st->cat, M, 0, 0, dcat, s);
   for (const Branch& br : st->branches) {
+    float* d2 = d2s[br.slot & 3];
+    float* d1 = d1s[br.slot & 3];
     const float* dslot = dcat + br.slot * kTD;
     const float* yslot = st->cat + br.slot * kTD;
     hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dslot, yslot, Kc, br.save_n, M, d2);

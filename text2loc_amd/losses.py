@@ -42,3 +42,46 @@ class ContrastiveLoss(torch.nn.Module):
 
     def forward(self, im, s):
         return _ContrastiveFn.apply(im, s, float(self.temperature))
+
+
+def _cosine_scores(im, s):
+    im = im / torch.norm(im, dim=1, keepdim=True)
+    s = s / torch.norm(s, dim=1, keepdim=True)
+    return im @ s.t()
+
+
+class PairwiseRankingLoss(torch.nn.Module):
+    """--ranking_loss pairwise (training/losses.py:178-216, the reference's args default): sum of all in-batch hinge
+    violations in both directions, divided by the batch size. Host-side bookkeeping on the [B,B] cosine matrix (2 MFLOP):
+    plain torch ops on whatever device the embeddings live on; gradients reach the object branch through the engine's
+    backward like any other loss on ``encode_objects``' output."""
+
+    def __init__(self, margin: float = 1.0):
+        super().__init__()
+        self.margin = margin
+
+    def forward(self, im, s):
+        scores = _cosine_scores(im, s)
+        diag = scores.diag()
+        off = ~torch.eye(len(im), dtype=torch.bool, device=scores.device)
+        cost_s = torch.clamp(self.margin - diag[:, None] + scores, min=0) * off   # vs the other cells of each text
+        cost_im = torch.clamp(self.margin - diag[None, :] + scores, min=0) * off  # vs the other texts of each cell
+        return (cost_s.sum() + cost_im.sum()) / len(im)
+
+
+class HardestRankingLoss(torch.nn.Module):
+    """--ranking_loss hardest, the definition in force (the module's SECOND HardestRankingLoss, training/losses.py:286-355,
+    shadows the first): the pairwise hinge costs, but only the largest violation of every row counts, times ``scale``."""
+
+    def __init__(self, margin: float = 1.0, scale: float = 64.0):
+        super().__init__()
+        self.margin = margin
+        self.scale = scale
+
+    def forward(self, images, captions):
+        scores = _cosine_scores(images, captions)
+        diag = scores.diag()
+        off = ~torch.eye(len(images), dtype=torch.bool, device=scores.device)
+        cost_s = torch.clamp(self.margin - diag[None, :] + scores, min=0) * off   # [i][j]: text j's own cell vs cell i
+        cost_im = torch.clamp(self.margin - diag[:, None] + scores, min=0) * off  # [i][j]: cell i's own text vs text j
+        return (cost_im.max(dim=1)[0].mean() + cost_s.max(dim=1)[0].mean()) * self.scale
