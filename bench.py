@@ -602,10 +602,14 @@ def main():
         ranks_seen = int(t_seen.item())
 
     N_CELLS, N_QUERIES = args.cells, args.queries
-    # hipEvents bracket scan launches INSIDE the timed region; every bracket costs queue time (two records around one
-    # kernel drain the launch pipeline: ~4 us beside a ~50 us step), so long runs bracket every n-th launch — but never
-    # fewer than 16 of them: at the driver's --steps 20 every launch is bracketed
-    EVENT_EVERY = max(1, args.steps // 16)
+    # Kernel durations are taken INSIDE the timed region two ways:
+    #  * HIP events on sampled launches (hipExtLaunchKernelGGL start / stop events on the launch stream). Any event pair
+    #    costs the stream ~6 us per sampled kernel (measured: marker packets and dispatch-attached events alike), so they
+    #    are sampled every 4th launch or sparser — at the driver's --steps 20 that is 5 scan launches;
+    #  * the paired scan's own span stamps (s_memrealtime, first workgroup start -> last workgroup end) on EVERY launch,
+    #    at no cost to the stream: >= 16 samples whatever --steps is. `roofline` is computed from the HIP events and
+    #    carries the stamp average beside it (the two agree to ~1 us: the events include the dispatch's start-up).
+    EVENT_EVERY = max(4, args.steps // 16)
     # N_BATCH distinct query batches, rotated step by step (the DB stays resident; a real evaluation never repeats a batch)
     N_BATCH = 4
     db, qs, target = synth.make_retrieval_problem(N_CELLS, N_QUERIES, DIM, seed=1, noise=0.5)
@@ -627,8 +631,8 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    eng.kernel_stats("search_scan")
-    eng.kernel_stats("search_rerank")
+    for nme in ("search_scan", "search_rerank", "search_scan_span"):
+        eng.kernel_stats(nme)
     eng.set_option("profile_events", EVENT_EVERY)  # restart the sampling phase: the first timed step is a bracketed one
     if dist:
         dist.barrier()
@@ -646,9 +650,11 @@ def main():
         elapsed = float(t.item())
     scan_ms, scan_n = eng.kernel_stats("search_scan")
     rerank_ms, _ = eng.kernel_stats("search_rerank")
+    span_ms, span_n = eng.kernel_stats("search_scan_span")
     eng.set_option("profile_events", 1)  # the side measurements below bracket every launch
     fallbacks = eng.search_fallbacks()
     rescored = eng.search_rescored()
+    counters = eng.search_counters()
 
     # parity, outside the timed region: EVERY (id, score) of every rotated batch vs the float64 C oracle (all Q x K pairs)
     parity, max_score_err, recall1, n_checked = True, 0.0, [], 0
@@ -713,7 +719,7 @@ def main():
         elif args.mode == 2:
             kname, peak, dtype, mult = "scanw_kernel<8, 4>", BF16_MFMA_PEAK_TFLOPS, "bf16x3", 3
         else:
-            kname, peak, dtype, mult = "scanh_kernel<8>", BF16_MFMA_PEAK_TFLOPS, "f16", 1
+            kname, peak, dtype, mult = "scanp_kernel<6, 4>", BF16_MFMA_PEAK_TFLOPS, "f16", 1
         out = {
             "metric": "coarse-retrieval queries/sec over 11k-cell DB, embed_dim=256; top-1/3/5 recall parity",
             "value": N_QUERIES * args.steps / elapsed,
@@ -737,14 +743,19 @@ def main():
                          "executed": achieved * mult, "frac_executed": achieved * mult / peak,
                          "traffic": pmc_traffic("t2l::" + kname), "traffic_source": PMC_SOURCE,
                          "kernel_ms": scan_ms, "launches_timed": scan_n,
-                         "flops_per_launch": flops},
-            "kernels_ms": {"search_scan": scan_ms, "search_rerank+exact": rerank_ms},
+                         "kernel_ms_in_kernel_span": span_ms, "launches_timed_in_kernel_span": span_n,
+                         "flops_per_launch": flops,
+                         # what the matrix pipe sustains on dense RANDOM f16 operands (power-limited clocks): measured by
+                         # tools/pair_probe.hip on this part, bare v_mfma_f32_32x32x16_f16 stream, 1.45-1.53 PFLOP/s
+                         "measured_random_data_mfma_ceiling_tflops": 1500.0,
+                         "frac_of_measured_ceiling": achieved * mult / 1500.0},
+            "kernels_ms": {"search_scan": scan_ms, "search_rerank": rerank_ms},  # the whole step is these two launches
             "secondary": secondary,
             "parity": {"ids_equal_float64_oracle": parity, "pairs_checked": n_checked,
                        "checked": f"all {N_QUERIES} x {TOPK} (id, score) pairs of {len(recall1)} query batch(es) vs the C oracle",
                        "max_abs_score_err": max_score_err, "recall_at_1_planted": recall1,
                        "exact_fallback_queries_last_step": fallbacks,
-                       "second_stage_rescored_queries_last_step": rescored},
+                       "first_certificate_failures_last_step": rescored, "counters_last_step": counters},
             "ranks_seen": ranks_seen, "query_batches_rotated": N_BATCH,
         }
         if alt is not None:

@@ -182,6 +182,11 @@ int t2l_search_fallbacks(t2l_ctx* ctx, int32_t* out_count);
 /* Number of queries of the LAST t2l_search whose first certificate failed and whose kept candidates were all re-scored in
  * float64 (second stage; the exact-scan count above is a subset of these). Synchronises. */
 int t2l_search_rescored(t2l_ctx* ctx, int32_t* out_count);
+/* All counters of the last t2l_search call (synchronises): out8[0] queries that ended in a float64 VALU scan of the shard,
+ * [1] queries re-scored beyond the first L candidates (in the re-rank wave or by the fallback kernel), [2] queries the
+ * re-rank handed to the fallback kernel, [3] auto-mode probe count, [4] queries deferred to the float64 MFMA stage (heavy
+ * mode), [5] = [0] + [4] of the previous call, [6] queries the MFMA stage could not certify, [7] queries it served. */
+int t2l_search_counters(t2l_ctx* ctx, int32_t* out8);
 
 /* ---- contrastive loss (a8) ------------------------------------------------------------------- */
 /* Replaces: ContrastiveLoss.forward (training/losses.py:269-283) and its autograd backward.
@@ -295,7 +300,9 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value);
  * (no synchronisation while recording; enabled by option "profile_events" >= 1, off by default).
  * Returns the average duration (ms) and the number of launches recorded since the previous call for
  * name = "search_scan" | "search_rerank" | "encode_cells" | "contrastive_loss" | "reduce_objects" | "train_forward" |
- * "train_backward" | "adam_step" | "pointnet" | "fine_objects" | "fine_match" (at most the last 512),
+ * "train_backward" | "adam_step" | "pointnet" | "fine_objects" | "fine_match" | "search_fallback" | "search_exact" (at most
+ * the last 512); "search_scan_span" needs no option: the paired scan stamps every launch itself (100 MHz clock, first
+ * workgroup start -> last workgroup end, the last 256 launches),
  * then clears the record. Synchronises on the recorded events. */
 int t2l_kernel_stats(t2l_ctx* ctx, const char* name, float* out_avg_ms, int32_t* out_count);
 

@@ -171,12 +171,15 @@ def test_auto_mode_leaves_the_f16_scan_on_packed_scores_and_returns(eng):
     assert np.array_equal(idx, ridx) and np.abs(sc - rsc).max() < 1e-12
     first = eng.search_rescored()
     assert first > len(q) // 8
-    idx, sc = _search(eng, packed, q, 10)  # the stand-in scan: its certificate holds
-    assert np.array_equal(idx, ridx) and np.abs(sc - rsc).max() < 1e-12
+    # the report card of a call is published by the NEXT call's re-rank (no extra launch, no synchronisation), so the
+    # stand-in scan takes over from the third call on: its certificate holds
+    for _ in range(2):
+        idx, sc = _search(eng, packed, q, 10)
+        assert np.array_equal(idx, ridx) and np.abs(sc - rsc).max() < 1e-12
     assert eng.search_rescored() < first
     db, qs, _ = synth.make_retrieval_problem(3000, 64, seed=31, noise=2.0)
     r2, _ = O.retrieve_topk(db, qs, 10)
-    for _ in range(3):  # ordinary data: one stand-in call reports "f16 would certify", the next ones are f16 again
+    for _ in range(4):  # ordinary data: the stand-in calls report "f16 would certify", the next ones are f16 again
         idx, _ = _search(eng, db, qs, 10)
         assert np.array_equal(idx, r2)
     assert eng.search_fallbacks() == 0

@@ -26,6 +26,28 @@ void event_begin(t2l_ctx* ctx, const char* name, hipStream_t s) {
   if (e.open) (void)hipEventRecord(e.a[e.head], s);
 }
 
+// The cheap form for a SINGLE kernel: hand the pair to hipExtLaunchKernelGGL, which stamps the dispatch itself (start / end
+// of the kernel from its completion signal) instead of putting two marker packets around it on the stream — markers break
+// back-to-back dispatch (~3.5 us each beside a 50 us step). Returns false when this launch is not a sampled one.
+bool event_pair(t2l_ctx* ctx, const char* name, hipEvent_t* a, hipEvent_t* b) {
+  if (!ctx->profile_events) return false;
+  EventRing& e = ctx->events[name];
+  if (e.a.empty()) {
+    e.a.resize(kEventRing);
+    e.b.resize(kEventRing);
+    for (int i = 0; i < kEventRing; ++i) {
+      (void)hipEventCreate(&e.a[i]);
+      (void)hipEventCreate(&e.b[i]);
+    }
+  }
+  if ((e.calls++ % ctx->profile_events) != 0) return false;
+  *a = e.a[e.head];
+  *b = e.b[e.head];
+  e.head = (e.head + 1) % kEventRing;
+  if (e.count < kEventRing) ++e.count;
+  return true;
+}
+
 void event_end(t2l_ctx* ctx, const char* name, hipStream_t s) {
   if (!ctx->profile_events) return;
   EventRing& e = ctx->events[name];
@@ -63,6 +85,10 @@ int t2l_create(t2l_ctx** out, int device_id) {
     if (hipHostGetDevicePointer((void**)&ctx->host_stat_dev, ctx->host_stat, 0) != hipSuccess) ctx->host_stat_dev = nullptr;
   }
   (void)hipMemset(ctx->fb_count, 0, 128 * sizeof(int32_t));
+  if (hipMalloc(&ctx->scan_span, sizeof(unsigned long long) * 2 * kSpanRing) == hipSuccess)
+    (void)hipMemset(ctx->scan_span, 0, sizeof(unsigned long long) * 2 * kSpanRing);
+  else
+    ctx->scan_span = nullptr;
   *out = ctx;
   return T2L_OK;
 }
@@ -76,7 +102,7 @@ void t2l_destroy(t2l_ctx* ctx) {
   free_pointnet(ctx);
   free_fine(ctx);
   for (void* p : {(void*)ctx->db, (void*)ctx->db_split, (void*)ctx->db_half, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
-                  (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count, ctx->reduce_ws})
+                  (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count, ctx->reduce_ws, (void*)ctx->scan_span})
     if (p) (void)hipFree(p);
   if (ctx->host_stat) (void)hipHostFree(ctx->host_stat);
   for (auto& kv : ctx->events) {
@@ -230,12 +256,20 @@ int t2l_search_fallbacks(t2l_ctx* ctx, int32_t* out_count) {
 #ifdef T2L_STAMPS
 int t2l_debug_stamps(t2l_ctx* ctx, long long* out8) {  // dev builds only: s_memrealtime stamps a kernel left in fb_count[16..]
   T2L_HIP(ctx, hipDeviceSynchronize());
-  T2L_HIP(ctx, hipMemcpy(out8, ctx->fb_count + 16, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+  T2L_HIP(ctx, hipMemcpy(out8, ctx->fb_count + 16, 16 * sizeof(long long), hipMemcpyDeviceToHost));
   const long long init[8] = {0, 0, 0, 0, LLONG_MAX, 0, LLONG_MAX, 0};  // re-arm the min / max slots
   T2L_HIP(ctx, hipMemcpy(ctx->fb_count + 16, init, sizeof(init), hipMemcpyHostToDevice));
   return T2L_OK;
 }
 #endif
+
+int t2l_search_counters(t2l_ctx* ctx, int32_t* out8) {
+  if (!ctx || !out8) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  T2L_HIP(ctx, hipDeviceSynchronize());
+  T2L_HIP(ctx, hipMemcpy(out8, ctx->fb_count, 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return T2L_OK;
+}
 
 int t2l_search_rescored(t2l_ctx* ctx, int32_t* out_count) {
   if (!ctx || !out_count) return T2L_EINVAL;
@@ -366,6 +400,26 @@ int t2l_kernel_stats(t2l_ctx* ctx, const char* name, float* out_avg_ms, int32_t*
   if (!ctx || !name || !out_avg_ms || !out_count) return T2L_EINVAL;
   *out_avg_ms = 0.f;
   *out_count = 0;
+  if (!strcmp(name, "search_scan_span")) {  // in-kernel stamps of the paired scan: first workgroup start -> last workgroup end
+    if (!ctx->scan_span || ctx->span_seq == ctx->span_read) return T2L_OK;
+    T2L_HIP(ctx, hipDeviceSynchronize());
+    std::vector<unsigned long long> h(2 * kSpanRing);
+    T2L_HIP(ctx, hipMemcpy(h.data(), ctx->scan_span, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    const unsigned first = ctx->span_seq - ctx->span_read > (unsigned)kSpanRing ? ctx->span_seq - kSpanRing + 1 : ctx->span_read + 1;
+    double sum = 0.0;
+    int n = 0;
+    const unsigned long long tmask = (1ull << 40) - 1;
+    for (unsigned q = first; q <= ctx->span_seq; ++q) {
+      const unsigned long long a = h[2 * (q % kSpanRing)], b = h[2 * (q % kSpanRing) + 1];
+      if ((a >> 40) != (q & 0xFFFFFFu) || (b >> 40) != (q & 0xFFFFFFu)) continue;  // slot overwritten or launch not finished
+      sum += (double)(((b & tmask) - (a & tmask)) & tmask) * 1e-5;  // 100 MHz ticks -> ms
+      ++n;
+    }
+    ctx->span_read = ctx->span_seq;
+    if (n) *out_avg_ms = (float)(sum / n);
+    *out_count = n;
+    return T2L_OK;
+  }
   auto it = ctx->events.find(name);
   if (it == ctx->events.end() || it->second.count == 0) return T2L_OK;
   EventRing& e = it->second;

@@ -14,8 +14,11 @@
 //                    row asc) and CERTIFIES: every row that was not re-scored has key <= g, so
 //                    s64_K > g + key-truncation + f32-rounding bound  ==> the top-K equals the float64
 //                    ranking exactly.
-//   fallback_kernel  only for queries whose certificate failed: (stage 2) re-score ALL kept candidates in
-//                    float64 and certify against the lists' floors; (stage 3) float64 scan of the shard.
+//                    A failed certificate is usually repaired inside the wave (the lists are still in registers: re-score
+//                    the few keys that can still reach the top-K); what is left — about one query in a million on
+//                    unit-Gaussian data — gets the exact float64 ranking from the re-rank's own workgroup (wg_exact_scan).
+//                    No third launch: an empty fallback kernel cost ~5 us of every ~55 us step in round 1.
+//   (heavy mode)     databases that defeat the certificates wholesale: search_exact.hip (float64 MFMA stage).
 //
 // HBM layout: DB f32[n_pad,256] row-major (n_pad = n rounded up to 32, tail rows zero and masked by
 // row >= n); queries f32[Q,256]; candidate keys f32 [Q][nsplit][2][L].
@@ -35,17 +38,20 @@ namespace t2l {
 // latency, so the VALU work below needs two independent chains to hide behind. After every 8th MFMA one
 // score of the PREVIOUS tile is turned into a key and inserted into the lane's list: ~L+4 VALU instructions
 // spread over the gaps (sched_group_barrier pins the interleave).
-// fb_count (dev i32[128]), per t2l_search call: [0] queries that ended in a float64 VALU scan, [1] second-stage re-scores,
-// [2] length of the re-rank's flagged list, [3] f16-probe count (auto mode), [4] queries deferred to the float64 MFMA stage
-// (heavy mode), [5] = [0] + [4] of the PREVIOUS call (reported to the host by the fallback kernel), [6] queries the MFMA
-// stage could not certify, [7] queries it served. The first scan launch of a call (zero_counts) rolls them over.
+// fb_count (dev i32[128]), per t2l_search call: [0] queries that ended in an exact float64 VALU scan, [1] queries re-scored
+// beyond the first L candidates, [2] queries the first certificate + in-wave re-score left unsettled, [3] f16-probe count
+// (auto mode), [4] queries deferred to the float64 MFMA stage (heavy mode), [6] queries the MFMA stage could not certify,
+// [7] queries it served, [9] Q and [10] stat mode of the call (rerank_kernel). The first scan launch of a call
+// (zero_counts) copies the finished call's [0..15] to [64..79] — rerank_kernel publishes that copy to the host's report
+// card — and clears the counters.
 __device__ __forceinline__ void reset_counts(int32_t* fb_count, int zero_counts, int tid) {
-  if (tid == 0) {
-    if (zero_counts) {
-      fb_count[5] = fb_count[0] + fb_count[4];
-      fb_count[0] = fb_count[1] = fb_count[4] = fb_count[6] = fb_count[7] = 0;
-    }
-    fb_count[2] = fb_count[3] = 0;
+  if (zero_counts && tid < 16) {
+    fb_count[64 + tid] = fb_count[tid];
+    fb_count[tid] = 0;
+  }
+  if (!zero_counts && tid == 0) {  // a later segment of a multi-segment shard: the deferred lists are per segment
+    fb_count[12] += fb_count[4];
+    fb_count[4] = fb_count[6] = 0;
   }
 }
 
@@ -507,7 +513,8 @@ template <int LL, int NS>
 __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__ dbt, int n_rows, int n_tiles, int code_bits,
                                                        const float* __restrict__ q, int Q, int nsplit,
                                                        float* __restrict__ cand, int32_t* __restrict__ fb_count,
-                                                       int zero_counts, float pinf) {
+                                                       int zero_counts, float pinf, unsigned long long* __restrict__ span,
+                                                       unsigned span_seq) {
   static_assert(NS == 4, "the step loop below is unrolled for a ring of 4 slots");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kSlotBytes = 2 * kHalfTileBytes;
@@ -525,6 +532,11 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
   asm volatile("" : "+v"(vmask));
   if (blockIdx.x == 0) reset_counts(fb_count, zero_counts, tid);
   if (steps == 0) return;  // (the host never launches an empty split)
+  // always-on span stamps (t2l_kernel_stats "search_scan_span"): workgroup 0 stores the launch's start, every workgroup's
+  // end goes through ONE atomic max — (launch sequence << 40 | 100 MHz ticks), so a newer launch overrides the slot's old
+  // content without anybody clearing it. Costs no packet on the stream, unlike an event pair around the kernel.
+  if (span && blockIdx.x == 0 && threadIdx.x == 0)
+    span[0] = ((unsigned long long)span_seq << 40) | ((unsigned long long)__builtin_amdgcn_s_memrealtime() & ((1ull << 40) - 1));
 #ifdef T2L_STAMPS
 #define T2L_STAMP(k)                                                                                                   \
   if (tid == 0) {                                                                                                      \
@@ -535,8 +547,10 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
     if (k == 3) atomicMin(reinterpret_cast<unsigned long long*>(fb_count + 16) + 6, (unsigned long long)t_);           \
     if (k == 3) atomicMax(reinterpret_cast<unsigned long long*>(fb_count + 16) + 7, (unsigned long long)t_);           \
   }
+#define T2L_STAMP2(k) if (tid == 0 && blockIdx.x == 37) reinterpret_cast<long long*>(fb_count + 32)[k] = __builtin_amdgcn_s_memrealtime()
 #else
 #define T2L_STAMP(k)
+#define T2L_STAMP2(k)
 #endif
   T2L_STAMP(0);
 
@@ -577,6 +591,12 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
       const float4* qp = reinterpret_cast<const float4*>(q + (size_t)qrow * kD + qt * 64);
 #pragma unroll
       for (int i = 0; i < 16; ++i) v[g][i] = qp[i];
+#ifdef T2L_EXP_HALFLOAD  // dev experiment: is the prologue bound by the bytes or by the round trip?
+      if (g == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[1][i] = v[0][i];
+      }
+#endif
     }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -586,6 +606,7 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
         m = fmaxf(fmaxf(m, fabsf(v[g][i].x)), fabsf(v[g][i].y));
         m = fmaxf(fmaxf(m, fabsf(v[g][i].z)), fabsf(v[g][i].w));
       }
+      if (g == 0) { T2L_STAMP2(0); } else { T2L_STAMP2(3); }
       m = fmaxf(m, dpp_f<kDppXor1>(m));  // the row's 4 quarters sit in 4 adjacent lanes
       m = fmaxf(m, dpp_f<kDppXor2>(m));
       int shift;
@@ -599,11 +620,13 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
                   pack_f16x2(b.z, b.w, shift)};
       }
       __syncthreads();
+      if (g == 0) { T2L_STAMP2(1); } else { T2L_STAMP2(4); }
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         const u32x4 f = *reinterpret_cast<const u32x4*>(ex_r + ((((half << 4) + s) ^ col) << 4));
         if (g == 0) q0[s] = pin_agpr(f); else q1[s] = pin_agpr(f);
       }
+      if (g == 0) { T2L_STAMP2(2); } else { T2L_STAMP2(5); }
     }
     __syncthreads();  // the exchange area is free: it is slots 2.. of the tile ring from here on
   }
@@ -674,7 +697,107 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
 #pragma unroll
     for (int i = 0; i < LL; ++i) out[i] = w.ls1[i];
   }
+  if (span && threadIdx.x == 0)
+    atomicMax(span + 1, ((unsigned long long)span_seq << 40) | ((unsigned long long)__builtin_amdgcn_s_memrealtime() & ((1ull << 40) - 1)));
   T2L_STAMP(3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The exact float64 ranking of ONE query by the re-rank's own workgroup (4 waves) — what a query gets when neither the
+// certificate nor the in-wave re-score settles it (about 1 query in 800,000 on unit-Gaussian data; when it becomes common,
+// search_impl's report card moves the database to the float64 MFMA stage, search_exact.hip). Lean on purpose: it lives
+// inside rerank_kernel (no separate launch: an empty launch costs ~5 us of a ~50 us step), so it must fit the re-rank's
+// register budget. Wave w takes row groups w, w+4, ... of 4 rows (one per 16-lane row of the wave, the re-rank's re-score
+// layout and arithmetic); the wave's top-32 is a list spread over lanes (lane i = i-th best, ordered by score desc, row asc);
+// the 4 lists meet in LDS and the first wave ranks the 128 entries.
+// ------------------------------------------------------------------------------------------------
+struct WgExactShared {
+  double score[4][32];
+  int row[4][32];
+};
+
+__device__ __forceinline__ void wg_exact_scan(const float* __restrict__ db, int n_rows, const float* __restrict__ qrow, int K,
+                                              int row_offset, int32_t* __restrict__ out_idx, double* __restrict__ out_score,
+                                              WgExactShared& sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int seg = lane & 15, grp = lane >> 4;
+  double qd[16];
+  {
+    const float4* qp = reinterpret_cast<const float4*>(qrow) + seg;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = qp[16 * i];
+      qd[4 * i] = (double)v.x;
+      qd[4 * i + 1] = (double)v.y;
+      qd[4 * i + 2] = (double)v.z;
+      qd[4 * i + 3] = (double)v.w;
+    }
+  }
+  double my_s = -__builtin_inf();  // lane i (< 32): the i-th best (score, row) this wave has seen
+  int my_r = INT_MAX;
+  const int n_groups = (n_rows + 3) / 4;
+  for (int g = wave; g < n_groups; g += 4) {
+    const int row = 4 * g + grp;
+    const float4* rp = reinterpret_cast<const float4*>(db + (size_t)min(row, n_rows - 1) * kD) + seg;
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 rv = rp[16 * i];
+      d0 += (double)rv.x * qd[4 * i];
+      d1 += (double)rv.y * qd[4 * i + 1];
+      d0 += (double)rv.z * qd[4 * i + 2];
+      d1 += (double)rv.w * qd[4 * i + 3];
+    }
+    const double d = row16_sum_f64(d0 + d1);  // every lane of 16-lane row `grp` holds the score of DB row `row`
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // the 4 candidates of this pass, one after the other (rows ascend with c)
+      const double cd = __shfl(d, 16 * c);
+      const int cr = 4 * g + c;
+      if (cr >= n_rows) break;  // wave-uniform
+      // position = how many list entries stay ahead of (cd, cr); nothing to do when all 32 do
+      const unsigned long long ahead = __ballot(lane < 32 && (my_s > cd || (my_s == cd && my_r < cr)));
+      const int pos = __popcll(ahead);
+      if (pos >= 32) continue;
+      const double up_s = __shfl_up(my_s, 1);
+      const int up_r = __shfl_up(my_r, 1);
+      if (lane == pos) {
+        my_s = cd;
+        my_r = cr;
+      } else if (lane > pos && lane < 32) {
+        my_s = up_s;
+        my_r = up_r;
+      }
+    }
+  }
+  if (lane < 32) {
+    sh.score[wave][lane] = my_s;
+    sh.row[wave][lane] = my_r;
+  }
+  __syncthreads();
+  if (wave == 0) {  // 128 entries, two per lane: rank by (score desc, row asc), the first K go out
+    const double s0 = (&sh.score[0][0])[lane], s1 = (&sh.score[0][0])[64 + lane];
+    const int r0 = (&sh.row[0][0])[lane], r1 = (&sh.row[0][0])[64 + lane];
+    int k0 = 0, k1 = 0;
+    for (int o = 0; o < 128; ++o) {
+      const double os = (&sh.score[0][0])[o];
+      const int orow = (&sh.row[0][0])[o];
+      k0 += (os > s0 || (os == s0 && orow < r0)) ? 1 : 0;
+      k1 += (os > s1 || (os == s1 && orow < r1)) ? 1 : 0;
+    }
+    if (lane < K) {
+      out_idx[lane] = -1;
+      if (out_score) out_score[lane] = -__builtin_inf();
+    }
+    if (r0 != INT_MAX && k0 < K) {
+      out_idx[k0] = r0 + row_offset;
+      if (out_score) out_score[k0] = s0;
+    }
+    if (r1 != INT_MAX && k1 < K) {
+      out_idx[k1] = r1 + row_offset;
+      if (out_score) out_score[k1] = s1;
+    }
+  }
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -688,10 +811,28 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
                                                      const float* __restrict__ db_norm_max, int half_mode,
                                                      int32_t* __restrict__ out_idx, double* __restrict__ out_score,
                                                      int32_t* __restrict__ flags, int32_t* __restrict__ fb_count,
-                                                     float eps_rel_probe, float pinf) {
+                                                     float eps_rel_probe, float pinf, int n_rows, int defer, int stat_mode,
+                                                     int32_t* __restrict__ host_stat, int seq) {
+  __shared__ WgExactShared exact_sh;
+  __shared__ int wg_flag[4];
   const int lane = threadIdx.x & 63;
   const int qid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (qid >= Q) return;
+  if (threadIdx.x < 4) wg_flag[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // the report card of the PREVIOUS call (its counters were parked at [64..] by this call's scan): mapped host memory the
+    // host reads at a later call — no stream operation, no fence (it only steers heuristics)
+    if (host_stat && seq > 0) {
+      host_stat[1] = fb_count[64 + 10] == 2 ? fb_count[64 + 3] : fb_count[64 + 2];  // f16-certificate failures (or the probe's)
+      host_stat[2] = fb_count[64 + 9];
+      host_stat[3] = fb_count[64 + 0] + fb_count[64 + 4] + fb_count[64 + 12];  // exact-stage queries
+      host_stat[4] = fb_count[64 + 10] != 0;
+      host_stat[0] = seq;
+    }
+    fb_count[9] = Q;
+    fb_count[10] = stat_mode;  // 0: not an f16-certificate count, 1: f16 scan, 2: split-bf16 stand-in probing for it
+  }
+  __syncthreads();
+  if (qid < Q) {
 
   // ---- every lane pulls its whole sorted key list into registers (one memory latency for the merge)
   float lst[LL];
@@ -734,24 +875,26 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
     }
   }
 
-  // ---- merge the `parts` lists into the top-L keys: L rounds of wave arg-max over the list heads
+  // ---- merge the `parts` lists into the top-L keys: L rounds of wave arg-max over the list heads. Round r leaves (key, part)
+  // in lane r; the row is decoded from them ONCE after the loop (it was 12 instructions inside every round), and the loop is
+  // unrolled so that popping the winner's head is 6 selects with no register copies behind them.
   float my_key = T2L_NEG_INF;
-  int my_row = INT_MAX;
-#pragma unroll 1
+  int my_part = 0;
+#pragma unroll
   for (int r = 0; r < L; ++r) {
     const float bk = wave_max_f32(lst[0], pinf);
     const unsigned long long who = __ballot(lst[0] == bk);
     const int bl = __ffsll((long long)who) - 1;  // equal keys: lowest part first
     if (lane == r) {
       my_key = bk;
-      my_row = bk == T2L_NEG_INF ? INT_MAX : key_row(bk, bl, parts >> 1, code_bits);
+      my_part = bl;
     }
-    if (lane == bl) {  // the winner pops its head (register shift, no memory)
+    const bool pop = lane == bl;  // the winner pops its head (register shift, no memory)
 #pragma unroll
-      for (int i = 0; i < LL - 1; ++i) lst[i] = lst[i + 1];
-      lst[LL - 1] = T2L_NEG_INF;
-    }
+    for (int i = 0; i < LL - 1; ++i) lst[i] = pop ? lst[i + 1] : lst[i];
+    lst[LL - 1] = pop ? T2L_NEG_INF : lst[LL - 1];
   }
+  int my_row = (lane < L && my_key != T2L_NEG_INF) ? key_row(my_key, my_part, parts >> 1, code_bits) : INT_MAX;
   // every row that is NOT re-scored has key <= g: kept rows lie at or below the L-th merged key, rows dropped inside a
   // lane at or below that lane's floor (with LL == L a floor above the L-th key cannot happen; with LL < L it can)
   const float g = fmaxf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_key), L - 1)), floor_max);
@@ -902,7 +1045,6 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
         out_idx[(size_t)qid * K + rank2] = my_row + row_offset;
         if (out_score) out_score[(size_t)qid * K + rank2] = my_d;
       }
-      if (lane == 0) atomicAdd(&fb_count[1], 1);  // counted with the second-stage queries
       settled = true;
     }
   }
@@ -910,237 +1052,24 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
   if (lane == 0) {
     const int flag = !representable ? 2 : ((certified || settled) ? 0 : 1);
     flags[qid] = flag;
-    reinterpret_cast<float*>(flags + Q)[qid] = thr;
-    if (flag) flags[2 * Q + atomicAdd(&fb_count[2], 1)] = qid;  // the fallback kernel walks this list
+    if (!certified || !representable) atomicAdd(&fb_count[1], 1);  // first certificate failed (settled in the wave or not)
+    if (flag) {
+      atomicAdd(&fb_count[2], 1);
+      if (!defer) wg_flag[threadIdx.x >> 6] = flag;  // settled below, by this workgroup
+      else if (flag == 2) flags[4 * Q + atomicAdd(&fb_count[6], 1)] = qid;  // heavy mode: -> exact_list_kernel
+      else flags[3 * Q + atomicAdd(&fb_count[4], 1)] = qid;                  //             -> exactd_kernel
+    }
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// fallback: one workgroup per flagged query.
-//   stage 2: float64 re-score of ALL kept candidates; rows that were dropped inside a lane have key <= that
-//            list's floor (its L-th key), so the certificate is against the largest floor.
-//   stage 3: exact float64 scan of the whole shard.
-// ------------------------------------------------------------------------------------------------
-constexpr int kMaxCand = kMaxParts * 32;  // parts * L upper bound
-
-template <int L>
-__global__ __launch_bounds__(256) void fallback_kernel(const float* __restrict__ db, int n_rows,
-                                                       const float* __restrict__ q, int Q, int K, int parts,
-                                                       int code_bits, const float* __restrict__ cand, int row_offset,
-                                                       float eps_rel, const float* __restrict__ db_norm_max, int half_mode,
-                                                       const int32_t* __restrict__ flags,
-                                                       int32_t* __restrict__ out_idx, double* __restrict__ out_score,
-                                                       int32_t* __restrict__ fb_count, int32_t* __restrict__ host_stat,
-                                                       int seq, int probe, int stat_mode, int defer) {
-  __shared__ double qs[kD];
-  __shared__ double cd[kMaxCand];
-  __shared__ int crow[kMaxCand];
-  __shared__ double red_s[256];
-  __shared__ int red_i[256];
-  __shared__ int red_t[256];
-  __shared__ float floor_max;
-  __shared__ double stat_dk;
-  __shared__ int stat_found;
-  constexpr int kMaxSel = 96;
-  __shared__ int n_sel, sel_bad;
-  __shared__ int sel_c[kMaxSel];
-  const int tid = threadIdx.x;
-  const int n_flagged = fb_count[2];  // queries the re-rank could not certify (usually none or a handful)
-  if (host_stat && blockIdx.x == 0 && threadIdx.x == 0) {  // report card for the host (mapped memory, read at a later call)
-    host_stat[1] = probe ? fb_count[3] : n_flagged;
-    host_stat[2] = Q;
-    host_stat[3] = fb_count[5];  // the PREVIOUS call's exact-stage queries (rolled over by this call's scan)
-    host_stat[4] = stat_mode;    // 1: [1] is an f16-certificate count the auto mode may act on
-    // (no system-scope fence before the sequence number: it would stall this kernel for a PCIe round trip, and the host
-    // only steers heuristics with these numbers — a report mixed from two calls is harmless)
-    host_stat[0] = seq;
-  }
-  for (int fi = blockIdx.x; fi < n_flagged; fi += gridDim.x) {
-  const int qid = flags[2 * Q + fi];
-  const int flag = flags[qid];
+  }  // qid < Q
+  // ---- unsettled queries of this workgroup: the exact float64 ranking, all 4 waves on one query at a time
   __syncthreads();
-  qs[tid] = (double)q[(size_t)qid * kD + tid];
-  if (flag == 2) {  // keys are meaningless (see rerank_kernel): straight to the exact scan
-    if (defer) {    // heavy mode: the float64 VALU scan runs as its own launch (exact_list_kernel) behind the MFMA stage
-      if (tid == 0) {
-        atomicAdd(&fb_count[1], 1);
-        const_cast<int32_t*>(flags)[4 * Q + atomicAdd(&fb_count[6], 1)] = qid;
-      }
-      continue;
-    }
-    if (tid == 0) {
-      atomicAdd(&fb_count[1], 1);
-      atomicAdd(&fb_count[0], 1);
-    }
-    __syncthreads();
-    exact_scan<32>(db, n_rows, qs, K, row_offset, out_idx + (size_t)qid * K,
-                   out_score ? out_score + (size_t)qid * K : nullptr, red_s, red_i, red_t);
-    continue;
-  }
-
-  // ---- stage 2a: only the kept candidates whose key can still reach the top-K (key >= the threshold the re-rank left;
-  // typically a few more than the L it re-scored). Valid when no list's floor reaches the threshold (dropped rows are below
-  // it too) — then the result is exact by construction. One wave per selected row, coalesced 1 KiB gathers.
-  {
-    const int total_a = parts * L;
-    const float* keys = cand + (size_t)qid * total_a;
-    const float thr = reinterpret_cast<const float*>(flags + Q)[qid];
-    if (tid == 0) {
-      n_sel = 0;
-      sel_bad = 0;
-    }
-    __syncthreads();
-    for (int c = tid; c < total_a; c += 256) {
-      const float key = keys[c];
-      if (key != T2L_NEG_INF && key >= thr) {
-        const int i = atomicAdd(&n_sel, 1);
-        if (i < kMaxSel) sel_c[i] = c;
-      }
-      if ((c % L) == L - 1 && key != T2L_NEG_INF && key >= thr) sel_bad = 1;  // a full list's floor reaches the threshold
-    }
-    __syncthreads();
-    const int ns = n_sel;
-    if (thr != T2L_NEG_INF && !sel_bad && ns >= K && ns <= kMaxSel) {  // block-uniform
-      const int lane = tid & 63, wave = tid >> 6;
-      const float4 qv = reinterpret_cast<const float4*>(q + (size_t)qid * kD)[lane];
-      for (int i0 = wave * 8; i0 < ns; i0 += 32) {  // 8 row gathers in flight per wave
-        float4 rows[8];
-        int rid[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int c = sel_c[min(i0 + e, ns - 1)];
-          rid[e] = key_row(keys[c], c / L, parts >> 1, code_bits);
-          rows[e] = reinterpret_cast<const float4*>(db + (size_t)rid[e] * kD)[lane];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const double d = wave_sum_f64((double)rows[e].x * qv.x + (double)rows[e].y * qv.y + (double)rows[e].z * qv.z +
-                                        (double)rows[e].w * qv.w);
-          if (lane == 0 && i0 + e < ns) {
-            cd[i0 + e] = d;
-            crow[i0 + e] = rid[e];
-          }
-        }
-      }
-      __syncthreads();
-      if (tid < ns) {
-        const double d = cd[tid];
-        const int row = crow[tid];
-        int rank = 0;
-        for (int o = 0; o < ns; ++o) {
-          const double od = cd[o];
-          const int orow = crow[o];
-          rank += (od > d || (od == d && orow < row)) ? 1 : 0;
-        }
-        if (rank < K) {
-          out_idx[(size_t)qid * K + rank] = row + row_offset;
-          if (out_score) out_score[(size_t)qid * K + rank] = d;
-        }
-      }
-      if (tid == 0) atomicAdd(&fb_count[1], 1);
-      continue;
-    }
-  }
-
-  if (defer) {  // heavy mode (search_impl): this database defeats the certificates wholesale, so re-scoring every kept
-                // candidate (stage 2) would only add 256+ row gathers per query: hand the query to the float64 MFMA stage
-    if (tid == 0) {
-      atomicAdd(&fb_count[1], 1);
-      const_cast<int32_t*>(flags)[3 * Q + atomicAdd(&fb_count[4], 1)] = qid;
-    }
-    continue;
-  }
-
-  // ---- stage 2: one thread per kept candidate — float64 dot (query broadcast from LDS), then every candidate counts
-  // the candidates ahead of it by (score desc, row asc): its rank. No sorting rounds, two barriers.
-  const int total = parts * L;
-  const float* mine = cand + (size_t)qid * total;
-  if (tid == 0) {
-    stat_dk = -__builtin_inf();
-    stat_found = 0;
-  }
-  __syncthreads();
-  int my_found = 0;
-  for (int c = tid; c < total; c += 256) {
-    const float key = mine[c];
-    double d = -__builtin_inf();
-    int row = INT_MAX;
-    if (key != T2L_NEG_INF) {
-      row = key_row(key, c / L, parts >> 1, code_bits);
-      const float4* rp = reinterpret_cast<const float4*>(db + (size_t)row * kD);
-      double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-#pragma unroll 4
-      for (int k = 0; k < kD / 4; ++k) {
-        const float4 v = rp[k];
-        d0 += (double)v.x * qs[4 * k];
-        d1 += (double)v.y * qs[4 * k + 1];
-        d2 += (double)v.z * qs[4 * k + 2];
-        d3 += (double)v.w * qs[4 * k + 3];
-      }
-      d = (d0 + d1) + (d2 + d3);
-      ++my_found;
-    }
-    cd[c] = d;
-    crow[c] = row;
-  }
-  if (my_found) atomicAdd(&stat_found, my_found);
-  if (tid < 64) {  // largest floor of a full list (wave 0)
-    float f = T2L_NEG_INF;
-    for (int p = tid; p < parts; p += 64) f = fmaxf(f, mine[p * L + L - 1]);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) f = fmaxf(f, __shfl_xor(f, off));
-    if (tid == 0) floor_max = f;
-  }
-  __syncthreads();
-  if (tid < K) {
-    out_idx[(size_t)qid * K + tid] = -1;
-    if (out_score) out_score[(size_t)qid * K + tid] = -__builtin_inf();
-  }
-  __syncthreads();
-  for (int c = tid; c < total; c += 256) {
-    const int row = crow[c];
-    if (row == INT_MAX) continue;
-    const double d = cd[c];
-    int rank = 0;
-    for (int o = 0; o < total; ++o) {
-      const double od = cd[o];
-      const int orow = crow[o];
-      rank += (orow != INT_MAX && (od > d || (od == d && orow < row))) ? 1 : 0;
-    }
-    if (rank < K) {
-      out_idx[(size_t)qid * K + rank] = row + row_offset;
-      if (out_score) out_score[(size_t)qid * K + rank] = d;
-      if (rank == K - 1) stat_dk = d;
-    }
-  }
-  __syncthreads();
-  const double dK = stat_dk;
-  const int found = min(stat_found, K);
-  bool certified = floor_max == T2L_NEG_INF;  // no list is full: nothing was ever dropped
-  if (!certified && found == K) {
-    double qn = 0.0, qm = 0.0;
-    for (int k = 0; k < kD; ++k) {
-      qn += qs[k] * qs[k];
-      qm = fmax(qm, fabs(qs[k]));
-    }
-    double kscale = 1.0;
-    if (half_mode) {
-      int sq, sd;
-      half_shift_of((float)qm, sq);  // (float)qm is exact: qm is one of the query's f32 values
-      half_shift_of(db_norm_max[1], sd);
-      kscale = ldexp(1.0, -(sq + sd));
-    }
-    const double eps32 = (double)eps_rel * sqrt(qn) * (double)(*db_norm_max);
-    certified = dK > (double)floor_max * kscale + key_slack(floor_max, code_bits, eps32, kscale);
-  }
-  if (tid == 0) atomicAdd(&fb_count[1], 1);
-  if (certified) continue;  // block-uniform
-
-  // ---- stage 3
-  if (tid == 0) atomicAdd(&fb_count[0], 1);
-  __syncthreads();
-  exact_scan<32>(db, n_rows, qs, K, row_offset, out_idx + (size_t)qid * K,
-                 out_score ? out_score + (size_t)qid * K : nullptr, red_s, red_i, red_t);
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+    if (!wg_flag[w]) continue;  // workgroup-uniform
+    const int fq = blockIdx.x * 4 + w;
+    if (threadIdx.x == 0) atomicAdd(&fb_count[0], 1);
+    wg_exact_scan(db, n_rows, q + (size_t)fq * kD, K, row_offset, out_idx + (size_t)fq * K,
+                  out_score ? out_score + (size_t)fq * K : nullptr, exact_sh);
   }
 }
 
@@ -1332,16 +1261,23 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
   const int zero = first;
   const int half_mode = ctx->eff_mode == 0;
   const bool probing = ctx->search_mode == 0 && ctx->eff_mode == 2;  // standing in for the f16 scan (search_impl)
-  event_begin(ctx, "search_scan", s);
   if constexpr (LL <= 6) {  // paired f16 MFMA scan (default): one 512-thread workgroup per CU, 256 queries each; `nsplit`
     // counts VIRTUAL splits here: the kernel takes physical ones (2 virtual splits per workgroup)
     const dim3 grid((Q + kWideQPerBlock - 1) / kWideQPerBlock * (nsplit / 2));
     const size_t lds = (size_t)4 * 2 * kHalfTileBytes;
     static bool once = (allow_lds(&scanp_kernel<LL, 4>, (size_t)4 * 2 * kHalfTileBytes), true);
     (void)once;
-    hipLaunchKernelGGL((scanp_kernel<LL, 4>), grid, dim3(512), lds, s, dbh, n_rows, n_tiles, code_bits, q, Q, nsplit / 2,
-                       ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
+    const unsigned span_seq = ++ctx->span_seq;
+    unsigned long long* span = ctx->scan_span ? ctx->scan_span + 2 * (span_seq % kSpanRing) : nullptr;
+    hipEvent_t ea, eb;
+    if (event_pair(ctx, "search_scan", &ea, &eb))  // sampled launch: the dispatch carries its own start / stop events
+      hipExtLaunchKernelGGL((scanp_kernel<LL, 4>), grid, dim3(512), (uint32_t)lds, s, ea, eb, 0u, dbh, n_rows, n_tiles, code_bits,
+                            q, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, zero, __builtin_inff(), span, span_seq);
+    else
+      hipLaunchKernelGGL((scanp_kernel<LL, 4>), grid, dim3(512), lds, s, dbh, n_rows, n_tiles, code_bits, q, Q, nsplit / 2,
+                         ctx->cand_score, ctx->fb_count, zero, __builtin_inff(), span, span_seq);
   } else {
+  event_begin(ctx, "search_scan", s);
   if (ctx->eff_mode == 0) {  // f16 MFMA scan, one wave per SIMD (tiny shards, k > 10): 256 queries per workgroup
     const dim3 grid((Q + kWideQPerBlock - 1) / kWideQPerBlock * nsplit);
     const size_t lds = (size_t)4 * kHalfTileBytes;
@@ -1364,26 +1300,31 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
     hipLaunchKernelGGL((scan_kernel<L>), grid, dim3(256), lds, s, db, n_rows, n_tiles, code_bits, q, Q, nsplit,
                        ctx->cand_score, ctx->fb_count, zero);
   }
-  }
   event_end(ctx, "search_scan", s);
+  }
   T2L_HIP(ctx, hipGetLastError());
   // f32 dot-product error bound: gamma_n * |a||b| with n = 256 terms (+ slack for the MFMA's k order), plus the operand
   // rounding of the scan that produced the keys: f16 (RNE, both operands) 2^-10 + 2^-21 and 2^-20 for denormal
   // elements, rounded up to 9.85e-4; split-bf16 2^-16 + 2^-18, rounded up to 2e-5; f32: none
   const double operand_eps = ctx->eff_mode == 0 ? 9.85e-4 : (ctx->eff_mode == 2 ? 2.0e-5 : 0.0);
   const float eps_rel = (float)(ctx->eps_scale * ((kD + 8) * 5.9604644775390625e-08 + operand_eps));
-  event_begin(ctx, "search_rerank", s);
-  hipLaunchKernelGGL((rerank_kernel<LL, L>), dim3((Q + 3) / 4), dim3(256), 0, s, db, q, Q, K, parts, code_bits,
-                     ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, half_mode, out_idx, out_score, ctx->flags,
-                     ctx->fb_count, probing ? (float)(ctx->eps_scale * ((kD + 8) * 5.9604644775390625e-08 + 9.85e-4)) : 0.f,
-                     __builtin_inff());
-  T2L_HIP(ctx, hipGetLastError());
-  // (an EMPTY launch of this kernel costs ~4.5 us whatever its grid: measured with 8 and with 128 workgroups)
-  hipLaunchKernelGGL(fallback_kernel<LL>, dim3(min(Q, 128)), dim3(256), 0, s, db, n_rows, q, Q, K, parts, code_bits,
-                     ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, half_mode, ctx->flags, out_idx, out_score,
-                     ctx->fb_count, ctx->host_stat_dev, ++ctx->stat_seq, probing ? 1 : 0, (half_mode || probing) ? 1 : 0,
-                     ctx->heavy ? 1 : 0);
-  event_end(ctx, "search_rerank", s);
+  const float eps_probe = probing ? (float)(ctx->eps_scale * ((kD + 8) * 5.9604644775390625e-08 + 9.85e-4)) : 0.f;
+  const int stat_mode = probing ? 2 : (half_mode ? 1 : 0);
+  const int seq = first ? ++ctx->stat_seq : 0;  // the report card goes out once per call
+  const int defer = ctx->heavy ? 1 : 0;
+  // Two launches per search. Queries the certificate and the in-wave re-score leave unsettled are ranked exactly by
+  // their own re-rank workgroup (wg_exact_scan) — there is no separate fallback launch to pay for when, as usual, there
+  // are none. (Heavy mode: they are deferred to the float64 MFMA stage instead, search_exact.hip.)
+  hipEvent_t ea, eb;
+  if (event_pair(ctx, "search_rerank", &ea, &eb))
+    hipExtLaunchKernelGGL((rerank_kernel<LL, L>), dim3((Q + 3) / 4), dim3(256), 0u, s, ea, eb, 0u, db, q, Q, K, parts, code_bits,
+                          (const float*)ctx->cand_score, row_offset, eps_rel, (const float*)ctx->db_norm_max, half_mode, out_idx,
+                          out_score, ctx->flags, ctx->fb_count, eps_probe, __builtin_inff(), n_rows, defer, stat_mode,
+                          ctx->host_stat_dev, seq);
+  else
+    hipLaunchKernelGGL((rerank_kernel<LL, L>), dim3((Q + 3) / 4), dim3(256), 0, s, db, q, Q, K, parts, code_bits,
+                       ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, half_mode, out_idx, out_score, ctx->flags,
+                       ctx->fb_count, eps_probe, __builtin_inff(), n_rows, defer, stat_mode, ctx->host_stat_dev, seq);
   T2L_HIP(ctx, hipGetLastError());
   if (ctx->heavy) return exact_stage_impl(ctx, db, n_rows, row_offset, q, Q, K, out_idx, out_score, s);
   return T2L_OK;

@@ -319,12 +319,15 @@ __device__ __forceinline__ unsigned dpp_u(unsigned v) {
 }
 constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
 
+// one DPP step of a maximum as ONE instruction (v_max_f32 with the DPP modifier on src0; the compiler's form is a
+// v_mov_b32_dpp + a VOP3 max). Inline asm is invisible to the hazard recogniser: the 2 wait states a DPP read needs after
+// the VALU write of its source are spelled out.
+#define T2L_MAX_DPP(v, ctrl) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf" : "+v"(v))
 __device__ __forceinline__ float wave_max_f32(float v, float pinf) {  // every lane gets the maximum
-#define T2L_MAXSTEP(o) v = __builtin_amdgcn_fmed3f(v, (o), pinf)
-  T2L_MAXSTEP(__uint_as_float(dpp_u<kDppXor1>(__float_as_uint(v))));
-  T2L_MAXSTEP(__uint_as_float(dpp_u<kDppXor2>(__float_as_uint(v))));
-  T2L_MAXSTEP(__uint_as_float(dpp_u<kDppHalfMirror>(__float_as_uint(v))));
-  T2L_MAXSTEP(__uint_as_float(dpp_u<kDppMirror>(__float_as_uint(v))));
+  T2L_MAX_DPP(v, "quad_perm:[1,0,3,2]");
+  T2L_MAX_DPP(v, "quad_perm:[2,3,0,1]");
+  T2L_MAX_DPP(v, "row_half_mirror");
+  T2L_MAX_DPP(v, "row_mirror");
   {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = __builtin_amdgcn_fmed3f(__uint_as_float(r[0]), __uint_as_float(r[1]), pinf);
@@ -333,7 +336,6 @@ __device__ __forceinline__ float wave_max_f32(float v, float pinf) {  // every l
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = __builtin_amdgcn_fmed3f(__uint_as_float(r[0]), __uint_as_float(r[1]), pinf);
   }
-#undef T2L_MAXSTEP
   return v;
 }
 

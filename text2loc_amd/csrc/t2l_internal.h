@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of libt2l.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <string>
@@ -28,6 +29,7 @@ constexpr int kMaxParts = 64;                      // per-query candidate partit
 // Per-kernel timing: a ring of hipEvent pairs recorded on the caller's stream (no sync when recording);
 // t2l_kernel_stats() reads them back after the caller's own synchronisation point.
 constexpr int kEventRing = 512;
+constexpr int kSpanRing = 256;  // in-kernel span stamps of the last 256 paired-scan launches (search.hip)
 struct EventRing {
   std::vector<hipEvent_t> a, b;
   int head = 0;   // next slot
@@ -94,6 +96,8 @@ struct t2l_ctx {
   int32_t* host_stat_dev = nullptr;  // its device address
   int stat_seq = 0, stat_seen = 0;
   int stream_min_rows = 65536;  // shards at least this large answer batches of <= 64 queries with the streaming scan
+  unsigned long long* scan_span = nullptr;  // dev u64[kSpanRing][2]: {seq << 40 | start tick, seq << 40 | last end tick}
+  unsigned span_seq = 0, span_read = 0;
   int profile_events = 0;  // 0 off, n >= 1: record every n-th launch of each kernel
   std::unordered_map<std::string, t2l::EventRing> events;
 };
@@ -111,6 +115,7 @@ int fail(t2l_ctx* ctx, int code, const std::string& msg);
 
 void event_begin(t2l_ctx* ctx, const char* name, hipStream_t s);
 void event_end(t2l_ctx* ctx, const char* name, hipStream_t s);
+bool event_pair(t2l_ctx* ctx, const char* name, hipEvent_t* a, hipEvent_t* b);
 
 // search.hip
 int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s);

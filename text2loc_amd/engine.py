@@ -65,6 +65,7 @@ EXPORTS = {
                                   C.c_void_p]),
     "t2l_search_fallbacks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "t2l_search_rescored": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "t2l_search_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "t2l_contrastive_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_fine_load_weights": (C.c_int, [C.c_void_p, C.POINTER(_WeightDesc), C.c_int32, C.POINTER(_ModelConfig)]),
@@ -408,6 +409,14 @@ class Engine:
         c = C.c_int32(0)
         self._check(self.lib.t2l_search_fallbacks(self._h, C.byref(c)))
         return int(c.value)
+
+    def search_counters(self) -> dict:
+        """Counters of the last search (include/t2l.h: t2l_search_counters)."""
+        c = (C.c_int32 * 8)()
+        self._check(self.lib.t2l_search_counters(self._h, c))
+        names = ("valu_exact_scans", "rescored", "to_fallback_kernel", "probe", "deferred_to_mfma_exact", "prev_exact",
+                 "mfma_exact_uncertified", "mfma_exact_served")
+        return {n: int(c[i]) for i, n in enumerate(names)}
 
     def search_rescored(self) -> int:
         """Queries of the last search whose first certificate failed (all kept candidates re-scored in float64)."""

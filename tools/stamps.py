@@ -11,14 +11,18 @@ dq = torch.from_numpy(qs).cuda()
 for a in sys.argv[1:]:
     k, v = a.split("=")
     eng.set_option(k, float(v))
-out = (C.c_longlong * 8)()
+out = (C.c_longlong * 16)()
 eng.lib.t2l_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
 for _ in range(20):
     eng.search(dq, 10)
 for rep in range(3):
-    eng.lib.t2l_debug_stamps(eng._h, out)  # arms the min/max slots
-    eng.search(dq, 10)
-    eng.lib.t2l_debug_stamps(eng._h, out)
+    for _ in range(10):
+        eng.search(dq, 10)  # steady state: back-to-back calls
+    eng.lib.t2l_debug_stamps(eng._h, out)  # arms the min/max slots (synchronises)
+    for _ in range(4):
+        eng.search(dq, 10)
+    eng.lib.t2l_debug_stamps(eng._h, out)  # block 37's stamps are those of the LAST call; min/max span the 4 calls
     t = [out[i] for i in range(4)]
-print("prologue %.2f us, loop %.2f us, epilogue %.2f us (one workgroup, 100 MHz clock)" % ((t[1]-t[0])/100, (t[2]-t[1])/100, (t[3]-t[2])/100))
-print("workgroup starts spread over %.2f us; first start -> first end %.2f us, -> last end %.2f us" % ((out[5]-out[4])/100, (out[6]-out[4])/100, (out[7]-out[4])/100))
+    u = [out[8 + i] for i in range(6)]
+    print("  inside the prologue (us from kernel start): loads0 landed %.2f, exchange0 written+barrier %.2f, frags0 read %.2f, loads1 landed %.2f, barrier1 %.2f, frags1 read %.2f" % tuple((x - t[0]) / 100 for x in u))
+    print("prologue %.2f us, loop %.2f us, epilogue %.2f us (one workgroup of the last of 4 back-to-back calls, 100 MHz clock)" % ((t[1]-t[0])/100, (t[2]-t[1])/100, (t[3]-t[2])/100))
