@@ -29,6 +29,10 @@
 #include "t2l_internal.h"
 #include "mfma_h3.h"
 
+#ifndef T2L_ENC_UNROLL
+#define T2L_ENC_UNROLL 4
+#endif
+
 namespace t2l {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -164,7 +168,7 @@ __device__ __forceinline__ void mm_pair(const float* __restrict__ arow, int qn, 
 // tiles already offset to their first step and to this lane (2 uint4 per lane and step, 128 uint4 per step)
 __device__ __forceinline__ void mm_pair_h(const float* __restrict__ arow, int steps, const uint4* __restrict__ w0,
                                           const uint4* __restrict__ w1, f32x16& acc0, f32x16& acc1) {
-#pragma unroll 4
+#pragma unroll T2L_ENC_UNROLL
   for (int s = 0; s < steps; ++s) {
     const HFrag a = split_h(arow + 8 * s);
     const HFrag b0 = load_h(w0 + s * 128), b1 = load_h(w1 + s * 128);
@@ -267,8 +271,12 @@ __device__ __forceinline__ void small_mlp(const SmallMlp& m, const float* __rest
   normalize_rows(dst, kLdX, nobj, wave, lane);
 }
 
-// LDS: x [32][260] + buf [32][260] = 66.6 KB, so TWO cells are in flight per CU (while one workgroup sits in a barrier, a
-// LayerNorm or a softmax, the other one keeps the MFMA pipe busy). What makes that fit:
+// LDS: x [32][260] + buf [32][260] = 66.6 KB per cell, one cell per workgroup, so TWO workgroups (cells) are in flight per CU:
+// while one sits in a barrier, a LayerNorm or a softmax, the other keeps the MFMA pipe busy.
+// (Measured and rejected in round 2: TWO cells per workgroup sharing every weight fragment in registers — 133 KB, one
+// workgroup per CU, bit-identical output — 5.35 ms against 3.70 ms for 11,259 cells: what it saves on the weight stream it loses
+// twice over by leaving each SIMD a single wave to hide the L2 latency of that stream.)
+// What makes a cell fit 66.6 KB:
 //  * the concatenated features never exist: every 256-wide slot is produced in `buf` and immediately contracted with its
 //    256-column slice of the merge weight into register accumulators;
 //  * q, k, v never touch LDS: head h = wave h computes q_h^T and k_h^T TRANSPOSED (A = packed weights, B = the x rows) and
@@ -276,112 +284,146 @@ __device__ __forceinline__ void small_mlp(const SmallMlp& m, const float* __rest
 //    operands of S^T = K Q^T and the v_h registers ARE the B operand of P V, so the whole head runs from registers;
 //  * the feed-forward hidden layer goes through `buf` in two halves of 256 units (chosen as the units that one half of the
 //    half-split weight packing covers), the second Linear accumulating over both halves in registers.
-template <bool H>  // H: split-f16 MFMAs for the big contractions (see the file header); !H: everything on the f32 MFMA
-__global__ __launch_bounds__(256, 2) void encode_cells_kernel(EncParams P, t2l_packed_cells in,
-                                                              float* __restrict__ out) {
+template <bool H, int NC = 1>  // H: split-f16 MFMAs for the big contractions (see the file header); !H: everything on the f32 MFMA
+__global__ __launch_bounds__(256, NC == 1 ? 2 : 1) void encode_cells_kernel(EncParams P, t2l_packed_cells in,
+                                                                           float* __restrict__ out) {
+  static_assert(NC == 1, "one cell per workgroup (the two-cell form was measured and rejected, see above)");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* x = smem;                   // [32][260] token buffer; scratch (small-MLP hidden / features2 staging) before it is live
-  float* buf = x + kXFloats;         // [32][260] feature slot -> attention output -> feed-forward hidden half
-  float* red = buf + kXFloats;       // [8]
-  float* hbuf = x;                   // [32][68]  overlay on x (feature phase only)
+  float* x[NC];    // [32][260] token buffer; scratch (small-MLP hidden / features2 staging) before it is live
+  float* buf[NC];  // [32][260] feature slot -> attention output -> feed-forward hidden half
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    x[c] = smem + c * 2 * kXFloats;
+    buf[c] = x[c] + kXFloats;
+  }
+  float* red = smem + NC * 2 * kXFloats;  // [8 * NC]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
-  const int cell = blockIdx.x;
-  const int obj0 = in.offsets[cell];
-  const int nobj = min(in.offsets[cell + 1] - obj0, kS);  // objects beyond 28 are dropped (cell_retrieval.py:94-98)
+  int cell[NC], obj0[NC], nobj[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    cell[c] = min((int)blockIdx.x * NC + c, in.n_cells - 1);  // an odd tail workgroup computes its last cell twice
+    obj0[c] = in.offsets[cell[c]];
+    nobj[c] = min(in.offsets[cell[c] + 1] - obj0[c], kS);  // objects beyond 28 are dropped (cell_retrieval.py:94-98)
+  }
 
   // ------------------------------------------------------------------ per-object features, merged slot by slot
-  f32x16 keep0, keep1;  // merge output tiles (wave, wave + 4)
+  f32x16 keep0[NC], keep1[NC];  // merge output tiles (wave, wave + 4)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) keep0[r] = keep1[r] = 0.f;
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) keep0[c][r] = keep1[c][r] = 0.f;
   int slot = 0;
   auto merge_slot = [&]() {  // buf holds slot `slot` (normalised rows): keep += buf @ Wmerge[:, 256*slot : 256*slot+256]^T
     __syncthreads();
     if (P.nfeat > 1) {
       if constexpr (H) {
         const uint4* hp = P.merge_hp + (size_t)slot * (kD * kD / 4);
-        mm_pair_h(buf + col * kLdX + half * 128, kD / 16, hp + ((size_t)wave * (kD / 16) * 64 + lane) * 2,
-                  hp + ((size_t)(wave + 4) * (kD / 16) * 64 + lane) * 2, keep0, keep1);
+        const uint4* w0 = hp + ((size_t)wave * (kD / 16) * 64 + lane) * 2;
+        const uint4* w1 = hp + ((size_t)(wave + 4) * (kD / 16) * 64 + lane) * 2;
+        mm_pair_h(buf[0] + col * kLdX + half * 128, kD / 16, w0, w1, keep0[0], keep1[0]);
       } else {
         const float4* wp = P.merge_wp + (size_t)slot * (kD * kD / 4);
-        mm_pair(buf + col * kLdX + half * 128, kD / 8, wp + (size_t)wave * (kD / 8) * 64 + lane,
-                wp + (size_t)(wave + 4) * (kD / 8) * 64 + lane, keep0, keep1);
+        mm_pair(buf[0] + col * kLdX + half * 128, kD / 8, wp + (size_t)wave * (kD / 8) * 64 + lane,
+                wp + (size_t)(wave + 4) * (kD / 8) * 64 + lane, keep0[0], keep1[0]);
       }
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        keep0[r] = buf[row * kLdX + wave * 32 + col];
-        keep1[r] = buf[row * kLdX + (wave + 4) * 32 + col];
-      }
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          keep0[c][r] = buf[c][row * kLdX + wave * 32 + col];
+          keep1[c][r] = buf[c][row * kLdX + (wave + 4) * 32 + col];
+        }
     }
     ++slot;
     __syncthreads();  // every wave is done reading buf (and the x-region scratch) before the next slot rewrites them
   };
   if (P.use_class) {
     if (P.class_embed) {  // object_encoder.py:103-110 (table rows pre-normalised on the host)
-      for (int o = 0; o < kSP; ++o) {
-        float v = 0.f;
-        if (o < nobj) {
-          const int ci = min(max(in.class_idx[obj0 + o], 0), P.n_class - 1);
-          v = P.class_tab[ci * kD + tid];
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        for (int o = 0; o < kSP; ++o) {
+          float v = 0.f;
+          if (o < nobj[c]) {
+            const int ci = min(max(in.class_idx[obj0[c] + o], 0), P.n_class - 1);
+            v = P.class_tab[ci * kD + tid];
+          }
+          buf[c][o * kLdX + tid] = v;
         }
-        buf[o * kLdX + tid] = v;
-      }
     } else {  // object_encoder.py:86-99,112: features2 -> mlp_pointnet -> normalize
-      float* stage = x;  // park features2 in the (not yet live) token buffer
-      for (int o = wave; o < kSP; o += 4) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (o < nobj) v = reinterpret_cast<const float4*>(in.pn_feat + (size_t)(obj0 + o) * kD)[lane];
-        reinterpret_cast<float4*>(stage + o * kLdX)[lane] = v;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        float* stage = x[c];  // park features2 in the (not yet live) token buffer
+        for (int o = wave; o < kSP; o += 4) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (o < nobj[c]) v = reinterpret_cast<const float4*>(in.pn_feat + (size_t)(obj0[c] + o) * kD)[lane];
+          reinterpret_cast<float4*>(stage + o * kLdX)[lane] = v;
+        }
       }
       __syncthreads();
       const float* pb = P.pn_b;
-      auto pn_epi = [&](int, int, int row, int c, float v) { buf[row * kLdX + c] = fmaxf(v + pb[c], 0.f); };
-      // (features2 is an input: its magnitude is not bounded by the weights, so this GEMM stays f32)
-      gemm32(stage, kLdX, kD, P.pn_wp, kD, wave, lane, pn_epi);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        float* dst = buf[c];
+        auto pn_epi = [&](int, int, int row, int cc, float v) { dst[row * kLdX + cc] = fmaxf(v + pb[cc], 0.f); };
+        // (features2 is an input: its magnitude is not bounded by the weights, so this GEMM stays f32)
+        gemm32(x[c], kLdX, kD, P.pn_wp, kD, wave, lane, pn_epi);
+      }
       __syncthreads();
-      normalize_rows(buf, kLdX, nobj, wave, lane);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) normalize_rows(buf[c], kLdX, nobj[c], wave, lane);
     }
     merge_slot();
   }
   if (P.use_color) {
     if (P.color_embed) {  // object_encoder.py:116-120
-      for (int o = 0; o < kSP; ++o) {
-        float v = 0.f;
-        if (o < nobj) {
-          const int ci = min(max(in.color_idx[obj0 + o], 0), P.n_color - 1);
-          v = P.color_tab[ci * kD + tid];
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        for (int o = 0; o < kSP; ++o) {
+          float v = 0.f;
+          if (o < nobj[c]) {
+            const int ci = min(max(in.color_idx[obj0[c] + o], 0), P.n_color - 1);
+            v = P.color_tab[ci * kD + tid];
+          }
+          buf[c][o * kLdX + tid] = v;
         }
-        buf[o * kLdX + tid] = v;
-      }
     } else {  // object_encoder.py:121-128
-      small_mlp<3>(P.color, in.rgb + (size_t)obj0 * 3, false, nobj, hbuf, buf, tid, wave, lane);
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        small_mlp<3>(P.color, in.rgb + (size_t)obj0[c] * 3, false, nobj[c], x[c], buf[c], tid, wave, lane);
     }
     merge_slot();
   }
   if (P.use_pos) {  // object_encoder.py:130-136
-    small_mlp<3>(P.pos, in.center + (size_t)obj0 * 3, false, nobj, hbuf, buf, tid, wave, lane);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      small_mlp<3>(P.pos, in.center + (size_t)obj0[c] * 3, false, nobj[c], x[c], buf[c], tid, wave, lane);
     merge_slot();
   }
   if (P.use_num) {  // object_encoder.py:138-145
-    small_mlp<1>(P.num, in.n_pts + obj0, true, nobj, hbuf, buf, tid, wave, lane);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) small_mlp<1>(P.num, in.n_pts + obj0[c], true, nobj[c], x[c], buf[c], tid, wave, lane);
     merge_slot();
   }
   // merge epilogue (object_encoder.py:148-149: Linear+BN folded, ReLU) + normalize (cell_retrieval.py:92)
   {
     const float* mb = P.merge_b;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int c0 = wave * 32 + col, c1 = (wave + 4) * 32 + col;
-      x[row * kLdX + c0] = P.nfeat > 1 ? fmaxf(keep0[r] + mb[c0], 0.f) : keep0[r];
-      x[row * kLdX + c1] = P.nfeat > 1 ? fmaxf(keep1[r] + mb[c1], 0.f) : keep1[r];
-    }
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int c0 = wave * 32 + col, c1 = (wave + 4) * 32 + col;
+        x[c][row * kLdX + c0] = P.nfeat > 1 ? fmaxf(keep0[c][r] + mb[c0], 0.f) : keep0[c][r];
+        x[c][row * kLdX + c1] = P.nfeat > 1 ? fmaxf(keep1[c][r] + mb[c1], 0.f) : keep1[c][r];
+      }
   }
   __syncthreads();
-  normalize_rows(x, kLdX, nobj, wave, lane);  // rows >= nobj become the zero pad slots (cell_retrieval.py:85)
+#pragma unroll
+  for (int c = 0; c < NC; ++c) normalize_rows(x[c], kLdX, nobj[c], wave, lane);  // rows >= nobj: the zero pad slots (cell_retrieval.py:85)
   __syncthreads();
 
   // ------------------------------------------------------------------ set transformer (cell_retrieval.py:101-103)
@@ -390,177 +432,246 @@ __global__ __launch_bounds__(256, 2) void encode_cells_kernel(EncParams P, t2l_p
     {  // head h = wave, registers only
       const int h = wave;
       constexpr int QN = kD / 8;  // 32 packed k-steps
-      const float* xr = x + col * kLdX + half * 128;
-      const float4* wq0 = W.in_wp + (size_t)(2 * h) * QN * 64 + lane;
-      const float4* wq1 = W.in_wp + (size_t)(2 * h + 1) * QN * 64 + lane;
-      const float4* wk0 = W.in_wp + (size_t)(8 + 2 * h) * QN * 64 + lane;
-      const float4* wk1 = W.in_wp + (size_t)(9 + 2 * h) * QN * 64 + lane;
-      const float4* wv0 = W.in_wp + (size_t)(16 + 2 * h) * QN * 64 + lane;
-      const float4* wv1 = W.in_wp + (size_t)(17 + 2 * h) * QN * 64 + lane;
-      f32x16 qT0, qT1, kT0, kT1, v0, v1;
+      const float* ib = W.in_b;
+      // ---- pass 1: q_h^T and k_h^T of every cell (the packed weights are the A operand, the token rows the B operand); one
+      // load of a weight fragment feeds every cell. v_h follows in its own pass: 12 live accumulators would not fit.
+      f32x16 st[NC];  // becomes S^T, then the unnormalised probabilities
+      float inv[NC];
+      {
+        f32x16 qT0[NC], qT1[NC], kT0[NC], kT1[NC];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) qT0[r] = qT1[r] = kT0[r] = kT1[r] = v0[r] = v1[r] = 0.f;
-      if constexpr (H) {
-        // q_h^T, k_h^T: the packed weights are the A operand and the token rows the B operand; v_h straight. One split
-        // of the token fragment feeds all 18 MFMAs of the step.
-        constexpr int HS = kD / 16;
-        const uint4* hq0 = W.in_hp + ((size_t)(2 * h) * HS * 64 + lane) * 2;
-        const uint4* hq1 = W.in_hp + ((size_t)(2 * h + 1) * HS * 64 + lane) * 2;
-        const uint4* hk0 = W.in_hp + ((size_t)(8 + 2 * h) * HS * 64 + lane) * 2;
-        const uint4* hk1 = W.in_hp + ((size_t)(9 + 2 * h) * HS * 64 + lane) * 2;
-        const uint4* hv0 = W.in_hp + ((size_t)(16 + 2 * h) * HS * 64 + lane) * 2;
-        const uint4* hv1 = W.in_hp + ((size_t)(17 + 2 * h) * HS * 64 + lane) * 2;
-#pragma unroll 4
-        for (int s = 0; s < HS; ++s) {
-          const HFrag xf = split_h(xr + 8 * s);
-          mfma_h3(qT0, load_h(hq0 + s * 128), xf);
-          mfma_h3(qT1, load_h(hq1 + s * 128), xf);
-          mfma_h3(kT0, load_h(hk0 + s * 128), xf);
-          mfma_h3(kT1, load_h(hk1 + s * 128), xf);
-          mfma_h3(v0, xf, load_h(hv0 + s * 128));
-          mfma_h3(v1, xf, load_h(hv1 + s * 128));
-        }
-      } else {
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) qT0[c][r] = qT1[c][r] = kT0[c][r] = kT1[c][r] = 0.f;
+        if constexpr (H) {
+          constexpr int HS = kD / 16;
+          const uint4* hq0 = W.in_hp + ((size_t)(2 * h) * HS * 64 + lane) * 2;
+          const uint4* hq1 = W.in_hp + ((size_t)(2 * h + 1) * HS * 64 + lane) * 2;
+          const uint4* hk0 = W.in_hp + ((size_t)(8 + 2 * h) * HS * 64 + lane) * 2;
+          const uint4* hk1 = W.in_hp + ((size_t)(9 + 2 * h) * HS * 64 + lane) * 2;
 #pragma unroll 2
-      for (int q = 0; q < QN; ++q) {
-        const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * q);
-        const float4 a0 = wq0[q * 64], a1 = wq1[q * 64], c0 = wk0[q * 64], c1 = wk1[q * 64], e0 = wv0[q * 64], e1 = wv1[q * 64];
-#define T2L_QKV(C)                                                            \
-  qT0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.C, xv.C, qT0, 0, 0, 0);       \
-  qT1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.C, xv.C, qT1, 0, 0, 0);       \
-  kT0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c0.C, xv.C, kT0, 0, 0, 0);       \
-  kT1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1.C, xv.C, kT1, 0, 0, 0);       \
-  v0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.C, e0.C, v0, 0, 0, 0);         \
-  v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.C, e1.C, v1, 0, 0, 0);
-        T2L_QKV(x) T2L_QKV(y) T2L_QKV(z) T2L_QKV(w)
-#undef T2L_QKV
-      }
-      }
-      {  // in_proj bias: q^T / k^T rows are features (register index), v columns are features (lane)
-        const float* ib = W.in_b;
-        const float bv0 = ib[2 * kD + h * 64 + col], bv1 = ib[2 * kD + h * 64 + 32 + col];
+          for (int s = 0; s < HS; ++s) {
+            HFrag xf[NC];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
-          qT0[r] += ib[h * 64 + f];
-          qT1[r] += ib[h * 64 + 32 + f];
-          kT0[r] += ib[kD + h * 64 + f];
-          kT1[r] += ib[kD + h * 64 + 32 + f];
-          v0[r] += bv0;
-          v1[r] += bv1;
+            for (int c = 0; c < NC; ++c) xf[c] = split_h(x[c] + col * kLdX + half * 128 + 8 * s);
+            {
+              const HFrag f = load_h(hq0 + s * 128);
+#pragma unroll
+              for (int c = 0; c < NC; ++c) mfma_h3(qT0[c], f, xf[c]);
+            }
+            {
+              const HFrag f = load_h(hq1 + s * 128);
+#pragma unroll
+              for (int c = 0; c < NC; ++c) mfma_h3(qT1[c], f, xf[c]);
+            }
+            {
+              const HFrag f = load_h(hk0 + s * 128);
+#pragma unroll
+              for (int c = 0; c < NC; ++c) mfma_h3(kT0[c], f, xf[c]);
+            }
+            {
+              const HFrag f = load_h(hk1 + s * 128);
+#pragma unroll
+              for (int c = 0; c < NC; ++c) mfma_h3(kT1[c], f, xf[c]);
+            }
+          }
+        } else {
+          const float* xr = x[0] + col * kLdX + half * 128;
+          const float4* wq0 = W.in_wp + (size_t)(2 * h) * QN * 64 + lane;
+          const float4* wq1 = W.in_wp + (size_t)(2 * h + 1) * QN * 64 + lane;
+          const float4* wk0 = W.in_wp + (size_t)(8 + 2 * h) * QN * 64 + lane;
+          const float4* wk1 = W.in_wp + (size_t)(9 + 2 * h) * QN * 64 + lane;
+#pragma unroll 2
+          for (int q = 0; q < QN; ++q) {
+            const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * q);
+            const float4 a0 = wq0[q * 64], a1 = wq1[q * 64], c0 = wk0[q * 64], c1 = wk1[q * 64];
+#define T2L_QK(C)                                                                   \
+  qT0[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.C, xv.C, qT0[0], 0, 0, 0);       \
+  qT1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.C, xv.C, qT1[0], 0, 0, 0);       \
+  kT0[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0.C, xv.C, kT0[0], 0, 0, 0);       \
+  kT1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1.C, xv.C, kT1[0], 0, 0, 0);
+            T2L_QK(x) T2L_QK(y) T2L_QK(z) T2L_QK(w)
+#undef T2L_QK
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          // in_proj bias: q^T / k^T rows are features (register index)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
+            qT0[c][r] += ib[h * 64 + f];
+            qT1[c][r] += ib[h * 64 + 32 + f];
+            kT0[c][r] += ib[kD + h * 64 + f];
+            kT1[c][r] += ib[kD + h * 64 + 32 + f];
+          }
+          // S^T[j][i] = k_j . q_i: k_h^T (token j = lane col, feature pair (f, f+4) = the two lane halves) is the A operand,
+          // q_h^T the B operand, one MFMA per register
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st[c][r] = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(kT0[c][r], qT0[c][r], st[c], 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(kT1[c][r], qT1[c][r], st[c], 0, 0, 0);
+          // lane: query i = col, keys j = (r&3) + 8*(r>>2) + 4*half ; keys >= 28 are the dead rows
+          float m = -__builtin_inff();
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
+            st[c][r] = (j < kS) ? st[c][r] * 0.125f : -__builtin_inff();  // 1/sqrt(head_dim = 64)
+            m = fmaxf(m, st[c][r]);
+          }
+          m = fmaxf(m, __shfl_xor(m, 32));
+          float sum = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            st[c][r] = __expf(st[c][r] - m);
+            sum += st[c][r];
+          }
+          sum += __shfl_xor(sum, 32);
+          inv[c] = 1.f / sum;
         }
       }
-      // S^T[j][i] = k_j . q_i: k_h^T (token j = lane col, feature pair (f, f+4) = the two lane halves) is the A operand,
-      // q_h^T the B operand, one MFMA per register
-      f32x16 st;
+      // ---- pass 2: v_h straight (A = token rows, B = packed weights), then o = P V from registers
+      {
+        f32x16 v0[NC], v1[NC];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kT0[r], qT0[r], st, 0, 0, 0);
+          for (int r = 0; r < 16; ++r) v0[c][r] = v1[c][r] = 0.f;
+        if constexpr (H) {
+          constexpr int HS = kD / 16;
+          const uint4* hv0 = W.in_hp + ((size_t)(16 + 2 * h) * HS * 64 + lane) * 2;
+          const uint4* hv1 = W.in_hp + ((size_t)(17 + 2 * h) * HS * 64 + lane) * 2;
+#pragma unroll 4
+          for (int s = 0; s < HS; ++s) {
+            const HFrag f0 = load_h(hv0 + s * 128), f1 = load_h(hv1 + s * 128);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kT1[r], qT1[r], st, 0, 0, 0);
-      // lane: query i = col, keys j = (r&3) + 8*(r>>2) + 4*half ; keys >= 28 are the dead rows
-      float m = -__builtin_inff();
+            for (int c = 0; c < NC; ++c) {
+              const HFrag xf = split_h(x[c] + col * kLdX + half * 128 + 8 * s);
+              mfma_h3(v0[c], xf, f0);
+              mfma_h3(v1[c], xf, f1);
+            }
+          }
+        } else {
+          const float* xr = x[0] + col * kLdX + half * 128;
+          const float4* wv0 = W.in_wp + (size_t)(16 + 2 * h) * QN * 64 + lane;
+          const float4* wv1 = W.in_wp + (size_t)(17 + 2 * h) * QN * 64 + lane;
+          mm_pair(xr, QN, wv0, wv1, v0[0], v1[0]);
+        }
+        const float bv0 = ib[2 * kD + h * 64 + col], bv1 = ib[2 * kD + h * 64 + 32 + col];  // v columns are features (lane)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
-        st[r] = (j < kS) ? st[r] * 0.125f : -__builtin_inff();  // 1/sqrt(head_dim = 64)
-        m = fmaxf(m, st[r]);
-      }
-      m = fmaxf(m, __shfl_xor(m, 32));
-      float sum = 0.f;
+        for (int c = 0; c < NC; ++c) {
+          // o[i][n] = sum_j P[i][j] v[j][n]: P (lane = query i, register = key j) is the A operand, v_h registers (lane =
+          // column n, register = key j) the B operand
+          f32x16 o0, o1;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        st[r] = __expf(st[r] - m);
-        sum += st[r];
-      }
-      sum += __shfl_xor(sum, 32);
-      const float inv = 1.f / sum;
-      // o[i][n] = sum_j P[i][j] v[j][n]: P (lane = query i, register = key j) is the A operand, v_h registers (lane = column n,
-      // register = key j) the B operand
-      f32x16 o0, o1;
+          for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+          for (int r = 0; r < 16; ++r) {
+            const float p = st[c][r] * inv[c];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p, v0[c][r] + bv0, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p, v1[c][r] + bv1, o1, 0, 0, 0);
+          }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = st[r] * inv;
-        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p, v0[r], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p, v1[r], o1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-        buf[i * kLdX + h * 64 + col] = o0[r];
-        buf[i * kLdX + h * 64 + 32 + col] = o1[r];
+          for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            buf[c][i * kLdX + h * 64 + col] = o0[r];
+            buf[c][i * kLdX + h * 64 + 32 + col] = o1[r];
+          }
+        }
       }
     }
     __syncthreads();
     {  // x = LN1(x + o @ out_proj^T + b)
       const float* b = W.out_b;
-      auto out_epi = [&](int, int, int row, int c, float v) { x[row * kLdX + c] += v + b[c]; };
-      if constexpr (H) gemm32_h(buf, kLdX, kD, W.out_hp, kD, wave, lane, out_epi);
-      else gemm32(buf, kLdX, kD, W.out_wp, kD, wave, lane, out_epi);
+      {
+        float* xd = x[0];
+        auto out_epi = [&](int, int, int row, int c, float v) { xd[row * kLdX + c] += v + b[c]; };
+        if constexpr (H) gemm32_h(buf[0], kLdX, kD, W.out_hp, kD, wave, lane, out_epi);
+        else gemm32(buf[0], kLdX, kD, W.out_wp, kD, wave, lane, out_epi);
+      }
     }
     __syncthreads();
-    layer_norm_rows(x, W.ln1_w, W.ln1_b, wave, lane);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) layer_norm_rows(x[c], W.ln1_w, W.ln1_b, wave, lane);
     __syncthreads();
     {  // x = LN2(x + relu(x W1^T + b1) W2^T + b2), hidden units in two halves through buf
-      f32x16 acc0, acc1;  // output tiles (wave, wave + 4)
+      f32x16 acc0[NC], acc1[NC];  // output tiles (wave, wave + 4)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[c][r] = acc1[c][r] = 0.f;
       const float* b1 = W.ff1_b;
       for (int hf = 0; hf < 2; ++hf) {
         // half hf = hidden units [128 hf, 128 hf + 128) and [256 + 128 hf, 256 + 128 hf + 128): exactly what k-steps
         // [32 hf, 32 hf + 32) of the half-split packing of W2 (K = 512) cover
         const int tA = 4 * hf + wave, tB = 8 + 4 * hf + wave;
-        f32x16 h0, h1;
+        f32x16 h0[NC], h1[NC];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h0[r] = h1[r] = 0.f;
-        if constexpr (H)
-          mm_pair_h(x + col * kLdX + half * 128, kD / 16, W.ff1_hp + ((size_t)tA * (kD / 16) * 64 + lane) * 2,
-                    W.ff1_hp + ((size_t)tB * (kD / 16) * 64 + lane) * 2, h0, h1);
-        else
-          mm_pair(x + col * kLdX + half * 128, kD / 8, W.ff1_wp + (size_t)tA * (kD / 8) * 64 + lane,
-                  W.ff1_wp + (size_t)tB * (kD / 8) * 64 + lane, h0, h1);
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) h0[c][r] = h1[c][r] = 0.f;
+        if constexpr (H) {
+          const uint4* w0 = W.ff1_hp + ((size_t)tA * (kD / 16) * 64 + lane) * 2;
+          const uint4* w1 = W.ff1_hp + ((size_t)tB * (kD / 16) * 64 + lane) * 2;
+          mm_pair_h(x[0] + col * kLdX + half * 128, kD / 16, w0, w1, h0[0], h1[0]);
+        } else {
+          mm_pair(x[0] + col * kLdX + half * 128, kD / 8, W.ff1_wp + (size_t)tA * (kD / 8) * 64 + lane,
+                  W.ff1_wp + (size_t)tB * (kD / 8) * 64 + lane, h0[0], h1[0]);
+        }
         if (hf) __syncthreads();  // every wave has consumed the first half from buf
         const float bA = b1[tA * 32 + col], bB = b1[tB * 32 + col];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-          buf[row * kLdX + 32 * wave + col] = fmaxf(h0[r] + bA, 0.f);
-          buf[row * kLdX + 128 + 32 * wave + col] = fmaxf(h1[r] + bB, 0.f);
-        }
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            buf[c][row * kLdX + 32 * wave + col] = fmaxf(h0[c][r] + bA, 0.f);
+            buf[c][row * kLdX + 128 + 32 * wave + col] = fmaxf(h1[c][r] + bB, 0.f);
+          }
         __syncthreads();
-        if constexpr (H)  // K = 512: 32 steps per tile, half hf = steps [16 hf, 16 hf + 16)
-          mm_pair_h(buf + col * kLdX + half * 128, kD / 16,
-                    W.ff2_hp + (((size_t)wave * (2 * kD / 16) + 16 * hf) * 64 + lane) * 2,
-                    W.ff2_hp + (((size_t)(wave + 4) * (2 * kD / 16) + 16 * hf) * 64 + lane) * 2, acc0, acc1);
-        else
-          mm_pair(buf + col * kLdX + half * 128, kD / 8, W.ff2_wp + ((size_t)wave * (2 * kD / 8) + 32 * hf) * 64 + lane,
-                  W.ff2_wp + ((size_t)(wave + 4) * (2 * kD / 8) + 32 * hf) * 64 + lane, acc0, acc1);
+        if constexpr (H) {  // K = 512: 32 steps per tile, half hf = steps [16 hf, 16 hf + 16)
+          const uint4* w0 = W.ff2_hp + (((size_t)wave * (2 * kD / 16) + 16 * hf) * 64 + lane) * 2;
+          const uint4* w1 = W.ff2_hp + (((size_t)(wave + 4) * (2 * kD / 16) + 16 * hf) * 64 + lane) * 2;
+          mm_pair_h(buf[0] + col * kLdX + half * 128, kD / 16, w0, w1, acc0[0], acc1[0]);
+        } else {
+          mm_pair(buf[0] + col * kLdX + half * 128, kD / 8, W.ff2_wp + ((size_t)wave * (2 * kD / 8) + 32 * hf) * 64 + lane,
+                  W.ff2_wp + ((size_t)(wave + 4) * (2 * kD / 8) + 32 * hf) * 64 + lane, acc0[0], acc1[0]);
+        }
       }
       const float* b2 = W.ff2_b;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int c0 = wave * 32 + col, c1 = (wave + 4) * 32 + col;
-        x[row * kLdX + c0] += acc0[r] + b2[c0];
-        x[row * kLdX + c1] += acc1[r] + b2[c1];
-      }
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int c0 = wave * 32 + col, c1 = (wave + 4) * 32 + col;
+          x[c][row * kLdX + c0] += acc0[c][r] + b2[c0];
+          x[c][row * kLdX + c1] += acc1[c][r] + b2[c1];
+        }
     }
     __syncthreads();
-    layer_norm_rows(x, W.ln2_w, W.ln2_b, wave, lane);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) layer_norm_rows(x[c], W.ln2_w, W.ln2_b, wave, lane);
     __syncthreads();
   }
 
   // ------------------------------------------------------------------ max over ALL 28 slots, pads included (cell_retrieval.py:107-108)
-  float mx = x[tid];
-  for (int i = 1; i < kS; ++i) mx = fmaxf(mx, x[i * kLdX + tid]);
-  const float ss = wave_sum(mx * mx);
-  if (lane == 0) red[wave] = ss;
+  float mx[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    mx[c] = x[c][tid];
+    for (int i = 1; i < kS; ++i) mx[c] = fmaxf(mx[c], x[c][i * kLdX + tid]);
+    const float ss = wave_sum(mx[c] * mx[c]);
+    if (lane == 0) red[c * 4 + wave] = ss;
+  }
   __syncthreads();
-  const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
-  out[(size_t)cell * kD + tid] = mx / fmaxf(nrm, 1e-12f);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float nrm = sqrtf(red[c * 4 + 0] + red[c * 4 + 1] + red[c * 4 + 2] + red[c * 4 + 3]);
+    if ((int)blockIdx.x * NC + c < in.n_cells) out[(size_t)cell[c] * kD + tid] = mx[c] / fmaxf(nrm, 1e-12f);
+  }
 }
 
 // ---- host side: BN folding, fragment packing, upload -------------------------------------------
