@@ -133,3 +133,53 @@ def test_dropout_mask_statistics():
         assert not np.array_equal(k, OT.dropout_keep(99, 4, 1 << 20, p))
         assert not np.array_equal(k, OT.dropout_keep(100, 3, 1 << 20, p))
     assert OT.dropout_keep(1, 1, 100, 0.0).all()
+
+
+def test_pointnet_train_oracle_gradients_match_central_differences():
+    """oracle/t2l_oracle_pointnet_train.py: analytic backward of the train-mode PointNet++ (per-cell BatchNorm statistics,
+    max aggregation, the bipartite self-loop edge) against central differences of its own float64 forward."""
+    from oracle import t2l_oracle_pointnet_train as OPT
+
+    cells = synth.make_cells(2, seed=3, min_obj=2, max_obj=2)
+    pos, rgb = synth.make_sampled_points(cells, 3)
+    sd = synth.make_pointnet_weights(1)
+    offs = cells["offsets"]
+    rng = np.random.default_rng(0)
+    R = rng.standard_normal((pos.shape[0], 256))
+    f2, info = OPT.forward_backward(pos, rgb, offs, sd, grad_f2=R)
+    assert f2.shape == (4, 256) and (f2 >= 0).all() and f2.max() > 0
+    # running statistics moved (two cells -> two momentum updates) and stay finite
+    k = "object_encoder.pointnet.sa2.point_conv.local_nn.0.1.running_var"
+    assert np.isfinite(info["running"][k]).all() and np.abs(info["running"][k] - sd[k]).max() > 1e-6
+
+    def loss(sd_mod):
+        out, _ = OPT.forward_backward(pos, rgb, offs, sd_mod)
+        return float((out * R).sum())
+
+    checked = 0
+    for name in ["object_encoder.pointnet.lin2.weight", "object_encoder.pointnet.lin1.bias",
+                 "object_encoder.pointnet.ga.mlp.1.0.weight", "object_encoder.pointnet.ga.mlp.0.1.weight",
+                 "object_encoder.pointnet.sa3.point_conv.local_nn.1.0.weight", "object_encoder.pointnet.sa3.point_conv.local_nn.0.1.bias",
+                 "object_encoder.pointnet.sa2.point_conv.local_nn.0.0.weight", "object_encoder.pointnet.sa1.point_conv.local_nn.1.1.weight",
+                 "object_encoder.pointnet.sa1.point_conv.local_nn.0.0.weight"]:
+        g = np.asarray(info["grads"][name])
+        flat = np.argsort(-np.abs(g).ravel())[:3]  # the three largest entries: well above the difference quotient's noise
+        for idx in flat:
+            base = np.asarray(sd[name], dtype=np.float64)
+            best = np.inf
+            for scale in (1e-6, 1e-7):  # an arg-max or ReLU switch inside +-eps shows as an O(1e-2) disagreement that a smaller
+                eps = scale * max(1.0, abs(base.ravel()[idx]))  # step does not see; smooth points agree to ~1e-8
+                vals = []
+                for sgn in (+1, -1):
+                    mod = dict(sd)
+                    w = base.copy()
+                    w.ravel()[idx] += sgn * eps
+                    mod[name] = w
+                    vals.append(loss(mod))
+                num = (vals[0] - vals[1]) / (2 * eps)
+                best = min(best, abs(num - g.ravel()[idx]) / max(1.0, abs(num)))
+                if best < 1e-5:
+                    break
+            assert best < 1e-5, (name, idx, num, g.ravel()[idx])
+            checked += 1
+    assert checked == 27
