@@ -255,6 +255,20 @@ int t2l_encode_cells_train(t2l_ctx* ctx, const t2l_packed_cells* in, float dropo
  * grad_pn_feat: dev f32[n_objects,256] receiving d loss / d pn_feat (class_embed == 0), or NULL. */
 int t2l_encode_cells_backward(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat, void* stream);
 
+/* The PointNet++ object backbone under model.train() — trained jointly with the rest in the published configuration
+ * (README.md:87-99, no --pointnet_freeze; models/pointcloud/pointnet2.py:18-100 via models/object_encoder.py:86-99). Needs
+ * every object_encoder.pointnet.{sa1,sa2,sa3}.point_conv.local_nn.* / ga.mlp.* / lin1.* / lin2.* tensor in the t2l_train_bind
+ * call WITH a gradient buffer (all or none). The reference calls the backbone once per cell, so every BatchNorm1d uses the
+ * statistics of that cell's rows and updates its running statistics once per cell, in cell order; this call does the whole
+ * batch at once with exactly that segmentation. pos, rgb: dev f32[n_objects,256,3]; cell_offsets: HOST i32[n_cells+1];
+ * out_features2: dev f32[n_objects,256] (feed it to t2l_encode_cells_train as pn_feat). Activations stay in the context
+ * (~14 KB per edge row; ~18 GB at 64 cells) until the next call. PARITY UNPINNED like t2l_pointnet_features. */
+int t2l_pointnet_features_train(t2l_ctx* ctx, const float* pos, const float* rgb, const int32_t* cell_offsets, int32_t n_cells,
+                                float* out_features2, void* stream);
+/* Backward of the call above: grad_features2 = d loss / d features2 (what t2l_encode_cells_backward wrote to grad_pn_feat),
+ * dev f32[n_objects,256]. Parameter gradients are ADDED to the bound buffers. */
+int t2l_pointnet_backward(t2l_ctx* ctx, const float* grad_features2, void* stream);
+
 /* optimizer.zero_grad() and torch.optim.Adam(lr, betas, eps).step() (no weight decay, no amsgrad — what
  * training/coarse.py:258 constructs) over every bound tensor that has a gradient buffer. */
 int t2l_zero_grad(t2l_ctx* ctx, void* stream);

@@ -330,6 +330,19 @@ int t2l_encode_cells_backward(t2l_ctx* ctx, const float* grad_emb, float* grad_p
   return train_backward_impl(ctx, grad_emb, grad_pn_feat, (hipStream_t)stream);
 }
 
+int t2l_pointnet_features_train(t2l_ctx* ctx, const float* pos, const float* rgb, const int32_t* cell_offsets, int32_t n_cells,
+                                float* out_features2, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return pn_train_forward_impl(ctx, pos, rgb, cell_offsets, n_cells, out_features2, (hipStream_t)stream);
+}
+
+int t2l_pointnet_backward(t2l_ctx* ctx, const float* grad_features2, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return pn_train_backward_impl(ctx, grad_features2, (hipStream_t)stream);
+}
+
 int t2l_zero_grad(t2l_ctx* ctx, void* stream) {
   if (!ctx) return T2L_EINVAL;
   T2L_HIP(ctx, hipSetDevice(ctx->device));

@@ -136,6 +136,9 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
 int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat, hipStream_t s);
 int adam_step_impl(t2l_ctx* ctx, float lr, float b1, float b2, float eps, hipStream_t s);
 int zero_grad_impl(t2l_ctx* ctx, hipStream_t s);
+int pn_train_forward_impl(t2l_ctx* ctx, const float* pos, const float* rgb, const int32_t* cell_offsets, int n_cells, float* out_f2,
+                          hipStream_t s);
+int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s);
 int adam_state_impl(t2l_ctx* ctx, int set, float* m, float* v, int64_t* step, int64_t* numel, hipStream_t s);
 void free_train(t2l_ctx* ctx);
 // pointnet.hip

@@ -72,7 +72,11 @@ struct TrainState {
   std::vector<LayerSave> layers;
   uint32_t seed = 0;
   float p = 0.f;
+  void* pn = nullptr;  // PnTrain (pointnet_train.h): the PointNet++ backbone's training state, when its tensors are bound
 };
+
+static void pn_train_free(void* p);
+static int pn_train_bind(t2l_ctx* ctx, TrainState* st, std::vector<std::string>& adam);
 
 static TrainState* state(t2l_ctx* ctx) { return reinterpret_cast<TrainState*>(ctx->train); }
 
@@ -81,6 +85,7 @@ void free_train(t2l_ctx* ctx) {
   if (!st) return;
   for (void* p : {(void*)st->d_tensors, (void*)st->d_chunks, (void*)st->mv, (void*)st->ws, (void*)st->bn_acc})
     if (p) (void)hipFree(p);
+  pn_train_free(st->pn);
   delete st;
   ctx->train = nullptr;
 }
@@ -224,6 +229,7 @@ int train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const 
       P.push_back(p + r.first);
     }
   }
+  if ((rc = pn_train_bind(ctx, st, P))) return rc;  // the PointNet++ backbone, when bound with gradients
   // Adam tables: moments zero-initialised, one chunk per 1,024 elements
   std::vector<AdamTensor> ts;
   std::vector<AdamChunk> cs;
@@ -570,3 +576,5 @@ int zero_grad_impl(t2l_ctx* ctx, hipStream_t s) {
 }
 
 }  // namespace t2l
+
+#include "pointnet_train.h"

@@ -75,6 +75,8 @@ EXPORTS = {
     "t2l_train_bind": (C.c_int, [C.c_void_p, C.POINTER(_TrainTensor), C.c_int32, C.POINTER(_ModelConfig)]),
     "t2l_encode_cells_train": (C.c_int, [C.c_void_p, C.POINTER(_PackedCells), C.c_float, C.c_uint32, C.c_void_p, C.c_void_p]),
     "t2l_encode_cells_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "t2l_pointnet_features_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "t2l_pointnet_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_zero_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
     "t2l_adam_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "t2l_adam_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
@@ -318,6 +320,26 @@ class Engine:
         self._check(self.lib.t2l_encode_cells_backward(self._h, _dev_ptr(grad_emb, torch.float32, "grad_emb"),
                                                        _dev_ptr(grad_pn_feat, torch.float32, "grad_pn_feat"),
                                                        _stream_ptr()))
+
+    def pointnet_features_train(self, pos: torch.Tensor, rgb: torch.Tensor, cell_offsets) -> torch.Tensor:
+        """The PointNet++ backbone under model.train() (per-cell BatchNorm statistics, running statistics updated once per
+        cell): same arguments as pointnet_features; needs the object_encoder.pointnet.* tensors bound with gradients."""
+        co = cell_offsets.cpu().numpy() if isinstance(cell_offsets, torch.Tensor) else np.asarray(cell_offsets)
+        co = np.ascontiguousarray(co, dtype=np.int32)
+        n = int(pos.shape[0])
+        if pos.shape != (n, 256, 3) or rgb.shape != (n, 256, 3) or int(co[-1]) != n:
+            raise T2LError(f"pointnet_features_train: expected [n,256,3] points and offsets ending at n, got {tuple(pos.shape)}, "
+                           f"{tuple(rgb.shape)}, {int(co[-1])}")
+        out = torch.empty((n, EMBED_DIM), dtype=torch.float32, device=pos.device)
+        self._check(self.lib.t2l_pointnet_features_train(self._h, _dev_ptr(pos, torch.float32, "pos"),
+                                                         _dev_ptr(rgb, torch.float32, "rgb"), co.ctypes.data, len(co) - 1,
+                                                         out.data_ptr(), _stream_ptr()))
+        self._pn_train_inputs = (pos, rgb)
+        return out
+
+    def pointnet_backward(self, grad_features2: torch.Tensor):
+        self._check(self.lib.t2l_pointnet_backward(self._h, _dev_ptr(grad_features2, torch.float32, "grad_features2"),
+                                                   _stream_ptr()))
 
     def zero_grad(self):
         self._check(self.lib.t2l_zero_grad(self._h, _stream_ptr()))
