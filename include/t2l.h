@@ -258,7 +258,8 @@ int t2l_encode_cells_backward(t2l_ctx* ctx, const float* grad_emb, float* grad_p
 /* The PointNet++ object backbone under model.train() — trained jointly with the rest in the published configuration
  * (README.md:87-99, no --pointnet_freeze; models/pointcloud/pointnet2.py:18-100 via models/object_encoder.py:86-99). Needs
  * every object_encoder.pointnet.{sa1,sa2,sa3}.point_conv.local_nn.* / ga.mlp.* / lin1.* / lin2.* tensor in the t2l_train_bind
- * call WITH a gradient buffer (all or none). The reference calls the backbone once per cell, so every BatchNorm1d uses the
+ * call: all WITH gradient buffers (trained jointly), or all WITHOUT (--pointnet_freeze, object_encoder.py:53-55: no backward,
+ * but the forward still runs in training mode). The reference calls the backbone once per cell, so every BatchNorm1d uses the
  * statistics of that cell's rows and updates its running statistics once per cell, in cell order; this call does the whole
  * batch at once with exactly that segmentation. pos, rgb: dev f32[n_objects,256,3]; cell_offsets: HOST i32[n_cells+1];
  * out_features2: dev f32[n_objects,256] (feed it to t2l_encode_cells_train as pn_feat). Activations stay in the context

@@ -132,3 +132,94 @@ def test_pointnet_train_needs_the_backbone_bound(eng):
     tensors[k] = (t, torch.zeros_like(t))
     with pytest.raises(T2LError, match="completely"):
         eng.train_bind(tensors, class_embed=False, color_embed=False)
+
+
+def _model(freeze=False):
+    from tests.test_gpu_train_loop import TableText, _args
+    from text2loc_amd.cell_retrieval import CellRetrievalNetwork
+
+    args = _args(class_embed=False, color_embed=False, pointnet_freeze=freeze)
+    model = CellRetrievalNetwork(synth.KNOWN_CLASS, synth.COLOR_NAMES, args, language_encoder=TableText(8, 1))
+    sd = dict(synth.make_object_branch_weights(6))
+    sd.update(synth.make_pointnet_weights(2))
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    for layer in model.obj_inter_module:  # the oracle chain below runs without dropout
+        layer.dropout.p = layer.dropout1.p = layer.dropout2.p = 0.0
+        layer.self_attn.dropout = 0.0
+    return model.to("cuda"), sd
+
+
+def test_model_train_step_reaches_the_backbone():
+    """CellRetrievalNetwork.train(): encode_objects(objects, point batches) -> loss.backward() -> optim.Adam.step() with the
+    backbone trained jointly (the published configuration), against the float64 oracle chain
+    PointNet++(train) -> encode_cells_train -> backward -> PointNet++ backward; then --pointnet_freeze."""
+    from oracle import t2l_oracle_train as OT
+    from tests.test_host_logic import make_objects
+    from text2loc_amd import packing
+    from text2loc_amd.optim import Adam
+
+    B = 3
+    cells = synth.make_cells(B, seed=21, min_obj=2, max_obj=3)
+    objects = make_objects(cells, 21)
+    pos, rgb = synth.make_sampled_points(cells, 5)
+    offs = cells["offsets"]
+    batches = [{"pos": torch.from_numpy(pos[offs[i]:offs[i + 1]].reshape(-1, 3)), "x": torch.from_numpy(rgb[offs[i]:offs[i + 1]].reshape(-1, 3))}
+               for i in range(B)]
+    model, sd = _model()
+    opt = Adam(model, lr=1e-3)
+    model.train()
+    nbt0 = int(model.object_encoder.pointnet.sa1.point_conv.local_nn[0][1].num_batches_tracked)
+    R = torch.randn(B, 256, generator=torch.Generator().manual_seed(0)).cuda()
+    opt.zero_grad()
+    out = model.encode_objects(objects, batches)
+    (out * R).sum().backward()
+    # oracle chain on the same inputs
+    packed = packing.pack_cells(objects, model.object_encoder.known_classes, model.object_encoder.known_colors)
+    f2, _ = OPT.forward_backward(pos, rgb, offs, sd)
+    c2 = dict(packed)
+    c2["pn_feat"] = f2
+    sd64 = {k: np.asarray(v, dtype=np.float64) for k, v in sd.items() if np.asarray(v).dtype.kind == "f"}
+    out_ref, info = OT.encode_cells_train(c2, sd64, False, False, grad_out=R.cpu().numpy().astype(np.float64))
+    assert np.abs(out.detach().cpu().numpy() - out_ref).max() < 5e-5
+    _, pinfo = OPT.forward_backward(pos, rgb, offs, sd, grad_f2=info["grad_pn_feat"])
+    params = dict(model.named_parameters())
+    tight = 0
+    for name, g in pinfo["grads"].items():
+        got = params[name].grad
+        assert got is not None, name
+        if name.endswith(".0.bias") and "lin" not in name:
+            continue
+        err = np.abs(got.cpu().numpy().astype(np.float64) - g)
+        ratio = np.sqrt((err ** 2).sum()) / max(np.sqrt((g ** 2).sum()), 1e-30)
+        assert ratio < 0.03, (name, ratio)
+        tight += ratio < 1e-3
+    assert tight >= 10
+    assert params[P + "class_classifier.weight"].grad is None  # not on the path, as in the reference
+    before = {n: p.detach().clone() for n, p in params.items() if n.startswith(P)}
+    opt.step()
+    moved = [n for n in before if not torch.equal(before[n], params[n].detach())]
+    assert P + "sa1.point_conv.local_nn.0.0.weight" in moved and P + "lin2.weight" in moved
+    assert P + "class_classifier.weight" not in moved
+    bn = model.object_encoder.pointnet.sa1.point_conv.local_nn[0][1]
+    assert int(bn.num_batches_tracked) - nbt0 == B  # one backbone call per cell in the reference
+    # eval after the step: the fused eval path sees the updated backbone (running statistics, not batch statistics)
+    model.eval()
+    with torch.no_grad():
+        ev = model.encode_objects(objects, batches)
+    assert torch.isfinite(ev).all() and float((ev - out.detach()).abs().max()) > 1e-4
+
+    # --pointnet_freeze: weights frozen, BatchNorm still in training mode (object_encoder.py:53-55 + model.train())
+    frozen, _ = _model(freeze=True)
+    frozen.train()
+    opt2 = Adam(frozen, lr=1e-3)
+    opt2.zero_grad()
+    rm0 = frozen.object_encoder.pointnet.sa2.point_conv.local_nn[1][1].running_mean.clone()
+    out2 = frozen.encode_objects(objects, batches)
+    assert float((out2 - out).abs().max()) < 1e-6  # same forward as the trainable model's first step
+    (out2 * R).sum().backward()
+    opt2.step()
+    fp = dict(frozen.named_parameters())
+    assert all(fp[n].grad is None for n in fp if n.startswith(P))
+    assert all(torch.equal(fp[n].detach().cpu(), torch.from_numpy(np.asarray(sd[n]))) for n in fp if n.startswith(P))
+    assert not torch.equal(rm0, frozen.object_encoder.pointnet.sa2.point_conv.local_nn[1][1].running_mean)
+    assert fp["object_encoder.mlp_pointnet.0.0.weight"].grad.abs().max() > 0

@@ -14,9 +14,11 @@ north star prescribes. PointNet++ (published feature mode) runs in the engine to
 cells' point batches (parity unpinned, see oracle/t2l_oracle_pointnet.py). Under ``model.train()`` ``encode_objects`` runs the engine's training-mode forward
 (batch-statistics BatchNorm, the TransformerEncoderLayers' dropout) and returns a tensor whose ``backward``
 runs the engine's backward kernels, which ADD into the ``.grad`` of these same nn.Parameters; step them with
-``text2loc_amd.optim.Adam`` (or any torch optimizer). PointNet++ is eval-only here (the ``--pointnet_freeze``
-setting): its backward is not built; precomputed ``features2`` passed as tensors that require grad do receive
-their gradient.
+``text2loc_amd.optim.Adam`` (or any torch optimizer). PointNet++ trains too (the published configuration: no
+``--pointnet_freeze``): with point batches in ``object_points`` the backbone's training-mode forward
+(t2l_pointnet_features_train: per-cell batch statistics, as the reference's one-call-per-cell loop) and backward
+(t2l_pointnet_backward) run in the engine; with ``--pointnet_freeze`` only the forward does (the reference freezes the
+weights, not the BatchNorm mode). Precomputed ``features2`` passed as tensors that require grad receive their gradient.
 """
 from __future__ import annotations
 
@@ -86,7 +88,7 @@ class ObjectEncoderParams(nn.Module):
     def __init__(self, embed_dim: int, known_classes: List[str], args, known_colors: Optional[List[str]] = None):
         super().__init__()
         self.pointnet = PointNet2Params(len(known_classes), len(known_colors) if known_colors is not None else 8)
-        if bool(getattr(args, "pointnet_freeze", True)):
+        if bool(getattr(args, "pointnet_freeze", False)):  # store_true flag, default off (training/args.py:54)
             self.pointnet.requires_grad_(False)
         self.known_classes = packing.class_table(known_classes)
         self.known_colors = packing.color_table()
@@ -190,6 +192,7 @@ class _EncodeObjectsTrainFn(torch.autograd.Function):
         ctx.model = model
         ctx.token = model._train_token = object()
         ctx.need_pn = pn_feat is not None and pn_feat.requires_grad
+        ctx.pn_engine = bool(model._pn_in_engine)  # features2 came from t2l_pointnet_features_train of a trainable backbone
         ctx.pn_shape = None if pn_feat is None else pn_feat.shape
         return out
 
@@ -199,9 +202,11 @@ class _EncodeObjectsTrainFn(torch.autograd.Function):
         if model._train_token is not ctx.token:
             raise T2LError("backward of a stale encode_objects call: the engine keeps the activations of the LAST "
                            "training-mode forward only (the reference's loop does one forward per backward too)")
-        gpn = torch.empty(ctx.pn_shape, dtype=torch.float32, device=grad_out.device) if ctx.need_pn else None
+        gpn = torch.empty(ctx.pn_shape, dtype=torch.float32, device=grad_out.device) if (ctx.need_pn or ctx.pn_engine) else None
         model._engine.encode_cells_backward(grad_out.contiguous().float(), gpn)
-        return None, gpn, None, None, None, None
+        if ctx.pn_engine:
+            model._engine.pointnet_backward(gpn)
+        return None, (gpn if ctx.need_pn else None), None, None, None, None
 
 
 class CellRetrievalNetwork(nn.Module):
@@ -232,6 +237,8 @@ class CellRetrievalNetwork(nn.Module):
         self._train_grads = {}       # name -> persistent gradient buffer (kept when .grad is set to None)
         self._train_token = None
         self._train_hook = None
+        self._pn_in_engine = False   # the last training-mode forward ran the backbone in the engine with gradients bound
+        self._pn_train_cells = 0
 
     # ---- reference surface ------------------------------------------------------------------------------
     def forward(self):
@@ -253,12 +260,13 @@ class CellRetrievalNetwork(nn.Module):
         with torch.no_grad():
             return self._encode_objects_eval(objects, object_points)
 
-    def _pn_features(self, object_points, eng: Engine):
+    def _pn_features(self, object_points, eng: Engine, train: bool = False):
         """PointNet++ ``features2`` [n_objects,256] on the GPU for the published feature mode (class_embed off), or None.
         ``object_points``: per cell EITHER a precomputed [n_i,256] feature array/tensor OR the cell's point batch as the
         reference's dataloader builds it (a PyG ``Batch`` or anything with ``.pos`` / ``.x`` of shape [n_i*256,3], or a
-        dict with those keys) — then the engine's PointNet++ kernels run (t2l_pointnet_features, eval mode, no gradient:
-        the ``--pointnet_freeze`` setting)."""
+        dict with those keys) — then the engine's PointNet++ kernels run: t2l_pointnet_features in eval mode,
+        t2l_pointnet_features_train (``train``) under model.train()."""
+        self._pn_in_engine = False
         a = self.args
         if not ("class" in a.use_features and not bool(getattr(a, "class_embed", False))):
             return None
@@ -279,7 +287,12 @@ class CellRetrievalNetwork(nn.Module):
             pos = torch.cat([torch.as_tensor(field(p, "pos")).reshape(-1, 256, 3) for p in object_points]).to(dev, torch.float32)
             rgb = torch.cat([x.reshape(-1, 256, 3) for x in xs]).to(dev, torch.float32)
             counts = [int(torch.as_tensor(field(p, "pos")).shape[0]) // 256 for p in object_points]
-            return eng.pointnet_features(pos.contiguous(), rgb.contiguous(), np.concatenate([[0], np.cumsum(counts)]).astype(np.int32))
+            offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+            if train:
+                self._pn_in_engine = any(p.requires_grad for p in self.object_encoder.pointnet.lin2.parameters())
+                self._pn_train_cells = len(counts)
+                return eng.pointnet_features_train(pos.contiguous(), rgb.contiguous(), offs)
+            return eng.pointnet_features(pos.contiguous(), rgb.contiguous(), offs)
         return torch.cat([p if isinstance(p, torch.Tensor) else torch.as_tensor(np.asarray(p)) for p in object_points],
                          dim=0).to(dev, torch.float32).reshape(-1, 256)
 
@@ -297,7 +310,9 @@ class CellRetrievalNetwork(nn.Module):
             skip.append("object_encoder.color_encoder.")
         if "color" not in a.use_features or not co:
             skip.append("object_encoder.color_embedding.")
-        skip.append("object_encoder.pointnet.")  # frozen backbone: not part of the engine's training step
+        if "class" not in a.use_features or ce:
+            skip.append("object_encoder.pointnet.")
+        skip += ["object_encoder.pointnet.class_classifier.", "object_encoder.pointnet.color_classifier."]  # features2 is consumed
         if "position" not in a.use_features:
             skip.append("object_encoder.pos_encoder.")
         if "num" not in a.use_features:
@@ -308,7 +323,9 @@ class CellRetrievalNetwork(nn.Module):
                 continue
             if n.endswith("num_batches_tracked"):
                 continue
-            if isinstance(t, nn.Parameter):
+            if isinstance(t, nn.Parameter) and not t.requires_grad:
+                out[n] = (t.data, None)  # --pointnet_freeze (object_encoder.py:53-55): forward only
+            elif isinstance(t, nn.Parameter):
                 g = self._train_grads.get(n)
                 if g is None or g.shape != t.shape or g.device != t.device:
                     g = self._train_grads[n] = torch.zeros_like(t.data)
@@ -348,12 +365,8 @@ class CellRetrievalNetwork(nn.Module):
         if dev.type != "cuda":
             raise T2LError("encode_objects runs on the MI355X only (model.to('cuda')); there is no CPU fallback")
         eng = self.train_engine()
-        if "class" in self.args.use_features and not bool(getattr(self.args, "class_embed", False)):
-            # the (frozen) PointNet++ weights travel with the eval-path upload: redo it whenever THEY changed
-            # (load_state_dict after the first call), not on every step's running-statistics bump
-            if self._pn_version() != self._pn_weights_version:
-                self.sync_weights()
-        pn = self._pn_features(object_points, eng)
+        self._pn_train_cells = 0
+        pn = self._pn_features(object_points, eng, train=True)  # reads the LIVE backbone tensors (t2l_train_bind)
         if any(getattr(o, "_t2l_feat", None) is None for objs in objects for o in objs):
             packed = packing.pack_cells_gpu(eng, objects, self.object_encoder.known_classes,
                                             self.object_encoder.known_colors, dev)
@@ -373,7 +386,10 @@ class CellRetrievalNetwork(nn.Module):
         used = {k for k, _, _ in self._train_bound}
         for name, m in self.named_modules():  # BatchNorm1d.train() side effect the engine does not see (int64)
             if isinstance(m, nn.BatchNorm1d) and m.num_batches_tracked is not None and name + ".running_mean" in used:
-                m.num_batches_tracked += 1
+                if name.startswith("object_encoder.pointnet."):
+                    m.num_batches_tracked += self._pn_train_cells  # one backbone call per cell (object_encoder.py:92-95)
+                else:
+                    m.num_batches_tracked += 1
         self._train_generation += 1  # running statistics moved: the eval-path weights must be re-folded
         return out
 

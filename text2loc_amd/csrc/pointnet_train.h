@@ -30,7 +30,7 @@ struct PnLevel {
 };
 
 struct PnTrain {
-  bool bound = false, have_forward = false;
+  bool bound = false, trainable = false, have_forward = false;
   char* ws = nullptr;
   size_t ws_cap = 0, ws_off = 0;
   int n_obj = 0, n_cells = 0;
@@ -337,7 +337,8 @@ static void gemm_nn_rows(const float* dY, const float* W, float* dX, size_t M, i
 }
 
 // object_encoder.pointnet.* tensors of the binding: all of them with gradient buffers -> the backbone trains in the engine
-// (their names join the Adam list); none -> it stays frozen / eval-only; anything in between is an error
+// (their names join the Adam list); all without -> frozen (models/object_encoder.py:53-55: requires_grad_(False), but still
+// under model.train(): batch statistics + running-statistics updates in the forward); absent -> no backbone on the path
 static int pn_train_bind(t2l_ctx* ctx, TrainState* st, std::vector<std::string>& adam) {
   const std::string P = "object_encoder.pointnet.";
   const int cin3[4] = {6, 67, 131, 259}, h1[4] = {32, 128, 256, 512}, h2[4] = {64, 128, 256, 1024};
@@ -359,24 +360,29 @@ static int pn_train_bind(t2l_ctx* ctx, TrainState* st, std::vector<std::string>&
   req.push_back({P + "lin1.bias", 512});
   req.push_back({P + "lin2.weight", 256 * 512});
   req.push_back({P + "lin2.bias", 256});
-  int with_grad = 0;
+  int with_grad = 0, present = 0;
   for (auto& r : req) {
     auto it = st->t.find(r.first);
     if (it == st->t.end()) continue;
+    ++present;
     if (it->second.grad) ++with_grad;
   }
-  if (with_grad == 0) return T2L_OK;  // frozen backbone
-  if (with_grad != (int)req.size())
-    return fail(ctx, T2L_EINVAL, "t2l_train_bind: object_encoder.pointnet.* must be bound completely (every sa*/ga/lin1/lin2 tensor with "
-                                 "a gradient buffer) or not at all");
+  if (present == 0) return T2L_OK;  // no backbone in this binding (precomputed features2 / class embedding)
+  const bool trainable = with_grad > 0;
+  if (present != (int)req.size() || (trainable && with_grad != (int)req.size()))
+    return fail(ctx, T2L_EINVAL, "t2l_train_bind: object_encoder.pointnet.* must be bound completely — every sa*/ga/lin1/lin2 tensor, "
+                                 "all of them with gradient buffers (trained jointly) or none (--pointnet_freeze: batch statistics in "
+                                 "the forward, no backward)");
   int rc;
   for (auto& r : req)
-    if ((rc = need(ctx, st, r.first, r.second, true, nullptr))) return rc;
+    if ((rc = need(ctx, st, r.first, r.second, trainable, nullptr))) return rc;
   for (auto& r : bufs)
     if ((rc = need(ctx, st, r.first, r.second, false, nullptr))) return rc;
-  for (auto& r : req) adam.push_back(r.first);
+  if (trainable)
+    for (auto& r : req) adam.push_back(r.first);
   PnTrain* pt = new PnTrain();
   pt->bound = true;
+  pt->trainable = trainable;
   st->pn = pt;
   return T2L_OK;
 }
@@ -572,6 +578,8 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
   TrainState* st = state(ctx);
   PnTrain* pt = st ? pn_state(st) : nullptr;
   if (!pt || !pt->have_forward) return fail(ctx, T2L_ESTATE, "t2l_pointnet_backward: no training-mode forward to differentiate");
+  if (!pt->trainable)
+    return fail(ctx, T2L_ESTATE, "t2l_pointnet_backward: the backbone was bound without gradient buffers (frozen)");
   if (!grad_f2) return fail(ctx, T2L_EINVAL, "t2l_pointnet_backward: null gradient");
   const size_t mark = pt->ws_off;
   const int n_obj = pt->n_obj;

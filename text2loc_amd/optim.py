@@ -1,5 +1,5 @@
 """``optim.Adam(model.parameters(), lr)`` of the reference's training script (training/coarse.py:258) for a
-``text2loc_amd.CellRetrievalNetwork``: the object-branch parameters are stepped by the engine's multi-tensor Adam kernel
+``text2loc_amd.CellRetrievalNetwork``: the object-branch parameters (with the PointNet++ backbone when it trains) are stepped by the engine's multi-tensor Adam kernel
 (t2l_adam_step: one launch over every bound tensor, moments kept in HBM by the library), everything else (the language
 head) by ``torch.optim.Adam`` with the same hyper-parameters. It is a ``torch.optim.Optimizer``, so the reference's
 ``ExponentialLR`` / ``StepLR`` schedulers (training/coarse.py:268-273) drive it unchanged through ``param_groups``.
@@ -15,8 +15,10 @@ class Adam(torch.optim.Optimizer):
         for n, p in model.named_parameters():
             if not p.requires_grad:
                 continue
-            if n.startswith(("object_encoder.", "obj_inter_module.")) and not n.startswith("object_encoder.pointnet."):
-                obj.append(p)
+            if n.startswith(("object_encoder.pointnet.class_classifier.", "object_encoder.pointnet.color_classifier.")):
+                rest.append(p)  # not on the path (features2 is consumed): .grad stays None, torch skips them as in the reference
+            elif n.startswith(("object_encoder.", "obj_inter_module.")):
+                obj.append(p)   # incl. the PointNet++ backbone unless --pointnet_freeze
             else:
                 rest.append(p)
         groups = [{"params": obj, "t2l_engine": True}]
