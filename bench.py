@@ -551,6 +551,32 @@ def secondary_measurements(eng):
     return out
 
 
+def roofline(kname, peak, mult, flops, time_ms, lanes, scan_ms, scan_n, span_ms, span_n, busy_ms, busy_n, serial):
+    achieved = flops / (time_ms * 1e-3) / 1e12 if time_ms > 0 else 0.0
+    out = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+           "executed": achieved * mult, "frac_executed": achieved * mult / peak,
+           "time_basis": ("timed-region wall clock per step (pipelined: kernel spans overlap)" if lanes > 1
+                          else "scan kernel average duration, HIP events over the timed region"),
+           "traffic": pmc_traffic("t2l::" + kname), "traffic_source": PMC_SOURCE,
+           "kernel_ms": scan_ms, "launches_timed": scan_n,
+           "kernel_ms_in_kernel_span": span_ms, "launches_timed_in_kernel_span": span_n,
+           # sum of the launch's workgroup durations / grid (in-kernel stamps, every launch): the GPU time a launch used
+           "kernel_ms_gpu_time": busy_ms, "launches_timed_gpu_time": busy_n,
+           "flops_per_launch": flops,
+           # what the matrix pipe sustains on dense RANDOM f16 operands (power-limited clocks): measured by
+           # tools/pair_probe.hip on this part, bare v_mfma_f32_32x32x16_f16 stream, 1.45-1.53 PFLOP/s
+           "measured_random_data_mfma_ceiling_tflops": 1500.0,
+           "frac_of_measured_ceiling": achieved * mult / 1500.0}
+    if serial is not None:
+        s_scan, s_span, s_busy, s_step = serial
+        alone = flops / (s_scan * 1e-3) / 1e12 if s_scan else 0.0
+        out["kernel_alone"] = {"measured": "stream-ordered loop of this run (--lanes 1 behaviour), HIP events on every 4th launch",
+                               "kernel_ms": s_scan, "kernel_ms_in_kernel_span": s_span, "kernel_ms_gpu_time": s_busy,
+                               "achieved": alone, "frac": alone / peak, "frac_of_measured_ceiling": alone * mult / 1500.0,
+                               "ms_per_step": s_step}
+    return out
+
+
 def main():
     global N_CELLS, N_QUERIES
     ap = argparse.ArgumentParser()
@@ -564,6 +590,10 @@ def main():
     ap.add_argument("--mode", type=int, default=0,
                     help="search_mode: 0 = f16 scan (default), 1 = f32 scan, 2 = split-bf16 scan")
     ap.add_argument("--nsplit", type=int, default=0, help="override the scan kernel's DB split count (0 = auto)")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="1 (default): every step stream-ordered behind the previous one; the pipelined form of the same loop "
+                         "is measured beside it (`pipelined`). n > 1 (N=1 only): the TIMED steps themselves pipeline over n "
+                         "internal streams of the engine (t2l_search_join closes the timed region)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -622,24 +652,65 @@ def main():
     d_qs = [torch.from_numpy(np.ascontiguousarray(b[0])).cuda() for b in batches]
     d_q = d_qs[0]
     lo, hi = searcher.set_db_shard(d_db)
-    eng.set_option("profile_events", EVENT_EVERY)
+    eng.set_option("profile_events", 97)  # outside the timed region: rare (the first samples create the event rings — not in the timed steps)
     eng.set_option("search_mode", args.mode)
     if args.nsplit:
         eng.set_option("search_nsplit", args.nsplit)
+    # N=1: the steps are independent jobs (a different query batch each) — they pipeline over `--lanes` internal streams of the
+    # engine (include/t2l.h: t2l_search only enqueues, t2l_search_join orders every result into the stream before the timed
+    # region closes). Output buffers rotate over 12 sets so that two calls sharing a set also share a lane (12 % lanes == 0).
+    lanes = args.lanes if world == 1 else 1
+    N_OUT = 12
+    outs = [(torch.empty((N_QUERIES, TOPK), dtype=torch.int32, device="cuda"),
+             torch.empty((N_QUERIES, TOPK), dtype=torch.float64, device="cuda")) for _ in range(N_OUT)]
+
     def step(i):
+        if lanes > 1:
+            return eng.search(d_qs[i % N_BATCH], TOPK, out=outs[i % N_OUT], join=False)
         return searcher.search(d_qs[i % N_BATCH], TOPK)
 
+    # the same loop stream-ordered (lanes = 1), for the record: what one call costs when the next one waits for it
+    serial_ms = None
+    if lanes > 1:
+        for i in range(1500):
+            searcher.search(d_qs[i % N_BATCH], TOPK)
+        eng.set_option("profile_events", 4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_serial = max(20, args.steps)
+        for i in range(n_serial):
+            searcher.search(d_qs[i % N_BATCH], TOPK)
+        torch.cuda.synchronize()
+        serial_ms = 1e3 * (time.perf_counter() - t0) / n_serial
+        serial_scan_ms, _ = eng.kernel_stats("search_scan")
+        serial_span_ms, _ = eng.kernel_stats("search_scan_span")
+        serial_busy_ms, _ = eng.kernel_stats("search_scan_busy")
+        eng.kernel_stats("search_rerank")
+        eng.set_option("profile_events", 97)
+        eng.set_option("search_lanes", lanes)
+    # An idle MI355X needs ~40 ms of continuous load to reach its sustained clocks (measured: 56.6 -> 46.8 us per step over the
+    # first 40 ms of this very loop): untimed ramp steps first, so that a short run (--steps 20 is 1 ms of GPU time) measures the
+    # steady state and not the power-state ramp. Then the W warmup steps, then the timed K.
+    RAMP_STEPS = max(0, 1500 - args.warmup)
+    for i in range(RAMP_STEPS):
+        step(i)
     for i in range(args.warmup):
         step(i)
-    for nme in ("search_scan", "search_rerank", "search_scan_span"):
-        eng.kernel_stats(nme)
-    eng.set_option("profile_events", EVENT_EVERY)  # restart the sampling phase: the first timed step is a bracketed one
+    if lanes > 1:
+        eng.search_join()
+    # forget the samples so far and restart the sampling phase — host-only, the stream keeps running: the first timed step is a
+    # bracketed one (pipelined: sparse — the in-kernel stamps cover every launch)
+    eng.set_option("stats_reset", 1)
+    eng.set_option("profile_rerank", 0)  # timed region: sampled launches bracket the dominant kernel only; the re-rank is timed below
+    eng.set_option("profile_events", EVENT_EVERY if lanes == 1 else max(10, args.steps // 8))
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         idx, sc = step(i)
+    if lanes > 1:
+        eng.search_join()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -649,15 +720,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     scan_ms, scan_n = eng.kernel_stats("search_scan")
-    rerank_ms, _ = eng.kernel_stats("search_rerank")
+    eng.set_option("profile_rerank", 1)
     span_ms, span_n = eng.kernel_stats("search_scan_span")
-    eng.set_option("profile_events", 1)  # the side measurements below bracket every launch
+    busy_ms, busy_n = eng.kernel_stats("search_scan_busy")
     fallbacks = eng.search_fallbacks()
     rescored = eng.search_rescored()
     counters = eng.search_counters()
+    # the re-rank kernel's duration: the same steps again right behind the timed region, every 4th launch bracketed
+    eng.set_option("search_lanes", 1)
+    eng.set_option("profile_events", 4)
+    for i in range(64):
+        searcher.search(d_qs[i % N_BATCH], TOPK)
+    torch.cuda.synchronize()
+    rerank_ms, _ = eng.kernel_stats("search_rerank")
+    eng.kernel_stats("search_scan")
+    eng.set_option("profile_events", 1)  # the side measurements below bracket every launch
 
+    # what the last N_BATCH pipelined steps left in their output sets (compared with stream-ordered calls below)
+    timed_out = {}
+    if lanes > 1:
+        for i in range(max(0, args.steps - N_BATCH), args.steps):
+            timed_out[i % N_BATCH] = (outs[i % N_OUT][0].clone(), outs[i % N_OUT][1].clone())
+        eng.set_option("search_lanes", 1)
     # parity, outside the timed region: EVERY (id, score) of every rotated batch vs the float64 C oracle (all Q x K pairs)
     parity, max_score_err, recall1, n_checked = True, 0.0, [], 0
+    pipelined_equal = True
+    serial_results = {}
     if rank == 0:
         from oracle import c_oracle
         from concurrent.futures import ThreadPoolExecutor
@@ -668,6 +756,10 @@ def main():
                 if bi != (args.steps - 1) % N_BATCH:
                     continue
                 gi, gs = idx, sc
+            serial_results[bi] = (gi, gs)
+            if bi in timed_out:  # the timed (pipelined) loop's own results are the ones checked
+                pipelined_equal = pipelined_equal and bool(torch.equal(timed_out[bi][0], gi) and torch.equal(timed_out[bi][1], gs))
+                gi, gs = timed_out[bi]
             got_i, got_s = gi.cpu().numpy().astype(np.int64), gs.cpu().numpy()
             chunks = np.array_split(np.arange(N_QUERIES), nthr)
             with ThreadPoolExecutor(nthr) as ex:  # ctypes releases the GIL: the scalar oracle runs on nthr host cores
@@ -678,6 +770,40 @@ def main():
             max_score_err = max(max_score_err, float(np.abs(got_s - rsc).max()))
             recall1.append(float((got_i[:, 0] == btarget).mean()))
             n_checked += int(ridx.size)
+
+    # N=1, outside the timed region: the same loop PIPELINED (include/t2l.h, t2l_search_join): consecutive steps are independent
+    # jobs, so step i runs its scan -> re-rank chain on internal stream i % 3 of the engine and the chains overlap. Reported
+    # beside `value` (whose steps are stream-ordered, so that its kernel durations mean what rocprofv3 reports).
+    pipelined = None
+    if world == 1 and lanes == 1 and rank == 0:
+        P_LANES = 3
+        eng.set_option("profile_events", 0)
+        eng.set_option("search_lanes", P_LANES)
+        n_pipe = max(400, args.steps)
+        for i in range(1500 + 24):  # (the GPU idled during the CPU oracle above: ramp its clocks again)
+            eng.search(d_qs[i % N_BATCH], TOPK, out=outs[i % N_OUT], join=False)
+        eng.search_join()
+        eng.set_option("stats_reset", 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_pipe):
+            eng.search(d_qs[i % N_BATCH], TOPK, out=outs[i % N_OUT], join=False)
+        eng.search_join()
+        torch.cuda.synchronize()
+        tp = (time.perf_counter() - t0) / n_pipe
+        p_span, _ = eng.kernel_stats("search_scan_span")
+        p_busy, _ = eng.kernel_stats("search_scan_busy")
+        same = True
+        for i in range(n_pipe - N_BATCH, n_pipe):
+            same = same and bool(torch.equal(outs[i % N_OUT][0], serial_results[i % N_BATCH][0]) and
+                                 torch.equal(outs[i % N_OUT][1], serial_results[i % N_BATCH][1]))
+        eng.set_option("search_lanes", 1)
+        eng.set_option("profile_events", 1)
+        pipelined = {"lanes": P_LANES, "steps": n_pipe, "ms_per_step": tp * 1e3, "queries_per_s": N_QUERIES / tp,
+                     "results_equal_stream_ordered": same,
+                     "scan_kernel_ms_overlapped_span": p_span, "scan_kernel_ms_gpu_time": p_busy,
+                     "note": "kernels of neighbouring steps share the chip: a launch's start -> end span overlaps its neighbours'; "
+                             "gpu_time = mean workgroup duration (in-kernel stamps)"}
 
     # N>1 only, outside the timed region: the OTHER use of N GPUs for a DB this small — replicate the 11.5 MB DB, split the
     # queries, no data-path collective (one all_gather of the results so every rank ends with all [Q,K] rows). Reported
@@ -713,7 +839,6 @@ def main():
         ms = 1e3 * elapsed / args.steps
         n_local = hi - lo
         flops = 2.0 * N_QUERIES * n_local * DIM  # algorithmic FLOPs of one scan launch on this rank's shard
-        achieved = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
         if args.mode == 1:
             kname, peak, dtype, mult = "scan_kernel<16>", F32_MFMA_PEAK_TFLOPS, "f32", 1
         elif args.mode == 2:
@@ -734,26 +859,31 @@ def main():
                                       1: "f32 MFMA candidate scan",
                                       2: "split-bf16 (3 MFMAs per product) candidate scan (f32 accumulate)"}[args.mode]
                                      + " -> float64 re-rank + certificate (ids and scores are the float64 ranking)",
-                       "parallelism": f"db-row-shard x{world}" if world > 1 else "single-gpu"},
-            # achieved = ALGORITHMIC flops (2*Q*N*D) / kernel time; `peak` is the dense MFMA peak of the dtype the pipe runs
-            # in (f16 and bf16 share the 2.5 PF rate). In --mode 2 every product is 3 bf16 MFMA products (hi*hi + hi*lo +
-            # lo*hi): `executed` / `frac_executed` give the matrix pipe's view (mult = 1 for the f16 and f32 scans).
-            "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved,
-                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "executed": achieved * mult, "frac_executed": achieved * mult / peak,
-                         "traffic": pmc_traffic("t2l::" + kname), "traffic_source": PMC_SOURCE,
-                         "kernel_ms": scan_ms, "launches_timed": scan_n,
-                         "kernel_ms_in_kernel_span": span_ms, "launches_timed_in_kernel_span": span_n,
-                         "flops_per_launch": flops,
-                         # what the matrix pipe sustains on dense RANDOM f16 operands (power-limited clocks): measured by
-                         # tools/pair_probe.hip on this part, bare v_mfma_f32_32x32x16_f16 stream, 1.45-1.53 PFLOP/s
-                         "measured_random_data_mfma_ceiling_tflops": 1500.0,
-                         "frac_of_measured_ceiling": achieved * mult / 1500.0},
+                       "parallelism": f"db-row-shard x{world}" if world > 1 else "single-gpu",
+                       "untimed_ramp_steps_before_warmup": RAMP_STEPS,
+                       "pipelining": (f"{lanes} lanes: step i runs its scan -> re-rank chain on internal stream i % {lanes}; "
+                                      "one t2l_search_join before the closing synchronize") if lanes > 1 else "none (stream-ordered steps)"},
+            # achieved = ALGORITHMIC flops (2*Q*N*D) per launch / time. Stream-ordered steps: time = the scan kernel's average
+            # duration (HIP events on sampled launches of the timed region; rocprofv3 agrees, profiles/). PIPELINED steps
+            # (default): kernels of neighbouring steps share the chip, so a launch's start -> end span (what events and
+            # rocprofv3 report: `kernel_ms`) overlaps its neighbours' and no longer measures the kernel; `achieved` is then the
+            # conservative whole-job figure — scan flops of the timed region / its wall clock (the re-rank's share of the time
+            # included) — and `kernel_alone` carries the kernel by itself (stream-ordered loop of this same run: HIP events,
+            # in-kernel stamps), the number that compares with rocprofv3 of `bench.py --lanes 1`.
+            # `peak` is the dense MFMA peak of the dtype the pipe runs in (f16 and bf16 share the 2.5 PF rate). In --mode 2
+            # every product is 3 bf16 MFMA products: `executed` / `frac_executed` give the matrix pipe's view.
+            "roofline": roofline(kname, peak, mult, flops, ms if lanes > 1 else scan_ms, lanes, scan_ms, scan_n, span_ms, span_n,
+                                 busy_ms, busy_n,
+                                 None if serial_ms is None else (serial_scan_ms, serial_span_ms, serial_busy_ms, serial_ms)),
             "kernels_ms": {"search_scan": scan_ms, "search_rerank": rerank_ms},  # the whole step is these two launches
+            # the same steps stream-ordered (lanes = 1): what one call costs when the next one waits for it
+            "stream_ordered": None if serial_ms is None else {"ms_per_step": serial_ms, "queries_per_s": N_QUERIES / (serial_ms * 1e-3)},
+            "pipelined": pipelined,
             "secondary": secondary,
             "parity": {"ids_equal_float64_oracle": parity, "pairs_checked": n_checked,
                        "checked": f"all {N_QUERIES} x {TOPK} (id, score) pairs of {len(recall1)} query batch(es) vs the C oracle",
                        "max_abs_score_err": max_score_err, "recall_at_1_planted": recall1,
+                       "pipelined_results_equal_stream_ordered": pipelined_equal if lanes > 1 else None,
                        "exact_fallback_queries_last_step": fallbacks,
                        "first_certificate_failures_last_step": rescored, "counters_last_step": counters},
             "ranks_seen": ranks_seen, "query_batches_rotated": N_BATCH,

@@ -215,7 +215,7 @@ def test_model_train_step_reaches_the_backbone():
     opt2.zero_grad()
     rm0 = frozen.object_encoder.pointnet.sa2.point_conv.local_nn[1][1].running_mean.clone()
     out2 = frozen.encode_objects(objects, batches)
-    assert float((out2 - out).abs().max()) < 1e-6  # same forward as the trainable model's first step
+    assert float((out2 - out).detach().abs().max()) < 1e-6  # same forward as the trainable model's first step
     (out2 * R).sum().backward()
     opt2.step()
     fp = dict(frozen.named_parameters())

@@ -390,3 +390,54 @@ def test_auto_mode_moves_a_clustered_database_to_the_exact_stage():
         assert e.kernel_stats("search_exact")[1] == 0  # released again
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("lanes", [2, 3, 4])
+def test_pipelined_searches_equal_stream_ordered_ones(lanes):
+    """t2l_set_option("search_lanes", n) + t2l_search_join: consecutive calls run on internal streams and overlap; every call's
+    (ids, scores) are those of the stream-ordered call, whatever mix of batch sizes (small batches and the streaming scan
+    join and run in the caller's stream), and the database may be replaced while calls are in flight."""
+    import torch
+    from oracle import c_oracle
+    from text2loc_amd.engine import Engine
+
+    eng = Engine(0)
+    db, q0, _ = synth.make_retrieval_problem(11259, 4096, seed=3, noise=0.5)
+    batches = [q0, synth.make_queries_for(db, 1000, seed=5, noise=0.5)[0], synth.make_queries_for(db, 257, seed=6, noise=2.0)[0],
+               synth.make_queries_for(db, 31, seed=7, noise=0.5)[0], synth.make_queries_for(db, 4096, seed=8, noise=0.5)[0]]
+    d_db = torch.from_numpy(db).cuda()
+    d_q = [torch.from_numpy(np.ascontiguousarray(b)).cuda() for b in batches]
+    eng.db_set(d_db)
+    ref = [tuple(t.clone() for t in eng.search(q, 10)) for q in d_q]
+    torch.cuda.synchronize()
+    ridx, rsc = c_oracle.retrieve_topk(db, batches[1], 10)
+    assert np.array_equal(ref[1][0].cpu().numpy(), ridx)
+    eng.set_option("search_lanes", lanes)
+    n_calls = 37
+    outs = [eng.search(d_q[i % len(d_q)], 10, join=False) for i in range(n_calls)]
+    eng.search_join()
+    torch.cuda.synchronize()
+    for i, (idx, sc) in enumerate(outs):
+        assert torch.equal(idx, ref[i % len(d_q)][0]) and torch.equal(sc, ref[i % len(d_q)][1]), i
+    # join=True (the default) keeps the stream-ordered contract call by call
+    idx, sc = eng.search(d_q[0], 10)
+    assert torch.equal(idx.cpu(), ref[0][0].cpu())
+    # a new database while calls are in flight: db_set orders itself behind them
+    db2 = np.ascontiguousarray(db[::-1])
+    pending = [eng.search(d_q[0], 10, join=False) for _ in range(5)]
+    eng.db_set(torch.from_numpy(db2).cuda())
+    after = [eng.search(d_q[4], 10, join=False) for _ in range(3)]
+    eng.search_join()
+    torch.cuda.synchronize()
+    for idx, sc in pending:
+        assert torch.equal(idx, ref[0][0])
+    r2, _ = c_oracle.retrieve_topk(db2, batches[4], 10)
+    for idx, sc in after:
+        assert np.array_equal(idx.cpu().numpy(), r2)
+    c = eng.search_counters()
+    assert c["valu_exact_scans"] == 0
+    eng.set_option("search_lanes", 1)
+    idx, sc = eng.search(d_q[4], 10)
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), r2)
+    eng.close()

@@ -85,8 +85,10 @@ int t2l_create(t2l_ctx** out, int device_id) {
     if (hipHostGetDevicePointer((void**)&ctx->host_stat_dev, ctx->host_stat, 0) != hipSuccess) ctx->host_stat_dev = nullptr;
   }
   (void)hipMemset(ctx->fb_count, 0, 128 * sizeof(int32_t));
-  if (hipMalloc(&ctx->scan_span, sizeof(unsigned long long) * 2 * kSpanRing) == hipSuccess)
-    (void)hipMemset(ctx->scan_span, 0, sizeof(unsigned long long) * 2 * kSpanRing);
+  if (hipMalloc(&ctx->scan_span, sizeof(unsigned long long) * 2 * kSpanWgs * kSpanRing) == hipSuccess) {
+    (void)hipMemset(ctx->scan_span, 0, sizeof(unsigned long long) * 2 * kSpanWgs * kSpanRing);
+    ctx->span_grid = new unsigned[kSpanRing]();
+  }
   else
     ctx->scan_span = nullptr;
   *out = ctx;
@@ -104,7 +106,9 @@ void t2l_destroy(t2l_ctx* ctx) {
   for (void* p : {(void*)ctx->db, (void*)ctx->db_split, (void*)ctx->db_half, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
                   (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count, ctx->reduce_ws, (void*)ctx->scan_span})
     if (p) (void)hipFree(p);
+  delete[] ctx->span_grid;
   if (ctx->host_stat) (void)hipHostFree(ctx->host_stat);
+  free_lanes(ctx);
   for (auto& kv : ctx->events) {
     for (hipEvent_t ev : kv.second.a) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : kv.second.b) (void)hipEventDestroy(ev);
@@ -166,6 +170,10 @@ int t2l_db_set(t2l_ctx* ctx, const float* emb, int64_t n_rows, int64_t row_offse
   if (n_rows + row_offset >= (int64_t)INT32_MAX) return fail(ctx, T2L_EINVAL, "t2l_db_set: row ids must fit int32");
   T2L_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = (hipStream_t)stream;
+  {  // pipelined searches still in flight read the planes this call rewrites
+    const int rc = search_join_impl(ctx, s);
+    if (rc != T2L_OK) return rc;
+  }
   const int64_t pad = (n_rows + kTileRows - 1) / kTileRows * kTileRows;
   if (pad > ctx->db_cap) {
     T2L_HIP(ctx, hipStreamSynchronize(s));
@@ -208,7 +216,13 @@ int t2l_search(t2l_ctx* ctx, const float* queries, int32_t n_queries, int32_t k,
     // an empty shard is legal (ragged sharding); it answers -1 / -inf everywhere
   }
   T2L_HIP(ctx, hipSetDevice(ctx->device));
-  return search_impl(ctx, queries, n_queries, k, out_idx, out_score, (hipStream_t)stream);
+  return search_lanes_impl(ctx, queries, n_queries, k, out_idx, out_score, (hipStream_t)stream);
+}
+
+int t2l_search_join(t2l_ctx* ctx, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return search_join_impl(ctx, (hipStream_t)stream);
 }
 
 int t2l_merge_topk(t2l_ctx* ctx, const int32_t* idx, const double* score, int32_t parts, int32_t n_queries, int32_t k,
@@ -243,12 +257,26 @@ int t2l_merge_pairs(t2l_ctx* ctx, const double* pairs, int32_t parts, int32_t n_
   return merge_pairs_impl(ctx, pairs, parts, n_queries, k, out_idx, out_score, (hipStream_t)stream);
 }
 
+// counters of the last search of the context's own scratch set, or — with lanes — of the last search of EVERY lane, summed
+static hipError_t read_counters(t2l_ctx* ctx, int32_t* out8) {
+  hipError_t e = hipMemcpy(out8, ctx->fb_count, 8 * sizeof(int32_t), hipMemcpyDeviceToHost);
+  if (e != hipSuccess || ctx->n_lanes <= 1) return e;
+  for (int i = 0; i < 8; ++i) out8[i] = 0;
+  for (int l = 0; l < ctx->n_lanes; ++l) {
+    if (!ctx->lanes[l].ready) continue;
+    int32_t c[8];
+    if ((e = hipMemcpy(c, ctx->lanes[l].fb_count, sizeof(c), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+    for (int i = 0; i < 8; ++i) out8[i] += c[i];
+  }
+  return hipSuccess;
+}
+
 int t2l_search_fallbacks(t2l_ctx* ctx, int32_t* out_count) {
   if (!ctx || !out_count) return T2L_EINVAL;
   T2L_HIP(ctx, hipSetDevice(ctx->device));
   T2L_HIP(ctx, hipDeviceSynchronize());
   int32_t c[8];
-  T2L_HIP(ctx, hipMemcpy(c, ctx->fb_count, sizeof(c), hipMemcpyDeviceToHost));
+  T2L_HIP(ctx, read_counters(ctx, c));
   *out_count = c[0] + (c[7] - c[6]);  // float64 VALU scans + queries the float64 MFMA stage certified (search_exact.hip)
   return T2L_OK;
 }
@@ -267,7 +295,7 @@ int t2l_search_counters(t2l_ctx* ctx, int32_t* out8) {
   if (!ctx || !out8) return T2L_EINVAL;
   T2L_HIP(ctx, hipSetDevice(ctx->device));
   T2L_HIP(ctx, hipDeviceSynchronize());
-  T2L_HIP(ctx, hipMemcpy(out8, ctx->fb_count, 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  T2L_HIP(ctx, read_counters(ctx, out8));
   return T2L_OK;
 }
 
@@ -275,7 +303,9 @@ int t2l_search_rescored(t2l_ctx* ctx, int32_t* out_count) {
   if (!ctx || !out_count) return T2L_EINVAL;
   T2L_HIP(ctx, hipSetDevice(ctx->device));
   T2L_HIP(ctx, hipDeviceSynchronize());
-  T2L_HIP(ctx, hipMemcpy(out_count, ctx->fb_count + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
+  int32_t c[8];
+  T2L_HIP(ctx, read_counters(ctx, c));
+  *out_count = c[1];
   return T2L_OK;
 }
 
@@ -395,6 +425,20 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     ctx->train_bf16 = value != 0;
   } else if (!strcmp(name, "train_keep_adam_state")) {
     ctx->train_keep_adam = value != 0;
+  } else if (!strcmp(name, "profile_rerank")) {
+    ctx->profile_rerank = value != 0;
+  } else if (!strcmp(name, "stats_reset")) {  // forget every kernel-time sample so far (host-only: no stream operation, no sync)
+    for (auto& kv : ctx->events) {
+      kv.second.count = 0;
+      kv.second.calls = 0;
+      kv.second.open = false;
+    }
+    ctx->span_read = ctx->busy_read = ctx->span_seq;
+  } else if (!strcmp(name, "search_lanes")) {
+    if (value < 1 || value > t2l_ctx::kMaxLanes) return fail(ctx, T2L_EINVAL, "search_lanes must be 1..4");
+    T2L_HIP(ctx, hipDeviceSynchronize());
+    for (auto& L : ctx->lanes) L.pending = false;
+    ctx->n_lanes = (int)value;
   } else if (!strcmp(name, "stream_min_rows")) {
     ctx->stream_min_rows = (int)value;
   } else if (!strcmp(name, "pointnet_pyg_self_loops")) {
@@ -413,22 +457,38 @@ int t2l_kernel_stats(t2l_ctx* ctx, const char* name, float* out_avg_ms, int32_t*
   if (!ctx || !name || !out_avg_ms || !out_count) return T2L_EINVAL;
   *out_avg_ms = 0.f;
   *out_count = 0;
-  if (!strcmp(name, "search_scan_span")) {  // in-kernel stamps of the paired scan: first workgroup start -> last workgroup end
-    if (!ctx->scan_span || ctx->span_seq == ctx->span_read) return T2L_OK;
+  const bool busy = !strcmp(name, "search_scan_busy");
+  if (busy || !strcmp(name, "search_scan_span")) {
+    // in-kernel stamps of the paired scan. span: first workgroup start -> last workgroup end of a launch; busy: the sum of its
+    // workgroups' own durations / grid = the GPU time it used (equal to the span when it has the chip to itself, the one
+    // that still means something when launches of several lanes overlap). Each name keeps its own read cursor.
+    unsigned& cursor = busy ? ctx->busy_read : ctx->span_read;
+    if (!ctx->scan_span || ctx->span_seq == cursor) return T2L_OK;
     T2L_HIP(ctx, hipDeviceSynchronize());
-    std::vector<unsigned long long> h(2 * kSpanRing);
+    std::vector<unsigned long long> h((size_t)2 * kSpanWgs * kSpanRing);
     T2L_HIP(ctx, hipMemcpy(h.data(), ctx->scan_span, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
-    const unsigned first = ctx->span_seq - ctx->span_read > (unsigned)kSpanRing ? ctx->span_seq - kSpanRing + 1 : ctx->span_read + 1;
+    const unsigned first = ctx->span_seq - cursor > (unsigned)kSpanRing ? ctx->span_seq - kSpanRing + 1 : cursor + 1;
     double sum = 0.0;
     int n = 0;
     const unsigned long long tmask = (1ull << 40) - 1;
     for (unsigned q = first; q <= ctx->span_seq; ++q) {
-      const unsigned long long a = h[2 * (q % kSpanRing)], b = h[2 * (q % kSpanRing) + 1];
-      if ((a >> 40) != (q & 0xFFFFFFu) || (b >> 40) != (q & 0xFFFFFFu)) continue;  // slot overwritten or launch not finished
-      sum += (double)(((b & tmask) - (a & tmask)) & tmask) * 1e-5;  // 100 MHz ticks -> ms
+      const unsigned long long* e = &h[(size_t)2 * kSpanWgs * (q % kSpanRing)];
+      const unsigned grid = ctx->span_grid[q % kSpanRing];
+      if (!grid) continue;
+      unsigned long long t_min = ~0ull, t_max = 0, total = 0;
+      bool ok = true;
+      for (unsigned w = 0; w < grid && ok; ++w) {
+        const unsigned long long a = e[2 * w], b = e[2 * w + 1];
+        ok = (a >> 40) == (q & 0xFFFFFFu) && (b >> 40) == (q & 0xFFFFFFu);  // else: slot overwritten or launch not finished
+        t_min = std::min(t_min, a & tmask);
+        t_max = std::max(t_max, b & tmask);
+        total += ((b & tmask) - (a & tmask)) & tmask;
+      }
+      if (!ok) continue;
+      sum += (busy ? (double)total / grid : (double)((t_max - t_min) & tmask)) * 1e-5;  // 100 MHz ticks -> ms
       ++n;
     }
-    ctx->span_read = ctx->span_seq;
+    cursor = ctx->span_seq;
     if (n) *out_avg_ms = (float)(sum / n);
     *out_count = n;
     return T2L_OK;

@@ -532,11 +532,11 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
   asm volatile("" : "+v"(vmask));
   if (blockIdx.x == 0) reset_counts(fb_count, zero_counts, tid);
   if (steps == 0) return;  // (the host never launches an empty split)
-  // always-on span stamps (t2l_kernel_stats "search_scan_span"): workgroup 0 stores the launch's start, every workgroup's
-  // end goes through ONE atomic max — (launch sequence << 40 | 100 MHz ticks), so a newer launch overrides the slot's old
-  // content without anybody clearing it. Costs no packet on the stream, unlike an event pair around the kernel.
-  if (span && blockIdx.x == 0 && threadIdx.x == 0)
-    span[0] = ((unsigned long long)span_seq << 40) | ((unsigned long long)__builtin_amdgcn_s_memrealtime() & ((1ull << 40) - 1));
+  // always-on stamps (t2l_kernel_stats "search_scan_span" / "search_scan_busy"): every workgroup stores its own start and end
+  // (launch sequence << 40 | 100 MHz ticks) in its own slot of the launch's ring entry — plain stores, no packet on the stream
+  // (an event pair around the kernel costs ~6 us) and no atomics (256 workgroups meeting in ONE atomic at the kernel's end
+  // cost ~3 us of kernel completion, measured). The host reduces: span = max end - min start, busy = mean (end - start).
+  const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();  // (scalar: lives in SGPRs)
 #ifdef T2L_STAMPS
 #define T2L_STAMP(k)                                                                                                   \
   if (tid == 0) {                                                                                                      \
@@ -697,8 +697,10 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
 #pragma unroll
     for (int i = 0; i < LL; ++i) out[i] = w.ls1[i];
   }
-  if (span && threadIdx.x == 0)
-    atomicMax(span + 1, ((unsigned long long)span_seq << 40) | ((unsigned long long)__builtin_amdgcn_s_memrealtime() & ((1ull << 40) - 1)));
+  if (span && threadIdx.x == 0) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), tag = (unsigned long long)span_seq << 40, tm = (1ull << 40) - 1;
+    *reinterpret_cast<ulonglong2*>(span + 2 * blockIdx.x) = make_ulonglong2(tag | (wg_t0 & tm), tag | (t1 & tm));
+  }
   T2L_STAMP(3);
 }
 
@@ -1268,7 +1270,8 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
     static bool once = (allow_lds(&scanp_kernel<LL, 4>, (size_t)4 * 2 * kHalfTileBytes), true);
     (void)once;
     const unsigned span_seq = ++ctx->span_seq;
-    unsigned long long* span = ctx->scan_span ? ctx->scan_span + 2 * (span_seq % kSpanRing) : nullptr;
+    unsigned long long* span = ctx->scan_span && grid.x <= (unsigned)kSpanWgs ? ctx->scan_span + (size_t)2 * kSpanWgs * (span_seq % kSpanRing) : nullptr;
+    if (ctx->span_grid) ctx->span_grid[span_seq % kSpanRing] = span ? grid.x : 0;
     hipEvent_t ea, eb;
     if (event_pair(ctx, "search_scan", &ea, &eb))  // sampled launch: the dispatch carries its own start / stop events
       hipExtLaunchKernelGGL((scanp_kernel<LL, 4>), grid, dim3(512), (uint32_t)lds, s, ea, eb, 0u, dbh, n_rows, n_tiles, code_bits,
@@ -1316,7 +1319,7 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
   // their own re-rank workgroup (wg_exact_scan) — there is no separate fallback launch to pay for when, as usual, there
   // are none. (Heavy mode: they are deferred to the float64 MFMA stage instead, search_exact.hip.)
   hipEvent_t ea, eb;
-  if (event_pair(ctx, "search_rerank", &ea, &eb))
+  if (ctx->profile_rerank && event_pair(ctx, "search_rerank", &ea, &eb))
     hipExtLaunchKernelGGL((rerank_kernel<LL, L>), dim3((Q + 3) / 4), dim3(256), 0u, s, ea, eb, 0u, db, q, Q, K, parts, code_bits,
                           (const float*)ctx->cand_score, row_offset, eps_rel, (const float*)ctx->db_norm_max, half_mode, out_idx,
                           out_score, ctx->flags, ctx->fb_count, eps_probe, __builtin_inff(), n_rows, defer, stat_mode,
@@ -1449,6 +1452,76 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
   }
   if (n_seg > 1) return merge_impl(ctx, ctx->seg_idx, ctx->seg_score, n_seg, Q, K, out_idx, out_score, s);
   return T2L_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lanes: pipelined independent searches (t2l_internal.h). Measured alternatives: all scans on one stream and the re-ranks on a
+// second one needs two cross-stream events per call on the scan stream — 59 us per call instead of 42 (a dependent event
+// hop costs more than the re-rank it hides); self-contained chains need none.
+// ------------------------------------------------------------------------------------------------
+static void swap_lane(t2l_ctx* ctx, t2l_ctx::SearchLane& L) {
+  std::swap(ctx->cand_score, L.cand_score);
+  std::swap(ctx->cand_cap, L.cand_cap);
+  std::swap(ctx->flags, L.flags);
+  std::swap(ctx->flag_cap, L.flag_cap);
+  std::swap(ctx->fb_count, L.fb_count);
+  std::swap(ctx->host_stat, L.host_stat);
+  std::swap(ctx->host_stat_dev, L.host_stat_dev);
+  std::swap(ctx->stat_seen, L.stat_seen);
+}
+
+int search_join_impl(t2l_ctx* ctx, hipStream_t s) {
+  for (auto& L : ctx->lanes) {
+    if (!L.pending) continue;
+    T2L_HIP(ctx, hipEventRecord(L.done, L.stream));
+    T2L_HIP(ctx, hipStreamWaitEvent(s, L.done, 0));
+    L.pending = false;
+  }
+  return T2L_OK;
+}
+
+void free_lanes(t2l_ctx* ctx) {
+  for (auto& L : ctx->lanes) {
+    for (void* p : {(void*)L.cand_score, (void*)L.flags, (void*)L.fb_count})
+      if (p) (void)hipFree(p);
+    if (L.host_stat) (void)hipHostFree(L.host_stat);
+    if (L.stream) (void)hipStreamDestroy(L.stream);
+    if (L.done) (void)hipEventDestroy(L.done);
+    L = t2l_ctx::SearchLane();
+  }
+  if (ctx->lane_fork) (void)hipEventDestroy(ctx->lane_fork);
+  ctx->lane_fork = nullptr;
+}
+
+int search_lanes_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s) {
+  // one launch pair per call is what pipelines; everything else (small batches on the streaming scan, multi-segment shards,
+  // databases in heavy mode with their extra stages, empty shards) runs in the caller's stream after a join
+  const bool plain = ctx->n_lanes <= 1 || Q < 256 || ctx->heavy || ctx->db_rows <= 0 || (int)ctx->db_rows > kSegmentRows;
+  if (plain) {
+    int rc = search_join_impl(ctx, s);
+    return rc != T2L_OK ? rc : search_impl(ctx, q, Q, K, out_idx, out_score, s);
+  }
+  t2l_ctx::SearchLane& L = ctx->lanes[ctx->lane_next++ % (unsigned)ctx->n_lanes];
+  if (!L.ready) {
+    T2L_HIP(ctx, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    T2L_HIP(ctx, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+    if (!ctx->lane_fork) T2L_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_fork, hipEventDisableTiming));
+    T2L_HIP(ctx, hipMalloc(&L.fb_count, 128 * sizeof(int32_t)));
+    T2L_HIP(ctx, hipMemset(L.fb_count, 0, 128 * sizeof(int32_t)));
+    if (hipHostMalloc((void**)&L.host_stat, 8 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess) {
+      for (int i = 0; i < 8; ++i) L.host_stat[i] = 0;
+      if (hipHostGetDevicePointer((void**)&L.host_stat_dev, L.host_stat, 0) != hipSuccess) L.host_stat_dev = nullptr;
+    }
+    L.ready = true;
+  }
+  // the queries (and whatever else the caller queued) are ordered before the lane's chain
+  T2L_HIP(ctx, hipEventRecord(ctx->lane_fork, s));
+  T2L_HIP(ctx, hipStreamWaitEvent(L.stream, ctx->lane_fork, 0));
+  swap_lane(ctx, L);
+  const int rc = search_impl(ctx, q, Q, K, out_idx, out_score, L.stream);
+  swap_lane(ctx, L);
+  L.pending = true;
+  return rc;
 }
 
 }  // namespace t2l

@@ -29,7 +29,8 @@ constexpr int kMaxParts = 64;                      // per-query candidate partit
 // Per-kernel timing: a ring of hipEvent pairs recorded on the caller's stream (no sync when recording);
 // t2l_kernel_stats() reads them back after the caller's own synchronisation point.
 constexpr int kEventRing = 512;
-constexpr int kSpanRing = 256;  // in-kernel span stamps of the last 256 paired-scan launches (search.hip)
+constexpr int kSpanRing = 64;   // in-kernel stamps of the last 64 paired-scan launches (search.hip) ...
+constexpr int kSpanWgs = 512;   // ... of up to 512 workgroups each (larger grids are not stamped)
 struct EventRing {
   std::vector<hipEvent_t> a, b;
   int head = 0;   // next slot
@@ -95,9 +96,29 @@ struct t2l_ctx {
   int32_t* host_stat = nullptr;      // mapped pinned host int32[8]: {sequence number of the last finished call, flagged, Q, previous exact-stage count, f16 stat}
   int32_t* host_stat_dev = nullptr;  // its device address
   int stat_seq = 0, stat_seen = 0;
+  // Pipelined searches (option "search_lanes" = n > 1): consecutive t2l_search calls are independent jobs, so call i runs its
+  // scan -> re-rank chain on internal stream i % n with that lane's own scratch set; the chains overlap on the GPU (the next
+  // scan's workgroups start while the previous call re-ranks; no kernel-boundary bubble between calls). Results are ordered
+  // into the caller's stream by t2l_search_join.
+  struct SearchLane {
+    float* cand_score = nullptr;
+    size_t cand_cap = 0, flag_cap = 0;
+    int32_t *flags = nullptr, *fb_count = nullptr, *host_stat = nullptr, *host_stat_dev = nullptr;
+    int stat_seen = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    bool pending = false, ready = false;
+  };
+  static constexpr int kMaxLanes = 4;
+  SearchLane lanes[kMaxLanes];
+  int n_lanes = 1;
+  unsigned lane_next = 0;
+  hipEvent_t lane_fork = nullptr;
   int stream_min_rows = 65536;  // shards at least this large answer batches of <= 64 queries with the streaming scan
-  unsigned long long* scan_span = nullptr;  // dev u64[kSpanRing][2]: {seq << 40 | start tick, seq << 40 | last end tick}
-  unsigned span_seq = 0, span_read = 0;
+  unsigned long long* scan_span = nullptr;  // dev u64[kSpanRing][kSpanWgs][2]: per workgroup {seq << 40 | start tick, seq << 40 | end tick}
+  unsigned* span_grid = nullptr;            // host u32[kSpanRing]: grid of the launch in each ring entry (0: not stamped)
+  unsigned span_seq = 0, span_read = 0, busy_read = 0;
+  int profile_rerank = 1;  // 0: sampled launches bracket the scan only (an event pair costs the stream ~6 us per kernel)
   int profile_events = 0;  // 0 off, n >= 1: record every n-th launch of each kernel
   std::unordered_map<std::string, t2l::EventRing> events;
 };
@@ -139,6 +160,9 @@ int zero_grad_impl(t2l_ctx* ctx, hipStream_t s);
 int pn_train_forward_impl(t2l_ctx* ctx, const float* pos, const float* rgb, const int32_t* cell_offsets, int n_cells, float* out_f2,
                           hipStream_t s);
 int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s);
+int search_lanes_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s);
+int search_join_impl(t2l_ctx* ctx, hipStream_t s);
+void free_lanes(t2l_ctx* ctx);
 int adam_state_impl(t2l_ctx* ctx, int set, float* m, float* v, int64_t* step, int64_t* numel, hipStream_t s);
 void free_train(t2l_ctx* ctx);
 // pointnet.hip

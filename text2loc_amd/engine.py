@@ -58,6 +58,7 @@ EXPORTS = {
     "t2l_db_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "t2l_db_rows": (C.c_int64, [C.c_void_p]),
     "t2l_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "t2l_search_join": (C.c_int, [C.c_void_p, C.c_void_p]),
     "t2l_merge_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
     "t2l_pack_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -134,6 +135,7 @@ class Engine:
         self._h = h
         self.db_owner = None
         self.db_generation = 0
+        self._lane_keepalive = []
 
     def close(self):
         if getattr(self, "_h", None):
@@ -385,8 +387,11 @@ class Engine:
     def db_rows(self) -> int:
         return int(self.lib.t2l_db_rows(self._h))
 
-    def search(self, queries: torch.Tensor, k: int, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
-        """Returns (idx i32[Q,k] global row ids best-first, scores f64[Q,k]); asynchronous on the current stream."""
+    def search(self, queries: torch.Tensor, k: int, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+               join: bool = True):
+        """Returns (idx i32[Q,k] global row ids best-first, scores f64[Q,k]); asynchronous on the current stream.
+        With ``set_option("search_lanes", n)`` consecutive calls pipeline on internal streams (t2l.h): pass ``join=False``
+        for a stream of independent batches and call ``search_join()`` before touching any of their results."""
         if queries.dim() != 2 or queries.shape[1] != EMBED_DIM:
             raise T2LError(f"search: expected [Q,{EMBED_DIM}], got {tuple(queries.shape)}")
         Q = int(queries.shape[0])
@@ -398,7 +403,16 @@ class Engine:
         qp = _dev_ptr(queries, torch.float32, "queries") if Q > 0 else None
         self._check(self.lib.t2l_search(self._h, qp, Q, int(k), _dev_ptr(idx, torch.int32, "out_idx"),
                                         _dev_ptr(sc, torch.float64, "out_score"), _stream_ptr()))
+        if join:
+            self.search_join()
+        else:
+            self._lane_keepalive.append((queries, idx, sc))  # the lane streams are invisible to torch's allocator
         return idx, sc
+
+    def search_join(self):
+        """Order every pipelined search issued so far into the current stream."""
+        self._check(self.lib.t2l_search_join(self._h, _stream_ptr()))
+        self._lane_keepalive.clear()
 
     def merge_topk(self, idx: torch.Tensor, score: torch.Tensor):
         """idx i32[P,Q,K], score f64[P,Q,K] (all-gathered per-shard results) -> (i32[Q,K], f64[Q,K])."""
