@@ -590,6 +590,8 @@ def main():
     ap.add_argument("--mode", type=int, default=0,
                     help="search_mode: 0 = f16 scan (default), 1 = f32 scan, 2 = split-bf16 scan")
     ap.add_argument("--nsplit", type=int, default=0, help="override the scan kernel's DB split count (0 = auto)")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the pipelined side measurement (profiling runs: its "
+                    "overlapping launches would enter the per-kernel averages)")
     ap.add_argument("--lanes", type=int, default=1,
                     help="1 (default): every step stream-ordered behind the previous one; the pipelined form of the same loop "
                          "is measured beside it (`pipelined`). n > 1 (N=1 only): the TIMED steps themselves pipeline over n "
@@ -775,7 +777,7 @@ def main():
     # jobs, so step i runs its scan -> re-rank chain on internal stream i % 3 of the engine and the chains overlap. Reported
     # beside `value` (whose steps are stream-ordered, so that its kernel durations mean what rocprofv3 reports).
     pipelined = None
-    if world == 1 and lanes == 1 and rank == 0:
+    if world == 1 and lanes == 1 and rank == 0 and not args.no_pipelined:
         P_LANES = 3
         eng.set_option("profile_events", 0)
         eng.set_option("search_lanes", P_LANES)

@@ -4,12 +4,12 @@
 # rocprofv3 of the HEADLINE command (bench.py without its side measurements, so per-kernel averages are those of the
 # timed loop) — kernel-trace stats + PMC passes in separate runs, as the MI355X guide prescribes — and one
 # kernel-trace + FETCH_SIZE/WRITE_SIZE pass of the side measurements (encoder, streaming scan, loss).
-TAG=${1:-r02}
+TAG=${1:-r02b}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-secondary"
+CMD="python $ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-secondary --no-pipelined"
 SEC="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o p -- $CMD > $OUT/pmc_sq.log 2>&1
