@@ -690,16 +690,19 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
   }
   const int part = 2 * vs + half, parts = 2 * vn;
   const int qrow0 = qb * kWideQPerBlock + wq * kWideQPerWave + col, qrow1 = qrow0 + 32;
-  if (qrow0 < Q) {
-    float* out = cand + ((size_t)qrow0 * parts + part) * LL;
+  auto put_list = [&](int qrow, const float* ls) {  // (measured: non-temporal stores here cost +2 us per step)
+    if (qrow >= Q) return;
+    float* out = cand + ((size_t)qrow * parts + part) * LL;
+    if constexpr (LL % 2 == 0) {  // 24-byte lists: three 8-byte stores
 #pragma unroll
-    for (int i = 0; i < LL; ++i) out[i] = w.ls0[i];
-  }
-  if (qrow1 < Q) {
-    float* out = cand + ((size_t)qrow1 * parts + part) * LL;
+      for (int i = 0; i < LL / 2; ++i) reinterpret_cast<float2*>(out)[i] = make_float2(ls[2 * i], ls[2 * i + 1]);
+    } else {
 #pragma unroll
-    for (int i = 0; i < LL; ++i) out[i] = w.ls1[i];
-  }
+      for (int i = 0; i < LL; ++i) out[i] = ls[i];
+    }
+  };
+  put_list(qrow0, w.ls0);
+  put_list(qrow1, w.ls1);
   if (span && threadIdx.x == 0) {
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), tag = (unsigned long long)span_seq << 40, tm = (1ull << 40) - 1;
     *reinterpret_cast<ulonglong2*>(span + 2 * blockIdx.x) = make_ulonglong2(tag | (wg_t0 & tm), tag | (t1 & tm));
