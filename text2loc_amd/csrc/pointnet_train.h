@@ -6,12 +6,14 @@
 //
 // What the reference's code fixes: the backbone is called once PER CELL (models/object_encoder.py:92-95), so every
 // BatchNorm1d normalises with the statistics of that cell's rows and updates its running statistics once per cell, in cell
-// order. Here the whole batch runs at once: the edge rows of a level are materialised in HBM for all objects
-// ([n_obj][centres][33 slots], slot 32 = PyG's bipartite self-loop edge, empty slots masked), the two Linear layers of the
-// edge MLP are plain GEMMs over all rows (gemm_kernel), and BatchNorm works per (cell, channel) SEGMENT: float64 partial
-// sums per cell, a finalize kernel (statistics + the sequential running-statistics updates), an apply kernel.
-// Saved for backward per level: neighbour table, edge inputs, pre-BN and post-ReLU activations of both layers, per-cell
-// statistics, arg-max rows. ~14 KB of activations per edge row at SA3: ≈18 GB at B = 64 cells (what 288 GB of HBM are for).
+// order. Here the whole batch runs at once. The index structure of all three levels depends on positions only, so it is
+// built first (FPS, ball query into a [group][33 slots] table, slot 32 = PyG's bipartite self-loop edge); the host
+// prefix-sums the rows per group and the edge rows of a level are then COMPACTED — only real edges exist as rows (ball
+// queries fill 37-47 % of their 32 slots on object-like point sets), addressed through src[row] / row_group[row] /
+// row_cell[row] and goff[group]. The two Linear layers of the edge MLP are plain GEMMs over all rows (gemm_kernel), and
+// BatchNorm works per (cell, channel) SEGMENT: float64 partial sums per cell, a finalize kernel (statistics + the
+// sequential running-statistics updates), an apply kernel. Saved for backward per level: the row tables, edge inputs,
+// pre-BN and post-ReLU activations of both layers, per-cell statistics, arg-max rows.
 #pragma once
 
 namespace t2l {
@@ -19,11 +21,12 @@ namespace t2l {
 struct PnLevel {
   std::string prefix;
   int cin = 0, kin = 0, kp = 0, h1 = 0, h2 = 0;  // source features, real layer-1 inputs (cin + 3), padded to 32, widths
-  int ns = 0, nd = 0, R = 0;                      // source points per object, groups per object, rows per group
+  int ns = 0, nd = 0;                             // source points per object, groups (centres) per object
   float radius = 0.f;
   bool sa = true;
-  size_t E = 0;
-  int32_t *nbr = nullptr, *arg = nullptr, *cnt = nullptr;
+  size_t E = 0, G = 0;                            // edge rows (valid ones only: compacted), groups
+  int32_t *nbr33 = nullptr, *cnt_g = nullptr;     // index workspace: ball-query table [G][33] (-1 = empty), rows per group
+  int32_t *goff = nullptr, *src = nullptr, *row_group = nullptr, *row_cell = nullptr, *arg = nullptr, *cnt = nullptr;
   float *X = nullptr, *y1 = nullptr, *a1 = nullptr, *y2 = nullptr, *a2 = nullptr;
   float *mean1 = nullptr, *rstd1 = nullptr, *mean2 = nullptr, *rstd2 = nullptr;
   float *xout = nullptr, *pos_out = nullptr, *w1p = nullptr, *dw1p = nullptr;
@@ -31,10 +34,10 @@ struct PnLevel {
 
 struct PnTrain {
   bool bound = false, trainable = false, have_forward = false;
-  char* ws = nullptr;
-  size_t ws_cap = 0, ws_off = 0;
+  char *ws = nullptr, *iws = nullptr;  // activations + scratch (sized exactly per call) / index tables (worst case, small)
+  size_t ws_cap = 0, ws_off = 0, iws_cap = 0, scratch_off = 0, scratch_bytes = 0;
   int n_obj = 0, n_cells = 0;
-  int32_t *cell_of_obj = nullptr, *cell_base = nullptr, *cell_lo = nullptr;  // device
+  int32_t *cell_of_obj = nullptr, *cell_base = nullptr;  // device
   const float *pos0 = nullptr, *rgb0 = nullptr;
   PnLevel lv[4];
   float *f0 = nullptr, *f1 = nullptr, *f2 = nullptr;
@@ -91,12 +94,11 @@ __global__ __launch_bounds__(256) void pt_fps_kernel(const float* __restrict__ p
 }
 
 // ball query, one wave per centre: the first 32 source points of the centre's object in index order with d^2 < r^2; slot 32 =
-// the extra (k -> k) source of PyG's add_self_loops on the bipartite cell batch (or -1); cnt[cell] += valid rows
+// the extra (k -> k) source of PyG's add_self_loops on the bipartite cell batch (or -1); cnt_g[group] = valid slots
 template <int PPL>
 __global__ __launch_bounds__(256) void pt_ball_kernel(const float* __restrict__ pos_src, const float* __restrict__ pos_ctr, int n_obj,
-                                                      int nd, float r2, const int32_t* __restrict__ cell_base,
-                                                      const int32_t* __restrict__ cell_of_obj, int self_loops,
-                                                      int32_t* __restrict__ nbr, int32_t* __restrict__ cnt) {
+                                                      int nd, float r2, const int32_t* __restrict__ cell_base, int self_loops,
+                                                      int32_t* __restrict__ nbr, int32_t* __restrict__ cnt_g) {
   constexpr int NS = 64 * PPL;
   const int lane = threadIdx.x & 63;
   const size_t g = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -120,24 +122,51 @@ __global__ __launch_bounds__(256) void pt_ball_kernel(const float* __restrict__ 
   if (lane == 32) {
     const int cb = cell_base[o];
     out[32] = self_loops ? cb * NS + (o - cb) * nd + t : -1;
-    atomicAdd(cnt + cell_of_obj[o], count + (self_loops ? 1 : 0));
+    cnt_g[g] = count + (self_loops ? 1 : 0);
   }
 }
 
-// edge inputs: X[row] = [x_src | pos_src - pos_centre | 0 pad] (SA), [x | pos | 0 pad] (global MLP: nbr == nullptr)
+// [group][33 slots] -> compacted rows: src (source row of the level below), row_group, row_cell
+__global__ __launch_bounds__(256) void pt_compact_kernel(const int32_t* __restrict__ nbr33, const int32_t* __restrict__ goff, size_t G, int nd,
+                                                         const int32_t* __restrict__ cell_of_obj, int32_t* __restrict__ src,
+                                                         int32_t* __restrict__ row_group, int32_t* __restrict__ row_cell) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= G * 33) return;
+  const size_t g = i / 33;
+  const int slot = (int)(i % 33);
+  const int v = nbr33[i];
+  if (v < 0) return;
+  const int row = slot < 32 ? goff[g] + slot : goff[g + 1] - 1;  // the valid slots 0..count-1 come first, the self-loop edge last
+  src[row] = v;
+  row_group[row] = (int32_t)g;
+  row_cell[row] = cell_of_obj[g / nd];
+}
+// global MLP: 32 rows per object, all valid
+__global__ __launch_bounds__(256) void pt_iota_rows_kernel(size_t E, int per, const int32_t* __restrict__ cell_of_obj, int32_t* __restrict__ src,
+                                                           int32_t* __restrict__ row_group, int32_t* __restrict__ row_cell,
+                                                           int32_t* __restrict__ goff) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i > E) return;
+  if (i % per == 0) goff[i / per] = (int32_t)i;  // (incl. goff[G] = E)
+  if (i == E) return;
+  src[i] = (int32_t)i;
+  row_group[i] = (int32_t)(i / per);
+  row_cell[i] = cell_of_obj[i / per];
+}
+
+// edge inputs: X[row] = [x_src | pos_src - pos_centre | 0 pad] (SA), [x | pos | 0 pad] (global MLP: pos_ctr == nullptr)
 __global__ __launch_bounds__(256) void pt_gather_kernel(const float* __restrict__ x_src, const float* __restrict__ pos_src,
-                                                        const float* __restrict__ pos_ctr, const int32_t* __restrict__ nbr, size_t E,
-                                                        int R, int cin, int kp, float* __restrict__ X) {
+                                                        const float* __restrict__ pos_ctr, const int32_t* __restrict__ src,
+                                                        const int32_t* __restrict__ row_group, size_t E, int cin, int kp,
+                                                        float* __restrict__ X) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= E * kp) return;
   const size_t row = i / kp;
   const int col = (int)(i % kp);
-  const long long src = nbr ? nbr[row] : (long long)row;
+  const size_t sr = (size_t)src[row];
   float v = 0.f;
-  if (src >= 0) {
-    if (col < cin) v = x_src[(size_t)src * cin + col];
-    else if (col < cin + 3) v = pos_src[(size_t)src * 3 + col - cin] - (nbr ? pos_ctr[(row / R) * 3 + col - cin] : 0.f);
-  }
+  if (col < cin) v = x_src[sr * cin + col];
+  else if (col < cin + 3) v = pos_src[sr * 3 + col - cin] - (pos_ctr ? pos_ctr[(size_t)row_group[row] * 3 + col - cin] : 0.f);
   X[i] = v;
 }
 
@@ -150,48 +179,70 @@ __global__ void pt_unpad_add_kernel(const float* __restrict__ dWp, int rows, int
   if (i < rows * kin) dW[i] += dWp[(i / kin) * kp + (i % kin)];
 }
 
-// per-(cell, channel) sums over the valid rows of one object's row block; grid (C/64, n_obj, chunks)
+// per-(cell, channel) sums over a block of kStatRows rows; grid (ceil(C/64), ceil(E/kStatRows)). Rows are sorted by cell, so a
+// thread keeps one running segment and flushes it (float64 atomics) when the cell changes; a block inside ONE cell — nearly
+// all of them — reduces its four row lanes through LDS first.
 // MODE 0: acc[cell][0][c] += sum y, acc[cell][1][c] += sum y^2. MODE 1: dv = a > 0 ? d : 0: sum dv, sum dv * xhat
+constexpr int kStatRows = 1024;
 template <int MODE>
 __global__ __launch_bounds__(256) void pt_bn_stats_kernel(const float* __restrict__ y, const float* __restrict__ d,
-                                                          const float* __restrict__ a, const int32_t* __restrict__ nbr, int C,
-                                                          int rows_per_obj, const int32_t* __restrict__ cell_of_obj,
-                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                          double* __restrict__ acc) {
+                                                          const float* __restrict__ a, int C, size_t E,
+                                                          const int32_t* __restrict__ row_cell, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, double* __restrict__ acc) {
   __shared__ float r1[256], r2[256];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
   const bool cok = c < C;  // (C = 32: half of the lanes idle)
-  const int o = blockIdx.y, cell = cell_of_obj[o];
-  const int per = (rows_per_obj + gridDim.z - 1) / gridDim.z;
-  const int lo = blockIdx.z * per, hi = cok ? min(rows_per_obj, lo + per) : 0;
-  const size_t base = (size_t)o * rows_per_obj;
+  const size_t lo = (size_t)blockIdx.y * kStatRows, hi = min(E, lo + kStatRows);
+  const int cell_first = row_cell[lo], cell_last = row_cell[hi - 1];
+  const bool one_cell = cell_first == cell_last;  // block-uniform
+  int cur = cell_first;
   float mu = 0.f, rs = 0.f;
   if (MODE == 1 && cok) {
-    mu = mean[(size_t)cell * C + c];
-    rs = rstd[(size_t)cell * C + c];
+    mu = mean[(size_t)cur * C + c];
+    rs = rstd[(size_t)cur * C + c];
   }
   float s1 = 0.f, s2 = 0.f;
-  for (int r = lo + g; r < hi; r += 4) {
-    const size_t row = base + r;
-    if (nbr && nbr[row] < 0) continue;
-    const size_t i = row * C + c;
-    if (MODE == 0) {
-      const float v = y[i];
-      s1 += v;
-      s2 += v * v;
-    } else {
-      const float dv = a[i] > 0.f ? d[i] : 0.f;
-      s1 += dv;
-      s2 += dv * (y[i] - mu) * rs;
+  if (cok) {
+    for (size_t row = lo + g; row < hi; row += 4) {
+      if (!one_cell) {
+        const int cell = row_cell[row];
+        if (cell != cur) {
+          atomicAdd(acc + ((size_t)cur * 2) * 1024 + c, (double)s1);
+          atomicAdd(acc + ((size_t)cur * 2 + 1) * 1024 + c, (double)s2);
+          s1 = s2 = 0.f;
+          cur = cell;
+          if (MODE == 1) {
+            mu = mean[(size_t)cur * C + c];
+            rs = rstd[(size_t)cur * C + c];
+          }
+        }
+      }
+      const size_t i = row * C + c;
+      if (MODE == 0) {
+        const float v = y[i];
+        s1 += v;
+        s2 += v * v;
+      } else {
+        const float dv = a[i] > 0.f ? d[i] : 0.f;
+        s1 += dv;
+        s2 += dv * (y[i] - mu) * rs;
+      }
     }
+  }
+  if (!one_cell) {
+    if (cok) {
+      atomicAdd(acc + ((size_t)cur * 2) * 1024 + c, (double)s1);
+      atomicAdd(acc + ((size_t)cur * 2 + 1) * 1024 + c, (double)s2);
+    }
+    return;
   }
   r1[threadIdx.x] = s1;
   r2[threadIdx.x] = s2;
   __syncthreads();
   if (g == 0 && cok) {
     const int t = threadIdx.x;
-    atomicAdd(acc + ((size_t)cell * 2) * 1024 + c, (double)r1[t] + (double)r1[t + 64] + (double)r1[t + 128] + (double)r1[t + 192]);
-    atomicAdd(acc + ((size_t)cell * 2 + 1) * 1024 + c, (double)r2[t] + (double)r2[t + 64] + (double)r2[t + 128] + (double)r2[t + 192]);
+    atomicAdd(acc + ((size_t)cur * 2) * 1024 + c, (double)r1[t] + (double)r1[t + 64] + (double)r1[t + 128] + (double)r1[t + 192]);
+    atomicAdd(acc + ((size_t)cur * 2 + 1) * 1024 + c, (double)r2[t] + (double)r2[t + 64] + (double)r2[t + 128] + (double)r2[t + 192]);
   }
 }
 
@@ -215,43 +266,53 @@ __global__ void pt_bn_finalize_kernel(const double* __restrict__ acc, const int3
   run_var[c] = rv;
 }
 
-__global__ __launch_bounds__(256) void pt_bn_apply_fwd_kernel(const float* __restrict__ y, size_t E, int C, int rows_per_obj,
-                                                              const int32_t* __restrict__ cell_of_obj, const int32_t* __restrict__ nbr,
-                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              float* __restrict__ a) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void pt_bn_apply_fwd_kernel(const float* __restrict__ y, size_t E, int C,
+                                                              const int32_t* __restrict__ row_cell, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ a) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;  // C is a multiple of 32: four channels of one row
   if (i >= E * C) return;
   const size_t row = i / C;
   const int c = (int)(i % C);
-  float v = 0.f;  // empty slots: 0 (a valid row of the same centre always exists — the centre itself — and ReLU outputs are >= 0)
-  if (!nbr || nbr[row] >= 0) {
-    const size_t sc = (size_t)cell_of_obj[row / rows_per_obj] * C + c;
-    v = fmaxf((y[i] - mean[sc]) * rstd[sc] * gamma[c] + beta[c], 0.f);
-  }
-  a[i] = v;
+  const size_t sc = (size_t)row_cell[row] * C + c;
+  const float4 v = *reinterpret_cast<const float4*>(y + i), m = *reinterpret_cast<const float4*>(mean + sc),
+               r = *reinterpret_cast<const float4*>(rstd + sc), ga = *reinterpret_cast<const float4*>(gamma + c),
+               be = *reinterpret_cast<const float4*>(beta + c);
+  float4 o;
+  o.x = fmaxf((v.x - m.x) * r.x * ga.x + be.x, 0.f);
+  o.y = fmaxf((v.y - m.y) * r.y * ga.y + be.y, 0.f);
+  o.z = fmaxf((v.z - m.z) * r.z * ga.z + be.z, 0.f);
+  o.w = fmaxf((v.w - m.w) * r.w * ga.w + be.w, 0.f);
+  *reinterpret_cast<float4*>(a + i) = o;
 }
 
 // d (gradient w.r.t. the ReLU output) -> gradient w.r.t. the Linear output, in place
 __global__ __launch_bounds__(256) void pt_bn_apply_bwd_kernel(float* __restrict__ d, const float* __restrict__ a, const float* __restrict__ y,
-                                                              size_t E, int C, int rows_per_obj, const int32_t* __restrict__ cell_of_obj,
-                                                              const int32_t* __restrict__ nbr, const int32_t* __restrict__ cnt,
-                                                              const double* __restrict__ acc, const float* __restrict__ gamma,
-                                                              const float* __restrict__ mean, const float* __restrict__ rstd) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+                                                              size_t E, int C, const int32_t* __restrict__ row_cell,
+                                                              const int32_t* __restrict__ cnt, const double* __restrict__ acc,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= E * C) return;
   const size_t row = i / C;
   const int c = (int)(i % C);
-  float v = 0.f;
-  if (!nbr || nbr[row] >= 0) {
-    const int cell = cell_of_obj[row / rows_per_obj];
-    const size_t sc = (size_t)cell * C + c;
-    const float n = (float)max(cnt[cell], 1), rs = rstd[sc];
-    const float s1 = (float)acc[((size_t)cell * 2) * 1024 + c], s2 = (float)acc[((size_t)cell * 2 + 1) * 1024 + c];
-    const float dv = a[i] > 0.f ? d[i] : 0.f;
-    v = gamma[c] * rs / n * (n * dv - s1 - (y[i] - mean[sc]) * rs * s2);
+  const int cell = row_cell[row];
+  const size_t sc = (size_t)cell * C + c;
+  const float n = (float)max(cnt[cell], 1);
+  const float4 dv4 = *reinterpret_cast<const float4*>(d + i), av = *reinterpret_cast<const float4*>(a + i),
+               yv = *reinterpret_cast<const float4*>(y + i), m = *reinterpret_cast<const float4*>(mean + sc),
+               r = *reinterpret_cast<const float4*>(rstd + sc), ga = *reinterpret_cast<const float4*>(gamma + c);
+  const double* a1 = acc + ((size_t)cell * 2) * 1024 + c;
+  const double* a2 = acc + ((size_t)cell * 2 + 1) * 1024 + c;
+  float4 o;
+#define T2L_PT_BWD(X, K)                                                                                   \
+  {                                                                                                        \
+    const float dv = av.X > 0.f ? dv4.X : 0.f;                                                             \
+    o.X = ga.X * r.X / n * (n * dv - (float)a1[K] - (yv.X - m.X) * r.X * (float)a2[K]);                    \
   }
-  d[i] = v;
+  T2L_PT_BWD(x, 0) T2L_PT_BWD(y, 1) T2L_PT_BWD(z, 2) T2L_PT_BWD(w, 3)
+#undef T2L_PT_BWD
+  *reinterpret_cast<float4*>(d + i) = o;
 }
 __global__ void pt_bn_param_grad_kernel(const double* __restrict__ acc, int n_cells, int C, float* __restrict__ dgamma,
                                         float* __restrict__ dbeta) {
@@ -266,44 +327,46 @@ __global__ void pt_bn_param_grad_kernel(const double* __restrict__ acc, int n_ce
   dgamma[c] += (float)s2;
 }
 
-// max over the R rows of every group (valid rows only; first maximum wins) + the winning row
-__global__ __launch_bounds__(256) void pt_segmax_kernel(const float* __restrict__ a, const int32_t* __restrict__ nbr, size_t n_groups, int R,
-                                                        int C, float* __restrict__ xout, int32_t* __restrict__ arg) {
+// max over the rows of every group (first maximum wins, as argmax) + the winning row
+__global__ __launch_bounds__(256) void pt_segmax_kernel(const float* __restrict__ a, const int32_t* __restrict__ goff, size_t n_groups, int C,
+                                                        float* __restrict__ xout, int32_t* __restrict__ arg) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_groups * C) return;
   const size_t g = i / C;
   const int c = (int)(i % C);
-  float best = -1.f;
-  long long br = -1;
-  for (int r = 0; r < R; ++r) {
-    const size_t row = g * R + r;
-    if (nbr && nbr[row] < 0) continue;
-    const float v = a[row * C + c];
+  const int lo = goff[g], hi = goff[g + 1];
+  float best = -1.f;  // ReLU outputs are >= 0 and every group has at least one row (the centre itself)
+  int br = -1;
+  for (int row = lo; row < hi; ++row) {
+    const float v = a[(size_t)row * C + c];
     if (v > best) {
       best = v;
-      br = (long long)row;
+      br = row;
     }
   }
-  xout[i] = best;
-  arg[i] = (int32_t)br;
+  xout[i] = fmaxf(best, 0.f);
+  arg[i] = br;
 }
-__global__ __launch_bounds__(256) void pt_maxbwd_kernel(const float* __restrict__ dxout, const int32_t* __restrict__ arg, size_t E, int R, int C,
-                                                        float* __restrict__ dA) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void pt_maxbwd_kernel(const float* __restrict__ dxout, const int32_t* __restrict__ arg,
+                                                        const int32_t* __restrict__ row_group, size_t E, int C, float* __restrict__ dA) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= E * C) return;
-  const size_t row = i / C, g = row / R;
+  const size_t row = i / C;
   const int c = (int)(i % C);
-  dA[i] = arg[g * C + c] == (int32_t)row ? dxout[g * C + c] : 0.f;
+  const size_t gi = (size_t)row_group[row] * C + c;
+  const int4 ar = *reinterpret_cast<const int4*>(arg + gi);
+  const float4 dv = *reinterpret_cast<const float4*>(dxout + gi);
+  const int r = (int)row;
+  *reinterpret_cast<float4*>(dA + i) = make_float4(ar.x == r ? dv.x : 0.f, ar.y == r ? dv.y : 0.f, ar.z == r ? dv.z : 0.f, ar.w == r ? dv.w : 0.f);
 }
 // dx_src[src][0:cin] += dX[row][0:cin]
-__global__ __launch_bounds__(256) void pt_scatter_kernel(const float* __restrict__ dX, const int32_t* __restrict__ nbr, size_t E, int cin, int kp,
+__global__ __launch_bounds__(256) void pt_scatter_kernel(const float* __restrict__ dX, const int32_t* __restrict__ src, size_t E, int cin, int kp,
                                                          float* __restrict__ dx_src) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= E * cin) return;
   const size_t row = i / cin;
   const int col = (int)(i % cin);
-  const int src = nbr[row];
-  if (src >= 0) unsafeAtomicAdd(dx_src + (size_t)src * cin + col, dX[row * kp + col]);
+  unsafeAtomicAdd(dx_src + (size_t)src[row] * cin + col, dX[row * kp + col]);
 }
 __global__ void pt_slice_kernel(const float* __restrict__ dX, size_t rows, int cin, int kp, float* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -322,6 +385,7 @@ static void pn_train_free(void* p) {
   PnTrain* pt = reinterpret_cast<PnTrain*>(p);
   if (!pt) return;
   if (pt->ws) (void)hipFree(pt->ws);
+  if (pt->iws) (void)hipFree(pt->iws);
   delete pt;
 }
 
@@ -396,20 +460,45 @@ static T* pn_bump(PnTrain* pt, size_t count) {
 }
 static inline unsigned pn_blocks(size_t n) { return (unsigned)((n + 255) / 256); }
 
-static size_t pn_workspace_bytes(int n_obj, int n_cells) {
-  const int ns[3] = {256, 128, 64}, cin[3] = {3, 64, 128}, h1[3] = {32, 128, 256}, h2[3] = {64, 128, 256};
-  size_t fl = 0, big = 0;
-  for (int l = 0; l < 3; ++l) {
-    const size_t nd = ns[l] / 2, E = (size_t)n_obj * nd * 33, kp = ((cin[l] + 3 + 31) / 32) * 32;
-    fl += E * (kp + 2 * h1[l] + 2 * h2[l] + 1) + (size_t)n_obj * nd * (2 * h2[l] + 3) + (size_t)n_cells * (2 * h1[l] + 2 * h2[l] + 1) + 2 * h1[l] * kp;
-    big = std::max(big, E * (size_t)(h1[l] + h2[l] + kp));
+// Every activation / table of the forward pass and the backward's scratch, laid out from pt->ws (E and G of every level are
+// known: the index phase ran). Called twice: with pt->ws == nullptr to measure, then for real.
+static size_t pn_layout(PnTrain* pt) {
+  const int n_obj = pt->n_obj, n_cells = pt->n_cells;
+  pt->ws_off = 0;
+  pt->cell_of_obj = pn_bump<int32_t>(pt, n_obj);
+  pt->cell_base = pn_bump<int32_t>(pt, n_obj);
+  pt->acc = pn_bump<double>(pt, (size_t)n_cells * 2 * 1024);
+  size_t scratch = 0;
+  for (int l = 0; l < 4; ++l) {
+    PnLevel& L = pt->lv[l];
+    L.cnt = pn_bump<int32_t>(pt, n_cells);
+    L.goff = pn_bump<int32_t>(pt, L.G + 1);
+    L.src = pn_bump<int32_t>(pt, L.E);
+    L.row_group = pn_bump<int32_t>(pt, L.E);
+    L.row_cell = pn_bump<int32_t>(pt, L.E);
+    L.X = pn_bump<float>(pt, L.E * L.kp);
+    L.w1p = pn_bump<float>(pt, (size_t)L.h1 * L.kp);
+    L.dw1p = pn_bump<float>(pt, (size_t)L.h1 * L.kp);
+    L.y1 = pn_bump<float>(pt, L.E * L.h1);
+    L.a1 = pn_bump<float>(pt, L.E * L.h1);
+    L.y2 = pn_bump<float>(pt, L.E * L.h2);
+    L.a2 = pn_bump<float>(pt, L.E * L.h2);
+    L.mean1 = pn_bump<float>(pt, (size_t)n_cells * L.h1);
+    L.rstd1 = pn_bump<float>(pt, (size_t)n_cells * L.h1);
+    L.mean2 = pn_bump<float>(pt, (size_t)n_cells * L.h2);
+    L.rstd2 = pn_bump<float>(pt, (size_t)n_cells * L.h2);
+    L.xout = pn_bump<float>(pt, L.G * L.h2);
+    L.arg = pn_bump<int32_t>(pt, L.G * L.h2);
+    // backward scratch of this level: dA2, dA1, dX (+ 256-byte roundings)
+    scratch = std::max(scratch, L.E * (size_t)(L.h2 + L.h1 + L.kp) * sizeof(float) + 3 * 256);
   }
-  const size_t Eg = (size_t)n_obj * 32;
-  fl += Eg * (288 + 2 * 512 + 2 * 1024) + (size_t)n_obj * (2 * 1024 + 512 + 256 + 1024) + (size_t)n_cells * (2 * 512 + 2 * 1024 + 1) + 2 * 512 * 288;
-  big = std::max(big, Eg * (size_t)(512 + 1024 + 288));
-  fl += big;                                                    // backward scratch (dA2, dA1, dX of the largest level)
-  fl += (size_t)n_obj * (256 * 3 + 128 * 64 + 64 * 128 + 32 * 256) * 2;  // dx buffers (+ slack)
-  return fl * sizeof(float) + (size_t)n_cells * 2 * 1024 * sizeof(double) + (size_t)(3 * n_obj + 64) * sizeof(int32_t) + (8u << 20);
+  pt->f1 = pn_bump<float>(pt, (size_t)n_obj * 512);
+  pt->f2 = pn_bump<float>(pt, (size_t)n_obj * 256);
+  // backward: d2, d1, two ping-pong buffers for the gradient w.r.t. a level's output (n_obj x 8192 floats covers all of
+  // them: 1024 at the top, 32 x 256, 64 x 128, 128 x 64 below), then the level scratch
+  pt->scratch_off = pt->ws_off;
+  pt->scratch_bytes = (size_t)n_obj * (256 + 512 + 2 * 8192) * sizeof(float) + 4 * 256 + scratch;
+  return pt->ws_off + pt->scratch_bytes;
 }
 
 // one get_mlp block in training mode over segmented rows: y = X W^T + b; per-cell BatchNorm; ReLU
@@ -417,17 +506,16 @@ static void pn_block_fwd(TrainState* st, PnTrain* pt, const PnLevel& L, int laye
                          float* a, float* mean, float* rstd, hipStream_t s) {
   using namespace train;
   const std::string p = L.prefix + "." + std::to_string(layer);
-  const int rows_per_obj = L.nd * L.R;
   gemm_nt_rows(X, W, T_(st, p + ".0.bias").data, y, L.E, C, K, 0, s);
   (void)hipMemsetAsync(pt->acc, 0, sizeof(double) * 2 * 1024 * pt->n_cells, s);
-  const int chunks = std::max(1, std::min(8, rows_per_obj / 256));
-  hipLaunchKernelGGL((pt_bn_stats_kernel<0>), dim3((C + 63) / 64, pt->n_obj, chunks), dim3(256), 0, s, y, (const float*)nullptr, (const float*)nullptr,
-                     (const int32_t*)L.nbr, C, rows_per_obj, (const int32_t*)pt->cell_of_obj, (const float*)nullptr, (const float*)nullptr, pt->acc);
+  const dim3 sgrid((C + 63) / 64, (unsigned)((L.E + kStatRows - 1) / kStatRows));
+  hipLaunchKernelGGL((pt_bn_stats_kernel<0>), sgrid, dim3(256), 0, s, (const float*)y, (const float*)nullptr, (const float*)nullptr, C, L.E,
+                     (const int32_t*)L.row_cell, (const float*)nullptr, (const float*)nullptr, pt->acc);
   hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)pt->acc, (const int32_t*)L.cnt, pt->n_cells, C,
                      mean, rstd, T_(st, p + ".1.running_mean").data, T_(st, p + ".1.running_var").data, 0.1f);
-  hipLaunchKernelGGL(pt_bn_apply_fwd_kernel, dim3(pn_blocks(L.E * C)), dim3(256), 0, s, (const float*)y, L.E, C, rows_per_obj,
-                     (const int32_t*)pt->cell_of_obj, (const int32_t*)L.nbr, (const float*)mean, (const float*)rstd,
-                     (const float*)T_(st, p + ".1.weight").data, (const float*)T_(st, p + ".1.bias").data, a);
+  hipLaunchKernelGGL(pt_bn_apply_fwd_kernel, dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, (const float*)y, L.E, C, (const int32_t*)L.row_cell,
+                     (const float*)mean, (const float*)rstd, (const float*)T_(st, p + ".1.weight").data,
+                     (const float*)T_(st, p + ".1.bias").data, a);
 }
 
 // d: gradient w.r.t. the block's ReLU output [E, C] (overwritten with the gradient w.r.t. the Linear output)
@@ -435,14 +523,12 @@ static void pn_block_bwd(TrainState* st, PnTrain* pt, const PnLevel& L, int laye
                          const float* mean, const float* rstd, hipStream_t s) {
   using namespace train;
   const std::string p = L.prefix + "." + std::to_string(layer);
-  const int rows_per_obj = L.nd * L.R;
   (void)hipMemsetAsync(pt->acc, 0, sizeof(double) * 2 * 1024 * pt->n_cells, s);
-  const int chunks = std::max(1, std::min(8, rows_per_obj / 256));
-  hipLaunchKernelGGL((pt_bn_stats_kernel<1>), dim3((C + 63) / 64, pt->n_obj, chunks), dim3(256), 0, s, y, (const float*)d, a, (const int32_t*)L.nbr, C,
-                     rows_per_obj, (const int32_t*)pt->cell_of_obj, mean, rstd, pt->acc);
-  hipLaunchKernelGGL(pt_bn_apply_bwd_kernel, dim3(pn_blocks(L.E * C)), dim3(256), 0, s, d, a, y, L.E, C, rows_per_obj,
-                     (const int32_t*)pt->cell_of_obj, (const int32_t*)L.nbr, (const int32_t*)L.cnt, (const double*)pt->acc,
-                     (const float*)T_(st, p + ".1.weight").data, mean, rstd);
+  const dim3 sgrid((C + 63) / 64, (unsigned)((L.E + kStatRows - 1) / kStatRows));
+  hipLaunchKernelGGL((pt_bn_stats_kernel<1>), sgrid, dim3(256), 0, s, y, (const float*)d, a, C, L.E, (const int32_t*)L.row_cell, mean, rstd,
+                     pt->acc);
+  hipLaunchKernelGGL(pt_bn_apply_bwd_kernel, dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, d, a, y, L.E, C, (const int32_t*)L.row_cell,
+                     (const int32_t*)L.cnt, (const double*)pt->acc, (const float*)T_(st, p + ".1.weight").data, mean, rstd);
   hipLaunchKernelGGL(pt_bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)pt->acc, pt->n_cells, C,
                      T_(st, p + ".1.weight").grad, T_(st, p + ".1.bias").grad);
 }
@@ -453,46 +539,21 @@ int pn_train_forward_impl(t2l_ctx* ctx, const float* pos, const float* rgb, cons
   TrainState* st = state(ctx);
   PnTrain* pt = st ? pn_state(st) : nullptr;
   if (!pt || !pt->bound)
-    return fail(ctx, T2L_ESTATE, "t2l_pointnet_features_train: bind the object_encoder.pointnet.* tensors (with gradients) first (t2l_train_bind)");
+    return fail(ctx, T2L_ESTATE, "t2l_pointnet_features_train: bind the object_encoder.pointnet.* tensors first (t2l_train_bind)");
   if (!pos || !rgb || !cell_offsets || n_cells <= 0 || !out_f2) return fail(ctx, T2L_EINVAL, "t2l_pointnet_features_train: bad arguments");
   const int n_obj = cell_offsets[n_cells];
   if (n_obj <= 0) return fail(ctx, T2L_EINVAL, "t2l_pointnet_features_train: no objects");
-  const size_t need = pn_workspace_bytes(n_obj, n_cells);
-  if (need > pt->ws_cap) {
-    T2L_HIP(ctx, hipStreamSynchronize(s));
-    if (pt->ws) (void)hipFree(pt->ws);
-    pt->ws = nullptr;
-    pt->ws_cap = 0;
-    T2L_HIP(ctx, hipMalloc(&pt->ws, need));
-    pt->ws_cap = need;
-  }
-  pt->ws_off = 0;
+  for (int c = 0; c < n_cells; ++c)
+    if (cell_offsets[c + 1] <= cell_offsets[c]) return fail(ctx, T2L_EINVAL, "t2l_pointnet_features_train: every cell needs at least one object");
   pt->have_forward = false;
   pt->n_obj = n_obj;
   pt->n_cells = n_cells;
   pt->pos0 = pos;
   pt->rgb0 = rgb;
   tl_gemm_bf16 = ctx->train_bf16;
-  {  // object -> cell tables
-    std::vector<int32_t> h(3 * (size_t)n_obj);
-    for (int c = 0; c < n_cells; ++c)
-      for (int o = cell_offsets[c]; o < cell_offsets[c + 1]; ++o) {
-        h[o] = c;
-        h[n_obj + o] = cell_offsets[c];
-      }
-    pt->cell_of_obj = pn_bump<int32_t>(pt, n_obj);
-    pt->cell_base = pn_bump<int32_t>(pt, n_obj);
-    T2L_HIP(ctx, hipMemcpyAsync(pt->cell_of_obj, h.data(), sizeof(int32_t) * n_obj, hipMemcpyHostToDevice, s));
-    T2L_HIP(ctx, hipMemcpyAsync(pt->cell_base, h.data() + n_obj, sizeof(int32_t) * n_obj, hipMemcpyHostToDevice, s));
-    T2L_HIP(ctx, hipStreamSynchronize(s));  // h goes out of scope
-  }
-  pt->acc = pn_bump<double>(pt, (size_t)n_cells * 2 * 1024);
-  event_begin(ctx, "pointnet_train_forward", s);
   const std::string P = "object_encoder.pointnet.";
   const int ns[3] = {256, 128, 64}, cin[3] = {3, 64, 128}, h1[4] = {32, 128, 256, 512}, h2[4] = {64, 128, 256, 1024};
   const float radius[3] = {0.2f, 0.3f, 0.4f};
-  const float* cur_pos = pos;
-  const float* cur_x = rgb;
   for (int l = 0; l < 4; ++l) {
     PnLevel& L = pt->lv[l];
     L.prefix = P + kPnBlocks[l];
@@ -504,71 +565,144 @@ int pn_train_forward_impl(t2l_ctx* ctx, const float* pos, const float* rgb, cons
     L.h2 = h2[l];
     L.ns = l < 3 ? ns[l] : 32;
     L.nd = l < 3 ? ns[l] / 2 : 1;
-    L.R = l < 3 ? 33 : 32;
-    L.E = (size_t)n_obj * L.nd * L.R;
-    L.cnt = pn_bump<int32_t>(pt, n_cells);
-    if (L.sa) {
-      L.radius = radius[l];
-      L.pos_out = pn_bump<float>(pt, (size_t)n_obj * L.nd * 3);
-      L.nbr = pn_bump<int32_t>(pt, L.E);
-      if (L.ns == 256) hipLaunchKernelGGL((pt_fps_kernel<4>), dim3((n_obj + 3) / 4), dim3(256), 0, s, cur_pos, n_obj, L.nd, L.pos_out);
-      else if (L.ns == 128) hipLaunchKernelGGL((pt_fps_kernel<2>), dim3((n_obj + 3) / 4), dim3(256), 0, s, cur_pos, n_obj, L.nd, L.pos_out);
-      else hipLaunchKernelGGL((pt_fps_kernel<1>), dim3((n_obj + 3) / 4), dim3(256), 0, s, cur_pos, n_obj, L.nd, L.pos_out);
-      T2L_HIP(ctx, hipMemsetAsync(L.cnt, 0, sizeof(int32_t) * n_cells, s));
-      const float r2 = radius[l] * radius[l];  // float32 product, as the restatement
-      const unsigned bg = (unsigned)(((size_t)n_obj * L.nd + 3) / 4);
-      if (L.ns == 256)
-        hipLaunchKernelGGL((pt_ball_kernel<4>), dim3(bg), dim3(256), 0, s, cur_pos, (const float*)L.pos_out, n_obj, L.nd, r2,
-                           (const int32_t*)pt->cell_base, (const int32_t*)pt->cell_of_obj, ctx->pn_self_loops, L.nbr, L.cnt);
-      else if (L.ns == 128)
-        hipLaunchKernelGGL((pt_ball_kernel<2>), dim3(bg), dim3(256), 0, s, cur_pos, (const float*)L.pos_out, n_obj, L.nd, r2,
-                           (const int32_t*)pt->cell_base, (const int32_t*)pt->cell_of_obj, ctx->pn_self_loops, L.nbr, L.cnt);
-      else
-        hipLaunchKernelGGL((pt_ball_kernel<1>), dim3(bg), dim3(256), 0, s, cur_pos, (const float*)L.pos_out, n_obj, L.nd, r2,
-                           (const int32_t*)pt->cell_base, (const int32_t*)pt->cell_of_obj, ctx->pn_self_loops, L.nbr, L.cnt);
-    } else {
-      L.nbr = nullptr;
-      std::vector<int32_t> hc(n_cells);
-      for (int c = 0; c < n_cells; ++c) hc[c] = (cell_offsets[c + 1] - cell_offsets[c]) * 32;
-      T2L_HIP(ctx, hipMemcpyAsync(L.cnt, hc.data(), sizeof(int32_t) * n_cells, hipMemcpyHostToDevice, s));
-      T2L_HIP(ctx, hipStreamSynchronize(s));
+    L.G = (size_t)n_obj * L.nd;
+    L.radius = l < 3 ? radius[l] : 0.f;
+  }
+  std::vector<int32_t> h_tab(2 * (size_t)n_obj);  // object -> cell, object -> first object of its cell
+  for (int c = 0; c < n_cells; ++c)
+    for (int o = cell_offsets[c]; o < cell_offsets[c + 1]; ++o) {
+      h_tab[o] = c;
+      h_tab[n_obj + o] = cell_offsets[c];
     }
-    L.X = pn_bump<float>(pt, L.E * L.kp);
-    hipLaunchKernelGGL(pt_gather_kernel, dim3(pn_blocks(L.E * L.kp)), dim3(256), 0, s, cur_x, cur_pos, (const float*)L.pos_out,
-                       (const int32_t*)L.nbr, L.E, L.R, L.cin, L.kp, L.X);
-    L.w1p = pn_bump<float>(pt, (size_t)L.h1 * L.kp);
-    L.dw1p = pn_bump<float>(pt, (size_t)L.h1 * L.kp);
+
+  // ---- index phase: FPS + ball query of all three levels (positions only), rows per group back to the host
+  size_t ineed = 256 * 8 + 2 * (size_t)n_obj * sizeof(int32_t);
+  for (int l = 0; l < 3; ++l) ineed += pt->lv[l].G * (3 * sizeof(float) + 34 * sizeof(int32_t)) + 3 * 256;
+  if (ineed > pt->iws_cap) {
+    T2L_HIP(ctx, hipStreamSynchronize(s));
+    if (pt->iws) (void)hipFree(pt->iws);
+    pt->iws = nullptr;
+    pt->iws_cap = 0;
+    T2L_HIP(ctx, hipMalloc(&pt->iws, ineed));
+    pt->iws_cap = ineed;
+  }
+  int32_t* i_cell_base;
+  {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+      char* p = pt->iws + off;
+      off += (bytes + 255) & ~(size_t)255;
+      return p;
+    };
+    i_cell_base = reinterpret_cast<int32_t*>(take((size_t)n_obj * sizeof(int32_t)));
+    for (int l = 0; l < 3; ++l) {
+      PnLevel& L = pt->lv[l];
+      L.pos_out = reinterpret_cast<float*>(take(L.G * 3 * sizeof(float)));
+      L.nbr33 = reinterpret_cast<int32_t*>(take(L.G * 33 * sizeof(int32_t)));
+      L.cnt_g = reinterpret_cast<int32_t*>(take(L.G * sizeof(int32_t)));
+    }
+  }
+  T2L_HIP(ctx, hipMemcpyAsync(i_cell_base, h_tab.data() + n_obj, sizeof(int32_t) * n_obj, hipMemcpyHostToDevice, s));
+  event_begin(ctx, "pointnet_train_index", s);
+  {
+    const float* cur_pos = pos;
+    for (int l = 0; l < 3; ++l) {
+      PnLevel& L = pt->lv[l];
+      const float r2 = radius[l] * radius[l];  // float32 product, as the restatement
+      const unsigned fg = (unsigned)((n_obj + 3) / 4), bg = (unsigned)((L.G + 3) / 4);
+      if (L.ns == 256) {
+        hipLaunchKernelGGL((pt_fps_kernel<4>), dim3(fg), dim3(256), 0, s, cur_pos, n_obj, L.nd, L.pos_out);
+        hipLaunchKernelGGL((pt_ball_kernel<4>), dim3(bg), dim3(256), 0, s, cur_pos, (const float*)L.pos_out, n_obj, L.nd, r2,
+                           (const int32_t*)i_cell_base, ctx->pn_self_loops, L.nbr33, L.cnt_g);
+      } else if (L.ns == 128) {
+        hipLaunchKernelGGL((pt_fps_kernel<2>), dim3(fg), dim3(256), 0, s, cur_pos, n_obj, L.nd, L.pos_out);
+        hipLaunchKernelGGL((pt_ball_kernel<2>), dim3(bg), dim3(256), 0, s, cur_pos, (const float*)L.pos_out, n_obj, L.nd, r2,
+                           (const int32_t*)i_cell_base, ctx->pn_self_loops, L.nbr33, L.cnt_g);
+      } else {
+        hipLaunchKernelGGL((pt_fps_kernel<1>), dim3(fg), dim3(256), 0, s, cur_pos, n_obj, L.nd, L.pos_out);
+        hipLaunchKernelGGL((pt_ball_kernel<1>), dim3(bg), dim3(256), 0, s, cur_pos, (const float*)L.pos_out, n_obj, L.nd, r2,
+                           (const int32_t*)i_cell_base, ctx->pn_self_loops, L.nbr33, L.cnt_g);
+      }
+      cur_pos = L.pos_out;
+    }
+  }
+  event_end(ctx, "pointnet_train_index", s);
+  std::vector<std::vector<int32_t>> h_goff(3), h_cnt(4, std::vector<int32_t>(n_cells, 0));
+  for (int l = 0; l < 3; ++l) {
+    h_goff[l].resize(pt->lv[l].G + 1);
+    T2L_HIP(ctx, hipMemcpyAsync(h_goff[l].data() + 1, pt->lv[l].cnt_g, sizeof(int32_t) * pt->lv[l].G, hipMemcpyDeviceToHost, s));
+  }
+  T2L_HIP(ctx, hipStreamSynchronize(s));
+  for (int l = 0; l < 3; ++l) {
+    PnLevel& L = pt->lv[l];
+    std::vector<int32_t>& g = h_goff[l];
+    g[0] = 0;
+    long long total = 0;
+    for (size_t i = 0; i < L.G; ++i) {
+      const int c = g[i + 1];
+      if (c < 1 || c > 33) return fail(ctx, T2L_EHIP, "t2l_pointnet_features_train: ball query returned an impossible row count");
+      h_cnt[l][h_tab[i / L.nd]] += c;
+      total += c;
+      g[i + 1] = (int32_t)total;
+    }
+    if (total > 0x3fffffffll) return fail(ctx, T2L_EINVAL, "t2l_pointnet_features_train: batch too large (more than 2^30 edge rows in one level)");
+    L.E = (size_t)total;
+  }
+  pt->lv[3].E = (size_t)n_obj * 32;
+  for (int c = 0; c < n_cells; ++c) h_cnt[3][c] = (cell_offsets[c + 1] - cell_offsets[c]) * 32;
+
+  // ---- activations: exact sizes
+  char* keep = pt->ws;
+  pt->ws = nullptr;
+  const size_t need = pn_layout(pt);
+  pt->ws = keep;
+  if (need > pt->ws_cap) {
+    if (pt->ws) (void)hipFree(pt->ws);
+    pt->ws = nullptr;
+    pt->ws_cap = 0;
+    T2L_HIP(ctx, hipMalloc(&pt->ws, need));
+    pt->ws_cap = need;
+  }
+  (void)pn_layout(pt);
+  T2L_HIP(ctx, hipMemcpyAsync(pt->cell_of_obj, h_tab.data(), sizeof(int32_t) * n_obj, hipMemcpyHostToDevice, s));
+  T2L_HIP(ctx, hipMemcpyAsync(pt->cell_base, h_tab.data() + n_obj, sizeof(int32_t) * n_obj, hipMemcpyHostToDevice, s));
+  for (int l = 0; l < 4; ++l) {
+    T2L_HIP(ctx, hipMemcpyAsync(pt->lv[l].cnt, h_cnt[l].data(), sizeof(int32_t) * n_cells, hipMemcpyHostToDevice, s));
+    if (l < 3)
+      T2L_HIP(ctx, hipMemcpyAsync(pt->lv[l].goff, h_goff[l].data(), sizeof(int32_t) * (pt->lv[l].G + 1), hipMemcpyHostToDevice, s));
+  }
+
+  event_begin(ctx, "pointnet_train_forward", s);
+  const float* cur_pos = pos;
+  const float* cur_x = rgb;
+  for (int l = 0; l < 4; ++l) {
+    PnLevel& L = pt->lv[l];
+    if (L.sa)
+      hipLaunchKernelGGL(pt_compact_kernel, dim3(pn_blocks(L.G * 33)), dim3(256), 0, s, (const int32_t*)L.nbr33, (const int32_t*)L.goff, L.G,
+                         L.nd, (const int32_t*)pt->cell_of_obj, L.src, L.row_group, L.row_cell);
+    else
+      hipLaunchKernelGGL(pt_iota_rows_kernel, dim3(pn_blocks(L.E + 1)), dim3(256), 0, s, L.E, 32, (const int32_t*)pt->cell_of_obj, L.src,
+                         L.row_group, L.row_cell, L.goff);
+    hipLaunchKernelGGL(pt_gather_kernel, dim3(pn_blocks(L.E * L.kp)), dim3(256), 0, s, cur_x, cur_pos, L.sa ? (const float*)L.pos_out : nullptr,
+                       (const int32_t*)L.src, (const int32_t*)L.row_group, L.E, L.cin, L.kp, L.X);
     hipLaunchKernelGGL(pt_pad_kernel, dim3(pn_blocks((size_t)L.h1 * L.kp)), dim3(256), 0, s, (const float*)T_(st, L.prefix + ".0.0.weight").data,
                        L.h1, L.kin, L.kp, L.w1p);
-    L.y1 = pn_bump<float>(pt, L.E * L.h1);
-    L.a1 = pn_bump<float>(pt, L.E * L.h1);
-    L.y2 = pn_bump<float>(pt, L.E * L.h2);
-    L.a2 = pn_bump<float>(pt, L.E * L.h2);
-    L.mean1 = pn_bump<float>(pt, (size_t)n_cells * L.h1);
-    L.rstd1 = pn_bump<float>(pt, (size_t)n_cells * L.h1);
-    L.mean2 = pn_bump<float>(pt, (size_t)n_cells * L.h2);
-    L.rstd2 = pn_bump<float>(pt, (size_t)n_cells * L.h2);
     pn_block_fwd(st, pt, L, 0, L.X, L.w1p, L.kp, L.h1, L.y1, L.a1, L.mean1, L.rstd1, s);
     pn_block_fwd(st, pt, L, 1, L.a1, T_(st, L.prefix + ".1.0.weight").data, L.h1, L.h2, L.y2, L.a2, L.mean2, L.rstd2, s);
-    const size_t n_groups = (size_t)n_obj * L.nd;
-    L.xout = pn_bump<float>(pt, n_groups * L.h2);
-    L.arg = pn_bump<int32_t>(pt, n_groups * L.h2);
-    hipLaunchKernelGGL(pt_segmax_kernel, dim3(pn_blocks(n_groups * L.h2)), dim3(256), 0, s, (const float*)L.a2, (const int32_t*)L.nbr, n_groups, L.R,
-                       L.h2, L.xout, L.arg);
+    hipLaunchKernelGGL(pt_segmax_kernel, dim3(pn_blocks(L.G * L.h2)), dim3(256), 0, s, (const float*)L.a2, (const int32_t*)L.goff, L.G, L.h2,
+                       L.xout, L.arg);
     if (L.sa) {
       cur_pos = L.pos_out;
       cur_x = L.xout;
     }
   }
   pt->f0 = pt->lv[3].xout;
-  pt->f1 = pn_bump<float>(pt, (size_t)n_obj * 512);
-  pt->f2 = pn_bump<float>(pt, (size_t)n_obj * 256);
   gemm_nt(pt->f0, T_(st, P + "lin1.weight").data, T_(st, P + "lin1.bias").data, pt->f1, n_obj, 512, 1024, 1, s);
   gemm_nt(pt->f1, T_(st, P + "lin2.weight").data, T_(st, P + "lin2.bias").data, pt->f2, n_obj, 256, 512, 1, s);
   T2L_HIP(ctx, hipMemcpyAsync(out_f2, pt->f2, sizeof(float) * (size_t)n_obj * 256, hipMemcpyDeviceToDevice, s));
   event_end(ctx, "pointnet_train_forward", s);
   T2L_HIP(ctx, hipGetLastError());
-  if (pt->ws_off > pt->ws_cap) return fail(ctx, T2L_ENOMEM, "t2l_pointnet_features_train: workspace bound exceeded (internal error)");
+  T2L_HIP(ctx, hipStreamSynchronize(s));  // the host tables above go out of scope
   pt->have_forward = true;
   return T2L_OK;
 }
@@ -581,14 +715,15 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
   if (!pt->trainable)
     return fail(ctx, T2L_ESTATE, "t2l_pointnet_backward: the backbone was bound without gradient buffers (frozen)");
   if (!grad_f2) return fail(ctx, T2L_EINVAL, "t2l_pointnet_backward: null gradient");
-  const size_t mark = pt->ws_off;
   const int n_obj = pt->n_obj;
   tl_gemm_bf16 = ctx->train_bf16;
   const std::string P = "object_encoder.pointnet.";
   event_begin(ctx, "pointnet_train_backward", s);
+  pt->ws_off = pt->scratch_off;
   float* d2 = pn_bump<float>(pt, (size_t)n_obj * 256);
   float* d1 = pn_bump<float>(pt, (size_t)n_obj * 512);
-  float* dx = pn_bump<float>(pt, (size_t)n_obj * 1024);  // gradient w.r.t. the current level's output
+  float* dx = pn_bump<float>(pt, (size_t)n_obj * 8192);  // gradient w.r.t. the current level's output ...
+  float* dx_next = pn_bump<float>(pt, (size_t)n_obj * 8192);  // ... and w.r.t. the output of the level below
   T2L_HIP(ctx, hipMemcpyAsync(d2, grad_f2, sizeof(float) * (size_t)n_obj * 256, hipMemcpyDeviceToDevice, s));
   hipLaunchKernelGGL(pt_relu_mask_kernel, dim3(pn_blocks((size_t)n_obj * 256)), dim3(256), 0, s, d2, (const float*)pt->f2, (size_t)n_obj * 256);
   gemm_tn(d2, pt->f1, T_(st, P + "lin2.weight").grad, T_(st, P + "lin2.bias").grad, n_obj, 256, 512, s);
@@ -601,7 +736,8 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
     const size_t lmark = pt->ws_off;
     float* dA2 = pn_bump<float>(pt, L.E * L.h2);
     float* dA1 = pn_bump<float>(pt, L.E * L.h1);
-    hipLaunchKernelGGL(pt_maxbwd_kernel, dim3(pn_blocks(L.E * L.h2)), dim3(256), 0, s, (const float*)dx, (const int32_t*)L.arg, L.E, L.R, L.h2, dA2);
+    hipLaunchKernelGGL(pt_maxbwd_kernel, dim3(pn_blocks(L.E * L.h2 / 4)), dim3(256), 0, s, (const float*)dx, (const int32_t*)L.arg,
+                       (const int32_t*)L.row_group, L.E, L.h2, dA2);
     pn_block_bwd(st, pt, L, 1, dA2, L.y2, L.a2, L.h2, L.mean2, L.rstd2, s);
     gemm_tn(dA2, L.a1, T_(st, L.prefix + ".1.0.weight").grad, T_(st, L.prefix + ".1.0.bias").grad, (int)L.E, L.h2, L.h1, s);
     gemm_nn_rows(dA2, T_(st, L.prefix + ".1.0.weight").data, dA1, L.E, L.h2, L.h1, s);
@@ -614,24 +750,21 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
       float* dX = pn_bump<float>(pt, L.E * L.kp);
       gemm_nn_rows(dA1, L.w1p, dX, L.E, L.h1, L.kp, s);
       const PnLevel& Lb = pt->lv[l - 1];
-      const size_t nprev = (size_t)n_obj * Lb.nd * Lb.h2;
-      // dx lives below the per-level scratch: write the new one after it, then move it down
-      float* dnew = pn_bump<float>(pt, nprev);
+      const size_t nprev = Lb.G * Lb.h2;
       if (L.sa) {
-        T2L_HIP(ctx, hipMemsetAsync(dnew, 0, sizeof(float) * nprev, s));
-        hipLaunchKernelGGL(pt_scatter_kernel, dim3(pn_blocks(L.E * L.cin)), dim3(256), 0, s, (const float*)dX, (const int32_t*)L.nbr, L.E, L.cin, L.kp, dnew);
+        T2L_HIP(ctx, hipMemsetAsync(dx_next, 0, sizeof(float) * nprev, s));
+        hipLaunchKernelGGL(pt_scatter_kernel, dim3(pn_blocks(L.E * L.cin)), dim3(256), 0, s, (const float*)dX, (const int32_t*)L.src, L.E, L.cin,
+                           L.kp, dx_next);
       } else {
-        hipLaunchKernelGGL(pt_slice_kernel, dim3(pn_blocks(L.E * L.cin)), dim3(256), 0, s, (const float*)dX, L.E, L.cin, L.kp, dnew);
+        hipLaunchKernelGGL(pt_slice_kernel, dim3(pn_blocks(L.E * L.cin)), dim3(256), 0, s, (const float*)dX, L.E, L.cin, L.kp, dx_next);
       }
-      pt->ws_off = lmark;
-      dx = pn_bump<float>(pt, nprev);  // == the old dA2 region start: move the result there
-      T2L_HIP(ctx, hipMemcpyAsync(dx, dnew, sizeof(float) * nprev, hipMemcpyDeviceToDevice, s));
-    } else {
-      pt->ws_off = lmark;
+      std::swap(dx, dx_next);
     }
+    if (pt->ws_off > pt->scratch_off + pt->scratch_bytes || pt->ws_off > pt->ws_cap)
+      return fail(ctx, T2L_ENOMEM, "t2l_pointnet_backward: scratch bound exceeded (internal error)");
+    pt->ws_off = lmark;
   }
   event_end(ctx, "pointnet_train_backward", s);
-  pt->ws_off = mark;
   T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;
 }
