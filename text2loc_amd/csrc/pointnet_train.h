@@ -179,9 +179,10 @@ __global__ void pt_unpad_add_kernel(const float* __restrict__ dWp, int rows, int
   if (i < rows * kin) dW[i] += dWp[(i / kin) * kp + (i % kin)];
 }
 
-// per-(cell, channel) sums over a block of kStatRows rows; grid (ceil(C/64), ceil(E/kStatRows)). Rows are sorted by cell, so a
-// thread keeps one running segment and flushes it (float64 atomics) when the cell changes; a block inside ONE cell — nearly
-// all of them — reduces its four row lanes through LDS first.
+// per-(cell, channel) sums over a block of kStatRows rows; grid (C/64, ceil(E/kStatRows)) (C = 32: grid.x = 1, half idle).
+// Thread = 4 channels (float4) x one of 16 row lanes: a wave covers 4 rows x 64 channels per load, 1 KiB. Rows are sorted by
+// cell, so a thread keeps one running segment and flushes it (float64 atomics) when the cell changes; a block inside ONE cell —
+// nearly all of them — reduces its 16 row lanes through LDS first.
 // MODE 0: acc[cell][0][c] += sum y, acc[cell][1][c] += sum y^2. MODE 1: dv = a > 0 ? d : 0: sum dv, sum dv * xhat
 constexpr int kStatRows = 1024;
 template <int MODE>
@@ -189,60 +190,71 @@ __global__ __launch_bounds__(256) void pt_bn_stats_kernel(const float* __restric
                                                           const float* __restrict__ a, int C, size_t E,
                                                           const int32_t* __restrict__ row_cell, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, double* __restrict__ acc) {
-  __shared__ float r1[256], r2[256];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-  const bool cok = c < C;  // (C = 32: half of the lanes idle)
+  __shared__ float4 r1[256], r2[256];
+  const int c = blockIdx.x * 64 + 4 * (threadIdx.x & 15), g = threadIdx.x >> 4;
+  const bool cok = c < C;
   const size_t lo = (size_t)blockIdx.y * kStatRows, hi = min(E, lo + kStatRows);
   const int cell_first = row_cell[lo], cell_last = row_cell[hi - 1];
   const bool one_cell = cell_first == cell_last;  // block-uniform
   int cur = cell_first;
-  float mu = 0.f, rs = 0.f;
-  if (MODE == 1 && cok) {
-    mu = mean[(size_t)cur * C + c];
-    rs = rstd[(size_t)cur * C + c];
-  }
-  float s1 = 0.f, s2 = 0.f;
+  float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = mu, s1 = mu, s2 = mu;
+  auto stat_of = [&](int cell) {
+    if (MODE == 1 && cok) {
+      mu = *reinterpret_cast<const float4*>(mean + (size_t)cell * C + c);
+      rs = *reinterpret_cast<const float4*>(rstd + (size_t)cell * C + c);
+    }
+  };
+  auto flush = [&](int cell) {
+    double* p1 = acc + ((size_t)cell * 2) * 1024 + c;
+    double* p2 = acc + ((size_t)cell * 2 + 1) * 1024 + c;
+    atomicAdd(p1, (double)s1.x); atomicAdd(p1 + 1, (double)s1.y); atomicAdd(p1 + 2, (double)s1.z); atomicAdd(p1 + 3, (double)s1.w);
+    atomicAdd(p2, (double)s2.x); atomicAdd(p2 + 1, (double)s2.y); atomicAdd(p2 + 2, (double)s2.z); atomicAdd(p2 + 3, (double)s2.w);
+    s1 = s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  stat_of(cur);
   if (cok) {
-    for (size_t row = lo + g; row < hi; row += 4) {
+#pragma unroll 2
+    for (size_t row = lo + g; row < hi; row += 16) {
       if (!one_cell) {
         const int cell = row_cell[row];
         if (cell != cur) {
-          atomicAdd(acc + ((size_t)cur * 2) * 1024 + c, (double)s1);
-          atomicAdd(acc + ((size_t)cur * 2 + 1) * 1024 + c, (double)s2);
-          s1 = s2 = 0.f;
+          flush(cur);
           cur = cell;
-          if (MODE == 1) {
-            mu = mean[(size_t)cur * C + c];
-            rs = rstd[(size_t)cur * C + c];
-          }
+          stat_of(cur);
         }
       }
       const size_t i = row * C + c;
+      const float4 v = *reinterpret_cast<const float4*>(y + i);
       if (MODE == 0) {
-        const float v = y[i];
-        s1 += v;
-        s2 += v * v;
+        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+        s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
       } else {
-        const float dv = a[i] > 0.f ? d[i] : 0.f;
-        s1 += dv;
-        s2 += dv * (y[i] - mu) * rs;
+        const float4 dv = *reinterpret_cast<const float4*>(d + i), av = *reinterpret_cast<const float4*>(a + i);
+        const float e0 = av.x > 0.f ? dv.x : 0.f, e1 = av.y > 0.f ? dv.y : 0.f, e2 = av.z > 0.f ? dv.z : 0.f, e3 = av.w > 0.f ? dv.w : 0.f;
+        s1.x += e0; s1.y += e1; s1.z += e2; s1.w += e3;
+        s2.x += e0 * (v.x - mu.x) * rs.x; s2.y += e1 * (v.y - mu.y) * rs.y; s2.z += e2 * (v.z - mu.z) * rs.z; s2.w += e3 * (v.w - mu.w) * rs.w;
       }
     }
   }
   if (!one_cell) {
-    if (cok) {
-      atomicAdd(acc + ((size_t)cur * 2) * 1024 + c, (double)s1);
-      atomicAdd(acc + ((size_t)cur * 2 + 1) * 1024 + c, (double)s2);
-    }
+    if (cok) flush(cur);
     return;
   }
   r1[threadIdx.x] = s1;
   r2[threadIdx.x] = s2;
   __syncthreads();
-  if (g == 0 && cok) {
-    const int t = threadIdx.x;
-    atomicAdd(acc + ((size_t)cur * 2) * 1024 + c, (double)r1[t] + (double)r1[t + 64] + (double)r1[t + 128] + (double)r1[t + 192]);
-    atomicAdd(acc + ((size_t)cur * 2 + 1) * 1024 + c, (double)r2[t] + (double)r2[t + 64] + (double)r2[t + 128] + (double)r2[t + 192]);
+  if (threadIdx.x < 64) {  // thread t: channel blockIdx.x * 64 + t, summed over the 16 row lanes
+    const int t = threadIdx.x, q = t >> 2, e = t & 3;
+    if (blockIdx.x * 64 + t < C) {
+      double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        t1 += (double)reinterpret_cast<const float*>(&r1[16 * j + q])[e];
+        t2 += (double)reinterpret_cast<const float*>(&r2[16 * j + q])[e];
+      }
+      atomicAdd(acc + ((size_t)cur * 2) * 1024 + blockIdx.x * 64 + t, t1);
+      atomicAdd(acc + ((size_t)cur * 2 + 1) * 1024 + blockIdx.x * 64 + t, t2);
+    }
   }
 }
 
@@ -286,12 +298,16 @@ __global__ __launch_bounds__(256) void pt_bn_apply_fwd_kernel(const float* __res
   *reinterpret_cast<float4*>(a + i) = o;
 }
 
-// d (gradient w.r.t. the ReLU output) -> gradient w.r.t. the Linear output, in place
+// d (gradient w.r.t. the ReLU output) -> gradient w.r.t. the Linear output, in place. FROM_MAX (second layer of a block): the
+// incoming gradient is not read from d but rebuilt from the max aggregation — row `arg[group][c]` receives dxout[group][c],
+// every other row 0 — and the result is written to d.
+template <bool FROM_MAX>
 __global__ __launch_bounds__(256) void pt_bn_apply_bwd_kernel(float* __restrict__ d, const float* __restrict__ a, const float* __restrict__ y,
                                                               size_t E, int C, const int32_t* __restrict__ row_cell,
                                                               const int32_t* __restrict__ cnt, const double* __restrict__ acc,
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                              const float* __restrict__ rstd) {
+                                                              const float* __restrict__ rstd, const int32_t* __restrict__ arg,
+                                                              const float* __restrict__ dxout, const int32_t* __restrict__ row_group) {
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= E * C) return;
   const size_t row = i / C;
@@ -299,9 +315,19 @@ __global__ __launch_bounds__(256) void pt_bn_apply_bwd_kernel(float* __restrict_
   const int cell = row_cell[row];
   const size_t sc = (size_t)cell * C + c;
   const float n = (float)max(cnt[cell], 1);
-  const float4 dv4 = *reinterpret_cast<const float4*>(d + i), av = *reinterpret_cast<const float4*>(a + i),
-               yv = *reinterpret_cast<const float4*>(y + i), m = *reinterpret_cast<const float4*>(mean + sc),
-               r = *reinterpret_cast<const float4*>(rstd + sc), ga = *reinterpret_cast<const float4*>(gamma + c);
+  float4 dv4;
+  if constexpr (FROM_MAX) {
+    const size_t gi = (size_t)row_group[row] * C + c;
+    const int4 ar = *reinterpret_cast<const int4*>(arg + gi);
+    const float4 dx = *reinterpret_cast<const float4*>(dxout + gi);
+    const int r = (int)row;
+    dv4 = make_float4(ar.x == r ? dx.x : 0.f, ar.y == r ? dx.y : 0.f, ar.z == r ? dx.z : 0.f, ar.w == r ? dx.w : 0.f);
+  } else {
+    dv4 = *reinterpret_cast<const float4*>(d + i);
+  }
+  const float4 av = *reinterpret_cast<const float4*>(a + i), yv = *reinterpret_cast<const float4*>(y + i),
+               m = *reinterpret_cast<const float4*>(mean + sc), r = *reinterpret_cast<const float4*>(rstd + sc),
+               ga = *reinterpret_cast<const float4*>(gamma + c);
   const double* a1 = acc + ((size_t)cell * 2) * 1024 + c;
   const double* a2 = acc + ((size_t)cell * 2 + 1) * 1024 + c;
   float4 o;
@@ -313,6 +339,43 @@ __global__ __launch_bounds__(256) void pt_bn_apply_bwd_kernel(float* __restrict_
   T2L_PT_BWD(x, 0) T2L_PT_BWD(y, 1) T2L_PT_BWD(z, 2) T2L_PT_BWD(w, 3)
 #undef T2L_PT_BWD
   *reinterpret_cast<float4*>(d + i) = o;
+}
+// BatchNorm-backward sums of a block's SECOND layer, straight from the max aggregation: only the arg-max row of every
+// (group, channel) carries a gradient, so sum dv and sum dv * xhat are sums over GROUPS (dv = dxout where the maximum is > 0;
+// xhat from one gathered y per (group, channel)) — no pass over the edge rows. grid (ceil(C/64), ceil(G/256)).
+__global__ __launch_bounds__(256) void pt_bn_stats_max_kernel(const float* __restrict__ y, const float* __restrict__ xout,
+                                                              const int32_t* __restrict__ arg, const float* __restrict__ dxout, size_t G, int C,
+                                                              int nd, const int32_t* __restrict__ cell_of_obj,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              double* __restrict__ acc) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), gl = threadIdx.x >> 6;
+  if (c >= C) return;
+  const size_t lo = (size_t)blockIdx.y * 256, hi = min(G, lo + 256);
+  int cur = -1;
+  float mu = 0.f, rs = 0.f, s1 = 0.f, s2 = 0.f;
+  for (size_t g = lo + gl; g < hi; g += 4) {
+    const int cell = cell_of_obj[g / nd];
+    if (cell != cur) {
+      if (cur >= 0) {
+        atomicAdd(acc + ((size_t)cur * 2) * 1024 + c, (double)s1);
+        atomicAdd(acc + ((size_t)cur * 2 + 1) * 1024 + c, (double)s2);
+      }
+      s1 = s2 = 0.f;
+      cur = cell;
+      mu = mean[(size_t)cur * C + c];
+      rs = rstd[(size_t)cur * C + c];
+    }
+    const size_t i = g * C + c;
+    if (xout[i] > 0.f) {
+      const float dv = dxout[i];
+      s1 += dv;
+      s2 += dv * (y[(size_t)arg[i] * C + c] - mu) * rs;
+    }
+  }
+  if (cur >= 0) {
+    atomicAdd(acc + ((size_t)cur * 2) * 1024 + c, (double)s1);
+    atomicAdd(acc + ((size_t)cur * 2 + 1) * 1024 + c, (double)s2);
+  }
 }
 __global__ void pt_bn_param_grad_kernel(const double* __restrict__ acc, int n_cells, int C, float* __restrict__ dgamma,
                                         float* __restrict__ dbeta) {
@@ -346,18 +409,6 @@ __global__ __launch_bounds__(256) void pt_segmax_kernel(const float* __restrict_
   }
   xout[i] = fmaxf(best, 0.f);
   arg[i] = br;
-}
-__global__ __launch_bounds__(256) void pt_maxbwd_kernel(const float* __restrict__ dxout, const int32_t* __restrict__ arg,
-                                                        const int32_t* __restrict__ row_group, size_t E, int C, float* __restrict__ dA) {
-  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= E * C) return;
-  const size_t row = i / C;
-  const int c = (int)(i % C);
-  const size_t gi = (size_t)row_group[row] * C + c;
-  const int4 ar = *reinterpret_cast<const int4*>(arg + gi);
-  const float4 dv = *reinterpret_cast<const float4*>(dxout + gi);
-  const int r = (int)row;
-  *reinterpret_cast<float4*>(dA + i) = make_float4(ar.x == r ? dv.x : 0.f, ar.y == r ? dv.y : 0.f, ar.z == r ? dv.z : 0.f, ar.w == r ? dv.w : 0.f);
 }
 // dx_src[src][0:cin] += dX[row][0:cin]
 __global__ __launch_bounds__(256) void pt_scatter_kernel(const float* __restrict__ dX, const int32_t* __restrict__ src, size_t E, int cin, int kp,
@@ -518,17 +569,27 @@ static void pn_block_fwd(TrainState* st, PnTrain* pt, const PnLevel& L, int laye
                      (const float*)T_(st, p + ".1.bias").data, a);
 }
 
-// d: gradient w.r.t. the block's ReLU output [E, C] (overwritten with the gradient w.r.t. the Linear output)
+// d: gradient w.r.t. the block's ReLU output [E, C] (overwritten with the gradient w.r.t. the Linear output). dxout != nullptr
+// (second layer): that gradient is implied by the max aggregation (dxout [G, C] at the arg-max rows) and d is only written.
 static void pn_block_bwd(TrainState* st, PnTrain* pt, const PnLevel& L, int layer, float* d, const float* y, const float* a, int C,
-                         const float* mean, const float* rstd, hipStream_t s) {
+                         const float* mean, const float* rstd, const float* dxout, hipStream_t s) {
   using namespace train;
   const std::string p = L.prefix + "." + std::to_string(layer);
   (void)hipMemsetAsync(pt->acc, 0, sizeof(double) * 2 * 1024 * pt->n_cells, s);
-  const dim3 sgrid((C + 63) / 64, (unsigned)((L.E + kStatRows - 1) / kStatRows));
-  hipLaunchKernelGGL((pt_bn_stats_kernel<1>), sgrid, dim3(256), 0, s, y, (const float*)d, a, C, L.E, (const int32_t*)L.row_cell, mean, rstd,
-                     pt->acc);
-  hipLaunchKernelGGL(pt_bn_apply_bwd_kernel, dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, d, a, y, L.E, C, (const int32_t*)L.row_cell,
-                     (const int32_t*)L.cnt, (const double*)pt->acc, (const float*)T_(st, p + ".1.weight").data, mean, rstd);
+  if (dxout) {
+    hipLaunchKernelGGL(pt_bn_stats_max_kernel, dim3((C + 63) / 64, (unsigned)((L.G + 255) / 256)), dim3(256), 0, s, y, (const float*)L.xout,
+                       (const int32_t*)L.arg, dxout, L.G, C, L.nd, (const int32_t*)pt->cell_of_obj, mean, rstd, pt->acc);
+    hipLaunchKernelGGL((pt_bn_apply_bwd_kernel<true>), dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, d, a, y, L.E, C,
+                       (const int32_t*)L.row_cell, (const int32_t*)L.cnt, (const double*)pt->acc, (const float*)T_(st, p + ".1.weight").data, mean,
+                       rstd, (const int32_t*)L.arg, dxout, (const int32_t*)L.row_group);
+  } else {
+    const dim3 sgrid((C + 63) / 64, (unsigned)((L.E + kStatRows - 1) / kStatRows));
+    hipLaunchKernelGGL((pt_bn_stats_kernel<1>), sgrid, dim3(256), 0, s, y, (const float*)d, a, C, L.E, (const int32_t*)L.row_cell, mean, rstd,
+                       pt->acc);
+    hipLaunchKernelGGL((pt_bn_apply_bwd_kernel<false>), dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, d, a, y, L.E, C,
+                       (const int32_t*)L.row_cell, (const int32_t*)L.cnt, (const double*)pt->acc, (const float*)T_(st, p + ".1.weight").data, mean,
+                       rstd, (const int32_t*)nullptr, (const float*)nullptr, (const int32_t*)nullptr);
+  }
   hipLaunchKernelGGL(pt_bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)pt->acc, pt->n_cells, C,
                      T_(st, p + ".1.weight").grad, T_(st, p + ".1.bias").grad);
 }
@@ -736,12 +797,10 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
     const size_t lmark = pt->ws_off;
     float* dA2 = pn_bump<float>(pt, L.E * L.h2);
     float* dA1 = pn_bump<float>(pt, L.E * L.h1);
-    hipLaunchKernelGGL(pt_maxbwd_kernel, dim3(pn_blocks(L.E * L.h2 / 4)), dim3(256), 0, s, (const float*)dx, (const int32_t*)L.arg,
-                       (const int32_t*)L.row_group, L.E, L.h2, dA2);
-    pn_block_bwd(st, pt, L, 1, dA2, L.y2, L.a2, L.h2, L.mean2, L.rstd2, s);
+    pn_block_bwd(st, pt, L, 1, dA2, L.y2, L.a2, L.h2, L.mean2, L.rstd2, dx, s);
     gemm_tn(dA2, L.a1, T_(st, L.prefix + ".1.0.weight").grad, T_(st, L.prefix + ".1.0.bias").grad, (int)L.E, L.h2, L.h1, s);
     gemm_nn_rows(dA2, T_(st, L.prefix + ".1.0.weight").data, dA1, L.E, L.h2, L.h1, s);
-    pn_block_bwd(st, pt, L, 0, dA1, L.y1, L.a1, L.h1, L.mean1, L.rstd1, s);
+    pn_block_bwd(st, pt, L, 0, dA1, L.y1, L.a1, L.h1, L.mean1, L.rstd1, nullptr, s);
     T2L_HIP(ctx, hipMemsetAsync(L.dw1p, 0, sizeof(float) * (size_t)L.h1 * L.kp, s));
     gemm_tn(dA1, L.X, L.dw1p, T_(st, L.prefix + ".0.0.bias").grad, (int)L.E, L.h1, L.kp, s);
     hipLaunchKernelGGL(pt_unpad_add_kernel, dim3(pn_blocks((size_t)L.h1 * L.kin)), dim3(256), 0, s, (const float*)L.dw1p, L.h1, L.kin, L.kp,
