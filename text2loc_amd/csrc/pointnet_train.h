@@ -27,7 +27,7 @@ struct PnLevel {
   size_t E = 0, G = 0;                            // edge rows (valid ones only: compacted), groups
   int32_t *nbr33 = nullptr, *cnt_g = nullptr;     // index workspace: ball-query table [G][33] (-1 = empty), rows per group
   int32_t *goff = nullptr, *src = nullptr, *row_group = nullptr, *row_cell = nullptr, *arg = nullptr, *cnt = nullptr;
-  float *X = nullptr, *y1 = nullptr, *a1 = nullptr, *y2 = nullptr, *a2 = nullptr;
+  float *X = nullptr, *y1 = nullptr, *a1 = nullptr, *y2 = nullptr;  // (the second layer's post-ReLU output is never stored)
   float *mean1 = nullptr, *rstd1 = nullptr, *mean2 = nullptr, *rstd2 = nullptr;
   float *xout = nullptr, *pos_out = nullptr, *w1p = nullptr, *dw1p = nullptr;
 };
@@ -307,7 +307,8 @@ __global__ __launch_bounds__(256) void pt_bn_apply_bwd_kernel(float* __restrict_
                                                               const int32_t* __restrict__ cnt, const double* __restrict__ acc,
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, const int32_t* __restrict__ arg,
-                                                              const float* __restrict__ dxout, const int32_t* __restrict__ row_group) {
+                                                              const float* __restrict__ dxout, const int32_t* __restrict__ row_group,
+                                                              const float* __restrict__ beta) {
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= E * C) return;
   const size_t row = i / C;
@@ -325,9 +326,16 @@ __global__ __launch_bounds__(256) void pt_bn_apply_bwd_kernel(float* __restrict_
   } else {
     dv4 = *reinterpret_cast<const float4*>(d + i);
   }
-  const float4 av = *reinterpret_cast<const float4*>(a + i), yv = *reinterpret_cast<const float4*>(y + i),
-               m = *reinterpret_cast<const float4*>(mean + sc), r = *reinterpret_cast<const float4*>(rstd + sc),
-               ga = *reinterpret_cast<const float4*>(gamma + c);
+  const float4 yv = *reinterpret_cast<const float4*>(y + i), m = *reinterpret_cast<const float4*>(mean + sc),
+               r = *reinterpret_cast<const float4*>(rstd + sc), ga = *reinterpret_cast<const float4*>(gamma + c);
+  float4 av;  // the ReLU output (its sign is what matters): stored for first layers, recomputed for second ones
+  if constexpr (FROM_MAX) {
+    const float4 be = *reinterpret_cast<const float4*>(beta + c);
+    av = make_float4((yv.x - m.x) * r.x * ga.x + be.x, (yv.y - m.y) * r.y * ga.y + be.y, (yv.z - m.z) * r.z * ga.z + be.z,
+                     (yv.w - m.w) * r.w * ga.w + be.w);
+  } else {
+    av = *reinterpret_cast<const float4*>(a + i);
+  }
   const double* a1 = acc + ((size_t)cell * 2) * 1024 + c;
   const double* a2 = acc + ((size_t)cell * 2 + 1) * 1024 + c;
   float4 o;
@@ -390,18 +398,23 @@ __global__ void pt_bn_param_grad_kernel(const double* __restrict__ acc, int n_ce
   dgamma[c] += (float)s2;
 }
 
-// max over the rows of every group (first maximum wins, as argmax) + the winning row
-__global__ __launch_bounds__(256) void pt_segmax_kernel(const float* __restrict__ a, const int32_t* __restrict__ goff, size_t n_groups, int C,
-                                                        float* __restrict__ xout, int32_t* __restrict__ arg) {
+// second layer of a block: BatchNorm + ReLU applied on the fly, max over the rows of every group (first maximum wins, as
+// argmax) + the winning row — the post-ReLU activations of the widest layer never exist in memory
+__global__ __launch_bounds__(256) void pt_segmax_kernel(const float* __restrict__ y, const int32_t* __restrict__ goff, size_t n_groups, int C,
+                                                        int nd, const int32_t* __restrict__ cell_of_obj, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ xout, int32_t* __restrict__ arg) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_groups * C) return;
   const size_t g = i / C;
   const int c = (int)(i % C);
+  const size_t sc = (size_t)cell_of_obj[g / nd] * C + c;
+  const float m = mean[sc], r = rstd[sc], ga = gamma[c], be = beta[c];
   const int lo = goff[g], hi = goff[g + 1];
   float best = -1.f;  // ReLU outputs are >= 0 and every group has at least one row (the centre itself)
   int br = -1;
   for (int row = lo; row < hi; ++row) {
-    const float v = a[(size_t)row * C + c];
+    const float v = fmaxf((y[(size_t)row * C + c] - m) * r * ga + be, 0.f);
     if (v > best) {
       best = v;
       br = row;
@@ -533,7 +546,6 @@ static size_t pn_layout(PnTrain* pt) {
     L.y1 = pn_bump<float>(pt, L.E * L.h1);
     L.a1 = pn_bump<float>(pt, L.E * L.h1);
     L.y2 = pn_bump<float>(pt, L.E * L.h2);
-    L.a2 = pn_bump<float>(pt, L.E * L.h2);
     L.mean1 = pn_bump<float>(pt, (size_t)n_cells * L.h1);
     L.rstd1 = pn_bump<float>(pt, (size_t)n_cells * L.h1);
     L.mean2 = pn_bump<float>(pt, (size_t)n_cells * L.h2);
@@ -554,7 +566,7 @@ static size_t pn_layout(PnTrain* pt) {
 
 // one get_mlp block in training mode over segmented rows: y = X W^T + b; per-cell BatchNorm; ReLU
 static void pn_block_fwd(TrainState* st, PnTrain* pt, const PnLevel& L, int layer, const float* X, const float* W, int K, int C, float* y,
-                         float* a, float* mean, float* rstd, hipStream_t s) {
+                         float* a, float* mean, float* rstd, hipStream_t s) {  // a == nullptr: the consumer applies BatchNorm + ReLU itself
   using namespace train;
   const std::string p = L.prefix + "." + std::to_string(layer);
   gemm_nt_rows(X, W, T_(st, p + ".0.bias").data, y, L.E, C, K, 0, s);
@@ -564,9 +576,10 @@ static void pn_block_fwd(TrainState* st, PnTrain* pt, const PnLevel& L, int laye
                      (const int32_t*)L.row_cell, (const float*)nullptr, (const float*)nullptr, pt->acc);
   hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)pt->acc, (const int32_t*)L.cnt, pt->n_cells, C,
                      mean, rstd, T_(st, p + ".1.running_mean").data, T_(st, p + ".1.running_var").data, 0.1f);
-  hipLaunchKernelGGL(pt_bn_apply_fwd_kernel, dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, (const float*)y, L.E, C, (const int32_t*)L.row_cell,
-                     (const float*)mean, (const float*)rstd, (const float*)T_(st, p + ".1.weight").data,
-                     (const float*)T_(st, p + ".1.bias").data, a);
+  if (a)
+    hipLaunchKernelGGL(pt_bn_apply_fwd_kernel, dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, (const float*)y, L.E, C, (const int32_t*)L.row_cell,
+                       (const float*)mean, (const float*)rstd, (const float*)T_(st, p + ".1.weight").data,
+                       (const float*)T_(st, p + ".1.bias").data, a);
 }
 
 // d: gradient w.r.t. the block's ReLU output [E, C] (overwritten with the gradient w.r.t. the Linear output). dxout != nullptr
@@ -581,14 +594,14 @@ static void pn_block_bwd(TrainState* st, PnTrain* pt, const PnLevel& L, int laye
                        (const int32_t*)L.arg, dxout, L.G, C, L.nd, (const int32_t*)pt->cell_of_obj, mean, rstd, pt->acc);
     hipLaunchKernelGGL((pt_bn_apply_bwd_kernel<true>), dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, d, a, y, L.E, C,
                        (const int32_t*)L.row_cell, (const int32_t*)L.cnt, (const double*)pt->acc, (const float*)T_(st, p + ".1.weight").data, mean,
-                       rstd, (const int32_t*)L.arg, dxout, (const int32_t*)L.row_group);
+                       rstd, (const int32_t*)L.arg, dxout, (const int32_t*)L.row_group, (const float*)T_(st, p + ".1.bias").data);
   } else {
     const dim3 sgrid((C + 63) / 64, (unsigned)((L.E + kStatRows - 1) / kStatRows));
     hipLaunchKernelGGL((pt_bn_stats_kernel<1>), sgrid, dim3(256), 0, s, y, (const float*)d, a, C, L.E, (const int32_t*)L.row_cell, mean, rstd,
                        pt->acc);
     hipLaunchKernelGGL((pt_bn_apply_bwd_kernel<false>), dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, d, a, y, L.E, C,
                        (const int32_t*)L.row_cell, (const int32_t*)L.cnt, (const double*)pt->acc, (const float*)T_(st, p + ".1.weight").data, mean,
-                       rstd, (const int32_t*)nullptr, (const float*)nullptr, (const int32_t*)nullptr);
+                       rstd, (const int32_t*)nullptr, (const float*)nullptr, (const int32_t*)nullptr, (const float*)nullptr);
   }
   hipLaunchKernelGGL(pt_bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)pt->acc, pt->n_cells, C,
                      T_(st, p + ".1.weight").grad, T_(st, p + ".1.bias").grad);
@@ -749,9 +762,10 @@ int pn_train_forward_impl(t2l_ctx* ctx, const float* pos, const float* rgb, cons
     hipLaunchKernelGGL(pt_pad_kernel, dim3(pn_blocks((size_t)L.h1 * L.kp)), dim3(256), 0, s, (const float*)T_(st, L.prefix + ".0.0.weight").data,
                        L.h1, L.kin, L.kp, L.w1p);
     pn_block_fwd(st, pt, L, 0, L.X, L.w1p, L.kp, L.h1, L.y1, L.a1, L.mean1, L.rstd1, s);
-    pn_block_fwd(st, pt, L, 1, L.a1, T_(st, L.prefix + ".1.0.weight").data, L.h1, L.h2, L.y2, L.a2, L.mean2, L.rstd2, s);
-    hipLaunchKernelGGL(pt_segmax_kernel, dim3(pn_blocks(L.G * L.h2)), dim3(256), 0, s, (const float*)L.a2, (const int32_t*)L.goff, L.G, L.h2,
-                       L.xout, L.arg);
+    pn_block_fwd(st, pt, L, 1, L.a1, T_(st, L.prefix + ".1.0.weight").data, L.h1, L.h2, L.y2, nullptr, L.mean2, L.rstd2, s);
+    hipLaunchKernelGGL(pt_segmax_kernel, dim3(pn_blocks(L.G * L.h2)), dim3(256), 0, s, (const float*)L.y2, (const int32_t*)L.goff, L.G, L.h2,
+                       L.nd, (const int32_t*)pt->cell_of_obj, (const float*)L.mean2, (const float*)L.rstd2,
+                       (const float*)T_(st, L.prefix + ".1.1.weight").data, (const float*)T_(st, L.prefix + ".1.1.bias").data, L.xout, L.arg);
     if (L.sa) {
       cur_pos = L.pos_out;
       cur_x = L.xout;
@@ -797,7 +811,7 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
     const size_t lmark = pt->ws_off;
     float* dA2 = pn_bump<float>(pt, L.E * L.h2);
     float* dA1 = pn_bump<float>(pt, L.E * L.h1);
-    pn_block_bwd(st, pt, L, 1, dA2, L.y2, L.a2, L.h2, L.mean2, L.rstd2, dx, s);
+    pn_block_bwd(st, pt, L, 1, dA2, L.y2, nullptr, L.h2, L.mean2, L.rstd2, dx, s);
     gemm_tn(dA2, L.a1, T_(st, L.prefix + ".1.0.weight").grad, T_(st, L.prefix + ".1.0.bias").grad, (int)L.E, L.h2, L.h1, s);
     gemm_nn_rows(dA2, T_(st, L.prefix + ".1.0.weight").data, dA1, L.E, L.h2, L.h1, s);
     pn_block_bwd(st, pt, L, 0, dA1, L.y1, L.a1, L.h1, L.mean1, L.rstd1, nullptr, s);
