@@ -271,7 +271,7 @@ int t2l_encode_cells_backward(t2l_ctx* ctx, const float* grad_emb, float* grad_p
  * statistics of that cell's rows and updates its running statistics once per cell, in cell order; this call does the whole
  * batch at once with exactly that segmentation. pos, rgb: dev f32[n_objects,256,3]; cell_offsets: HOST i32[n_cells+1];
  * out_features2: dev f32[n_objects,256] (feed it to t2l_encode_cells_train as pn_feat). Activations stay in the context
- * (~14 KB per edge row; ~18 GB at 64 cells) until the next call. PARITY UNPINNED like t2l_pointnet_features. */
+ * (only real edges are rows; ~9 GB at 64 cells) until the next call. PARITY UNPINNED like t2l_pointnet_features. */
 int t2l_pointnet_features_train(t2l_ctx* ctx, const float* pos, const float* rgb, const int32_t* cell_offsets, int32_t n_cells,
                                 float* out_features2, void* stream);
 /* Backward of the call above: grad_features2 = d loss / d features2 (what t2l_encode_cells_backward wrote to grad_pn_feat),
