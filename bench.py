@@ -305,16 +305,24 @@ def secondary_measurements(eng):
         out["search_clustered"] = {"error": repr(e)}
     # latency of small query batches against the resident DB (the reference answers one query at a time)
     lat = {}
+    eng.set_option("profile_events", 0)  # (an event pair costs ~6 us per kernel: not inside a latency measurement)
     for qn in (1, 64):
         dq = torch.from_numpy(np.ascontiguousarray(_QS[:qn])).cuda()
-        for _ in range(10):
-            eng.search(dq, TOPK)
+        o = (torch.empty((qn, TOPK), dtype=torch.int32, device="cuda"), torch.empty((qn, TOPK), dtype=torch.float64, device="cuda"))
+        for _ in range(2000):  # (clock ramp, see main)
+            eng.search(dq, TOPK, out=o)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(200):
-            eng.search(dq, TOPK)
+        for _ in range(1000):
+            eng.search(dq, TOPK, out=o)
         torch.cuda.synchronize()
-        lat[f"q{qn}_us_per_call"] = (time.perf_counter() - t0) / 200 * 1e6
+        lat[f"q{qn}_us_per_call"] = (time.perf_counter() - t0) / 1000 * 1e6  # back to back on the stream
+        t0 = time.perf_counter()
+        for _ in range(200):
+            eng.search(dq, TOPK, out=o)
+            torch.cuda.synchronize()
+        lat[f"q{qn}_us_per_call_synchronized"] = (time.perf_counter() - t0) / 200 * 1e6  # host-visible round trip of one call
+    eng.set_option("profile_events", 1)
     out["search_latency"] = lat
     # HBM-streaming regime (SURVEY.md §8d config 2'): 32 queries against N = 2,097,152 rows (1 GiB of f16 DB plane,
     # 4x the Infinity Cache): algorithmic bytes = that plane once per launch (512 B per row)
@@ -411,6 +419,49 @@ def secondary_measurements(eng):
         eng_p.close()
     except Exception as e:
         out["pointnet"] = {"error": repr(e)}
+    # a9 + a3: the backbone in TRAINING mode at the published batch (64 cells): per-cell BatchNorm statistics, full backward
+    try:
+        eng_t = Engine(eng.device)
+        cells_t = synth.make_cells(64, seed=1)
+        pos_t, rgb_t = synth.make_sampled_points(cells_t, 1)
+        sd_t = dict(synth.make_object_branch_weights(2))
+        sd_t.update(synth.make_pointnet_weights(1))
+        tens = {}
+        for k, v in sd_t.items():
+            if k.endswith("num_batches_tracked") or k.endswith("_embedding.weight") or "classifier" in k:
+                continue
+            t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda()
+            tens[k] = (t, None if "running_" in k else torch.zeros_like(t))
+        eng_t.train_bind(tens, class_embed=False, color_embed=False)
+        offs_t = np.asarray(cells_t["offsets"], dtype=np.int32)
+        dpos_t, drgb_t = torch.from_numpy(pos_t).cuda(), torch.from_numpy(rgb_t).cuda()
+        g_t = torch.randn(pos_t.shape[0], 256, device="cuda")
+        res = {}
+        for variant, bf in (("f32", 0), ("bf16_gemms", 1)):
+            eng_t.set_option("train_bf16", bf)
+            fw, bw = [], []
+            for it in range(4):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                eng_t.pointnet_features_train(dpos_t, drgb_t, offs_t)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                eng_t.pointnet_backward(g_t)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                if it:
+                    fw.append(t1 - t0)
+                    bw.append(t2 - t1)
+            res[variant] = {"forward_ms": 1e3 * min(fw), "backward_ms": 1e3 * min(bw)}
+        free_b, total_b = torch.cuda.mem_get_info()
+        out["pointnet_train_b64"] = dict(res, cells=64, objects=int(pos_t.shape[0]),
+                                         parity="self-consistent only (float64 restatement + central differences, tests/test_gpu_pointnet_train.py)",
+                                         note="wall clock around t2l_pointnet_features_train / t2l_pointnet_backward (the forward includes its "
+                                              "index phase's host round trip)")
+        eng_t.close()
+        del tens
+    except Exception as e:
+        out["pointnet_train_b64"] = {"error": repr(e)}
     # f-1: fine stage on the coarse result — descriptors of all 11,259 database cells once, then Q x top-10 (pose, cell) pairs
     try:
         sd_f = synth.make_fine_weights(0)

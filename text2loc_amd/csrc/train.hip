@@ -462,12 +462,8 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   float* dqkv = bump<float>(st, (size_t)T * 3 * kTD);
   float* dfeat = bump<float>(st, (size_t)M * kTD);
   float* dcat = bump<float>(st, (size_t)M * Kc);
-  float* d2s[4];
-  float* d1s[4];
-  for (int i = 0; i < 4; ++i) {  // one scratch pair per feature branch: the branches run side by side
-    d2s[i] = bump<float>(st, (size_t)M * kTD);
-    d1s[i] = bump<float>(st, (size_t)M * 64);
-  }
+  float* d2 = bump<float>(st, (size_t)M * kTD);  // scratch of the feature branches (one after the other on the stream)
+  float* d1 = bump<float>(st, (size_t)M * 64);
   if (st->ws_off > st->ws_cap) {
     st->ws_off = mark;
     return fail(ctx, T2L_ENOMEM, "t2l_encode_cells_backward: workspace bound exceeded (internal error)");
@@ -509,8 +505,6 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   hipLaunchKernelGGL(scatter_norm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dcur, st->X0, st->save_nf, st->offsets, B, M, dfeat);
   mlp_layer_bwd(st, st->merge, dfeat, st->cat, M, 0, 0, dcat, s);
   for (const Branch& br : st->branches) {
-    float* d2 = d2s[br.slot & 3];
-    float* d1 = d1s[br.slot & 3];
     const float* dslot = dcat + br.slot * kTD;
     const float* yslot = st->cat + br.slot * kTD;
     hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dslot, yslot, Kc, br.save_n, M, d2);
