@@ -539,17 +539,23 @@ def secondary_measurements(eng):
             eng.adam_step(1e-3)
             return loss
 
-        for i in range(5):
+        # wall clock without event pairs (each costs the stream ~6 us) and after a clock ramp; phase times from a second, bracketed loop
+        eng.set_option("profile_events", 0)
+        for i in range(150):
             train_step(i)
-        for nme in ("train_forward", "train_backward", "adam_step", "contrastive_loss"):
-            eng.kernel_stats(nme)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n_steps = 50
+        n_steps = 100
         for i in range(n_steps):
-            last = train_step(100 + i)
+            last = train_step(1000 + i)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / n_steps
+        eng.set_option("profile_events", 1)
+        for nme in ("train_forward", "train_backward", "adam_step", "contrastive_loss"):
+            eng.kernel_stats(nme)
+        for i in range(30):
+            train_step(100 + i)
+        torch.cuda.synchronize()
         kept64 = int(np.minimum(cells64["counts"], 28).sum())
         fl = 3.0 * (64 * 60.33e6 + kept64 * 0.67e6)  # forward + 2x for backward (dX and dW contractions)
         out["train_step_b64"] = {"workload": "B=64 cells, %d objects, dropout 0.1, ContrastiveLoss(0.1), Adam" % int(cells64["offsets"][-1]),
@@ -569,13 +575,15 @@ def secondary_measurements(eng):
             eng.set_option("train_bf16", 1)
             pos16 = eng.encode_cells_train(p64, dropout_p=0.0, seed=1).clone()
             l16 = float(eng.contrastive_loss(anchor, pos16, 0.1)[0])
-            for i in range(5):
+            eng.set_option("profile_events", 0)
+            for i in range(150):
                 train_step(200 + i)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(n_steps):
-                train_step(300 + i)
+                train_step(2000 + i)
             torch.cuda.synchronize()
+            eng.set_option("profile_events", 1)
             out["train_step_b64"]["bf16_variant"] = {"ms_per_step_wall": (time.perf_counter() - t0) / n_steps * 1e3,
                                                      "max_abs_embedding_diff_vs_f32": float((pos16 - pos32).abs().max()),
                                                      "loss_f32": l32, "loss_bf16": l16}
@@ -688,11 +696,11 @@ def main():
     # Kernel durations are taken INSIDE the timed region two ways:
     #  * HIP events on sampled launches (hipExtLaunchKernelGGL start / stop events on the launch stream). Any event pair
     #    costs the stream ~6 us per sampled kernel (measured: marker packets and dispatch-attached events alike), so they
-    #    are sampled every 4th launch or sparser — at the driver's --steps 20 that is 5 scan launches;
+    #    are sampled every 8th launch or sparser — at the driver's --steps 20 that is 3 scan launches;
     #  * the paired scan's own span stamps (s_memrealtime, first workgroup start -> last workgroup end) on EVERY launch,
     #    at no cost to the stream: >= 16 samples whatever --steps is. `roofline` is computed from the HIP events and
     #    carries the stamp average beside it (the two agree to ~1 us: the events include the dispatch's start-up).
-    EVENT_EVERY = max(4, args.steps // 16)
+    EVENT_EVERY = max(8, args.steps // 16)
     # N_BATCH distinct query batches, rotated step by step (the DB stays resident; a real evaluation never repeats a batch)
     N_BATCH = 4
     db, qs, target = synth.make_retrieval_problem(N_CELLS, N_QUERIES, DIM, seed=1, noise=0.5)
@@ -720,6 +728,8 @@ def main():
     def step(i):
         if lanes > 1:
             return eng.search(d_qs[i % N_BATCH], TOPK, out=outs[i % N_OUT], join=False)
+        if world == 1:  # (ShardedSearcher.search is this call plus the exchange step that one rank does not have)
+            return eng.search(d_qs[i % N_BATCH], TOPK, out=outs[i % N_OUT])
         return searcher.search(d_qs[i % N_BATCH], TOPK)
 
     # the same loop stream-ordered (lanes = 1), for the record: what one call costs when the next one waits for it
