@@ -1120,6 +1120,8 @@ __global__ __launch_bounds__(256) void db_norm_kernel(const float* __restrict__ 
 // idx/score [parts][Q][K] (as all-gathered over RCCL) -> [Q][K] by (score desc, row id asc).
 // One wave per query; parts*K <= 256.
 // ------------------------------------------------------------------------------------------------
+// PAIRS: the input is the all-gathered {score, row id as f64} records of t2l_pack_pairs (idx unused) — no unpack launch.
+template <bool PAIRS>
 __global__ __launch_bounds__(256) void merge_kernel(const int32_t* __restrict__ idx, const double* __restrict__ score,
                                                     int parts, int Q, int K, int32_t* __restrict__ out_idx,
                                                     double* __restrict__ out_score) {
@@ -1136,10 +1138,19 @@ __global__ __launch_bounds__(256) void merge_kernel(const int32_t* __restrict__ 
     id[e] = INT_MAX;
     if (c < total) {
       const size_t off = ((size_t)(c / K) * Q + qid) * K + (c % K);
-      const int v = idx[off];
-      if (v >= 0) {
-        id[e] = v;
-        s[e] = score[off];
+      if constexpr (PAIRS) {
+        const double2 pr = reinterpret_cast<const double2*>(score)[off];
+        const int v = (int)pr.y;
+        if (v >= 0) {
+          id[e] = v;
+          s[e] = pr.x;
+        }
+      } else {
+        const int v = idx[off];
+        if (v >= 0) {
+          id[e] = v;
+          s[e] = score[off];
+        }
       }
     }
   }
@@ -1193,14 +1204,6 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(const int32_t* __restri
     pairs[2 * i + 1] = (double)idx[i];
   }
 }
-__global__ __launch_bounds__(256) void unpack_pairs_kernel(const double* __restrict__ pairs, int n,
-                                                           int32_t* __restrict__ idx, double* __restrict__ score) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) {
-    score[i] = pairs[2 * i];
-    idx[i] = (int32_t)pairs[2 * i + 1];
-  }
-}
 
 int pack_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int n, double* pairs, hipStream_t s) {
   if (n > 0) hipLaunchKernelGGL(pack_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, idx, score, n, pairs);
@@ -1210,21 +1213,16 @@ int pack_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int n, doub
 
 int merge_pairs_impl(t2l_ctx* ctx, const double* pairs, int parts, int Q, int K, int32_t* out_idx, double* out_score,
                      hipStream_t s) {
-  const int n = parts * Q * K;
-  int rc;
-  if ((rc = grow(ctx, (void**)&ctx->seg_idx, &ctx->seg_idx_cap, (size_t)n * sizeof(int32_t))) != T2L_OK ||
-      (rc = grow(ctx, (void**)&ctx->seg_score, &ctx->seg_score_cap, (size_t)n * sizeof(double))) != T2L_OK)
-    return rc;
-  if (n > 0)
-    hipLaunchKernelGGL(unpack_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pairs, n, ctx->seg_idx, ctx->seg_score);
+  if (parts * K > 256) return fail(ctx, T2L_EINVAL, "t2l_merge_pairs: parts * k must be <= 256");
+  hipLaunchKernelGGL((merge_kernel<true>), dim3((Q + 3) / 4), dim3(256), 0, s, (const int32_t*)nullptr, pairs, parts, Q, K, out_idx, out_score);
   T2L_HIP(ctx, hipGetLastError());
-  return merge_impl(ctx, ctx->seg_idx, ctx->seg_score, parts, Q, K, out_idx, out_score, s);
+  return T2L_OK;
 }
 
 int merge_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int parts, int Q, int K, int32_t* out_idx,
                double* out_score, hipStream_t s) {
   if (parts * K > 256) return fail(ctx, T2L_EINVAL, "t2l_merge_topk: parts * k must be <= 256");
-  hipLaunchKernelGGL(merge_kernel, dim3((Q + 3) / 4), dim3(256), 0, s, idx, score, parts, Q, K, out_idx, out_score);
+  hipLaunchKernelGGL((merge_kernel<false>), dim3((Q + 3) / 4), dim3(256), 0, s, idx, score, parts, Q, K, out_idx, out_score);
   T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;
 }
