@@ -437,7 +437,7 @@ def secondary_measurements(eng):
         dpos_t, drgb_t = torch.from_numpy(pos_t).cuda(), torch.from_numpy(rgb_t).cuda()
         g_t = torch.randn(pos_t.shape[0], 256, device="cuda")
         res = {}
-        for variant, bf in (("f32", 0), ("bf16_gemms", 1)):
+        for variant, bf in (("f32", 0), ("split_bf16_gemms", 2), ("bf16_gemms", 1)):
             eng_t.set_option("train_bf16", bf)
             fw, bw = [], []
             for it in range(4):
@@ -587,6 +587,22 @@ def secondary_measurements(eng):
             out["train_step_b64"]["bf16_variant"] = {"ms_per_step_wall": (time.perf_counter() - t0) / n_steps * 1e3,
                                                      "max_abs_embedding_diff_vs_f32": float((pos16 - pos32).abs().max()),
                                                      "loss_f32": l32, "loss_bf16": l16}
+            # option train_bf16 = 2: split-bf16 (hi + lo operands, three MFMAs per 16-step): f32-class accuracy, bf16-class speed
+            eng.set_option("train_bf16", 2)
+            pos2 = eng.encode_cells_train(p64, dropout_p=0.0, seed=1).clone()
+            l2 = float(eng.contrastive_loss(anchor, pos2, 0.1)[0])
+            eng.set_option("profile_events", 0)
+            for i in range(150):
+                train_step(400 + i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_steps):
+                train_step(3000 + i)
+            torch.cuda.synchronize()
+            eng.set_option("profile_events", 1)
+            out["train_step_b64"]["split_bf16_variant"] = {"ms_per_step_wall": (time.perf_counter() - t0) / n_steps * 1e3,
+                                                           "max_abs_embedding_diff_vs_f32": float((pos2 - pos32).abs().max()),
+                                                           "loss_f32": l32, "loss_split_bf16": l2}
             eng.set_option("train_bf16", 0)
         except Exception as e:
             out["train_step_b64"]["bf16_variant"] = {"error": repr(e)}

@@ -6,7 +6,7 @@ from text2loc_amd import synth
 from text2loc_amd.engine import Engine
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-bf16 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+bf16 = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 0 f32, 1 bf16, 2 split-bf16
 eng = Engine(0)
 eng.set_option("train_bf16", bf16)
 cells = synth.make_cells(B, seed=1)
