@@ -239,6 +239,20 @@ def secondary_measurements(eng):
     ms32, _ = eng.kernel_stats("encode_cells")
     eng.set_option("encoder_f32", 0)
     out["encode_cells"]["f32_mfma_kernel"] = {"kernel_ms": ms32, "frac_of_f32_peak": flops / (ms32 * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
+    # option encoder_f16: one f16 product per operand pair (the north star's bar is 1e-3 on the embeddings; the default holds 2e-7)
+    ref_emb = eng.encode_cells(packed).clone()
+    eng.set_option("encoder_f16", 1)
+    for _ in range(10):
+        emb16 = eng.encode_cells(packed)
+    eng.kernel_stats("encode_cells")
+    for _ in range(5):
+        emb16 = eng.encode_cells(packed)
+    torch.cuda.synchronize()
+    ms16, _ = eng.kernel_stats("encode_cells")
+    eng.set_option("encoder_f16", 0)
+    out["encode_cells"]["plain_f16_option"] = {"kernel_ms": ms16, "cells_per_s": N_CELLS / (ms16 * 1e-3),
+                                               "max_abs_diff_vs_default_embeddings": float((emb16 - ref_emb).abs().max()),
+                                               "frac_executed": tf / BF16_MFMA_PEAK_TFLOPS}
     # (ii) cold end-to-end = encode the N cells from packed features + build the DB + search Q queries;
     # and the same-GPU stock-library comparator for the search (rocBLAS f32 GEMM + torch.topk, f32 scores only)
     try:

@@ -138,3 +138,29 @@ def test_full_size_batch(eng):
     assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-5
     ref = O.encode_cells(_take(cells, n_cells=40), sd, True, True)
     assert np.abs(out[:40] - ref).max() < TOL
+
+
+@pytest.mark.parametrize("name,embed", [("encoder_embed", True), ("encoder_pn", False)])
+def test_plain_f16_option_meets_the_north_star_bar(golden, name, embed):
+    """Option encoder_f16: one f16 product per operand pair instead of the three of the split form (28 % less time). The bar it
+    has to meet is the north star's 1e-3 on unit-norm embeddings; measured ~7e-5 — asserted at 3e-4 — and it really is the
+    other kernel (the default's 2e-7 is out of its reach)."""
+    from text2loc_amd.engine import Engine
+
+    g = golden(name)
+    sd = synth.make_object_branch_weights(int(g["weight_seed"]))
+    e = Engine(0)
+    try:
+        e.load_weights(sd, class_embed=embed, color_embed=embed)
+        cells = _cells(g)
+        if not embed:
+            cells["pn_feat"] = synth.make_cells(int(g["n_cells"]), seed=int(g["cell_seed"]), with_pn_feat=True)["pn_feat"]
+        ref = e.encode_cells(_to_gpu(cells)).cpu().numpy()
+        e.set_option("encoder_f16", 1)
+        out = e.encode_cells(_to_gpu(cells)).cpu().numpy()
+        err = np.abs(out - g["cell_embeddings"]).max()
+        assert 1e-6 < err < 3e-4, err
+        assert np.abs(ref - g["cell_embeddings"]).max() < TOL
+        assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-5
+    finally:
+        e.close()

@@ -407,6 +407,8 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     ctx->search_mode = (int)value;
   } else if (!strcmp(name, "encoder_f32")) {
     ctx->encoder_f32 = value != 0;
+  } else if (!strcmp(name, "encoder_f16")) {
+    ctx->encoder_f16 = value != 0;
   } else if (!strcmp(name, "search_auto")) {
     ctx->search_auto = value != 0;
     if (!ctx->search_auto) {  // forget the state and every report of a search launched so far

@@ -28,12 +28,15 @@ constexpr float kSplitF16Safe = 3.0e4f;  // bound below which an operand may ent
 struct HFrag {
   h3_f16x8 hi, lo;
 };
+// SINGLE: the plain-f16 variant (one product per pair of operands, |error| <= 2^-10 relative per product): no low part
+template <bool SINGLE = false>
 __device__ __forceinline__ HFrag split_h(const float* __restrict__ p) {  // 8 consecutive floats (16-byte aligned)
   const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
   const h3_f32x8 v = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   HFrag f;
   f.hi = __builtin_convertvector(v, h3_f16x8);
-  f.lo = __builtin_convertvector(v - __builtin_convertvector(f.hi, h3_f32x8), h3_f16x8);
+  if constexpr (SINGLE) f.lo = f.hi;  // (never read)
+  else f.lo = __builtin_convertvector(v - __builtin_convertvector(f.hi, h3_f32x8), h3_f16x8);
   return f;
 }
 __device__ __forceinline__ HFrag load_h(const uint4* __restrict__ wp) {
@@ -45,10 +48,22 @@ __device__ __forceinline__ HFrag load_h(const uint4* __restrict__ wp) {
   return f;
 }
 // acc += A * B with A, B split fragments (a = A operand, b = B operand of the MFMA)
+template <bool SINGLE = false>
 __device__ __forceinline__ void mfma_h3(h3_f32x16& acc, const HFrag& a, const HFrag& b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, acc, 0, 0, 0);
+  if constexpr (!SINGLE) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, acc, 0, 0, 0);
+  }
+}
+template <bool SINGLE = false>
+__device__ __forceinline__ HFrag load_h1(const uint4* __restrict__ wp) {  // SINGLE: the high half only (half the weight bytes)
+  const __attribute__((address_space(1))) uint4* gp = (const __attribute__((address_space(1))) uint4*)wp;
+  HFrag f;
+  f.hi = __builtin_bit_cast(h3_f16x8, gp[0]);
+  if constexpr (SINGLE) f.lo = f.hi;
+  else f.lo = __builtin_bit_cast(h3_f16x8, gp[1]);
+  return f;
 }
 // acc += A[32 x 16*STEPS] (this lane's LDS row half) * W^T (one packed weight tile, offset to its first step and to this
 // lane: 2 uint4 per lane and step, 128 uint4 per step)
