@@ -430,6 +430,17 @@ def secondary_measurements(eng):
                            "frac": fl * n_obj / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                            "frac_executed": 3 * fl * n_obj / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, "launches_timed": n,
                            "parity": "self-consistent only (third-party reference arithmetic, unpinned)"}
+        eng_p.set_option("encoder_f16", 1)  # one f16 product per operand pair
+        for _ in range(3):
+            f2h = eng_p.pointnet_features(d_pos, d_rgb, cells_p["offsets"])
+        eng_p.kernel_stats("pointnet")
+        for _ in range(3):
+            f2h = eng_p.pointnet_features(d_pos, d_rgb, cells_p["offsets"])
+        torch.cuda.synchronize()
+        ms_h, _ = eng_p.kernel_stats("pointnet")
+        out["pointnet"]["plain_f16_option"] = {"kernel_ms": ms_h, "objects_per_s": n_obj / (ms_h * 1e-3),
+                                               "max_abs_diff_vs_default": float((f2h - f2).abs().max()),
+                                               "max_abs_feature": float(f2.abs().max())}
         eng_p.close()
     except Exception as e:
         out["pointnet"] = {"error": repr(e)}
@@ -528,6 +539,18 @@ def secondary_measurements(eng):
                              "peak_tflops": BF16_MFMA_PEAK_TFLOPS,
                              "frac": 23.0e6 * n_pairs / (ms_m * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
                              "frac_executed": 3 * 23.0e6 * n_pairs / (ms_m * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS}
+        # option encoder_f16 (one f16 product per operand pair) on the match kernel
+        eng_f.set_option("encoder_f16", 1)
+        for _ in range(10):
+            off16 = eng_f.fine_match(desc, hints, top_idx.reshape(-1).contiguous(), hi)
+        eng_f.kernel_stats("fine_match")
+        for _ in range(5):
+            off16 = eng_f.fine_match(desc, hints, top_idx.reshape(-1).contiguous(), hi)
+        torch.cuda.synchronize()
+        ms16, _ = eng_f.kernel_stats("fine_match")
+        out["fine_stage"]["plain_f16_option"] = {"match_kernel_ms": ms16, "pairs_per_s": n_pairs / (ms16 * 1e-3),
+                                                 "max_abs_offset_diff_vs_default": float((off16 - off).abs().max()),
+                                                 "max_abs_err_vs_oracle_on_sample": float(np.abs(off16.cpu().numpy()[sel] - ref_off).max())}
         eng_f.close()
     except Exception as e:
         out["fine_stage"] = {"error": repr(e)}

@@ -301,7 +301,7 @@ struct TileGroups {
 // v_h straight (A = mem token rows, B = packed rows); in those MFMA output layouts k_h^T / q_h^T are the A / B operands of
 // S^T = K Q^T and v_h is the B operand of P V (the trick of encode.hip). Keys of another pair (or padding rows) are masked.
 // Writes o_h (32 rows x 32 columns) into obuf[:, 32 h ..]. x == mem for self-attention.
-template <bool H>
+template <int H>
 __device__ __forceinline__ void f_attention_regs(const float* __restrict__ x, TileGroups gx, const float* __restrict__ mem, TileGroups gm,
                                                  const FPacked in_proj, float* __restrict__ obuf) {
   const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
@@ -314,17 +314,17 @@ __device__ __forceinline__ void f_attention_regs(const float* __restrict__ x, Ti
   f32x16 qT, kT, v;
 #pragma unroll
   for (int r = 0; r < 16; ++r) qT[r] = kT[r] = v[r] = 0.f;
-  if constexpr (H) {
+  if constexpr (H != 0) {
     constexpr int HS = kFD / 16;  // 8 steps of 16
     const uint4* hq = in_proj.h + ((size_t)h * HS * 64 + lane) * 2;
     const uint4* hk = in_proj.h + ((size_t)(4 + h) * HS * 64 + lane) * 2;
     const uint4* hv = in_proj.h + ((size_t)(8 + h) * HS * 64 + lane) * 2;
 #pragma unroll 4
     for (int st = 0; st < HS; ++st) {
-      const HFrag xf = split_h(xr + 8 * st), mf = split_h(mr + 8 * st);
-      mfma_h3(qT, load_h(hq + st * 128), xf);
-      mfma_h3(kT, load_h(hk + st * 128), mf);
-      mfma_h3(v, mf, load_h(hv + st * 128));
+      const HFrag xf = split_h<H == 2>(xr + 8 * st), mf = split_h<H == 2>(mr + 8 * st);
+      mfma_h3<H == 2>(qT, load_h1<H == 2>(hq + st * 128), xf);
+      mfma_h3<H == 2>(kT, load_h1<H == 2>(hk + st * 128), mf);
+      mfma_h3<H == 2>(v, mf, load_h1<H == 2>(hv + st * 128));
     }
   } else {
 #pragma unroll 4
@@ -386,13 +386,13 @@ __device__ __forceinline__ void f_attention_regs(const float* __restrict__ x, Ti
 }
 
 // x += A @ W^T + b for a 128 -> 128 Linear (out_proj): one 32-column tile per wave
-template <bool H>
+template <int H>
 __device__ __forceinline__ void f_proj_add(const float* __restrict__ A, const FPacked L, float* __restrict__ x) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  if constexpr (H) mm32_dot_h<kFD / 16>(A + col * kFS + half * (kFD / 2), L.h + ((size_t)w * (kFD / 16) * 64 + lane) * 2, acc);
+  if constexpr (H != 0) mm32_dot_h<kFD / 16, H == 2>(A + col * kFS + half * (kFD / 2), L.h + ((size_t)w * (kFD / 16) * 64 + lane) * 2, acc);
   else mm32_dot<kFD / 8>(A + col * kFS + half * (kFD / 2), L.w + (size_t)w * (kFD / 8) * 64 + lane, acc);
   const float bv = L.b[w * 32 + col];
 #pragma unroll
@@ -401,7 +401,7 @@ __device__ __forceinline__ void f_proj_add(const float* __restrict__ A, const FP
 
 // nn.TransformerDecoderLayer (post-norm, ReLU, eval, no masks) for the kPairs pairs of a workgroup. x / mem: 32-row token
 // tiles (LDS, stride kFS); buf: one more 32 x 128 tile (attention output, then the feed-forward hidden in four quarters).
-template <bool H>
+template <int H>
 __device__ void f_decoder(float* x, TileGroups gx, const float* mem, TileGroups gm, const FDecoder D, float* buf) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
   f_attention_regs<H>(x, gx, x, gx, D.sa_in, buf);
@@ -427,15 +427,15 @@ __device__ void f_decoder(float* x, TileGroups gx, const float* mem, TileGroups 
       f32x16 hh;
 #pragma unroll
       for (int r = 0; r < 16; ++r) hh[r] = 0.f;
-      if constexpr (H) mm32_dot_h<kFD / 16>(x + col * kFS + half * (kFD / 2), D.l1.h + ((size_t)tile * (kFD / 16) * 64 + lane) * 2, hh);
+      if constexpr (H != 0) mm32_dot_h<kFD / 16, H == 2>(x + col * kFS + half * (kFD / 2), D.l1.h + ((size_t)tile * (kFD / 16) * 64 + lane) * 2, hh);
       else mm32_dot<kFD / 8>(x + col * kFS + half * (kFD / 2), D.l1.w + (size_t)tile * (kFD / 8) * 64 + lane, hh);
       if (qtr) __syncthreads();  // every wave has consumed the previous quarter
       const float bv = D.l1.b[tile * 32 + col];
 #pragma unroll
       for (int r = 0; r < 16; ++r) buf[((r & 3) + 8 * (r >> 2) + 4 * half) * kFS + w * 32 + col] = fmaxf(hh[r] + bv, 0.f);
       __syncthreads();
-      if constexpr (H)  // K = 512: 32 steps per tile, quarter qtr = steps [8 qtr, 8 qtr + 8)
-        mm32_dot_h<kFD / 16>(buf + col * kFS + half * (kFD / 2), D.l2.h + (((size_t)w * (4 * kFD / 16) + 8 * qtr) * 64 + lane) * 2, acc);
+      if constexpr (H != 0)  // K = 512: 32 steps per tile, quarter qtr = steps [8 qtr, 8 qtr + 8)
+        mm32_dot_h<kFD / 16, H == 2>(buf + col * kFS + half * (kFD / 2), D.l2.h + (((size_t)w * (4 * kFD / 16) + 8 * qtr) * 64 + lane) * 2, acc);
       else
         mm32_dot<kFD / 8>(buf + col * kFS + half * (kFD / 2), D.l2.w + ((size_t)w * (4 * kFD / 8) + 16 * qtr) * 64 + lane, acc);
     }
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void fine_objects_kernel(FineParams P, t2l_pac
 // workgroups per CU.
 // H = split-f16 MFMAs: a workgroup whose raw descriptor rows exceed kFGuardNorm writes wg_flags[block] = 1 and leaves; the
 // !H launch that follows (all-f32 MFMA) serves exactly those workgroups (wg_flags == nullptr: every workgroup).
-template <bool H>
+template <int H>
 __global__ __launch_bounds__(256, 3) void fine_match_kernel(FineParams P, const float* __restrict__ cell_desc, const int32_t* __restrict__ cell_index,
                                                             const float* __restrict__ hint_desc, const int32_t* __restrict__ hint_index,
                                                             int n_pairs, int n_hints, float* __restrict__ out, int32_t* __restrict__ wg_flags) {
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256, 3) void fine_match_kernel(FineParams P, const 
     d1[row * kFS + c] = v;
   }
   __syncthreads();
-  if constexpr (H) {  // guard: largest 2-norm of the 64 raw rows (NaN fails the comparison too)
+  if constexpr (H != 0) {  // guard: largest 2-norm of the 64 raw rows (NaN fails the comparison too)
     const int w = tid >> 6, lane = tid & 63;
     float worst = 0.f;
     for (int t = w; t < 64; t += 4) {
@@ -609,8 +609,9 @@ int fine_match_impl(t2l_ctx* ctx, const float* cell_desc, const int32_t* cell_in
   const size_t lds = sizeof(float) * (3 * 32 * kFS + kPairs * kFD + kPairs * 64);  // 52 KB: three workgroups per CU
   static bool attr = false;
   if (!attr) {
-    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fine_match_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fine_match_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fine_match_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fine_match_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fine_match_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
   const int n_wg = (n_pairs + kPairs - 1) / kPairs;
@@ -624,12 +625,17 @@ int fine_match_impl(t2l_ctx* ctx, const float* cell_desc, const int32_t* cell_in
   }
   event_begin(ctx, "fine_match", s);
   if (split) {
-    hipLaunchKernelGGL(fine_match_kernel<true>, dim3(n_wg), dim3(256), lds, s, W->p, cell_desc, cell_index, hint_desc, hint_index, n_pairs,
-                       n_hints, out, W->wg_flags);
-    hipLaunchKernelGGL(fine_match_kernel<false>, dim3(n_wg), dim3(256), lds, s, W->p, cell_desc, cell_index, hint_desc, hint_index, n_pairs,
+    // option encoder_f16: one f16 product per operand pair instead of three (offsets within ~1e-4 instead of 3e-7; same guard)
+    if (ctx->encoder_f16)
+      hipLaunchKernelGGL(fine_match_kernel<2>, dim3(n_wg), dim3(256), lds, s, W->p, cell_desc, cell_index, hint_desc, hint_index, n_pairs,
+                         n_hints, out, W->wg_flags);
+    else
+      hipLaunchKernelGGL(fine_match_kernel<1>, dim3(n_wg), dim3(256), lds, s, W->p, cell_desc, cell_index, hint_desc, hint_index, n_pairs,
+                         n_hints, out, W->wg_flags);
+    hipLaunchKernelGGL(fine_match_kernel<0>, dim3(n_wg), dim3(256), lds, s, W->p, cell_desc, cell_index, hint_desc, hint_index, n_pairs,
                        n_hints, out, W->wg_flags);  // only the workgroups the guard turned away
   } else {
-    hipLaunchKernelGGL(fine_match_kernel<false>, dim3(n_wg), dim3(256), lds, s, W->p, cell_desc, cell_index, hint_desc, hint_index, n_pairs,
+    hipLaunchKernelGGL(fine_match_kernel<0>, dim3(n_wg), dim3(256), lds, s, W->p, cell_desc, cell_index, hint_desc, hint_index, n_pairs,
                        n_hints, out, (int32_t*)nullptr);
   }
   event_end(ctx, "fine_match", s);

@@ -67,10 +67,10 @@ __device__ __forceinline__ HFrag load_h1(const uint4* __restrict__ wp) {  // SIN
 }
 // acc += A[32 x 16*STEPS] (this lane's LDS row half) * W^T (one packed weight tile, offset to its first step and to this
 // lane: 2 uint4 per lane and step, 128 uint4 per step)
-template <int STEPS>
+template <int STEPS, bool SINGLE = false>
 __device__ __forceinline__ void mm32_dot_h(const float* __restrict__ arow, const uint4* __restrict__ wp, h3_f32x16& acc) {
 #pragma unroll 4
-  for (int s = 0; s < STEPS; ++s) mfma_h3(acc, split_h(arow + 8 * s), load_h(wp + s * 128));
+  for (int s = 0; s < STEPS; ++s) mfma_h3<SINGLE>(acc, split_h<SINGLE>(arow + 8 * s), load_h1<SINGLE>(wp + s * 128));
 }
 
 // W [rows][cin] row-major (optionally [W | bias column | 0] of width kp, as pack_half_split) -> split-f16 fragments; bit

@@ -258,6 +258,7 @@ __device__ __forceinline__ void sa_mlp_tile(const float (&xrow)[k1p(CIN) / 2], c
 }
 
 // 8 register values -> split fragment; amax tracks the largest magnitude that entered a split product
+template <bool SG = false>  // SG: plain f16 (option encoder_f16): the high part only
 __device__ __forceinline__ HFrag split_vals(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
                                             float& amax) {
   amax = fmaxf(fmaxf(fmaxf(amax, fabsf(v0)), fmaxf(fabsf(v1), fabsf(v2))), fmaxf(fmaxf(fabsf(v3), fabsf(v4)), fabsf(v5)));
@@ -265,13 +266,14 @@ __device__ __forceinline__ HFrag split_vals(float v0, float v1, float v2, float 
   const h3_f32x8 v = {v0, v1, v2, v3, v4, v5, v6, v7};
   HFrag f;
   f.hi = __builtin_convertvector(v, h3_f16x8);
-  f.lo = __builtin_convertvector(v - __builtin_convertvector(f.hi, h3_f32x8), h3_f16x8);
+  if constexpr (SG) f.lo = f.hi;  // (never read)
+  else f.lo = __builtin_convertvector(v - __builtin_convertvector(f.hi, h3_f32x8), h3_f16x8);
   return f;
 }
 
 // The steps of the two layers as template recursions (the compiler does not unroll a 72-step loop with this body, and
 // run-time indices would put the fragment arrays into scratch memory).
-template <int STEP, int STEPS, int S, int PF, int FT>
+template <int STEP, int STEPS, int S, int PF, int FT, bool SG>
 __device__ __forceinline__ void sa_l1_steps(HFrag (&ring)[PF], const uint4*& wp, f32x16& acc, const HFrag (&xf)[S], HFrag (&hf)[FT][2],
                                             float& amax) {
   if constexpr (STEP < STEPS) {
@@ -282,47 +284,47 @@ __device__ __forceinline__ void sa_l1_steps(HFrag (&ring)[PF], const uint4*& wp,
     }
     const HFrag wf = ring[STEP % PF];
     if constexpr (STEP + PF < STEPS) {
-      ring[STEP % PF] = load_h(wp);
+      ring[STEP % PF] = load_h1<SG>(wp);
       wp += 128;
       asm volatile("" : "+v"(wp));
     }
-    mfma_h3(acc, wf, xf[st]);
+    mfma_h3<SG>(acc, wf, xf[st]);
     __builtin_amdgcn_sched_barrier(0);  // keep the ring's distance: no further hoisting of loads (register pressure)
     if constexpr (st == S - 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);  // BatchNorm + bias folded; ReLU
-      hf[ft][0] = split_vals(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7], amax);
-      hf[ft][1] = split_vals(acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15], amax);
+      hf[ft][0] = split_vals<SG>(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7], amax);
+      hf[ft][1] = split_vals<SG>(acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15], amax);
     }
-    sa_l1_steps<STEP + 1, STEPS, S, PF, FT>(ring, wp, acc, xf, hf, amax);
+    sa_l1_steps<STEP + 1, STEPS, S, PF, FT, SG>(ring, wp, acc, xf, hf, amax);
   }
 }
-template <int STEP, int STEPS, int PF, int FT>
+template <int STEP, int STEPS, int PF, int FT, bool SG>
 __device__ __forceinline__ void sa_l2_steps(HFrag (&ring)[PF], const uint4*& wp, f32x16& acc, const HFrag (&hf)[FT][2], bool not_last_tile) {
   if constexpr (STEP < STEPS) {
     const HFrag wf = ring[STEP % PF];
     if (not_last_tile || STEP + PF < STEPS) {  // the stream continues into the next output tile
-      ring[STEP % PF] = load_h(wp);
+      ring[STEP % PF] = load_h1<SG>(wp);
       wp += 128;
       asm volatile("" : "+v"(wp));
     }
-    mfma_h3(acc, hf[STEP / 2][STEP % 2], wf);
+    mfma_h3<SG>(acc, hf[STEP / 2][STEP % 2], wf);
     __builtin_amdgcn_sched_barrier(0);
-    sa_l2_steps<STEP + 1, STEPS, PF, FT>(ring, wp, acc, hf, not_last_tile);
+    sa_l2_steps<STEP + 1, STEPS, PF, FT, SG>(ring, wp, acc, hf, not_last_tile);
   }
 }
 
 // sa_mlp_tile on split-f16 MFMAs. xrow: this lane's half of the row padded to k1ph(CIN). Layer 1 transposed (A = packed
 // weights, B = the row fragments, split once per tile); its accumulator registers 0..7 / 8..15 are the two A fragments of
 // layer 2 for that feature tile (pack_sa_l2_h orders the weights to match), split once and reused by all output tiles.
-template <int CIN, int H1, int H2, typename Emit>
+template <int CIN, int H1, int H2, bool SG, typename Emit>
 __device__ __forceinline__ void sa_mlp_tile_h(const float (&xrow)[k1ph(CIN) / 2], const uint4* __restrict__ w1, const uint4* __restrict__ w2,
                                               int lane, float& amax, Emit&& emit) {
   constexpr int S = k1ph(CIN) / 16, FT = H1 / 32, NT = H2 / 32;
   HFrag xf[S];
 #pragma unroll
   for (int s = 0; s < S; ++s)
-    xf[s] = split_vals(xrow[8 * s], xrow[8 * s + 1], xrow[8 * s + 2], xrow[8 * s + 3], xrow[8 * s + 4], xrow[8 * s + 5], xrow[8 * s + 6],
+    xf[s] = split_vals<SG>(xrow[8 * s], xrow[8 * s + 1], xrow[8 * s + 2], xrow[8 * s + 3], xrow[8 * s + 4], xrow[8 * s + 5], xrow[8 * s + 6],
                        xrow[8 * s + 7], amax);
   // One wave per SIMD: the L2 latency of the weight stream is hidden by an explicit ring of PF fragment pairs in flight
   // (PF x 3 MFMAs = PF x 96 cycles of look-ahead). The pointers run (opaque increments): with `base + constant` addressing
@@ -335,12 +337,12 @@ __device__ __forceinline__ void sa_mlp_tile_h(const float (&xrow)[k1ph(CIN) / 2]
     HFrag ring[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-      ring[i] = load_h(wp);
+      ring[i] = load_h1<SG>(wp);
       wp += 128;
       asm volatile("" : "+v"(wp));
     }
     f32x16 acc;
-    sa_l1_steps<0, STEPS, S, PF, FT>(ring, wp, acc, xf, hf, amax);
+    sa_l1_steps<0, STEPS, S, PF, FT, SG>(ring, wp, acc, xf, hf, amax);
   }
   {
     constexpr int STEPS = FT * 2, PF = STEPS < 4 ? STEPS : 4;  // per output tile; STEPS is a multiple of PF
@@ -349,7 +351,7 @@ __device__ __forceinline__ void sa_mlp_tile_h(const float (&xrow)[k1ph(CIN) / 2]
     HFrag ring[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-      ring[i] = load_h(wp);
+      ring[i] = load_h1<SG>(wp);
       wp += 128;
       asm volatile("" : "+v"(wp));
     }
@@ -358,7 +360,7 @@ __device__ __forceinline__ void sa_mlp_tile_h(const float (&xrow)[k1ph(CIN) / 2]
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      sa_l2_steps<0, STEPS, PF, FT>(ring, wp, acc, hf, nt + 1 < NT);
+      sa_l2_steps<0, STEPS, PF, FT, SG>(ring, wp, acc, hf, nt + 1 < NT);
       emit(nt, acc);
     }
   }
@@ -396,7 +398,7 @@ struct SaParams {
   int32_t* obj_flags;  // [n_obj]: 1 = this object's magnitudes left the split-f16 range (or were not finite): f32 launches only
 };
 
-template <int CIN, int H1, int H2, int NS, bool H>
+template <int CIN, int H1, int H2, int NS, int H>
 __global__ __launch_bounds__(256, 1) void pn_sa_kernel(SaParams P) {
   constexpr int ND = NS / 2, XS = CIN + 4, PPL = NS / 64;
   constexpr int HALF = (H ? k1ph(CIN) : k1p(CIN)) / 2;
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(256, 1) void pn_sa_kernel(SaParams P) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) selfm[(tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * H2 + nt * 32 + j] = acc[r];
       };
-      if constexpr (H) sa_mlp_tile_h<CIN, H1, H2>(xrow, P.w1h, P.w2h, lane, amax, keep);
+      if constexpr (H != 0) sa_mlp_tile_h<CIN, H1, H2, H == 2>(xrow, P.w1h, P.w2h, lane, amax, keep);
       else sa_mlp_tile<CIN, H1, H2>(xrow, P.w1, P.w2, lane, keep);
     }
   } else {
@@ -499,10 +501,10 @@ __global__ __launch_bounds__(256, 1) void pn_sa_kernel(SaParams P) {
       const int c = nt * 32 + j;
       if (kh == 0) P.dst_x[((size_t)o * ND + t) * H2 + c] = fmaxf(fmaxf(m, selfm[t * H2 + c]) + P.b2[c], 0.f);
     };
-    if constexpr (H) sa_mlp_tile_h<CIN, H1, H2>(xrow, P.w1h, P.w2h, lane, amax, pool);
+    if constexpr (H != 0) sa_mlp_tile_h<CIN, H1, H2, H == 2>(xrow, P.w1h, P.w2h, lane, amax, pool);
     else sa_mlp_tile<CIN, H1, H2>(xrow, P.w1, P.w2, lane, pool);
   }
-  if constexpr (H) {  // anything at or beyond 3e4 (or NaN: the comparison fails) entered a split product: hand the object over
+  if constexpr (H != 0) {  // anything at or beyond 3e4 (or NaN: the comparison fails) entered a split product: hand the object over
     if (!(amax < kSplitF16Safe)) P.obj_flags[o] = 1;
   }
 }
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(256, 1) void pn_sa_kernel(SaParams P) {
 // 68 KB of LDS instead of 100 KB, two objects per CU.
 constexpr int kGaH1 = 512, kGaHS = 256 + 4, kGaH2 = 1024;
 constexpr int ga_k(bool h) { return h ? 272 : 264; }  // [x(256) | pos(3) | 1 | 0..] padded to 8 (f32 steps) / 16 (split-f16 steps)
-template <bool H>
+template <int H>
 __global__ __launch_bounds__(256, 2) void pn_ga_kernel(const float* __restrict__ pos3, const float* __restrict__ x3,
                                                        const float4* __restrict__ w1, const float4* __restrict__ w2,
                                                        const uint4* __restrict__ w1h, const uint4* __restrict__ w2h,
@@ -549,16 +551,16 @@ __global__ __launch_bounds__(256, 2) void pn_ga_kernel(const float* __restrict__
     f32x16 h[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) h[0][r] = h[1][r] = 0.f;
-    if constexpr (H) {  // the two tiles share every (split) A fragment
+    if constexpr (H != 0) {  // the two tiles share every (split) A fragment
       const float* xr = X + j * kGaXS + kh * (kGaK / 2);
       constexpr int S = kGaK / 16;
       const uint4* wa = w1h + ((size_t)(4 * hf + w) * S * 64 + lane) * 2;
       const uint4* wb = w1h + ((size_t)(8 + 4 * hf + w) * S * 64 + lane) * 2;
 #pragma unroll 2
       for (int st = 0; st < S; ++st) {
-        const HFrag a = split_h(xr + 8 * st);
-        mfma_h3(h[0], a, load_h(wa + st * 128));
-        mfma_h3(h[1], a, load_h(wb + st * 128));
+        const HFrag a = split_h<H == 2>(xr + 8 * st);
+        mfma_h3<H == 2>(h[0], a, load_h1<H == 2>(wa + st * 128));
+        mfma_h3<H == 2>(h[1], a, load_h1<H == 2>(wb + st * 128));
       }
     } else {  // the two tiles share every A fragment
       const float* xr = X + j * kGaXS + kh * (kGaK / 2);
@@ -588,14 +590,14 @@ __global__ __launch_bounds__(256, 2) void pn_ga_kernel(const float* __restrict__
         amax = fmaxf(amax, hv);
       }
     __syncthreads();
-    if constexpr (H) {  // layer 2 partial: 8 column tiles share every split A fragment; K = 512: half hf = steps [16 hf, 16 hf + 16)
+    if constexpr (H != 0) {  // layer 2 partial: 8 column tiles share every split A fragment; K = 512: half hf = steps [16 hf, 16 hf + 16)
       const float* hr = Hd + j * kGaHS + kh * 128;
       const uint4* wp = w2h + (((size_t)w * (kGaH1 / 16) + 16 * hf) * 64 + lane) * 2;
 #pragma unroll 2
       for (int st = 0; st < 16; ++st) {
-        const HFrag a = split_h(hr + 8 * st);
+        const HFrag a = split_h<H == 2>(hr + 8 * st);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) mfma_h3(acc[t], a, load_h(wp + ((size_t)4 * t * (kGaH1 / 16) + st) * 128));
+        for (int t = 0; t < 8; ++t) mfma_h3<H == 2>(acc[t], a, load_h1<H == 2>(wp + ((size_t)4 * t * (kGaH1 / 16) + st) * 128));
       }
     } else {  // layer 2 partial: the 8 column tiles of this wave share every A fragment (one LDS read, 8 weight loads, 32 MFMAs)
       const float* hr = Hd + j * kGaHS + kh * 128;
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(256, 2) void pn_ga_kernel(const float* __restrict__
     const int c = (w + 4 * t) * 32 + j;
     if (kh == 0) f0[(size_t)o * kGaH2 + c] = fmaxf(m + b2[c], 0.f);
   }
-  if constexpr (H) {
+  if constexpr (H != 0) {
     if (!(amax < kSplitF16Safe)) obj_flags[o] = 1;
   }
 }
@@ -688,20 +690,24 @@ static size_t sa_lds_bytes() {
 // split = true: the split-f16 launch over all objects (it skips flagged ones and flags new ones) followed by the f32 launch
 // that serves exactly the flagged objects; split = false: one f32 launch over everything (P.obj_flags must be null)
 template <int CIN, int H1, int H2, int NS>
-static hipError_t launch_sa(const SaParams& P, int n_obj, bool split, hipStream_t s) {
+static hipError_t launch_sa(const SaParams& P, int n_obj, bool split, bool single, hipStream_t s) {
   const size_t lds = sa_lds_bytes<CIN, H1, H2, NS>();
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_kernel<CIN, H1, H2, NS, true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_kernel<CIN, H1, H2, NS, 1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_kernel<CIN, H1, H2, NS, false>),
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_kernel<CIN, H1, H2, NS, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_kernel<CIN, H1, H2, NS, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr = true;
   }
-  if (split) hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, true>), dim3(n_obj), dim3(256), lds, s, P);
-  hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, false>), dim3(n_obj), dim3(256), lds, s, P);
+  if (split && single) hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, 2>), dim3(n_obj), dim3(256), lds, s, P);  // option encoder_f16
+  else if (split) hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, 1>), dim3(n_obj), dim3(256), lds, s, P);
+  hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, 0>), dim3(n_obj), dim3(256), lds, s, P);
   return hipGetLastError();
 }
 
@@ -744,22 +750,25 @@ int pointnet_features_impl(t2l_ctx* ctx, const float* pos, const float* rgb, con
   event_begin(ctx, "pointnet", s);
   const float radii[3] = {0.2f, 0.3f, 0.4f};
   SaParams P{pos, rgb, p1, x1, d_base, W->w1[0], W->w2[0], W->b2[0], radii[0] * radii[0], ctx->pn_self_loops, W->w1h[0], W->w2h[0], d_flags};
-  T2L_HIP(ctx, (launch_sa<3, 32, 64, 256>(P, n_obj, split, s)));
+  T2L_HIP(ctx, (launch_sa<3, 32, 64, 256>(P, n_obj, split, ctx->encoder_f16 != 0, s)));
   P = SaParams{p1, x1, p2, x2, d_base, W->w1[1], W->w2[1], W->b2[1], radii[1] * radii[1], ctx->pn_self_loops, W->w1h[1], W->w2h[1], d_flags};
-  T2L_HIP(ctx, (launch_sa<64, 128, 128, 128>(P, n_obj, split, s)));
+  T2L_HIP(ctx, (launch_sa<64, 128, 128, 128>(P, n_obj, split, ctx->encoder_f16 != 0, s)));
   P = SaParams{p2, x2, p3, x3, d_base, W->w1[2], W->w2[2], W->b2[2], radii[2] * radii[2], ctx->pn_self_loops, W->w1h[2], W->w2h[2], d_flags};
-  T2L_HIP(ctx, (launch_sa<128, 256, 256, 64>(P, n_obj, split, s)));
+  T2L_HIP(ctx, (launch_sa<128, 256, 256, 64>(P, n_obj, split, ctx->encoder_f16 != 0, s)));
   {
     const size_t lds_h = sizeof(float) * (32 * (ga_k(true) + 4) + 32 * kGaHS), lds_f = sizeof(float) * (32 * (ga_k(false) + 4) + 32 * kGaHS);
     static bool attr = false;
     if (!attr) {
-      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
-      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
+      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
+      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
       attr = true;
     }
-    if (split)
-      hipLaunchKernelGGL(pn_ga_kernel<true>, dim3(n_obj), dim3(256), lds_h, s, p3, x3, W->ga1, W->ga2, W->ga1h, W->ga2h, W->gab2, f0, d_flags);
-    hipLaunchKernelGGL(pn_ga_kernel<false>, dim3(n_obj), dim3(256), lds_f, s, p3, x3, W->ga1, W->ga2, W->ga1h, W->ga2h, W->gab2, f0, d_flags);
+    if (split && ctx->encoder_f16)
+      hipLaunchKernelGGL(pn_ga_kernel<2>, dim3(n_obj), dim3(256), lds_h, s, p3, x3, W->ga1, W->ga2, W->ga1h, W->ga2h, W->gab2, f0, d_flags);
+    else if (split)
+      hipLaunchKernelGGL(pn_ga_kernel<1>, dim3(n_obj), dim3(256), lds_h, s, p3, x3, W->ga1, W->ga2, W->ga1h, W->ga2h, W->gab2, f0, d_flags);
+    hipLaunchKernelGGL(pn_ga_kernel<0>, dim3(n_obj), dim3(256), lds_f, s, p3, x3, W->ga1, W->ga2, W->ga1h, W->ga2h, W->gab2, f0, d_flags);
   }
   {  // lin1 / lin2 + ReLU over all objects (pointnet2.py:86-89): plain GEMMs on the row-major torch weights
     train::GemmArgs g{f0, W->lin1w, f1, W->lin1b, n_obj, 512, 1024, 1024, 1024, 512, 1, 0, 1024, nullptr};
