@@ -201,5 +201,5 @@ def test_plain_f16_option_of_the_backbone(eng):
     scale = max(1.0, float(np.abs(ref).max()))
     assert np.abs(base - ref).max() < 2e-4 * scale
     assert np.abs(got - ref).max() < 1e-3 * scale
-    assert not np.array_equal(got, base)  # really the other kernel
+    assert eng.all_f32 or not np.array_equal(got, base)  # really the other kernel (the all-f32 set ignores the option)
     assert np.isfinite(got2).all()
