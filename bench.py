@@ -431,10 +431,11 @@ def secondary_measurements(eng):
                            "frac_executed": 3 * fl * n_obj / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, "launches_timed": n,
                            "parity": "self-consistent only (third-party reference arithmetic, unpinned)"}
         eng_p.set_option("encoder_f16", 1)  # one f16 product per operand pair
-        for _ in range(3):
+        for _ in range(6):
             f2h = eng_p.pointnet_features(d_pos, d_rgb, cells_p["offsets"])
+        torch.cuda.synchronize()
         eng_p.kernel_stats("pointnet")
-        for _ in range(3):
+        for _ in range(5):
             f2h = eng_p.pointnet_features(d_pos, d_rgb, cells_p["offsets"])
         torch.cuda.synchronize()
         ms_h, _ = eng_p.kernel_stats("pointnet")
@@ -625,6 +626,9 @@ def secondary_measurements(eng):
                                                      "max_abs_embedding_diff_vs_f32": float((pos16 - pos32).abs().max()),
                                                      "loss_f32": l32, "loss_bf16": l16}
             # option train_bf16 = 2: split-bf16 (hi + lo operands, three MFMAs per 16-step): f32-class accuracy, bf16-class speed
+            eng.set_option("train_bf16", 0)  # (the weights moved during the loop above: a fresh f32 reference on the current ones)
+            pos32b = eng.encode_cells_train(p64, dropout_p=0.0, seed=1).clone()
+            l32b = float(eng.contrastive_loss(anchor, pos32b, 0.1)[0])
             eng.set_option("train_bf16", 2)
             pos2 = eng.encode_cells_train(p64, dropout_p=0.0, seed=1).clone()
             l2 = float(eng.contrastive_loss(anchor, pos2, 0.1)[0])
@@ -638,8 +642,8 @@ def secondary_measurements(eng):
             torch.cuda.synchronize()
             eng.set_option("profile_events", 1)
             out["train_step_b64"]["split_bf16_variant"] = {"ms_per_step_wall": (time.perf_counter() - t0) / n_steps * 1e3,
-                                                           "max_abs_embedding_diff_vs_f32": float((pos2 - pos32).abs().max()),
-                                                           "loss_f32": l32, "loss_split_bf16": l2}
+                                                           "max_abs_embedding_diff_vs_f32": float((pos2 - pos32b).abs().max()),
+                                                           "loss_f32": l32b, "loss_split_bf16": l2}
             eng.set_option("train_bf16", 0)
         except Exception as e:
             out["train_step_b64"]["bf16_variant"] = {"error": repr(e)}
