@@ -31,6 +31,7 @@ from text2loc_amd.sharded import QueryShardedSearcher, ShardedSearcher, shard_bo
 
 N_CELLS, N_QUERIES, DIM, TOPK = 11259, 4096, 256, 10
 _QS = None
+_QUICK = False
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (AMD's 5 PF figure is 2:1 sparse)
 
@@ -323,19 +324,20 @@ def secondary_measurements(eng):
     for qn in (1, 64):
         dq = torch.from_numpy(np.ascontiguousarray(_QS[:qn])).cuda()
         o = (torch.empty((qn, TOPK), dtype=torch.int32, device="cuda"), torch.empty((qn, TOPK), dtype=torch.float64, device="cuda"))
-        for _ in range(2000):  # (clock ramp, see main)
+        n_ramp, n_lat = (10, 20) if _QUICK else (2000, 1000)
+        for _ in range(n_ramp):  # (clock ramp, see main)
             eng.search(dq, TOPK, out=o)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(1000):
+        for _ in range(n_lat):
             eng.search(dq, TOPK, out=o)
         torch.cuda.synchronize()
-        lat[f"q{qn}_us_per_call"] = (time.perf_counter() - t0) / 1000 * 1e6  # back to back on the stream
+        lat[f"q{qn}_us_per_call"] = (time.perf_counter() - t0) / n_lat * 1e6  # back to back on the stream
         t0 = time.perf_counter()
-        for _ in range(200):
+        for _ in range(20 if _QUICK else 200):
             eng.search(dq, TOPK, out=o)
             torch.cuda.synchronize()
-        lat[f"q{qn}_us_per_call_synchronized"] = (time.perf_counter() - t0) / 200 * 1e6  # host-visible round trip of one call
+        lat[f"q{qn}_us_per_call_synchronized"] = (time.perf_counter() - t0) / (20 if _QUICK else 200) * 1e6  # host-visible round trip of one call
     eng.set_option("profile_events", 1)
     out["search_latency"] = lat
     # HBM-streaming regime (SURVEY.md §8d config 2'): 32 queries against N = 2,097,152 rows (1 GiB of f16 DB plane,
@@ -579,11 +581,12 @@ def secondary_measurements(eng):
 
         # wall clock without event pairs (each costs the stream ~6 us) and after a clock ramp; phase times from a second, bracketed loop
         eng.set_option("profile_events", 0)
-        for i in range(150):
+        n_ramp_t = 3 if _QUICK else 150
+        for i in range(n_ramp_t):
             train_step(i)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n_steps = 100
+        n_steps = 5 if _QUICK else 100
         for i in range(n_steps):
             last = train_step(1000 + i)
         torch.cuda.synchronize()
@@ -591,7 +594,7 @@ def secondary_measurements(eng):
         eng.set_option("profile_events", 1)
         for nme in ("train_forward", "train_backward", "adam_step", "contrastive_loss"):
             eng.kernel_stats(nme)
-        for i in range(30):
+        for i in range(3 if _QUICK else 30):
             train_step(100 + i)
         torch.cuda.synchronize()
         kept64 = int(np.minimum(cells64["counts"], 28).sum())
@@ -614,7 +617,7 @@ def secondary_measurements(eng):
             pos16 = eng.encode_cells_train(p64, dropout_p=0.0, seed=1).clone()
             l16 = float(eng.contrastive_loss(anchor, pos16, 0.1)[0])
             eng.set_option("profile_events", 0)
-            for i in range(150):
+            for i in range(n_ramp_t):
                 train_step(200 + i)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -633,7 +636,7 @@ def secondary_measurements(eng):
             pos2 = eng.encode_cells_train(p64, dropout_p=0.0, seed=1).clone()
             l2 = float(eng.contrastive_loss(anchor, pos2, 0.1)[0])
             eng.set_option("profile_events", 0)
-            for i in range(150):
+            for i in range(n_ramp_t):
                 train_step(400 + i)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -708,6 +711,8 @@ def main():
     ap.add_argument("--nsplit", type=int, default=0, help="override the scan kernel's DB split count (0 = auto)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the pipelined side measurement (profiling runs: its "
                     "overlapping launches would enter the per-kernel averages)")
+    ap.add_argument("--quick", action="store_true", help="profiling runs (rocprofv3 --pmc slows every launch ~100x and does not "
+                    "survive tens of thousands of them): no clock-ramp steps, short side loops, no pipelined measurement")
     ap.add_argument("--lanes", type=int, default=1,
                     help="1 (default): every step stream-ordered behind the previous one; the pipelined form of the same loop "
                          "is measured beside it (`pipelined`). n > 1 (N=1 only): the TIMED steps themselves pipeline over n "
@@ -811,7 +816,7 @@ def main():
     # An idle MI355X needs ~40 ms of continuous load to reach its sustained clocks (measured: 56.6 -> 46.8 us per step over the
     # first 40 ms of this very loop): untimed ramp steps first, so that a short run (--steps 20 is 1 ms of GPU time) measures the
     # steady state and not the power-state ramp. Then the W warmup steps, then the timed K.
-    RAMP_STEPS = max(0, 1500 - args.warmup)
+    RAMP_STEPS = 0 if args.quick else max(0, 1500 - args.warmup)
     for i in range(RAMP_STEPS):
         step(i)
     for i in range(args.warmup):
@@ -895,7 +900,7 @@ def main():
     # jobs, so step i runs its scan -> re-rank chain on internal stream i % 3 of the engine and the chains overlap. Reported
     # beside `value` (whose steps are stream-ordered, so that its kernel durations mean what rocprofv3 reports).
     pipelined = None
-    if world == 1 and lanes == 1 and rank == 0 and not args.no_pipelined:
+    if world == 1 and lanes == 1 and rank == 0 and not args.no_pipelined and not args.quick:
         P_LANES = 3
         eng.set_option("profile_events", 0)
         eng.set_option("search_lanes", P_LANES)
@@ -954,6 +959,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary:
         global _QS
         _QS = qs
+        global _QUICK
+        _QUICK = bool(args.quick)
         secondary = secondary_measurements(eng)
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
