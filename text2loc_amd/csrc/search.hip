@@ -591,9 +591,12 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const int qrow = min(qb * kWideQPerBlock + (ql >> 5) * kWideQPerWave + g * 32 + (ql & 31), Q - 1);
-      const float4* qp = reinterpret_cast<const float4*>(q + (size_t)qrow * kD + qt * 64);
+      // thread (ql, qt) owns the 16-byte chunks 4 i + qt of the row: the 4 lanes of a row read one whole 64-byte line per load
+      // (a quarter-row per thread made every line arrive in four separate requests: the workgroup's 256 KB then took 4.3 us
+      // to trickle through the CU's L1 — the slowest wave sets the barrier)
+      const float4* qp = reinterpret_cast<const float4*>(q + (size_t)qrow * kD) + qt;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[g][i] = qp[i];
+      for (int i = 0; i < 16; ++i) v[g][i] = qp[4 * i];
 #ifdef T2L_EXP_HALFLOAD  // dev experiment: is the prologue bound by the bytes or by the round trip?
       if (g == 1) {
 #pragma unroll
@@ -616,11 +619,11 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
       half_shift_of(m, shift);
       if (g == 1) __syncthreads();  // every wave has read round 0's fragments: the exchange area may be overwritten
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float4 a = v[g][2 * j], b = v[g][2 * j + 1];
-        *reinterpret_cast<u32x4*>(ex_w + (((qt * 8 + j) ^ (ql & 31)) << 4)) =
-            u32x4{pack_f16x2(a.x, a.y, shift), pack_f16x2(a.z, a.w, shift), pack_f16x2(b.x, b.y, shift),
-                  pack_f16x2(b.z, b.w, shift)};
+      for (int j = 0; j < 16; ++j) {  // f32 chunk 4 j + qt = half (qt & 1) of f16 chunk 2 j + (qt >> 1)
+        const float4 a = v[g][j];
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(ex_w + (((2 * j + (qt >> 1)) ^ (ql & 31)) << 4) + ((qt & 1) << 3)) =
+            u32x2{pack_f16x2(a.x, a.y, shift), pack_f16x2(a.z, a.w, shift)};
       }
       __syncthreads();
       if (g == 0) { T2L_STAMP2(1); } else { T2L_STAMP2(4); }

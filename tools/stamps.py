@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from text2loc_amd import engine as E, synth
 E._LIB_PATH = os.path.join(os.path.dirname(E._LIB_PATH), "libt2l_stamps.so")
 eng = E.Engine(0)
-db, qs, _ = synth.make_retrieval_problem(11259, 4096, seed=1, noise=0.5)
+QN = int(os.environ.get("T2L_Q", "4096"))
+db, qs, _ = synth.make_retrieval_problem(11259, QN, seed=1, noise=0.5)
 eng.db_set(torch.from_numpy(db).cuda())
 dq = torch.from_numpy(qs).cuda()
 for a in sys.argv[1:]:
@@ -13,7 +14,7 @@ for a in sys.argv[1:]:
     eng.set_option(k, float(v))
 out = (C.c_longlong * 16)()
 eng.lib.t2l_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
-for _ in range(20):
+for _ in range(1500):
     eng.search(dq, 10)
 for rep in range(3):
     for _ in range(10):
