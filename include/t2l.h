@@ -165,7 +165,7 @@ int t2l_search(t2l_ctx* ctx, const float* queries, int32_t n_queries, int32_t k,
 /* Pipelined searches. With t2l_set_option("search_lanes", n), 2 <= n <= 4, consecutive t2l_search calls — independent jobs
  * in the reference's loop too (training/coarse.py:119-125 runs query after query) — run their scan -> re-rank chains on n
  * internal streams, round-robin, each with its own scratch: the next call's scan overlaps the previous call's re-rank and no
- * kernel-boundary bubble separates calls (measured: 48.5 -> 42 us per 4,096-query call). t2l_search then only ENQUEUES;
+ * kernel-boundary bubble separates calls (measured: 42.9 -> 40.3 us per 4,096-query call). t2l_search then only ENQUEUES;
  * the outputs of every call issued so far are ordered into `stream` by t2l_search_join (queries and output buffers must
  * stay untouched until then). Batches under 256 queries, multi-segment shards and databases in heavy mode join and run in
  * the caller's stream as before. Default n = 1: t2l_search is stream-ordered and t2l_search_join is a no-op. */
