@@ -910,58 +910,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
   // lane at or below that lane's floor (with LL == L a floor above the L-th key cannot happen; with LL < L it can)
   const float g = fmaxf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_key), L - 1)), floor_max);
 
-  // ---- float64 re-score of the selected rows (products of f32 values are exact in f64). Four rows at a time, one per
-  // 16-lane row of the wave: a lane multiplies 16 elements and the row sum is 4 DPP steps (a whole-wave reduction per
-  // row costs 3x the VALU). All gathers are issued before the first sum.
-  double qn = 0.0;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) qn += qd[i] * qd[i];
-  qn = row16_sum_f64(qn);
-  float4 rows[L / 4][4];
-#pragma unroll
-  for (int p = 0; p < L / 4; ++p) {
-    const int row = __shfl(my_row, 4 * p + (lane >> 4));  // candidate 4p + g is re-scored by 16-lane row g
-    const float4* rp = reinterpret_cast<const float4*>(db + (size_t)(row == INT_MAX ? 0 : row) * kD) + seg;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rows[p][i] = rp[16 * i];
-  }
-  double my_d = -__builtin_inf();
-#pragma unroll
-  for (int p = 0; p < L / 4; ++p) {
-    double d0 = 0.0, d1 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      d0 += (double)rows[p][i].x * qd[4 * i];
-      d1 += (double)rows[p][i].y * qd[4 * i + 1];
-      d0 += (double)rows[p][i].z * qd[4 * i + 2];
-      d1 += (double)rows[p][i].w * qd[4 * i + 3];
-    }
-    const double d = row16_sum_f64(d0 + d1);
-    const double mine = __shfl(d, 16 * (lane & 3));  // lane c = 4p + g takes the sum of row g
-    if ((lane >> 2) == p && lane < L && my_row != INT_MAX) my_d = mine;
-  }
-
-  // ---- order by (float64 score desc, row asc); lane c computes its rank among the L
-  int rank = 0;
-#pragma unroll
-  for (int j = 0; j < L; ++j) {
-    const unsigned long long bj = __double_as_longlong(my_d);
-    const double dj = __longlong_as_double(((unsigned long long)__builtin_amdgcn_readlane((unsigned)(bj >> 32), j) << 32) |
-                                           (unsigned)__builtin_amdgcn_readlane((unsigned)bj, j));
-    const int ij = __builtin_amdgcn_readlane(my_row, j);
-    rank += (dj > my_d || (dj == my_d && ij < my_row)) ? 1 : 0;
-  }
-  const bool valid = lane < L && my_row != INT_MAX;
-  if (lane < K) {
-    out_idx[(size_t)qid * K + lane] = -1;
-    if (out_score) out_score[(size_t)qid * K + lane] = -__builtin_inf();
-  }
-  if (valid && rank < K) {
-    out_idx[(size_t)qid * K + rank] = my_row + row_offset;
-    if (out_score) out_score[(size_t)qid * K + rank] = my_d;
-  }
-
-  // ---- certificate (keys of the f16 scan are true scores times 2^(shift_db + shift_q): undo that exactly)
+  // ---- certificate scale (keys of the f16 scan are true scores times 2^(shift_db + shift_q): undo that exactly)
   double kscale = 1.0;
   bool representable = true;
   {
@@ -977,6 +926,93 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
       representable = representable && abs(sq - 14) <= 40 && abs(sd - 14) <= 40;
     }
   }
+
+  // ---- float64 re-score of the selected rows (products of f32 values are exact in f64). Four rows at a time, one per
+  // 16-lane row of the wave: a lane multiplies 16 elements and the row sum is 4 DPP steps (a whole-wave reduction per
+  // row costs 3x the VALU). The re-rank is bound by these gathers (16 KB per query from L2 / Infinity Cache: skipping four
+  // of the sixteen rows was measured at -1.3 us per step), so they come in two stages: the best L - 4 candidates first, and
+  // when the certificate already holds against the (L-4)-th merged key — 9 queries in 10 — the last four rows are never
+  // fetched: everything not re-scored, those four included, has a key at or below that bound.
+  double qn = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) qn += qd[i] * qd[i];
+  qn = row16_sum_f64(qn);
+  const double eps32 = (double)eps_rel * sqrt(qn) * (double)(*db_norm_max);
+  constexpr int LA = L - 4;
+  float4 rows[L / 4][4];
+  auto gather = [&](int p) {
+    const int row = __shfl(my_row, 4 * p + (lane >> 4));  // candidate 4p + g is re-scored by 16-lane row g
+    const float4* rp = reinterpret_cast<const float4*>(db + (size_t)(row == INT_MAX ? 0 : row) * kD) + seg;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rows[p][i] = rp[16 * i];
+  };
+  double my_d = -__builtin_inf();
+  auto score = [&](int p) {
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      d0 += (double)rows[p][i].x * qd[4 * i];
+      d1 += (double)rows[p][i].y * qd[4 * i + 1];
+      d0 += (double)rows[p][i].z * qd[4 * i + 2];
+      d1 += (double)rows[p][i].w * qd[4 * i + 3];
+    }
+    const double d = row16_sum_f64(d0 + d1);
+    const double mine = __shfl(d, 16 * (lane & 3));  // lane c = 4p + g takes the sum of row g
+    if ((lane >> 2) == p && lane < L && my_row != INT_MAX) my_d = mine;
+  };
+  // order by (float64 score desc, row asc) among the first N candidates: lane c < N computes its rank
+  auto rank_among = [&](auto n_tag) {
+    constexpr int N = decltype(n_tag)::value;
+    int r = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const unsigned long long bj = __double_as_longlong(my_d);
+      const double dj = __longlong_as_double(((unsigned long long)__builtin_amdgcn_readlane((unsigned)(bj >> 32), j) << 32) |
+                                             (unsigned)__builtin_amdgcn_readlane((unsigned)bj, j));
+      const int ij = __builtin_amdgcn_readlane(my_row, j);
+      r += (dj > my_d || (dj == my_d && ij < my_row)) ? 1 : 0;
+    }
+    return r;
+  };
+  auto emit = [&](bool ok, int r) {
+    if (lane < K) {
+      out_idx[(size_t)qid * K + lane] = -1;
+      if (out_score) out_score[(size_t)qid * K + lane] = -__builtin_inf();
+    }
+    if (ok && r < K) {
+      out_idx[(size_t)qid * K + r] = my_row + row_offset;
+      if (out_score) out_score[(size_t)qid * K + r] = my_d;
+    }
+  };
+#pragma unroll
+  for (int p = 0; p < L / 4 - 1; ++p) gather(p);
+#pragma unroll
+  for (int p = 0; p < L / 4 - 1; ++p) score(p);
+  bool early = false;
+  if (K <= LA && representable && eps_rel_probe == 0.f) {  // (the stand-in probe counts against the full certificate below)
+    const float gA = fmaxf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_key), LA - 1)), floor_max);
+    if (gA != T2L_NEG_INF) {  // (fewer than L - 4 candidates: the full path certifies trivially)
+      const int rA = rank_among(std::integral_constant<int, LA>{});
+      const bool validA = lane < LA && my_row != INT_MAX;
+      const unsigned long long kthA = __ballot(validA && rA == K - 1);
+      if (kthA != 0ull) {
+        const double dK = __shfl(my_d, __ffsll((long long)kthA) - 1);
+        if (dK > (double)gA * kscale + key_slack(gA, code_bits, eps32, kscale)) {  // wave-uniform
+          emit(validA, rA);
+          early = true;
+        }
+      }
+    }
+  }
+  if (early) {
+    if (lane == 0) flags[qid] = 0;
+  } else {
+  gather(L / 4 - 1);
+  score(L / 4 - 1);
+  const int rank = rank_among(std::integral_constant<int, L>{});
+  const bool valid = lane < L && my_row != INT_MAX;
+  emit(valid, rank);
+
   bool certified = true;
   float thr = T2L_NEG_INF;  // fallback: only rows with key >= thr can still reach the top-K
   if (g != T2L_NEG_INF) {  // an L-th candidate exists, so something may not have been re-scored
@@ -984,7 +1020,6 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
     const unsigned long long kth = __ballot(valid && rank == K - 1);
     if (K <= L && kth != 0ull) {
       const double dK = __shfl(my_d, __ffsll((long long)kth) - 1);
-      const double eps32 = (double)eps_rel * sqrt(qn) * (double)(*db_norm_max);
       certified = dK > (double)g * kscale + key_slack(g, code_bits, eps32, kscale);
       // while the split-bf16 scan stands in for the f16 scan on a DB that overwhelmed its certificate, count the queries
       // the f16 error band would still flag: the host goes back to the f16 scan when they become rare
@@ -1071,6 +1106,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
       else flags[3 * Q + atomicAdd(&fb_count[4], 1)] = qid;                  //             -> exactd_kernel
     }
   }
+  }  // !early
   }  // qid < Q
   // ---- unsettled queries of this workgroup: the exact float64 ranking, all 4 waves on one query at a time
   __syncthreads();
