@@ -273,3 +273,48 @@ def test_train_and_eval_epochs_on_a_kitti360pose_directory():
     dl_val = torch.utils.data.DataLoader(ds, batch_size=4, collate_fn=K.Kitti360PoseDataset.collate_fn, shuffle=False)
     acc, acc_close, retrievals = eval_epoch(model, dl_val, args)
     assert set(acc) == {1, 3} and all(0.0 <= v <= 1.0 for v in acc.values()) and len(retrievals) == len(ds)
+
+
+def test_batch_of_64_cells_equals_its_parts(eng):
+    """The published batch (64 cells, ~1,300 objects, 2.7 M edge rows at SA1: beyond one GEMM launch's 65,535 row tiles): every
+    cell's BatchNorm is its own, so features of a cell and the parameter gradients summed over parts of the batch must equal
+    those of the whole batch (to float32 summation order)."""
+    cells = synth.make_cells(64, seed=1)
+    pos, rgb = synth.make_sampled_points(cells, 1)
+    tensors = bind_all(eng, synth.make_object_branch_weights(2), synth.make_pointnet_weights(3))
+    offs = np.asarray(cells["offsets"], dtype=np.int32)
+    dpos, drgb = torch.from_numpy(pos).cuda(), torch.from_numpy(rgb).cuda()
+    g = torch.randn(pos.shape[0], 256, generator=torch.Generator().manual_seed(1)).cuda()
+    names = [k for k in tensors if k.startswith(P) and tensors[k][1] is not None]
+    run0 = {k: tensors[k][0].clone() for k in tensors if "running_" in k}
+
+    full = eng.pointnet_features_train(dpos, drgb, offs).clone()
+    eng.zero_grad()
+    eng.pointnet_backward(g)
+    torch.cuda.synchronize()
+    g_full = {k: tensors[k][1].clone() for k in names}
+    run_full = {k: tensors[k][0].clone() for k in run0}
+
+    for k, v in run0.items():  # the same starting running statistics for the run in parts
+        tensors[k][0].copy_(v)
+    eng.zero_grad()
+    parts = []
+    for c0 in range(0, 64, 16):
+        lo, hi = int(offs[c0]), int(offs[c0 + 16])
+        sub = (offs[c0:c0 + 17] - offs[c0]).astype(np.int32)
+        parts.append(eng.pointnet_features_train(dpos[lo:hi].contiguous(), drgb[lo:hi].contiguous(), sub).clone())
+        eng.pointnet_backward(g[lo:hi].contiguous())
+    torch.cuda.synchronize()
+    got = torch.cat(parts)
+    assert float((got - full).abs().max()) < 2e-5 * max(1.0, float(full.abs().max()))
+    for k in names:
+        a, b = tensors[k][1], g_full[k]
+        if k.endswith(".0.bias") and "lin" not in k:
+            continue  # in front of a BatchNorm: float32 noise around a zero gradient
+        err = float((a - b).norm() / (b.norm() + 1e-30))
+        # the BatchNorm sums meet in a different order (float64 atomics of float32 partials): among 2.7 M edge rows a few
+        # arg-max / ReLU decisions fall the other way and move single gradients by a few 1e-3; a mis-sliced GEMM would lose
+        # a quarter of the rows
+        assert err < 1e-2, (k, err)
+    for k in run0:  # sequential per-cell momentum updates: the same sequence either way
+        assert float((tensors[k][0] - run_full[k]).abs().max()) < 1e-5 * max(1.0, float(run_full[k].abs().max())), k
