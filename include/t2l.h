@@ -303,6 +303,9 @@ int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step,
  * "train_bf16"        (default 0): 1 = the GEMMs of t2l_encode_cells_train / t2l_encode_cells_backward round their operands to
  *     bf16 (RNE) and run on the bf16 MFMA with f32 accumulation; parameters, activations, BatchNorm / LayerNorm / softmax,
  *     the loss and Adam stay f32 (what torch.autocast(bfloat16) keeps in f32 too). BASELINE config 4's "bf16".
+ *     2 = split-bf16: every operand as hi + lo bf16, three MFMAs per 16-step (relative product error <= 2^-16 + 2^-18, f32's
+ *     exponent range): the f32 goldens are met to 1e-4 at close to the bf16 variant's speed. Applies to the PointNet++
+ *     training calls too.
  * "search_pair"       (default 1): mode 0 only — 1 = the paired scan (two waves per SIMD), 0 = one wave per SIMD.
  * "search_heavy"      (set by the engine, see search_auto): 1 = queries no certificate settles go to the float64 MFMA exact
  *     stage instead of the fallback kernel's float64 VALU scan. With search_auto = 0 the caller may force it.
@@ -315,8 +318,15 @@ int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step,
  *     MFMA. By default their big contractions use split-f16 MFMAs (hi*hi + hi*lo + lo*hi, ~5e-7 relative) behind range
  *     safeguards — bounds derived from the weights at load time (encoder, fine stage), a row-norm guard on the raw
  *     descriptors (fine stage), a magnitude watch (PointNet++) — and whatever fails them is computed by the f32 kernels.
+ * "encoder_f16"       (default 0): 1 = ONE f16 product per operand pair in those kernels instead of the three of the split
+ *     form (the high halves of the same packing): embeddings / offsets / features within ~1e-4 of the reference's instead of
+ *     2e-7 (the published target is 1e-3), 20-40 % less time. The range safeguards stay in force.
+ * "search_lanes"      (default 1): 2..4 = pipelined searches, see t2l_search_join.
+ * "search_pair_ll"    (default 6): per-lane list length of the paired scan (5: experiment, halves the certificate's margin).
  * "profile_events"    (default 0): n >= 1 records hipEvents around every n-th launch of each kernel (t2l_kernel_stats);
- *                     two records cost a few microseconds of queue time, which matters beside a 40 us kernel. */
+ *                     two records cost ~6 us of queue time per bracketed kernel, which matters beside a 30 us kernel.
+ * "profile_rerank"    (default 1): 0 = sampled search launches bracket the scan only.
+ * "stats_reset"       (any value): forget every kernel-time sample so far (host-only: no stream operation, no sync). */
 int t2l_set_option(t2l_ctx* ctx, const char* name, double value);
 
 /* Per-kernel device time measured with hipEvent pairs recorded on the caller's stream around each launch
@@ -324,8 +334,10 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value);
  * Returns the average duration (ms) and the number of launches recorded since the previous call for
  * name = "search_scan" | "search_rerank" | "encode_cells" | "contrastive_loss" | "reduce_objects" | "train_forward" |
  * "train_backward" | "adam_step" | "pointnet" | "fine_objects" | "fine_match" | "search_fallback" | "search_exact" (at most
- * the last 512); "search_scan_span" needs no option: the paired scan stamps every launch itself (100 MHz clock, first
- * workgroup start -> last workgroup end, the last 256 launches),
+ * the last 512), "pointnet_train_index" | "pointnet_train_forward" | "pointnet_train_backward";
+ * "search_scan_span" and "search_scan_busy" need no option: every workgroup of the paired scan stamps its own start and end
+ * (100 MHz clock, the last 64 launches) — span = first workgroup start -> last workgroup end, busy = mean workgroup
+ * duration (the GPU time a launch used: what still means something when pipelined launches overlap);
  * then clears the record. Synchronises on the recorded events. */
 int t2l_kernel_stats(t2l_ctx* ctx, const char* name, float* out_avg_ms, int32_t* out_count);
 
