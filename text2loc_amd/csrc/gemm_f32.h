@@ -151,5 +151,95 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Row-streaming GEMM for TALL problems (M = 10^5 .. 10^7 rows, N and K <= 1024: the edge MLPs of PointNet++ in training
+// mode): C[M,N] = A[M,K] B (+ bias[n]), A row-major (k contiguous), B_KC: B(k,n) = B[n*ldb + k] (Y = X W^T) else
+// B(k,n) = B[k*ldb + n] (dX = dY W). gemm_kernel gives every 32x32 output tile its own workgroup: on these shapes the rows are
+// re-read N/32 times and four waves split a reduction of 2-16 steps and meet in LDS. Here a wave owns 32 ROWS: one A
+// fragment per 16-step feeds up to four column tiles (128 columns of accumulators), no split-K, no LDS, no barrier; wider
+// outputs take another pass over the rows. B is small (<= 2 MB) and stays in L1 / L2. K must be a multiple of 16, N of 32.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool B_KC>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 31, kh = lane >> 5;
+  const int m0 = blockIdx.x * 128 + w * 32;
+  if (m0 >= g.M) return;
+  const int arow = min(m0 + i, g.M - 1);  // rows past the end repeat the last one (never stored)
+  const float* ap = g.A + (size_t)arow * g.lda + 8 * kh;
+  constexpr int kRing = 4;  // the rows stream from HBM (~2 us away): four 16-steps of them in flight per wave
+  for (int n0 = 0; n0 < g.N; n0 += 128) {
+    const int nt = min(4, (g.N - n0) >> 5);  // column tiles of this pass (workgroup-uniform)
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float a[kRing][8];
+    auto load_a = [&](int k0, float (&d)[8]) {
+      const float4 x = *reinterpret_cast<const float4*>(ap + k0), y = *reinterpret_cast<const float4*>(ap + k0 + 4);
+      d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w; d[4] = y.x; d[5] = y.y; d[6] = y.z; d[7] = y.w;
+    };
+#pragma unroll
+    for (int d = 0; d < kRing; ++d)
+      if (16 * d < g.K) load_a(16 * d, a[d]);
+    for (int kb = 0; kb < g.K; kb += 16 * kRing) {
+#pragma unroll
+      for (int d = 0; d < kRing; ++d) {
+        const int k0 = kb + 16 * d;
+        if (k0 < g.K) {
+          gemm_bf16x8 ah, al;
+          if (g.bf16 == 2) gemm_split_bf16(a[d], ah, al);
+          else if (g.bf16) ah = gemm_to_bf16(a[d]);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (t < nt) {
+              float b[8];
+              const int n = n0 + 32 * t + i;
+              if (B_KC) {
+                const float* bp = g.B + (size_t)n * g.ldb + k0 + 8 * kh;
+                const float4 x = *reinterpret_cast<const float4*>(bp), y = *reinterpret_cast<const float4*>(bp + 4);
+                b[0] = x.x; b[1] = x.y; b[2] = x.z; b[3] = x.w; b[4] = y.x; b[5] = y.y; b[6] = y.z; b[7] = y.w;
+              } else {
+                const float* bp = g.B + (size_t)(k0 + 8 * kh) * g.ldb + n;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[j] = bp[(size_t)j * g.ldb];
+              }
+              if (g.bf16 == 2) {
+                gemm_bf16x8 bh, bl;
+                gemm_split_bf16(b, bh, bl);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+              } else if (g.bf16) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gemm_to_bf16(b), acc[t], 0, 0, 0);
+              } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][j], b[j], acc[t], 0, 0, 0);
+              }
+            }
+          }
+          if (k0 + 16 * kRing < g.K) load_a(k0 + 16 * kRing, a[d]);  // refill this slot with the step one ring ahead
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t < nt) {
+        const int cg = n0 + 32 * t + i;
+        const float bv = g.bias ? g.bias[cg] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          if (row < g.M) {
+            float v = acc[t][r] + bv;
+            if (g.relu) v = fmaxf(v, 0.f);
+            g.C[(size_t)row * g.ldc + cg] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace train
 }  // namespace t2l

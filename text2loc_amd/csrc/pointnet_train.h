@@ -42,6 +42,7 @@ struct PnTrain {
   PnLevel lv[4];
   float *f0 = nullptr, *f1 = nullptr, *f2 = nullptr;
   double* acc = nullptr;  // [n_cells][2][1024]
+  float* wt = nullptr;    // [1024 x 512]: a weight matrix transposed for the input-gradient GEMM
 };
 
 static const char* kPnBlocks[4] = {"sa1.point_conv.local_nn", "sa2.point_conv.local_nn", "sa3.point_conv.local_nn", "ga.mlp"};
@@ -453,15 +454,22 @@ static void pn_train_free(void* p) {
   delete pt;
 }
 
-// grid.y carries the row tiles of gemm_kernel: at most 65,535 of them per launch — the edge matrices have millions of rows
-constexpr int kGemmRowSlice = 65535 * 32;
-static void gemm_nt_rows(const float* X, const float* W, const float* b, float* Y, size_t M, int N, int K, int relu, hipStream_t s) {
-  for (size_t r0 = 0; r0 < M; r0 += kGemmRowSlice)
-    gemm_nt(X + r0 * K, W, b, Y + r0 * N, (int)std::min<size_t>(kGemmRowSlice, M - r0), N, K, relu, s);
+// the tall GEMMs of the edge MLPs: row-streaming kernel (gemm_f32.h), one launch whatever M is
+static void launch_rows_nt(const train::GemmArgs& g, hipStream_t s) {
+  hipLaunchKernelGGL((train::gemm_rows_kernel<true>), dim3((unsigned)((g.M + 127) / 128)), dim3(256), 0, s, g);
 }
-static void gemm_nn_rows(const float* dY, const float* W, float* dX, size_t M, int N, int Kp, hipStream_t s) {
-  for (size_t r0 = 0; r0 < M; r0 += kGemmRowSlice)
-    gemm_nn(dY + r0 * N, W, dX + r0 * Kp, (int)std::min<size_t>(kGemmRowSlice, M - r0), N, Kp, 0, s);
+static void gemm_nt_rows(const float* X, const float* W, const float* b, float* Y, size_t M, int N, int K, int relu, hipStream_t s) {
+  launch_rows_nt(train::GemmArgs{X, W, Y, b, (int)M, N, K, K, K, N, relu, 0, 0, nullptr, tl_gemm_bf16}, s);
+}
+// dX[M,Kp] = dY[M,N] W[N,Kp]: W is transposed once (<= 2 MB) so that the weight fragments are k-contiguous float4 loads too
+// (eight strided scalar loads per tile and step made this form 3 ms slower than the 32x32-tile kernel it replaces)
+__global__ void pt_transpose_kernel(const float* __restrict__ W, int N, int Kp, float* __restrict__ Wt) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < N * Kp) Wt[(size_t)(i % Kp) * N + i / Kp] = W[i];
+}
+static void gemm_nn_rows(const float* dY, const float* W, float* Wt, float* dX, size_t M, int N, int Kp, hipStream_t s) {
+  hipLaunchKernelGGL(pt_transpose_kernel, dim3((unsigned)((N * Kp + 255) / 256)), dim3(256), 0, s, W, N, Kp, Wt);
+  launch_rows_nt(train::GemmArgs{dY, Wt, dX, nullptr, (int)M, Kp, N, N, N, Kp, 0, 0, 0, nullptr, tl_gemm_bf16}, s);
 }
 
 // object_encoder.pointnet.* tensors of the binding: all of them with gradient buffers -> the backbone trains in the engine
@@ -532,6 +540,7 @@ static size_t pn_layout(PnTrain* pt) {
   pt->cell_of_obj = pn_bump<int32_t>(pt, n_obj);
   pt->cell_base = pn_bump<int32_t>(pt, n_obj);
   pt->acc = pn_bump<double>(pt, (size_t)n_cells * 2 * 1024);
+  pt->wt = pn_bump<float>(pt, (size_t)1024 * 512);
   size_t scratch = 0;
   for (int l = 0; l < 4; ++l) {
     PnLevel& L = pt->lv[l];
@@ -813,7 +822,7 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
     float* dA1 = pn_bump<float>(pt, L.E * L.h1);
     pn_block_bwd(st, pt, L, 1, dA2, L.y2, nullptr, L.h2, L.mean2, L.rstd2, dx, s);
     gemm_tn(dA2, L.a1, T_(st, L.prefix + ".1.0.weight").grad, T_(st, L.prefix + ".1.0.bias").grad, (int)L.E, L.h2, L.h1, s);
-    gemm_nn_rows(dA2, T_(st, L.prefix + ".1.0.weight").data, dA1, L.E, L.h2, L.h1, s);
+    gemm_nn_rows(dA2, T_(st, L.prefix + ".1.0.weight").data, pt->wt, dA1, L.E, L.h2, L.h1, s);
     pn_block_bwd(st, pt, L, 0, dA1, L.y1, L.a1, L.h1, L.mean1, L.rstd1, nullptr, s);
     T2L_HIP(ctx, hipMemsetAsync(L.dw1p, 0, sizeof(float) * (size_t)L.h1 * L.kp, s));
     gemm_tn(dA1, L.X, L.dw1p, T_(st, L.prefix + ".0.0.bias").grad, (int)L.E, L.h1, L.kp, s);
@@ -821,7 +830,7 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
                        T_(st, L.prefix + ".0.0.weight").grad);
     if (l > 0) {  // the input gradient: features of the level below (positions are data)
       float* dX = pn_bump<float>(pt, L.E * L.kp);
-      gemm_nn_rows(dA1, L.w1p, dX, L.E, L.h1, L.kp, s);
+      gemm_nn_rows(dA1, L.w1p, pt->wt, dX, L.E, L.h1, L.kp, s);
       const PnLevel& Lb = pt->lv[l - 1];
       const size_t nprev = Lb.G * Lb.h2;
       if (L.sa) {
