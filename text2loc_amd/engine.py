@@ -424,10 +424,10 @@ class Engine:
                                             out_s.data_ptr(), _stream_ptr()))
         return out_i, out_s
 
-    def pack_pairs(self, idx: torch.Tensor, score: torch.Tensor) -> torch.Tensor:
+    def pack_pairs(self, idx: torch.Tensor, score: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """(idx i32[Q,K], score f64[Q,K]) -> f64[Q,K,2] records {score, row id}: one buffer for one collective."""
         Q, K = (int(x) for x in idx.shape)
-        pairs = torch.empty((Q, K, 2), dtype=torch.float64, device=idx.device)
+        pairs = out if out is not None else torch.empty((Q, K, 2), dtype=torch.float64, device=idx.device)
         self._check(self.lib.t2l_pack_pairs(self._h, _dev_ptr(idx, torch.int32, "idx"),
                                             _dev_ptr(score, torch.float64, "score"), Q, K, pairs.data_ptr(), _stream_ptr()))
         return pairs

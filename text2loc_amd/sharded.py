@@ -101,6 +101,7 @@ class ShardedSearcher:
         self._default_fns = search_fn is None and merge_fn is None
         self.search_fn = search_fn or (lambda q, k: engine.search(q, k))
         self.merge_fn = merge_fn or (lambda i, s: engine.merge_topk(i, s))
+        self._scratch = {}  # (Q, k, device) -> intermediates of the engine path (stream-ordered reuse: nothing of them is returned)
 
     def set_db_shard(self, all_rows_or_shard, n_total: Optional[int] = None):
         """Give either the full [N,256] matrix (this rank keeps its slice) or this rank's slice + n_total."""
@@ -120,16 +121,27 @@ class ShardedSearcher:
     def search(self, queries, k: int):
         import torch
 
+        if self.world > 1 and self.engine is not None and self._default_fns:
+            # ONE collective: {score, row id} records (row ids are exact in float64), 16 B per candidate. The per-shard
+            # results and the exchange buffers are scratch, reused call after call (a step is ~70 us of GPU time: five
+            # tensor allocations per call would make the host the bottleneck)
+            Q = int(queries.shape[0])
+            key = (Q, int(k), queries.device)
+            sbuf = self._scratch.get(key)
+            if sbuf is None:
+                dev = queries.device
+                sbuf = self._scratch[key] = (torch.empty((Q, k), dtype=torch.int32, device=dev), torch.empty((Q, k), dtype=torch.float64, device=dev),
+                                             torch.empty((Q, k, 2), dtype=torch.float64, device=dev),
+                                             torch.empty((self.world * Q, k, 2), dtype=torch.float64, device=dev))
+            idx, sc, pairs, allp = sbuf
+            self.engine.search(queries, k, out=(idx, sc))
+            self.engine.pack_pairs(idx, sc, out=pairs)
+            _all_gather(self.dist, allp, pairs, self.group)
+            return self.engine.merge_pairs(allp.view(self.world, Q, k, 2))
         idx, sc = self.search_fn(queries, k)
         if self.world == 1:
             return idx, sc
         Q = idx.shape[0]
-        if self.engine is not None and self._default_fns:
-            # ONE collective: {score, row id} records (row ids are exact in float64), 16 B per candidate
-            pairs = self.engine.pack_pairs(idx, sc)
-            allp = torch.empty((self.world * Q, k, 2), dtype=torch.float64, device=pairs.device)
-            _all_gather(self.dist, allp, pairs, self.group)
-            return self.engine.merge_pairs(allp.view(self.world, Q, k, 2))
         # rank-major concatenation along dim 0 (the layout both RCCL and gloo accept) == [world][Q][k]
         all_i = torch.empty((self.world * Q, k), dtype=idx.dtype, device=idx.device)
         all_s = torch.empty((self.world * Q, k), dtype=sc.dtype, device=sc.device)
