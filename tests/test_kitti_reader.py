@@ -86,3 +86,22 @@ def test_unpickler_refuses_foreign_classes(tmp_path):
     pickle.dump(osp.join, open(p, "wb"))  # a global from a module outside the whitelist
     with pytest.raises(pickle.UnpicklingError, match="refusing"):
         K.load_pickle(str(p))
+
+
+def test_unpickler_is_an_allow_list(tmp_path):
+    """A dataset pickle is untrusted input: a reduce through builtins.eval / os.system / getattr must not resolve."""
+    from text2loc_amd import kitti360pose as K
+
+    payloads = [b"cbuiltins\neval\n(V__import__('os').getpid()\ntR.", b"cos\nsystem\n(Vtrue\ntR.",
+                b"cbuiltins\ngetattr\n(cbuiltins\nlist\nVappend\ntR.", b"cnumpy\nload\n(V/dev/null\ntR.",
+                b"cbuiltins\n__import__\n(Vos\ntR."]
+    for i, blob in enumerate(payloads):
+        f = tmp_path / f"evil{i}.pkl"
+        f.write_bytes(blob)
+        with pytest.raises(pickle.UnpicklingError):
+            K.load_pickle(str(f))
+    # what the data needs still loads: arrays, scalars, containers
+    f = tmp_path / "ok.pkl"
+    f.write_bytes(pickle.dumps({"a": np.arange(6.0).reshape(2, 3), "b": np.float64(2.5), "c": [1, (2, 3)], "d": {4}}))
+    ok = K.load_pickle(str(f))
+    assert np.array_equal(ok["a"], np.arange(6.0).reshape(2, 3)) and ok["b"] == 2.5 and ok["c"] == [1, (2, 3)]

@@ -93,16 +93,32 @@ _CLASS_MAP = {"Object3d": ObjectRecord, "Cell": CellRecord, "Pose": PoseRecord, 
               "DescriptionPoseCell": HintRecord, "Description": HintRecord}
 
 
+# Exact (module, name) pairs a KITTI360Pose pickle may resolve besides the reference's own record classes: what numpy
+# arrays / scalars and plain containers need to rebuild themselves (both numpy 1.x and 2.x module spellings). Nothing else
+# — in particular nothing of ``builtins`` that can call or import (eval, exec, getattr, __import__) — is reachable, so a
+# crafted dataset pickle cannot execute code through ``load_pickle``.
+_SAFE_GLOBALS = {
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("_codecs", "encode"),
+    ("collections", "OrderedDict"),
+} | {("builtins", n) for n in ("list", "dict", "set", "tuple", "str", "int", "float", "bool", "bytes", "bytearray", "complex",
+                                 "frozenset", "slice", "range", "object")}
+
+
 class KittiUnpickler(pickle.Unpickler):
-    """Resolves classes of the reference's ``datapreparation.kitti360pose`` package to the records above; everything else
-    (numpy reconstructors, builtins) goes the normal way. Unknown classes of that package become generic ``Record``s."""
+    """Resolves classes of the reference's ``datapreparation.kitti360pose`` package to the records above and the exact
+    numpy / container reconstructors of ``_SAFE_GLOBALS``; every other global raises ``UnpicklingError``. Unknown classes
+    of the reference's package become generic ``Record``s."""
 
     def find_class(self, module, name):
-        if module == _REF_PACKAGE or module.startswith(_REF_PACKAGE + "."):
-            return _CLASS_MAP.get(name, Record)
-        if module.startswith("numpy") or module in ("builtins", "collections", "copyreg", "_codecs"):
+        if module == _REF_PACKAGE or module.startswith(_REF_PACKAGE + ".") or module.startswith("datapreparation.kitti360."):
+            return _CLASS_MAP.get(name, Record)  # dataloading/__init__.py:8-10 aliases the old package name
+        if (module, name) in _SAFE_GLOBALS:
             return super().find_class(module, name)
-        raise pickle.UnpicklingError(f"refusing to import {module}.{name} while reading a KITTI360Pose pickle")
+        raise pickle.UnpicklingError(f"refusing to resolve {module}.{name} while reading a KITTI360Pose pickle")
 
 
 def load_pickle(path: str):
