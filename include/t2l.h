@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define T2L_ABI_VERSION 1
+#define T2L_ABI_VERSION 2
 #define T2L_EMBED_DIM 256
 #define T2L_OBJECT_SIZE 28 /* args.object_size, models/cell_retrieval.py:32 */
 #define T2L_MAX_TOPK 26    /* max(top_k) supported by the fused search (eval default is 10) */
@@ -93,15 +93,23 @@ int t2l_reduce_objects(t2l_ctx* ctx, const float* xyz, const float* rgb, const i
                        float* out_center, float* out_npts, int32_t* out_color_idx, void* stream);
 
 /* ---- point batches for PointNet++ (a3, dataloader side) ------------------------------------------ */
-/* Replaces: batch_object_points(objects, transform) with transform = Compose([FixedPoints(256), NormalizeScale()])
- * (dataloading/kitti360pose/utils.py:91-147, evaluation/pipeline.py:215-223), which the reference runs per object on the host
- * inside the dataloader: 256 point indices drawn with replacement, positions centred on the mean of the sample and scaled by
- * 0.999999 / max |coordinate|, colours gathered. xyz, rgb: dev f32[n_points,3] (objects concatenated);
- * point_offsets: DEV i64[n_objects+1]; out_pos / out_rgb: dev f32[n_objects,256,3] — the inputs of t2l_pointnet_features.
- * Sampling is counter-based (the reference uses numpy's global RNG: equal in distribution, not in the draw): index j of
- * object o is floor(u * n_o) with u = (lowbias32(j * 0x9E3779B1 + (seed ^ o * 0x85EBCA77)) >> 8) / 2^24. */
+/* Replaces: batch_object_points(objects, transform) (dataloading/kitti360pose/utils.py:91-147), which the reference runs per
+ * object on the host inside the dataloader, for the three transforms its scripts compose:
+ *   transform_flags = 0                                        FixedPoints(256)                      `--no_pc_augment`: EVERY published
+ *       command (README.md:89,107,125-126,139-140; evaluation/pipeline.py:215-216, training/coarse.py:182-184) — positions stay in
+ *       the cell-normalised frame, the ball-query radii 0.2 / 0.3 / 0.4 are absolute;
+ *   T2L_SAMPLE_NORMALIZE                                       FixedPoints + NormalizeScale          evaluation without the flag
+ *       (evaluation/pipeline.py:217-218, training/coarse.py:193): centred on the mean of the sample, scaled by 0.999999 / max |coordinate|;
+ *   T2L_SAMPLE_ROTATE | T2L_SAMPLE_NORMALIZE, rotate_deg = 120 FixedPoints + RandomRotate(120, axis=2) + NormalizeScale   training
+ *       without the flag (training/coarse.py:185-192): one angle per object, uniform in [-rotate_deg, +rotate_deg], about z.
+ * xyz, rgb: dev f32[n_points,3] (objects concatenated); point_offsets: DEV i64[n_objects+1]; out_pos / out_rgb: dev
+ * f32[n_objects,256,3] — the inputs of t2l_pointnet_features. Sampling is counter-based (the reference uses numpy's global RNG: equal
+ * in distribution, not in the draw): index j of object o is floor(u * n_o) with u = (lowbias32(j * 0x9E3779B1 + key_o) >> 8) / 2^24,
+ * key_o = seed ^ o * 0x85EBCA77; the angle is rotate_deg * (2u' - 1) with u' = (lowbias32(0xA5A5A5A5 + key_o) >> 8) / 2^24. */
+#define T2L_SAMPLE_NORMALIZE 1
+#define T2L_SAMPLE_ROTATE 2
 int t2l_sample_object_points(t2l_ctx* ctx, const float* xyz, const float* rgb, const int64_t* point_offsets, int32_t n_objects,
-                             uint32_t seed, float* out_pos, float* out_rgb, void* stream);
+                             uint32_t seed, int32_t transform_flags, float rotate_deg, float* out_pos, float* out_rgb, void* stream);
 
 /* ---- PointNet++ object backbone (a3), eval mode ------------------------------------------------ */
 /* Replaces: PointNet2.forward(...).features2 (models/pointcloud/pointnet2.py:66-100) as ObjectEncoder.forward calls it

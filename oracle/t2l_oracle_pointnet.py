@@ -107,26 +107,42 @@ def pointnet_features(pos: np.ndarray, rgb: np.ndarray, cell_offsets: np.ndarray
     return f2
 
 
-def sample_object_points(xyz: np.ndarray, rgb: np.ndarray, point_offsets: np.ndarray, seed: int, num: int = 256):
-    """FixedPoints(num) (indices with replacement) + NormalizeScale (centre on the sample mean, scale by 0.999999 / max |coord|)
-    as the reference composes them (evaluation/pipeline.py:215-223) per object (dataloading/kitti360pose/utils.py:138-143),
-    with the build's counter-based index draw (include/t2l.h: t2l_sample_object_points) in place of numpy's global RNG."""
+def _lowbias32(x):
+    M = np.uint64(0xFFFFFFFF)
+    x = x & M
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & M
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & M
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def sample_object_points(xyz: np.ndarray, rgb: np.ndarray, point_offsets: np.ndarray, seed: int, num: int = 256,
+                         transform: str = "fixed", rotate_deg: float = 120.0):
+    """FixedPoints(num) (indices with replacement) and, by ``transform``: "fixed" nothing else (`--no_pc_augment`, every published
+    command: evaluation/pipeline.py:215-216, training/coarse.py:182-184), "normalize" NormalizeScale (centre on the sample mean, scale
+    by 0.999999 / max |coord|; evaluation/pipeline.py:217-218), "rotate_normalize" RandomRotate(rotate_deg, axis=2) before it
+    (training/coarse.py:185-192) — per object (dataloading/kitti360pose/utils.py:138-143), with the build's counter-based draws
+    (include/t2l.h: t2l_sample_object_points) in place of numpy's global RNG."""
     n_obj = len(point_offsets) - 1
     pos = np.zeros((n_obj, num, 3), dtype=F32)
     col = np.zeros((n_obj, num, 3), dtype=F32)
-    M = np.uint64(0xFFFFFFFF)
     j = np.arange(num, dtype=np.uint64)
     for o in range(n_obj):
         p0, n = int(point_offsets[o]), int(point_offsets[o + 1] - point_offsets[o])
-        x = (j * np.uint64(0x9E3779B1) + np.uint64((seed ^ ((o * 0x85EBCA77) & 0xFFFFFFFF)) & 0xFFFFFFFF)) & M
-        x ^= x >> np.uint64(16)
-        x = (x * np.uint64(0x7FEB352D)) & M
-        x ^= x >> np.uint64(15)
-        x = (x * np.uint64(0x846CA68B)) & M
-        x ^= x >> np.uint64(16)
+        okey = np.uint64((seed ^ ((o * 0x85EBCA77) & 0xFFFFFFFF)) & 0xFFFFFFFF)
+        x = _lowbias32(j * np.uint64(0x9E3779B1) + okey)
         idx = (((x >> np.uint64(8)) * np.uint64(n)) >> np.uint64(24)).astype(np.int64)
         p = xyz[p0 + idx].astype(F32)
-        p = p - p.mean(axis=0, dtype=np.float64).astype(F32)
-        pos[o] = p * (F32(1.0) / np.abs(p).max() * F32(0.999999))
+        if transform == "rotate_normalize":
+            u = F32(int(_lowbias32(np.uint64(0xA5A5A5A5) + okey) >> np.uint64(8))) * F32(1.0 / 16777216.0)
+            ang = F32(F32(rotate_deg) * F32(0.017453292519943295)) * (F32(2.0) * u - F32(1.0))
+            c, sn = F32(np.cos(ang)), F32(np.sin(ang))
+            p = np.stack([p[:, 0] * c - p[:, 1] * sn, p[:, 0] * sn + p[:, 1] * c, p[:, 2]], axis=1).astype(F32)
+        if transform != "fixed":
+            p = p - p.mean(axis=0, dtype=np.float64).astype(F32)
+            p = p * (F32(1.0) / np.abs(p).max() * F32(0.999999))
+        pos[o] = p
         col[o] = rgb[p0 + idx]
     return pos, col

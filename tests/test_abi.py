@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(lib, name), f"libt2l.so does not export {name}"
     assert set(engine.EXPORTS) == set(_declared()), "ctypes binding and header disagree"
-    assert lib.t2l_abi_version() == 1
+    assert lib.t2l_abi_version() == 2
 
 
 def test_null_context_is_rejected_without_a_gpu():

@@ -124,7 +124,7 @@ def test_drop_in_published_mode_from_point_batches():
     sd.update(synth.make_pointnet_weights(2, n_classes=len(synth.KNOWN_CLASS), n_colors=len(synth.COLOR_NAMES)))
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
     model = model.to("cuda").eval()
-    batches = packing.sample_object_points(objects, 256, np.random.default_rng(0))
+    batches = packing.sample_object_points(objects, 256, np.random.default_rng(0), transform="normalize")
     emb = model.encode_objects(objects, batches).cpu().numpy()
     # the same chain through the restatements
     pos = np.concatenate([b["pos"].reshape(-1, 256, 3) for b in batches])
@@ -163,24 +163,63 @@ def test_argument_errors(eng):
         eng.pointnet_features(z.cpu(), z, np.array([0, 2]))
 
 
-def test_point_batches_sampled_on_the_gpu(eng):
-    """FixedPoints(256) + NormalizeScale on the GPU vs the numpy restatement (same counter-based draw), then straight into PointNet++."""
+@pytest.mark.parametrize("transform", ["fixed", "normalize", "rotate_normalize"])
+def test_point_batches_sampled_on_the_gpu(eng, transform):
+    """FixedPoints(256) [+ RandomRotate(120, z)] [+ NormalizeScale] on the GPU vs the numpy restatement (same counter-based
+    draws), then straight into PointNet++. "fixed" = `--no_pc_augment`, the published configuration."""
     rs = np.random.default_rng(4)
     n_pts = np.array([8, 25, 300, 4000, 61], dtype=np.int64)
     poff = np.concatenate([[0], np.cumsum(n_pts)]).astype(np.int64)
-    xyz = (rs.standard_normal((int(poff[-1]), 3)) * 3 + 10).astype(np.float32)
+    centre = rs.uniform(0.2, 0.8, size=(5, 3)).repeat(n_pts, axis=0)
+    xyz = (centre + rs.standard_normal((int(poff[-1]), 3)) * 0.08).astype(np.float32)  # cell-frame objects
     rgb = rs.uniform(0, 1, size=(int(poff[-1]), 3)).astype(np.float32)
-    pos, col = eng.sample_object_points(torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda(), torch.from_numpy(poff).cuda(), seed=77)
-    rpos, rcol = OP.sample_object_points(xyz, rgb, poff, 77)
+    args = (torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda(), torch.from_numpy(poff).cuda())
+    pos, col = eng.sample_object_points(*args, seed=77, transform=transform)
+    rpos, rcol = OP.sample_object_points(xyz, rgb, poff, 77, transform=transform)
     assert np.array_equal(col.cpu().numpy(), rcol)  # same indices
-    assert np.abs(pos.cpu().numpy() - rpos).max() < 2e-6
     p = pos.cpu().numpy()
-    assert np.abs(p.mean(axis=1)).max() < 1e-5 and np.all(np.abs(p).max(axis=(1, 2)) <= 1.0) and np.all(np.abs(p).max(axis=(1, 2)) > 0.9999)
-    pos2, _ = eng.sample_object_points(torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda(), torch.from_numpy(poff).cuda(), seed=78)
+    if transform == "fixed":
+        assert np.array_equal(p, rpos)  # raw points, bit for bit
+        for o in range(5):
+            raw = xyz[poff[o]:poff[o + 1]]
+            assert all((raw == q).all(axis=1).any() for q in p[o, :16])
+    else:
+        assert np.abs(p - rpos).max() < 4e-6
+        assert np.abs(p.mean(axis=1)).max() < 1e-5 and np.all(np.abs(p).max(axis=(1, 2)) <= 1.0) and np.all(np.abs(p).max(axis=(1, 2)) > 0.9999)
+    if transform == "rotate_normalize":
+        pn, _ = eng.sample_object_points(*args, seed=77, transform="normalize")
+        assert not torch.equal(pos, pn)
+        # a rotation about z: z differs from the un-rotated batch by the normalisation scale only
+        zr, zn = p[..., 2], pn.cpu().numpy()[..., 2]
+        ratio = (zr / np.where(np.abs(zn) > 1e-3, zn, np.nan))
+        assert np.nanstd(ratio, axis=1).max() < 1e-3
+    pos2, _ = eng.sample_object_points(*args, seed=78, transform=transform)
     assert not torch.equal(pos, pos2)
     f2 = eng.pointnet_features(pos, col, np.array([0, 2, 5]))
     ref = OP.pointnet_features(rpos, rcol, np.array([0, 2, 5]), eng._sd)
     assert np.abs(f2.cpu().numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    with pytest.raises(Exception, match="transform"):
+        eng.sample_object_points(*args, seed=1, transform="bogus")
+
+
+def test_raw_cell_frame_coordinates_through_the_backbone(eng):
+    """`--no_pc_augment`: the backbone eats cell-normalised coordinates as they are (objects a few percent of the cell wide,
+    anywhere in [0,1]^3), so most ball queries hold MORE than 32 in-radius points (first 32 in index order) and the
+    relative positions are small against the absolute ones. Also a cell-sized object (a building facade) in the same batch."""
+    cells = synth.make_cells(3, seed=21, min_obj=2, max_obj=5)
+    total = int(cells["offsets"][-1])
+    rs = np.random.default_rng(21)
+    centre = rs.uniform(0.05, 0.95, size=(total, 1, 3))
+    extent = rs.uniform(0.01, 0.12, size=(total, 1, 3))
+    pos = (centre + rs.standard_normal((total, 256, 3)) * extent).astype(np.float32)
+    pos[0] = rs.uniform(0, 1, size=(256, 3)).astype(np.float32) * np.array([1, 0.05, 0.6], np.float32)  # facade across the cell
+    rgb = np.clip(rs.uniform(0, 1, size=(total, 1, 3)) + 0.1 * rs.standard_normal((total, 256, 3)), 0, 1).astype(np.float32)
+    d = np.linalg.norm(pos[1][:, None] - pos[1][None], axis=-1)
+    assert (d < 0.2).sum(axis=1).max() > 32  # the saturating regime really occurs
+    got = run(eng, cells, pos, rgb)
+    ref = OP.pointnet_features(pos, rgb, cells["offsets"], eng._sd)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
 
 
 def test_plain_f16_option_of_the_backbone(eng):

@@ -105,3 +105,106 @@ def test_unpickler_is_an_allow_list(tmp_path):
     f.write_bytes(pickle.dumps({"a": np.arange(6.0).reshape(2, 3), "b": np.float64(2.5), "c": [1, (2, 3)], "d": {4}}))
     ok = K.load_pickle(str(f))
     assert np.array_equal(ok["a"], np.arange(6.0).reshape(2, 3)) and ok["b"] == 2.5 and ok["c"] == [1, (2, 3)]
+
+
+def _item_arrays(it):
+    pose, cell = it["poses"], it["cells"]
+    return (np.asarray(pose.pose, dtype=np.float64), np.concatenate([o.xyz for o in cell.objects]).astype(np.float64),
+            np.array([d.closest_point for d in pose.descriptions], dtype=np.float64))
+
+
+def test_training_augmentations_equal_the_reference_draw_for_draw(golden):
+    """shuffle_hints / flip_poses (cells.py:80-91, utils.py:15-88): with aug_rng = RandomState(s) every fetched item equals
+    what the reference's own Kitti360CoarseDatasetMulti(shuffle_hints=True, flip_poses=True) returned under
+    np.random.seed(s) — texts, mirrored pose-in-cell, mirrored object points, mirrored closest points."""
+    from text2loc_amd import kitti360pose as K
+
+    g = golden("k360_augment")
+    scenes = [str(s) for s in g["scenes"]]
+    for s in g["seeds"].tolist():
+        ds = K.Kitti360PoseDataset(BASE, scenes, shuffle_hints=True, flip_poses=True, aug_rng=np.random.RandomState(s))
+        lo_x = lo_c = 0
+        flipped = 0
+        for i in range(len(ds)):
+            it = ds[i]
+            p, x, c = _item_arrays(it)
+            assert it["texts"] == str(g[f"seed{s}_texts"][i])
+            assert np.array_equal(p, g[f"seed{s}_pose"][i])
+            n = int(g[f"seed{s}_xyz_counts"][i])
+            assert np.array_equal(x, g[f"seed{s}_xyz"][lo_x:lo_x + n])
+            assert np.array_equal(c, g[f"seed{s}_closest"][lo_c:lo_c + len(c)])
+            lo_x, lo_c = lo_x + n, lo_c + len(c)
+            flipped += int(not np.array_equal(p, np.asarray(ds.all_poses[i].pose, dtype=np.float64)))
+        assert flipped > 0  # the fixture really exercises the flips
+        # the stored records were copied, not modified (a second epoch starts from the same data)
+        plain = K.Kitti360PoseDataset(BASE, scenes)
+        for a, b in zip(ds.all_cells, plain.all_cells):
+            assert all(np.array_equal(oa.xyz, ob.xyz) for oa, ob in zip(a.objects, b.objects))
+
+
+def test_flip_pose_in_cell_both_directions(golden):
+    from text2loc_amd import kitti360pose as K
+
+    g = golden("k360_augment")
+    ds = K.Kitti360PoseDataset(BASE, [str(s) for s in g["scenes"]])
+    it = ds[1]
+    for name, dirs in (("h", [1]), ("v", [-1]), ("hv", [1, -1])):
+        pose, cell, text = it["poses"], it["cells"], it["texts"]
+        for d in dirs:
+            pose, cell, text = K.flip_pose_in_cell(pose, cell, text, d)
+        p, x, c = _item_arrays({"poses": pose, "cells": cell})
+        assert text == str(g[f"flip_{name}_text"])
+        assert np.array_equal(p, g[f"flip_{name}_pose"]) and np.array_equal(x, g[f"flip_{name}_xyz"])
+        assert np.array_equal(c, g[f"flip_{name}_closest"])
+    with pytest.raises(ValueError):
+        K.flip_pose_in_cell(it["poses"], it["cells"], it["texts"], 0)
+
+
+def test_flipped_cells_are_repacked_from_the_mirrored_points():
+    """The packer caches per-object reductions on the object; a mirrored copy must not inherit the un-mirrored centre."""
+    from text2loc_amd import kitti360pose as K
+    from text2loc_amd import packing
+
+    ds = K.Kitti360PoseDataset(BASE, ["2013_05_28_drive_0010_sync"])
+    it = ds[0]
+    kc = packing.class_table(ds.get_known_classes())
+    before = packing.pack_cells([it["objects"]], kc)
+    pose, cell, _ = K.flip_pose_in_cell(it["poses"], it["cells"], it["texts"], 1)
+    after = packing.pack_cells([cell.objects], kc)
+    assert np.allclose(after["center"][:, 0], 1 - before["center"][:, 0], atol=1e-6)
+    assert np.allclose(after["center"][:, 1:], before["center"][:, 1:], atol=1e-7)
+
+
+def test_point_transform_follows_no_pc_augment():
+    """--no_pc_augment (every published command) = FixedPoints only: raw cell-frame coordinates; without it NormalizeScale
+    (+ RandomRotate in training) — evaluation/pipeline.py:215-223, training/coarse.py:182-193."""
+    import argparse
+
+    from text2loc_amd import kitti360pose as K
+    from text2loc_amd import packing
+
+    A = argparse.Namespace
+    assert packing.point_transform_from_args(A(no_pc_augment=True)) == "fixed"
+    assert packing.point_transform_from_args(A(no_pc_augment=True), train=True) == "fixed"
+    assert packing.point_transform_from_args(A(no_pc_augment=False)) == "normalize"
+    assert packing.point_transform_from_args(A(no_pc_augment=False), train=True) == "rotate_normalize"
+    assert packing.point_transform_from_args(A(no_pc_augment=False, no_pc_augment_fine=True), fine=True) == "fixed"
+    ds = K.Kitti360PoseDataset(BASE, ["2013_05_28_drive_0010_sync"], object_points="sample", seed=1)  # default = published
+    it = ds[0]
+    pos = it["object_points"]["pos"].reshape(-1, 256, 3)
+    for o, p in zip(it["objects"], pos):  # every sampled point IS one of the object's raw points
+        raw = np.asarray(o.xyz, dtype=np.float32)
+        assert all((raw == q).all(axis=1).any() for q in p[:8])
+    dn = K.Kitti360PoseDataset(BASE, ["2013_05_28_drive_0010_sync"], object_points="sample", seed=1, transform="normalize")
+    pn = dn[0]["object_points"]["pos"].reshape(-1, 256, 3)
+    assert np.abs(pn.mean(axis=1)).max() < 1e-5 and np.all(np.abs(pn).max(axis=(1, 2)) > 0.9999)
+    dr = K.Kitti360PoseDataset(BASE, ["2013_05_28_drive_0010_sync"], object_points="sample", seed=1, transform="rotate_normalize")
+    a, b = dr[0]["object_points"]["pos"], dr[0]["object_points"]["pos"]
+    assert not np.array_equal(a, b)  # a fresh rotation per fetch
+    assert dr.get_cell_dataset()._transform == "normalize"  # the cell-only (validation) side never rotates
+    # rotation about z keeps z and the xy radius of the un-normalised points
+    objs = [it["objects"][:1]]
+    r0 = packing.sample_object_points(objs, 256, np.random.default_rng(5), transform="fixed")[0]["pos"]
+    rng = np.random.default_rng(5)
+    sel = rng.integers(0, len(objs[0][0].xyz), size=256)
+    assert np.array_equal(r0, np.asarray(objs[0][0].xyz, dtype=np.float32)[sel])

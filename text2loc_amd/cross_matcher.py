@@ -196,8 +196,17 @@ def run_fine(model: CrossMatch, retrievals, dataloader, args, transform_fine=Non
     every pose that retrieved it; here every distinct retrieved cell is padded and encoded ONCE, every pose's hints are
     encoded once, and all poses x max(top_k) pairs are matched in one launch.
     ``object_points_fn(list_of_padded_object_lists) -> object_points`` supplies the PointNet++ inputs in the published
-    feature mode (e.g. ``packing.sample_object_points``); ``transform_fine`` is accepted for signature compatibility."""
+    feature mode. Without one they are sampled here (``packing.sample_object_points``) under ``transform_fine`` — a transform
+    name ("fixed" / "normalize"), or, as in the reference's script, chosen from ``args.no_pc_augment_fine``
+    (evaluation/pipeline.py:220-223: FixedPoints only under the flag, which the published commands pass)."""
     model.eval()
+    a = model.args
+    if object_points_fn is None and "class" in a.use_features and not bool(getattr(a, "class_embed", False)):
+        name = transform_fine if isinstance(transform_fine, str) else packing.point_transform_from_args(args, fine=True)
+        pts_rng = np.random.default_rng(int(getattr(args, "seed", 0) or 0))
+
+        def object_points_fn(chunk):
+            return packing.sample_object_points(chunk, 256, pts_rng, transform=name)
     ds = dataloader.dataset
     poses, cells = ds.all_poses, ds.all_cells
     K = max(args.top_k)

@@ -127,10 +127,10 @@ int t2l_load_weights(t2l_ctx* ctx, const t2l_weight_desc* w, int32_t n, const t2
 }
 
 int t2l_sample_object_points(t2l_ctx* ctx, const float* xyz, const float* rgb, const int64_t* point_offsets, int32_t n_objects,
-                             uint32_t seed, float* out_pos, float* out_rgb, void* stream) {
+                             uint32_t seed, int32_t transform_flags, float rotate_deg, float* out_pos, float* out_rgb, void* stream) {
   if (!ctx) return T2L_EINVAL;
   T2L_HIP(ctx, hipSetDevice(ctx->device));
-  return sample_points_impl(ctx, xyz, rgb, point_offsets, n_objects, seed, out_pos, out_rgb, (hipStream_t)stream);
+  return sample_points_impl(ctx, xyz, rgb, point_offsets, n_objects, seed, transform_flags, rotate_deg, out_pos, out_rgb, (hipStream_t)stream);
 }
 
 int t2l_pointnet_features(t2l_ctx* ctx, const float* pos, const float* rgb, const int32_t* cell_offsets, int32_t n_cells,

@@ -631,28 +631,50 @@ __global__ __launch_bounds__(256, 2) void pn_ga_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The point batches PointNet++ eats, built on the GPU from the raw object points: FixedPoints(256) — 256 indices drawn
-// with replacement — then NormalizeScale (centre on the mean of the sampled points, scale by 0.999999 / max |coordinate|):
-// torch_geometric.transforms as the reference composes them (evaluation/pipeline.py:215-223) and applies them per object
-// on the host (dataloading/kitti360pose/utils.py:138-143). The reference draws from numpy's global RNG; here index j of
-// object o is floor(u * n) with u = the top 24 bits of lowbias32(j * 0x9E3779B1 + (seed ^ o * 0x85EBCA77)) / 2^24.
-// One workgroup per object, one thread per sampled point.
+// The point batches PointNet++ eats, built on the GPU from the raw object points, for the three transforms the reference
+// composes (torch_geometric.transforms, applied per object on the host: dataloading/kitti360pose/utils.py:138-143):
+//   flags 0                      FixedPoints(256) only — `--no_pc_augment`, what EVERY published command passes
+//                                (README.md:89,107,125-126,139-140; evaluation/pipeline.py:215-216, training/coarse.py:182-184):
+//                                the backbone sees the cell-normalised coordinates as they are, radii 0.2/0.3/0.4 absolute;
+//   T2L_SAMPLE_NORMALIZE         + NormalizeScale (centre on the mean of the sampled points, scale by 0.999999 / max |coordinate|)
+//                                — evaluation without the flag (evaluation/pipeline.py:217-218, training/coarse.py:193);
+//   T2L_SAMPLE_ROTATE|NORMALIZE  + RandomRotate(rotate_deg, axis=2) in between — training without the flag
+//                                (training/coarse.py:185-192): one angle per object, uniform in [-deg, +deg].
+// FixedPoints = 256 indices drawn with replacement. The reference draws from numpy's / python's global RNGs; here index j of
+// object o is floor(u * n) with u = the top 24 bits of lowbias32(j * 0x9E3779B1 + (seed ^ o * 0x85EBCA77)) / 2^24 and the
+// angle comes from lowbias32(0xA5A5A5A5 + (seed ^ o * 0x85EBCA77)) the same way. One workgroup per object, one thread per point.
 // ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+
 __global__ __launch_bounds__(256) void sample_points_kernel(const float* __restrict__ xyz, const float* __restrict__ rgb,
-                                                            const int64_t* __restrict__ offsets, uint32_t seed,
-                                                            float* __restrict__ out_pos, float* __restrict__ out_rgb) {
+                                                            const int64_t* __restrict__ offsets, uint32_t seed, int flags,
+                                                            float rotate_rad, float* __restrict__ out_pos, float* __restrict__ out_rgb) {
   __shared__ float red[4][4];
   const int o = blockIdx.x, j = threadIdx.x, lane = j & 63, w = j >> 6;
   const int64_t p0 = offsets[o];
   const uint32_t n = (uint32_t)(offsets[o + 1] - p0);
-  uint32_t x = (uint32_t)j * 0x9E3779B1u + (seed ^ ((uint32_t)o * 0x85EBCA77u));
-  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  const uint32_t okey = seed ^ ((uint32_t)o * 0x85EBCA77u);
+  const uint32_t x = lowbias32((uint32_t)j * 0x9E3779B1u + okey);
   const uint32_t idx = (uint32_t)(((uint64_t)(x >> 8) * n) >> 24);
   const float* src = xyz + (size_t)(p0 + idx) * 3;
   float px = src[0], py = src[1], pz = src[2];
   const float* col = rgb + (size_t)(p0 + idx) * 3;
   const size_t ob = ((size_t)o * 256 + j) * 3;
   out_rgb[ob] = col[0]; out_rgb[ob + 1] = col[1]; out_rgb[ob + 2] = col[2];
+  if (flags & T2L_SAMPLE_ROTATE) {  // pos @ [[c, s, 0], [-s, c, 0], [0, 0, 1]]
+    const float u = (float)(lowbias32(0xA5A5A5A5u + okey) >> 8) * (1.f / 16777216.f);
+    const float ang = rotate_rad * (2.f * u - 1.f);
+    const float c = cosf(ang), sn = sinf(ang);
+    const float rx = px * c - py * sn, ry = px * sn + py * c;
+    px = rx; py = ry;
+  }
+  if (!(flags & T2L_SAMPLE_NORMALIZE)) {  // uniform branch
+    out_pos[ob] = px; out_pos[ob + 1] = py; out_pos[ob + 2] = pz;
+    return;
+  }
   float sx = px, sy = py, sz = pz;
 #pragma unroll
   for (int off = 32; off; off >>= 1) { sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); sz += __shfl_xor(sz, off); }
@@ -673,10 +695,12 @@ __global__ __launch_bounds__(256) void sample_points_kernel(const float* __restr
 }
 
 int sample_points_impl(t2l_ctx* ctx, const float* xyz, const float* rgb, const int64_t* point_offsets_dev, int n_objects, uint32_t seed,
-                       float* out_pos, float* out_rgb, hipStream_t s) {
+                       int flags, float rotate_deg, float* out_pos, float* out_rgb, hipStream_t s) {
   if (!xyz || !rgb || !point_offsets_dev || !out_pos || !out_rgb) return fail(ctx, T2L_EINVAL, "t2l_sample_object_points: null argument");
   if (n_objects <= 0) return n_objects == 0 ? T2L_OK : fail(ctx, T2L_EINVAL, "t2l_sample_object_points: n_objects < 0");
-  hipLaunchKernelGGL(sample_points_kernel, dim3(n_objects), dim3(256), 0, s, xyz, rgb, point_offsets_dev, seed, out_pos, out_rgb);
+  if (flags & ~(T2L_SAMPLE_NORMALIZE | T2L_SAMPLE_ROTATE)) return fail(ctx, T2L_EINVAL, "t2l_sample_object_points: unknown transform flag");
+  hipLaunchKernelGGL(sample_points_kernel, dim3(n_objects), dim3(256), 0, s, xyz, rgb, point_offsets_dev, seed, flags,
+                     rotate_deg * 0.017453292519943295f, out_pos, out_rgb);
   T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;
 }

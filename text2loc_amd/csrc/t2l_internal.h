@@ -171,6 +171,7 @@ int pointnet_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n);
 int pointnet_features_impl(t2l_ctx* ctx, const float* pos, const float* rgb, const int32_t* cell_offsets, int n_cells, float* out,
                            hipStream_t s);
 int sample_points_impl(t2l_ctx* ctx, const float* xyz, const float* rgb, const int64_t* point_offsets_dev, int n_objects, uint32_t seed,
+                       int flags, float rotate_deg,
                        float* out_pos, float* out_rgb, hipStream_t s);
 void free_pointnet(t2l_ctx* ctx);
 // fine.hip

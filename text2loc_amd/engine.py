@@ -50,8 +50,8 @@ EXPORTS = {
     "t2l_last_error": (C.c_char_p, [C.c_void_p]),
     "t2l_load_weights": (C.c_int, [C.c_void_p, C.POINTER(_WeightDesc), C.c_int32, C.POINTER(_ModelConfig)]),
     "t2l_encode_cells": (C.c_int, [C.c_void_p, C.POINTER(_PackedCells), C.c_void_p, C.c_void_p]),
-    "t2l_sample_object_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p,
-                                           C.c_void_p, C.c_void_p]),
+    "t2l_sample_object_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_int32, C.c_float,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_pointnet_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "t2l_reduce_objects": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -195,15 +195,23 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ PointNet++ backbone (a3)
-    def sample_object_points(self, xyz: torch.Tensor, rgb: torch.Tensor, point_offsets: torch.Tensor, seed: int = 0):
-        """FixedPoints(256) + NormalizeScale on the GPU: xyz, rgb f32[n_points,3], point_offsets i64[n_objects+1] (all on the
-        GPU) -> (pos f32[n_objects,256,3], rgb f32[n_objects,256,3])."""
+    def sample_object_points(self, xyz: torch.Tensor, rgb: torch.Tensor, point_offsets: torch.Tensor, seed: int = 0,
+                             transform: str = "fixed", rotate_deg: float = 120.0):
+        """The dataloader's point batches on the GPU: xyz, rgb f32[n_points,3], point_offsets i64[n_objects+1] (all on the GPU)
+        -> (pos f32[n_objects,256,3], rgb f32[n_objects,256,3]). ``transform`` (packing.POINT_TRANSFORMS): "fixed" =
+        FixedPoints(256) only (`--no_pc_augment`, the published commands), "normalize" = + NormalizeScale, "rotate_normalize" =
+        + RandomRotate(rotate_deg, axis=2) before it (training without the flag)."""
+        from .packing import POINT_TRANSFORMS
+
+        if transform not in POINT_TRANSFORMS:
+            raise T2LError(f"sample_object_points: transform must be one of {sorted(POINT_TRANSFORMS)}, got {transform!r}")
         n = int(point_offsets.numel()) - 1
         pos = torch.empty((max(n, 0), 256, 3), dtype=torch.float32, device=xyz.device)
         col = torch.empty_like(pos)
         self._check(self.lib.t2l_sample_object_points(self._h, _dev_ptr(xyz, torch.float32, "xyz"), _dev_ptr(rgb, torch.float32, "rgb"),
                                                       _dev_ptr(point_offsets, torch.int64, "point_offsets"), n, int(seed) & 0xFFFFFFFF,
-                                                      pos.data_ptr(), col.data_ptr(), _stream_ptr()))
+                                                      POINT_TRANSFORMS[transform], float(rotate_deg), pos.data_ptr(), col.data_ptr(),
+                                                      _stream_ptr()))
         return pos, col
 
     def pointnet_features(self, pos: torch.Tensor, rgb: torch.Tensor, cell_offsets) -> torch.Tensor:

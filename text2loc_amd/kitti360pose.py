@@ -9,16 +9,18 @@ the rest of this package duck-types against (``.label/.xyz/.rgb``, ``.id/.object
 ``.pose_w/.cell_id/.descriptions[*].direction/.object_color_text/.object_label``).
 
 On top of that, the dataset surface ``evaluation.pipeline`` / ``training.coarse.eval_epoch`` consume
-(dataloading/kitti360pose/cells.py:36-205), eval-time only (no flipping / hint shuffling augmentation):
+(dataloading/kitti360pose/cells.py:36-205), with the training-time augmentations (``shuffle_hints``, ``flip_poses``):
 
-    ds = Kitti360PoseDataset(base_path, scene_names)           # ~ Kitti360CoarseDatasetMulti
+    ds = Kitti360PoseDataset(base_path, scene_names)           # ~ Kitti360CoarseDatasetMulti(..., transform, shuffle_hints, flip_poses)
     ds.all_cells, ds.all_poses, ds.get_cell_dataset(), ds[i] -> {"poses","cells","objects","object_points","texts","cell_ids",...}
     dl = DataLoader(ds, batch_size=..., collate_fn=Kitti360PoseDataset.collate_fn)
     db = CellDatabase.build(model, ds.get_cell_dataset())
 
-``object_points``: the reference hands PointNet++ a PyG batch of FixedPoints(256)+NormalizeScale samples per cell
-(dataloading/kitti360pose/utils.py:91-147). Here ``object_points="sample"`` builds the same batches with
-``packing.sample_object_points`` (host, seeded), ``None`` skips them (class_embed mode does not read them).
+``object_points``: the reference hands PointNet++ a PyG batch of per-object FixedPoints(256) samples per cell — and nothing
+else under ``--no_pc_augment``, which every published command passes; NormalizeScale (and RandomRotate in training) only
+without the flag (dataloading/kitti360pose/utils.py:91-147, evaluation/pipeline.py:215-223, training/coarse.py:182-193).
+``object_points="sample"`` builds those batches with ``packing.sample_object_points`` (host, seeded) under ``transform``
+("fixed" by default = the published configuration); ``None`` skips them (class_embed mode does not read them).
 """
 from __future__ import annotations
 
@@ -141,13 +143,41 @@ def hint_sentences(pose) -> List[str]:
     return [f"The pose is {d.direction} of a {d.object_color_text} {d.object_label}." for d in pose.descriptions]
 
 
-class CellOnlyDataset:
-    """cells.py:187-205 ``Kitti360CoarseCellOnlyDataset``: one item per database cell, in ``all_cells`` order."""
+def _swap_words(text: str, a: str, b: str) -> str:
+    return text.replace(a, a + "-flipped").replace(b, a).replace(a + "-flipped", b)
 
-    def __init__(self, cells: Sequence[CellRecord], object_points: Optional[str] = None, seed: int = 0):
+
+def flip_pose_in_cell(pose, cell, text: str, direction: int):
+    """dataloading/kitti360pose/utils.py:15-88 (the three-value form the coarse dataset uses): mirror the cell about x = 0.5
+    (``direction`` +1, "horizontally": east <-> west in the text) or y = 0.5 (-1, "vertically": north <-> south). Pose and
+    cell are copied first; object points, the pose-in-cell and every description's ``closest_point`` are mirrored, the
+    descriptions' ``direction`` fields are NOT (as in the reference: only the text changes)."""
+    import copy
+
+    if direction not in (-1, 1):
+        raise ValueError("direction must be +1 (horizontal) or -1 (vertical)")
+    pose, cell = copy.deepcopy(pose), copy.deepcopy(cell)
+    ax = 0 if direction == 1 else 1
+    pose.pose[ax] = 1.0 - pose.pose[ax]
+    for obj in cell.objects:
+        obj.xyz[:, ax] = 1 - obj.xyz[:, ax]
+        if hasattr(obj, "_t2l_feat"):
+            del obj._t2l_feat  # cached reductions of the un-mirrored points
+    for d in pose.descriptions:
+        d.closest_point[ax] = 1.0 - d.closest_point[ax]
+    text = _swap_words(text, "east", "west") if direction == 1 else _swap_words(text, "north", "south")
+    return pose, cell, text
+
+
+class CellOnlyDataset:
+    """cells.py:187-205 ``Kitti360CoarseCellOnlyDataset``: one item per database cell, in ``all_cells`` order (never flipped
+    or shuffled, as in the reference)."""
+
+    def __init__(self, cells: Sequence[CellRecord], object_points: Optional[str] = None, seed: int = 0, transform: str = "fixed"):
         self.cells = list(cells)
         self._points = object_points
         self._seed = seed
+        self._transform = "normalize" if transform == "rotate_normalize" else transform  # val transform: no rotation
 
     def __len__(self):
         return len(self.cells)
@@ -156,7 +186,7 @@ class CellOnlyDataset:
         if self._points is None:
             return None
         rng = np.random.default_rng([self._seed, idx])
-        return packing.sample_object_points([cell.objects], 256, rng)[0]
+        return packing.sample_object_points([cell.objects], 256, rng, transform=self._transform)[0]
 
     def __getitem__(self, idx):
         cell = self.cells[idx]
@@ -164,13 +194,29 @@ class CellOnlyDataset:
 
 
 class Kitti360PoseDataset:
-    """One item per pose over several scenes (cells.py:36-185), evaluation settings."""
+    """One item per pose over several scenes (cells.py:36-185 ``Kitti360CoarseDataset`` / ``...Multi``).
 
-    def __init__(self, base_path: str, scene_names: Sequence[str], object_points: Optional[str] = None, seed: int = 0):
+    ``transform``: the point transform of ``object_points="sample"`` — "fixed" (FixedPoints(256) only: `--no_pc_augment`,
+    what every published command passes and therefore the default), "normalize", "rotate_normalize"
+    (``packing.point_transform_from_args(args, train=...)`` picks it the way the reference's scripts do).
+    ``shuffle_hints`` / ``flip_poses``: the training-time augmentations of cells.py:80-91 (training/coarse.py:196-202 turns
+    both on): the hint sentences are permuted, and with probability 1/2 each the cell is mirrored horizontally and
+    vertically (``flip_pose_in_cell``). Their draws come from ``aug_rng`` — a ``numpy.random.RandomState`` consumed with the
+    reference's own call sequence (one ``choice`` without replacement over the hints, then two ``choice((True, False))``), so
+    ``RandomState(s)`` here reproduces the reference under ``np.random.seed(s)`` item for item; ``None`` = numpy's global
+    stream, i.e. exactly what the reference draws from."""
+
+    def __init__(self, base_path: str, scene_names: Sequence[str], object_points: Optional[str] = None, seed: int = 0,
+                 transform: str = "fixed", shuffle_hints: bool = False, flip_poses: bool = False, aug_rng=None):
         if object_points not in (None, "sample"):
             raise ValueError("object_points must be None or 'sample'")
+        if transform not in packing.POINT_TRANSFORMS:
+            raise ValueError(f"transform must be one of {sorted(packing.POINT_TRANSFORMS)}")
         self.scene_names = list(scene_names)
-        self._points, self._seed = object_points, seed
+        self._points, self._seed, self._transform = object_points, seed, transform
+        self.shuffle_hints, self.flip_poses = bool(shuffle_hints), bool(flip_poses)
+        self._aug = aug_rng if aug_rng is not None else np.random
+        self._epoch_draw = 0
         self.all_cells: List[CellRecord] = []
         self.all_poses: List[PoseRecord] = []
         self._pose_scene: List[str] = []
@@ -193,18 +239,30 @@ class Kitti360PoseDataset:
         pose = self.all_poses[idx]
         cell = self.cells_dict[pose.cell_id]
         hints = self.hint_descriptions[idx]
+        if self.shuffle_hints:  # cells.py:80-81
+            hints = self._aug.choice(hints, size=len(hints), replace=False)
+        text = " ".join(hints)
+        if self.flip_poses:     # cells.py:86-90
+            if self._aug.choice((True, False)):
+                pose, cell, text = flip_pose_in_cell(pose, cell, text, 1)
+            if self._aug.choice((True, False)):
+                pose, cell, text = flip_pose_in_cell(pose, cell, text, -1)
         pts = None
         if self._points is not None:
-            rng = np.random.default_rng([self._seed, self._cell_row[cell.id]])
-            pts = packing.sample_object_points([cell.objects], 256, rng)[0]
-        return {"poses": pose, "cells": cell, "objects": cell.objects, "object_points": pts, "texts": " ".join(hints),
+            if self._transform == "rotate_normalize":  # a fresh rotation / draw every time an item is fetched
+                self._epoch_draw += 1
+                rng = np.random.default_rng([self._seed, self._cell_row[cell.id], self._epoch_draw])
+            else:
+                rng = np.random.default_rng([self._seed, self._cell_row[cell.id]])
+            pts = packing.sample_object_points([cell.objects], 256, rng, transform=self._transform)[0]
+        return {"poses": pose, "cells": cell, "objects": cell.objects, "object_points": pts, "texts": text,
                 "cell_ids": pose.cell_id, "scene_names": self._pose_scene[idx], "debug_hint_descriptions": hints}
 
     def get_known_classes(self):
         return list(packing.KNOWN_CLASS)
 
     def get_cell_dataset(self) -> CellOnlyDataset:
-        return CellOnlyDataset(self.all_cells, self._points, self._seed)
+        return CellOnlyDataset(self.all_cells, self._points, self._seed, self._transform)
 
     @staticmethod
     def collate_fn(data):

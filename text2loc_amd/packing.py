@@ -110,11 +110,31 @@ def pack_cells_gpu(engine, objects: List[List[object]], known_classes: Dict[str,
     return red
 
 
-def sample_object_points(objects: List[List[object]], num: int = 256, rng: Optional[np.random.Generator] = None):
-    """Per cell, the point batch the reference's dataloader hands PointNet++ (dataloading/kitti360pose/utils.py:91-147 with
-    the eval transform of evaluation/pipeline.py:215-223): ``FixedPoints(num)`` — ``num`` indices drawn with replacement —
-    then ``NormalizeScale`` (centre on the mean, scale by 0.999999 / max|coordinate|). Returns a list of dicts
+# transform name -> t2l_sample_object_points flags (include/t2l.h: T2L_SAMPLE_NORMALIZE = 1, T2L_SAMPLE_ROTATE = 2)
+POINT_TRANSFORMS = {"fixed": 0, "normalize": 1, "rotate_normalize": 3}
+
+
+def point_transform_from_args(args, train: bool = False, fine: bool = False) -> str:
+    """The transform the reference's scripts build from their arguments: ``--no_pc_augment`` (``--no_pc_augment_fine`` for the
+    fine dataset) -> FixedPoints only — every published command passes it (README.md:89,107,125-126,139-140); without it
+    FixedPoints + NormalizeScale for evaluation / validation and + RandomRotate(120, axis=2) for training
+    (evaluation/pipeline.py:215-223, training/coarse.py:182-193)."""
+    flag = bool(getattr(args, "no_pc_augment_fine" if fine else "no_pc_augment", False))
+    if flag:
+        return "fixed"
+    return "rotate_normalize" if train else "normalize"
+
+
+def sample_object_points(objects: List[List[object]], num: int = 256, rng: Optional[np.random.Generator] = None,
+                         transform: str = "fixed", rotate_deg: float = 120.0):
+    """Per cell, the point batch the reference's dataloader hands PointNet++ (dataloading/kitti360pose/utils.py:91-147):
+    ``FixedPoints(num)`` — ``num`` indices drawn with replacement — and, by ``transform`` (see ``point_transform_from_args``):
+    "fixed" nothing else (`--no_pc_augment`, the published configuration: positions stay in the cell-normalised frame),
+    "normalize" ``NormalizeScale`` (centre on the mean, scale by 0.999999 / max|coordinate|), "rotate_normalize"
+    ``RandomRotate(rotate_deg, axis=2)`` then ``NormalizeScale``. Returns a list of dicts
     ``{"pos": f32[n_i*num,3], "x": f32[n_i*num,3]}`` (object-major), the duck type ``encode_objects`` accepts."""
+    if transform not in POINT_TRANSFORMS:
+        raise ValueError(f"transform must be one of {sorted(POINT_TRANSFORMS)}, got {transform!r}")
     rng = rng or np.random.default_rng()
     out = []
     for objs in objects:
@@ -122,17 +142,24 @@ def sample_object_points(objects: List[List[object]], num: int = 256, rng: Optio
         for o in objs:
             xyz, rgb = np.asarray(o.xyz, dtype=np.float32), np.asarray(o.rgb, dtype=np.float32)
             sel = rng.integers(0, len(xyz), size=num)
-            p = xyz[sel] - xyz[sel].mean(axis=0, keepdims=True)
-            p = p * (np.float32(0.999999) / max(float(np.abs(p).max()), 1e-12))
+            p = xyz[sel]
+            if transform == "rotate_normalize":
+                ang = np.deg2rad(rotate_deg) * rng.uniform(-1.0, 1.0)
+                c, sn = np.float32(np.cos(ang)), np.float32(np.sin(ang))
+                p = p @ np.array([[c, sn, 0], [-sn, c, 0], [0, 0, 1]], dtype=np.float32)
+            if transform != "fixed":
+                p = p - p.mean(axis=0, keepdims=True)
+                p = p * (np.float32(0.999999) / max(float(np.abs(p).max()), 1e-12))
             pos.append(p.astype(np.float32))
             x.append(rgb[sel])
         out.append({"pos": np.concatenate(pos, axis=0), "x": np.concatenate(x, axis=0)})
     return out
 
 
-def sample_object_points_gpu(engine, objects: List[List[object]], device="cuda", seed: int = 0):
+def sample_object_points_gpu(engine, objects: List[List[object]], device="cuda", seed: int = 0, transform: str = "fixed",
+                             rotate_deg: float = 120.0):
     """``sample_object_points`` on the GPU (t2l_sample_object_points): the raw points are concatenated and copied over once,
-    FixedPoints(256) + NormalizeScale run as one kernel (counter-based draw, so equal to the host sampler in distribution,
+    FixedPoints(256) and the transform run as one kernel (counter-based draw, so equal to the host sampler in distribution,
     not in the indices). Returns the same per-cell ``{"pos", "x"}`` batches, as CUDA tensors."""
     import torch
 
@@ -143,7 +170,7 @@ def sample_object_points_gpu(engine, objects: List[List[object]], device="cuda",
     xyz = np.concatenate([np.asarray(o.xyz, dtype=np.float32) for o in flat], axis=0)
     rgb = np.concatenate([np.asarray(o.rgb, dtype=np.float32) for o in flat], axis=0)
     pos, col = engine.sample_object_points(torch.from_numpy(xyz).to(device), torch.from_numpy(rgb).to(device),
-                                           torch.from_numpy(poff).to(device), seed)
+                                           torch.from_numpy(poff).to(device), seed, transform=transform, rotate_deg=rotate_deg)
     out, lo = [], 0
     for objs in objects:
         hi = lo + len(objs)
@@ -160,4 +187,5 @@ def to_device(packed: Dict[str, np.ndarray], device) -> Dict[str, "torch.Tensor"
 
 
 __all__ = ["KNOWN_CLASS", "COLOR_NAMES", "class_table", "color_table", "object_features", "pack_cells",
-           "pack_cells_gpu", "sample_object_points", "sample_object_points_gpu", "to_device"]
+           "pack_cells_gpu", "sample_object_points", "sample_object_points_gpu", "to_device", "POINT_TRANSFORMS",
+           "point_transform_from_args"]
