@@ -30,6 +30,7 @@ extern "C" {
 #define T2L_ABI_VERSION 2
 #define T2L_EMBED_DIM 256
 #define T2L_OBJECT_SIZE 28 /* args.object_size, models/cell_retrieval.py:32 */
+#define T2L_MAX_LOSS_BATCH 1024 /* rows of the contrastive matrix (one fused launch up to 128, a short chain beyond) */
 #define T2L_MAX_TOPK 26    /* max(top_k) supported by the fused search (eval default is 10) */
 
 enum {
@@ -176,8 +177,13 @@ int t2l_search(t2l_ctx* ctx, const float* queries, int32_t n_queries, int32_t k,
  * kernel-boundary bubble separates calls (measured: 42.9 -> 40.3 us per 4,096-query call). t2l_search then only ENQUEUES;
  * the outputs of every call issued so far are ordered into `stream` by t2l_search_join (queries and output buffers must
  * stay untouched until then). Batches under 256 queries, multi-segment shards and databases in heavy mode join and run in
- * the caller's stream as before. Default n = 1: t2l_search is stream-ordered and t2l_search_join is a no-op. */
+ * the caller's stream as before. Default n = 1: t2l_search is stream-ordered and t2l_search_join is a no-op.
+ * t2l_search_ordered is t2l_search WITHOUT the lanes whatever "search_lanes" says: pending lane work is joined, then scan and
+ * re-rank run on `stream` itself — for callers that consume the result right away (sharded exchange, eval_epoch), where a fork
+ * onto a lane followed by an immediate join would cost two cross-stream hops per call for nothing. */
 int t2l_search_join(t2l_ctx* ctx, void* stream);
+int t2l_search_ordered(t2l_ctx* ctx, const float* queries, int32_t n_queries, int32_t k, int32_t* out_idx,
+                       double* out_score, void* stream);
 
 /* The ONE exchange step of the row-sharded database (new design; the reference is single-device):
  * every rank searches its shard (global ids via row_offset), the per-rank [n_queries,k] results are
@@ -207,7 +213,9 @@ int t2l_search_counters(t2l_ctx* ctx, int32_t* out8);
 /* ---- contrastive loss (a8) ------------------------------------------------------------------- */
 /* Replaces: ContrastiveLoss.forward (training/losses.py:269-283) and its autograd backward.
  * anchor/positive: dev f32[batch,256] (need not be normalised: the loss re-normalises, :271-272).
- * loss: dev f32[1]; grad_anchor/grad_positive: dev f32[batch,256] = d loss/d input, or NULL. batch <= 128. */
+ * loss: dev f32[1]; grad_anchor/grad_positive: dev f32[batch,256] = d loss/d input, or NULL. batch <= 128 is ONE launch;
+ * 128 < batch <= T2L_MAX_LOSS_BATCH (the all-gathered global batch of data-parallel training, SURVEY.md 8e: W ranks x B rows,
+ * text2loc_amd.losses.ContrastiveLoss(group=...)) runs the same arithmetic as six launches over a [batch][batch] matrix in HBM. */
 int t2l_contrastive_loss(t2l_ctx* ctx, const float* anchor, const float* positive, int32_t batch,
                          float temperature, float* loss, float* grad_anchor, float* grad_positive,
                          void* stream);
@@ -287,7 +295,10 @@ int t2l_pointnet_features_train(t2l_ctx* ctx, const float* pos, const float* rgb
 int t2l_pointnet_backward(t2l_ctx* ctx, const float* grad_features2, void* stream);
 
 /* optimizer.zero_grad() and torch.optim.Adam(lr, betas, eps).step() (no weight decay, no amsgrad — what
- * training/coarse.py:258 constructs) over every bound tensor that has a gradient buffer. */
+ * training/coarse.py:258 constructs) over every bound tensor that has a gradient buffer. torch.optim.Adam skips parameters
+ * whose .grad is None and counts steps per parameter; here the bound tensors form two groups with a step counter each — the
+ * object branch (steps on every call) and the PointNet++ backbone, which steps only when t2l_pointnet_backward ran since the
+ * last t2l_zero_grad (a batch fed precomputed features2 leaves the backbone's weights AND moments untouched). */
 int t2l_zero_grad(t2l_ctx* ctx, void* stream);
 int t2l_adam_step(t2l_ctx* ctx, float lr, float beta1, float beta2, float eps, void* stream);
 
@@ -295,7 +306,7 @@ int t2l_adam_step(t2l_ctx* ctx, float lr, float beta1, float beta2, float eps, v
  * step per parameter; here they live inside the library). numel (out, may be NULL) = total elements over the stepped
  * tensors, concatenated in the order of t2l_train_bind's parameter walk (feature branches, mlp_merge, obj_inter_module.*).
  * m == v == NULL: query numel and (set == 0) step only. Otherwise m, v: dev f32[numel]; set == 0 copies the moments out and
- * writes *step, set != 0 copies them in and takes *step. A re-bind with an unchanged parameter list (same names and sizes,
+ * writes *step, set != 0 copies them in and takes *step (*step = object-branch step | backbone step << 32). A re-bind with an unchanged parameter list (same names and sizes,
  * new pointers: model.to(), re-assigned .grad) keeps moments and step IF option "train_keep_adam_state" is 1 at the time of
  * the re-bind (default 0: every bind starts from zero moments — a different model may use the same names). */
 int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step, int64_t* numel, void* stream);

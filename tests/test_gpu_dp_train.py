@@ -1,0 +1,130 @@
+"""GPU tier, SURVEY.md 8e / f-4b: data-parallel training of the object branch. Two processes share GPU 0 (one engine context
+each, gloo rendezvous: RCCL refuses duplicate devices, the collectives are staged through the host) and run
+``ContrastiveLoss(gather=True)`` (all_gather of the [B,256] text and cell embeddings -> the GLOBAL contrastive matrix) +
+``optim.Adam(data_parallel=True)`` (ONE all_reduce over the engine-owned flat gradient buffer). The reference is single
+process (training/coarse.py:31-58), so the checker is the single-process engine itself: the same 2 x 32 cells as two
+accumulated backward passes of the global loss (BatchNorm statistics are per rank = per half in both)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from text2loc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+B_LOCAL, LR = 32, 1e-3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(world):
+    from tests.test_gpu_train_loop import TableText, _args
+    from tests.test_host_logic import make_objects
+    from text2loc_amd.cell_retrieval import CellRetrievalNetwork
+
+    n = world * B_LOCAL
+    cells = synth.make_cells(n, seed=61)
+    objects = make_objects(cells, 61)
+    model = CellRetrievalNetwork(synth.KNOWN_CLASS, synth.COLOR_NAMES, _args(), language_encoder=TableText(n, 9))
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_object_branch_weights(8).items()}, strict=False)
+    for layer in model.obj_inter_module:  # dropout off: the two runs draw different mask seeds
+        layer.dropout.p = layer.dropout1.p = layer.dropout2.p = 0.0
+        layer.self_attn.dropout = 0.0
+    return model.to("cuda").train(), objects
+
+
+def _params(model):
+    return {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters()
+            if n.startswith(("obj_inter_module.", "object_encoder.mlp_merge", "object_encoder.pos_encoder", "language_encoder."))}
+
+
+def _worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from text2loc_amd.losses import ContrastiveLoss
+    from text2loc_amd.optim import Adam
+
+    model, objects = _build(world)
+    opt = Adam(model, lr=LR, data_parallel=True)
+    crit = ContrastiveLoss(0.1, gather=True)
+    lo = rank * B_LOCAL
+    ids = list(range(lo, lo + B_LOCAL))
+    opt.zero_grad()
+    loss = crit(model.encode_text(ids), model.encode_objects(objects[lo:lo + B_LOCAL]))
+    loss.backward()
+    local = model.train_flat_grad().detach().cpu().numpy().copy()
+    opt.all_reduce_grads()
+    summed = model.train_flat_grad().detach().cpu().numpy().copy()
+    table_grad = model.language_encoder.table.grad.detach().cpu().numpy().copy()
+    opt._dp = False  # the gradients are reduced already
+    opt.step()
+    torch.cuda.synchronize()
+    out_q.put((rank, float(loss.detach()), local, summed, table_grad, _params(model)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_the_accumulated_single_process_step():
+    world = 2
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out_q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+
+    # the checker: one process, the global loss differentiated half by half into the same gradient buffers
+    from text2loc_amd.losses import ContrastiveLoss
+    from text2loc_amd.optim import Adam
+
+    model, objects = _build(world)
+    opt = Adam(model, lr=LR)
+    crit = ContrastiveLoss(0.1)
+    A, Bh = list(range(0, B_LOCAL)), list(range(B_LOCAL, 2 * B_LOCAL))
+    opt.zero_grad()
+    pA_det = model.encode_objects(objects[:B_LOCAL]).detach().clone()
+    pB = model.encode_objects(objects[B_LOCAL:])
+    tA, tB = model.encode_text(A), model.encode_text(Bh)
+    loss1 = crit(torch.cat([tA.detach(), tB]), torch.cat([pA_det, pB]))
+    loss1.backward()
+    pB_det = pB.detach().clone()
+    pA = model.encode_objects(objects[:B_LOCAL])
+    loss2 = crit(torch.cat([model.encode_text(A), model.encode_text(Bh).detach()]), torch.cat([pA, pB_det]))
+    loss2.backward()
+    flat_ref = model.train_flat_grad().detach().cpu().numpy().copy()
+    table_ref = model.language_encoder.table.grad.detach().cpu().numpy().copy()
+    opt.step()
+    torch.cuda.synchronize()
+    ref_params = _params(model)
+
+    (_, l0, loc0, sum0, tg0, p0), (_, l1, loc1, sum1, tg1, p1) = res
+    assert abs(l0 - l1) < 1e-6 and abs(l0 - float(loss1.detach())) < 2e-5 * abs(l0) and abs(float(loss1.detach()) - float(loss2.detach())) < 1e-5
+    assert np.array_equal(sum0, sum1)                      # both ranks hold the same reduced gradient ...
+    assert np.allclose(sum0, loc0 + loc1, rtol=0, atol=0)  # ... which is the SUM of the local ones (one flat collective)
+    assert not np.array_equal(loc0, loc1)
+    rms = float(np.sqrt((flat_ref ** 2).mean()))
+    assert np.abs(sum0 - flat_ref).max() < 2e-3 * rms, (np.abs(sum0 - flat_ref).max(), rms)  # float atomics order only
+    assert np.median(np.abs(sum0 - flat_ref)) < 1e-5 * rms
+    assert np.array_equal(tg0, tg1) and np.abs(tg0 - table_ref).max() < 1e-6 + 1e-4 * np.abs(table_ref).max()
+    for n, v in ref_params.items():
+        assert np.array_equal(p0[n], p1[n]), n  # replicas stay in lock-step
+        err = np.abs(p0[n] - v)
+        # Adam's first step is lr * g / (|g| + eps): elements whose gradient is rounding noise may move by up to 2 lr
+        assert float((err < 1e-5 * (1 + np.abs(v))).mean()) > 0.97 and float(err.max()) <= 2.1 * LR, (n, float(err.max()))

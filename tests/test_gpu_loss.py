@@ -2,6 +2,7 @@
 Tolerance (fp32, exp of |x| <= 10): 3e-5 relative on the loss, 3e-6 absolute on gradients (|g| <= ~0.2)."""
 import numpy as np
 import pytest
+import torch
 
 from oracle import t2l_oracle as O
 
@@ -59,3 +60,24 @@ def test_autograd_function(eng):
     assert abs(loss.item() - rl) < 3e-5 * abs(rl)
     assert np.abs(a.grad.cpu().numpy() - 2 * rga).max() < 6e-6
     assert np.abs(p.grad.cpu().numpy() - 2 * rgp).max() < 6e-6
+
+
+@pytest.mark.parametrize("B", [129, 200, 512, 1024])
+def test_global_batches_beyond_the_fused_kernel(B):
+    """B > 128 — the all-gathered W x B batch of data-parallel training (8 x 64 = 512) — runs as a chain of launches over a
+    [B][B] matrix in HBM: same value and gradients as the float64 restatement of training/losses.py:269-283."""
+    from text2loc_amd.engine import Engine
+
+    rs = np.random.default_rng(B)
+    a = rs.standard_normal((B, 256)).astype(np.float32)
+    p = (a + 0.7 * rs.standard_normal((B, 256))).astype(np.float32) * rs.uniform(0.5, 2.0, size=(B, 1)).astype(np.float32)
+    eng = Engine(0)
+    loss, ga, gp = eng.contrastive_loss(torch.from_numpy(a).cuda(), torch.from_numpy(p).cuda(), 0.1)
+    rl, rga, rgp = O.contrastive_loss(a, p, 0.1, dtype=np.float64)
+    assert abs(float(loss.item()) - rl) < 3e-5 * abs(rl)
+    assert np.abs(ga.cpu().numpy() - rga).max() < 3e-6 and np.abs(gp.cpu().numpy() - rgp).max() < 3e-6
+    l2, g2, _ = eng.contrastive_loss(torch.from_numpy(a).cuda(), torch.from_numpy(p).cuda(), 0.1, need_grad=False)
+    assert g2 is None and abs(float(l2.item()) - float(loss.item())) < 1e-7
+    with pytest.raises(Exception, match="1024"):
+        eng.contrastive_loss(torch.zeros(1025, 256, device="cuda"), torch.zeros(1025, 256, device="cuda"), 0.1)
+    eng.close()

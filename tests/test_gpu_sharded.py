@@ -67,7 +67,7 @@ def _run(world, n_rows, n_q, k):
     return sorted(res, key=lambda r: r[0])
 
 
-@pytest.mark.parametrize("world,n_rows,n_q", [(4, 11259, 1024), (3, 11259, 4096), (2, 777, 130)])
+@pytest.mark.parametrize("world,n_rows,n_q", [(8, 11259, 4096), (4, 11259, 1024), (3, 11259, 4096), (2, 777, 130)])
 def test_engine_row_sharded_equals_unsharded(world, n_rows, n_q):
     k = 10
     res = _run(world, n_rows, n_q, k)
@@ -93,6 +93,105 @@ def test_engine_empty_shard_inside_sharded_search():
     for rank, lo, hi, idx, sc, qi, qsc in res:
         assert np.array_equal(idx.astype(np.int64)[:, : ridx.shape[1]], ridx)
         assert np.abs(sc[:, : ridx.shape[1]] - rsc).max() < 1e-12
+
+
+def test_world_8_with_empty_and_short_shards():
+    """BASELINE config 3's process count with real engines: N=50 over 8 ranks = shards of 7,7,7,7,7,7,7,1 rows, k=10 > every
+    shard; N=9 = 2,2,2,2,1,0,0,0 (three EMPTY shards inside the exchange)."""
+    for n_rows in (50, 9):
+        k = 10
+        res = _run(8, n_rows, 33, k)
+        db, qs, _ = synth.make_retrieval_problem(n_rows, 33, seed=21, noise=1.0)
+        ridx, rsc = c_oracle.retrieve_topk(db, qs, k)
+        kk = ridx.shape[1]
+        assert [r[2] - r[1] for r in res] == [max(0, min(n_rows, (r + 1) * -(-n_rows // 8)) - min(n_rows, r * -(-n_rows // 8))) for r in range(8)]
+        for rank, lo, hi, idx, sc, qi, qsc in res:
+            assert np.array_equal(idx.astype(np.int64)[:, :kk], ridx), f"N={n_rows} rank {rank}"
+            assert np.abs(sc[:, :kk] - rsc).max() < 1e-12
+            assert (idx[:, kk:] == -1).all()
+
+
+# ---- BASELINE config 5 on N ranks: cross_matcher.run_fine's world > 1 branch (consumer: evaluation/pipeline.py:90-204) ----------
+def _fine_problem():
+    from tests.test_gpu_fine import HintTable, _fine_args
+    from tests.test_host_logic import StubCell, make_objects
+    from text2loc_amd.cross_matcher import CrossMatch
+
+    args = _fine_args(True)
+    args.top_k, n_cells, Q = [1, 3, 5, 10], 37, 53
+    cells_np = synth.make_cells(n_cells, seed=77, min_obj=4, max_obj=22)
+    objects = make_objects(cells_np, 77)
+    rng = np.random.default_rng(5)
+    table = rng.standard_normal((Q, 6, 128)).astype(np.float32)
+    model = CrossMatch(synth.KNOWN_CLASS, synth.COLOR_NAMES, args, language_encoder=HintTable(table))
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_fine_weights(5).items()}, strict=False)
+
+    class D:
+        def __init__(self, i):
+            self.direction, self.object_color_text, self.object_label = "north", "red", f"q{i}x"
+
+    class Pose:
+        def __init__(self, i, cell):
+            self.descriptions = [D(i)]
+            self.cell_id = cell.id
+            self.pose_w = np.array([*(cell.bbox_w[0:2] + rng.uniform(0, 1, 2) * cell.cell_size), 0.0])
+
+    stub_cells = []
+    for i in range(n_cells):
+        lo = np.array([15.0 * (i % 6), 15.0 * (i // 6), 0.0])
+        c = StubCell(f"sceneA_{i:03d}", np.concatenate([lo, lo + 30.0]), 30.0)
+        c.objects = objects[i]
+        stub_cells.append(c)
+    retr = [np.array([stub_cells[j].id for j in rng.choice(n_cells, size=10, replace=False)]) for _ in range(Q)]
+    poses = [Pose(i, stub_cells[int(np.where([c.id == retr[i][0] for c in stub_cells])[0][0])]) for i in range(Q)]
+
+    class Ds:
+        all_poses, all_cells = poses, stub_cells
+
+    class Dl:
+        dataset = Ds()
+
+    return model.to("cuda").eval(), retr, Dl(), args
+
+
+def _fine_worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from text2loc_amd.cross_matcher import run_fine
+
+    model, retr, dl, args = _fine_problem()
+    acc, offsets = run_fine(model, retr, dl, args, return_offsets=True)
+    torch.cuda.synchronize()
+    out_q.put((rank, acc, offsets))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_run_fine_sharded_equals_single_process(world):
+    """The distinct retrieved cells (37 -> blocks of 19/18 or 10/10/10/7) and the 530 (pose, cell) pairs are split across the
+    ranks and all-gathered once each: accuracies AND every offset equal the single-process run bit for bit."""
+    from text2loc_amd.cross_matcher import run_fine
+
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fine_worker, args=(r, world, port, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out_q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    model, retr, dl, args = _fine_problem()
+    acc1, off1 = run_fine(model, retr, dl, args, return_offsets=True)
+    assert off1.shape == (53, 10, 2) and np.isfinite(off1).all()
+    for rank, acc, off in res:
+        assert acc == acc1, (rank, acc, acc1)
+        assert np.array_equal(off, off1), f"rank {rank}: offsets differ from the single-process run"
 
 
 def test_empty_database_answers_minus_one():

@@ -165,3 +165,70 @@ def test_gather_rows_under_gloo(world, n_rows):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+# ---- data-parallel training plumbing: gathered global loss + summed gradients ------------------------
+def _torch_contrastive(im, s, t=0.1):
+    im = im / torch.norm(im, dim=1, keepdim=True)
+    s = s / torch.norm(s, dim=1, keepdim=True)
+    sim = im @ s.t()
+    num = torch.exp(torch.diag(sim) / t)
+    den = torch.exp(sim / t)
+    return torch.mean(-torch.log(num / den.sum(0)) - torch.log(num / den.sum(1)))
+
+
+def _dp_problem(world, b_local):
+    g = torch.Generator().manual_seed(3)
+    n = world * b_local
+    x_txt, x_cell = torch.randn(n, 24, generator=g), torch.randn(n, 40, generator=g)
+    w_txt, w_cell = torch.randn(24, 256, generator=g) * 0.2, torch.randn(40, 256, generator=g) * 0.2
+    return x_txt.double(), x_cell.double(), w_txt.double(), w_cell.double()
+
+
+def _dp_worker(rank, world, port, b_local, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from text2loc_amd.losses import gather_rows_with_grad
+    from text2loc_amd.optim import all_reduce_flat
+
+    x_txt, x_cell, w_txt, w_cell = _dp_problem(world, b_local)
+    w_txt.requires_grad_(True)
+    w_cell.requires_grad_(True)
+    lo = rank * b_local
+    im = gather_rows_with_grad(x_txt[lo:lo + b_local] @ w_txt)     # local rows -> the global [W*B,256] matrix, on every rank
+    s = gather_rows_with_grad(x_cell[lo:lo + b_local] @ w_cell)
+    loss = _torch_contrastive(im, s)
+    loss.backward()                                               # d(global loss)/d(local rows) only
+    flat = torch.cat([w_txt.grad.reshape(-1), w_cell.grad.reshape(-1)])
+    local = flat.clone()
+    all_reduce_flat(flat, None)                                   # ONE collective, SUM
+    out_q.put((rank, float(loss.detach()), local.numpy(), flat.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,b_local", [(2, 8), (3, 5)])
+def test_gathered_loss_and_summed_gradients_equal_the_single_process_step(world, b_local):
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, b_local, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out_q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x_txt, x_cell, w_txt, w_cell = _dp_problem(world, b_local)
+    w_txt.requires_grad_(True)
+    w_cell.requires_grad_(True)
+    loss = _torch_contrastive(x_txt @ w_txt, x_cell @ w_cell)
+    loss.backward()
+    ref = torch.cat([w_txt.grad.reshape(-1), w_cell.grad.reshape(-1)]).numpy()
+    for rank, l, local, summed in res:
+        assert abs(l - float(loss.detach())) < 1e-12           # every rank evaluates the GLOBAL loss
+        assert np.abs(summed - ref).max() < 1e-12                # sum of the per-rank gradients == the full-batch gradient
+        assert np.abs(local - ref).max() > 1e-6                  # ... which no rank has by itself
+    assert np.abs(sum(r[2] for r in res) - ref).max() < 1e-12

@@ -234,7 +234,9 @@ class CellRetrievalNetwork(nn.Module):
         self._pn_weights_version = None
         self._train_generation = 0   # bumped whenever the engine changes parameters/buffers behind torch's back
         self._train_bound = None     # pointer set the engine's training path is bound to
-        self._train_grads = {}       # name -> persistent gradient buffer (kept when .grad is set to None)
+        self._train_grads = {}       # name -> persistent gradient buffer (kept when .grad is set to None): views of _train_flat
+        self._train_flat = None
+        self._train_flat_layout = None
         self._train_token = None
         self._train_hook = None
         self._pn_in_engine = False   # the last training-mode forward ran the backbone in the engine with gradients bound
@@ -318,26 +320,46 @@ class CellRetrievalNetwork(nn.Module):
         if "num" not in a.use_features:
             skip.append("object_encoder.num_encoder.")
         out = {}
+        live = []
         for n, t in self.state_dict(keep_vars=True).items():
             if not n.startswith(("object_encoder.", "obj_inter_module.")) or n.startswith(tuple(skip)):
                 continue
             if n.endswith("num_batches_tracked"):
                 continue
+            live.append((n, t))
+        # Gradient buffers of the engine-stepped parameters are views into ONE flat tensor (64-float aligned): data-parallel
+        # training all-reduces it as a single RCCL collective (optim.Adam(group=...)), and zero_grad(set_to_none=True) /
+        # model.to() only drop or move references, never the buffers the engine is bound to.
+        want = [(n, t) for n, t in live if isinstance(t, nn.Parameter) and t.requires_grad]
+        layout = tuple((n, int(t.numel())) for n, t in want)
+        dev = want[0][1].device if want else None
+        if want and (self._train_flat is None or self._train_flat_layout != layout or self._train_flat.device != dev):
+            offs, total = [], 0
+            for _, t in want:
+                offs.append(total)
+                total += (int(t.numel()) + 63) // 64 * 64
+            self._train_flat = torch.zeros(total, dtype=torch.float32, device=dev)
+            self._train_flat_layout = layout
+            self._train_grads = {n: self._train_flat[o:o + t.numel()].view(t.shape) for (n, t), o in zip(want, offs)}
+        for n, t in live:
             if isinstance(t, nn.Parameter) and not t.requires_grad:
                 out[n] = (t.data, None)  # --pointnet_freeze (object_encoder.py:53-55): forward only
             elif isinstance(t, nn.Parameter):
-                g = self._train_grads.get(n)
-                if g is None or g.shape != t.shape or g.device != t.device:
-                    g = self._train_grads[n] = torch.zeros_like(t.data)
+                g = self._train_grads[n]
                 if t.grad is None:
                     t.grad = g  # hand the persistent buffer back (zero_grad(set_to_none=True) only drops the reference)
                     g.zero_()
                 elif t.grad.data_ptr() != g.data_ptr():
-                    self._train_grads[n] = g = t.grad
+                    g.copy_(t.grad)  # a gradient assigned from outside keeps its VALUE; the storage stays the flat buffer's
+                    t.grad = g
                 out[n] = (t.data, g)
             else:
                 out[n] = (t, None)
         return out
+
+    def train_flat_grad(self) -> Optional[torch.Tensor]:
+        """The flat buffer every engine-stepped parameter's ``.grad`` is a view of (None before the first bind)."""
+        return self._train_flat
 
     def train_engine(self) -> Engine:
         """The engine with the training path bound to the CURRENT parameter / gradient / buffer storage."""

@@ -190,7 +190,8 @@ def encode_pose_hints(language_encoder, texts: List[str], max_batch: int = 256) 
 
 
 @torch.no_grad()
-def run_fine(model: CrossMatch, retrievals, dataloader, args, transform_fine=None, object_points_fn=None):
+def run_fine(model: CrossMatch, retrievals, dataloader, args, transform_fine=None, object_points_fn=None,
+             return_offsets: bool = False):
     """evaluation/pipeline.py:88-204: offsets of every pose against its max(top_k) retrieved cells -> {k: {t: accuracy}}.
     The reference builds a ``Kitti360TopKDataset`` item per pose and runs one forward per pose, re-encoding a cell for
     every pose that retrieved it; here every distinct retrieved cell is padded and encoded ONCE, every pose's hints are
@@ -238,4 +239,5 @@ def run_fine(model: CrossMatch, retrievals, dataloader, args, transform_fine=Non
 
     pose_xy, pose_scene, bbox_xy, size, scene = _pose_cell_tables(poses, cells, retrievals)
     ok = sample_accuracies_batch(pose_xy, pose_scene, bbox_xy, size, scene, offsets.astype(np.float64), args.top_k, args.threshs)
-    return {k: {t: float(np.mean(ok[k][t])) for t in args.threshs} for k in args.top_k}
+    acc = {k: {t: float(np.mean(ok[k][t])) for t in args.threshs} for k in args.top_k}
+    return (acc, offsets) if return_offsets else acc  # offsets f32[n_poses, max(top_k), 2]: the per-pair estimates

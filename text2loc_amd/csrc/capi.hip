@@ -104,7 +104,7 @@ void t2l_destroy(t2l_ctx* ctx) {
   free_pointnet(ctx);
   free_fine(ctx);
   for (void* p : {(void*)ctx->db, (void*)ctx->db_split, (void*)ctx->db_half, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
-                  (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count, ctx->reduce_ws, (void*)ctx->scan_span})
+                  (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count, ctx->reduce_ws, ctx->loss_ws, (void*)ctx->scan_span})
     if (p) (void)hipFree(p);
   delete[] ctx->span_grid;
   if (ctx->host_stat) (void)hipHostFree(ctx->host_stat);
@@ -219,6 +219,18 @@ int t2l_search(t2l_ctx* ctx, const float* queries, int32_t n_queries, int32_t k,
   return search_lanes_impl(ctx, queries, n_queries, k, out_idx, out_score, (hipStream_t)stream);
 }
 
+int t2l_search_ordered(t2l_ctx* ctx, const float* queries, int32_t n_queries, int32_t k, int32_t* out_idx, double* out_score,
+                       void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  if (n_queries < 0 || k < 1 || k > T2L_MAX_TOPK)
+    return fail(ctx, T2L_EINVAL, "t2l_search_ordered: need n_queries >= 0 and 1 <= k <= T2L_MAX_TOPK");
+  if (n_queries == 0) return T2L_OK;
+  if (!queries || !out_idx) return fail(ctx, T2L_EINVAL, "t2l_search_ordered: null buffer");
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  const int rc = search_join_impl(ctx, (hipStream_t)stream);  // anything still pipelined is ordered first
+  return rc != T2L_OK ? rc : search_impl(ctx, queries, n_queries, k, out_idx, out_score, (hipStream_t)stream);
+}
+
 int t2l_search_join(t2l_ctx* ctx, void* stream) {
   if (!ctx) return T2L_EINVAL;
   T2L_HIP(ctx, hipSetDevice(ctx->device));
@@ -312,8 +324,8 @@ int t2l_search_rescored(t2l_ctx* ctx, int32_t* out_count) {
 int t2l_contrastive_loss(t2l_ctx* ctx, const float* anchor, const float* positive, int32_t batch, float temperature,
                          float* loss, float* grad_anchor, float* grad_positive, void* stream) {
   if (!ctx) return T2L_EINVAL;
-  if (batch < 1 || batch > 128 || !(temperature > 0.f))
-    return fail(ctx, T2L_EINVAL, "t2l_contrastive_loss: need 1 <= batch <= 128 and temperature > 0");
+  if (batch < 1 || batch > T2L_MAX_LOSS_BATCH || !(temperature > 0.f))
+    return fail(ctx, T2L_EINVAL, "t2l_contrastive_loss: need 1 <= batch <= 1024 and temperature > 0");
   if (!anchor || !positive || !loss) return fail(ctx, T2L_EINVAL, "t2l_contrastive_loss: null buffer");
   if ((grad_anchor == nullptr) != (grad_positive == nullptr))
     return fail(ctx, T2L_EINVAL, "t2l_contrastive_loss: pass both gradients or neither");

@@ -191,9 +191,128 @@ __global__ __launch_bounds__(256, 1) void contrastive_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Batches beyond the fused kernel's 128 rows — the GLOBAL contrastive matrix of data-parallel training (SURVEY.md §8e:
+// every rank all-gathers the [B,256] embeddings of all ranks and evaluates the loss of the whole W*B batch; 8 x 64 = 512,
+// up to 1,024 rows): the same arithmetic as a short chain of launches over a [B][B] matrix in HBM (4 MB at B = 1,024).
+// Deterministic (no atomics): row / column sums are one wave per index.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cl_norm_kernel(const float* __restrict__ im, const float* __restrict__ s, int B,
+                                                      float* __restrict__ ia, float* __restrict__ ip) {
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= B) return;
+  const float4 a = reinterpret_cast<const float4*>(im + (size_t)i * kD)[lane];
+  const float4 p = reinterpret_cast<const float4*>(s + (size_t)i * kD)[lane];
+  const float sa = wave_sum_f32(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w);
+  const float sp = wave_sum_f32(p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w);
+  if (lane == 0) { ia[i] = 1.f / sqrtf(sa); ip[i] = 1.f / sqrtf(sp); }
+}
+
+__global__ __launch_bounds__(64) void cl_sim_kernel(const float* __restrict__ im, const float* __restrict__ s, int B, int nb,
+                                                    float inv_t, const float* __restrict__ ia, const float* __restrict__ ip,
+                                                    float* __restrict__ E, float* __restrict__ diag) {
+  const int lane = threadIdx.x, col = lane & 31, half = lane >> 5;
+  const int i0 = (blockIdx.x / nb) * 32, j0 = (blockIdx.x % nb) * 32;
+  const float4* ap = reinterpret_cast<const float4*>(im + (size_t)min(i0 + col, B - 1) * kD + half * 128);
+  const float4* pp = reinterpret_cast<const float4*>(s + (size_t)min(j0 + col, B - 1) * kD + half * 128);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+  for (int q = 0; q < 32; ++q) {
+    const float4 a = ap[q], p = pp[q];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, p.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, p.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, p.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, p.w, acc, 0, 0, 0);
+  }
+  const int j = j0 + col;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (i < B && j < B) {
+      const float sim = acc[r] * ia[i] * ip[j];
+      E[(size_t)i * B + j] = __expf(sim * inv_t);
+      if (i == j) diag[i] = sim;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cl_sums_kernel(const float* __restrict__ E, int B, float* __restrict__ R, float* __restrict__ C) {
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= B) return;
+  float r = 0.f, c = 0.f;
+  for (int j = lane; j < B; j += 64) {
+    r += E[(size_t)i * B + j];
+    c += E[(size_t)j * B + i];
+  }
+  r = wave_sum_f32(r);
+  c = wave_sum_f32(c);
+  if (lane == 0) { R[i] = r; C[i] = c; }
+}
+
+__global__ __launch_bounds__(256) void cl_loss_kernel(const float* __restrict__ R, const float* __restrict__ C,
+                                                      const float* __restrict__ diag, int B, float inv_t, float* __restrict__ loss) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float v = 0.f;
+  for (int i = tid; i < B; i += 256) v += __logf(C[i]) + __logf(R[i]) - 2.f * diag[i] * inv_t;
+  v = wave_sum_f32(v);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (tid == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+}
+
+__global__ __launch_bounds__(256) void cl_g_kernel(float* __restrict__ E, const float* __restrict__ R, const float* __restrict__ C,
+                                                   int B, float sc) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (size_t)B * B) return;
+  const int i = (int)(e / B), j = (int)(e % B);
+  const float v = E[e];
+  E[e] = (v / C[j] + v / R[i] - (i == j ? 2.f : 0.f)) * sc;
+}
+
+__global__ __launch_bounds__(64) void cl_grad_kernel(const float* __restrict__ G, int B, int nb, const float* __restrict__ im,
+                                                     const float* __restrict__ s, const float* __restrict__ ia,
+                                                     const float* __restrict__ ip, float* __restrict__ g_im, float* __restrict__ g_s) {
+  const int task = blockIdx.x, i0 = (task % nb) * 32;
+  if (task < nb)
+    grad_rowblock(G, B, false, B, i0, s, ip, im, ia, g_im, threadIdx.x);
+  else
+    grad_rowblock(G, B, true, B, i0, im, ia, s, ip, g_s, threadIdx.x);
+}
+
+static int loss_big_impl(t2l_ctx* ctx, const float* a, const float* p, int B, float temp, float* loss, float* ga, float* gp,
+                         hipStream_t s) {
+  const size_t need = ((size_t)B * B + 5 * (size_t)B) * sizeof(float);
+  if (ctx->loss_ws_cap < need) {
+    if (ctx->loss_ws) T2L_HIP(ctx, hipFree(ctx->loss_ws));
+    ctx->loss_ws = nullptr;
+    ctx->loss_ws_cap = 0;
+    T2L_HIP(ctx, hipMalloc(&ctx->loss_ws, need));
+    ctx->loss_ws_cap = need;
+  }
+  float* E = (float*)ctx->loss_ws;
+  float *ia = E + (size_t)B * B, *ip = ia + B, *diag = ip + B, *R = diag + B, *C = R + B;
+  const int nb = (B + 31) / 32, rows4 = (B + 3) / 4;
+  event_begin(ctx, "contrastive_loss", s);
+  hipLaunchKernelGGL(cl_norm_kernel, dim3(rows4), dim3(256), 0, s, a, p, B, ia, ip);
+  hipLaunchKernelGGL(cl_sim_kernel, dim3(nb * nb), dim3(64), 0, s, a, p, B, nb, 1.0f / temp, ia, ip, E, diag);
+  hipLaunchKernelGGL(cl_sums_kernel, dim3(rows4), dim3(256), 0, s, E, B, R, C);
+  hipLaunchKernelGGL(cl_loss_kernel, dim3(1), dim3(256), 0, s, R, C, diag, B, 1.0f / temp, loss);
+  if (ga) {
+    hipLaunchKernelGGL(cl_g_kernel, dim3((unsigned)(((size_t)B * B + 255) / 256)), dim3(256), 0, s, E, R, C, B, 1.0f / (temp * (float)B));
+    hipLaunchKernelGGL(cl_grad_kernel, dim3(2 * nb), dim3(64), 0, s, E, B, nb, a, p, ia, ip, ga, gp);
+  }
+  event_end(ctx, "contrastive_loss", s);
+  T2L_HIP(ctx, hipGetLastError());
+  return T2L_OK;
+}
+
 int loss_impl(t2l_ctx* ctx, const float* a, const float* p, int B, float temp, float* loss, float* ga, float* gp,
               hipStream_t s) {
-  if (B > 128) return fail(ctx, T2L_EINVAL, "t2l_contrastive_loss: batch > 128 not supported by the fused kernel");
+  if (B > T2L_MAX_LOSS_BATCH) return fail(ctx, T2L_EINVAL, "t2l_contrastive_loss: batch > 1024 not supported");
+  if (B > 128) return loss_big_impl(ctx, a, p, B, temp, loss, ga, gp, s);
   const int Bp = (B + 31) / 32 * 32;
   const size_t lds = ((size_t)Bp * (Bp + 1) + 5 * Bp + 4) * sizeof(float);
   static bool attr_done = false;

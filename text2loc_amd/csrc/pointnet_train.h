@@ -796,6 +796,7 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
   TrainState* st = state(ctx);
   PnTrain* pt = st ? pn_state(st) : nullptr;
   if (!pt || !pt->have_forward) return fail(ctx, T2L_ESTATE, "t2l_pointnet_backward: no training-mode forward to differentiate");
+  st->pn_touched = true;  // the backbone's gradients carry this batch: its tensors take part in the next t2l_adam_step
   if (!pt->trainable)
     return fail(ctx, T2L_ESTATE, "t2l_pointnet_backward: the backbone was bound without gradient buffers (frozen)");
   if (!grad_f2) return fail(ctx, T2L_EINVAL, "t2l_pointnet_backward: null gradient");

@@ -831,13 +831,15 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
   if (threadIdx.x < 4) wg_flag[threadIdx.x] = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // the report card of the PREVIOUS call (its counters were parked at [64..] by this call's scan): mapped host memory the
-    // host reads at a later call — no stream operation, no fence (it only steers heuristics)
+    // host reads at a later call — no stream operation, no synchronisation (it only steers heuristics); the sequence number is
+    // published LAST with system-scope release ordering, the host reads it first with an acquire load, so a new sequence
+    // number is never paired with the previous call's counts
     if (host_stat && seq > 0) {
       host_stat[1] = fb_count[64 + 10] == 2 ? fb_count[64 + 3] : fb_count[64 + 2];  // f16-certificate failures (or the probe's)
       host_stat[2] = fb_count[64 + 9];
       host_stat[3] = fb_count[64 + 0] + fb_count[64 + 4] + fb_count[64 + 12];  // exact-stage queries
       host_stat[4] = fb_count[64 + 10] != 0;
-      host_stat[0] = seq;
+      __hip_atomic_store(&host_stat[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     fb_count[9] = Q;
     fb_count[10] = stat_mode;  // 0: not an f16-certificate count, 1: f16 scan, 2: split-bf16 stand-in probing for it
@@ -1408,7 +1410,7 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
   // (search_exact.hip) instead of the fallback kernel's VALU scan, until fewer than 1 in 256 need it
   if (ctx->host_stat) {
     const volatile int32_t* hs = ctx->host_stat;
-    const int done = hs[0];
+    const int done = __atomic_load_n(ctx->host_stat, __ATOMIC_ACQUIRE);  // pairs with the kernel's system-scope release store
     if (done > ctx->stat_seen) {
       ctx->stat_seen = done;
       const int64_t flagged = hs[1], total = hs[2], exact_prev = hs[3];

@@ -68,6 +68,8 @@ struct t2l_ctx {
   int32_t* seg_idx = nullptr;    // per-segment results when the shard exceeds one scan launch
   double* seg_score = nullptr;
   size_t cand_cap = 0, flag_cap = 0, seg_idx_cap = 0, seg_score_cap = 0;  // bytes
+  void* loss_ws = nullptr;       // [B][B] matrix + row vectors of the contrastive loss beyond 128 rows (loss.hip)
+  size_t loss_ws_cap = 0;
   void* reduce_ws = nullptr;     // work items + float64 accumulators of t2l_reduce_objects
   size_t reduce_ws_cap = 0;
   // encoder

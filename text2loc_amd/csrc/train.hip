@@ -57,7 +57,10 @@ struct TrainState {
   double* bn_acc = nullptr;  // [kBnSlots][2*1024] float64 partial sums of the BatchNorm stages (one slot per BN pass)
   int bn_slot = 0;
   int n_chunks = 0;
-  int64_t step = 0;
+  int pn_chunk0 = 0;         // chunks [pn_chunk0, n_chunks) belong to the PointNet++ backbone (bound last)
+  int64_t step = 0;          // Adam step of the object branch
+  int64_t step_pn = 0;       // ... of the backbone: it only steps when its backward ran since the last zero_grad (torch.optim.Adam
+  bool pn_touched = false;   // skips parameters whose .grad is None and keeps a step count per parameter)
   // workspace (bump-allocated per forward)
   char* ws = nullptr;
   size_t ws_cap = 0, ws_off = 0;
@@ -165,13 +168,14 @@ int train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const 
   std::vector<std::string> old_names;
   std::vector<int64_t> old_numel;
   float* old_mv = nullptr;
-  int64_t old_step = 0;
+  int64_t old_step = 0, old_step_pn = 0;
   if (old && ctx->train_keep_adam) {
     old_names = old->adam_names;
     for (auto& nme : old_names) old_numel.push_back(old->t[nme].numel);
     old_mv = old->mv;
     old->mv = nullptr;  // survives free_train below
     old_step = old->step;
+    old_step_pn = old->step_pn;
   }
   struct MvGuard {
     float* p;
@@ -229,6 +233,7 @@ int train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const 
       P.push_back(p + r.first);
     }
   }
+  const size_t n_obj_tensors = P.size();
   if ((rc = pn_train_bind(ctx, st, P))) return rc;  // the PointNet++ backbone, when bound with gradients
   // Adam tables: moments zero-initialised, one chunk per 1,024 elements
   std::vector<AdamTensor> ts;
@@ -245,16 +250,20 @@ int train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const 
     if (same) {
       T2L_HIP(ctx, hipMemcpy(st->mv, old_mv, sizeof(float) * 2 * (size_t)total, hipMemcpyDeviceToDevice));
       st->step = old_step;
+      st->step_pn = old_step_pn;
     }
   }
   int64_t off = 0;
+  st->pn_chunk0 = -1;
   for (auto& nme : P) {
     const TTensor& t = st->t[nme];
+    if (ts.size() == n_obj_tensors) st->pn_chunk0 = (int)cs.size();
     ts.push_back(AdamTensor{t.data, t.grad, st->mv + off, st->mv + total + off, t.numel});
     for (int64_t c = 0; c * 1024 < t.numel; ++c) cs.push_back(AdamChunk{(int32_t)ts.size() - 1, (int32_t)c});
     off += t.numel;
   }
   st->n_chunks = (int)cs.size();
+  if (st->pn_chunk0 < 0) st->pn_chunk0 = st->n_chunks;
   T2L_HIP(ctx, hipMalloc(&st->d_tensors, sizeof(AdamTensor) * ts.size()));
   T2L_HIP(ctx, hipMalloc(&st->d_chunks, sizeof(AdamChunk) * cs.size()));
   T2L_HIP(ctx, hipMemcpy(st->d_tensors, ts.data(), sizeof(AdamTensor) * ts.size(), hipMemcpyHostToDevice));
@@ -526,14 +535,28 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   return T2L_OK;
 }
 
+static void adam_launch(TrainState* st, int chunk0, int chunk1, int64_t step, float lr, float b1, float b2, float eps, hipStream_t s) {
+  if (chunk1 <= chunk0) return;
+  const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)b2, (double)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(chunk1 - chunk0), dim3(256), 0, s, st->d_tensors, st->d_chunks + chunk0, lr, b1, b2, eps, bc1, bc2s);
+}
+
 int adam_step_impl(t2l_ctx* ctx, float lr, float b1, float b2, float eps, hipStream_t s) {
   TrainState* st = state(ctx);
   if (!st) return fail(ctx, T2L_ESTATE, "t2l_adam_step: call t2l_train_bind first");
   st->step += 1;
-  const float bc1 = (float)(1.0 - pow((double)b1, (double)st->step));
-  const float bc2s = (float)sqrt(1.0 - pow((double)b2, (double)st->step));
+  // the backbone's tensors step only when its backward added into their gradients since the last zero_grad (a batch that
+  // passed precomputed features2 leaves them untouched: torch.optim.Adam would skip .grad = None parameters, not decay them)
+  const bool pn = st->pn_chunk0 < st->n_chunks && st->pn_touched;
+  if (pn) st->step_pn += 1;
   event_begin(ctx, "adam_step", s);
-  hipLaunchKernelGGL(adam_kernel, dim3(st->n_chunks), dim3(256), 0, s, st->d_tensors, st->d_chunks, lr, b1, b2, eps, bc1, bc2s);
+  if (pn && st->step_pn == st->step) {
+    adam_launch(st, 0, st->n_chunks, st->step, lr, b1, b2, eps, s);
+  } else {
+    adam_launch(st, 0, st->pn_chunk0, st->step, lr, b1, b2, eps, s);
+    if (pn) adam_launch(st, st->pn_chunk0, st->n_chunks, st->step_pn, lr, b1, b2, eps, s);
+  }
   event_end(ctx, "adam_step", s);
   T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;
@@ -544,7 +567,7 @@ int adam_state_impl(t2l_ctx* ctx, int set, float* m, float* v, int64_t* step, in
   if (!st) return fail(ctx, T2L_ESTATE, "t2l_adam_state: call t2l_train_bind first");
   if (numel) *numel = st->mv_total;
   if (!m && !v) {  // size / step query
-    if (step && !set) *step = st->step;
+    if (step && !set) *step = st->step | (st->step_pn << 32);
     return T2L_OK;
   }
   if (!m || !v || !step) return fail(ctx, T2L_EINVAL, "t2l_adam_state: pass m, v and step together");
@@ -552,11 +575,12 @@ int adam_state_impl(t2l_ctx* ctx, int set, float* m, float* v, int64_t* step, in
   if (set) {
     T2L_HIP(ctx, hipMemcpyAsync(st->mv, m, bytes, hipMemcpyDeviceToDevice, s));
     T2L_HIP(ctx, hipMemcpyAsync(st->mv + st->mv_total, v, bytes, hipMemcpyDeviceToDevice, s));
-    st->step = *step;
+    st->step = *step & 0xFFFFFFFFll;
+    st->step_pn = st->pn_chunk0 < st->n_chunks ? (*step >> 32) : 0;
   } else {
     T2L_HIP(ctx, hipMemcpyAsync(m, st->mv, bytes, hipMemcpyDeviceToDevice, s));
     T2L_HIP(ctx, hipMemcpyAsync(v, st->mv + st->mv_total, bytes, hipMemcpyDeviceToDevice, s));
-    *step = st->step;
+    *step = st->step | (st->step_pn << 32);
   }
   return T2L_OK;
 }
@@ -565,6 +589,7 @@ int zero_grad_impl(t2l_ctx* ctx, hipStream_t s) {
   TrainState* st = state(ctx);
   if (!st) return fail(ctx, T2L_ESTATE, "t2l_zero_grad: call t2l_train_bind first");
   hipLaunchKernelGGL(zero_kernel, dim3(st->n_chunks), dim3(256), 0, s, st->d_tensors, st->d_chunks);
+  st->pn_touched = false;
   T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;
 }

@@ -59,6 +59,7 @@ EXPORTS = {
     "t2l_db_rows": (C.c_int64, [C.c_void_p]),
     "t2l_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_search_join": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "t2l_search_ordered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_merge_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
     "t2l_pack_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -398,8 +399,10 @@ class Engine:
     def search(self, queries: torch.Tensor, k: int, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                join: bool = True):
         """Returns (idx i32[Q,k] global row ids best-first, scores f64[Q,k]); asynchronous on the current stream.
-        With ``set_option("search_lanes", n)`` consecutive calls pipeline on internal streams (t2l.h): pass ``join=False``
-        for a stream of independent batches and call ``search_join()`` before touching any of their results."""
+        ``join=True`` (default): stream-ordered on the caller's stream (t2l_search_ordered — the lanes are bypassed, no
+        cross-stream hop). With ``set_option("search_lanes", n)`` pass ``join=False`` for a stream of independent batches:
+        consecutive calls pipeline on internal streams (t2l.h); call ``search_join()`` before touching any of their results
+        or re-using their ``queries`` / ``out`` buffers (after 64 un-joined calls the engine joins by itself)."""
         if queries.dim() != 2 or queries.shape[1] != EMBED_DIM:
             raise T2LError(f"search: expected [Q,{EMBED_DIM}], got {tuple(queries.shape)}")
         Q = int(queries.shape[0])
@@ -409,12 +412,15 @@ class Engine:
         else:
             idx, sc = out
         qp = _dev_ptr(queries, torch.float32, "queries") if Q > 0 else None
-        self._check(self.lib.t2l_search(self._h, qp, Q, int(k), _dev_ptr(idx, torch.int32, "out_idx"),
-                                        _dev_ptr(sc, torch.float64, "out_score"), _stream_ptr()))
+        fn = self.lib.t2l_search_ordered if join else self.lib.t2l_search
+        self._check(fn(self._h, qp, Q, int(k), _dev_ptr(idx, torch.int32, "out_idx"), _dev_ptr(sc, torch.float64, "out_score"),
+                       _stream_ptr()))
         if join:
-            self.search_join()
+            self._lane_keepalive.clear()  # t2l_search_ordered joined whatever was pending
         else:
             self._lane_keepalive.append((queries, idx, sc))  # the lane streams are invisible to torch's allocator
+            if len(self._lane_keepalive) >= 64:
+                self.search_join()
         return idx, sc
 
     def search_join(self):

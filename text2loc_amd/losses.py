@@ -33,14 +33,57 @@ class _ContrastiveFn(torch.autograd.Function):
         return grad_out * ga, grad_out * gp, None
 
 
-class ContrastiveLoss(torch.nn.Module):
-    """Symmetric InfoNCE; ``forward(im, s)`` as in the reference (both inputs are re-normalised inside)."""
+class _GatherRowsFn(torch.autograd.Function):
+    """all_gather of the ranks' [B,D] rows into [W*B,D] (rank-major), differentiable: the backward hands every rank the slice
+    of the incoming gradient that belongs to ITS rows — no communication. With a loss every rank evaluates identically on the
+    gathered rows, that slice is d(global loss)/d(local rows); parameter gradients then only need a SUM over the ranks
+    (``optim.Adam(group=..., grad_reduce="sum")``)."""
 
-    def __init__(self, temperature: float = 1.0):
+    @staticmethod
+    def forward(ctx, x, group):
+        import torch.distributed as dist
+
+        from .sharded import _all_gather
+
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        ctx.lo, ctx.n = rank * x.shape[0], x.shape[0]
+        out = x.new_empty((world * x.shape[0],) + tuple(x.shape[1:]))
+        _all_gather(dist, out, x.detach().contiguous(), group)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad[ctx.lo:ctx.lo + ctx.n].contiguous(), None
+
+
+def gather_rows_with_grad(x, group=None):
+    """[B,D] per rank -> [W*B,D] on every rank, gradients flowing back to the local rows (every rank must hold B rows)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return x
+    return _GatherRowsFn.apply(x, group)
+
+
+class ContrastiveLoss(torch.nn.Module):
+    """Symmetric InfoNCE; ``forward(im, s)`` as in the reference (both inputs are re-normalised inside).
+
+    Data-parallel training (not in the reference, which is single-process): with ``group`` (or
+    ``gather=True`` for the default process group) every rank all-gathers the [B,256] text and cell embeddings of ALL ranks
+    — two collectives of W*B*1 KiB — and evaluates the loss of the GLOBAL W*B batch (every cell of every rank is a negative
+    for every text), exactly the value one process would compute on the concatenated batch; the backward returns
+    d(global loss)/d(local rows). Sum the parameter gradients over the ranks (``optim.Adam(model, group=...)``) and the step
+    equals the single-process step on the W*B batch, except that BatchNorm statistics stay per rank."""
+
+    def __init__(self, temperature: float = 1.0, group=None, gather: bool = False):
         super().__init__()
         self.temperature = temperature
+        self.group = group
+        self.gather = bool(gather) or group is not None
 
     def forward(self, im, s):
+        if self.gather:
+            im, s = gather_rows_with_grad(im, self.group), gather_rows_with_grad(s, self.group)
         return _ContrastiveFn.apply(im, s, float(self.temperature))
 
 

@@ -3,14 +3,43 @@
 (t2l_adam_step: one launch over every bound tensor, moments kept in HBM by the library), everything else (the language
 head) by ``torch.optim.Adam`` with the same hyper-parameters. It is a ``torch.optim.Optimizer``, so the reference's
 ``ExponentialLR`` / ``StepLR`` schedulers (training/coarse.py:268-273) drive it unchanged through ``param_groups``.
+
+Data-parallel training (one process per GPU; not in the reference — SURVEY.md 8e): ``Adam(model, lr, group=pg)`` all-reduces
+the gradients at the top of ``step()``. The engine-stepped parameters' ``.grad`` are views of ONE flat buffer
+(``CellRetrievalNetwork.train_flat_grad``), so they travel as a single RCCL all_reduce (16.5 M floats = 66 MB with the
+backbone: per-link bound on xGMI, one large collective instead of ~150 small ones); the language head's gradients are
+flattened into a second one. ``grad_reduce="sum"`` pairs with ``ContrastiveLoss(group=pg)`` (every rank differentiates the
+GLOBAL loss w.r.t. its own rows: the sum over ranks is the exact gradient); ``"mean"`` is the usual average for per-rank losses.
 """
 from __future__ import annotations
 
 import torch
 
 
+def all_reduce_flat(buf: torch.Tensor, group=None, mean: bool = False) -> torch.Tensor:
+    """In-place all_reduce (sum, or mean) of one flat gradient buffer: RCCL on the tensor's own device under "nccl"; under gloo a
+    device tensor is staged through the host (several processes on one GPU in the tests — RCCL refuses duplicate devices)."""
+    import torch.distributed as dist
+
+    if buf.is_cuda and dist.get_backend(group) != "nccl":
+        h = buf.cpu()
+        dist.all_reduce(h, group=group)
+        buf.copy_(h)
+    else:
+        dist.all_reduce(buf, group=group)
+    if mean:
+        buf.div_(dist.get_world_size(group))
+    return buf
+
+
 class Adam(torch.optim.Optimizer):
-    def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+    def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, group=None, grad_reduce: str = "sum",
+                 data_parallel: bool = False):
+        """``group``: a torch.distributed process group, or ``data_parallel=True`` for the default one — turns the gradient
+        all-reduce of ``step()`` on."""
+        if grad_reduce not in ("sum", "mean"):
+            raise ValueError("grad_reduce must be 'sum' or 'mean'")
+        self._group, self._grad_reduce, self._dp = group, grad_reduce, bool(data_parallel) or group is not None
         obj, rest = [], []
         for n, p in model.named_parameters():
             if not p.requires_grad:
@@ -35,12 +64,43 @@ class Adam(torch.optim.Optimizer):
         if self._torch is not None:
             self._torch.zero_grad(set_to_none=set_to_none)
 
+    # ---- data parallel ------------------------------------------------------------------------------------------------
+    def _world(self) -> int:
+        import torch.distributed as dist
+
+        if not self._dp:
+            return 1
+        return dist.get_world_size(self._group) if dist.is_available() and dist.is_initialized() else 1
+
+    @torch.no_grad()
+    def all_reduce_grads(self):
+        """ONE all_reduce over the engine-owned flat gradient buffer + one over the flattened torch-side gradients."""
+        world = self._world()
+        if world == 1:
+            return
+        self._model.train_engine()  # binds (and so allocates) the flat buffer if nothing has yet
+        bufs = []
+        flat = self._model.train_flat_grad()
+        if flat is not None:
+            bufs.append((flat, None))
+        rest = [p for g in self.param_groups[1:] for p in g["params"] if p.grad is not None]
+        if rest:
+            bufs.append((torch.cat([p.grad.reshape(-1) for p in rest]), rest))
+        for buf, params in bufs:
+            all_reduce_flat(buf, self._group, mean=self._grad_reduce == "mean")
+            if params is not None:
+                off = 0
+                for p in params:
+                    p.grad.copy_(buf[off:off + p.numel()].view_as(p.grad))
+                    off += p.numel()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self.all_reduce_grads()
         g = self.param_groups[0]
         eng = self._model.train_engine()
         eng.adam_step(g["lr"], g["betas"][0], g["betas"][1], g["eps"])

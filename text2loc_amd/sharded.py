@@ -101,7 +101,7 @@ class ShardedSearcher:
         self._default_fns = search_fn is None and merge_fn is None
         self.search_fn = search_fn or (lambda q, k: engine.search(q, k))
         self.merge_fn = merge_fn or (lambda i, s: engine.merge_topk(i, s))
-        self._scratch = {}  # (Q, k, device) -> intermediates of the engine path (stream-ordered reuse: nothing of them is returned)
+        self._scratch = None  # intermediates of the engine path: ONE set, sized to the largest (Q, k) seen and sliced
 
     def set_db_shard(self, all_rows_or_shard, n_total: Optional[int] = None):
         """Give either the full [N,256] matrix (this rank keeps its slice) or this rank's slice + n_total."""
@@ -118,6 +118,31 @@ class ShardedSearcher:
             self.engine.db_set(shard, row_offset=lo)
         return lo, hi
 
+    def _scratch_for(self, Q: int, k: int, dev):
+        """(idx i32[Q,k], score f64[Q,k], pairs f64[Q,k,2], all pairs f64[world*Q,k,2]) as contiguous slices of one scratch set
+        that only grows (variable query-batch sizes do not accumulate buffers). Reuse is safe because every consumer is
+        ordered on the stream that owns the set; a caller on ANOTHER stream gets fresh tensors for that call."""
+        import torch
+
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        need = Q * k
+        sc = self._scratch
+        if sc is not None and (sc["dev"] != dev or sc["stream"] != stream):
+            if sc["dev"] == dev:  # foreign stream: do not touch the owner's buffers
+                return (torch.empty((Q, k), dtype=torch.int32, device=dev), torch.empty((Q, k), dtype=torch.float64, device=dev),
+                        torch.empty((Q, k, 2), dtype=torch.float64, device=dev),
+                        torch.empty((self.world * Q, k, 2), dtype=torch.float64, device=dev))
+            sc = None
+        if sc is None or sc["cap"] < need:
+            cap = max(need, 0 if sc is None else sc["cap"])
+            sc = self._scratch = {"dev": dev, "stream": stream, "cap": cap,
+                                  "idx": torch.empty(cap, dtype=torch.int32, device=dev),
+                                  "sc": torch.empty(cap, dtype=torch.float64, device=dev),
+                                  "pairs": torch.empty(cap * 2, dtype=torch.float64, device=dev),
+                                  "all": torch.empty(self.world * cap * 2, dtype=torch.float64, device=dev)}
+        return (sc["idx"][:need].view(Q, k), sc["sc"][:need].view(Q, k), sc["pairs"][:need * 2].view(Q, k, 2),
+                sc["all"][:self.world * need * 2].view(self.world * Q, k, 2))
+
     def search(self, queries, k: int):
         import torch
 
@@ -126,14 +151,7 @@ class ShardedSearcher:
             # results and the exchange buffers are scratch, reused call after call (a step is ~70 us of GPU time: five
             # tensor allocations per call would make the host the bottleneck)
             Q = int(queries.shape[0])
-            key = (Q, int(k), queries.device)
-            sbuf = self._scratch.get(key)
-            if sbuf is None:
-                dev = queries.device
-                sbuf = self._scratch[key] = (torch.empty((Q, k), dtype=torch.int32, device=dev), torch.empty((Q, k), dtype=torch.float64, device=dev),
-                                             torch.empty((Q, k, 2), dtype=torch.float64, device=dev),
-                                             torch.empty((self.world * Q, k, 2), dtype=torch.float64, device=dev))
-            idx, sc, pairs, allp = sbuf
+            idx, sc, pairs, allp = self._scratch_for(Q, int(k), queries.device)
             self.engine.search(queries, k, out=(idx, sc))
             self.engine.pack_pairs(idx, sc, out=pairs)
             _all_gather(self.dist, allp, pairs, self.group)
