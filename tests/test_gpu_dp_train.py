@@ -125,6 +125,8 @@ def test_two_ranks_equal_the_accumulated_single_process_step():
     assert np.array_equal(tg0, tg1) and np.abs(tg0 - table_ref).max() < 1e-6 + 1e-4 * np.abs(table_ref).max()
     for n, v in ref_params.items():
         assert np.array_equal(p0[n], p1[n]), n  # replicas stay in lock-step
+        if (n.startswith("object_encoder.") and n.endswith(".0.bias")) or n.endswith("in_proj_bias"):
+            continue  # zero true gradient (a Linear bias in front of a BatchNorm, the attention's key bias): Adam steps on rounding noise
         err = np.abs(p0[n] - v)
         # Adam's first step is lr * g / (|g| + eps): elements whose gradient is rounding noise may move by up to 2 lr
         assert float((err < 1e-5 * (1 + np.abs(v))).mean()) > 0.97 and float(err.max()) <= 2.1 * LR, (n, float(err.max()))
