@@ -220,6 +220,25 @@ int t2l_contrastive_loss(t2l_ctx* ctx, const float* anchor, const float* positiv
                          float temperature, float* loss, float* grad_anchor, float* grad_positive,
                          void* stream);
 
+/* ---- text head after the frozen T5 encoder (f-4a), eval mode ------------------------------------ */
+/* Replaces: LanguageEncoder.forward from `description_encodings = out.last_hidden_state` up to and including `self.inter_mlp`
+ * (models/language_encoder.py:127-135): one nn.TransformerEncoderLayer(d_model 1024, 4 heads, dim_feedforward 4096, post-norm,
+ * ReLU, no padding mask) over the token positions of every sentence, max over the tokens, Linear(1024 -> D) + BatchNorm1d (eval).
+ * T5 itself and what follows inter_mlp (the D-wide inter-sentence layer of the coarse model, language_encoder.py:137-147, or
+ * nothing for the fine model) stay on PyTorch-ROCm. Weights: host fp32 blobs under `prefix` (NULL = "language_encoder."):
+ * intra_module.0.{self_attn.in_proj_weight [3072,1024], self_attn.in_proj_bias, self_attn.out_proj.{weight,bias},
+ * linear1.{weight [4096,1024],bias}, linear2.{weight [1024,4096],bias}, norm1.*, norm2.*}, inter_mlp.0.{0.weight [D,1024], 0.bias,
+ * 1.weight, 1.bias, 1.running_mean, 1.running_var}, D <= 256; intra_module_num_layers must be 1 (the reference's default,
+ * training/args.py:71). Synchronous; the library keeps packed copies.
+ * t2l_text_head: hidden = dev f32[n_sentences, n_tokens, 1024] (T5's last_hidden_state, sentence-major as the reference's
+ * tokenizer call produces it), 1 <= n_tokens <= 32; out = dev f32[n_sentences, D]. Arithmetic: split-f16 MFMA products with f32
+ * accumulation (~5e-7 relative; option "encoder_f16" = 1: one f16 product per operand pair, ~1e-4). *overflow (dev int32, may be
+ * NULL) is set to 1 when a value entering a product left the f16 range (|v| >= 3e4 or non-finite): `out` is then not to be
+ * trusted and the caller runs that batch on its f32 path. Option "text_head_rows" (default 16,384): token rows per pass. */
+int t2l_text_head_load_weights(t2l_ctx* ctx, const t2l_weight_desc* w, int32_t n, const char* prefix);
+int t2l_text_head(t2l_ctx* ctx, const float* hidden, int32_t n_sentences, int32_t n_tokens, float* out, int32_t* overflow,
+                  void* stream);
+
 /* ---- fine stage (f-1): CrossMatch downstream of the text branch, eval mode ---------------------- */
 /* Replaces CrossMatch.load_state_dict for everything except language_encoder.* (evaluation/pipeline.py:258-262): tensors named
  * as in the reference's fine checkpoint — object_encoder.* at fine_embed_dim = 128 (models/cross_matcher.py:57),

@@ -104,7 +104,8 @@ class ObjectEncoderParams(nn.Module):
 class LanguageEncoder(nn.Module):
     """Text branch (models/language_encoder.py:76-152): frozen T5 encoder -> 1 Transformer layer over tokens (no
     padding mask) -> max over tokens -> Linear+BN -> residual Transformer layer over the hint sentences -> max.
-    Stays on PyTorch-ROCm. ``llm_model``/``tokenizer`` may be injected (tests, precomputed-embedding runs)."""
+    T5 stays on PyTorch-ROCm; the d=1024 layer + max + inter_mlp behind it run in the HIP engine in eval mode on the GPU
+    (``_head_first_half``). ``llm_model``/``tokenizer`` may be injected (tests, precomputed-embedding runs)."""
 
     def __init__(self, embedding_dim: int, hungging_model: Optional[str] = None, fixed_embedding: bool = False,
                  intra_module_num_layers: int = 2, intra_module_num_heads: int = 4, is_fine: bool = False,
@@ -138,13 +139,45 @@ class LanguageEncoder(nn.Module):
     def split_sentences(text: str) -> List[str]:
         return [s for s in re.split(r"(?<=[.!?])\s+", text.strip()) if s]
 
-    def head(self, hidden: torch.Tensor, batch_size: int) -> torch.Tensor:
-        """hidden: last_hidden_state [n_sentences_total, L, C] -> [B, D] (language_encoder.py:127-148)."""
+    # ---- the head after T5 --------------------------------------------------------------------------------------------
+    use_engine_head = True   # eval mode on the GPU: intra_module + max + inter_mlp run in the HIP engine (t2l_text_head)
+    head_engine_calls = 0    # calls served by the engine / by the PyTorch path (f16-range overflow, training mode, CPU, ...)
+    head_torch_calls = 0
+
+    def _head_engine(self, device) -> Optional[Engine]:
+        """The engine context holding this head's packed weights on ``device`` (re-packed when a tensor changes)."""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        params = [t for n, t in self.state_dict(keep_vars=True).items() if n.startswith(("intra_module.", "inter_mlp."))]
+        version = (idx,) + tuple((t.data_ptr(), t._version) for t in params)
+        if getattr(self, "_th_version", None) != version:
+            if getattr(self, "_th_engine", None) is None or self._th_engine.device != idx:
+                self._th_engine = Engine(idx)
+            sd = {"language_encoder." + n: t for n, t in self.state_dict().items() if n.startswith(("intra_module.", "inter_mlp."))}
+            self._th_engine.text_head_load_weights(sd)
+            self._th_version = version
+        return self._th_engine
+
+    def _head_first_half(self, hidden: torch.Tensor) -> torch.Tensor:
+        """[n_sentences, L, C] -> [n_sentences, D]: intra_module over the tokens, max over the tokens, inter_mlp
+        (language_encoder.py:127-135). On the GPU in eval mode this is t2l_text_head (split-f16 MFMA GEMMs); the PyTorch
+        modules below it are the training path and the path of a batch whose activations leave the f16 range."""
+        if (self.use_engine_head and hidden.is_cuda and not self.training and not torch.is_grad_enabled() and len(self.intra_module) == 1
+                and hidden.shape[-1] == 1024 and 1 <= hidden.shape[1] <= 32 and self.inter_mlp[0][0].out_features <= 256
+                and self.intra_module[0].linear1.out_features == 4096 and self.intra_module[0].self_attn.num_heads == 4):
+            out, overflowed = self._head_engine(hidden.device).text_head(hidden.contiguous().float())
+            if not overflowed:
+                LanguageEncoder.head_engine_calls += 1
+                return out
+        LanguageEncoder.head_torch_calls += 1
         x = hidden.permute(1, 0, 2)
         for layer in self.intra_module:
             x = layer(x)
         x = x.permute(1, 0, 2).contiguous().max(dim=1)[0]
-        x = self.inter_mlp(x)
+        return self.inter_mlp(x)
+
+    def head(self, hidden: torch.Tensor, batch_size: int) -> torch.Tensor:
+        """hidden: last_hidden_state [n_sentences_total, L, C] -> [B, D] (language_encoder.py:127-148)."""
+        x = self._head_first_half(hidden)
         if x.shape[0] % batch_size:
             raise T2LError(f"{x.shape[0]} sentences do not split evenly over {batch_size} descriptions")
         x = x.view(batch_size, x.shape[0] // batch_size, -1)

@@ -103,6 +103,7 @@ void t2l_destroy(t2l_ctx* ctx) {
   free_train(ctx);
   free_pointnet(ctx);
   free_fine(ctx);
+  free_text_head(ctx);
   for (void* p : {(void*)ctx->db, (void*)ctx->db_split, (void*)ctx->db_half, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
                   (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count, ctx->reduce_ws, ctx->loss_ws, (void*)ctx->scan_span})
     if (p) (void)hipFree(p);
@@ -333,6 +334,19 @@ int t2l_contrastive_loss(t2l_ctx* ctx, const float* anchor, const float* positiv
   return loss_impl(ctx, anchor, positive, batch, temperature, loss, grad_anchor, grad_positive, (hipStream_t)stream);
 }
 
+int t2l_text_head_load_weights(t2l_ctx* ctx, const t2l_weight_desc* w, int32_t n, const char* prefix) {
+  if (!ctx) return T2L_EINVAL;
+  if (!w || n <= 0) return fail(ctx, T2L_EINVAL, "t2l_text_head_load_weights: null/empty arguments");
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return text_head_load_impl(ctx, w, n, prefix);
+}
+
+int t2l_text_head(t2l_ctx* ctx, const float* hidden, int32_t n_sentences, int32_t n_tokens, float* out, int32_t* overflow, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return text_head_impl(ctx, hidden, n_sentences, n_tokens, out, overflow, (hipStream_t)stream);
+}
+
 int t2l_fine_load_weights(t2l_ctx* ctx, const t2l_weight_desc* w, int32_t n, const t2l_model_config* cfg) {
   if (!ctx) return T2L_EINVAL;
   T2L_HIP(ctx, hipSetDevice(ctx->device));
@@ -421,6 +435,9 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     ctx->encoder_f32 = value != 0;
   } else if (!strcmp(name, "encoder_f16")) {
     ctx->encoder_f16 = value != 0;
+  } else if (!strcmp(name, "text_head_rows")) {
+    if (value < 0 || value > (1 << 22)) return fail(ctx, T2L_EINVAL, "text_head_rows: 0 (default) .. 4194304");
+    ctx->text_head_rows = (int)value;
   } else if (!strcmp(name, "search_auto")) {
     ctx->search_auto = value != 0;
     if (!ctx->search_auto) {  // forget the state and every report of a search launched so far

@@ -77,6 +77,8 @@ struct t2l_ctx {
   void* train = nullptr;         // t2l::TrainState (train.hip)
   void* pn = nullptr;            // t2l::PointNetWeights (pointnet.hip), null when no pointnet.* tensors were loaded
   void* fine = nullptr;          // t2l::FineWeights (fine.hip)
+  void* text_head = nullptr;     // t2l::th::Weights (text_head.hip)
+  int text_head_rows = 0;        // token rows per pass of the text head (0 = default 16,384)
   int pn_self_loops = 1;         // PyG PointConv add_self_loops quirk on the bipartite batch (oracle/t2l_oracle_pointnet.py)
   // options
   double eps_scale = 1.0;
@@ -182,6 +184,10 @@ int fine_encode_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float* out, hipSt
 int fine_match_impl(t2l_ctx* ctx, const float* cell_desc, const int32_t* cell_index, const float* hint_desc, const int32_t* hint_index,
                     int n_pairs, int n_hints, float* out, hipStream_t s);
 void free_fine(t2l_ctx* ctx);
+// text_head.hip
+int text_head_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const char* prefix);
+int text_head_impl(t2l_ctx* ctx, const float* hidden, int n_sentences, int n_tokens, float* out, int32_t* overflow, hipStream_t s);
+void free_text_head(t2l_ctx* ctx);
 // loss.hip
 int loss_impl(t2l_ctx* ctx, const float* a, const float* p, int B, float temp, float* loss, float* ga, float* gp,
               hipStream_t s);

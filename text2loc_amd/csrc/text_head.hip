@@ -1,0 +1,662 @@
+// The text head after the frozen T5 encoder on the f16 matrix pipe.
+//
+// Replaces: LanguageEncoder.forward downstream of `out.last_hidden_state` up to and including `inter_mlp`
+// (models/language_encoder.py:127-135): hidden [n_sentences, L, 1024] -> TransformerEncoderLayer(d_model = 1024, 4 heads,
+// dim_feedforward = 4096, post-norm, ReLU, NO padding mask) over the L token positions of every sentence -> max over the
+// tokens -> Linear(1024 -> D) + BatchNorm1d (eval, folded). T5 itself and the 256-wide inter-sentence layer behind it stay
+// on PyTorch-ROCm (north star); this is the part that costs: 25.2 MFLOP per token, 9.9 TFLOP for one search step's worth of
+// queries (4,096 descriptions x 6 hints x 16 tokens), 82 ms on rocBLAS f32.
+//
+// Arithmetic: split-f16 (mfma_h3.h): every f32 operand a = hi + lo, hi = f16(a), lo = f16(a - hi); a product is
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with f32 accumulation (~5e-7 relative) — or ONE product per pair with
+// option encoder_f16 (~1e-4, north-star bar 1e-3). Everything that enters a product is watched against the f16 range
+// (3e4): a call that leaves it raises the overflow flag and the caller (text2loc_amd.cell_retrieval.LanguageEncoder.head)
+// re-runs that batch on the PyTorch path.
+//
+// Data layout in HBM. Rows = tokens (sentence-major: row = sentence * L + token), padded to a multiple of 256.
+//   T16 (operands of the matrix pipe, as separate hi and lo planes): f16 [rows/32][cols/8][32][8] — for every 32-row tile
+//       and every 8-wide k chunk, 32 rows x 16 B = 512 B contiguous. That block IS the LDS image of a 32x8 operand
+//       fragment half (lane (row, kh) of a 32x32x16 MFMA reads 16 B at row * 16 of chunk 2 s + kh), so an LDS-DMA piece is a
+//       contiguous 1 KiB copy (two chunks) and every fragment read is one conflict-free ds_read_b128 at base + immediate.
+//       Weights [N][K] are packed the same way at load time.
+//   T32 (f32 intermediates that the matrix pipe does not read): f32 [rows/32][cols/4][32][4]: the 4 consecutive output
+//       columns a lane owns in the MFMA's C/D layout are one 16 B store and a wave's store is 1 KiB contiguous.
+//
+// Kernels:
+//   th_split_kernel   row-major f32 -> T16 hi/lo planes (the T5 hidden states; the pooled sentence vectors)
+//   th_gemm_kernel    C^T = W * X^T on 256 x 256 tiles, 8 waves (2 per SIMD), k in steps of 16 through a 4-slot LDS ring
+//                     (32 KiB per slot: W_hi, W_lo, X_hi, X_lo) filled by LDS-DMA three steps ahead; ONE s_waitcnt vmcnt +
+//                     s_barrier per step. The transposed product puts 4 consecutive output COLUMNS into one lane, so every
+//                     epilogue (bias, residual from T16 planes, ReLU, re-split) stores 8/16 B pieces that tile full lines.
+//   th_attn_kernel    softmax(q k^T / 16) v per (sentence, head), L <= 32 tokens, f32 on the VALU (0.3 % of the FLOPs)
+//   th_ln_kernel      LayerNorm over 1024 columns from T32, two-pass in registers; writes T16 planes, or (POOL) the max over
+//                     each sentence's tokens
+#include "mfma_h3.h"
+#include "search_dev.h"
+#include "t2l_internal.h"
+
+namespace t2l {
+namespace th {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kDM = 1024;      // d_model of the T5 encoder the head is built for (t5-large)
+constexpr int kFF = 4096;      // dim_feedforward = 4 * d_model (language_encoder.py:95)
+constexpr int kHeads = 4, kHD = 256;
+constexpr int kMaxL = 32;      // token positions per sentence the attention kernel holds
+constexpr int kTile = 256;     // GEMM tile (rows of X and rows of W per workgroup)
+constexpr int kSlotBytes = 32 * 1024, kSlots = 4, kPlaneBytes = 8 * 1024;
+
+__device__ __forceinline__ size_t t16_index(int m, int k, int cols) {  // element index into a T16 plane
+  return ((size_t)(m >> 5) * (cols >> 3) + (k >> 3)) * 256 + (m & 31) * 8 + (k & 7);
+}
+__device__ __forceinline__ size_t t32_index(int m, int n, int cols) {  // element index into a T32 array
+  return ((size_t)(m >> 5) * (cols >> 2) + (n >> 2)) * 128 + (m & 31) * 4 + (n & 3);
+}
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
+  hi = __builtin_convertvector(v, f16x4);
+  lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
+}
+__device__ __forceinline__ bool out_of_f16_range(const f32x4 v) {  // true for |v| >= 3e4, inf and NaN
+  return !(fabsf(v[0]) < kSplitF16Safe && fabsf(v[1]) < kSplitF16Safe && fabsf(v[2]) < kSplitF16Safe && fabsf(v[3]) < kSplitF16Safe);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// row-major f32 [M][C] -> T16 hi / lo planes of M_pad rows (rows >= M are written as zeros). One workgroup per 32 rows x 256
+// columns; thread (row, chunk group): consecutive threads write one 512-byte block.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void th_split_kernel(const float* __restrict__ x, int M, int C, _Float16* __restrict__ hi,
+                                                       _Float16* __restrict__ lo, int* __restrict__ flag) {
+  const int r = threadIdx.x & 31, cg = threadIdx.x >> 5;
+  const int m = blockIdx.x * 32 + r, col0 = blockIdx.y * 256;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = col0 + (cg * 4 + j) * 8;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (m < M) {
+      a = *reinterpret_cast<const f32x4*>(x + (size_t)m * C + k);
+      b = *reinterpret_cast<const f32x4*>(x + (size_t)m * C + k + 4);
+    }
+    bad = bad || out_of_f16_range(a) || out_of_f16_range(b);
+    f16x4 ah, al, bh, bl;
+    split4(a, ah, al);
+    split4(b, bh, bl);
+    const size_t o = t16_index(m, k, C);
+    *reinterpret_cast<f16x8*>(hi + o) = f16x8{ah[0], ah[1], ah[2], ah[3], bh[0], bh[1], bh[2], bh[3]};
+    *reinterpret_cast<f16x8*>(lo + o) = f16x8{al[0], al[1], al[2], al[3], bl[0], bl[1], bl[2], bl[3]};
+  }
+  if (bad) atomicOr(flag, 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The GEMM. Workgroup (m tile, n tile): OUT[m][n] = sum_k X[m][k] W[n][k] for 256 rows x 256 columns, computed transposed
+// (MFMA A operand = 32 rows of W, B operand = 32 rows of X) so that lane (c, kh) of accumulator tile (nt, mt) holds row
+// m = 32 mt + c and columns n = 32 nt + 8 g + 4 kh + {0,1,2,3} in registers 4 g .. 4 g + 3.
+// Wave w: wm = w & 1 -> rows [128 wm, +128) (4 tiles), wn = w >> 1 -> columns [64 wn, +64) (2 tiles): 8 accumulators,
+// per k-step 12 fragment reads (SINGLE: 6) feed 24 MFMAs (SINGLE: 8).
+// ---------------------------------------------------------------------------------------------------------------
+enum Epi { kEpiT32 = 0, kEpiResidT32 = 1, kEpiReluT16 = 2, kEpiRowMajor = 3 };
+
+struct GemmArgs {
+  const char *wh, *wl;   // T16 planes of W [n_pad][K]
+  const char *xh, *xl;   // T16 planes of X [m_pad][K]
+  const float* bias;     // [n_pad]
+  const char *rh, *rl;   // kEpiResidT32: T16 planes of the residual [m_pad][N]
+  void *out0, *out1;     // T32 f32 | T16 hi, lo | row-major f32
+  int* flag;             // overflow flag (kEpiReluT16)
+  int m_tiles, n_tiles, K, N, M, n_real;  // N = output columns of the tiled layouts (= 256 n_tiles), M / n_real: row-major bounds
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int EPI, bool SINGLE>
+__global__ __launch_bounds__(512, 1) void th_gemm_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PPW = SINGLE ? 2 : 4;  // LDS-DMA pieces (1 KiB) per wave and k-step
+  const int lane = threadIdx.x & 63, w = uniform_wave_id();
+  // blockIdx -> tile: the n tiles of one m tile run back to back on ONE XCD (blockIdx % 8), so the X rows of an m tile are
+  // fetched from HBM once and every XCD's L2 keeps the weights
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int mt_idx = (seq / p.n_tiles) * 8 + xcd, nt_idx = seq % p.n_tiles;
+  if (mt_idx >= p.m_tiles) return;
+  const int K = p.K, KT = K >> 4;
+  const size_t rt_stride = (size_t)K * 64;  // bytes between consecutive 32-row tiles of a T16 plane
+
+  // ---- this wave's DMA pieces: piece ids [w * PPW, +PPW) of the slot; plane = id / 8, row tile = id % 8
+  const int pid0 = w * PPW;
+  const int plane = pid0 >> 3, rt0 = pid0 & 7;
+  const char* src;
+  unsigned dst_off;
+  if constexpr (SINGLE) {
+    src = plane == 0 ? p.wh : p.xh;
+    dst_off = (plane == 0 ? 0u : 2u * kPlaneBytes) + rt0 * 1024;
+  } else {
+    src = plane == 0 ? p.wh : plane == 1 ? p.wl : plane == 2 ? p.xh : p.xl;
+    dst_off = plane * kPlaneBytes + rt0 * 1024;
+  }
+  const bool is_w = SINGLE ? plane == 0 : plane < 2;
+  src += ((size_t)(is_w ? nt_idx : mt_idx) * 8 + rt0) * rt_stride;
+  unsigned voff[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) voff[j] = (unsigned)(lane * 16) + (unsigned)(j * rt_stride);
+  const unsigned lds0 = lds_addr_of(smem);
+  auto issue = [&](int kt) {
+    const unsigned dst = lds0 + (kt & 3) * kSlotBytes + dst_off;
+    const char* s = src + (size_t)kt * 1024;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) lds_dma_row(dst + j * 1024, voff[j], s);
+  };
+
+  h3_f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int wm = w & 1, wn = w >> 1;
+  const char* fr = smem + lane * 16;
+  const int w_off = wn * 2 * 1024, x_off = 2 * kPlaneBytes + wm * 4 * 1024;
+
+  issue(0);
+  if (KT > 1) issue(1);
+  if (KT > 2) issue(2);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int ahead = min(KT - 1, kt + 2) - kt;  // k-steps issued behind step kt
+    if (ahead >= 2) wait_vmcnt<2 * PPW>();
+    else if (ahead == 1) wait_vmcnt<PPW>();
+    else wait_vmcnt<0>();
+    asm volatile("s_barrier" ::: "memory");  // every wave's pieces of step kt have landed; everybody is done reading step kt-1
+    if (kt + 3 < KT) issue(kt + 3);          // ... whose slot is refilled
+    const char* sb = fr + (kt & 3) * kSlotBytes;
+    f16x8 xh[4], xl[4], wh[2], wl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      wh[i] = *reinterpret_cast<const f16x8*>(sb + w_off + i * 1024);
+      if constexpr (!SINGLE) wl[i] = *reinterpret_cast<const f16x8*>(sb + kPlaneBytes + w_off + i * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xh[i] = *reinterpret_cast<const f16x8*>(sb + x_off + i * 1024);
+      if constexpr (!SINGLE) xl[i] = *reinterpret_cast<const f16x8*>(sb + kPlaneBytes + x_off + i * 1024);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[a], xh[b], acc[a][b], 0, 0, 0);
+        if constexpr (!SINGLE) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[a], xl[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[a], xh[b], acc[a][b], 0, 0, 0);
+        }
+      }
+  }
+
+  // ---- epilogue. Loads are issued in batches (the 8 bias vectors up front, a tile's 8 residual pieces together) so that the
+  // wave pays one memory latency per batch, not one per piece
+  const int c = lane & 31, kh = lane >> 5;
+  bool bad = false;
+  f32x4 bias_v[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias_v[a][g] = *reinterpret_cast<const f32x4*>(p.bias + nt_idx * kTile + wn * 64 + a * 32 + 8 * g + 4 * kh);
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int n_base = nt_idx * kTile + wn * 64 + a * 32;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int m = mt_idx * kTile + wm * 128 + b * 32 + c;
+      f16x4 rh[4], rl[4];
+      if constexpr (EPI == kEpiResidT32) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const size_t ro = t16_index(m, n_base + 8 * g + 4 * kh, p.N);
+          rh[g] = *reinterpret_cast<const f16x4*>((const _Float16*)p.rh + ro);
+          rl[g] = *reinterpret_cast<const f16x4*>((const _Float16*)p.rl + ro);  // (SINGLE too: the residual stays exact)
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n0 = n_base + 8 * g + 4 * kh;
+        const f32x4 bv = bias_v[a][g];
+        f32x4 v = {acc[a][b][4 * g] + bv[0], acc[a][b][4 * g + 1] + bv[1], acc[a][b][4 * g + 2] + bv[2], acc[a][b][4 * g + 3] + bv[3]};
+        if constexpr (EPI == kEpiT32) {
+          *reinterpret_cast<f32x4*>((float*)p.out0 + t32_index(m, n0, p.N)) = v;
+        } else if constexpr (EPI == kEpiResidT32) {
+          const f32x4 res = __builtin_convertvector(rh[g], f32x4) + __builtin_convertvector(rl[g], f32x4);
+          *reinterpret_cast<f32x4*>((float*)p.out0 + t32_index(m, n0, p.N)) = v + res;
+        } else if constexpr (EPI == kEpiReluT16) {
+          v = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+          bad = bad || (m < p.M && out_of_f16_range(v));  // (padding rows carry whatever the buffers held)
+          f16x4 hi, lo;
+          split4(v, hi, lo);
+          const size_t o = t16_index(m, n0, p.N);
+          *reinterpret_cast<f16x4*>((_Float16*)p.out0 + o) = hi;
+          if constexpr (!SINGLE) *reinterpret_cast<f16x4*>((_Float16*)p.out1 + o) = lo;
+        } else {  // row-major f32 [M][n_real]
+          if (m < p.M && n0 < p.n_real) *reinterpret_cast<f32x4*>((float*)p.out0 + (size_t)m * p.n_real + n0) = v;
+        }
+      }
+    }
+  }
+  if constexpr (EPI == kEpiReluT16) {
+    if (bad) atomicOr(p.flag, 1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Self-attention over the L token positions of one sentence, one wave per (sentence, head), no mask
+// (nn.TransformerEncoderLayer as language_encoder.py:130-131 calls it). qkv: T32 [m_pad][3072] (q | k | v, head h at columns
+// 256 h). Lane (i, hf): token i (idle when i >= L), feature half hf. k and v of the head sit in LDS (rows of 260 floats);
+// q and the output never do.
+// ---------------------------------------------------------------------------------------------------------------
+template <int LMAX>
+__global__ __launch_bounds__(64) void th_attn_kernel(const float* __restrict__ qkv, int L, _Float16* __restrict__ ohi,
+                                                     _Float16* __restrict__ olo, int* __restrict__ flag) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RS = 260;  // LDS row stride in floats
+  float* Ks = reinterpret_cast<float*>(smem);
+  float* Vs = Ks + LMAX * RS;
+  const int s = blockIdx.x >> 2, h = blockIdx.x & 3;
+  const int lane = threadIdx.x, i = lane & 31, hf = lane >> 5;
+  const int m = s * L + i;
+  const bool live = i < L;
+  const int N3 = 3 * kDM;
+  if (live) {
+#pragma unroll 8
+    for (int cq = 0; cq < 32; ++cq) {
+      const int col = h * kHD + 4 * (hf * 32 + cq);
+      *reinterpret_cast<f32x4*>(Ks + i * RS + 4 * (hf * 32 + cq)) = *reinterpret_cast<const f32x4*>(qkv + t32_index(m, kDM + col, N3));
+      *reinterpret_cast<f32x4*>(Vs + i * RS + 4 * (hf * 32 + cq)) = *reinterpret_cast<const f32x4*>(qkv + t32_index(m, 2 * kDM + col, N3));
+    }
+  }
+  __syncthreads();
+  float sc[LMAX];
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) sc[j] = 0.f;
+  if (live) {
+#pragma unroll 2
+    for (int cq = 0; cq < 32; ++cq) {
+      const int d = 4 * (hf * 32 + cq);
+      const f32x4 q = *reinterpret_cast<const f32x4*>(qkv + t32_index(m, h * kHD + d, N3));
+#pragma unroll
+      for (int j = 0; j < LMAX; ++j)
+        if (j < L) {
+          const f32x4 kv = *reinterpret_cast<const f32x4*>(Ks + j * RS + d);
+          sc[j] += q[0] * kv[0] + q[1] * kv[1] + q[2] * kv[2] + q[3] * kv[3];
+        }
+    }
+  }
+  float mx = -__builtin_inff();
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) {
+    sc[j] += __shfl_xor(sc[j], 32);  // the two feature halves
+    if (j < L) mx = fmaxf(mx, sc[j]);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) {
+    sc[j] = j < L ? expf((sc[j] - mx) * 0.0625f) : 0.f;  // / sqrt(head_dim = 256)
+    sum += sc[j];
+  }
+  const float inv = 1.f / sum;
+  if (!live) return;
+  bool bad = false;
+#pragma unroll 2
+  for (int cp = 0; cp < 16; ++cp) {  // two quads = one 8-wide chunk per step: 16-byte stores
+    const int d = 8 * (hf * 16 + cp);
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+#pragma unroll
+    for (int j = 0; j < LMAX; ++j)
+      if (j < L) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(Vs + j * RS + d), v1 = *reinterpret_cast<const f32x4*>(Vs + j * RS + d + 4);
+        o0 += sc[j] * v0;
+        o1 += sc[j] * v1;
+      }
+    o0 *= inv;
+    o1 *= inv;
+    bad = bad || out_of_f16_range(o0) || out_of_f16_range(o1);
+    f16x4 h0, l0, h1, l1;
+    split4(o0, h0, l0);
+    split4(o1, h1, l1);
+    const size_t o = t16_index(m, h * kHD + d, kDM);
+    *reinterpret_cast<f16x8*>(ohi + o) = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    *reinterpret_cast<f16x8*>(olo + o) = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+  }
+  if (bad) atomicOr(flag, 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm over the 1024 columns of every row (eps 1e-5, biased variance, two passes over registers), input T32.
+// One workgroup per 32-row tile; thread (r, g) holds quads g, g + 8, ..., g + 248 of row r (128 floats).
+// POOL = false: writes the T16 hi / lo planes (the next GEMM's operand and residual).
+// POOL = true : max over the L token rows of each sentence -> pooled [n_sentences][1024] row-major (pre-filled with -inf;
+//               sentences that lie inside this tile are stored, straddlers meet through float atomic max).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+  if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(256) void th_ln_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, int M, int L, _Float16* __restrict__ hi,
+                                                    _Float16* __restrict__ lo, float* __restrict__ pooled, int* __restrict__ flag) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);  // [8][32]
+  const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int rt = blockIdx.x, m = rt * 32 + r;
+  const float* base = y + (size_t)rt * (kDM / 4) * 128 + r * 4;
+  f32x4 v[32];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    v[j] = *reinterpret_cast<const f32x4*>(base + (size_t)(j * 8 + g) * 128);
+    s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  }
+  red[g * 32 + r] = s;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) mean += red[k * 32 + r];
+  mean *= 1.f / kDM;
+  __syncthreads();
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    v[j] -= mean;
+    q += (v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3]);
+  }
+  red[g * 32 + r] = q;
+  __syncthreads();
+  float var = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) var += red[k * 32 + r];
+  const float rstd = 1.f / sqrtf(var * (1.f / kDM) + 1e-5f);
+  bool bad = false;
+  if constexpr (!POOL) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int n0 = 4 * (j * 8 + g);
+      const f32x4 o = v[j] * rstd * *reinterpret_cast<const f32x4*>(gamma + n0) + *reinterpret_cast<const f32x4*>(beta + n0);
+      bad = bad || (m < M && out_of_f16_range(o));
+      f16x4 h, l;
+      split4(o, h, l);
+      const size_t off = t16_index(m, n0, kDM);
+      *reinterpret_cast<f16x4*>(hi + off) = h;
+      *reinterpret_cast<f16x4*>(lo + off) = l;
+    }
+    if (bad) atomicOr(flag, 1);
+  } else {
+    __syncthreads();
+    constexpr int RS = kDM + 4;
+    float* tile = reinterpret_cast<float*>(smem);  // [32][1028]
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int n0 = 4 * (j * 8 + g);
+      *reinterpret_cast<f32x4*>(tile + r * RS + n0) =
+          v[j] * rstd * *reinterpret_cast<const f32x4*>(gamma + n0) + *reinterpret_cast<const f32x4*>(beta + n0);
+    }
+    __syncthreads();
+    const int n0 = threadIdx.x * 4, m0 = rt * 32;
+    int row = 0;
+    while (row < 32 && m0 + row < M) {
+      const int sent = (m0 + row) / L;
+      const int first = sent * L, last = first + L - 1;  // the sentence's rows
+      const int end = min(32, last - m0 + 1);
+      f32x4 mx = *reinterpret_cast<const f32x4*>(tile + row * RS + n0);
+      for (int k = row + 1; k < end; ++k) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(tile + k * RS + n0);
+        mx = {fmaxf(mx[0], t[0]), fmaxf(mx[1], t[1]), fmaxf(mx[2], t[2]), fmaxf(mx[3], t[3])};
+      }
+      float* dstp = pooled + (size_t)sent * kDM + n0;
+      if (first >= m0 && last < m0 + 32) {
+        *reinterpret_cast<f32x4*>(dstp) = mx;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomic_max_f32(dstp + e, mx[e]);
+      }
+      row = end;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+struct Weights {
+  // T16 planes (device) + biases; one encoder layer + inter_mlp
+  char *qkv_h = nullptr, *qkv_l = nullptr, *out_h = nullptr, *out_l = nullptr, *ff1_h = nullptr, *ff1_l = nullptr, *ff2_h = nullptr,
+       *ff2_l = nullptr, *mlp_h = nullptr, *mlp_l = nullptr;
+  float *qkv_b = nullptr, *out_b = nullptr, *ff1_b = nullptr, *ff2_b = nullptr, *mlp_b = nullptr, *ln1_g = nullptr, *ln1_b = nullptr,
+        *ln2_g = nullptr, *ln2_b = nullptr;
+  int out_dim = 0;  // D of inter_mlp (256 coarse, 128 fine)
+  // workspace
+  char* ws = nullptr;
+  size_t ws_cap = 0;
+  int* flag = nullptr;        // device overflow flag
+  int* flag_host = nullptr;   // pinned copy target
+  std::vector<void*> owned;
+};
+
+static void pack_t16(const float* W, int rows, int rows_pad, int K, std::vector<uint16_t>& hi, std::vector<uint16_t>& lo) {
+  hi.assign((size_t)rows_pad * K, 0);
+  lo.assign((size_t)rows_pad * K, 0);
+  for (int n = 0; n < rows; ++n)
+    for (int k = 0; k < K; ++k) {
+      const float w = W[(size_t)n * K + k];
+      const _Float16 h = (_Float16)w;
+      const _Float16 l = (_Float16)(w - (float)h);
+      const size_t o = ((size_t)(n >> 5) * (K >> 3) + (k >> 3)) * 256 + (n & 31) * 8 + (k & 7);
+      memcpy(&hi[o], &h, 2);
+      memcpy(&lo[o], &l, 2);
+    }
+}
+
+}  // namespace th
+
+using th::Weights;
+
+static const t2l_weight_desc* th_find(const t2l_weight_desc* w, int n, const std::string& name, int64_t numel) {
+  for (int i = 0; i < n; ++i)
+    if (w[i].name && name == w[i].name) return w[i].numel == numel ? &w[i] : nullptr;
+  return nullptr;
+}
+
+void free_text_head(t2l_ctx* ctx) {
+  Weights* W = (Weights*)ctx->text_head;
+  if (!W) return;
+  for (void* p : W->owned) (void)hipFree(p);
+  if (W->ws) (void)hipFree(W->ws);
+  if (W->flag) (void)hipFree(W->flag);
+  if (W->flag_host) (void)hipHostFree(W->flag_host);
+  delete W;
+  ctx->text_head = nullptr;
+}
+
+int text_head_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const char* prefix) {
+  using namespace th;
+  const std::string P = prefix ? prefix : "language_encoder.";
+  const std::string L0 = P + "intra_module.0.";
+  if (th_find(w, n, P + "intra_module.1.linear1.weight", (int64_t)kFF * kDM))
+    return fail(ctx, T2L_EINVAL, "t2l_text_head_load_weights: the engine's text head is built for intra_module_num_layers = 1");
+  struct Req { const char* key; int64_t numel; };
+  const Req req[] = {{"self_attn.in_proj_weight", 3ll * kDM * kDM}, {"self_attn.in_proj_bias", 3 * kDM},
+                     {"self_attn.out_proj.weight", (int64_t)kDM * kDM}, {"self_attn.out_proj.bias", kDM},
+                     {"linear1.weight", (int64_t)kFF * kDM}, {"linear1.bias", kFF}, {"linear2.weight", (int64_t)kDM * kFF},
+                     {"linear2.bias", kDM}, {"norm1.weight", kDM}, {"norm1.bias", kDM}, {"norm2.weight", kDM}, {"norm2.bias", kDM}};
+  const t2l_weight_desc* t[12];
+  for (int i = 0; i < 12; ++i) {
+    t[i] = th_find(w, n, L0 + req[i].key, req[i].numel);
+    if (!t[i]) return fail(ctx, T2L_EINVAL, "t2l_text_head_load_weights: missing or mis-sized tensor " + L0 + req[i].key +
+                                                " (the engine's text head is built for d_model 1024, dim_feedforward 4096)");
+  }
+  // inter_mlp = Linear(1024 -> D) + BatchNorm1d, eval mode: folded
+  const std::string M0 = P + "inter_mlp.0.";
+  int D = 0;
+  const t2l_weight_desc* mw = nullptr;
+  for (int i = 0; i < n; ++i)
+    if (w[i].name && M0 + "0.weight" == w[i].name) { mw = &w[i]; D = (int)(w[i].numel / kDM); }
+  if (!mw || D <= 0 || D > 256 || (int64_t)D * kDM != mw->numel || D % 4)
+    return fail(ctx, T2L_EINVAL, "t2l_text_head_load_weights: inter_mlp.0.0.weight missing or not [D <= 256][1024]");
+  const t2l_weight_desc *mb = th_find(w, n, M0 + "0.bias", D), *bg = th_find(w, n, M0 + "1.weight", D), *bb = th_find(w, n, M0 + "1.bias", D),
+                        *bm = th_find(w, n, M0 + "1.running_mean", D), *bv = th_find(w, n, M0 + "1.running_var", D);
+  if (!mb || !bg || !bb || !bm || !bv) return fail(ctx, T2L_EINVAL, "t2l_text_head_load_weights: inter_mlp.0 Linear/BatchNorm tensors missing");
+  free_text_head(ctx);
+  Weights* W = new Weights();
+  ctx->text_head = W;
+  W->out_dim = D;
+  std::vector<uint16_t> hi, lo;
+  auto upload = [&](const void* host, size_t bytes, void** dev) -> int {
+    T2L_HIP(ctx, hipMalloc(dev, bytes));
+    W->owned.push_back(*dev);
+    T2L_HIP(ctx, hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+    return T2L_OK;
+  };
+  auto planes = [&](const float* src, int rows, int K, char** dh, char** dl) -> int {
+    const int rows_pad = (rows + kTile - 1) / kTile * kTile;
+    pack_t16(src, rows, rows_pad, K, hi, lo);
+    int rc = upload(hi.data(), hi.size() * 2, (void**)dh);
+    return rc ? rc : upload(lo.data(), lo.size() * 2, (void**)dl);
+  };
+  auto vec = [&](const float* src, int nn, int pad, float** d) -> int {
+    std::vector<float> v(pad, 0.f);
+    memcpy(v.data(), src, sizeof(float) * nn);
+    return upload(v.data(), sizeof(float) * pad, (void**)d);
+  };
+  int rc;
+  if ((rc = planes(t[0]->data, 3 * kDM, kDM, &W->qkv_h, &W->qkv_l)) || (rc = vec(t[1]->data, 3 * kDM, 3 * kDM, &W->qkv_b)) ||
+      (rc = planes(t[2]->data, kDM, kDM, &W->out_h, &W->out_l)) || (rc = vec(t[3]->data, kDM, kDM, &W->out_b)) ||
+      (rc = planes(t[4]->data, kFF, kDM, &W->ff1_h, &W->ff1_l)) || (rc = vec(t[5]->data, kFF, kFF, &W->ff1_b)) ||
+      (rc = planes(t[6]->data, kDM, kFF, &W->ff2_h, &W->ff2_l)) || (rc = vec(t[7]->data, kDM, kDM, &W->ff2_b)) ||
+      (rc = vec(t[8]->data, kDM, kDM, &W->ln1_g)) || (rc = vec(t[9]->data, kDM, kDM, &W->ln1_b)) ||
+      (rc = vec(t[10]->data, kDM, kDM, &W->ln2_g)) || (rc = vec(t[11]->data, kDM, kDM, &W->ln2_b)))
+    return rc;
+  {  // y = ((x W^T + b) - mean) * gamma / sqrt(var + eps) + beta
+    std::vector<float> wf((size_t)D * kDM), bf(kTile, 0.f);
+    for (int o = 0; o < D; ++o) {
+      const float sc = bg->data[o] / sqrtf(bv->data[o] + 1e-5f);
+      for (int k = 0; k < kDM; ++k) wf[(size_t)o * kDM + k] = mw->data[(size_t)o * kDM + k] * sc;
+      bf[o] = (mb->data[o] - bm->data[o]) * sc + bb->data[o];
+    }
+    if ((rc = planes(wf.data(), D, kDM, &W->mlp_h, &W->mlp_l)) || (rc = upload(bf.data(), sizeof(float) * kTile, (void**)&W->mlp_b))) return rc;
+  }
+  T2L_HIP(ctx, hipMalloc(&W->flag, sizeof(int)));
+  T2L_HIP(ctx, hipMemset(W->flag, 0, sizeof(int)));
+  T2L_HIP(ctx, hipHostMalloc((void**)&W->flag_host, sizeof(int), hipHostMallocDefault));
+  *W->flag_host = 0;
+  static bool attr_done = false;
+  if (!attr_done) {
+    const int lds = kSlots * kSlotBytes;
+#define T2L_TH_ATTR(E, S) T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&th_gemm_kernel<E, S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
+    T2L_TH_ATTR(kEpiT32, false); T2L_TH_ATTR(kEpiT32, true); T2L_TH_ATTR(kEpiResidT32, false); T2L_TH_ATTR(kEpiResidT32, true);
+    T2L_TH_ATTR(kEpiReluT16, false); T2L_TH_ATTR(kEpiReluT16, true); T2L_TH_ATTR(kEpiRowMajor, false); T2L_TH_ATTR(kEpiRowMajor, true);
+#undef T2L_TH_ATTR
+    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&th_ln_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1028 * 4));
+    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&th_attn_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 260 * 4));
+    attr_done = true;
+  }
+  return T2L_OK;
+}
+
+template <int EPI>
+static void th_launch_gemm(bool single, const th::GemmArgs& a, hipStream_t s) {
+  const int grid = (a.m_tiles + 7) / 8 * 8 * a.n_tiles;
+  const int lds = th::kSlots * th::kSlotBytes;
+  if (single) hipLaunchKernelGGL((th::th_gemm_kernel<EPI, true>), dim3(grid), dim3(512), lds, s, a);
+  else hipLaunchKernelGGL((th::th_gemm_kernel<EPI, false>), dim3(grid), dim3(512), lds, s, a);
+}
+
+int text_head_impl(t2l_ctx* ctx, const float* hidden, int n_sent, int L, float* out, int32_t* overflow, hipStream_t s) {
+  using namespace th;
+  Weights* W = (Weights*)ctx->text_head;
+  if (!W) return fail(ctx, T2L_ESTATE, "t2l_text_head: call t2l_text_head_load_weights first");
+  if (!hidden || !out) return fail(ctx, T2L_EINVAL, "t2l_text_head: null buffer");
+  if (n_sent <= 0) return n_sent == 0 ? T2L_OK : fail(ctx, T2L_EINVAL, "t2l_text_head: n_sentences < 0");
+  if (L < 1 || L > kMaxL) return fail(ctx, T2L_EINVAL, "t2l_text_head: need 1 <= n_tokens <= 32");
+  const bool single = ctx->encoder_f16 != 0;
+  // sentences per pass: ~16 k token rows keep every intermediate of a pass inside the 256 MB Infinity Cache and make every
+  // GEMM grid a multiple of the 256 CUs (64 m tiles x 12 / 4 / 16 / 4 n tiles)
+  const int rows_target = ctx->text_head_rows > 0 ? ctx->text_head_rows : 16384;
+  const int spc = max(1, min(n_sent, rows_target / L));
+  const int m_cap = (spc * L + kTile - 1) / kTile * kTile;
+  const int n_chunks = (n_sent + spc - 1) / spc;
+  const int sp_cap = (n_sent + kTile - 1) / kTile * kTile;  // pooled rows (all sentences), padded
+  // workspace: X planes, QKV (T32), O planes, Y (T32), X1 planes, H planes; pooled f32 + its planes
+  const size_t plane = (size_t)m_cap * kDM * 2;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_xh = take(plane), o_xl = take(plane), o_qkv = take((size_t)m_cap * 3 * kDM * 4), o_oh = take(plane), o_ol = take(plane),
+               o_y = take((size_t)m_cap * kDM * 4), o_1h = take(plane), o_1l = take(plane), o_hh = take(plane * 4), o_hl = take(plane * 4),
+               o_pool = take((size_t)sp_cap * kDM * 4), o_ph = take((size_t)sp_cap * kDM * 2), o_pl = take((size_t)sp_cap * kDM * 2);
+  if (W->ws_cap < off) {
+    if (W->ws) T2L_HIP(ctx, hipFree(W->ws));
+    W->ws = nullptr;
+    W->ws_cap = 0;
+    T2L_HIP(ctx, hipMalloc(&W->ws, off));
+    W->ws_cap = off;
+  }
+  char* ws = W->ws;
+  T2L_HIP(ctx, hipMemsetAsync(W->flag, 0, sizeof(int), s));
+  T2L_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ws + o_pool), (int)0xFF800000u, (size_t)sp_cap * kDM, s));  // -inf
+  event_begin(ctx, "text_head", s);
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    const int s0 = ch * spc, ns = min(spc, n_sent - s0);
+    const int M = ns * L, m_tiles = (M + kTile - 1) / kTile, m_pad = m_tiles * kTile;
+    const float* x = hidden + (size_t)s0 * L * kDM;
+    hipLaunchKernelGGL(th_split_kernel, dim3(m_pad / 32, kDM / 256), dim3(256), 0, s, x, M, kDM, (_Float16*)(ws + o_xh), (_Float16*)(ws + o_xl), W->flag);
+    GemmArgs g{};
+    g.flag = W->flag;
+    g.m_tiles = m_tiles;
+    g.M = M;
+    // q | k | v = x W_in^T + b_in  -> T32
+    g.wh = W->qkv_h; g.wl = W->qkv_l; g.xh = ws + o_xh; g.xl = ws + o_xl; g.bias = W->qkv_b; g.out0 = ws + o_qkv;
+    g.n_tiles = 3 * kDM / kTile; g.K = kDM; g.N = 3 * kDM; g.n_real = 3 * kDM;
+    th_launch_gemm<kEpiT32>(single, g, s);
+    if (L <= 16)
+      hipLaunchKernelGGL(th_attn_kernel<16>, dim3(ns * kHeads), dim3(64), 2 * 16 * 260 * 4, s, (const float*)(ws + o_qkv), L, (_Float16*)(ws + o_oh),
+                         (_Float16*)(ws + o_ol), W->flag);
+    else
+      hipLaunchKernelGGL(th_attn_kernel<32>, dim3(ns * kHeads), dim3(64), 2 * 32 * 260 * 4, s, (const float*)(ws + o_qkv), L, (_Float16*)(ws + o_oh),
+                         (_Float16*)(ws + o_ol), W->flag);
+    // y = x + o W_out^T + b_out -> T32; x1 = LayerNorm1(y) -> planes
+    g.wh = W->out_h; g.wl = W->out_l; g.xh = ws + o_oh; g.xl = ws + o_ol; g.bias = W->out_b; g.rh = ws + o_xh; g.rl = ws + o_xl; g.out0 = ws + o_y;
+    g.n_tiles = kDM / kTile; g.K = kDM; g.N = kDM; g.n_real = kDM;
+    th_launch_gemm<kEpiResidT32>(single, g, s);
+    hipLaunchKernelGGL(th_ln_kernel<false>, dim3(m_pad / 32), dim3(256), 8 * 32 * 4, s, (const float*)(ws + o_y), W->ln1_g, W->ln1_b, M, L,
+                       (_Float16*)(ws + o_1h), (_Float16*)(ws + o_1l), (float*)nullptr, W->flag);
+    // h = relu(x1 W_1^T + b_1) -> planes; y2 = x1 + h W_2^T + b_2 -> T32
+    g.wh = W->ff1_h; g.wl = W->ff1_l; g.xh = ws + o_1h; g.xl = ws + o_1l; g.bias = W->ff1_b; g.out0 = ws + o_hh; g.out1 = ws + o_hl;
+    g.n_tiles = kFF / kTile; g.K = kDM; g.N = kFF; g.n_real = kFF;
+    th_launch_gemm<kEpiReluT16>(single, g, s);
+    g.wh = W->ff2_h; g.wl = W->ff2_l; g.xh = ws + o_hh; g.xl = ws + o_hl; g.bias = W->ff2_b; g.rh = ws + o_1h; g.rl = ws + o_1l; g.out0 = ws + o_y;
+    g.n_tiles = kDM / kTile; g.K = kFF; g.N = kDM; g.n_real = kDM;
+    th_launch_gemm<kEpiResidT32>(single, g, s);
+    // LayerNorm2 + max over the sentence's tokens -> pooled rows [s0, s0 + ns)
+    hipLaunchKernelGGL(th_ln_kernel<true>, dim3(m_pad / 32), dim3(256), 32 * 1028 * 4, s, (const float*)(ws + o_y), W->ln2_g, W->ln2_b, M, L,
+                       (_Float16*)nullptr, (_Float16*)nullptr, (float*)(ws + o_pool) + (size_t)s0 * kDM, W->flag);
+  }
+  // inter_mlp (Linear + folded BatchNorm) on the pooled sentence vectors -> out [n_sent][D] row-major
+  hipLaunchKernelGGL(th_split_kernel, dim3(sp_cap / 32, kDM / 256), dim3(256), 0, s, (const float*)(ws + o_pool), n_sent, kDM, (_Float16*)(ws + o_ph),
+                     (_Float16*)(ws + o_pl), W->flag);
+  {
+    GemmArgs g{};
+    g.flag = W->flag;
+    g.m_tiles = sp_cap / kTile; g.M = n_sent;
+    g.wh = W->mlp_h; g.wl = W->mlp_l; g.xh = ws + o_ph; g.xl = ws + o_pl; g.bias = W->mlp_b; g.out0 = out;
+    g.n_tiles = 1; g.K = kDM; g.N = kTile; g.n_real = W->out_dim;
+    th_launch_gemm<kEpiRowMajor>(single, g, s);
+  }
+  event_end(ctx, "text_head", s);
+  if (overflow) T2L_HIP(ctx, hipMemcpyAsync(overflow, W->flag, sizeof(int), hipMemcpyDeviceToDevice, s));
+  T2L_HIP(ctx, hipGetLastError());
+  return T2L_OK;
+}
+
+}  // namespace t2l

@@ -70,6 +70,8 @@ EXPORTS = {
     "t2l_search_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "t2l_contrastive_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "t2l_text_head_load_weights": (C.c_int, [C.c_void_p, C.POINTER(_WeightDesc), C.c_int32, C.c_char_p]),
+    "t2l_text_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_fine_load_weights": (C.c_int, [C.c_void_p, C.POINTER(_WeightDesc), C.c_int32, C.POINTER(_ModelConfig)]),
     "t2l_fine_encode_objects": (C.c_int, [C.c_void_p, C.POINTER(_PackedCells), C.c_void_p, C.c_void_p]),
     "t2l_fine_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
@@ -247,6 +249,36 @@ class Engine:
             _dev_ptr(packed.get("pn_feat"), torch.float32, "pn_feat"))
         self._check(self.lib.t2l_encode_cells(self._h, C.byref(pc), out.data_ptr(), _stream_ptr()))
         return out
+
+    # ------------------------------------------------------------------ text head after T5 (f-4a)
+    def text_head_load_weights(self, state_dict: Dict[str, object], prefix: str = "language_encoder."):
+        """state_dict: name -> tensor / ndarray holding ``<prefix>intra_module.0.*`` and ``<prefix>inter_mlp.0.*`` (fp32)."""
+        keep, descs = [], []
+        for name, v in state_dict.items():
+            if not name.startswith((prefix + "intra_module.", prefix + "inter_mlp.")) or name.endswith("num_batches_tracked"):
+                continue
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            keep.append(a)
+            descs.append(_WeightDesc(name.encode(), a.ctypes.data, a.size))
+        if not descs:
+            raise T2LError(f"text_head_load_weights: no tensors under {prefix}intra_module / {prefix}inter_mlp")
+        arr = (_WeightDesc * len(descs))(*descs)
+        self._check(self.lib.t2l_text_head_load_weights(self._h, arr, len(descs), prefix.encode()))
+        self._text_head_dim = int(state_dict[prefix + "inter_mlp.0.0.weight"].shape[0])
+
+    def text_head(self, hidden: torch.Tensor, check: bool = True):
+        """hidden f32[n_sentences, n_tokens, 1024] (T5 last_hidden_state) on the GPU -> f32[n_sentences, D] = inter_mlp(max over
+        tokens(intra_module(hidden))) (models/language_encoder.py:127-135). ``check``: read the overflow flag (one 4-byte
+        copy + a stream sync) and return ``(out, overflowed)``; otherwise ``(out, flag tensor)``."""
+        if hidden.dim() != 3 or hidden.shape[2] != 1024:
+            raise T2LError(f"text_head: expected [n_sentences, n_tokens, 1024], got {tuple(hidden.shape)}")
+        S, L = int(hidden.shape[0]), int(hidden.shape[1])
+        out = torch.empty((S, self._text_head_dim), dtype=torch.float32, device=hidden.device)
+        flag = torch.zeros((1,), dtype=torch.int32, device=hidden.device)
+        self._check(self.lib.t2l_text_head(self._h, _dev_ptr(hidden, torch.float32, "hidden"), S, L, out.data_ptr(), flag.data_ptr(),
+                                           _stream_ptr()))
+        return (out, bool(flag.item())) if check else (out, flag)
 
     # ------------------------------------------------------------------ fine stage (f-1)
     def fine_load_weights(self, state_dict: Dict[str, object], class_embed: bool, color_embed: bool,
