@@ -436,7 +436,7 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
   } else if (!strcmp(name, "encoder_f16")) {
     ctx->encoder_f16 = value != 0;
   } else if (!strcmp(name, "text_head_rows")) {
-    if (value < 0 || value > (1 << 22)) return fail(ctx, T2L_EINVAL, "text_head_rows: 0 (default) .. 4194304");
+    if (value < 0 || value > (1 << 18)) return fail(ctx, T2L_EINVAL, "text_head_rows: 0 (default) .. 262144");
     ctx->text_head_rows = (int)value;
   } else if (!strcmp(name, "search_auto")) {
     ctx->search_auto = value != 0;

@@ -28,7 +28,8 @@
 //                     (32 KiB per slot: W_hi, W_lo, X_hi, X_lo) filled by LDS-DMA three steps ahead; ONE s_waitcnt vmcnt +
 //                     s_barrier per step. The transposed product puts 4 consecutive output COLUMNS into one lane, so every
 //                     epilogue (bias, residual from T16 planes, ReLU, re-split) stores 8/16 B pieces that tile full lines.
-//   th_attn_kernel    softmax(q k^T / 16) v per (sentence, head), L <= 32 tokens, f32 on the VALU (0.3 % of the FLOPs)
+//   th_attn_kernel    softmax(q k^T / 16) v per (group of sentences filling a 32-row tile, head), L <= 32 tokens, f32 MFMA from
+//                     registers (0.3 % of the FLOPs)
 //   th_ln_kernel      LayerNorm over 1024 columns from T32, two-pass in registers; writes T16 planes, or (POOL) the max over
 //                     each sentence's tokens
 #include "mfma_h3.h"
@@ -251,83 +252,106 @@ __global__ __launch_bounds__(512, 1) void th_gemm_kernel(const GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Self-attention over the L token positions of one sentence, one wave per (sentence, head), no mask
-// (nn.TransformerEncoderLayer as language_encoder.py:130-131 calls it). qkv: T32 [m_pad][3072] (q | k | v, head h at columns
-// 256 h). Lane (i, hf): token i (idle when i >= L), feature half hf. k and v of the head sit in LDS (rows of 260 floats);
-// q and the output never do.
+// Self-attention over the L token positions of every sentence, no mask (nn.TransformerEncoderLayer as
+// language_encoder.py:130-131 calls it), on the f32 MFMA, from registers — no LDS. qkv: T32 [m_pad][3072] (q | k | v, head h at
+// columns 256 h). One wave per (group of G = floor(32 / L) consecutive sentences = up to 32 consecutive token rows, head):
+//   S^T = K Q^T   A operand = key rows, B operand = query rows; the k-sum is order-free, so lane (c, kh) takes
+//                 k in [128 kh, 128 kh + 128): its operands are 32 contiguous float4 of row c. D layout: lane (i = c, kh)
+//                 holds keys j = (r & 3) + 8 (r >> 2) + 4 kh, r = 0..15 — the softmax over keys is in-lane + one lane ^ 32
+//                 exchange; keys of another sentence of the group (and rows beyond the group) are masked out.
+//   O^T = V^T P^T the probability registers ARE the B operand (k-step s <-> register s); the A operand gathers
+//                 V[key j(s, kh)][32 dt + c] straight from the T32 array (4-byte loads, 16 B segments, L1/L2 hits);
+//                 lane (i, kh) ends up with 4 consecutive output columns per register quad -> 8-byte T16 stores.
 // ---------------------------------------------------------------------------------------------------------------
-template <int LMAX>
-__global__ __launch_bounds__(64) void th_attn_kernel(const float* __restrict__ qkv, int L, _Float16* __restrict__ ohi,
-                                                     _Float16* __restrict__ olo, int* __restrict__ flag) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int RS = 260;  // LDS row stride in floats
-  float* Ks = reinterpret_cast<float*>(smem);
-  float* Vs = Ks + LMAX * RS;
-  const int s = blockIdx.x >> 2, h = blockIdx.x & 3;
-  const int lane = threadIdx.x, i = lane & 31, hf = lane >> 5;
-  const int m = s * L + i;
-  const bool live = i < L;
+__global__ __launch_bounds__(256) void th_attn_kernel(const float* __restrict__ qkv, int n_sent, int L, int n_groups,
+                                                      _Float16* __restrict__ ohi, _Float16* __restrict__ olo, int* __restrict__ flag) {
+  const int lane = threadIdx.x & 63, c = lane & 31, kh = lane >> 5;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);  // (group, head)
+  if (unit >= n_groups * kHeads) return;
+  const int grp = unit >> 2, h = unit & 3;
+  const int G = 32 / L;
+  const int s_first = grp * G, rows = min(G, n_sent - s_first) * L;  // valid token rows of this group
+  const int m0 = s_first * L;
   const int N3 = 3 * kDM;
-  if (live) {
-#pragma unroll 8
-    for (int cq = 0; cq < 32; ++cq) {
-      const int col = h * kHD + 4 * (hf * 32 + cq);
-      *reinterpret_cast<f32x4*>(Ks + i * RS + 4 * (hf * 32 + cq)) = *reinterpret_cast<const f32x4*>(qkv + t32_index(m, kDM + col, N3));
-      *reinterpret_cast<f32x4*>(Vs + i * RS + 4 * (hf * 32 + cq)) = *reinterpret_cast<const f32x4*>(qkv + t32_index(m, 2 * kDM + col, N3));
-    }
-  }
-  __syncthreads();
-  float sc[LMAX];
+  const int mc = m0 + min(c, rows - 1);  // this lane's row (clamped: rows beyond the group are masked)
+  // ---- S^T = K Q^T over head_dim = 256
+  h3_f32x16 st;
 #pragma unroll
-  for (int j = 0; j < LMAX; ++j) sc[j] = 0.f;
-  if (live) {
+  for (int r = 0; r < 16; ++r) st[r] = 0.f;
+  const float* qrow = qkv + t32_index(mc, h * kHD + 128 * kh, N3);          // quad t of the lane's half row: + t * 128 floats
+  const float* krow = qkv + t32_index(mc, kDM + h * kHD + 128 * kh, N3);
 #pragma unroll 2
-    for (int cq = 0; cq < 32; ++cq) {
-      const int d = 4 * (hf * 32 + cq);
-      const f32x4 q = *reinterpret_cast<const f32x4*>(qkv + t32_index(m, h * kHD + d, N3));
+  for (int t0 = 0; t0 < 32; t0 += 4) {
+    f32x4 qv[4], kv[4];
 #pragma unroll
-      for (int j = 0; j < LMAX; ++j)
-        if (j < L) {
-          const f32x4 kv = *reinterpret_cast<const f32x4*>(Ks + j * RS + d);
-          sc[j] += q[0] * kv[0] + q[1] * kv[1] + q[2] * kv[2] + q[3] * kv[3];
-        }
+    for (int t = 0; t < 4; ++t) {
+      qv[t] = *reinterpret_cast<const f32x4*>(qrow + (size_t)(t0 + t) * 128);
+      kv[t] = *reinterpret_cast<const f32x4*>(krow + (size_t)(t0 + t) * 128);
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[t][e], qv[t][e], st, 0, 0, 0);
   }
+  // ---- softmax over the keys of this lane's query row i = c (its own sentence only)
+  const int my_sent = c / L;
   float mx = -__builtin_inff();
 #pragma unroll
-  for (int j = 0; j < LMAX; ++j) {
-    sc[j] += __shfl_xor(sc[j], 32);  // the two feature halves
-    if (j < L) mx = fmaxf(mx, sc[j]);
+  for (int r = 0; r < 16; ++r) {
+    const int j = (r & 3) + 8 * (r >> 2) + 4 * kh;
+    const bool ok = j < rows && j / L == my_sent;
+    st[r] = ok ? st[r] * 0.0625f : -__builtin_inff();  // / sqrt(head_dim)
+    mx = fmaxf(mx, st[r]);
   }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
   float sum = 0.f;
 #pragma unroll
-  for (int j = 0; j < LMAX; ++j) {
-    sc[j] = j < L ? expf((sc[j] - mx) * 0.0625f) : 0.f;  // / sqrt(head_dim = 256)
-    sum += sc[j];
+  for (int r = 0; r < 16; ++r) {
+    st[r] = c < rows ? __expf(st[r] - mx) : 0.f;  // (a row beyond the group has no valid key: mx = -inf)
+    sum += st[r];
   }
-  const float inv = 1.f / sum;
-  if (!live) return;
-  bool bad = false;
-#pragma unroll 2
-  for (int cp = 0; cp < 16; ++cp) {  // two quads = one 8-wide chunk per step: 16-byte stores
-    const int d = 8 * (hf * 16 + cp);
-    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+  sum += __shfl_xor(sum, 32);
+  const float inv = c < rows ? 1.f / sum : 0.f;
 #pragma unroll
-    for (int j = 0; j < LMAX; ++j)
-      if (j < L) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(Vs + j * RS + d), v1 = *reinterpret_cast<const f32x4*>(Vs + j * RS + d + 4);
-        o0 += sc[j] * v0;
-        o1 += sc[j] * v1;
+  for (int r = 0; r < 16; ++r) st[r] *= inv;
+  // ---- O^T = V^T P^T, 8 column tiles of 32
+  int vrow[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int j = min((s & 3) + 8 * (s >> 2) + 4 * kh, rows - 1);  // (masked keys carry probability 0: any finite row will do)
+    const int m = m0 + j;
+    vrow[s] = (m >> 5) * (N3 >> 2) * 128 + (m & 31) * 4;
+  }
+  const float* vbase = qkv + (size_t)((2 * kDM + h * kHD) >> 2) * 128 + ((c >> 2) * 128 + (c & 3));
+  bool bad = false;
+  float va[16], vb[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) va[s] = vbase[vrow[s]];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) {
+    if (dt + 1 < 8) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) vb[s] = vbase[vrow[s] + (dt + 1) * 8 * 128];
+    }
+    h3_f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(va[s], st[s], o, 0, 0, 0);
+    if (c < rows) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+        bad = bad || out_of_f16_range(v);
+        f16x4 hi, lo;
+        split4(v, hi, lo);
+        const size_t off = t16_index(m0 + c, h * kHD + dt * 32 + 8 * g + 4 * kh, kDM);
+        *reinterpret_cast<f16x4*>(ohi + off) = hi;
+        *reinterpret_cast<f16x4*>(olo + off) = lo;
       }
-    o0 *= inv;
-    o1 *= inv;
-    bad = bad || out_of_f16_range(o0) || out_of_f16_range(o1);
-    f16x4 h0, l0, h1, l1;
-    split4(o0, h0, l0);
-    split4(o1, h1, l1);
-    const size_t o = t16_index(m, h * kHD + d, kDM);
-    *reinterpret_cast<f16x8*>(ohi + o) = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-    *reinterpret_cast<f16x8*>(olo + o) = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) va[s] = vb[s];
   }
   if (bad) atomicOr(flag, 1);
 }
@@ -559,7 +583,6 @@ int text_head_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const cha
     T2L_TH_ATTR(kEpiReluT16, false); T2L_TH_ATTR(kEpiReluT16, true); T2L_TH_ATTR(kEpiRowMajor, false); T2L_TH_ATTR(kEpiRowMajor, true);
 #undef T2L_TH_ATTR
     T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&th_ln_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1028 * 4));
-    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&th_attn_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 260 * 4));
     attr_done = true;
   }
   return T2L_OK;
@@ -619,12 +642,11 @@ int text_head_impl(t2l_ctx* ctx, const float* hidden, int n_sent, int L, float* 
     g.wh = W->qkv_h; g.wl = W->qkv_l; g.xh = ws + o_xh; g.xl = ws + o_xl; g.bias = W->qkv_b; g.out0 = ws + o_qkv;
     g.n_tiles = 3 * kDM / kTile; g.K = kDM; g.N = 3 * kDM; g.n_real = 3 * kDM;
     th_launch_gemm<kEpiT32>(single, g, s);
-    if (L <= 16)
-      hipLaunchKernelGGL(th_attn_kernel<16>, dim3(ns * kHeads), dim3(64), 2 * 16 * 260 * 4, s, (const float*)(ws + o_qkv), L, (_Float16*)(ws + o_oh),
+    {
+      const int G = 32 / L, n_groups = (ns + G - 1) / G;
+      hipLaunchKernelGGL(th_attn_kernel, dim3(n_groups), dim3(256), 0, s, (const float*)(ws + o_qkv), ns, L, n_groups, (_Float16*)(ws + o_oh),
                          (_Float16*)(ws + o_ol), W->flag);
-    else
-      hipLaunchKernelGGL(th_attn_kernel<32>, dim3(ns * kHeads), dim3(64), 2 * 32 * 260 * 4, s, (const float*)(ws + o_qkv), L, (_Float16*)(ws + o_oh),
-                         (_Float16*)(ws + o_ol), W->flag);
+    }
     // y = x + o W_out^T + b_out -> T32; x1 = LayerNorm1(y) -> planes
     g.wh = W->out_h; g.wl = W->out_l; g.xh = ws + o_oh; g.xl = ws + o_ol; g.bias = W->out_b; g.rh = ws + o_xh; g.rl = ws + o_xl; g.out0 = ws + o_y;
     g.n_tiles = kDM / kTile; g.K = kDM; g.N = kDM; g.n_real = kDM;

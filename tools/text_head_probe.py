@@ -5,7 +5,8 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from text2loc_amd import synth
 from text2loc_amd.engine import Engine
 
