@@ -42,6 +42,7 @@ namespace th {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kDM = 1024;      // d_model of the T5 encoder the head is built for (t5-large)
 constexpr int kFF = 4096;      // dim_feedforward = 4 * d_model (language_encoder.py:95)
@@ -66,26 +67,36 @@ __device__ __forceinline__ bool out_of_f16_range(const f32x4 v) {  // true for |
 
 // ---------------------------------------------------------------------------------------------------------------
 // row-major f32 [M][C] -> T16 hi / lo planes of M_pad rows (rows >= M are written as zeros). One workgroup per 32 rows x 256
-// columns; thread (row, chunk group): consecutive threads write one 512-byte block.
+// columns, through LDS: whole-row reads (1 KiB per wave-load), then thread (row, chunk group) so that consecutive threads
+// write one 512-byte block.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void th_split_kernel(const float* __restrict__ x, int M, int C, _Float16* __restrict__ hi,
                                                        _Float16* __restrict__ lo, int* __restrict__ flag) {
+  __shared__ __attribute__((aligned(16))) float tile[32][260];
+  const int m0 = blockIdx.x * 32, col0 = blockIdx.y * 256;
+  {  // a wave reads whole 1 KiB row pieces (64 lanes x 16 B contiguous), 8 rows per wave
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = wv * 8 + i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m0 + row < M) v = *reinterpret_cast<const f32x4*>(x + (size_t)(m0 + row) * C + col0 + lane * 4);
+      *reinterpret_cast<f32x4*>(&tile[row][lane * 4]) = v;
+    }
+  }
+  __syncthreads();
   const int r = threadIdx.x & 31, cg = threadIdx.x >> 5;
-  const int m = blockIdx.x * 32 + r, col0 = blockIdx.y * 256;
+  const int m = m0 + r;
   bool bad = false;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int k = col0 + (cg * 4 + j) * 8;
-    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
-    if (m < M) {
-      a = *reinterpret_cast<const f32x4*>(x + (size_t)m * C + k);
-      b = *reinterpret_cast<const f32x4*>(x + (size_t)m * C + k + 4);
-    }
+    const int kc = (cg * 4 + j) * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(&tile[r][kc]), b = *reinterpret_cast<const f32x4*>(&tile[r][kc + 4]);
     bad = bad || out_of_f16_range(a) || out_of_f16_range(b);
     f16x4 ah, al, bh, bl;
     split4(a, ah, al);
     split4(b, bh, bl);
-    const size_t o = t16_index(m, k, C);
+    const size_t o = t16_index(m, col0 + kc, C);
     *reinterpret_cast<f16x8*>(hi + o) = f16x8{ah[0], ah[1], ah[2], ah[3], bh[0], bh[1], bh[2], bh[3]};
     *reinterpret_cast<f16x8*>(lo + o) = f16x8{al[0], al[1], al[2], al[3], bl[0], bl[1], bl[2], bl[3]};
   }
@@ -112,104 +123,175 @@ struct GemmArgs {
 };
 
 template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 63 : N) : "memory"); }
 
+// PERSISTENT: the grid is one workgroup per CU; workgroup b walks the tiles vb = b, b + grid, ... as ONE continuous stream of
+// k-steps — the LDS-DMA of a tile's first three steps is issued during the last three steps of the tile before it, so the
+// matrix pipe restarts right behind an epilogue instead of behind a cold pipeline fill, and the epilogues' store bursts of
+// different CUs drift apart instead of hitting HBM together (measured before: 85 us per 64-step tile against 51 us of MFMA time).
+// vmcnt counts the epilogue's stores too (in-order retirement): for the three steps behind an epilogue the wait allows them
+// to stay in flight (they are younger than the awaited pieces), from the fourth step on they must have retired.
 template <int EPI, bool SINGLE>
 __global__ __launch_bounds__(512, 1) void th_gemm_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PPW = SINGLE ? 2 : 4;  // LDS-DMA pieces (1 KiB) per wave and k-step
+  // stores per wave and epilogue that are CERTAIN to be issued (an over-estimate would under-wait): the row-major epilogue
+  // stores conditionally -> 0 (its stores must retire before the next tile's first step; it has one n tile per m tile)
+  constexpr int NST = EPI == kEpiRowMajor ? 0 : (EPI == kEpiReluT16 && !SINGLE) ? 64 : 32;
   const int lane = threadIdx.x & 63, w = uniform_wave_id();
-  // blockIdx -> tile: the n tiles of one m tile run back to back on ONE XCD (blockIdx % 8), so the X rows of an m tile are
-  // fetched from HBM once and every XCD's L2 keeps the weights
-  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-  const int mt_idx = (seq / p.n_tiles) * 8 + xcd, nt_idx = seq % p.n_tiles;
-  if (mt_idx >= p.m_tiles) return;
+  // virtual block vb -> tile: the n tiles of one m tile run back to back on ONE XCD (vb % 8 = blockIdx % 8: the grid is a
+  // multiple of 8), so the X rows of an m tile are fetched from HBM once and every XCD's L2 keeps the weights
+  const int xcd = blockIdx.x & 7, grid = gridDim.x;
   const int K = p.K, KT = K >> 4;
+  const int n_vb = (p.m_tiles + 7) / 8 * 8 * p.n_tiles;
+  int n_my = 0;  // this workgroup's tiles: a prefix of vb = blockIdx + i * grid (an m tile beyond m_tiles ends the list)
+  for (int vb = blockIdx.x; vb < n_vb; vb += grid) {
+    if (((vb >> 3) / p.n_tiles) * 8 + xcd >= p.m_tiles) break;
+    ++n_my;
+  }
+  if (n_my == 0) return;
   const size_t rt_stride = (size_t)K * 64;  // bytes between consecutive 32-row tiles of a T16 plane
 
   // ---- this wave's DMA pieces: piece ids [w * PPW, +PPW) of the slot; plane = id / 8, row tile = id % 8
   const int pid0 = w * PPW;
   const int plane = pid0 >> 3, rt0 = pid0 & 7;
-  const char* src;
+  const char* plane_base;
   unsigned dst_off;
   if constexpr (SINGLE) {
-    src = plane == 0 ? p.wh : p.xh;
+    plane_base = plane == 0 ? p.wh : p.xh;
     dst_off = (plane == 0 ? 0u : 2u * kPlaneBytes) + rt0 * 1024;
   } else {
-    src = plane == 0 ? p.wh : plane == 1 ? p.wl : plane == 2 ? p.xh : p.xl;
+    plane_base = plane == 0 ? p.wh : plane == 1 ? p.wl : plane == 2 ? p.xh : p.xl;
     dst_off = plane * kPlaneBytes + rt0 * 1024;
   }
   const bool is_w = SINGLE ? plane == 0 : plane < 2;
-  src += ((size_t)(is_w ? nt_idx : mt_idx) * 8 + rt0) * rt_stride;
+  auto tile_src = [&](int i) {
+    const int seq = (blockIdx.x + i * grid) >> 3;
+    const int t = is_w ? seq % p.n_tiles : (seq / p.n_tiles) * 8 + xcd;
+    return plane_base + ((size_t)t * 8 + rt0) * rt_stride;
+  };
   unsigned voff[PPW];
 #pragma unroll
   for (int j = 0; j < PPW; ++j) voff[j] = (unsigned)(lane * 16) + (unsigned)(j * rt_stride);
   const unsigned lds0 = lds_addr_of(smem);
-  auto issue = [&](int kt) {
-    const unsigned dst = lds0 + (kt & 3) * kSlotBytes + dst_off;
-    const char* s = src + (size_t)kt * 1024;
+  int it_tile = 0, it_kt = 0;  // the issue cursor runs three k-steps ahead of the compute cursor, across tile boundaries
+  unsigned gi = 0;
+  const char* it_src = tile_src(0);
+  auto issue = [&]() {
+    if (it_tile < n_my) {
+      const unsigned dst = lds0 + (gi & 3) * kSlotBytes + dst_off;
+      const char* s = it_src + (size_t)it_kt * 1024;
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) lds_dma_row(dst + j * 1024, voff[j], s);
+      for (int j = 0; j < PPW; ++j) lds_dma_row(dst + j * 1024, voff[j], s);
+      ++gi;
+      if (++it_kt == KT) {
+        it_kt = 0;
+        if (++it_tile < n_my) it_src = tile_src(it_tile);
+      }
+    }
   };
-
-  h3_f32x16 acc[2][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int wm = w & 1, wn = w >> 1;
   const char* fr = smem + lane * 16;
   const int w_off = wn * 2 * 1024, x_off = 2 * kPlaneBytes + wm * 4 * 1024;
+  const int c = lane & 31, kh = lane >> 5;
+  bool bad = false;
 
-  issue(0);
-  if (KT > 1) issue(1);
-  if (KT > 2) issue(2);
-  for (int kt = 0; kt < KT; ++kt) {
-    const int ahead = min(KT - 1, kt + 2) - kt;  // k-steps issued behind step kt
-    if (ahead >= 2) wait_vmcnt<2 * PPW>();
-    else if (ahead == 1) wait_vmcnt<PPW>();
-    else wait_vmcnt<0>();
-    asm volatile("s_barrier" ::: "memory");  // every wave's pieces of step kt have landed; everybody is done reading step kt-1
-    if (kt + 3 < KT) issue(kt + 3);          // ... whose slot is refilled
-    const char* sb = fr + (kt & 3) * kSlotBytes;
+  // Fragments are double-buffered in registers: step g multiplies the set read during step g - 1 while the set of step g + 1
+  // is being read, so the LDS latency sits behind 24 MFMAs instead of in front of them. Step g's barrier therefore certifies
+  // the pieces of step g + 1 (and that everybody finished READING slot g, which step g + 4's pieces then refill).
+  struct Frags {
     f16x8 xh[4], xl[4], wh[2], wl[2];
+  };
+  auto read_frags = [&](Frags& f, unsigned slot) {
+    const char* sb = fr + slot * kSlotBytes;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      wh[i] = *reinterpret_cast<const f16x8*>(sb + w_off + i * 1024);
-      if constexpr (!SINGLE) wl[i] = *reinterpret_cast<const f16x8*>(sb + kPlaneBytes + w_off + i * 1024);
+      f.wh[i] = *reinterpret_cast<const f16x8*>(sb + w_off + i * 1024);
+      if constexpr (!SINGLE) f.wl[i] = *reinterpret_cast<const f16x8*>(sb + kPlaneBytes + w_off + i * 1024);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      xh[i] = *reinterpret_cast<const f16x8*>(sb + x_off + i * 1024);
-      if constexpr (!SINGLE) xl[i] = *reinterpret_cast<const f16x8*>(sb + kPlaneBytes + x_off + i * 1024);
+      f.xh[i] = *reinterpret_cast<const f16x8*>(sb + x_off + i * 1024);
+      if constexpr (!SINGLE) f.xl[i] = *reinterpret_cast<const f16x8*>(sb + kPlaneBytes + x_off + i * 1024);
     }
+  };
+  const unsigned total = (unsigned)n_my * KT;
+  issue();
+  issue();
+  issue();
+  issue();
+  // (total >= 64: every wait below has its three younger groups except at the very end)
+  wait_vmcnt<3 * PPW>();
+  asm volatile("s_barrier" ::: "memory");
+  Frags fa, fb;
+  read_frags(fa, 0);
+  unsigned g = 0;
+  for (int ti = 0; ti < n_my; ++ti) {
+    const int seq = (blockIdx.x + ti * grid) >> 3;
+    const int mt_idx = (seq / p.n_tiles) * 8 + xcd, nt_idx = seq % p.n_tiles;
+    h3_f32x16 acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[a], xh[b], acc[a][b], 0, 0, 0);
-        if constexpr (!SINGLE) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[a], xl[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[a], xh[b], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto step = [&](const Frags& cur, Frags& nxt, int kt) {
+      // pieces of step g + 1 must have landed: groups g + 2, g + 3 (and, right behind an epilogue, its stores) may stay in flight
+      const unsigned ahead = min(total - 1 - g, 3u);  // k-steps issued behind step g
+      if (ahead >= 1) {
+        if (ti > 0 && kt < 3) {  // the previous tile's stores are younger than group g + 1 (issued before that epilogue)
+          if (ahead == 3) wait_vmcnt<2 * PPW + NST>();
+          else if (ahead == 2) wait_vmcnt<PPW + NST>();
+          else wait_vmcnt<NST>();
+        } else {
+          if (ahead == 3) wait_vmcnt<2 * PPW>();
+          else if (ahead == 2) wait_vmcnt<PPW>();
+          else wait_vmcnt<0>();
         }
       }
-  }
+      __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's reads of slot g % 4 returned long ago (and the compiler knows)
+      asm volatile("s_barrier" ::: "memory");
+      issue();  // group g + 4 into slot g % 4 (everybody read it during step g - 1)
+      if (ahead >= 1) read_frags(nxt, (g + 1) & 3);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wh[a], cur.xh[b], acc[a][b], 0, 0, 0);
+          if constexpr (!SINGLE) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wh[a], cur.xl[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wl[a], cur.xh[b], acc[a][b], 0, 0, 0);
+          }
+        }
+      ++g;
+    };
+    for (int kt = 0; kt < KT; kt += 2) {  // (K is a multiple of 32)
+      step(fa, fb, kt);
+      step(fb, fa, kt + 1);
+    }
 
-  // ---- epilogue. Loads are issued in batches (the 8 bias vectors up front, a tile's 8 residual pieces together) so that the
-  // wave pays one memory latency per batch, not one per piece
-  const int c = lane & 31, kh = lane >> 5;
-  bool bad = false;
-  f32x4 bias_v[2][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bias_v[a][g] = *reinterpret_cast<const f32x4*>(p.bias + nt_idx * kTile + wn * 64 + a * 32 + 8 * g + 4 * kh);
+    // ---- epilogue. The bias comes through scalar loads (wave-uniform address; lgkmcnt, so the DMA queue keeps running);
+    // a tile's 8 residual pieces are loaded together (one memory latency per batch, not one per piece)
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     const int n_base = nt_idx * kTile + wn * 64 + a * 32;
+    f32x4 bias_v[4];
+    {
+      f32x8 s0, s1, s2, s3;  // this half's 32 bias values: 4 scalar loads in flight, one wait
+      const float* bp = p.bias + n_base;
+      asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x20\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_load_dwordx8 %3, %4, 0x60\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3)
+                   : "s"(bp)
+                   : "memory");
+      bias_v[0] = kh ? f32x4{s0[4], s0[5], s0[6], s0[7]} : f32x4{s0[0], s0[1], s0[2], s0[3]};
+      bias_v[1] = kh ? f32x4{s1[4], s1[5], s1[6], s1[7]} : f32x4{s1[0], s1[1], s1[2], s1[3]};
+      bias_v[2] = kh ? f32x4{s2[4], s2[5], s2[6], s2[7]} : f32x4{s2[0], s2[1], s2[2], s2[3]};
+      bias_v[3] = kh ? f32x4{s3[4], s3[5], s3[6], s3[7]} : f32x4{s3[0], s3[1], s3[2], s3[3]};
+    }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int m = mt_idx * kTile + wm * 128 + b * 32 + c;
@@ -225,7 +307,7 @@ __global__ __launch_bounds__(512, 1) void th_gemm_kernel(const GemmArgs p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n0 = n_base + 8 * g + 4 * kh;
-        const f32x4 bv = bias_v[a][g];
+        const f32x4 bv = bias_v[g];
         f32x4 v = {acc[a][b][4 * g] + bv[0], acc[a][b][4 * g + 1] + bv[1], acc[a][b][4 * g + 2] + bv[2], acc[a][b][4 * g + 3] + bv[3]};
         if constexpr (EPI == kEpiT32) {
           *reinterpret_cast<f32x4*>((float*)p.out0 + t32_index(m, n0, p.N)) = v;
@@ -246,6 +328,7 @@ __global__ __launch_bounds__(512, 1) void th_gemm_kernel(const GemmArgs p) {
       }
     }
   }
+  }  // tiles
   if constexpr (EPI == kEpiReluT16) {
     if (bad) atomicOr(p.flag, 1);
   }
@@ -590,7 +673,15 @@ int text_head_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const cha
 
 template <int EPI>
 static void th_launch_gemm(bool single, const th::GemmArgs& a, hipStream_t s) {
-  const int grid = (a.m_tiles + 7) / 8 * 8 * a.n_tiles;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu < 8) n_cu = 256;
+  }
+  const int n_vb = (a.m_tiles + 7) / 8 * 8 * a.n_tiles;
+  const int grid = min(n_cu / 8 * 8, n_vb);  // persistent: one workgroup per CU, a multiple of the 8 XCDs
   const int lds = th::kSlots * th::kSlotBytes;
   if (single) hipLaunchKernelGGL((th::th_gemm_kernel<EPI, true>), dim3(grid), dim3(512), lds, s, a);
   else hipLaunchKernelGGL((th::th_gemm_kernel<EPI, false>), dim3(grid), dim3(512), lds, s, a);
