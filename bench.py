@@ -128,7 +128,11 @@ def torch_train_step_ms(sd, cells64, anchor, steps=20):
 
 
 
-def text_head_measure(n_desc, n_hints=6, n_tok=16):
+def text_head_measure(eng, d_db_rows, n_desc, n_hints=6, n_tok=16):
+    """a5 / f-4a: the head after T5 for one search step's worth of queries. `total_ms` = what LanguageEncoder.head costs now
+    (t2l_text_head — split-f16 MFMA GEMMs — for the d=1024 layer + max + inter_mlp, PyTorch-ROCm for the 256-d half);
+    the all-PyTorch path (round 2: 82 ms) and the plain-f16 option beside it; then the cold query path: T5 hidden states ->
+    head -> t2l_search ids, on the device, one stream."""
     import torch.nn.functional as F
     from text2loc_amd.cell_retrieval import LanguageEncoder
 
@@ -137,9 +141,10 @@ def text_head_measure(n_desc, n_hints=6, n_tok=16):
     sd = {k[len("language_encoder."):]: torch.from_numpy(v) for k, v in synth.make_language_head_weights(0).items()}
     enc.load_state_dict(sd, strict=False)
     enc = enc.cuda().eval()
-    hidden = torch.randn(n_desc * n_hints, n_tok, 1024, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    hidden = 0.2 * torch.randn(n_desc * n_hints, n_tok, 1024, device="cuda", generator=g)
 
-    def first_half(h):  # language_encoder.py:127-136: intra layer(s) at d=1024 over tokens, max, Linear+BN -> [B*6,256]
+    def first_half_torch(h):  # language_encoder.py:127-136: intra layer(s) at d=1024 over tokens, max, Linear+BN -> [B*6,256]
         x = h.permute(1, 0, 2)
         for layer in enc.intra_module:
             x = layer(x)
@@ -161,12 +166,34 @@ def text_head_measure(n_desc, n_hints=6, n_tok=16):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps * 1e3, r
 
+    heng = enc._head_engine(hidden.device)
+    flops = 2.0 * hidden.shape[0] * n_tok * (1024 * 3072 + 1024 * 1024 + 2 * 1024 * 4096) + 2.0 * hidden.shape[0] * 1024 * 256
     with torch.no_grad():
-        ms1, mid = timed(first_half, hidden)
-        ms2, _ = timed(second_half, mid)
-    return {"workload": f"{n_desc} descriptions x {n_hints} hints x {n_tok} tokens, d=1024 (T5-large width), PyTorch-ROCm eager, f32",
-            "d1024_layer_plus_linear_ms": ms1, "d256_half_ms": ms2, "total_ms": ms1 + ms2,
-            "d256_half_share": ms2 / (ms1 + ms2)}
+        ms_t, mid_t = timed(first_half_torch, hidden, reps=3)
+        ms_e, (mid_e, flag) = timed(lambda h: heng.text_head(h, check=False), hidden)
+        overflow = bool(flag.item())
+        heng.set_option("encoder_f16", 1)
+        ms_f, (mid_f, _) = timed(lambda h: heng.text_head(h, check=False), hidden)
+        heng.set_option("encoder_f16", 0)
+        ms2, _ = timed(second_half, mid_e)
+        e1 = float((mid_e - mid_t).abs().max() / mid_t.abs().max())
+        e2 = float((mid_f - mid_t).abs().max() / mid_t.abs().max())
+        # cold query path: hidden states -> head (engine + 256-d half) -> normalise -> search against the resident DB
+        def cold(h):
+            q = F.normalize(enc.head(h, n_desc)).contiguous()
+            return eng.search(q, TOPK)
+        ms_cold, _ = timed(cold, hidden, reps=3)
+    return {"workload": f"{n_desc} descriptions x {n_hints} hints x {n_tok} tokens, d=1024 (T5-large width)",
+            "d1024_layer_plus_linear_ms": ms_e, "d256_half_ms": ms2, "total_ms": ms_e + ms2,
+            "engine_split_f16": {"ms": ms_e, "tflops_algorithmic": flops / ms_e / 1e9, "tflops_executed_f16": 3 * flops / ms_e / 1e9,
+                                 "frac_of_f16_peak_executed": 3 * flops / ms_e / 1e9 / BF16_MFMA_PEAK_TFLOPS,
+                                 "max_rel_err_vs_torch_f32": e1, "overflow_flag": overflow},
+            "engine_plain_f16_option": {"ms": ms_f, "tflops": flops / ms_f / 1e9, "max_rel_err_vs_torch_f32": e2},
+            "pytorch_rocm_eager_f32": {"d1024_layer_plus_linear_ms": ms_t, "total_ms": ms_t + ms2},
+            "d256_half_share": ms2 / (ms_e + ms2),
+            "cold_query_path": {"what": f"T5 hidden states of {n_desc} descriptions -> LanguageEncoder.head (t2l_text_head + 256-d half) -> "
+                                        f"normalise -> t2l_search top-{TOPK} over {d_db_rows} cells, one stream, on the device",
+                                "ms": ms_cold, "queries_per_s": n_desc / (ms_cold * 1e-3)}}
 
 
 def clustered_measure(eng, packed_cells):
@@ -318,7 +345,7 @@ def secondary_measurements(eng):
     # worth of queries (4,096 descriptions x 6 hints, 16 tokens each, T5-large width 1024), split into the d=1024
     # intra-layer + max + Linear/BN and the 256-d half (inter_module + max + normalize)
     try:
-        out["text_head"] = text_head_measure(N_QUERIES)
+        out["text_head"] = text_head_measure(eng, N_CELLS, N_QUERIES)
     except Exception as e:
         out["text_head"] = {"error": repr(e)}
     # the data cliff: tightly clustered databases (what an encoder over overlapping cells produces) instead of the
@@ -568,6 +595,69 @@ def secondary_measurements(eng):
         eng_f.close()
     except Exception as e:
         out["fine_stage"] = {"error": repr(e)}
+    # SURVEY.md 8e, measured on ONE GPU: what every rank of an 8-GPU row-sharded step does apart from the collective itself —
+    # scan + re-rank over ceil(N/8) rows for ALL queries, pack the {score, id} records, merge 8 gathered lists per query.
+    # This is the per-rank floor of config 3's step (the all_gather of 8 x 655 KB over xGMI comes on top).
+    try:
+        P = 8
+        eng_s = Engine(eng.device)
+        n_shard = -(-N_CELLS // P)
+        rs = np.random.default_rng(5)
+        shard = torch.from_numpy(synth.unit_rows(rs.standard_normal((n_shard, DIM)).astype(np.float32))).cuda()
+        eng_s.db_set(shard, row_offset=0)
+        dq_all = torch.from_numpy(np.ascontiguousarray(_QS)).cuda()
+        Qn = int(dq_all.shape[0])
+        own, idx_s, sc_s, bb, so = eng_s.result_block(Qn, TOPK, "cuda")          # ids | scores: one exchange block
+        allb = torch.empty((P, bb), dtype=torch.uint8, device="cuda")
+        eng_s.search(dq_all, TOPK, out=(idx_s, sc_s))
+        for r in range(P):  # stand-in for the all_gather: rank r's block = this shard's scores scaled down a little, ids shifted
+            blk_i = allb[r, :Qn * TOPK * 4].view(torch.int32).view(Qn, TOPK)
+            blk_s = allb[r, so:so + Qn * TOPK * 8].view(torch.float64).view(Qn, TOPK)
+            blk_i.copy_(idx_s + r * n_shard)
+            blk_s.copy_(sc_s * (1.0 - 0.003 * ((r * 5) % P)))
+        eng_s.set_option("profile_events", 0)
+
+        def shard_step():
+            eng_s.search(dq_all, TOPK, out=(idx_s, sc_s))   # (rank 0's block is re-written in place with the same values)
+            allb[0].copy_(own[0], non_blocking=True)        # the local block's trip into the gathered buffer
+            return eng_s.merge_gathered(allb.view(-1), bb, so, P, Qn, TOPK)
+
+        n_ramp_s, n_s = (10, 20) if _QUICK else (1500, 400)
+        for _ in range(n_ramp_s):
+            shard_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_s):
+            mi, ms_ = shard_step()
+        torch.cuda.synchronize()
+        t_all = (time.perf_counter() - t0) / n_s
+
+        def only(fn):
+            for _ in range(50 if not _QUICK else 5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_s):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n_s * 1e3
+
+        t_search = only(lambda: eng_s.search(dq_all, TOPK, out=(idx_s, sc_s)))
+        t_merge = only(lambda: eng_s.merge_gathered(allb.view(-1), bb, so, P, Qn, TOPK))
+        from text2loc_amd.sharded import merge_topk_host
+        hi_, hs_ = [], []
+        for r in range(P):
+            hi_.append(allb[r, :Qn * TOPK * 4].view(torch.int32).view(Qn, TOPK)[:256].cpu().numpy())
+            hs_.append(allb[r, so:so + Qn * TOPK * 8].view(torch.float64).view(Qn, TOPK)[:256].cpu().numpy())
+        ref_i, ref_s = merge_topk_host(np.stack(hi_), np.stack(hs_), TOPK)
+        ok = bool(np.array_equal(mi[:256].cpu().numpy().astype(np.int64), ref_i)) and bool(np.array_equal(ms_[:256].cpu().numpy(), ref_s))
+        out["shard_step_model"] = {"what": f"per-rank work of an {P}-GPU row-sharded step on one GPU: t2l_search over {n_shard} rows for all "
+                                           f"{Qn} queries (ids | scores written into one exchange block) + the block's copy into the gathered buffer + t2l_merge_gathered(P={P}); the all_gather itself is not in it",
+                                   "us_per_step": t_all * 1e6, "search_us": t_search * 1e3, "merge_us": t_merge * 1e3,
+                                   "queries_per_s_if_the_collective_were_free": Qn / t_all, "merge_equals_host_merge_on_256_queries": ok}
+        eng_s.close()
+    except Exception as e:
+        out["shard_step_model"] = {"error": repr(e)}
     # a9 / SURVEY.md §8d config 4: one training step of the object branch at B=64 (train-mode forward with dropout 0.1 ->
     # contrastive loss -> backward -> Adam), text side supplied as a precomputed [64,256] batch
     try:
@@ -828,6 +918,21 @@ def main():
     # first 40 ms of this very loop): untimed ramp steps first, so that a short run (--steps 20 is 1 ms of GPU time) measures the
     # steady state and not the power-state ramp. Then the W warmup steps, then the timed K.
     RAMP_STEPS = 0 if args.quick else max(0, 1500 - args.warmup)
+    # for the record, the same K steps WITHOUT the ramp (W warmup steps from an idle GPU, then K timed): what the workaround hides
+    unramped = None
+    if world == 1 and lanes == 1 and not args.quick:
+        torch.cuda.synchronize()
+        time.sleep(0.25)  # let the clocks fall back to idle
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        t0u = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        tu = (time.perf_counter() - t0u) / args.steps
+        unramped = {"steps": args.steps, "warmup": args.warmup, "ms_per_step": tu * 1e3, "queries_per_s": N_QUERIES / tu,
+                    "note": "idle GPU -> W warmup steps -> K timed steps, no clock-ramp steps (the first ~40 ms of load run below the sustained clocks)"}
     for i in range(RAMP_STEPS):
         step(i)
     for i in range(args.warmup):
@@ -980,6 +1085,74 @@ def main():
                "ids_equal_row_sharded": bool(torch.equal(qi, idx))}
         eng_q.close()
 
+    # N>1 only, outside the timed region: (i) the WEAK-scaling point of the same layout — every rank holds a full 11,259-row
+    # shard of an N x 11,259-row database (BASELINE config 3 says "Full DB": more rows is where row-sharding pays), same Q;
+    # (ii) BASELINE config 5 on N ranks: coarse (row-sharded search) + fine (the Q x top-k (pose, cell) pairs split across the
+    # ranks, offsets all-gathered: cross_matcher.run_fine's world > 1 decomposition on resident descriptor / hint tables).
+    weak = None
+    cfg5 = None
+    if world > 1:
+        from text2loc_amd.sharded import gather_rows, shard_bounds
+
+        def timed_ranks(fn, n):
+            for _ in range(3):
+                fn()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                r = fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            te = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            return float(te.item()) / n, r
+
+        try:
+            eng_w = Engine(dev)
+            sw = ShardedSearcher(eng_w)
+            n_total = world * N_CELLS
+            rs = np.random.default_rng(1000 + rank)
+            shard = torch.from_numpy(synth.unit_rows(rs.standard_normal((N_CELLS, DIM)).astype(np.float32))).cuda()
+            sw.set_db_shard(shard, n_total=n_total)  # shard_bounds(n_total, world, rank) == [rank * N, (rank + 1) * N)
+            n_w = max(10, args.steps // 2)
+            tw, (wi, wsc) = timed_ranks(lambda: sw.search(d_q, TOPK), n_w)
+            lo_w = rank * N_CELLS  # the merged result must agree with this rank's own shard wherever it contributed
+            li, ls = eng_w.search(d_q, TOPK)
+            mine = (wi >= lo_w) & (wi < lo_w + N_CELLS)
+            consistent = bool(torch.all(torch.isin(wi[mine], li)))
+            weak = {"layout": f"every rank holds {N_CELLS} rows of an {n_total}-row database (rank-seeded unit rows), same {N_QUERIES} queries per step",
+                    "rows_total": n_total, "ms_per_step": tw * 1e3, "queries_per_s": N_QUERIES / tw,
+                    "row_query_pairs_per_s": N_QUERIES * n_total / tw, "own_rows_in_merged_topk_are_in_local_topk": consistent}
+            eng_w.close()
+        except Exception as e:
+            weak = {"error": repr(e)}
+        try:
+            eng_f = Engine(dev)
+            eng_f.fine_load_weights(synth.make_fine_weights(0), class_embed=True, color_embed=True)
+            c_lo, c_hi = shard_bounds(N_CELLS, world, rank)
+            cells16 = synth.make_cells(c_hi - c_lo, seed=7000 + rank, min_obj=16, max_obj=16)
+            pk = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cells16.items() if k != "counts"}
+            desc = gather_rows(eng_f.fine_encode_objects(pk), N_CELLS)      # every rank: the [N,16,128] descriptor table
+            hints = torch.nn.functional.normalize(torch.randn(N_QUERIES, 6, 128, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)), dim=-1)
+            hi_all = torch.arange(N_QUERIES, dtype=torch.int32, device="cuda").repeat_interleave(TOPK)
+            n_pairs = N_QUERIES * TOPK
+            p_lo, p_hi = shard_bounds(n_pairs, world, rank)
+
+            def coarse_fine():
+                ids, _ = searcher.search(d_q, TOPK)
+                ci = ids.reshape(-1)[p_lo:p_hi].contiguous()
+                off = eng_f.fine_match(desc, hints, ci, hi_all[p_lo:p_hi].contiguous())
+                return gather_rows(off, n_pairs)
+
+            t5, off_all = timed_ranks(coarse_fine, max(5, args.steps // 4))
+            cfg5 = {"what": f"coarse (row-sharded search, one all_gather) + fine ({n_pairs} (pose, cell) pairs split over {world} ranks, offsets "
+                            "all-gathered) per step; descriptor table built from rank shards with one all_gather",
+                    "ms_per_step": t5 * 1e3, "queries_per_s": N_QUERIES / t5, "offsets_finite": bool(torch.isfinite(off_all).all())}
+            eng_f.close()
+        except Exception as e:
+            cfg5 = {"error": repr(e)}
+
     secondary = {}
     if rank == 0 and world == 1 and not args.no_secondary:
         global _QS
@@ -1031,6 +1204,7 @@ def main():
             # the same steps stream-ordered (lanes = 1): what one call costs when the next one waits for it
             "stream_ordered": None if serial_ms is None else {"ms_per_step": serial_ms, "queries_per_s": N_QUERIES / (serial_ms * 1e-3)},
             "steady_state_400_steps": steady,
+            "unramped_contract_region": unramped,
             "pipelined": pipelined,
             "secondary": secondary,
             "parity": {"ids_equal_float64_oracle": parity, "pairs_checked": n_checked,
@@ -1043,6 +1217,10 @@ def main():
         }
         if alt is not None:
             out["alt_query_sharded"] = alt
+        if weak is not None:
+            out["weak_scaling_point"] = weak
+        if cfg5 is not None:
+            out["config5_coarse_plus_fine"] = cfg5
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(db, qs)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -198,6 +198,12 @@ int t2l_pack_pairs(t2l_ctx* ctx, const int32_t* idx, const double* score, int32_
                    void* stream);
 int t2l_merge_pairs(t2l_ctx* ctx, const double* pairs, int32_t parts, int32_t n_queries, int32_t k, int32_t* out_idx,
                     double* out_score, void* stream);
+/* Same exchange with ONE collective and NO pack launch: a rank hands t2l_search output pointers into ONE block —
+ * ids i32[n_queries][k] at offset 0, scores f64[n_queries][k] at score_offset (8-byte aligned, >= 4 * n_queries * k) — the
+ * blocks of all ranks are all-gathered back to back (block_bytes each, 12 bytes per candidate on the wire) and merged here.
+ * (text2loc_amd.sharded.ShardedSearcher: search -> all_gather -> this; the per-rank work of an 8-GPU step is three launches.) */
+int t2l_merge_gathered(t2l_ctx* ctx, const void* blocks, int64_t block_bytes, int64_t score_offset, int32_t parts,
+                       int32_t n_queries, int32_t k, int32_t* out_idx, double* out_score, void* stream);
 
 /* Number of queries of the LAST t2l_search that took the exact-scan fallback (synchronises). */
 int t2l_search_fallbacks(t2l_ctx* ctx, int32_t* out_count);
@@ -345,6 +351,13 @@ int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step,
  *     exponent range): the f32 goldens are met to 1e-4 at close to the bf16 variant's speed. Applies to the PointNet++
  *     training calls too.
  * "search_pair"       (default 1): mode 0 only — 1 = the paired scan (two waves per SIMD), 0 = one wave per SIMD.
+ * "search_xcd_qgroups" (default 4; 1, 2, 4, 8): paired scan — the workgroups of one XCD form a rectangle of (query blocks) x
+ *     (splits): with g groups an XCD's L2 pulls 1/g of the query batch in the prologue and g/8 of the f16 plane over the main
+ *     loop (1 = all queries, 1/8 of the plane: round 2's mapping). Applies when the grid divides evenly, else 1.
+ * "search_prep"       (default 0): paired scan — 1 = the queries' f16 fragment plane is built ONCE per call by a pre-pass launch
+ *     (prep_queries_kernel) instead of by every workgroup's prologue. Measured at Q = 4096: the scan's span drops by 0.7 us, the
+ *     extra dependent launch costs 2 us per stream-ordered step (the prologue is bound by the cold start behind a kernel
+ *     boundary, not by the conversion); under "search_lanes" it is neutral. Results are bit-identical either way.
  * "search_heavy"      (set by the engine, see search_auto): 1 = queries no certificate settles go to the float64 MFMA exact
  *     stage instead of the fallback kernel's float64 VALU scan. With search_auto = 0 the caller may force it.
  * "train_keep_adam_state" (default 0): see t2l_adam_state.

@@ -282,6 +282,20 @@ def test_hip_merge_kernel_vs_host_merge(eng):
     pi, ps = eng.merge_pairs(pairs)
     assert np.array_equal(pi.cpu().numpy().astype(np.int64), hi)
     assert np.array_equal(ps.cpu().numpy(), hs)
+    # the block form (no pack launch): every rank's {ids | scores} block back to back, as t2l_search fills and all_gather delivers
+    buf, _, _, bb, so = eng.result_block(Q, K, "cuda", parts=P)
+    for p_ in range(P):
+        buf[p_, :Q * K * 4].view(torch.int32).view(Q, K).copy_(torch.from_numpy(idx[p_]))
+        buf[p_, so:so + Q * K * 8].view(torch.float64).view(Q, K).copy_(torch.from_numpy(sc[p_]))
+    bi, bs = eng.merge_gathered(buf.view(-1), bb, so, P, Q, K)
+    assert np.array_equal(bi.cpu().numpy().astype(np.int64), hi) and np.array_equal(bs.cpu().numpy(), hs)
+    # wider lists than one lane per candidate (26 x 9 = 234 candidates), odd query counts, K = 1
+    for P2, Q2, K2 in ((9, 5, 26), (2, 131, 1), (25, 3, 10)):
+        idx2 = np.stack([np.stack([rng.permutation(5000)[:K2] for _ in range(Q2)]) + 5000 * p_ for p_ in range(P2)]).astype(np.int32)
+        sc2 = -np.sort(-rng.standard_normal((P2, Q2, K2)), axis=2)
+        g2i, g2s = eng.merge_topk(torch.from_numpy(idx2).cuda(), torch.from_numpy(sc2).cuda())
+        h2i, h2s = merge_topk_host(idx2, sc2, K2)
+        assert np.array_equal(g2i.cpu().numpy().astype(np.int64), h2i) and np.array_equal(g2s.cpu().numpy(), h2s)
 
 
 @pytest.mark.parametrize("n,q,k", [(1, 1, 1), (33, 5, 10), (1000, 64, 10), (4097, 17, 26), (70001, 33, 10)])

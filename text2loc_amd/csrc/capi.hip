@@ -105,7 +105,7 @@ void t2l_destroy(t2l_ctx* ctx) {
   free_fine(ctx);
   free_text_head(ctx);
   for (void* p : {(void*)ctx->db, (void*)ctx->db_split, (void*)ctx->db_half, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
-                  (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count, ctx->reduce_ws, ctx->loss_ws, (void*)ctx->scan_span})
+                  (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count, ctx->reduce_ws, ctx->loss_ws, ctx->qplane, (void*)ctx->scan_span})
     if (p) (void)hipFree(p);
   delete[] ctx->span_grid;
   if (ctx->host_stat) (void)hipHostFree(ctx->host_stat);
@@ -268,6 +268,17 @@ int t2l_merge_pairs(t2l_ctx* ctx, const double* pairs, int32_t parts, int32_t n_
   if (!pairs || !out_idx) return fail(ctx, T2L_EINVAL, "t2l_merge_pairs: null buffer");
   T2L_HIP(ctx, hipSetDevice(ctx->device));
   return merge_pairs_impl(ctx, pairs, parts, n_queries, k, out_idx, out_score, (hipStream_t)stream);
+}
+
+int t2l_merge_gathered(t2l_ctx* ctx, const void* blocks, int64_t block_bytes, int64_t score_offset, int32_t parts, int32_t n_queries,
+                       int32_t k, int32_t* out_idx, double* out_score, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  if (parts < 1 || n_queries < 0 || k < 1 || k > T2L_MAX_TOPK)
+    return fail(ctx, T2L_EINVAL, "t2l_merge_gathered: bad parts / n_queries / k");
+  if (n_queries == 0) return T2L_OK;
+  if (!blocks || !out_idx) return fail(ctx, T2L_EINVAL, "t2l_merge_gathered: null buffer");
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return merge_gathered_impl(ctx, blocks, block_bytes, score_offset, parts, n_queries, k, out_idx, out_score, (hipStream_t)stream);
 }
 
 // counters of the last search of the context's own scratch set, or — with lanes — of the last search of EVERY lane, summed
@@ -447,6 +458,11 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     }
   } else if (!strcmp(name, "search_heavy")) {  // force (1) / release (0) the float64 MFMA exact stage (tests)
     ctx->heavy = value != 0;
+  } else if (!strcmp(name, "search_prep")) {
+    ctx->search_prep = value != 0;
+  } else if (!strcmp(name, "search_xcd_qgroups")) {
+    if (value != 1 && value != 2 && value != 4 && value != 8) return fail(ctx, T2L_EINVAL, "search_xcd_qgroups must be 1, 2, 4 or 8");
+    ctx->xcd_qgroups = (int)value;
   } else if (!strcmp(name, "search_pair_ll")) {
     if (value != 5 && value != 6) return fail(ctx, T2L_EINVAL, "search_pair_ll must be 5 or 6");
     ctx->pair_ll = (int)value;

@@ -509,12 +509,16 @@ __device__ __forceinline__ float dpp_f(float v) {
   return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, true));
 }
 
-template <int LL, int NS>
+// PREP: the queries arrive as the f16 fragment plane of prep_queries_kernel ([query block][wave slot][group][k-step][lane] x 16 B:
+// a wave's fragment load is one contiguous 1 KiB) instead of being converted by every workgroup — the 16 splits of a query
+// block then read 128 KB of f16 each instead of converting 256 KB of f32 each (67 MB -> 33 MB through the L2s, no LDS exchange,
+// no barrier in the prologue).
+template <int LL, int NS, bool PREP>
 __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__ dbt, int n_rows, int n_tiles, int code_bits,
-                                                       const float* __restrict__ q, int Q, int nsplit,
+                                                       const float* __restrict__ q, const uint4* __restrict__ qplane, int Q, int nsplit,
                                                        float* __restrict__ cand, int32_t* __restrict__ fb_count,
                                                        int zero_counts, float pinf, unsigned long long* __restrict__ span,
-                                                       unsigned span_seq) {
+                                                       unsigned span_seq, int xcd_qgroups) {
   static_assert(NS == 4, "the step loop below is unrolled for a ring of 4 slots");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kSlotBytes = 2 * kHalfTileBytes;
@@ -524,7 +528,15 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
   // workgroup -> (query block, split): blockIdx % 8 is the XCD, so the workgroups of one XCD share SPLITS (its L2 pulls all
   // queries and 1/8 of the plane). Measured alternative — sharing query blocks instead (1/8 of the queries in the prologue, the
   // whole plane over the main loop): 47.6 vs 46.7 us per step, rejected.
-  const int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
+  // xcd_qgroups = GQ > 1: XCD x owns the RECTANGLE {query blocks = x % GQ (mod GQ)} x {splits = x / GQ (mod 8 / GQ)} instead: its
+  // L2 pulls 1/GQ of the queries in the prologue (the burst every CU waits for) and GQ/8 of the plane over the main loop.
+  int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
+  if (xcd_qgroups > 1) {
+    const int GQ = xcd_qgroups, GS = 8 / GQ, nqb = gridDim.x / nsplit;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, per = nqb / GQ;
+    qb = (j % per) * GQ + x % GQ;
+    sp = (j / per) * GS + x / GQ;
+  }
   const int uwave = uniform_wave_id();
   const int quad = uwave >> 2, wq = uwave & 3;
   const int vn = 2 * nsplit, vs = sp + quad * nsplit;                     // this wave's virtual split
@@ -581,6 +593,21 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
   // qb*256 + slot*64 + g*32 + col; thread (ql, quarter) = (tid >> 2, tid & 3). LDS exchange rows are 512 B (one f16 query),
   // 16-byte chunk c of row ql at chunk c ^ (ql & 31): conflict-free for the quarter-row writers and the fragment readers.
   u32x4 q0[16], q1[16];  // 128 AGPRs
+  if constexpr (PREP) {
+    const uint4* pl = qplane + (size_t)((qb * 4 + wq) * 2) * 16 * 64 + lane;
+    uint4 v0[16], v1[16];  // all 32 loads in flight, then parked in the AGPRs
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) {
+      v0[s_] = pl[s_ * 64];
+      v1[s_] = pl[(16 + s_) * 64];
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) {
+      q0[s_] = pin_agpr(as_u32x4(v0[s_]));
+      q1[s_] = pin_agpr(as_u32x4(v1[s_]));
+    }
+    __syncthreads();  // (steps 0 and 1 of the tile ring have landed for every wave: vmcnt retired in order behind them)
+  } else
   {
     const int ql = tid >> 2, qt = tid & 3;
     char* ex_w = reinterpret_cast<char*>(smem) + kExchange + ql * 512;
@@ -1162,14 +1189,21 @@ __global__ __launch_bounds__(256) void db_norm_kernel(const float* __restrict__ 
 // One wave per query; parts*K <= 256.
 // ------------------------------------------------------------------------------------------------
 // PAIRS: the input is the all-gathered {score, row id as f64} records of t2l_pack_pairs (idx unused) — no unpack launch.
+// Otherwise part p's ids / scores start part_stride BYTES after part p-1's (t2l_merge_topk: two separate [parts][Q][K] arrays;
+// t2l_merge_gathered: every rank's contiguous {ids | scores} block as all-gathered, no pack launch either).
+// Ranking by counting: the wave's <= 256 candidates sit in LDS ((score, id) = 12 bytes each), every lane counts how many
+// candidates beat each of its own (broadcast reads, no cross-lane dependency chain: the previous K rounds of a 6-step f64
+// butterfly cost ~10k dependent cycles per query) and the K best go straight to their output slots.
 template <bool PAIRS>
-__global__ __launch_bounds__(256) void merge_kernel(const int32_t* __restrict__ idx, const double* __restrict__ score,
-                                                    int parts, int Q, int K, int32_t* __restrict__ out_idx,
+__global__ __launch_bounds__(256) void merge_kernel(const char* __restrict__ idx, size_t idx_stride, const char* __restrict__ score,
+                                                    size_t score_stride, int parts, int Q, int K, int32_t* __restrict__ out_idx,
                                                     double* __restrict__ out_score) {
-  const int lane = threadIdx.x & 63;
-  const int qid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (qid >= Q) return;
-  const int total = parts * K;
+  __shared__ double sh_s[4][256];
+  __shared__ int sh_i[4][256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int qid = blockIdx.x * 4 + wv;
+  if (qid >= Q) return;  // (one wave per query: no workgroup barrier below)
+  const int total = parts * K, ne = (total + 63) >> 6;
   double s[4];
   int id[4];
 #pragma unroll
@@ -1177,53 +1211,71 @@ __global__ __launch_bounds__(256) void merge_kernel(const int32_t* __restrict__ 
     const int c = lane + 64 * e;
     s[e] = -__builtin_inf();
     id[e] = INT_MAX;
-    if (c < total) {
-      const size_t off = ((size_t)(c / K) * Q + qid) * K + (c % K);
+    if (e < ne && c < total) {
+      const int part = c / K;
+      const size_t off = (size_t)qid * K + (c - part * K);
       if constexpr (PAIRS) {
-        const double2 pr = reinterpret_cast<const double2*>(score)[off];
+        const double2 pr = reinterpret_cast<const double2*>(score + part * score_stride)[off];
         const int v = (int)pr.y;
         if (v >= 0) {
           id[e] = v;
           s[e] = pr.x;
         }
       } else {
-        const int v = idx[off];
+        const int v = reinterpret_cast<const int32_t*>(idx + part * idx_stride)[off];
         if (v >= 0) {
           id[e] = v;
-          s[e] = score[off];
+          s[e] = reinterpret_cast<const double*>(score + part * score_stride)[off];
         }
       }
     }
   }
-  for (int r = 0; r < K; ++r) {
-    double bs = s[0];
-    int bi = id[0];
+  // Every shard's list is sorted, so B = the largest K-th entry over the shards is a lower bound of the global K-th best
+  // (that shard alone holds K candidates >= B): only candidates >= B can make the cut — usually K .. 2K of the parts * K —
+  // and only those are ranked. (All scores equal: everybody survives, the loop below is the full all-pairs count.)
+  double bnd = -__builtin_inf();
 #pragma unroll
-    for (int e = 1; e < 4; ++e)
-      if (s[e] > bs || (s[e] == bs && id[e] < bi)) {
-        bs = s[e];
-        bi = id[e];
-      }
+  for (int e = 0; e < 4; ++e) {
+    const int c = lane + 64 * e;
+    if (e < ne && c < total && (c % K) == K - 1) bnd = fmax(bnd, s[e]);
+  }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double os = __shfl_xor(bs, off);
-      const int oi = __shfl_xor(bi, off);
-      if (os > bs || (os == bs && oi < bi)) {
-        bs = os;
-        bi = oi;
-      }
+  for (int off = 32; off >= 1; off >>= 1) bnd = fmax(bnd, __shfl_xor(bnd, off));
+  int n_s = 0;
+  bool sv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sv[e] = e < ne && id[e] != INT_MAX && s[e] >= bnd;
+    const unsigned long long m = __ballot(sv[e]);
+    const int pos = n_s + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+    if (sv[e]) {
+      sh_s[wv][pos] = s[e];
+      sh_i[wv][pos] = id[e];
     }
-    if (lane == 0) {
-      out_idx[(size_t)qid * K + r] = bi == INT_MAX ? -1 : bi;
-      if (out_score) out_score[(size_t)qid * K + r] = bs;
-    }
+    n_s += __popcll(m);
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes are visible to its reads
+  int rank[4] = {0, 0, 0, 0};
+  for (int o = 0; o < n_s; ++o) {
+    const double os = sh_s[wv][o];
+    const int oi = sh_i[wv][o];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      if (bi != INT_MAX && id[e] == bi) {  // row ids are unique across shards
-        s[e] = -__builtin_inf();
-        id[e] = INT_MAX;
-      }
+      if (e < ne) rank[e] += (os > s[e] || (os == s[e] && oi < id[e])) ? 1 : 0;  // row ids are unique across shards
   }
+  // among the survivors the ranks are a permutation of 0..n_s-1, and n_s >= min(K, valid candidates)
+  if (lane < K) {  // default fill for lists with fewer than K valid candidates
+    out_idx[(size_t)qid * K + lane] = -1;
+    if (out_score) out_score[(size_t)qid * K + lane] = -__builtin_inf();
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (sv[e] && rank[e] < K) {
+      out_idx[(size_t)qid * K + rank[e]] = id[e];
+      if (out_score) out_score[(size_t)qid * K + rank[e]] = s[e];
+    }
 }
 
 static int grow(t2l_ctx* ctx, void** p, size_t* cap, size_t need_bytes) {
@@ -1255,7 +1307,8 @@ int pack_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int n, doub
 int merge_pairs_impl(t2l_ctx* ctx, const double* pairs, int parts, int Q, int K, int32_t* out_idx, double* out_score,
                      hipStream_t s) {
   if (parts * K > 256) return fail(ctx, T2L_EINVAL, "t2l_merge_pairs: parts * k must be <= 256");
-  hipLaunchKernelGGL((merge_kernel<true>), dim3((Q + 3) / 4), dim3(256), 0, s, (const int32_t*)nullptr, pairs, parts, Q, K, out_idx, out_score);
+  hipLaunchKernelGGL((merge_kernel<true>), dim3((Q + 3) / 4), dim3(256), 0, s, (const char*)nullptr, (size_t)0, (const char*)pairs,
+                     (size_t)Q * K * 16, parts, Q, K, out_idx, out_score);
   T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;
 }
@@ -1263,7 +1316,20 @@ int merge_pairs_impl(t2l_ctx* ctx, const double* pairs, int parts, int Q, int K,
 int merge_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int parts, int Q, int K, int32_t* out_idx,
                double* out_score, hipStream_t s) {
   if (parts * K > 256) return fail(ctx, T2L_EINVAL, "t2l_merge_topk: parts * k must be <= 256");
-  hipLaunchKernelGGL((merge_kernel<false>), dim3((Q + 3) / 4), dim3(256), 0, s, idx, score, parts, Q, K, out_idx, out_score);
+  hipLaunchKernelGGL((merge_kernel<false>), dim3((Q + 3) / 4), dim3(256), 0, s, (const char*)idx, (size_t)Q * K * 4, (const char*)score,
+                     (size_t)Q * K * 8, parts, Q, K, out_idx, out_score);
+  T2L_HIP(ctx, hipGetLastError());
+  return T2L_OK;
+}
+
+// every rank's {ids i32[Q][K] | scores f64[Q][K] at score_offset} block, all-gathered back to back: merged without a pack launch
+int merge_gathered_impl(t2l_ctx* ctx, const void* blocks, int64_t block_bytes, int64_t score_offset, int parts, int Q, int K,
+                        int32_t* out_idx, double* out_score, hipStream_t s) {
+  if (parts * K > 256) return fail(ctx, T2L_EINVAL, "t2l_merge_gathered: parts * k must be <= 256");
+  if (score_offset % 8 || block_bytes % 8 || score_offset < (int64_t)Q * K * 4 || block_bytes < score_offset + (int64_t)Q * K * 8)
+    return fail(ctx, T2L_EINVAL, "t2l_merge_gathered: a block is {i32[Q][K] ids, f64[Q][K] scores at an 8-byte aligned score_offset}");
+  hipLaunchKernelGGL((merge_kernel<false>), dim3((Q + 3) / 4), dim3(256), 0, s, (const char*)blocks, (size_t)block_bytes,
+                     (const char*)blocks + score_offset, (size_t)block_bytes, parts, Q, K, out_idx, out_score);
   T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;
 }
@@ -1290,6 +1356,34 @@ int db_norm_impl(t2l_ctx* ctx, hipStream_t s) {
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// The queries of one search as the paired scan's f16 fragment plane, converted ONCE (option "search_prep"): per query the
+// power-of-two scale of half_shift_of(max |element|) and RNE to f16 — the arithmetic of the in-kernel prologue, bit for bit —
+// laid out [query block 256][wave slot 4][group 2][k-step 16][lane 64] x 16 B, lane (col, half) of k-step s holding chunk
+// half * 16 + s (k in [8 chunk, +8)) of query block*256 + slot*64 + group*32 + col. Rows beyond Q repeat row Q - 1 (as the
+// in-kernel prologue clamps). One workgroup per 32 queries: coalesced 1 KiB row reads, 512-byte contiguous plane writes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void prep_queries_kernel(const float* __restrict__ q, int Q, uint4* __restrict__ plane) {
+  __shared__ uint4 tile[32][33];
+  const int t = threadIdx.x, ql = t >> 5, c = t & 31;
+  const int base = blockIdx.x * 32;
+  const int qrow = min(base + ql, Q - 1);
+  const float4* qp = reinterpret_cast<const float4*>(q + (size_t)qrow * kD + 8 * c);
+  const float4 a = qp[0], b = qp[1];
+  float m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                  fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));  // the 32 lanes of the row
+  int shift;
+  half_shift_of(m, shift);
+  tile[c][ql] = make_uint4(pack_f16x2(a.x, a.y, shift), pack_f16x2(a.z, a.w, shift), pack_f16x2(b.x, b.y, shift), pack_f16x2(b.z, b.w, shift));
+  __syncthreads();
+  const int c2 = t >> 5, col = t & 31;  // chunk c2 of query base + col
+  const int qb = base >> 8, wq = (base & 255) >> 6, g = (base & 63) >> 5;
+  const int s_ = c2 & 15, half = c2 >> 4;
+  plane[((size_t)(((qb * 4 + wq) * 2 + g) * 16 + s_)) * 64 + half * 32 + col] = tile[c2][col];
+}
+
 static size_t scan_lds_bytes() { return (size_t)2 * kTileFloats * sizeof(float); }
 
 template <typename Kern>
@@ -1312,18 +1406,34 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
     // counts VIRTUAL splits here: the kernel takes physical ones (2 virtual splits per workgroup)
     const dim3 grid((Q + kWideQPerBlock - 1) / kWideQPerBlock * (nsplit / 2));
     const size_t lds = (size_t)4 * 2 * kHalfTileBytes;
-    static bool once = (allow_lds(&scanp_kernel<LL, 4>, (size_t)4 * 2 * kHalfTileBytes), true);
+    static bool once = (allow_lds(&scanp_kernel<LL, 4, false>, (size_t)4 * 2 * kHalfTileBytes),
+                        allow_lds(&scanp_kernel<LL, 4, true>, (size_t)4 * 2 * kHalfTileBytes), true);
     (void)once;
+    const bool prep = ctx->search_prep != 0;
+    if (prep) {  // the f16 fragment plane of this call's queries, converted once (prep_queries_kernel) instead of by every workgroup
+      const int q_pad = (Q + kWideQPerBlock - 1) / kWideQPerBlock * kWideQPerBlock;
+      int rc_ = grow(ctx, (void**)&ctx->qplane, &ctx->qplane_cap, (size_t)q_pad * 512);
+      if (rc_ != T2L_OK) return rc_;
+      hipLaunchKernelGGL(prep_queries_kernel, dim3(q_pad / 32), dim3(1024), 0, s, q, Q, (uint4*)ctx->qplane);
+    }
     const unsigned span_seq = ++ctx->span_seq;
     unsigned long long* span = ctx->scan_span && grid.x <= (unsigned)kSpanWgs ? ctx->scan_span + (size_t)2 * kSpanWgs * (span_seq % kSpanRing) : nullptr;
     if (ctx->span_grid) ctx->span_grid[span_seq % kSpanRing] = span ? grid.x : 0;
+    // the XCD rectangle needs whole query-block groups and split groups on every XCD (else: splits only, as before)
+    int xq = ctx->xcd_qgroups;
+    {
+      const int nqb = (Q + kWideQPerBlock - 1) / kWideQPerBlock, ns = nsplit / 2;
+      if (xq < 2 || 8 % xq || nqb % xq || ns % (8 / xq) || (nqb * ns) % 8) xq = 1;
+    }
     hipEvent_t ea, eb;
     if (event_pair(ctx, "search_scan", &ea, &eb))  // sampled launch: the dispatch carries its own start / stop events
-      hipExtLaunchKernelGGL((scanp_kernel<LL, 4>), grid, dim3(512), (uint32_t)lds, s, ea, eb, 0u, dbh, n_rows, n_tiles, code_bits,
-                            q, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, zero, __builtin_inff(), span, span_seq);
+      hipExtLaunchKernelGGL(prep ? (scanp_kernel<LL, 4, true>) : (scanp_kernel<LL, 4, false>), grid, dim3(512), (uint32_t)lds, s, ea, eb, 0u,
+                            dbh, n_rows, n_tiles, code_bits, q, (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, zero,
+                            __builtin_inff(), span, span_seq, xq);
     else
-      hipLaunchKernelGGL((scanp_kernel<LL, 4>), grid, dim3(512), lds, s, dbh, n_rows, n_tiles, code_bits, q, Q, nsplit / 2,
-                         ctx->cand_score, ctx->fb_count, zero, __builtin_inff(), span, span_seq);
+      hipLaunchKernelGGL(prep ? (scanp_kernel<LL, 4, true>) : (scanp_kernel<LL, 4, false>), grid, dim3(512), lds, s, dbh, n_rows, n_tiles,
+                         code_bits, q, (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, zero, __builtin_inff(), span,
+                         span_seq, xq);
   } else {
   event_begin(ctx, "search_scan", s);
   if (ctx->eff_mode == 0) {  // f16 MFMA scan, one wave per SIMD (tiny shards, k > 10): 256 queries per workgroup
@@ -1513,6 +1623,8 @@ static void swap_lane(t2l_ctx* ctx, t2l_ctx::SearchLane& L) {
   std::swap(ctx->host_stat, L.host_stat);
   std::swap(ctx->host_stat_dev, L.host_stat_dev);
   std::swap(ctx->stat_seen, L.stat_seen);
+  std::swap(ctx->qplane, L.qplane);
+  std::swap(ctx->qplane_cap, L.qplane_cap);
 }
 
 int search_join_impl(t2l_ctx* ctx, hipStream_t s) {
@@ -1527,7 +1639,7 @@ int search_join_impl(t2l_ctx* ctx, hipStream_t s) {
 
 void free_lanes(t2l_ctx* ctx) {
   for (auto& L : ctx->lanes) {
-    for (void* p : {(void*)L.cand_score, (void*)L.flags, (void*)L.fb_count})
+    for (void* p : {(void*)L.cand_score, (void*)L.flags, (void*)L.fb_count, L.qplane})
       if (p) (void)hipFree(p);
     if (L.host_stat) (void)hipHostFree(L.host_stat);
     if (L.stream) (void)hipStreamDestroy(L.stream);

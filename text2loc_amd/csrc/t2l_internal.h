@@ -44,6 +44,8 @@ int search_stream_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_
 int pack_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int n, double* pairs, hipStream_t s);
 int merge_pairs_impl(t2l_ctx* ctx, const double* pairs, int parts, int Q, int K, int32_t* out_idx, double* out_score,
                      hipStream_t s);
+int merge_gathered_impl(t2l_ctx* ctx, const void* blocks, int64_t block_bytes, int64_t score_offset, int parts, int Q, int K,
+                        int32_t* out_idx, double* out_score, hipStream_t s);
 // reduce.hip
 int reduce_impl(t2l_ctx* ctx, const float* xyz, const float* rgb, const int64_t* offsets, int n_objects,
                 const float* centers, const int32_t* rows, int n_colors, float* out_rgb, float* out_center,
@@ -92,6 +94,11 @@ struct t2l_ctx {
   int encoder_f16 = 0;   // 1: plain-f16 products (one MFMA per operand pair) instead of split-f16: ~1e-4 instead of 2e-7, 28 % faster
   int search_auto = 1;
   int pair_ll = 6;       // per-lane list length of the paired scan (5 or 6)
+  int search_prep = 0;   // paired scan: 1 = the queries' f16 fragment plane is built by a pre-pass launch, once per call
+  void* qplane = nullptr;  // ... that plane (q_pad x 512 B)
+  size_t qplane_cap = 0;
+  int xcd_qgroups = 4;   // paired scan: query-block groups per XCD rectangle (1 = every XCD sees all queries and 1/8 of the splits;
+                         // 4 = a quarter of the queries and half of the splits: -1.3 us of scan span at Q = 4096 x N = 11,259, measured)
   int search_pair = 1;   // mode 0: 1 = the paired scan (two waves per SIMD, scanp_kernel), 0 = scanh_kernel (one wave per SIMD)
   int train_bf16 = 0;       // 1: the training step's GEMMs round their operands to bf16 (one bf16 MFMA per 16-step); 2: split-bf16 (three)
   int train_keep_adam = 0;  // 1: t2l_train_bind keeps Adam moments + step when the parameter list is unchanged (a re-bind)
@@ -107,7 +114,8 @@ struct t2l_ctx {
   // into the caller's stream by t2l_search_join.
   struct SearchLane {
     float* cand_score = nullptr;
-    size_t cand_cap = 0, flag_cap = 0;
+    void* qplane = nullptr;
+    size_t cand_cap = 0, flag_cap = 0, qplane_cap = 0;
     int32_t *flags = nullptr, *fb_count = nullptr, *host_stat = nullptr, *host_stat_dev = nullptr;
     int stat_seen = 0;
     hipStream_t stream = nullptr;

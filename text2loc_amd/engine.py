@@ -65,6 +65,8 @@ EXPORTS = {
     "t2l_pack_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "t2l_merge_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
+    "t2l_merge_gathered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
     "t2l_search_fallbacks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "t2l_search_rescored": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "t2l_search_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
@@ -485,6 +487,25 @@ class Engine:
         out_s = torch.empty((Q, K), dtype=torch.float64, device=pairs.device)
         self._check(self.lib.t2l_merge_pairs(self._h, _dev_ptr(pairs, torch.float64, "pairs"), P, Q, K, out_i.data_ptr(),
                                              out_s.data_ptr(), _stream_ptr()))
+        return out_i, out_s
+
+    @staticmethod
+    def result_block(Q: int, k: int, device, parts: int = 1):
+        """One exchange block per part: ``(buf u8[parts, block_bytes], idx i32[Q,k] view, score f64[Q,k] view, block_bytes,
+        score_offset)`` — the views alias part 0's block, so ``search(..., out=(idx, score))`` fills it in place."""
+        score_offset = (Q * k * 4 + 7) // 8 * 8
+        block_bytes = score_offset + Q * k * 8
+        buf = torch.empty((parts, block_bytes), dtype=torch.uint8, device=device)
+        idx = buf[0, :Q * k * 4].view(torch.int32).view(Q, k)
+        sc = buf[0, score_offset:score_offset + Q * k * 8].view(torch.float64).view(Q, k)
+        return buf, idx, sc, block_bytes, score_offset
+
+    def merge_gathered(self, blocks: torch.Tensor, block_bytes: int, score_offset: int, parts: int, Q: int, k: int):
+        """blocks u8[parts * block_bytes] (all-gathered ``result_block``s) -> (idx i32[Q,k], score f64[Q,k])."""
+        out_i = torch.empty((Q, k), dtype=torch.int32, device=blocks.device)
+        out_s = torch.empty((Q, k), dtype=torch.float64, device=blocks.device)
+        self._check(self.lib.t2l_merge_gathered(self._h, _dev_ptr(blocks, torch.uint8, "blocks"), int(block_bytes), int(score_offset),
+                                                int(parts), int(Q), int(k), out_i.data_ptr(), out_s.data_ptr(), _stream_ptr()))
         return out_i, out_s
 
     def search_fallbacks(self) -> int:

@@ -119,43 +119,36 @@ class ShardedSearcher:
         return lo, hi
 
     def _scratch_for(self, Q: int, k: int, dev):
-        """(idx i32[Q,k], score f64[Q,k], pairs f64[Q,k,2], all pairs f64[world*Q,k,2]) as contiguous slices of one scratch set
-        that only grows (variable query-batch sizes do not accumulate buffers). Reuse is safe because every consumer is
-        ordered on the stream that owns the set; a caller on ANOTHER stream gets fresh tensors for that call."""
+        """(own block u8[block_bytes] with idx / score views into it, all blocks u8[world * block_bytes], block_bytes,
+        score_offset): ONE scratch set per (Q, k) geometry last used — it is re-made when the geometry changes, so variable
+        query-batch sizes do not accumulate buffers. Reuse is safe because every consumer is ordered on the stream that owns
+        the set; a caller on ANOTHER stream gets fresh tensors for that call."""
         import torch
 
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
-        need = Q * k
         sc = self._scratch
-        if sc is not None and (sc["dev"] != dev or sc["stream"] != stream):
-            if sc["dev"] == dev:  # foreign stream: do not touch the owner's buffers
-                return (torch.empty((Q, k), dtype=torch.int32, device=dev), torch.empty((Q, k), dtype=torch.float64, device=dev),
-                        torch.empty((Q, k, 2), dtype=torch.float64, device=dev),
-                        torch.empty((self.world * Q, k, 2), dtype=torch.float64, device=dev))
-            sc = None
-        if sc is None or sc["cap"] < need:
-            cap = max(need, 0 if sc is None else sc["cap"])
-            sc = self._scratch = {"dev": dev, "stream": stream, "cap": cap,
-                                  "idx": torch.empty(cap, dtype=torch.int32, device=dev),
-                                  "sc": torch.empty(cap, dtype=torch.float64, device=dev),
-                                  "pairs": torch.empty(cap * 2, dtype=torch.float64, device=dev),
-                                  "all": torch.empty(self.world * cap * 2, dtype=torch.float64, device=dev)}
-        return (sc["idx"][:need].view(Q, k), sc["sc"][:need].view(Q, k), sc["pairs"][:need * 2].view(Q, k, 2),
-                sc["all"][:self.world * need * 2].view(self.world * Q, k, 2))
+        if sc is not None and sc["key"] == (Q, k, dev) and sc["stream"] != stream:
+            own, idx, score, bb, so = self.engine.result_block(Q, k, dev)
+            return own.view(-1), idx, score, torch.empty(self.world * bb, dtype=torch.uint8, device=dev), bb, so
+        if sc is None or sc["key"] != (Q, k, dev):
+            own, idx, score, bb, so = self.engine.result_block(Q, k, dev)
+            sc = self._scratch = {"key": (Q, k, dev), "stream": stream, "own": own.view(-1), "idx": idx, "score": score,
+                                  "all": torch.empty(self.world * bb, dtype=torch.uint8, device=dev), "bb": bb, "so": so}
+        return sc["own"], sc["idx"], sc["score"], sc["all"], sc["bb"], sc["so"]
 
     def search(self, queries, k: int):
         import torch
 
         if self.world > 1 and self.engine is not None and self._default_fns:
-            # ONE collective: {score, row id} records (row ids are exact in float64), 16 B per candidate. The per-shard
-            # results and the exchange buffers are scratch, reused call after call (a step is ~70 us of GPU time: five
-            # tensor allocations per call would make the host the bottleneck)
+            # ONE collective and THREE launches per rank: scan + re-rank write ids and scores into one block, the blocks of all
+            # ranks are all-gathered back to back (12 B per candidate), t2l_merge_gathered ranks them. The exchange buffers are
+            # scratch, reused call after call (a step is tens of microseconds of GPU time: per-call allocations would make the
+            # host the bottleneck)
             Q = int(queries.shape[0])
-            idx, sc, pairs, allp = self._scratch_for(Q, int(k), queries.device)
+            own, idx, sc, allb, bb, so = self._scratch_for(Q, int(k), queries.device)
             self.engine.search(queries, k, out=(idx, sc))
-            self.engine.pack_pairs(idx, sc, out=pairs)
-            _all_gather(self.dist, allp, pairs, self.group)
-            return self.engine.merge_pairs(allp.view(self.world, Q, k, 2))
+            _all_gather(self.dist, allb, own, self.group)
+            return self.engine.merge_gathered(allb, bb, so, self.world, Q, int(k))
         idx, sc = self.search_fn(queries, k)
         if self.world == 1:
             return idx, sc
