@@ -607,20 +607,21 @@ def secondary_measurements(eng):
         eng_s.db_set(shard, row_offset=0)
         dq_all = torch.from_numpy(np.ascontiguousarray(_QS)).cuda()
         Qn = int(dq_all.shape[0])
-        own, idx_s, sc_s, bb, so = eng_s.result_block(Qn, TOPK, "cuda")          # ids | scores: one exchange block
-        allb = torch.empty((P, bb), dtype=torch.uint8, device="cuda")
+        allb, idx_s, sc_s, bb, so = eng_s.result_block(Qn, TOPK, "cuda", parts=P)   # P exchange blocks {ids | scores}; the views alias block 0
+        m_out = (torch.empty((Qn, TOPK), dtype=torch.int32, device="cuda"), torch.empty((Qn, TOPK), dtype=torch.float64, device="cuda"))
         eng_s.search(dq_all, TOPK, out=(idx_s, sc_s))
-        for r in range(P):  # stand-in for the all_gather: rank r's block = this shard's scores scaled down a little, ids shifted
+        for r in range(1, P):  # stand-in for the all_gather: rank r's block = this shard's scores scaled down a little, ids shifted
             blk_i = allb[r, :Qn * TOPK * 4].view(torch.int32).view(Qn, TOPK)
             blk_s = allb[r, so:so + Qn * TOPK * 8].view(torch.float64).view(Qn, TOPK)
             blk_i.copy_(idx_s + r * n_shard)
             blk_s.copy_(sc_s * (1.0 - 0.003 * ((r * 5) % P)))
         eng_s.set_option("profile_events", 0)
 
-        def shard_step():
-            eng_s.search(dq_all, TOPK, out=(idx_s, sc_s))   # (rank 0's block is re-written in place with the same values)
-            allb[0].copy_(own[0], non_blocking=True)        # the local block's trip into the gathered buffer
-            return eng_s.merge_gathered(allb.view(-1), bb, so, P, Qn, TOPK)
+        allv = allb.view(-1)
+
+        def shard_step():  # (no allocation, no torch op: the host must not be what is measured)
+            eng_s.search(dq_all, TOPK, out=(idx_s, sc_s))   # this rank's block, written in place (block 0 of the gathered buffer)
+            return eng_s.merge_gathered(allv, bb, so, P, Qn, TOPK, out=m_out)
 
         n_ramp_s, n_s = (10, 20) if _QUICK else (1500, 400)
         for _ in range(n_ramp_s):
@@ -643,7 +644,13 @@ def secondary_measurements(eng):
             return (time.perf_counter() - t0) / n_s * 1e3
 
         t_search = only(lambda: eng_s.search(dq_all, TOPK, out=(idx_s, sc_s)))
-        t_merge = only(lambda: eng_s.merge_gathered(allb.view(-1), bb, so, P, Qn, TOPK))
+        t_merge = only(lambda: eng_s.merge_gathered(allv, bb, so, P, Qn, TOPK, out=m_out))
+        eng_s.set_option("profile_events", 1)
+        for _ in range(20):
+            shard_step()
+        torch.cuda.synchronize()
+        k_scan, k_rr = eng_s.kernel_stats("search_scan")[0], eng_s.kernel_stats("search_rerank")[0]
+        eng_s.set_option("profile_events", 0)
         from text2loc_amd.sharded import merge_topk_host
         hi_, hs_ = [], []
         for r in range(P):
@@ -652,8 +659,9 @@ def secondary_measurements(eng):
         ref_i, ref_s = merge_topk_host(np.stack(hi_), np.stack(hs_), TOPK)
         ok = bool(np.array_equal(mi[:256].cpu().numpy().astype(np.int64), ref_i)) and bool(np.array_equal(ms_[:256].cpu().numpy(), ref_s))
         out["shard_step_model"] = {"what": f"per-rank work of an {P}-GPU row-sharded step on one GPU: t2l_search over {n_shard} rows for all "
-                                           f"{Qn} queries (ids | scores written into one exchange block) + the block's copy into the gathered buffer + t2l_merge_gathered(P={P}); the all_gather itself is not in it",
-                                   "us_per_step": t_all * 1e6, "search_us": t_search * 1e3, "merge_us": t_merge * 1e3,
+                                           f"{Qn} queries (ids | scores written straight into its exchange block) + t2l_merge_gathered(P={P}): three launches; the all_gather itself is not in it",
+                                   "us_per_step": t_all * 1e6, "search_us_back_to_back": t_search * 1e3, "merge_us_back_to_back": t_merge * 1e3,
+                                   "scan_kernel_us": k_scan * 1e3, "rerank_kernel_us": k_rr * 1e3,
                                    "queries_per_s_if_the_collective_were_free": Qn / t_all, "merge_equals_host_merge_on_256_queries": ok}
         eng_s.close()
     except Exception as e:
@@ -893,7 +901,7 @@ def main():
             return eng.search(d_qs[i % N_BATCH], TOPK, out=outs[i % N_OUT], join=False)
         if world == 1:  # (ShardedSearcher.search is this call plus the exchange step that one rank does not have)
             return eng.search(d_qs[i % N_BATCH], TOPK, out=outs[i % N_OUT])
-        return searcher.search(d_qs[i % N_BATCH], TOPK)
+        return searcher.search(d_qs[i % N_BATCH], TOPK, out=outs[i % N_OUT])
 
     # the same loop stream-ordered (lanes = 1), for the record: what one call costs when the next one waits for it
     serial_ms = None
@@ -1001,16 +1009,19 @@ def main():
     parity, max_score_err, recall1, n_checked = True, 0.0, [], 0
     pipelined_equal = True
     serial_results = {}
+    sharded_results = {}
+    if world > 1:  # every rank takes part in the exchange of every rotated batch; rank 0 then checks all of them
+        for bi in range(N_BATCH):
+            ri, rs_ = searcher.search(d_qs[bi], TOPK)
+            sharded_results[bi] = (ri.clone(), rs_.clone())
     if rank == 0:
         from oracle import c_oracle
         from concurrent.futures import ThreadPoolExecutor
         nthr = min(32, os.cpu_count() or 1)
         for bi, (bq, btarget) in enumerate(batches):
             gi, gs = searcher.search(d_qs[bi], TOPK) if world == 1 else (None, None)
-            if world > 1:  # collectives need every rank: use the timed loop's last result for its own batch only
-                if bi != (args.steps - 1) % N_BATCH:
-                    continue
-                gi, gs = idx, sc
+            if world > 1:
+                gi, gs = sharded_results[bi]
             serial_results[bi] = (gi, gs)
             if bi in timed_out:  # the timed (pipelined) loop's own results are the ones checked
                 pipelined_equal = pipelined_equal and bool(torch.equal(timed_out[bi][0], gi) and torch.equal(timed_out[bi][1], gs))

@@ -32,7 +32,23 @@ struct GemmArgs {
                   // weights, f32 everything else). 2: split-bf16 — every operand as hi + lo bf16 (lo = bf16(v - hi)) and three
                   // MFMAs per 16-step (hi*hi + hi*lo + lo*hi): relative product error <= 2^-16 + 2^-18 with f32's exponent
                   // range (no magnitude guards needed, unlike split-f16), 2.7x fewer matrix-pipe cycles than f32
+  // fused element-wise links of the training step (all optional; element index = row * ldc + column, as the standalone kernels):
+  float* C2;               // epi == 1: C = relu output (saved for backward), C2 = the same after dropout (the next GEMM's input)
+  const float* mask_src;   // epi == 2: value *= (mask_src[idx] > 0) and the dropout factor (ReLU + dropout backward)
+  uint32_t drop_key, drop_thr;  // counter-based dropout (train_kernels.h: keep_bit); drop_thr == 0: identity
+  float drop_scale;
+  int epi;
 };
+
+__device__ __forceinline__ bool gemm_keep_bit(uint32_t key, uint32_t idx, uint32_t thr) {  // == train_kernels.h: keep_bit
+  uint32_t x = idx * 0x9E3779B1u + key;
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return (x >> 8) >= thr;
+}
 
 typedef __bf16 gemm_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float gemm_f32x8 __attribute__((ext_vector_type(8)));
@@ -66,12 +82,10 @@ __device__ __forceinline__ void gemm_load(const float* __restrict__ P, int ld, i
 }
 
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  __shared__ float red[4 * 16 * 64];
-  __shared__ float cred[4 * 64];
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, int bx, int by, int bz, float* red, float* cred) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, kh = lane >> 5;
-  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
-  const int kb = blockIdx.z * g.kchunk, ke = min(g.K, kb + g.kchunk);
+  const int n0 = bx * 32, m0 = by * 32;
+  const int kb = bz * g.kchunk, ke = min(g.K, kb + g.kchunk);
   const int slice = ((((ke - kb) + 3) / 4) + 15) & ~15;  // per-wave share of the reduction range, whole 16-steps
   const int wk0 = kb + w * slice, wk1 = min(ke, wk0 + slice);
   const bool a_ok = !A_KC || (m0 + i) < g.M;
@@ -82,7 +96,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // from L2 (~1 us away), so the loads of several steps have to be in flight at once — nothing else hides that latency
   constexpr int kRing = 4;
   float a[kRing][8], b[kRing][8], csum = 0.f;
-  const bool do_colsum = !A_KC && g.colsum && blockIdx.x == 0;
+  const bool do_colsum = !A_KC && g.colsum && bx == 0;
 #pragma unroll
   for (int d = 0; d < kRing; ++d)
     if (wk0 + 16 * d < wk1) {
@@ -140,14 +154,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), cg = n0 + (l & 31);
     if (row < g.M) {
       float v = red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l];
-      if (g.bias && blockIdx.z == 0) v += g.bias[cg];
+      if (g.bias && bz == 0) v += g.bias[cg];
       if (g.relu) v = fmaxf(v, 0.f);
-      float* dst = g.C + (size_t)row * g.ldc + cg;
+      const size_t idx = (size_t)row * g.ldc + cg;
+      if (g.epi == 2) {  // ReLU + dropout backward of the layer whose output fed this product's left operand
+        v = g.mask_src[idx] > 0.f ? v : 0.f;
+        if (g.drop_thr) v = gemm_keep_bit(g.drop_key, (uint32_t)idx, g.drop_thr) ? v * g.drop_scale : 0.f;
+      }
+      float* dst = g.C + idx;
       if (g.accumulate)
         unsafeAtomicAdd(dst, v);
       else
         *dst = v;
+      if (g.epi == 1) g.C2[idx] = gemm_keep_bit(g.drop_key, (uint32_t)idx, g.drop_thr) ? v * g.drop_scale : 0.f;
     }
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  __shared__ float red[4 * 16 * 64];
+  __shared__ float cred[4 * 64];
+  gemm_body<A_KC, B_KC>(g, blockIdx.x, blockIdx.y, blockIdx.z, red, cred);
+}
+
+// Two products that depend on the same dY and on nothing of each other — dW += dY^T X (with the bias gradient) and
+// dX = dY W — as ONE launch: workgroups [0, tn_blocks) take the first, the rest the second (a dependent launch costs ~5 us
+// whatever its size: 11 of them per training step).
+struct GemmPair {
+  GemmArgs tn, nn;
+  int tn_gx, tn_gy, tn_blocks, nn_gx;
+};
+static __global__ __launch_bounds__(256) void gemm_pair_kernel(GemmPair p) {
+  __shared__ float red[4 * 16 * 64];
+  __shared__ float cred[4 * 64];
+  const int b = blockIdx.x;
+  if (b < p.tn_blocks) {
+    const int bx = b % p.tn_gx, by = (b / p.tn_gx) % p.tn_gy, bz = b / (p.tn_gx * p.tn_gy);
+    gemm_body<false, false>(p.tn, bx, by, bz, red, cred);
+  } else {
+    const int c = b - p.tn_blocks;
+    gemm_body<true, false>(p.nn, c % p.nn_gx, c / p.nn_gx, 0, red, cred);
   }
 }
 

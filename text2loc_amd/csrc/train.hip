@@ -130,6 +130,31 @@ static void gemm_tn(const float* dY, const float* X, float* dW, float* db, int M
   GemmArgs g{dY, X, dW, nullptr, N, Kp, M, N, Kp, Kp, 0, 1, kchunk, db, tl_gemm_bf16};
   hipLaunchKernelGGL((gemm_kernel<false, false>), dim3(Kp / 32, N / 32, ksplit), dim3(256), 0, s, g);
 }
+// dW[N,Kp] += dY^T X (+ db) and dX[M,Kp] (+)= dY W in ONE launch (both read dY only); mask_src / drop: the ReLU + dropout backward
+// of the layer that produced X's pre-image, applied in dX's epilogue (epi 2) instead of by a launch of its own
+static void gemm_tn_nn(const float* dY, const float* X, float* dW, float* db, const float* W, float* dX, int M, int N, int Kp, int accumulate,
+                       const float* mask_src, const Drop* drop, hipStream_t s) {
+  const int tiles = (N / 32) * (Kp / 32);
+  int ksplit = std::max(1, std::min((M + 255) / 256, (1024 + tiles - 1) / tiles));
+  int kchunk = (((M + ksplit - 1) / ksplit) + 63) & ~63;
+  ksplit = (M + kchunk - 1) / kchunk;
+  GemmPair p{};
+  p.tn = GemmArgs{dY, X, dW, nullptr, N, Kp, M, N, Kp, Kp, 0, 1, kchunk, db, tl_gemm_bf16};
+  p.nn = GemmArgs{dY, W, dX, nullptr, M, Kp, N, N, Kp, Kp, 0, accumulate, N, nullptr, tl_gemm_bf16};
+  if (mask_src) {
+    p.nn.epi = 2;
+    p.nn.mask_src = mask_src;
+    p.nn.drop_key = drop->key;
+    p.nn.drop_thr = drop->thr;
+    p.nn.drop_scale = drop->scale;
+  }
+  p.tn_gx = Kp / 32;
+  p.tn_gy = N / 32;
+  p.tn_blocks = p.tn_gx * p.tn_gy * ksplit;
+  p.nn_gx = Kp / 32;
+  const int nn_blocks = p.nn_gx * ((M + 31) / 32);
+  hipLaunchKernelGGL(gemm_pair_kernel, dim3(p.tn_blocks + nn_blocks), dim3(256), 0, s, p);
+}
 static int need(t2l_ctx* ctx, TrainState* st, const std::string& name, int64_t numel, bool with_grad, TTensor** out) {
   auto it = st->t.find(name);
   if (it == st->t.end()) return fail(ctx, T2L_EINVAL, "t2l_train_bind: missing tensor '" + name + "'");
@@ -409,10 +434,18 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
     gemm_nt(L.O, T_(st, L.prefix + ".self_attn.out_proj.weight").data, T_(st, L.prefix + ".self_attn.out_proj.bias").data, tmp, T, kTD, kTD, 0, s);
     hipLaunchKernelGGL(ln_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, x, tmp, T, T_(st, L.prefix + ".norm1.weight").data,
                        T_(st, L.prefix + ".norm1.bias").data, make_drop(seed, l * 4 + 1, p), L.x1, L.xhat1, L.rstd1);
-    gemm_nt(L.x1, T_(st, L.prefix + ".linear1.weight").data, T_(st, L.prefix + ".linear1.bias").data, L.h, T, 2 * kTD, kTD, 1, s);
-    if (p > 0.f) {
-      const size_t n = (size_t)T * 2 * kTD;
-      hipLaunchKernelGGL(drop_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, L.h, n, make_drop(seed, l * 4 + 2, p), L.hd);
+    {  // linear1 + ReLU, and the dropout behind it in the same epilogue (h is kept for backward, hd feeds linear2)
+      GemmArgs g{L.x1, T_(st, L.prefix + ".linear1.weight").data, L.h, T_(st, L.prefix + ".linear1.bias").data, T, 2 * kTD, kTD, kTD, kTD, 2 * kTD,
+                 1, 0, kTD, nullptr, tl_gemm_bf16};
+      if (p > 0.f) {
+        const Drop dr = make_drop(seed, l * 4 + 2, p);
+        g.epi = 1;
+        g.C2 = L.hd;
+        g.drop_key = dr.key;
+        g.drop_thr = dr.thr;
+        g.drop_scale = dr.scale;
+      }
+      hipLaunchKernelGGL((gemm_kernel<true, true>), dim3(2 * kTD / 32, (T + 31) / 32, 1), dim3(256), 0, s, g);
     }
     gemm_nt(L.hd, T_(st, L.prefix + ".linear2.weight").data, T_(st, L.prefix + ".linear2.bias").data, tmp, T, kTD, 2 * kTD, 0, s);
     hipLaunchKernelGGL(ln_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, L.x1, tmp, T, T_(st, L.prefix + ".norm2.weight").data,
@@ -446,8 +479,11 @@ static void mlp_layer_bwd(TrainState* st, const MlpLayer& L, float* d, const flo
     hipLaunchKernelGGL(smallk_bwd_kernel, dim3((M + rows - 1) / rows), dim3(256), 0, s, x, M, small_k, d, standardize, 1826.6844940968194f,
                        2516.8905096993817f, rows, T_(st, L.prefix + ".0.weight").grad, T_(st, L.prefix + ".0.bias").grad);
   } else {
-    gemm_tn(d, x, T_(st, L.prefix + ".0.weight").grad, T_(st, L.prefix + ".0.bias").grad, M, L.cout, L.cin, s);
-    if (dx) gemm_nn(d, T_(st, L.prefix + ".0.weight").data, dx, M, L.cout, L.cin, 0, s);
+    if (dx)
+      gemm_tn_nn(d, x, T_(st, L.prefix + ".0.weight").grad, T_(st, L.prefix + ".0.bias").grad, T_(st, L.prefix + ".0.weight").data, dx, M, L.cout,
+                 L.cin, 0, nullptr, nullptr, s);
+    else
+      gemm_tn(d, x, T_(st, L.prefix + ".0.weight").grad, T_(st, L.prefix + ".0.bias").grad, M, L.cout, L.cin, s);
   }
 }
 
@@ -488,26 +524,22 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_grid), dim3(256), 0, s, dcur, L.xhat2, L.rstd2, T, W(".norm2.weight").data,
                        make_drop(st->seed, l * 4 + 3, st->p), dA, dB, W(".norm2.weight").grad, W(".norm2.bias").grad);
     // linear2
-    gemm_tn(dB, L.hd, W(".linear2.weight").grad, W(".linear2.bias").grad, T, kTD, 2 * kTD, s);
-    gemm_nn(dB, W(".linear2.weight").data, dH, T, kTD, 2 * kTD, 0, s);
-    {
-      const size_t n = (size_t)T * 2 * kTD;
-      hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dH, L.h, n,
-                         make_drop(st->seed, l * 4 + 2, st->p));
+    {  // dW2 += dB^T hd, and dH = (dB W2) through the ReLU + dropout backward — one launch
+      const Drop dr = make_drop(st->seed, l * 4 + 2, st->p);
+      gemm_tn_nn(dB, L.hd, W(".linear2.weight").grad, W(".linear2.bias").grad, W(".linear2.weight").data, dH, T, kTD, 2 * kTD, 0, L.h, &dr, s);
     }
     // linear1; dA (= dz2, the residual path) += dH W1
-    gemm_tn(dH, L.x1, W(".linear1.weight").grad, W(".linear1.bias").grad, T, 2 * kTD, kTD, s);
-    gemm_nn(dH, W(".linear1.weight").data, dA, T, 2 * kTD, kTD, 1, s);
+    gemm_tn_nn(dH, L.x1, W(".linear1.weight").grad, W(".linear1.bias").grad, W(".linear1.weight").data, dA, T, 2 * kTD, kTD, 1, nullptr, nullptr, s);
     // norm1 + dropout1
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_grid), dim3(256), 0, s, dA, L.xhat1, L.rstd1, T, W(".norm1.weight").data,
                        make_drop(st->seed, l * 4 + 1, st->p), dC, dB2, W(".norm1.weight").grad, W(".norm1.bias").grad);
     // out_proj
-    gemm_tn(dB2, L.O, W(".self_attn.out_proj.weight").grad, W(".self_attn.out_proj.bias").grad, T, kTD, kTD, s);
-    gemm_nn(dB2, W(".self_attn.out_proj.weight").data, dO, T, kTD, kTD, 0, s);
+    gemm_tn_nn(dB2, L.O, W(".self_attn.out_proj.weight").grad, W(".self_attn.out_proj.bias").grad, W(".self_attn.out_proj.weight").data, dO, T, kTD,
+               kTD, 0, nullptr, nullptr, s);
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * kTH), dim3(256), 0, s, L.qkv, L.P, dO, dqkv, make_drop(st->seed, l * 4 + 0, st->p));
     // in_proj; dC (= dz1, the residual path) += dqkv Win
-    gemm_tn(dqkv, L.x_in, W(".self_attn.in_proj_weight").grad, W(".self_attn.in_proj_bias").grad, T, 3 * kTD, kTD, s);
-    gemm_nn(dqkv, W(".self_attn.in_proj_weight").data, dC, T, 3 * kTD, kTD, 1, s);
+    gemm_tn_nn(dqkv, L.x_in, W(".self_attn.in_proj_weight").grad, W(".self_attn.in_proj_bias").grad, W(".self_attn.in_proj_weight").data, dC, T,
+               3 * kTD, kTD, 1, nullptr, nullptr, s);
     std::swap(dcur, dC);
   }
   // tokens -> objects, merge MLP

@@ -500,10 +500,13 @@ class Engine:
         sc = buf[0, score_offset:score_offset + Q * k * 8].view(torch.float64).view(Q, k)
         return buf, idx, sc, block_bytes, score_offset
 
-    def merge_gathered(self, blocks: torch.Tensor, block_bytes: int, score_offset: int, parts: int, Q: int, k: int):
+    def merge_gathered(self, blocks: torch.Tensor, block_bytes: int, score_offset: int, parts: int, Q: int, k: int, out=None):
         """blocks u8[parts * block_bytes] (all-gathered ``result_block``s) -> (idx i32[Q,k], score f64[Q,k])."""
-        out_i = torch.empty((Q, k), dtype=torch.int32, device=blocks.device)
-        out_s = torch.empty((Q, k), dtype=torch.float64, device=blocks.device)
+        if out is None:
+            out_i = torch.empty((Q, k), dtype=torch.int32, device=blocks.device)
+            out_s = torch.empty((Q, k), dtype=torch.float64, device=blocks.device)
+        else:
+            out_i, out_s = out
         self._check(self.lib.t2l_merge_gathered(self._h, _dev_ptr(blocks, torch.uint8, "blocks"), int(block_bytes), int(score_offset),
                                                 int(parts), int(Q), int(k), out_i.data_ptr(), out_s.data_ptr(), _stream_ptr()))
         return out_i, out_s

@@ -136,7 +136,9 @@ class ShardedSearcher:
                                   "all": torch.empty(self.world * bb, dtype=torch.uint8, device=dev), "bb": bb, "so": so}
         return sc["own"], sc["idx"], sc["score"], sc["all"], sc["bb"], sc["so"]
 
-    def search(self, queries, k: int):
+    def search(self, queries, k: int, out=None):
+        """``out`` = (idx i32[Q,k], score f64[Q,k]) to write the merged result into (engine path; a serving loop that
+        rotates a few output sets avoids two allocations per call)."""
         import torch
 
         if self.world > 1 and self.engine is not None and self._default_fns:
@@ -148,7 +150,9 @@ class ShardedSearcher:
             own, idx, sc, allb, bb, so = self._scratch_for(Q, int(k), queries.device)
             self.engine.search(queries, k, out=(idx, sc))
             _all_gather(self.dist, allb, own, self.group)
-            return self.engine.merge_gathered(allb, bb, so, self.world, Q, int(k))
+            return self.engine.merge_gathered(allb, bb, so, self.world, Q, int(k), out=out)
+        if self.world == 1 and self.engine is not None and self._default_fns:
+            return self.engine.search(queries, k, out=out)
         idx, sc = self.search_fn(queries, k)
         if self.world == 1:
             return idx, sc
