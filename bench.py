@@ -345,7 +345,7 @@ def secondary_measurements(eng):
     # worth of queries (4,096 descriptions x 6 hints, 16 tokens each, T5-large width 1024), split into the d=1024
     # intra-layer + max + Linear/BN and the 256-d half (inter_module + max + normalize)
     try:
-        out["text_head"] = text_head_measure(eng, N_CELLS, N_QUERIES)
+        out["text_head"] = text_head_measure(eng, N_CELLS, 512 if _QUICK else N_QUERIES)
     except Exception as e:
         out["text_head"] = {"error": repr(e)}
     # the data cliff: tightly clustered databases (what an encoder over overlapping cells produces) instead of the
@@ -1180,7 +1180,7 @@ def main():
         elif args.mode == 2:
             kname, peak, dtype, mult = "scanw_kernel<8, 4>", BF16_MFMA_PEAK_TFLOPS, "bf16x3", 3
         else:
-            kname, peak, dtype, mult = "scanp_kernel<6, 4>", BF16_MFMA_PEAK_TFLOPS, "f16", 1
+            kname, peak, dtype, mult = "scanp_kernel<6, 4, false>", BF16_MFMA_PEAK_TFLOPS, "f16", 1
         out = {
             "metric": "coarse-retrieval queries/sec over 11k-cell DB, embed_dim=256; top-1/3/5 recall parity",
             "value": N_QUERIES * args.steps / elapsed,

@@ -4,7 +4,7 @@
 # rocprofv3 of the HEADLINE command (bench.py without its side measurements, so per-kernel averages are those of the
 # timed loop) — kernel-trace stats + PMC passes in separate runs, as the MI355X guide prescribes — and one
 # kernel-trace + FETCH_SIZE/WRITE_SIZE pass of the side measurements (encoder, streaming scan, loss).
-TAG=${1:-r02f}
+TAG=${1:-r03a}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
