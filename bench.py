@@ -595,6 +595,40 @@ def secondary_measurements(eng):
         eng_f.close()
     except Exception as e:
         out["fine_stage"] = {"error": repr(e)}
+    # the same search with FOUR batches' worth of queries per call (Q = 16,384): what the scan kernel reaches when a launch's fixed
+    # costs (dispatch, the cold start behind the kernel boundary, the candidate write-back) are spread over four times the work.
+    # A side line: the headline's step stays Q = 4,096 per call.
+    try:
+        rs = np.random.default_rng(17)
+        q_big = torch.from_numpy(np.concatenate([_QS] + [synth.unit_rows(rs.standard_normal(_QS.shape).astype(np.float32)) for _ in range(3)])).cuda()
+        Qb = int(q_big.shape[0])
+        ob = (torch.empty((Qb, TOPK), dtype=torch.int32, device="cuda"), torch.empty((Qb, TOPK), dtype=torch.float64, device="cuda"))
+        eng.set_option("profile_events", 0)
+        n_ramp_b, n_b = (5, 10) if _QUICK else (400, 200)
+        for _ in range(n_ramp_b):
+            eng.search(q_big, TOPK, out=ob)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_b):
+            eng.search(q_big, TOPK, out=ob)
+        torch.cuda.synchronize()
+        tb = (time.perf_counter() - t0) / n_b
+        eng.set_option("profile_events", 4)
+        eng.kernel_stats("search_scan")
+        for _ in range(24):
+            eng.search(q_big, TOPK, out=ob)
+        torch.cuda.synchronize()
+        kb = eng.kernel_stats("search_scan")[0]
+        eng.set_option("profile_events", 1)
+        first = eng.search(torch.from_numpy(np.ascontiguousarray(_QS)).cuda(), TOPK)
+        same = bool(torch.equal(ob[0][:N_QUERIES], first[0])) and bool(torch.equal(ob[1][:N_QUERIES], first[1]))
+        fl_b = 2.0 * Qb * N_CELLS * DIM
+        out["search_q16k_per_call"] = {"queries_per_call": Qb, "ms_per_call": tb * 1e3, "queries_per_s": Qb / tb, "scan_kernel_ms": kb,
+                                       "scan_tflops": fl_b / (kb * 1e-3) / 1e12 if kb else None,
+                                       "scan_frac_of_f16_peak": fl_b / (kb * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS if kb else None,
+                                       "first_4096_rows_equal_the_4096_query_call": same}
+    except Exception as e:
+        out["search_q16k_per_call"] = {"error": repr(e)}
     # SURVEY.md 8e, measured on ONE GPU: what every rank of an 8-GPU row-sharded step does apart from the collective itself —
     # scan + re-rank over ceil(N/8) rows for ALL queries, pack the {score, id} records, merge 8 gathered lists per query.
     # This is the per-rank floor of config 3's step (the all_gather of 8 x 655 KB over xGMI comes on top).

@@ -455,3 +455,43 @@ def test_pipelined_searches_equal_stream_ordered_ones(lanes):
     torch.cuda.synchronize()
     assert np.array_equal(idx.cpu().numpy(), r2)
     eng.close()
+
+
+def test_scan_mapping_and_prepass_options_are_result_neutral():
+    """search_xcd_qgroups (which workgroups share an XCD) and search_prep (queries converted once by a pre-pass launch instead of
+    by every workgroup's prologue) change speed only: ids AND float64 scores are bit-identical, stream-ordered and pipelined,
+    including a query count that is not a multiple of 256 and rows that are not a multiple of 32."""
+    import torch
+    from oracle import c_oracle
+    from text2loc_amd.engine import Engine
+
+    e = Engine(0)
+    try:
+        for n, q in ((11259, 4096), (5000, 1000), (11259, 257)):
+            db, qs, _ = synth.make_retrieval_problem(n, q, seed=77 + q, noise=0.7)
+            e.db_set(torch.from_numpy(db).cuda())
+            dq = torch.from_numpy(qs).cuda()
+            e.set_option("search_xcd_qgroups", 1)
+            e.set_option("search_prep", 0)
+            ref_i, ref_s = (t.clone() for t in e.search(dq, 10))
+            if q <= 1000:
+                ridx, rsc = c_oracle.retrieve_topk(db, qs, 10)
+                assert np.array_equal(ref_i.cpu().numpy().astype(np.int64), ridx) and np.abs(ref_s.cpu().numpy() - rsc).max() < 1e-12
+            for gq in (1, 2, 4, 8):
+                for prep in (0, 1):
+                    e.set_option("search_xcd_qgroups", gq)
+                    e.set_option("search_prep", prep)
+                    i1, s1 = e.search(dq, 10)
+                    assert torch.equal(i1, ref_i) and torch.equal(s1, ref_s), (n, q, gq, prep)
+            e.set_option("search_prep", 1)
+            e.set_option("search_lanes", 3)
+            outs = [e.search(dq, 10, join=False) for _ in range(5)]
+            e.search_join()
+            e.set_option("search_lanes", 1)
+            assert all(torch.equal(o[0], ref_i) and torch.equal(o[1], ref_s) for o in outs)
+        e.set_option("search_xcd_qgroups", 4)
+        e.set_option("search_prep", 0)
+        with pytest.raises(Exception, match="1, 2, 4 or 8"):
+            e.set_option("search_xcd_qgroups", 3)
+    finally:
+        e.close()
