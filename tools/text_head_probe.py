@@ -17,6 +17,8 @@ eng.text_head_load_weights(synth.make_language_head_weights(0))
 S = n_desc * 6
 g = torch.Generator(device="cuda").manual_seed(0)
 hidden = 0.2 * torch.randn(S, L, 1024, device="cuda", generator=g)
+if len(sys.argv) > 3 and sys.argv[3] == "zeros":   # power probe: the same launches on all-zero activations
+    hidden.zero_()
 for f16 in (0, 1):
     eng.set_option("encoder_f16", f16)
     for _ in range(2):
