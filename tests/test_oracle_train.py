@@ -22,7 +22,8 @@ def golden_view(g, tag, name, full):
 
 
 def load_case(g, mode):
-    cells = synth.make_cells(int(g["n_cells"]), seed=int(g["cell_seed"]), with_pn_feat=True)
+    shape = {k: int(g[k]) for k in ("min_obj", "max_obj") if k in g.files}  # the margin fixtures use small cells
+    cells = synth.make_cells(int(g["n_cells"]), seed=int(g["cell_seed"]), with_pn_feat=True, **shape)
     for k in ("class_idx", "color_idx", "rgb", "center", "n_pts", "offsets", "counts"):
         cells[k] = g["in_" + k]  # exactly what the reference derived from its Object3d instances
     sd = synth.make_object_branch_weights(int(g["weight_seed"]))
@@ -79,6 +80,39 @@ def test_train_step_oracle_matches_the_reference(golden, mode):
         p0 = flat if flat.size <= 1024 else flat[sample_index(n, flat.size)]
         p1, _, _ = OT.adam_step(p0, g[f"grad/{n}"].astype(np.float64), 0.0, 0.0, 1, float(g["lr"]))
         assert np.abs(p1 - g[f"adam/{n}"]).max() < 2e-7, n
+
+
+def margin_grad_check(g, n, got_full, scale=1.0):
+    """Gradient tensor ``n`` against a margin fixture: 1e-4 of the tensor's rms, element-wise maximum. Two families are
+    not informative and keep their own bounds: Linear biases in front of a BatchNorm (true gradient 0) and the Linear
+    weights in front of a BatchNorm (y = BN(w x + b) is invariant to the scale of w, so the true gradient is the residual
+    of terms that cancel to ~1e-4 of their size)."""
+    exp, got = golden_view(g, "grad", n, got_full)
+    rms = float(g[f"grad_norm/{n}"]) / np.sqrt(max(np.asarray(got_full).size, 1))
+    if n.startswith("object_encoder.") and n.endswith(".0.bias"):
+        assert np.abs(got).max() < 1e-3 and np.abs(exp).max() < 1e-3, n  # float32 cancellation noise around 0
+        return
+    tol = 2e-3 if n.startswith("object_encoder.") and n.endswith(".0.weight") else 1e-4
+    err = np.abs(got - exp).max()
+    assert err < scale * tol * rms + 1e-9, (n, err / rms)
+
+
+@pytest.mark.parametrize("mode", ["embed", "pn"])
+def test_margin_fixture_pins_the_gradients_at_rounding_level(golden, mode):
+    """tests/golden/train_step_margin_*.npz: a B=3 batch picked by seed search (oracle/gen_golden_train.py) so that every
+    ReLU input of the reference's run is >= 1e-4 away from 0 — no rounding order can flip a unit, and the float64 oracle
+    meets the float32 reference's parameter gradients to 1e-4 of each tensor's rms (element-wise maximum, not a quantile)."""
+    g = golden(f"train_step_margin_{mode}")
+    assert float(g["relu_margin"]) > 5e-5
+    cells, sd, embed = load_case(g, mode)
+    out0, _ = OT.encode_cells_train(cells, sd, embed, embed)
+    assert np.abs(out0 - g["positive"]).max() < 2e-6
+    loss, d_anchor, d_pos = O.contrastive_loss(g["anchor"], out0, float(g["temperature"]), dtype=np.float64)
+    assert abs(loss - float(g["loss"])) < 1e-5 and np.abs(d_anchor - g["grad_anchor"]).max() < 1e-5  # float32 reference, |grad| ~ 0.3
+    for dtype in (np.float64, np.float32):
+        _, info = OT.encode_cells_train(cells, sd, embed, embed, grad_out=d_pos, dtype=dtype)
+        for n in [str(x) for x in g["used_params"]]:
+            margin_grad_check(g, n, info["grads"][n])
 
 
 def test_backward_matches_central_differences_with_dropout():

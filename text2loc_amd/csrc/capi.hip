@@ -468,6 +468,8 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     ctx->pair_ll = (int)value;
   } else if (!strcmp(name, "search_pair")) {
     ctx->search_pair = value != 0;
+  } else if (!strcmp(name, "pointnet_train_v1")) {
+    ctx->pn_train_v1 = value != 0;
   } else if (!strcmp(name, "train_bf16")) {
     if (value != 0 && value != 1 && value != 2) return fail(ctx, T2L_EINVAL, "train_bf16: 0 (f32 MFMA), 1 (bf16 operands) or 2 (split-bf16, three products)");
     ctx->train_bf16 = (int)value;

@@ -15,6 +15,7 @@
 // sequential running-statistics updates), an apply kernel. Saved for backward per level: the row tables, edge inputs,
 // pre-BN and post-ReLU activations of both layers, per-cell statistics, arg-max rows.
 #pragma once
+#include "gemm_rows2.h"
 
 namespace t2l {
 
@@ -29,11 +30,13 @@ struct PnLevel {
   int32_t *goff = nullptr, *src = nullptr, *row_group = nullptr, *row_cell = nullptr, *arg = nullptr, *cnt = nullptr;
   float *X = nullptr, *y1 = nullptr, *a1 = nullptr, *y2 = nullptr;  // (the second layer's post-ReLU output is never stored)
   float *mean1 = nullptr, *rstd1 = nullptr, *mean2 = nullptr, *rstd2 = nullptr;
+  float* rg1 = nullptr;  // rstd1 * gamma1 per (cell, channel): the fused BatchNorm + ReLU operand loads of the second version
   float *xout = nullptr, *pos_out = nullptr, *w1p = nullptr, *dw1p = nullptr;
 };
 
 struct PnTrain {
   bool bound = false, trainable = false, have_forward = false;
+  bool v1 = false;  // the forward that is kept ran the first version's GEMM kernels (option pointnet_train_v1): a1 is stored
   char *ws = nullptr, *iws = nullptr;  // activations + scratch (sized exactly per call) / index tables (worst case, small)
   size_t ws_cap = 0, ws_off = 0, iws_cap = 0, scratch_off = 0, scratch_bytes = 0;
   int n_obj = 0, n_cells = 0;
@@ -186,11 +189,15 @@ __global__ void pt_unpad_add_kernel(const float* __restrict__ dWp, int rows, int
 // nearly all of them — reduces its 16 row lanes through LDS first.
 // MODE 0: acc[cell][0][c] += sum y, acc[cell][1][c] += sum y^2. MODE 1: dv = a > 0 ? d : 0: sum dv, sum dv * xhat
 constexpr int kStatRows = 1024;
+// The post-ReLU activation of a block's first layer is not stored by the second version: a == nullptr -> its sign is recomputed
+// from y exactly as the fused operand loads compute it (pt_bn_relu: fma(y - mean, rg, beta)).
+__device__ __forceinline__ float pt_bn_relu(float y, float m, float rg, float be) { return fmaxf(__fmaf_rn(__fsub_rn(y, m), rg, be), 0.f); }
 template <int MODE>
 __global__ __launch_bounds__(256) void pt_bn_stats_kernel(const float* __restrict__ y, const float* __restrict__ d,
                                                           const float* __restrict__ a, int C, size_t E,
                                                           const int32_t* __restrict__ row_cell, const float* __restrict__ mean,
-                                                          const float* __restrict__ rstd, double* __restrict__ acc) {
+                                                          const float* __restrict__ rstd, double* __restrict__ acc,
+                                                          const float* __restrict__ rg, const float* __restrict__ beta) {
   __shared__ float4 r1[256], r2[256];
   const int c = blockIdx.x * 64 + 4 * (threadIdx.x & 15), g = threadIdx.x >> 4;
   const bool cok = c < C;
@@ -198,11 +205,13 @@ __global__ __launch_bounds__(256) void pt_bn_stats_kernel(const float* __restric
   const int cell_first = row_cell[lo], cell_last = row_cell[hi - 1];
   const bool one_cell = cell_first == cell_last;  // block-uniform
   int cur = cell_first;
-  float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = mu, s1 = mu, s2 = mu;
+  float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = mu, s1 = mu, s2 = mu, rgv = mu, bev = mu;
+  if (MODE == 1 && !a && cok) bev = *reinterpret_cast<const float4*>(beta + c);
   auto stat_of = [&](int cell) {
     if (MODE == 1 && cok) {
       mu = *reinterpret_cast<const float4*>(mean + (size_t)cell * C + c);
       rs = *reinterpret_cast<const float4*>(rstd + (size_t)cell * C + c);
+      if (!a) rgv = *reinterpret_cast<const float4*>(rg + (size_t)cell * C + c);
     }
   };
   auto flush = [&](int cell) {
@@ -230,7 +239,10 @@ __global__ __launch_bounds__(256) void pt_bn_stats_kernel(const float* __restric
         s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
         s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
       } else {
-        const float4 dv = *reinterpret_cast<const float4*>(d + i), av = *reinterpret_cast<const float4*>(a + i);
+        const float4 dv = *reinterpret_cast<const float4*>(d + i);
+        const float4 av = a ? *reinterpret_cast<const float4*>(a + i)
+                            : make_float4(pt_bn_relu(v.x, mu.x, rgv.x, bev.x), pt_bn_relu(v.y, mu.y, rgv.y, bev.y),
+                                          pt_bn_relu(v.z, mu.z, rgv.z, bev.z), pt_bn_relu(v.w, mu.w, rgv.w, bev.w));
         const float e0 = av.x > 0.f ? dv.x : 0.f, e1 = av.y > 0.f ? dv.y : 0.f, e2 = av.z > 0.f ? dv.z : 0.f, e3 = av.w > 0.f ? dv.w : 0.f;
         s1.x += e0; s1.y += e1; s1.z += e2; s1.w += e3;
         s2.x += e0 * (v.x - mu.x) * rs.x; s2.y += e1 * (v.y - mu.y) * rs.y; s2.z += e2 * (v.z - mu.z) * rs.z; s2.w += e3 * (v.w - mu.w) * rs.w;
@@ -260,18 +272,22 @@ __global__ __launch_bounds__(256) void pt_bn_stats_kernel(const float* __restric
 }
 
 // statistics of every cell + the running-statistics updates the reference performs once per cell, in cell order
+// (rg != nullptr: also rg[cell][c] = rstd * gamma[c], the scale of the fused BatchNorm + ReLU operand loads — pt_bn_relu)
 __global__ void pt_bn_finalize_kernel(const double* __restrict__ acc, const int32_t* __restrict__ cnt, int n_cells, int C,
                                       float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
-                                      float* __restrict__ run_var, float momentum) {
+                                      float* __restrict__ run_var, float momentum, const float* __restrict__ gamma, float* __restrict__ rg) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   float rm = run_mean[c], rv = run_var[c];
+  const float ga = rg ? gamma[c] : 0.f;
   for (int cell = 0; cell < n_cells; ++cell) {
     const double n = (double)max(cnt[cell], 1);
     const double m = acc[((size_t)cell * 2) * 1024 + c] / n;
     const double var = fmax(acc[((size_t)cell * 2 + 1) * 1024 + c] / n - m * m, 0.0);
     mean[(size_t)cell * C + c] = (float)m;
-    rstd[(size_t)cell * C + c] = 1.0f / sqrtf((float)var + kBnEps);
+    const float rs = 1.0f / sqrtf((float)var + kBnEps);
+    rstd[(size_t)cell * C + c] = rs;
+    if (rg) rg[(size_t)cell * C + c] = rs * ga;
     rm = (1.f - momentum) * rm + momentum * (float)m;
     rv = (1.f - momentum) * rv + momentum * (float)(var * (n / fmax(n - 1.0, 1.0)));
   }
@@ -309,7 +325,7 @@ __global__ __launch_bounds__(256) void pt_bn_apply_bwd_kernel(float* __restrict_
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, const int32_t* __restrict__ arg,
                                                               const float* __restrict__ dxout, const int32_t* __restrict__ row_group,
-                                                              const float* __restrict__ beta) {
+                                                              const float* __restrict__ beta, const float* __restrict__ rg) {
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= E * C) return;
   const size_t row = i / C;
@@ -334,8 +350,12 @@ __global__ __launch_bounds__(256) void pt_bn_apply_bwd_kernel(float* __restrict_
     const float4 be = *reinterpret_cast<const float4*>(beta + c);
     av = make_float4((yv.x - m.x) * r.x * ga.x + be.x, (yv.y - m.y) * r.y * ga.y + be.y, (yv.z - m.z) * r.z * ga.z + be.z,
                      (yv.w - m.w) * r.w * ga.w + be.w);
-  } else {
+  } else if (a) {
     av = *reinterpret_cast<const float4*>(a + i);
+  } else {  // second version: a1 is not stored
+    const float4 be = *reinterpret_cast<const float4*>(beta + c), g4 = *reinterpret_cast<const float4*>(rg + sc);
+    av = make_float4(pt_bn_relu(yv.x, m.x, g4.x, be.x), pt_bn_relu(yv.y, m.y, g4.y, be.y), pt_bn_relu(yv.z, m.z, g4.z, be.z),
+                     pt_bn_relu(yv.w, m.w, g4.w, be.w));
   }
   const double* a1 = acc + ((size_t)cell * 2) * 1024 + c;
   const double* a2 = acc + ((size_t)cell * 2 + 1) * 1024 + c;
@@ -472,6 +492,70 @@ static void gemm_nn_rows(const float* dY, const float* W, float* Wt, float* dX, 
   launch_rows_nt(train::GemmArgs{dY, Wt, dX, nullptr, (int)M, Kp, N, N, N, Kp, 0, 0, 0, nullptr, tl_gemm_bf16}, s);
 }
 
+// ---- second version: LDS-resident weights (gemm_rows2.h) ----------------------------------------------------------------
+static int pn_cu_count() {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu < 8) n_cu = 256;
+  }
+  return n_cu;
+}
+template <int MODE, bool AF, bool ST>
+static void rows2_launch_t(const train::Rows2Args& a, int grid, size_t lds, hipStream_t s) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(train::rows2_kernel<MODE, AF, ST>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            train::kRows2Lds);
+  hipLaunchKernelGGL((train::rows2_kernel<MODE, AF, ST>), dim3(grid), dim3(train::kRows2Threads), lds, s, a);
+}
+template <int MODE>
+static void rows2_launch_m(const train::Rows2Args& a, int grid, size_t lds, hipStream_t s) {
+  const bool af = a.a_mean != nullptr, st = a.acc != nullptr;
+  if (af && st) rows2_launch_t<MODE, true, true>(a, grid, lds, s);
+  else if (st) rows2_launch_t<MODE, false, true>(a, grid, lds, s);
+  else if (af) rows2_launch_t<MODE, true, false>(a, grid, lds, s);
+  else rows2_launch_t<MODE, false, false>(a, grid, lds, s);
+}
+// C[M,N] = f(A)[M,K] W[N,K]^T + bias; a_mean != nullptr: f = BatchNorm + ReLU of the layer below (tables [cell][K]); acc != nullptr:
+// the BatchNorm partial sums of C per (cell, column). K is a multiple of 16, N of 32.
+static void gemm_rows2(const float* A, const float* W, const float* bias, float* C, size_t M, int N, int K, const float* a_mean,
+                       const float* a_rg, const float* a_beta, const int32_t* row_cell, double* acc, hipStream_t s) {
+  const int mode = tl_gemm_bf16, bpe = mode == 1 ? 2 : 4;
+  int tp = std::max(1, std::min(std::min(train::kRows2MaxT, N / 32), train::kRows2Lds / (32 * K * bpe)));
+  tp = (N / 32 + (N / 32 + tp - 1) / tp - 1) / ((N / 32 + tp - 1) / tp);  // the same number of passes, balanced
+  const size_t lds = (size_t)tp * 32 * K * bpe;
+  const int grid = (int)std::min<size_t>((size_t)pn_cu_count(), (M + 255) / 256);
+  const int rpw = (int)(((M + (size_t)grid * 8 - 1) / ((size_t)grid * 8) + 31) / 32 * 32);
+  const train::Rows2Args a{A, W, bias, C, (int)M, N, K, K, K, N, tp, rpw, a_mean, a_rg, a_beta, row_cell, acc};
+  if (mode == 2) rows2_launch_m<2>(a, grid, lds, s);
+  else if (mode == 1) rows2_launch_m<1>(a, grid, lds, s);
+  else rows2_launch_m<0>(a, grid, lds, s);
+}
+template <int MODE, bool XF>
+static void tn2_launch_t(const train::Tn2Args& a, dim3 grid, size_t lds, hipStream_t s) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(train::tn2_kernel<MODE, XF>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+  hipLaunchKernelGGL((train::tn2_kernel<MODE, XF>), grid, dim3(train::kRows2Threads), lds, s, a);
+}
+// dW[N][ldw] += dY[M,N]^T f(X)[M,K] (columns k < k_real), db[n] += sum_m dY; x_mean != nullptr: f = BatchNorm + ReLU (tables [cell][K])
+static void gemm_tn2(const float* dY, const float* X, float* dW, float* db, size_t M, int N, int K, int k_real, int ldw, const float* x_mean,
+                     const float* x_rg, const float* x_beta, const int32_t* row_cell, hipStream_t s) {
+  const int mode = tl_gemm_bf16;
+  const int KT = K / 32, kblocks = (KT + train::kTn2MaxT - 1) / train::kTn2MaxT, kb_tiles = (KT + kblocks - 1) / kblocks;
+  const int gy = (N + 255) / 256, gz = kblocks;
+  const int NB = std::min(256, N), KB = 32 * kb_tiles, RG = 8 / (NB / 32), SR = RG * 32;
+  const size_t lds = 2 * (size_t)SR * (NB + 4 + KB + 4) * sizeof(float);
+  int gx = std::max(1, pn_cu_count() / (gy * gz));
+  gx = (int)std::min<size_t>((size_t)gx, (M + SR - 1) / SR);
+  const int rpw = (int)(((M + gx - 1) / gx + SR - 1) / SR * SR);
+  const train::Tn2Args a{dY, X, dW, db, (int)M, N, K, N, K, ldw, rpw, kb_tiles, k_real, x_mean, x_rg, x_beta, row_cell};
+  const dim3 grid(gx, gy, gz);
+  const bool xf = x_mean != nullptr;
+  if (mode == 2) xf ? tn2_launch_t<2, true>(a, grid, lds, s) : tn2_launch_t<2, false>(a, grid, lds, s);
+  else if (mode == 1) xf ? tn2_launch_t<1, true>(a, grid, lds, s) : tn2_launch_t<1, false>(a, grid, lds, s);
+  else xf ? tn2_launch_t<0, true>(a, grid, lds, s) : tn2_launch_t<0, false>(a, grid, lds, s);
+}
+
 // object_encoder.pointnet.* tensors of the binding: all of them with gradient buffers -> the backbone trains in the engine
 // (their names join the Adam list); all without -> frozen (models/object_encoder.py:53-55: requires_grad_(False), but still
 // under model.train(): batch statistics + running-statistics updates in the forward); absent -> no backbone on the path
@@ -553,7 +637,8 @@ static size_t pn_layout(PnTrain* pt) {
     L.w1p = pn_bump<float>(pt, (size_t)L.h1 * L.kp);
     L.dw1p = pn_bump<float>(pt, (size_t)L.h1 * L.kp);
     L.y1 = pn_bump<float>(pt, L.E * L.h1);
-    L.a1 = pn_bump<float>(pt, L.E * L.h1);
+    L.a1 = pt->v1 ? pn_bump<float>(pt, L.E * L.h1) : nullptr;  // second version: recomputed from y1 wherever it is consumed
+    L.rg1 = pn_bump<float>(pt, (size_t)n_cells * L.h1);
     L.y2 = pn_bump<float>(pt, L.E * L.h2);
     L.mean1 = pn_bump<float>(pt, (size_t)n_cells * L.h1);
     L.rstd1 = pn_bump<float>(pt, (size_t)n_cells * L.h1);
@@ -573,18 +658,27 @@ static size_t pn_layout(PnTrain* pt) {
   return pt->ws_off + pt->scratch_bytes;
 }
 
-// one get_mlp block in training mode over segmented rows: y = X W^T + b; per-cell BatchNorm; ReLU
+// one get_mlp block in training mode over segmented rows: y = X W^T + b; per-cell BatchNorm; ReLU.
+// Second version (default): the GEMM's epilogue forms the BatchNorm partial sums, and a block's first layer leaves only y1 — its
+// BatchNorm + ReLU is applied by whoever loads it (x_fuse: the layer below's tables for THIS layer's left operand).
 static void pn_block_fwd(TrainState* st, PnTrain* pt, const PnLevel& L, int layer, const float* X, const float* W, int K, int C, float* y,
-                         float* a, float* mean, float* rstd, hipStream_t s) {  // a == nullptr: the consumer applies BatchNorm + ReLU itself
+                         float* a, float* mean, float* rstd, float* rg, bool x_fuse, hipStream_t s) {
   using namespace train;
   const std::string p = L.prefix + "." + std::to_string(layer);
-  gemm_nt_rows(X, W, T_(st, p + ".0.bias").data, y, L.E, C, K, 0, s);
   (void)hipMemsetAsync(pt->acc, 0, sizeof(double) * 2 * 1024 * pt->n_cells, s);
-  const dim3 sgrid((C + 63) / 64, (unsigned)((L.E + kStatRows - 1) / kStatRows));
-  hipLaunchKernelGGL((pt_bn_stats_kernel<0>), sgrid, dim3(256), 0, s, (const float*)y, (const float*)nullptr, (const float*)nullptr, C, L.E,
-                     (const int32_t*)L.row_cell, (const float*)nullptr, (const float*)nullptr, pt->acc);
+  if (pt->v1) {
+    gemm_nt_rows(X, W, T_(st, p + ".0.bias").data, y, L.E, C, K, 0, s);
+    const dim3 sgrid((C + 63) / 64, (unsigned)((L.E + kStatRows - 1) / kStatRows));
+    hipLaunchKernelGGL((pt_bn_stats_kernel<0>), sgrid, dim3(256), 0, s, (const float*)y, (const float*)nullptr, (const float*)nullptr, C, L.E,
+                       (const int32_t*)L.row_cell, (const float*)nullptr, (const float*)nullptr, pt->acc, (const float*)nullptr,
+                       (const float*)nullptr);
+  } else {
+    gemm_rows2(X, W, T_(st, p + ".0.bias").data, y, L.E, C, K, x_fuse ? L.mean1 : nullptr, x_fuse ? L.rg1 : nullptr,
+               x_fuse ? T_(st, L.prefix + ".0.1.bias").data : nullptr, L.row_cell, pt->acc, s);
+  }
   hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)pt->acc, (const int32_t*)L.cnt, pt->n_cells, C,
-                     mean, rstd, T_(st, p + ".1.running_mean").data, T_(st, p + ".1.running_var").data, 0.1f);
+                     mean, rstd, T_(st, p + ".1.running_mean").data, T_(st, p + ".1.running_var").data, 0.1f,
+                     (const float*)T_(st, p + ".1.weight").data, rg);
   if (a)
     hipLaunchKernelGGL(pt_bn_apply_fwd_kernel, dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, (const float*)y, L.E, C, (const int32_t*)L.row_cell,
                        (const float*)mean, (const float*)rstd, (const float*)T_(st, p + ".1.weight").data,
@@ -594,7 +688,7 @@ static void pn_block_fwd(TrainState* st, PnTrain* pt, const PnLevel& L, int laye
 // d: gradient w.r.t. the block's ReLU output [E, C] (overwritten with the gradient w.r.t. the Linear output). dxout != nullptr
 // (second layer): that gradient is implied by the max aggregation (dxout [G, C] at the arg-max rows) and d is only written.
 static void pn_block_bwd(TrainState* st, PnTrain* pt, const PnLevel& L, int layer, float* d, const float* y, const float* a, int C,
-                         const float* mean, const float* rstd, const float* dxout, hipStream_t s) {
+                         const float* mean, const float* rstd, const float* rg, const float* dxout, hipStream_t s) {
   using namespace train;
   const std::string p = L.prefix + "." + std::to_string(layer);
   (void)hipMemsetAsync(pt->acc, 0, sizeof(double) * 2 * 1024 * pt->n_cells, s);
@@ -603,14 +697,15 @@ static void pn_block_bwd(TrainState* st, PnTrain* pt, const PnLevel& L, int laye
                        (const int32_t*)L.arg, dxout, L.G, C, L.nd, (const int32_t*)pt->cell_of_obj, mean, rstd, pt->acc);
     hipLaunchKernelGGL((pt_bn_apply_bwd_kernel<true>), dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, d, a, y, L.E, C,
                        (const int32_t*)L.row_cell, (const int32_t*)L.cnt, (const double*)pt->acc, (const float*)T_(st, p + ".1.weight").data, mean,
-                       rstd, (const int32_t*)L.arg, dxout, (const int32_t*)L.row_group, (const float*)T_(st, p + ".1.bias").data);
+                       rstd, (const int32_t*)L.arg, dxout, (const int32_t*)L.row_group, (const float*)T_(st, p + ".1.bias").data,
+                       (const float*)nullptr);
   } else {
     const dim3 sgrid((C + 63) / 64, (unsigned)((L.E + kStatRows - 1) / kStatRows));
     hipLaunchKernelGGL((pt_bn_stats_kernel<1>), sgrid, dim3(256), 0, s, y, (const float*)d, a, C, L.E, (const int32_t*)L.row_cell, mean, rstd,
-                       pt->acc);
+                       pt->acc, rg, (const float*)T_(st, p + ".1.bias").data);
     hipLaunchKernelGGL((pt_bn_apply_bwd_kernel<false>), dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, d, a, y, L.E, C,
                        (const int32_t*)L.row_cell, (const int32_t*)L.cnt, (const double*)pt->acc, (const float*)T_(st, p + ".1.weight").data, mean,
-                       rstd, (const int32_t*)nullptr, (const float*)nullptr, (const int32_t*)nullptr, (const float*)nullptr);
+                       rstd, (const int32_t*)nullptr, (const float*)nullptr, (const int32_t*)nullptr, (const float*)T_(st, p + ".1.bias").data, rg);
   }
   hipLaunchKernelGGL(pt_bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)pt->acc, pt->n_cells, C,
                      T_(st, p + ".1.weight").grad, T_(st, p + ".1.bias").grad);
@@ -735,6 +830,7 @@ int pn_train_forward_impl(t2l_ctx* ctx, const float* pos, const float* rgb, cons
   for (int c = 0; c < n_cells; ++c) h_cnt[3][c] = (cell_offsets[c + 1] - cell_offsets[c]) * 32;
 
   // ---- activations: exact sizes
+  pt->v1 = ctx->pn_train_v1 != 0;
   char* keep = pt->ws;
   pt->ws = nullptr;
   const size_t need = pn_layout(pt);
@@ -770,8 +866,9 @@ int pn_train_forward_impl(t2l_ctx* ctx, const float* pos, const float* rgb, cons
                        (const int32_t*)L.src, (const int32_t*)L.row_group, L.E, L.cin, L.kp, L.X);
     hipLaunchKernelGGL(pt_pad_kernel, dim3(pn_blocks((size_t)L.h1 * L.kp)), dim3(256), 0, s, (const float*)T_(st, L.prefix + ".0.0.weight").data,
                        L.h1, L.kin, L.kp, L.w1p);
-    pn_block_fwd(st, pt, L, 0, L.X, L.w1p, L.kp, L.h1, L.y1, L.a1, L.mean1, L.rstd1, s);
-    pn_block_fwd(st, pt, L, 1, L.a1, T_(st, L.prefix + ".1.0.weight").data, L.h1, L.h2, L.y2, nullptr, L.mean2, L.rstd2, s);
+    pn_block_fwd(st, pt, L, 0, L.X, L.w1p, L.kp, L.h1, L.y1, L.a1, L.mean1, L.rstd1, L.rg1, false, s);
+    pn_block_fwd(st, pt, L, 1, pt->v1 ? L.a1 : L.y1, T_(st, L.prefix + ".1.0.weight").data, L.h1, L.h2, L.y2, nullptr, L.mean2, L.rstd2, nullptr,
+                 !pt->v1, s);
     hipLaunchKernelGGL(pt_segmax_kernel, dim3(pn_blocks(L.G * L.h2)), dim3(256), 0, s, (const float*)L.y2, (const int32_t*)L.goff, L.G, L.h2,
                        L.nd, (const int32_t*)pt->cell_of_obj, (const float*)L.mean2, (const float*)L.rstd2,
                        (const float*)T_(st, L.prefix + ".1.1.weight").data, (const float*)T_(st, L.prefix + ".1.1.bias").data, L.xout, L.arg);
@@ -821,17 +918,37 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
     const size_t lmark = pt->ws_off;
     float* dA2 = pn_bump<float>(pt, L.E * L.h2);
     float* dA1 = pn_bump<float>(pt, L.E * L.h1);
-    pn_block_bwd(st, pt, L, 1, dA2, L.y2, nullptr, L.h2, L.mean2, L.rstd2, dx, s);
-    gemm_tn(dA2, L.a1, T_(st, L.prefix + ".1.0.weight").grad, T_(st, L.prefix + ".1.0.bias").grad, (int)L.E, L.h2, L.h1, s);
-    gemm_nn_rows(dA2, T_(st, L.prefix + ".1.0.weight").data, pt->wt, dA1, L.E, L.h2, L.h1, s);
-    pn_block_bwd(st, pt, L, 0, dA1, L.y1, L.a1, L.h1, L.mean1, L.rstd1, nullptr, s);
-    T2L_HIP(ctx, hipMemsetAsync(L.dw1p, 0, sizeof(float) * (size_t)L.h1 * L.kp, s));
-    gemm_tn(dA1, L.X, L.dw1p, T_(st, L.prefix + ".0.0.bias").grad, (int)L.E, L.h1, L.kp, s);
-    hipLaunchKernelGGL(pt_unpad_add_kernel, dim3(pn_blocks((size_t)L.h1 * L.kin)), dim3(256), 0, s, (const float*)L.dw1p, L.h1, L.kin, L.kp,
-                       T_(st, L.prefix + ".0.0.weight").grad);
+    pn_block_bwd(st, pt, L, 1, dA2, L.y2, nullptr, L.h2, L.mean2, L.rstd2, nullptr, dx, s);
+    const float* be1 = T_(st, L.prefix + ".0.1.bias").data;
+    if (pt->v1) {
+      gemm_tn(dA2, L.a1, T_(st, L.prefix + ".1.0.weight").grad, T_(st, L.prefix + ".1.0.bias").grad, (int)L.E, L.h2, L.h1, s);
+      gemm_nn_rows(dA2, T_(st, L.prefix + ".1.0.weight").data, pt->wt, dA1, L.E, L.h2, L.h1, s);
+    } else {  // a1 = relu(bn(y1)) is rebuilt while y1 is staged
+      gemm_tn2(dA2, L.y1, T_(st, L.prefix + ".1.0.weight").grad, T_(st, L.prefix + ".1.0.bias").grad, L.E, L.h2, L.h1, L.h1, L.h1, L.mean1,
+               L.rg1, be1, L.row_cell, s);
+      hipLaunchKernelGGL(pt_transpose_kernel, dim3((unsigned)((L.h2 * L.h1 + 255) / 256)), dim3(256), 0, s,
+                         (const float*)T_(st, L.prefix + ".1.0.weight").data, L.h2, L.h1, pt->wt);
+      gemm_rows2(dA2, pt->wt, nullptr, dA1, L.E, L.h1, L.h2, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+    }
+    pn_block_bwd(st, pt, L, 0, dA1, L.y1, L.a1, L.h1, L.mean1, L.rstd1, L.rg1, nullptr, s);
+    if (pt->v1) {
+      T2L_HIP(ctx, hipMemsetAsync(L.dw1p, 0, sizeof(float) * (size_t)L.h1 * L.kp, s));
+      gemm_tn(dA1, L.X, L.dw1p, T_(st, L.prefix + ".0.0.bias").grad, (int)L.E, L.h1, L.kp, s);
+      hipLaunchKernelGGL(pt_unpad_add_kernel, dim3(pn_blocks((size_t)L.h1 * L.kin)), dim3(256), 0, s, (const float*)L.dw1p, L.h1, L.kin, L.kp,
+                         T_(st, L.prefix + ".0.0.weight").grad);
+    } else {  // straight into the unpadded gradient: the padding columns of X are not written
+      gemm_tn2(dA1, L.X, T_(st, L.prefix + ".0.0.weight").grad, T_(st, L.prefix + ".0.0.bias").grad, L.E, L.h1, L.kp, L.kin, L.kin, nullptr,
+               nullptr, nullptr, nullptr, s);
+    }
     if (l > 0) {  // the input gradient: features of the level below (positions are data)
       float* dX = pn_bump<float>(pt, L.E * L.kp);
-      gemm_nn_rows(dA1, L.w1p, pt->wt, dX, L.E, L.h1, L.kp, s);
+      if (pt->v1) {
+        gemm_nn_rows(dA1, L.w1p, pt->wt, dX, L.E, L.h1, L.kp, s);
+      } else {
+        hipLaunchKernelGGL(pt_transpose_kernel, dim3((unsigned)((L.h1 * L.kp + 255) / 256)), dim3(256), 0, s, (const float*)L.w1p, L.h1, L.kp,
+                           pt->wt);
+        gemm_rows2(dA1, pt->wt, nullptr, dX, L.E, L.kp, L.h1, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+      }
       const PnLevel& Lb = pt->lv[l - 1];
       const size_t nprev = Lb.G * Lb.h2;
       if (L.sa) {

@@ -1,4 +1,4 @@
-"""PointNet++ training-mode forward/backward timing at the published batch (64 cells): python tools/pn_train_probe.py [B] [bf16]"""
+"""PointNet++ training-mode forward/backward timing at the published batch (64 cells): python tools/pn_train_probe.py [B] [bf16] [v1]"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")
@@ -9,6 +9,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 bf16 = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 0 f32, 1 bf16, 2 split-bf16
 eng = Engine(0)
 eng.set_option("train_bf16", bf16)
+if len(sys.argv) > 3: eng.set_option("pointnet_train_v1", int(sys.argv[3]))
 cells = synth.make_cells(B, seed=1)
 pos, rgb = synth.make_sampled_points(cells, 1)
 sd = dict(synth.make_object_branch_weights(2)); sd.update(synth.make_pointnet_weights(1))
