@@ -32,7 +32,7 @@ struct Rows2Args {
   const float* bias;   // [N] or nullptr
   float* C;            // [M][ldc]
   int M, N, K, lda, ldw, ldc;
-  int tp;              // column tiles per pass (host: min(kRows2MaxT, LDS budget))
+  int tp;              // column tiles per pass (= the TP the kernel was instantiated with; the last pass may be partly past N)
   int rows_per_wave;   // contiguous rows per wave (multiple of 32)
   // AFUSE: A := relu((A - mean[cell][k]) * rg[cell][k] + beta[k]) (BatchNorm in batch-statistics mode + ReLU of the layer below)
   const float *a_mean, *a_rg, *a_beta;
@@ -47,13 +47,13 @@ struct Rows2Args {
 //   MODE 1 (bf16):  [t][ks][lane][8 bf16]
 //   MODE 2 (split): hi plane as MODE 1, lo plane behind it (+ plane bytes)
 template <int MODE>
-__device__ __forceinline__ void rows2_fill(char* lds, const float* __restrict__ W, int ldw, int n0, int tp, int K) {
+__device__ __forceinline__ void rows2_fill(char* lds, const float* __restrict__ W, int ldw, int n0, int tp, int K, int N) {
   const int KS = K >> 4;
   const int items = tp * 32 * KS * 2;
   const int plane = tp * KS * 64 * 16;
   for (int it = threadIdx.x; it < items; it += kRows2Threads) {
     const int kh = it & 1, ks = (it >> 1) % KS, i = ((it >> 1) / KS) & 31, t = (it >> 1) / (KS * 32);
-    const float* p = W + (size_t)(n0 + 32 * t + i) * ldw + 16 * ks + 8 * kh;
+    const float* p = W + (size_t)min(n0 + 32 * t + i, N - 1) * ldw + 16 * ks + 8 * kh;  // (tiles past N repeat the last row: never stored)
     const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
     const int lane = kh * 32 + i;
     if (MODE == 0) {
@@ -72,7 +72,12 @@ __device__ __forceinline__ void rows2_fill(char* lds, const float* __restrict__ 
   }
 }
 
-template <int MODE, bool AFUSE, bool STATS>
+// TP (column tiles per pass) is a template parameter and the k loop has no data-dependent branch between the issue of a ring
+// slot's loads and their use: with run-time tile / step guards the compiler's wait-count pass gives up and puts s_waitcnt
+// vmcnt(0) in front of every MFMA group — the ring then hides nothing (first build of this kernel: 44 % of the wave cycles
+// waiting on VMEM, 0.41 of the f32 peak). K / 16 is even for every layer (K = 32 .. 512), so the loop runs whole rounds of the
+// 4-slot ring plus at most one half round; refills past the end re-load the last step (clamped address, never used).
+template <int MODE, bool AFUSE, bool STATS, int TP>
 __global__ __launch_bounds__(kRows2Threads) void rows2_kernel(const Rows2Args g) {
   extern __shared__ __attribute__((aligned(16))) char r2_lds[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 31, kh = lane >> 5;
@@ -80,24 +85,24 @@ __global__ __launch_bounds__(kRows2Threads) void rows2_kernel(const Rows2Args g)
   const long gw = (long)blockIdx.x * 8 + w;
   const long row_lo = gw * g.rows_per_wave, row_hi = min((long)g.M, row_lo + g.rows_per_wave);
   constexpr int kRing = 4;
-  for (int n0 = 0; n0 < g.N; n0 += 32 * g.tp) {
-    const int tp = min(g.tp, (g.N - n0) >> 5);
+  const int plane = TP * KS * 64 * 16;
+  for (int n0 = 0; n0 < g.N; n0 += 32 * TP) {
     __syncthreads();  // the previous pass's readers are done
-    rows2_fill<MODE>(r2_lds, g.W, g.ldw, n0, tp, g.K);
+    rows2_fill<MODE>(r2_lds, g.W, g.ldw, n0, TP, g.K, g.N);
     __syncthreads();
-    const int plane = tp * KS * 64 * 16;
     // running BatchNorm sums of this wave's rows for the cell `cur` (flushed when the cell changes)
-    float run1[kRows2MaxT], run2[kRows2MaxT];
+    float run1[TP], run2[TP], bv[TP];
     int cur = -1;
-    if (STATS) {
 #pragma unroll
-      for (int t = 0; t < kRows2MaxT; ++t) run1[t] = run2[t] = 0.f;
+    for (int t = 0; t < TP; ++t) {
+      run1[t] = run2[t] = 0.f;
+      bv[t] = g.bias && n0 + 32 * t + i < g.N ? g.bias[n0 + 32 * t + i] : 0.f;
     }
     auto flush = [&]() {
       if (cur < 0) return;
 #pragma unroll
-      for (int t = 0; t < kRows2MaxT; ++t)
-        if (t < tp && kh == 0) {
+      for (int t = 0; t < TP; ++t)
+        if (n0 + 32 * t < g.N && kh == 0) {
           double* p = g.acc + ((size_t)cur * 2) * 1024 + n0 + 32 * t + i;
           atomicAdd(p, (double)run1[t]);
           atomicAdd(p + 1024, (double)run2[t]);
@@ -112,13 +117,14 @@ __global__ __launch_bounds__(kRows2Threads) void rows2_kernel(const Rows2Args g)
       const float* mp = AFUSE ? g.a_mean + (size_t)acell * g.K + 8 * kh : nullptr;
       const float* rp = AFUSE ? g.a_rg + (size_t)acell * g.K + 8 * kh : nullptr;
       const float* bp = AFUSE ? g.a_beta + 8 * kh : nullptr;
-      f32x16 acc[kRows2MaxT];
+      f32x16 acc[TP];
 #pragma unroll
-      for (int t = 0; t < kRows2MaxT; ++t)
+      for (int t = 0; t < TP; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
       float a[kRing][8];
-      auto load_a = [&](int k0, float (&d)[8]) {
+      auto load_a = [&](int ks, float (&d)[8]) {
+        const int k0 = 16 * min(ks, KS - 1);
         const float4 x = *reinterpret_cast<const float4*>(ap + k0), y = *reinterpret_cast<const float4*>(ap + k0 + 4);
         d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w; d[4] = y.x; d[5] = y.y; d[6] = y.z; d[7] = y.w;
         if (AFUSE) {
@@ -132,83 +138,100 @@ __global__ __launch_bounds__(kRows2Threads) void rows2_kernel(const Rows2Args g)
           for (int j = 0; j < 8; ++j) d[j] = fmaxf(__fmaf_rn(__fsub_rn(d[j], mm[j]), rr[j], bb[j]), 0.f);
         }
       };
+      auto step = [&](int ks, const float (&av)[8]) {
+        gemm_bf16x8 ah, al;
+        if (MODE == 2) gemm_split_bf16(av, ah, al);
+        else if (MODE == 1) ah = gemm_to_bf16(av);
 #pragma unroll
-      for (int d = 0; d < kRing; ++d)
-        if (d < KS) load_a(16 * d, a[d]);
-      for (int kb = 0; kb < KS; kb += kRing) {
+        for (int t = 0; t < TP; ++t) {
+          if (MODE == 0) {
+            const float4* f = reinterpret_cast<const float4*>(r2_lds) + ((size_t)(t * KS + ks) * 2) * 64 + lane;
+            const float4 x = f[0], y = f[64];
+            const float b[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
 #pragma unroll
-        for (int d = 0; d < kRing; ++d) {
-          const int ks = kb + d;
-          if (ks < KS) {
-            gemm_bf16x8 ah, al;
-            if (MODE == 2) gemm_split_bf16(a[d], ah, al);
-            else if (MODE == 1) ah = gemm_to_bf16(a[d]);
-#pragma unroll
-            for (int t = 0; t < kRows2MaxT; ++t) {
-              if (t < tp) {
-                if (MODE == 0) {
-                  const float4* f = reinterpret_cast<const float4*>(r2_lds) + ((size_t)(t * KS + ks) * 2) * 64 + lane;
-                  const float4 x = f[0], y = f[64];
-                  const float b[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
-#pragma unroll
-                  for (int j = 0; j < 8; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][j], b[j], acc[t], 0, 0, 0);
-                } else {
-                  const gemm_bf16x8* f = reinterpret_cast<const gemm_bf16x8*>(r2_lds) + (size_t)(t * KS + ks) * 64 + lane;
-                  const gemm_bf16x8 bh = *f;
-                  acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
-                  if (MODE == 2) {
-                    const gemm_bf16x8 bl = *reinterpret_cast<const gemm_bf16x8*>(reinterpret_cast<const char*>(f) + plane);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-                  }
-                }
-              }
+            for (int j = 0; j < 8; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[j], acc[t], 0, 0, 0);
+          } else {
+            const gemm_bf16x8* f = reinterpret_cast<const gemm_bf16x8*>(r2_lds) + (size_t)(t * KS + ks) * 64 + lane;
+            const gemm_bf16x8 bh = *f;
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+            if (MODE == 2) {
+              const gemm_bf16x8 bl = *reinterpret_cast<const gemm_bf16x8*>(reinterpret_cast<const char*>(f) + plane);
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
             }
-            if (ks + kRing < KS) load_a(16 * (ks + kRing), a[d]);  // refill this slot with the step one ring ahead
           }
         }
+      };
+#pragma unroll
+      for (int d = 0; d < kRing; ++d) load_a(d, a[d]);
+      int kb = 0;
+      for (; kb + kRing <= KS; kb += kRing) {
+#pragma unroll
+        for (int d = 0; d < kRing; ++d) {
+          step(kb + d, a[d]);
+          load_a(kb + d + kRing, a[d]);  // refill this slot with the step one ring ahead (clamped past the end)
+        }
       }
+      if (kb < KS) {  // K / 16 = 2 mod 4: the half round
+        step(kb, a[0]);
+        step(kb + 1, a[1]);
+      }
+      // (the same guard as in tn2_kernel: no VALU read of an accumulator closer than a 16-pass MFMA's latency behind its issue)
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
       // epilogue: bias, store, BatchNorm partial sums
       bool uniform = true;
-      int c_first = 0;
       if (STATS) {
-        c_first = g.row_cell[m0];
-        const int c_last = g.row_cell[min(m0 + 31, (long)g.M - 1)];
+        const int c_first = g.row_cell[m0], c_last = g.row_cell[min(m0 + 31, (long)g.M - 1)];
         uniform = c_first == c_last;
         if (uniform && c_first != cur) {
           flush();
           cur = c_first;
         }
       }
+      // (full tiles — all but a wave's last — store without per-row branches: a guarded store makes the compiler wait for
+      //  vmcnt(0), i.e. for the previous STORE, in front of every store)
+      const bool full = m0 + 32 <= (long)g.M;
 #pragma unroll
-      for (int t = 0; t < kRows2MaxT; ++t) {
-        if (t < tp) {
-          const int cg = n0 + 32 * t + i;
-          const float bv = g.bias ? g.bias[cg] : 0.f;
-          float s1 = 0.f, s2 = 0.f;
+      for (int t = 0; t < TP; ++t) {
+        const int cg = n0 + 32 * t + i;
+        if (cg < g.N) {
+          float v[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const long row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row < g.M) {
-              const float v = acc[t][r] + bv;
-              g.C[(size_t)row * g.ldc + cg] = v;
-              if (STATS) {
-                if (uniform) {
-                  s1 += v;
-                  s2 += v * v;
-                } else {  // a tile that straddles two cells (one per cell boundary): element-wise
+          for (int r = 0; r < 16; ++r) v[r] = acc[t][r] + bv[t];
+          float* cp = g.C + (size_t)(m0 + 4 * kh) * g.ldc + cg;
+          if (full) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = v[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (m0 + 4 * kh + (r & 3) + 8 * (r >> 2) < (long)g.M) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = v[r];
+          }
+          if (STATS) {
+            if (uniform && full) {
+              float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                s1 += v[r];
+                s2 += v[r] * v[r];
+              }
+              s1 += __shfl_xor(s1, 32);
+              s2 += __shfl_xor(s2, 32);
+              run1[t] += s1;
+              run2[t] += s2;
+            } else {  // a tile that straddles two cells (one per cell boundary) or the ragged last tile: element-wise
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const long row = m0 + 4 * kh + (r & 3) + 8 * (r >> 2);
+                if (row < (long)g.M) {
                   double* p = g.acc + ((size_t)g.row_cell[row] * 2) * 1024 + cg;
-                  atomicAdd(p, (double)v);
-                  atomicAdd(p + 1024, (double)v * (double)v);
+                  atomicAdd(p, (double)v[r]);
+                  atomicAdd(p + 1024, (double)v[r] * (double)v[r]);
                 }
               }
             }
-          }
-          if (STATS && uniform) {
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            run1[t] += s1;
-            run2[t] += s2;
           }
         }
       }
@@ -237,82 +260,73 @@ struct Tn2Args {
   const float *x_mean, *x_rg, *x_beta;  // XFUSE: [cell][K], [cell][K], [K]
   const int32_t* row_cell;
 };
-constexpr int kTn2MaxUnits = 8;  // float4 units a thread stages per step: <= 256 rows x 64 or 64 rows x 256 or 32 rows x 384 floats / 4 / 512 threads
-
-template <int MODE, bool XFUSE>
+// NT and KT are template parameters: the LDS row strides are compile-time constants (every fragment read is base + immediate),
+// the staging loops are exact and branch-free (rows past the chunk are loaded from a clamped address and zeroed by a select).
+template <int MODE, bool XFUSE, int NT, int KT>
 __global__ __launch_bounds__(kRows2Threads) void tn2_kernel(const Tn2Args g) {
   extern __shared__ __attribute__((aligned(16))) char t2_lds[];
+  constexpr int NB = 32 * NT, KB = 32 * KT, RG = 8 / NT, SR = RG * 32;
+  constexpr int ldyl = NB + 4, ldxl = KB + 4;  // LDS row strides (floats)
+  constexpr int buf_floats = SR * (ldyl + ldxl);
+  constexpr int UY = SR * (NB / 4) / kRows2Threads;                        // = 4: float4 units of dY per thread and step
+  constexpr int UXT = SR * (KB / 4), UX = (UXT + kRows2Threads - 1) / kRows2Threads;  // ... of X (the last one may be partial)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, kh = lane >> 5;
   const int n_base = 256 * blockIdx.y, k_base = 32 * g.kb_tiles * blockIdx.z;
-  const int NB = min(256, g.N - n_base), KB = min(32 * g.kb_tiles, g.K - k_base), NT = NB >> 5, KT = KB >> 5, RG = 8 / NT;
   const int nt = w % NT, rg = w / NT;
-  const int SR = RG * 32;                      // rows per step
-  const int ldyl = NB + 4, ldxl = KB + 4;      // LDS row strides (floats)
-  const int buf_floats = SR * (ldyl + ldxl);
   float* lds = reinterpret_cast<float*>(t2_lds);
   const long m_lo = (long)blockIdx.x * g.rows_per_wg, m_hi = min((long)g.M, m_lo + g.rows_per_wg);
-  const int steps = m_hi > m_lo ? (int)((m_hi - m_lo + SR - 1) / SR) : 0;
-  const int uy = SR * (NB >> 2), units = uy + SR * (KB >> 2);
-  f32x16 acc[kTn2MaxT];
+  if (m_hi <= m_lo) return;
+  const int steps = (int)((m_hi - m_lo + SR - 1) / SR);
+  f32x16 acc[KT];
 #pragma unroll
-  for (int t = 0; t < kTn2MaxT; ++t)
+  for (int t = 0; t < KT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float csum = 0.f;
   const bool do_db = g.db && blockIdx.z == 0;
-  float4 st[kTn2MaxUnits];
+  float4 sy[UY], sx[UX];
   auto load_regs = [&](int s) {
     const long m0 = m_lo + (long)s * SR;
 #pragma unroll
-    for (int q = 0; q < kTn2MaxUnits; ++q) {
-      const int u = tid + q * kRows2Threads;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (u < units) {
-        if (u < uy) {
-          const int r = u / (NB >> 2), c = (u % (NB >> 2)) << 2;
-          const long row = m0 + r;
-          if (row < m_hi) v = *reinterpret_cast<const float4*>(g.dY + (size_t)row * g.ldy + n_base + c);
-        } else {
-          const int u2 = u - uy, r = u2 / (KB >> 2), c = (u2 % (KB >> 2)) << 2;
-          const long row = m0 + r;
-          if (row < m_hi) {
-            v = *reinterpret_cast<const float4*>(g.X + (size_t)row * g.ldx + k_base + c);
-            if (XFUSE) {
-              const size_t o = (size_t)g.row_cell[row] * g.K + k_base + c;
-              const float4 mm = *reinterpret_cast<const float4*>(g.x_mean + o), rr = *reinterpret_cast<const float4*>(g.x_rg + o),
-                           bb = *reinterpret_cast<const float4*>(g.x_beta + k_base + c);
-              v.x = fmaxf(__fmaf_rn(__fsub_rn(v.x, mm.x), rr.x, bb.x), 0.f);
-              v.y = fmaxf(__fmaf_rn(__fsub_rn(v.y, mm.y), rr.y, bb.y), 0.f);
-              v.z = fmaxf(__fmaf_rn(__fsub_rn(v.z, mm.z), rr.z, bb.z), 0.f);
-              v.w = fmaxf(__fmaf_rn(__fsub_rn(v.w, mm.w), rr.w, bb.w), 0.f);
-            }
-          }
-        }
+    for (int q = 0; q < UY; ++q) {
+      const int u = tid + q * kRows2Threads, r = u / (NB / 4), c = (u % (NB / 4)) * 4;
+      const long row = m0 + r;
+      const float4 v = *reinterpret_cast<const float4*>(g.dY + (size_t)min(row, m_hi - 1) * g.ldy + n_base + c);
+      sy[q] = row < m_hi ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < UX; ++q) {
+      const int u = min(tid + q * kRows2Threads, UXT - 1), r = u / (KB / 4), c = (u % (KB / 4)) * 4;
+      const long row = m0 + r, rowc = min(row, m_hi - 1);
+      float4 v = *reinterpret_cast<const float4*>(g.X + (size_t)rowc * g.ldx + k_base + c);
+      if (XFUSE) {
+        const size_t o = (size_t)g.row_cell[rowc] * g.K + k_base + c;
+        const float4 mm = *reinterpret_cast<const float4*>(g.x_mean + o), rr = *reinterpret_cast<const float4*>(g.x_rg + o),
+                     bb = *reinterpret_cast<const float4*>(g.x_beta + k_base + c);
+        v.x = fmaxf(__fmaf_rn(__fsub_rn(v.x, mm.x), rr.x, bb.x), 0.f);
+        v.y = fmaxf(__fmaf_rn(__fsub_rn(v.y, mm.y), rr.y, bb.y), 0.f);
+        v.z = fmaxf(__fmaf_rn(__fsub_rn(v.z, mm.z), rr.z, bb.z), 0.f);
+        v.w = fmaxf(__fmaf_rn(__fsub_rn(v.w, mm.w), rr.w, bb.w), 0.f);
       }
-      st[q] = v;
+      sx[q] = row < m_hi ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto write_lds = [&](int b) {
     float* yb = lds + (size_t)b * buf_floats;
     float* xb = yb + SR * ldyl;
 #pragma unroll
-    for (int q = 0; q < kTn2MaxUnits; ++q) {
-      const int u = tid + q * kRows2Threads;
-      if (u < units) {
-        if (u < uy) {
-          const int r = u / (NB >> 2), c = (u % (NB >> 2)) << 2;
-          *reinterpret_cast<float4*>(yb + r * ldyl + c) = st[q];
-        } else {
-          const int u2 = u - uy, r = u2 / (KB >> 2), c = (u2 % (KB >> 2)) << 2;
-          *reinterpret_cast<float4*>(xb + r * ldxl + c) = st[q];
-        }
-      }
+    for (int q = 0; q < UY; ++q) {
+      const int u = tid + q * kRows2Threads, r = u / (NB / 4), c = (u % (NB / 4)) * 4;
+      *reinterpret_cast<float4*>(yb + r * ldyl + c) = sy[q];
+    }
+#pragma unroll
+    for (int q = 0; q < UX; ++q) {
+      const int u = tid + q * kRows2Threads, r = u / (KB / 4), c = (u % (KB / 4)) * 4;
+      if (UXT % kRows2Threads == 0 || u < UXT) *reinterpret_cast<float4*>(xb + r * ldxl + c) = sx[q];
     }
   };
-  if (steps > 0) {
-    load_regs(0);
-    write_lds(0);
-  }
+  load_regs(0);
+  write_lds(0);
   __syncthreads();
   for (int s = 0; s < steps; ++s) {
     if (s + 1 < steps) load_regs(s + 1);
@@ -320,51 +334,56 @@ __global__ __launch_bounds__(kRows2Threads) void tn2_kernel(const Tn2Args g) {
     const float* xb = yb + SR * ldyl;
     if (do_db && tid < NB) {
       float c = 0.f;
+#pragma unroll 8
       for (int r = 0; r < SR; ++r) c += yb[r * ldyl + tid];
       csum += c;
     }
+    const float* ya = yb + (rg * 32 + 8 * kh) * ldyl + nt * 32 + i;
+    const float* xa = xb + (rg * 32 + 8 * kh) * ldxl + i;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int rb = rg * 32 + 16 * h + 8 * kh;
       float a[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] = yb[(rb + j) * ldyl + nt * 32 + i];
+      for (int j = 0; j < 8; ++j) a[j] = ya[(16 * h + j) * ldyl];
       gemm_bf16x8 ah, al;
       if (MODE == 2) gemm_split_bf16(a, ah, al);
       else if (MODE == 1) ah = gemm_to_bf16(a);
 #pragma unroll
-      for (int t = 0; t < kTn2MaxT; ++t) {
-        if (t < KT) {
-          float b[8];
+      for (int t = 0; t < KT; ++t) {
+        float b[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) b[j] = xb[(rb + j) * ldxl + t * 32 + i];
-          if (MODE == 0) {
+        for (int j = 0; j < 8; ++j) b[j] = xa[(16 * h + j) * ldxl + t * 32];
+        if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[t], 0, 0, 0);
-          } else if (MODE == 1) {
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gemm_to_bf16(b), acc[t], 0, 0, 0);
-          } else {
-            gemm_bf16x8 bh, bl;
-            gemm_split_bf16(b, bh, bl);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-          }
+          for (int j = 0; j < 8; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[t], 0, 0, 0);
+        } else if (MODE == 1) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gemm_to_bf16(b), acc[t], 0, 0, 0);
+        } else {
+          gemm_bf16x8 bh, bl;
+          gemm_split_bf16(b, bh, bl);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
         }
       }
     }
+    // ROCm 7.2 / gfx950: without this wait, when the loop is left the register allocator's copy of the last accumulator register
+    // follows the final 16-pass MFMA by five scalar instructions (branch, compare, wait, barrier, branch) and reads it BEFORE the
+    // MFMA has written it (observed: output rows 27 and 31 of tile 0 — accumulator register 15 — off by 4 % in
+    // tn2_kernel<0, true, 2, 1>, nothing else wrong). 32 idle cycles per step against thousands of MFMA cycles.
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     if (s + 1 < steps) write_lds((s + 1) & 1);
     __syncthreads();
   }
-  if (steps == 0) return;
 #pragma unroll
-  for (int t = 0; t < kTn2MaxT; ++t) {
-    if (t < KT) {
+  for (int t = 0; t < KT; ++t) {
+    const int k = k_base + t * 32 + i;
+    if (k < g.k_real) {
+      float* dp = g.dW + (size_t)(n_base + nt * 32 + 4 * kh) * g.ldw + k;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n_base + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (k_base + t * 32 + i < g.k_real) unsafeAtomicAdd(g.dW + (size_t)n * g.ldw + k_base + t * 32 + i, acc[t][r]);
-      }
+      for (int r = 0; r < 16; ++r) unsafeAtomicAdd(dp + (size_t)((r & 3) + 8 * (r >> 2)) * g.ldw, acc[t][r]);
     }
   }
   if (do_db && tid < NB) unsafeAtomicAdd(g.db + n_base + tid, csum);

@@ -503,19 +503,27 @@ static int pn_cu_count() {
   }
   return n_cu;
 }
-template <int MODE, bool AF, bool ST>
+template <int MODE, bool AF, bool ST, int TP>
 static void rows2_launch_t(const train::Rows2Args& a, int grid, size_t lds, hipStream_t s) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(train::rows2_kernel<MODE, AF, ST>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(train::rows2_kernel<MODE, AF, ST, TP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             train::kRows2Lds);
-  hipLaunchKernelGGL((train::rows2_kernel<MODE, AF, ST>), dim3(grid), dim3(train::kRows2Threads), lds, s, a);
+  hipLaunchKernelGGL((train::rows2_kernel<MODE, AF, ST, TP>), dim3(grid), dim3(train::kRows2Threads), lds, s, a);
+}
+template <int MODE, bool AF, bool ST>
+static void rows2_launch_tp(const train::Rows2Args& a, int grid, size_t lds, hipStream_t s) {
+  switch (a.tp) {
+    case 1: rows2_launch_t<MODE, AF, ST, 1>(a, grid, lds, s); break;
+    case 2: rows2_launch_t<MODE, AF, ST, 2>(a, grid, lds, s); break;
+    case 3: rows2_launch_t<MODE, AF, ST, 3>(a, grid, lds, s); break;
+    default: rows2_launch_t<MODE, AF, ST, 4>(a, grid, lds, s); break;
+  }
 }
 template <int MODE>
 static void rows2_launch_m(const train::Rows2Args& a, int grid, size_t lds, hipStream_t s) {
   const bool af = a.a_mean != nullptr, st = a.acc != nullptr;
-  if (af && st) rows2_launch_t<MODE, true, true>(a, grid, lds, s);
-  else if (st) rows2_launch_t<MODE, false, true>(a, grid, lds, s);
-  else if (af) rows2_launch_t<MODE, true, false>(a, grid, lds, s);
-  else rows2_launch_t<MODE, false, false>(a, grid, lds, s);
+  if (af && st) rows2_launch_tp<MODE, true, true>(a, grid, lds, s);
+  else if (st) rows2_launch_tp<MODE, false, true>(a, grid, lds, s);
+  else rows2_launch_tp<MODE, false, false>(a, grid, lds, s);  // (a fused operand without statistics does not occur)
 }
 // C[M,N] = f(A)[M,K] W[N,K]^T + bias; a_mean != nullptr: f = BatchNorm + ReLU of the layer below (tables [cell][K]); acc != nullptr:
 // the BatchNorm partial sums of C per (cell, column). K is a multiple of 16, N of 32.
@@ -532,28 +540,59 @@ static void gemm_rows2(const float* A, const float* W, const float* bias, float*
   else if (mode == 1) rows2_launch_m<1>(a, grid, lds, s);
   else rows2_launch_m<0>(a, grid, lds, s);
 }
-template <int MODE, bool XF>
-static void tn2_launch_t(const train::Tn2Args& a, dim3 grid, size_t lds, hipStream_t s) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(train::tn2_kernel<MODE, XF>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-  hipLaunchKernelGGL((train::tn2_kernel<MODE, XF>), grid, dim3(train::kRows2Threads), lds, s, a);
+template <int MODE, bool XF, int NT, int KT>
+static void tn2_launch_t(const train::Tn2Args& a, dim3 grid, hipStream_t s) {
+  constexpr size_t lds = 2 * (size_t)(8 / NT * 32) * (32 * NT + 4 + 32 * KT + 4) * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(train::tn2_kernel<MODE, XF, NT, KT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  hipLaunchKernelGGL((train::tn2_kernel<MODE, XF, NT, KT>), grid, dim3(train::kRows2Threads), lds, s, a);
 }
-// dW[N][ldw] += dY[M,N]^T f(X)[M,K] (columns k < k_real), db[n] += sum_m dY; x_mean != nullptr: f = BatchNorm + ReLU (tables [cell][K])
-static void gemm_tn2(const float* dY, const float* X, float* dW, float* db, size_t M, int N, int K, int k_real, int ldw, const float* x_mean,
+// the (n tiles, k tiles) block shapes the backbone's layers produce: dW2 [h2, h1] with the fused operand, dW1 [h1, kp] without
+template <int MODE>
+static bool tn2_launch_m(const train::Tn2Args& a, dim3 grid, int nt, int kt, bool xf, hipStream_t s) {
+  if (xf) {
+    if (nt == 2 && kt == 1) tn2_launch_t<MODE, true, 2, 1>(a, grid, s);
+    else if (nt == 4 && kt == 4) tn2_launch_t<MODE, true, 4, 4>(a, grid, s);
+    else if (nt == 8 && kt == 4) tn2_launch_t<MODE, true, 8, 4>(a, grid, s);
+    else return false;
+  } else {
+    if (nt == 1 && kt == 1) tn2_launch_t<MODE, false, 1, 1>(a, grid, s);
+    else if (nt == 4 && kt == 3) tn2_launch_t<MODE, false, 4, 3>(a, grid, s);
+    else if (nt == 8 && kt == 3) tn2_launch_t<MODE, false, 8, 3>(a, grid, s);
+    else if (nt == 8 && kt == 2) tn2_launch_t<MODE, false, 8, 2>(a, grid, s);
+    else return false;
+  }
+  return true;
+}
+// dW[N][ldw] += dY[M,N]^T f(X)[M,K] (columns k < k_real), db[n] += sum_m dY; x_mean != nullptr: f = BatchNorm + ReLU (tables [cell][K]).
+// Blocks along K are launched per distinct block width (K = 160 -> one block of 3 tiles and one of 2).
+static bool gemm_tn2(const float* dY, const float* X, float* dW, float* db, size_t M, int N, int K, int k_real, int ldw, const float* x_mean,
                      const float* x_rg, const float* x_beta, const int32_t* row_cell, hipStream_t s) {
   const int mode = tl_gemm_bf16;
   const int KT = K / 32, kblocks = (KT + train::kTn2MaxT - 1) / train::kTn2MaxT, kb_tiles = (KT + kblocks - 1) / kblocks;
-  const int gy = (N + 255) / 256, gz = kblocks;
-  const int NB = std::min(256, N), KB = 32 * kb_tiles, RG = 8 / (NB / 32), SR = RG * 32;
-  const size_t lds = 2 * (size_t)SR * (NB + 4 + KB + 4) * sizeof(float);
-  int gx = std::max(1, pn_cu_count() / (gy * gz));
-  gx = (int)std::min<size_t>((size_t)gx, (M + SR - 1) / SR);
-  const int rpw = (int)(((M + gx - 1) / gx + SR - 1) / SR * SR);
-  const train::Tn2Args a{dY, X, dW, db, (int)M, N, K, N, K, ldw, rpw, kb_tiles, k_real, x_mean, x_rg, x_beta, row_cell};
-  const dim3 grid(gx, gy, gz);
-  const bool xf = x_mean != nullptr;
-  if (mode == 2) xf ? tn2_launch_t<2, true>(a, grid, lds, s) : tn2_launch_t<2, false>(a, grid, lds, s);
-  else if (mode == 1) xf ? tn2_launch_t<1, true>(a, grid, lds, s) : tn2_launch_t<1, false>(a, grid, lds, s);
-  else xf ? tn2_launch_t<0, true>(a, grid, lds, s) : tn2_launch_t<0, false>(a, grid, lds, s);
+  const int gy = (N + 255) / 256, nt = std::min(256, N) / 32, SR = 8 / nt * 32;
+  const int last_tiles = KT - kb_tiles * (kblocks - 1);  // tiles of the last block along K (<= kb_tiles)
+  bool ok = true;
+  for (int part = 0; part < 2 && ok; ++part) {
+    // part 0: the blocks [0, nfull) of kb_tiles tiles; part 1: a narrower last block, as its own launch
+    const int nfull = last_tiles == kb_tiles ? kblocks : kblocks - 1;
+    const int gz = part == 0 ? nfull : (last_tiles == kb_tiles ? 0 : 1);
+    if (gz == 0) continue;
+    const int kt = part == 0 ? kb_tiles : last_tiles;
+    int gx = std::max(1, pn_cu_count() / (gy * gz));
+    gx = (int)std::min<size_t>((size_t)gx, (M + SR - 1) / SR);
+    const int rpw = (int)(((M + gx - 1) / gx + SR - 1) / SR * SR);
+    // a narrower last block starts at column 32 * kb_tiles * nfull: shift the operand pointers, keep kb_tiles for the block stride
+    const int k0 = part == 0 ? 0 : 32 * kb_tiles * nfull;
+    const train::Tn2Args a{dY, X + k0, dW + k0, part == 0 ? db : nullptr, (int)M, N, K, N, K, ldw, rpw, kb_tiles, k_real - k0,
+                           x_mean ? x_mean + k0 : nullptr, x_rg ? x_rg + k0 : nullptr, x_beta ? x_beta + k0 : nullptr, row_cell};
+    const dim3 grid(gx, gy, gz);
+    const bool xf = x_mean != nullptr;
+    if (mode == 2) ok = tn2_launch_m<2>(a, grid, nt, kt, xf, s);
+    else if (mode == 1) ok = tn2_launch_m<1>(a, grid, nt, kt, xf, s);
+    else ok = tn2_launch_m<0>(a, grid, nt, kt, xf, s);
+  }
+  return ok;
 }
 
 // object_encoder.pointnet.* tensors of the binding: all of them with gradient buffers -> the backbone trains in the engine
@@ -924,8 +963,9 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
       gemm_tn(dA2, L.a1, T_(st, L.prefix + ".1.0.weight").grad, T_(st, L.prefix + ".1.0.bias").grad, (int)L.E, L.h2, L.h1, s);
       gemm_nn_rows(dA2, T_(st, L.prefix + ".1.0.weight").data, pt->wt, dA1, L.E, L.h2, L.h1, s);
     } else {  // a1 = relu(bn(y1)) is rebuilt while y1 is staged
-      gemm_tn2(dA2, L.y1, T_(st, L.prefix + ".1.0.weight").grad, T_(st, L.prefix + ".1.0.bias").grad, L.E, L.h2, L.h1, L.h1, L.h1, L.mean1,
-               L.rg1, be1, L.row_cell, s);
+      if (!gemm_tn2(dA2, L.y1, T_(st, L.prefix + ".1.0.weight").grad, T_(st, L.prefix + ".1.0.bias").grad, L.E, L.h2, L.h1, L.h1, L.h1,
+                    L.mean1, L.rg1, be1, L.row_cell, s))
+        return fail(ctx, T2L_EHIP, "t2l_pointnet_backward: no tn2_kernel instance for this layer shape (internal error)");
       hipLaunchKernelGGL(pt_transpose_kernel, dim3((unsigned)((L.h2 * L.h1 + 255) / 256)), dim3(256), 0, s,
                          (const float*)T_(st, L.prefix + ".1.0.weight").data, L.h2, L.h1, pt->wt);
       gemm_rows2(dA2, pt->wt, nullptr, dA1, L.E, L.h1, L.h2, nullptr, nullptr, nullptr, nullptr, nullptr, s);
@@ -937,8 +977,9 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
       hipLaunchKernelGGL(pt_unpad_add_kernel, dim3(pn_blocks((size_t)L.h1 * L.kin)), dim3(256), 0, s, (const float*)L.dw1p, L.h1, L.kin, L.kp,
                          T_(st, L.prefix + ".0.0.weight").grad);
     } else {  // straight into the unpadded gradient: the padding columns of X are not written
-      gemm_tn2(dA1, L.X, T_(st, L.prefix + ".0.0.weight").grad, T_(st, L.prefix + ".0.0.bias").grad, L.E, L.h1, L.kp, L.kin, L.kin, nullptr,
-               nullptr, nullptr, nullptr, s);
+      if (!gemm_tn2(dA1, L.X, T_(st, L.prefix + ".0.0.weight").grad, T_(st, L.prefix + ".0.0.bias").grad, L.E, L.h1, L.kp, L.kin, L.kin,
+                    nullptr, nullptr, nullptr, nullptr, s))
+        return fail(ctx, T2L_EHIP, "t2l_pointnet_backward: no tn2_kernel instance for this layer shape (internal error)");
     }
     if (l > 0) {  // the input gradient: features of the level below (positions are data)
       float* dX = pn_bump<float>(pt, L.E * L.kp);

@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pn_prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $ROOT/tools/pn_train_probe.py ${1:-64} ${2:-0} > $OUT/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $ROOT/tools/pn_train_probe.py ${1:-64} ${2:-0} ${4:-0} > $OUT/trace.log 2>&1
 cd $ROOT
 python - <<EOF2
 import csv, glob

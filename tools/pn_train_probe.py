@@ -1,4 +1,4 @@
-"""PointNet++ training-mode forward/backward timing at the published batch (64 cells): python tools/pn_train_probe.py [B] [bf16] [v1]"""
+"""PointNet++ training-mode forward/backward timing at the published batch (64 cells): python tools/pn_train_probe.py [B] [bf16] [v1] [iterations]"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")
@@ -24,7 +24,8 @@ offs = np.asarray(cells["offsets"], dtype=np.int32)
 dpos, drgb = torch.from_numpy(pos).cuda(), torch.from_numpy(rgb).cuda()
 g = torch.randn(pos.shape[0], 256, device="cuda")
 print("objects", pos.shape[0])
-for it in range(3):
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+for it in range(iters):  # (the GPU reaches its sustained clocks after ~40 ms of load: the last lines are the steady state)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     f2 = eng.pointnet_features_train(dpos, drgb, offs)
     torch.cuda.synchronize(); t1 = time.perf_counter()
