@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 # float32 MFMA accumulation order on the device vs torch's CPU kernels: the margin fixtures are asserted at GPU_MARGIN_SCALE x 1e-4
 # of each gradient tensor's rms (the float64 / float32 numpy oracles meet 1e-4, tests/test_oracle_train.py)
-GPU_MARGIN_SCALE = 5.0
+GPU_MARGIN_SCALE = 10.0
 
 
 def used_names(sd, embed):

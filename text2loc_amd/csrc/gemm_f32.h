@@ -138,6 +138,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int bx, int by, int
       }
     }
   }
+  // (see gemm_rows2.h: no VALU read of an accumulator right behind the last MFMA of a loop)
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[(w * 16 + r) * 64 + lane] = acc[r];
   if (do_colsum) cred[w * 64 + lane] = csum;
@@ -148,25 +152,39 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int bx, int by, int
     for (int q = 0; q < 4; ++q) s += cred[q * 64 + tid] + cred[q * 64 + 32 + tid];
     unsafeAtomicAdd(g.colsum + m0 + tid, s);
   }
+  // epilogue in two phases — every load of the four elements a thread owns first (bias: one column for all four; the ReLU mask),
+  // then the stores: a load next to each guarded store made every store wait for the previous one (s_waitcnt vmcnt(0) each)
+  {
+    const int l = tid & 63, cg = n0 + (l & 31);
+    const float bv = (g.bias && bz == 0) ? g.bias[cg] : 0.f;
+    float v[4], mk[4];
+    size_t idx[4];
+    bool ok[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int e = tid + 256 * q, r = e >> 6, l = e & 63;
-    const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), cg = n0 + (l & 31);
-    if (row < g.M) {
-      float v = red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l];
-      if (g.bias && bz == 0) v += g.bias[cg];
-      if (g.relu) v = fmaxf(v, 0.f);
-      const size_t idx = (size_t)row * g.ldc + cg;
+    for (int q = 0; q < 4; ++q) {
+      const int r = (tid >> 6) + 4 * q;
+      const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      ok[q] = row < g.M;
+      idx[q] = (size_t)min(row, g.M - 1) * g.ldc + cg;
+      mk[q] = g.epi == 2 ? g.mask_src[idx[q]] : 1.f;
+      v[q] = red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l] + bv;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float x = v[q];
+      if (g.relu) x = fmaxf(x, 0.f);
       if (g.epi == 2) {  // ReLU + dropout backward of the layer whose output fed this product's left operand
-        v = g.mask_src[idx] > 0.f ? v : 0.f;
-        if (g.drop_thr) v = gemm_keep_bit(g.drop_key, (uint32_t)idx, g.drop_thr) ? v * g.drop_scale : 0.f;
+        x = mk[q] > 0.f ? x : 0.f;
+        if (g.drop_thr) x = gemm_keep_bit(g.drop_key, (uint32_t)idx[q], g.drop_thr) ? x * g.drop_scale : 0.f;
       }
-      float* dst = g.C + idx;
-      if (g.accumulate)
-        unsafeAtomicAdd(dst, v);
-      else
-        *dst = v;
-      if (g.epi == 1) g.C2[idx] = gemm_keep_bit(g.drop_key, (uint32_t)idx, g.drop_thr) ? v * g.drop_scale : 0.f;
+      if (ok[q]) {
+        float* dst = g.C + idx[q];
+        if (g.accumulate)
+          unsafeAtomicAdd(dst, x);
+        else
+          *dst = x;
+        if (g.epi == 1) g.C2[idx[q]] = gemm_keep_bit(g.drop_key, (uint32_t)idx[q], g.drop_thr) ? x * g.drop_scale : 0.f;
+      }
     }
   }
 }

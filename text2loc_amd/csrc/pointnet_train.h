@@ -31,6 +31,7 @@ struct PnLevel {
   float *X = nullptr, *y1 = nullptr, *a1 = nullptr, *y2 = nullptr;  // (the second layer's post-ReLU output is never stored)
   float *mean1 = nullptr, *rstd1 = nullptr, *mean2 = nullptr, *rstd2 = nullptr;
   float* rg1 = nullptr;  // rstd1 * gamma1 per (cell, channel): the fused BatchNorm + ReLU operand loads of the second version
+  float* ysel = nullptr;  // pre-BatchNorm value of the second layer at the arg-max row, per (group, channel)
   float *xout = nullptr, *pos_out = nullptr, *w1p = nullptr, *dw1p = nullptr;
 };
 
@@ -158,20 +159,35 @@ __global__ __launch_bounds__(256) void pt_iota_rows_kernel(size_t E, int per, co
   row_cell[i] = cell_of_obj[i / per];
 }
 
-// edge inputs: X[row] = [x_src | pos_src - pos_centre | 0 pad] (SA), [x | pos | 0 pad] (global MLP: pos_ctr == nullptr)
+// edge inputs: X[row] = [x_src | pos_src - pos_centre | 0 pad] (SA), [x | pos | 0 pad] (global MLP: pos_ctr == nullptr).
+// One thread per 4 consecutive columns (kp is a multiple of 32): whole float4 loads of the source row where the 4 columns are
+// features and cin is a multiple of 4 (every level but the first, whose 3 + 3 real columns fit the scalar path).
 __global__ __launch_bounds__(256) void pt_gather_kernel(const float* __restrict__ x_src, const float* __restrict__ pos_src,
                                                         const float* __restrict__ pos_ctr, const int32_t* __restrict__ src,
                                                         const int32_t* __restrict__ row_group, size_t E, int cin, int kp,
                                                         float* __restrict__ X) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= E * kp) return;
-  const size_t row = i / kp;
-  const int col = (int)(i % kp);
+  const int q = kp >> 2;
+  if (i >= E * q) return;
+  const size_t row = i / q;
+  const int col = (int)(i % q) * 4;
   const size_t sr = (size_t)src[row];
-  float v = 0.f;
-  if (col < cin) v = x_src[sr * cin + col];
-  else if (col < cin + 3) v = pos_src[sr * 3 + col - cin] - (pos_ctr ? pos_ctr[(size_t)row_group[row] * 3 + col - cin] : 0.f);
-  X[i] = v;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col + 4 <= cin && (cin & 3) == 0) {
+    v = *reinterpret_cast<const float4*>(x_src + sr * cin + col);
+  } else if (col < cin + 3) {
+    float e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = col + j;
+      float x = 0.f;
+      if (c < cin) x = x_src[sr * cin + c];
+      else if (c < cin + 3) x = pos_src[sr * 3 + c - cin] - (pos_ctr ? pos_ctr[(size_t)row_group[row] * 3 + c - cin] : 0.f);
+      e[j] = x;
+    }
+    v = make_float4(e[0], e[1], e[2], e[3]);
+  }
+  *reinterpret_cast<float4*>(X + row * kp + col) = v;
 }
 
 __global__ void pt_pad_kernel(const float* __restrict__ W, int rows, int kin, int kp, float* __restrict__ Wp) {
@@ -272,27 +288,54 @@ __global__ __launch_bounds__(256) void pt_bn_stats_kernel(const float* __restric
 }
 
 // statistics of every cell + the running-statistics updates the reference performs once per cell, in cell order
-// (rg != nullptr: also rg[cell][c] = rstd * gamma[c], the scale of the fused BatchNorm + ReLU operand loads — pt_bn_relu)
-__global__ void pt_bn_finalize_kernel(const double* __restrict__ acc, const int32_t* __restrict__ cnt, int n_cells, int C,
-                                      float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
-                                      float* __restrict__ run_var, float momentum, const float* __restrict__ gamma, float* __restrict__ rg) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float rm = run_mean[c], rv = run_var[c];
-  const float ga = rg ? gamma[c] : 0.f;
-  for (int cell = 0; cell < n_cells; ++cell) {
-    const double n = (double)max(cnt[cell], 1);
-    const double m = acc[((size_t)cell * 2) * 1024 + c] / n;
-    const double var = fmax(acc[((size_t)cell * 2 + 1) * 1024 + c] / n - m * m, 0.0);
-    mean[(size_t)cell * C + c] = (float)m;
-    const float rs = 1.0f / sqrtf((float)var + kBnEps);
-    rstd[(size_t)cell * C + c] = rs;
-    if (rg) rg[(size_t)cell * C + c] = rs * ga;
-    rm = (1.f - momentum) * rm + momentum * (float)m;
-    rv = (1.f - momentum) * rv + momentum * (float)(var * (n / fmax(n - 1.0, 1.0)));
+// (rg != nullptr: also rg[cell][c] = rstd * gamma[c], the scale of the fused BatchNorm + ReLU operand loads — pt_bn_relu).
+// Block = 32 channels x 8 cell lanes: the per-cell statistics are computed in parallel (chunks of 256 cells through LDS), the
+// momentum recurrence then runs over the chunk from LDS (the first version walked the cells with two dependent float64 loads
+// each: 45-65 us per launch, eight launches per forward).
+__global__ __launch_bounds__(256) void pt_bn_finalize_kernel(const double* __restrict__ acc, const int32_t* __restrict__ cnt, int n_cells, int C,
+                                                             float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
+                                                             float* __restrict__ run_var, float momentum, const float* __restrict__ gamma,
+                                                             float* __restrict__ rg) {
+  __shared__ float sm[256][33], sv[256][33];
+  const int cl = threadIdx.x & 31, lane8 = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+  const bool cok = c < C;
+  const float ga = rg && cok ? gamma[c] : 0.f;
+  float rm = 0.f, rv = 0.f;
+  if (lane8 == 0 && cok) {
+    rm = run_mean[c];
+    rv = run_var[c];
   }
-  run_mean[c] = rm;
-  run_var[c] = rv;
+  for (int base = 0; base < n_cells; base += 256) {
+    const int nc = min(256, n_cells - base);
+    for (int j = lane8; j < nc; j += 8) {
+      const int cell = base + j;
+      float mf = 0.f, vu = 0.f;
+      if (cok) {
+        const double n = (double)max(cnt[cell], 1);
+        const double m = acc[((size_t)cell * 2) * 1024 + c] / n;
+        const double var = fmax(acc[((size_t)cell * 2 + 1) * 1024 + c] / n - m * m, 0.0);
+        mf = (float)m;
+        vu = (float)(var * (n / fmax(n - 1.0, 1.0)));
+        mean[(size_t)cell * C + c] = mf;
+        const float rs = 1.0f / sqrtf((float)var + kBnEps);
+        rstd[(size_t)cell * C + c] = rs;
+        if (rg) rg[(size_t)cell * C + c] = rs * ga;
+      }
+      sm[j][cl] = mf;
+      sv[j][cl] = vu;
+    }
+    __syncthreads();
+    if (lane8 == 0 && cok)
+      for (int j = 0; j < nc; ++j) {
+        rm = (1.f - momentum) * rm + momentum * sm[j][cl];
+        rv = (1.f - momentum) * rv + momentum * sv[j][cl];
+      }
+    __syncthreads();
+  }
+  if (lane8 == 0 && cok) {
+    run_mean[c] = rm;
+    run_var[c] = rv;
+  }
 }
 
 __global__ __launch_bounds__(256) void pt_bn_apply_fwd_kernel(const float* __restrict__ y, size_t E, int C,
@@ -372,8 +415,8 @@ __global__ __launch_bounds__(256) void pt_bn_apply_bwd_kernel(float* __restrict_
 // BatchNorm-backward sums of a block's SECOND layer, straight from the max aggregation: only the arg-max row of every
 // (group, channel) carries a gradient, so sum dv and sum dv * xhat are sums over GROUPS (dv = dxout where the maximum is > 0;
 // xhat from one gathered y per (group, channel)) — no pass over the edge rows. grid (ceil(C/64), ceil(G/256)).
-__global__ __launch_bounds__(256) void pt_bn_stats_max_kernel(const float* __restrict__ y, const float* __restrict__ xout,
-                                                              const int32_t* __restrict__ arg, const float* __restrict__ dxout, size_t G, int C,
+__global__ __launch_bounds__(256) void pt_bn_stats_max_kernel(const float* __restrict__ ysel, const float* __restrict__ xout,
+                                                              const float* __restrict__ dxout, size_t G, int C,
                                                               int nd, const int32_t* __restrict__ cell_of_obj,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               double* __restrict__ acc) {
@@ -398,7 +441,7 @@ __global__ __launch_bounds__(256) void pt_bn_stats_max_kernel(const float* __res
     if (xout[i] > 0.f) {
       const float dv = dxout[i];
       s1 += dv;
-      s2 += dv * (y[(size_t)arg[i] * C + c] - mu) * rs;
+      s2 += dv * (ysel[i] - mu) * rs;
     }
   }
   if (cur >= 0) {
@@ -420,29 +463,41 @@ __global__ void pt_bn_param_grad_kernel(const double* __restrict__ acc, int n_ce
 }
 
 // second layer of a block: BatchNorm + ReLU applied on the fly, max over the rows of every group (first maximum wins, as
-// argmax) + the winning row — the post-ReLU activations of the widest layer never exist in memory
+// argmax) + the winning row and its pre-BatchNorm value (ysel: the backward's statistics need y at the arg-max row and read it
+// from here instead of gathering it) — the post-ReLU activations of the widest layer never exist in memory.
+// One thread per (group, 4 channels): float4 loads, a wave covers 1 KiB of a row.
 __global__ __launch_bounds__(256) void pt_segmax_kernel(const float* __restrict__ y, const int32_t* __restrict__ goff, size_t n_groups, int C,
                                                         int nd, const int32_t* __restrict__ cell_of_obj, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float* __restrict__ xout, int32_t* __restrict__ arg) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+                                                        const float* __restrict__ beta, float* __restrict__ xout, int32_t* __restrict__ arg,
+                                                        float* __restrict__ ysel) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n_groups * C) return;
   const size_t g = i / C;
   const int c = (int)(i % C);
   const size_t sc = (size_t)cell_of_obj[g / nd] * C + c;
-  const float m = mean[sc], r = rstd[sc], ga = gamma[c], be = beta[c];
+  const float4 m = *reinterpret_cast<const float4*>(mean + sc), r = *reinterpret_cast<const float4*>(rstd + sc),
+               ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
   const int lo = goff[g], hi = goff[g + 1];
-  float best = -1.f;  // ReLU outputs are >= 0 and every group has at least one row (the centre itself)
-  int br = -1;
+  float best[4] = {-1.f, -1.f, -1.f, -1.f}, ys[4] = {0.f, 0.f, 0.f, 0.f};  // ReLU outputs are >= 0 and every group has at least one row
+  int br[4] = {-1, -1, -1, -1};
+#pragma unroll 4
   for (int row = lo; row < hi; ++row) {
-    const float v = fmaxf((y[(size_t)row * C + c] - m) * r * ga + be, 0.f);
-    if (v > best) {
-      best = v;
-      br = row;
-    }
+    const float4 yv = *reinterpret_cast<const float4*>(y + (size_t)row * C + c);
+    const float v[4] = {fmaxf((yv.x - m.x) * r.x * ga.x + be.x, 0.f), fmaxf((yv.y - m.y) * r.y * ga.y + be.y, 0.f),
+                        fmaxf((yv.z - m.z) * r.z * ga.z + be.z, 0.f), fmaxf((yv.w - m.w) * r.w * ga.w + be.w, 0.f)};
+    const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (v[j] > best[j]) {
+        best[j] = v[j];
+        br[j] = row;
+        ys[j] = yy[j];
+      }
   }
-  xout[i] = fmaxf(best, 0.f);
-  arg[i] = br;
+  *reinterpret_cast<float4*>(xout + i) = make_float4(fmaxf(best[0], 0.f), fmaxf(best[1], 0.f), fmaxf(best[2], 0.f), fmaxf(best[3], 0.f));
+  *reinterpret_cast<int4*>(arg + i) = make_int4(br[0], br[1], br[2], br[3]);
+  *reinterpret_cast<float4*>(ysel + i) = make_float4(ys[0], ys[1], ys[2], ys[3]);
 }
 // dx_src[src][0:cin] += dX[row][0:cin]
 __global__ __launch_bounds__(256) void pt_scatter_kernel(const float* __restrict__ dX, const int32_t* __restrict__ src, size_t E, int cin, int kp,
@@ -685,6 +740,7 @@ static size_t pn_layout(PnTrain* pt) {
     L.rstd2 = pn_bump<float>(pt, (size_t)n_cells * L.h2);
     L.xout = pn_bump<float>(pt, L.G * L.h2);
     L.arg = pn_bump<int32_t>(pt, L.G * L.h2);
+    L.ysel = pn_bump<float>(pt, L.G * L.h2);
     // backward scratch of this level: dA2, dA1, dX (+ 256-byte roundings)
     scratch = std::max(scratch, L.E * (size_t)(L.h2 + L.h1 + L.kp) * sizeof(float) + 3 * 256);
   }
@@ -715,7 +771,7 @@ static void pn_block_fwd(TrainState* st, PnTrain* pt, const PnLevel& L, int laye
     gemm_rows2(X, W, T_(st, p + ".0.bias").data, y, L.E, C, K, x_fuse ? L.mean1 : nullptr, x_fuse ? L.rg1 : nullptr,
                x_fuse ? T_(st, L.prefix + ".0.1.bias").data : nullptr, L.row_cell, pt->acc, s);
   }
-  hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)pt->acc, (const int32_t*)L.cnt, pt->n_cells, C,
+  hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const double*)pt->acc, (const int32_t*)L.cnt, pt->n_cells, C,
                      mean, rstd, T_(st, p + ".1.running_mean").data, T_(st, p + ".1.running_var").data, 0.1f,
                      (const float*)T_(st, p + ".1.weight").data, rg);
   if (a)
@@ -732,8 +788,8 @@ static void pn_block_bwd(TrainState* st, PnTrain* pt, const PnLevel& L, int laye
   const std::string p = L.prefix + "." + std::to_string(layer);
   (void)hipMemsetAsync(pt->acc, 0, sizeof(double) * 2 * 1024 * pt->n_cells, s);
   if (dxout) {
-    hipLaunchKernelGGL(pt_bn_stats_max_kernel, dim3((C + 63) / 64, (unsigned)((L.G + 255) / 256)), dim3(256), 0, s, y, (const float*)L.xout,
-                       (const int32_t*)L.arg, dxout, L.G, C, L.nd, (const int32_t*)pt->cell_of_obj, mean, rstd, pt->acc);
+    hipLaunchKernelGGL(pt_bn_stats_max_kernel, dim3((C + 63) / 64, (unsigned)((L.G + 255) / 256)), dim3(256), 0, s, (const float*)L.ysel,
+                       (const float*)L.xout, dxout, L.G, C, L.nd, (const int32_t*)pt->cell_of_obj, mean, rstd, pt->acc);
     hipLaunchKernelGGL((pt_bn_apply_bwd_kernel<true>), dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, d, a, y, L.E, C,
                        (const int32_t*)L.row_cell, (const int32_t*)L.cnt, (const double*)pt->acc, (const float*)T_(st, p + ".1.weight").data, mean,
                        rstd, (const int32_t*)L.arg, dxout, (const int32_t*)L.row_group, (const float*)T_(st, p + ".1.bias").data,
@@ -901,16 +957,17 @@ int pn_train_forward_impl(t2l_ctx* ctx, const float* pos, const float* rgb, cons
     else
       hipLaunchKernelGGL(pt_iota_rows_kernel, dim3(pn_blocks(L.E + 1)), dim3(256), 0, s, L.E, 32, (const int32_t*)pt->cell_of_obj, L.src,
                          L.row_group, L.row_cell, L.goff);
-    hipLaunchKernelGGL(pt_gather_kernel, dim3(pn_blocks(L.E * L.kp)), dim3(256), 0, s, cur_x, cur_pos, L.sa ? (const float*)L.pos_out : nullptr,
+    hipLaunchKernelGGL(pt_gather_kernel, dim3(pn_blocks(L.E * (L.kp / 4))), dim3(256), 0, s, cur_x, cur_pos, L.sa ? (const float*)L.pos_out : nullptr,
                        (const int32_t*)L.src, (const int32_t*)L.row_group, L.E, L.cin, L.kp, L.X);
     hipLaunchKernelGGL(pt_pad_kernel, dim3(pn_blocks((size_t)L.h1 * L.kp)), dim3(256), 0, s, (const float*)T_(st, L.prefix + ".0.0.weight").data,
                        L.h1, L.kin, L.kp, L.w1p);
     pn_block_fwd(st, pt, L, 0, L.X, L.w1p, L.kp, L.h1, L.y1, L.a1, L.mean1, L.rstd1, L.rg1, false, s);
     pn_block_fwd(st, pt, L, 1, pt->v1 ? L.a1 : L.y1, T_(st, L.prefix + ".1.0.weight").data, L.h1, L.h2, L.y2, nullptr, L.mean2, L.rstd2, nullptr,
                  !pt->v1, s);
-    hipLaunchKernelGGL(pt_segmax_kernel, dim3(pn_blocks(L.G * L.h2)), dim3(256), 0, s, (const float*)L.y2, (const int32_t*)L.goff, L.G, L.h2,
+    hipLaunchKernelGGL(pt_segmax_kernel, dim3(pn_blocks(L.G * L.h2 / 4)), dim3(256), 0, s, (const float*)L.y2, (const int32_t*)L.goff, L.G, L.h2,
                        L.nd, (const int32_t*)pt->cell_of_obj, (const float*)L.mean2, (const float*)L.rstd2,
-                       (const float*)T_(st, L.prefix + ".1.1.weight").data, (const float*)T_(st, L.prefix + ".1.1.bias").data, L.xout, L.arg);
+                       (const float*)T_(st, L.prefix + ".1.1.weight").data, (const float*)T_(st, L.prefix + ".1.1.bias").data, L.xout, L.arg,
+                       L.ysel);
     if (L.sa) {
       cur_pos = L.pos_out;
       cur_x = L.xout;
