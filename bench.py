@@ -504,8 +504,10 @@ def secondary_measurements(eng):
         dpos_t, drgb_t = torch.from_numpy(pos_t).cuda(), torch.from_numpy(rgb_t).cuda()
         g_t = torch.randn(pos_t.shape[0], 256, device="cuda")
         res = {}
-        for variant, bf in (("f32", 0), ("split_bf16_gemms", 2), ("bf16_gemms", 1)):
+        for variant, bf, v1 in (("f32", 0, 0), ("split_bf16_gemms", 2, 0), ("bf16_gemms", 1, 0), ("first_version_f32", 0, 1),
+                                ("first_version_bf16_gemms", 1, 1)):
             eng_t.set_option("train_bf16", bf)
+            eng_t.set_option("pointnet_train_v1", v1)  # 1: the round-2 GEMM kernels (operands from L2, a1 stored), for the A/B line
             fw, bw = [], []
             for it in range(4):
                 torch.cuda.synchronize()
@@ -519,7 +521,9 @@ def secondary_measurements(eng):
                 if it:
                     fw.append(t1 - t0)
                     bw.append(t2 - t1)
-            res[variant] = {"forward_ms": 1e3 * min(fw), "backward_ms": 1e3 * min(bw)}
+            res[variant] = {"forward_ms": 1e3 * min(fw), "backward_ms": 1e3 * min(bw), "step_ms": 1e3 * (min(fw) + min(bw))}
+        eng_t.set_option("pointnet_train_v1", 0)
+        eng_t.set_option("train_bf16", 0)
         free_b, total_b = torch.cuda.mem_get_info()
         out["pointnet_train_b64"] = dict(res, cells=64, objects=int(pos_t.shape[0]),
                                          parity="self-consistent only (float64 restatement + central differences, tests/test_gpu_pointnet_train.py)",

@@ -615,6 +615,7 @@ static bool tn2_launch_m(const train::Tn2Args& a, dim3 grid, int nt, int kt, boo
     else if (nt == 4 && kt == 3) tn2_launch_t<MODE, false, 4, 3>(a, grid, s);
     else if (nt == 8 && kt == 3) tn2_launch_t<MODE, false, 8, 3>(a, grid, s);
     else if (nt == 8 && kt == 2) tn2_launch_t<MODE, false, 8, 2>(a, grid, s);
+    else if (nt == 8 && kt == 4) tn2_launch_t<MODE, false, 8, 4>(a, grid, s);
     else return false;
   }
   return true;
@@ -731,7 +732,9 @@ static size_t pn_layout(PnTrain* pt) {
     L.w1p = pn_bump<float>(pt, (size_t)L.h1 * L.kp);
     L.dw1p = pn_bump<float>(pt, (size_t)L.h1 * L.kp);
     L.y1 = pn_bump<float>(pt, L.E * L.h1);
-    L.a1 = pt->v1 ? pn_bump<float>(pt, L.E * L.h1) : nullptr;  // second version: recomputed from y1 wherever it is consumed
+    // second version: a1 is recomputed from y1 wherever it is consumed — except in the global MLP (45 k rows x 512: 92 MB), whose
+    // wide layers would pay the fused operand transform once per column pass (K = 512 leaves two column tiles per pass)
+    L.a1 = (pt->v1 || l == 3) ? pn_bump<float>(pt, L.E * L.h1) : nullptr;
     L.rg1 = pn_bump<float>(pt, (size_t)n_cells * L.h1);
     L.y2 = pn_bump<float>(pt, L.E * L.h2);
     L.mean1 = pn_bump<float>(pt, (size_t)n_cells * L.h1);
@@ -962,8 +965,8 @@ int pn_train_forward_impl(t2l_ctx* ctx, const float* pos, const float* rgb, cons
     hipLaunchKernelGGL(pt_pad_kernel, dim3(pn_blocks((size_t)L.h1 * L.kp)), dim3(256), 0, s, (const float*)T_(st, L.prefix + ".0.0.weight").data,
                        L.h1, L.kin, L.kp, L.w1p);
     pn_block_fwd(st, pt, L, 0, L.X, L.w1p, L.kp, L.h1, L.y1, L.a1, L.mean1, L.rstd1, L.rg1, false, s);
-    pn_block_fwd(st, pt, L, 1, pt->v1 ? L.a1 : L.y1, T_(st, L.prefix + ".1.0.weight").data, L.h1, L.h2, L.y2, nullptr, L.mean2, L.rstd2, nullptr,
-                 !pt->v1, s);
+    pn_block_fwd(st, pt, L, 1, L.a1 ? L.a1 : L.y1, T_(st, L.prefix + ".1.0.weight").data, L.h1, L.h2, L.y2, nullptr, L.mean2, L.rstd2, nullptr,
+                 L.a1 == nullptr, s);
     hipLaunchKernelGGL(pt_segmax_kernel, dim3(pn_blocks(L.G * L.h2 / 4)), dim3(256), 0, s, (const float*)L.y2, (const int32_t*)L.goff, L.G, L.h2,
                        L.nd, (const int32_t*)pt->cell_of_obj, (const float*)L.mean2, (const float*)L.rstd2,
                        (const float*)T_(st, L.prefix + ".1.1.weight").data, (const float*)T_(st, L.prefix + ".1.1.bias").data, L.xout, L.arg,
@@ -1020,8 +1023,8 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
       gemm_tn(dA2, L.a1, T_(st, L.prefix + ".1.0.weight").grad, T_(st, L.prefix + ".1.0.bias").grad, (int)L.E, L.h2, L.h1, s);
       gemm_nn_rows(dA2, T_(st, L.prefix + ".1.0.weight").data, pt->wt, dA1, L.E, L.h2, L.h1, s);
     } else {  // a1 = relu(bn(y1)) is rebuilt while y1 is staged
-      if (!gemm_tn2(dA2, L.y1, T_(st, L.prefix + ".1.0.weight").grad, T_(st, L.prefix + ".1.0.bias").grad, L.E, L.h2, L.h1, L.h1, L.h1,
-                    L.mean1, L.rg1, be1, L.row_cell, s))
+      if (!gemm_tn2(dA2, L.a1 ? L.a1 : L.y1, T_(st, L.prefix + ".1.0.weight").grad, T_(st, L.prefix + ".1.0.bias").grad, L.E, L.h2, L.h1, L.h1,
+                    L.h1, L.a1 ? nullptr : L.mean1, L.a1 ? nullptr : L.rg1, L.a1 ? nullptr : be1, L.row_cell, s))
         return fail(ctx, T2L_EHIP, "t2l_pointnet_backward: no tn2_kernel instance for this layer shape (internal error)");
       hipLaunchKernelGGL(pt_transpose_kernel, dim3((unsigned)((L.h2 * L.h1 + 255) / 256)), dim3(256), 0, s,
                          (const float*)T_(st, L.prefix + ".1.0.weight").data, L.h2, L.h1, pt->wt);
