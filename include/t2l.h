@@ -350,6 +350,10 @@ int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step,
  *     2 = split-bf16: every operand as hi + lo bf16, three MFMAs per 16-step (relative product error <= 2^-16 + 2^-18, f32's
  *     exponent range): the f32 goldens are met to 1e-4 at close to the bf16 variant's speed. Applies to the PointNet++
  *     training calls too.
+ * "pointnet_train_v1" (default 0): 1 = t2l_pointnet_features_train / t2l_pointnet_backward on the first version's GEMM kernels
+ *     (operands straight from L2, the first layer's post-ReLU activations stored) instead of the second version's (weights
+ *     resident in LDS, BatchNorm sums in the GEMM epilogue, BatchNorm + ReLU fused into the operand load). Same results to
+ *     float32 summation order; 26 ms against 17 ms per 64-cell step (22 against 13 with train_bf16 = 1). Kept for A/B runs.
  * "search_pair"       (default 1): mode 0 only — 1 = the paired scan (two waves per SIMD), 0 = one wave per SIMD.
  * "search_xcd_qgroups" (default 4; 1, 2, 4, 8): paired scan — the workgroups of one XCD form a rectangle of (query blocks) x
  *     (splits): with g groups an XCD's L2 pulls 1/g of the query batch in the prologue and g/8 of the f16 plane over the main
