@@ -566,6 +566,15 @@ static void rows2_launch_t(const train::Rows2Args& a, int grid, size_t lds, hipS
 }
 template <int MODE, bool AF, bool ST>
 static void rows2_launch_tp(const train::Rows2Args& a, int grid, size_t lds, hipStream_t s) {
+  if constexpr (MODE == 1) {  // bf16 operands: half the LDS bytes per tile and no low parts in registers — up to 8 tiles per pass
+    switch (a.tp) {
+      case 5: rows2_launch_t<MODE, AF, ST, 5>(a, grid, lds, s); return;
+      case 6: rows2_launch_t<MODE, AF, ST, 6>(a, grid, lds, s); return;
+      case 7: rows2_launch_t<MODE, AF, ST, 7>(a, grid, lds, s); return;
+      case 8: rows2_launch_t<MODE, AF, ST, 8>(a, grid, lds, s); return;
+      default: break;
+    }
+  }
   switch (a.tp) {
     case 1: rows2_launch_t<MODE, AF, ST, 1>(a, grid, lds, s); break;
     case 2: rows2_launch_t<MODE, AF, ST, 2>(a, grid, lds, s); break;
@@ -585,7 +594,9 @@ static void rows2_launch_m(const train::Rows2Args& a, int grid, size_t lds, hipS
 static void gemm_rows2(const float* A, const float* W, const float* bias, float* C, size_t M, int N, int K, const float* a_mean,
                        const float* a_rg, const float* a_beta, const int32_t* row_cell, double* acc, hipStream_t s) {
   const int mode = tl_gemm_bf16, bpe = mode == 1 ? 2 : 4;
-  int tp = std::max(1, std::min(std::min(train::kRows2MaxT, N / 32), train::kRows2Lds / (32 * K * bpe)));
+  // (bf16: the fused operand transform's tables spill from 7 tiles on)
+  const int maxt = mode == 1 ? (a_mean ? 6 : 8) : train::kRows2MaxT;
+  int tp = std::max(1, std::min(std::min(maxt, N / 32), train::kRows2Lds / (32 * K * bpe)));
   tp = (N / 32 + (N / 32 + tp - 1) / tp - 1) / ((N / 32 + tp - 1) / tp);  // the same number of passes, balanced
   const size_t lds = (size_t)tp * 32 * K * bpe;
   const int grid = (int)std::min<size_t>((size_t)pn_cu_count(), (M + 255) / 256);
