@@ -68,24 +68,48 @@ __device__ __forceinline__ void grad_rowblock(const float* __restrict__ G, int l
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xr[32 * t] * scale, acc[t], 0, 0, 0);
   }
-  // lane holds column 32*t + col, rows i0 + (r&3) + 8*(r>>2) + 4*half
+  // lane holds column 32*t + col, rows i0 + (r&3) + 8*(r>>2) + 4*half.
+  // The y rows of the NEXT four accumulator rows are loaded before the current four are stored (double-buffered registers, full
+  // blocks store without a branch): written row by row — 8 loads, a reduction, 8 guarded stores — every row's loads queued behind
+  // the previous row's stores (s_waitcnt vmcnt(7) x 8 per row: 16 store-drain + load round trips, ~20 of the kernel's 44 us).
+  const bool full = i0 + 32 <= B;
+  float yb[2][4][8], ib[2][4];
+  auto load_rows = [&](int b4, float (&yy)[4][8], float (&ii)[4]) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    const bool ok = row < B;
-    const float inv = ok ? iy[row] : 0.f;
-    const float* yr = y + (size_t)(ok ? row : 0) * kD + col;
-    float yv[8];
-    float part = 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const int r = 4 * b4 + q;
+      const int row = min(i0 + (r & 3) + 8 * (r >> 2) + 4 * half, B - 1);
+      ii[q] = iy[row];
+      const float* yr = y + (size_t)row * kD + col;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      yv[t] = yr[32 * t] * inv;
-      part += acc[t][r] * yv[t];
+      for (int t = 0; t < 8; ++t) yy[q][t] = yr[32 * t];
     }
-    const float dot = half_sum(part);
-    if (ok) {
+  };
+  load_rows(0, yb[0], ib[0]);
 #pragma unroll
-      for (int t = 0; t < 8; ++t) out[(size_t)row * kD + 32 * t + col] = (acc[t][r] - yv[t] * dot) * inv;
+  for (int b4 = 0; b4 < 4; ++b4) {
+    if (b4 + 1 < 4) load_rows(b4 + 1, yb[(b4 + 1) & 1], ib[(b4 + 1) & 1]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = 4 * b4 + q;
+      const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float inv = row < B ? ib[b4 & 1][q] : 0.f;
+      float yv[8];
+      float part = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        yv[t] = yb[b4 & 1][q][t] * inv;
+        part += acc[t][r] * yv[t];
+      }
+      const float dot = half_sum(part);
+      float* orow = out + (size_t)min(row, B - 1) * kD + col;
+      if (full) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) orow[32 * t] = (acc[t][r] - yv[t] * dot) * inv;
+      } else if (row < B) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) orow[32 * t] = (acc[t][r] - yv[t] * dot) * inv;
+      }
     }
   }
 }
