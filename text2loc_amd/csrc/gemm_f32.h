@@ -216,6 +216,34 @@ static __global__ __launch_bounds__(256) void gemm_pair_kernel(GemmPair p) {
   }
 }
 
+// The same products for up to three independent jobs of identical shape in ONE launch (the feature branches of the training step):
+// blockIdx.z = job for the plain product (its own z is 1), blockIdx.y = job for the dW + dX pair (whose blocks are flattened in x).
+struct GemmMulti {
+  GemmArgs j[3];
+};
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_multi_kernel(GemmMulti m) {
+  __shared__ float red[4 * 16 * 64];
+  __shared__ float cred[4 * 64];
+  gemm_body<A_KC, B_KC>(m.j[blockIdx.z], blockIdx.x, blockIdx.y, 0, red, cred);
+}
+struct GemmPairMulti {
+  GemmPair p[3];
+};
+static __global__ __launch_bounds__(256) void gemm_pair_multi_kernel(GemmPairMulti m) {
+  __shared__ float red[4 * 16 * 64];
+  __shared__ float cred[4 * 64];
+  const GemmPair& p = m.p[blockIdx.y];
+  const int b = blockIdx.x;
+  if (b < p.tn_blocks) {
+    const int bx = b % p.tn_gx, by = (b / p.tn_gx) % p.tn_gy, bz = b / (p.tn_gx * p.tn_gy);
+    gemm_body<false, false>(p.tn, bx, by, bz, red, cred);
+  } else {
+    const int c = b - p.tn_blocks;
+    gemm_body<true, false>(p.nn, c % p.nn_gx, c / p.nn_gx, 0, red, cred);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Row-streaming GEMM for TALL problems (M = 10^5 .. 10^7 rows, N and K <= 1024: the edge MLPs of PointNet++ in training
 // mode): C[M,N] = A[M,K] B (+ bias[n]), A row-major (k contiguous), B_KC: B(k,n) = B[n*ldb + k] (Y = X W^T) else

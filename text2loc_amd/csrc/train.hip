@@ -325,6 +325,118 @@ static MlpLayer make_layer(TrainState* st, const std::string& prefix, int cin, i
   return L;
 }
 
+// ---- the small feature branches (position, point count, colour: [K -> 64 -> 256] + normalize, identical shapes) stage by stage,
+// every stage ONE launch over all of them (kMaxJobs = 3): 7 launches instead of 7 per branch, forward and backward
+static BnJob bn_job(TrainState* st, const MlpLayer& L, float* d) {
+  BnJob j{};
+  j.y = L.y;
+  j.out = L.a;
+  j.d = d;
+  j.acc = st->bn_acc + (size_t)(st->bn_slot++ % kBnSlots) * 2048;
+  j.gamma = T_(st, L.prefix + ".1.weight").data;
+  j.beta = T_(st, L.prefix + ".1.bias").data;
+  j.run_mean = T_(st, L.prefix + ".1.running_mean").data;
+  j.run_var = T_(st, L.prefix + ".1.running_var").data;
+  j.save_mean = L.mean;
+  j.save_rstd = L.rstd;
+  j.dgamma = T_(st, L.prefix + ".1.weight").grad;
+  j.dbeta = T_(st, L.prefix + ".1.bias").grad;
+  return j;
+}
+static void small_branches_fwd(TrainState* st, const std::vector<int>& which, int M, int Kc, hipStream_t s) {
+  const int n = (int)which.size();
+  SmallkMulti sk{};
+  sk.M = M;
+  sk.mean = 1826.6844940968194f;
+  sk.stdv = 2516.8905096993817f;
+  BnMulti b0{}, b1{};
+  b0.M = b1.M = M;
+  b0.C = 64;
+  b1.C = kTD;
+  b0.momentum = b1.momentum = 0.1f;
+  GemmMulti gm{};
+  RownormMulti rn{};
+  rn.M = M;
+  rn.ld = Kc;
+  for (int q = 0; q < n; ++q) {
+    Branch& br = st->branches[which[q]];
+    const MlpLayer &L0 = br.layers[0], &L1 = br.layers[1];
+    sk.j[q].x = br.x;
+    sk.j[q].K = br.k_in;
+    sk.j[q].standardize = br.standardize;
+    sk.j[q].w = T_(st, L0.prefix + ".0.weight").data;
+    sk.j[q].b = T_(st, L0.prefix + ".0.bias").data;
+    sk.j[q].y = L0.y;
+    b0.j[q] = bn_job(st, L0, nullptr);
+    gm.j[q] = GemmArgs{L0.a, T_(st, L1.prefix + ".0.weight").data, L1.y, T_(st, L1.prefix + ".0.bias").data, M, kTD, 64, 64, 64, kTD, 0, 0, 64,
+                       nullptr, tl_gemm_bf16};
+    b1.j[q] = bn_job(st, L1, nullptr);
+    rn.j[q] = RownormJob{L1.a, nullptr, st->cat + br.slot * kTD, nullptr, br.save_n};
+  }
+  hipLaunchKernelGGL(smallk_fwd_multi_kernel, dim3((M * 64 + 255) / 256, n), dim3(256), 0, s, sk);
+  hipLaunchKernelGGL((bn_stats_multi_kernel<0>), dim3(1, (M + kBnRows - 1) / kBnRows, n), dim3(256), 0, s, b0);
+  hipLaunchKernelGGL(bn_apply_fwd_multi_kernel, dim3((unsigned)(((size_t)M * 64 + 255) / 256), n), dim3(256), 0, s, b0);
+  hipLaunchKernelGGL((gemm_multi_kernel<true, true>), dim3(kTD / 32, (M + 31) / 32, n), dim3(256), 0, s, gm);
+  hipLaunchKernelGGL((bn_stats_multi_kernel<0>), dim3(kTD / 64, (M + kBnRows - 1) / kBnRows, n), dim3(256), 0, s, b1);
+  hipLaunchKernelGGL(bn_apply_fwd_multi_kernel, dim3((unsigned)(((size_t)M * kTD + 255) / 256), n), dim3(256), 0, s, b1);
+  hipLaunchKernelGGL(rownorm_fwd_multi_kernel, dim3((M + 3) / 4, n), dim3(256), 0, s, rn);
+}
+// d2 / d1: [n][M][256] / [n][M][64] scratch (every branch needs its own now)
+static void small_branches_bwd(TrainState* st, const std::vector<int>& which, int M, int Kc, const float* dcat, float* d2, float* d1,
+                               hipStream_t s) {
+  const int n = (int)which.size();
+  RownormMulti rn{};
+  rn.M = M;
+  rn.ld = Kc;
+  BnMulti b1{}, b0{};
+  b0.M = b1.M = M;
+  b0.C = 64;
+  b1.C = kTD;
+  GemmPairMulti gp{};
+  SmallkMulti sk{};
+  sk.M = M;
+  sk.mean = 1826.6844940968194f;
+  sk.stdv = 2516.8905096993817f;
+  sk.rows_per_block = 32;
+  const int N = kTD, Kp = 64;
+  const int tiles = (N / 32) * (Kp / 32);
+  int ksplit = std::max(1, std::min((M + 255) / 256, (1024 + tiles - 1) / tiles));
+  const int kchunk = (((M + ksplit - 1) / ksplit) + 63) & ~63;
+  ksplit = (M + kchunk - 1) / kchunk;
+  int pair_blocks = 0;
+  for (int q = 0; q < n; ++q) {
+    const Branch& br = st->branches[which[q]];
+    const MlpLayer &L0 = br.layers[0], &L1 = br.layers[1];
+    float* dq2 = d2 + (size_t)q * M * kTD;
+    float* dq1 = d1 + (size_t)q * M * 64;
+    rn.j[q] = RownormJob{dcat + br.slot * kTD, nullptr, dq2, st->cat + br.slot * kTD, br.save_n};
+    b1.j[q] = bn_job(st, L1, dq2);
+    GemmPair& p = gp.p[q];
+    p.tn = GemmArgs{dq2, L0.a, T_(st, L1.prefix + ".0.weight").grad, nullptr, N, Kp, M, N, Kp, Kp, 0, 1, kchunk,
+                    T_(st, L1.prefix + ".0.bias").grad, tl_gemm_bf16};
+    p.nn = GemmArgs{dq2, T_(st, L1.prefix + ".0.weight").data, dq1, nullptr, M, Kp, N, N, Kp, Kp, 0, 0, N, nullptr, tl_gemm_bf16};
+    p.tn_gx = Kp / 32;
+    p.tn_gy = N / 32;
+    p.tn_blocks = p.tn_gx * p.tn_gy * ksplit;
+    p.nn_gx = Kp / 32;
+    pair_blocks = p.tn_blocks + p.nn_gx * ((M + 31) / 32);
+    b0.j[q] = bn_job(st, L0, dq1);
+    sk.j[q].x = br.x;
+    sk.j[q].K = br.k_in;
+    sk.j[q].standardize = br.standardize;
+    sk.j[q].dy = dq1;
+    sk.j[q].dW = T_(st, L0.prefix + ".0.weight").grad;
+    sk.j[q].db = T_(st, L0.prefix + ".0.bias").grad;
+  }
+  hipLaunchKernelGGL(rownorm_bwd_multi_kernel, dim3((M + 3) / 4, n), dim3(256), 0, s, rn);
+  hipLaunchKernelGGL((bn_stats_multi_kernel<1>), dim3(kTD / 64, (M + kBnRows - 1) / kBnRows, n), dim3(256), 0, s, b1);
+  hipLaunchKernelGGL(bn_apply_bwd_multi_kernel, dim3((unsigned)(((size_t)M * kTD + 255) / 256), n), dim3(256), 0, s, b1);
+  hipLaunchKernelGGL(gemm_pair_multi_kernel, dim3(pair_blocks, n), dim3(256), 0, s, gp);
+  hipLaunchKernelGGL((bn_stats_multi_kernel<1>), dim3(1, (M + kBnRows - 1) / kBnRows, n), dim3(256), 0, s, b0);
+  hipLaunchKernelGGL(bn_apply_bwd_multi_kernel, dim3((unsigned)(((size_t)M * 64 + 255) / 256), n), dim3(256), 0, s, b0);
+  hipLaunchKernelGGL(smallk_bwd_multi_kernel, dim3((M + 31) / 32, n), dim3(256), 0, s, sk);
+}
+
 int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32_t seed, float* out_emb, hipStream_t s) {
   TrainState* st = state(ctx);
   if (!st) return fail(ctx, T2L_ESTATE, "t2l_encode_cells_train: call t2l_train_bind first");
@@ -339,7 +451,7 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
   if ((uint64_t)T * 2 * kTD >= (1ull << 32)) return fail(ctx, T2L_EINVAL, "t2l_encode_cells_train: batch too large for the dropout counters");
   // workspace: generous closed-form bound, grown on demand
   const size_t need_bytes =
-      sizeof(float) * ((size_t)M * (2 * Kc + 26 * kTD) + (size_t)T * kTD * 18 +
+      sizeof(float) * ((size_t)M * (2 * Kc + 30 * kTD) + (size_t)T * kTD * 18 +
                        (size_t)c.num_layers * ((size_t)T * (13 * kTD + 8) + (size_t)B * kTH * kTS * kTS) + (size_t)B * kTD * 4) +
       (1 << 20);
   if (need_bytes > st->ws_cap) {
@@ -365,16 +477,14 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
   st->cat = bump<float>(st, (size_t)M * Kc);
   const std::string oe = "object_encoder.";
   int slot = 0;
+  std::vector<int> smalls;  // indices of the small branches: launched together below, one launch per stage
   auto small_branch = [&](const std::string& name, const float* x, int k, int standardize) {
     Branch br;
     br.kind = 1; br.slot = slot++; br.x = x; br.k_in = k; br.standardize = standardize;
     br.layers.push_back(make_layer(st, oe + name + ".0", k, 64, M));
     br.layers.push_back(make_layer(st, oe + name + ".1", 64, kTD, M));
     br.save_n = bump<float>(st, M);
-    mlp_layer_fwd(st, br.layers[0], x, M, k, standardize, s);
-    mlp_layer_fwd(st, br.layers[1], br.layers[0].a, M, 0, 0, s);
-    hipLaunchKernelGGL(rownorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, br.layers[1].a, (const int32_t*)nullptr, M,
-                       st->cat + br.slot * kTD, Kc, br.save_n);
+    smalls.push_back((int)st->branches.size());
     st->branches.push_back(br);
   };
   auto embed_branch = [&](const std::string& table, const int32_t* idx) {
@@ -405,6 +515,7 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
   }
   if (c.use_position) small_branch("pos_encoder", in->center, 3, 0);
   if (c.use_num) small_branch("num_encoder", in->n_pts, 1, 1);
+  if (!smalls.empty()) small_branches_fwd(st, smalls, M, Kc, s);
 
   st->merge = make_layer(st, oe + "mlp_merge.0", Kc, kTD, M);
   mlp_layer_fwd(st, st->merge, st->cat, M, 0, 0, s);
@@ -507,8 +618,8 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   float* dqkv = bump<float>(st, (size_t)T * 3 * kTD);
   float* dfeat = bump<float>(st, (size_t)M * kTD);
   float* dcat = bump<float>(st, (size_t)M * Kc);
-  float* d2 = bump<float>(st, (size_t)M * kTD);  // scratch of the feature branches (one after the other on the stream)
-  float* d1 = bump<float>(st, (size_t)M * 64);
+  float* d2 = bump<float>(st, (size_t)kMaxJobs * M * kTD);  // scratch of the feature branches: one region per small branch (they run
+  float* d1 = bump<float>(st, (size_t)kMaxJobs * M * 64);   // together, stage by stage); the others use region 0 one after the other
   if (st->ws_off > st->ws_cap) {
     st->ws_off = mark;
     return fail(ctx, T2L_ENOMEM, "t2l_encode_cells_backward: workspace bound exceeded (internal error)");
@@ -546,6 +657,7 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   hipLaunchKernelGGL(scatter_norm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dcur, st->X0, st->save_nf, st->offsets, B, M, dfeat);
   mlp_layer_bwd(st, st->merge, dfeat, st->cat, M, 0, 0, dcat, s);
   for (const Branch& br : st->branches) {
+    if (br.kind == 1) continue;  // the small branches follow, all of them together
     const float* dslot = dcat + br.slot * kTD;
     const float* yslot = st->cat + br.slot * kTD;
     hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dslot, yslot, Kc, br.save_n, M, d2);
@@ -554,12 +666,13 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
       if (rows > 1) hipLaunchKernelGGL(embed_sum_kernel, dim3(rows - 1, kEmbSplit), dim3(256), 0, s, d2, br.idx, M, T_(st, br.table).grad);
       continue;
     }
-    if (br.kind == 2) {
-      mlp_layer_bwd(st, br.layers[0], d2, br.x, M, 0, 0, grad_pn_feat, s);
-    } else {
-      mlp_layer_bwd(st, br.layers[1], d2, br.layers[0].a, M, 0, 0, d1, s);
-      mlp_layer_bwd(st, br.layers[0], d1, br.x, M, br.k_in, br.standardize, nullptr, s);
-    }
+    if (br.kind == 2) mlp_layer_bwd(st, br.layers[0], d2, br.x, M, 0, 0, grad_pn_feat, s);
+  }
+  {
+    std::vector<int> smalls;
+    for (size_t i = 0; i < st->branches.size(); ++i)
+      if (st->branches[i].kind == 1) smalls.push_back((int)i);
+    if (!smalls.empty()) small_branches_bwd(st, smalls, M, Kc, dcat, d2, d1, s);
   }
   event_end(ctx, "train_backward", s);
   st->ws_off = mark;

@@ -64,24 +64,49 @@ __device__ __forceinline__ float small_in(const float* x, int m, int K, int k, i
   float v = x[(size_t)m * K + k];
   return standardize ? (v - mean) / stdv : v;
 }
-__global__ void smallk_fwd_kernel(const float* __restrict__ x, int M, int K, const float* __restrict__ w,
-                                  const float* __restrict__ b, int standardize, float mean, float stdv,
-                                  float* __restrict__ y) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// (every kernel of the feature branches exists as a body + a plain launch + a MULTI launch: the two or three small branches —
+//  position, point count, colour — are independent chains of identical shape, so each stage of all of them is ONE launch with the
+//  branch in an extra grid dimension: a dependent launch costs ~5 us whatever it does, and the branches ran one after the other)
+constexpr int kMaxJobs = 3;
+__device__ __forceinline__ void smallk_fwd_body(const float* __restrict__ x, int M, int K, const float* __restrict__ w,
+                                                const float* __restrict__ b, int standardize, float mean, float stdv,
+                                                float* __restrict__ y, unsigned bx) {
+  const int i = bx * blockDim.x + threadIdx.x;
   if (i >= M * 64) return;
   const int m = i >> 6, c = i & 63;
   float s = b[c];
   for (int k = 0; k < K; ++k) s += small_in(x, m, K, k, standardize, mean, stdv) * w[c * K + k];
   y[i] = s;
 }
+__global__ void smallk_fwd_kernel(const float* __restrict__ x, int M, int K, const float* __restrict__ w,
+                                  const float* __restrict__ b, int standardize, float mean, float stdv,
+                                  float* __restrict__ y) {
+  smallk_fwd_body(x, M, K, w, b, standardize, mean, stdv, y, blockIdx.x);
+}
+struct SmallkJob {
+  const float* x;
+  int K, standardize;
+  const float *w, *b;   // forward
+  float* y;             // forward
+  const float* dy;      // backward
+  float *dW, *db;       // backward
+};
+struct SmallkMulti {
+  SmallkJob j[kMaxJobs];
+  int M, rows_per_block;
+  float mean, stdv;
+};
+__global__ void smallk_fwd_multi_kernel(SmallkMulti m) {
+  const SmallkJob& j = m.j[blockIdx.y];
+  smallk_fwd_body(j.x, m.M, j.K, j.w, j.b, j.standardize, m.mean, m.stdv, j.y, blockIdx.x);
+}
 // dW[c][k] += sum_m dy[m][c] x[m][k]   grid = row chunks, 256 threads = 64 channels x 4 row lanes
-__global__ __launch_bounds__(256) void smallk_bwd_kernel(const float* __restrict__ x, int M, int K,
-                                                         const float* __restrict__ dy, int standardize, float mean,
-                                                         float stdv, int rows_per_block, float* __restrict__ dW,
-                                                         float* __restrict__ db) {
+__device__ __forceinline__ void smallk_bwd_body(const float* __restrict__ x, int M, int K, const float* __restrict__ dy, int standardize,
+                                                float mean, float stdv, int rows_per_block, float* __restrict__ dW,
+                                                float* __restrict__ db, unsigned bx) {
   __shared__ float red[4][256];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int lo = blockIdx.x * rows_per_block, hi = min(M, lo + rows_per_block);
+  const int lo = bx * rows_per_block, hi = min(M, lo + rows_per_block);
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   for (int m = lo + g; m < hi; m += 4) {
     const float d = dy[(size_t)m * 64 + c];
@@ -96,6 +121,16 @@ __global__ __launch_bounds__(256) void smallk_bwd_kernel(const float* __restrict
     unsafeAtomicAdd(db + c, red[3][c] + red[3][c + 64] + red[3][c + 128] + red[3][c + 192]);
   }
 }
+__global__ __launch_bounds__(256) void smallk_bwd_kernel(const float* __restrict__ x, int M, int K,
+                                                         const float* __restrict__ dy, int standardize, float mean,
+                                                         float stdv, int rows_per_block, float* __restrict__ dW,
+                                                         float* __restrict__ db) {
+  smallk_bwd_body(x, M, K, dy, standardize, mean, stdv, rows_per_block, dW, db, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void smallk_bwd_multi_kernel(SmallkMulti m) {
+  const SmallkJob& j = m.j[blockIdx.y];
+  smallk_bwd_body(j.x, m.M, j.K, j.dy, j.standardize, m.mean, m.stdv, m.rows_per_block, j.dW, j.db, blockIdx.x);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // BatchNorm1d in training mode (+ ReLU). Two stages so that the whole chip takes part although there are only 64-1024
@@ -106,13 +141,12 @@ __global__ __launch_bounds__(256) void smallk_bwd_kernel(const float* __restrict
 constexpr int kBnRows = 64;
 // MODE 0: acc[c] += sum y, acc[C+c] += sum y^2.  MODE 1: dv = out>0 ? d : 0; acc[c] += sum dv, acc[C+c] += sum dv*xhat
 template <int MODE>
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, const float* __restrict__ d,
-                                                       const float* __restrict__ out, int M, int C,
-                                                       const float* __restrict__ save_mean,
-                                                       const float* __restrict__ save_rstd, double* __restrict__ acc) {
+__device__ __forceinline__ void bn_stats_body(const float* __restrict__ y, const float* __restrict__ d, const float* __restrict__ out, int M,
+                                              int C, const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                              double* __restrict__ acc, unsigned bx, unsigned by) {
   __shared__ float r1[256], r2[256];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-  const int lo = blockIdx.y * kBnRows, hi = min(M, lo + kBnRows);
+  const int c = bx * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  const int lo = by * kBnRows, hi = min(M, lo + kBnRows);
   float mean = 0.f, rstd = 0.f;
   if (MODE == 1) {
     mean = save_mean[c];
@@ -140,13 +174,38 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     atomicAdd(acc + C + c, (double)r2[t] + (double)r2[t + 64] + (double)r2[t + 128] + (double)r2[t + 192]);
   }
 }
-__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ y, int M, int C,
-                                                           const double* __restrict__ acc,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                           float momentum, float* __restrict__ out,
-                                                           float* __restrict__ save_mean, float* __restrict__ save_rstd) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, const float* __restrict__ d,
+                                                       const float* __restrict__ out, int M, int C,
+                                                       const float* __restrict__ save_mean,
+                                                       const float* __restrict__ save_rstd, double* __restrict__ acc) {
+  bn_stats_body<MODE>(y, d, out, M, C, save_mean, save_rstd, acc, blockIdx.x, blockIdx.y);
+}
+// one BatchNorm layer of one branch: everything the statistics / apply kernels of either direction need
+struct BnJob {
+  const float* y;       // pre-BatchNorm Linear output
+  float* out;           // forward: post-ReLU output (written); backward: the same (read: ReLU mask)
+  float* d;             // backward: gradient w.r.t. out, overwritten with the gradient w.r.t. y
+  double* acc;
+  const float *gamma, *beta;
+  float *run_mean, *run_var, *save_mean, *save_rstd, *dgamma, *dbeta;
+};
+struct BnMulti {
+  BnJob j[kMaxJobs];
+  int M, C;
+  float momentum;
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_stats_multi_kernel(BnMulti m) {
+  const BnJob& j = m.j[blockIdx.z];
+  bn_stats_body<MODE>(j.y, j.d, j.out, m.M, m.C, j.save_mean, j.save_rstd, j.acc, blockIdx.x, blockIdx.y);
+}
+__device__ __forceinline__ void bn_apply_fwd_body(const float* __restrict__ y, int M, int C, const double* __restrict__ acc,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  float* __restrict__ run_mean, float* __restrict__ run_var, float momentum,
+                                                  float* __restrict__ out, float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                  unsigned bx) {
+  const size_t i = (size_t)bx * 256 + threadIdx.x;
   if (i < (size_t)M * C) {
     const int c = (int)(i % C);
     const double mean = acc[c] / M;
@@ -154,7 +213,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
     const float rstd = 1.0f / sqrtf((float)var + kBnEps);
     out[i] = fmaxf((y[i] - (float)mean) * rstd * gamma[c] + beta[c], 0.f);
   }
-  if (blockIdx.x == 0)
+  if (bx == 0)
     for (int c = threadIdx.x; c < C; c += 256) {
       const double mean = acc[c] / M;
       const double var = fmax(acc[C + c] / M - mean * mean, 0.0);
@@ -164,25 +223,47 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
       run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * ((double)M / (double)max(M - 1, 1)));
     }
 }
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ y, int M, int C,
+                                                           const double* __restrict__ acc,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                           float momentum, float* __restrict__ out,
+                                                           float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+  bn_apply_fwd_body(y, M, C, acc, gamma, beta, run_mean, run_var, momentum, out, save_mean, save_rstd, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void bn_apply_fwd_multi_kernel(BnMulti m) {
+  const BnJob& j = m.j[blockIdx.y];
+  bn_apply_fwd_body(j.y, m.M, m.C, j.acc, j.gamma, j.beta, j.run_mean, j.run_var, m.momentum, j.out, j.save_mean, j.save_rstd, blockIdx.x);
+}
 // d: gradient w.r.t. the ReLU output (in), overwritten with the gradient w.r.t. the Linear output y.
-__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(float* __restrict__ d, const float* __restrict__ out,
-                                                           const float* __restrict__ y, int M, int C,
-                                                           const double* __restrict__ acc, const float* __restrict__ gamma,
-                                                           const float* __restrict__ save_mean,
-                                                           const float* __restrict__ save_rstd, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void bn_apply_bwd_body(float* __restrict__ d, const float* __restrict__ out, const float* __restrict__ y, int M,
+                                                  int C, const double* __restrict__ acc, const float* __restrict__ gamma,
+                                                  const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, unsigned bx) {
+  const size_t i = (size_t)bx * 256 + threadIdx.x;
   if (i < (size_t)M * C) {
     const int c = (int)(i % C);
     const float rstd = save_rstd[c], s1 = (float)acc[c], s2 = (float)acc[C + c];
     const float dv = out[i] > 0.f ? d[i] : 0.f;
     d[i] = gamma[c] * rstd / (float)M * ((float)M * dv - s1 - (y[i] - save_mean[c]) * rstd * s2);
   }
-  if (blockIdx.x == 0)
+  if (bx == 0)
     for (int c = threadIdx.x; c < C; c += 256) {
       unsafeAtomicAdd(dgamma + c, (float)acc[C + c]);
       unsafeAtomicAdd(dbeta + c, (float)acc[c]);
     }
+}
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(float* __restrict__ d, const float* __restrict__ out,
+                                                           const float* __restrict__ y, int M, int C,
+                                                           const double* __restrict__ acc, const float* __restrict__ gamma,
+                                                           const float* __restrict__ save_mean,
+                                                           const float* __restrict__ save_rstd, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
+  bn_apply_bwd_body(d, out, y, M, C, acc, gamma, save_mean, save_rstd, dgamma, dbeta, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void bn_apply_bwd_multi_kernel(BnMulti m) {
+  const BnJob& j = m.j[blockIdx.y];
+  bn_apply_bwd_body(j.d, j.out, j.y, m.M, m.C, j.acc, j.gamma, j.save_mean, j.save_rstd, j.dgamma, j.dbeta, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -198,9 +279,9 @@ __device__ __forceinline__ float4 norm_bwd(float4 dy, float4 y, float n) {
   return make_float4((dy.x - y.x * t) / n, (dy.y - y.y * t) / n, (dy.z - y.z * t) / n, (dy.w - y.w * t) / n);
 }
 // src row = table[idx[m]] when idx != nullptr (embedding lookup) else src[m]; dst row stride ldd (a 256-wide slot of cat)
-__global__ void rownorm_fwd_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int M,
-                                   float* __restrict__ dst, int ldd, float* __restrict__ save_n) {
-  const int m = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+__device__ __forceinline__ void rownorm_fwd_body(const float* __restrict__ src, const int32_t* __restrict__ idx, int M, float* __restrict__ dst,
+                                                 int ldd, float* __restrict__ save_n, unsigned bx) {
+  const int m = (bx * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (m >= M) return;
   const size_t row = idx ? (size_t)idx[m] : (size_t)m;
   const float4 v = *reinterpret_cast<const float4*>(src + row * kTD + lane * 4);
@@ -209,14 +290,41 @@ __global__ void rownorm_fwd_kernel(const float* __restrict__ src, const int32_t*
   *reinterpret_cast<float4*>(dst + (size_t)m * ldd + lane * 4) = y;
   if (lane == 0) save_n[m] = n;
 }
+__global__ void rownorm_fwd_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int M,
+                                   float* __restrict__ dst, int ldd, float* __restrict__ save_n) {
+  rownorm_fwd_body(src, idx, M, dst, ldd, save_n, blockIdx.x);
+}
+struct RownormJob {
+  const float* src;      // forward: rows to normalise (or the embedding table); backward: dy (a slot of dcat)
+  const int32_t* idx;    // forward: embedding lookup or nullptr
+  float* dst;            // forward: slot of cat; backward: dx [M][256]
+  const float* y;        // backward: the normalised rows (slot of cat)
+  float* save_n;
+};
+struct RownormMulti {
+  RownormJob j[kMaxJobs];
+  int M, ld;
+};
+__global__ void rownorm_fwd_multi_kernel(RownormMulti m) {
+  const RownormJob& j = m.j[blockIdx.y];
+  rownorm_fwd_body(j.src, j.idx, m.M, j.dst, m.ld, j.save_n, blockIdx.x);
+}
 // dx[m] = normalize_bwd(dy[m], y[m], n[m])
-__global__ void rownorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int ld,
-                                   const float* __restrict__ save_n, int M, float* __restrict__ dx) {
-  const int m = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+__device__ __forceinline__ void rownorm_bwd_body(const float* __restrict__ dy, const float* __restrict__ y, int ld,
+                                                 const float* __restrict__ save_n, int M, float* __restrict__ dx, unsigned bx) {
+  const int m = (bx * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (m >= M) return;
   const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)m * ld + lane * 4);
   const float4 yy = *reinterpret_cast<const float4*>(y + (size_t)m * ld + lane * 4);
   *reinterpret_cast<float4*>(dx + (size_t)m * kTD + lane * 4) = norm_bwd(d, yy, save_n[m]);
+}
+__global__ void rownorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int ld,
+                                   const float* __restrict__ save_n, int M, float* __restrict__ dx) {
+  rownorm_bwd_body(dy, y, ld, save_n, M, dx, blockIdx.x);
+}
+__global__ void rownorm_bwd_multi_kernel(RownormMulti m) {
+  const RownormJob& j = m.j[blockIdx.y];
+  rownorm_bwd_body(j.src, j.y, m.ld, j.save_n, m.M, j.dst, blockIdx.x);
 }
 // Embedding-table gradient, stage 2 (stage 1 = rownorm_bwd_kernel writing g[M,256] = normalize_bwd per object):
 // dtable[r] += sum over the objects with idx == r of g[m]. grid (table rows - 1, kEmbSplit): row 0 = padding_idx never
