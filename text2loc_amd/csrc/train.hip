@@ -487,12 +487,12 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
     smalls.push_back((int)st->branches.size());
     st->branches.push_back(br);
   };
+  std::vector<int> embeds;  // the embedding lookups: one launch for both tables
   auto embed_branch = [&](const std::string& table, const int32_t* idx) {
     Branch br;
     br.kind = 0; br.slot = slot++; br.table = oe + table; br.idx = idx;
     br.save_n = bump<float>(st, M);
-    hipLaunchKernelGGL(rownorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, T_(st, br.table).data, idx, M, st->cat + br.slot * kTD, Kc,
-                       br.save_n);
+    embeds.push_back((int)st->branches.size());
     st->branches.push_back(br);
   };
   if (c.use_class) {
@@ -515,6 +515,16 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
   }
   if (c.use_position) small_branch("pos_encoder", in->center, 3, 0);
   if (c.use_num) small_branch("num_encoder", in->n_pts, 1, 1);
+  if (!embeds.empty()) {
+    RownormMulti rn{};
+    rn.M = M;
+    rn.ld = Kc;
+    for (size_t q = 0; q < embeds.size(); ++q) {
+      const Branch& br = st->branches[embeds[q]];
+      rn.j[q] = RownormJob{T_(st, br.table).data, br.idx, st->cat + br.slot * kTD, nullptr, br.save_n};
+    }
+    hipLaunchKernelGGL(rownorm_fwd_multi_kernel, dim3((M + 3) / 4, (unsigned)embeds.size()), dim3(256), 0, s, rn);
+  }
   if (!smalls.empty()) small_branches_fwd(st, smalls, M, Kc, s);
 
   st->merge = make_layer(st, oe + "mlp_merge.0", Kc, kTD, M);
@@ -656,17 +666,34 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   // tokens -> objects, merge MLP
   hipLaunchKernelGGL(scatter_norm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dcur, st->X0, st->save_nf, st->offsets, B, M, dfeat);
   mlp_layer_bwd(st, st->merge, dfeat, st->cat, M, 0, 0, dcat, s);
-  for (const Branch& br : st->branches) {
-    if (br.kind == 1) continue;  // the small branches follow, all of them together
-    const float* dslot = dcat + br.slot * kTD;
-    const float* yslot = st->cat + br.slot * kTD;
-    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dslot, yslot, Kc, br.save_n, M, d2);
-    if (br.kind == 0) {
-      const int rows = (int)(T_(st, br.table).numel / kTD);
-      if (rows > 1) hipLaunchKernelGGL(embed_sum_kernel, dim3(rows - 1, kEmbSplit), dim3(256), 0, s, d2, br.idx, M, T_(st, br.table).grad);
-      continue;
+  {  // embedding tables: normalize-backward of both slots in one launch, then the per-row sums of both tables in one
+    RownormMulti rn{};
+    rn.M = M;
+    rn.ld = Kc;
+    EmbedSumMulti es{};
+    es.M = M;
+    int ne = 0, max_rows = 0;
+    for (const Branch& br : st->branches) {
+      if (br.kind != 0) continue;
+      float* dq = d2 + (size_t)ne * M * kTD;
+      rn.j[ne] = RownormJob{dcat + br.slot * kTD, nullptr, dq, st->cat + br.slot * kTD, br.save_n};
+      es.g[ne] = dq;
+      es.idx[ne] = br.idx;
+      es.dtable[ne] = T_(st, br.table).grad;
+      es.rows[ne] = (int)(T_(st, br.table).numel / kTD);
+      max_rows = std::max(max_rows, es.rows[ne]);
+      ++ne;
     }
-    if (br.kind == 2) mlp_layer_bwd(st, br.layers[0], d2, br.x, M, 0, 0, grad_pn_feat, s);
+    if (ne) {
+      hipLaunchKernelGGL(rownorm_bwd_multi_kernel, dim3((M + 3) / 4, ne), dim3(256), 0, s, rn);
+      if (max_rows > 1) hipLaunchKernelGGL(embed_sum_multi_kernel, dim3(max_rows - 1, kEmbSplit, ne), dim3(256), 0, s, es);
+    }
+  }
+  for (const Branch& br : st->branches) {
+    if (br.kind != 2) continue;  // the PointNet++-feature branch: one [256 -> 256] block
+    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, dcat + br.slot * kTD, st->cat + br.slot * kTD, Kc, br.save_n, M,
+                       d2);
+    mlp_layer_bwd(st, br.layers[0], d2, br.x, M, 0, 0, grad_pn_feat, s);
   }
   {
     std::vector<int> smalls;

@@ -331,18 +331,18 @@ __global__ void rownorm_bwd_multi_kernel(RownormMulti m) {
 // receives gradient (models/object_encoder.py:33,37). Each workgroup lists in LDS the matching objects with
 // m % kEmbSplit == blockIdx.y, its 4 waves add their rows (independent coalesced 1 KiB loads), then 256 float atomics.
 constexpr int kEmbSplit = 8;
-__global__ __launch_bounds__(256) void embed_sum_kernel(const float* __restrict__ g, const int32_t* __restrict__ idx, int M,
-                                                        float* __restrict__ dtable) {
+__device__ __forceinline__ void embed_sum_body(const float* __restrict__ g, const int32_t* __restrict__ idx, int M, float* __restrict__ dtable,
+                                               unsigned bx, unsigned by) {
   __shared__ float4 red[256];
   __shared__ int list[2048];
   __shared__ int cnt;
-  const int r = blockIdx.x + 1, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = bx + 1, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int base = 0; base < M; base += 2048) {
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
     for (int m = base + threadIdx.x; m < min(M, base + 2048); m += 256)
-      if (idx[m] == r && (m % kEmbSplit) == (int)blockIdx.y) list[atomicAdd(&cnt, 1)] = m;  // this workgroup's share
+      if (idx[m] == r && (m % kEmbSplit) == (int)by) list[atomicAdd(&cnt, 1)] = m;  // this workgroup's share
     __syncthreads();
     const int n = cnt;
 #pragma unroll 4
@@ -362,6 +362,22 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(const float* __restrict_
     float* t = dtable + (size_t)r * kTD + lane * 4;
     unsafeAtomicAdd(t + 0, a.x); unsafeAtomicAdd(t + 1, a.y); unsafeAtomicAdd(t + 2, a.z); unsafeAtomicAdd(t + 3, a.w);
   }
+}
+__global__ __launch_bounds__(256) void embed_sum_kernel(const float* __restrict__ g, const int32_t* __restrict__ idx, int M,
+                                                        float* __restrict__ dtable) {
+  embed_sum_body(g, idx, M, dtable, blockIdx.x, blockIdx.y);
+}
+struct EmbedSumMulti {
+  const float* g[kMaxJobs];
+  const int32_t* idx[kMaxJobs];
+  float* dtable[kMaxJobs];
+  int rows[kMaxJobs];  // table rows (row 0 = padding_idx receives nothing); grid.x = max(rows) - 1
+  int M;
+};
+__global__ __launch_bounds__(256) void embed_sum_multi_kernel(EmbedSumMulti m) {
+  const int j = blockIdx.z;
+  if ((int)blockIdx.x + 1 >= m.rows[j]) return;  // (workgroup-uniform: the barriers inside are not reached by anyone)
+  embed_sum_body(m.g[j], m.idx[j], m.M, m.dtable[j], blockIdx.x, blockIdx.y);
 }
 // tokens: X0[b*28+s] = normalize(feats[offsets[b]+s]) for s < min(count,28), zeros otherwise (cell_retrieval.py:85-98)
 __global__ void scatter_norm_fwd_kernel(const float* __restrict__ feats, const int32_t* __restrict__ offsets, int B,
