@@ -54,8 +54,9 @@ struct TrainState {
   AdamChunk* d_chunks = nullptr;
   float* mv = nullptr;       // [2][mv_total]: first moments of all Adam tensors (adam_names order), then second moments
   int64_t mv_total = 0;
-  double* bn_acc = nullptr;  // [kBnSlots][2*1024] float64 partial sums of the BatchNorm stages (one slot per BN pass)
+  double* bn_acc = nullptr;  // [2][kBnSlots][2*1024] float64 partial sums of the BatchNorm stages (one slot per BN pass; forward | backward)
   int bn_slot = 0;
+  bool bwd_acc_clean = false;  // the forward's memset zeroed the backward's slots too (one memset launch per step instead of two)
   int n_chunks = 0;
   int pn_chunk0 = 0;         // chunks [pn_chunk0, n_chunks) belong to the PointNet++ backbone (bound last)
   int64_t step = 0;          // Adam step of the object branch
@@ -265,7 +266,7 @@ int train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const 
   std::vector<AdamChunk> cs;
   int64_t total = 0;
   for (auto& nme : P) total += st->t[nme].numel;
-  T2L_HIP(ctx, hipMalloc(&st->bn_acc, sizeof(double) * 2 * 1024 * kBnSlots));
+  T2L_HIP(ctx, hipMalloc(&st->bn_acc, sizeof(double) * 2 * 1024 * kBnSlots * 2));  // slots of the forward, then of the backward
   T2L_HIP(ctx, hipMalloc(&st->mv, sizeof(float) * 2 * (size_t)total));
   T2L_HIP(ctx, hipMemset(st->mv, 0, sizeof(float) * 2 * (size_t)total));
   st->mv_total = total;
@@ -305,7 +306,7 @@ static void mlp_layer_fwd(TrainState* st, MlpLayer& L, const float* x, int M, in
                        1826.6844940968194f, 2516.8905096993817f, L.y);
   else
     gemm_nt(x, W.data, b.data, L.y, M, L.cout, L.cin, 0, s);
-  double* acc = st->bn_acc + (size_t)(st->bn_slot++ % kBnSlots) * 2048;
+  double* acc = st->bn_acc + (size_t)(st->bn_slot++ % (2 * kBnSlots)) * 2048;
   hipLaunchKernelGGL((bn_stats_kernel<0>), dim3(L.cout / 64, (M + kBnRows - 1) / kBnRows), dim3(256), 0, s, L.y, (const float*)nullptr,
                      (const float*)nullptr, M, L.cout, (const float*)nullptr, (const float*)nullptr, acc);
   hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)(((size_t)M * L.cout + 255) / 256)), dim3(256), 0, s, L.y, M, L.cout, acc,
@@ -332,7 +333,7 @@ static BnJob bn_job(TrainState* st, const MlpLayer& L, float* d) {
   j.y = L.y;
   j.out = L.a;
   j.d = d;
-  j.acc = st->bn_acc + (size_t)(st->bn_slot++ % kBnSlots) * 2048;
+  j.acc = st->bn_acc + (size_t)(st->bn_slot++ % (2 * kBnSlots)) * 2048;
   j.gamma = T_(st, L.prefix + ".1.weight").data;
   j.beta = T_(st, L.prefix + ".1.bias").data;
   j.run_mean = T_(st, L.prefix + ".1.running_mean").data;
@@ -472,7 +473,8 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
   st->layers.clear();
   event_begin(ctx, "train_forward", s);
   st->bn_slot = 0;
-  T2L_HIP(ctx, hipMemsetAsync(st->bn_acc, 0, sizeof(double) * 2048 * kBnSlots, s));
+  T2L_HIP(ctx, hipMemsetAsync(st->bn_acc, 0, sizeof(double) * 2048 * kBnSlots * 2, s));
+  st->bwd_acc_clean = true;
 
   st->cat = bump<float>(st, (size_t)M * Kc);
   const std::string oe = "object_encoder.";
@@ -577,8 +579,7 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
   st->out = bump<float>(st, (size_t)B * kTD);
   st->pool_n = bump<float>(st, B);
   st->pool_arg = bump<int32_t>(st, (size_t)B * kTD);
-  hipLaunchKernelGGL(pool_norm_fwd_kernel, dim3(B), dim3(256), 0, s, x, st->out, st->pool_arg, st->pool_n);
-  T2L_HIP(ctx, hipMemcpyAsync(out_emb, st->out, sizeof(float) * (size_t)B * kTD, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(pool_norm_fwd_kernel, dim3(B), dim3(256), 0, s, x, st->out, st->pool_arg, st->pool_n, out_emb);
   event_end(ctx, "train_forward", s);
   T2L_HIP(ctx, hipGetLastError());
   if (st->ws_off > st->ws_cap) return fail(ctx, T2L_ENOMEM, "t2l_encode_cells_train: workspace bound exceeded (internal error)");
@@ -590,7 +591,7 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
 // d: gradient w.r.t. the block's ReLU output [M,cout] (overwritten); x: the block's input; dx (optional) receives d W.
 static void mlp_layer_bwd(TrainState* st, const MlpLayer& L, float* d, const float* x, int M, int small_k, int standardize, float* dx,
                           hipStream_t s) {
-  double* acc = st->bn_acc + (size_t)(st->bn_slot++ % kBnSlots) * 2048;
+  double* acc = st->bn_acc + (size_t)(st->bn_slot++ % (2 * kBnSlots)) * 2048;
   hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(L.cout / 64, (M + kBnRows - 1) / kBnRows), dim3(256), 0, s, L.y, (const float*)d, (const float*)L.a,
                      M, L.cout, (const float*)L.mean, (const float*)L.rstd, acc);
   hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((unsigned)(((size_t)M * L.cout + 255) / 256)), dim3(256), 0, s, d, L.a, L.y, M, L.cout, acc,
@@ -616,8 +617,9 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   tl_gemm_bf16 = ctx->train_bf16;
   const size_t mark = st->ws_off;
   event_begin(ctx, "train_backward", s);
-  st->bn_slot = 0;
-  T2L_HIP(ctx, hipMemsetAsync(st->bn_acc, 0, sizeof(double) * 2048 * kBnSlots, s));
+  st->bn_slot = kBnSlots;  // the backward's half of the accumulators: zeroed by the forward's memset, unless this is a second backward
+  if (!st->bwd_acc_clean) T2L_HIP(ctx, hipMemsetAsync(st->bn_acc + (size_t)kBnSlots * 2048, 0, sizeof(double) * 2048 * kBnSlots, s));
+  st->bwd_acc_clean = false;
   float* dcur = bump<float>(st, (size_t)T * kTD);
   float* dA = bump<float>(st, (size_t)T * kTD);
   float* dB = bump<float>(st, (size_t)T * kTD);

@@ -627,7 +627,8 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 __global__ __launch_bounds__(256) void pool_norm_fwd_kernel(const float* __restrict__ X, float* __restrict__ out,
-                                                            int32_t* __restrict__ arg, float* __restrict__ save_n) {
+                                                            int32_t* __restrict__ arg, float* __restrict__ save_n,
+                                                            float* __restrict__ out2) {  // out2: the caller's copy (no memcpy launch)
   __shared__ float red[4];
   const int b = blockIdx.x, c = threadIdx.x;
   float mx = X[(size_t)b * kTS * kTD + c];
@@ -638,6 +639,7 @@ __global__ __launch_bounds__(256) void pool_norm_fwd_kernel(const float* __restr
   }
   const float n = fmaxf(sqrtf(block_sum256(mx * mx, red)), kNormEps);
   out[(size_t)b * kTD + c] = mx / n;
+  out2[(size_t)b * kTD + c] = mx / n;
   arg[(size_t)b * kTD + c] = am;
   if (c == 0) save_n[b] = n;
 }
