@@ -350,6 +350,10 @@ int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step,
  *     2 = split-bf16: every operand as hi + lo bf16, three MFMAs per 16-step (relative product error <= 2^-16 + 2^-18, f32's
  *     exponent range): the f32 goldens are met to 1e-4 at close to the bf16 variant's speed. Applies to the PointNet++
  *     training calls too.
+ * "train_gemm_block"  (default 0 = by measurement; 32, 64): output block of the training step's tile GEMMs. 64 = every wave holds
+ *     2 x 2 accumulator tiles (half the L2 -> L1 operand traffic, a quarter of the workgroups): 4 % faster with bf16 / split-bf16
+ *     operands, 3 % slower in f32 (the deeper operand ring of the 32 x 32 form does not fit beside 64 accumulators) — so 0 picks 64
+ *     with train_bf16 != 0 and 32 otherwise. Results are identical up to float32 summation order.
  * "pointnet_train_v1" (default 0): 1 = t2l_pointnet_features_train / t2l_pointnet_backward on the first version's GEMM kernels
  *     (operands straight from L2, the first layer's post-ReLU activations stored) instead of the second version's (weights
  *     resident in LDS, BatchNorm sums in the GEMM epilogue, BatchNorm + ReLU fused into the operand load). Same results to

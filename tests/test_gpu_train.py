@@ -339,3 +339,31 @@ def test_split_bf16_variant_stays_at_f32_accuracy(golden, mode):
         assert n_checked >= 10 and worst_cos > 0.9999, (n_checked, worst_cos)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("mode", ["embed", "pn"])
+def test_gemm_block_64_equals_32(eng, golden, mode):
+    """The 64 x 64-block form of the tile GEMMs (2 x 2 accumulator tiles per wave; the default with bf16 operands) against the
+    32 x 32 form in float32 on the reference's train-step case: forward, loss gradients and every parameter gradient agree to
+    float32 summation order (the same products, partial sums met in a different order)."""
+    g = golden(f"train_step_{mode}")
+    cells, sd, embed = load_case(g, mode)
+    res = {}
+    try:
+        for blk in (32, 64):
+            eng.set_option("train_gemm_block", blk)
+            tensors = bind(eng, sd, embed)
+            positive = eng.encode_cells_train(to_dev(cells, embed), dropout_p=0.1, seed=5)
+            anchor = torch.from_numpy(g["anchor"]).cuda()
+            loss, ga, gp = eng.contrastive_loss(anchor, positive, float(g["temperature"]))
+            eng.encode_cells_backward(gp)
+            torch.cuda.synchronize()
+            res[blk] = (positive.clone(), {n: t[1].clone() for n, t in tensors.items() if t[1] is not None})
+    finally:
+        eng.set_option("train_gemm_block", 0)
+    assert float((res[32][0] - res[64][0]).abs().max()) < 2e-6
+    for n, a in res[32][1].items():
+        b = res[64][1][n]
+        if n.startswith("object_encoder.") and n.endswith(".0.bias"):
+            continue  # in front of a BatchNorm: noise around a zero gradient
+        assert float((a - b).norm()) <= 2e-4 * float(a.norm()) + 1e-9, n

@@ -196,6 +196,163 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   gemm_body<A_KC, B_KC>(g, blockIdx.x, blockIdx.y, blockIdx.z, red, cred);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same product on a 64 x 64 output block: every wave holds 2 x 2 accumulator tiles over its quarter of the reduction (two A and
+// two B fragments feed four MFMA chains per 16-step), so the workgroup reads (64 + 64) rows of operands for four output tiles
+// instead of (32 + 32) for one — HALF the L2 -> L1 operand traffic, which is what bounds these GEMMs (rocprofv3, round 3: 14-25 us
+// for 0.3-0.9 GFLOP; 86 MB of operand reads for the QKV product). The four partial blocks meet in LDS so that wave t ends up with
+// the complete tile t (tm = t >> 1, tn = t & 1) in its registers and stores it itself (48 KiB: three foreign partials per tile).
+// Needs every output dimension to be a multiple of 64 where it is not ragged-checked (N; and M when !A_KC); M may be ragged when A_KC.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kGemm4RedFloats = 4 * 3 * 16 * 64;  // 48 KiB
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void gemm_body4(const GemmArgs& g, int bx, int by, int bz, float* red, float* cred) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, kh = lane >> 5;
+  const int n0 = bx * 64, m0 = by * 64;
+  const int kb = bz * g.kchunk, ke = min(g.K, kb + g.kchunk);
+  const int slice = ((((ke - kb) + 3) / 4) + 15) & ~15;
+  const int wk0 = kb + w * slice, wk1 = min(ke, wk0 + slice);
+  const bool a_ok[2] = {!A_KC || (m0 + i) < g.M, !A_KC || (m0 + 32 + i) < g.M};
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+  constexpr int kRing = 2;  // (four steps of 2 x 2 fragments are 128 registers: with the 64 accumulators they spill at two waves per SIMD)
+  float a[kRing][2][8], b[kRing][2][8], csum[2] = {0.f, 0.f};
+  const bool do_colsum = !A_KC && g.colsum && bx == 0;
+  auto load = [&](int k0, float (&av)[2][8], float (&bv)[2][8]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      gemm_load<A_KC>(g.A, g.lda, m0 + 32 * t + i, a_ok[t], k0, kh, wk1, av[t]);
+      gemm_load<B_KC>(g.B, g.ldb, n0 + 32 * t + i, true, k0, kh, wk1, bv[t]);
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < kRing; ++d)
+    if (wk0 + 16 * d < wk1) load(wk0 + 16 * d, a[d], b[d]);
+  for (int k0 = wk0; k0 < wk1; k0 += 16 * kRing) {
+#pragma unroll
+    for (int d = 0; d < kRing; ++d) {
+      if (k0 + 16 * d < wk1) {
+        if (g.bf16 == 2) {
+          gemm_bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            gemm_split_bf16(a[d][t], ah[t], al[t]);
+            gemm_split_bf16(b[d][t], bh[t], bl[t]);
+          }
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            }
+        } else if (g.bf16) {
+          gemm_bf16x8 ah[2], bh[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            ah[t] = gemm_to_bf16(a[d][t]);
+            bh[t] = gemm_to_bf16(b[d][t]);
+          }
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+              for (int tn = 0; tn < 2; ++tn)
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][tm][j], b[d][tn][j], acc[tm][tn], 0, 0, 0);
+        }
+        if (do_colsum) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) csum[t] += a[d][t][j];
+        }
+        if (k0 + 16 * (d + kRing) < wk1) load(k0 + 16 * (d + kRing), a[d], b[d]);
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  // wave w parks its partials of the three tiles it does not own: tile t's slot (w - t - 1) & 3 in {0, 1, 2}
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t != w) {
+      const int slot = (w - t - 1) & 3;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((t * 3 + slot) * 16 + r) * 64 + lane] = acc[t >> 1][t & 1][r];
+    }
+  }
+  if (do_colsum) {
+    cred[(w * 2 + 0) * 64 + lane] = csum[0];
+    cred[(w * 2 + 1) * 64 + lane] = csum[1];
+  }
+  __syncthreads();
+  if (do_colsum && tid < 64) {
+    const int t = tid >> 5, c = tid & 31;
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s += cred[(q * 2 + t) * 64 + c] + cred[(q * 2 + t) * 64 + 32 + c];
+    unsafeAtomicAdd(g.colsum + m0 + 32 * t + c, s);
+  }
+  // wave w completes and stores tile w (every accumulator index below is a compile-time constant after the switch)
+  f32x16 full;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (t == w) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        full[r] = acc[t >> 1][t & 1][r] + red[((t * 3 + 0) * 16 + r) * 64 + lane] + red[((t * 3 + 1) * 16 + r) * 64 + lane] +
+                  red[((t * 3 + 2) * 16 + r) * 64 + lane];
+    }
+  const int tm = w >> 1, tn = w & 1;
+  const int cg = n0 + 32 * tn + i;
+  const float bv = (g.bias && bz == 0) ? g.bias[cg] : 0.f;
+  // (element offsets as 32-bit: the training step's tensors are far below 2^31 elements; the dropout counter is 32-bit anyway)
+  const int rbase = m0 + 32 * tm + 4 * kh;
+  float mk[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1);
+    mk[r] = g.epi == 2 ? g.mask_src[(unsigned)row * (unsigned)g.ldc + cg] : 1.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = rbase + (r & 3) + 8 * (r >> 2);
+    const unsigned idx = (unsigned)min(row, g.M - 1) * (unsigned)g.ldc + cg;
+    float x = full[r] + bv;
+    if (g.relu) x = fmaxf(x, 0.f);
+    if (g.epi == 2) {
+      x = mk[r] > 0.f ? x : 0.f;
+      if (g.drop_thr) x = gemm_keep_bit(g.drop_key, idx, g.drop_thr) ? x * g.drop_scale : 0.f;
+    }
+    if (row < g.M) {
+      float* dst = g.C + idx;
+      if (g.accumulate)
+        unsafeAtomicAdd(dst, x);
+      else
+        *dst = x;
+      if (g.epi == 1) g.C2[idx] = gemm_keep_bit(g.drop_key, idx, g.drop_thr) ? x * g.drop_scale : 0.f;
+    }
+  }
+}
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmArgs g) {
+  __shared__ float red[kGemm4RedFloats];
+  __shared__ float cred[8 * 64];
+  gemm_body4<A_KC, B_KC>(g, blockIdx.x, blockIdx.y, blockIdx.z, red, cred);
+}
 // Two products that depend on the same dY and on nothing of each other — dW += dY^T X (with the bias gradient) and
 // dX = dY W — as ONE launch: workgroups [0, tn_blocks) take the first, the rest the second (a dependent launch costs ~5 us
 // whatever its size: 11 of them per training step).
@@ -213,6 +370,20 @@ static __global__ __launch_bounds__(256) void gemm_pair_kernel(GemmPair p) {
   } else {
     const int c = b - p.tn_blocks;
     gemm_body<true, false>(p.nn, c % p.nn_gx, c / p.nn_gx, 0, red, cred);
+  }
+}
+
+// the dW + dX pair on 64 x 64 blocks (GemmPair's tn_gx / tn_gy / nn_gx count 64-wide blocks here)
+static __global__ __launch_bounds__(256, 2) void gemm4_pair_kernel(const GemmPair p) {
+  __shared__ float red[kGemm4RedFloats];
+  __shared__ float cred[8 * 64];
+  const int b = blockIdx.x;
+  if (b < p.tn_blocks) {
+    const int bx = b % p.tn_gx, by = (b / p.tn_gx) % p.tn_gy, bz = b / (p.tn_gx * p.tn_gy);
+    gemm_body4<false, false>(p.tn, bx, by, bz, red, cred);
+  } else {
+    const int c = b - p.tn_blocks;
+    gemm_body4<true, false>(p.nn, c % p.nn_gx, c / p.nn_gx, 0, red, cred);
   }
 }
 

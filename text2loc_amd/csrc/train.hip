@@ -112,33 +112,52 @@ static T* bump(TrainState* st, size_t count) {
 
 // ---- GEMM launchers -----------------------------------------------------------------------------------------
 static thread_local int tl_gemm_bf16 = 0;  // set from the context option "train_bf16" at the top of every forward / backward
+static thread_local int tl_gemm_block64 = 0;  // option "train_gemm_block": 64 x 64 output blocks where the shape allows (default: with bf16 operands)
+static inline bool blk64(int rows_out_mult, int cols_out) { return tl_gemm_block64 && rows_out_mult % 64 == 0 && cols_out % 64 == 0; }
 // Y[M,N] = X[M,K] W[N,K]^T + b (relu)
+static void gemm_nt_args(const GemmArgs& g, hipStream_t s) {  // g.M rows (ragged allowed), g.N columns
+  if (blk64(64, g.N))
+    hipLaunchKernelGGL((gemm4_kernel<true, true>), dim3(g.N / 64, (g.M + 63) / 64, 1), dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL((gemm_kernel<true, true>), dim3(g.N / 32, (g.M + 31) / 32, 1), dim3(256), 0, s, g);
+}
 static void gemm_nt(const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int relu, hipStream_t s) {
-  GemmArgs g{X, W, Y, b, M, N, K, K, K, N, relu, 0, K, nullptr, tl_gemm_bf16};
-  hipLaunchKernelGGL((gemm_kernel<true, true>), dim3(N / 32, (M + 31) / 32, 1), dim3(256), 0, s, g);
+  gemm_nt_args(GemmArgs{X, W, Y, b, M, N, K, K, K, N, relu, 0, K, nullptr, tl_gemm_bf16}, s);
 }
 // dX[M,Kp] (+)= dY[M,N] W[N,Kp]
 static void gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kp, int accumulate, hipStream_t s) {
   GemmArgs g{dY, W, dX, nullptr, M, Kp, N, N, Kp, Kp, 0, accumulate, N, nullptr, tl_gemm_bf16};
-  hipLaunchKernelGGL((gemm_kernel<true, false>), dim3(Kp / 32, (M + 31) / 32, 1), dim3(256), 0, s, g);
+  if (blk64(64, Kp))
+    hipLaunchKernelGGL((gemm4_kernel<true, false>), dim3(Kp / 64, (M + 63) / 64, 1), dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL((gemm_kernel<true, false>), dim3(Kp / 32, (M + 31) / 32, 1), dim3(256), 0, s, g);
+}
+// reduction split of dW[N,Kp] += dY[M,N]^T X[M,Kp] over the M rows: >= 64 rows per wave, ~1k workgroups
+static void tn_split(int M, int N, int Kp, int blk, int& ksplit, int& kchunk) {
+  const int tiles = (N / blk) * (Kp / blk);
+  ksplit = std::max(1, std::min((M + 255) / 256, (1024 + tiles - 1) / tiles));
+  kchunk = (((M + ksplit - 1) / ksplit) + 63) & ~63;
+  ksplit = (M + kchunk - 1) / kchunk;
 }
 // dW[N,Kp] += dY[M,N]^T X[M,Kp]   (reduction over the M rows, split over grid.z, float atomics);  db[N] += column sums of dY
 static void gemm_tn(const float* dY, const float* X, float* dW, float* db, int M, int N, int Kp, hipStream_t s) {
-  const int tiles = (N / 32) * (Kp / 32);
-  int ksplit = std::max(1, std::min((M + 255) / 256, (1024 + tiles - 1) / tiles));  // >= 64 rows per wave, ~1k workgroups
-  int kchunk = (((M + ksplit - 1) / ksplit) + 63) & ~63;
-  ksplit = (M + kchunk - 1) / kchunk;
+  const bool b64 = blk64(N, Kp);
+  int ksplit, kchunk;
+  tn_split(M, N, Kp, b64 ? 64 : 32, ksplit, kchunk);
   GemmArgs g{dY, X, dW, nullptr, N, Kp, M, N, Kp, Kp, 0, 1, kchunk, db, tl_gemm_bf16};
-  hipLaunchKernelGGL((gemm_kernel<false, false>), dim3(Kp / 32, N / 32, ksplit), dim3(256), 0, s, g);
+  if (b64)
+    hipLaunchKernelGGL((gemm4_kernel<false, false>), dim3(Kp / 64, N / 64, ksplit), dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL((gemm_kernel<false, false>), dim3(Kp / 32, N / 32, ksplit), dim3(256), 0, s, g);
 }
 // dW[N,Kp] += dY^T X (+ db) and dX[M,Kp] (+)= dY W in ONE launch (both read dY only); mask_src / drop: the ReLU + dropout backward
 // of the layer that produced X's pre-image, applied in dX's epilogue (epi 2) instead of by a launch of its own
 static void gemm_tn_nn(const float* dY, const float* X, float* dW, float* db, const float* W, float* dX, int M, int N, int Kp, int accumulate,
                        const float* mask_src, const Drop* drop, hipStream_t s) {
-  const int tiles = (N / 32) * (Kp / 32);
-  int ksplit = std::max(1, std::min((M + 255) / 256, (1024 + tiles - 1) / tiles));
-  int kchunk = (((M + ksplit - 1) / ksplit) + 63) & ~63;
-  ksplit = (M + kchunk - 1) / kchunk;
+  const bool b64 = blk64(N, Kp);
+  const int blk = b64 ? 64 : 32;
+  int ksplit, kchunk;
+  tn_split(M, N, Kp, blk, ksplit, kchunk);
   GemmPair p{};
   p.tn = GemmArgs{dY, X, dW, nullptr, N, Kp, M, N, Kp, Kp, 0, 1, kchunk, db, tl_gemm_bf16};
   p.nn = GemmArgs{dY, W, dX, nullptr, M, Kp, N, N, Kp, Kp, 0, accumulate, N, nullptr, tl_gemm_bf16};
@@ -149,12 +168,15 @@ static void gemm_tn_nn(const float* dY, const float* X, float* dW, float* db, co
     p.nn.drop_thr = drop->thr;
     p.nn.drop_scale = drop->scale;
   }
-  p.tn_gx = Kp / 32;
-  p.tn_gy = N / 32;
+  p.tn_gx = Kp / blk;
+  p.tn_gy = N / blk;
   p.tn_blocks = p.tn_gx * p.tn_gy * ksplit;
-  p.nn_gx = Kp / 32;
-  const int nn_blocks = p.nn_gx * ((M + 31) / 32);
-  hipLaunchKernelGGL(gemm_pair_kernel, dim3(p.tn_blocks + nn_blocks), dim3(256), 0, s, p);
+  p.nn_gx = Kp / blk;
+  const int nn_blocks = p.nn_gx * ((M + blk - 1) / blk);
+  if (b64)
+    hipLaunchKernelGGL(gemm4_pair_kernel, dim3(p.tn_blocks + nn_blocks), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL(gemm_pair_kernel, dim3(p.tn_blocks + nn_blocks), dim3(256), 0, s, p);
 }
 static int need(t2l_ctx* ctx, TrainState* st, const std::string& name, int64_t numel, bool with_grad, TTensor** out) {
   auto it = st->t.find(name);
@@ -463,6 +485,7 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
     st->ws_cap = need_bytes;
   }
   tl_gemm_bf16 = ctx->train_bf16;
+  tl_gemm_block64 = ctx->train_gemm_block == 64 || (ctx->train_gemm_block == 0 && ctx->train_bf16 != 0);
   st->ws_off = 0;
   st->have_forward = false;
   st->M = M; st->B = B; st->T = T;
@@ -568,7 +591,7 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
         g.drop_thr = dr.thr;
         g.drop_scale = dr.scale;
       }
-      hipLaunchKernelGGL((gemm_kernel<true, true>), dim3(2 * kTD / 32, (T + 31) / 32, 1), dim3(256), 0, s, g);
+      gemm_nt_args(g, s);
     }
     gemm_nt(L.hd, T_(st, L.prefix + ".linear2.weight").data, T_(st, L.prefix + ".linear2.bias").data, tmp, T, kTD, 2 * kTD, 0, s);
     hipLaunchKernelGGL(ln_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, L.x1, tmp, T, T_(st, L.prefix + ".norm2.weight").data,
@@ -615,6 +638,7 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   if (!grad_emb) return fail(ctx, T2L_EINVAL, "t2l_encode_cells_backward: null gradient");
   const int M = st->M, B = st->B, T = st->T, Kc = st->n_feat * kTD;
   tl_gemm_bf16 = ctx->train_bf16;
+  tl_gemm_block64 = ctx->train_gemm_block == 64 || (ctx->train_gemm_block == 0 && ctx->train_bf16 != 0);
   const size_t mark = st->ws_off;
   event_begin(ctx, "train_backward", s);
   st->bn_slot = kBnSlots;  // the backward's half of the accumulators: zeroed by the forward's memset, unless this is a second backward
