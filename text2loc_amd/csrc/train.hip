@@ -420,7 +420,7 @@ static void small_branches_bwd(TrainState* st, const std::vector<int>& which, in
   sk.M = M;
   sk.mean = 1826.6844940968194f;
   sk.stdv = 2516.8905096993817f;
-  sk.rows_per_block = 32;
+  sk.rows_per_block = 32;  // (64 rows per workgroup halve the end-of-workgroup atomics but double the serial row loop: 7.8 -> 10.4 us)
   const int N = kTD, Kp = 64;
   const int tiles = (N / 32) * (Kp / 32);
   int ksplit = std::max(1, std::min((M + 255) / 256, (1024 + tiles - 1) / tiles));
@@ -663,12 +663,12 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   const float* xl = st->layers.empty() ? st->X0 : st->layers.back().x2;
   (void)xl;
   hipLaunchKernelGGL(pool_norm_bwd_kernel, dim3(B), dim3(256), 0, s, grad_emb, st->out, st->pool_arg, st->pool_n, dcur);
-  const int ln_grid = std::min(64, (T + 3) / 4);  // few workgroups: each ends with 512 float atomics on the same addresses
+  const int ln_grid = std::min(32, (T + 15) / 16);  // few workgroups (each ends with 512 float atomics on the same addresses) of 16 waves
   for (int l = (int)st->layers.size() - 1; l >= 0; --l) {
     const LayerSave& L = st->layers[l];
     auto W = [&](const char* n) -> const TTensor& { return T_(st, L.prefix + n); };
     // norm2 + dropout2
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_grid), dim3(256), 0, s, dcur, L.xhat2, L.rstd2, T, W(".norm2.weight").data,
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_grid), dim3(1024), 0, s, dcur, L.xhat2, L.rstd2, T, W(".norm2.weight").data,
                        make_drop(st->seed, l * 4 + 3, st->p), dA, dB, W(".norm2.weight").grad, W(".norm2.bias").grad);
     // linear2
     {  // dW2 += dB^T hd, and dH = (dB W2) through the ReLU + dropout backward — one launch
@@ -678,7 +678,7 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
     // linear1; dA (= dz2, the residual path) += dH W1
     gemm_tn_nn(dH, L.x1, W(".linear1.weight").grad, W(".linear1.bias").grad, W(".linear1.weight").data, dA, T, 2 * kTD, kTD, 1, nullptr, nullptr, s);
     // norm1 + dropout1
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_grid), dim3(256), 0, s, dA, L.xhat1, L.rstd1, T, W(".norm1.weight").data,
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_grid), dim3(1024), 0, s, dA, L.xhat1, L.rstd1, T, W(".norm1.weight").data,
                        make_drop(st->seed, l * 4 + 1, st->p), dC, dB2, W(".norm1.weight").grad, W(".norm1.bias").grad);
     // out_proj
     gemm_tn_nn(dB2, L.O, W(".self_attn.out_proj.weight").grad, W(".self_attn.out_proj.bias").grad, W(".self_attn.out_proj.weight").data, dO, T, kTD,

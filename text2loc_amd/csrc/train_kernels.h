@@ -557,25 +557,42 @@ __global__ void ln_fwd_kernel(const float* __restrict__ x, const float* __restri
 }
 // dz = LN backward of dout; d_res = dz (gradient of the residual input), d_y = dz * dropout mask (gradient of y).
 // dgamma/dbeta: per-workgroup column partials, then atomics. grid = any; each workgroup strides over tokens.
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ xhat,
+// Workgroups of 16 waves: the dgamma / dbeta atomics of a workgroup land on the same 512 addresses as everybody else's (~75 ns per
+// same-address atomic: 64 workgroups of 4 waves spent ~5 of their 10.7 us there, 128 workgroups took 15.5 us), so the rows are
+// spread over MORE WAVES per workgroup instead of more workgroups.
+__global__ __launch_bounds__(1024) void ln_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ xhat,
                                                      const float* __restrict__ save_rstd, int T,
                                                      const float* __restrict__ gamma, Drop dr, float* __restrict__ d_res,
                                                      float* __restrict__ d_y, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta) {
-  __shared__ float4 rg[256], rb[256];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ float4 rg[1024], rb[1024];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
   float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
-  for (int t = blockIdx.x * 4 + w; t < T; t += gridDim.x * 4) {
+  // a wave walks ~7 token rows: the next row's operands are loaded before the current row is reduced and stored (written as
+  // load -> reduce -> store per row, every row paid its own L2 round trip behind the previous row's stores: 11.4 us per launch)
+  const int stride = gridDim.x * nw;
+  int t = blockIdx.x * nw + w;
+  float4 d = make_float4(0.f, 0.f, 0.f, 0.f), h = d;
+  float rstd = 0.f;
+  if (t < T) {
     const size_t o = (size_t)t * kTD + lane * 4;
-    const float4 d = *reinterpret_cast<const float4*>(dout + o);
-    const float4 h = *reinterpret_cast<const float4*>(xhat + o);
+    d = *reinterpret_cast<const float4*>(dout + o);
+    h = *reinterpret_cast<const float4*>(xhat + o);
+    rstd = save_rstd[t];
+  }
+  while (t < T) {
+    const int tn = min(t + stride, T - 1);  // (clamped: the last prefetch re-reads a valid row and is dropped)
+    const size_t on = (size_t)tn * kTD + lane * 4;
+    const float4 nd = *reinterpret_cast<const float4*>(dout + on);
+    const float4 nh = *reinterpret_cast<const float4*>(xhat + on);
+    const float nrstd = save_rstd[tn];
+    const size_t o = (size_t)t * kTD + lane * 4;
     ag.x += d.x * h.x; ag.y += d.y * h.y; ag.z += d.z * h.z; ag.w += d.w * h.w;
     ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
     const float4 dh = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
     const float m1 = wsum(dh.x + dh.y + dh.z + dh.w) * (1.f / kTD);
     const float m2 = wsum(dh.x * h.x + dh.y * h.y + dh.z * h.z + dh.w * h.w) * (1.f / kTD);
-    const float rstd = save_rstd[t];
     float4 dz = make_float4(rstd * (dh.x - m1 - h.x * m2), rstd * (dh.y - m1 - h.y * m2), rstd * (dh.z - m1 - h.z * m2),
                             rstd * (dh.w - m1 - h.w * m2));
     *reinterpret_cast<float4*>(d_res + o) = dz;
@@ -586,12 +603,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       dz.w = keep_bit(dr.key, (uint32_t)o + 3, dr.thr) ? dz.w * dr.scale : 0.f;
     }
     *reinterpret_cast<float4*>(d_y + o) = dz;
+    d = nd;
+    h = nh;
+    rstd = nrstd;
+    t += stride;
   }
   rg[threadIdx.x] = ag;
   rb[threadIdx.x] = ab;
   __syncthreads();
   if (w == 0) {
-    for (int i = 1; i < 4; ++i) {
+    for (int i = 1; i < nw; ++i) {
       const float4 a = rg[lane + 64 * i], c = rb[lane + 64 * i];
       ag.x += a.x; ag.y += a.y; ag.z += a.z; ag.w += a.w;
       ab.x += c.x; ab.y += c.y; ab.z += c.z; ab.w += c.w;
