@@ -108,6 +108,7 @@ __device__ __forceinline__ void smallk_bwd_body(const float* __restrict__ x, int
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int lo = bx * rows_per_block, hi = min(M, lo + rows_per_block);
   float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
   for (int m = lo + g; m < hi; m += 4) {
     const float d = dy[(size_t)m * 64 + c];
     s[3] += d;
@@ -153,6 +154,7 @@ __device__ __forceinline__ void bn_stats_body(const float* __restrict__ y, const
     rstd = save_rstd[c];
   }
   float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8  // 16 rows per thread: the loads of eight of them in flight (each row's loads otherwise wait for the previous row's)
   for (int m = lo + g; m < hi; m += 4) {
     const size_t i = (size_t)m * C + c;
     if (MODE == 0) {
@@ -423,6 +425,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
                                                        float* __restrict__ O, Drop dr) {
   __shared__ float q[kTS * kAS], k[kTS * kAS], v[kTS * kAS], p[kTS * (kTS + 1)];
   const int b = blockIdx.x >> 2, h = blockIdx.x & 3, tid = threadIdx.x;
+#pragma unroll  // (7 trips: every global load of the tile issued before the first LDS write waits for one)
   for (int i = tid; i < kTS * kTHd; i += 256) {
     const int s = i >> 6, d = i & 63;
     const float* base = qkv + (size_t)(b * kTS + s) * (3 * kTD) + h * kTHd + d;
@@ -472,6 +475,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   __shared__ float q[kTS * kAS], k[kTS * kAS], v[kTS * kAS], go[kTS * kAS];
   __shared__ float p[kTS * (kTS + 1)], pd[kTS * (kTS + 1)], ds[kTS * (kTS + 1)];
   const int b = blockIdx.x >> 2, h = blockIdx.x & 3, tid = threadIdx.x;
+#pragma unroll  // (7 trips: every global load of the tile issued before the first LDS write waits for one)
   for (int i = tid; i < kTS * kTHd; i += 256) {
     const int s = i >> 6, d = i & 63;
     const float* base = qkv + (size_t)(b * kTS + s) * (3 * kTD) + h * kTHd + d;
@@ -654,6 +658,7 @@ __global__ __launch_bounds__(256) void pool_norm_fwd_kernel(const float* __restr
   const int b = blockIdx.x, c = threadIdx.x;
   float mx = X[(size_t)b * kTS * kTD + c];
   int am = 0;
+#pragma unroll
   for (int s = 1; s < kTS; ++s) {
     const float v = X[((size_t)b * kTS + s) * kTD + c];
     if (v > mx) { mx = v; am = s; }
