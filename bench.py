@@ -649,11 +649,19 @@ def secondary_measurements(eng):
         allb, idx_s, sc_s, bb, so = eng_s.result_block(Qn, TOPK, "cuda", parts=P)   # P exchange blocks {ids | scores}; the views alias block 0
         m_out = (torch.empty((Qn, TOPK), dtype=torch.int32, device="cuda"), torch.empty((Qn, TOPK), dtype=torch.float64, device="cuda"))
         eng_s.search(dq_all, TOPK, out=(idx_s, sc_s))
-        for r in range(1, P):  # stand-in for the all_gather: rank r's block = this shard's scores scaled down a little, ids shifted
+        # stand-in for the all_gather: rank r's block = the real result of ANOTHER random shard of the same size for the same
+        # queries (independent rows, as the shards of a real database are: the merge's work depends on how many of the 8 x K candidates
+        # reach the bound — K .. 2K for independent shards; scaled copies of one list would make nearly all 80 survive), ids shifted
+        for r in range(1, P):
+            shard_r = torch.from_numpy(synth.unit_rows(np.random.default_rng(50 + r).standard_normal((n_shard, DIM)).astype(np.float32))).cuda()
+            eng_s.db_set(shard_r, row_offset=r * n_shard)
+            i_r, s_r = eng_s.search(dq_all, TOPK)
             blk_i = allb[r, :Qn * TOPK * 4].view(torch.int32).view(Qn, TOPK)
             blk_s = allb[r, so:so + Qn * TOPK * 8].view(torch.float64).view(Qn, TOPK)
-            blk_i.copy_(idx_s + r * n_shard)
-            blk_s.copy_(sc_s * (1.0 - 0.003 * ((r * 5) % P)))
+            blk_i.copy_(i_r)
+            blk_s.copy_(s_r)
+        eng_s.db_set(shard, row_offset=0)
+        eng_s.search(dq_all, TOPK, out=(idx_s, sc_s))
         eng_s.set_option("profile_events", 0)
 
         allv = allb.view(-1)
@@ -689,6 +697,7 @@ def secondary_measurements(eng):
             shard_step()
         torch.cuda.synchronize()
         k_scan, k_rr = eng_s.kernel_stats("search_scan")[0], eng_s.kernel_stats("search_rerank")[0]
+        k_merge = eng_s.kernel_stats("merge")[0]
         eng_s.set_option("profile_events", 0)
         from text2loc_amd.sharded import merge_topk_host
         hi_, hs_ = [], []
@@ -700,7 +709,10 @@ def secondary_measurements(eng):
         out["shard_step_model"] = {"what": f"per-rank work of an {P}-GPU row-sharded step on one GPU: t2l_search over {n_shard} rows for all "
                                            f"{Qn} queries (ids | scores written straight into its exchange block) + t2l_merge_gathered(P={P}): three launches; the all_gather itself is not in it",
                                    "us_per_step": t_all * 1e6, "search_us_back_to_back": t_search * 1e3, "merge_us_back_to_back": t_merge * 1e3,
-                                   "scan_kernel_us": k_scan * 1e3, "rerank_kernel_us": k_rr * 1e3,
+                                   "scan_kernel_us": k_scan * 1e3, "rerank_kernel_us": k_rr * 1e3, "merge_kernel_us": k_merge * 1e3,
+                                   "note": "the *_back_to_back numbers are wall clock per call through the Python binding (a call costs ~14 us on "
+                                           "the host whatever it launches: the merge loop is host-bound); kernel_us = HIP events around the launches; "
+                                           "blocks 1..7 are real results of seven other random shards",
                                    "queries_per_s_if_the_collective_were_free": Qn / t_all, "merge_equals_host_merge_on_256_queries": ok}
         eng_s.close()
     except Exception as e:

@@ -1221,11 +1221,12 @@ __global__ __launch_bounds__(256) void merge_kernel(const char* __restrict__ idx
           id[e] = v;
           s[e] = pr.x;
         }
-      } else {
+      } else {  // (both loads issued together: the score's address does not depend on the id)
         const int v = reinterpret_cast<const int32_t*>(idx + part * idx_stride)[off];
+        const double sv = reinterpret_cast<const double*>(score + part * score_stride)[off];
         if (v >= 0) {
           id[e] = v;
-          s[e] = reinterpret_cast<const double*>(score + part * score_stride)[off];
+          s[e] = sv;
         }
       }
     }
@@ -1233,14 +1234,15 @@ __global__ __launch_bounds__(256) void merge_kernel(const char* __restrict__ idx
   // Every shard's list is sorted, so B = the largest K-th entry over the shards is a lower bound of the global K-th best
   // (that shard alone holds K candidates >= B): only candidates >= B can make the cut — usually K .. 2K of the parts * K —
   // and only those are ranked. (All scores equal: everybody survives, the loop below is the full all-pairs count.)
-  double bnd = -__builtin_inf();
+  // (the bound only has to be a LOWER bound: it is taken in float32 rounded towards -inf and reduced over the wave on DPP — the
+  //  float64 butterfly it replaces was six steps of two LDS-crossbar permutes each)
+  float bnd32 = -__builtin_inff();
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int c = lane + 64 * e;
-    if (e < ne && c < total && (c % K) == K - 1) bnd = fmax(bnd, s[e]);
+    if (e < ne && c < total && (c % K) == K - 1 && id[e] != INT_MAX) bnd32 = fmaxf(bnd32, __double2float_rd(s[e]));
   }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) bnd = fmax(bnd, __shfl_xor(bnd, off));
+  const double bnd = (double)wave_max_f32(bnd32, __builtin_inff());
   int n_s = 0;
   bool sv[4];
 #pragma unroll
@@ -1257,6 +1259,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const char* __restrict__ idx
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes are visible to its reads
   int rank[4] = {0, 0, 0, 0};
+#pragma unroll 4  // (the LDS reads of four candidates in flight: one read-wait per candidate made the loop latency-bound)
   for (int o = 0; o < n_s; ++o) {
     const double os = sh_s[wv][o];
     const int oi = sh_i[wv][o];
@@ -1328,8 +1331,10 @@ int merge_gathered_impl(t2l_ctx* ctx, const void* blocks, int64_t block_bytes, i
   if (parts * K > 256) return fail(ctx, T2L_EINVAL, "t2l_merge_gathered: parts * k must be <= 256");
   if (score_offset % 8 || block_bytes % 8 || score_offset < (int64_t)Q * K * 4 || block_bytes < score_offset + (int64_t)Q * K * 8)
     return fail(ctx, T2L_EINVAL, "t2l_merge_gathered: a block is {i32[Q][K] ids, f64[Q][K] scores at an 8-byte aligned score_offset}");
+  event_begin(ctx, "merge", s);
   hipLaunchKernelGGL((merge_kernel<false>), dim3((Q + 3) / 4), dim3(256), 0, s, (const char*)blocks, (size_t)block_bytes,
                      (const char*)blocks + score_offset, (size_t)block_bytes, parts, Q, K, out_idx, out_score);
+  event_end(ctx, "merge", s);
   T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;
 }
