@@ -38,6 +38,13 @@ struct Rows2Args {
   const float *a_mean, *a_rg, *a_beta;
   const int32_t* row_cell;   // AFUSE and/or stats: cell of every row (rows are sorted by cell)
   double* acc;               // stats: acc[cell][0][n] += sum C, acc[cell][1][n] += sum C^2 ([cell][2][1024] doubles) or nullptr
+  // scattered output (scat_dst != nullptr; the input gradient of a set-abstraction level): instead of C[row][n],
+  // scat_dst[scat_src[row]][n] += value for n < scat_cols (float atomics: several edge rows share a source row) — the [E, kp]
+  // gradient of the edge inputs is never stored and no scatter launch reads it back; columns >= scat_cols (the relative positions and
+  // the padding) have no consumer
+  const int32_t* scat_src;
+  float* scat_dst;
+  int scat_cols;
 };
 
 // W chunk -> LDS in fragment order. Item (t, i, ks, kh): the 8 values W[n0 + 32 t + i][16 ks + 8 kh + j], j = 0..7 — what lane
@@ -200,6 +207,16 @@ __global__ __launch_bounds__(kRows2Threads) void rows2_kernel(const Rows2Args g)
           float v[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = acc[t][r] + bv[t];
+          if (g.scat_dst) {  // (workgroup-uniform)
+            if (cg < g.scat_cols) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const long row = m0 + 4 * kh + (r & 3) + 8 * (r >> 2);
+                if (row < (long)g.M) unsafeAtomicAdd(g.scat_dst + (size_t)g.scat_src[row] * g.scat_cols + cg, v[r]);
+              }
+            }
+            continue;
+          }
           float* cp = g.C + (size_t)(m0 + 4 * kh) * g.ldc + cg;
           if (full) {
 #pragma unroll

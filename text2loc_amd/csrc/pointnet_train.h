@@ -592,7 +592,8 @@ static void rows2_launch_m(const train::Rows2Args& a, int grid, size_t lds, hipS
 // C[M,N] = f(A)[M,K] W[N,K]^T + bias; a_mean != nullptr: f = BatchNorm + ReLU of the layer below (tables [cell][K]); acc != nullptr:
 // the BatchNorm partial sums of C per (cell, column). K is a multiple of 16, N of 32.
 static void gemm_rows2(const float* A, const float* W, const float* bias, float* C, size_t M, int N, int K, const float* a_mean,
-                       const float* a_rg, const float* a_beta, const int32_t* row_cell, double* acc, hipStream_t s) {
+                       const float* a_rg, const float* a_beta, const int32_t* row_cell, double* acc, hipStream_t s,
+                       const int32_t* scat_src = nullptr, float* scat_dst = nullptr, int scat_cols = 0) {
   const int mode = tl_gemm_bf16, bpe = mode == 1 ? 2 : 4;
   // (bf16: the fused operand transform's tables spill from 7 tiles on)
   const int maxt = mode == 1 ? (a_mean ? 6 : 8) : train::kRows2MaxT;
@@ -601,7 +602,7 @@ static void gemm_rows2(const float* A, const float* W, const float* bias, float*
   const size_t lds = (size_t)tp * 32 * K * bpe;
   const int grid = (int)std::min<size_t>((size_t)pn_cu_count(), (M + 255) / 256);
   const int rpw = (int)(((M + (size_t)grid * 8 - 1) / ((size_t)grid * 8) + 31) / 32 * 32);
-  const train::Rows2Args a{A, W, bias, C, (int)M, N, K, K, K, N, tp, rpw, a_mean, a_rg, a_beta, row_cell, acc};
+  const train::Rows2Args a{A, W, bias, C, (int)M, N, K, K, K, N, tp, rpw, a_mean, a_rg, a_beta, row_cell, acc, scat_src, scat_dst, scat_cols};
   if (mode == 2) rows2_launch_m<2>(a, grid, lds, s);
   else if (mode == 1) rows2_launch_m<1>(a, grid, lds, s);
   else rows2_launch_m<0>(a, grid, lds, s);
@@ -1053,22 +1054,31 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
         return fail(ctx, T2L_EHIP, "t2l_pointnet_backward: no tn2_kernel instance for this layer shape (internal error)");
     }
     if (l > 0) {  // the input gradient: features of the level below (positions are data)
-      float* dX = pn_bump<float>(pt, L.E * L.kp);
-      if (pt->v1) {
-        gemm_nn_rows(dA1, L.w1p, pt->wt, dX, L.E, L.h1, L.kp, s);
-      } else {
-        hipLaunchKernelGGL(pt_transpose_kernel, dim3((unsigned)((L.h1 * L.kp + 255) / 256)), dim3(256), 0, s, (const float*)L.w1p, L.h1, L.kp,
-                           pt->wt);
-        gemm_rows2(dA1, pt->wt, nullptr, dX, L.E, L.kp, L.h1, nullptr, nullptr, nullptr, nullptr, nullptr, s);
-      }
       const PnLevel& Lb = pt->lv[l - 1];
       const size_t nprev = Lb.G * Lb.h2;
-      if (L.sa) {
+      if (!pt->v1 && L.sa) {  // second version: the product's epilogue scatters (atomics through src): no [E, kp] gradient, no scatter launch
         T2L_HIP(ctx, hipMemsetAsync(dx_next, 0, sizeof(float) * nprev, s));
-        hipLaunchKernelGGL(pt_scatter_kernel, dim3(pn_blocks(L.E * L.cin)), dim3(256), 0, s, (const float*)dX, (const int32_t*)L.src, L.E, L.cin,
-                           L.kp, dx_next);
+        hipLaunchKernelGGL(pt_transpose_kernel, dim3((unsigned)((L.h1 * L.kp + 255) / 256)), dim3(256), 0, s, (const float*)L.w1p, L.h1, L.kp,
+                           pt->wt);
+        // (only the tiles that hold feature columns: N = cin rounded up to 32)
+        gemm_rows2(dA1, pt->wt, nullptr, nullptr, L.E, (L.cin + 31) / 32 * 32, L.h1, nullptr, nullptr, nullptr, nullptr, nullptr, s,
+                   (const int32_t*)L.src, dx_next, L.cin);
       } else {
-        hipLaunchKernelGGL(pt_slice_kernel, dim3(pn_blocks(L.E * L.cin)), dim3(256), 0, s, (const float*)dX, L.E, L.cin, L.kp, dx_next);
+        float* dX = pn_bump<float>(pt, L.E * L.kp);
+        if (pt->v1) {
+          gemm_nn_rows(dA1, L.w1p, pt->wt, dX, L.E, L.h1, L.kp, s);
+        } else {
+          hipLaunchKernelGGL(pt_transpose_kernel, dim3((unsigned)((L.h1 * L.kp + 255) / 256)), dim3(256), 0, s, (const float*)L.w1p, L.h1, L.kp,
+                             pt->wt);
+          gemm_rows2(dA1, pt->wt, nullptr, dX, L.E, L.kp, L.h1, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+        }
+        if (L.sa) {
+          T2L_HIP(ctx, hipMemsetAsync(dx_next, 0, sizeof(float) * nprev, s));
+          hipLaunchKernelGGL(pt_scatter_kernel, dim3(pn_blocks(L.E * L.cin)), dim3(256), 0, s, (const float*)dX, (const int32_t*)L.src, L.E, L.cin,
+                             L.kp, dx_next);
+        } else {
+          hipLaunchKernelGGL(pt_slice_kernel, dim3(pn_blocks(L.E * L.cin)), dim3(256), 0, s, (const float*)dX, L.E, L.cin, L.kp, dx_next);
+        }
       }
       std::swap(dx, dx_next);
     }
