@@ -58,7 +58,7 @@ def cpu_baseline(db, qs, budget_s=12.0):
 
 
 PMC_SOURCE = ("profiles/pmc_latest.json = profiles/r03c_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-              "tools/profile.sh r03a, separate runs as the MI355X guide prescribes; not measured in this run)")
+              "tools/profile.sh r03c, separate runs as the MI355X guide prescribes; not measured in this run)")
 
 
 def pmc_traffic(kernel):
