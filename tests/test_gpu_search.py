@@ -495,3 +495,17 @@ def test_scan_mapping_and_prepass_options_are_result_neutral():
             e.set_option("search_xcd_qgroups", 3)
     finally:
         e.close()
+
+
+def test_merge_kernel_randomised_against_the_host_merge():
+    """tools/fuzz_merge.py (60 draws here): random part counts, k, query counts, short lists, empty parts, exact ties across parts,
+    scores over sixty decades, scores packed tighter than float32 resolves (the merge's float32 bound must stay a LOWER bound)
+    and negative scores — t2l_merge_gathered and t2l_merge_topk equal the host merge bit for bit."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("fuzz_merge", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                             "tools", "fuzz_merge.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(60, 17) == 0
