@@ -479,6 +479,12 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
               } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][j], b[j], acc[t], 0, 0, 0);
+                // (tools/mfma_hazard_scan.py: the register allocator's accumulator copies behind this branch sat 12-17 wait states
+                //  after the last 16-pass MFMA — the recogniser padded for the 8-pass bf16 path that joins here; this kernel is the
+                //  first version's, kept for A/B runs: 16 idle cycles per 512 of MFMAs)
+                __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise hoists the wait in between the MFMAs)
+                asm volatile("s_nop 15" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
               }
             }
           }
