@@ -202,3 +202,69 @@ def test_empty_database_answers_minus_one():
     idx, sc = eng.search(torch.randn(7, 256, device="cuda"), 3)
     assert (idx.cpu().numpy() == -1).all() and np.isneginf(sc.cpu().numpy()).all()
     eng.close()
+
+
+# ---- RCCL itself (backend "nccl"), as far as one GPU allows: a single-rank process group on cuda:0 --------------------------------
+def _rccl_worker(port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from text2loc_amd.engine import Engine
+    from text2loc_amd.losses import _GatherRowsFn
+    from text2loc_amd.optim import all_reduce_flat
+    from text2loc_amd.sharded import ShardedSearcher, _all_gather
+
+    n_rows, n_q, k = 11259, 512, 10
+    db, qs, _ = synth.make_retrieval_problem(n_rows, n_q, seed=21, noise=1.0)
+    d_db, d_q = torch.from_numpy(db).cuda(), torch.from_numpy(qs).cuda()
+    eng = Engine(0)
+    ss = ShardedSearcher(eng)
+    ss.set_db_shard(d_db)
+    ref_i, ref_s = eng.search(d_q, k)
+    # the three lines of ShardedSearcher.search's world > 1 branch, on the real exchange buffers, with the collective on the device:
+    # scan + re-rank fill the rank's own block, RCCL gathers the blocks (u8), the merge kernel ranks them — ordered by streams only
+    ok = True
+    for _ in range(20):
+        own, idx, sc, allb, bb, so = ss._scratch_for(n_q, k, d_q.device)
+        allb.zero_()
+        eng.search(d_q, k, out=(idx, sc))
+        _all_gather(dist, allb, own, None)
+        mi, ms = eng.merge_gathered(allb, bb, so, 1, n_q, k)
+        ok = ok and bool(torch.equal(mi, ref_i)) and bool(torch.equal(ms, ref_s))
+    # every dtype the N > 1 paths send through all_gather / all_reduce
+    dtypes_ok = {}
+    for dt in (torch.uint8, torch.int32, torch.float64, torch.float32):
+        x = (torch.arange(4096, device="cuda") % 251).to(dt)
+        y = torch.empty_like(x)
+        _all_gather(dist, y, x, None)
+        dtypes_ok[str(dt)] = bool(torch.equal(x, y))
+    g = torch.full((1 << 20,), 0.5, device="cuda")
+    all_reduce_flat(g, None, mean=True)
+    e = torch.randn(16, 256, device="cuda", requires_grad=True)
+    ge = _GatherRowsFn.apply(e, None)  # (gather_rows_with_grad short-cuts a world of 1)
+    ge.square().sum().backward()
+    torch.cuda.synchronize()
+    out_q.put((ok, dtypes_ok, float(g.min()), float(g.max()), tuple(ge.shape), float((e.grad - 2 * e.detach()).abs().max())))
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_rccl_single_rank_group_drives_the_exchange_on_the_device():
+    """RCCL refuses two ranks on one GPU, so a box with one GPU can only run a world of 1 over it — which still proves what the
+    gloo runs above cannot: the library initialises in this image, the exchange block (u8), ids (i32), scores (f64) and gradients
+    (f32) are dtypes it accepts, and scan -> re-rank -> all_gather -> merge is correctly ordered when the collective runs on the
+    device (RCCL's own stream against the engine's launches on the current stream)."""
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), out_q))
+    p.start()
+    ok, dtypes_ok, gmin, gmax, gshape, gerr = out_q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert ok
+    assert all(dtypes_ok.values()), dtypes_ok
+    assert gmin == gmax == 0.5
+    assert gshape == (16, 256) and gerr < 1e-6
