@@ -468,6 +468,8 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     ctx->pair_ll = (int)value;
   } else if (!strcmp(name, "search_pair")) {
     ctx->search_pair = value != 0;
+  } else if (!strcmp(name, "loss_single_wg")) {
+    ctx->loss_single_wg = value != 0;
   } else if (!strcmp(name, "train_gemm_block")) {
     if (value != 0 && value != 32 && value != 64) return fail(ctx, T2L_EINVAL, "train_gemm_block must be 0 (auto), 32 or 64");
     ctx->train_gemm_block = (int)value;

@@ -216,6 +216,177 @@ __global__ __launch_bounds__(256, 1) void contrastive_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The same loss as 4*nb workgroups (default; `loss_single_wg` = 1 keeps the kernel above). The single workgroup spent half its time
+// in the two gradient products — 2*nb row blocks of 8 column tiles on 4 waves — and a quarter in load round trips ahead of the
+// similarity tiles. Here EVERY workgroup repeats the cheap part (similarity tiles, E, row / column sums, G: B^2 work, in its own LDS;
+// the inverse norms fall out of the operand loads of the similarity tiles, there is no norm pass), and the gradients' 2*nb*8 output
+// tiles are dealt one per WAVE over the whole grid: the correction term of the normalisation's backward,
+//   rowdot_i = sum_c (G @ s^)_ic * im^_ic = sum_k G_ik * cos_ik        (and sum_k G_ki * cos_ki for d s),
+// comes from the B x B matrices in LDS, so a tile needs nothing from its row's other tiles. Workgroup 0 writes the loss.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void contrastive_tiles_kernel(const float* __restrict__ im, const float* __restrict__ s, int B,
+                                                                   float inv_t, float* __restrict__ loss, float* __restrict__ g_im,
+                                                                   float* __restrict__ g_s) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Bp = (B + 31) / 32 * 32;
+  const int ldg = Bp + 1;
+  float* E = smem;               // [Bp][ldg]  E, then G
+  float* S = E + Bp * ldg;       // [Bp][ldg]  raw dot products, then cosines
+  float* ia = S + Bp * ldg;      // [Bp]
+  float* ip = ia + Bp;           // [Bp]
+  float* R = ip + Bp;            // [Bp]
+  float* C = R + Bp;             // [Bp]
+  float* rdA = C + Bp;           // [Bp]  rowdot of d im
+  float* rdP = rdA + Bp;         // [Bp]  rowdot of d s
+  float* part = rdP + Bp;        // [4][Bp] per-wave column partials
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int nb = Bp / 32;
+
+  // 1. raw similarity tiles; a lane streams half a row of each operand, so the squared norms come with them
+  for (int tile = wave; tile < nb * nb; tile += 4) {
+    const int i0 = (tile / nb) * 32, j0 = (tile % nb) * 32;
+    const float4* ap = reinterpret_cast<const float4*>(im + (size_t)min(i0 + col, B - 1) * kD + half * 128);
+    const float4* pp = reinterpret_cast<const float4*>(s + (size_t)min(j0 + col, B - 1) * kD + half * 128);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float na = 0.f, np = 0.f;
+#pragma unroll 16
+    for (int q = 0; q < 32; ++q) {
+      const float4 a = ap[q], p = pp[q];
+      na += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+      np += p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, p.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, p.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, p.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, p.w, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (MFMA -> VALU read behind a loop exit: see gemm_rows2.h)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    na += __shfl_xor(na, 32);
+    np += __shfl_xor(np, 32);
+    if (half == 0) {
+      if (j0 == 0) ia[i0 + col] = i0 + col < B ? 1.f / sqrtf(na) : 0.f;
+      if (i0 == 0) ip[j0 + col] = j0 + col < B ? 1.f / sqrtf(np) : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[(i0 + (r & 3) + 8 * (r >> 2) + 4 * half) * ldg + j0 + col] = acc[r];
+  }
+  __syncthreads();
+
+  // 2. cosines, E, row sums (wave reduction) and per-wave column partials; columns j = lane, lane + 64
+  {
+    float c0 = 0.f, c1 = 0.f;
+    const float p0 = ip[min(lane, Bp - 1)], p1 = lane + 64 < Bp ? ip[lane + 64] : 0.f;
+    for (int i = wave; i < Bp; i += 4) {
+      const float a = ia[i];
+      float e0 = 0.f, e1 = 0.f;
+      if (lane < Bp) {
+        const float c = S[i * ldg + lane] * a * p0;
+        S[i * ldg + lane] = c;
+        e0 = (i < B && lane < B) ? __expf(c * inv_t) : 0.f;
+        E[i * ldg + lane] = e0;
+      }
+      if (lane + 64 < Bp) {
+        const float c = S[i * ldg + lane + 64] * a * p1;
+        S[i * ldg + lane + 64] = c;
+        e1 = (i < B && lane + 64 < B) ? __expf(c * inv_t) : 0.f;
+        E[i * ldg + lane + 64] = e1;
+      }
+      c0 += e0;
+      c1 += e1;
+      const float r = wave_sum_f32(e0 + e1);
+      if (lane == 0) R[i] = r;
+    }
+    if (lane < Bp) part[wave * Bp + lane] = c0;
+    if (lane + 64 < Bp) part[wave * Bp + lane + 64] = c1;
+  }
+  __syncthreads();
+  if (tid < Bp) C[tid] = part[tid] + part[Bp + tid] + part[2 * Bp + tid] + part[3 * Bp + tid];
+  __syncthreads();
+  if (blockIdx.x == 0 && wave == 0) {
+    float v = 0.f;
+    for (int i = lane; i < B; i += 64) v += __logf(C[i]) + __logf(R[i]) - 2.f * S[i * ldg + i] * inv_t;
+    v = wave_sum_f32(v);
+    if (lane == 0) loss[0] = v / (float)B;
+  }
+  if (!g_im) return;
+
+  // 3. G in place of E, and the two rowdot vectors
+  {
+    const float sc = inv_t / (float)B;
+    float d0 = 0.f, d1 = 0.f;
+    const float ic0 = lane < B ? 1.f / C[lane] : 0.f, ic1 = lane + 64 < B ? 1.f / C[lane + 64] : 0.f;
+    for (int i = wave; i < Bp; i += 4) {
+      const float ir = i < B ? 1.f / R[i] : 0.f;
+      float t0 = 0.f, t1 = 0.f;
+      if (lane < Bp) {
+        const float v = E[i * ldg + lane];
+        const float g = (v * ic0 + v * ir - ((i == lane && i < B) ? 2.f : 0.f)) * sc;
+        E[i * ldg + lane] = g;
+        t0 = g * S[i * ldg + lane];
+      }
+      if (lane + 64 < Bp) {
+        const float v = E[i * ldg + lane + 64];
+        const float g = (v * ic1 + v * ir - ((i == lane + 64 && i < B) ? 2.f : 0.f)) * sc;
+        E[i * ldg + lane + 64] = g;
+        t1 = g * S[i * ldg + lane + 64];
+      }
+      d0 += t0;
+      d1 += t1;
+      const float r = wave_sum_f32(t0 + t1);
+      if (lane == 0) rdA[i] = r;
+    }
+    if (lane < Bp) part[wave * Bp + lane] = d0;
+    if (lane + 64 < Bp) part[wave * Bp + lane + 64] = d1;
+  }
+  __syncthreads();
+  if (tid < Bp) rdP[tid] = part[tid] + part[Bp + tid] + part[2 * Bp + tid] + part[3 * Bp + tid];
+  __syncthreads();
+
+  // 4. one 32 x 32 tile of d im (mat 0) or d s (mat 1) per wave:  out = ((M @ X^) - Y^ * rowdot) * iy
+  const int task = blockIdx.x * 4 + wave;
+  if (task >= 2 * nb * 8) return;
+  const int mat = task / (nb * 8), i0 = (task % (nb * 8)) / 8 * 32, c0 = (task % 8) * 32;
+  const float* x = mat ? im : s;
+  const float* ix = mat ? ia : ip;
+  const float* y = mat ? s : im;
+  const float* iy = mat ? ip : ia;
+  const float* rd = mat ? rdP : rdA;
+  float* out = mat ? g_s : g_im;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int gi = i0 + col;
+  for (int k0 = 0; k0 < Bp; k0 += 32) {  // 16 steps per round, their operand loads all in flight
+    float xv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xv[q] = x[(size_t)min(k0 + 2 * q + half, B - 1) * kD + c0 + col];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int k = k0 + 2 * q + half;
+      const float a = mat ? E[k * ldg + gi] : E[gi * ldg + k];  // zero beyond B (E is), so the clamped x rows do not count
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xv[q] * ix[k], acc, 0, 0, 0);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  float yv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) yv[r] = y[(size_t)min(i0 + (r & 3) + 8 * (r >> 2) + 4 * half, B - 1) * kD + c0 + col];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    const float inv = iy[row];
+    const float v = (acc[r] - yv[r] * inv * rd[row]) * inv;
+    if (row < B) out[(size_t)row * kD + c0 + col] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Batches beyond the fused kernel's 128 rows — the GLOBAL contrastive matrix of data-parallel training (SURVEY.md §8e:
 // every rank all-gathers the [B,256] embeddings of all ranks and evaluates the loss of the whole W*B batch; 8 x 64 = 512,
 // up to 1,024 rows): the same arithmetic as a short chain of launches over a [B][B] matrix in HBM (4 MB at B = 1,024).
@@ -346,7 +517,18 @@ int loss_impl(t2l_ctx* ctx, const float* a, const float* p, int B, float temp, f
     attr_done = true;
   }
   event_begin(ctx, "contrastive_loss", s);
-  hipLaunchKernelGGL(contrastive_kernel, dim3(1), dim3(256), lds, s, a, p, B, 1.0f / temp, loss, ga, gp);
+  if (ctx->loss_single_wg) {
+    hipLaunchKernelGGL(contrastive_kernel, dim3(1), dim3(256), lds, s, a, p, B, 1.0f / temp, loss, ga, gp);
+  } else {
+    static bool attr2_done = false;
+    if (!attr2_done) {
+      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&contrastive_tiles_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      attr2_done = true;
+    }
+    const size_t lds2 = (2 * (size_t)Bp * (Bp + 1) + 10 * Bp) * sizeof(float);
+    hipLaunchKernelGGL(contrastive_tiles_kernel, dim3(ga ? 4 * (Bp / 32) : 1), dim3(256), lds2, s, a, p, B, 1.0f / temp, loss, ga, gp);
+  }
   event_end(ctx, "contrastive_loss", s);
   T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;
