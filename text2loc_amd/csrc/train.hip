@@ -56,7 +56,8 @@ struct TrainState {
   int64_t mv_total = 0;
   double* bn_acc = nullptr;  // [2][kBnSlots][2*1024] float64 partial sums of the BatchNorm stages (one slot per BN pass; forward | backward)
   int bn_slot = 0;
-  bool bwd_acc_clean = false;  // the forward's memset zeroed the backward's slots too (one memset launch per step instead of two)
+  bool fwd_acc_clean = false;  // the previous forward's last launch zeroed all accumulators (no memset launch in a step)
+  bool bwd_acc_clean = false;  // the forward zeroed the backward half too; false after a backward used it (a second backward memsets)
   int n_chunks = 0;
   int pn_chunk0 = 0;         // chunks [pn_chunk0, n_chunks) belong to the PointNet++ backbone (bound last)
   int64_t step = 0;          // Adam step of the object branch
@@ -496,8 +497,10 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
   st->layers.clear();
   event_begin(ctx, "train_forward", s);
   st->bn_slot = 0;
-  T2L_HIP(ctx, hipMemsetAsync(st->bn_acc, 0, sizeof(double) * 2048 * kBnSlots * 2, s));
-  st->bwd_acc_clean = true;
+  // the accumulators are cleared by the previous forward's last launch (pool_norm_fwd_kernel); a memset only the first time or after
+  // a forward that did not get that far
+  if (!st->fwd_acc_clean) T2L_HIP(ctx, hipMemsetAsync(st->bn_acc, 0, sizeof(double) * 2048 * kBnSlots, s));
+  st->fwd_acc_clean = false;
 
   st->cat = bump<float>(st, (size_t)M * Kc);
   const std::string oe = "object_encoder.";
@@ -602,9 +605,12 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
   st->out = bump<float>(st, (size_t)B * kTD);
   st->pool_n = bump<float>(st, B);
   st->pool_arg = bump<int32_t>(st, (size_t)B * kTD);
-  hipLaunchKernelGGL(pool_norm_fwd_kernel, dim3(B), dim3(256), 0, s, x, st->out, st->pool_arg, st->pool_n, out_emb);
+  hipLaunchKernelGGL(pool_norm_fwd_kernel, dim3(B), dim3(256), 0, s, x, st->out, st->pool_arg, st->pool_n, out_emb, st->bn_acc,
+                     2048 * kBnSlots * 2);
   event_end(ctx, "train_forward", s);
   T2L_HIP(ctx, hipGetLastError());
+  st->fwd_acc_clean = true;
+  st->bwd_acc_clean = true;
   if (st->ws_off > st->ws_cap) return fail(ctx, T2L_ENOMEM, "t2l_encode_cells_train: workspace bound exceeded (internal error)");
   st->have_forward = true;
   return T2L_OK;

@@ -653,9 +653,13 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
 }
 __global__ __launch_bounds__(256) void pool_norm_fwd_kernel(const float* __restrict__ X, float* __restrict__ out,
                                                             int32_t* __restrict__ arg, float* __restrict__ save_n,
-                                                            float* __restrict__ out2) {  // out2: the caller's copy (no memcpy launch)
+                                                            float* __restrict__ out2,  // out2: the caller's copy (no memcpy launch)
+                                                            double* __restrict__ zero, int zero_n) {
   __shared__ float red[4];
   const int b = blockIdx.x, c = threadIdx.x;
+  // the forward's last launch clears the BatchNorm accumulators of this step's backward and of the next forward (every
+  // forward-side reader is behind it on the stream): no memset launch in the step
+  for (int i = b * 256 + c; i < zero_n; i += gridDim.x * 256) zero[i] = 0.0;
   float mx = X[(size_t)b * kTS * kTD + c];
   int am = 0;
 #pragma unroll
