@@ -57,8 +57,8 @@ def cpu_baseline(db, qs, budget_s=12.0):
             "sample": f"{done} queries x N={len(db)} (float64 C@t + full argsort per query, numpy) in {dt:.1f}s"}
 
 
-PMC_SOURCE = ("profiles/pmc_latest.json = profiles/r03c_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-              "tools/profile.sh r03c, separate runs as the MI355X guide prescribes; not measured in this run)")
+PMC_SOURCE = ("profiles/pmc_latest.json = profiles/r03d_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+              "tools/profile.sh r03d, separate runs as the MI355X guide prescribes; not measured in this run)")
 
 
 def pmc_traffic(kernel):
