@@ -350,6 +350,8 @@ int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step,
  *     2 = split-bf16: every operand as hi + lo bf16, three MFMAs per 16-step (relative product error <= 2^-16 + 2^-18, f32's
  *     exponent range): the f32 goldens are met to 1e-4 at close to the bf16 variant's speed. Applies to the PointNet++
  *     training calls too.
+ * "train_xcd_map"     (default 0): 1 = the training step's tile GEMMs walk their output tiles in per-XCD bands (an eighth of one operand
+ *                      per L2). Measured slower with f32 operands (0.589 -> 0.630 ms per step), neutral with bf16; kept for A/B.
  * "loss_single_wg"    (default 0): 1 = t2l_contrastive_loss (batch <= 128) as ONE workgroup (round 1-2 kernel, kept for A/B); default:
  *                      4 * ceil(batch / 32) workgroups, every gradient tile on its own wave (38.6 -> 22.4 us per call at batch 64).
  * "train_gemm_block"  (default 0 = by measurement; 32, 64): output block of the training step's tile GEMMs. 64 = every wave holds

@@ -468,6 +468,8 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     ctx->pair_ll = (int)value;
   } else if (!strcmp(name, "search_pair")) {
     ctx->search_pair = value != 0;
+  } else if (!strcmp(name, "train_xcd_map")) {
+    ctx->train_xcd_map = value != 0;
   } else if (!strcmp(name, "loss_single_wg")) {
     ctx->loss_single_wg = value != 0;
   } else if (!strcmp(name, "train_gemm_block")) {

@@ -38,7 +38,29 @@ struct GemmArgs {
   uint32_t drop_key, drop_thr;  // counter-based dropout (train_kernels.h: keep_bit); drop_thr == 0: identity
   float drop_scale;
   int epi;
+  int xcd_bands;  // option train_xcd_map = 1: the XCD bands of xcd_logical below (measured SLOWER in f32, see there); default 0: launch order
 };
+
+// Workgroups are dealt to the 8 XCDs round robin in launch order, so neighbouring blocks land on eight different L2s. Launch position b
+// -> logical position: XCD x = b % 8 works through ONE contiguous band of the logical order (x fastest: a band of row blocks against
+// all column tiles, or a range of reduction chunks of a dW product), i.e. an eighth of one operand and all of the other. Bijective
+// for every block count (the first n % 8 XCDs take one block more).
+// MEASURED (round 3, training step at B = 64): 0.589 -> 0.630 ms per step with f32 operands, neutral (0.479 / 0.481) with bf16. The
+// launch order is not XCD-blind on these shapes: every product of the step has a multiple of 8 column tiles (N = 256 / 512 / 768), so
+// block b = bx + gx * by lands on XCD bx % 8 — each L2 already holds an eighth of the WEIGHT operand and streams the activations;
+// row bands trade that for an eighth of the activations against all of the weights, and lose. Kept as an option (default off).
+__device__ __forceinline__ int xcd_logical(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+  return x * q + min(x, r) + i;
+}
+__device__ __forceinline__ void xcd_remap3(int& bx, int& by, int& bz) {
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int l = xcd_logical(bx + gx * (by + gy * bz), gx * gy * (int)gridDim.z);
+  bx = l % gx;
+  const int t = l / gx;
+  by = t % gy;
+  bz = t / gy;
+}
 
 __device__ __forceinline__ bool gemm_keep_bit(uint32_t key, uint32_t idx, uint32_t thr) {  // == train_kernels.h: keep_bit
   uint32_t x = idx * 0x9E3779B1u + key;
@@ -193,7 +215,9 @@ template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   __shared__ float red[4 * 16 * 64];
   __shared__ float cred[4 * 64];
-  gemm_body<A_KC, B_KC>(g, blockIdx.x, blockIdx.y, blockIdx.z, red, cred);
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (g.xcd_bands) xcd_remap3(bx, by, bz);
+  gemm_body<A_KC, B_KC>(g, bx, by, bz, red, cred);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -351,7 +375,9 @@ template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmArgs g) {
   __shared__ float red[kGemm4RedFloats];
   __shared__ float cred[8 * 64];
-  gemm_body4<A_KC, B_KC>(g, blockIdx.x, blockIdx.y, blockIdx.z, red, cred);
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (g.xcd_bands) xcd_remap3(bx, by, bz);
+  gemm_body4<A_KC, B_KC>(g, bx, by, bz, red, cred);
 }
 // Two products that depend on the same dY and on nothing of each other — dW += dY^T X (with the bias gradient) and
 // dX = dY W — as ONE launch: workgroups [0, tn_blocks) take the first, the rest the second (a dependent launch costs ~5 us
@@ -363,7 +389,7 @@ struct GemmPair {
 static __global__ __launch_bounds__(256) void gemm_pair_kernel(GemmPair p) {
   __shared__ float red[4 * 16 * 64];
   __shared__ float cred[4 * 64];
-  const int b = blockIdx.x;
+  const int b = p.tn.xcd_bands ? xcd_logical(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   if (b < p.tn_blocks) {
     const int bx = b % p.tn_gx, by = (b / p.tn_gx) % p.tn_gy, bz = b / (p.tn_gx * p.tn_gy);
     gemm_body<false, false>(p.tn, bx, by, bz, red, cred);
@@ -377,7 +403,7 @@ static __global__ __launch_bounds__(256) void gemm_pair_kernel(GemmPair p) {
 static __global__ __launch_bounds__(256, 2) void gemm4_pair_kernel(const GemmPair p) {
   __shared__ float red[kGemm4RedFloats];
   __shared__ float cred[8 * 64];
-  const int b = blockIdx.x;
+  const int b = p.tn.xcd_bands ? xcd_logical(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   if (b < p.tn_blocks) {
     const int bx = b % p.tn_gx, by = (b / p.tn_gx) % p.tn_gy, bz = b / (p.tn_gx * p.tn_gy);
     gemm_body4<false, false>(p.tn, bx, by, bz, red, cred);
@@ -396,7 +422,9 @@ template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_multi_kernel(GemmMulti m) {
   __shared__ float red[4 * 16 * 64];
   __shared__ float cred[4 * 64];
-  gemm_body<A_KC, B_KC>(m.j[blockIdx.z], blockIdx.x, blockIdx.y, 0, red, cred);
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (m.j[0].xcd_bands) xcd_remap3(bx, by, bz);
+  gemm_body<A_KC, B_KC>(m.j[bz], bx, by, 0, red, cred);
 }
 struct GemmPairMulti {
   GemmPair p[3];
@@ -404,8 +432,13 @@ struct GemmPairMulti {
 static __global__ __launch_bounds__(256) void gemm_pair_multi_kernel(GemmPairMulti m) {
   __shared__ float red[4 * 16 * 64];
   __shared__ float cred[4 * 64];
-  const GemmPair& p = m.p[blockIdx.y];
-  const int b = blockIdx.x;
+  int job = blockIdx.y, b = blockIdx.x;
+  if (m.p[0].tn.xcd_bands) {
+    const int l = xcd_logical(b + (int)gridDim.x * job, (int)(gridDim.x * gridDim.y));
+    job = l / (int)gridDim.x;
+    b = l % (int)gridDim.x;
+  }
+  const GemmPair& p = m.p[job];
   if (b < p.tn_blocks) {
     const int bx = b % p.tn_gx, by = (b / p.tn_gx) % p.tn_gy, bz = b / (p.tn_gx * p.tn_gy);
     gemm_body<false, false>(p.tn, bx, by, bz, red, cred);

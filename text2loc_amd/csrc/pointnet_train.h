@@ -839,6 +839,7 @@ int pn_train_forward_impl(t2l_ctx* ctx, const float* pos, const float* rgb, cons
   pt->pos0 = pos;
   pt->rgb0 = rgb;
   tl_gemm_bf16 = ctx->train_bf16;
+  tl_xcd_bands = ctx->train_xcd_map ? 1 : 0;
   const std::string P = "object_encoder.pointnet.";
   const int ns[3] = {256, 128, 64}, cin[3] = {3, 64, 128}, h1[4] = {32, 128, 256, 512}, h2[4] = {64, 128, 256, 1024};
   const float radius[3] = {0.2f, 0.3f, 0.4f};
@@ -1010,6 +1011,7 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
   if (!grad_f2) return fail(ctx, T2L_EINVAL, "t2l_pointnet_backward: null gradient");
   const int n_obj = pt->n_obj;
   tl_gemm_bf16 = ctx->train_bf16;
+  tl_xcd_bands = ctx->train_xcd_map ? 1 : 0;
   const std::string P = "object_encoder.pointnet.";
   event_begin(ctx, "pointnet_train_backward", s);
   pt->ws_off = pt->scratch_off;

@@ -101,6 +101,7 @@ struct t2l_ctx {
                          // 4 = a quarter of the queries and half of the splits: -1.3 us of scan span at Q = 4096 x N = 11,259, measured)
   int search_pair = 1;   // mode 0: 1 = the paired scan (two waves per SIMD, scanp_kernel), 0 = scanh_kernel (one wave per SIMD)
   int train_bf16 = 0;       // 1: the training step's GEMMs round their operands to bf16 (one bf16 MFMA per 16-step); 2: split-bf16 (three)
+  int train_xcd_map = 0;      // 1 = the training step's tile GEMMs take their blocks in XCD bands (gemm_f32.h; measured slower in f32)
   int loss_single_wg = 0;     // 1 = t2l_contrastive_loss (B <= 128) as the single-workgroup kernel (A/B; default: 4 * ceil(B/32) workgroups)
   int train_gemm_block = 0;   // output block of the training step's tile GEMMs: 64 (2 x 2 tiles per wave: half the operand traffic), 32, or
                               // 0 = by measurement: 64 with bf16 / split-bf16 operands (0.555 -> 0.533 ms per step), 32 in f32 (0.640 vs 0.660)

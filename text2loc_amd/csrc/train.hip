@@ -113,10 +113,12 @@ static T* bump(TrainState* st, size_t count) {
 
 // ---- GEMM launchers -----------------------------------------------------------------------------------------
 static thread_local int tl_gemm_bf16 = 0;  // set from the context option "train_bf16" at the top of every forward / backward
+static thread_local int tl_xcd_bands = 0;  // option "train_xcd_map" = 1: the XCD bands of gemm_f32.h (A/B; measured slower in f32)
 static thread_local int tl_gemm_block64 = 0;  // option "train_gemm_block": 64 x 64 output blocks where the shape allows (default: with bf16 operands)
 static inline bool blk64(int rows_out_mult, int cols_out) { return tl_gemm_block64 && rows_out_mult % 64 == 0 && cols_out % 64 == 0; }
 // Y[M,N] = X[M,K] W[N,K]^T + b (relu)
-static void gemm_nt_args(const GemmArgs& g, hipStream_t s) {  // g.M rows (ragged allowed), g.N columns
+static void gemm_nt_args(GemmArgs g, hipStream_t s) {  // g.M rows (ragged allowed), g.N columns
+  g.xcd_bands = tl_xcd_bands;
   if (blk64(64, g.N))
     hipLaunchKernelGGL((gemm4_kernel<true, true>), dim3(g.N / 64, (g.M + 63) / 64, 1), dim3(256), 0, s, g);
   else
@@ -128,6 +130,7 @@ static void gemm_nt(const float* X, const float* W, const float* b, float* Y, in
 // dX[M,Kp] (+)= dY[M,N] W[N,Kp]
 static void gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kp, int accumulate, hipStream_t s) {
   GemmArgs g{dY, W, dX, nullptr, M, Kp, N, N, Kp, Kp, 0, accumulate, N, nullptr, tl_gemm_bf16};
+  g.xcd_bands = tl_xcd_bands;
   if (blk64(64, Kp))
     hipLaunchKernelGGL((gemm4_kernel<true, false>), dim3(Kp / 64, (M + 63) / 64, 1), dim3(256), 0, s, g);
   else
@@ -146,6 +149,7 @@ static void gemm_tn(const float* dY, const float* X, float* dW, float* db, int M
   int ksplit, kchunk;
   tn_split(M, N, Kp, b64 ? 64 : 32, ksplit, kchunk);
   GemmArgs g{dY, X, dW, nullptr, N, Kp, M, N, Kp, Kp, 0, 1, kchunk, db, tl_gemm_bf16};
+  g.xcd_bands = tl_xcd_bands;
   if (b64)
     hipLaunchKernelGGL((gemm4_kernel<false, false>), dim3(Kp / 64, N / 64, ksplit), dim3(256), 0, s, g);
   else
@@ -162,6 +166,7 @@ static void gemm_tn_nn(const float* dY, const float* X, float* dW, float* db, co
   GemmPair p{};
   p.tn = GemmArgs{dY, X, dW, nullptr, N, Kp, M, N, Kp, Kp, 0, 1, kchunk, db, tl_gemm_bf16};
   p.nn = GemmArgs{dY, W, dX, nullptr, M, Kp, N, N, Kp, Kp, 0, accumulate, N, nullptr, tl_gemm_bf16};
+  p.tn.xcd_bands = p.nn.xcd_bands = tl_xcd_bands;
   if (mask_src) {
     p.nn.epi = 2;
     p.nn.mask_src = mask_src;
@@ -400,6 +405,7 @@ static void small_branches_fwd(TrainState* st, const std::vector<int>& which, in
   hipLaunchKernelGGL(smallk_fwd_multi_kernel, dim3((M * 64 + 255) / 256, n), dim3(256), 0, s, sk);
   hipLaunchKernelGGL((bn_stats_multi_kernel<0>), dim3(1, (M + kBnRows - 1) / kBnRows, n), dim3(256), 0, s, b0);
   hipLaunchKernelGGL(bn_apply_fwd_multi_kernel, dim3((unsigned)(((size_t)M * 64 + 255) / 256), n), dim3(256), 0, s, b0);
+  gm.j[0].xcd_bands = tl_xcd_bands;
   hipLaunchKernelGGL((gemm_multi_kernel<true, true>), dim3(kTD / 32, (M + 31) / 32, n), dim3(256), 0, s, gm);
   hipLaunchKernelGGL((bn_stats_multi_kernel<0>), dim3(kTD / 64, (M + kBnRows - 1) / kBnRows, n), dim3(256), 0, s, b1);
   hipLaunchKernelGGL(bn_apply_fwd_multi_kernel, dim3((unsigned)(((size_t)M * kTD + 255) / 256), n), dim3(256), 0, s, b1);
@@ -455,6 +461,7 @@ static void small_branches_bwd(TrainState* st, const std::vector<int>& which, in
   hipLaunchKernelGGL(rownorm_bwd_multi_kernel, dim3((M + 3) / 4, n), dim3(256), 0, s, rn);
   hipLaunchKernelGGL((bn_stats_multi_kernel<1>), dim3(kTD / 64, (M + kBnRows - 1) / kBnRows, n), dim3(256), 0, s, b1);
   hipLaunchKernelGGL(bn_apply_bwd_multi_kernel, dim3((unsigned)(((size_t)M * kTD + 255) / 256), n), dim3(256), 0, s, b1);
+  gp.p[0].tn.xcd_bands = tl_xcd_bands;
   hipLaunchKernelGGL(gemm_pair_multi_kernel, dim3(pair_blocks, n), dim3(256), 0, s, gp);
   hipLaunchKernelGGL((bn_stats_multi_kernel<1>), dim3(1, (M + kBnRows - 1) / kBnRows, n), dim3(256), 0, s, b0);
   hipLaunchKernelGGL(bn_apply_bwd_multi_kernel, dim3((unsigned)(((size_t)M * 64 + 255) / 256), n), dim3(256), 0, s, b0);
@@ -486,6 +493,7 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
     st->ws_cap = need_bytes;
   }
   tl_gemm_bf16 = ctx->train_bf16;
+  tl_xcd_bands = ctx->train_xcd_map ? 1 : 0;
   tl_gemm_block64 = ctx->train_gemm_block == 64 || (ctx->train_gemm_block == 0 && ctx->train_bf16 != 0);
   st->ws_off = 0;
   st->have_forward = false;
@@ -644,6 +652,7 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   if (!grad_emb) return fail(ctx, T2L_EINVAL, "t2l_encode_cells_backward: null gradient");
   const int M = st->M, B = st->B, T = st->T, Kc = st->n_feat * kTD;
   tl_gemm_bf16 = ctx->train_bf16;
+  tl_xcd_bands = ctx->train_xcd_map ? 1 : 0;
   tl_gemm_block64 = ctx->train_gemm_block == 64 || (ctx->train_gemm_block == 0 && ctx->train_bf16 != 0);
   const size_t mark = st->ws_off;
   event_begin(ctx, "train_backward", s);

@@ -5,10 +5,11 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 from text2loc_amd import synth
 from text2loc_amd.engine import Engine
 
-def main(steps=30, B=64, streams=1, bf16=0, block=0):
+def main(steps=30, B=64, streams=1, bf16=0, block=0, xcd=0):
     eng = Engine(0)
     eng.set_option("train_bf16", bf16)
     if block: eng.set_option("train_gemm_block", block)
+    eng.set_option("train_xcd_map", xcd)
     sd = synth.make_object_branch_weights(0)
     cells = synth.make_cells(B, seed=9)
     tens = {}
@@ -30,7 +31,7 @@ def main(steps=30, B=64, streams=1, bf16=0, block=0):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(steps): step(10 + i)
     torch.cuda.synchronize()
-    print("steps", steps, "B", B, "bf16", bf16, "gemm block", block or "default", "ms/step", (time.perf_counter() - t0) / steps * 1e3)
+    print("steps", steps, "B", B, "bf16", bf16, "gemm block", block or "default", "xcd map", xcd, "ms/step", (time.perf_counter() - t0) / steps * 1e3)
 
 if __name__ == "__main__":
     main(*(int(a) for a in sys.argv[1:]))
