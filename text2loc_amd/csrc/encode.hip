@@ -948,15 +948,15 @@ int encode_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float* out, hipStream_
       (P.use_color && !P.color_embed && !in->rgb) || (P.use_pos && !in->center) || (P.use_num && !in->n_pts))
     return fail(ctx, T2L_EINVAL, "t2l_encode_cells: a per-object input required by the loaded config is NULL");
   const size_t lds = (size_t)(2 * kXFloats + 8) * sizeof(float);  // 66.6 KB: two cells per CU
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_done;
+  if (attr_done.need(ctx->device)) {
     T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_cells_kernel<1>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_cells_kernel<2>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_cells_kernel<0>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
+    attr_done.mark(ctx->device);
   }
   event_begin(ctx, "encode_cells", s);
   // encoder_f16 (option, off by default): ONE f16 product per operand pair instead of the three of the split form — embeddings

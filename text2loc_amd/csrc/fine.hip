@@ -607,12 +607,12 @@ int fine_match_impl(t2l_ctx* ctx, const float* cell_desc, const int32_t* cell_in
   if (n_hints < 1 || n_hints > kFHintMax) return fail(ctx, T2L_EINVAL, "t2l_fine_match: 1 <= n_hints <= 8");
   if (n_pairs == 0) return T2L_OK;
   const size_t lds = sizeof(float) * (3 * 32 * kFS + kPairs * kFD + kPairs * 64);  // 52 KB: three workgroups per CU
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  if (attr.need(ctx->device)) {
     T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fine_match_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fine_match_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fine_match_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
+    attr.mark(ctx->device);
   }
   const int n_wg = (n_pairs + kPairs - 1) / kPairs;
   const bool split = W->p.split_ok && !ctx->encoder_f32;

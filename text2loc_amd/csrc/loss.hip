@@ -510,21 +510,21 @@ int loss_impl(t2l_ctx* ctx, const float* a, const float* p, int B, float temp, f
   if (B > 128) return loss_big_impl(ctx, a, p, B, temp, loss, ga, gp, s);
   const int Bp = (B + 31) / 32 * 32;
   const size_t lds = ((size_t)Bp * (Bp + 1) + 5 * Bp + 4) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_done;
+  if (attr_done.need(ctx->device)) {
     T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&contrastive_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
-    attr_done = true;
+    attr_done.mark(ctx->device);
   }
   event_begin(ctx, "contrastive_loss", s);
   if (ctx->loss_single_wg) {
     hipLaunchKernelGGL(contrastive_kernel, dim3(1), dim3(256), lds, s, a, p, B, 1.0f / temp, loss, ga, gp);
   } else {
-    static bool attr2_done = false;
-    if (!attr2_done) {
+    static PerDeviceOnce attr2_done;
+    if (attr2_done.need(ctx->device)) {
       T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&contrastive_tiles_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-      attr2_done = true;
+      attr2_done.mark(ctx->device);
     }
     const size_t lds2 = (2 * (size_t)Bp * (Bp + 1) + 10 * Bp) * sizeof(float);
     hipLaunchKernelGGL(contrastive_tiles_kernel, dim3(ga ? 4 * (Bp / 32) : 1), dim3(256), lds2, s, a, p, B, 1.0f / temp, loss, ga, gp);

@@ -716,8 +716,10 @@ static size_t sa_lds_bytes() {
 template <int CIN, int H1, int H2, int NS>
 static hipError_t launch_sa(const SaParams& P, int n_obj, bool split, bool single, hipStream_t s) {
   const size_t lds = sa_lds_bytes<CIN, H1, H2, NS>();
-  static bool attr = false;
-  if (!attr) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  static PerDeviceOnce attr;
+  if (attr.need(dev)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_kernel<CIN, H1, H2, NS, 1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess)
@@ -727,7 +729,7 @@ static hipError_t launch_sa(const SaParams& P, int n_obj, bool split, bool singl
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_kernel<CIN, H1, H2, NS, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr = true;
+    attr.mark(dev);
   }
   if (split && single) hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, 2>), dim3(n_obj), dim3(256), lds, s, P);  // option encoder_f16
   else if (split) hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, 1>), dim3(n_obj), dim3(256), lds, s, P);
@@ -781,12 +783,12 @@ int pointnet_features_impl(t2l_ctx* ctx, const float* pos, const float* rgb, con
   T2L_HIP(ctx, (launch_sa<128, 256, 256, 64>(P, n_obj, split, ctx->encoder_f16 != 0, s)));
   {
     const size_t lds_h = sizeof(float) * (32 * (ga_k(true) + 4) + 32 * kGaHS), lds_f = sizeof(float) * (32 * (ga_k(false) + 4) + 32 * kGaHS);
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.need(ctx->device)) {
       T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
       T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
       T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-      attr = true;
+      attr.mark(ctx->device);
     }
     if (split && ctx->encoder_f16)
       hipLaunchKernelGGL(pn_ga_kernel<2>, dim3(n_obj), dim3(256), lds_h, s, p3, x3, W->ga1, W->ga2, W->ga1h, W->ga2h, W->gab2, f0, d_flags);

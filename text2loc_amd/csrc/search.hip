@@ -1411,9 +1411,12 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
     // counts VIRTUAL splits here: the kernel takes physical ones (2 virtual splits per workgroup)
     const dim3 grid((Q + kWideQPerBlock - 1) / kWideQPerBlock * (nsplit / 2));
     const size_t lds = (size_t)4 * 2 * kHalfTileBytes;
-    static bool once = (allow_lds(&scanp_kernel<LL, 4, false>, (size_t)4 * 2 * kHalfTileBytes),
-                        allow_lds(&scanp_kernel<LL, 4, true>, (size_t)4 * 2 * kHalfTileBytes), true);
-    (void)once;
+    static PerDeviceOnce once;
+    if (once.need(ctx->device)) {
+      allow_lds(&scanp_kernel<LL, 4, false>, (size_t)4 * 2 * kHalfTileBytes);
+      allow_lds(&scanp_kernel<LL, 4, true>, (size_t)4 * 2 * kHalfTileBytes);
+      once.mark(ctx->device);
+    }
     const bool prep = ctx->search_prep != 0;
     if (prep) {  // the f16 fragment plane of this call's queries, converted once (prep_queries_kernel) instead of by every workgroup
       const int q_pad = (Q + kWideQPerBlock - 1) / kWideQPerBlock * kWideQPerBlock;
@@ -1444,22 +1447,31 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
   if (ctx->eff_mode == 0) {  // f16 MFMA scan, one wave per SIMD (tiny shards, k > 10): 256 queries per workgroup
     const dim3 grid((Q + kWideQPerBlock - 1) / kWideQPerBlock * nsplit);
     const size_t lds = (size_t)4 * kHalfTileBytes;
-    static bool once = (allow_lds(&scanh_kernel<LL>, (size_t)4 * kHalfTileBytes), true);
-    (void)once;
+    static PerDeviceOnce once;
+    if (once.need(ctx->device)) {
+      allow_lds(&scanh_kernel<LL>, (size_t)4 * kHalfTileBytes);
+      once.mark(ctx->device);
+    }
     hipLaunchKernelGGL((scanh_kernel<LL>), grid, dim3(256), lds, s, dbh, n_rows, n_tiles, code_bits, q, Q, nsplit,
                        ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
   } else if (ctx->eff_mode == 2) {  // split-bf16 MFMA scan, same structure, three MFMAs per product
     const dim3 grid((Q + kWideQPerBlock - 1) / kWideQPerBlock * nsplit);
     const size_t lds = (size_t)4 * kTileFloats * sizeof(float);
-    static bool once = (allow_lds(&scanw_kernel<LL, 4>, (size_t)4 * kTileFloats * sizeof(float)), true);
-    (void)once;
+    static PerDeviceOnce once;
+    if (once.need(ctx->device)) {
+      allow_lds(&scanw_kernel<LL, 4>, (size_t)4 * kTileFloats * sizeof(float));
+      once.mark(ctx->device);
+    }
     hipLaunchKernelGGL((scanw_kernel<LL, 4>), grid, dim3(256), lds, s, dbs, n_rows, n_tiles, code_bits, q, Q, nsplit,
                        ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
   } else if constexpr (LL == L) {  // exact-f32 MFMA scan
     const dim3 grid((Q + kQPerBlock - 1) / kQPerBlock * nsplit);
     const size_t lds = scan_lds_bytes();
-    static bool once = (allow_lds(&scan_kernel<L>, scan_lds_bytes()), true);
-    (void)once;
+    static PerDeviceOnce once;
+    if (once.need(ctx->device)) {
+      allow_lds(&scan_kernel<L>, scan_lds_bytes());
+      once.mark(ctx->device);
+    }
     hipLaunchKernelGGL((scan_kernel<L>), grid, dim3(256), lds, s, db, n_rows, n_tiles, code_bits, q, Q, nsplit,
                        ctx->cand_score, ctx->fb_count, zero);
   }

@@ -238,10 +238,12 @@ int exact_stage_impl(t2l_ctx* ctx, const float* db, int n_rows, int row_offset, 
   int code_bits = 2;
   while ((1 << code_bits) < ((n_tiles + 3) / 4) * 4) ++code_bits;
   const size_t lds = (size_t)4 * 2 * kExactTileBytes;
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&exactd_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)4 * 2 * kExactTileBytes)),
-                      true);
-  (void)once;
+  static PerDeviceOnce once;
+  if (once.need(ctx->device)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&exactd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((size_t)4 * 2 * kExactTileBytes));
+    once.mark(ctx->device);
+  }
   int32_t* list3 = ctx->flags + (size_t)3 * Q;
   int32_t* list4 = ctx->flags + (size_t)4 * Q;
   event_begin(ctx, "search_exact", s);

@@ -353,11 +353,11 @@ static int stream_launch(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* ou
       (rc = grow_buf(ctx, (void**)&ctx->flags, &ctx->flag_cap, (size_t)Q * sizeof(int32_t))) != T2L_OK)
     return rc;
   const size_t lds = (size_t)4 * 2 * kHalfTileBytes;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_done;
+  if (attr_done.need(ctx->device)) {
     T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&scanq_kernel<L>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
+    attr_done.mark(ctx->device);
   }
   const float eps_rel = (float)(ctx->eps_scale * ((kD + 8) * 5.9604644775390625e-08 + 9.85e-4));  // f16 operands (search.hip)
   T2L_HIP(ctx, hipMemsetAsync(ctx->fb_count, 0, 2 * sizeof(int32_t), s));

@@ -202,6 +202,14 @@ int text_head_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const cha
 int text_head_impl(t2l_ctx* ctx, const float* hidden, int n_sentences, int n_tokens, float* out, int32_t* overflow, hipStream_t s);
 void free_text_head(t2l_ctx* ctx);
 // loss.hip
+// hipFuncSetAttribute applies to the CURRENT device's instance of a kernel, and one process may hold contexts on several GPUs: a call
+// site's "attribute set" flag is one bit per device (the callers are serialised per context, as everything in this library).
+struct PerDeviceOnce {
+  uint64_t done = 0;
+  bool need(int dev) const { return !((done >> (dev & 63)) & 1); }
+  void mark(int dev) { done |= 1ull << (dev & 63); }
+};
+
 int loss_impl(t2l_ctx* ctx, const float* a, const float* p, int B, float temp, float* loss, float* ga, float* gp,
               hipStream_t s);
 

@@ -658,15 +658,15 @@ int text_head_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const cha
   T2L_HIP(ctx, hipMemset(W->flag, 0, sizeof(int)));
   T2L_HIP(ctx, hipHostMalloc((void**)&W->flag_host, sizeof(int), hipHostMallocDefault));
   *W->flag_host = 0;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static PerDeviceOnce attr_done;
+  if (attr_done.need(ctx->device)) {
     const int lds = kSlots * kSlotBytes;
 #define T2L_TH_ATTR(E, S) T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&th_gemm_kernel<E, S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
     T2L_TH_ATTR(kEpiT32, false); T2L_TH_ATTR(kEpiT32, true); T2L_TH_ATTR(kEpiResidT32, false); T2L_TH_ATTR(kEpiResidT32, true);
     T2L_TH_ATTR(kEpiReluT16, false); T2L_TH_ATTR(kEpiReluT16, true); T2L_TH_ATTR(kEpiRowMajor, false); T2L_TH_ATTR(kEpiRowMajor, true);
 #undef T2L_TH_ATTR
     T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&th_ln_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1028 * 4));
-    attr_done = true;
+    attr_done.mark(ctx->device);
   }
   return T2L_OK;
 }
