@@ -111,8 +111,9 @@ def load_library() -> C.CDLL:
     return lib
 
 
-def _stream_ptr() -> int:
-    return int(torch.cuda.current_stream().cuda_stream)
+def _stream_ptr(device=None) -> int:
+    """torch's current stream ON THE ENGINE'S DEVICE (the current device may be another GPU of the same process)."""
+    return int(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _dev_ptr(t: Optional[torch.Tensor], dtype, name: str) -> Optional[int]:
@@ -196,7 +197,7 @@ class Engine:
             self._h, _dev_ptr(xyz, torch.float32, "xyz"), _dev_ptr(rgb, torch.float32, "rgb"),
             po.ctypes.data, n, cc.ctypes.data, cr.ctypes.data, len(cr),
             out["rgb"].data_ptr(), out["center"].data_ptr(), out["n_pts"].data_ptr(), out["color_idx"].data_ptr(),
-            _stream_ptr()))
+            _stream_ptr(self.device)))
         return out
 
     # ------------------------------------------------------------------ PointNet++ backbone (a3)
@@ -216,7 +217,7 @@ class Engine:
         self._check(self.lib.t2l_sample_object_points(self._h, _dev_ptr(xyz, torch.float32, "xyz"), _dev_ptr(rgb, torch.float32, "rgb"),
                                                       _dev_ptr(point_offsets, torch.int64, "point_offsets"), n, int(seed) & 0xFFFFFFFF,
                                                       POINT_TRANSFORMS[transform], float(rotate_deg), pos.data_ptr(), col.data_ptr(),
-                                                      _stream_ptr()))
+                                                      _stream_ptr(self.device)))
         return pos, col
 
     def pointnet_features(self, pos: torch.Tensor, rgb: torch.Tensor, cell_offsets) -> torch.Tensor:
@@ -229,7 +230,7 @@ class Engine:
                            f"{tuple(rgb.shape)}, {int(co[-1])}")
         out = torch.empty((n, EMBED_DIM), dtype=torch.float32, device=pos.device)
         self._check(self.lib.t2l_pointnet_features(self._h, _dev_ptr(pos, torch.float32, "pos"), _dev_ptr(rgb, torch.float32, "rgb"),
-                                                   co.ctypes.data, len(co) - 1, out.data_ptr(), _stream_ptr()))
+                                                   co.ctypes.data, len(co) - 1, out.data_ptr(), _stream_ptr(self.device)))
         return out
 
     # ------------------------------------------------------------------ cell encoding
@@ -249,7 +250,7 @@ class Engine:
             _dev_ptr(packed.get("rgb"), torch.float32, "rgb"), _dev_ptr(packed.get("center"), torch.float32, "center"),
             _dev_ptr(packed.get("n_pts"), torch.float32, "n_pts"),
             _dev_ptr(packed.get("pn_feat"), torch.float32, "pn_feat"))
-        self._check(self.lib.t2l_encode_cells(self._h, C.byref(pc), out.data_ptr(), _stream_ptr()))
+        self._check(self.lib.t2l_encode_cells(self._h, C.byref(pc), out.data_ptr(), _stream_ptr(self.device)))
         return out
 
     # ------------------------------------------------------------------ text head after T5 (f-4a)
@@ -279,7 +280,7 @@ class Engine:
         out = torch.empty((S, self._text_head_dim), dtype=torch.float32, device=hidden.device)
         flag = torch.zeros((1,), dtype=torch.int32, device=hidden.device)
         self._check(self.lib.t2l_text_head(self._h, _dev_ptr(hidden, torch.float32, "hidden"), S, L, out.data_ptr(), flag.data_ptr(),
-                                           _stream_ptr()))
+                                           _stream_ptr(self.device)))
         return (out, bool(flag.item())) if check else (out, flag)
 
     # ------------------------------------------------------------------ fine stage (f-1)
@@ -302,7 +303,7 @@ class Engine:
         """packed cells of exactly 16 objects each -> f32[n_cells,16,128] unit-row object descriptors."""
         pc = self._packed_struct(packed)
         out = torch.empty((pc.n_cells, 16, 128), dtype=torch.float32, device=packed["offsets"].device)
-        self._check(self.lib.t2l_fine_encode_objects(self._h, C.byref(pc), out.data_ptr(), _stream_ptr()))
+        self._check(self.lib.t2l_fine_encode_objects(self._h, C.byref(pc), out.data_ptr(), _stream_ptr(self.device)))
         return out
 
     def fine_match(self, cell_desc: torch.Tensor, hint_desc: torch.Tensor, cell_index: Optional[torch.Tensor] = None,
@@ -320,7 +321,7 @@ class Engine:
                                             _dev_ptr(cell_index, torch.int32, "cell_index"),
                                             _dev_ptr(hint_desc, torch.float32, "hint_desc"),
                                             _dev_ptr(hint_index, torch.int32, "hint_index"), n_pairs, int(hint_desc.shape[1]),
-                                            out.data_ptr(), _stream_ptr()))
+                                            out.data_ptr(), _stream_ptr(self.device)))
         return out
 
     # ------------------------------------------------------------------ training step (a9)
@@ -357,14 +358,14 @@ class Engine:
         pc = self._packed_struct(packed)
         out = torch.empty((pc.n_cells, EMBED_DIM), dtype=torch.float32, device=packed["offsets"].device)
         self._check(self.lib.t2l_encode_cells_train(self._h, C.byref(pc), float(dropout_p), int(seed) & 0xFFFFFFFF,
-                                                    out.data_ptr(), _stream_ptr()))
+                                                    out.data_ptr(), _stream_ptr(self.device)))
         self._train_inputs = packed  # the device arrays must outlive the backward call
         return out
 
     def encode_cells_backward(self, grad_emb: torch.Tensor, grad_pn_feat: Optional[torch.Tensor] = None):
         self._check(self.lib.t2l_encode_cells_backward(self._h, _dev_ptr(grad_emb, torch.float32, "grad_emb"),
                                                        _dev_ptr(grad_pn_feat, torch.float32, "grad_pn_feat"),
-                                                       _stream_ptr()))
+                                                       _stream_ptr(self.device)))
 
     def pointnet_features_train(self, pos: torch.Tensor, rgb: torch.Tensor, cell_offsets) -> torch.Tensor:
         """The PointNet++ backbone under model.train() (per-cell BatchNorm statistics, running statistics updated once per
@@ -378,39 +379,39 @@ class Engine:
         out = torch.empty((n, EMBED_DIM), dtype=torch.float32, device=pos.device)
         self._check(self.lib.t2l_pointnet_features_train(self._h, _dev_ptr(pos, torch.float32, "pos"),
                                                          _dev_ptr(rgb, torch.float32, "rgb"), co.ctypes.data, len(co) - 1,
-                                                         out.data_ptr(), _stream_ptr()))
+                                                         out.data_ptr(), _stream_ptr(self.device)))
         self._pn_train_inputs = (pos, rgb)
         return out
 
     def pointnet_backward(self, grad_features2: torch.Tensor):
         self._check(self.lib.t2l_pointnet_backward(self._h, _dev_ptr(grad_features2, torch.float32, "grad_features2"),
-                                                   _stream_ptr()))
+                                                   _stream_ptr(self.device)))
 
     def zero_grad(self):
-        self._check(self.lib.t2l_zero_grad(self._h, _stream_ptr()))
+        self._check(self.lib.t2l_zero_grad(self._h, _stream_ptr(self.device)))
 
     def adam_step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
-        self._check(self.lib.t2l_adam_step(self._h, float(lr), float(beta1), float(beta2), float(eps), _stream_ptr()))
+        self._check(self.lib.t2l_adam_step(self._h, float(lr), float(beta1), float(beta2), float(eps), _stream_ptr(self.device)))
 
     def adam_state(self):
         """(exp_avg f32[n], exp_avg_sq f32[n], step) of the engine-stepped tensors, flat in bind order (GPU tensors)."""
         n, step = C.c_int64(0), C.c_int64(0)
-        self._check(self.lib.t2l_adam_state(self._h, 0, None, None, C.byref(step), C.byref(n), _stream_ptr()))
+        self._check(self.lib.t2l_adam_state(self._h, 0, None, None, C.byref(step), C.byref(n), _stream_ptr(self.device)))
         dev = torch.device("cuda", self.device)
         m = torch.empty((int(n.value),), dtype=torch.float32, device=dev)
         v = torch.empty_like(m)
-        self._check(self.lib.t2l_adam_state(self._h, 0, m.data_ptr(), v.data_ptr(), C.byref(step), C.byref(n), _stream_ptr()))
+        self._check(self.lib.t2l_adam_state(self._h, 0, m.data_ptr(), v.data_ptr(), C.byref(step), C.byref(n), _stream_ptr(self.device)))
         return m, v, int(step.value)
 
     def set_adam_state(self, m: torch.Tensor, v: torch.Tensor, step: int):
         n, st = C.c_int64(0), C.c_int64(int(step))
-        self._check(self.lib.t2l_adam_state(self._h, 0, None, None, C.byref(C.c_int64(0)), C.byref(n), _stream_ptr()))
+        self._check(self.lib.t2l_adam_state(self._h, 0, None, None, C.byref(C.c_int64(0)), C.byref(n), _stream_ptr(self.device)))
         if int(m.numel()) != int(n.value) or int(v.numel()) != int(n.value):
             raise T2LError(f"adam state of {int(m.numel())} elements does not match the bound tensors ({int(n.value)})")
         dev = torch.device("cuda", self.device)
         m = m.to(dev, torch.float32).contiguous()
         v = v.to(dev, torch.float32).contiguous()
-        self._check(self.lib.t2l_adam_state(self._h, 1, m.data_ptr(), v.data_ptr(), C.byref(st), C.byref(n), _stream_ptr()))
+        self._check(self.lib.t2l_adam_state(self._h, 1, m.data_ptr(), v.data_ptr(), C.byref(st), C.byref(n), _stream_ptr(self.device)))
         torch.cuda.current_stream().synchronize()  # m, v may be temporaries
 
     # ------------------------------------------------------------------ database + search
@@ -424,7 +425,7 @@ class Engine:
         if emb.dim() != 2 or emb.shape[1] != EMBED_DIM:
             raise T2LError(f"db_set: expected [N,{EMBED_DIM}], got {tuple(emb.shape)}")
         ptr = _dev_ptr(emb, torch.float32, "db") if n > 0 else None
-        self._check(self.lib.t2l_db_set(self._h, ptr, n, int(row_offset), _stream_ptr()))
+        self._check(self.lib.t2l_db_set(self._h, ptr, n, int(row_offset), _stream_ptr(self.device)))
 
     @property
     def db_rows(self) -> int:
@@ -448,7 +449,7 @@ class Engine:
         qp = _dev_ptr(queries, torch.float32, "queries") if Q > 0 else None
         fn = self.lib.t2l_search_ordered if join else self.lib.t2l_search
         self._check(fn(self._h, qp, Q, int(k), _dev_ptr(idx, torch.int32, "out_idx"), _dev_ptr(sc, torch.float64, "out_score"),
-                       _stream_ptr()))
+                       _stream_ptr(self.device)))
         if join:
             self._lane_keepalive.clear()  # t2l_search_ordered joined whatever was pending
         else:
@@ -459,7 +460,7 @@ class Engine:
 
     def search_join(self):
         """Order every pipelined search issued so far into the current stream."""
-        self._check(self.lib.t2l_search_join(self._h, _stream_ptr()))
+        self._check(self.lib.t2l_search_join(self._h, _stream_ptr(self.device)))
         self._lane_keepalive.clear()
 
     def merge_topk(self, idx: torch.Tensor, score: torch.Tensor):
@@ -469,7 +470,7 @@ class Engine:
         out_s = torch.empty((Q, K), dtype=torch.float64, device=idx.device)
         self._check(self.lib.t2l_merge_topk(self._h, _dev_ptr(idx, torch.int32, "idx"),
                                             _dev_ptr(score, torch.float64, "score"), P, Q, K, out_i.data_ptr(),
-                                            out_s.data_ptr(), _stream_ptr()))
+                                            out_s.data_ptr(), _stream_ptr(self.device)))
         return out_i, out_s
 
     def pack_pairs(self, idx: torch.Tensor, score: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -477,7 +478,7 @@ class Engine:
         Q, K = (int(x) for x in idx.shape)
         pairs = out if out is not None else torch.empty((Q, K, 2), dtype=torch.float64, device=idx.device)
         self._check(self.lib.t2l_pack_pairs(self._h, _dev_ptr(idx, torch.int32, "idx"),
-                                            _dev_ptr(score, torch.float64, "score"), Q, K, pairs.data_ptr(), _stream_ptr()))
+                                            _dev_ptr(score, torch.float64, "score"), Q, K, pairs.data_ptr(), _stream_ptr(self.device)))
         return pairs
 
     def merge_pairs(self, pairs: torch.Tensor):
@@ -486,7 +487,7 @@ class Engine:
         out_i = torch.empty((Q, K), dtype=torch.int32, device=pairs.device)
         out_s = torch.empty((Q, K), dtype=torch.float64, device=pairs.device)
         self._check(self.lib.t2l_merge_pairs(self._h, _dev_ptr(pairs, torch.float64, "pairs"), P, Q, K, out_i.data_ptr(),
-                                             out_s.data_ptr(), _stream_ptr()))
+                                             out_s.data_ptr(), _stream_ptr(self.device)))
         return out_i, out_s
 
     @staticmethod
@@ -508,7 +509,7 @@ class Engine:
         else:
             out_i, out_s = out
         self._check(self.lib.t2l_merge_gathered(self._h, _dev_ptr(blocks, torch.uint8, "blocks"), int(block_bytes), int(score_offset),
-                                                int(parts), int(Q), int(k), out_i.data_ptr(), out_s.data_ptr(), _stream_ptr()))
+                                                int(parts), int(Q), int(k), out_i.data_ptr(), out_s.data_ptr(), _stream_ptr(self.device)))
         return out_i, out_s
 
     def search_fallbacks(self) -> int:
@@ -539,7 +540,7 @@ class Engine:
         self._check(self.lib.t2l_contrastive_loss(
             self._h, _dev_ptr(anchor, torch.float32, "anchor"), _dev_ptr(positive, torch.float32, "positive"), B,
             float(temperature), loss.data_ptr(), _dev_ptr(ga, torch.float32, "ga"), _dev_ptr(gp, torch.float32, "gp"),
-            _stream_ptr()))
+            _stream_ptr(self.device)))
         return loss, ga, gp
 
     # ------------------------------------------------------------------ knobs
