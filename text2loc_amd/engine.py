@@ -129,6 +129,12 @@ def _dev_ptr(t: Optional[torch.Tensor], dtype, name: str) -> Optional[int]:
 class Engine:
     """One context per GPU (one process per GPU)."""
 
+    def _ptr(self, t: Optional[torch.Tensor], dtype, name: str) -> Optional[int]:
+        """Device pointer of a contiguous tensor of ``dtype`` that lives on THIS engine's GPU (anything else raises)."""
+        if t is not None and t.is_cuda and t.device.index != self.device:
+            raise T2LError(f"{name}: tensor is on cuda:{t.device.index}, this engine drives cuda:{self.device}")
+        return _dev_ptr(t, dtype, name)
+
     def __init__(self, device: Optional[int] = None):
         self.lib = load_library()
         if not torch.cuda.is_available():
@@ -194,7 +200,7 @@ class Engine:
         cc = np.ascontiguousarray(color_centers, dtype=np.float32)
         cr = np.ascontiguousarray(color_rows, dtype=np.int32)
         self._check(self.lib.t2l_reduce_objects(
-            self._h, _dev_ptr(xyz, torch.float32, "xyz"), _dev_ptr(rgb, torch.float32, "rgb"),
+            self._h, self._ptr(xyz, torch.float32, "xyz"), self._ptr(rgb, torch.float32, "rgb"),
             po.ctypes.data, n, cc.ctypes.data, cr.ctypes.data, len(cr),
             out["rgb"].data_ptr(), out["center"].data_ptr(), out["n_pts"].data_ptr(), out["color_idx"].data_ptr(),
             _stream_ptr(self.device)))
@@ -214,8 +220,8 @@ class Engine:
         n = int(point_offsets.numel()) - 1
         pos = torch.empty((max(n, 0), 256, 3), dtype=torch.float32, device=xyz.device)
         col = torch.empty_like(pos)
-        self._check(self.lib.t2l_sample_object_points(self._h, _dev_ptr(xyz, torch.float32, "xyz"), _dev_ptr(rgb, torch.float32, "rgb"),
-                                                      _dev_ptr(point_offsets, torch.int64, "point_offsets"), n, int(seed) & 0xFFFFFFFF,
+        self._check(self.lib.t2l_sample_object_points(self._h, self._ptr(xyz, torch.float32, "xyz"), self._ptr(rgb, torch.float32, "rgb"),
+                                                      self._ptr(point_offsets, torch.int64, "point_offsets"), n, int(seed) & 0xFFFFFFFF,
                                                       POINT_TRANSFORMS[transform], float(rotate_deg), pos.data_ptr(), col.data_ptr(),
                                                       _stream_ptr(self.device)))
         return pos, col
@@ -229,7 +235,7 @@ class Engine:
             raise T2LError(f"pointnet_features: expected [n,256,3] points and offsets ending at n, got {tuple(pos.shape)}, "
                            f"{tuple(rgb.shape)}, {int(co[-1])}")
         out = torch.empty((n, EMBED_DIM), dtype=torch.float32, device=pos.device)
-        self._check(self.lib.t2l_pointnet_features(self._h, _dev_ptr(pos, torch.float32, "pos"), _dev_ptr(rgb, torch.float32, "rgb"),
+        self._check(self.lib.t2l_pointnet_features(self._h, self._ptr(pos, torch.float32, "pos"), self._ptr(rgb, torch.float32, "rgb"),
                                                    co.ctypes.data, len(co) - 1, out.data_ptr(), _stream_ptr(self.device)))
         return out
 
@@ -244,12 +250,12 @@ class Engine:
         if n_cells <= 0:
             return out
         pc = _PackedCells(
-            n_cells, n_obj, _dev_ptr(offsets, torch.int32, "offsets"),
-            _dev_ptr(packed.get("class_idx"), torch.int32, "class_idx"),
-            _dev_ptr(packed.get("color_idx"), torch.int32, "color_idx"),
-            _dev_ptr(packed.get("rgb"), torch.float32, "rgb"), _dev_ptr(packed.get("center"), torch.float32, "center"),
-            _dev_ptr(packed.get("n_pts"), torch.float32, "n_pts"),
-            _dev_ptr(packed.get("pn_feat"), torch.float32, "pn_feat"))
+            n_cells, n_obj, self._ptr(offsets, torch.int32, "offsets"),
+            self._ptr(packed.get("class_idx"), torch.int32, "class_idx"),
+            self._ptr(packed.get("color_idx"), torch.int32, "color_idx"),
+            self._ptr(packed.get("rgb"), torch.float32, "rgb"), self._ptr(packed.get("center"), torch.float32, "center"),
+            self._ptr(packed.get("n_pts"), torch.float32, "n_pts"),
+            self._ptr(packed.get("pn_feat"), torch.float32, "pn_feat"))
         self._check(self.lib.t2l_encode_cells(self._h, C.byref(pc), out.data_ptr(), _stream_ptr(self.device)))
         return out
 
@@ -279,7 +285,7 @@ class Engine:
         S, L = int(hidden.shape[0]), int(hidden.shape[1])
         out = torch.empty((S, self._text_head_dim), dtype=torch.float32, device=hidden.device)
         flag = torch.zeros((1,), dtype=torch.int32, device=hidden.device)
-        self._check(self.lib.t2l_text_head(self._h, _dev_ptr(hidden, torch.float32, "hidden"), S, L, out.data_ptr(), flag.data_ptr(),
+        self._check(self.lib.t2l_text_head(self._h, self._ptr(hidden, torch.float32, "hidden"), S, L, out.data_ptr(), flag.data_ptr(),
                                            _stream_ptr(self.device)))
         return (out, bool(flag.item())) if check else (out, flag)
 
@@ -317,10 +323,10 @@ class Engine:
         if cell_desc.shape[1:] != (16, 128) or hint_desc.shape[2] != 128:
             raise T2LError(f"fine_match: expected [*,16,128] and [*,n_hints,128], got {tuple(cell_desc.shape)}, {tuple(hint_desc.shape)}")
         out = torch.empty((n_pairs, 2), dtype=torch.float32, device=cell_desc.device)
-        self._check(self.lib.t2l_fine_match(self._h, _dev_ptr(cell_desc, torch.float32, "cell_desc"),
-                                            _dev_ptr(cell_index, torch.int32, "cell_index"),
-                                            _dev_ptr(hint_desc, torch.float32, "hint_desc"),
-                                            _dev_ptr(hint_index, torch.int32, "hint_index"), n_pairs, int(hint_desc.shape[1]),
+        self._check(self.lib.t2l_fine_match(self._h, self._ptr(cell_desc, torch.float32, "cell_desc"),
+                                            self._ptr(cell_index, torch.int32, "cell_index"),
+                                            self._ptr(hint_desc, torch.float32, "hint_desc"),
+                                            self._ptr(hint_index, torch.int32, "hint_index"), n_pairs, int(hint_desc.shape[1]),
                                             out.data_ptr(), _stream_ptr(self.device)))
         return out
 
@@ -330,12 +336,12 @@ class Engine:
         n_cells = int(offsets.numel()) - 1
         n_obj = int(packed["n_pts"].numel()) if packed.get("n_pts") is not None else int(packed["class_idx"].numel())
         return _PackedCells(
-            n_cells, n_obj, _dev_ptr(offsets, torch.int32, "offsets"),
-            _dev_ptr(packed.get("class_idx"), torch.int32, "class_idx"),
-            _dev_ptr(packed.get("color_idx"), torch.int32, "color_idx"),
-            _dev_ptr(packed.get("rgb"), torch.float32, "rgb"), _dev_ptr(packed.get("center"), torch.float32, "center"),
-            _dev_ptr(packed.get("n_pts"), torch.float32, "n_pts"),
-            _dev_ptr(packed.get("pn_feat"), torch.float32, "pn_feat"))
+            n_cells, n_obj, self._ptr(offsets, torch.int32, "offsets"),
+            self._ptr(packed.get("class_idx"), torch.int32, "class_idx"),
+            self._ptr(packed.get("color_idx"), torch.int32, "color_idx"),
+            self._ptr(packed.get("rgb"), torch.float32, "rgb"), self._ptr(packed.get("center"), torch.float32, "center"),
+            self._ptr(packed.get("n_pts"), torch.float32, "n_pts"),
+            self._ptr(packed.get("pn_feat"), torch.float32, "pn_feat"))
 
     def train_bind(self, tensors: Dict[str, Tuple[torch.Tensor, Optional[torch.Tensor]]], class_embed: bool,
                    color_embed: bool, use_features=("class", "color", "position", "num"), num_layers: int = 2,
@@ -345,8 +351,8 @@ class Engine:
         descs, keep = [], []
         for name, (data, grad) in tensors.items():
             keep.append((data, grad))
-            descs.append(_TrainTensor(name.encode(), _dev_ptr(data, torch.float32, name),
-                                      _dev_ptr(grad, torch.float32, name + ".grad"), data.numel()))
+            descs.append(_TrainTensor(name.encode(), self._ptr(data, torch.float32, name),
+                                      self._ptr(grad, torch.float32, name + ".grad"), data.numel()))
         arr = (_TrainTensor * len(descs))(*descs)
         cfg = _ModelConfig(int(class_embed), int(color_embed), int("class" in use_features),
                            int("color" in use_features), int("position" in use_features), int("num" in use_features),
@@ -363,8 +369,8 @@ class Engine:
         return out
 
     def encode_cells_backward(self, grad_emb: torch.Tensor, grad_pn_feat: Optional[torch.Tensor] = None):
-        self._check(self.lib.t2l_encode_cells_backward(self._h, _dev_ptr(grad_emb, torch.float32, "grad_emb"),
-                                                       _dev_ptr(grad_pn_feat, torch.float32, "grad_pn_feat"),
+        self._check(self.lib.t2l_encode_cells_backward(self._h, self._ptr(grad_emb, torch.float32, "grad_emb"),
+                                                       self._ptr(grad_pn_feat, torch.float32, "grad_pn_feat"),
                                                        _stream_ptr(self.device)))
 
     def pointnet_features_train(self, pos: torch.Tensor, rgb: torch.Tensor, cell_offsets) -> torch.Tensor:
@@ -377,14 +383,14 @@ class Engine:
             raise T2LError(f"pointnet_features_train: expected [n,256,3] points and offsets ending at n, got {tuple(pos.shape)}, "
                            f"{tuple(rgb.shape)}, {int(co[-1])}")
         out = torch.empty((n, EMBED_DIM), dtype=torch.float32, device=pos.device)
-        self._check(self.lib.t2l_pointnet_features_train(self._h, _dev_ptr(pos, torch.float32, "pos"),
-                                                         _dev_ptr(rgb, torch.float32, "rgb"), co.ctypes.data, len(co) - 1,
+        self._check(self.lib.t2l_pointnet_features_train(self._h, self._ptr(pos, torch.float32, "pos"),
+                                                         self._ptr(rgb, torch.float32, "rgb"), co.ctypes.data, len(co) - 1,
                                                          out.data_ptr(), _stream_ptr(self.device)))
         self._pn_train_inputs = (pos, rgb)
         return out
 
     def pointnet_backward(self, grad_features2: torch.Tensor):
-        self._check(self.lib.t2l_pointnet_backward(self._h, _dev_ptr(grad_features2, torch.float32, "grad_features2"),
+        self._check(self.lib.t2l_pointnet_backward(self._h, self._ptr(grad_features2, torch.float32, "grad_features2"),
                                                    _stream_ptr(self.device)))
 
     def zero_grad(self):
@@ -424,7 +430,7 @@ class Engine:
         n = int(emb.shape[0])
         if emb.dim() != 2 or emb.shape[1] != EMBED_DIM:
             raise T2LError(f"db_set: expected [N,{EMBED_DIM}], got {tuple(emb.shape)}")
-        ptr = _dev_ptr(emb, torch.float32, "db") if n > 0 else None
+        ptr = self._ptr(emb, torch.float32, "db") if n > 0 else None
         self._check(self.lib.t2l_db_set(self._h, ptr, n, int(row_offset), _stream_ptr(self.device)))
 
     @property
@@ -446,9 +452,9 @@ class Engine:
             sc = torch.empty((Q, k), dtype=torch.float64, device=queries.device)
         else:
             idx, sc = out
-        qp = _dev_ptr(queries, torch.float32, "queries") if Q > 0 else None
+        qp = self._ptr(queries, torch.float32, "queries") if Q > 0 else None
         fn = self.lib.t2l_search_ordered if join else self.lib.t2l_search
-        self._check(fn(self._h, qp, Q, int(k), _dev_ptr(idx, torch.int32, "out_idx"), _dev_ptr(sc, torch.float64, "out_score"),
+        self._check(fn(self._h, qp, Q, int(k), self._ptr(idx, torch.int32, "out_idx"), self._ptr(sc, torch.float64, "out_score"),
                        _stream_ptr(self.device)))
         if join:
             self._lane_keepalive.clear()  # t2l_search_ordered joined whatever was pending
@@ -468,8 +474,8 @@ class Engine:
         P, Q, K = (int(x) for x in idx.shape)
         out_i = torch.empty((Q, K), dtype=torch.int32, device=idx.device)
         out_s = torch.empty((Q, K), dtype=torch.float64, device=idx.device)
-        self._check(self.lib.t2l_merge_topk(self._h, _dev_ptr(idx, torch.int32, "idx"),
-                                            _dev_ptr(score, torch.float64, "score"), P, Q, K, out_i.data_ptr(),
+        self._check(self.lib.t2l_merge_topk(self._h, self._ptr(idx, torch.int32, "idx"),
+                                            self._ptr(score, torch.float64, "score"), P, Q, K, out_i.data_ptr(),
                                             out_s.data_ptr(), _stream_ptr(self.device)))
         return out_i, out_s
 
@@ -477,8 +483,8 @@ class Engine:
         """(idx i32[Q,K], score f64[Q,K]) -> f64[Q,K,2] records {score, row id}: one buffer for one collective."""
         Q, K = (int(x) for x in idx.shape)
         pairs = out if out is not None else torch.empty((Q, K, 2), dtype=torch.float64, device=idx.device)
-        self._check(self.lib.t2l_pack_pairs(self._h, _dev_ptr(idx, torch.int32, "idx"),
-                                            _dev_ptr(score, torch.float64, "score"), Q, K, pairs.data_ptr(), _stream_ptr(self.device)))
+        self._check(self.lib.t2l_pack_pairs(self._h, self._ptr(idx, torch.int32, "idx"),
+                                            self._ptr(score, torch.float64, "score"), Q, K, pairs.data_ptr(), _stream_ptr(self.device)))
         return pairs
 
     def merge_pairs(self, pairs: torch.Tensor):
@@ -486,7 +492,7 @@ class Engine:
         P, Q, K, _ = (int(x) for x in pairs.shape)
         out_i = torch.empty((Q, K), dtype=torch.int32, device=pairs.device)
         out_s = torch.empty((Q, K), dtype=torch.float64, device=pairs.device)
-        self._check(self.lib.t2l_merge_pairs(self._h, _dev_ptr(pairs, torch.float64, "pairs"), P, Q, K, out_i.data_ptr(),
+        self._check(self.lib.t2l_merge_pairs(self._h, self._ptr(pairs, torch.float64, "pairs"), P, Q, K, out_i.data_ptr(),
                                              out_s.data_ptr(), _stream_ptr(self.device)))
         return out_i, out_s
 
@@ -508,7 +514,7 @@ class Engine:
             out_s = torch.empty((Q, k), dtype=torch.float64, device=blocks.device)
         else:
             out_i, out_s = out
-        self._check(self.lib.t2l_merge_gathered(self._h, _dev_ptr(blocks, torch.uint8, "blocks"), int(block_bytes), int(score_offset),
+        self._check(self.lib.t2l_merge_gathered(self._h, self._ptr(blocks, torch.uint8, "blocks"), int(block_bytes), int(score_offset),
                                                 int(parts), int(Q), int(k), out_i.data_ptr(), out_s.data_ptr(), _stream_ptr(self.device)))
         return out_i, out_s
 
@@ -538,8 +544,8 @@ class Engine:
         ga = torch.empty_like(anchor) if need_grad else None
         gp = torch.empty_like(positive) if need_grad else None
         self._check(self.lib.t2l_contrastive_loss(
-            self._h, _dev_ptr(anchor, torch.float32, "anchor"), _dev_ptr(positive, torch.float32, "positive"), B,
-            float(temperature), loss.data_ptr(), _dev_ptr(ga, torch.float32, "ga"), _dev_ptr(gp, torch.float32, "gp"),
+            self._h, self._ptr(anchor, torch.float32, "anchor"), self._ptr(positive, torch.float32, "positive"), B,
+            float(temperature), loss.data_ptr(), self._ptr(ga, torch.float32, "ga"), self._ptr(gp, torch.float32, "gp"),
             _stream_ptr(self.device)))
         return loss, ga, gp
 
