@@ -170,10 +170,10 @@ def _fine_worker(rank, world, port, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_run_fine_sharded_equals_single_process(world):
-    """The distinct retrieved cells (37 -> blocks of 19/18 or 10/10/10/7) and the 530 (pose, cell) pairs are split across the
-    ranks and all-gathered once each: accuracies AND every offset equal the single-process run bit for bit."""
+    """The distinct retrieved cells (37 -> blocks of 19/18, 10/10/10/7 or 5/5/5/5/5/4/4/4 — BASELINE config 5 names 8 GPUs) and the
+    530 (pose, cell) pairs are split across the ranks and all-gathered once each: accuracies AND every offset equal the single-process run bit for bit."""
     from text2loc_amd.cross_matcher import run_fine
 
     ctx = mp.get_context("spawn")
