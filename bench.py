@@ -357,6 +357,13 @@ def secondary_measurements(eng):
         out["search_clustered"] = clustered_measure(eng, packed)
     except Exception as e:
         out["search_clustered"] = {"error": repr(e)}
+    # the same step across data distributions: >= 6 tightness points between the headline's unit-Gaussian rows and the
+    # one-direction database, plus a database produced by a TRAINED encoder over overlapping cells (bench_distribution.py)
+    try:
+        import bench_distribution
+        out["search_distribution"] = bench_distribution.measure(N_CELLS, N_QUERIES, TOPK, quick=_QUICK)
+    except Exception as e:
+        out["search_distribution"] = {"error": repr(e)}
     # latency of small query batches against the resident DB (the reference answers one query at a time)
     lat = {}
     eng.set_option("profile_events", 0)  # (an event pair costs ~6 us per kernel: not inside a latency measurement)

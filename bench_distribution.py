@@ -1,0 +1,240 @@
+"""bench.py -> secondary.search_distribution: the search step across DATA DISTRIBUTIONS.
+
+The headline workload (unit-Gaussian rows + planted positives) is the most benign input the certificates can meet; the only
+encoder-produced database measured so far (an UNTRAINED encoder: every row within 1e-3 of one direction) is the worst. This
+module measures the points in between on the same N x Q x K:
+
+* ``tightness``: DB = normalize(alpha * centroid_c + unit noise), C clusters, alpha from 0 (unit-Gaussian) up to the
+  one-direction-1e-3 database; queries = normalize(row + 0.25 * spread * unit noise) as in ``search_clustered``;
+* ``trained``: a database produced by a TRAINED encoder over OVERLAPPING cells — a synthetic trajectory (30 m cells every 10 m,
+  objects shared by neighbouring cells, cell-relative object centres: dataloading/kitti360pose/cells.py's geometry) whose text
+  side is a planted embedding of six hinted objects per pose (class + colour + direction codes, dataloading/kitti360pose/
+  base.py:60-68); the engine's own training step (t2l_encode_cells_train -> t2l_contrastive_loss -> backward -> Adam) runs a few
+  thousand steps against it, then the eval-mode encoder builds the DB and held-out poses of the same cells are the queries.
+
+Per point: share of queries whose first certificate failed, share that ended in an exact float64 stage, which scan the auto mode
+settled on, ms per step, recall@1 of the planted target, ids == the float64 C oracle on a sample. Test infrastructure: the oracle
+is only the checker here (outside every timed region).
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from text2loc_amd import synth
+from text2loc_amd.engine import Engine
+
+DIM = 256
+
+
+def _measure_point(e2, dbc, q, target, topk, reps, oracle_sample=8):
+    from oracle import c_oracle
+
+    n_q = len(q)
+    dq = torch.from_numpy(np.ascontiguousarray(q)).cuda()
+    e2.set_option("search_auto", 0)  # forget the previous database's report card
+    e2.set_option("search_auto", 1)
+    e2.db_set(torch.from_numpy(np.ascontiguousarray(dbc)).cuda())
+    for _ in range(8):  # the auto mode settles on a scan / the heavy stage within a few calls
+        e2.search(dq, topk)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        gi, gs = e2.search(dq, topk)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    cnt = e2.search_counters()
+    flagged = e2.search_rescored()
+    exact = cnt["valu_exact_scans"] + cnt["deferred_to_mfma_exact"]
+    sel = np.arange(0, n_q, oracle_sample)
+    ridx, _ = c_oracle.retrieve_topk(np.ascontiguousarray(dbc), np.ascontiguousarray(q[sel]), topk)
+    ids = gi.cpu().numpy().astype(np.int64)
+    # stock-library comparator on the same GPU and data: rocBLAS f32 mm + torch.topk (an f32 ranking, not the float64 one)
+    d_db = torch.from_numpy(np.ascontiguousarray(dbc)).cuda()
+    for _ in range(3):
+        torch.topk(dq @ d_db.t(), topk, dim=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ti = torch.topk(dq @ d_db.t(), topk, dim=1)[1]
+    torch.cuda.synchronize()
+    dt_torch = (time.perf_counter() - t0) / reps
+    # top-10 score spacing: how far apart the float64 scores around the cut are (what the error bands have to resolve)
+    sc = gs.cpu().numpy()
+    gap = np.median(sc[:, topk - 2] - sc[:, topk - 1]) if topk >= 2 else float("nan")
+    return {"ms_per_step": dt * 1e3, "queries_per_s": n_q / dt,
+            "first_certificate_failed_share": flagged / n_q, "exact_stage_share": exact / n_q,
+            "counters": cnt,
+            "recall_at_1_planted": float((ids[:, 0] == target).mean()) if target is not None else None,
+            "median_gap_rank9_to_rank10": float(gap),
+            "ids_equal_float64_oracle_on_sample": bool(np.array_equal(ids[sel], ridx)), "sample": int(len(sel)),
+            "torch_mm_topk_f32_same_gpu_ms": dt_torch * 1e3,
+            "torch_f32_ranking_ids_equal_ours_share": float((ti.cpu().numpy() == ids).all(axis=1).mean())}
+
+
+def tightness_points(n_cells, n_queries, topk, quick=False):
+    out = []
+    rs = np.random.default_rng(31)
+    e2 = Engine(torch.cuda.current_device())
+    C = 64
+    cent = synth.unit_rows(rs.standard_normal((C, DIM)))
+    noise = synth.unit_rows(rs.standard_normal((n_cells, DIM)))
+    member = rs.integers(0, C, size=n_cells)
+    cases = [("unit_gaussian", 0.0, C), ("alpha_1", 1.0, C), ("alpha_3", 3.0, C), ("alpha_10", 10.0, C), ("alpha_30", 30.0, C),
+             ("alpha_100", 100.0, C), ("alpha_300", 300.0, C), ("one_direction_1e-3", 1000.0, 1)]
+    for name, alpha, c_n in cases:
+        cc = cent[member] if c_n > 1 else cent[:1]
+        dbc = synth.unit_rows(alpha * cc + noise).astype(np.float32)
+        tgt = rs.integers(0, n_cells, size=n_queries)
+        spread = float(np.linalg.norm(dbc - cc * (dbc * cc).sum(1, keepdims=True), axis=1).mean()) if alpha > 0 else 1.0
+        q = synth.unit_rows(dbc[tgt].astype(np.float64) + 0.25 * spread * synth.unit_rows(rs.standard_normal((n_queries, DIM)))).astype(np.float32)
+        r = _measure_point(e2, dbc, q, tgt, topk, 4 if quick else 10)
+        r.update({"name": name, "alpha": alpha, "clusters": c_n, "mean_distance_to_own_centroid": spread})
+        out.append(r)
+    e2.close()
+    return out
+
+
+# ---- the trained database -------------------------------------------------------------------------------------------------------
+def make_trajectory_cells(n_cells, seed=0, cell_m=30.0, stride_m=10.0, density=0.6):
+    """Overlapping cells along one synthetic trajectory: objects at global positions x ~ U[0, L), a cell = the objects inside
+    [i*stride, i*stride + cell), centres in the cell's own frame ([0,1]^3, as the reference normalises them). Returns the packed
+    SoA dict of ``synth.make_cells`` plus ``global_obj`` (the global object index of every packed object)."""
+    rng = np.random.default_rng([seed, 0x7247])
+    length = (n_cells - 1) * stride_m + cell_m
+    n_obj = int(length * density)
+    gx = np.sort(rng.uniform(0, length, size=n_obj))
+    gy, gz = rng.uniform(0, 1, size=n_obj), rng.uniform(0, 1, size=n_obj)
+    g_class = rng.integers(1, len(synth.KNOWN_CLASS) + 1, size=n_obj).astype(np.int32)
+    g_rgb = rng.uniform(0, 1, size=(n_obj, 3))
+    sigma2 = np.log(1.0 + (synth.NUM_STD / synth.NUM_MEAN) ** 2)
+    mu = np.log(synth.NUM_MEAN) - 0.5 * sigma2
+    g_npts = np.clip(np.round(rng.lognormal(mu, np.sqrt(sigma2), size=n_obj)), 25, 60000)
+    lo = np.searchsorted(gx, np.arange(n_cells) * stride_m, side="left")
+    hi = np.searchsorted(gx, np.arange(n_cells) * stride_m + cell_m, side="left")
+    hi = np.maximum(hi, lo + 1)
+    counts = (hi - lo).astype(np.int32)
+    offsets = np.zeros(n_cells + 1, dtype=np.int32)
+    np.cumsum(counts, out=offsets[1:])
+    gidx = np.concatenate([np.arange(a, b) for a, b in zip(lo, hi)])
+    cell_of = np.repeat(np.arange(n_cells), counts)
+    center = np.stack([(gx[gidx] - cell_of * stride_m) / cell_m, gy[gidx], gz[gidx]], axis=1)
+    cells = {"counts": counts, "offsets": offsets, "class_idx": g_class[gidx],
+             "color_idx": synth.color_name_to_embed_index(synth.nearest_color_index(g_rgb[gidx])).astype(np.int32),
+             "rgb": g_rgb[gidx].astype(np.float32), "center": center.astype(np.float32), "n_pts": g_npts[gidx].astype(np.float32)}
+    return cells, gidx
+
+
+def planted_text(cells, gidx, seed, n_hints=6):
+    """One pose per cell (at the cell centre) described by ``n_hints`` of its objects: t = normalize(sum of class code + colour
+    code + direction code), direction = quadrant of the object's centre relative to the pose (base.py:60-68's template slots)."""
+    rng = np.random.default_rng([seed, 0x7E87])
+    code = np.random.default_rng(0xC0DE)
+    e_cls = code.standard_normal((len(synth.KNOWN_CLASS) + 1, DIM))
+    e_col = code.standard_normal((16, DIM))
+    e_dir = code.standard_normal((5, DIM))
+    for e in (e_cls, e_col, e_dir):  # centred codebooks: two unrelated descriptions are orthogonal in expectation
+        e -= e.mean(0, keepdims=True)
+    n = len(cells["counts"])
+    t = np.zeros((n, DIM))
+    for i in range(n):
+        a, b = int(cells["offsets"][i]), int(cells["offsets"][i + 1])
+        pick = a + rng.choice(b - a, size=min(n_hints, b - a), replace=False)
+        c = cells["center"][pick] - 0.5
+        d = np.where(np.abs(c[:, 0]) + np.abs(c[:, 1]) < 0.1, 4, np.where(np.abs(c[:, 0]) > np.abs(c[:, 1]), (c[:, 0] > 0).astype(int), 2 + (c[:, 1] > 0).astype(int)))
+        t[i] = (e_cls[cells["class_idx"][pick]] + e_col[cells["color_idx"][pick]] + e_dir[d]).sum(0)
+    t -= t.mean(0, keepdims=True)  # (colour / direction usage is not uniform: remove what every description shares)
+    return synth.unit_rows(t).astype(np.float32)
+
+
+def _subset(cells, rows):
+    """Packed SoA of the cells ``rows`` (host gather)."""
+    cnt = cells["counts"][rows]
+    off = np.zeros(len(rows) + 1, dtype=np.int32)
+    np.cumsum(cnt, out=off[1:])
+    idx = np.concatenate([np.arange(cells["offsets"][r], cells["offsets"][r + 1]) for r in rows])
+    out = {"counts": cnt, "offsets": off}
+    for k in ("class_idx", "color_idx", "rgb", "center", "n_pts"):
+        out[k] = cells[k][idx]
+    return out
+
+
+def trained_point(n_cells, n_queries, topk, steps=2000, quick=False):
+    if quick:
+        steps = 60
+    dev = torch.cuda.current_device()
+    cells, gidx = make_trajectory_cells(n_cells, seed=3)
+    eng = Engine(dev)
+    sd = synth.make_object_branch_weights(21)
+    tens = {}
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked") or ".color_encoder." in k or ".mlp_pointnet." in k or ".pointnet." in k:
+            continue
+        t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda()
+        tens[k] = (t, None if "running_" in k else torch.zeros_like(t))
+    eng.train_bind(tens, class_embed=True, color_embed=True)
+    rng = np.random.default_rng(17)
+    text_train = [planted_text(cells, gidx, s) for s in range(4)]  # four descriptions per cell (different hint subsets)
+    B = 64
+    t0 = time.perf_counter()
+    losses = []
+    for it in range(steps):
+        rows = rng.choice(n_cells, size=B, replace=False)
+        rows.sort()
+        sub = _subset(cells, rows)
+        p = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sub.items() if k != "counts"}
+        anchor = torch.from_numpy(text_train[it % 4][rows]).cuda()
+        eng.zero_grad()
+        pos = eng.encode_cells_train(p, dropout_p=0.1, seed=it)
+        loss, _, gp = eng.contrastive_loss(anchor, pos, 0.1)
+        eng.encode_cells_backward(gp)
+        eng.adam_step(5e-4 * (0.4 ** (it // max(1, steps // 3))))  # README.md:87-99's schedule shape (lr 5e-4, x0.4 steps)
+        if it % max(1, steps // 8) == 0 or it == steps - 1:
+            losses.append(float(loss.item()))
+    torch.cuda.synchronize()
+    train_s = time.perf_counter() - t0
+    # the trained weights (parameters + the BatchNorm running statistics the steps updated) -> the eval-mode encoder
+    sd_t = dict(sd)
+    for k, (t, _) in tens.items():
+        sd_t[k] = t.detach().cpu().numpy()
+    eng.load_weights(sd_t, class_embed=True, color_embed=True)
+    packed = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cells.items() if k != "counts"}
+    dbc = eng.encode_cells(packed).cpu().numpy()
+    eng.close()
+    tgt = np.random.default_rng(23).integers(0, n_cells, size=n_queries)
+    q = planted_text(cells, gidx, 99)[tgt]  # held-out descriptions (a hint subset the training never saw) of the target cells
+    e2 = Engine(dev)
+    r = _measure_point(e2, dbc, q, tgt, topk, 4 if quick else 10)
+    e2.close()
+    ids_in_top = None
+    nb = np.abs(dbc @ dbc[:256].T)  # cosine of the first 256 cells against all: how similar neighbours along the trajectory are
+    r.update({"name": "trained_encoder_overlapping_cells", "train_steps": steps, "train_seconds": train_s, "loss_curve": losses,
+              "cells": "synthetic trajectory: 30 m cells every 10 m (2/3 of the objects shared with each neighbour), cell-relative centres",
+              "text": "planted: normalize(sum over 6 hinted objects of class + colour + direction codes); queries = held-out hint subsets",
+              "mean_cosine_to_next_cell": float(np.mean([dbc[i] @ dbc[i + 1] for i in range(0, n_cells - 1, 7)])),
+              "mean_cosine_to_random_cell": float(np.mean(nb[np.random.default_rng(1).integers(0, n_cells, 4096), np.arange(4096) % 256])),
+              "mean_norm_of_db_mean": float(np.linalg.norm(dbc.mean(0)))})
+    return r
+
+
+def measure(n_cells, n_queries, topk, quick=False):
+    out = {}
+    try:
+        out["tightness"] = tightness_points(n_cells, n_queries, topk, quick)
+    except Exception as e:  # a side measurement must never take the headline down
+        out["tightness"] = {"error": repr(e)}
+    try:
+        out["trained"] = trained_point(n_cells, n_queries, topk, quick=quick)
+    except Exception as e:
+        out["trained"] = {"error": repr(e)}
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    import sys
+
+    quick = "--quick" in sys.argv
+    print(json.dumps(measure(11259, 4096, 10, quick), indent=1))

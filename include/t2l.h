@@ -385,6 +385,9 @@ int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step,
  *     form (the high halves of the same packing): embeddings / offsets / features within ~1e-4 of the reference's instead of
  *     2e-7 (the published target is 1e-3), 20-40 % less time. The range safeguards stay in force.
  * "search_lanes"      (default 1): 2..4 = pipelined searches, see t2l_search_join.
+ * "search_wide_repair" (default 512, at most 1024): rows a re-rank wave may re-score in float64 to settle a query whose certificate failed
+ *                     (every kept key that reaches the threshold + every row of a list whose floor does) before the query is
+ *                     handed to an exact scan of the whole shard; 0 = off (tests of the exact stages).
  * "search_pair_ll"    (default 6): per-lane list length of the paired scan (5: experiment, halves the certificate's margin).
  * "profile_events"    (default 0): n >= 1 records hipEvents around every n-th launch of each kernel (t2l_kernel_stats);
  *                     two records cost ~6 us of queue time per bracketed kernel, which matters beside a 30 us kernel.

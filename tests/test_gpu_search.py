@@ -152,6 +152,33 @@ def test_clustered_scores_use_the_second_stage(eng):
     assert eng.search_rescored() >= eng.search_fallbacks()
 
 
+@pytest.mark.parametrize("alpha,n,clusters", [(5.0, 11259, 64), (4.0, 6000, 24), (6.0, 2500, 40)])
+def test_tight_clusters_are_settled_by_the_wide_repair(eng, alpha, n, clusters):
+    """DB = normalize(alpha * centroid + unit noise): the top-k of a query all lie in one cluster, a few dozen to a few hundred
+    keys reach the threshold and some full lists dropped rows that could. The re-rank wave re-scores exactly those (kept keys of
+    the good lists + every row of the bad ones, rerank_kernel's wide repair) instead of sending the query to a float64 scan of
+    the whole shard: ids equal the oracle, and (default scan) the wide repair — not the exact scan — served them."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(int(alpha * 10) + n)
+    cent = synth.unit_rows(rng.standard_normal((clusters, 256)))
+    member = rng.integers(0, clusters, size=n)
+    db = synth.unit_rows(alpha * cent[member] + synth.unit_rows(rng.standard_normal((n, 256)))).astype(np.float32)
+    tgt = rng.integers(0, n, size=600)
+    spread = 1.0 / np.sqrt(1.0 + alpha * alpha)
+    q = synth.unit_rows(db[tgt].astype(np.float64) + 0.25 * spread * synth.unit_rows(rng.standard_normal((600, 256)))).astype(np.float32)
+    eng.set_option("search_auto", 0)  # stay on this engine's scan: the test is about the re-rank's repair
+    idx, sc = _search(eng, db, q, 10)
+    ridx, rsc = c_oracle.retrieve_topk(db, q, 10)
+    cnt = eng.search_counters()
+    eng.set_option("search_auto", 1)
+    assert np.array_equal(idx, ridx)
+    assert np.abs(sc - rsc).max() < 1e-12
+    if eng.scan_mode == 0:
+        assert cnt["wide_repairs"] > 0, cnt
+        assert cnt["valu_exact_scans"] <= cnt["wide_repairs"] // 4, cnt
+
+
 def test_auto_mode_leaves_the_f16_scan_on_packed_scores_and_returns(eng):
     """Scores packed ~1e-4 apart: the f16 error band cannot separate anything, every query is flagged; the engine
     reads that count back (no synchronisation of its own) and serves the next batches with the split-bf16 scan, then goes
@@ -167,20 +194,32 @@ def test_auto_mode_leaves_the_f16_scan_on_packed_scores_and_returns(eng):
     base = synth.unit_rows(rng.standard_normal((1, 256)))
     packed = synth.unit_rows(base + 1e-3 * rng.standard_normal((3000, 256))).astype(np.float32)
     ridx, rsc = O.retrieve_topk(packed, q, 10)
+
+    def again(qq):  # (the database stays resident: t2l_db_set voids the report cards, a new database starts on the f16 scan)
+        i, s = eng.search(torch.from_numpy(np.ascontiguousarray(qq)).cuda(), 10)
+        torch.cuda.synchronize()
+        return i.cpu().numpy().astype(np.int64), s.cpu().numpy()
+
     idx, sc = _search(eng, packed, q, 10)
     assert np.array_equal(idx, ridx) and np.abs(sc - rsc).max() < 1e-12
     first = eng.search_rescored()
     assert first > len(q) // 8
     # the report card of a call is published by the NEXT call's re-rank (no extra launch, no synchronisation), so the
     # stand-in scan takes over from the third call on: its certificate holds
-    for _ in range(2):
-        idx, sc = _search(eng, packed, q, 10)
+    for _ in range(3):
+        idx, sc = again(q)
         assert np.array_equal(idx, ridx) and np.abs(sc - rsc).max() < 1e-12
     assert eng.search_rescored() < first
+    assert eng.search_counters()["probe"] > len(q) // 8  # the stand-in is counting what the f16 band would still flag
+    # friendly QUERIES against the same rows (far from the packed direction's fine structure? no: any query sees packed scores here),
+    # so release is exercised on a friendly database below; a new database starts on the f16 scan at once
     db, qs, _ = synth.make_retrieval_problem(3000, 64, seed=31, noise=2.0)
     r2, _ = O.retrieve_topk(db, qs, 10)
-    for _ in range(4):  # ordinary data: the stand-in calls report "f16 would certify", the next ones are f16 again
-        idx, _ = _search(eng, db, qs, 10)
+    idx, _ = _search(eng, db, qs, 10)
+    assert np.array_equal(idx, r2)
+    assert eng.search_counters()["probe"] == 0  # t2l_db_set voided the old database's report cards: the f16 scan is back
+    for _ in range(3):
+        idx, _ = again(qs)
         assert np.array_equal(idx, r2)
     assert eng.search_fallbacks() == 0
 
@@ -353,6 +392,7 @@ def test_float64_mfma_exact_stage_on_clustered_database(n, q, k, spread):
     try:
         e.set_option("search_auto", 0)
         e.set_option("search_heavy", 1)
+        e.set_option("search_wide_repair", 0)  # this test is about the exact stages behind the re-rank's repairs
         e.set_option("profile_events", 1)
         e.db_set(torch.from_numpy(db).cuda(), 3)
         idx, sc = e.search(torch.from_numpy(qs).cuda(), k)

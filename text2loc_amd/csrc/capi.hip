@@ -191,6 +191,14 @@ int t2l_db_set(t2l_ctx* ctx, const float* emb, int64_t n_rows, int64_t row_offse
     ctx->db_cap = pad;
   }
   ctx->db_rows = n_rows;
+  // a new database: what earlier report cards said about the previous one (split-bf16 stand-in, heavy / all-exact mode) is void,
+  // and so is every report of a search still in flight
+  if (ctx->search_auto) {
+    ctx->escalated = false;
+    ctx->heavy = false;
+    ctx->all_exact = false;
+    ctx->stat_seen = ctx->stat_seq + 1;  // (the NEXT call's re-rank still publishes the report of the last call on the old rows)
+  }
   ctx->db_pad = pad;
   ctx->row_offset = row_offset;
   if (n_rows > 0) {
@@ -454,6 +462,7 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     if (!ctx->search_auto) {  // forget the state and every report of a search launched so far
       ctx->escalated = false;
       ctx->heavy = false;
+      ctx->all_exact = false;
       ctx->stat_seen = ctx->stat_seq;
     }
   } else if (!strcmp(name, "search_heavy")) {  // force (1) / release (0) the float64 MFMA exact stage (tests)
@@ -463,6 +472,9 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
   } else if (!strcmp(name, "search_xcd_qgroups")) {
     if (value != 1 && value != 2 && value != 4 && value != 8) return fail(ctx, T2L_EINVAL, "search_xcd_qgroups must be 1, 2, 4 or 8");
     ctx->xcd_qgroups = (int)value;
+  } else if (!strcmp(name, "search_wide_repair")) {
+    if (value < 0 || value > 1024) return fail(ctx, T2L_EINVAL, "search_wide_repair: 0 (off) .. 1024 rows");
+    ctx->wide_repair = (int)value;
   } else if (!strcmp(name, "search_pair_ll")) {
     if (value != 5 && value != 6) return fail(ctx, T2L_EINVAL, "search_pair_ll must be 5 or 6");
     ctx->pair_ll = (int)value;

@@ -40,7 +40,8 @@ namespace t2l {
 // spread over the gaps (sched_group_barrier pins the interleave).
 // fb_count (dev i32[128]), per t2l_search call: [0] queries that ended in an exact float64 VALU scan, [1] queries re-scored
 // beyond the first L candidates, [2] queries the first certificate + in-wave re-score left unsettled, [3] f16-probe count
-// (auto mode), [4] queries deferred to the float64 MFMA stage (heavy mode), [6] queries the MFMA stage could not certify,
+// (auto mode), [4] queries deferred to the float64 MFMA stage (heavy mode), [5] queries a WIDE in-wave repair settled,
+// [6] queries the MFMA stage could not certify,
 // [7] queries it served, [9] Q and [10] stat mode of the call (rerank_kernel). The first scan launch of a call
 // (zero_counts) copies the finished call's [0..15] to [64..79] — rerank_kernel publishes that copy to the host's report
 // card — and clears the counters.
@@ -754,6 +755,34 @@ struct WgExactShared {
   int row[4][32];
 };
 
+// Rows one wave re-scores in a WIDE repair (rerank_kernel) before the query is handed to an exact scan of the whole shard.
+constexpr int kWideCap = 1024;
+
+// A wave's running top-32 as a list spread over lanes 0..31 (lane i = i-th best by (score desc, row asc); empty = -inf / INT_MAX):
+// insert (cd, cr) unless that row is already in the list. Wave-uniform control flow.
+__device__ __forceinline__ void top32_insert(double& ts, int& tr, double cd, int cr, int lane) {
+  {  // most candidates of a long run lose to the 32nd entry: one readlane pair and a scalar compare, no cross-lane traffic
+    const unsigned long long b31 = __double_as_longlong(ts);
+    const double s31 = __longlong_as_double(((unsigned long long)__builtin_amdgcn_readlane((unsigned)(b31 >> 32), 31) << 32) |
+                                            (unsigned)__builtin_amdgcn_readlane((unsigned)b31, 31));
+    const int r31 = __builtin_amdgcn_readlane(tr, 31);
+    if (s31 > cd || (s31 == cd && r31 <= cr)) return;
+  }
+  if (__ballot(lane < 32 && tr == cr) != 0ull) return;
+  const unsigned long long ahead = __ballot(lane < 32 && (ts > cd || (ts == cd && tr < cr)));
+  const int pos = __popcll(ahead);
+  if (pos >= 32) return;
+  const double up_s = __shfl_up(ts, 1);
+  const int up_r = __shfl_up(tr, 1);
+  if (lane == pos) {
+    ts = cd;
+    tr = cr;
+  } else if (lane > pos && lane < 32) {
+    ts = up_s;
+    tr = up_r;
+  }
+}
+
 __device__ __forceinline__ void wg_exact_scan(const float* __restrict__ db, int n_rows, const float* __restrict__ qrow, int K,
                                               int row_offset, int32_t* __restrict__ out_idx, double* __restrict__ out_score,
                                               WgExactShared& sh) {
@@ -850,9 +879,10 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
                                                      int32_t* __restrict__ out_idx, double* __restrict__ out_score,
                                                      int32_t* __restrict__ flags, int32_t* __restrict__ fb_count,
                                                      float eps_rel_probe, float pinf, int n_rows, int defer, int stat_mode,
-                                                     int32_t* __restrict__ host_stat, int seq) {
+                                                     int32_t* __restrict__ host_stat, int seq, int wide_cap) {
   __shared__ WgExactShared exact_sh;
   __shared__ int wg_flag[4];
+  __shared__ int wide_rows[4][kWideCap];  // per wave: the rows a wide repair re-scores
   const int lane = threadIdx.x & 63;
   const int qid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (threadIdx.x < 4) wg_flag[threadIdx.x] = 0;
@@ -865,7 +895,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
       host_stat[1] = fb_count[64 + 10] == 2 ? fb_count[64 + 3] : fb_count[64 + 2];  // f16-certificate failures (or the probe's)
       host_stat[2] = fb_count[64 + 9];
       host_stat[3] = fb_count[64 + 0] + fb_count[64 + 4] + fb_count[64 + 12];  // exact-stage queries
-      host_stat[4] = fb_count[64 + 10] != 0;
+      host_stat[4] = fb_count[64 + 10];  // 0: not an f16-certificate count, 1: the f16 scan's own, 2: the split-bf16 stand-in's probe
+      host_stat[5] = fb_count[64 + 10] == 2 ? fb_count[64 + 3] : fb_count[64 + 1];  // first-certificate failures (settled in the wave or not)
       __hip_atomic_store(&host_stat[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     fb_count[9] = Q;
@@ -1077,7 +1108,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off);
     const bool bad = lane_floor != T2L_NEG_INF && lane_floor >= thr;  // this list dropped rows that could still matter
-    if (__ballot(bad) == 0ull && total <= 16) {
+    const unsigned long long bad_mask = __ballot(bad);
+    if (bad_mask == 0ull && total <= 16) {
       for (int e = 0; e < total; ++e) {  // the next best kept keys, in key order, into lanes L, L+1, ...
         const float bk = wave_max_f32(lst[0], pinf);
         const int bl = __ffsll((long long)__ballot(lst[0] == bk)) - 1;
@@ -1121,6 +1153,94 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
         if (out_score) out_score[(size_t)qid * K + rank2] = my_d;
       }
       settled = true;
+    } else {
+      // ---- the WIDE repair: more than 16 kept keys reach the threshold, or full lists dropped rows that could (their floor
+      // reaches it) — what a database of tight clusters does to a few queries long before it defeats the certificates
+      // wholesale. Every row whose key reaches the threshold is either a kept key of a list that dropped nothing relevant, or
+      // a row of one of the `bad` lists: re-score the former and ALL rows of the latter (a list covers per * 16 rows of the
+      // shard) — same arithmetic as above — into a running top-32 spread over the lanes; rows below the threshold cannot reach
+      // the top-K (the argument of the in-wave re-score above). Only when that is more than kWideCap rows does the query go
+      // to an exact scan of the whole shard (one workgroup: ~300 us per query at N = 11 k — two such queries were 0.6 ms of
+      // a 0.7 ms step on clustered data, bench_distribution.py).
+      const int vn_ = parts >> 1;
+      const int n_tiles_ = (n_rows + kTileRows - 1) / kTileRows;
+      const int my_nt = (lane < parts && (lane >> 1) < n_tiles_) ? (n_tiles_ - (lane >> 1) + vn_ - 1) / vn_ : 0;
+      int work = bad ? my_nt * 16 : cnt;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) work += __shfl_xor(work, off);
+      if (work <= wide_cap) {
+        int* wr = wide_rows[threadIdx.x >> 6];
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        int base = 0;
+#pragma unroll
+        for (int i = 0; i < LL; ++i) {  // kept keys of the lists that dropped nothing relevant
+          const bool pred = !bad && lst[i] >= thr;
+          const unsigned long long m = __ballot(pred);
+          if (pred) wr[base + __popcll(m & lt_mask)] = key_row(lst[i], lane, vn_, code_bits);
+          base += __popcll(m);
+        }
+        for (unsigned long long m = bad_mask; m != 0ull; m &= m - 1ull) {  // every row of the lists that did
+          const int b = __ffsll((long long)m) - 1;
+          const int nb = __shfl(my_nt, b) * 16;
+          for (int idx = lane; idx < nb; idx += 64) {  // (a list position IS its key code: tile ordinal << 4 | accumulator register)
+            const int row = key_row(__int_as_float(idx), b, vn_, code_bits);
+            wr[base + idx] = row < n_rows ? row : INT_MAX;
+          }
+          base += nb;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (this wave's LDS writes are read back by its other lanes)
+        double ts = -__builtin_inf();
+        int tr = INT_MAX;
+        for (int j = 0; j < L; ++j) {  // what is already re-scored
+          const double cd = __shfl(my_d, j);
+          const int cr = __shfl(my_row, j);
+          if (cr != INT_MAX) top32_insert(ts, tr, cd, cr, lane);
+        }
+        const int n_round = (base + 3) >> 2;
+        auto row_of = [&](int p) {
+          const int i = 4 * p + (lane >> 4);
+          return i < base ? wr[i] : INT_MAX;
+        };
+        float4 cur[4], nxt[4];
+        int row_c = n_round > 0 ? row_of(0) : INT_MAX, row_n = INT_MAX;
+        {
+          const float4* rp = reinterpret_cast<const float4*>(db + (size_t)(row_c == INT_MAX ? 0 : row_c) * kD) + seg;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) cur[i] = rp[16 * i];
+        }
+        for (int p = 0; p < n_round; ++p) {
+          if (p + 1 < n_round) {  // the next round's rows travel while this round's are multiplied (wave-uniform)
+            row_n = row_of(p + 1);
+            const float4* rp = reinterpret_cast<const float4*>(db + (size_t)(row_n == INT_MAX ? 0 : row_n) * kD) + seg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) nxt[i] = rp[16 * i];
+          }
+          double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            d0 += (double)cur[i].x * qd[4 * i];
+            d1 += (double)cur[i].y * qd[4 * i + 1];
+            d0 += (double)cur[i].z * qd[4 * i + 2];
+            d1 += (double)cur[i].w * qd[4 * i + 3];
+          }
+          const double d = row16_sum_f64(d0 + d1);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const double cd = __shfl(d, 16 * c);
+            const int cr = __shfl(row_c, 16 * c);
+            if (cr != INT_MAX) top32_insert(ts, tr, cd, cr, lane);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+          row_c = row_n;
+        }
+        if (lane < K) {
+          out_idx[(size_t)qid * K + lane] = tr == INT_MAX ? -1 : tr + row_offset;
+          if (out_score) out_score[(size_t)qid * K + lane] = ts;
+        }
+        if (lane == 0) atomicAdd(&fb_count[5], 1);
+        settled = true;
+      }
     }
   }
   // 2 = the f16 operands of this query (or of the DB) were not representable: its keys mean nothing, scan exactly
@@ -1495,11 +1615,12 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
     hipExtLaunchKernelGGL((rerank_kernel<LL, L>), dim3((Q + 3) / 4), dim3(256), 0u, s, ea, eb, 0u, db, q, Q, K, parts, code_bits,
                           (const float*)ctx->cand_score, row_offset, eps_rel, (const float*)ctx->db_norm_max, half_mode, out_idx,
                           out_score, ctx->flags, ctx->fb_count, eps_probe, __builtin_inff(), n_rows, defer, stat_mode,
-                          ctx->host_stat_dev, seq);
+                          ctx->host_stat_dev, seq, min(ctx->wide_repair, kWideCap));
   else
     hipLaunchKernelGGL((rerank_kernel<LL, L>), dim3((Q + 3) / 4), dim3(256), 0, s, db, q, Q, K, parts, code_bits,
                        ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, half_mode, out_idx, out_score, ctx->flags,
-                       ctx->fb_count, eps_probe, __builtin_inff(), n_rows, defer, stat_mode, ctx->host_stat_dev, seq);
+                       ctx->fb_count, eps_probe, __builtin_inff(), n_rows, defer, stat_mode, ctx->host_stat_dev, seq,
+                       min(ctx->wide_repair, kWideCap));
   T2L_HIP(ctx, hipGetLastError());
   if (ctx->heavy) return exact_stage_impl(ctx, db, n_rows, row_offset, q, Q, K, out_idx, out_score, s);
   return T2L_OK;
@@ -1516,6 +1637,31 @@ __global__ __launch_bounds__(256) void empty_result_kernel(int n, int32_t* __res
     out_idx[i] = -1;
     if (out_score) out_score[i] = -__builtin_inf();
   }
+}
+
+// all-exact mode (search_impl): no candidate scan, no re-rank — this launch does their bookkeeping (counters parked and cleared,
+// the previous call's report card published, as reset_counts + rerank_kernel's first thread do) and puts every query on the exact
+// stage's list.
+__global__ __launch_bounds__(256) void all_exact_prep_kernel(int Q, int32_t* __restrict__ list, int32_t* __restrict__ fb_count,
+                                                             int32_t* __restrict__ host_stat, int seq) {
+  if (blockIdx.x == 0) {
+    reset_counts(fb_count, 1, threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (host_stat && seq > 0) {
+        host_stat[1] = fb_count[64 + 10] == 2 ? fb_count[64 + 3] : fb_count[64 + 2];
+        host_stat[2] = fb_count[64 + 9];
+        host_stat[3] = fb_count[64 + 0] + fb_count[64 + 4] + fb_count[64 + 12];
+        host_stat[4] = fb_count[64 + 10];
+        host_stat[5] = fb_count[64 + 10] == 2 ? fb_count[64 + 3] : fb_count[64 + 1];
+        __hip_atomic_store(&host_stat[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      fb_count[9] = Q;
+      fb_count[10] = 0;
+      fb_count[1] = fb_count[2] = fb_count[4] = Q;  // every query counts as flagged and deferred
+    }
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < Q; i += gridDim.x * 256) list[i] = i;
 }
 
 int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s) {
@@ -1540,14 +1686,26 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     const int done = __atomic_load_n(ctx->host_stat, __ATOMIC_ACQUIRE);  // pairs with the kernel's system-scope release store
     if (done > ctx->stat_seen) {
       ctx->stat_seen = done;
-      const int64_t flagged = hs[1], total = hs[2], exact_prev = hs[3];
+      const int64_t flagged = hs[1], total = hs[2], exact_prev = hs[3], rescored = hs[5];
       if (ctx->search_mode == 0 && ctx->search_auto && hs[4]) {
-        if (!ctx->escalated && flagged * 8 > total) ctx->escalated = true;
-        else if (ctx->escalated && flagged * 16 < total) ctx->escalated = false;
+        // ... or more than 1 in 2 failed the first certificate: the in-wave repairs settle them, but a wide repair re-scores
+        // dozens to hundreds of rows per query — measured on a clustered database with 92 % of the queries repaired: 185 us per
+        // step on the f16 scan against 133 us on the split-bf16 scan, whose 50x tighter band certifies them outright
+        // (a report is two calls old: only a report of the f16 scan escalates, only one of the stand-in's probe releases —
+        // an f16 report that arrives after the switch must not undo it)
+        if (hs[4] == 1 && !ctx->escalated && (flagged * 8 > total || rescored * 2 > total)) ctx->escalated = true;
+        else if (hs[4] == 2 && ctx->escalated && flagged * 16 < total) ctx->escalated = false;
       }
       if (ctx->search_auto) {
         if (!ctx->heavy && exact_prev * 64 > total) ctx->heavy = true;
         else if (ctx->heavy && exact_prev * 256 < total) ctx->heavy = false;
+        // 7 in 8 queries end in the exact stage whatever the candidate scan says: stop paying for the scan and the re-rank
+        // (0.26 ms of a 1.0 ms step on such a database) and hand EVERY query to the float64 MFMA stage; one call in 8 still
+        // takes the long way and its report decides whether that remains true
+        // (only on the word of the split-bf16 stand-in, whose band is the tightest a candidate scan has: a database that defeats
+        // the f16 scan alone gets the stand-in first; reports of all-exact calls themselves carry no scan and change nothing)
+        if (hs[4] == 2) ctx->all_exact = ctx->heavy && exact_prev * 8 >= total * 7;
+        else if (hs[4] == 1) ctx->all_exact = false;
       }
     }
   }
@@ -1565,6 +1723,14 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
   int rc;
   // flags[Q] + f32 thresholds[Q] + flagged list[Q] + deferred list[Q] + uncertified list[Q] (search_exact.hip)
   if ((rc = grow(ctx, (void**)&ctx->flags, &ctx->flag_cap, (size_t)5 * Q * sizeof(int32_t))) != T2L_OK) return rc;
+  if (ctx->search_auto && ctx->heavy && ctx->all_exact && n_seg == 1 && (ctx->all_exact_calls++ & 7) != 7) {
+    const int seq = ++ctx->stat_seq;
+    // (block 0 parks the counters before any block's exactd successor reads them: the launches are stream-ordered)
+    hipLaunchKernelGGL(all_exact_prep_kernel, dim3(min((Q + 255) / 256, 64)), dim3(256), 0, s, Q, ctx->flags + (size_t)3 * Q, ctx->fb_count,
+                       ctx->host_stat_dev, seq);
+    T2L_HIP(ctx, hipGetLastError());
+    return exact_stage_impl(ctx, ctx->db, n_rows, (int)ctx->row_offset, q, Q, K, out_idx, out_score, s);
+  }
   int32_t* seg_idx = out_idx;
   double* seg_score = out_score;
   if (n_seg > 1) {

@@ -94,6 +94,7 @@ struct t2l_ctx {
   int encoder_f16 = 0;   // 1: plain-f16 products (one MFMA per operand pair) instead of split-f16: ~1e-4 instead of 2e-7, 28 % faster
   int search_auto = 1;
   int pair_ll = 6;       // per-lane list length of the paired scan (5 or 6)
+  int wide_repair = 512;  // rows a re-rank wave may re-score in a wide repair before the query goes to an exact scan (0: never)
   int search_prep = 0;   // paired scan: 1 = the queries' f16 fragment plane is built by a pre-pass launch, once per call
   void* qplane = nullptr;  // ... that plane (q_pad x 512 B)
   size_t qplane_cap = 0;
@@ -109,8 +110,10 @@ struct t2l_ctx {
   int train_keep_adam = 0;  // 1: t2l_train_bind keeps Adam moments + step when the parameter list is unchanged (a re-bind)
   int eff_mode = 0;           // the scan the current t2l_search call runs
   bool heavy = false;         // the database defeats the certificates: flagged queries go to the float64 MFMA stage
+  bool all_exact = false;     // ... and nearly all of them: EVERY query goes there, no candidate scan (search_impl)
+  unsigned all_exact_calls = 0;
   bool escalated = false;     // the split-bf16 scan is standing in (it counts what the f16 band would still flag)
-  int32_t* host_stat = nullptr;      // mapped pinned host int32[8]: {sequence number of the last finished call, flagged, Q, previous exact-stage count, f16 stat}
+  int32_t* host_stat = nullptr;      // mapped pinned host int32[8]: {sequence number of the last finished call, flagged, Q, previous exact-stage count, f16 stat, first-certificate failures}
   int32_t* host_stat_dev = nullptr;  // its device address
   int stat_seq = 0, stat_seen = 0;
   // Pipelined searches (option "search_lanes" = n > 1): consecutive t2l_search calls are independent jobs, so call i runs its

@@ -527,7 +527,7 @@ class Engine:
         """Counters of the last search (include/t2l.h: t2l_search_counters)."""
         c = (C.c_int32 * 8)()
         self._check(self.lib.t2l_search_counters(self._h, c))
-        names = ("valu_exact_scans", "rescored", "to_fallback_kernel", "probe", "deferred_to_mfma_exact", "prev_exact",
+        names = ("valu_exact_scans", "rescored", "to_fallback_kernel", "probe", "deferred_to_mfma_exact", "wide_repairs",
                  "mfma_exact_uncertified", "mfma_exact_served")
         return {n: int(c[i]) for i, n in enumerate(names)}
 
