@@ -37,9 +37,9 @@ def _measure_point(e2, dbc, q, target, topk, reps, oracle_sample=8):
     e2.set_option("search_auto", 0)  # forget the previous database's report card
     e2.set_option("search_auto", 1)
     e2.db_set(torch.from_numpy(np.ascontiguousarray(dbc)).cuda())
-    for _ in range(8):  # the auto mode settles on a scan / the heavy stage within a few calls
-        e2.search(dq, topk)
-    torch.cuda.synchronize()
+    for _ in range(14):  # the auto mode settles within a few calls — of a loop that consumes each result before the next call, as
+        e2.search(dq, topk)   # eval_epoch does (a report card is read when a call is ENQUEUED: calls queued ahead of the GPU see none)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         gi, gs = e2.search(dq, topk)
@@ -90,7 +90,7 @@ def tightness_points(n_cells, n_queries, topk, quick=False):
         tgt = rs.integers(0, n_cells, size=n_queries)
         spread = float(np.linalg.norm(dbc - cc * (dbc * cc).sum(1, keepdims=True), axis=1).mean()) if alpha > 0 else 1.0
         q = synth.unit_rows(dbc[tgt].astype(np.float64) + 0.25 * spread * synth.unit_rows(rs.standard_normal((n_queries, DIM)))).astype(np.float32)
-        r = _measure_point(e2, dbc, q, tgt, topk, 4 if quick else 10)
+        r = _measure_point(e2, dbc, q, tgt, topk, 4 if quick else 16)
         r.update({"name": name, "alpha": alpha, "clusters": c_n, "mean_distance_to_own_centroid": spread})
         out.append(r)
     e2.close()
@@ -206,9 +206,8 @@ def trained_point(n_cells, n_queries, topk, steps=2000, quick=False):
     tgt = np.random.default_rng(23).integers(0, n_cells, size=n_queries)
     q = planted_text(cells, gidx, 99)[tgt]  # held-out descriptions (a hint subset the training never saw) of the target cells
     e2 = Engine(dev)
-    r = _measure_point(e2, dbc, q, tgt, topk, 4 if quick else 10)
+    r = _measure_point(e2, dbc, q, tgt, topk, 4 if quick else 16)
     e2.close()
-    ids_in_top = None
     nb = np.abs(dbc @ dbc[:256].T)  # cosine of the first 256 cells against all: how similar neighbours along the trajectory are
     r.update({"name": "trained_encoder_overlapping_cells", "train_steps": steps, "train_seconds": train_s, "loss_curve": losses,
               "cells": "synthetic trajectory: 30 m cells every 10 m (2/3 of the objects shared with each neighbour), cell-relative centres",

@@ -230,8 +230,8 @@ int t2l_contrastive_loss(t2l_ctx* ctx, const float* anchor, const float* positiv
 /* Replaces: LanguageEncoder.forward from `description_encodings = out.last_hidden_state` up to and including `self.inter_mlp`
  * (models/language_encoder.py:127-135): one nn.TransformerEncoderLayer(d_model 1024, 4 heads, dim_feedforward 4096, post-norm,
  * ReLU, no padding mask) over the token positions of every sentence, max over the tokens, Linear(1024 -> D) + BatchNorm1d (eval).
- * T5 itself and what follows inter_mlp (the D-wide inter-sentence layer of the coarse model, language_encoder.py:137-147, or
- * nothing for the fine model) stay on PyTorch-ROCm. Weights: host fp32 blobs under `prefix` (NULL = "language_encoder."):
+ * T5 itself stays on PyTorch-ROCm; what follows inter_mlp (the D-wide inter-sentence layer of the coarse model,
+ * language_encoder.py:137-147; nothing for the fine model) is t2l_text_inter below. Weights: host fp32 blobs under `prefix` (NULL = "language_encoder."):
  * intra_module.0.{self_attn.in_proj_weight [3072,1024], self_attn.in_proj_bias, self_attn.out_proj.{weight,bias},
  * linear1.{weight [4096,1024],bias}, linear2.{weight [1024,4096],bias}, norm1.*, norm2.*}, inter_mlp.0.{0.weight [D,1024], 0.bias,
  * 1.weight, 1.bias, 1.running_mean, 1.running_var}, D <= 256; intra_module_num_layers must be 1 (the reference's default,
@@ -244,6 +244,18 @@ int t2l_contrastive_loss(t2l_ctx* ctx, const float* anchor, const float* positiv
 int t2l_text_head_load_weights(t2l_ctx* ctx, const t2l_weight_desc* w, int32_t n, const char* prefix);
 int t2l_text_head(t2l_ctx* ctx, const float* hidden, int32_t n_sentences, int32_t n_tokens, float* out, int32_t* overflow,
                   void* stream);
+/* t2l_text_inter — the other half of the head, eval mode. Replaces: LanguageEncoder.forward from
+ * `description_encodings.view(batch_size, num_sentence, -1)` to its return value (models/language_encoder.py:137-147):
+ * x = sent.view(n_descriptions, n_sentences_per, 256); x += TransformerEncoderLayer(d_model 256, 4 heads, dim_feedforward 1024,
+ * post-norm, ReLU)(x) over the sentences of every description (the residual AROUND the layer is the reference's `+=`); max over
+ * the sentences. sent = dev f32[n_descriptions * n_sentences_per, 256], description-major (exactly what t2l_text_head returns for
+ * the reference's sentence order); out = dev f32[n_descriptions, 256] (NOT normalised: CellRetrievalNetwork.encode_text does that,
+ * models/cell_retrieval.py:57-63). 1 <= n_sentences_per <= 32. Needs `inter_module.0.*` (in_proj [768,256], out_proj [256,256],
+ * linear1 [1024,256], linear2 [256,1024], norm1, norm2) among the tensors handed to t2l_text_head_load_weights and
+ * inter_module_num_layers = 1 (training/args.py:72's default); T2L_ESTATE otherwise (the fine model has no such layer). Same
+ * arithmetic, overflow flag and kernels (with d_model 256) as t2l_text_head. */
+int t2l_text_inter(t2l_ctx* ctx, const float* sent, int32_t n_descriptions, int32_t n_sentences_per, float* out, int32_t* overflow,
+                   void* stream);
 
 /* ---- fine stage (f-1): CrossMatch downstream of the text branch, eval mode ---------------------- */
 /* Replaces CrossMatch.load_state_dict for everything except language_encoder.* (evaluation/pipeline.py:258-262): tensors named

@@ -140,31 +140,88 @@ class LanguageEncoder(nn.Module):
         return [s for s in re.split(r"(?<=[.!?])\s+", text.strip()) if s]
 
     # ---- the head after T5 --------------------------------------------------------------------------------------------
-    use_engine_head = True   # eval mode on the GPU: intra_module + max + inter_mlp run in the HIP engine (t2l_text_head)
+    use_engine_head = True   # eval mode on the GPU: the whole head after T5 runs in the HIP engine (t2l_text_head + t2l_text_inter)
     head_engine_calls = 0    # calls served by the engine / by the PyTorch path (f16-range overflow, training mode, CPU, ...)
     head_torch_calls = 0
+    inter_engine_calls = 0   # ... and for the inter-sentence half (t2l_text_inter)
+    inter_torch_calls = 0
+
+    @staticmethod
+    def _layer_is_stock(layer, d, ff, heads) -> bool:
+        """What text_head.hip hard-codes about a TransformerEncoderLayer: post-norm, ReLU, LayerNorm eps 1e-5, (d, ff, heads)."""
+        act = getattr(layer, "activation", None)
+        relu = act is F.relu or isinstance(act, nn.ReLU) or getattr(act, "__name__", "") == "relu"
+        return (not getattr(layer, "norm_first", False) and relu and layer.linear1.in_features == d and layer.linear1.out_features == ff
+                and layer.self_attn.num_heads == heads and abs(layer.norm1.eps - 1e-5) < 1e-12 and abs(layer.norm2.eps - 1e-5) < 1e-12)
+
+    def _engine_gate(self, hidden: torch.Tensor) -> bool:
+        """Everything t2l_text_head_load_weights / t2l_text_head would reject is refused HERE, so eval mode never raises where the
+        PyTorch path works (shapes, D % 4, layer flavour, BatchNorm eps)."""
+        if not (self.use_engine_head and hidden.is_cuda and not self.training and not torch.is_grad_enabled()):
+            return False
+        D = self.inter_mlp[0][0].out_features
+        bn = self.inter_mlp[0][1]
+        return (len(self.intra_module) == 1 and hidden.shape[-1] == 1024 and 1 <= hidden.shape[1] <= 32 and D <= 256 and D % 4 == 0
+                and self._layer_is_stock(self.intra_module[0], 1024, 4096, 4) and isinstance(bn, nn.BatchNorm1d) and abs(bn.eps - 1e-5) < 1e-12)
+
+    def _inter_gate(self, n_sent_per: int) -> bool:
+        return (not self.is_fine and len(self.inter_module) == 1 and self.inter_mlp[0][0].out_features == 256 and 1 <= n_sent_per <= 32
+                and self._layer_is_stock(self.inter_module[0], 256, 1024, 4))
+
+    def _head_params(self):
+        ps = getattr(self, "_th_params", None)
+        if ps is None:  # (cached: walking state_dict() on every forward showed up in the profile of small batches)
+            ps = self._th_params = [t for n, t in self.state_dict(keep_vars=True).items()
+                                    if n.startswith(("intra_module.", "inter_mlp.", "inter_module."))]
+        return ps
 
     def _head_engine(self, device) -> Optional[Engine]:
         """The engine context holding this head's packed weights on ``device`` (re-packed when a tensor changes)."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        params = [t for n, t in self.state_dict(keep_vars=True).items() if n.startswith(("intra_module.", "inter_mlp."))]
-        version = (idx,) + tuple((t.data_ptr(), t._version) for t in params)
+        version = (idx,) + tuple((t.data_ptr(), t._version) for t in self._head_params())
         if getattr(self, "_th_version", None) != version:
             if getattr(self, "_th_engine", None) is None or self._th_engine.device != idx:
                 self._th_engine = Engine(idx)
-            sd = {"language_encoder." + n: t for n, t in self.state_dict().items() if n.startswith(("intra_module.", "inter_mlp."))}
+            sd = {"language_encoder." + n: t for n, t in self.state_dict().items()
+                  if n.startswith(("intra_module.", "inter_mlp.", "inter_module."))}
             self._th_engine.text_head_load_weights(sd)
+            self._th_params = None  # (load_state_dict may have swapped tensors: re-collect)
+            version = (idx,) + tuple((t.data_ptr(), t._version) for t in self._head_params())
             self._th_version = version
         return self._th_engine
+
+    # Overflow handling. An engine call raises a device flag when a value entering an f16 product left the f16 range; the batch
+    # must then be re-run on the PyTorch path. Default: read the flag after every call (one 4-byte copy + stream sync, as in
+    # round 3). Between begin_deferred() and end_deferred() no call synchronises: the flags are collected on the device, an
+    # overflowed batch is poisoned with NaN on the device (never silently wrong), and end_deferred() returns — after ONE sync —
+    # the ordinals of the calls to re-run (coarse.eval_epoch does exactly that around its text loop).
+    def begin_deferred(self):
+        self._deferred = []
+
+    def end_deferred(self) -> List[int]:
+        flags, self._deferred = getattr(self, "_deferred", None), None
+        if not flags:
+            return []
+        host = torch.stack([f.reshape(()) for f in flags]).cpu().numpy()
+        return [i for i, v in enumerate(host) if v != 0]
+
+    def _settle(self, out: torch.Tensor, flag: torch.Tensor):
+        """-> (out, overflowed): synchronous check, or (deferred mode) NaN-poison on the device and report False."""
+        if getattr(self, "_deferred", None) is None:
+            return out, bool(flag.item())
+        if not self._deferred:  # (a stage called outside head(): its own entry)
+            self._deferred.append(torch.zeros((1,), dtype=torch.int32, device=out.device))
+        self._deferred[-1] = torch.maximum(self._deferred[-1], flag)
+        poison = torch.where(flag == 0, torch.ones((), device=out.device), torch.full((), float("nan"), device=out.device))
+        return out * poison, False
 
     def _head_first_half(self, hidden: torch.Tensor) -> torch.Tensor:
         """[n_sentences, L, C] -> [n_sentences, D]: intra_module over the tokens, max over the tokens, inter_mlp
         (language_encoder.py:127-135). On the GPU in eval mode this is t2l_text_head (split-f16 MFMA GEMMs); the PyTorch
         modules below it are the training path and the path of a batch whose activations leave the f16 range."""
-        if (self.use_engine_head and hidden.is_cuda and not self.training and not torch.is_grad_enabled() and len(self.intra_module) == 1
-                and hidden.shape[-1] == 1024 and 1 <= hidden.shape[1] <= 32 and self.inter_mlp[0][0].out_features <= 256
-                and self.intra_module[0].linear1.out_features == 4096 and self.intra_module[0].self_attn.num_heads == 4):
-            out, overflowed = self._head_engine(hidden.device).text_head(hidden.contiguous().float())
+        if self._engine_gate(hidden):
+            out, flag = self._head_engine(hidden.device).text_head(hidden.contiguous().float(), check=False)
+            out, overflowed = self._settle(out, flag)
             if not overflowed:
                 LanguageEncoder.head_engine_calls += 1
                 return out
@@ -177,13 +234,24 @@ class LanguageEncoder(nn.Module):
 
     def head(self, hidden: torch.Tensor, batch_size: int) -> torch.Tensor:
         """hidden: last_hidden_state [n_sentences_total, L, C] -> [B, D] (language_encoder.py:127-148)."""
+        if getattr(self, "_deferred", None) is not None:
+            self._deferred.append(torch.zeros((1,), dtype=torch.int32, device=hidden.device))  # one entry per head() call
+        n_eng = LanguageEncoder.head_engine_calls
         x = self._head_first_half(hidden)
+        gate = LanguageEncoder.head_engine_calls != n_eng  # (a batch that fell back to the PyTorch modules stays on them to the end)
         if x.shape[0] % batch_size:
             raise T2LError(f"{x.shape[0]} sentences do not split evenly over {batch_size} descriptions")
-        x = x.view(batch_size, x.shape[0] // batch_size, -1)
+        n_per = x.shape[0] // batch_size
         if self.is_fine:
-            return x
-        x = x.permute(1, 0, 2)
+            return x.view(batch_size, n_per, -1)
+        if gate and self._inter_gate(n_per):  # the 256-wide half in the engine too (t2l_text_inter)
+            out, flag = self._head_engine(hidden.device).text_inter(x.contiguous(), batch_size, check=False)
+            out, overflowed = self._settle(out, flag)
+            if not overflowed:
+                LanguageEncoder.inter_engine_calls += 1
+                return out
+        LanguageEncoder.inter_torch_calls += 1
+        x = x.view(batch_size, n_per, -1).permute(1, 0, 2)
         for layer in self.inter_module:
             x = x + layer(x)
         return x.max(dim=0)[0]

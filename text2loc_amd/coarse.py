@@ -87,10 +87,23 @@ def eval_epoch(model, dataloader, args, return_encodings: bool = False, return_d
 
     # ---- query side (text path stays on PyTorch)
     t0 = time.time()
-    text_parts, query_cell_ids = [], []
+    text_parts, query_cell_ids, text_batches = [], [], []
+    le = getattr(model, "language_encoder", None)
+    deferred = hasattr(le, "begin_deferred") and hasattr(le, "end_deferred")
+    if deferred:  # no host sync per batch: the head's overflow flags are collected on the device and read ONCE behind the loop
+        le.begin_deferred()
     for batch in dataloader:
         text_parts.append(model.encode_text(batch["texts"]).detach().float())
         query_cell_ids.extend(batch["cell_ids"])
+        if deferred:
+            text_batches.append(batch["texts"])
+    if deferred:
+        for i in le.end_deferred():  # a batch whose activations left the f16 range: again, on the PyTorch modules
+            keep, le.use_engine_head = le.use_engine_head, False
+            try:
+                text_parts[i] = model.encode_text(text_batches[i]).detach().float()
+            finally:
+                le.use_engine_head = keep
     text_enc = torch.cat(text_parts, dim=0)
     print(f"Encoded {len(text_enc)} query texts in {time.time() - t0:0.2f}.")
 

@@ -366,6 +366,12 @@ int t2l_text_head(t2l_ctx* ctx, const float* hidden, int32_t n_sentences, int32_
   return text_head_impl(ctx, hidden, n_sentences, n_tokens, out, overflow, (hipStream_t)stream);
 }
 
+int t2l_text_inter(t2l_ctx* ctx, const float* sent, int32_t n_descriptions, int32_t n_sentences_per, float* out, int32_t* overflow, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return text_inter_impl(ctx, sent, n_descriptions, n_sentences_per, out, overflow, (hipStream_t)stream);
+}
+
 int t2l_fine_load_weights(t2l_ctx* ctx, const t2l_weight_desc* w, int32_t n, const t2l_model_config* cfg) {
   if (!ctx) return T2L_EINVAL;
   T2L_HIP(ctx, hipSetDevice(ctx->device));

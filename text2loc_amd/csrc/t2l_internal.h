@@ -203,6 +203,7 @@ void free_fine(t2l_ctx* ctx);
 // text_head.hip
 int text_head_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const char* prefix);
 int text_head_impl(t2l_ctx* ctx, const float* hidden, int n_sentences, int n_tokens, float* out, int32_t* overflow, hipStream_t s);
+int text_inter_impl(t2l_ctx* ctx, const float* sent, int n_desc, int S, float* out, int32_t* overflow, hipStream_t s);
 void free_text_head(t2l_ctx* ctx);
 // loss.hip
 // hipFuncSetAttribute applies to the CURRENT device's instance of a kernel, and one process may hold contexts on several GPUs: a call

@@ -346,8 +346,13 @@ __global__ __launch_bounds__(512, 1) void th_gemm_kernel(const GemmArgs p) {
 //                 V[key j(s, kh)][32 dt + c] straight from the T32 array (4-byte loads, 16 B segments, L1/L2 hits);
 //                 lane (i, kh) ends up with 4 consecutive output columns per register quad -> 8-byte T16 stores.
 // ---------------------------------------------------------------------------------------------------------------
+template <int DM>  // d_model: 1024 (the token layer, head_dim 256) or 256 (the inter-sentence layer, head_dim 64)
 __global__ __launch_bounds__(256) void th_attn_kernel(const float* __restrict__ qkv, int n_sent, int L, int n_groups,
                                                       _Float16* __restrict__ ohi, _Float16* __restrict__ olo, int* __restrict__ flag) {
+  constexpr int kDM = DM, kHD = DM / kHeads;
+  constexpr int kQuads = kHD / 8;          // float4 quads of a lane's half row (k in [kHD/2 * kh, +kHD/2))
+  constexpr float kScale = kHD == 256 ? 0.0625f : 0.125f;  // 1 / sqrt(head_dim)
+  static_assert(kHD == 256 || kHD == 64, "head_dim 256 or 64");
   const int lane = threadIdx.x & 63, c = lane & 31, kh = lane >> 5;
   const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);  // (group, head)
   if (unit >= n_groups * kHeads) return;
@@ -361,10 +366,10 @@ __global__ __launch_bounds__(256) void th_attn_kernel(const float* __restrict__ 
   h3_f32x16 st;
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[r] = 0.f;
-  const float* qrow = qkv + t32_index(mc, h * kHD + 128 * kh, N3);          // quad t of the lane's half row: + t * 128 floats
-  const float* krow = qkv + t32_index(mc, kDM + h * kHD + 128 * kh, N3);
+  const float* qrow = qkv + t32_index(mc, h * kHD + (kHD / 2) * kh, N3);    // quad t of the lane's half row: + t * 128 floats
+  const float* krow = qkv + t32_index(mc, kDM + h * kHD + (kHD / 2) * kh, N3);
 #pragma unroll 2
-  for (int t0 = 0; t0 < 32; t0 += 4) {
+  for (int t0 = 0; t0 < kQuads; t0 += 4) {
     f32x4 qv[4], kv[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(256) void th_attn_kernel(const float* __restrict__ 
   for (int r = 0; r < 16; ++r) {
     const int j = (r & 3) + 8 * (r >> 2) + 4 * kh;
     const bool ok = j < rows && j / L == my_sent;
-    st[r] = ok ? st[r] * 0.0625f : -__builtin_inff();  // / sqrt(head_dim)
+    st[r] = ok ? st[r] * kScale : -__builtin_inff();  // / sqrt(head_dim)
     mx = fmaxf(mx, st[r]);
   }
   mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -411,8 +416,8 @@ __global__ __launch_bounds__(256) void th_attn_kernel(const float* __restrict__ 
 #pragma unroll
   for (int s = 0; s < 16; ++s) va[s] = vbase[vrow[s]];
 #pragma unroll
-  for (int dt = 0; dt < 8; ++dt) {
-    if (dt + 1 < 8) {
+  for (int dt = 0; dt < kHD / 32; ++dt) {
+    if (dt + 1 < kHD / 32) {
 #pragma unroll
       for (int s = 0; s < 16; ++s) vb[s] = vbase[vrow[s] + (dt + 1) * 8 * 128];
     }
@@ -446,24 +451,30 @@ __global__ __launch_bounds__(256) void th_attn_kernel(const float* __restrict__ 
 // POOL = true : max over the L token rows of each sentence -> pooled [n_sentences][1024] row-major (pre-filled with -inf;
 //               sentences that lie inside this tile are stored, straddlers meet through float atomic max).
 // ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int m0_of(int row_tile) { return row_tile * 32; }
 __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
   if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
   else atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
 }
 
-template <bool POOL>
+// DM = 256 (the inter-sentence layer): the same with 8 quads per thread; POOL then adds `resid` (row-major f32 [M][DM], the
+// layer's own input: `x += layer(x)`, language_encoder.py:143-144) to every normalised row before the max over each
+// description's L sentence rows.
+template <bool POOL, int DM = 1024>
 __global__ __launch_bounds__(256) void th_ln_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, int M, int L, _Float16* __restrict__ hi,
-                                                    _Float16* __restrict__ lo, float* __restrict__ pooled, int* __restrict__ flag) {
+                                                    _Float16* __restrict__ lo, float* __restrict__ pooled, int* __restrict__ flag,
+                                                    const float* __restrict__ resid = nullptr) {
+  constexpr int kDM = DM, NQ = DM / 32;  // quads per thread
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem);  // [8][32]
   const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int rt = blockIdx.x, m = rt * 32 + r;
   const float* base = y + (size_t)rt * (kDM / 4) * 128 + r * 4;
-  f32x4 v[32];
+  f32x4 v[NQ];
   float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < 32; ++j) {
+  for (int j = 0; j < NQ; ++j) {
     v[j] = *reinterpret_cast<const f32x4*>(base + (size_t)(j * 8 + g) * 128);
     s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
   }
@@ -476,7 +487,7 @@ __global__ __launch_bounds__(256) void th_ln_kernel(const float* __restrict__ y,
   __syncthreads();
   float q = 0.f;
 #pragma unroll
-  for (int j = 0; j < 32; ++j) {
+  for (int j = 0; j < NQ; ++j) {
     v[j] -= mean;
     q += (v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3]);
   }
@@ -489,7 +500,7 @@ __global__ __launch_bounds__(256) void th_ln_kernel(const float* __restrict__ y,
   bool bad = false;
   if constexpr (!POOL) {
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
+    for (int j = 0; j < NQ; ++j) {
       const int n0 = 4 * (j * 8 + g);
       const f32x4 o = v[j] * rstd * *reinterpret_cast<const f32x4*>(gamma + n0) + *reinterpret_cast<const f32x4*>(beta + n0);
       bad = bad || (m < M && out_of_f16_range(o));
@@ -505,15 +516,23 @@ __global__ __launch_bounds__(256) void th_ln_kernel(const float* __restrict__ y,
     constexpr int RS = kDM + 4;
     float* tile = reinterpret_cast<float*>(smem);  // [32][1028]
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
+    for (int j = 0; j < NQ; ++j) {
       const int n0 = 4 * (j * 8 + g);
       *reinterpret_cast<f32x4*>(tile + r * RS + n0) =
           v[j] * rstd * *reinterpret_cast<const f32x4*>(gamma + n0) + *reinterpret_cast<const f32x4*>(beta + n0);
     }
     __syncthreads();
+    if (resid) {  // x + layer(x): whole-row reads of the layer's input
+      for (int i = threadIdx.x; i < 32 * (kDM / 4); i += 256) {
+        const int rr = i / (kDM / 4), cq = i % (kDM / 4);
+        if (m0_of(rt) + rr < M)
+          *reinterpret_cast<f32x4*>(tile + rr * RS + 4 * cq) += *reinterpret_cast<const f32x4*>(resid + (size_t)(m0_of(rt) + rr) * kDM + 4 * cq);
+      }
+      __syncthreads();
+    }
     const int n0 = threadIdx.x * 4, m0 = rt * 32;
     int row = 0;
-    while (row < 32 && m0 + row < M) {
+    while (n0 < kDM && row < 32 && m0 + row < M) {
       const int sent = (m0 + row) / L;
       const int first = sent * L, last = first + L - 1;  // the sentence's rows
       const int end = min(32, last - m0 + 1);
@@ -544,6 +563,14 @@ struct Weights {
   float *qkv_b = nullptr, *out_b = nullptr, *ff1_b = nullptr, *ff2_b = nullptr, *mlp_b = nullptr, *ln1_g = nullptr, *ln1_b = nullptr,
         *ln2_g = nullptr, *ln2_b = nullptr;
   int out_dim = 0;  // D of inter_mlp (256 coarse, 128 fine)
+  // the inter-sentence layer (inter_module.0: d_model 256, 4 heads, dim_feedforward 1024) — coarse model only
+  bool has_inter = false;
+  char *i_qkv_h = nullptr, *i_qkv_l = nullptr, *i_out_h = nullptr, *i_out_l = nullptr, *i_ff1_h = nullptr, *i_ff1_l = nullptr, *i_ff2_h = nullptr,
+       *i_ff2_l = nullptr;
+  float *i_qkv_b = nullptr, *i_out_b = nullptr, *i_ff1_b = nullptr, *i_ff2_b = nullptr, *i_ln1_g = nullptr, *i_ln1_b = nullptr, *i_ln2_g = nullptr,
+        *i_ln2_b = nullptr;
+  char* ws2 = nullptr;  // workspace of t2l_text_inter
+  size_t ws2_cap = 0;
   // workspace
   char* ws = nullptr;
   size_t ws_cap = 0;
@@ -581,6 +608,7 @@ void free_text_head(t2l_ctx* ctx) {
   if (!W) return;
   for (void* p : W->owned) (void)hipFree(p);
   if (W->ws) (void)hipFree(W->ws);
+  if (W->ws2) (void)hipFree(W->ws2);
   if (W->flag) (void)hipFree(W->flag);
   if (W->flag_host) (void)hipHostFree(W->flag_host);
   delete W;
@@ -654,6 +682,26 @@ int text_head_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const cha
     }
     if ((rc = planes(wf.data(), D, kDM, &W->mlp_h, &W->mlp_l)) || (rc = upload(bf.data(), sizeof(float) * kTile, (void**)&W->mlp_b))) return rc;
   }
+  {  // inter_module.0 (language_encoder.py:101,143-144), when present and of the published shape: D = 256, 4 heads, ff 1024
+    constexpr int ID = 256, IF = 1024;
+    const std::string I0 = P + "inter_module.0.";
+    const Req ireq[] = {{"self_attn.in_proj_weight", 3ll * ID * ID}, {"self_attn.in_proj_bias", 3 * ID}, {"self_attn.out_proj.weight", (int64_t)ID * ID},
+                        {"self_attn.out_proj.bias", ID}, {"linear1.weight", (int64_t)IF * ID}, {"linear1.bias", IF}, {"linear2.weight", (int64_t)ID * IF},
+                        {"linear2.bias", ID}, {"norm1.weight", ID}, {"norm1.bias", ID}, {"norm2.weight", ID}, {"norm2.bias", ID}};
+    const t2l_weight_desc* it[12];
+    bool all = D == ID && !th_find(w, n, P + "inter_module.1.linear1.weight", (int64_t)IF * ID);
+    for (int i = 0; i < 12 && all; ++i) all = (it[i] = th_find(w, n, I0 + ireq[i].key, ireq[i].numel)) != nullptr;
+    if (all) {
+      if ((rc = planes(it[0]->data, 3 * ID, ID, &W->i_qkv_h, &W->i_qkv_l)) || (rc = vec(it[1]->data, 3 * ID, 3 * ID, &W->i_qkv_b)) ||
+          (rc = planes(it[2]->data, ID, ID, &W->i_out_h, &W->i_out_l)) || (rc = vec(it[3]->data, ID, ID, &W->i_out_b)) ||
+          (rc = planes(it[4]->data, IF, ID, &W->i_ff1_h, &W->i_ff1_l)) || (rc = vec(it[5]->data, IF, IF, &W->i_ff1_b)) ||
+          (rc = planes(it[6]->data, ID, IF, &W->i_ff2_h, &W->i_ff2_l)) || (rc = vec(it[7]->data, ID, ID, &W->i_ff2_b)) ||
+          (rc = vec(it[8]->data, ID, ID, &W->i_ln1_g)) || (rc = vec(it[9]->data, ID, ID, &W->i_ln1_b)) ||
+          (rc = vec(it[10]->data, ID, ID, &W->i_ln2_g)) || (rc = vec(it[11]->data, ID, ID, &W->i_ln2_b)))
+        return rc;
+      W->has_inter = true;
+    }
+  }
   T2L_HIP(ctx, hipMalloc(&W->flag, sizeof(int)));
   T2L_HIP(ctx, hipMemset(W->flag, 0, sizeof(int)));
   T2L_HIP(ctx, hipHostMalloc((void**)&W->flag_host, sizeof(int), hipHostMallocDefault));
@@ -666,6 +714,7 @@ int text_head_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const cha
     T2L_TH_ATTR(kEpiReluT16, false); T2L_TH_ATTR(kEpiReluT16, true); T2L_TH_ATTR(kEpiRowMajor, false); T2L_TH_ATTR(kEpiRowMajor, true);
 #undef T2L_TH_ATTR
     T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&th_ln_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 1028 * 4));
+    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&th_ln_kernel<true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 260 * 4));
     attr_done.mark(ctx->device);
   }
   return T2L_OK;
@@ -735,7 +784,7 @@ int text_head_impl(t2l_ctx* ctx, const float* hidden, int n_sent, int L, float* 
     th_launch_gemm<kEpiT32>(single, g, s);
     {
       const int G = 32 / L, n_groups = (ns + G - 1) / G;
-      hipLaunchKernelGGL(th_attn_kernel, dim3(n_groups), dim3(256), 0, s, (const float*)(ws + o_qkv), ns, L, n_groups, (_Float16*)(ws + o_oh),
+      hipLaunchKernelGGL(th_attn_kernel<1024>, dim3(n_groups), dim3(256), 0, s, (const float*)(ws + o_qkv), ns, L, n_groups, (_Float16*)(ws + o_oh),
                          (_Float16*)(ws + o_ol), W->flag);
     }
     // y = x + o W_out^T + b_out -> T32; x1 = LayerNorm1(y) -> planes
@@ -767,6 +816,78 @@ int text_head_impl(t2l_ctx* ctx, const float* hidden, int n_sent, int L, float* 
     th_launch_gemm<kEpiRowMajor>(single, g, s);
   }
   event_end(ctx, "text_head", s);
+  if (overflow) T2L_HIP(ctx, hipMemcpyAsync(overflow, W->flag, sizeof(int), hipMemcpyDeviceToDevice, s));
+  T2L_HIP(ctx, hipGetLastError());
+  return T2L_OK;
+}
+
+// The inter-sentence half of the head (models/language_encoder.py:137-147): sent [n_desc * S][256] row-major (what t2l_text_head
+// returns, description-major) -> view [n_desc, S, 256] -> x += TransformerEncoderLayer(256, 4 heads, ff 1024)(x) over the S
+// sentences of every description -> max over the S sentences -> out [n_desc][256]. The same kernels as the token layer with
+// d_model 256: rows = sentences, "tokens per sentence" = S.
+int text_inter_impl(t2l_ctx* ctx, const float* sent, int n_desc, int S, float* out, int32_t* overflow, hipStream_t s) {
+  using namespace th;
+  constexpr int ID = 256, IF = 1024;
+  Weights* W = (Weights*)ctx->text_head;
+  if (!W) return fail(ctx, T2L_ESTATE, "t2l_text_inter: call t2l_text_head_load_weights first");
+  if (!W->has_inter) return fail(ctx, T2L_ESTATE, "t2l_text_inter: the loaded head has no inter_module.0 of the published shape (256 / 4 heads / 1024)");
+  if (!sent || !out) return fail(ctx, T2L_EINVAL, "t2l_text_inter: null buffer");
+  if (n_desc <= 0) return n_desc == 0 ? T2L_OK : fail(ctx, T2L_EINVAL, "t2l_text_inter: n_descriptions < 0");
+  if (S < 1 || S > kMaxL) return fail(ctx, T2L_EINVAL, "t2l_text_inter: need 1 <= sentences per description <= 32");
+  const bool single = ctx->encoder_f16 != 0;
+  const int rows_target = 65536;  // descriptions per pass: every intermediate of a pass (11.3 KB per row) stays inside the Infinity Cache
+  const int dpc = max(1, min(n_desc, rows_target / S));
+  const int m_cap = (dpc * S + kTile - 1) / kTile * kTile;
+  const int n_chunks = (n_desc + dpc - 1) / dpc;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t plane = (size_t)m_cap * ID * 2;
+  const size_t o_xh = take(plane), o_xl = take(plane), o_qkv = take((size_t)m_cap * 3 * ID * 4), o_oh = take(plane), o_ol = take(plane),
+               o_y = take((size_t)m_cap * ID * 4), o_1h = take(plane), o_1l = take(plane), o_hh = take(plane * 4), o_hl = take(plane * 4);
+  if (W->ws2_cap < off) {
+    if (W->ws2) T2L_HIP(ctx, hipFree(W->ws2));
+    W->ws2 = nullptr;
+    W->ws2_cap = 0;
+    T2L_HIP(ctx, hipMalloc(&W->ws2, off));
+    W->ws2_cap = off;
+  }
+  char* ws = W->ws2;
+  T2L_HIP(ctx, hipMemsetAsync(W->flag, 0, sizeof(int), s));
+  T2L_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)out, (int)0xFF800000u, (size_t)n_desc * ID, s));  // -inf: straddling descriptions meet by atomic max
+  event_begin(ctx, "text_inter", s);
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    const int d0 = ch * dpc, nd = min(dpc, n_desc - d0);
+    const int M = nd * S, m_tiles = (M + kTile - 1) / kTile, m_pad = m_tiles * kTile;
+    const float* x = sent + (size_t)d0 * S * ID;
+    hipLaunchKernelGGL(th_split_kernel, dim3(m_pad / 32, 1), dim3(256), 0, s, x, M, ID, (_Float16*)(ws + o_xh), (_Float16*)(ws + o_xl), W->flag);
+    GemmArgs g{};
+    g.flag = W->flag;
+    g.m_tiles = m_tiles;
+    g.M = M;
+    g.wh = W->i_qkv_h; g.wl = W->i_qkv_l; g.xh = ws + o_xh; g.xl = ws + o_xl; g.bias = W->i_qkv_b; g.out0 = ws + o_qkv;
+    g.n_tiles = 3 * ID / kTile; g.K = ID; g.N = 3 * ID; g.n_real = 3 * ID;
+    th_launch_gemm<kEpiT32>(single, g, s);
+    {
+      const int G = 32 / S, n_groups = (nd + G - 1) / G;
+      hipLaunchKernelGGL(th_attn_kernel<256>, dim3(n_groups), dim3(256), 0, s, (const float*)(ws + o_qkv), nd, S, n_groups, (_Float16*)(ws + o_oh),
+                         (_Float16*)(ws + o_ol), W->flag);
+    }
+    g.wh = W->i_out_h; g.wl = W->i_out_l; g.xh = ws + o_oh; g.xl = ws + o_ol; g.bias = W->i_out_b; g.rh = ws + o_xh; g.rl = ws + o_xl; g.out0 = ws + o_y;
+    g.n_tiles = 1; g.K = ID; g.N = ID; g.n_real = ID;
+    th_launch_gemm<kEpiResidT32>(single, g, s);
+    hipLaunchKernelGGL((th_ln_kernel<false, 256>), dim3(m_pad / 32), dim3(256), 8 * 32 * 4, s, (const float*)(ws + o_y), W->i_ln1_g, W->i_ln1_b, M, S,
+                       (_Float16*)(ws + o_1h), (_Float16*)(ws + o_1l), (float*)nullptr, W->flag, (const float*)nullptr);
+    g.wh = W->i_ff1_h; g.wl = W->i_ff1_l; g.xh = ws + o_1h; g.xl = ws + o_1l; g.bias = W->i_ff1_b; g.out0 = ws + o_hh; g.out1 = ws + o_hl;
+    g.n_tiles = IF / kTile; g.K = ID; g.N = IF; g.n_real = IF;
+    th_launch_gemm<kEpiReluT16>(single, g, s);
+    g.wh = W->i_ff2_h; g.wl = W->i_ff2_l; g.xh = ws + o_hh; g.xl = ws + o_hl; g.bias = W->i_ff2_b; g.rh = ws + o_1h; g.rl = ws + o_1l; g.out0 = ws + o_y;
+    g.n_tiles = 1; g.K = IF; g.N = ID; g.n_real = ID;
+    th_launch_gemm<kEpiResidT32>(single, g, s);
+    // LayerNorm2, + x (the residual AROUND the layer), max over the description's S sentence rows
+    hipLaunchKernelGGL((th_ln_kernel<true, 256>), dim3(m_pad / 32), dim3(256), 32 * 260 * 4, s, (const float*)(ws + o_y), W->i_ln2_g, W->i_ln2_b, M, S,
+                       (_Float16*)nullptr, (_Float16*)nullptr, out + (size_t)d0 * ID, W->flag, x);
+  }
+  event_end(ctx, "text_inter", s);
   if (overflow) T2L_HIP(ctx, hipMemcpyAsync(overflow, W->flag, sizeof(int), hipMemcpyDeviceToDevice, s));
   T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;

@@ -74,6 +74,7 @@ EXPORTS = {
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_text_head_load_weights": (C.c_int, [C.c_void_p, C.POINTER(_WeightDesc), C.c_int32, C.c_char_p]),
     "t2l_text_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "t2l_text_inter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_fine_load_weights": (C.c_int, [C.c_void_p, C.POINTER(_WeightDesc), C.c_int32, C.POINTER(_ModelConfig)]),
     "t2l_fine_encode_objects": (C.c_int, [C.c_void_p, C.POINTER(_PackedCells), C.c_void_p, C.c_void_p]),
     "t2l_fine_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
@@ -264,7 +265,7 @@ class Engine:
         """state_dict: name -> tensor / ndarray holding ``<prefix>intra_module.0.*`` and ``<prefix>inter_mlp.0.*`` (fp32)."""
         keep, descs = [], []
         for name, v in state_dict.items():
-            if not name.startswith((prefix + "intra_module.", prefix + "inter_mlp.")) or name.endswith("num_batches_tracked"):
+            if not name.startswith((prefix + "intra_module.", prefix + "inter_mlp.", prefix + "inter_module.")) or name.endswith("num_batches_tracked"):
                 continue
             a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
             a = np.ascontiguousarray(a, dtype=np.float32)
@@ -283,10 +284,25 @@ class Engine:
         if hidden.dim() != 3 or hidden.shape[2] != 1024:
             raise T2LError(f"text_head: expected [n_sentences, n_tokens, 1024], got {tuple(hidden.shape)}")
         S, L = int(hidden.shape[0]), int(hidden.shape[1])
+        if getattr(self, "_text_head_dim", None) is None:
+            raise T2LError("text_head: call text_head_load_weights first")
         out = torch.empty((S, self._text_head_dim), dtype=torch.float32, device=hidden.device)
         flag = torch.zeros((1,), dtype=torch.int32, device=hidden.device)
         self._check(self.lib.t2l_text_head(self._h, self._ptr(hidden, torch.float32, "hidden"), S, L, out.data_ptr(), flag.data_ptr(),
                                            _stream_ptr(self.device)))
+        return (out, bool(flag.item())) if check else (out, flag)
+
+    def text_inter(self, sent: torch.Tensor, n_descriptions: int, check: bool = True):
+        """sent f32[n_descriptions * S, 256] (t2l_text_head's output, description-major) -> f32[n_descriptions, 256] =
+        max over the S sentences of x + inter_module[0](x) (models/language_encoder.py:137-147). Returns (out, overflowed) like
+        ``text_head``."""
+        if sent.dim() != 2 or sent.shape[1] != 256 or n_descriptions <= 0 or sent.shape[0] % n_descriptions:
+            raise T2LError(f"text_inter: expected [n_descriptions * S, 256], got {tuple(sent.shape)} for {n_descriptions} descriptions")
+        S = int(sent.shape[0]) // n_descriptions
+        out = torch.empty((n_descriptions, 256), dtype=torch.float32, device=sent.device)
+        flag = torch.zeros((1,), dtype=torch.int32, device=sent.device)
+        self._check(self.lib.t2l_text_inter(self._h, self._ptr(sent, torch.float32, "sent"), n_descriptions, S, out.data_ptr(), flag.data_ptr(),
+                                            _stream_ptr(self.device)))
         return (out, bool(flag.item())) if check else (out, flag)
 
     # ------------------------------------------------------------------ fine stage (f-1)
