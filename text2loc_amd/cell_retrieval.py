@@ -232,20 +232,28 @@ class LanguageEncoder(nn.Module):
         x = x.permute(1, 0, 2).contiguous().max(dim=1)[0]
         return self.inter_mlp(x)
 
+    def _open_call(self, device):
+        if getattr(self, "_deferred", None) is not None:
+            self._deferred.append(torch.zeros((1,), dtype=torch.int32, device=device))  # one entry per head() / forward() call
+
     def head(self, hidden: torch.Tensor, batch_size: int) -> torch.Tensor:
         """hidden: last_hidden_state [n_sentences_total, L, C] -> [B, D] (language_encoder.py:127-148)."""
-        if getattr(self, "_deferred", None) is not None:
-            self._deferred.append(torch.zeros((1,), dtype=torch.int32, device=hidden.device))  # one entry per head() call
+        self._open_call(hidden.device)
         n_eng = LanguageEncoder.head_engine_calls
         x = self._head_first_half(hidden)
         gate = LanguageEncoder.head_engine_calls != n_eng  # (a batch that fell back to the PyTorch modules stays on them to the end)
+        return self._head_second_half(x, batch_size, gate)
+
+    def _head_second_half(self, x: torch.Tensor, batch_size: int, engine_ok: bool) -> torch.Tensor:
+        """[n_sentences_total, D] -> [B, D]: view per description, x += inter_module(x), max over the sentences
+        (language_encoder.py:137-147); the fine model returns the view (:139-140)."""
         if x.shape[0] % batch_size:
             raise T2LError(f"{x.shape[0]} sentences do not split evenly over {batch_size} descriptions")
         n_per = x.shape[0] // batch_size
         if self.is_fine:
             return x.view(batch_size, n_per, -1)
-        if gate and self._inter_gate(n_per):  # the 256-wide half in the engine too (t2l_text_inter)
-            out, flag = self._head_engine(hidden.device).text_inter(x.contiguous(), batch_size, check=False)
+        if engine_ok and self._inter_gate(n_per):  # the 256-wide half in the engine too (t2l_text_inter)
+            out, flag = self._head_engine(x.device).text_inter(x.contiguous(), batch_size, check=False)
             out, overflowed = self._settle(out, flag)
             if not overflowed:
                 LanguageEncoder.inter_engine_calls += 1
@@ -256,7 +264,46 @@ class LanguageEncoder(nn.Module):
             x = x + layer(x)
         return x.max(dim=0)[0]
 
+    # ---- T5 behind a per-sentence cache (text2loc_amd.text_cache.TextCache) ----------------------------------------------------
+    text_cache = None            # set to a TextCache: sentences it holds skip the tokenizer + T5 (valid while T5 is frozen)
+    memoise_sentence_vectors = True  # eval mode: the per-sentence half of the head is memoised too (a function of sentence and L)
+    cache_in_training = False    # opt-in: under model.train() the reference leaves the frozen T5 in train mode too, i.e. its dropout
+                                 # (p = 0.1) stays ACTIVE (language_encoder.py:118-126 never calls llm_model.eval()); the cache
+                                 # holds eval-mode states, so serving a training step from it removes that noise
+    cache_calls = 0              # forward() calls served from the cache / through T5
+    t5_calls = 0
+
+    def _cache_usable(self) -> bool:
+        return self.text_cache is not None and self.fixed_embedding and (not self.training or self.cache_in_training)
+
+    def _from_cache(self, sentences: List[str], batch_size: int, hit=None) -> Optional[torch.Tensor]:
+        cache = self.text_cache
+        if hit is None:
+            if not self._cache_usable():
+                return None
+            hit = cache.lookup(sentences)
+            if hit is None:
+                return None
+        rows, L = hit
+        LanguageEncoder.cache_calls += 1
+        inference = not self.training and not torch.is_grad_enabled()
+        if inference and self.memoise_sentence_vectors:
+            version = (bool(self.use_engine_head),) + tuple((t.data_ptr(), t._version) for t in self._head_params())
+            deferred, self._deferred = getattr(self, "_deferred", None), None  # (the memo is checked synchronously: never cache a poisoned batch)
+            try:
+                vec = cache.sentence_vectors(self, L, version)
+            finally:
+                self._deferred = deferred
+            self._open_call(vec.device)
+            engine_ok = self.use_engine_head and vec.is_cuda
+            return self._head_second_half(vec.index_select(0, rows), batch_size, engine_ok)
+        return self.head(cache.hidden_states(rows, L), batch_size)
+
     def forward(self, descriptions: List[str]) -> torch.Tensor:
+        if self._cache_usable() and len(descriptions) and isinstance(descriptions[0], str):
+            hit = self.text_cache.lookup_descriptions(descriptions)  # descriptions seen before: no regex, one dict probe each
+            if hit is not None:
+                return self._from_cache([], len(descriptions), hit[:2])
         sentences: List[str] = []
         per_desc = []
         for d in descriptions:
@@ -267,6 +314,11 @@ class LanguageEncoder(nn.Module):
             # the reference reshapes [n_sentences_total] -> [batch, n // batch] (language_encoder.py:113,138): ragged hint
             # counts either crash there or silently hand sentences to the wrong description. Refuse them.
             raise T2LError(f"every description of a batch must hold the same number of sentences, got {sorted(set(per_desc))}")
+        cached = self._from_cache(sentences, len(descriptions))
+        if cached is not None:
+            self.text_cache.remember(descriptions, sentences)
+            return cached
+        LanguageEncoder.t5_calls += 1
         inputs = self.tokenizer(sentences, return_tensors="pt", padding="longest")
         dev = self.device
         out = self.llm_model(input_ids=inputs["input_ids"].to(dev), attention_mask=inputs["attention_mask"].to(dev),

@@ -1,0 +1,151 @@
+"""Per-sentence cache of the frozen T5 encoder's output — the query side of "T5 embeddings precomputed" (BASELINE config 2).
+
+Reference: ``LanguageEncoder.forward`` (models/language_encoder.py:106-126) tokenises every hint sentence of every description
+and runs T5-large over them on EVERY call, although the hints are template sentences (dataloading/kitti360pose/base.py:60-68:
+direction x colour x class, about 10^3 distinct strings) and T5 is frozen (``--fixed_embedding``, README.md:87-99). With
+``padding="longest"`` + the attention mask, T5's hidden state at position i of a sentence depends on that sentence and on i
+only — real tokens and pad positions alike: pad keys are masked, the position bias is relative, everything else is per position —
+so it can be computed ONCE per distinct sentence for positions [0, Lmax) and gathered:
+
+    cache = TextCache.build(model.language_encoder, dataset)        # distinct sentences -> T5 once -> f32[n, Lmax, 1024] in HBM
+    model.language_encoder.text_cache = cache                       # encode_text = gather + t2l_text_head + t2l_text_inter
+
+A batch whose longest sentence has L tokens uses positions [0, L) of each of its sentences — exactly the tensor the reference's
+tokenizer call + T5 produce for that batch (up to the rounding of differently-shaped rocBLAS calls). T5 itself is untouched and
+remains the path of a batch holding a sentence the cache cannot take (longer than Lmax); unseen sentences are encoded once and
+added. In eval mode the head's per-sentence half (intra_module + max + inter_mlp: a function of the sentence and L alone) is
+memoised too (``sentence_vectors``), keyed on L and the head's weight version: encode_text is then a gather of [256]-vectors and
+the inter-sentence layer.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional
+
+import numpy as np
+import torch
+
+
+class TextCache:
+    def __init__(self, tokenizer, llm_model, device, max_tokens: int = 32, dim: int = 1024):
+        self.tokenizer, self.llm_model, self.device = tokenizer, llm_model, torch.device(device)
+        self.max_tokens, self.dim = int(max_tokens), int(dim)
+        self.index: Dict[str, int] = {}
+        self.hidden = torch.empty((0, self.max_tokens, self.dim), dtype=torch.float32, device=self.device)
+        self.n_tok = np.zeros((0,), dtype=np.int32)          # token count of every cached sentence (host: it sizes the batch)
+        self._vec: Dict[tuple, torch.Tensor] = {}            # (L, weights version) -> f32[n, D] per-sentence vectors (eval mode)
+        self._desc: Dict[str, np.ndarray] = {}               # description string -> its sentences' rows (evaluation sets repeat)
+        self.t5_sentences = 0                                # sentences that went through T5 (build + later misses)
+        self.hits = self.misses = 0
+
+    # ------------------------------------------------------------------ building
+    @staticmethod
+    def sentences_of(source) -> List[str]:
+        """Distinct hint sentences of a dataset (``hint_descriptions``: one list of sentences per pose), of an iterable of
+        descriptions (split like the reference's sent_tokenize on the template, language_encoder.py:108-110) or of sentences."""
+        from .cell_retrieval import LanguageEncoder
+
+        out = set()
+        hd = getattr(source, "hint_descriptions", None)
+        if hd is not None:
+            for hints in hd:
+                out.update(str(h) for h in hints)
+        else:
+            for d in source:
+                out.update(LanguageEncoder.split_sentences(str(d)))
+        return sorted(out)
+
+    @classmethod
+    def build(cls, language_encoder, source, max_tokens: Optional[int] = None, batch_size: int = 512, margin: int = 2) -> "TextCache":
+        sentences = cls.sentences_of(source)
+        tok = language_encoder.tokenizer
+        lens = [len(ids) for ids in tok(sentences)["input_ids"]] if sentences else [1]
+        if max_tokens is None:
+            max_tokens = min(32, max(lens) + margin)  # (t2l_text_head holds up to 32 token positions per sentence)
+        dim = language_encoder.intra_module[0].linear1.in_features
+        cache = cls(tok, language_encoder.llm_model, language_encoder.device, max_tokens, dim)
+        cache.add(sentences, batch_size)
+        return cache
+
+    def add(self, sentences: Iterable[str], batch_size: int = 512) -> bool:
+        """T5 over the sentences not cached yet, all padded to ``max_tokens``. False (nothing added) when one is too long."""
+        new = [s for s in dict.fromkeys(sentences) if s not in self.index]
+        if not new:
+            return True
+        lens = [len(ids) for ids in self.tokenizer(new)["input_ids"]]
+        if max(lens) > self.max_tokens:
+            return False
+        parts = []
+        with torch.no_grad():
+            for lo in range(0, len(new), batch_size):
+                enc = self.tokenizer(new[lo:lo + batch_size], return_tensors="pt", padding="max_length", max_length=self.max_tokens)
+                out = self.llm_model(input_ids=enc["input_ids"].to(self.device), attention_mask=enc["attention_mask"].to(self.device),
+                                     output_attentions=False)
+                parts.append(out.last_hidden_state.detach().float())
+        base = len(self.index)
+        for i, s in enumerate(new):
+            self.index[s] = base + i
+        self.hidden = torch.cat([self.hidden] + parts, dim=0).contiguous()
+        self.n_tok = np.concatenate([self.n_tok, np.asarray(lens, dtype=np.int32)])
+        self.t5_sentences += len(new)
+        self._vec.clear()
+        return True
+
+    # ------------------------------------------------------------------ serving
+    def lookup(self, sentences: List[str], add_missing: bool = True):
+        """-> (row index i64 tensor on the device, L = token count of the batch's longest sentence) or None (use T5)."""
+        idx = [self.index.get(s, -1) for s in sentences]
+        if min(idx) < 0:
+            self.misses += 1
+            if not (add_missing and self.add([s for s, i in zip(sentences, idx) if i < 0])):
+                return None
+            idx = [self.index[s] for s in sentences]
+        else:
+            self.hits += 1
+        ia = np.asarray(idx, dtype=np.int64)
+        return torch.from_numpy(ia).to(self.device), int(self.n_tok[ia].max())
+
+    def lookup_descriptions(self, descriptions: List[str]):
+        """The same for whole descriptions seen before (one dict probe per description instead of a regex split and one probe per
+        sentence: 4,096 descriptions cost ~1 ms of Python instead of ~15). -> (rows, L, sentences per description) or None."""
+        parts = []
+        for d in descriptions:
+            r = self._desc.get(d)
+            if r is None:
+                return None
+            parts.append(r)
+        n_per = len(parts[0])
+        if any(len(r) != n_per for r in parts):
+            return None
+        ia = np.concatenate(parts)
+        self.hits += 1
+        return torch.from_numpy(ia).to(self.device), int(self.n_tok[ia].max()), n_per
+
+    def remember(self, descriptions: List[str], sentences: List[str]):
+        n_per = len(sentences) // max(1, len(descriptions))
+        if len(self._desc) > (1 << 20):
+            self._desc.clear()
+        for i, d in enumerate(descriptions):
+            if d not in self._desc:
+                self._desc[d] = np.asarray([self.index[s] for s in sentences[i * n_per:(i + 1) * n_per]], dtype=np.int64)
+
+    def hidden_states(self, rows: torch.Tensor, L: int) -> torch.Tensor:
+        """[n_sentences, L, dim]: what the reference's tokenizer(padding="longest") + T5 hand the head for these sentences."""
+        return self.hidden[:, :L].index_select(0, rows)
+
+    def sentence_vectors(self, language_encoder, L: int, version) -> torch.Tensor:
+        """Eval mode: f32[n_cached, D] = inter_mlp(max over tokens(intra_module(hidden[:, :L]))) of EVERY cached sentence, computed
+        once per (L, head weights version) by the head's own first half (engine or PyTorch, whatever serves the model)."""
+        key = (int(L), version)
+        v = self._vec.get(key)
+        if v is None:
+            if len(self._vec) > 8:
+                self._vec.clear()
+            with torch.no_grad():
+                parts = [language_encoder._head_first_half(self.hidden[lo:lo + 4096, :L].contiguous())
+                         for lo in range(0, len(self.hidden), 4096)]
+            v = self._vec[key] = torch.cat(parts, dim=0).contiguous()
+        return v
+
+    def stats(self) -> dict:
+        return {"sentences": len(self.index), "max_tokens": self.max_tokens, "hbm_mbytes": self.hidden.numel() * 4 / 1e6,
+                "t5_sentences": self.t5_sentences, "batches_all_hits": self.hits, "batches_with_misses": self.misses}
