@@ -337,6 +337,30 @@ int t2l_pointnet_backward(t2l_ctx* ctx, const float* grad_features2, void* strea
  * object branch (steps on every call) and the PointNet++ backbone, which steps only when t2l_pointnet_backward ran since the
  * last t2l_zero_grad (a batch fed precomputed features2 leaves the backbone's weights AND moments untouched). */
 int t2l_zero_grad(t2l_ctx* ctx, void* stream);
+
+/* ---- the text head in TRAINING mode (f-4 / the text half of a9) ---------------------------------- */
+/* Replaces: LanguageEncoder.forward downstream of T5's last_hidden_state under model.train() + its autograd backward
+ * (models/language_encoder.py:127-147 as run by training/coarse.py:44,55-56; the published command trains this head —
+ * --fixed_embedding freezes T5 only, README.md:87-99).
+ * t2l_text_train_bind: live device pointers (data, grad) of `<prefix>intra_module.0.*` (d_model 1024, 4 heads, ff 4096),
+ * `<prefix>inter_mlp.0.{0.weight [256,1024], 0.bias, 1.weight, 1.bias, 1.running_mean, 1.running_var}` (the two running buffers
+ * without grad) and `<prefix>inter_module.0.*` (d_model 256, 4 heads, ff 1024); prefix NULL = "language_encoder.". No copies: the
+ * kernels read the parameters and accumulate (+=) into the gradient buffers the caller's optimizer owns (torch.optim.Adam steps
+ * them). Pointers must stay valid until the next bind.
+ * t2l_text_head_train: hidden = dev f32[n_sentences, n_tokens, 1024], sentence-major and description-major (sentence j of
+ * description i is row i * S + j, S = n_sentences / n_descriptions — the reference's own order); out = dev f32[n_descriptions, 256],
+ * not normalised. Training-mode semantics: the four dropout sites of both TransformerEncoderLayers drop with probability
+ * dropout_p by the counter-based masks of t2l_encode_cells_train (sites 0-3: the token layer, 4-7: the inter-sentence layer);
+ * BatchNorm1d of inter_mlp normalises with the statistics of THIS batch of sentences and updates the running buffers (momentum
+ * 0.1, unbiased running variance). Activations are kept inside the context until the next forward.
+ * t2l_text_head_backward: grad_out = dev f32[n_descriptions, 256] (dLoss / d out); parameter gradients are accumulated into the
+ * bound buffers; `hidden` receives no gradient (T5 is frozen; a caller that trains T5 keeps the PyTorch path).
+ * Arithmetic: f32 (option "train_bf16" = 1 / 2: bf16 / split-bf16 GEMM operands as for the object branch). */
+int t2l_text_train_bind(t2l_ctx* ctx, const t2l_train_tensor* tensors, int32_t n, const char* prefix);
+int t2l_text_head_train(t2l_ctx* ctx, const float* hidden, int32_t n_sentences, int32_t n_tokens, int32_t n_descriptions, float dropout_p,
+                        uint32_t seed, float* out, void* stream);
+int t2l_text_head_backward(t2l_ctx* ctx, const float* grad_out, void* stream);
+
 int t2l_adam_step(t2l_ctx* ctx, float lr, float beta1, float beta2, float eps, void* stream);
 
 /* optimizer.state_dict() / load_state_dict() for the engine-stepped tensors (torch.optim.Adam keeps exp_avg / exp_avg_sq /

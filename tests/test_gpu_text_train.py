@@ -1,0 +1,196 @@
+"""GPU tier, SURVEY.md 8 f-4 / the text half of a9: the head after the frozen T5 in TRAINING mode on the engine
+(t2l_text_train_bind / t2l_text_head_train / t2l_text_head_backward, behind ``LanguageEncoder.head`` under ``model.train()``):
+against the float64 oracle (oracle/t2l_oracle_text_train.py, pinned to the reference by tests/test_oracle_train.py) with the
+counter-based dropout masks ON, against the reference's own step (tests/golden/train_step_text.npz, dropout sites at p = 0), and
+against torch autograd over the same nn.Modules for a few Adam steps."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from text2loc_amd import synth
+
+pytestmark = pytest.mark.gpu
+P = "language_encoder."
+
+
+def _bind(eng, sd):
+    tensors = {}
+    for k, v in sd.items():
+        if not k.startswith((P + "intra_module.0.", P + "inter_mlp.0.", P + "inter_module.0.")) or k.endswith("num_batches_tracked"):
+            continue
+        t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda()
+        tensors[k] = (t, None if "running_" in k else torch.zeros_like(t))
+    eng.text_train_bind(tensors)
+    return tensors
+
+
+def _check_grads(tensors, ref_grads, tol_rms, frac=0.97):
+    worst = {}
+    for n, rg in ref_grads.items():
+        g = tensors[n][1].cpu().numpy().astype(np.float64)
+        rg = np.asarray(rg, dtype=np.float64).reshape(g.shape)
+        rms = float(np.sqrt((rg ** 2).mean()))
+        err = np.abs(g - rg)
+        if n.endswith(("inter_mlp.0.0.bias", "intra_module.0.norm2.bias")):
+            # true gradient 0: a constant per column in front of a BatchNorm (the Linear's bias; LayerNorm2's bias shifts every token
+            # of a column alike, so it passes the max and the Linear as a constant) — float32 leaves noise
+            assert np.abs(rg).max() < 1e-9 and err.max() < 1e-4, n
+            continue
+        if n.endswith("in_proj_bias"):  # the key third has true gradient 0 (softmax is shift-invariant)
+            D = g.size // 3
+            sel = np.r_[0:D, 2 * D:3 * D]
+            err, rms = err[sel], float(np.sqrt((rg[sel] ** 2).mean()))
+        worst[n] = float(err.max() / (rms + 1e-12))
+        assert float((err < tol_rms * rms + 1e-7).mean()) >= frac and err.max() < 20 * tol_rms * rms + 1e-6, (n, worst[n])
+    return worst
+
+
+@pytest.mark.parametrize("n_desc,S,L,p", [(4, 6, 7, 0.1), (3, 6, 16, 0.0), (2, 5, 32, 0.1), (9, 1, 1, 0.1), (16, 6, 12, 0.1)])
+def test_engine_text_train_matches_the_float64_oracle(n_desc, S, L, p):
+    from oracle import t2l_oracle_text_train as OTT
+    from text2loc_amd.engine import Engine
+
+    sd = synth.make_language_head_weights(6)
+    hidden = synth.make_t5_hidden(n_desc * S, L, seed=n_desc * 10 + L)
+    rng = np.random.default_rng(L)
+    G = rng.standard_normal((n_desc, 256)).astype(np.float32)
+    seed = 1234 + L
+    eng = Engine(0)
+    try:
+        tensors = _bind(eng, sd)
+        out = eng.text_head_train(torch.from_numpy(hidden).cuda(), n_desc, dropout_p=p, seed=seed)
+        eng.text_head_backward(torch.from_numpy(G).cuda())
+        torch.cuda.synchronize()
+        ref, info = OTT.text_head_train(hidden, sd, n_desc, grad_out=G, p_drop=float(np.float32(p)), seed=seed)
+        assert np.abs(out.cpu().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+        # float32 summation order under a BatchNorm over a few dozen rows and through two LayerNorm'd layers: median-tight, tails bounded
+        _check_grads(tensors, info["grads"], tol_rms=5e-3, frac=0.9)
+        new = __import__("oracle.t2l_oracle_train", fromlist=["x"]).bn_running_update(sd, info["bn_stats"])
+        for k in (P + "inter_mlp.0.1.running_mean", P + "inter_mlp.0.1.running_var"):
+            assert np.allclose(tensors[k][0].cpu().numpy(), new[k], rtol=2e-4, atol=2e-5), k
+        # a second backward of the same forward accumulates (+=)
+        g1 = tensors[P + "inter_module.0.linear2.weight"][1].clone()
+        eng.text_head_backward(torch.from_numpy(G).cuda())
+        torch.cuda.synchronize()
+        assert torch.allclose(tensors[P + "inter_module.0.linear2.weight"][1], 2 * g1, rtol=1e-4, atol=1e-6)
+    finally:
+        eng.close()
+
+
+def _encoder(seed):
+    from text2loc_amd.cell_retrieval import LanguageEncoder
+
+    enc = LanguageEncoder(256, fixed_embedding=True, intra_module_num_layers=1, inter_module_num_layers=1, llm_model=object(),
+                          tokenizer=None, input_dim=1024)
+    sd = {k[len(P):]: torch.from_numpy(v) for k, v in synth.make_language_head_weights(seed).items()}
+    missing, unexpected = enc.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    return enc.cuda()
+
+
+def _no_dropout(enc):
+    for layer in list(enc.intra_module) + list(enc.inter_module):
+        layer.dropout.p = layer.dropout1.p = layer.dropout2.p = 0.0
+        layer.self_attn.dropout = 0.0
+
+
+def test_language_encoder_train_step_matches_the_reference_step(golden):
+    """LanguageEncoder.head under train() -> F.normalize -> ContrastiveLoss -> backward, served by the engine, against the imported
+    reference's own run of exactly that (train_step_text.npz: head output, loss, every head gradient, the BatchNorm buffers)."""
+    from tests.test_oracle_train import golden_view
+    from text2loc_amd.cell_retrieval import LanguageEncoder
+    from text2loc_amd.losses import ContrastiveLoss
+
+    g = golden("train_step_text")
+    B, S, L = int(g["batch"]), int(g["n_hints"]), int(g["n_tokens"])
+    enc = _encoder(int(g["weight_seed"]))
+    _no_dropout(enc)
+    enc.train()
+    hidden = torch.from_numpy(synth.make_t5_hidden(B * S, L, seed=int(g["hidden_seed"]))).cuda()
+    n0 = LanguageEncoder.train_engine_calls
+    out = enc.head(hidden, B)
+    assert LanguageEncoder.train_engine_calls == n0 + 1 and out.requires_grad
+    assert np.abs(out.detach().cpu().numpy() - g["head_out"]).max() < 5e-5 * max(1.0, np.abs(g["head_out"]).max())
+    anchor = torch.nn.functional.normalize(out)
+    loss = ContrastiveLoss(float(g["temperature"]))(anchor, torch.from_numpy(g["cells"]).cuda())
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+    loss.backward()
+    torch.cuda.synchronize()
+    params = dict(enc.named_parameters())
+    for n in [str(x) for x in g["used_params"]]:
+        grad = params[n[len(P):]].grad
+        assert grad is not None, n
+        exp, got = golden_view(g, "grad", n, grad.cpu().numpy())
+        rms = float(g[f"grad_norm/{n}"]) / np.sqrt(max(grad.numel(), 1))
+        if n.endswith(("inter_mlp.0.0.bias", "intra_module.0.norm2.bias")):
+            assert np.abs(got).max() < 1e-4
+            continue
+        if n.endswith("in_proj_bias") and len(got) <= 1024:
+            D = len(got) // 3
+            sel = np.r_[0:D, 2 * D:3 * D]
+            exp, got = exp[sel], got[sel]
+        err = np.abs(got - exp)
+        assert (err < 1e-2 * rms + 1e-6).mean() >= 0.95 and err.max() < 0.2 * rms + 1e-5, (n, float(err.max()), rms)
+    for k in g.files:
+        if k.startswith("buf/"):
+            got = dict(enc.named_buffers())[k[4 + len(P):]].cpu().numpy()
+            assert np.allclose(got, g[k], rtol=2e-4, atol=2e-5), k
+
+
+def test_engine_train_head_tracks_torch_autograd_over_adam_steps():
+    """Four optimisation steps (dropout off): the engine-served head + torch.optim.Adam on its parameters follows a deep copy
+    trained by torch autograd on the PyTorch modules; then eval-mode agreement of the two."""
+    from text2loc_amd.cell_retrieval import LanguageEncoder
+    from text2loc_amd.losses import ContrastiveLoss
+
+    B, S, L = 16, 6, 10
+    enc = _encoder(3)
+    _no_dropout(enc)
+    ref = copy.deepcopy(enc)
+    ref.use_engine_head = False
+    opt, opt_ref = torch.optim.Adam(enc.parameters(), lr=1e-4), torch.optim.Adam(ref.parameters(), lr=1e-4)
+    crit = ContrastiveLoss(0.1)
+    enc.train()
+    ref.train()
+    cells = torch.nn.functional.normalize(torch.randn(B, 256, generator=torch.Generator().manual_seed(0))).cuda()
+    losses, losses_ref = [], []
+    n0, t0 = LanguageEncoder.train_engine_calls, LanguageEncoder.head_torch_calls
+    for step in range(4):
+        hidden = torch.from_numpy(synth.make_t5_hidden(B * S, L, seed=50 + step)).cuda()
+        for o, m, acc in ((opt, enc, losses), (opt_ref, ref, losses_ref)):
+            o.zero_grad()
+            loss = crit(torch.nn.functional.normalize(m.head(hidden, B)), cells)
+            loss.backward()
+            o.step()
+            acc.append(float(loss.detach()))
+    assert LanguageEncoder.train_engine_calls == n0 + 4 and LanguageEncoder.head_torch_calls == t0 + 4
+    assert np.allclose(losses, losses_ref, rtol=2e-3), (losses, losses_ref)
+    enc.eval()
+    ref.eval()
+    hidden = torch.from_numpy(synth.make_t5_hidden(B * S, L, seed=99)).cuda()
+    with torch.no_grad():
+        a, b = enc.head(hidden, B), ref.head(hidden, B)
+    assert float((a - b).abs().max()) < 5e-3 * float(b.abs().max())
+    assert int(enc.inter_mlp[0][1].num_batches_tracked) == int(ref.inter_mlp[0][1].num_batches_tracked)
+
+
+def test_training_mode_keeps_the_pytorch_modules_where_the_engine_does_not_apply():
+    from text2loc_amd.cell_retrieval import LanguageEncoder
+
+    enc = _encoder(1)
+    enc.train()
+    hidden = torch.from_numpy(synth.make_t5_hidden(12, 8, seed=1)).cuda()
+    n0 = LanguageEncoder.train_engine_calls
+    enc.intra_module[0].dropout1.p = 0.3  # site-specific probabilities: the PyTorch path
+    y = enc.head(hidden, 2)
+    assert LanguageEncoder.train_engine_calls == n0 and y.requires_grad
+    enc.intra_module[0].dropout1.p = 0.1
+    h2 = hidden.clone().requires_grad_(True)  # a trainable T5 upstream needs d/d hidden
+    enc.head(h2, 2).sum().backward()
+    assert LanguageEncoder.train_engine_calls == n0 and h2.grad is not None
+    y = enc.head(hidden, 2)  # the published configuration: served by the engine, with live dropout
+    assert LanguageEncoder.train_engine_calls == n0 + 1
+    y2 = enc.head(hidden, 2)
+    assert float((y - y2).abs().max()) > 1e-4  # a fresh mask every call

@@ -217,3 +217,85 @@ def test_pointnet_train_oracle_gradients_match_central_differences():
             assert best < 1e-5, (name, idx, num, g.ravel()[idx])
             checked += 1
     assert checked == 27
+
+
+# ---- the TEXT half of the step (oracle/t2l_oracle_text_train.py) ---------------------------------------------------------------
+def _text_case(g):
+    from oracle import t2l_oracle_text_train as OTT
+
+    B, S, L = int(g["batch"]), int(g["n_hints"]), int(g["n_tokens"])
+    sd = synth.make_language_head_weights(int(g["weight_seed"]))
+    hidden = synth.make_t5_hidden(B * S, L, seed=int(g["hidden_seed"]))
+    return OTT, sd, hidden, B
+
+
+def text_loss_grad(head_out, cells, temperature):
+    """d ContrastiveLoss(F.normalize(head_out), cells) / d head_out (cell_retrieval.py:57-63 + training/losses.py:269-283)."""
+    y, n = OT._normalize_fwd(np.asarray(head_out, dtype=np.float64))
+    loss, d_anchor, _ = O.contrastive_loss(y, cells, temperature, dtype=np.float64)
+    return loss, y, OT._normalize_bwd(d_anchor, y, n)
+
+
+def test_text_head_train_oracle_matches_the_reference_step(golden):
+    g = golden("train_step_text")
+    OTT, sd, hidden, B = _text_case(g)
+    out0, _ = OTT.text_head_train(hidden, sd, B)
+    assert np.abs(out0 - g["head_out"]).max() < 2e-5 * max(1.0, np.abs(g["head_out"]).max())
+    loss, anchor, d_out = text_loss_grad(out0, g["cells"], float(g["temperature"]))
+    assert np.abs(anchor - g["anchor"]).max() < 2e-6 and abs(loss - float(g["loss"])) < 2e-6 * max(1.0, abs(loss))
+    _, info = OTT.text_head_train(hidden, sd, B, grad_out=d_out)
+    used = [str(n) for n in g["used_params"]]
+    assert sorted(used) == sorted(info["grads"].keys()) and len(used) == 28
+    for n in used:
+        exp, got = golden_view(g, "grad", n, info["grads"][n])
+        rms = float(g[f"grad_norm/{n}"]) / np.sqrt(max(np.asarray(info["grads"][n]).size, 1))
+        if n.endswith(("inter_mlp.0.0.bias", "intra_module.0.norm2.bias")):  # a constant per column in front of a BatchNorm: true gradient 0
+            assert np.abs(got).max() < 1e-9 and np.abs(exp).max() < 1e-4, n
+            continue
+        if n.endswith("in_proj_bias"):  # the key bias has true gradient 0 (softmax is shift-invariant): compare where it is not noise
+            D = len(got) // 3
+            sel = np.r_[0:D, 2 * D:3 * D] if len(got) <= 1024 else None
+            if sel is not None:
+                exp, got = exp[sel], got[sel]
+        err = np.abs(got - exp)
+        assert (err < 1e-2 * rms + 1e-6).mean() >= 0.95 and err.max() < 0.2 * rms + 1e-5, (n, float(err.max()), rms)
+    new = OT.bn_running_update(sd, info["bn_stats"])
+    for k in g.files:
+        if k.startswith("buf/"):
+            assert np.allclose(np.asarray(new[k[4:]], dtype=np.float64), g[k], rtol=2e-5, atol=2e-6), k
+
+
+def test_text_head_train_oracle_backward_is_the_derivative_of_its_forward(golden):
+    """Central differences of the float64 forward with the dropout masks ON (p = 0.1), on a small case."""
+    from oracle import t2l_oracle_text_train as OTT
+
+    sd = {k: np.asarray(v, dtype=np.float64) for k, v in synth.make_language_head_weights(7).items()}
+    hidden = synth.make_t5_hidden(4 * 3, 5, seed=3).astype(np.float64)
+    rng = np.random.default_rng(0)
+    G = rng.standard_normal((4, 256))
+
+    def f(sd_):
+        out, _ = OTT.text_head_train(hidden, sd_, 4, p_drop=0.1, seed=11)
+        return float((out * G).sum())
+
+    _, info = OTT.text_head_train(hidden, sd, 4, grad_out=G, p_drop=0.1, seed=11)
+    checked = 0
+    for name in ("language_encoder.intra_module.0.linear1.weight", "language_encoder.intra_module.0.self_attn.in_proj_weight",
+                 "language_encoder.inter_mlp.0.0.weight", "language_encoder.inter_mlp.0.1.weight",
+                 "language_encoder.inter_module.0.self_attn.out_proj.weight", "language_encoder.inter_module.0.norm2.bias",
+                 "language_encoder.intra_module.0.norm1.weight"):
+        w = sd[name]
+        flat = w.reshape(-1)
+        for i in rng.choice(flat.size, size=3, replace=False):
+            old = flat[i]
+            eps = 1e-6 * max(1.0, abs(old))  # (small: a ReLU or an arg-max switching inside the interval is the only way to fail)
+            flat[i] = old + eps
+            fp = f(sd)
+            flat[i] = old - eps
+            fm = f(sd)
+            flat[i] = old
+            num = (fp - fm) / (2 * eps)
+            ana = float(np.asarray(info["grads"][name]).reshape(-1)[i])
+            assert abs(num - ana) < 1e-5 * max(1.0, abs(ana)) + 1e-7, (name, i, num, ana)
+            checked += 1
+    assert checked == 21

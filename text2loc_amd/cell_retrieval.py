@@ -101,6 +101,28 @@ class ObjectEncoderParams(nn.Module):
         self.mlp_merge = get_mlp([len(args.use_features) * embed_dim, embed_dim])
 
 
+class _TextHeadTrainFn(torch.autograd.Function):
+    """The head after T5 under model.train(): forward and backward are HIP (t2l_text_head_train / t2l_text_head_backward). Parameter
+    gradients do not flow through autograd: the engine accumulates them straight into the parameters' ``.grad`` buffers (bound by
+    pointer), which torch's Adam steps; the hidden states are constants (T5 is frozen). ``hook`` is a dummy leaf that makes
+    autograd call ``backward``."""
+
+    @staticmethod
+    def forward(ctx, hook, hidden, enc, batch_size, p_drop, seed):
+        out = enc._th_train_engine.text_head_train(hidden, batch_size, dropout_p=p_drop, seed=seed)
+        ctx.enc = enc
+        ctx.token = enc._th_train_token = object()
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        enc = ctx.enc
+        if enc._th_train_token is not ctx.token:
+            raise T2LError("backward of a stale text-head call: the engine keeps the activations of the LAST training-mode forward only")
+        enc._th_train_engine.text_head_backward(grad_out.contiguous().float())
+        return None, None, None, None, None, None
+
+
 class LanguageEncoder(nn.Module):
     """Text branch (models/language_encoder.py:76-152): frozen T5 encoder -> 1 Transformer layer over tokens (no
     padding mask) -> max over tokens -> Linear+BN -> residual Transformer layer over the hint sentences -> max.
@@ -236,8 +258,65 @@ class LanguageEncoder(nn.Module):
         if getattr(self, "_deferred", None) is not None:
             self._deferred.append(torch.zeros((1,), dtype=torch.int32, device=device))  # one entry per head() / forward() call
 
+    # ---- training mode: the whole head after T5 in the engine (t2l_text_head_train / _backward) ------------------------------------
+    use_engine_train_head = True
+    train_engine_calls = 0
+    _th_train_engine = None
+    _th_train_token = None
+    _th_train_key = None
+    _th_drop_calls = 0
+
+    def _train_gate(self, hidden: torch.Tensor, batch_size: int):
+        """-> dropout p when the engine's training head can serve this call, else None (the PyTorch modules do)."""
+        if not (self.use_engine_head and self.use_engine_train_head and self.training and torch.is_grad_enabled() and hidden.is_cuda
+                and not hidden.requires_grad and not self.is_fine and hidden.dim() == 3 and hidden.shape[-1] == 1024
+                and 1 <= hidden.shape[1] <= 32 and hidden.shape[0] % batch_size == 0 and hidden.shape[0] // batch_size <= 32):
+            return None
+        if not (len(self.intra_module) == 1 and len(self.inter_module) == 1 and self.inter_mlp[0][0].out_features == 256
+                and self._layer_is_stock(self.intra_module[0], 1024, 4096, 4) and self._layer_is_stock(self.inter_module[0], 256, 1024, 4)
+                and isinstance(self.inter_mlp[0][1], nn.BatchNorm1d) and abs(self.inter_mlp[0][1].eps - 1e-5) < 1e-12
+                and self.inter_mlp[0][1].momentum == 0.1 and self.inter_mlp[0][1].track_running_stats):
+            return None
+        ps = set()
+        for layer in (self.intra_module[0], self.inter_module[0]):
+            ps.update((float(layer.dropout.p), float(layer.dropout1.p), float(layer.dropout2.p), float(layer.self_attn.dropout)))
+        if len(ps) != 1 or not all(p.requires_grad for p in self._head_params() if p.dtype == torch.float32 and p.dim() > 0 and p.is_leaf
+                                   and isinstance(p, nn.Parameter)):
+            return None  # (site-specific probabilities / partly frozen heads: the PyTorch path)
+        return ps.pop()
+
+    def _bind_text_train(self, device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if self._th_train_engine is None or self._th_train_engine.device != idx:
+            self._th_train_engine, self._th_train_key = Engine(idx), None
+        tensors = {}
+        for n, t in self.state_dict(keep_vars=True).items():
+            if not n.startswith(("intra_module.0.", "inter_mlp.0.", "inter_module.0.")) or n.endswith("num_batches_tracked"):
+                continue
+            if isinstance(t, nn.Parameter):
+                if t.grad is None:
+                    t.grad = torch.zeros_like(t)  # the engine accumulates into it (optimizer.zero_grad(set_to_none=True) drops it again)
+                tensors["language_encoder." + n] = (t.data, t.grad)
+            else:
+                tensors["language_encoder." + n] = (t, None)
+        key = tuple((d.data_ptr(), 0 if g is None else g.data_ptr()) for d, g in tensors.values())
+        if key != self._th_train_key:
+            self._th_train_engine.text_train_bind(tensors)
+            self._th_train_key = key
+
     def head(self, hidden: torch.Tensor, batch_size: int) -> torch.Tensor:
         """hidden: last_hidden_state [n_sentences_total, L, C] -> [B, D] (language_encoder.py:127-148)."""
+        p_drop = self._train_gate(hidden, batch_size)
+        if p_drop is not None:
+            self._bind_text_train(hidden.device)
+            LanguageEncoder.train_engine_calls += 1
+            self._th_drop_calls += 1
+            seed = (torch.initial_seed() * 0x9E3779B1 + self._th_drop_calls * 0x85EBCA6B) & 0xFFFFFFFF
+            hook = torch.zeros((), device=hidden.device, requires_grad=True)
+            bn = self.inter_mlp[0][1]
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+            return _TextHeadTrainFn.apply(hook, hidden.contiguous().float(), self, batch_size, p_drop, seed)
         self._open_call(hidden.device)
         n_eng = LanguageEncoder.head_engine_calls
         x = self._head_first_half(hidden)

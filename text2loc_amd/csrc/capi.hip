@@ -101,6 +101,7 @@ void t2l_destroy(t2l_ctx* ctx) {
   (void)hipDeviceSynchronize();
   free_weights(ctx);
   free_train(ctx);
+  free_text_train(ctx);
   free_pointnet(ctx);
   free_fine(ctx);
   free_text_head(ctx);
@@ -364,6 +365,25 @@ int t2l_text_head(t2l_ctx* ctx, const float* hidden, int32_t n_sentences, int32_
   if (!ctx) return T2L_EINVAL;
   T2L_HIP(ctx, hipSetDevice(ctx->device));
   return text_head_impl(ctx, hidden, n_sentences, n_tokens, out, overflow, (hipStream_t)stream);
+}
+
+int t2l_text_train_bind(t2l_ctx* ctx, const t2l_train_tensor* tensors, int32_t n, const char* prefix) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return text_train_bind_impl(ctx, tensors, n, prefix);
+}
+
+int t2l_text_head_train(t2l_ctx* ctx, const float* hidden, int32_t n_sentences, int32_t n_tokens, int32_t n_descriptions, float dropout_p,
+                        uint32_t seed, float* out, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return text_train_forward_impl(ctx, hidden, n_sentences, n_tokens, n_descriptions, dropout_p, seed, out, (hipStream_t)stream);
+}
+
+int t2l_text_head_backward(t2l_ctx* ctx, const float* grad_out, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return text_train_backward_impl(ctx, grad_out, (hipStream_t)stream);
 }
 
 int t2l_text_inter(t2l_ctx* ctx, const float* sent, int32_t n_descriptions, int32_t n_sentences_per, float* out, int32_t* overflow, void* stream) {

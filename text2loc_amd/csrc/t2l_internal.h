@@ -80,6 +80,7 @@ struct t2l_ctx {
   void* pn = nullptr;            // t2l::PointNetWeights (pointnet.hip), null when no pointnet.* tensors were loaded
   void* fine = nullptr;          // t2l::FineWeights (fine.hip)
   void* text_head = nullptr;     // t2l::th::Weights (text_head.hip)
+  void* text_train = nullptr;    // t2l::TextTrain (train.hip): the text head's training state
   int text_head_rows = 0;        // token rows per pass of the text head (0 = default 16,384)
   int pn_self_loops = 1;         // PyG PointConv add_self_loops quirk on the bipartite batch (oracle/t2l_oracle_pointnet.py)
   // options
@@ -186,6 +187,10 @@ int search_join_impl(t2l_ctx* ctx, hipStream_t s);
 void free_lanes(t2l_ctx* ctx);
 int adam_state_impl(t2l_ctx* ctx, int set, float* m, float* v, int64_t* step, int64_t* numel, hipStream_t s);
 void free_train(t2l_ctx* ctx);
+void free_text_train(t2l_ctx* ctx);
+int text_train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const char* prefix);
+int text_train_forward_impl(t2l_ctx* ctx, const float* hidden, int n_sent, int L, int n_desc, float p, uint32_t seed, float* out, hipStream_t s);
+int text_train_backward_impl(t2l_ctx* ctx, const float* grad_out, hipStream_t s);
 // pointnet.hip
 int pointnet_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n);
 int pointnet_features_impl(t2l_ctx* ctx, const float* pos, const float* rgb, const int32_t* cell_offsets, int n_cells, float* out,

@@ -807,6 +807,277 @@ int zero_grad_impl(t2l_ctx* ctx, hipStream_t s) {
   return T2L_OK;
 }
 
+// =================================================================================================================
+// The TEXT head in training mode (SURVEY.md 8 f-4 / a9's other half): LanguageEncoder.forward downstream of the frozen T5's
+// hidden states under model.train() (models/language_encoder.py:127-147 as run by training/coarse.py:44,55-56 — the published
+// command trains this head: --fixed_embedding freezes T5 only, README.md:87-99):
+//   hidden [n_sent, L, 1024] -> TransformerEncoderLayer(1024, 4 heads, ff 4096; the four dropout sites live) over the L tokens ->
+//   max over tokens -> Linear(1024 -> 256) + BatchNorm1d with the statistics of THIS batch of sentences (running buffers
+//   updated) -> view [n_desc, S, 256] -> x += TransformerEncoderLayer(256, 4 heads, ff 1024)(x) over the S sentences -> max
+//   over the sentences -> out [n_desc, 256]  (F.normalize stays with the caller: cell_retrieval.py:57-63).
+// Forward keeps the activations; backward accumulates (+=) into the bound .grad buffers — the parameters stay torch's and are
+// stepped by the torch-side Adam of text2loc_amd.optim (the 16.8 M head parameters are one foreach launch there). The same
+// modular f32 kernels as the object branch (gemm_f32.h products, option train_bf16 for bf16 / split-bf16 operands), with the
+// attention / LayerNorm kernels in their generic forms (train_kernels.h).
+// =================================================================================================================
+struct TextLayer {
+  std::string prefix;
+  int T = 0, B = 0, S = 0, site0 = 0;
+  const float* x_in = nullptr;
+  float *qkv = nullptr, *P = nullptr, *O = nullptr, *xhat1 = nullptr, *rstd1 = nullptr, *x1 = nullptr, *h = nullptr, *hd = nullptr,
+        *xhat2 = nullptr, *rstd2 = nullptr, *x2 = nullptr;
+};
+struct TextTrain {
+  std::unordered_map<std::string, TTensor> t;
+  std::string prefix;
+  char* ws = nullptr;
+  size_t ws_cap = 0, ws_off = 0;
+  bool have_forward = false;
+  int n_sent = 0, L = 0, n_desc = 0, S = 0;
+  float p = 0.f;
+  uint32_t seed = 0;
+  TextLayer intra, inter;
+  float *pooled = nullptr, *mlp_y = nullptr, *mlp_out = nullptr, *bn_mean = nullptr, *bn_rstd = nullptr, *out = nullptr;
+  int32_t *tok_arg = nullptr, *sent_arg = nullptr;
+};
+static TextTrain* tstate(t2l_ctx* ctx) { return reinterpret_cast<TextTrain*>(ctx->text_train); }
+void free_text_train(t2l_ctx* ctx) {
+  TextTrain* st = tstate(ctx);
+  if (!st) return;
+  if (st->ws) (void)hipFree(st->ws);
+  delete st;
+  ctx->text_train = nullptr;
+}
+template <typename T>
+static T* tbump(TextTrain* st, size_t count) {
+  const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+  T* p = reinterpret_cast<T*>(st->ws + st->ws_off);
+  st->ws_off += bytes;
+  return p;
+}
+static const TTensor& TT(TextTrain* st, const std::string& n) { return st->t.at(st->prefix + n); }
+
+__global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += b[i];
+}
+
+int text_train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const char* prefix) {
+  if (!tensors || n <= 0) return fail(ctx, T2L_EINVAL, "t2l_text_train_bind: null argument");
+  free_text_train(ctx);
+  TextTrain* st = new TextTrain();
+  ctx->text_train = st;
+  st->prefix = prefix ? prefix : "language_encoder.";
+  for (int i = 0; i < n; ++i) {
+    if (!tensors[i].name || !tensors[i].data) return fail(ctx, T2L_EINVAL, "t2l_text_train_bind: null name/data");
+    st->t[tensors[i].name] = TTensor{tensors[i].data, tensors[i].grad, tensors[i].numel};
+  }
+  auto need_t = [&](const std::string& name, int64_t numel, bool grad) -> int {
+    auto it = st->t.find(st->prefix + name);
+    if (it == st->t.end() || it->second.numel != numel || (grad && !it->second.grad))
+      return fail(ctx, T2L_EINVAL, "t2l_text_train_bind: tensor '" + st->prefix + name + "' missing, mis-sized or without a gradient buffer "
+                                   "(the engine trains the published head: intra_module 1 x (1024, 4 heads, 4096), inter_mlp 1024 -> 256, "
+                                   "inter_module 1 x (256, 4 heads, 1024))");
+    return T2L_OK;
+  };
+  int rc;
+  auto layer = [&](const std::string& lp, int64_t D, int64_t FF) -> int {
+    const std::pair<const char*, int64_t> req[] = {{".self_attn.in_proj_weight", 3 * D * D}, {".self_attn.in_proj_bias", 3 * D},
+                                                   {".self_attn.out_proj.weight", D * D},    {".self_attn.out_proj.bias", D},
+                                                   {".linear1.weight", FF * D},              {".linear1.bias", FF},
+                                                   {".linear2.weight", D * FF},              {".linear2.bias", D},
+                                                   {".norm1.weight", D},                     {".norm1.bias", D},
+                                                   {".norm2.weight", D},                     {".norm2.bias", D}};
+    for (auto& r : req)
+      if ((rc = need_t(lp + r.first, r.second, true))) return rc;
+    return T2L_OK;
+  };
+  if ((rc = layer("intra_module.0", 1024, 4096)) || (rc = layer("inter_module.0", 256, 1024))) return rc;
+  if ((rc = need_t("inter_mlp.0.0.weight", 256 * 1024, true)) || (rc = need_t("inter_mlp.0.0.bias", 256, true)) ||
+      (rc = need_t("inter_mlp.0.1.weight", 256, true)) || (rc = need_t("inter_mlp.0.1.bias", 256, true)) ||
+      (rc = need_t("inter_mlp.0.1.running_mean", 256, false)) || (rc = need_t("inter_mlp.0.1.running_var", 256, false)))
+    return rc;
+  static PerDeviceOnce once;
+  if (once.need(ctx->device)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_g_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_g_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    once.mark(ctx->device);
+  }
+  return T2L_OK;
+}
+
+static size_t attn_lds(int S, int HD, bool bwd) { return sizeof(float) * ((size_t)(bwd ? 4 : 3) * S * (HD + 1) + (size_t)(bwd ? 3 : 1) * S * (S + 1)); }
+
+template <int D>
+static void text_layer_alloc(TextTrain* st, TextLayer& L, float p) {
+  const size_t T = (size_t)L.T;
+  L.qkv = tbump<float>(st, T * 3 * D);
+  L.P = tbump<float>(st, (size_t)L.B * 4 * L.S * L.S);
+  L.O = tbump<float>(st, T * D);
+  L.xhat1 = tbump<float>(st, T * D);
+  L.rstd1 = tbump<float>(st, T);
+  L.x1 = tbump<float>(st, T * D);
+  L.h = tbump<float>(st, T * 4 * D);
+  L.hd = p > 0.f ? tbump<float>(st, T * 4 * D) : L.h;
+  L.xhat2 = tbump<float>(st, T * D);
+  L.rstd2 = tbump<float>(st, T);
+  L.x2 = tbump<float>(st, T * D);
+}
+template <int D>
+static void text_layer_fwd(TextTrain* st, TextLayer& L, float* tmp, hipStream_t s) {
+  constexpr int HD = D / 4, FF = 4 * D;
+  const int T = L.T;
+  auto W = [&](const char* n) -> const TTensor& { return TT(st, L.prefix + n); };
+  gemm_nt(L.x_in, W(".self_attn.in_proj_weight").data, W(".self_attn.in_proj_bias").data, L.qkv, T, 3 * D, D, 0, s);
+  hipLaunchKernelGGL((attn_fwd_g_kernel<HD>), dim3(L.B * 4), dim3(256), attn_lds(L.S, HD, false), s, L.qkv, L.P, L.O, L.S,
+                     make_drop(st->seed, L.site0 + 0, st->p));
+  gemm_nt(L.O, W(".self_attn.out_proj.weight").data, W(".self_attn.out_proj.bias").data, tmp, T, D, D, 0, s);
+  hipLaunchKernelGGL((ln_fwd_g_kernel<D>), dim3((T + 3) / 4), dim3(256), 0, s, L.x_in, (const float*)tmp, T, W(".norm1.weight").data,
+                     W(".norm1.bias").data, make_drop(st->seed, L.site0 + 1, st->p), L.x1, L.xhat1, L.rstd1);
+  {
+    GemmArgs g{L.x1, W(".linear1.weight").data, L.h, W(".linear1.bias").data, T, FF, D, D, D, FF, 1, 0, D, nullptr, tl_gemm_bf16};
+    if (st->p > 0.f) {
+      const Drop dr = make_drop(st->seed, L.site0 + 2, st->p);
+      g.epi = 1;
+      g.C2 = L.hd;
+      g.drop_key = dr.key;
+      g.drop_thr = dr.thr;
+      g.drop_scale = dr.scale;
+    }
+    gemm_nt_args(g, s);
+  }
+  gemm_nt(L.hd, W(".linear2.weight").data, W(".linear2.bias").data, tmp, T, D, FF, 0, s);
+  hipLaunchKernelGGL((ln_fwd_g_kernel<D>), dim3((T + 3) / 4), dim3(256), 0, s, (const float*)L.x1, (const float*)tmp, T, W(".norm2.weight").data,
+                     W(".norm2.bias").data, make_drop(st->seed, L.site0 + 3, st->p), L.x2, L.xhat2, L.rstd2);
+}
+// dcur: gradient w.r.t. the layer's output x2 (read). Returns the gradient w.r.t. the layer's input (nullptr when need_dx is false).
+template <int D>
+static float* text_layer_bwd(TextTrain* st, const TextLayer& L, const float* dcur, bool need_dx, hipStream_t s) {
+  constexpr int HD = D / 4, FF = 4 * D;
+  const int T = L.T;
+  const size_t n = (size_t)T * D;
+  float *dA = tbump<float>(st, n), *dB = tbump<float>(st, n), *dC = tbump<float>(st, n), *dB2 = tbump<float>(st, n), *dO = tbump<float>(st, n),
+        *dH = tbump<float>(st, n * 4), *dqkv = tbump<float>(st, n * 3);
+  auto W = [&](const char* nme) -> const TTensor& { return TT(st, L.prefix + nme); };
+  const int ln_grid = std::min(64, (T + 15) / 16);
+  hipLaunchKernelGGL((ln_bwd_g_kernel<D>), dim3(ln_grid), dim3(256), 0, s, dcur, (const float*)L.xhat2, (const float*)L.rstd2, T,
+                     W(".norm2.weight").data, make_drop(st->seed, L.site0 + 3, st->p), dA, dB, W(".norm2.weight").grad, W(".norm2.bias").grad);
+  {
+    const Drop dr = make_drop(st->seed, L.site0 + 2, st->p);
+    gemm_tn_nn(dB, L.hd, W(".linear2.weight").grad, W(".linear2.bias").grad, W(".linear2.weight").data, dH, T, D, FF, 0, L.h, &dr, s);
+  }
+  gemm_tn_nn(dH, L.x1, W(".linear1.weight").grad, W(".linear1.bias").grad, W(".linear1.weight").data, dA, T, FF, D, 1, nullptr, nullptr, s);
+  hipLaunchKernelGGL((ln_bwd_g_kernel<D>), dim3(ln_grid), dim3(256), 0, s, (const float*)dA, (const float*)L.xhat1, (const float*)L.rstd1, T,
+                     W(".norm1.weight").data, make_drop(st->seed, L.site0 + 1, st->p), dC, dB2, W(".norm1.weight").grad, W(".norm1.bias").grad);
+  gemm_tn_nn(dB2, L.O, W(".self_attn.out_proj.weight").grad, W(".self_attn.out_proj.bias").grad, W(".self_attn.out_proj.weight").data, dO, T, D, D,
+             0, nullptr, nullptr, s);
+  hipLaunchKernelGGL((attn_bwd_g_kernel<HD>), dim3(L.B * 4), dim3(256), attn_lds(L.S, HD, true), s, (const float*)L.qkv, (const float*)L.P,
+                     (const float*)dO, dqkv, L.S, make_drop(st->seed, L.site0 + 0, st->p));
+  if (need_dx) {
+    gemm_tn_nn(dqkv, L.x_in, W(".self_attn.in_proj_weight").grad, W(".self_attn.in_proj_bias").grad, W(".self_attn.in_proj_weight").data, dC, T,
+               3 * D, D, 1, nullptr, nullptr, s);
+    return dC;
+  }
+  gemm_tn(dqkv, L.x_in, W(".self_attn.in_proj_weight").grad, W(".self_attn.in_proj_bias").grad, T, 3 * D, D, s);
+  return nullptr;
+}
+
+int text_train_forward_impl(t2l_ctx* ctx, const float* hidden, int n_sent, int L, int n_desc, float p, uint32_t seed, float* out, hipStream_t s) {
+  TextTrain* st = tstate(ctx);
+  if (!st) return fail(ctx, T2L_ESTATE, "t2l_text_head_train: call t2l_text_train_bind first");
+  if (!hidden || !out) return fail(ctx, T2L_EINVAL, "t2l_text_head_train: null buffer");
+  if (n_desc < 1 || n_sent < n_desc || n_sent % n_desc) return fail(ctx, T2L_EINVAL, "t2l_text_head_train: the sentences must split evenly over the descriptions");
+  const int S = n_sent / n_desc;
+  if (L < 1 || L > 32 || S > 32) return fail(ctx, T2L_EINVAL, "t2l_text_head_train: need 1 <= n_tokens <= 32 and <= 32 sentences per description");
+  if (!(p >= 0.f && p < 1.f)) return fail(ctx, T2L_EINVAL, "t2l_text_head_train: dropout_p must be in [0, 1)");
+  tl_gemm_bf16 = ctx->train_bf16;
+  tl_xcd_bands = 0;
+  tl_gemm_block64 = ctx->train_gemm_block == 64 || (ctx->train_gemm_block == 0 && ctx->train_bf16 != 0);
+  const size_t T1 = (size_t)n_sent * L;
+  // saved activations + the backward's scratch: ~31 floats per (row, column) of each layer, see text_layer_alloc / text_layer_bwd
+  const size_t need = sizeof(float) * (32 * (T1 * 1024 + (size_t)n_sent * 256) + 2 * (size_t)n_sent * 4 * L * L + 2 * (size_t)n_desc * 4 * S * S +
+                                       8 * (size_t)n_sent * 1024 + 16 * (size_t)n_desc * 256) + (1 << 20);
+  if (st->ws_cap < need) {
+    if (st->ws) T2L_HIP(ctx, hipFree(st->ws));
+    st->ws = nullptr;
+    st->ws_cap = 0;
+    T2L_HIP(ctx, hipMalloc(&st->ws, need));
+    st->ws_cap = need;
+  }
+  st->ws_off = 0;
+  st->have_forward = false;
+  st->n_sent = n_sent; st->L = L; st->n_desc = n_desc; st->S = S; st->p = p; st->seed = seed;
+  event_begin(ctx, "text_train_forward", s);
+  float* tmp = tbump<float>(st, T1 * 1024);
+  TextLayer& A = st->intra;
+  A = TextLayer{};
+  A.prefix = "intra_module.0"; A.T = (int)T1; A.B = n_sent; A.S = L; A.site0 = 0; A.x_in = hidden;
+  text_layer_alloc<1024>(st, A, p);
+  text_layer_fwd<1024>(st, A, tmp, s);
+  st->pooled = tbump<float>(st, (size_t)n_sent * 1024);
+  st->tok_arg = tbump<int32_t>(st, (size_t)n_sent * 1024);
+  hipLaunchKernelGGL(seq_max_fwd_kernel, dim3((unsigned)(((size_t)n_sent * 1024 + 255) / 256)), dim3(256), 0, s, (const float*)A.x2, (const float*)nullptr,
+                     n_sent, L, 1024, st->pooled, st->tok_arg);
+  st->mlp_y = tbump<float>(st, (size_t)n_sent * 256);
+  st->mlp_out = tbump<float>(st, (size_t)n_sent * 256);
+  st->bn_mean = tbump<float>(st, 256);
+  st->bn_rstd = tbump<float>(st, 256);
+  gemm_nt(st->pooled, TT(st, "inter_mlp.0.0.weight").data, TT(st, "inter_mlp.0.0.bias").data, st->mlp_y, n_sent, 256, 1024, 0, s);
+  hipLaunchKernelGGL(bn_plain_fwd_kernel, dim3(1), dim3(256), 0, s, (const float*)st->mlp_y, n_sent, 256, TT(st, "inter_mlp.0.1.weight").data,
+                     TT(st, "inter_mlp.0.1.bias").data, TT(st, "inter_mlp.0.1.running_mean").data, TT(st, "inter_mlp.0.1.running_var").data, 0.1f,
+                     st->mlp_out, st->bn_mean, st->bn_rstd);
+  TextLayer& I = st->inter;
+  I = TextLayer{};
+  I.prefix = "inter_module.0"; I.T = n_sent; I.B = n_desc; I.S = S; I.site0 = 4; I.x_in = st->mlp_out;
+  text_layer_alloc<256>(st, I, p);
+  text_layer_fwd<256>(st, I, tmp, s);
+  st->out = tbump<float>(st, (size_t)n_desc * 256);
+  st->sent_arg = tbump<int32_t>(st, (size_t)n_desc * 256);
+  hipLaunchKernelGGL(seq_max_fwd_kernel, dim3((unsigned)(((size_t)n_desc * 256 + 255) / 256)), dim3(256), 0, s, (const float*)I.x2,
+                     (const float*)st->mlp_out, n_desc, S, 256, st->out, st->sent_arg);
+  T2L_HIP(ctx, hipMemcpyAsync(out, st->out, sizeof(float) * (size_t)n_desc * 256, hipMemcpyDeviceToDevice, s));
+  event_end(ctx, "text_train_forward", s);
+  T2L_HIP(ctx, hipGetLastError());
+  if (st->ws_off > st->ws_cap) return fail(ctx, T2L_ENOMEM, "t2l_text_head_train: workspace bound exceeded (internal error)");
+  st->have_forward = true;
+  return T2L_OK;
+}
+
+int text_train_backward_impl(t2l_ctx* ctx, const float* grad_out, hipStream_t s) {
+  TextTrain* st = tstate(ctx);
+  if (!st || !st->have_forward) return fail(ctx, T2L_ESTATE, "t2l_text_head_backward: no forward pass to differentiate");
+  if (!grad_out) return fail(ctx, T2L_EINVAL, "t2l_text_head_backward: null gradient");
+  tl_gemm_bf16 = ctx->train_bf16;
+  tl_xcd_bands = 0;
+  tl_gemm_block64 = ctx->train_gemm_block == 64 || (ctx->train_gemm_block == 0 && ctx->train_bf16 != 0);
+  const size_t mark = st->ws_off;
+  const int n_sent = st->n_sent, n_desc = st->n_desc, S = st->S, L = st->L;
+  event_begin(ctx, "text_train_backward", s);
+  // max over the sentences: the gradient goes to the arg-max row of (x + layer(x)) — to the layer's output AND to the residual x
+  float* dY2 = tbump<float>(st, (size_t)n_sent * 256);
+  hipLaunchKernelGGL(seq_max_bwd_kernel, dim3((unsigned)(((size_t)n_sent * 256 + 255) / 256)), dim3(256), 0, s, grad_out, (const int32_t*)st->sent_arg,
+                     n_desc, S, 256, dY2);
+  float* dX = text_layer_bwd<256>(st, st->inter, dY2, true, s);
+  hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)(((size_t)n_sent * 256 + 255) / 256)), dim3(256), 0, s, dX, (const float*)dY2, (size_t)n_sent * 256);
+  // inter_mlp: BatchNorm (batch statistics), Linear
+  hipLaunchKernelGGL(bn_plain_bwd_kernel, dim3(1), dim3(256), 0, s, dX, (const float*)st->mlp_y, n_sent, 256, TT(st, "inter_mlp.0.1.weight").data,
+                     (const float*)st->bn_mean, (const float*)st->bn_rstd, TT(st, "inter_mlp.0.1.weight").grad, TT(st, "inter_mlp.0.1.bias").grad);
+  float* dpool = tbump<float>(st, (size_t)n_sent * 1024);
+  gemm_tn_nn(dX, st->pooled, TT(st, "inter_mlp.0.0.weight").grad, TT(st, "inter_mlp.0.0.bias").grad, TT(st, "inter_mlp.0.0.weight").data, dpool, n_sent,
+             256, 1024, 0, nullptr, nullptr, s);
+  // max over the tokens, then the d = 1024 layer (its input, T5's hidden states, is a constant: no dX)
+  float* dX2 = tbump<float>(st, (size_t)n_sent * L * 1024);
+  hipLaunchKernelGGL(seq_max_bwd_kernel, dim3((unsigned)(((size_t)n_sent * L * 1024 + 255) / 256)), dim3(256), 0, s, (const float*)dpool,
+                     (const int32_t*)st->tok_arg, n_sent, L, 1024, dX2);
+  text_layer_bwd<1024>(st, st->intra, dX2, false, s);
+  event_end(ctx, "text_train_backward", s);
+  const bool over = st->ws_off > st->ws_cap;
+  st->ws_off = mark;
+  T2L_HIP(ctx, hipGetLastError());
+  if (over) return fail(ctx, T2L_ENOMEM, "t2l_text_head_backward: workspace bound exceeded (internal error)");
+  return T2L_OK;
+}
+
 }  // namespace t2l
 
 #include "pointnet_train.h"

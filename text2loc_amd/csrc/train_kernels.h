@@ -729,5 +729,312 @@ __global__ void zero_kernel(const AdamTensor* __restrict__ ts, const AdamChunk* 
   }
 }
 
+// ===============================================================================================================
+// Generic forms for the TEXT head's training step (train.hip: text_train_*): the same ops at the head's shapes —
+// d_model 1024 / head_dim 256 over L <= 32 tokens per sentence, and d_model 256 / head_dim 64 over S <= 32 sentences
+// per description (models/language_encoder.py:97-101,127-147).
+// ===============================================================================================================
+// self-attention over the S rows of one group (sentence / description), one workgroup per (group, head); qkv [rows][3 D],
+// D = 4 HD. Dynamic LDS: q, k, v tiles [S][HD + 1] + p [S][S + 1] (forward), + go and two more [S][S + 1] (backward).
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_g_kernel(const float* __restrict__ qkv, float* __restrict__ P, float* __restrict__ O,
+                                                         int S, Drop dr) {
+  extern __shared__ float sm[];
+  constexpr int AS = HD + 1, D = 4 * HD;
+  float *q = sm, *k = q + S * AS, *v = k + S * AS, *p = v + S * AS;
+  const int b = blockIdx.x >> 2, h = blockIdx.x & 3, tid = threadIdx.x, SP = S + 1;
+  const float scale = 1.0f / sqrtf((float)HD);
+  for (int i = tid; i < S * HD; i += 256) {
+    const int s = i / HD, d = i - s * HD;
+    const float* base = qkv + (size_t)(b * S + s) * (3 * D) + h * HD + d;
+    q[s * AS + d] = base[0];
+    k[s * AS + d] = base[D];
+    v[s * AS + d] = base[2 * D];
+  }
+  __syncthreads();
+  for (int e = tid; e < S * S; e += 256) {
+    const int i = e / S, j = e - i * S;
+    float s = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < HD; ++d) s += q[i * AS + d] * k[j * AS + d];
+    p[i * SP + j] = s * scale;
+  }
+  __syncthreads();
+  if (tid < S) {
+    float* row = p + tid * SP;
+    float mx = row[0];
+    for (int j = 1; j < S; ++j) mx = fmaxf(mx, row[j]);
+    float sum = 0.f;
+    for (int j = 0; j < S; ++j) {
+      row[j] = expf(row[j] - mx);
+      sum += row[j];
+    }
+    for (int j = 0; j < S; ++j) row[j] /= sum;
+  }
+  __syncthreads();
+  const size_t pbase = (size_t)blockIdx.x * S * S;
+  for (int e = tid; e < S * S; e += 256) {
+    const int i = e / S, j = e - i * S;
+    float pv = p[i * SP + j];
+    P[pbase + e] = pv;  // probabilities BEFORE dropout (softmax backward needs them)
+    if (dr.thr) pv = keep_bit(dr.key, (uint32_t)(pbase + e), dr.thr) ? pv * dr.scale : 0.f;
+    p[i * SP + j] = pv;
+  }
+  __syncthreads();
+  for (int e = tid; e < S * HD; e += 256) {
+    const int i = e / HD, d = e - i * HD;
+    float s = 0.f;
+    for (int j = 0; j < S; ++j) s += p[i * SP + j] * v[j * AS + d];
+    O[(size_t)(b * S + i) * D + h * HD + d] = s;
+  }
+}
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_g_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
+                                                         const float* __restrict__ dO, float* __restrict__ dqkv, int S, Drop dr) {
+  extern __shared__ float sm[];
+  constexpr int AS = HD + 1, D = 4 * HD;
+  const int SP = S + 1;
+  float *q = sm, *k = q + S * AS, *v = k + S * AS, *go = v + S * AS, *p = go + S * AS, *pd = p + S * SP, *ds = pd + S * SP;
+  const int b = blockIdx.x >> 2, h = blockIdx.x & 3, tid = threadIdx.x;
+  const float scale = 1.0f / sqrtf((float)HD);
+  for (int i = tid; i < S * HD; i += 256) {
+    const int s = i / HD, d = i - s * HD;
+    const float* base = qkv + (size_t)(b * S + s) * (3 * D) + h * HD + d;
+    q[s * AS + d] = base[0];
+    k[s * AS + d] = base[D];
+    v[s * AS + d] = base[2 * D];
+    go[s * AS + d] = dO[(size_t)(b * S + s) * D + h * HD + d];
+  }
+  const size_t pbase = (size_t)blockIdx.x * S * S;
+  for (int e = tid; e < S * S; e += 256) {
+    const int i = e / S, j = e - i * S;
+    const float pv = P[pbase + e];
+    const float m = dr.thr ? (keep_bit(dr.key, (uint32_t)(pbase + e), dr.thr) ? dr.scale : 0.f) : 1.f;
+    p[i * SP + j] = pv;
+    pd[i * SP + j] = pv * m;
+    ds[i * SP + j] = m;  // mask factor for now
+  }
+  __syncthreads();
+  for (int e = tid; e < S * HD; e += 256) {  // dV[j][d] = sum_i Pd[i][j] dO[i][d]
+    const int j = e / HD, d = e - j * HD;
+    float s = 0.f;
+    for (int i = 0; i < S; ++i) s += pd[i * SP + j] * go[i * AS + d];
+    dqkv[(size_t)(b * S + j) * (3 * D) + 2 * D + h * HD + d] = s;
+  }
+  for (int e = tid; e < S * S; e += 256) {  // dP[i][j] = mask * sum_d dO[i][d] V[j][d]
+    const int i = e / S, j = e - i * S;
+    float s = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < HD; ++d) s += go[i * AS + d] * v[j * AS + d];
+    ds[i * SP + j] *= s;
+  }
+  __syncthreads();
+  if (tid < S) {  // dS = P * (dP - sum_j dP*P) / sqrt(hd)
+    float t = 0.f;
+    for (int j = 0; j < S; ++j) t += ds[tid * SP + j] * p[tid * SP + j];
+    for (int j = 0; j < S; ++j) ds[tid * SP + j] = p[tid * SP + j] * (ds[tid * SP + j] - t) * scale;
+  }
+  __syncthreads();
+  for (int e = tid; e < S * HD; e += 256) {
+    const int i = e / HD, d = e - i * HD;
+    float sq = 0.f, sk = 0.f;
+    for (int j = 0; j < S; ++j) {
+      sq += ds[i * SP + j] * k[j * AS + d];
+      sk += ds[j * SP + i] * q[j * AS + d];
+    }
+    float* base = dqkv + (size_t)(b * S + i) * (3 * D) + h * HD + d;
+    base[0] = sq;
+    base[D] = sk;
+  }
+}
+
+// out = LayerNorm(x + dropout(y)) over D columns, one wave per row (D / 256 float4 per lane, each wave-load 1 KiB contiguous).
+template <int D>
+__global__ void ln_fwd_g_kernel(const float* __restrict__ x, const float* __restrict__ y, int T, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, Drop dr, float* __restrict__ out, float* __restrict__ xhat,
+                                float* __restrict__ save_rstd) {
+  constexpr int NV = D / 256;
+  const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (t >= T) return;
+  float4 a[NV];
+  float s1 = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const size_t o = (size_t)t * D + j * 256 + lane * 4;
+    a[j] = *reinterpret_cast<const float4*>(x + o);
+    float4 f = *reinterpret_cast<const float4*>(y + o);
+    if (dr.thr) {
+      f.x = keep_bit(dr.key, (uint32_t)o + 0, dr.thr) ? f.x * dr.scale : 0.f;
+      f.y = keep_bit(dr.key, (uint32_t)o + 1, dr.thr) ? f.y * dr.scale : 0.f;
+      f.z = keep_bit(dr.key, (uint32_t)o + 2, dr.thr) ? f.z * dr.scale : 0.f;
+      f.w = keep_bit(dr.key, (uint32_t)o + 3, dr.thr) ? f.w * dr.scale : 0.f;
+    }
+    a[j].x += f.x; a[j].y += f.y; a[j].z += f.z; a[j].w += f.w;
+    s1 += (a[j].x + a[j].y) + (a[j].z + a[j].w);
+  }
+  const float mu = wsum(s1) * (1.f / D);
+  float s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    a[j].x -= mu; a[j].y -= mu; a[j].z -= mu; a[j].w -= mu;
+    s2 += (a[j].x * a[j].x + a[j].y * a[j].y) + (a[j].z * a[j].z + a[j].w * a[j].w);
+  }
+  const float rstd = 1.0f / sqrtf(wsum(s2) * (1.f / D) + kLnEps);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const size_t o = (size_t)t * D + j * 256 + lane * 4;
+    const float4 h = make_float4(a[j].x * rstd, a[j].y * rstd, a[j].z * rstd, a[j].w * rstd);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + j * 256 + lane * 4);
+    const float4 be = *reinterpret_cast<const float4*>(beta + j * 256 + lane * 4);
+    *reinterpret_cast<float4*>(xhat + o) = h;
+    *reinterpret_cast<float4*>(out + o) = make_float4(h.x * g.x + be.x, h.y * g.y + be.y, h.z * g.z + be.z, h.w * g.w + be.w);
+  }
+  if (lane == 0) save_rstd[t] = rstd;
+}
+// LN backward (see ln_bwd_kernel): d_res = dz, d_y = dz * dropout mask; dgamma / dbeta by per-workgroup partials + atomics.
+// 256-thread workgroups (4 waves), each wave strides over rows.
+template <int D>
+__global__ __launch_bounds__(256) void ln_bwd_g_kernel(const float* __restrict__ dout, const float* __restrict__ xhat,
+                                                       const float* __restrict__ save_rstd, int T, const float* __restrict__ gamma,
+                                                       Drop dr, float* __restrict__ d_res, float* __restrict__ d_y,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  constexpr int NV = D / 256;
+  __shared__ float4 rg[256 * NV], rb[256 * NV];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float4 g[NV], ag[NV], ab[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    g[j] = *reinterpret_cast<const float4*>(gamma + j * 256 + lane * 4);
+    ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int t = blockIdx.x * 4 + w; t < T; t += gridDim.x * 4) {
+    const float rstd = save_rstd[t];
+    float4 d[NV], h[NV], dh[NV];
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const size_t o = (size_t)t * D + j * 256 + lane * 4;
+      d[j] = *reinterpret_cast<const float4*>(dout + o);
+      h[j] = *reinterpret_cast<const float4*>(xhat + o);
+      ag[j].x += d[j].x * h[j].x; ag[j].y += d[j].y * h[j].y; ag[j].z += d[j].z * h[j].z; ag[j].w += d[j].w * h[j].w;
+      ab[j].x += d[j].x; ab[j].y += d[j].y; ab[j].z += d[j].z; ab[j].w += d[j].w;
+      dh[j] = make_float4(d[j].x * g[j].x, d[j].y * g[j].y, d[j].z * g[j].z, d[j].w * g[j].w);
+      m1 += (dh[j].x + dh[j].y) + (dh[j].z + dh[j].w);
+      m2 += (dh[j].x * h[j].x + dh[j].y * h[j].y) + (dh[j].z * h[j].z + dh[j].w * h[j].w);
+    }
+    m1 = wsum(m1) * (1.f / D);
+    m2 = wsum(m2) * (1.f / D);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const size_t o = (size_t)t * D + j * 256 + lane * 4;
+      float4 dz = make_float4(rstd * (dh[j].x - m1 - h[j].x * m2), rstd * (dh[j].y - m1 - h[j].y * m2),
+                              rstd * (dh[j].z - m1 - h[j].z * m2), rstd * (dh[j].w - m1 - h[j].w * m2));
+      *reinterpret_cast<float4*>(d_res + o) = dz;
+      if (dr.thr) {
+        dz.x = keep_bit(dr.key, (uint32_t)o + 0, dr.thr) ? dz.x * dr.scale : 0.f;
+        dz.y = keep_bit(dr.key, (uint32_t)o + 1, dr.thr) ? dz.y * dr.scale : 0.f;
+        dz.z = keep_bit(dr.key, (uint32_t)o + 2, dr.thr) ? dz.z * dr.scale : 0.f;
+        dz.w = keep_bit(dr.key, (uint32_t)o + 3, dr.thr) ? dz.w * dr.scale : 0.f;
+      }
+      *reinterpret_cast<float4*>(d_y + o) = dz;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    rg[threadIdx.x * NV + j] = ag[j];
+    rb[threadIdx.x * NV + j] = ab[j];
+  }
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      float4 sg = ag[j], sb = ab[j];
+      for (int i = 1; i < 4; ++i) {
+        const float4 a = rg[(lane + 64 * i) * NV + j], c = rb[(lane + 64 * i) * NV + j];
+        sg.x += a.x; sg.y += a.y; sg.z += a.z; sg.w += a.w;
+        sb.x += c.x; sb.y += c.y; sb.z += c.z; sb.w += c.w;
+      }
+      float* pg = dgamma + j * 256 + lane * 4;
+      float* pb = dbeta + j * 256 + lane * 4;
+      unsafeAtomicAdd(pg + 0, sg.x); unsafeAtomicAdd(pg + 1, sg.y); unsafeAtomicAdd(pg + 2, sg.z); unsafeAtomicAdd(pg + 3, sg.w);
+      unsafeAtomicAdd(pb + 0, sb.x); unsafeAtomicAdd(pb + 1, sb.y); unsafeAtomicAdd(pb + 2, sb.z); unsafeAtomicAdd(pb + 3, sb.w);
+    }
+  }
+}
+
+// out[b][c] = max over the S rows of group b of (X + R) (R optional: the residual AROUND the inter-sentence layer); first maximal
+// row wins, as torch.max does. arg keeps the row for the backward scatter.
+__global__ __launch_bounds__(256) void seq_max_fwd_kernel(const float* __restrict__ X, const float* __restrict__ R, int B, int S, int D,
+                                                          float* __restrict__ out, int32_t* __restrict__ arg) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)B * D) return;
+  const int b = (int)(i / D), c = (int)(i - (size_t)b * D);
+  float mx = 0.f;
+  int am = 0;
+  for (int s = 0; s < S; ++s) {
+    const size_t o = ((size_t)b * S + s) * D + c;
+    const float v = R ? X[o] + R[o] : X[o];
+    if (s == 0 || v > mx) { mx = v; am = s; }
+  }
+  out[i] = mx;
+  arg[i] = am;
+}
+// dX[b][s][c] = g[b][c] at s = arg, else 0 (the gradient of X and, with a residual, of R alike)
+__global__ __launch_bounds__(256) void seq_max_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ arg, int B, int S, int D,
+                                                          float* __restrict__ dX) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)B * S * D) return;
+  const int c = (int)(i % D);
+  const size_t bs = i / D;
+  const int s = (int)(bs % S);
+  const size_t b = bs / S;
+  dX[i] = arg[b * D + c] == s ? g[b * D + c] : 0.f;
+}
+
+// BatchNorm1d in training mode WITHOUT a ReLU behind it (inter_mlp = get_mlp2([1024, D]): Linear + BatchNorm1d,
+// models/language_encoder.py:43-74,99) over M rows (a few hundred sentences) x C <= 256 columns: one thread per column.
+__global__ __launch_bounds__(256) void bn_plain_fwd_kernel(const float* __restrict__ y, int M, int C, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                           float* __restrict__ run_var, float momentum, float* __restrict__ out,
+                                                           float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int m = 0; m < M; ++m) {
+    const double v = y[(size_t)m * C + c];
+    s1 += v;
+    s2 += v * v;
+  }
+  const double mean = s1 / M, var = fmax(s2 / M - mean * mean, 0.0);
+  const float rstd = 1.0f / sqrtf((float)var + kBnEps), g = gamma[c], be = beta[c];
+  for (int m = 0; m < M; ++m) out[(size_t)m * C + c] = (y[(size_t)m * C + c] - (float)mean) * rstd * g + be;
+  save_mean[c] = (float)mean;
+  save_rstd[c] = rstd;
+  run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+  run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * ((double)M / (double)max(M - 1, 1)));
+}
+// d: gradient w.r.t. the BatchNorm output (in), overwritten with the gradient w.r.t. its input y
+__global__ __launch_bounds__(256) void bn_plain_bwd_kernel(float* __restrict__ d, const float* __restrict__ y, int M, int C,
+                                                           const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                           const float* __restrict__ save_rstd, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float mean = save_mean[c], rstd = save_rstd[c];
+  double s1 = 0.0, s2 = 0.0;
+  for (int m = 0; m < M; ++m) {
+    const float dv = d[(size_t)m * C + c];
+    s1 += dv;
+    s2 += dv * (y[(size_t)m * C + c] - mean) * rstd;
+  }
+  const float f1 = (float)s1, f2 = (float)s2, g = gamma[c];
+  for (int m = 0; m < M; ++m) {
+    const size_t i = (size_t)m * C + c;
+    d[i] = g * rstd / (float)M * ((float)M * d[i] - f1 - (y[i] - mean) * rstd * f2);
+  }
+  dgamma[c] += f2;
+  dbeta[c] += f1;
+}
+
 }  // namespace train
 }  // namespace t2l

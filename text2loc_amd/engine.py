@@ -82,6 +82,9 @@ EXPORTS = {
     "t2l_train_bind": (C.c_int, [C.c_void_p, C.POINTER(_TrainTensor), C.c_int32, C.POINTER(_ModelConfig)]),
     "t2l_encode_cells_train": (C.c_int, [C.c_void_p, C.POINTER(_PackedCells), C.c_float, C.c_uint32, C.c_void_p, C.c_void_p]),
     "t2l_encode_cells_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "t2l_text_train_bind": (C.c_int, [C.c_void_p, C.POINTER(_TrainTensor), C.c_int32, C.c_char_p]),
+    "t2l_text_head_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "t2l_text_head_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_pointnet_features_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "t2l_pointnet_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_zero_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -388,6 +391,34 @@ class Engine:
         self._check(self.lib.t2l_encode_cells_backward(self._h, self._ptr(grad_emb, torch.float32, "grad_emb"),
                                                        self._ptr(grad_pn_feat, torch.float32, "grad_pn_feat"),
                                                        _stream_ptr(self.device)))
+
+    # ------------------------------------------------------------------ the text head in training mode (f-4)
+    def text_train_bind(self, tensors: Dict[str, Tuple[torch.Tensor, Optional[torch.Tensor]]], prefix: str = "language_encoder."):
+        """tensors: ``<prefix>intra_module.0.* / inter_mlp.0.* / inter_module.0.*`` -> (live fp32 CUDA tensor, its .grad buffer or None
+        for the BatchNorm running buffers). POINTERS are kept, not copies."""
+        descs, keep = [], []
+        for name, (data, grad) in tensors.items():
+            keep.append((data, grad))
+            descs.append(_TrainTensor(name.encode(), self._ptr(data, torch.float32, name),
+                                      self._ptr(grad, torch.float32, name + ".grad"), data.numel()))
+        arr = (_TrainTensor * len(descs))(*descs)
+        self._check(self.lib.t2l_text_train_bind(self._h, arr, len(descs), prefix.encode()))
+        self._text_train_keepalive = keep
+
+    def text_head_train(self, hidden: torch.Tensor, n_descriptions: int, dropout_p: float = 0.1, seed: int = 0) -> torch.Tensor:
+        """hidden f32[n_sentences, n_tokens, 1024] -> f32[n_descriptions, 256] (not normalised): LanguageEncoder.forward after T5 under
+        model.train() (models/language_encoder.py:127-147); activations stay in the context for ``text_head_backward``."""
+        if hidden.dim() != 3 or hidden.shape[2] != 1024:
+            raise T2LError(f"text_head_train: expected [n_sentences, n_tokens, 1024], got {tuple(hidden.shape)}")
+        out = torch.empty((int(n_descriptions), 256), dtype=torch.float32, device=hidden.device)
+        self._check(self.lib.t2l_text_head_train(self._h, self._ptr(hidden, torch.float32, "hidden"), int(hidden.shape[0]), int(hidden.shape[1]),
+                                                 int(n_descriptions), float(dropout_p), int(seed) & 0xFFFFFFFF, out.data_ptr(),
+                                                 _stream_ptr(self.device)))
+        self._text_train_input = hidden  # must outlive the backward call
+        return out
+
+    def text_head_backward(self, grad_out: torch.Tensor):
+        self._check(self.lib.t2l_text_head_backward(self._h, self._ptr(grad_out, torch.float32, "grad_out"), _stream_ptr(self.device)))
 
     def pointnet_features_train(self, pos: torch.Tensor, rgb: torch.Tensor, cell_offsets) -> torch.Tensor:
         """The PointNet++ backbone under model.train() (per-cell BatchNorm statistics, running statistics updated once per
