@@ -129,6 +129,69 @@ def torch_train_step_ms(sd, cells64, anchor, steps=20):
 
 
 
+def full_train_step_measure(eng, p64, n_ramp, n_steps, B=64, n_hints=6, n_tok=16):
+    import torch.nn.functional as F
+    from text2loc_amd.cell_retrieval import LanguageEncoder
+
+    enc = LanguageEncoder(256, fixed_embedding=True, intra_module_num_layers=1, inter_module_num_layers=1,
+                          llm_model=object(), tokenizer=None, input_dim=1024)
+    enc.load_state_dict({k[len("language_encoder."):]: torch.from_numpy(v) for k, v in synth.make_language_head_weights(0).items()}, strict=False)
+    enc = enc.cuda().train()
+    hidden = 0.2 * torch.randn(B * n_hints, n_tok, 1024, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    opt = torch.optim.Adam(enc.parameters(), lr=1e-4)
+    res = {}
+
+    def step(i):
+        eng.zero_grad()
+        opt.zero_grad(set_to_none=False)
+        anchor = F.normalize(enc.head(hidden, B))
+        pos = eng.encode_cells_train(p64, dropout_p=0.1, seed=i)
+        loss, ga, gp = eng.contrastive_loss(anchor.detach().contiguous(), pos, 0.1)
+        eng.encode_cells_backward(gp)
+        anchor.backward(ga)
+        eng.adam_step(1e-3)
+        opt.step()
+        return loss
+
+    for name, on, bf16 in (("engine_text_head_f32", True, 0), ("engine_text_head_bf16", True, 1), ("engine_text_head_split_bf16", True, 2),
+                           ("pytorch_text_head_f32", False, 0)):
+        enc.use_engine_train_head = on
+        eng.set_option("train_bf16", bf16)
+        if enc._th_train_engine is not None:
+            enc._th_train_engine.set_option("text_train_bf16", bf16)
+        eng.set_option("profile_events", 0)
+        for i in range(max(3, n_ramp // 3)):
+            step(i)
+        if on:
+            enc._th_train_engine.set_option("text_train_bf16", bf16)  # (the head's own engine context exists after the first step)
+            for i in range(3):
+                step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            last = step(100 + i)
+        torch.cuda.synchronize()
+        res[name] = {"ms_per_step_wall": (time.perf_counter() - t0) / n_steps * 1e3, "final_loss": float(last)}
+        if on:
+            te = enc._th_train_engine
+            te.set_option("profile_events", 1)
+            for nme in ("text_train_forward", "text_train_backward"):
+                te.kernel_stats(nme)
+            for i in range(5):
+                step(500 + i)
+            torch.cuda.synchronize()
+            res[name]["text_head_forward_ms"] = te.kernel_stats("text_train_forward")[0]
+            res[name]["text_head_backward_ms"] = te.kernel_stats("text_train_backward")[0]
+            te.set_option("profile_events", 0)
+    eng.set_option("train_bf16", 0)
+    eng.set_option("profile_events", 1)
+    tok = B * n_hints * n_tok
+    flops = 3.0 * (2.0 * tok * (1024 * 3072 + 1024 * 1024 + 2 * 1024 * 4096) + 2.0 * B * n_hints * (1024 * 256 + 256 * (768 + 256 + 2048)))
+    res["workload"] = f"B={B} descriptions x {n_hints} hints x {n_tok} tokens (T5-large width) + the B=64 object-branch step; head FLOPs fwd+bwd {flops / 1e9:.0f} G"
+    res["text_head_algorithmic_gflop_fwd_bwd"] = flops / 1e9
+    return res
+
+
 def text_head_measure(eng, d_db_rows, n_desc, n_hints=6, n_tok=16):
     """a5 / f-4a: the head after T5 for one search step's worth of queries. `total_ms` = what LanguageEncoder.head costs now
     (t2l_text_head — split-f16 MFMA GEMMs — for the d=1024 layer + max + inter_mlp, PyTorch-ROCm for the 256-d half);
@@ -851,6 +914,14 @@ def secondary_measurements(eng):
             eng.set_option("train_bf16", 0)
         except Exception as e:
             out["train_step_b64"]["bf16_variant"] = {"error": repr(e)}
+        # the FULL published step (README.md:87-99 trains the object branch AND the head after the frozen T5): text leaf = T5 hidden
+        # states [64 x 6 sentences, 16 tokens, 1024] (what the sentence cache serves), LanguageEncoder.head under train() on the
+        # engine (t2l_text_head_train / _backward, torch.optim.Adam on its 16.8 M parameters) + the object-branch step above + the
+        # fused contrastive loss; beside it the same step with the head on its PyTorch modules
+        try:
+            out["train_step_b64"]["full_step_with_text_head"] = full_train_step_measure(eng, p64, n_ramp_t, n_steps)
+        except Exception as e:
+            out["train_step_b64"]["full_step_with_text_head"] = {"error": repr(e)}
         try:
             out["train_step_b64"]["torch_eager_ms_per_step_same_gpu"] = torch_train_step_ms(sd, cells64, anchor)
         except Exception as e:

@@ -355,7 +355,9 @@ int t2l_zero_grad(t2l_ctx* ctx, void* stream);
  * 0.1, unbiased running variance). Activations are kept inside the context until the next forward.
  * t2l_text_head_backward: grad_out = dev f32[n_descriptions, 256] (dLoss / d out); parameter gradients are accumulated into the
  * bound buffers; `hidden` receives no gradient (T5 is frozen; a caller that trains T5 keeps the PyTorch path).
- * Arithmetic: f32 (option "train_bf16" = 1 / 2: bf16 / split-bf16 GEMM operands as for the object branch). */
+ * Arithmetic: option "text_train_bf16" (default 2): GEMM operands as split-bf16 (hi + lo bf16, three bf16 MFMAs per 16-step: products
+ * within 2^-16 + 2^-18 relative, f32 accumulation, f32's exponent range — gradients need no loss scaling); 1: plain bf16 operands
+ * (BASELINE config 4's arithmetic); 0: f32 MFMA. Everything else (softmax, LayerNorm, BatchNorm, pooling, dropout) is f32. */
 int t2l_text_train_bind(t2l_ctx* ctx, const t2l_train_tensor* tensors, int32_t n, const char* prefix);
 int t2l_text_head_train(t2l_ctx* ctx, const float* hidden, int32_t n_sentences, int32_t n_tokens, int32_t n_descriptions, float dropout_p,
                         uint32_t seed, float* out, void* stream);

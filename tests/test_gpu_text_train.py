@@ -43,12 +43,15 @@ def _check_grads(tensors, ref_grads, tol_rms, frac=0.97):
             sel = np.r_[0:D, 2 * D:3 * D]
             err, rms = err[sel], float(np.sqrt((rg[sel] ** 2).mean()))
         worst[n] = float(err.max() / (rms + 1e-12))
-        assert float((err < tol_rms * rms + 1e-7).mean()) >= frac and err.max() < 20 * tol_rms * rms + 1e-6, (n, worst[n])
+        # (a ReLU input within rounding of 0 lands on the other side in another arithmetic and moves that unit's whole row / column of
+        # the upstream gradients: the tail bound is on the 99.5th percentile, not on the maximum — cf. DESIGN.md §1, train_step goldens)
+        assert float((err < tol_rms * rms + 1e-7).mean()) >= frac and float(np.quantile(err, 0.995)) < 20 * tol_rms * rms + 1e-6, (n, worst[n])
     return worst
 
 
+@pytest.mark.parametrize("arith", [2, 0, 1], ids=["split_bf16", "f32", "bf16"])
 @pytest.mark.parametrize("n_desc,S,L,p", [(4, 6, 7, 0.1), (3, 6, 16, 0.0), (2, 5, 32, 0.1), (9, 1, 1, 0.1), (16, 6, 12, 0.1)])
-def test_engine_text_train_matches_the_float64_oracle(n_desc, S, L, p):
+def test_engine_text_train_matches_the_float64_oracle(n_desc, S, L, p, arith):
     from oracle import t2l_oracle_text_train as OTT
     from text2loc_amd.engine import Engine
 
@@ -60,13 +63,21 @@ def test_engine_text_train_matches_the_float64_oracle(n_desc, S, L, p):
     eng = Engine(0)
     try:
         tensors = _bind(eng, sd)
+        eng.set_option("text_train_bf16", arith)  # default 2 (split-bf16: f32-class); 0 = f32 MFMA; 1 = plain bf16 operands (config 4)
         out = eng.text_head_train(torch.from_numpy(hidden).cuda(), n_desc, dropout_p=p, seed=seed)
         eng.text_head_backward(torch.from_numpy(G).cuda())
         torch.cuda.synchronize()
         ref, info = OTT.text_head_train(hidden, sd, n_desc, grad_out=G, p_drop=float(np.float32(p)), seed=seed)
+        if arith == 1:  # bf16 operands: 2^-9 per product — the forward within 2 % of the output scale, gradients not compared element-wise
+            assert np.abs(out.cpu().numpy() - ref).max() < 2e-2 * max(1.0, np.abs(ref).max())
+            g = tensors[P + "inter_module.0.linear2.weight"][1].cpu().numpy().astype(np.float64)
+            rg = np.asarray(info["grads"][P + "inter_module.0.linear2.weight"]).reshape(g.shape)
+            cos = float((g * rg).sum() / np.sqrt((g * g).sum() * (rg * rg).sum()))
+            assert cos > 0.9, cos  # (a BatchNorm over a few dozen rows amplifies 2^-9 operand rounding: direction, not elements)
+            return
         assert np.abs(out.cpu().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
         # float32 summation order under a BatchNorm over a few dozen rows and through two LayerNorm'd layers: median-tight, tails bounded
-        _check_grads(tensors, info["grads"], tol_rms=5e-3, frac=0.9)
+        _check_grads(tensors, info["grads"], tol_rms=5e-3 if arith == 0 else 1e-2, frac=0.9)
         new = __import__("oracle.t2l_oracle_train", fromlist=["x"]).bn_running_update(sd, info["bn_stats"])
         for k in (P + "inter_mlp.0.1.running_mean", P + "inter_mlp.0.1.running_var"):
             assert np.allclose(tensors[k][0].cpu().numpy(), new[k], rtol=2e-4, atol=2e-5), k

@@ -498,6 +498,9 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
   } else if (!strcmp(name, "search_xcd_qgroups")) {
     if (value != 1 && value != 2 && value != 4 && value != 8) return fail(ctx, T2L_EINVAL, "search_xcd_qgroups must be 1, 2, 4 or 8");
     ctx->xcd_qgroups = (int)value;
+  } else if (!strcmp(name, "text_train_bf16")) {
+    if (value != 0 && value != 1 && value != 2) return fail(ctx, T2L_EINVAL, "text_train_bf16: 0 (f32), 1 (bf16) or 2 (split-bf16)");
+    ctx->text_train_bf16 = (int)value;
   } else if (!strcmp(name, "search_wide_repair")) {
     if (value < 0 || value > 1024) return fail(ctx, T2L_EINVAL, "search_wide_repair: 0 (off) .. 1024 rows");
     ctx->wide_repair = (int)value;

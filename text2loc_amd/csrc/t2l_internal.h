@@ -103,6 +103,8 @@ struct t2l_ctx {
                          // 4 = a quarter of the queries and half of the splits: -1.3 us of scan span at Q = 4096 x N = 11,259, measured)
   int search_pair = 1;   // mode 0: 1 = the paired scan (two waves per SIMD, scanp_kernel), 0 = scanh_kernel (one wave per SIMD)
   int train_bf16 = 0;       // 1: the training step's GEMMs round their operands to bf16 (one bf16 MFMA per 16-step); 2: split-bf16 (three)
+  int text_train_bf16 = 2;  // the same for the TEXT head's training GEMMs (d_model 1024: 466 GFLOP per step at B = 64): default split-bf16 —
+                            // f32-class products (<= 2^-16 + 2^-18 relative, f32 accumulation, f32 exponent range) at 1.8x the f32 MFMA path's speed
   int train_xcd_map = 0;      // 1 = the training step's tile GEMMs take their blocks in XCD bands (gemm_f32.h; measured slower in f32)
   int loss_single_wg = 0;     // 1 = t2l_contrastive_loss (B <= 128) as the single-workgroup kernel (A/B; default: 4 * ceil(B/32) workgroups)
   int train_gemm_block = 0;   // output block of the training step's tile GEMMs: 64 (2 x 2 tiles per wave: half the operand traffic), 32, or

@@ -990,9 +990,9 @@ int text_train_forward_impl(t2l_ctx* ctx, const float* hidden, int n_sent, int L
   const int S = n_sent / n_desc;
   if (L < 1 || L > 32 || S > 32) return fail(ctx, T2L_EINVAL, "t2l_text_head_train: need 1 <= n_tokens <= 32 and <= 32 sentences per description");
   if (!(p >= 0.f && p < 1.f)) return fail(ctx, T2L_EINVAL, "t2l_text_head_train: dropout_p must be in [0, 1)");
-  tl_gemm_bf16 = ctx->train_bf16;
+  tl_gemm_bf16 = ctx->text_train_bf16;
   tl_xcd_bands = 0;
-  tl_gemm_block64 = ctx->train_gemm_block == 64 || (ctx->train_gemm_block == 0 && ctx->train_bf16 != 0);
+  tl_gemm_block64 = ctx->train_gemm_block == 64 || (ctx->train_gemm_block == 0 && ctx->text_train_bf16 != 0);
   const size_t T1 = (size_t)n_sent * L;
   // saved activations + the backward's scratch: ~31 floats per (row, column) of each layer, see text_layer_alloc / text_layer_bwd
   const size_t need = sizeof(float) * (32 * (T1 * 1024 + (size_t)n_sent * 256) + 2 * (size_t)n_sent * 4 * L * L + 2 * (size_t)n_desc * 4 * S * S +
@@ -1047,9 +1047,9 @@ int text_train_backward_impl(t2l_ctx* ctx, const float* grad_out, hipStream_t s)
   TextTrain* st = tstate(ctx);
   if (!st || !st->have_forward) return fail(ctx, T2L_ESTATE, "t2l_text_head_backward: no forward pass to differentiate");
   if (!grad_out) return fail(ctx, T2L_EINVAL, "t2l_text_head_backward: null gradient");
-  tl_gemm_bf16 = ctx->train_bf16;
+  tl_gemm_bf16 = ctx->text_train_bf16;
   tl_xcd_bands = 0;
-  tl_gemm_block64 = ctx->train_gemm_block == 64 || (ctx->train_gemm_block == 0 && ctx->train_bf16 != 0);
+  tl_gemm_block64 = ctx->train_gemm_block == 64 || (ctx->train_gemm_block == 0 && ctx->text_train_bf16 != 0);
   const size_t mark = st->ws_off;
   const int n_sent = st->n_sent, n_desc = st->n_desc, S = st->S, L = st->L;
   event_begin(ctx, "text_train_backward", s);
