@@ -75,7 +75,7 @@ int t2l_create(t2l_ctx** out, int device_id) {
   t2l_ctx* ctx = new t2l_ctx();
   ctx->device = device_id;
   if (hipMalloc(&ctx->db_norm_max, 2 * sizeof(float)) != hipSuccess ||
-      hipMalloc(&ctx->fb_count, 128 * sizeof(int32_t)) != hipSuccess) {
+      hipMalloc(&ctx->fb_count, 256 * sizeof(int32_t)) != hipSuccess) {
     delete ctx;
     return T2L_ENOMEM;
   }
@@ -84,7 +84,8 @@ int t2l_create(t2l_ctx** out, int device_id) {
     memset(ctx->host_stat, 0, 8 * sizeof(int32_t));
     if (hipHostGetDevicePointer((void**)&ctx->host_stat_dev, ctx->host_stat, 0) != hipSuccess) ctx->host_stat_dev = nullptr;
   }
-  (void)hipMemset(ctx->fb_count, 0, 128 * sizeof(int32_t));
+  (void)hipMemset(ctx->fb_count, 0, 256 * sizeof(int32_t));
+  ctx->fb_prev = ctx->fb_count + 128;  // two banks (search.hip: reset_counts)
   if (hipMalloc(&ctx->scan_span, sizeof(unsigned long long) * 2 * kSpanWgs * kSpanRing) == hipSuccess) {
     (void)hipMemset(ctx->scan_span, 0, sizeof(unsigned long long) * 2 * kSpanWgs * kSpanRing);
     ctx->span_grid = new unsigned[kSpanRing]();
@@ -106,7 +107,7 @@ void t2l_destroy(t2l_ctx* ctx) {
   free_fine(ctx);
   free_text_head(ctx);
   for (void* p : {(void*)ctx->db, (void*)ctx->db_split, (void*)ctx->db_half, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
-                  (void*)ctx->seg_score, (void*)ctx->flags, (void*)ctx->fb_count, ctx->reduce_ws, ctx->loss_ws, ctx->qplane, (void*)ctx->scan_span})
+                  (void*)ctx->seg_score, (void*)ctx->flags, (void*)(ctx->fb_count < ctx->fb_prev ? ctx->fb_count : ctx->fb_prev), ctx->reduce_ws, ctx->loss_ws, ctx->qplane, (void*)ctx->scan_span})
     if (p) (void)hipFree(p);
   delete[] ctx->span_grid;
   if (ctx->host_stat) (void)hipHostFree(ctx->host_stat);

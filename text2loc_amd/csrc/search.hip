@@ -45,10 +45,14 @@ namespace t2l {
 // [7] queries it served, [9] Q and [10] stat mode of the call (rerank_kernel). The first scan launch of a call
 // (zero_counts) copies the finished call's [0..15] to [64..79] — rerank_kernel publishes that copy to the host's report
 // card — and clears the counters.
-__device__ __forceinline__ void reset_counts(int32_t* fb_count, int zero_counts, int tid) {
+// Two banks (round 4): a call counts in `fb_count`, which the call before it left zeroed; `fb_prev` is that earlier call's bank — its
+// final counts are parked at fb_count[64..79] (the report card) and it is cleared for the call after this one. The host swaps the two
+// per call. No workgroup of a call ever waits for this reset (a fused scan + re-rank launch counts from its first finished query
+// block on, whatever workgroup 0 is doing).
+__device__ __forceinline__ void reset_counts(int32_t* fb_count, int32_t* fb_prev, int zero_counts, int tid) {
   if (zero_counts && tid < 16) {
-    fb_count[64 + tid] = fb_count[tid];
-    fb_count[tid] = 0;
+    fb_count[64 + tid] = fb_prev[tid];
+    fb_prev[tid] = 0;
   }
   if (!zero_counts && tid == 0) {  // a later segment of a multi-segment shard: the deferred lists are per segment
     fb_count[12] += fb_count[4];
@@ -92,7 +96,7 @@ __device__ __forceinline__ void tile_mfma(const float* tb, const float (&qa)[128
 template <int L>
 __global__ __launch_bounds__(256, L <= 16 ? 2 : 1) void scan_kernel(const float* __restrict__ db, int n_rows, int n_tiles,
                                                       int code_bits, const float* __restrict__ q, int Q, int nsplit,
-                                                      float* __restrict__ cand, int32_t* __restrict__ fb_count, int zero_counts) {
+                                                      float* __restrict__ cand, int32_t* __restrict__ fb_count, int32_t* __restrict__ fb_prev, int zero_counts) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tiles = smem;
 
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256, L <= 16 ? 2 : 1) void scan_kernel(const float*
   const int qrow = qb * kQPerBlock + wave * kQPerWave + col;
   const int qload = min(qrow, Q - 1);
   const int mask = ~((1 << code_bits) - 1);
-  if (blockIdx.x == 0) reset_counts(fb_count, zero_counts, tid);
+  if (blockIdx.x == 0) reset_counts(fb_count, fb_prev, zero_counts, tid);
 
   // B operand (queries), register resident for the whole scan. The MFMA sums over k in any order as
   // long as A and B agree: lane (col, half) owns k in [128*half, 128*half+128), one contiguous
@@ -229,7 +233,7 @@ constexpr int kWideQPerBlock = 4 * kWideQPerWave;
 template <int LL, int NBUF>
 __global__ __launch_bounds__(256, 1) void scanw_kernel(const uint4* __restrict__ dbs, int n_rows, int n_tiles, int code_bits,
                                                        const float* __restrict__ q, int Q, int nsplit,
-                                                       float* __restrict__ cand, int32_t* __restrict__ fb_count,
+                                                       float* __restrict__ cand, int32_t* __restrict__ fb_count, int32_t* __restrict__ fb_prev,
                                                        int zero_counts, float pinf) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void scanw_kernel(const uint4* __restrict__
   const int mask = ~((1 << code_bits) - 1);
   int vmask = mask;
   asm volatile("" : "+v"(vmask));
-  if (blockIdx.x == 0) reset_counts(fb_count, zero_counts, tid);
+  if (blockIdx.x == 0) reset_counts(fb_count, fb_prev, zero_counts, tid);
   if (nt == 0) return;  // (the host never launches an empty split)
   const int uwave = uniform_wave_id();
 
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(256) void half_db_kernel(const float* __restrict__ 
 template <int LL>
 __global__ __launch_bounds__(256, 1) void scanh_kernel(const uint4* __restrict__ dbh, int n_rows, int n_tiles, int code_bits,
                                                        const float* __restrict__ q, int Q, int nsplit,
-                                                       float* __restrict__ cand, int32_t* __restrict__ fb_count,
+                                                       float* __restrict__ cand, int32_t* __restrict__ fb_count, int32_t* __restrict__ fb_prev,
                                                        int zero_counts, float pinf) {
   constexpr int NBUF = 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void scanh_kernel(const uint4* __restrict__
   const int mask = ~((1 << code_bits) - 1);
   int vmask = mask;
   asm volatile("" : "+v"(vmask));
-  if (blockIdx.x == 0) reset_counts(fb_count, zero_counts, tid);
+  if (blockIdx.x == 0) reset_counts(fb_count, fb_prev, zero_counts, tid);
   if (nt == 0) return;  // (the host never launches an empty split)
 
   // ---- LDS-DMA plan: wave w moves pieces 4w .. 4w+3 (1 KiB each, contiguous) of a tile: global image == LDS image
@@ -517,7 +521,7 @@ __device__ __forceinline__ float dpp_f(float v) {
 template <int LL, int NS, bool PREP>
 __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__ dbt, int n_rows, int n_tiles, int code_bits,
                                                        const float* __restrict__ q, const uint4* __restrict__ qplane, int Q, int nsplit,
-                                                       float* __restrict__ cand, int32_t* __restrict__ fb_count,
+                                                       float* __restrict__ cand, int32_t* __restrict__ fb_count, int32_t* __restrict__ fb_prev,
                                                        int zero_counts, float pinf, unsigned long long* __restrict__ span,
                                                        unsigned span_seq, int xcd_qgroups) {
   static_assert(NS == 4, "the step loop below is unrolled for a ring of 4 slots");
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
   const int mask = ~((1 << code_bits) - 1);
   int vmask = mask;
   asm volatile("" : "+v"(vmask));
-  if (blockIdx.x == 0) reset_counts(fb_count, zero_counts, tid);
+  if (blockIdx.x == 0) reset_counts(fb_count, fb_prev, zero_counts, tid);
   if (steps == 0) return;  // (the host never launches an empty split)
   // always-on stamps (t2l_kernel_stats "search_scan_span" / "search_scan_busy"): every workgroup stores its own start and end
   // (launch sequence << 40 | 100 MHz ticks) in its own slot of the launch's ring entry — plain stores, no packet on the stream
@@ -1556,11 +1560,11 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
     hipEvent_t ea, eb;
     if (event_pair(ctx, "search_scan", &ea, &eb))  // sampled launch: the dispatch carries its own start / stop events
       hipExtLaunchKernelGGL(prep ? (scanp_kernel<LL, 4, true>) : (scanp_kernel<LL, 4, false>), grid, dim3(512), (uint32_t)lds, s, ea, eb, 0u,
-                            dbh, n_rows, n_tiles, code_bits, q, (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, zero,
+                            dbh, n_rows, n_tiles, code_bits, q, (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, ctx->fb_prev, zero,
                             __builtin_inff(), span, span_seq, xq);
     else
       hipLaunchKernelGGL(prep ? (scanp_kernel<LL, 4, true>) : (scanp_kernel<LL, 4, false>), grid, dim3(512), lds, s, dbh, n_rows, n_tiles,
-                         code_bits, q, (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, zero, __builtin_inff(), span,
+                         code_bits, q, (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, ctx->fb_prev, zero, __builtin_inff(), span,
                          span_seq, xq);
   } else {
   event_begin(ctx, "search_scan", s);
@@ -1573,7 +1577,7 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
       once.mark(ctx->device);
     }
     hipLaunchKernelGGL((scanh_kernel<LL>), grid, dim3(256), lds, s, dbh, n_rows, n_tiles, code_bits, q, Q, nsplit,
-                       ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
+                       ctx->cand_score, ctx->fb_count, ctx->fb_prev, zero, __builtin_inff());
   } else if (ctx->eff_mode == 2) {  // split-bf16 MFMA scan, same structure, three MFMAs per product
     const dim3 grid((Q + kWideQPerBlock - 1) / kWideQPerBlock * nsplit);
     const size_t lds = (size_t)4 * kTileFloats * sizeof(float);
@@ -1583,7 +1587,7 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
       once.mark(ctx->device);
     }
     hipLaunchKernelGGL((scanw_kernel<LL, 4>), grid, dim3(256), lds, s, dbs, n_rows, n_tiles, code_bits, q, Q, nsplit,
-                       ctx->cand_score, ctx->fb_count, zero, __builtin_inff());
+                       ctx->cand_score, ctx->fb_count, ctx->fb_prev, zero, __builtin_inff());
   } else if constexpr (LL == L) {  // exact-f32 MFMA scan
     const dim3 grid((Q + kQPerBlock - 1) / kQPerBlock * nsplit);
     const size_t lds = scan_lds_bytes();
@@ -1593,7 +1597,7 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
       once.mark(ctx->device);
     }
     hipLaunchKernelGGL((scan_kernel<L>), grid, dim3(256), lds, s, db, n_rows, n_tiles, code_bits, q, Q, nsplit,
-                       ctx->cand_score, ctx->fb_count, zero);
+                       ctx->cand_score, ctx->fb_count, ctx->fb_prev, zero);
   }
   event_end(ctx, "search_scan", s);
   }
@@ -1643,9 +1647,9 @@ __global__ __launch_bounds__(256) void empty_result_kernel(int n, int32_t* __res
 // the previous call's report card published, as reset_counts + rerank_kernel's first thread do) and puts every query on the exact
 // stage's list.
 __global__ __launch_bounds__(256) void all_exact_prep_kernel(int Q, int32_t* __restrict__ list, int32_t* __restrict__ fb_count,
-                                                             int32_t* __restrict__ host_stat, int seq) {
+                                                             int32_t* __restrict__ fb_prev, int32_t* __restrict__ host_stat, int seq) {
   if (blockIdx.x == 0) {
-    reset_counts(fb_count, 1, threadIdx.x);
+    reset_counts(fb_count, fb_prev, 1, threadIdx.x);
     __syncthreads();
     if (threadIdx.x == 0) {
       if (host_stat && seq > 0) {
@@ -1723,11 +1727,12 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
   int rc;
   // flags[Q] + f32 thresholds[Q] + flagged list[Q] + deferred list[Q] + uncertified list[Q] (search_exact.hip)
   if ((rc = grow(ctx, (void**)&ctx->flags, &ctx->flag_cap, (size_t)5 * Q * sizeof(int32_t))) != T2L_OK) return rc;
+  std::swap(ctx->fb_count, ctx->fb_prev);  // this call counts in the bank the previous call cleared (reset_counts)
   if (ctx->search_auto && ctx->heavy && ctx->all_exact && n_seg == 1 && (ctx->all_exact_calls++ & 7) != 7) {
     const int seq = ++ctx->stat_seq;
     // (block 0 parks the counters before any block's exactd successor reads them: the launches are stream-ordered)
     hipLaunchKernelGGL(all_exact_prep_kernel, dim3(min((Q + 255) / 256, 64)), dim3(256), 0, s, Q, ctx->flags + (size_t)3 * Q, ctx->fb_count,
-                       ctx->host_stat_dev, seq);
+                       ctx->fb_prev, ctx->host_stat_dev, seq);
     T2L_HIP(ctx, hipGetLastError());
     return exact_stage_impl(ctx, ctx->db, n_rows, (int)ctx->row_offset, q, Q, K, out_idx, out_score, s);
   }
@@ -1803,6 +1808,7 @@ static void swap_lane(t2l_ctx* ctx, t2l_ctx::SearchLane& L) {
   std::swap(ctx->flags, L.flags);
   std::swap(ctx->flag_cap, L.flag_cap);
   std::swap(ctx->fb_count, L.fb_count);
+  std::swap(ctx->fb_prev, L.fb_prev);
   std::swap(ctx->host_stat, L.host_stat);
   std::swap(ctx->host_stat_dev, L.host_stat_dev);
   std::swap(ctx->stat_seen, L.stat_seen);
@@ -1822,7 +1828,7 @@ int search_join_impl(t2l_ctx* ctx, hipStream_t s) {
 
 void free_lanes(t2l_ctx* ctx) {
   for (auto& L : ctx->lanes) {
-    for (void* p : {(void*)L.cand_score, (void*)L.flags, (void*)L.fb_count, L.qplane})
+    for (void* p : {(void*)L.cand_score, (void*)L.flags, (void*)(L.fb_count < L.fb_prev ? L.fb_count : L.fb_prev), L.qplane})
       if (p) (void)hipFree(p);
     if (L.host_stat) (void)hipHostFree(L.host_stat);
     if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -1846,8 +1852,9 @@ int search_lanes_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_i
     T2L_HIP(ctx, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
     T2L_HIP(ctx, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
     if (!ctx->lane_fork) T2L_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_fork, hipEventDisableTiming));
-    T2L_HIP(ctx, hipMalloc(&L.fb_count, 128 * sizeof(int32_t)));
-    T2L_HIP(ctx, hipMemset(L.fb_count, 0, 128 * sizeof(int32_t)));
+    T2L_HIP(ctx, hipMalloc(&L.fb_count, 256 * sizeof(int32_t)));  // two banks (reset_counts)
+    T2L_HIP(ctx, hipMemset(L.fb_count, 0, 256 * sizeof(int32_t)));
+    L.fb_prev = L.fb_count + 128;
     if (hipHostMalloc((void**)&L.host_stat, 8 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess) {
       for (int i = 0; i < 8; ++i) L.host_stat[i] = 0;
       if (hipHostGetDevicePointer((void**)&L.host_stat_dev, L.host_stat, 0) != hipSuccess) L.host_stat_dev = nullptr;

@@ -67,6 +67,7 @@ struct t2l_ctx {
   float* cand_score = nullptr;   // candidate keys [Q][2*nsplit][L]
   int32_t* flags = nullptr;      // dev i32[Q]: 1 = first-stage certificate failed -> fallback kernel
   int32_t* fb_count = nullptr;   // dev i32[128] (2 used): [0] exact-scan fallbacks, [1] stage-2 re-scores of the last search
+  int32_t* fb_prev = nullptr;    // the other bank of the same allocation (search.hip: reset_counts); the host swaps the two per call
   int32_t* seg_idx = nullptr;    // per-segment results when the shard exceeds one scan launch
   double* seg_score = nullptr;
   size_t cand_cap = 0, flag_cap = 0, seg_idx_cap = 0, seg_score_cap = 0;  // bytes
@@ -127,7 +128,7 @@ struct t2l_ctx {
     float* cand_score = nullptr;
     void* qplane = nullptr;
     size_t cand_cap = 0, flag_cap = 0, qplane_cap = 0;
-    int32_t *flags = nullptr, *fb_count = nullptr, *host_stat = nullptr, *host_stat_dev = nullptr;
+    int32_t *flags = nullptr, *fb_count = nullptr, *fb_prev = nullptr, *host_stat = nullptr, *host_stat_dev = nullptr;
     int stat_seen = 0;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
