@@ -871,43 +871,60 @@ __device__ __forceinline__ void wg_exact_scan(const float* __restrict__ db, int 
   __syncthreads();
 }
 
-// ------------------------------------------------------------------------------------------------
-// rerank (stage 1): one wave per query, 4 queries per 256-thread block.
-// ------------------------------------------------------------------------------------------------
-// LL = length of the per-lane lists the scan wrote, L = rows re-scored per query (LL <= L).
-template <int LL, int L>
-__global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ db, const float* __restrict__ q, int Q,
-                                                     int K, int parts, int code_bits,
-                                                     const float* __restrict__ cand, int row_offset, float eps_rel,
-                                                     const float* __restrict__ db_norm_max, int half_mode,
-                                                     int32_t* __restrict__ out_idx, double* __restrict__ out_score,
-                                                     int32_t* __restrict__ flags, int32_t* __restrict__ fb_count,
-                                                     float eps_rel_probe, float pinf, int n_rows, int defer, int stat_mode,
-                                                     int32_t* __restrict__ host_stat, int seq, int wide_cap) {
-  __shared__ WgExactShared exact_sh;
-  __shared__ int wg_flag[4];
-  __shared__ int wide_rows[4][kWideCap];  // per wave: the rows a wide repair re-scores
-  const int lane = threadIdx.x & 63;
-  const int qid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (threadIdx.x < 4) wg_flag[threadIdx.x] = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    // the report card of the PREVIOUS call (its counters were parked at [64..] by this call's scan): mapped host memory the
-    // host reads at a later call — no stream operation, no synchronisation (it only steers heuristics); the sequence number is
-    // published LAST with system-scope release ordering, the host reads it first with an acquire load, so a new sequence
-    // number is never paired with the previous call's counts
-    if (host_stat && seq > 0) {
-      host_stat[1] = fb_count[64 + 10] == 2 ? fb_count[64 + 3] : fb_count[64 + 2];  // f16-certificate failures (or the probe's)
-      host_stat[2] = fb_count[64 + 9];
-      host_stat[3] = fb_count[64 + 0] + fb_count[64 + 4] + fb_count[64 + 12];  // exact-stage queries
-      host_stat[4] = fb_count[64 + 10];  // 0: not an f16-certificate count, 1: the f16 scan's own, 2: the split-bf16 stand-in's probe
-      host_stat[5] = fb_count[64 + 10] == 2 ? fb_count[64 + 3] : fb_count[64 + 1];  // first-certificate failures (settled in the wave or not)
-      __hip_atomic_store(&host_stat[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    fb_count[9] = Q;
-    fb_count[10] = stat_mode;  // 0: not an f16-certificate count, 1: f16 scan, 2: split-bf16 stand-in probing for it
+// The arguments of the re-rank (one struct: rerank_kernel and the fused scan + re-rank launch share the per-query routine below).
+struct RerankArgs {
+  const float* db;
+  const float* q;
+  int Q, K, parts, code_bits;
+  const float* cand;
+  int row_offset;
+  float eps_rel;
+  const float* db_norm_max;
+  int half_mode;
+  int32_t* out_idx;
+  double* out_score;
+  int32_t* flags;
+  int32_t* fb_count;
+  float eps_rel_probe, pinf;
+  int n_rows, defer, stat_mode;
+  int32_t* host_stat;
+  int seq, wide_cap;
+};
+
+// The report card of the PREVIOUS call (its counters were parked at [64..] by reset_counts): mapped host memory the host reads at a
+// later call — no stream operation, no synchronisation (it only steers heuristics); the sequence number is published LAST with
+// system-scope release ordering, the host reads it first with an acquire load, so a new sequence number is never paired with the
+// previous call's counts. One thread of one workgroup per call.
+__device__ __forceinline__ void publish_report(const RerankArgs& a) {
+  int32_t* fb_count = a.fb_count;
+  if (a.host_stat && a.seq > 0) {
+    a.host_stat[1] = fb_count[64 + 10] == 2 ? fb_count[64 + 3] : fb_count[64 + 2];  // f16-certificate failures (or the probe's)
+    a.host_stat[2] = fb_count[64 + 9];
+    a.host_stat[3] = fb_count[64 + 0] + fb_count[64 + 4] + fb_count[64 + 12];  // exact-stage queries
+    a.host_stat[4] = fb_count[64 + 10];  // 0: not an f16-certificate count, 1: the f16 scan's own, 2: the split-bf16 stand-in's probe
+    a.host_stat[5] = fb_count[64 + 10] == 2 ? fb_count[64 + 3] : fb_count[64 + 1];  // first-certificate failures (settled in the wave or not)
+    __hip_atomic_store(&a.host_stat[0], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  __syncthreads();
-  if (qid < Q) {
+  fb_count[9] = a.Q;
+  fb_count[10] = a.stat_mode;  // 0: not an f16-certificate count, 1: f16 scan, 2: split-bf16 stand-in probing for it
+}
+
+// One query, one wave. `my_wg_flag`: this wave's slot of the workgroup's "rank exactly" flags; `wr_buf`: kWideCap ints of LDS.
+// SC1: the candidate lists are read with agent-scope (L1-bypassing) loads — the fused launch, where they were written by other
+// workgroups of the same launch.
+template <int LL, int L, bool SC1>
+__device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid, const int lane, int* my_wg_flag, int* wr_buf) {
+  const float* __restrict__ db = a.db;
+  const float* __restrict__ q = a.q;
+  const int Q = a.Q, K = a.K, parts = a.parts, code_bits = a.code_bits, row_offset = a.row_offset, half_mode = a.half_mode;
+  const float* __restrict__ cand = a.cand;
+  const float eps_rel = a.eps_rel, eps_rel_probe = a.eps_rel_probe, pinf = a.pinf;
+  const float* __restrict__ db_norm_max = a.db_norm_max;
+  int32_t* __restrict__ out_idx = a.out_idx;
+  double* __restrict__ out_score = a.out_score;
+  int32_t* __restrict__ flags = a.flags;
+  int32_t* __restrict__ fb_count = a.fb_count;
+  const int n_rows = a.n_rows, defer = a.defer, wide_cap = a.wide_cap;
 
   // ---- every lane pulls its whole sorted key list into registers (one memory latency for the merge)
   float lst[LL];
@@ -916,9 +933,16 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
     if constexpr (LL % 2 == 0) {  // (LL = 6 lists are 24 bytes: 8-byte loads keep every list aligned)
 #pragma unroll
       for (int i = 0; i < LL / 2; ++i) {
-        const float2 v = reinterpret_cast<const float2*>(mine)[i];
-        lst[2 * i] = v.x;
-        lst[2 * i + 1] = v.y;
+        if constexpr (SC1) {  // fused launch: the lists were published by OTHER workgroups of this launch (sc1 stores): L1-bypassing loads
+          const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(mine) + i, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+          lst[2 * i] = __uint_as_float((unsigned)u);
+          lst[2 * i + 1] = __uint_as_float((unsigned)(u >> 32));
+        } else {
+          const float2 v = reinterpret_cast<const float2*>(mine)[i];
+          lst[2 * i] = v.x;
+          lst[2 * i + 1] = v.y;
+        }
       }
     } else {
 #pragma unroll
@@ -1173,7 +1197,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) work += __shfl_xor(work, off);
       if (work <= wide_cap) {
-        int* wr = wide_rows[threadIdx.x >> 6];
+        int* wr = wr_buf;
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
         int base = 0;
 #pragma unroll
@@ -1254,13 +1278,38 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
     if (!certified || !representable) atomicAdd(&fb_count[1], 1);  // first certificate failed (settled in the wave or not)
     if (flag) {
       atomicAdd(&fb_count[2], 1);
-      if (!defer) wg_flag[threadIdx.x >> 6] = flag;  // settled below, by this workgroup
+      if (!defer) *my_wg_flag = flag;  // settled below, by this workgroup
       else if (flag == 2) flags[4 * Q + atomicAdd(&fb_count[6], 1)] = qid;  // heavy mode: -> exact_list_kernel
       else flags[3 * Q + atomicAdd(&fb_count[4], 1)] = qid;                  //             -> exactd_kernel
     }
   }
   }  // !early
-  }  // qid < Q
+}
+
+// ------------------------------------------------------------------------------------------------
+// rerank (stage 1): one wave per query, 4 queries per 256-thread block.
+// ------------------------------------------------------------------------------------------------
+// LL = length of the per-lane lists the scan wrote, L = rows re-scored per query (LL <= L).
+template <int LL, int L>
+__global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ db, const float* __restrict__ q, int Q,
+                                                     int K, int parts, int code_bits,
+                                                     const float* __restrict__ cand, int row_offset, float eps_rel,
+                                                     const float* __restrict__ db_norm_max, int half_mode,
+                                                     int32_t* __restrict__ out_idx, double* __restrict__ out_score,
+                                                     int32_t* __restrict__ flags, int32_t* __restrict__ fb_count,
+                                                     float eps_rel_probe, float pinf, int n_rows, int defer, int stat_mode,
+                                                     int32_t* __restrict__ host_stat, int seq, int wide_cap) {
+  __shared__ WgExactShared exact_sh;
+  __shared__ int wg_flag[4];
+  __shared__ int wide_rows[4][kWideCap];  // per wave: the rows a wide repair re-scores
+  const RerankArgs a{db, q, Q, K, parts, code_bits, cand, row_offset, eps_rel, db_norm_max, half_mode, out_idx, out_score, flags, fb_count,
+                     eps_rel_probe, pinf, n_rows, defer, stat_mode, host_stat, seq, wide_cap};
+  const int lane = threadIdx.x & 63;
+  const int qid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (threadIdx.x < 4) wg_flag[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) publish_report(a);
+  __syncthreads();
+  if (qid < Q) rerank_query<LL, L, false>(a, qid, lane, &wg_flag[threadIdx.x >> 6], wide_rows[threadIdx.x >> 6]);
   // ---- unsettled queries of this workgroup: the exact float64 ranking, all 4 waves on one query at a time
   __syncthreads();
 #pragma unroll 1
