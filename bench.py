@@ -981,6 +981,7 @@ def main():
     ap.add_argument("--mode", type=int, default=0,
                     help="search_mode: 0 = f16 scan (default), 1 = f32 scan, 2 = split-bf16 scan")
     ap.add_argument("--nsplit", type=int, default=0, help="override the scan kernel's DB split count (0 = auto)")
+    ap.add_argument("--fused", type=int, default=-1, help="search_fused: 1 = scan + re-rank as one launch, 0 = two launches, -1 = the library's default")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the pipelined side measurement (profiling runs: its "
                     "overlapping launches would enter the per-kernel averages)")
     ap.add_argument("--quick", action="store_true", help="profiling runs (rocprofv3 --pmc slows every launch ~100x and does not "
@@ -1049,6 +1050,8 @@ def main():
     lo, hi = searcher.set_db_shard(d_db)
     eng.set_option("profile_events", 97)  # outside the timed region: rare (the first samples create the event rings — not in the timed steps)
     eng.set_option("search_mode", args.mode)
+    if args.fused >= 0:
+        eng.set_option("search_fused", args.fused)
     if args.nsplit:
         eng.set_option("search_nsplit", args.nsplit)
     # N=1: the steps are independent jobs (a different query batch each) — they pipeline over `--lanes` internal streams of the

@@ -107,7 +107,7 @@ void t2l_destroy(t2l_ctx* ctx) {
   free_fine(ctx);
   free_text_head(ctx);
   for (void* p : {(void*)ctx->db, (void*)ctx->db_split, (void*)ctx->db_half, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
-                  (void*)ctx->seg_score, (void*)ctx->flags, (void*)(ctx->fb_count < ctx->fb_prev ? ctx->fb_count : ctx->fb_prev), ctx->reduce_ws, ctx->loss_ws, ctx->qplane, (void*)ctx->scan_span})
+                  (void*)ctx->seg_score, (void*)ctx->flags, (void*)(ctx->fb_count < ctx->fb_prev ? ctx->fb_count : ctx->fb_prev), (void*)ctx->qb_cnt, ctx->reduce_ws, ctx->loss_ws, ctx->qplane, (void*)ctx->scan_span})
     if (p) (void)hipFree(p);
   delete[] ctx->span_grid;
   if (ctx->host_stat) (void)hipHostFree(ctx->host_stat);
@@ -502,6 +502,8 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
   } else if (!strcmp(name, "text_train_bf16")) {
     if (value != 0 && value != 1 && value != 2) return fail(ctx, T2L_EINVAL, "text_train_bf16: 0 (f32), 1 (bf16) or 2 (split-bf16)");
     ctx->text_train_bf16 = (int)value;
+  } else if (!strcmp(name, "search_fused")) {
+    ctx->search_fused = value != 0;
   } else if (!strcmp(name, "search_wide_repair")) {
     if (value < 0 || value > 1024) return fail(ctx, T2L_EINVAL, "search_wide_repair: 0 (off) .. 1024 rows");
     ctx->wide_repair = (int)value;

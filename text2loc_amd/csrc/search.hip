@@ -518,12 +518,47 @@ __device__ __forceinline__ float dpp_f(float v) {
 // a wave's fragment load is one contiguous 1 KiB) instead of being converted by every workgroup — the 16 splits of a query
 // block then read 128 KB of f16 each instead of converting 256 KB of f32 each (67 MB -> 33 MB through the L2s, no LDS exchange,
 // no barrier in the prologue).
-template <int LL, int NS, bool PREP>
+// The arguments of the re-rank (one struct: rerank_kernel and the fused scan + re-rank launch share the per-query routine below).
+struct RerankArgs {
+  const float* db;
+  const float* q;
+  int Q, K, parts, code_bits;
+  const float* cand;
+  int row_offset;
+  float eps_rel;
+  const float* db_norm_max;
+  int half_mode;
+  int32_t* out_idx;
+  double* out_score;
+  int32_t* flags;
+  int32_t* fb_count;
+  float eps_rel_probe, pinf;
+  int n_rows, defer, stat_mode;
+  int32_t* host_stat;
+  int seq, wide_cap;
+};
+
+// FUSED (round 4): scan + re-rank in ONE launch. A workgroup publishes its candidate lists with write-through (sc1) stores, arrives on
+// its query block's counter, waits until the block's other splits have arrived (they are co-resident: a query block's workgroups
+// are consecutive in launch order) and then re-ranks its share of the block's queries (rerank_query, lists read with sc1 loads) —
+// no second dispatch, no kernel boundary between the two stages. The wait is bounded: a workgroup whose partners do not show up
+// (the chip shared with another process, fewer CUs than a block has splits) ranks its queries exactly instead (wg_exact_scan).
+struct FusedArgs {
+  RerankArgs rr;
+  int32_t* qb_cnt;  // [2][kFusedMaxQb] arrival counters, by call parity: a call counts in one half and zeroes the other for the next
+  int parity;
+};
+constexpr int kFusedMaxQb = 4096;
+constexpr int kFusedSpinMax = 1 << 15;  // x s_sleep(16) ~ 1 us each: ~30 ms, then the exact fallback
+template <int LL>
+__device__ void fused_rerank_tail(const FusedArgs& fa, float* smem, int qb, int sp, int nsplit, int Q);  // (defined behind rerank_query)
+
+template <int LL, int NS, bool PREP, bool FUSED = false>
 __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__ dbt, int n_rows, int n_tiles, int code_bits,
                                                        const float* __restrict__ q, const uint4* __restrict__ qplane, int Q, int nsplit,
                                                        float* __restrict__ cand, int32_t* __restrict__ fb_count, int32_t* __restrict__ fb_prev,
                                                        int zero_counts, float pinf, unsigned long long* __restrict__ span,
-                                                       unsigned span_seq, int xcd_qgroups) {
+                                                       unsigned span_seq, int xcd_qgroups, const FusedArgs fa = FusedArgs{}) {
   static_assert(NS == 4, "the step loop below is unrolled for a ring of 4 slots");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kSlotBytes = 2 * kHalfTileBytes;
@@ -536,7 +571,14 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
   // xcd_qgroups = GQ > 1: XCD x owns the RECTANGLE {query blocks = x % GQ (mod GQ)} x {splits = x / GQ (mod 8 / GQ)} instead: its
   // L2 pulls 1/GQ of the queries in the prologue (the burst every CU waits for) and GQ/8 of the plane over the main loop.
   int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
-  if (xcd_qgroups > 1) {
+  if (xcd_qgroups < 0) {
+    // fused launch, 16 splits, query blocks in fours: WINDOWS of 64 consecutive workgroups = 4 query blocks x 16 splits, XCD x =
+    // blockIdx % 8 takes query block x % 4 of the window and splits (x / 4) * 8 + 0..7 — the same L2 footprint as the rectangle
+    // below (a quarter of the queries, half the plane per XCD) with every query block's workgroups inside one window
+    const int r = blockIdx.x & 63, x = r & 7;
+    qb = (blockIdx.x >> 6) * 4 + (x & 3);
+    sp = (x >> 2) * 8 + (r >> 3);
+  } else if (xcd_qgroups > 1) {
     const int GQ = xcd_qgroups, GS = 8 / GQ, nqb = gridDim.x / nsplit;
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3, per = nqb / GQ;
     qb = (j % per) * GQ + x % GQ;
@@ -551,6 +593,9 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
   int vmask = mask;
   asm volatile("" : "+v"(vmask));
   if (blockIdx.x == 0) reset_counts(fb_count, fb_prev, zero_counts, tid);
+  if constexpr (FUSED) {
+    if (sp == 0 && tid == 0) fa.qb_cnt[(fa.parity ^ 1) * kFusedMaxQb + qb] = 0;  // the next call's counter of this query block
+  }
   if (steps == 0) return;  // (the host never launches an empty split)
   // always-on stamps (t2l_kernel_stats "search_scan_span" / "search_scan_busy"): every workgroup stores its own start and end
   // (launch sequence << 40 | 100 MHz ticks) in its own slot of the launch's ring entry — plain stores, no packet on the stream
@@ -730,7 +775,14 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
     float* out = cand + ((size_t)qrow * parts + part) * LL;
     if constexpr (LL % 2 == 0) {  // 24-byte lists: three 8-byte stores
 #pragma unroll
-      for (int i = 0; i < LL / 2; ++i) reinterpret_cast<float2*>(out)[i] = make_float2(ls[2 * i], ls[2 * i + 1]);
+      for (int i = 0; i < LL / 2; ++i) {
+        if constexpr (FUSED)  // write-through: read by other workgroups of this launch
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(out) + i,
+                             (unsigned long long)__float_as_uint(ls[2 * i]) | ((unsigned long long)__float_as_uint(ls[2 * i + 1]) << 32),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+          reinterpret_cast<float2*>(out)[i] = make_float2(ls[2 * i], ls[2 * i + 1]);
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < LL; ++i) out[i] = ls[i];
@@ -743,6 +795,7 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
     *reinterpret_cast<ulonglong2*>(span + 2 * blockIdx.x) = make_ulonglong2(tag | (wg_t0 & tm), tag | (t1 & tm));
   }
   T2L_STAMP(3);
+  if constexpr (FUSED) fused_rerank_tail<LL>(fa, smem, qb, sp, nsplit, Q);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -754,10 +807,12 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
 // layout and arithmetic); the wave's top-32 is a list spread over lanes (lane i = i-th best, ordered by score desc, row asc);
 // the 4 lists meet in LDS and the first wave ranks the 128 entries.
 // ------------------------------------------------------------------------------------------------
-struct WgExactShared {
-  double score[4][32];
-  int row[4][32];
+template <int NW>
+struct WgExactSharedN {
+  double score[NW][32];
+  int row[NW][32];
 };
+typedef WgExactSharedN<4> WgExactShared;
 
 // Rows one wave re-scores in a WIDE repair (rerank_kernel) before the query is handed to an exact scan of the whole shard.
 constexpr int kWideCap = 1024;
@@ -787,9 +842,10 @@ __device__ __forceinline__ void top32_insert(double& ts, int& tr, double cd, int
   }
 }
 
+template <int NW = 4>  // waves of the workgroup (4: rerank_kernel, 8: the fused scan + re-rank launch)
 __device__ __forceinline__ void wg_exact_scan(const float* __restrict__ db, int n_rows, const float* __restrict__ qrow, int K,
                                               int row_offset, int32_t* __restrict__ out_idx, double* __restrict__ out_score,
-                                              WgExactShared& sh) {
+                                              WgExactSharedN<NW>& sh) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int seg = lane & 15, grp = lane >> 4;
   double qd[16];
@@ -807,7 +863,7 @@ __device__ __forceinline__ void wg_exact_scan(const float* __restrict__ db, int 
   double my_s = -__builtin_inf();  // lane i (< 32): the i-th best (score, row) this wave has seen
   int my_r = INT_MAX;
   const int n_groups = (n_rows + 3) / 4;
-  for (int g = wave; g < n_groups; g += 4) {
+  for (int g = wave; g < n_groups; g += NW) {
     const int row = 4 * g + grp;
     const float4* rp = reinterpret_cast<const float4*>(db + (size_t)min(row, n_rows - 1) * kD) + seg;
     double d0 = 0.0, d1 = 0.0;
@@ -845,51 +901,36 @@ __device__ __forceinline__ void wg_exact_scan(const float* __restrict__ db, int 
     sh.row[wave][lane] = my_r;
   }
   __syncthreads();
-  if (wave == 0) {  // 128 entries, two per lane: rank by (score desc, row asc), the first K go out
-    const double s0 = (&sh.score[0][0])[lane], s1 = (&sh.score[0][0])[64 + lane];
-    const int r0 = (&sh.row[0][0])[lane], r1 = (&sh.row[0][0])[64 + lane];
-    int k0 = 0, k1 = 0;
-    for (int o = 0; o < 128; ++o) {
+  if (wave == 0) {  // 32 NW entries, NW / 2 per lane: rank by (score desc, row asc), the first K go out
+    constexpr int PER = NW / 2, TOT = 32 * NW;
+    double sv[PER];
+    int rv[PER], kv[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      sv[e] = (&sh.score[0][0])[64 * e + lane];
+      rv[e] = (&sh.row[0][0])[64 * e + lane];
+      kv[e] = 0;
+    }
+    for (int o = 0; o < TOT; ++o) {
       const double os = (&sh.score[0][0])[o];
       const int orow = (&sh.row[0][0])[o];
-      k0 += (os > s0 || (os == s0 && orow < r0)) ? 1 : 0;
-      k1 += (os > s1 || (os == s1 && orow < r1)) ? 1 : 0;
+#pragma unroll
+      for (int e = 0; e < PER; ++e) kv[e] += (os > sv[e] || (os == sv[e] && orow < rv[e])) ? 1 : 0;
     }
     if (lane < K) {
       out_idx[lane] = -1;
       if (out_score) out_score[lane] = -__builtin_inf();
     }
-    if (r0 != INT_MAX && k0 < K) {
-      out_idx[k0] = r0 + row_offset;
-      if (out_score) out_score[k0] = s0;
-    }
-    if (r1 != INT_MAX && k1 < K) {
-      out_idx[k1] = r1 + row_offset;
-      if (out_score) out_score[k1] = s1;
-    }
+#pragma unroll
+    for (int e = 0; e < PER; ++e)
+      if (rv[e] != INT_MAX && kv[e] < K) {
+        out_idx[kv[e]] = rv[e] + row_offset;
+        if (out_score) out_score[kv[e]] = sv[e];
+      }
   }
   __syncthreads();
 }
 
-// The arguments of the re-rank (one struct: rerank_kernel and the fused scan + re-rank launch share the per-query routine below).
-struct RerankArgs {
-  const float* db;
-  const float* q;
-  int Q, K, parts, code_bits;
-  const float* cand;
-  int row_offset;
-  float eps_rel;
-  const float* db_norm_max;
-  int half_mode;
-  int32_t* out_idx;
-  double* out_score;
-  int32_t* flags;
-  int32_t* fb_count;
-  float eps_rel_probe, pinf;
-  int n_rows, defer, stat_mode;
-  int32_t* host_stat;
-  int seq, wide_cap;
-};
 
 // The report card of the PREVIOUS call (its counters were parked at [64..] by reset_counts): mapped host memory the host reads at a
 // later call — no stream operation, no synchronisation (it only steers heuristics); the sequence number is published LAST with
@@ -1286,6 +1327,55 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
   }  // !early
 }
 
+// The second half of the fused launch (scanp_kernel<..., FUSED>): publish is done (the caller's lists went out with sc1 stores).
+template <int LL>
+__device__ void fused_rerank_tail(const FusedArgs& fa, float* smem, int qb, int sp, int nsplit, int Q) {
+  static_assert(LL % 2 == 0, "the fused launch publishes 8-byte list pieces");
+  const int tid = threadIdx.x, lane = tid & 63, uwave = uniform_wave_id();
+  // ---- arrive, wait for the query block's other splits
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list pieces have left (write-through)
+  __syncthreads();                                     // ... and every wave's; the tile ring is free from here on
+  int* wide_rows = reinterpret_cast<int*>(smem);                                        // [8][kWideCap]
+  WgExactSharedN<8>& exact_sh = *reinterpret_cast<WgExactSharedN<8>*>(smem + 8 * kWideCap);
+  int* wg_flag = reinterpret_cast<int*>(smem + 8 * kWideCap) + sizeof(WgExactSharedN<8>) / 4;  // [per_q <= 64] + [1]
+  const int per_q = kWideQPerBlock / nsplit;  // queries of the block this workgroup re-ranks
+  if (tid <= per_q) wg_flag[tid] = 0;
+  __syncthreads();
+  if (tid == 0) {
+    int32_t* c = fa.qb_cnt + fa.parity * kFusedMaxQb + qb;
+    __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    bool ok;
+    while (!(ok = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nsplit) && ++spins < kFusedSpinMax)
+      __builtin_amdgcn_s_sleep(16);
+    wg_flag[per_q] = ok ? 1 : 0;
+  }
+  if (blockIdx.x == 0 && tid == 0) publish_report(fa.rr);  // (reset_counts parked the previous call's counters at the kernel's top)
+  __syncthreads();
+  const bool arrived = wg_flag[per_q] != 0;
+  const int q_base = qb * kWideQPerBlock + sp * per_q;
+  if (arrived) {
+    for (int i = uwave; i < per_q; i += 8) {
+      const int qid = q_base + i;
+      if (qid < Q) rerank_query<LL, 16, true>(fa.rr, qid, lane, &wg_flag[i], wide_rows + uwave * kWideCap);
+    }
+  } else if (tid < per_q && q_base + tid < Q) {
+    wg_flag[tid] = 3;  // the partners never showed up: these queries are ranked exactly, by this workgroup
+    fa.rr.flags[q_base + tid] = 3;
+    atomicAdd(&fa.rr.fb_count[1], 1);
+    atomicAdd(&fa.rr.fb_count[2], 1);
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int i = 0; i < per_q; ++i) {
+    if (!wg_flag[i]) continue;  // workgroup-uniform
+    const int fq = q_base + i;
+    if (tid == 0) atomicAdd(&fa.rr.fb_count[0], 1);
+    wg_exact_scan<8>(fa.rr.db, fa.rr.n_rows, fa.rr.q + (size_t)fq * kD, fa.rr.K, fa.rr.row_offset, fa.rr.out_idx + (size_t)fq * fa.rr.K,
+                     fa.rr.out_score ? fa.rr.out_score + (size_t)fq * fa.rr.K : nullptr, exact_sh);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // rerank (stage 1): one wave per query, 4 queries per 256-thread block.
 // ------------------------------------------------------------------------------------------------
@@ -1580,6 +1670,16 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
   const int zero = first;
   const int half_mode = ctx->eff_mode == 0;
   const bool probing = ctx->search_mode == 0 && ctx->eff_mode == 2;  // standing in for the f16 scan (search_impl)
+  // f32 dot-product error bound: gamma_n * |a||b| with n = 256 terms (+ slack for the MFMA's k order), plus the operand
+  // rounding of the scan that produced the keys: f16 (RNE, both operands) 2^-10 + 2^-21 and 2^-20 for denormal
+  // elements, rounded up to 9.85e-4; split-bf16 2^-16 + 2^-18, rounded up to 2e-5; f32: none
+  const double operand_eps = ctx->eff_mode == 0 ? 9.85e-4 : (ctx->eff_mode == 2 ? 2.0e-5 : 0.0);
+  const float eps_rel = (float)(ctx->eps_scale * ((kD + 8) * 5.9604644775390625e-08 + operand_eps));
+  const float eps_probe = probing ? (float)(ctx->eps_scale * ((kD + 8) * 5.9604644775390625e-08 + 9.85e-4)) : 0.f;
+  const int stat_mode = probing ? 2 : (half_mode ? 1 : 0);
+  const int seq = first ? ++ctx->stat_seq : 0;  // the report card goes out once per call
+  const int defer = ctx->heavy ? 1 : 0;
+  bool fused = false;  // scan + re-rank went out as ONE launch (scanp_kernel<..., FUSED>)
   if constexpr (LL <= 6) {  // paired f16 MFMA scan (default): one 512-thread workgroup per CU, 256 queries each; `nsplit`
     // counts VIRTUAL splits here: the kernel takes physical ones (2 virtual splits per workgroup)
     const dim3 grid((Q + kWideQPerBlock - 1) / kWideQPerBlock * (nsplit / 2));
@@ -1606,15 +1706,60 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
       const int nqb = (Q + kWideQPerBlock - 1) / kWideQPerBlock, ns = nsplit / 2;
       if (xq < 2 || 8 % xq || nqb % xq || ns % (8 / xq) || (nqb * ns) % 8) xq = 1;
     }
+    FusedArgs fa{};
+    if constexpr (LL % 2 == 0 && L == 16) {
+      // one launch for scan + re-rank (option "search_fused"): every query block's workgroups must be co-resident — they are
+      // consecutive in launch order (windows of 64, or runs of `nsplit / 2`), one workgroup per CU
+      const int nqb = (Q + kWideQPerBlock - 1) / kWideQPerBlock, ns = nsplit / 2;
+      if (ctx->search_fused && !prep && ctx->n_lanes <= 1 && nqb <= kFusedMaxQb && kWideQPerBlock % ns == 0 && kWideQPerBlock / ns <= 64) {
+        if (!ctx->n_cu) {
+          int v = 0;
+          if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess) ctx->n_cu = v;
+        }
+        if (!ctx->qb_cnt && hipMalloc(&ctx->qb_cnt, sizeof(int32_t) * 2 * kFusedMaxQb) == hipSuccess)
+          (void)hipMemset(ctx->qb_cnt, 0, sizeof(int32_t) * 2 * kFusedMaxQb);
+        const bool window = ns == 16 && nqb % 4 == 0 && ctx->n_cu >= 128;
+        if (ctx->qb_cnt && (window || ctx->n_cu >= 2 * ns)) {
+          fused = true;
+          xq = window ? -1 : 1;
+          fa.rr = RerankArgs{db, q, Q, K, parts, code_bits, ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, half_mode, out_idx,
+                             out_score, ctx->flags, ctx->fb_count, eps_probe, __builtin_inff(), n_rows, defer, stat_mode, ctx->host_stat_dev,
+                             seq, min(ctx->wide_repair, kWideCap)};
+          fa.qb_cnt = ctx->qb_cnt;
+          fa.parity = (int)(ctx->fused_seq++ & 1u);
+        }
+      }
+    }
     hipEvent_t ea, eb;
-    if (event_pair(ctx, "search_scan", &ea, &eb))  // sampled launch: the dispatch carries its own start / stop events
+    const bool ev = event_pair(ctx, "search_scan", &ea, &eb);  // sampled launch: the dispatch carries its own start / stop events
+    bool launched = false;
+    if constexpr (LL % 2 == 0 && L == 16) {
+      if (fused) {
+        static PerDeviceOnce once_f;
+        if (once_f.need(ctx->device)) {
+          allow_lds(&scanp_kernel<LL, 4, false, true>, (size_t)4 * 2 * kHalfTileBytes);
+          once_f.mark(ctx->device);
+        }
+        if (ev)
+          hipExtLaunchKernelGGL((scanp_kernel<LL, 4, false, true>), grid, dim3(512), (uint32_t)lds, s, ea, eb, 0u, dbh, n_rows, n_tiles, code_bits, q,
+                                (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, ctx->fb_prev, zero, __builtin_inff(), span,
+                                span_seq, xq, fa);
+        else
+          hipLaunchKernelGGL((scanp_kernel<LL, 4, false, true>), grid, dim3(512), lds, s, dbh, n_rows, n_tiles, code_bits, q,
+                             (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, ctx->fb_prev, zero, __builtin_inff(), span,
+                             span_seq, xq, fa);
+        launched = true;
+      }
+    }
+    if (launched) {
+    } else if (ev)
       hipExtLaunchKernelGGL(prep ? (scanp_kernel<LL, 4, true>) : (scanp_kernel<LL, 4, false>), grid, dim3(512), (uint32_t)lds, s, ea, eb, 0u,
                             dbh, n_rows, n_tiles, code_bits, q, (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, ctx->fb_prev, zero,
-                            __builtin_inff(), span, span_seq, xq);
+                            __builtin_inff(), span, span_seq, xq, fa);
     else
       hipLaunchKernelGGL(prep ? (scanp_kernel<LL, 4, true>) : (scanp_kernel<LL, 4, false>), grid, dim3(512), lds, s, dbh, n_rows, n_tiles,
                          code_bits, q, (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, ctx->fb_prev, zero, __builtin_inff(), span,
-                         span_seq, xq);
+                         span_seq, xq, fa);
   } else {
   event_begin(ctx, "search_scan", s);
   if (ctx->eff_mode == 0) {  // f16 MFMA scan, one wave per SIMD (tiny shards, k > 10): 256 queries per workgroup
@@ -1651,15 +1796,11 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
   event_end(ctx, "search_scan", s);
   }
   T2L_HIP(ctx, hipGetLastError());
-  // f32 dot-product error bound: gamma_n * |a||b| with n = 256 terms (+ slack for the MFMA's k order), plus the operand
-  // rounding of the scan that produced the keys: f16 (RNE, both operands) 2^-10 + 2^-21 and 2^-20 for denormal
-  // elements, rounded up to 9.85e-4; split-bf16 2^-16 + 2^-18, rounded up to 2e-5; f32: none
-  const double operand_eps = ctx->eff_mode == 0 ? 9.85e-4 : (ctx->eff_mode == 2 ? 2.0e-5 : 0.0);
-  const float eps_rel = (float)(ctx->eps_scale * ((kD + 8) * 5.9604644775390625e-08 + operand_eps));
-  const float eps_probe = probing ? (float)(ctx->eps_scale * ((kD + 8) * 5.9604644775390625e-08 + 9.85e-4)) : 0.f;
-  const int stat_mode = probing ? 2 : (half_mode ? 1 : 0);
-  const int seq = first ? ++ctx->stat_seq : 0;  // the report card goes out once per call
-  const int defer = ctx->heavy ? 1 : 0;
+  if (fused) {
+    T2L_HIP(ctx, hipGetLastError());
+    if (ctx->heavy) return exact_stage_impl(ctx, db, n_rows, row_offset, q, Q, K, out_idx, out_score, s);
+    return T2L_OK;
+  }
   // Two launches per search. Queries the certificate and the in-wave re-score leave unsettled are ranked exactly by
   // their own re-rank workgroup (wg_exact_scan) — there is no separate fallback launch to pay for when, as usual, there
   // are none. (Heavy mode: they are deferred to the float64 MFMA stage instead, search_exact.hip.)

@@ -97,6 +97,10 @@ struct t2l_ctx {
   int search_auto = 1;
   int pair_ll = 6;       // per-lane list length of the paired scan (5 or 6)
   int wide_repair = 512;  // rows a re-rank wave may re-score in a wide repair before the query goes to an exact scan (0: never)
+  int search_fused = 0;    // 1: scan + re-rank as ONE launch where the shapes allow (search.hip: scanp_kernel<..., FUSED>)
+  int32_t* qb_cnt = nullptr;  // its per-query-block arrival counters [2][4096]
+  unsigned fused_seq = 0;
+  int n_cu = 0;
   int search_prep = 0;   // paired scan: 1 = the queries' f16 fragment plane is built by a pre-pass launch, once per call
   void* qplane = nullptr;  // ... that plane (q_pad x 512 B)
   size_t qplane_cap = 0;
