@@ -188,7 +188,9 @@ int t2l_search_ordered(t2l_ctx* ctx, const float* queries, int32_t n_queries, in
 /* The ONE exchange step of the row-sharded database (new design; the reference is single-device):
  * every rank searches its shard (global ids via row_offset), the per-rank [n_queries,k] results are
  * all-gathered (RCCL over xGMI) into idx/score dev [parts][n_queries][k], and this merges them to the
- * global top-k by (score desc, row id asc). parts * k <= 256. out_score may be NULL. */
+ * global top-k by (score desc, row id asc). parts * k <= 256. out_score may be NULL. No order is assumed inside a part and
+ * invalid entries (id -1) may sit anywhere; row ids are meant to be unique across parts (disjoint row shards) — a (score, id)
+ * pair present in two parts comes out twice. */
 int t2l_merge_topk(t2l_ctx* ctx, const int32_t* idx, const double* score, int32_t parts, int32_t n_queries,
                    int32_t k, int32_t* out_idx, double* out_score, void* stream);
 

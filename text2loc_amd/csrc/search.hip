@@ -1494,28 +1494,39 @@ __global__ __launch_bounds__(256) void merge_kernel(const char* __restrict__ idx
       }
     }
   }
-  // Every shard's list is sorted, so B = the largest K-th entry over the shards is a lower bound of the global K-th best
-  // (that shard alone holds K candidates >= B): only candidates >= B can make the cut — usually K .. 2K of the parts * K —
-  // and only those are ranked. (All scores equal: everybody survives, the loop below is the full all-pairs count.)
-  // (the bound only has to be a LOWER bound: it is taken in float32 rounded towards -inf and reduced over the wave on DPP — the
-  //  float64 butterfly it replaces was six steps of two LDS-crossbar permutes each)
-  float bnd32 = -__builtin_inff();
+  // B = the largest, over the parts that hold K valid entries, of the part's SMALLEST entry is a lower bound of the global K-th best
+  // (that part alone holds K candidates >= B): only candidates >= B can make the cut — usually K .. 2K of the parts * K — and only
+  // those are ranked. No order is assumed inside a part (round 3 took the part's K-th entry, i.e. required best-first lists with the
+  // invalid entries trailing — a precondition the public t2l_merge_topk never stated); sorted inputs give the same bound.
+  // (All scores equal: everybody survives, the loop below is the full all-pairs count.) The bound only has to be a LOWER bound: it is
+  // taken in float32 rounded towards -inf; the per-part minimum goes through LDS (every candidate's f32 image, K reads per part).
+  float* sh_f = reinterpret_cast<float*>(&sh_i[wv][0]);  // (sh_i is written with the survivors' ids only after this phase)
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int c = lane + 64 * e;
-    if (e < ne && c < total && (c % K) == K - 1 && id[e] != INT_MAX) bnd32 = fmaxf(bnd32, __double2float_rd(s[e]));
+    if (e < ne && c < total) sh_f[c] = id[e] != INT_MAX ? __double2float_rd(s[e]) : -__builtin_inff();
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  float bnd32 = -__builtin_inff();
+  for (int p = lane; p < parts; p += 64) {  // a part with an invalid entry has minimum -inf: it does not raise the bound
+    float mn = __builtin_inff();
+    for (int j = 0; j < K; ++j) mn = fminf(mn, sh_f[p * K + j]);
+    bnd32 = fmaxf(bnd32, mn);
   }
   const double bnd = (double)wave_max_f32(bnd32, __builtin_inff());
+  __builtin_amdgcn_wave_barrier();  // (sh_f is dead: sh_i may be overwritten)
   int n_s = 0;
   bool sv[4];
+  int my_pos[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     sv[e] = e < ne && id[e] != INT_MAX && s[e] >= bnd;
     const unsigned long long m = __ballot(sv[e]);
-    const int pos = n_s + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+    my_pos[e] = n_s + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
     if (sv[e]) {
-      sh_s[wv][pos] = s[e];
-      sh_i[wv][pos] = id[e];
+      sh_s[wv][my_pos[e]] = s[e];
+      sh_i[wv][my_pos[e]] = id[e];
     }
     n_s += __popcll(m);
   }
@@ -1527,15 +1538,16 @@ __global__ __launch_bounds__(256) void merge_kernel(const char* __restrict__ idx
     const double os = sh_s[wv][o];
     const int oi = sh_i[wv][o];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (e < ne) rank[e] += (os > s[e] || (os == s[e] && oi < id[e])) ? 1 : 0;  // row ids are unique across shards
+    for (int e = 0; e < 4; ++e)  // (score desc, row id asc, then position: a duplicated (score, id) pair — row ids are meant to be unique
+      if (e < ne)                //  across parts — still gets two different ranks: no slot is written twice, none is left out)
+        rank[e] += (os > s[e] || (os == s[e] && (oi < id[e] || (oi == id[e] && o < my_pos[e])))) ? 1 : 0;
   }
-  // among the survivors the ranks are a permutation of 0..n_s-1, and n_s >= min(K, valid candidates)
-  if (lane < K) {  // default fill for lists with fewer than K valid candidates
+  // the survivors' ranks are a permutation of 0..n_s-1 and n_s >= min(K, valid candidates): slots [n_s, K) — and only those — take
+  // the default fill (no slot has two writers)
+  if (lane >= n_s && lane < K) {
     out_idx[(size_t)qid * K + lane] = -1;
     if (out_score) out_score[(size_t)qid * K + lane] = -__builtin_inf();
   }
-  __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int e = 0; e < 4; ++e)
     if (sv[e] && rank[e] < K) {

@@ -517,7 +517,9 @@ class Engine:
         self._lane_keepalive.clear()
 
     def merge_topk(self, idx: torch.Tensor, score: torch.Tensor):
-        """idx i32[P,Q,K], score f64[P,Q,K] (all-gathered per-shard results) -> (i32[Q,K], f64[Q,K])."""
+        """idx i32[P,Q,K], score f64[P,Q,K] (all-gathered per-shard results) -> (i32[Q,K], f64[Q,K]) by (score desc, id asc). No
+        order is assumed inside a part, -1 entries may sit anywhere; ids are meant to be unique across parts (a duplicated
+        (score, id) pair comes out twice)."""
         P, Q, K = (int(x) for x in idx.shape)
         out_i = torch.empty((Q, K), dtype=torch.int32, device=idx.device)
         out_s = torch.empty((Q, K), dtype=torch.float64, device=idx.device)

@@ -42,6 +42,9 @@ def main(n_draws=200, seed=3):
         tail = np.arange(K)[None, None, :] >= valid[:, :, None]
         ids[tail] = -1
         sc[tail] = -np.inf
+        if it % 3 == 1:  # UNSORTED parts, invalid entries anywhere (the public t2l_merge_topk promises no order inside a part)
+            perm = rng.permuted(np.tile(np.arange(K), (P, Q, 1)), axis=2)
+            ids, sc = np.take_along_axis(ids, perm, axis=2), np.take_along_axis(sc, perm, axis=2)
         ref_i, ref_s = merge_topk_host(ids, sc, K)
         buf, _, _, bb, so = eng.result_block(Q, K, "cuda", parts=P)
         for p in range(P):
@@ -55,6 +58,13 @@ def main(n_draws=200, seed=3):
             if not ok:
                 bad += 1
                 print("MISMATCH", name, "draw", it, "P", P, "K", K, "Q", Q, "kind", kind)
+    # a duplicated (score, id) pair (row ids are meant to be unique across parts): both copies come out, no slot is left unwritten
+    ids = np.array([[[7, 9, 11]], [[7, 20, 21]]], dtype=np.int32)
+    sc = np.array([[[0.9, 0.5, 0.1]], [[0.9, 0.6, 0.2]]])
+    di, ds = eng.merge_topk(torch.from_numpy(ids).cuda(), torch.from_numpy(sc).cuda())
+    if di.cpu().numpy().tolist() != [[7, 7, 20]] or ds.cpu().numpy().tolist() != [[0.9, 0.9, 0.6]]:
+        bad += 1
+        print("MISMATCH duplicate pair", di.cpu().numpy(), ds.cpu().numpy())
     print("draws", n_draws, "mismatches", bad)
     return bad
 
