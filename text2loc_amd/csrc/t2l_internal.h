@@ -1,6 +1,8 @@
 // Internal declarations shared by the HIP translation units of libt2l.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
@@ -220,10 +222,10 @@ void free_text_head(t2l_ctx* ctx);
 // loss.hip
 // hipFuncSetAttribute applies to the CURRENT device's instance of a kernel, and one process may hold contexts on several GPUs: a call
 // site's "attribute set" flag is one bit per device (the callers are serialised per context, as everything in this library).
-struct PerDeviceOnce {
-  uint64_t done = 0;
-  bool need(int dev) const { return !((done >> (dev & 63)) & 1); }
-  void mark(int dev) { done |= 1ull << (dev & 63); }
+struct PerDeviceOnce {  // (static instances are shared by the contexts of every device and thread: atomic bits; a lost race repeats
+  std::atomic<uint64_t> done{0};  //  an idempotent hipFuncSetAttribute)
+  bool need(int dev) const { return !((done.load(std::memory_order_acquire) >> (dev & 63)) & 1); }
+  void mark(int dev) { done.fetch_or(1ull << (dev & 63), std::memory_order_release); }
 };
 
 int loss_impl(t2l_ctx* ctx, const float* a, const float* p, int B, float temp, float* loss, float* ga, float* gp,

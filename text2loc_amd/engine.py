@@ -465,7 +465,7 @@ class Engine:
         m = m.to(dev, torch.float32).contiguous()
         v = v.to(dev, torch.float32).contiguous()
         self._check(self.lib.t2l_adam_state(self._h, 1, m.data_ptr(), v.data_ptr(), C.byref(st), C.byref(n), _stream_ptr(self.device)))
-        torch.cuda.current_stream().synchronize()  # m, v may be temporaries
+        torch.cuda.current_stream(self.device).synchronize()  # m, v may be temporaries (the ENGINE's device: not the caller's current one)
 
     # ------------------------------------------------------------------ database + search
     def db_set(self, emb: torch.Tensor, row_offset: int = 0, owner=None):

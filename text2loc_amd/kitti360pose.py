@@ -30,6 +30,7 @@ import pickle
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
+import torch.utils.data
 
 from . import packing
 
@@ -217,6 +218,7 @@ class Kitti360PoseDataset:
         self.shuffle_hints, self.flip_poses = bool(shuffle_hints), bool(flip_poses)
         self._aug = aug_rng if aug_rng is not None else np.random
         self._epoch_draw = 0
+        self._epoch = 0
         self.all_cells: List[CellRecord] = []
         self.all_poses: List[PoseRecord] = []
         self._pose_scene: List[str] = []
@@ -250,13 +252,21 @@ class Kitti360PoseDataset:
         pts = None
         if self._points is not None:
             if self._transform == "rotate_normalize":  # a fresh rotation / draw every time an item is fetched
+                # keyed on (seed, cell, epoch, DataLoader worker, per-process counter): a worker process starts from a COPY of the
+                # parent's counter every epoch, so the counter alone repeated the draws across epochs and collided across workers
                 self._epoch_draw += 1
-                rng = np.random.default_rng([self._seed, self._cell_row[cell.id], self._epoch_draw])
+                wi = torch.utils.data.get_worker_info()
+                rng = np.random.default_rng([self._seed, self._cell_row[cell.id], self._epoch, 0 if wi is None else wi.id + 1, self._epoch_draw])
             else:
                 rng = np.random.default_rng([self._seed, self._cell_row[cell.id]])
             pts = packing.sample_object_points([cell.objects], 256, rng, transform=self._transform)[0]
         return {"poses": pose, "cells": cell, "objects": cell.objects, "object_points": pts, "texts": text,
                 "cell_ids": pose.cell_id, "scene_names": self._pose_scene[idx], "debug_hint_descriptions": hints}
+
+    def set_epoch(self, epoch: int):
+        """Call once per epoch (as DistributedSampler.set_epoch): part of the key of the augmentation draws under
+        transform="rotate_normalize" (DataLoader workers restart from a copy of this object every epoch)."""
+        self._epoch = int(epoch)
 
     def get_known_classes(self):
         return list(packing.KNOWN_CLASS)

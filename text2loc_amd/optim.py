@@ -83,15 +83,21 @@ class Adam(torch.optim.Optimizer):
         flat = self._model.train_flat_grad()
         if flat is not None:
             bufs.append((flat, None))
-        rest = [p for g in self.param_groups[1:] for p in g["params"] if p.grad is not None]
+        # a rank-INDEPENDENT list: every torch-side parameter, a missing gradient (a branch this rank's batch skipped, set_to_none) as
+        # zeros — ranks that disagreed on which gradients exist would issue all_reduces of different sizes (a hang, or silent garbage)
+        rest = [p for g in self.param_groups[1:] for p in g["params"]]
         if rest:
-            bufs.append((torch.cat([p.grad.reshape(-1) for p in rest]), rest))
+            bufs.append((torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in rest]), rest))
         for buf, params in bufs:
             all_reduce_flat(buf, self._group, mean=self._grad_reduce == "mean")
             if params is not None:
                 off = 0
                 for p in params:
-                    p.grad.copy_(buf[off:off + p.numel()].view_as(p.grad))
+                    g = buf[off:off + p.numel()].view_as(p)
+                    if p.grad is None:
+                        p.grad = g.clone()  # (another rank may have contributed: every rank steps the same set)
+                    else:
+                        p.grad.copy_(g)
                     off += p.numel()
 
     @torch.no_grad()
@@ -117,7 +123,9 @@ class Adam(torch.optim.Optimizer):
               "torch": self._torch.state_dict() if self._torch is not None else None, "t2l_engine": None}
         if self._model.device.type == "cuda":
             m, v, step = self._model.train_engine().adam_state()
-            sd["t2l_engine"] = {"exp_avg": m.cpu(), "exp_avg_sq": v.cpu(), "step": step}
+            # the engine keeps one bias-correction step for the object branch and one for the PointNet++ backbone (which only steps
+            # when its backward ran): two explicit fields (round 3 leaked the packed word step | step_pn << 32 into "step")
+            sd["t2l_engine"] = {"exp_avg": m.cpu(), "exp_avg_sq": v.cpu(), "step": int(step) & 0xFFFFFFFF, "step_pn": int(step) >> 32}
         return sd
 
     def load_state_dict(self, sd):
@@ -127,4 +135,6 @@ class Adam(torch.optim.Optimizer):
             self._torch.load_state_dict(sd["torch"])
         e = sd.get("t2l_engine")
         if e is not None:
-            self._model.train_engine().set_adam_state(e["exp_avg"], e["exp_avg_sq"], int(e["step"]))
+            step = int(e["step"])
+            step_pn = int(e["step_pn"]) if "step_pn" in e else (step >> 32 if step >> 32 else step & 0xFFFFFFFF)  # older checkpoints:
+            self._model.train_engine().set_adam_state(e["exp_avg"], e["exp_avg_sq"], (step & 0xFFFFFFFF) | (step_pn << 32))  # packed, or one step for both
