@@ -57,14 +57,55 @@ def cpu_baseline(db, qs, budget_s=12.0):
             "sample": f"{done} queries x N={len(db)} (float64 C@t + full argsort per query, numpy) in {dt:.1f}s"}
 
 
-PMC_SOURCE = ("profiles/pmc_latest.json = profiles/r03d_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-              "tools/profile.sh r03d, separate runs as the MI355X guide prescribes; not measured in this run)")
+PMC_SOURCE = ("profiles/pmc_latest.json = the latest committed profiles/r*_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+              "tools/profile.sh, separate runs as the MI355X guide prescribes; not measured in this run)")
+
+
+_PMC_LIVE = {}
+
+
+def measure_traffic_in_run(kernel_prefix="t2l::scanp_kernel"):
+    """HBM-side bytes per launch of the dominant kernel measured IN THIS RUN: two extra `rocprofv3 --kernel-trace --pmc` passes
+    (FETCH_SIZE, WRITE_SIZE: separate passes, as MI355X_MICROARCH.md prescribes; no trace domain beside the counters) of this
+    very script in --quick form, as subprocesses outside the timed region. 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes (the guide's
+    gfx950 correction). Returns None (and the committed profile is used) when rocprofv3 is not on PATH or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if os.environ.get("T2L_BENCH_CHILD") or not shutil.which("rocprofv3"):
+        return None
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="t2l_pmc_")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-secondary", "--no-pipelined", "--quick"]
+        try:
+            subprocess.run(cmd, env=dict(os.environ, T2L_BENCH_CHILD="1", TMPDIR="/tmp"), cwd="/tmp", timeout=240, capture_output=True, check=True)
+            acc = []
+            for f in glob.glob(os.path.join(d, "**", "p_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter and r["Kernel_Name"].replace("void ", "").startswith(kernel_prefix):
+                        acc.append(float(r["Counter_Value"]))
+            if not acc:
+                return None
+            vals[counter] = (sum(acc) / len(acc), len(acc))
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"hbm_bytes_per_launch": 2 * vals["FETCH_SIZE"][0] * 1024 + vals["WRITE_SIZE"][0] * 1024, "launches": vals["FETCH_SIZE"][1],
+            "FETCH_SIZE_KiB": vals["FETCH_SIZE"][0], "WRITE_SIZE_KiB": vals["WRITE_SIZE"][0]}
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_latest.json, written
     by tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, gfx950 correction per MI355X_MICROARCH.md).
     None when no profile has been committed for this kernel name."""
+    if kernel in _PMC_LIVE:
+        return _PMC_LIVE[kernel]["hbm_bytes_per_launch"]
     try:
         d = json.load(open(os.path.join(REPO, "profiles", "pmc_latest.json")))
         return d[kernel]["hbm_bytes_per_launch"]
@@ -481,6 +522,23 @@ def secondary_measurements(eng):
             eng.search(dq, TOPK, out=o)
             torch.cuda.synchronize()
         lat[f"q{qn}_us_per_call_synchronized"] = (time.perf_counter() - t0) / (20 if _QUICK else 200) * 1e6  # host-visible round trip of one call
+    # the same single-query searches issued from C (t2l_search_many: 1,000 independent searches per call): what a search costs the
+    # DEVICE back to back, without the ~14 us a Python ctypes call costs the host
+    for qn in (1, 64):
+        nb = 50 if _QUICK else 1000
+        dqm = torch.from_numpy(np.ascontiguousarray(np.tile(_QS[:qn][None], (nb, 1, 1)))).cuda()
+        om = (torch.empty((nb, qn, TOPK), dtype=torch.int32, device="cuda"), torch.empty((nb, qn, TOPK), dtype=torch.float64, device="cuda"))
+        for _ in range(2):
+            eng.search_many(dqm, TOPK, out=om)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 2 if _QUICK else 5
+        for _ in range(reps):
+            eng.search_many(dqm, TOPK, out=om)
+        torch.cuda.synchronize()
+        lat[f"q{qn}_us_per_call_issued_from_c"] = (time.perf_counter() - t0) / (reps * nb) * 1e6
+        one_i, _ = eng.search(dqm[0].contiguous(), TOPK)
+        lat[f"q{qn}_search_many_equals_search"] = bool(torch.equal(om[0][nb - 1], one_i))
     eng.set_option("profile_events", 1)
     out["search_latency"] = lat
     # HBM-streaming regime (SURVEY.md §8d config 2'): 32 queries against N = 2,097,152 rows (1 GiB of f16 DB plane,
@@ -947,8 +1005,11 @@ def roofline(kname, peak, mult, flops, time_ms, lanes, scan_ms, scan_n, span_ms,
     out = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
            "executed": achieved * mult, "frac_executed": achieved * mult / peak,
            "time_basis": ("timed-region wall clock per step (pipelined: kernel spans overlap)" if lanes > 1
-                          else "scan kernel average duration, HIP events over the timed region"),
-           "traffic": pmc_traffic("t2l::" + kname), "traffic_source": PMC_SOURCE,
+                          else "scan kernel average duration, HIP events on sampled launches of the timed region and of the 64 steps of the same loop behind it"),
+           "traffic": pmc_traffic("t2l::" + kname),
+           "traffic_source": ("measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --quick` as subprocesses "
+                              "outside the timed region, 2 x FETCH_SIZE + WRITE_SIZE" if ("t2l::" + kname) in _PMC_LIVE else PMC_SOURCE),
+           "traffic_detail": _PMC_LIVE.get("t2l::" + kname),
            "kernel_ms": scan_ms, "launches_timed": scan_n,
            "kernel_ms_in_kernel_span": span_ms, "launches_timed_in_kernel_span": span_n,
            # sum of the launch's workgroup durations / grid (in-kernel stamps, every launch): the GPU time a launch used
@@ -1135,6 +1196,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     scan_ms, scan_n = eng.kernel_stats("search_scan")
+    # more HIP-event samples of the same kernel than a K = 20 region can carry without paying for them (an event pair costs the stream
+    # ~6 us): the SAME loop continues right behind the timed region for 64 steps with every 4th launch bracketed -> 16 samples
+    scan_post_ms, scan_post_n = None, 0
+    scan_region_ms, scan_region_n = scan_ms, scan_n
+    if world == 1 and lanes == 1:
+        eng.set_option("profile_events", 4)
+        for i in range(16 if args.quick else 64):
+            step(args.steps + i)
+        torch.cuda.synchronize()
+        scan_post_ms, scan_post_n = eng.kernel_stats("search_scan")
+        if scan_post_n:  # the roofline's basis: every bracketed launch of this loop — those inside the timed region and the 16 behind it
+            scan_region_ms, scan_region_n = scan_ms, scan_n
+            scan_ms = (scan_ms * scan_n + scan_post_ms * scan_post_n) / max(1, scan_n + scan_post_n)
+            scan_n = scan_n + scan_post_n
     eng.set_option("profile_rerank", 1)
     span_ms, span_n = eng.kernel_stats("search_scan_span")
     busy_ms, busy_n = eng.kernel_stats("search_scan_busy")
@@ -1347,6 +1422,10 @@ def main():
             kname, peak, dtype, mult = "scanw_kernel<8, 4>", BF16_MFMA_PEAK_TFLOPS, "bf16x3", 3
         else:
             kname, peak, dtype, mult = "scanp_kernel<6, 4, false>", BF16_MFMA_PEAK_TFLOPS, "f16", 1
+        if world == 1 and args.mode == 0 and not args.quick and not os.environ.get("T2L_BENCH_CHILD"):
+            live = measure_traffic_in_run("t2l::scanp_kernel")  # (outside every timed region; ~40 s; None without rocprofv3)
+            if live is not None:
+                _PMC_LIVE["t2l::" + kname] = live
         out = {
             "metric": "coarse-retrieval queries/sec over 11k-cell DB, embed_dim=256; top-1/3/5 recall parity",
             "value": N_QUERIES * args.steps / elapsed,
@@ -1378,6 +1457,10 @@ def main():
                                  busy_ms, busy_n,
                                  None if serial_ms is None else (serial_scan_ms, serial_span_ms, serial_busy_ms, serial_ms)),
             "kernels_ms": {"search_scan": scan_ms, "search_rerank": rerank_ms},  # the whole step is these two launches
+            "scan_kernel_event_samples": {"inside_the_timed_region": {"kernel_ms": scan_region_ms, "launches_timed": scan_region_n},
+                                          "behind_the_timed_region": {"kernel_ms": scan_post_ms, "launches_timed": scan_post_n},
+                                          "note": "roofline.kernel_ms averages both sets: an event pair costs the stream ~6 us, so the K = 20 "
+                                                  "region carries 3 of them and the same loop continues for 64 steps with every 4th launch bracketed"},
             # the same steps stream-ordered (lanes = 1): what one call costs when the next one waits for it
             "stream_ordered": None if serial_ms is None else {"ms_per_step": serial_ms, "queries_per_s": N_QUERIES / (serial_ms * 1e-3)},
             "steady_state_400_steps": steady,

@@ -171,6 +171,12 @@ int64_t t2l_db_rows(const t2l_ctx* ctx);
  * whose certificate fails are re-done by an exact float64 scan on the device (no host round trip). */
 int t2l_search(t2l_ctx* ctx, const float* queries, int32_t n_queries, int32_t k, int32_t* out_idx,
                double* out_score, void* stream);
+/* n_batches independent searches of n_queries queries each, issued back to back from C: queries dev f32[n_batches, n_queries, 256],
+ * out_idx dev i32[n_batches, n_queries, k], out_score dev f64[...] or NULL. Exactly t2l_search called n_batches times (the
+ * reference's loop answers query after query, training/coarse.py:119-125) without the caller's per-call binding cost — a Python
+ * ctypes call costs ~14 us, twice the device time of a single-query search. */
+int t2l_search_many(t2l_ctx* ctx, const float* queries, int32_t n_batches, int32_t n_queries, int32_t k, int32_t* out_idx,
+                    double* out_score, void* stream);
 /* Pipelined searches. With t2l_set_option("search_lanes", n), 2 <= n <= 4, consecutive t2l_search calls — independent jobs
  * in the reference's loop too (training/coarse.py:119-125 runs query after query) — run their scan -> re-rank chains on n
  * internal streams, round-robin, each with its own scratch: the next call's scan overlaps the previous call's re-rank and no

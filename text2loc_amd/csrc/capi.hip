@@ -230,6 +230,23 @@ int t2l_search(t2l_ctx* ctx, const float* queries, int32_t n_queries, int32_t k,
   return search_lanes_impl(ctx, queries, n_queries, k, out_idx, out_score, (hipStream_t)stream);
 }
 
+int t2l_search_many(t2l_ctx* ctx, const float* queries, int32_t n_batches, int32_t n_queries, int32_t k, int32_t* out_idx, double* out_score,
+                    void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  if (n_batches < 0 || n_queries < 0 || k < 1 || k > T2L_MAX_TOPK)
+    return fail(ctx, T2L_EINVAL, "t2l_search_many: need n_batches >= 0, n_queries >= 0 and 1 <= k <= T2L_MAX_TOPK");
+  if (n_batches == 0 || n_queries == 0) return T2L_OK;
+  if (!queries || !out_idx) return fail(ctx, T2L_EINVAL, "t2l_search_many: null buffer");
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  for (int32_t b = 0; b < n_batches; ++b) {  // independent searches, enqueued back to back from C (no per-call binding cost)
+    const size_t o = (size_t)b * n_queries;
+    const int rc = search_lanes_impl(ctx, queries + o * kD, n_queries, k, out_idx + o * k, out_score ? out_score + o * k : nullptr,
+                                     (hipStream_t)stream);
+    if (rc != T2L_OK) return rc;
+  }
+  return T2L_OK;
+}
+
 int t2l_search_ordered(t2l_ctx* ctx, const float* queries, int32_t n_queries, int32_t k, int32_t* out_idx, double* out_score,
                        void* stream) {
   if (!ctx) return T2L_EINVAL;

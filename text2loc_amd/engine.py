@@ -59,6 +59,7 @@ EXPORTS = {
     "t2l_db_rows": (C.c_int64, [C.c_void_p]),
     "t2l_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_search_join": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "t2l_search_many": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_search_ordered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_merge_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
@@ -566,6 +567,19 @@ class Engine:
         self._check(self.lib.t2l_merge_gathered(self._h, self._ptr(blocks, torch.uint8, "blocks"), int(block_bytes), int(score_offset),
                                                 int(parts), int(Q), int(k), out_i.data_ptr(), out_s.data_ptr(), _stream_ptr(self.device)))
         return out_i, out_s
+
+    def search_many(self, queries: torch.Tensor, k: int, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """queries f32[n_batches, Q, 256]: n_batches independent searches of Q queries each (t2l_search_many: the loop runs in C).
+        Returns (idx i32[n_batches, Q, k], scores f64[n_batches, Q, k])."""
+        if queries.dim() != 3 or queries.shape[2] != EMBED_DIM:
+            raise T2LError(f"search_many: expected [n_batches, Q, {EMBED_DIM}], got {tuple(queries.shape)}")
+        nb, Q = int(queries.shape[0]), int(queries.shape[1])
+        if out is None:
+            out = (torch.empty((nb, Q, k), dtype=torch.int32, device=queries.device),
+                   torch.empty((nb, Q, k), dtype=torch.float64, device=queries.device))
+        self._check(self.lib.t2l_search_many(self._h, self._ptr(queries, torch.float32, "queries"), nb, Q, int(k), out[0].data_ptr(),
+                                             out[1].data_ptr(), _stream_ptr(self.device)))
+        return out
 
     def search_fallbacks(self) -> int:
         c = C.c_int32(0)
