@@ -232,3 +232,63 @@ def test_gathered_loss_and_summed_gradients_equal_the_single_process_step(world,
         assert np.abs(summed - ref).max() < 1e-12                # sum of the per-rank gradients == the full-batch gradient
         assert np.abs(local - ref).max() > 1e-6                  # ... which no rank has by itself
     assert np.abs(sum(r[2] for r in res) - ref).max() < 1e-12
+
+
+# ---- the layout policy (sharded.choose_layout / AutoSearcher) ---------------------------------------------------------------------
+def test_choose_layout_replicates_what_fits_and_row_shards_beyond():
+    from text2loc_amd.sharded import ROW_BYTES_RESIDENT, choose_layout
+
+    hbm = 288 << 30
+    assert choose_layout(11259, hbm) == "query"              # KITTI360Pose: 29 MB resident
+    assert choose_layout(20_000_000, hbm) == "query"         # 51 GB: still a sixth of one GPU
+    assert choose_layout(40_000_000, hbm) == "row"           # 102 GB: shard it
+    edge = int(0.25 * hbm) // ROW_BYTES_RESIDENT
+    assert choose_layout(edge, hbm) == "query" and choose_layout(edge + 1, hbm) == "row"
+
+
+def _aworker(rank, world, port, layout, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from text2loc_amd.sharded import AutoSearcher
+
+    db, qs, _ = synth.make_retrieval_problem(257, 21, seed=8, noise=2.0)
+    K = 5
+    state = {}
+
+    def search_fn(q, k):  # stands in for the HIP search over whatever rows this rank holds
+        lo, hi = state.get("lo", 0), state.get("hi", len(db))
+        i, s = O.retrieve_topk(db[lo:hi], q.numpy(), k)
+        return torch.from_numpy((i + lo).astype(np.int32)), torch.from_numpy(s)
+
+    def merge_fn(i, s):
+        a, b = merge_topk_host(i.numpy(), s.numpy(), K)
+        return torch.from_numpy(a), torch.from_numpy(b)
+
+    srch = AutoSearcher(engine=None, layout=layout, search_fn=search_fn, merge_fn=merge_fn)
+    lo, hi = srch.set_db(torch.from_numpy(db))
+    if srch.layout == "row":
+        state["lo"], state["hi"] = lo, hi
+    idx, sc = srch.search(torch.from_numpy(qs), K)
+    ridx, rsc = O.retrieve_topk(db, qs, K)
+    ok = np.array_equal(np.asarray(idx), ridx) and np.abs(np.asarray(sc) - rsc).max() < 1e-12
+    out_q.put((rank, bool(ok), srch.layout))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("layout,expect", [("auto", "query"), ("row", "row"), ("query", "query")])
+def test_auto_searcher_under_gloo(layout, expect):
+    """every rank hands over the same full database and queries and gets the complete result, in either layout"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_aworker, args=(r, world, port, layout, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok and lay == expect for _, ok, lay in res), res

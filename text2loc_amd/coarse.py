@@ -63,6 +63,18 @@ def _engine_retrieve(model) -> Callable:
         if k > MAX_TOPK:
             raise ValueError(f"max(top_k)={k} exceeds the engine's T2L_MAX_TOPK={MAX_TOPK} (include/t2l.h)")
         eng = model.engine()
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # N ranks (one per GPU): the layout sharded.choose_layout picks — the database replicated and the QUERIES split while it
+            # fits a quarter of one GPU's HBM (KITTI360Pose: 11 k rows of ~28 M), row shards + top-k merge beyond; every rank gets
+            # the complete result
+            from .sharded import AutoSearcher
+
+            srch = AutoSearcher(eng, layout=str(getattr(model.args, "shard_layout", "auto")))
+            srch.set_db(cell_enc.contiguous())
+            idx, sc = srch.search(text_enc.contiguous(), k)
+            return idx.cpu().numpy().astype(np.int64), sc.cpu().numpy()
         eng.db_set(cell_enc.contiguous())
         idx, sc = eng.search(text_enc.contiguous(), k)
         return idx.cpu().numpy().astype(np.int64), sc.cpu().numpy()

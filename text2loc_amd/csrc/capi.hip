@@ -107,7 +107,7 @@ void t2l_destroy(t2l_ctx* ctx) {
   free_fine(ctx);
   free_text_head(ctx);
   for (void* p : {(void*)ctx->db, (void*)ctx->db_split, (void*)ctx->db_half, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
-                  (void*)ctx->seg_score, (void*)ctx->flags, (void*)(ctx->fb_count < ctx->fb_prev ? ctx->fb_count : ctx->fb_prev), (void*)ctx->qb_cnt, ctx->reduce_ws, ctx->loss_ws, ctx->qplane, (void*)ctx->scan_span})
+                  (void*)ctx->seg_score, (void*)ctx->flags, (void*)(ctx->fb_count < ctx->fb_prev ? ctx->fb_count : ctx->fb_prev), (void*)ctx->qb_cnt, ctx->fast_ws, (void*)ctx->fast_zero, ctx->reduce_ws, ctx->loss_ws, ctx->qplane, (void*)ctx->scan_span})
     if (p) (void)hipFree(p);
   delete[] ctx->span_grid;
   if (ctx->host_stat) (void)hipHostFree(ctx->host_stat);
@@ -516,6 +516,10 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
   } else if (!strcmp(name, "search_xcd_qgroups")) {
     if (value != 1 && value != 2 && value != 4 && value != 8) return fail(ctx, T2L_EINVAL, "search_xcd_qgroups must be 1, 2, 4 or 8");
     ctx->xcd_qgroups = (int)value;
+  } else if (!strcmp(name, "fast_gemm_ksplit")) {
+    ctx->fast_gemm_ksplit = value != 0;
+  } else if (!strcmp(name, "text_train_fast")) {
+    ctx->text_train_fast = value != 0;
   } else if (!strcmp(name, "text_train_bf16")) {
     if (value != 0 && value != 1 && value != 2) return fail(ctx, T2L_EINVAL, "text_train_bf16: 0 (f32), 1 (bf16) or 2 (split-bf16)");
     ctx->text_train_bf16 = (int)value;

@@ -84,6 +84,9 @@ struct t2l_ctx {
   void* fine = nullptr;          // t2l::FineWeights (fine.hip)
   void* text_head = nullptr;     // t2l::th::Weights (text_head.hip)
   void* text_train = nullptr;    // t2l::TextTrain (train.hip): the text head's training state
+  void* fast_ws = nullptr;       // operand planes of fast_gemm (text_head.hip)
+  size_t fast_ws_cap = 0;
+  float* fast_zero = nullptr;
   int text_head_rows = 0;        // token rows per pass of the text head (0 = default 16,384)
   int pn_self_loops = 1;         // PyG PointConv add_self_loops quirk on the bipartite batch (oracle/t2l_oracle_pointnet.py)
   // options
@@ -110,6 +113,8 @@ struct t2l_ctx {
                          // 4 = a quarter of the queries and half of the splits: -1.3 us of scan span at Q = 4096 x N = 11,259, measured)
   int search_pair = 1;   // mode 0: 1 = the paired scan (two waves per SIMD, scanp_kernel), 0 = scanh_kernel (one wave per SIMD)
   int train_bf16 = 0;       // 1: the training step's GEMMs round their operands to bf16 (one bf16 MFMA per 16-step); 2: split-bf16 (three)
+  int fast_gemm_ksplit = 1;  // cut the contraction of few-tile training products into jobs (partial slabs + one reduction pass)
+  int text_train_fast = 1;  // its Linear products on the tiled bf16-plane GEMM of text_head.hip (0: the object branch's tile-per-workgroup products)
   int text_train_bf16 = 2;  // the same for the TEXT head's training GEMMs (d_model 1024: 466 GFLOP per step at B = 64): default split-bf16 —
                             // f32-class products (<= 2^-16 + 2^-18 relative, f32 accumulation, f32 exponent range) at 1.8x the f32 MFMA path's speed
   int train_xcd_map = 0;      // 1 = the training step's tile GEMMs take their blocks in XCD bands (gemm_f32.h; measured slower in f32)
@@ -217,6 +222,9 @@ void free_fine(t2l_ctx* ctx);
 // text_head.hip
 int text_head_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const char* prefix);
 int text_head_impl(t2l_ctx* ctx, const float* hidden, int n_sentences, int n_tokens, float* out, int32_t* overflow, hipStream_t s);
+int fast_gemm(t2l_ctx* ctx, const float* A, bool a_trans, const float* B, bool b_trans, const float* bias, float* out, int Mo, int No, int Kc,
+              int relu, int accumulate, bool single, hipStream_t s, float* a_colsum = nullptr);  // text_head.hip: the tiled bf16-plane GEMM for training
+void fast_colsum(const float* a, int M, int N, float* out, hipStream_t s);
 int text_inter_impl(t2l_ctx* ctx, const float* sent, int n_desc, int S, float* out, int32_t* overflow, hipStream_t s);
 void free_text_head(t2l_ctx* ctx);
 // loss.hip

@@ -120,6 +120,10 @@ struct GemmArgs {
   void *out0, *out1;     // T32 f32 | T16 hi, lo | row-major f32
   int* flag;             // overflow flag (kEpiReluT16)
   int m_tiles, n_tiles, K, N, M, n_real;  // N = output columns of the tiled layouts (= 256 n_tiles), M / n_real: row-major bounds
+  int relu = 0, accumulate = 0;           // kEpiRowMajor only: out = max(.., 0); accumulate 1: out += (dW accumulates, dX adds to a residual
+                                          // path); 2: the same with float atomics (several workgroups per output tile: ksplit > 1)
+  int ksplit = 1;                         // kEpiRowMajor only: the contraction of every output tile is cut into ksplit jobs (few-tile products —
+                                          // dW [N][K] over thousands of rows — would otherwise leave most CUs idle); needs accumulate = 2
 };
 
 template <int N>
@@ -131,7 +135,10 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // different CUs drift apart instead of hitting HBM together (measured before: 85 us per 64-step tile against 51 us of MFMA time).
 // vmcnt counts the epilogue's stores too (in-order retirement): for the three steps behind an epilogue the wait allows them
 // to stay in flight (they are younger than the awaited pieces), from the fourth step on they must have retired.
-template <int EPI, bool SINGLE>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// BF16 (the training GEMMs, train.hip -> fast_gemm): the planes hold bf16 hi / lo halves (f32's exponent range: gradients need no
+// scaling) and the products run on v_mfma_f32_32x32x16_bf16 — same shape, same rate, same plane layout as the f16 form.
+template <int EPI, bool SINGLE, bool BF16 = false>
 __global__ __launch_bounds__(512, 1) void th_gemm_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PPW = SINGLE ? 2 : 4;  // LDS-DMA pieces (1 KiB) per wave and k-step
@@ -142,11 +149,12 @@ __global__ __launch_bounds__(512, 1) void th_gemm_kernel(const GemmArgs p) {
   // virtual block vb -> tile: the n tiles of one m tile run back to back on ONE XCD (vb % 8 = blockIdx % 8: the grid is a
   // multiple of 8), so the X rows of an m tile are fetched from HBM once and every XCD's L2 keeps the weights
   const int xcd = blockIdx.x & 7, grid = gridDim.x;
-  const int K = p.K, KT = K >> 4;
-  const int n_vb = (p.m_tiles + 7) / 8 * 8 * p.n_tiles;
-  int n_my = 0;  // this workgroup's tiles: a prefix of vb = blockIdx + i * grid (an m tile beyond m_tiles ends the list)
+  const int ks = EPI == kEpiRowMajor ? max(1, p.ksplit) : 1;
+  const int K = p.K, KT = (K >> 4) / ks;  // k-steps of one job (a tile, or a ksplit-th of one)
+  const int n_vb = (p.m_tiles + 7) / 8 * 8 * p.n_tiles * ks;
+  int n_my = 0;  // this workgroup's jobs: a prefix of vb = blockIdx + i * grid (an m tile beyond m_tiles ends the list)
   for (int vb = blockIdx.x; vb < n_vb; vb += grid) {
-    if (((vb >> 3) / p.n_tiles) * 8 + xcd >= p.m_tiles) break;
+    if (((vb >> 3) / (p.n_tiles * ks)) * 8 + xcd >= p.m_tiles) break;
     ++n_my;
   }
   if (n_my == 0) return;
@@ -167,8 +175,9 @@ __global__ __launch_bounds__(512, 1) void th_gemm_kernel(const GemmArgs p) {
   const bool is_w = SINGLE ? plane == 0 : plane < 2;
   auto tile_src = [&](int i) {
     const int seq = (blockIdx.x + i * grid) >> 3;
-    const int t = is_w ? seq % p.n_tiles : (seq / p.n_tiles) * 8 + xcd;
-    return plane_base + ((size_t)t * 8 + rt0) * rt_stride;
+    const int kp = seq % ks, t2 = seq / ks;
+    const int t = is_w ? t2 % p.n_tiles : (t2 / p.n_tiles) * 8 + xcd;
+    return plane_base + ((size_t)t * 8 + rt0) * rt_stride + (size_t)kp * KT * 1024;
   };
   unsigned voff[PPW];
 #pragma unroll
@@ -229,7 +238,8 @@ __global__ __launch_bounds__(512, 1) void th_gemm_kernel(const GemmArgs p) {
   unsigned g = 0;
   for (int ti = 0; ti < n_my; ++ti) {
     const int seq = (blockIdx.x + ti * grid) >> 3;
-    const int mt_idx = (seq / p.n_tiles) * 8 + xcd, nt_idx = seq % p.n_tiles;
+    const int kpart = seq % ks, seq2 = seq / ks;
+    const int mt_idx = (seq2 / p.n_tiles) * 8 + xcd, nt_idx = seq2 % p.n_tiles;
     h3_f32x16 acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -260,10 +270,18 @@ __global__ __launch_bounds__(512, 1) void th_gemm_kernel(const GemmArgs p) {
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
+          if constexpr (BF16) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.wh[a]), __builtin_bit_cast(bf16x8, cur.xh[b]), acc[a][b], 0, 0, 0);
+            if constexpr (!SINGLE) {
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.wh[a]), __builtin_bit_cast(bf16x8, cur.xl[b]), acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.wl[a]), __builtin_bit_cast(bf16x8, cur.xh[b]), acc[a][b], 0, 0, 0);
+            }
+          } else {
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wh[a], cur.xh[b], acc[a][b], 0, 0, 0);
           if constexpr (!SINGLE) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wh[a], cur.xl[b], acc[a][b], 0, 0, 0);
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wl[a], cur.xh[b], acc[a][b], 0, 0, 0);
+          }
           }
         }
       ++g;
@@ -307,7 +325,7 @@ __global__ __launch_bounds__(512, 1) void th_gemm_kernel(const GemmArgs p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n0 = n_base + 8 * g + 4 * kh;
-        const f32x4 bv = bias_v[g];
+        const f32x4 bv = (kpart == 0 && p.accumulate != 3) ? bias_v[g] : f32x4{0.f, 0.f, 0.f, 0.f};  // (first k-part only; slabs: the reduction adds it)
         f32x4 v = {acc[a][b][4 * g] + bv[0], acc[a][b][4 * g + 1] + bv[1], acc[a][b][4 * g + 2] + bv[2], acc[a][b][4 * g + 3] + bv[3]};
         if constexpr (EPI == kEpiT32) {
           *reinterpret_cast<f32x4*>((float*)p.out0 + t32_index(m, n0, p.N)) = v;
@@ -323,7 +341,19 @@ __global__ __launch_bounds__(512, 1) void th_gemm_kernel(const GemmArgs p) {
           *reinterpret_cast<f16x4*>((_Float16*)p.out0 + o) = hi;
           if constexpr (!SINGLE) *reinterpret_cast<f16x4*>((_Float16*)p.out1 + o) = lo;
         } else {  // row-major f32 [M][n_real]
-          if (m < p.M && n0 < p.n_real) *reinterpret_cast<f32x4*>((float*)p.out0 + (size_t)m * p.n_real + n0) = v;
+          if (m < p.M && n0 < p.n_real) {
+            f32x4* dst = reinterpret_cast<f32x4*>((float*)p.out0 + (size_t)m * p.n_real + n0);
+            if (p.relu) v = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+            if (p.accumulate == 3) {  // this k-part's slab of the partial-sum scratch (th_reduce_parts_kernel adds the slabs up)
+              dst[(size_t)kpart * ((size_t)p.M * p.n_real / 4)] = v;
+            } else if (p.accumulate == 2) {
+              float* d = reinterpret_cast<float*>(dst);
+              unsafeAtomicAdd(d, v[0]); unsafeAtomicAdd(d + 1, v[1]); unsafeAtomicAdd(d + 2, v[2]); unsafeAtomicAdd(d + 3, v[3]);
+            } else {
+              if (p.accumulate) v += *dst;
+              *dst = v;
+            }
+          }
         }
       }
     }
@@ -551,6 +581,100 @@ __global__ __launch_bounds__(256) void th_ln_kernel(const float* __restrict__ y,
       row = end;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Operand planes of the TRAINING GEMMs (fast_gemm below): row-major f32 -> T16 planes of bf16 hi / lo halves.
+//   TRANS = false: A [R][C] -> planes of A      (rows R -> padded to a multiple of 256, contraction C a multiple of 32)
+//   TRANS = true : A [R][C] -> planes of A^T    (rows C a multiple of 256, contraction R -> padded to a multiple of 32)
+// Through LDS, whole-line reads and 512-byte plane blocks on both sides; rows / columns beyond the matrix are zeros.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool TRANS>
+__global__ __launch_bounds__(256) void th_split_bf16_kernel(const float* __restrict__ a, int R, int C, int k_pad, __bf16* __restrict__ hi,
+                                                            __bf16* __restrict__ lo, float* __restrict__ colsum = nullptr) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  auto emit = [&](int orow, int kcol, const f32x4 x, const f32x4 y) {
+    const bf16x4 xh = __builtin_convertvector(x, bf16x4), yh = __builtin_convertvector(y, bf16x4);
+    const bf16x4 xl = __builtin_convertvector(x - __builtin_convertvector(xh, f32x4), bf16x4);
+    const bf16x4 yl = __builtin_convertvector(y - __builtin_convertvector(yh, f32x4), bf16x4);
+    const size_t o = t16_index(orow, kcol, k_pad);
+    *reinterpret_cast<bf16x8*>(hi + o) = bf16x8{xh[0], xh[1], xh[2], xh[3], yh[0], yh[1], yh[2], yh[3]};
+    *reinterpret_cast<bf16x8*>(lo + o) = bf16x8{xl[0], xl[1], xl[2], xl[3], yl[0], yl[1], yl[2], yl[3]};
+  };
+  if constexpr (!TRANS) {  // grid (rows_pad / 32, ceil(k_pad / 256)): 32 output rows x 256 contraction columns
+    __shared__ __attribute__((aligned(16))) float tile[32][260];
+    const int o0 = blockIdx.x * 32, k0 = blockIdx.y * 256;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // whole 1 KiB row pieces
+      const int row = wv * 8 + i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (o0 + row < R && k0 + lane * 4 < C) v = *reinterpret_cast<const f32x4*>(a + (size_t)(o0 + row) * C + k0 + lane * 4);
+      *reinterpret_cast<f32x4*>(&tile[row][lane * 4]) = v;
+    }
+    __syncthreads();
+    const int r = threadIdx.x & 31, cg = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kc = (cg * 4 + j) * 8;
+      if (k0 + kc >= k_pad) continue;
+      emit(o0 + r, k0 + kc, *reinterpret_cast<const f32x4*>(&tile[r][kc]), *reinterpret_cast<const f32x4*>(&tile[r][kc + 4]));
+    }
+  } else {  // grid (rows_pad / 128, k_pad / 64): 128 output rows (= input columns: 512-byte row pieces) x 64 contraction (= input rows)
+    __shared__ __attribute__((aligned(16))) float tile[128][68];
+    const int o0 = blockIdx.x * 128, k0 = blockIdx.y * 64;
+    const int cq = threadIdx.x & 31, rg = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = i * 8 + rg;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (k0 + r < R && o0 + cq * 4 < C) v = *reinterpret_cast<const f32x4*>(a + (size_t)(k0 + r) * C + o0 + cq * 4);
+      tile[cq * 4 + 0][r] = v[0];
+      tile[cq * 4 + 1][r] = v[1];
+      tile[cq * 4 + 2][r] = v[2];
+      tile[cq * 4 + 3][r] = v[3];
+    }
+    __syncthreads();
+    if (colsum && threadIdx.x < 128 && o0 + threadIdx.x < C) {  // TRANS only: colsum[c] += sum over the rows of a[.][c] — the bias gradient of
+      float sacc = 0.f;                                          // the dY this pass reads anyway (one atomic per column and 64-row block)
+#pragma unroll 8
+      for (int r2 = 0; r2 < 64; ++r2) sacc += tile[threadIdx.x][r2];
+      unsafeAtomicAdd(colsum + o0 + threadIdx.x, sacc);
+    }
+    const int r = threadIdx.x & 31, ch = threadIdx.x >> 5;  // output row within a 32-row tile, 8-wide contraction chunk
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int orow = rt * 32 + r;
+      emit(o0 + orow, k0 + ch * 8, *reinterpret_cast<const f32x4*>(&tile[orow][ch * 8]), *reinterpret_cast<const f32x4*>(&tile[orow][ch * 8 + 4]));
+    }
+  }
+}
+
+// column sums of a row-major [M][N] matrix added to out[N] (bias gradients): grid (N / 256, row chunks), float atomics
+__global__ __launch_bounds__(256) void th_colsum_kernel(const float* __restrict__ a, int M, int N, int rows_per, float* __restrict__ out) {
+  const int n = blockIdx.x * 256 + threadIdx.x, m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+  if (n >= N) return;
+  float s0 = 0.f, s1 = 0.f;
+  int m = m0;
+  for (; m + 1 < m1; m += 2) {
+    s0 += a[(size_t)m * N + n];
+    s1 += a[(size_t)(m + 1) * N + n];
+  }
+  if (m < m1) s0 += a[(size_t)m * N + n];
+  unsafeAtomicAdd(out + n, s0 + s1);
+}
+
+// out[m][n] (+)= sum over the ks partial slabs (+ bias[n]) (relu): the second half of a split-K product (fast_gemm)
+__global__ __launch_bounds__(256) void th_reduce_parts_kernel(const float* __restrict__ parts, int ks, size_t mn, int N, const float* __restrict__ bias,
+                                                              int relu, int accumulate, float* __restrict__ out) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= mn) return;
+  f32x4 v = *reinterpret_cast<const f32x4*>(parts + i);
+  for (int k = 1; k < ks; ++k) v += *reinterpret_cast<const f32x4*>(parts + (size_t)k * mn + i);
+  if (bias) v += *reinterpret_cast<const f32x4*>(bias + (i % (size_t)N));
+  if (relu) v = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+  if (accumulate) v += *reinterpret_cast<const f32x4*>(out + i);
+  *reinterpret_cast<f32x4*>(out + i) = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -891,6 +1015,84 @@ int text_inter_impl(t2l_ctx* ctx, const float* sent, int n_desc, int S, float* o
   if (overflow) T2L_HIP(ctx, hipMemcpyAsync(overflow, W->flag, sizeof(int), hipMemcpyDeviceToDevice, s));
   T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fast_gemm: OUT[Mo][No] (+)= A B^T (+ bias) (relu) for the TRAINING step of the text head (train.hip), on the tiled LDS-ring GEMM
+// above with bf16 planes. A: row-major [Mo][Kc], or (a_trans) [Kc][Mo]; B: row-major [No][Kc], or (b_trans) [Kc][No]; f32
+// row-major output. Covers the three products of a Linear: Y = X W^T + b (plain), dX (+)= dY W (b_trans), dW += dY^T X (a_trans,
+// b_trans, accumulate). single: one bf16 product per operand pair (text_train_bf16 = 1); else split-bf16 (three). No must be a
+// multiple of 256, the contraction is zero-padded to a multiple of 32. Workspace: the operand planes, grown on demand.
+// ---------------------------------------------------------------------------------------------------------------
+int fast_gemm(t2l_ctx* ctx, const float* A, bool a_trans, const float* B, bool b_trans, const float* bias, float* out, int Mo, int No, int Kc,
+              int relu, int accumulate, bool single, hipStream_t s, float* a_colsum) {
+  using namespace th;
+  if (No % kTile || Mo < 1 || Kc < 1) return fail(ctx, T2L_EINVAL, "fast_gemm: unsupported shape");
+  const int k_pad = (Kc + 63) / 64 * 64, m_pad = (Mo + kTile - 1) / kTile * kTile;  // (64: the transposed split's tile, and an even k-step count)
+  const size_t pa = (size_t)m_pad * k_pad * 2, pb = (size_t)No * k_pad * 2;
+  // few output tiles against a long contraction (dW over thousands of rows: 16 .. 64 tiles for 256 CUs; 1024-wide outputs: 96): the
+  // contraction is cut into ks jobs per tile, every job stores its partial tile into its own slab (plain stores — float atomics
+  // into the output were measured 2x SLOWER than no split at all) and one pass adds the slabs up (+ bias, ReLU, accumulate)
+  const int m_tiles = m_pad / kTile, n_tiles = No / kTile, kt = k_pad >> 4;
+  int ks = 1;
+  while (ctx->fast_gemm_ksplit && ks < 8 && m_tiles * n_tiles * ks < 192 && kt % (ks * 4) == 0 && kt / (ks * 2) >= 8) ks *= 2;
+  const size_t part_bytes = ks > 1 ? sizeof(float) * (size_t)ks * Mo * No : 0;
+  const size_t need = 2 * pa + 2 * pb + part_bytes + 256;
+  if (ctx->fast_ws_cap < need) {  // (the context's own scratch: calls of one context are serialised by its caller)
+    if (ctx->fast_ws) {
+      T2L_HIP(ctx, hipStreamSynchronize(s));
+      T2L_HIP(ctx, hipFree(ctx->fast_ws));
+    }
+    ctx->fast_ws = nullptr;
+    ctx->fast_ws_cap = 0;
+    T2L_HIP(ctx, hipMalloc(&ctx->fast_ws, need + need / 4));
+    ctx->fast_ws_cap = need + need / 4;
+  }
+  if (!ctx->fast_zero) {  // a zero bias vector for products without one (allocated once)
+    T2L_HIP(ctx, hipMalloc(&ctx->fast_zero, sizeof(float) * 16384));
+    T2L_HIP(ctx, hipMemset(ctx->fast_zero, 0, sizeof(float) * 16384));
+  }
+  if (No > 16384) return fail(ctx, T2L_EINVAL, "fast_gemm: more than 16384 output columns");
+  char *ah = (char*)ctx->fast_ws, *al = ah + pa, *bh = al + pa, *bl = bh + pb;
+  float* parts = reinterpret_cast<float*>(bl + pb);
+  static PerDeviceOnce once;
+  if (once.need(ctx->device)) {
+    const int lds = kSlots * kSlotBytes;
+    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&th_gemm_kernel<kEpiRowMajor, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&th_gemm_kernel<kEpiRowMajor, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    once.mark(ctx->device);
+  }
+  const dim3 ga(m_pad / 32, (k_pad + 255) / 256), gb(No / 32, (k_pad + 255) / 256), gat(m_pad / 128, k_pad / 64), gbt(No / 128, k_pad / 64);
+  if (a_trans) hipLaunchKernelGGL(th_split_bf16_kernel<true>, gat, dim3(256), 0, s, A, Kc, Mo, k_pad, (__bf16*)ah, (__bf16*)al, a_colsum);
+  else hipLaunchKernelGGL(th_split_bf16_kernel<false>, ga, dim3(256), 0, s, A, Mo, Kc, k_pad, (__bf16*)ah, (__bf16*)al, (float*)nullptr);
+  if (b_trans) hipLaunchKernelGGL(th_split_bf16_kernel<true>, gbt, dim3(256), 0, s, B, Kc, No, k_pad, (__bf16*)bh, (__bf16*)bl, (float*)nullptr);
+  else hipLaunchKernelGGL(th_split_bf16_kernel<false>, gb, dim3(256), 0, s, B, No, Kc, k_pad, (__bf16*)bh, (__bf16*)bl, (float*)nullptr);
+  GemmArgs g{};
+  g.wh = bh; g.wl = bl; g.xh = ah; g.xl = al; g.bias = bias ? bias : ctx->fast_zero; g.out0 = ks > 1 ? (void*)parts : (void*)out;
+  g.m_tiles = m_tiles; g.n_tiles = n_tiles; g.K = k_pad; g.N = No; g.M = Mo; g.n_real = No;
+  g.relu = ks > 1 ? 0 : relu; g.accumulate = ks > 1 ? 3 : accumulate; g.ksplit = ks;
+  static int n_cu = 0;
+  if (!n_cu) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu < 8) n_cu = 256;
+  }
+  const int n_vb = (g.m_tiles + 7) / 8 * 8 * g.n_tiles * ks;
+  const int grid = min(n_cu / 8 * 8, n_vb);
+  const int lds = kSlots * kSlotBytes;
+  if (single) hipLaunchKernelGGL((th_gemm_kernel<kEpiRowMajor, true, true>), dim3(grid), dim3(512), lds, s, g);
+  else hipLaunchKernelGGL((th_gemm_kernel<kEpiRowMajor, false, true>), dim3(grid), dim3(512), lds, s, g);
+  if (ks > 1) {
+    const size_t mn = (size_t)Mo * No;
+    hipLaunchKernelGGL(th_reduce_parts_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, s, (const float*)parts, ks, mn, No, bias, relu, accumulate, out);
+  }
+  T2L_HIP(ctx, hipGetLastError());
+  return T2L_OK;
+}
+
+void fast_colsum(const float* a, int M, int N, float* out, hipStream_t s) {
+  const int rows_per = 256;
+  hipLaunchKernelGGL(th::th_colsum_kernel, dim3((N + 255) / 256, (M + rows_per - 1) / rows_per), dim3(256), 0, s, a, M, N, rows_per, out);
 }
 
 }  // namespace t2l

@@ -828,6 +828,7 @@ struct TextLayer {
         *xhat2 = nullptr, *rstd2 = nullptr, *x2 = nullptr;
 };
 struct TextTrain {
+  t2l_ctx* ctx = nullptr;
   std::unordered_map<std::string, TTensor> t;
   std::string prefix;
   char* ws = nullptr;
@@ -867,6 +868,7 @@ int text_train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, c
   free_text_train(ctx);
   TextTrain* st = new TextTrain();
   ctx->text_train = st;
+  st->ctx = ctx;
   st->prefix = prefix ? prefix : "language_encoder.";
   for (int i = 0; i < n; ++i) {
     if (!tensors[i].name || !tensors[i].data) return fail(ctx, T2L_EINVAL, "t2l_text_train_bind: null name/data");
@@ -906,6 +908,37 @@ int text_train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, c
   return T2L_OK;
 }
 
+// The head's Linear products. With bf16 / split-bf16 operands (option text_train_bf16 != 0, the default) they run on the tiled
+// LDS-ring GEMM of text_head.hip (fast_gemm: 256 x 256 tiles, bf16 planes — 466 GFLOP per step at B = 64 are GEMM-shaped work that
+// the object branch's tile-per-workgroup products, built for 1,792-row operands, serve at a third of its rate); f32 operands
+// (text_train_bf16 = 0) and shapes it does not take keep the f32-MFMA products of gemm_f32.h.
+static bool t_fast(TextTrain* st, int M, int N, int K) {
+  return st->ctx->text_train_bf16 != 0 && st->ctx->text_train_fast && N % 256 == 0 && K % 32 == 0 && K % 4 == 0 && M >= 64;
+}
+static void t_gemm_nt(TextTrain* st, const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int relu, hipStream_t s) {
+  if (t_fast(st, M, N, K)) (void)fast_gemm(st->ctx, X, false, W, false, b, Y, M, N, K, relu, 0, st->ctx->text_train_bf16 == 1, s);
+  else gemm_nt(X, W, b, Y, M, N, K, relu, s);
+}
+// dW[N,Kp] += dY^T X, db[N] += column sums of dY, and (dX != nullptr) dX[M,Kp] (+)= dY W, through the ReLU + dropout backward of the
+// layer that produced X's pre-image when mask_src is given
+static void t_gemm_tn_nn(TextTrain* st, const float* dY, const float* X, float* dW, float* db, const float* W, float* dX, int M, int N, int Kp,
+                         int accumulate, const float* mask_src, const Drop* drop, hipStream_t s) {
+  if (t_fast(st, N, Kp, M) && (!dX || t_fast(st, M, Kp, N)) && N % 4 == 0) {
+    const bool single = st->ctx->text_train_bf16 == 1;
+    (void)fast_gemm(st->ctx, dY, true, X, true, nullptr, dW, N, Kp, M, 0, 1, single, s, db);  // (db: column sums of dY, in its split pass)
+    if (dX) {
+      (void)fast_gemm(st->ctx, dY, false, W, true, nullptr, dX, M, Kp, N, 0, accumulate, single, s);
+      if (mask_src) {
+        const size_t n = (size_t)M * Kp;
+        hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dX, mask_src, n, *drop);
+      }
+    }
+    return;
+  }
+  if (dX) gemm_tn_nn(dY, X, dW, db, W, dX, M, N, Kp, accumulate, mask_src, drop, s);
+  else gemm_tn(dY, X, dW, db, M, N, Kp, s);
+}
+
 static size_t attn_lds(int S, int HD, bool bwd) { return sizeof(float) * ((size_t)(bwd ? 4 : 3) * S * (HD + 1) + (size_t)(bwd ? 3 : 1) * S * (S + 1)); }
 
 template <int D>
@@ -928,12 +961,19 @@ static void text_layer_fwd(TextTrain* st, TextLayer& L, float* tmp, hipStream_t 
   constexpr int HD = D / 4, FF = 4 * D;
   const int T = L.T;
   auto W = [&](const char* n) -> const TTensor& { return TT(st, L.prefix + n); };
-  gemm_nt(L.x_in, W(".self_attn.in_proj_weight").data, W(".self_attn.in_proj_bias").data, L.qkv, T, 3 * D, D, 0, s);
+  t_gemm_nt(st, L.x_in, W(".self_attn.in_proj_weight").data, W(".self_attn.in_proj_bias").data, L.qkv, T, 3 * D, D, 0, s);
   hipLaunchKernelGGL((attn_fwd_g_kernel<HD>), dim3(L.B * 4), dim3(256), attn_lds(L.S, HD, false), s, L.qkv, L.P, L.O, L.S,
                      make_drop(st->seed, L.site0 + 0, st->p));
-  gemm_nt(L.O, W(".self_attn.out_proj.weight").data, W(".self_attn.out_proj.bias").data, tmp, T, D, D, 0, s);
+  t_gemm_nt(st, L.O, W(".self_attn.out_proj.weight").data, W(".self_attn.out_proj.bias").data, tmp, T, D, D, 0, s);
   hipLaunchKernelGGL((ln_fwd_g_kernel<D>), dim3((T + 3) / 4), dim3(256), 0, s, L.x_in, (const float*)tmp, T, W(".norm1.weight").data,
                      W(".norm1.bias").data, make_drop(st->seed, L.site0 + 1, st->p), L.x1, L.xhat1, L.rstd1);
+  if (t_fast(st, T, FF, D)) {  // linear1 + ReLU in the GEMM's epilogue (h is kept for backward); the dropout behind it as one pass
+    (void)fast_gemm(st->ctx, L.x1, false, W(".linear1.weight").data, false, W(".linear1.bias").data, L.h, T, FF, D, 1, 0, st->ctx->text_train_bf16 == 1, s);
+    if (st->p > 0.f) {
+      const size_t n = (size_t)T * FF;
+      hipLaunchKernelGGL(drop_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)L.h, n, make_drop(st->seed, L.site0 + 2, st->p), L.hd);
+    }
+  } else
   {
     GemmArgs g{L.x1, W(".linear1.weight").data, L.h, W(".linear1.bias").data, T, FF, D, D, D, FF, 1, 0, D, nullptr, tl_gemm_bf16};
     if (st->p > 0.f) {
@@ -946,7 +986,7 @@ static void text_layer_fwd(TextTrain* st, TextLayer& L, float* tmp, hipStream_t 
     }
     gemm_nt_args(g, s);
   }
-  gemm_nt(L.hd, W(".linear2.weight").data, W(".linear2.bias").data, tmp, T, D, FF, 0, s);
+  t_gemm_nt(st, L.hd, W(".linear2.weight").data, W(".linear2.bias").data, tmp, T, D, FF, 0, s);
   hipLaunchKernelGGL((ln_fwd_g_kernel<D>), dim3((T + 3) / 4), dim3(256), 0, s, (const float*)L.x1, (const float*)tmp, T, W(".norm2.weight").data,
                      W(".norm2.bias").data, make_drop(st->seed, L.site0 + 3, st->p), L.x2, L.xhat2, L.rstd2);
 }
@@ -964,21 +1004,22 @@ static float* text_layer_bwd(TextTrain* st, const TextLayer& L, const float* dcu
                      W(".norm2.weight").data, make_drop(st->seed, L.site0 + 3, st->p), dA, dB, W(".norm2.weight").grad, W(".norm2.bias").grad);
   {
     const Drop dr = make_drop(st->seed, L.site0 + 2, st->p);
-    gemm_tn_nn(dB, L.hd, W(".linear2.weight").grad, W(".linear2.bias").grad, W(".linear2.weight").data, dH, T, D, FF, 0, L.h, &dr, s);
+    t_gemm_tn_nn(st, dB, L.hd, W(".linear2.weight").grad, W(".linear2.bias").grad, W(".linear2.weight").data, dH, T, D, FF, 0, L.h, &dr, s);
   }
-  gemm_tn_nn(dH, L.x1, W(".linear1.weight").grad, W(".linear1.bias").grad, W(".linear1.weight").data, dA, T, FF, D, 1, nullptr, nullptr, s);
+  t_gemm_tn_nn(st, dH, L.x1, W(".linear1.weight").grad, W(".linear1.bias").grad, W(".linear1.weight").data, dA, T, FF, D, 1, nullptr, nullptr, s);
   hipLaunchKernelGGL((ln_bwd_g_kernel<D>), dim3(ln_grid), dim3(256), 0, s, (const float*)dA, (const float*)L.xhat1, (const float*)L.rstd1, T,
                      W(".norm1.weight").data, make_drop(st->seed, L.site0 + 1, st->p), dC, dB2, W(".norm1.weight").grad, W(".norm1.bias").grad);
-  gemm_tn_nn(dB2, L.O, W(".self_attn.out_proj.weight").grad, W(".self_attn.out_proj.bias").grad, W(".self_attn.out_proj.weight").data, dO, T, D, D,
-             0, nullptr, nullptr, s);
+  t_gemm_tn_nn(st, dB2, L.O, W(".self_attn.out_proj.weight").grad, W(".self_attn.out_proj.bias").grad, W(".self_attn.out_proj.weight").data, dO, T, D,
+               D, 0, nullptr, nullptr, s);
   hipLaunchKernelGGL((attn_bwd_g_kernel<HD>), dim3(L.B * 4), dim3(256), attn_lds(L.S, HD, true), s, (const float*)L.qkv, (const float*)L.P,
                      (const float*)dO, dqkv, L.S, make_drop(st->seed, L.site0 + 0, st->p));
   if (need_dx) {
-    gemm_tn_nn(dqkv, L.x_in, W(".self_attn.in_proj_weight").grad, W(".self_attn.in_proj_bias").grad, W(".self_attn.in_proj_weight").data, dC, T,
-               3 * D, D, 1, nullptr, nullptr, s);
+    t_gemm_tn_nn(st, dqkv, L.x_in, W(".self_attn.in_proj_weight").grad, W(".self_attn.in_proj_bias").grad, W(".self_attn.in_proj_weight").data, dC,
+                 T, 3 * D, D, 1, nullptr, nullptr, s);
     return dC;
   }
-  gemm_tn(dqkv, L.x_in, W(".self_attn.in_proj_weight").grad, W(".self_attn.in_proj_bias").grad, T, 3 * D, D, s);
+  t_gemm_tn_nn(st, dqkv, L.x_in, W(".self_attn.in_proj_weight").grad, W(".self_attn.in_proj_bias").grad, nullptr, nullptr, T, 3 * D, D, 0, nullptr,
+               nullptr, s);
   return nullptr;
 }
 
@@ -1022,8 +1063,8 @@ int text_train_forward_impl(t2l_ctx* ctx, const float* hidden, int n_sent, int L
   st->mlp_out = tbump<float>(st, (size_t)n_sent * 256);
   st->bn_mean = tbump<float>(st, 256);
   st->bn_rstd = tbump<float>(st, 256);
-  gemm_nt(st->pooled, TT(st, "inter_mlp.0.0.weight").data, TT(st, "inter_mlp.0.0.bias").data, st->mlp_y, n_sent, 256, 1024, 0, s);
-  hipLaunchKernelGGL(bn_plain_fwd_kernel, dim3(1), dim3(256), 0, s, (const float*)st->mlp_y, n_sent, 256, TT(st, "inter_mlp.0.1.weight").data,
+  t_gemm_nt(st, st->pooled, TT(st, "inter_mlp.0.0.weight").data, TT(st, "inter_mlp.0.0.bias").data, st->mlp_y, n_sent, 256, 1024, 0, s);
+  hipLaunchKernelGGL(bn_plain_fwd_kernel, dim3(64), dim3(256), 0, s, (const float*)st->mlp_y, n_sent, 256, TT(st, "inter_mlp.0.1.weight").data,
                      TT(st, "inter_mlp.0.1.bias").data, TT(st, "inter_mlp.0.1.running_mean").data, TT(st, "inter_mlp.0.1.running_var").data, 0.1f,
                      st->mlp_out, st->bn_mean, st->bn_rstd);
   TextLayer& I = st->inter;
@@ -1060,11 +1101,11 @@ int text_train_backward_impl(t2l_ctx* ctx, const float* grad_out, hipStream_t s)
   float* dX = text_layer_bwd<256>(st, st->inter, dY2, true, s);
   hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)(((size_t)n_sent * 256 + 255) / 256)), dim3(256), 0, s, dX, (const float*)dY2, (size_t)n_sent * 256);
   // inter_mlp: BatchNorm (batch statistics), Linear
-  hipLaunchKernelGGL(bn_plain_bwd_kernel, dim3(1), dim3(256), 0, s, dX, (const float*)st->mlp_y, n_sent, 256, TT(st, "inter_mlp.0.1.weight").data,
+  hipLaunchKernelGGL(bn_plain_bwd_kernel, dim3(64), dim3(256), 0, s, dX, (const float*)st->mlp_y, n_sent, 256, TT(st, "inter_mlp.0.1.weight").data,
                      (const float*)st->bn_mean, (const float*)st->bn_rstd, TT(st, "inter_mlp.0.1.weight").grad, TT(st, "inter_mlp.0.1.bias").grad);
   float* dpool = tbump<float>(st, (size_t)n_sent * 1024);
-  gemm_tn_nn(dX, st->pooled, TT(st, "inter_mlp.0.0.weight").grad, TT(st, "inter_mlp.0.0.bias").grad, TT(st, "inter_mlp.0.0.weight").data, dpool, n_sent,
-             256, 1024, 0, nullptr, nullptr, s);
+  t_gemm_tn_nn(st, dX, st->pooled, TT(st, "inter_mlp.0.0.weight").grad, TT(st, "inter_mlp.0.0.bias").grad, TT(st, "inter_mlp.0.0.weight").data, dpool,
+               n_sent, 256, 1024, 0, nullptr, nullptr, s);
   // max over the tokens, then the d = 1024 layer (its input, T5's hidden states, is a constant: no dX)
   float* dX2 = tbump<float>(st, (size_t)n_sent * L * 1024);
   hipLaunchKernelGGL(seq_max_bwd_kernel, dim3((unsigned)(((size_t)n_sent * L * 1024 + 255) / 256)), dim3(256), 0, s, (const float*)dpool,

@@ -205,3 +205,48 @@ class QueryShardedSearcher:
         _all_gather(self.dist, all_i, pi, self.group)
         _all_gather(self.dist, all_s, ps, self.group)
         return all_i[:Q], all_s[:Q]
+
+
+# ---- which layout for which database ------------------------------------------------------------------------------------------
+# A resident row costs 2.5 KiB of HBM in the engine (f32 row 1 KiB + f16 plane 0.5 KiB + split-bf16 plane 1 KiB). Row-sharding
+# is what a database needs that does NOT fit one GPU; for one that does, it makes every rank convert, scan against and re-rank
+# EVERY query and merge P lists per query (measured per-rank floor of an 8-GPU step at N = 11,259 x Q = 4,096: 39 us against a
+# 45 us single-GPU step — no scaling), whereas replicating it and splitting the QUERIES has no data-path exchange at all and
+# scales with the number of GPUs. `layout="auto"`: query-sharded while the whole database takes at most `replicate_fraction`
+# (default a quarter) of one GPU's HBM — at 288 GB that is ~28 M rows; KITTI360Pose has 11 k —, row-sharded beyond.
+ROW_BYTES_RESIDENT = 2560
+
+
+def choose_layout(n_rows: int, hbm_bytes: Optional[int] = None, replicate_fraction: float = 0.25) -> str:
+    if hbm_bytes is None:
+        try:
+            import torch
+
+            hbm_bytes = torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory if torch.cuda.is_available() else 288 << 30
+        except Exception:
+            hbm_bytes = 288 << 30
+    return "query" if n_rows * ROW_BYTES_RESIDENT <= replicate_fraction * hbm_bytes else "row"
+
+
+class AutoSearcher:
+    """``set_db(all_rows)`` + ``search(queries, k)`` over N ranks with the layout ``choose_layout`` picks (or a forced one): every
+    rank passes the SAME full [N,256] matrix and the SAME queries and gets the complete [Q,k] result back — what
+    ``coarse.eval_epoch`` calls when torch.distributed is initialised."""
+
+    def __init__(self, engine=None, group=None, layout: str = "auto", search_fn: Optional[Callable] = None, merge_fn: Optional[Callable] = None):
+        if layout not in ("auto", "query", "row"):
+            raise ValueError("layout must be 'auto', 'query' or 'row'")
+        self._args = (engine, group, search_fn, merge_fn)
+        self.layout_request, self.layout, self.impl = layout, None, None
+
+    def set_db(self, all_rows):
+        engine, group, search_fn, merge_fn = self._args
+        self.layout = self.layout_request if self.layout_request != "auto" else choose_layout(int(all_rows.shape[0]))
+        if self.layout == "query":
+            self.impl = QueryShardedSearcher(engine, group, search_fn=search_fn)
+            return self.impl.set_db(all_rows)
+        self.impl = ShardedSearcher(engine, group, search_fn=search_fn, merge_fn=merge_fn)
+        return self.impl.set_db_shard(all_rows)
+
+    def search(self, queries, k: int):
+        return self.impl.search(queries, k)
