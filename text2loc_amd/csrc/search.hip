@@ -1467,15 +1467,17 @@ __global__ __launch_bounds__(256) void merge_kernel(const char* __restrict__ idx
   const int qid = blockIdx.x * 4 + wv;
   if (qid >= Q) return;  // (one wave per query: no workgroup barrier below)
   const int total = parts * K, ne = (total + 63) >> 6;
+  const float inv_k = 1.0f / (float)K;  // c / K for c < 256, K <= 26 without an integer division (~35 instructions each, a dozen per wave)
   double s[4];
-  int id[4];
+  int id[4], part_of[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int c = lane + 64 * e;
     s[e] = -__builtin_inf();
     id[e] = INT_MAX;
+    part_of[e] = (int)(((float)c + 0.5f) * inv_k);
     if (e < ne && c < total) {
-      const int part = c / K;
+      const int part = part_of[e];
       const size_t off = (size_t)qid * K + (c - part * K);
       if constexpr (PAIRS) {
         const double2 pr = reinterpret_cast<const double2*>(score + part * score_stride)[off];
@@ -1499,21 +1501,24 @@ __global__ __launch_bounds__(256) void merge_kernel(const char* __restrict__ idx
   // those are ranked. No order is assumed inside a part (round 3 took the part's K-th entry, i.e. required best-first lists with the
   // invalid entries trailing — a precondition the public t2l_merge_topk never stated); sorted inputs give the same bound.
   // (All scores equal: everybody survives, the loop below is the full all-pairs count.) The bound only has to be a LOWER bound: it is
-  // taken in float32 rounded towards -inf; the per-part minimum goes through LDS (every candidate's f32 image, K reads per part).
-  float* sh_f = reinterpret_cast<float*>(&sh_i[wv][0]);  // (sh_i is written with the survivors' ids only after this phase)
+  // taken in float32 rounded towards -inf.
+  // per-part minimum through LDS integer atomics on the order-preserving integer image of the f32 value (one ds_min per candidate
+  // instead of K dependent reads per part: the first form of this pass cost the merge 3 us)
+  int* sh_min = &sh_i[wv][0];  // (sh_i takes the survivors' ids only after this phase)
+  auto ord = [](float f) { const int b = __float_as_int(f); return b ^ ((b >> 31) & 0x7fffffff); };  // monotone: f < g <=> ord(f) < ord(g)
+  auto unord = [](int o) { return __int_as_float(o ^ ((o >> 31) & 0x7fffffff)); };
+  for (int p = lane; p < parts; p += 64) sh_min[p] = INT_MAX;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int c = lane + 64 * e;
-    if (e < ne && c < total) sh_f[c] = id[e] != INT_MAX ? __double2float_rd(s[e]) : -__builtin_inff();
+    if (e < ne && c < total) atomicMin(&sh_min[part_of[e]], ord(id[e] != INT_MAX ? __double2float_rd(s[e]) : -__builtin_inff()));
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xC07F);
   float bnd32 = -__builtin_inff();
-  for (int p = lane; p < parts; p += 64) {  // a part with an invalid entry has minimum -inf: it does not raise the bound
-    float mn = __builtin_inff();
-    for (int j = 0; j < K; ++j) mn = fminf(mn, sh_f[p * K + j]);
-    bnd32 = fmaxf(bnd32, mn);
-  }
+  for (int p = lane; p < parts; p += 64) bnd32 = fmaxf(bnd32, unord(sh_min[p]));  // a part with an invalid entry has minimum -inf
   const double bnd = (double)wave_max_f32(bnd32, __builtin_inff());
   __builtin_amdgcn_wave_barrier();  // (sh_f is dead: sh_i may be overwritten)
   int n_s = 0;
