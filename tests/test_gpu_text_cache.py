@@ -88,6 +88,18 @@ def test_eval_epoch_with_the_sentence_cache_equals_the_uncached_run():
     st = cache.stats()
     assert st["t5_sentences"] == len(sentences) and st["batches_with_misses"] == 0
 
+    # the cache as a file ("T5 embeddings precomputed"): a fresh load serves the same embeddings without tokenizer or T5
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        fn = osp.join(td, "t5_states.npz")
+        cache.save(fn)
+        loaded = TextCache.load(fn, device="cuda")
+        assert loaded.tokenizer is None and len(loaded.index) == len(cache.index)
+        le.text_cache = loaded
+        le.memoise_sentence_vectors = True
+        _, _, _, _, te_c = eval_epoch(model, dl, args, return_encodings=True)
+        assert np.abs(te_c - te_a).max() < 2e-5
+        le.text_cache = cache
     # an unseen sentence is encoded once and added; one the cache cannot hold sends the batch through T5
     new = "The pose is north of a gray pole."
     texts = [" ".join([new] + list(ds.hint_descriptions[0][1:]))]

@@ -71,6 +71,8 @@ class TextCache:
         new = [s for s in dict.fromkeys(sentences) if s not in self.index]
         if not new:
             return True
+        if self.tokenizer is None or self.llm_model is None:
+            return False  # (a cache loaded without its encoder: the caller's own T5 path serves the batch)
         lens = [len(ids) for ids in self.tokenizer(new)["input_ids"]]
         if max(lens) > self.max_tokens:
             return False
@@ -145,6 +147,27 @@ class TextCache:
                          for lo in range(0, len(self.hidden), 4096)]
             v = self._vec[key] = torch.cat(parts, dim=0).contiguous()
         return v
+
+    # ------------------------------------------------------------------ persistence ("T5-large embeddings precomputed", BASELINE config 2)
+    def save(self, path: str):
+        """One .npz: the sentences, their token counts and hidden states (f32) — what an evaluation run needs instead of T5-large."""
+        order = sorted(self.index, key=self.index.get)
+        np.savez(path, sentences=np.array(order, dtype=object), n_tok=self.n_tok, hidden=self.hidden.cpu().numpy(),
+                 max_tokens=np.int32(self.max_tokens), dim=np.int32(self.dim), allow_pickle=True)
+
+    @classmethod
+    def load(cls, path: str, language_encoder=None, device=None) -> "TextCache":
+        """``language_encoder`` (optional) supplies tokenizer + T5 for sentences the file does not hold; without it a miss sends the
+        batch to the encoder's own T5 path."""
+        z = np.load(path, allow_pickle=True)
+        dev = device if device is not None else (language_encoder.device if language_encoder is not None else "cuda")
+        tok = getattr(language_encoder, "tokenizer", None)
+        t5 = getattr(language_encoder, "llm_model", None)
+        c = cls(tok, t5, dev, int(z["max_tokens"]), int(z["dim"]))
+        c.index = {str(sn): i for i, sn in enumerate(z["sentences"])}
+        c.n_tok = np.asarray(z["n_tok"], dtype=np.int32)
+        c.hidden = torch.from_numpy(np.ascontiguousarray(z["hidden"])).to(c.device)
+        return c
 
     def stats(self) -> dict:
         return {"sentences": len(self.index), "max_tokens": self.max_tokens, "hbm_mbytes": self.hidden.numel() * 4 / 1e6,
