@@ -371,6 +371,24 @@ int t2l_text_head_train(t2l_ctx* ctx, const float* hidden, int32_t n_sentences, 
                         uint32_t seed, float* out, void* stream);
 int t2l_text_head_backward(t2l_ctx* ctx, const float* grad_out, void* stream);
 
+/* Data-parallel training with the reference's batch statistics. The reference trains ONE process on the whole batch
+ * (training/coarse.py:31-58): every BatchNorm1d of the object branch (object_encoder.py:41-52, 121-149) and of inter_mlp
+ * (language_encoder.py:99) normalises over all objects / sentences of the batch. With the batch split over ranks, the per-channel
+ * sums (forward: sum y, sum y^2, rows; backward: sum dy, sum dy * xhat, rows) must be added up over the ranks between the statistics
+ * and the apply launch of every BatchNorm — torch.nn.SyncBatchNorm's exchange. The library has no collectives of its own
+ * (RCCL stays with the host: sharded.py / torch.distributed), so the caller supplies both the memory and the sum:
+ *   buf   dev f64[t2l_train_sync_bn_doubles()] — replaces the library's own accumulator slots from the next forward on;
+ *   fn    called from inside t2l_encode_cells_train / _backward / t2l_text_head_train / _backward, on the calling thread, once per
+ *         BatchNorm stage (3 or 4 per direction of an object-branch step, 1 per direction of a text-head step): must replace buf[0..n) at `range` by its sum over
+ *         all ranks, ordered on `stream` after what is already enqueued there and before what follows (torch.distributed.all_reduce
+ *         on the current stream does exactly that). Returns 0, or non-zero to fail the enclosing call with T2L_ESTATE.
+ * fn == NULL returns to per-rank statistics (and the library's own slots). Running statistics are updated with the global values on
+ * every rank; the parameter gradients of the BatchNorm layers stay per rank (the gradient all_reduce adds them up). PointNet++'s
+ * BatchNorms are per cell (pointnet_train.h) and never cross ranks. */
+typedef int (*t2l_allreduce_fn)(void* user, double* range, int64_t n, void* stream);
+int64_t t2l_train_sync_bn_doubles(void);
+int t2l_train_sync_bn(t2l_ctx* ctx, double* buf, int64_t n_doubles, t2l_allreduce_fn fn, void* user);
+
 int t2l_adam_step(t2l_ctx* ctx, float lr, float beta1, float beta2, float eps, void* stream);
 
 /* optimizer.state_dict() / load_state_dict() for the engine-stepped tensors (torch.optim.Adam keeps exp_avg / exp_avg_sq /

@@ -49,7 +49,7 @@ def _params(model):
             if n.startswith(("obj_inter_module.", "object_encoder.mlp_merge", "object_encoder.pos_encoder", "language_encoder."))}
 
 
-def _worker(rank, world, b_local, port, out_q):
+def _worker(rank, world, b_local, port, out_q, sync_bn=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
 
@@ -59,7 +59,7 @@ def _worker(rank, world, b_local, port, out_q):
     from text2loc_amd.optim import Adam
 
     model, objects = _build(world, b_local)
-    opt = Adam(model, lr=LR, data_parallel=True)
+    opt = Adam(model, lr=LR, data_parallel=True, sync_bn=sync_bn)
     crit = ContrastiveLoss(0.1, gather=True)
     lo = rank * b_local
     ids = list(range(lo, lo + b_local))
@@ -144,3 +144,67 @@ def test_ranks_equal_the_accumulated_single_process_step(world, b_local):
         err = np.abs(p0[n] - v)
         # Adam's first step is lr * g / (|g| + eps): elements whose gradient is rounding noise may move by up to 2 lr
         assert float((err < 1e-5 * (1 + np.abs(v))).mean()) > 0.97 and float(err.max()) <= 2.1 * LR, (n, float(err.max()))
+
+
+@pytest.mark.parametrize("world,b_local", [(2, 32), (8, 8)])
+def test_ranks_with_sync_batchnorm_equal_the_one_process_step_on_the_global_batch(world, b_local):
+    """``optim.Adam(data_parallel=True, sync_bn=True)`` + ``ContrastiveLoss(gather=True)``: BatchNorm statistics over every rank's
+    objects (t2l_train_sync_bn) — the checker is now ONE process taking ONE step on all world x b_local cells, i.e. the reference's own
+    geometry (training/coarse.py:31-58), not an accumulation of per-block passes."""
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, b_local, port, out_q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out_q.get(timeout=900) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+
+    from text2loc_amd.losses import ContrastiveLoss
+    from text2loc_amd.optim import Adam
+
+    model, objects = _build(world, b_local)
+    opt = Adam(model, lr=LR)
+    opt.zero_grad()
+    n = world * b_local
+    loss = ContrastiveLoss(0.1)(model.encode_text(list(range(n))), model.encode_objects(objects))
+    loss.backward()
+    flat_ref = model.train_flat_grad().detach().cpu().numpy().copy()
+    table_ref = model.language_encoder.table.grad.detach().cpu().numpy().copy()
+    opt.step()
+    torch.cuda.synchronize()
+    ref_params = _params(model)
+
+    l0, _, sum0, tg0, p0 = res[0][1:]
+    assert abs(l0 - float(loss.detach())) < 2e-5 * abs(l0)
+    for _, lr_, _, summ, tg, pr in res:
+        assert abs(lr_ - l0) < 1e-6 and np.array_equal(summ, sum0) and np.array_equal(tg, tg0)
+    rms = float(np.sqrt((flat_ref ** 2).mean()))
+    # float32 sums over differently partitioned rows (each rank's statistics blocks vs one process's): the tolerances of the
+    # reference-golden train-step test (tests/test_gpu_train.py), tensor by tensor
+    base = model.train_flat_grad().data_ptr()
+    for name, gv in model._train_grads.items():
+        o = (gv.data_ptr() - base) // 4
+        got, exp = sum0[o:o + gv.numel()].astype(np.float64), flat_ref[o:o + gv.numel()].astype(np.float64)
+        err, rms_t = np.abs(got - exp), float(np.sqrt((exp ** 2).mean()))
+        if name.startswith("object_encoder.") and name.endswith(".0.bias"):
+            assert err.max() < 1e-4, name  # true gradient 0 (a BatchNorm follows); the ranks' local sums cancel to rounding noise
+            continue
+        if ".num_encoder.0." in name:
+            # [64,1] Linear in front of a BatchNorm: scale-invariant (its gradient is the eps / (var + eps) residual of cancelling terms),
+            # and with these weights var(w x) is of eps' order, so 1 / sqrt(var + eps) amplifies the float32 rounding of (y - mean) by
+            # ~300 into this BatchNorm's own gradients
+            assert err.max() < 0.1 * np.abs(exp).max() + 2e-4, (name, err.max())
+            continue
+        assert (err < 1e-2 * rms_t + 1e-6).mean() >= 0.95 and err.max() < 0.2 * rms_t + 1e-5, (name, float(err.max()), rms_t)
+    assert np.median(np.abs(sum0 - flat_ref)) < 1e-4 * rms
+    assert np.abs(tg0 - table_ref).max() < 1e-6 + 1e-4 * np.abs(table_ref).max()
+    for name, v in ref_params.items():
+        for _, _, _, _, _, pr in res[1:]:
+            assert np.array_equal(p0[name], pr[name]), name
+        if (name.startswith("object_encoder.") and name.endswith(".0.bias")) or name.endswith("in_proj_bias"):
+            continue
+        err = np.abs(p0[name] - v)
+        assert float((err < 1e-5 * (1 + np.abs(v))).mean()) > 0.97 and float(err.max()) <= 2.1 * LR, (name, float(err.max()))

@@ -123,6 +123,16 @@ class _TextHeadTrainFn(torch.autograd.Function):
         return None, None, None, None, None, None
 
 
+def _apply_sync_bn(eng: Engine, cfg):
+    """cfg: None (per-rank BatchNorm statistics) or (group,) — see CellRetrievalNetwork.sync_batchnorm."""
+    if getattr(eng, "_sync_bn_cfg", None) != cfg:
+        if cfg is None:
+            eng.train_sync_bn(enable=False)
+        else:
+            eng.train_sync_bn(group=cfg[0])
+        eng._sync_bn_cfg = cfg
+
+
 class LanguageEncoder(nn.Module):
     """Text branch (models/language_encoder.py:76-152): frozen T5 encoder -> 1 Transformer layer over tokens (no
     padding mask) -> max over tokens -> Linear+BN -> residual Transformer layer over the hint sentences -> max.
@@ -303,6 +313,7 @@ class LanguageEncoder(nn.Module):
         if key != self._th_train_key:
             self._th_train_engine.text_train_bind(tensors)
             self._th_train_key = key
+        _apply_sync_bn(self._th_train_engine, getattr(self, "_sync_bn_cfg", None))
 
     def head(self, hidden: torch.Tensor, batch_size: int) -> torch.Tensor:
         """hidden: last_hidden_state [n_sentences_total, L, C] -> [B, D] (language_encoder.py:127-148)."""
@@ -612,7 +623,19 @@ class CellRetrievalNetwork(nn.Module):
                                     color_embed=bool(getattr(a, "color_embed", False)), use_features=tuple(a.use_features),
                                     num_layers=a.object_inter_module_num_layers, num_heads=a.object_inter_module_num_heads)
             self._train_bound = key
+        _apply_sync_bn(self._engine, getattr(self, "_sync_bn_cfg", None))
         return self._engine
+
+    def sync_batchnorm(self, group=None, enable: bool = True):
+        """Data-parallel training with the reference's batch statistics: every BatchNorm1d of the object branch
+        (object_encoder.py:41-52,121-149) and the text head's inter_mlp (language_encoder.py:99) normalises over the objects /
+        sentences of ALL ranks' batches — 8 ranks x 8 cells then take the step the reference takes on its one batch of 64
+        (training/coarse.py:31-58); what torch.nn.SyncBatchNorm.convert_sync_batchnorm does for module-level BatchNorms. Needs an
+        initialised process group; ``ContrastiveLoss(gather=True)`` and ``optim.Adam(data_parallel=True)`` complete the step."""
+        cfg = (group,) if enable else None
+        self._sync_bn_cfg = cfg
+        if hasattr(self.language_encoder, "_bind_text_train"):
+            self.language_encoder._sync_bn_cfg = cfg
 
     def _encode_objects_train(self, objects, object_points):
         dev = self.device

@@ -404,6 +404,20 @@ int t2l_text_head_backward(t2l_ctx* ctx, const float* grad_out, void* stream) {
   return text_train_backward_impl(ctx, grad_out, (hipStream_t)stream);
 }
 
+int64_t t2l_train_sync_bn_doubles(void) { return train_sync_bn_doubles(); }
+
+int t2l_train_sync_bn(t2l_ctx* ctx, double* buf, int64_t n_doubles, t2l_allreduce_fn fn, void* user) {
+  if (!ctx) return T2L_EINVAL;
+  if (fn && (!buf || n_doubles < train_sync_bn_doubles()))
+    return fail(ctx, T2L_EINVAL, "t2l_train_sync_bn: buf must hold t2l_train_sync_bn_doubles() float64 values");
+  ctx->sync_fn = fn;
+  ctx->sync_user = fn ? user : nullptr;
+  ctx->sync_buf = fn ? buf : nullptr;
+  ctx->sync_failed = false;
+  train_sync_changed(ctx);
+  return T2L_OK;
+}
+
 int t2l_text_inter(t2l_ctx* ctx, const float* sent, int32_t n_descriptions, int32_t n_sentences_per, float* out, int32_t* overflow, void* stream) {
   if (!ctx) return T2L_EINVAL;
   T2L_HIP(ctx, hipSetDevice(ctx->device));

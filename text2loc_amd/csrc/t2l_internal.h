@@ -84,6 +84,12 @@ struct t2l_ctx {
   void* fine = nullptr;          // t2l::FineWeights (fine.hip)
   void* text_head = nullptr;     // t2l::th::Weights (text_head.hip)
   void* text_train = nullptr;    // t2l::TextTrain (train.hip): the text head's training state
+  // cross-rank BatchNorm statistics (t2l_train_sync_bn): the accumulator slots live in the caller's buffer and the callback sums a
+  // range of it over the ranks, ordered on the stream it is handed
+  int (*sync_fn)(void* user, double* buf, int64_t n, void* stream) = nullptr;
+  void* sync_user = nullptr;
+  double* sync_buf = nullptr;
+  bool sync_failed = false;
   void* fast_ws = nullptr;       // operand planes of fast_gemm (text_head.hip)
   size_t fast_ws_cap = 0;
   float* fast_zero = nullptr;
@@ -202,6 +208,8 @@ void free_lanes(t2l_ctx* ctx);
 int adam_state_impl(t2l_ctx* ctx, int set, float* m, float* v, int64_t* step, int64_t* numel, hipStream_t s);
 void free_train(t2l_ctx* ctx);
 void free_text_train(t2l_ctx* ctx);
+int64_t train_sync_bn_doubles();
+void train_sync_changed(t2l_ctx* ctx);  // the accumulator slots moved: the next forward clears them
 int text_train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const char* prefix);
 int text_train_forward_impl(t2l_ctx* ctx, const float* hidden, int n_sent, int L, int n_desc, float p, uint32_t seed, float* out, hipStream_t s);
 int text_train_backward_impl(t2l_ctx* ctx, const float* grad_out, hipStream_t s);

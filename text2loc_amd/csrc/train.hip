@@ -47,6 +47,7 @@ struct LayerSave {
 constexpr int kBnSlots = 8;  // BatchNorm layers per pass: <= 2*3 small branches + pointnet mlp + merge
 
 struct TrainState {
+  t2l_ctx* ctx = nullptr;
   std::unordered_map<std::string, TTensor> t;
   t2l_model_config cfg{};
   std::vector<std::string> adam_names;
@@ -54,7 +55,7 @@ struct TrainState {
   AdamChunk* d_chunks = nullptr;
   float* mv = nullptr;       // [2][mv_total]: first moments of all Adam tensors (adam_names order), then second moments
   int64_t mv_total = 0;
-  double* bn_acc = nullptr;  // [2][kBnSlots][2*1024] float64 partial sums of the BatchNorm stages (one slot per BN pass; forward | backward)
+  double* bn_acc = nullptr;  // [2][kBnSlots][kBnStride] float64 partial sums of the BatchNorm stages (one slot per BN pass; forward | backward)
   int bn_slot = 0;
   bool fwd_acc_clean = false;  // the previous forward's last launch zeroed all accumulators (no memset launch in a step)
   bool bwd_acc_clean = false;  // the forward zeroed the backward half too; false after a backward used it (a second backward memsets)
@@ -84,6 +85,19 @@ static void pn_train_free(void* p);
 static int pn_train_bind(t2l_ctx* ctx, TrainState* st, std::vector<std::string>& adam);
 
 static TrainState* state(t2l_ctx* ctx) { return reinterpret_cast<TrainState*>(ctx->train); }
+
+// ---- cross-rank BatchNorm statistics (t2l_train_sync_bn): slots [0, 2 kBnSlots) are the object branch's (forward | backward), the two
+// behind them the text head's inter_mlp (forward, backward)
+int64_t train_sync_bn_doubles() { return (int64_t)(2 * kBnSlots + 2) * kBnStride; }
+void train_sync_changed(t2l_ctx* ctx) {
+  if (TrainState* st = state(ctx)) st->fwd_acc_clean = st->bwd_acc_clean = false;
+}
+static double* acc_base(t2l_ctx* ctx, TrainState* st) { return ctx->sync_fn ? ctx->sync_buf : st->bn_acc; }
+// sum `slots` consecutive accumulator slots over the ranks (between a statistics launch and its apply launch)
+static void sync_slots(t2l_ctx* ctx, double* first, int slots, hipStream_t s) {
+  if (!ctx->sync_fn) return;
+  if (ctx->sync_fn(ctx->sync_user, first, (int64_t)slots * kBnStride, (void*)s) != 0) ctx->sync_failed = true;
+}
 
 void free_train(t2l_ctx* ctx) {
   TrainState* st = state(ctx);
@@ -294,7 +308,8 @@ int train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const 
   std::vector<AdamChunk> cs;
   int64_t total = 0;
   for (auto& nme : P) total += st->t[nme].numel;
-  T2L_HIP(ctx, hipMalloc(&st->bn_acc, sizeof(double) * 2 * 1024 * kBnSlots * 2));  // slots of the forward, then of the backward
+  T2L_HIP(ctx, hipMalloc(&st->bn_acc, sizeof(double) * kBnStride * kBnSlots * 2));  // slots of the forward, then of the backward
+  st->ctx = ctx;
   T2L_HIP(ctx, hipMalloc(&st->mv, sizeof(float) * 2 * (size_t)total));
   T2L_HIP(ctx, hipMemset(st->mv, 0, sizeof(float) * 2 * (size_t)total));
   st->mv_total = total;
@@ -334,12 +349,14 @@ static void mlp_layer_fwd(TrainState* st, MlpLayer& L, const float* x, int M, in
                        1826.6844940968194f, 2516.8905096993817f, L.y);
   else
     gemm_nt(x, W.data, b.data, L.y, M, L.cout, L.cin, 0, s);
-  double* acc = st->bn_acc + (size_t)(st->bn_slot++ % (2 * kBnSlots)) * 2048;
+  const int sync = st->ctx->sync_fn ? 1 : 0;
+  double* acc = acc_base(st->ctx, st) + (size_t)(st->bn_slot++ % (2 * kBnSlots)) * kBnStride;
   hipLaunchKernelGGL((bn_stats_kernel<0>), dim3(L.cout / 64, (M + kBnRows - 1) / kBnRows), dim3(256), 0, s, L.y, (const float*)nullptr,
-                     (const float*)nullptr, M, L.cout, (const float*)nullptr, (const float*)nullptr, acc);
+                     (const float*)nullptr, M, L.cout, (const float*)nullptr, (const float*)nullptr, acc, sync, (float*)nullptr, (float*)nullptr);
+  sync_slots(st->ctx, acc, 1, s);
   hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)(((size_t)M * L.cout + 255) / 256)), dim3(256), 0, s, L.y, M, L.cout, acc,
                      T_(st, L.prefix + ".1.weight").data, T_(st, L.prefix + ".1.bias").data, T_(st, L.prefix + ".1.running_mean").data,
-                     T_(st, L.prefix + ".1.running_var").data, 0.1f, L.a, L.mean, L.rstd);
+                     T_(st, L.prefix + ".1.running_var").data, 0.1f, L.a, L.mean, L.rstd, sync);
 }
 
 static MlpLayer make_layer(TrainState* st, const std::string& prefix, int cin, int cout, int M) {
@@ -356,12 +373,13 @@ static MlpLayer make_layer(TrainState* st, const std::string& prefix, int cin, i
 
 // ---- the small feature branches (position, point count, colour: [K -> 64 -> 256] + normalize, identical shapes) stage by stage,
 // every stage ONE launch over all of them (kMaxJobs = 3): 7 launches instead of 7 per branch, forward and backward
-static BnJob bn_job(TrainState* st, const MlpLayer& L, float* d) {
+// slot: the launch's jobs take CONSECUTIVE accumulator slots (one cross-rank sum covers them)
+static BnJob bn_job(TrainState* st, const MlpLayer& L, float* d, int slot) {
   BnJob j{};
   j.y = L.y;
   j.out = L.a;
   j.d = d;
-  j.acc = st->bn_acc + (size_t)(st->bn_slot++ % (2 * kBnSlots)) * 2048;
+  j.acc = acc_base(st->ctx, st) + (size_t)(slot % (2 * kBnSlots)) * kBnStride;
   j.gamma = T_(st, L.prefix + ".1.weight").data;
   j.beta = T_(st, L.prefix + ".1.bias").data;
   j.run_mean = T_(st, L.prefix + ".1.running_mean").data;
@@ -383,6 +401,9 @@ static void small_branches_fwd(TrainState* st, const std::vector<int>& which, in
   b0.C = 64;
   b1.C = kTD;
   b0.momentum = b1.momentum = 0.1f;
+  b0.sync = b1.sync = st->ctx->sync_fn ? 1 : 0;
+  const int slot0 = st->bn_slot, slot1 = st->bn_slot + n;
+  st->bn_slot += 2 * n;
   GemmMulti gm{};
   RownormMulti rn{};
   rn.M = M;
@@ -396,18 +417,20 @@ static void small_branches_fwd(TrainState* st, const std::vector<int>& which, in
     sk.j[q].w = T_(st, L0.prefix + ".0.weight").data;
     sk.j[q].b = T_(st, L0.prefix + ".0.bias").data;
     sk.j[q].y = L0.y;
-    b0.j[q] = bn_job(st, L0, nullptr);
+    b0.j[q] = bn_job(st, L0, nullptr, slot0 + q);
     gm.j[q] = GemmArgs{L0.a, T_(st, L1.prefix + ".0.weight").data, L1.y, T_(st, L1.prefix + ".0.bias").data, M, kTD, 64, 64, 64, kTD, 0, 0, 64,
                        nullptr, tl_gemm_bf16};
-    b1.j[q] = bn_job(st, L1, nullptr);
+    b1.j[q] = bn_job(st, L1, nullptr, slot1 + q);
     rn.j[q] = RownormJob{L1.a, nullptr, st->cat + br.slot * kTD, nullptr, br.save_n};
   }
   hipLaunchKernelGGL(smallk_fwd_multi_kernel, dim3((M * 64 + 255) / 256, n), dim3(256), 0, s, sk);
   hipLaunchKernelGGL((bn_stats_multi_kernel<0>), dim3(1, (M + kBnRows - 1) / kBnRows, n), dim3(256), 0, s, b0);
+  sync_slots(st->ctx, b0.j[0].acc, n, s);
   hipLaunchKernelGGL(bn_apply_fwd_multi_kernel, dim3((unsigned)(((size_t)M * 64 + 255) / 256), n), dim3(256), 0, s, b0);
   gm.j[0].xcd_bands = tl_xcd_bands;
   hipLaunchKernelGGL((gemm_multi_kernel<true, true>), dim3(kTD / 32, (M + 31) / 32, n), dim3(256), 0, s, gm);
   hipLaunchKernelGGL((bn_stats_multi_kernel<0>), dim3(kTD / 64, (M + kBnRows - 1) / kBnRows, n), dim3(256), 0, s, b1);
+  sync_slots(st->ctx, b1.j[0].acc, n, s);
   hipLaunchKernelGGL(bn_apply_fwd_multi_kernel, dim3((unsigned)(((size_t)M * kTD + 255) / 256), n), dim3(256), 0, s, b1);
   hipLaunchKernelGGL(rownorm_fwd_multi_kernel, dim3((M + 3) / 4, n), dim3(256), 0, s, rn);
 }
@@ -422,6 +445,9 @@ static void small_branches_bwd(TrainState* st, const std::vector<int>& which, in
   b0.M = b1.M = M;
   b0.C = 64;
   b1.C = kTD;
+  b0.sync = b1.sync = st->ctx->sync_fn ? 1 : 0;
+  const int slot1 = st->bn_slot, slot0 = st->bn_slot + n;
+  st->bn_slot += 2 * n;
   GemmPairMulti gp{};
   SmallkMulti sk{};
   sk.M = M;
@@ -440,7 +466,7 @@ static void small_branches_bwd(TrainState* st, const std::vector<int>& which, in
     float* dq2 = d2 + (size_t)q * M * kTD;
     float* dq1 = d1 + (size_t)q * M * 64;
     rn.j[q] = RownormJob{dcat + br.slot * kTD, nullptr, dq2, st->cat + br.slot * kTD, br.save_n};
-    b1.j[q] = bn_job(st, L1, dq2);
+    b1.j[q] = bn_job(st, L1, dq2, slot1 + q);
     GemmPair& p = gp.p[q];
     p.tn = GemmArgs{dq2, L0.a, T_(st, L1.prefix + ".0.weight").grad, nullptr, N, Kp, M, N, Kp, Kp, 0, 1, kchunk,
                     T_(st, L1.prefix + ".0.bias").grad, tl_gemm_bf16};
@@ -450,7 +476,7 @@ static void small_branches_bwd(TrainState* st, const std::vector<int>& which, in
     p.tn_blocks = p.tn_gx * p.tn_gy * ksplit;
     p.nn_gx = Kp / 32;
     pair_blocks = p.tn_blocks + p.nn_gx * ((M + 31) / 32);
-    b0.j[q] = bn_job(st, L0, dq1);
+    b0.j[q] = bn_job(st, L0, dq1, slot0 + q);
     sk.j[q].x = br.x;
     sk.j[q].K = br.k_in;
     sk.j[q].standardize = br.standardize;
@@ -460,10 +486,12 @@ static void small_branches_bwd(TrainState* st, const std::vector<int>& which, in
   }
   hipLaunchKernelGGL(rownorm_bwd_multi_kernel, dim3((M + 3) / 4, n), dim3(256), 0, s, rn);
   hipLaunchKernelGGL((bn_stats_multi_kernel<1>), dim3(kTD / 64, (M + kBnRows - 1) / kBnRows, n), dim3(256), 0, s, b1);
+  sync_slots(st->ctx, b1.j[0].acc, n, s);
   hipLaunchKernelGGL(bn_apply_bwd_multi_kernel, dim3((unsigned)(((size_t)M * kTD + 255) / 256), n), dim3(256), 0, s, b1);
   gp.p[0].tn.xcd_bands = tl_xcd_bands;
   hipLaunchKernelGGL(gemm_pair_multi_kernel, dim3(pair_blocks, n), dim3(256), 0, s, gp);
   hipLaunchKernelGGL((bn_stats_multi_kernel<1>), dim3(1, (M + kBnRows - 1) / kBnRows, n), dim3(256), 0, s, b0);
+  sync_slots(st->ctx, b0.j[0].acc, n, s);
   hipLaunchKernelGGL(bn_apply_bwd_multi_kernel, dim3((unsigned)(((size_t)M * 64 + 255) / 256), n), dim3(256), 0, s, b0);
   hipLaunchKernelGGL(smallk_bwd_multi_kernel, dim3((M + 31) / 32, n), dim3(256), 0, s, sk);
 }
@@ -507,7 +535,8 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
   st->bn_slot = 0;
   // the accumulators are cleared by the previous forward's last launch (pool_norm_fwd_kernel); a memset only the first time or after
   // a forward that did not get that far
-  if (!st->fwd_acc_clean) T2L_HIP(ctx, hipMemsetAsync(st->bn_acc, 0, sizeof(double) * 2048 * kBnSlots, s));
+  ctx->sync_failed = false;
+  if (!st->fwd_acc_clean) T2L_HIP(ctx, hipMemsetAsync(acc_base(ctx, st), 0, sizeof(double) * kBnStride * kBnSlots, s));
   st->fwd_acc_clean = false;
 
   st->cat = bump<float>(st, (size_t)M * Kc);
@@ -613,13 +642,14 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
   st->out = bump<float>(st, (size_t)B * kTD);
   st->pool_n = bump<float>(st, B);
   st->pool_arg = bump<int32_t>(st, (size_t)B * kTD);
-  hipLaunchKernelGGL(pool_norm_fwd_kernel, dim3(B), dim3(256), 0, s, x, st->out, st->pool_arg, st->pool_n, out_emb, st->bn_acc,
-                     2048 * kBnSlots * 2);
+  hipLaunchKernelGGL(pool_norm_fwd_kernel, dim3(B), dim3(256), 0, s, x, st->out, st->pool_arg, st->pool_n, out_emb, acc_base(ctx, st),
+                     kBnStride * kBnSlots * 2);
   event_end(ctx, "train_forward", s);
   T2L_HIP(ctx, hipGetLastError());
   st->fwd_acc_clean = true;
   st->bwd_acc_clean = true;
   if (st->ws_off > st->ws_cap) return fail(ctx, T2L_ENOMEM, "t2l_encode_cells_train: workspace bound exceeded (internal error)");
+  if (ctx->sync_failed) return fail(ctx, T2L_ESTATE, "t2l_encode_cells_train: the cross-rank sum callback (t2l_train_sync_bn) failed");
   st->have_forward = true;
   return T2L_OK;
 }
@@ -628,11 +658,15 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
 // d: gradient w.r.t. the block's ReLU output [M,cout] (overwritten); x: the block's input; dx (optional) receives d W.
 static void mlp_layer_bwd(TrainState* st, const MlpLayer& L, float* d, const float* x, int M, int small_k, int standardize, float* dx,
                           hipStream_t s) {
-  double* acc = st->bn_acc + (size_t)(st->bn_slot++ % (2 * kBnSlots)) * 2048;
+  const int sync = st->ctx->sync_fn ? 1 : 0;
+  double* acc = acc_base(st->ctx, st) + (size_t)(st->bn_slot++ % (2 * kBnSlots)) * kBnStride;
   hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(L.cout / 64, (M + kBnRows - 1) / kBnRows), dim3(256), 0, s, L.y, (const float*)d, (const float*)L.a,
-                     M, L.cout, (const float*)L.mean, (const float*)L.rstd, acc);
+                     M, L.cout, (const float*)L.mean, (const float*)L.rstd, acc, sync, T_(st, L.prefix + ".1.weight").grad,
+                     T_(st, L.prefix + ".1.bias").grad);
+  sync_slots(st->ctx, acc, 1, s);
   hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((unsigned)(((size_t)M * L.cout + 255) / 256)), dim3(256), 0, s, d, L.a, L.y, M, L.cout, acc,
-                     T_(st, L.prefix + ".1.weight").data, L.mean, L.rstd, T_(st, L.prefix + ".1.weight").grad, T_(st, L.prefix + ".1.bias").grad);
+                     T_(st, L.prefix + ".1.weight").data, L.mean, L.rstd, T_(st, L.prefix + ".1.weight").grad, T_(st, L.prefix + ".1.bias").grad,
+                     sync);
   if (small_k) {
     const int rows = 32;
     hipLaunchKernelGGL(smallk_bwd_kernel, dim3((M + rows - 1) / rows), dim3(256), 0, s, x, M, small_k, d, standardize, 1826.6844940968194f,
@@ -657,7 +691,9 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   const size_t mark = st->ws_off;
   event_begin(ctx, "train_backward", s);
   st->bn_slot = kBnSlots;  // the backward's half of the accumulators: zeroed by the forward's memset, unless this is a second backward
-  if (!st->bwd_acc_clean) T2L_HIP(ctx, hipMemsetAsync(st->bn_acc + (size_t)kBnSlots * 2048, 0, sizeof(double) * 2048 * kBnSlots, s));
+  ctx->sync_failed = false;
+  if (!st->bwd_acc_clean)
+    T2L_HIP(ctx, hipMemsetAsync(acc_base(ctx, st) + (size_t)kBnSlots * kBnStride, 0, sizeof(double) * kBnStride * kBnSlots, s));
   st->bwd_acc_clean = false;
   float* dcur = bump<float>(st, (size_t)T * kTD);
   float* dA = bump<float>(st, (size_t)T * kTD);
@@ -745,6 +781,7 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   event_end(ctx, "train_backward", s);
   st->ws_off = mark;
   T2L_HIP(ctx, hipGetLastError());
+  if (ctx->sync_failed) return fail(ctx, T2L_ESTATE, "t2l_encode_cells_backward: the cross-rank sum callback (t2l_train_sync_bn) failed");
   return T2L_OK;
 }
 
@@ -1064,9 +1101,20 @@ int text_train_forward_impl(t2l_ctx* ctx, const float* hidden, int n_sent, int L
   st->bn_mean = tbump<float>(st, 256);
   st->bn_rstd = tbump<float>(st, 256);
   t_gemm_nt(st, st->pooled, TT(st, "inter_mlp.0.0.weight").data, TT(st, "inter_mlp.0.0.bias").data, st->mlp_y, n_sent, 256, 1024, 0, s);
-  hipLaunchKernelGGL(bn_plain_fwd_kernel, dim3(64), dim3(256), 0, s, (const float*)st->mlp_y, n_sent, 256, TT(st, "inter_mlp.0.1.weight").data,
-                     TT(st, "inter_mlp.0.1.bias").data, TT(st, "inter_mlp.0.1.running_mean").data, TT(st, "inter_mlp.0.1.running_var").data, 0.1f,
-                     st->mlp_out, st->bn_mean, st->bn_rstd);
+#define T2L_TEXT_BN_FWD(PHASE, ACC)                                                                                                       \
+  hipLaunchKernelGGL((bn_plain_fwd_kernel<PHASE>), dim3(64), dim3(256), 0, s, (const float*)st->mlp_y, n_sent, 256,                       \
+                     TT(st, "inter_mlp.0.1.weight").data, TT(st, "inter_mlp.0.1.bias").data, TT(st, "inter_mlp.0.1.running_mean").data,   \
+                     TT(st, "inter_mlp.0.1.running_var").data, 0.1f, st->mlp_out, st->bn_mean, st->bn_rstd, ACC)
+  if (ctx->sync_fn) {  // statistics | sum over the ranks | apply (t2l_train_sync_bn)
+    double* acc = ctx->sync_buf + (size_t)(2 * kBnSlots) * kBnStride;
+    ctx->sync_failed = false;
+    T2L_TEXT_BN_FWD(1, acc);
+    sync_slots(ctx, acc, 1, s);
+    T2L_TEXT_BN_FWD(2, acc);
+  } else {
+    T2L_TEXT_BN_FWD(0, (double*)nullptr);
+  }
+#undef T2L_TEXT_BN_FWD
   TextLayer& I = st->inter;
   I = TextLayer{};
   I.prefix = "inter_module.0"; I.T = n_sent; I.B = n_desc; I.S = S; I.site0 = 4; I.x_in = st->mlp_out;
@@ -1080,6 +1128,7 @@ int text_train_forward_impl(t2l_ctx* ctx, const float* hidden, int n_sent, int L
   event_end(ctx, "text_train_forward", s);
   T2L_HIP(ctx, hipGetLastError());
   if (st->ws_off > st->ws_cap) return fail(ctx, T2L_ENOMEM, "t2l_text_head_train: workspace bound exceeded (internal error)");
+  if (ctx->sync_failed) return fail(ctx, T2L_ESTATE, "t2l_text_head_train: the cross-rank sum callback (t2l_train_sync_bn) failed");
   st->have_forward = true;
   return T2L_OK;
 }
@@ -1101,8 +1150,20 @@ int text_train_backward_impl(t2l_ctx* ctx, const float* grad_out, hipStream_t s)
   float* dX = text_layer_bwd<256>(st, st->inter, dY2, true, s);
   hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)(((size_t)n_sent * 256 + 255) / 256)), dim3(256), 0, s, dX, (const float*)dY2, (size_t)n_sent * 256);
   // inter_mlp: BatchNorm (batch statistics), Linear
-  hipLaunchKernelGGL(bn_plain_bwd_kernel, dim3(64), dim3(256), 0, s, dX, (const float*)st->mlp_y, n_sent, 256, TT(st, "inter_mlp.0.1.weight").data,
-                     (const float*)st->bn_mean, (const float*)st->bn_rstd, TT(st, "inter_mlp.0.1.weight").grad, TT(st, "inter_mlp.0.1.bias").grad);
+#define T2L_TEXT_BN_BWD(PHASE, ACC)                                                                                                    \
+  hipLaunchKernelGGL((bn_plain_bwd_kernel<PHASE>), dim3(64), dim3(256), 0, s, dX, (const float*)st->mlp_y, n_sent, 256,                 \
+                     TT(st, "inter_mlp.0.1.weight").data, (const float*)st->bn_mean, (const float*)st->bn_rstd,                         \
+                     TT(st, "inter_mlp.0.1.weight").grad, TT(st, "inter_mlp.0.1.bias").grad, ACC)
+  if (ctx->sync_fn) {
+    double* acc = ctx->sync_buf + (size_t)(2 * kBnSlots + 1) * kBnStride;
+    ctx->sync_failed = false;
+    T2L_TEXT_BN_BWD(1, acc);
+    sync_slots(ctx, acc, 1, s);
+    T2L_TEXT_BN_BWD(2, acc);
+  } else {
+    T2L_TEXT_BN_BWD(0, (double*)nullptr);
+  }
+#undef T2L_TEXT_BN_BWD
   float* dpool = tbump<float>(st, (size_t)n_sent * 1024);
   t_gemm_tn_nn(st, dX, st->pooled, TT(st, "inter_mlp.0.0.weight").grad, TT(st, "inter_mlp.0.0.bias").grad, TT(st, "inter_mlp.0.0.weight").data, dpool,
                n_sent, 256, 1024, 0, nullptr, nullptr, s);
@@ -1116,6 +1177,7 @@ int text_train_backward_impl(t2l_ctx* ctx, const float* grad_out, hipStream_t s)
   st->ws_off = mark;
   T2L_HIP(ctx, hipGetLastError());
   if (over) return fail(ctx, T2L_ENOMEM, "t2l_text_head_backward: workspace bound exceeded (internal error)");
+  if (ctx->sync_failed) return fail(ctx, T2L_ESTATE, "t2l_text_head_backward: the cross-rank sum callback (t2l_train_sync_bn) failed");
   return T2L_OK;
 }
 

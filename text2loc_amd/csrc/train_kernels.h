@@ -140,11 +140,16 @@ __global__ __launch_bounds__(256) void smallk_bwd_multi_kernel(SmallkMulti m) {
 // unbiased variance (momentum 0.1), as torch does.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kBnRows = 64;
+// One accumulator slot: [2 * 1024] channel sums + the ROW COUNT at kBnCount (cross-rank BatchNorm only, `sync`: the slot is summed over
+// the ranks between the statistics and the apply launch — t2l_train_sync_bn — and the apply side then divides by the global count).
+constexpr int kBnCount = 2048;
+constexpr int kBnStride = 2056;
 // MODE 0: acc[c] += sum y, acc[C+c] += sum y^2.  MODE 1: dv = out>0 ? d : 0; acc[c] += sum dv, acc[C+c] += sum dv*xhat
 template <int MODE>
 __device__ __forceinline__ void bn_stats_body(const float* __restrict__ y, const float* __restrict__ d, const float* __restrict__ out, int M,
                                               int C, const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
-                                              double* __restrict__ acc, unsigned bx, unsigned by) {
+                                              double* __restrict__ acc, unsigned bx, unsigned by, int sync = 0,
+                                              float* __restrict__ dgamma = nullptr, float* __restrict__ dbeta = nullptr) {
   __shared__ float r1[256], r2[256];
   const int c = bx * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
   const int lo = by * kBnRows, hi = min(M, lo + kBnRows);
@@ -172,16 +177,28 @@ __device__ __forceinline__ void bn_stats_body(const float* __restrict__ y, const
   __syncthreads();
   if (g == 0) {
     const int t = threadIdx.x;
-    atomicAdd(acc + c, (double)r1[t] + (double)r1[t + 64] + (double)r1[t + 128] + (double)r1[t + 192]);
-    atomicAdd(acc + C + c, (double)r2[t] + (double)r2[t + 64] + (double)r2[t + 128] + (double)r2[t + 192]);
+    const double t1 = (double)r1[t] + (double)r1[t + 64] + (double)r1[t + 128] + (double)r1[t + 192];
+    const double t2 = (double)r2[t] + (double)r2[t + 64] + (double)r2[t + 128] + (double)r2[t + 192];
+    atomicAdd(acc + c, t1);
+    atomicAdd(acc + C + c, t2);
+    if (sync) {
+      // cross-rank statistics: the slot will hold GLOBAL sums when the apply launch reads it, and the parameter gradients are this
+      // rank's own sums (the gradient all_reduce adds the ranks' up) — so they are taken here, not in the apply launch
+      if (MODE == 1) {
+        unsafeAtomicAdd(dgamma + c, (float)t2);
+        unsafeAtomicAdd(dbeta + c, (float)t1);
+      }
+      if (bx == 0 && by == 0 && t == 0) atomicAdd(acc + kBnCount, (double)M);
+    }
   }
 }
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, const float* __restrict__ d,
                                                        const float* __restrict__ out, int M, int C,
                                                        const float* __restrict__ save_mean,
-                                                       const float* __restrict__ save_rstd, double* __restrict__ acc) {
-  bn_stats_body<MODE>(y, d, out, M, C, save_mean, save_rstd, acc, blockIdx.x, blockIdx.y);
+                                                       const float* __restrict__ save_rstd, double* __restrict__ acc, int sync,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  bn_stats_body<MODE>(y, d, out, M, C, save_mean, save_rstd, acc, blockIdx.x, blockIdx.y, sync, dgamma, dbeta);
 }
 // one BatchNorm layer of one branch: everything the statistics / apply kernels of either direction need
 struct BnJob {
@@ -196,33 +213,35 @@ struct BnMulti {
   BnJob j[kMaxJobs];
   int M, C;
   float momentum;
+  int sync;
 };
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_stats_multi_kernel(BnMulti m) {
   const BnJob& j = m.j[blockIdx.z];
-  bn_stats_body<MODE>(j.y, j.d, j.out, m.M, m.C, j.save_mean, j.save_rstd, j.acc, blockIdx.x, blockIdx.y);
+  bn_stats_body<MODE>(j.y, j.d, j.out, m.M, m.C, j.save_mean, j.save_rstd, j.acc, blockIdx.x, blockIdx.y, m.sync, j.dgamma, j.dbeta);
 }
 __device__ __forceinline__ void bn_apply_fwd_body(const float* __restrict__ y, int M, int C, const double* __restrict__ acc,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   float* __restrict__ run_mean, float* __restrict__ run_var, float momentum,
                                                   float* __restrict__ out, float* __restrict__ save_mean, float* __restrict__ save_rstd,
-                                                  unsigned bx) {
+                                                  unsigned bx, int sync = 0) {
   const size_t i = (size_t)bx * 256 + threadIdx.x;
+  const double Mg = sync ? acc[kBnCount] : (double)M;  // rows behind the sums: this rank's, or every rank's
   if (i < (size_t)M * C) {
     const int c = (int)(i % C);
-    const double mean = acc[c] / M;
-    const double var = fmax(acc[C + c] / M - mean * mean, 0.0);
+    const double mean = acc[c] / Mg;
+    const double var = fmax(acc[C + c] / Mg - mean * mean, 0.0);
     const float rstd = 1.0f / sqrtf((float)var + kBnEps);
     out[i] = fmaxf((y[i] - (float)mean) * rstd * gamma[c] + beta[c], 0.f);
   }
   if (bx == 0)
     for (int c = threadIdx.x; c < C; c += 256) {
-      const double mean = acc[c] / M;
-      const double var = fmax(acc[C + c] / M - mean * mean, 0.0);
+      const double mean = acc[c] / Mg;
+      const double var = fmax(acc[C + c] / Mg - mean * mean, 0.0);
       save_mean[c] = (float)mean;
       save_rstd[c] = 1.0f / sqrtf((float)var + kBnEps);
       run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
-      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * ((double)M / (double)max(M - 1, 1)));
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * (Mg / fmax(Mg - 1.0, 1.0)));
     }
 }
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ y, int M, int C,
@@ -230,26 +249,27 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ run_mean, float* __restrict__ run_var,
                                                            float momentum, float* __restrict__ out,
-                                                           float* __restrict__ save_mean, float* __restrict__ save_rstd) {
-  bn_apply_fwd_body(y, M, C, acc, gamma, beta, run_mean, run_var, momentum, out, save_mean, save_rstd, blockIdx.x);
+                                                           float* __restrict__ save_mean, float* __restrict__ save_rstd, int sync) {
+  bn_apply_fwd_body(y, M, C, acc, gamma, beta, run_mean, run_var, momentum, out, save_mean, save_rstd, blockIdx.x, sync);
 }
 __global__ __launch_bounds__(256) void bn_apply_fwd_multi_kernel(BnMulti m) {
   const BnJob& j = m.j[blockIdx.y];
-  bn_apply_fwd_body(j.y, m.M, m.C, j.acc, j.gamma, j.beta, j.run_mean, j.run_var, m.momentum, j.out, j.save_mean, j.save_rstd, blockIdx.x);
+  bn_apply_fwd_body(j.y, m.M, m.C, j.acc, j.gamma, j.beta, j.run_mean, j.run_var, m.momentum, j.out, j.save_mean, j.save_rstd, blockIdx.x, m.sync);
 }
 // d: gradient w.r.t. the ReLU output (in), overwritten with the gradient w.r.t. the Linear output y.
 __device__ __forceinline__ void bn_apply_bwd_body(float* __restrict__ d, const float* __restrict__ out, const float* __restrict__ y, int M,
                                                   int C, const double* __restrict__ acc, const float* __restrict__ gamma,
                                                   const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
-                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, unsigned bx) {
+                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, unsigned bx, int sync = 0) {
   const size_t i = (size_t)bx * 256 + threadIdx.x;
   if (i < (size_t)M * C) {
     const int c = (int)(i % C);
+    const float Mg = sync ? (float)acc[kBnCount] : (float)M;
     const float rstd = save_rstd[c], s1 = (float)acc[c], s2 = (float)acc[C + c];
     const float dv = out[i] > 0.f ? d[i] : 0.f;
-    d[i] = gamma[c] * rstd / (float)M * ((float)M * dv - s1 - (y[i] - save_mean[c]) * rstd * s2);
+    d[i] = gamma[c] * rstd / Mg * (Mg * dv - s1 - (y[i] - save_mean[c]) * rstd * s2);
   }
-  if (bx == 0)
+  if (bx == 0 && !sync)  // (sync: the statistics launch took this rank's own sums)
     for (int c = threadIdx.x; c < C; c += 256) {
       unsafeAtomicAdd(dgamma + c, (float)acc[C + c]);
       unsafeAtomicAdd(dbeta + c, (float)acc[c]);
@@ -260,12 +280,12 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(float* __restrict__ d
                                                            const double* __restrict__ acc, const float* __restrict__ gamma,
                                                            const float* __restrict__ save_mean,
                                                            const float* __restrict__ save_rstd, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta) {
-  bn_apply_bwd_body(d, out, y, M, C, acc, gamma, save_mean, save_rstd, dgamma, dbeta, blockIdx.x);
+                                                           float* __restrict__ dbeta, int sync) {
+  bn_apply_bwd_body(d, out, y, M, C, acc, gamma, save_mean, save_rstd, dgamma, dbeta, blockIdx.x, sync);
 }
 __global__ __launch_bounds__(256) void bn_apply_bwd_multi_kernel(BnMulti m) {
   const BnJob& j = m.j[blockIdx.y];
-  bn_apply_bwd_body(j.d, j.out, j.y, m.M, m.C, j.acc, j.gamma, j.save_mean, j.save_rstd, j.dgamma, j.dbeta, blockIdx.x);
+  bn_apply_bwd_body(j.d, j.out, j.y, m.M, m.C, j.acc, j.gamma, j.save_mean, j.save_rstd, j.dgamma, j.dbeta, blockIdx.x, m.sync);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1005,58 +1025,95 @@ __device__ __forceinline__ void bn4_reduce(double s1, double s2, double (*red)[4
   }
   __syncthreads();
 }
+// PHASE 0: statistics + apply in one launch. Cross-rank statistics (t2l_train_sync_bn) split it: PHASE 1 stores this rank's sums and row
+// count into the slot `acc` (plain stores: a column has one owner), the host sums the slot over the ranks, PHASE 2 applies from it.
+template <int PHASE = 0>
 __global__ __launch_bounds__(256) void bn_plain_fwd_kernel(const float* __restrict__ y, int M, int C, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ run_mean,
                                                            float* __restrict__ run_var, float momentum, float* __restrict__ out,
-                                                           float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+                                                           float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                           double* __restrict__ acc = nullptr) {
   __shared__ double red[64][4][2];
   const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2, c = blockIdx.x * 4 + cl;
-  double s1 = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int m = rl; m < M; m += 64) {
-      const double v = y[(size_t)m * C + c];
-      s1 += v;
-      s2 += v * v;
+  double t1, t2, Mg = (double)M;
+  if (PHASE != 2) {
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+      for (int m = rl; m < M; m += 64) {
+        const double v = y[(size_t)m * C + c];
+        s1 += v;
+        s2 += v * v;
+      }
+    bn4_reduce(s1, s2, red, cl, rl, t1, t2);
+  }
+  if (PHASE == 1) {
+    if (c < C && rl == 0) {
+      acc[c] = t1;
+      acc[C + c] = t2;
     }
-  double t1, t2;
-  bn4_reduce(s1, s2, red, cl, rl, t1, t2);
+    if (blockIdx.x == 0 && threadIdx.x == 0) acc[kBnCount] = (double)M;
+    return;
+  }
   if (c >= C) return;
-  const double mean = t1 / M, var = fmax(t2 / M - mean * mean, 0.0);
+  if (PHASE == 2) {
+    t1 = acc[c];
+    t2 = acc[C + c];
+    Mg = acc[kBnCount];
+  }
+  const double mean = t1 / Mg, var = fmax(t2 / Mg - mean * mean, 0.0);
   const float rstd = 1.0f / sqrtf((float)var + kBnEps), g = gamma[c], be = beta[c];
   for (int m = rl; m < M; m += 64) out[(size_t)m * C + c] = (y[(size_t)m * C + c] - (float)mean) * rstd * g + be;
   if (rl == 0) {
     save_mean[c] = (float)mean;
     save_rstd[c] = rstd;
     run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
-    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * ((double)M / (double)max(M - 1, 1)));
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * (Mg / fmax(Mg - 1.0, 1.0)));
   }
 }
-// d: gradient w.r.t. the BatchNorm output (in), overwritten with the gradient w.r.t. its input y
+// d: gradient w.r.t. the BatchNorm output (in), overwritten with the gradient w.r.t. its input y. PHASE as above; the parameter
+// gradients are this rank's own sums in every phase form (the gradient all_reduce adds the ranks' up).
+template <int PHASE = 0>
 __global__ __launch_bounds__(256) void bn_plain_bwd_kernel(float* __restrict__ d, const float* __restrict__ y, int M, int C,
                                                            const float* __restrict__ gamma, const float* __restrict__ save_mean,
                                                            const float* __restrict__ save_rstd, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta) {
+                                                           float* __restrict__ dbeta, double* __restrict__ acc = nullptr) {
   __shared__ double red[64][4][2];
   const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2, c = blockIdx.x * 4 + cl;
   const float mean = c < C ? save_mean[c] : 0.f, rstd = c < C ? save_rstd[c] : 0.f;
-  double s1 = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int m = rl; m < M; m += 64) {
-      const float dv = d[(size_t)m * C + c];
-      s1 += dv;
-      s2 += dv * (y[(size_t)m * C + c] - mean) * rstd;
-    }
   double t1, t2;
-  bn4_reduce(s1, s2, red, cl, rl, t1, t2);
+  float Mg = (float)M;
+  if (PHASE != 2) {
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+      for (int m = rl; m < M; m += 64) {
+        const float dv = d[(size_t)m * C + c];
+        s1 += dv;
+        s2 += dv * (y[(size_t)m * C + c] - mean) * rstd;
+      }
+    bn4_reduce(s1, s2, red, cl, rl, t1, t2);
+    if (c < C && rl == 0) {
+      dgamma[c] += (float)t2;
+      dbeta[c] += (float)t1;
+    }
+  }
+  if (PHASE == 1) {
+    if (c < C && rl == 0) {
+      acc[c] = t1;
+      acc[C + c] = t2;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) acc[kBnCount] = (double)M;
+    return;
+  }
   if (c >= C) return;
+  if (PHASE == 2) {
+    t1 = acc[c];
+    t2 = acc[C + c];
+    Mg = (float)acc[kBnCount];
+  }
   const float f1 = (float)t1, f2 = (float)t2, g = gamma[c];
   for (int m = rl; m < M; m += 64) {
     const size_t i = (size_t)m * C + c;
-    d[i] = g * rstd / (float)M * ((float)M * d[i] - f1 - (y[i] - mean) * rstd * f2);
-  }
-  if (rl == 0) {
-    dgamma[c] += f2;
-    dbeta[c] += f1;
+    d[i] = g * rstd / Mg * (Mg * d[i] - f1 - (y[i] - mean) * rstd * f2);
   }
 }
 

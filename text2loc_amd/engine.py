@@ -88,6 +88,8 @@ EXPORTS = {
     "t2l_text_head_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_pointnet_features_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "t2l_pointnet_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "t2l_train_sync_bn_doubles": (C.c_int64, []),
+    "t2l_train_sync_bn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "t2l_zero_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
     "t2l_adam_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "t2l_adam_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
@@ -440,6 +442,49 @@ class Engine:
     def pointnet_backward(self, grad_features2: torch.Tensor):
         self._check(self.lib.t2l_pointnet_backward(self._h, self._ptr(grad_features2, torch.float32, "grad_features2"),
                                                    _stream_ptr(self.device)))
+
+    def train_sync_bn(self, group=None, enable: bool = True):
+        """Cross-rank BatchNorm statistics for data-parallel training (t2l.h: t2l_train_sync_bn): every BatchNorm of the object branch
+        and of the text head's inter_mlp normalises over the rows of ALL ranks of ``group`` — the reference's single-process batch
+        (training/coarse.py:31-58) split over GPUs. The sums travel through ``torch.distributed.all_reduce`` on the current stream (RCCL
+        on the node; gloo stages through the host). ``enable=False`` returns to per-rank statistics."""
+        if not enable:
+            self._check(self.lib.t2l_train_sync_bn(self._h, None, 0, None, None))
+            self._sync_bn = None
+            return
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            raise T2LError("train_sync_bn needs an initialised torch.distributed process group")
+        n = int(self.lib.t2l_train_sync_bn_doubles())
+        buf = torch.zeros(n, dtype=torch.float64, device=torch.device("cuda", self.device))
+        base = buf.data_ptr()
+        calls = [0]
+
+        def _sum(_user, ptr, count, _stream):
+            # (the engine enqueues on torch's current stream of its device, and so does all_reduce: stream order is the dependency)
+            try:
+                off = (int(ptr) - base) // 8
+                view = buf[off:off + int(count)]
+                if dist.get_backend(group) != "nccl":  # gloo (several processes on one GPU in the tests): staged through the host
+                    h = view.cpu()
+                    dist.all_reduce(h, group=group)
+                    view.copy_(h)
+                else:
+                    dist.all_reduce(view, group=group)
+                calls[0] += 1
+                return 0
+            except Exception:  # a Python exception cannot cross the C frame: the enclosing engine call fails with T2L_ESTATE
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)(_sum)
+        self._check(self.lib.t2l_train_sync_bn(self._h, buf.data_ptr(), n, C.cast(cb, C.c_void_p), None))
+        self._sync_bn = (buf, cb, calls)  # the library keeps raw pointers to both
+
+    def sync_bn_calls(self) -> int:
+        """Cross-rank sums issued since train_sync_bn (one per BatchNorm stage and direction)."""
+        return 0 if getattr(self, "_sync_bn", None) is None else self._sync_bn[2][0]
 
     def zero_grad(self):
         self._check(self.lib.t2l_zero_grad(self._h, _stream_ptr(self.device)))

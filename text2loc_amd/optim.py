@@ -34,9 +34,10 @@ def all_reduce_flat(buf: torch.Tensor, group=None, mean: bool = False) -> torch.
 
 class Adam(torch.optim.Optimizer):
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, group=None, grad_reduce: str = "sum",
-                 data_parallel: bool = False):
+                 data_parallel: bool = False, sync_bn: bool = False):
         """``group``: a torch.distributed process group, or ``data_parallel=True`` for the default one — turns the gradient
-        all-reduce of ``step()`` on."""
+        all-reduce of ``step()`` on. ``sync_bn``: also ``model.sync_batchnorm(group)`` — BatchNorm statistics over all ranks' batches,
+        i.e. the reference's one-process step on the global batch."""
         if grad_reduce not in ("sum", "mean"):
             raise ValueError("grad_reduce must be 'sum' or 'mean'")
         self._group, self._grad_reduce, self._dp = group, grad_reduce, bool(data_parallel) or group is not None
@@ -55,6 +56,8 @@ class Adam(torch.optim.Optimizer):
             groups.append({"params": rest, "t2l_engine": False})
         super().__init__(groups, dict(lr=lr, betas=tuple(betas), eps=eps))
         self._model = model
+        if sync_bn:
+            model.sync_batchnorm(group)
         self._torch = torch.optim.Adam(rest, lr=lr, betas=tuple(betas), eps=eps) if rest else None
 
     def zero_grad(self, set_to_none: bool = False):
