@@ -452,6 +452,11 @@ int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step,
  * "search_wide_repair" (default 512, at most 1024): rows a re-rank wave may re-score in float64 to settle a query whose certificate failed
  *                     (every kept key that reaches the threshold + every row of a list whose floor does) before the query is
  *                     handed to an exact scan of the whole shard; 0 = off (tests of the exact stages).
+ * "search_merge_lists" (default 2): the paired scan's candidate hand-off to the re-rank. 0 = four 24-byte lists per (query, workgroup);
+ *                     1 = ONE 32-byte record (the best 7 of their 24 keys, the source list in two more code bits, + a bound on every other
+ *                     key): a third of the bytes written back at the end of the launch, -0.7 us per step at Q = 4096; 2 = records while the
+ *                     report cards show fewer than 1 query in 64 failing its first certificate (a repair behind a record re-scores 4x the
+ *                     rows of a plain list's), plain lists otherwise. Results are bit-identical in every setting.
  * "search_pair_ll"    (default 6): per-lane list length of the paired scan (5: experiment, halves the certificate's margin).
  * "profile_events"    (default 0): n >= 1 records hipEvents around every n-th launch of each kernel (t2l_kernel_stats);
  *                     two records cost ~6 us of queue time per bracketed kernel, which matters beside a 30 us kernel.

@@ -619,3 +619,95 @@ def test_fused_launch_on_clustered_data_and_in_heavy_mode():
             assert (cnt["deferred_to_mfma_exact"] > 0) if heavy else (cnt["wide_repairs"] > 0), cnt
     finally:
         e.close()
+
+
+def _cluster_db(rng, n, clusters, alpha):
+    cent = synth.unit_rows(rng.standard_normal((clusters, 256)))
+    return synth.unit_rows(alpha * cent[rng.integers(0, clusters, size=n)] + synth.unit_rows(rng.standard_normal((n, 256)))).astype(np.float32)
+
+
+@pytest.mark.parametrize("kind,n,q,k", [("gauss", 11259, 4096, 10), ("gauss", 11259, 1000, 10), ("gauss", 1023, 257, 10), ("gauss", 4097, 300, 5),
+                                        ("clusters3", 11259, 2048, 10), ("clusters6", 6000, 700, 10), ("runs16", 11259, 1024, 10),
+                                        ("dups", 3000, 512, 10)])
+def test_merged_candidate_records_equal_the_plain_lists(kind, n, q, k):
+    """``search_merge_lists``: the paired scan hands the re-rank ONE 32-byte record per (query, workgroup) — the best 7 of the workgroup's
+    24 kept keys, the source list in two extra code bits, + a bound on everything else — instead of four 24-byte lists. Same ids, same
+    float64 scores bit for bit, on benign data, on clusters (where records overflow and the bound sends queries to the repairs), on runs
+    of 16 near-identical neighbouring rows (one lane's list overflows) and on exact duplicates (ties: lower row first)."""
+    import torch
+    from oracle import c_oracle
+    from text2loc_amd.engine import Engine
+
+    rng = np.random.default_rng(n + q)
+    if kind == "gauss":
+        db = synth.unit_rows(rng.standard_normal((n, 256))).astype(np.float32)
+    elif kind.startswith("clusters"):
+        db = _cluster_db(rng, n, 64, float(kind[8:]))
+    elif kind == "runs16":
+        base = synth.unit_rows(rng.standard_normal(((n + 15) // 16, 256)))
+        db = synth.unit_rows(3.0 * np.repeat(base, 16, axis=0)[:n] + synth.unit_rows(rng.standard_normal((n, 256)))).astype(np.float32)
+    else:
+        db = synth.unit_rows(rng.standard_normal((n, 256))).astype(np.float32)
+        db[rng.integers(0, n, size=n // 3)] = db[rng.integers(0, n, size=n // 3)]
+    qs = synth.unit_rows(db[rng.integers(0, n, size=q)].astype(np.float64) + 0.3 * synth.unit_rows(rng.standard_normal((q, 256)))).astype(np.float32)
+    ridx, rsc = c_oracle.retrieve_topk(db, qs, k)
+    e = Engine(0)
+    try:
+        e.set_option("search_auto", 0)
+        e.db_set(torch.from_numpy(db).cuda())
+        qd = torch.from_numpy(qs).cuda()
+        got = {}
+        for merge in (0, 1):
+            e.set_option("search_merge_lists", merge)
+            idx, sc = e.search(qd, k)
+            torch.cuda.synchronize()
+            got[merge] = (idx.cpu().numpy().astype(np.int64), sc.cpu().numpy(), e.search_counters())
+            assert np.array_equal(got[merge][0], ridx), (merge, got[merge][2])
+            assert np.abs(got[merge][1] - rsc).max() < 1e-12
+        assert np.array_equal(got[0][1], got[1][1])
+        if kind == "gauss":  # benign data: neither format needs a repair worth the name
+            assert got[0][2]["valu_exact_scans"] == 0 and got[1][2]["valu_exact_scans"] == 0 and got[1][2]["rescored"] <= 8, (got[0][2], got[1][2])
+    finally:
+        e.close()
+
+
+def test_merged_records_follow_the_report_card():
+    """Default (``search_merge_lists = 2``): merged records while next to no query fails its first certificate; a clustered database moves
+    the engine to plain lists within a few calls (a repair behind a merged record re-scores 4x the rows: the wide repair's cap sends those
+    queries to exact scans), and a benign database brings the records back. Results are the oracle's throughout."""
+    import torch
+    from oracle import c_oracle
+    from text2loc_amd.engine import Engine
+
+    rng = np.random.default_rng(5)
+    n, q = 11259, 2048
+    benign = synth.unit_rows(rng.standard_normal((n, 256))).astype(np.float32)
+    # runs of 16 neighbouring near-identical rows: eight of a run sit in ONE lane's list of six
+    base = synth.unit_rows(rng.standard_normal(((n + 15) // 16, 256)))
+    tight = synth.unit_rows(3.0 * np.repeat(base, 16, axis=0)[:n] + synth.unit_rows(rng.standard_normal((n, 256)))).astype(np.float32)
+    e = Engine(0)
+    try:
+        def calls(db, times):
+            qs = synth.unit_rows(db[rng.integers(0, n, size=q)].astype(np.float64) + 0.3 * synth.unit_rows(rng.standard_normal((q, 256)))).astype(np.float32)
+            ridx, _ = c_oracle.retrieve_topk(db, qs, 10)
+            e.db_set(torch.from_numpy(db).cuda())
+            qd = torch.from_numpy(qs).cuda()
+            out = []
+            for _ in range(times):
+                idx, _ = e.search(qd, 10)
+                torch.cuda.synchronize()
+                assert np.array_equal(idx.cpu().numpy().astype(np.int64), ridx)
+                out.append(e.search_counters())
+            return out
+
+        c = calls(benign, 3)
+        assert all(x["valu_exact_scans"] == 0 and x["wide_repairs"] == 0 for x in c), c
+        c = calls(tight, 6)
+        # the first calls run on merged records (overflowing records -> exact scans); once the report card is in, plain lists and
+        # their wide repairs take over
+        assert c[0]["valu_exact_scans"] > 100, [(x["valu_exact_scans"], x["wide_repairs"]) for x in c]
+        assert c[-1]["wide_repairs"] > 0 and c[-1]["valu_exact_scans"] < c[0]["valu_exact_scans"] // 2, [(x["valu_exact_scans"], x["wide_repairs"]) for x in c]
+        c = calls(benign, 4)
+        assert all(x["valu_exact_scans"] == 0 for x in c), c
+    finally:
+        e.close()

@@ -199,6 +199,7 @@ int t2l_db_set(t2l_ctx* ctx, const float* emb, int64_t n_rows, int64_t row_offse
     ctx->escalated = false;
     ctx->heavy = false;
     ctx->all_exact = false;
+    ctx->merge_live = true;
     ctx->stat_seen = ctx->stat_seq + 1;  // (the NEXT call's re-rank still publishes the report of the last call on the old rows)
   }
   ctx->db_pad = pad;
@@ -521,6 +522,7 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
       ctx->escalated = false;
       ctx->heavy = false;
       ctx->all_exact = false;
+      ctx->merge_live = true;
       ctx->stat_seen = ctx->stat_seq;
     }
   } else if (!strcmp(name, "search_heavy")) {  // force (1) / release (0) the float64 MFMA exact stage (tests)
@@ -537,6 +539,10 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
   } else if (!strcmp(name, "text_train_bf16")) {
     if (value != 0 && value != 1 && value != 2) return fail(ctx, T2L_EINVAL, "text_train_bf16: 0 (f32), 1 (bf16) or 2 (split-bf16)");
     ctx->text_train_bf16 = (int)value;
+  } else if (!strcmp(name, "search_merge_lists")) {
+    if (value != 0 && value != 1 && value != 2) return fail(ctx, T2L_EINVAL, "search_merge_lists: 0 (plain lists), 1 (merged records), 2 (default: by report card)");
+    ctx->search_merge = (int)value;
+    ctx->merge_live = true;
   } else if (!strcmp(name, "search_fused")) {
     ctx->search_fused = value != 0;
   } else if (!strcmp(name, "search_wide_repair")) {

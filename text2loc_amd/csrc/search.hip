@@ -553,13 +553,18 @@ constexpr int kFusedSpinMax = 1 << 15;  // x s_sleep(16) ~ 1 us each: ~30 ms, th
 template <int LL>
 __device__ void fused_rerank_tail(const FusedArgs& fa, float* smem, int qb, int sp, int nsplit, int Q);  // (defined behind rerank_query)
 
-template <int LL, int NS, bool PREP, bool FUSED = false>
+// MERGE: the workgroup's four lists per query (two lane halves x two waves, 24 keys) leave as ONE record of 8 floats — the best 7 keys,
+// re-keyed so that the source list rides in two more code bits, + a bound on every key that did not make it (kMergedLL; the
+// re-rank's MG form reads it): a third of the bytes written back at the end of the launch and read by the re-rank.
+constexpr int kMergedLL = 8;
+template <int LL, int NS, bool PREP, bool FUSED = false, bool MERGE = false>
 __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__ dbt, int n_rows, int n_tiles, int code_bits,
                                                        const float* __restrict__ q, const uint4* __restrict__ qplane, int Q, int nsplit,
                                                        float* __restrict__ cand, int32_t* __restrict__ fb_count, int32_t* __restrict__ fb_prev,
                                                        int zero_counts, float pinf, unsigned long long* __restrict__ span,
                                                        unsigned span_seq, int xcd_qgroups, const FusedArgs fa = FusedArgs{}) {
   static_assert(NS == 4, "the step loop below is unrolled for a ring of 4 slots");
+  static_assert(!MERGE || (LL == 6 && !FUSED), "the in-workgroup list merge is written for the two-launch search with lists of 6");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kSlotBytes = 2 * kHalfTileBytes;
   constexpr unsigned kExchange = 2 * kSlotBytes;  // slots 2.. double as the query exchange area (64 KiB) in the prologue
@@ -589,7 +594,11 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
   const int vn = 2 * nsplit, vs = sp + quad * nsplit;                     // this wave's virtual split
   const int nt = vs < n_tiles ? (n_tiles - vs + vn - 1) / vn : 0;         // its tiles: vs, vs + vn, ...
   const int steps = sp < n_tiles ? (n_tiles - sp + vn - 1) / vn : 0;      // = nt of the first quad >= nt of the second
-  const int mask = ~((1 << code_bits) - 1);
+  // MERGE: keys are born in the merged record's form — code << 2 | source list (2 quad + half; the half bit is OR-ed in at the end: one
+  // scalar code per accumulator register, as before) — so that the lists stay sorted through the merge
+  constexpr int kCS = MERGE ? 2 : 0;
+  const int mask = ~((1 << (code_bits + kCS)) - 1);
+  const int code_q = MERGE ? (quad << 1) : 0;
   int vmask = mask;
   asm volatile("" : "+v"(vmask));
   if (blockIdx.x == 0) reset_counts(fb_count, fb_prev, zero_counts, tid);
@@ -740,11 +749,11 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
   auto step = [&](auto slot_tag, int i, f32x16& cur0, f32x16& cur1, const f32x16& prev0, const f32x16& prev1) {
     constexpr int SLOT = decltype(slot_tag)::value;
     const PairDma d = dma_of(i + NS - 1, (SLOT + NS - 1) % NS);
-    tilep_steps<LL, 0, 12, SLOT, NS>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, (i - 1) << 4, pinf, w, ring, d);
+    tilep_steps<LL, 0, 12, SLOT, NS, kCS>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, ((i - 1) << (4 + kCS)) | code_q, pinf, w, ring, d);
     // step i+1 (issued two steps ago) has landed for this wave; after the barrier it has for every wave, and every wave
     // is past its last read of step i-1, whose slot the DMA below refills
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (NS - 3)) : "memory");
-    tilep_steps<LL, 12, 16, SLOT, NS>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, (i - 1) << 4, pinf, w, ring, d);
+    tilep_steps<LL, 12, 16, SLOT, NS, kCS>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, ((i - 1) << (4 + kCS)) | code_q, pinf, w, ring, d);
   };
   for (int i = 0; i < steps; i += 4) {
     step(std::integral_constant<int, 0>{}, i, accA0, accA1, accB0, accB1);
@@ -758,20 +767,23 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
   if (nt == steps) {  // the wave's last tile's scores are still in registers; only here can rows be >= n_rows. (A wave with
                       // nt == steps - 1 ran its last step on a clamped tile: that step inserted the real last tile's scores.)
     const int row0 = (vs + (nt - 1) * vn) * kTileRows + 4 * half;
-    const int code0 = (nt - 1) << 4;
+    const int code0 = ((nt - 1) << (4 + kCS)) | code_q;
     const bool odd = nt & 1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const bool ok = row0 + (r & 3) + 8 * (r >> 2) < n_rows;
       const float s0 = odd ? accA0[r] : accB0[r], s1 = odd ? accA1[r] : accB1[r];
-      ins_key<LL>(w.ls0, ok ? make_key(s0, mask, code0 + r) : T2L_NEG_INF);
-      ins_key<LL>(w.ls1, ok ? make_key(s1, mask, code0 + r) : T2L_NEG_INF);
+      ins_key<LL>(w.ls0, ok ? make_key(s0, mask, code0 + (r << kCS)) : T2L_NEG_INF);
+      ins_key<LL>(w.ls1, ok ? make_key(s1, mask, code0 + (r << kCS)) : T2L_NEG_INF);
     }
   }
   const int part = 2 * vs + half, parts = 2 * vn;
   const int qrow0 = qb * kWideQPerBlock + wq * kWideQPerWave + col, qrow1 = qrow0 + 32;
   auto put_list = [&](int qrow, const float* ls) {  // (measured: non-temporal stores here cost +2 us per step)
     if (qrow >= Q) return;
+#ifdef T2L_EXP_THIRDLISTS  // dev experiment (make exp_thirdlists, tools/listwrite_probe.py): what would a 3x smaller list write-back buy?
+    if (part % 3) return;
+#endif
     float* out = cand + ((size_t)qrow * parts + part) * LL;
     if constexpr (LL % 2 == 0) {  // 24-byte lists: three 8-byte stores
 #pragma unroll
@@ -788,8 +800,83 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
       for (int i = 0; i < LL; ++i) out[i] = ls[i];
     }
   };
-  put_list(qrow0, w.ls0);
-  put_list(qrow1, w.ls1);
+  if constexpr (MERGE) {
+    // ---- the four lists of a query (this lane, its other half, the same two lanes of wave uwave ^ 4) -> top 7 of 24 + bound.
+    // The keys carry code << 2 | quad << 1 already; the lane half goes into bit 0 here (the same bit into every key of a list: it stays
+    // sorted). Two sorted lists meet in a bitonic network: max(A_i, B_{7-i}) are the 8 largest, three compare-exchange stages sort them.
+    auto with_half = [&](float k) { return k == T2L_NEG_INF ? k : __int_as_float(__float_as_int(k) | half); };
+    const float ninf = -pinf;
+    auto cx = [&](float& hi, float& lo) {  // compare-exchange, one op per side (med3 against +-inf: no canonicalising extra)
+      const float a = hi, b = lo;
+      hi = __builtin_amdgcn_fmed3f(a, b, pinf);
+      lo = __builtin_amdgcn_fmed3f(a, b, ninf);
+    };
+    auto sort_bitonic8 = [&](float (&c)[kMergedLL]) {
+#pragma unroll
+      for (int d = 4; d >= 1; d >>= 1)
+#pragma unroll
+        for (int i = 0; i < kMergedLL; ++i)
+          if ((i & d) == 0) cx(c[i], c[i + d]);
+    };
+    float A0[kMergedLL], A1[kMergedLL], O0[LL], O1[LL];
+#pragma unroll
+    for (int i = 0; i < LL; ++i) {
+      O0[i] = with_half(w.ls0[i]);
+      O1[i] = with_half(w.ls1[i]);
+    }
+    // a lane's FLOOR (its 6th key: every row the lane saw and dropped lies at or below it) bounds what the record cannot list
+    float f0 = O0[LL - 1], f1 = O1[LL - 1];
+    f0 = fmaxf(f0, __shfl_xor(f0, 32));
+    f1 = fmaxf(f1, __shfl_xor(f1, 32));
+    {
+      float B0[LL], B1[LL];
+#pragma unroll
+      for (int i = 0; i < LL; ++i) {
+        B0[i] = __shfl_xor(O0[i], 32);
+        B1[i] = __shfl_xor(O1[i], 32);
+      }
+      static_assert(LL == 6 && kMergedLL == 8, "the half merge below is written out for 6 + 6 -> 8");
+      A0[0] = O0[0]; A0[1] = O0[1]; A0[6] = B0[1]; A0[7] = B0[0];
+      A1[0] = O1[0]; A1[1] = O1[1]; A1[6] = B1[1]; A1[7] = B1[0];
+#pragma unroll
+      for (int i = 2; i < 6; ++i) {
+        A0[i] = __builtin_amdgcn_fmed3f(O0[i], B0[7 - i], pinf);
+        A1[i] = __builtin_amdgcn_fmed3f(O1[i], B1[7 - i], pinf);
+      }
+      sort_bitonic8(A0);
+      sort_bitonic8(A1);
+    }
+    // both halves now hold the same two merged lists; half h carries query col + 32 h from here on
+    float M[kMergedLL];
+#pragma unroll
+    for (int i = 0; i < kMergedLL; ++i) M[i] = half ? A1[i] : A0[i];
+    float fl = half ? f1 : f0;
+    float* xch = smem + ((size_t)wq * 64 + lane) * (kMergedLL + 1);  // 9-float records: conflict-free
+    __syncthreads();  // every wave is done with the tile ring
+    if (quad == 1) {
+#pragma unroll
+      for (int i = 0; i < kMergedLL; ++i) xch[i] = M[i];
+      xch[kMergedLL] = fl;
+    }
+    __syncthreads();
+    if (quad == 0) {
+#pragma unroll
+      for (int i = 0; i < kMergedLL; ++i) M[i] = __builtin_amdgcn_fmed3f(M[i], xch[kMergedLL - 1 - i], pinf);
+      sort_bitonic8(M);
+      fl = fmaxf(fl, xch[kMergedLL]);
+      // everything evicted on the way lies at or below the 8th merged key; everything a lane dropped at or below its floor
+      M[kMergedLL - 1] = fmaxf(M[kMergedLL - 1], fl);
+      const int qrow = qb * kWideQPerBlock + wq * kWideQPerWave + lane;
+      if (qrow < Q) {
+        float4* out = reinterpret_cast<float4*>(cand + ((size_t)qrow * nsplit + sp) * kMergedLL);
+        out[0] = make_float4(M[0], M[1], M[2], M[3]);
+        out[1] = make_float4(M[4], M[5], M[6], M[7]);
+      }
+    }
+  } else {
+    put_list(qrow0, w.ls0);
+    put_list(qrow1, w.ls1);
+  }
   if (span && threadIdx.x == 0) {
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), tag = (unsigned long long)span_seq << 40, tm = (1ull << 40) - 1;
     *reinterpret_cast<ulonglong2*>(span + 2 * blockIdx.x) = make_ulonglong2(tag | (wg_t0 & tm), tag | (t1 & tm));
@@ -953,11 +1040,25 @@ __device__ __forceinline__ void publish_report(const RerankArgs& a) {
 // One query, one wave. `my_wg_flag`: this wave's slot of the workgroup's "rank exactly" flags; `wr_buf`: kWideCap ints of LDS.
 // SC1: the candidate lists are read with agent-scope (L1-bypassing) loads — the fused launch, where they were written by other
 // workgroups of the same launch.
-template <int LL, int L, bool SC1>
+// MG: the lists are the MERGED records of scanp_kernel<..., MERGE> — `parts` = physical splits, one record of kMergedLL floats per
+// (query, split): 7 keys whose low bits are code << 2 | source list, then the bound on every key the record does not list (what
+// `lane_floor` is for a plain list: the floor of a full list).
+template <int LL, int L, bool SC1, bool MG = false>
 __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid, const int lane, int* my_wg_flag, int* wr_buf) {
+  static_assert(!MG || (LL == kMergedLL && !SC1), "merged records are 8 floats and belong to the two-launch search");
   const float* __restrict__ db = a.db;
   const float* __restrict__ q = a.q;
   const int Q = a.Q, K = a.K, parts = a.parts, code_bits = a.code_bits, row_offset = a.row_offset, half_mode = a.half_mode;
+  const int slack_bits = MG ? code_bits + 2 : code_bits;  // score bits a key gave up for its code
+  // row of a key held by list `part`
+  auto krow = [&](float key, int part) {
+    if constexpr (MG) {
+      const int b = __float_as_int(key), src = b & 3;
+      return key_row(__int_as_float(b >> 2), 2 * (part + (src >> 1) * parts) + (src & 1), 2 * parts, code_bits);
+    } else {
+      return key_row(key, part, parts >> 1, code_bits);
+    }
+  };
   const float* __restrict__ cand = a.cand;
   const float eps_rel = a.eps_rel, eps_rel_probe = a.eps_rel_probe, pinf = a.pinf;
   const float* __restrict__ db_norm_max = a.db_norm_max;
@@ -971,7 +1072,11 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
   float lst[LL];
   {
     const float* mine = cand + ((size_t)qid * parts + min(lane, parts - 1)) * LL;
-    if constexpr (LL % 2 == 0) {  // (LL = 6 lists are 24 bytes: 8-byte loads keep every list aligned)
+    if constexpr (MG) {
+      const float4 v0 = reinterpret_cast<const float4*>(mine)[0], v1 = reinterpret_cast<const float4*>(mine)[1];
+      lst[0] = v0.x; lst[1] = v0.y; lst[2] = v0.z; lst[3] = v0.w;
+      lst[4] = v1.x; lst[5] = v1.y; lst[6] = v1.z; lst[7] = v1.w;
+    } else if constexpr (LL % 2 == 0) {  // (LL = 6 lists are 24 bytes: 8-byte loads keep every list aligned)
 #pragma unroll
       for (int i = 0; i < LL / 2; ++i) {
         if constexpr (SC1) {  // fused launch: the lists were published by OTHER workgroups of this launch (sc1 stores): L1-bypassing loads
@@ -996,6 +1101,7 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
   }
   // a FULL list dropped rows inside its lane: all of them have key <= its floor (-inf when nothing was dropped)
   const float lane_floor = lst[LL - 1];
+  if constexpr (MG) lst[LL - 1] = T2L_NEG_INF;  // (the record's last slot is its bound, not a key)
   const float floor_max = wave_max_f32(lane_floor, pinf);
   // the query as float64, 16 elements per lane (dims 64 i + 4 seg + e: each load instruction reads 256 contiguous bytes
   // per 16-lane row); the lanes of one row cover the 256 dims, the 4 rows hold copies
@@ -1034,7 +1140,7 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
     for (int i = 0; i < LL - 1; ++i) lst[i] = pop ? lst[i + 1] : lst[i];
     lst[LL - 1] = pop ? T2L_NEG_INF : lst[LL - 1];
   }
-  int my_row = (lane < L && my_key != T2L_NEG_INF) ? key_row(my_key, my_part, parts >> 1, code_bits) : INT_MAX;
+  int my_row = (lane < L && my_key != T2L_NEG_INF) ? krow(my_key, my_part) : INT_MAX;
   // every row that is NOT re-scored has key <= g: kept rows lie at or below the L-th merged key, rows dropped inside a
   // lane at or below that lane's floor (with LL == L a floor above the L-th key cannot happen; with LL < L it can)
   const float g = fmaxf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_key), L - 1)), floor_max);
@@ -1126,7 +1232,7 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
       const unsigned long long kthA = __ballot(validA && rA == K - 1);
       if (kthA != 0ull) {
         const double dK = __shfl(my_d, __ffsll((long long)kthA) - 1);
-        if (dK > (double)gA * kscale + key_slack(gA, code_bits, eps32, kscale)) {  // wave-uniform
+        if (dK > (double)gA * kscale + key_slack(gA, slack_bits, eps32, kscale)) {  // wave-uniform
           emit(validA, rA);
           early = true;
         }
@@ -1149,15 +1255,15 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
     const unsigned long long kth = __ballot(valid && rank == K - 1);
     if (K <= L && kth != 0ull) {
       const double dK = __shfl(my_d, __ffsll((long long)kth) - 1);
-      certified = dK > (double)g * kscale + key_slack(g, code_bits, eps32, kscale);
+      certified = dK > (double)g * kscale + key_slack(g, slack_bits, eps32, kscale);
       // while the split-bf16 scan stands in for the f16 scan on a DB that overwhelmed its certificate, count the queries
       // the f16 error band would still flag: the host goes back to the f16 scan when they become rare
       if (eps_rel_probe > 0.f && lane == 0 &&
-          !(dK > (double)g * kscale + key_slack(g, code_bits, (double)eps_rel_probe * sqrt(qn) * (double)(*db_norm_max), kscale)))
+          !(dK > (double)g * kscale + key_slack(g, slack_bits, (double)eps_rel_probe * sqrt(qn) * (double)(*db_norm_max), kscale)))
         atomicAdd(&fb_count[3], 1);
       // a row with key k has score <= k*kscale + |k|*kscale*2^(cb-22) + eps32; with S = 2*(|dK|*2^(cb-22) + eps32) every
       // key below (dK - S)/kscale is therefore below the current K-th best score dK (and the final K-th is >= dK)
-      const double S = 2.0 * (fabs(dK) * ldexp(1.0, code_bits - 22) + eps32);
+      const double S = 2.0 * (fabs(dK) * ldexp(1.0, slack_bits - 22) + eps32);
       const double t = (dK - S) / kscale;
       thr = (float)t;
       if ((double)thr > t) thr = __uint_as_float(__float_as_uint(thr) + (thr > 0.f ? -1 : 1));  // round down
@@ -1184,7 +1290,7 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
         const int bl = __ffsll((long long)__ballot(lst[0] == bk)) - 1;
         if (lane == L + e) {
           my_key = bk;
-          my_row = key_row(bk, bl, parts >> 1, code_bits);
+          my_row = krow(bk, bl);
         }
         if (lane == bl) {
 #pragma unroll
@@ -1231,10 +1337,14 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
       // the top-K (the argument of the in-wave re-score above). Only when that is more than kWideCap rows does the query go
       // to an exact scan of the whole shard (one workgroup: ~300 us per query at N = 11 k — two such queries were 0.6 ms of
       // a 0.7 ms step on clustered data, bench_distribution.py).
-      const int vn_ = parts >> 1;
+      // rows behind a list: a plain list covers the tiles of ONE virtual split at one lane half (16 rows per tile); a merged record the
+      // two virtual splits of its workgroup at both halves (64 per tile ordinal; the second split may be one tile shorter: filtered below)
+      const int vn_ = MG ? 2 * parts : parts >> 1;
+      constexpr int kRowsPerTile = MG ? 64 : 16;
       const int n_tiles_ = (n_rows + kTileRows - 1) / kTileRows;
-      const int my_nt = (lane < parts && (lane >> 1) < n_tiles_) ? (n_tiles_ - (lane >> 1) + vn_ - 1) / vn_ : 0;
-      int work = bad ? my_nt * 16 : cnt;
+      const int my_vs = MG ? lane : lane >> 1;
+      const int my_nt = (lane < parts && my_vs < n_tiles_) ? (n_tiles_ - my_vs + vn_ - 1) / vn_ : 0;
+      int work = bad ? my_nt * kRowsPerTile : cnt;
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) work += __shfl_xor(work, off);
       if (work <= wide_cap) {
@@ -1245,14 +1355,14 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
         for (int i = 0; i < LL; ++i) {  // kept keys of the lists that dropped nothing relevant
           const bool pred = !bad && lst[i] >= thr;
           const unsigned long long m = __ballot(pred);
-          if (pred) wr[base + __popcll(m & lt_mask)] = key_row(lst[i], lane, vn_, code_bits);
+          if (pred) wr[base + __popcll(m & lt_mask)] = krow(lst[i], lane);
           base += __popcll(m);
         }
         for (unsigned long long m = bad_mask; m != 0ull; m &= m - 1ull) {  // every row of the lists that did
           const int b = __ffsll((long long)m) - 1;
-          const int nb = __shfl(my_nt, b) * 16;
-          for (int idx = lane; idx < nb; idx += 64) {  // (a list position IS its key code: tile ordinal << 4 | accumulator register)
-            const int row = key_row(__int_as_float(idx), b, vn_, code_bits);
+          const int nb = __shfl(my_nt, b) * kRowsPerTile;
+          for (int idx = lane; idx < nb; idx += 64) {  // (a list position IS its key code: tile ordinal << 4 | accumulator register [<< 2 | source])
+            const int row = krow(__int_as_float(idx), b);
             wr[base + idx] = row < n_rows ? row : INT_MAX;
           }
           base += nb;
@@ -1380,7 +1490,7 @@ __device__ void fused_rerank_tail(const FusedArgs& fa, float* smem, int qb, int 
 // rerank (stage 1): one wave per query, 4 queries per 256-thread block.
 // ------------------------------------------------------------------------------------------------
 // LL = length of the per-lane lists the scan wrote, L = rows re-scored per query (LL <= L).
-template <int LL, int L>
+template <int LL, int L, bool MG = false>
 __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ db, const float* __restrict__ q, int Q,
                                                      int K, int parts, int code_bits,
                                                      const float* __restrict__ cand, int row_offset, float eps_rel,
@@ -1399,7 +1509,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
   if (threadIdx.x < 4) wg_flag[threadIdx.x] = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) publish_report(a);
   __syncthreads();
-  if (qid < Q) rerank_query<LL, L, false>(a, qid, lane, &wg_flag[threadIdx.x >> 6], wide_rows[threadIdx.x >> 6]);
+  if (qid < Q) rerank_query<LL, L, false, MG>(a, qid, lane, &wg_flag[threadIdx.x >> 6], wide_rows[threadIdx.x >> 6]);
   // ---- unsettled queries of this workgroup: the exact float64 ranking, all 4 waves on one query at a time
   __syncthreads();
 #pragma unroll 1
@@ -1697,6 +1807,7 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
   const int seq = first ? ++ctx->stat_seq : 0;  // the report card goes out once per call
   const int defer = ctx->heavy ? 1 : 0;
   bool fused = false;  // scan + re-rank went out as ONE launch (scanp_kernel<..., FUSED>)
+  bool merged = false;  // the candidate lists are merged records (scanp_kernel<..., MERGE>)
   if constexpr (LL <= 6) {  // paired f16 MFMA scan (default): one 512-thread workgroup per CU, 256 queries each; `nsplit`
     // counts VIRTUAL splits here: the kernel takes physical ones (2 virtual splits per workgroup)
     const dim3 grid((Q + kWideQPerBlock - 1) / kWideQPerBlock * (nsplit / 2));
@@ -1768,6 +1879,26 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
         launched = true;
       }
     }
+    if constexpr (LL == 6 && L == 16) {
+      // merged records (option "search_merge_lists"): the workgroup's four lists per query leave as one 32-byte record
+      // (two more code bits come out of the key's score: kept to shards whose keys still hold 12 score bits below the exponent)
+      if (!launched && (ctx->search_merge == 1 || (ctx->search_merge == 2 && ctx->merge_live && !ctx->heavy)) && !prep && code_bits <= 9) {
+        static PerDeviceOnce once_m;
+        if (once_m.need(ctx->device)) {
+          allow_lds(&scanp_kernel<LL, 4, false, false, true>, (size_t)4 * 2 * kHalfTileBytes);
+          once_m.mark(ctx->device);
+        }
+        if (ev)
+          hipExtLaunchKernelGGL((scanp_kernel<LL, 4, false, false, true>), grid, dim3(512), (uint32_t)lds, s, ea, eb, 0u, dbh, n_rows, n_tiles,
+                                code_bits, q, (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, ctx->fb_prev, zero,
+                                __builtin_inff(), span, span_seq, xq, fa);
+        else
+          hipLaunchKernelGGL((scanp_kernel<LL, 4, false, false, true>), grid, dim3(512), lds, s, dbh, n_rows, n_tiles, code_bits, q,
+                             (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, ctx->fb_prev, zero, __builtin_inff(), span,
+                             span_seq, xq, fa);
+        launched = merged = true;
+      }
+    }
     if (launched) {
     } else if (ev)
       hipExtLaunchKernelGGL(prep ? (scanp_kernel<LL, 4, true>) : (scanp_kernel<LL, 4, false>), grid, dim3(512), (uint32_t)lds, s, ea, eb, 0u,
@@ -1822,6 +1953,24 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
   // their own re-rank workgroup (wg_exact_scan) — there is no separate fallback launch to pay for when, as usual, there
   // are none. (Heavy mode: they are deferred to the float64 MFMA stage instead, search_exact.hip.)
   hipEvent_t ea, eb;
+  if constexpr (LL == 6 && L == 16) {
+    if (merged) {
+      const bool evr = ctx->profile_rerank && event_pair(ctx, "search_rerank", &ea, &eb);
+      if (evr)
+        hipExtLaunchKernelGGL((rerank_kernel<kMergedLL, L, true>), dim3((Q + 3) / 4), dim3(256), 0u, s, ea, eb, 0u, db, q, Q, K, nsplit / 2,
+                              code_bits, (const float*)ctx->cand_score, row_offset, eps_rel, (const float*)ctx->db_norm_max, half_mode, out_idx,
+                              out_score, ctx->flags, ctx->fb_count, eps_probe, __builtin_inff(), n_rows, defer, stat_mode,
+                              ctx->host_stat_dev, seq, min(ctx->wide_repair, kWideCap));
+      else
+        hipLaunchKernelGGL((rerank_kernel<kMergedLL, L, true>), dim3((Q + 3) / 4), dim3(256), 0, s, db, q, Q, K, nsplit / 2, code_bits,
+                           ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, half_mode, out_idx, out_score, ctx->flags,
+                           ctx->fb_count, eps_probe, __builtin_inff(), n_rows, defer, stat_mode, ctx->host_stat_dev, seq,
+                           min(ctx->wide_repair, kWideCap));
+      T2L_HIP(ctx, hipGetLastError());
+      if (ctx->heavy) return exact_stage_impl(ctx, db, n_rows, row_offset, q, Q, K, out_idx, out_score, s);
+      return T2L_OK;
+    }
+  }
   if (ctx->profile_rerank && event_pair(ctx, "search_rerank", &ea, &eb))
     hipExtLaunchKernelGGL((rerank_kernel<LL, L>), dim3((Q + 3) / 4), dim3(256), 0u, s, ea, eb, 0u, db, q, Q, K, parts, code_bits,
                           (const float*)ctx->cand_score, row_offset, eps_rel, (const float*)ctx->db_norm_max, half_mode, out_idx,
@@ -1906,6 +2055,12 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
         // an f16 report that arrives after the switch must not undo it)
         if (hs[4] == 1 && !ctx->escalated && (flagged * 8 > total || rescored * 2 > total)) ctx->escalated = true;
         else if (hs[4] == 2 && ctx->escalated && flagged * 16 < total) ctx->escalated = false;
+      }
+      // merged candidate records pay while repairs are rare: more than 1 query in 64 failing its first certificate -> plain lists
+      // (their repairs re-score a quarter of the rows), back below 1 in 256
+      if (hs[4] == 1) {
+        if (ctx->merge_live && rescored * 64 > total) ctx->merge_live = false;
+        else if (!ctx->merge_live && rescored * 256 <= total) ctx->merge_live = true;
       }
       if (ctx->search_auto) {
         if (!ctx->heavy && exact_prev * 64 > total) ctx->heavy = true;

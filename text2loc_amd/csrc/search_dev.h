@@ -285,7 +285,8 @@ __device__ __forceinline__ u32x4 pair_frag(lds_cptr lb0, lds_cptr lb1) {
   else return *reinterpret_cast<frag_ptr>(lb1 + (OFF - 65536));
 }
 
-template <int LL, int S, int S_END, int SLOT, int NS>
+// CS: the key code of accumulator register S is code0 + (S << CS) (2: the merged-record form leaves the two low code bits to the source list)
+template <int LL, int S, int S_END, int SLOT, int NS, int CS = 0>
 __device__ __forceinline__ void tilep_steps(lds_cptr lb0, lds_cptr lb1, const u32x4 (&q0)[16], const u32x4 (&q1)[16],
                                             f32x16& cur0, f32x16& cur1, const f32x16& prev0, const f32x16& prev1, int vmask,
                                             int code0, float pinf, WideLists<LL>& w, u32x4 (&ring)[4], const PairDma& dma) {
@@ -293,7 +294,7 @@ __device__ __forceinline__ void tilep_steps(lds_cptr lb0, lds_cptr lb1, const u3
     constexpr int VPM = LL + 1;
     constexpr int NXT = (SLOT + 1) % NS;
     const u32x4 a = ring[S & 3];
-    const int code = __builtin_amdgcn_readfirstlane(code0 + S);
+    const int code = __builtin_amdgcn_readfirstlane(code0 + (S << CS));
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (S == 0) mfma_f16_first(cur0, a, q0[S]); else mfma_f16_acc(cur0, a, q0[S]);
     if constexpr (S + 4 < 16) ring[S & 3] = pair_frag<SLOT, S + 4>(lb0, lb1);
@@ -306,7 +307,7 @@ __device__ __forceinline__ void tilep_steps(lds_cptr lb0, lds_cptr lb1, const u3
     __builtin_amdgcn_sched_barrier(0);
     wide_sel_ops<LL, S, VPM, 2 * VPM>(w, prev0, prev1, vmask, code, pinf);
     __builtin_amdgcn_sched_barrier(0);
-    tilep_steps<LL, S + 1, S_END, SLOT, NS>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, code0, pinf, w, ring, dma);
+    tilep_steps<LL, S + 1, S_END, SLOT, NS, CS>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, code0, pinf, w, ring, dma);
   }
 }
 

@@ -108,6 +108,10 @@ struct t2l_ctx {
   int search_auto = 1;
   int pair_ll = 6;       // per-lane list length of the paired scan (5 or 6)
   int wide_repair = 512;  // rows a re-rank wave may re-score in a wide repair before the query goes to an exact scan (0: never)
+  int search_merge = 2;    // the paired scan merges a workgroup's four lists per query into one 32-byte record (search.hip: MERGE / MG):
+                           // 0 never, 1 always, 2 while the f16 report cards show next to no failed first certificates (a repair behind
+                           // a merged record re-scores 4x the rows of a plain list's)
+  bool merge_live = true;  // (search_merge == 2) what the report cards say right now
   int search_fused = 0;    // 1: scan + re-rank as ONE launch where the shapes allow (search.hip: scanp_kernel<..., FUSED>)
   int32_t* qb_cnt = nullptr;  // its per-query-block arrival counters [2][4096]
   unsigned fused_seq = 0;

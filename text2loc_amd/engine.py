@@ -8,6 +8,7 @@ library, or calling it with CPU tensors, raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import os.path as osp
 from typing import Dict, Optional, Tuple
 
@@ -17,7 +18,8 @@ import torch
 EMBED_DIM = 256
 OBJECT_SIZE = 28
 MAX_TOPK = 26
-_LIB_PATH = osp.join(osp.dirname(osp.abspath(__file__)), "libt2l.so")
+# (T2L_LIB: a dev build beside the shipped one — the stamped or an experiment library of csrc/Makefile; never a fallback)
+_LIB_PATH = os.environ.get("T2L_LIB") or osp.join(osp.dirname(osp.abspath(__file__)), "libt2l.so")
 
 
 class T2LError(RuntimeError):
