@@ -711,3 +711,41 @@ def test_merged_records_follow_the_report_card():
         assert all(x["valu_exact_scans"] == 0 for x in c), c
     finally:
         e.close()
+
+
+def test_merged_records_with_the_exact_stage_and_pipelined_lanes():
+    """Forced combinations the report card never picks by itself: merged records + heavy mode (flagged queries deferred to the float64
+    MFMA stage) on a database that defeats the certificates, and merged records under three pipelined lanes."""
+    import torch
+    from oracle import c_oracle
+    from text2loc_amd.engine import Engine
+
+    rng = np.random.default_rng(91)
+    n, q = 11259, 1024
+    e = Engine(0)
+    try:
+        e.set_option("search_auto", 0)
+        e.set_option("search_merge_lists", 1)
+        db = _cluster_db(rng, n, 64, 30.0)
+        qs = synth.unit_rows(db[rng.integers(0, n, size=q)].astype(np.float64) + 0.01 * synth.unit_rows(rng.standard_normal((q, 256)))).astype(np.float32)
+        ridx, rsc = c_oracle.retrieve_topk(db, qs, 10)
+        e.set_option("search_heavy", 1)
+        e.db_set(torch.from_numpy(db).cuda())
+        idx, sc = e.search(torch.from_numpy(qs).cuda(), 10)
+        torch.cuda.synchronize()
+        cnt = e.search_counters()
+        assert np.array_equal(idx.cpu().numpy().astype(np.int64), ridx) and np.abs(sc.cpu().numpy() - rsc).max() < 1e-12
+        assert cnt["deferred_to_mfma_exact"] > 0, cnt
+        e.set_option("search_heavy", 0)
+        db = synth.unit_rows(rng.standard_normal((n, 256))).astype(np.float32)
+        e.db_set(torch.from_numpy(db).cuda())
+        e.set_option("search_lanes", 3)
+        batches = [synth.unit_rows(rng.standard_normal((777, 256))).astype(np.float32) for _ in range(7)]
+        outs = [e.search(torch.from_numpy(b).cuda(), 10, join=False) for b in batches]
+        e.search_join()
+        torch.cuda.synchronize()
+        for b, (idx, sc) in zip(batches, outs):
+            ridx, rsc = c_oracle.retrieve_topk(db, b, 10)
+            assert np.array_equal(idx.cpu().numpy().astype(np.int64), ridx) and np.abs(sc.cpu().numpy() - rsc).max() < 1e-12
+    finally:
+        e.close()
