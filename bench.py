@@ -183,15 +183,22 @@ def full_train_step_measure(eng, p64, n_ramp, n_steps, B=64, n_hints=6, n_tok=16
     res = {}
 
     def step(i):
+        on_engine = enc.use_engine_train_head
         eng.zero_grad()
-        opt.zero_grad(set_to_none=False)
+        if on_engine:
+            enc.engine_zero_grad()
+        else:
+            opt.zero_grad(set_to_none=False)
         anchor = F.normalize(enc.head(hidden, B))
         pos = eng.encode_cells_train(p64, dropout_p=0.1, seed=i)
         loss, ga, gp = eng.contrastive_loss(anchor.detach().contiguous(), pos, 0.1)
         eng.encode_cells_backward(gp)
         anchor.backward(ga)
         eng.adam_step(1e-3)
-        opt.step()
+        if on_engine:
+            enc.engine_adam_step(1e-4)  # t2l_text_adam_step: the head's 13.6 M parameters in one launch (what optim.Adam routes them to)
+        else:
+            opt.step()
         return loss
 
     for name, on, bf16 in (("engine_text_head_f32", True, 0), ("engine_text_head_bf16", True, 1), ("engine_text_head_split_bf16", True, 2),

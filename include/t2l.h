@@ -371,6 +371,16 @@ int t2l_text_head_train(t2l_ctx* ctx, const float* hidden, int32_t n_sentences, 
                         uint32_t seed, float* out, void* stream);
 int t2l_text_head_backward(t2l_ctx* ctx, const float* grad_out, void* stream);
 
+/* The head's optimizer (training/coarse.py:42,56 with optim.Adam(model.parameters()), :258: the published command trains the head's
+ * 13.6 M parameters). t2l_text_adam_step: torch.optim.Adam's arithmetic (defaults: no weight decay, no amsgrad) over every tensor that
+ * t2l_text_train_bind received WITH a gradient buffer, in bind order, in ONE launch; exp_avg / exp_avg_sq live inside the library, the
+ * step count starts at 0 with a bind (a re-bind of an unchanged list under option "train_keep_adam_state" keeps moments and step).
+ * t2l_text_zero_grad zeroes the bound gradient buffers in place (one launch). t2l_text_adam_state: as t2l_adam_state (m, v:
+ * dev f32[numel], concatenated in bind order; m == v == NULL queries numel and, set == 0, step). */
+int t2l_text_adam_step(t2l_ctx* ctx, float lr, float beta1, float beta2, float eps, void* stream);
+int t2l_text_zero_grad(t2l_ctx* ctx, void* stream);
+int t2l_text_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step, int64_t* numel, void* stream);
+
 /* Data-parallel training with the reference's batch statistics. The reference trains ONE process on the whole batch
  * (training/coarse.py:31-58): every BatchNorm1d of the object branch (object_encoder.py:41-52, 121-149) and of inter_mlp
  * (language_encoder.py:99) normalises over all objects / sentences of the batch. With the batch split over ranks, the per-channel

@@ -205,3 +205,122 @@ def test_training_mode_keeps_the_pytorch_modules_where_the_engine_does_not_apply
     assert LanguageEncoder.train_engine_calls == n0 + 1
     y2 = enc.head(hidden, 2)
     assert float((y - y2).abs().max()) > 1e-4  # a fresh mask every call
+
+
+def test_engine_adam_for_the_head_is_torch_adam_arithmetic_and_survives_a_checkpoint():
+    """``t2l_text_adam_step`` (what ``text2loc_amd.optim.Adam`` hands the head's trained parameters to): three steps on given gradients
+    equal ``torch.optim.Adam`` on a deep copy element for element (same float32 arithmetic: 1e-7 relative), ``zero_grad`` clears the bound
+    buffers in place, the moments travel through ``text_adam_state`` / ``set_text_adam_state`` into a second head that then takes the same
+    fourth step, and the eval-mode weights of the engine head follow the stepped parameters (no stale fold)."""
+    enc = _encoder(11)
+    ref = copy.deepcopy(enc)
+    named = enc.engine_optimizer_params()
+    assert len(named) == 28 and sum(p.numel() for _, p in named) > 13_000_000
+    ref_params = dict(ref.named_parameters())
+    opt_ref = torch.optim.Adam([ref_params[n] for n, _ in named], lr=3e-4, betas=(0.9, 0.999), eps=1e-8)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+
+    def give_grads(step):
+        for n, p in named:
+            g = torch.randn(p.shape, device="cuda", generator=gen) * (10.0 ** (step - 2))
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            ref_params[n].grad = g.clone()
+
+    for step in range(3):
+        give_grads(step)
+        enc.engine_adam_step(3e-4, (0.9, 0.999), 1e-8)
+        opt_ref.step()
+    torch.cuda.synchronize()
+    for n, p in named:
+        a, b = p.detach(), ref_params[n].detach()
+        assert float((a - b).abs().max()) <= 2e-7 * (1.0 + float(b.abs().max())), n
+    # zero_grad in place: same storage, all zeros
+    ptrs = [p.grad.data_ptr() for _, p in named]
+    enc.engine_zero_grad()
+    torch.cuda.synchronize()
+    assert all(float(p.grad.abs().max()) == 0.0 for _, p in named) and ptrs == [p.grad.data_ptr() for _, p in named]
+    # checkpoint: moments + step into a fresh head holding the same parameters
+    m, v, st = enc._th_train_engine.text_adam_state()
+    assert st == 3 and m.numel() == sum(p.numel() for _, p in named)
+    twin = _encoder(11)
+    twin.load_state_dict(enc.state_dict())
+    twin._bind_text_train(torch.device("cuda", 0))
+    twin._th_train_engine.set_text_adam_state(m, v, st)
+    tw = dict(twin.named_parameters())
+    give_grads(3)
+    for n, p in named:
+        tw[n].grad.copy_(p.grad)
+    enc.engine_adam_step(3e-4)
+    twin.engine_adam_step(3e-4)
+    opt_ref.step()
+    torch.cuda.synchronize()
+    for n, p in named:
+        assert torch.equal(p.detach(), tw[n].detach()), n
+        assert float((p.detach() - ref_params[n].detach()).abs().max()) <= 3e-7 * (1.0 + float(ref_params[n].detach().abs().max())), n
+    # the eval-mode engine head folds the STEPPED weights (the step happened behind torch's version counters)
+    enc.eval()
+    ref.eval()
+    ref.use_engine_head = False
+    hidden = torch.from_numpy(synth.make_t5_hidden(4 * 6, 9, seed=5)).cuda()
+    with torch.no_grad():
+        a, b = enc.head(hidden, 4), ref.head(hidden, 4)
+    assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_optimizer_routes_the_head_to_the_engine_and_steps_like_torch():
+    """``text2loc_amd.optim.Adam`` over a CellRetrievalNetwork with the real LanguageEncoder head: the head's 28 trained tensors form the
+    "text_head" group (stepped by the engine), and two training steps follow a twin whose head is stepped by torch.optim.Adam
+    (``text_engine=False``): same losses, same parameters to float32 rounding of Adam's normalised update."""
+    from tests.test_gpu_train_loop import _args
+    from tests.test_host_logic import make_objects
+    from text2loc_amd.cell_retrieval import CellRetrievalNetwork
+    from text2loc_amd.losses import ContrastiveLoss
+    from text2loc_amd.optim import Adam
+
+    B, S, L = 16, 6, 8
+    cells = synth.make_cells(B, seed=3)
+    objects = make_objects(cells, 3)
+
+    def build(text_engine):
+        enc = _encoder(7)
+        _no_dropout(enc)
+        model = CellRetrievalNetwork(synth.KNOWN_CLASS, synth.COLOR_NAMES, _args(), language_encoder=enc)
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_object_branch_weights(8).items()}, strict=False)
+        for layer in model.obj_inter_module:
+            layer.dropout.p = layer.dropout1.p = layer.dropout2.p = 0.0
+            layer.self_attn.dropout = 0.0
+        model = model.to("cuda").train()
+        return model, Adam(model, lr=2e-4, text_engine=text_engine)
+
+    (ma, oa), (mb, ob) = build(True), build(False)
+    kinds = [g["t2l_engine"] for g in oa.param_groups]
+    assert kinds[0] is True and kinds[-1] == "text_head" and len(oa.param_groups[-1]["params"]) == 28
+    assert all(g["t2l_engine"] != "text_head" for g in ob.param_groups)
+    crit = ContrastiveLoss(0.1)
+    la, lb = [], []
+    for step in range(2):
+        hidden = torch.from_numpy(synth.make_t5_hidden(B * S, L, seed=70 + step)).cuda()
+        for model, opt, acc in ((ma, oa, la), (mb, ob, lb)):
+            opt.zero_grad()
+            anchor = torch.nn.functional.normalize(model.language_encoder.head(hidden, B))
+            loss = crit(anchor, model.encode_objects(objects))
+            loss.backward()
+            opt.step()
+            acc.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    assert np.allclose(la, lb, rtol=1e-5), (la, lb)
+    pb = dict(mb.named_parameters())
+    for n, p in ma.named_parameters():
+        if n.startswith("language_encoder.") and p.requires_grad and p.grad is not None:
+            err = (p.detach() - pb[n].detach()).abs()
+            # Adam's first steps are lr * g / (|g| + eps): the two runs' gradients differ in the last bits (float atomics), and an element
+            # whose gradient is rounding noise (whole families here: biases in front of a BatchNorm / a softmax) may move by up to 2 lr per
+            # step in either direction — bounded everywhere, tight in the median of the weight matrices
+            assert float(err.max()) <= 4.2 * 2e-4, n
+            if p.dim() == 2:
+                assert float(err.median()) < 2e-6, (n, float(err.median()))
+    sd = oa.state_dict()
+    assert sd["t2l_text_engine"]["step"] == 2 and sd["t2l_text_engine"]["exp_avg"].numel() > 13_000_000

@@ -210,7 +210,7 @@ class LanguageEncoder(nn.Module):
     def _head_engine(self, device) -> Optional[Engine]:
         """The engine context holding this head's packed weights on ``device`` (re-packed when a tensor changes)."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        version = (idx,) + tuple((t.data_ptr(), t._version) for t in self._head_params())
+        version = (idx, self._head_generation) + tuple((t.data_ptr(), t._version) for t in self._head_params())
         if getattr(self, "_th_version", None) != version:
             if getattr(self, "_th_engine", None) is None or self._th_engine.device != idx:
                 self._th_engine = Engine(idx)
@@ -218,7 +218,7 @@ class LanguageEncoder(nn.Module):
                   if n.startswith(("intra_module.", "inter_mlp.", "inter_module."))}
             self._th_engine.text_head_load_weights(sd)
             self._th_params = None  # (load_state_dict may have swapped tensors: re-collect)
-            version = (idx,) + tuple((t.data_ptr(), t._version) for t in self._head_params())
+            version = (idx, self._head_generation) + tuple((t.data_ptr(), t._version) for t in self._head_params())
             self._th_version = version
         return self._th_engine
 
@@ -270,6 +270,7 @@ class LanguageEncoder(nn.Module):
 
     # ---- training mode: the whole head after T5 in the engine (t2l_text_head_train / _backward) ------------------------------------
     use_engine_train_head = True
+    _head_generation = 0
     train_engine_calls = 0
     _th_train_engine = None
     _th_train_token = None
@@ -281,6 +282,13 @@ class LanguageEncoder(nn.Module):
         if not (self.use_engine_head and self.use_engine_train_head and self.training and torch.is_grad_enabled() and hidden.is_cuda
                 and not hidden.requires_grad and not self.is_fine and hidden.dim() == 3 and hidden.shape[-1] == 1024
                 and 1 <= hidden.shape[1] <= 32 and hidden.shape[0] % batch_size == 0 and hidden.shape[0] // batch_size <= 32):
+            return None
+        return self._train_structure_gate()
+
+    def _train_structure_gate(self):
+        """The call-independent half of _train_gate: is this the published head (one stock layer each side of inter_mlp, one dropout
+        probability, nothing frozen)? -> that probability, else None."""
+        if not (self.use_engine_head and self.use_engine_train_head and not self.is_fine):
             return None
         if not (len(self.intra_module) == 1 and len(self.inter_module) == 1 and self.inter_mlp[0][0].out_features == 256
                 and self._layer_is_stock(self.intra_module[0], 1024, 4096, 4) and self._layer_is_stock(self.inter_module[0], 256, 1024, 4)
@@ -294,6 +302,26 @@ class LanguageEncoder(nn.Module):
                                    and isinstance(p, nn.Parameter)):
             return None  # (site-specific probabilities / partly frozen heads: the PyTorch path)
         return ps.pop()
+
+    # ---- the head's optimizer on the engine (t2l_text_adam_step; text2loc_amd.optim.Adam routes the head's parameters here)
+    def engine_optimizer_params(self):
+        """[(name, parameter)] of the head parameters the engine's training path binds — what ``optim.Adam`` hands to
+        ``engine_adam_step`` instead of a torch optimizer — or [] when this head stays on the PyTorch modules in training."""
+        if self._train_structure_gate() is None:
+            return []
+        return [(n, p) for n, p in self.named_parameters()
+                if n.startswith(("intra_module.0.", "inter_mlp.0.", "inter_module.0.")) and p.requires_grad]
+
+    def engine_adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
+        dev = next(self.intra_module.parameters()).device
+        self._bind_text_train(dev)  # (a head that only ran on its PyTorch modules so far: the same .grad tensors get bound now)
+        self._th_train_engine.text_adam_step(lr, betas[0], betas[1], eps)
+        self._head_generation += 1  # parameters changed behind torch's back (no ._version bump): eval-mode weights / memos are stale
+
+    def engine_zero_grad(self):
+        dev = next(self.intra_module.parameters()).device
+        self._bind_text_train(dev)
+        self._th_train_engine.text_zero_grad()
 
     def _bind_text_train(self, device):
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -311,6 +339,8 @@ class LanguageEncoder(nn.Module):
                 tensors["language_encoder." + n] = (t, None)
         key = tuple((d.data_ptr(), 0 if g is None else g.data_ptr()) for d, g in tensors.values())
         if key != self._th_train_key:
+            # same head, moved storage (model.to(), a re-assigned .grad): the engine-side Adam moments must survive the re-bind
+            self._th_train_engine.set_option("train_keep_adam_state", 1 if self._th_train_key is not None else 0)
             self._th_train_engine.text_train_bind(tensors)
             self._th_train_key = key
         _apply_sync_bn(self._th_train_engine, getattr(self, "_sync_bn_cfg", None))
@@ -378,7 +408,7 @@ class LanguageEncoder(nn.Module):
         LanguageEncoder.cache_calls += 1
         inference = not self.training and not torch.is_grad_enabled()
         if inference and self.memoise_sentence_vectors:
-            version = (bool(self.use_engine_head),) + tuple((t.data_ptr(), t._version) for t in self._head_params())
+            version = (bool(self.use_engine_head), self._head_generation) + tuple((t.data_ptr(), t._version) for t in self._head_params())
             deferred, self._deferred = getattr(self, "_deferred", None), None  # (the memo is checked synchronously: never cache a poisoned batch)
             try:
                 vec = cache.sentence_vectors(self, L, version)

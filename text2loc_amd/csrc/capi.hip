@@ -405,6 +405,24 @@ int t2l_text_head_backward(t2l_ctx* ctx, const float* grad_out, void* stream) {
   return text_train_backward_impl(ctx, grad_out, (hipStream_t)stream);
 }
 
+int t2l_text_adam_step(t2l_ctx* ctx, float lr, float beta1, float beta2, float eps, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return text_adam_step_impl(ctx, lr, beta1, beta2, eps, (hipStream_t)stream);
+}
+
+int t2l_text_zero_grad(t2l_ctx* ctx, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return text_zero_grad_impl(ctx, (hipStream_t)stream);
+}
+
+int t2l_text_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step, int64_t* numel, void* stream) {
+  if (!ctx) return T2L_EINVAL;
+  T2L_HIP(ctx, hipSetDevice(ctx->device));
+  return text_adam_state_impl(ctx, set, m, v, step, numel, (hipStream_t)stream);
+}
+
 int64_t t2l_train_sync_bn_doubles(void) { return train_sync_bn_doubles(); }
 
 int t2l_train_sync_bn(t2l_ctx* ctx, double* buf, int64_t n_doubles, t2l_allreduce_fn fn, void* user) {

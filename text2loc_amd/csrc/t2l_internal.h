@@ -212,6 +212,9 @@ void free_lanes(t2l_ctx* ctx);
 int adam_state_impl(t2l_ctx* ctx, int set, float* m, float* v, int64_t* step, int64_t* numel, hipStream_t s);
 void free_train(t2l_ctx* ctx);
 void free_text_train(t2l_ctx* ctx);
+int text_adam_step_impl(t2l_ctx* ctx, float lr, float b1, float b2, float eps, hipStream_t s);
+int text_zero_grad_impl(t2l_ctx* ctx, hipStream_t s);
+int text_adam_state_impl(t2l_ctx* ctx, int set, float* m, float* v, int64_t* step, int64_t* numel, hipStream_t s);
 int64_t train_sync_bn_doubles();
 void train_sync_changed(t2l_ctx* ctx);  // the accumulator slots moved: the next forward clears them
 int text_train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const char* prefix);

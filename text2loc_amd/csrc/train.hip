@@ -853,7 +853,7 @@ int zero_grad_impl(t2l_ctx* ctx, hipStream_t s) {
 //   updated) -> view [n_desc, S, 256] -> x += TransformerEncoderLayer(256, 4 heads, ff 1024)(x) over the S sentences -> max
 //   over the sentences -> out [n_desc, 256]  (F.normalize stays with the caller: cell_retrieval.py:57-63).
 // Forward keeps the activations; backward accumulates (+=) into the bound .grad buffers — the parameters stay torch's and are
-// stepped by the torch-side Adam of text2loc_amd.optim (the 16.8 M head parameters are one foreach launch there). The same
+// stepped by t2l_text_adam_step (one launch over the 13.6 M head parameters; torch.optim.Adam when the caller prefers). The same
 // modular f32 kernels as the object branch (gemm_f32.h products, option train_bf16 for bf16 / split-bf16 operands), with the
 // attention / LayerNorm kernels in their generic forms (train_kernels.h).
 // =================================================================================================================
@@ -877,12 +877,21 @@ struct TextTrain {
   TextLayer intra, inter;
   float *pooled = nullptr, *mlp_y = nullptr, *mlp_out = nullptr, *bn_mean = nullptr, *bn_rstd = nullptr, *out = nullptr;
   int32_t *tok_arg = nullptr, *sent_arg = nullptr;
+  // Adam over the head's parameters (t2l_text_adam_step): moments inside the library, one launch through the chunk table
+  std::vector<std::string> adam_names;  // bind order
+  std::vector<int64_t> adam_numel;
+  AdamTensor* d_tensors = nullptr;
+  AdamChunk* d_chunks = nullptr;
+  float* mv = nullptr;  // [2][mv_total]
+  int64_t mv_total = 0, step = 0;
+  int n_chunks = 0;
 };
 static TextTrain* tstate(t2l_ctx* ctx) { return reinterpret_cast<TextTrain*>(ctx->text_train); }
 void free_text_train(t2l_ctx* ctx) {
   TextTrain* st = tstate(ctx);
   if (!st) return;
-  if (st->ws) (void)hipFree(st->ws);
+  for (void* p : {(void*)st->ws, (void*)st->d_tensors, (void*)st->d_chunks, (void*)st->mv})
+    if (p) (void)hipFree(p);
   delete st;
   ctx->text_train = nullptr;
 }
@@ -902,6 +911,21 @@ __global__ void add_inplace_kernel(float* __restrict__ a, const float* __restric
 
 int text_train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, const char* prefix) {
   if (!tensors || n <= 0) return fail(ctx, T2L_EINVAL, "t2l_text_train_bind: null argument");
+  // a re-bind of the same parameter list (moved storage: model.to(), re-assigned .grad) keeps the optimizer state, as t2l_train_bind does
+  std::vector<std::string> old_names;
+  std::vector<int64_t> old_numel;
+  float* old_mv = nullptr;
+  int64_t old_total = 0, old_step = 0;
+  if (TextTrain* o = tstate(ctx)) {
+    if (ctx->train_keep_adam && o->mv) {
+      old_names = o->adam_names;
+      old_numel = o->adam_numel;
+      old_mv = o->mv;
+      old_total = o->mv_total;
+      old_step = o->step;
+      o->mv = nullptr;  // (free_text_train below must not free it)
+    }
+  }
   free_text_train(ctx);
   TextTrain* st = new TextTrain();
   ctx->text_train = st;
@@ -936,6 +960,37 @@ int text_train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, c
       (rc = need_t("inter_mlp.0.1.weight", 256, true)) || (rc = need_t("inter_mlp.0.1.bias", 256, true)) ||
       (rc = need_t("inter_mlp.0.1.running_mean", 256, false)) || (rc = need_t("inter_mlp.0.1.running_var", 256, false)))
     return rc;
+  {  // Adam tables over every bound tensor that has a gradient buffer, in bind order; moments zero-initialised
+    std::vector<AdamTensor> ts;
+    std::vector<AdamChunk> cs;
+    for (int i = 0; i < n; ++i)
+      if (tensors[i].grad && st->t.count(tensors[i].name)) {
+        st->adam_names.push_back(tensors[i].name);
+        st->adam_numel.push_back(tensors[i].numel);
+        st->mv_total += tensors[i].numel;
+      }
+    const bool same = old_mv && old_names == st->adam_names && old_numel == st->adam_numel && old_total == st->mv_total;
+    if (same) {
+      st->mv = old_mv;
+      st->step = old_step;
+    } else {
+      if (old_mv) (void)hipFree(old_mv);
+      T2L_HIP(ctx, hipMalloc(&st->mv, sizeof(float) * 2 * (size_t)st->mv_total));
+      T2L_HIP(ctx, hipMemset(st->mv, 0, sizeof(float) * 2 * (size_t)st->mv_total));
+    }
+    int64_t off = 0;
+    for (size_t i = 0; i < st->adam_names.size(); ++i) {
+      const TTensor& t = st->t[st->adam_names[i]];
+      ts.push_back(AdamTensor{t.data, t.grad, st->mv + off, st->mv + st->mv_total + off, t.numel});
+      for (int64_t c = 0; c * 1024 < t.numel; ++c) cs.push_back(AdamChunk{(int32_t)i, (int32_t)c});
+      off += t.numel;
+    }
+    st->n_chunks = (int)cs.size();
+    T2L_HIP(ctx, hipMalloc(&st->d_tensors, sizeof(AdamTensor) * ts.size()));
+    T2L_HIP(ctx, hipMalloc(&st->d_chunks, sizeof(AdamChunk) * cs.size()));
+    T2L_HIP(ctx, hipMemcpy(st->d_tensors, ts.data(), sizeof(AdamTensor) * ts.size(), hipMemcpyHostToDevice));
+    T2L_HIP(ctx, hipMemcpy(st->d_chunks, cs.data(), sizeof(AdamChunk) * cs.size(), hipMemcpyHostToDevice));
+  }
   static PerDeviceOnce once;
   if (once.need(ctx->device)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_g_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -1178,6 +1233,50 @@ int text_train_backward_impl(t2l_ctx* ctx, const float* grad_out, hipStream_t s)
   T2L_HIP(ctx, hipGetLastError());
   if (over) return fail(ctx, T2L_ENOMEM, "t2l_text_head_backward: workspace bound exceeded (internal error)");
   if (ctx->sync_failed) return fail(ctx, T2L_ESTATE, "t2l_text_head_backward: the cross-rank sum callback (t2l_train_sync_bn) failed");
+  return T2L_OK;
+}
+
+// ---- the head's optimizer: torch.optim.Adam's arithmetic (adam_kernel) over every bound parameter in ONE launch
+int text_adam_step_impl(t2l_ctx* ctx, float lr, float b1, float b2, float eps, hipStream_t s) {
+  TextTrain* st = tstate(ctx);
+  if (!st) return fail(ctx, T2L_ESTATE, "t2l_text_adam_step: call t2l_text_train_bind first");
+  st->step += 1;
+  const float bc1 = (float)(1.0 - pow((double)b1, (double)st->step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)b2, (double)st->step));
+  event_begin(ctx, "text_adam_step", s);
+  hipLaunchKernelGGL(adam_kernel, dim3(st->n_chunks), dim3(256), 0, s, st->d_tensors, st->d_chunks, lr, b1, b2, eps, bc1, bc2s);
+  event_end(ctx, "text_adam_step", s);
+  T2L_HIP(ctx, hipGetLastError());
+  return T2L_OK;
+}
+
+int text_zero_grad_impl(t2l_ctx* ctx, hipStream_t s) {
+  TextTrain* st = tstate(ctx);
+  if (!st) return fail(ctx, T2L_ESTATE, "t2l_text_zero_grad: call t2l_text_train_bind first");
+  hipLaunchKernelGGL(zero_kernel, dim3(st->n_chunks), dim3(256), 0, s, st->d_tensors, st->d_chunks);
+  T2L_HIP(ctx, hipGetLastError());
+  return T2L_OK;
+}
+
+int text_adam_state_impl(t2l_ctx* ctx, int set, float* m, float* v, int64_t* step, int64_t* numel, hipStream_t s) {
+  TextTrain* st = tstate(ctx);
+  if (!st) return fail(ctx, T2L_ESTATE, "t2l_text_adam_state: call t2l_text_train_bind first");
+  if (numel) *numel = st->mv_total;
+  if (!m && !v) {
+    if (step && !set) *step = st->step;
+    return T2L_OK;
+  }
+  if (!m || !v || !step) return fail(ctx, T2L_EINVAL, "t2l_text_adam_state: pass m, v and step together");
+  const size_t bytes = sizeof(float) * (size_t)st->mv_total;
+  if (set) {
+    T2L_HIP(ctx, hipMemcpyAsync(st->mv, m, bytes, hipMemcpyDeviceToDevice, s));
+    T2L_HIP(ctx, hipMemcpyAsync(st->mv + st->mv_total, v, bytes, hipMemcpyDeviceToDevice, s));
+    st->step = *step;
+  } else {
+    T2L_HIP(ctx, hipMemcpyAsync(m, st->mv, bytes, hipMemcpyDeviceToDevice, s));
+    T2L_HIP(ctx, hipMemcpyAsync(v, st->mv + st->mv_total, bytes, hipMemcpyDeviceToDevice, s));
+    *step = st->step;
+  }
   return T2L_OK;
 }
 

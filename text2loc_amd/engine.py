@@ -90,6 +90,10 @@ EXPORTS = {
     "t2l_text_head_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2l_pointnet_features_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "t2l_pointnet_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "t2l_text_adam_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "t2l_text_zero_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "t2l_text_adam_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                      C.c_void_p]),
     "t2l_train_sync_bn_doubles": (C.c_int64, []),
     "t2l_train_sync_bn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "t2l_zero_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -514,6 +518,33 @@ class Engine:
         v = v.to(dev, torch.float32).contiguous()
         self._check(self.lib.t2l_adam_state(self._h, 1, m.data_ptr(), v.data_ptr(), C.byref(st), C.byref(n), _stream_ptr(self.device)))
         torch.cuda.current_stream(self.device).synchronize()  # m, v may be temporaries (the ENGINE's device: not the caller's current one)
+
+    # ---- the text head's optimizer (t2l_text_adam_step: the tensors of text_train_bind that carry a gradient buffer, bind order)
+    def text_zero_grad(self):
+        self._check(self.lib.t2l_text_zero_grad(self._h, _stream_ptr(self.device)))
+
+    def text_adam_step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
+        self._check(self.lib.t2l_text_adam_step(self._h, float(lr), float(beta1), float(beta2), float(eps), _stream_ptr(self.device)))
+
+    def text_adam_state(self):
+        n, step = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.t2l_text_adam_state(self._h, 0, None, None, C.byref(step), C.byref(n), _stream_ptr(self.device)))
+        dev = torch.device("cuda", self.device)
+        m = torch.empty((int(n.value),), dtype=torch.float32, device=dev)
+        v = torch.empty_like(m)
+        self._check(self.lib.t2l_text_adam_state(self._h, 0, m.data_ptr(), v.data_ptr(), C.byref(step), C.byref(n), _stream_ptr(self.device)))
+        return m, v, int(step.value)
+
+    def set_text_adam_state(self, m: torch.Tensor, v: torch.Tensor, step: int):
+        n, st = C.c_int64(0), C.c_int64(int(step))
+        self._check(self.lib.t2l_text_adam_state(self._h, 0, None, None, C.byref(C.c_int64(0)), C.byref(n), _stream_ptr(self.device)))
+        if int(m.numel()) != int(n.value) or int(v.numel()) != int(n.value):
+            raise T2LError(f"text-head adam state of {int(m.numel())} elements does not match the bound tensors ({int(n.value)})")
+        dev = torch.device("cuda", self.device)
+        m = m.to(dev, torch.float32).contiguous()
+        v = v.to(dev, torch.float32).contiguous()
+        self._check(self.lib.t2l_text_adam_state(self._h, 1, m.data_ptr(), v.data_ptr(), C.byref(st), C.byref(n), _stream_ptr(self.device)))
+        torch.cuda.current_stream(self.device).synchronize()
 
     # ------------------------------------------------------------------ database + search
     def db_set(self, emb: torch.Tensor, row_offset: int = 0, owner=None):

@@ -34,16 +34,24 @@ def all_reduce_flat(buf: torch.Tensor, group=None, mean: bool = False) -> torch.
 
 class Adam(torch.optim.Optimizer):
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, group=None, grad_reduce: str = "sum",
-                 data_parallel: bool = False, sync_bn: bool = False):
+                 data_parallel: bool = False, sync_bn: bool = False, text_engine: bool = True):
         """``group``: a torch.distributed process group, or ``data_parallel=True`` for the default one — turns the gradient
         all-reduce of ``step()`` on. ``sync_bn``: also ``model.sync_batchnorm(group)`` — BatchNorm statistics over all ranks' batches,
-        i.e. the reference's one-process step on the global batch."""
+        i.e. the reference's one-process step on the global batch. ``text_engine``: the language head's trained parameters (when the
+        engine's training head serves this model: ``LanguageEncoder.engine_optimizer_params``) are stepped by ``t2l_text_adam_step`` — one
+        launch, moments inside the library — instead of a torch.optim.Adam beside the engine."""
         if grad_reduce not in ("sum", "mean"):
             raise ValueError("grad_reduce must be 'sum' or 'mean'")
         self._group, self._grad_reduce, self._dp = group, grad_reduce, bool(data_parallel) or group is not None
-        obj, rest = [], []
+        obj, rest, text = [], [], []
+        le = getattr(model, "language_encoder", None)
+        on_gpu = any(p.is_cuda for p in model.parameters())
+        text_ids = {id(p) for _, p in le.engine_optimizer_params()} if (text_engine and on_gpu and hasattr(le, "engine_optimizer_params")) else set()
         for n, p in model.named_parameters():
             if not p.requires_grad:
+                continue
+            if id(p) in text_ids:
+                text.append(p)  # the text head's trained parameters: t2l_text_adam_step (one launch, moments inside the library)
                 continue
             if n.startswith(("object_encoder.pointnet.class_classifier.", "object_encoder.pointnet.color_classifier.")):
                 rest.append(p)  # not on the path (features2 is consumed): .grad stays None, torch skips them as in the reference
@@ -54,8 +62,11 @@ class Adam(torch.optim.Optimizer):
         groups = [{"params": obj, "t2l_engine": True}]
         if rest:
             groups.append({"params": rest, "t2l_engine": False})
+        if text:
+            groups.append({"params": text, "t2l_engine": "text_head"})
         super().__init__(groups, dict(lr=lr, betas=tuple(betas), eps=eps))
         self._model = model
+        self._text = bool(text)
         if sync_bn:
             model.sync_batchnorm(group)
         self._torch = torch.optim.Adam(rest, lr=lr, betas=tuple(betas), eps=eps) if rest else None
@@ -64,6 +75,8 @@ class Adam(torch.optim.Optimizer):
         """Object-branch gradients are zeroed IN PLACE by one kernel (the engine accumulates into fixed buffers)."""
         if self._model.device.type == "cuda":
             self._model.train_engine().zero_grad()
+            if self._text:
+                self._model.language_encoder.engine_zero_grad()  # in place: the engine accumulates into the bound buffers
         if self._torch is not None:
             self._torch.zero_grad(set_to_none=set_to_none)
 
@@ -115,20 +128,28 @@ class Adam(torch.optim.Optimizer):
         eng.adam_step(g["lr"], g["betas"][0], g["betas"][1], g["eps"])
         self._model._train_generation += 1  # parameters changed behind torch's back: eval weights must be re-folded
         if self._torch is not None:
-            for src, dst in zip(self.param_groups[1:], self._torch.param_groups):
+            for src, dst in zip([g_ for g_ in self.param_groups[1:] if g_["t2l_engine"] is False], self._torch.param_groups):
                 dst["lr"], dst["betas"], dst["eps"] = src["lr"], src["betas"], src["eps"]
             self._torch.step()
+        if self._text:
+            gt = self.param_groups[-1]
+            self._model.language_encoder.engine_adam_step(gt["lr"], gt["betas"], gt["eps"])
         return loss
 
     # ---- checkpoint / resume: the engine-side moments are part of the optimizer state -------------------------------
     def state_dict(self):
         sd = {"param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
-              "torch": self._torch.state_dict() if self._torch is not None else None, "t2l_engine": None}
+              "torch": self._torch.state_dict() if self._torch is not None else None, "t2l_engine": None, "t2l_text_engine": None}
         if self._model.device.type == "cuda":
             m, v, step = self._model.train_engine().adam_state()
             # the engine keeps one bias-correction step for the object branch and one for the PointNet++ backbone (which only steps
             # when its backward ran): two explicit fields (round 3 leaked the packed word step | step_pn << 32 into "step")
             sd["t2l_engine"] = {"exp_avg": m.cpu(), "exp_avg_sq": v.cpu(), "step": int(step) & 0xFFFFFFFF, "step_pn": int(step) >> 32}
+            if self._text:
+                le = self._model.language_encoder
+                le._bind_text_train(self._model.device)
+                m, v, step = le._th_train_engine.text_adam_state()
+                sd["t2l_text_engine"] = {"exp_avg": m.cpu(), "exp_avg_sq": v.cpu(), "step": int(step)}
         return sd
 
     def load_state_dict(self, sd):
@@ -141,3 +162,8 @@ class Adam(torch.optim.Optimizer):
             step = int(e["step"])
             step_pn = int(e["step_pn"]) if "step_pn" in e else (step >> 32 if step >> 32 else step & 0xFFFFFFFF)  # older checkpoints:
             self._model.train_engine().set_adam_state(e["exp_avg"], e["exp_avg_sq"], (step & 0xFFFFFFFF) | (step_pn << 32))  # packed, or one step for both
+        t = sd.get("t2l_text_engine")
+        if t is not None and self._text:
+            le = self._model.language_encoder
+            le._bind_text_train(self._model.device)
+            le._th_train_engine.set_text_adam_state(t["exp_avg"], t["exp_avg_sq"], int(t["step"]))
