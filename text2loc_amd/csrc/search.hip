@@ -1177,6 +1177,17 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
   float4 rows[L / 4][4];
   auto gather = [&](int p) {
     const int row = __shfl(my_row, 4 * p + (lane >> 4));  // candidate 4p + g is re-scored by 16-lane row g
+#ifdef T2L_EXP_RERANK_TWICE  // dev experiment: every gather also fetches a second, unrelated row (results unchanged): is the re-rank
+    {                         // bound by its gather traffic? (tools/listwrite_probe.py; measured: see DESIGN 3.2)
+      const int other = row == INT_MAX ? 0 : (row * 7 + 13) % n_rows;
+      const float4* op = reinterpret_cast<const float4*>(db + (size_t)other * kD) + seg;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float4 v = op[16 * i];
+        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+      }
+    }
+#endif
     const float4* rp = reinterpret_cast<const float4*>(db + (size_t)(row == INT_MAX ? 0 : row) * kD) + seg;
 #pragma unroll
     for (int i = 0; i < 4; ++i) rows[p][i] = rp[16 * i];

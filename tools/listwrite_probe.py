@@ -29,5 +29,13 @@ for _ in range(3):
         eng.search(qd, 10)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 400
-    ks = {k: eng.kernel_stats(k) for k in ("scan", "rerank")} if hasattr(eng, "kernel_stats") else {}
+    eng.set_option("profile_events", 1)
+    eng.set_option("profile_rerank", 1)
+    for nme in ("search_scan", "search_rerank"):
+        eng.kernel_stats(nme)
+    for _ in range(200):
+        eng.search(qd, 10)
+    torch.cuda.synchronize()
+    ks = {nme: round(eng.kernel_stats(nme)[0] * 1e3, 2) for nme in ("search_scan", "search_rerank")}
+    eng.set_option("profile_events", 0)
     print(_LIB_PATH.split("/")[-1], "us/step %.2f" % (dt * 1e6), ks)
