@@ -33,7 +33,12 @@ class TextCache:
         self.hidden = torch.empty((0, self.max_tokens, self.dim), dtype=torch.float32, device=self.device)
         self.n_tok = np.zeros((0,), dtype=np.int32)          # token count of every cached sentence (host: it sizes the batch)
         self._vec: Dict[tuple, torch.Tensor] = {}            # (L, weights version) -> f32[n, D] per-sentence vectors (eval mode)
-        self._desc: Dict[str, np.ndarray] = {}               # description string -> its sentences' rows (evaluation sets repeat)
+        # description string -> slot of (_desc_rows, _desc_n): its sentences' rows (evaluation sets repeat). A batch of 4,096 known
+        # descriptions is one C-speed map() over the dict + one numpy fancy index (a Python loop over per-description arrays + a
+        # concatenate was 0.6 ms of the 0.98 ms cached query path)
+        self._desc: Dict[str, int] = {}
+        self._desc_rows = np.full((1024, 8), -1, dtype=np.int64)
+        self._desc_n = np.zeros((1024,), dtype=np.int32)
         self.t5_sentences = 0                                # sentences that went through T5 (build + later misses)
         self.hits = self.misses = 0
 
@@ -109,26 +114,39 @@ class TextCache:
     def lookup_descriptions(self, descriptions: List[str]):
         """The same for whole descriptions seen before (one dict probe per description instead of a regex split and one probe per
         sentence: 4,096 descriptions cost ~1 ms of Python instead of ~15). -> (rows, L, sentences per description) or None."""
-        parts = []
-        for d in descriptions:
-            r = self._desc.get(d)
-            if r is None:
-                return None
-            parts.append(r)
-        n_per = len(parts[0])
-        if any(len(r) != n_per for r in parts):
+        if not descriptions:
             return None
-        ia = np.concatenate(parts)
+        ids = list(map(self._desc.get, descriptions))
+        if None in ids:
+            return None
+        ids = np.asarray(ids, dtype=np.int64)  # (one list -> array conversion: each fancy index below would repeat it)
+        n = self._desc_n[ids]
+        n_per = int(n[0])
+        if n_per == 0 or (n != n_per).any():
+            return None
+        ia = self._desc_rows[ids, :n_per].reshape(-1)
         self.hits += 1
         return torch.from_numpy(ia).to(self.device), int(self.n_tok[ia].max()), n_per
 
     def remember(self, descriptions: List[str], sentences: List[str]):
         n_per = len(sentences) // max(1, len(descriptions))
+        if n_per == 0:
+            return
         if len(self._desc) > (1 << 20):
             self._desc.clear()
+        if n_per > self._desc_rows.shape[1]:
+            wide = np.full((self._desc_rows.shape[0], n_per), -1, dtype=np.int64)
+            wide[:, :self._desc_rows.shape[1]] = self._desc_rows
+            self._desc_rows = wide
         for i, d in enumerate(descriptions):
             if d not in self._desc:
-                self._desc[d] = np.asarray([self.index[s] for s in sentences[i * n_per:(i + 1) * n_per]], dtype=np.int64)
+                slot = len(self._desc)
+                if slot >= len(self._desc_n):
+                    self._desc_rows = np.concatenate([self._desc_rows, np.full_like(self._desc_rows, -1)])
+                    self._desc_n = np.concatenate([self._desc_n, np.zeros_like(self._desc_n)])
+                self._desc_rows[slot, :n_per] = [self.index[s] for s in sentences[i * n_per:(i + 1) * n_per]]
+                self._desc_n[slot] = n_per
+                self._desc[d] = slot
 
     def hidden_states(self, rows: torch.Tensor, L: int) -> torch.Tensor:
         """[n_sentences, L, dim]: what the reference's tokenizer(padding="longest") + T5 hand the head for these sentences."""
