@@ -108,6 +108,7 @@ struct t2l_ctx {
   int search_auto = 1;
   int pair_ll = 6;       // per-lane list length of the paired scan (5 or 6)
   int wide_repair = 512;  // rows a re-rank wave may re-score in a wide repair before the query goes to an exact scan (0: never)
+  int text_inter_fused = 1;  // t2l_text_inter as one fused launch (0: the nine-launch tiled-GEMM chain of text_head.hip)
   int search_merge = 2;    // the paired scan merges a workgroup's four lists per query into one 32-byte record (search.hip: MERGE / MG):
                            // 0 never, 1 always, 2 while the f16 report cards show next to no failed first certificates (a repair behind
                            // a merged record re-scores 4x the rows of a plain list's)
@@ -211,6 +212,15 @@ int search_join_impl(t2l_ctx* ctx, hipStream_t s);
 void free_lanes(t2l_ctx* ctx);
 int adam_state_impl(t2l_ctx* ctx, int set, float* m, float* v, int64_t* step, int64_t* numel, hipStream_t s);
 void free_train(t2l_ctx* ctx);
+// t2l_text_inter as ONE launch (encode.hip: text_inter_fused_kernel — the cell encoder's per-tile transformer layer at S sentences per
+// description): the inter layer's matrices in the encoder's split-f16 fragment packing (mfma_h3.h: pack_split_f16) + its f32 vectors
+struct InterFusedW {
+  const uint4 *in_hp = nullptr, *out_hp = nullptr, *ff1_hp = nullptr, *ff2_hp = nullptr;
+  const float *in_b = nullptr, *out_b = nullptr, *ff1_b = nullptr, *ff2_b = nullptr, *ln1_w = nullptr, *ln1_b = nullptr, *ln2_w = nullptr,
+              *ln2_b = nullptr;
+};
+int text_inter_fused_launch(t2l_ctx* ctx, const InterFusedW& W, bool single, const float* sent, int n_desc, int S, float* out, int* flag,
+                            hipStream_t s);
 void free_text_train(t2l_ctx* ctx);
 int text_adam_step_impl(t2l_ctx* ctx, float lr, float b1, float b2, float eps, hipStream_t s);
 int text_zero_grad_impl(t2l_ctx* ctx, hipStream_t s);

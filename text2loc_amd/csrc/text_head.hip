@@ -689,6 +689,7 @@ struct Weights {
   int out_dim = 0;  // D of inter_mlp (256 coarse, 128 fine)
   // the inter-sentence layer (inter_module.0: d_model 256, 4 heads, dim_feedforward 1024) — coarse model only
   bool has_inter = false;
+  InterFusedW fused;  // the inter layer once more in the encoder's fragment packing (text_inter_fused_kernel, encode.hip)
   char *i_qkv_h = nullptr, *i_qkv_l = nullptr, *i_out_h = nullptr, *i_out_l = nullptr, *i_ff1_h = nullptr, *i_ff1_l = nullptr, *i_ff2_h = nullptr,
        *i_ff2_l = nullptr;
   float *i_qkv_b = nullptr, *i_out_b = nullptr, *i_ff1_b = nullptr, *i_ff2_b = nullptr, *i_ln1_g = nullptr, *i_ln1_b = nullptr, *i_ln2_g = nullptr,
@@ -823,6 +824,20 @@ int text_head_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const cha
           (rc = vec(it[8]->data, ID, ID, &W->i_ln1_g)) || (rc = vec(it[9]->data, ID, ID, &W->i_ln1_b)) ||
           (rc = vec(it[10]->data, ID, ID, &W->i_ln2_g)) || (rc = vec(it[11]->data, ID, ID, &W->i_ln2_b)))
         return rc;
+      {  // the same four matrices as split-f16 MFMA fragments for the one-launch form (mfma_h3.h packing; 1.5 MB)
+        auto frag = [&](const float* Wm, int rows, int cols, const uint4** dst) -> int {
+          const std::vector<float> pk = pack_split_f16(Wm, nullptr, rows, cols, cols);
+          void* d = nullptr;
+          const int r = upload(pk.data(), pk.size() * sizeof(float), &d);
+          *dst = reinterpret_cast<const uint4*>(d);
+          return r;
+        };
+        if ((rc = frag(it[0]->data, 3 * ID, ID, &W->fused.in_hp)) || (rc = frag(it[2]->data, ID, ID, &W->fused.out_hp)) ||
+            (rc = frag(it[4]->data, IF, ID, &W->fused.ff1_hp)) || (rc = frag(it[6]->data, ID, IF, &W->fused.ff2_hp)))
+          return rc;
+        W->fused.in_b = W->i_qkv_b; W->fused.out_b = W->i_out_b; W->fused.ff1_b = W->i_ff1_b; W->fused.ff2_b = W->i_ff2_b;
+        W->fused.ln1_w = W->i_ln1_g; W->fused.ln1_b = W->i_ln1_b; W->fused.ln2_w = W->i_ln2_g; W->fused.ln2_b = W->i_ln2_b;
+      }
       W->has_inter = true;
     }
   }
@@ -959,6 +974,15 @@ int text_inter_impl(t2l_ctx* ctx, const float* sent, int n_desc, int S, float* o
   if (n_desc <= 0) return n_desc == 0 ? T2L_OK : fail(ctx, T2L_EINVAL, "t2l_text_inter: n_descriptions < 0");
   if (S < 1 || S > kMaxL) return fail(ctx, T2L_EINVAL, "t2l_text_inter: need 1 <= sentences per description <= 32");
   const bool single = ctx->encoder_f16 != 0;
+  if (ctx->text_inter_fused) {  // one launch: a tile of floor(32 / S) descriptions per workgroup, everything in LDS (encode.hip)
+    T2L_HIP(ctx, hipMemsetAsync(W->flag, 0, sizeof(int), s));
+    event_begin(ctx, "text_inter", s);
+    const int rc_ = text_inter_fused_launch(ctx, W->fused, single, sent, n_desc, S, out, W->flag, s);
+    event_end(ctx, "text_inter", s);
+    if (rc_ != T2L_OK) return rc_;
+    if (overflow) T2L_HIP(ctx, hipMemcpyAsync(overflow, W->flag, sizeof(int), hipMemcpyDeviceToDevice, s));
+    return T2L_OK;
+  }
   const int rows_target = 65536;  // descriptions per pass: every intermediate of a pass (11.3 KB per row) stays inside the Infinity Cache
   const int dpc = max(1, min(n_desc, rows_target / S));
   const int m_cap = (dpc * S + kTile - 1) / kTile * kTile;
