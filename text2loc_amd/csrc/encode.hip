@@ -32,6 +32,14 @@
 #ifndef T2L_ENC_UNROLL
 #define T2L_ENC_UNROLL 4
 #endif
+// dev experiment (make exp_enc EXPFLAG=-DT2L_EXP_HOTW, tools/hotw_probe.py; WRONG results, timing only): every weight fragment of a tile
+// comes from its first two k-steps — the packed-weight stream out of the L2 disappears, the instruction stream stays. How much of the
+// fused kernels' time is that stream?
+#ifdef T2L_EXP_HOTW
+#define T2L_WSTEP(s) ((s) & 1)
+#else
+#define T2L_WSTEP(s) (s)
+#endif
 
 namespace t2l {
 
@@ -172,7 +180,7 @@ __device__ __forceinline__ void mm_pair_h(const float* __restrict__ arow, int st
 #pragma unroll T2L_ENC_UNROLL
   for (int s = 0; s < steps; ++s) {
     const HFrag a = split_h<SG>(arow + 8 * s);
-    const HFrag b0 = load_h1<SG>(w0 + s * 128), b1 = load_h1<SG>(w1 + s * 128);
+    const HFrag b0 = load_h1<SG>(w0 + T2L_WSTEP(s) * 128), b1 = load_h1<SG>(w1 + T2L_WSTEP(s) * 128);
     mfma_h3<SG>(acc0, a, b0);
     mfma_h3<SG>(acc1, a, b1);
   }
@@ -457,22 +465,22 @@ __global__ __launch_bounds__(256, NC == 1 ? 2 : 1) void encode_cells_kernel(EncP
 #pragma unroll
             for (int c = 0; c < NC; ++c) xf[c] = split_h<H == 2>(x[c] + col * kLdX + half * 128 + 8 * s);
             {
-              const HFrag f = load_h1<H == 2>(hq0 + s * 128);
+              const HFrag f = load_h1<H == 2>(hq0 + T2L_WSTEP(s) * 128);
 #pragma unroll
               for (int c = 0; c < NC; ++c) mfma_h3<H == 2>(qT0[c], f, xf[c]);
             }
             {
-              const HFrag f = load_h1<H == 2>(hq1 + s * 128);
+              const HFrag f = load_h1<H == 2>(hq1 + T2L_WSTEP(s) * 128);
 #pragma unroll
               for (int c = 0; c < NC; ++c) mfma_h3<H == 2>(qT1[c], f, xf[c]);
             }
             {
-              const HFrag f = load_h1<H == 2>(hk0 + s * 128);
+              const HFrag f = load_h1<H == 2>(hk0 + T2L_WSTEP(s) * 128);
 #pragma unroll
               for (int c = 0; c < NC; ++c) mfma_h3<H == 2>(kT0[c], f, xf[c]);
             }
             {
-              const HFrag f = load_h1<H == 2>(hk1 + s * 128);
+              const HFrag f = load_h1<H == 2>(hk1 + T2L_WSTEP(s) * 128);
 #pragma unroll
               for (int c = 0; c < NC; ++c) mfma_h3<H == 2>(kT1[c], f, xf[c]);
             }
@@ -547,7 +555,7 @@ __global__ __launch_bounds__(256, NC == 1 ? 2 : 1) void encode_cells_kernel(EncP
           const uint4* hv1 = W.in_hp + ((size_t)(17 + 2 * h) * HS * 64 + lane) * 2;
 #pragma unroll 4
           for (int s = 0; s < HS; ++s) {
-            const HFrag f0 = load_h1<H == 2>(hv0 + s * 128), f1 = load_h1<H == 2>(hv1 + s * 128);
+            const HFrag f0 = load_h1<H == 2>(hv0 + T2L_WSTEP(s) * 128), f1 = load_h1<H == 2>(hv1 + T2L_WSTEP(s) * 128);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
               const HFrag xf = split_h<H == 2>(x[c] + col * kLdX + half * 128 + 8 * s);
@@ -727,10 +735,10 @@ __global__ __launch_bounds__(256, 2) void text_inter_fused_kernel(InterFusedW W,
 #pragma unroll 2
       for (int s = 0; s < HS; ++s) {
         const HFrag xf = split_h<SG>(x + col * kLdX + half * 128 + 8 * s);
-        mfma_h3<SG>(qT0, load_h1<SG>(hq0 + s * 128), xf);
-        mfma_h3<SG>(qT1, load_h1<SG>(hq1 + s * 128), xf);
-        mfma_h3<SG>(kT0, load_h1<SG>(hk0 + s * 128), xf);
-        mfma_h3<SG>(kT1, load_h1<SG>(hk1 + s * 128), xf);
+        mfma_h3<SG>(qT0, load_h1<SG>(hq0 + T2L_WSTEP(s) * 128), xf);
+        mfma_h3<SG>(qT1, load_h1<SG>(hq1 + T2L_WSTEP(s) * 128), xf);
+        mfma_h3<SG>(kT0, load_h1<SG>(hk0 + T2L_WSTEP(s) * 128), xf);
+        mfma_h3<SG>(kT1, load_h1<SG>(hk1 + T2L_WSTEP(s) * 128), xf);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
