@@ -462,8 +462,10 @@ int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step,
  * "search_wide_repair" (default 512, at most 1024): rows a re-rank wave may re-score in float64 to settle a query whose certificate failed
  *                     (every kept key that reaches the threshold + every row of a list whose floor does) before the query is
  *                     handed to an exact scan of the whole shard; 0 = off (tests of the exact stages).
- * "text_inter_fused"  (default 1): t2l_text_inter as ONE launch (a tile of floor(32 / S) descriptions per workgroup, everything in LDS);
- *                     0 = the chain of tiled GEMM / attention / LayerNorm launches. Same results (both are tested against the restatement).
+ * "text_inter_fused"  (default 2): t2l_text_inter as ONE launch — 2: two tiles of floor(32 / S) descriptions per eight-wave workgroup, the
+ *                     activations as split-f16 planes in LDS, every weight fragment of out_proj / linear1 / linear2 shared by both tiles;
+ *                     1: one tile per four-wave workgroup on f32 tiles; 0 = the chain of tiled GEMM / attention / LayerNorm launches.
+ *                     Same results (all three are tested against the restatement).
  * "search_merge_lists" (default 2): the paired scan's candidate hand-off to the re-rank. 0 = four 24-byte lists per (query, workgroup);
  *                     1 = ONE 32-byte record (the best 7 of their 24 keys, the source list in two more code bits, + a bound on every other
  *                     key): a third of the bytes written back at the end of the launch, -0.7 us per step at Q = 4096; 2 = records while the

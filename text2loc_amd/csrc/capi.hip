@@ -558,7 +558,8 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     if (value != 0 && value != 1 && value != 2) return fail(ctx, T2L_EINVAL, "text_train_bf16: 0 (f32), 1 (bf16) or 2 (split-bf16)");
     ctx->text_train_bf16 = (int)value;
   } else if (!strcmp(name, "text_inter_fused")) {
-    ctx->text_inter_fused = value != 0;
+    if (value != 0 && value != 1 && value != 2) return fail(ctx, T2L_EINVAL, "text_inter_fused: 0 (GEMM chain), 1 (one launch), 2 (one launch, two tiles per workgroup on LDS planes)");
+    ctx->text_inter_fused = (int)value;
   } else if (!strcmp(name, "search_merge_lists")) {
     if (value != 0 && value != 1 && value != 2) return fail(ctx, T2L_EINVAL, "search_merge_lists: 0 (plain lists), 1 (merged records), 2 (default: by report card)");
     ctx->search_merge = (int)value;

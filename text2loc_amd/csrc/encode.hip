@@ -865,8 +865,372 @@ __global__ __launch_bounds__(256, 2) void text_inter_fused_kernel(InterFusedW W,
   if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicOr(flag, 1);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Second form (option text_inter_fused = 2) — the testbed for the lever the encoder family is left with (the packed-weight
+// stream out of the L2 is worth 23-32 % of these kernels, the per-MFMA VALU work another third): TWO row tiles per workgroup of EIGHT
+// waves, every activation resident in LDS as split-f16 PLANES (hi | lo, rows of 264 halves), so that
+//  * out_proj, linear1 and linear2 (3/4 of the FLOPs) load each weight fragment ONCE for both tiles — wave w owns one 32-wide tile of
+//    output features and multiplies it into both token tiles (products computed transposed: A = weight fragment, B = token fragment);
+//  * no operand is split in a GEMM loop: a token fragment is two ds_read_b128; the splitting happens once per produced element in the
+//    epilogues, which hold 4 consecutive features per register quad (transposed C layout) and store 8-byte plane pieces;
+//  * the attention runs as in the first form, one wave per (tile, head), q/k/v projected per tile (their fragments are not shared), with
+//    O^T = V^T P^T so that its output has the same store-friendly layout.
+// 135 KB of LDS: one workgroup (two waves per SIMD) per CU. The residual is rebuilt from hi + lo (22 significand bits).
+#ifndef T2L_RING_DEPTH
+#define T2L_RING_DEPTH 3
+#endif
+#ifndef T2L_QK_RING
+#define T2L_QK_RING 3
+#endif
+constexpr int kQkRing = T2L_QK_RING;  // the same for the q / k projection (four weight tiles = 32 VGPRs per step; v: twice as deep)
+constexpr int kRingDepth = T2L_RING_DEPTH;  // k-steps of weight fragments in flight per wave in the row-wise products (8 VGPRs per step)
+constexpr int kLdP = 264;                 // halves per plane row (528 B: rows 4 banks apart, as the f32 tiles)
+constexpr int kPlane = kSP * kLdP;        // halves per plane
+typedef _Float16 ti_f16x4 __attribute__((ext_vector_type(4)));
+typedef float ti_f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool SG>
+__device__ __forceinline__ HFrag plane_frag(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo, int off) {
+  HFrag f;
+  f.hi = *reinterpret_cast<const h3_f16x8*>(hi + off);
+  if constexpr (SG) f.lo = f.hi;
+  else f.lo = *reinterpret_cast<const h3_f16x8*>(lo + off);
+  return f;
+}
+template <bool SG>
+__device__ __forceinline__ void plane_put4(_Float16* __restrict__ hi, _Float16* __restrict__ lo, int off, ti_f32x4 v) {
+  const ti_f16x4 h = __builtin_convertvector(v, ti_f16x4);
+  *reinterpret_cast<ti_f16x4*>(hi + off) = h;
+  if constexpr (!SG) *reinterpret_cast<ti_f16x4*>(lo + off) = __builtin_convertvector(v - __builtin_convertvector(h, ti_f32x4), ti_f16x4);
+}
+template <bool SG>
+__device__ __forceinline__ ti_f32x4 plane_get4(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo, int off) {
+  ti_f32x4 v = __builtin_convertvector(*reinterpret_cast<const ti_f16x4*>(hi + off), ti_f32x4);
+  if constexpr (!SG) v += __builtin_convertvector(*reinterpret_cast<const ti_f16x4*>(lo + off), ti_f32x4);
+  return v;
+}
+
+// The weight fragments of one tile pass, STEPS k-steps, through a register ring D steps deep: the fragment of step s + D is requested
+// when step s is consumed, sched_barriers keep the requests where they are written (the compiler otherwise sinks every load to its use:
+// one L2 round trip of ~1 us in front of every 0.1 us of MFMAs). body(s, fragment). Measured on t2l_text_inter (4,096 x 6): no ring
+// 0.218 ms; D = 2 / 3 / 4 / 5 / 6 / 8 / 12 / 16: 0.169 / 0.168 / 0.169 / 0.170 / 0.173 / 0.174 / 0.181 / 0.186 ms — what matters is that the
+// next requests are out before the MFMAs start, not how many (deeper rings cost registers and scalar spills).
+template <bool SG, int STEPS, int D, typename F>
+__device__ __forceinline__ void stream_weights(const uint4* __restrict__ wp, F&& body) {
+  HFrag ring[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) ring[i] = load_h1<SG>(wp + T2L_WSTEP(i) * 128);
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const HFrag wf = ring[s % D];
+    if (s + D < STEPS) ring[s % D] = load_h1<SG>(wp + T2L_WSTEP(s + D) * 128);
+    __builtin_amdgcn_sched_barrier(0);
+    body(s, wf);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(512, 1) void text_inter_fused2_kernel(InterFusedW W, const float* __restrict__ sent, int n_desc, int S, int dpt,
+                                                                   float* __restrict__ out, int* __restrict__ flag) {
+  static_assert(H == 1 || H == 2, "split-f16 or plain f16");
+  constexpr bool SG = H == 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  _Float16* base = reinterpret_cast<_Float16*>(smem);
+  // per tile t: X planes (token tile), B planes (attention output -> hidden pass; at the very end an f32 [32][260] tile)
+  auto XH = [&](int t) { return base + (size_t)(4 * t + 0) * kPlane; };
+  auto XL = [&](int t) { return base + (size_t)(4 * t + 1) * kPlane; };
+  auto BH = [&](int t) { return base + (size_t)(4 * t + 2) * kPlane; };
+  auto BL = [&](int t) { return base + (size_t)(4 * t + 3) * kPlane; };
+  int* grp = reinterpret_cast<int*>(base + (size_t)8 * kPlane);  // [32]: description of a tile-local row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int d0 = blockIdx.x * 2 * dpt;
+  bool bad = false;
+  auto watch = [&](float v) { bad = bad || !(fabsf(v) < kSplitF16Safe); };
+  auto watch4 = [&](ti_f32x4 v) { watch(v[0]); watch(v[1]); watch(v[2]); watch(v[3]); };
+  int nd[2], rows[2];
+  nd[0] = min(dpt, n_desc - d0);
+  nd[1] = max(0, min(dpt, n_desc - d0 - dpt));
+  rows[0] = nd[0] * S;
+  rows[1] = nd[1] * S;
+  // ---- the 64 rows -> planes (8 rows per wave, 4 columns per lane)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = wave * 8 + i, t = r >> 5, lr = r & 31;
+    ti_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (lr < rows[t]) {
+      const float4 g = reinterpret_cast<const float4*>(sent + ((size_t)(d0 + t * dpt) * S + lr) * kD)[lane];
+      v = ti_f32x4{g.x, g.y, g.z, g.w};
+    }
+    watch4(v);
+    plane_put4<SG>(XH(t), XL(t), lr * kLdP + 4 * lane, v);
+  }
+  if (tid < kSP) grp[tid] = tid / S;
+  __syncthreads();
+
+  {  // ---- self-attention: wave -> (tile t, head h); q^T, k^T, v from the tile's planes, scores / softmax / O^T from registers
+    const int t = wave >> 2, h = wave & 3;
+    constexpr int HS = kD / 16;
+    const float* ib = W.in_b;
+    const _Float16 *xh = XH(t) + col * kLdP + half * 128, *xl = XL(t) + col * kLdP + half * 128;
+    f32x16 st;
+    float inv;
+    {
+      f32x16 qT0, qT1, kT0, kT1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) qT0[r] = qT1[r] = kT0[r] = kT1[r] = 0.f;
+      const uint4* hq0 = W.in_hp + ((size_t)(2 * h) * HS * 64 + lane) * 2;
+      const uint4* hq1 = W.in_hp + ((size_t)(2 * h + 1) * HS * 64 + lane) * 2;
+      const uint4* hk0 = W.in_hp + ((size_t)(8 + 2 * h) * HS * 64 + lane) * 2;
+      const uint4* hk1 = W.in_hp + ((size_t)(9 + 2 * h) * HS * 64 + lane) * 2;
+      {  // four weight tiles per step through a ring kQkRing steps deep (32 VGPRs per step)
+        constexpr int D = kQkRing;
+        HFrag ring[D][4];
+        auto load4 = [&](int s, HFrag (&f)[4]) {
+          f[0] = load_h1<SG>(hq0 + T2L_WSTEP(s) * 128);
+          f[1] = load_h1<SG>(hq1 + T2L_WSTEP(s) * 128);
+          f[2] = load_h1<SG>(hk0 + T2L_WSTEP(s) * 128);
+          f[3] = load_h1<SG>(hk1 + T2L_WSTEP(s) * 128);
+        };
+#pragma unroll
+        for (int i = 0; i < D; ++i) load4(i, ring[i]);
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+          HFrag f[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[e] = ring[s % D][e];
+          if (s + D < HS) load4(s + D, ring[s % D]);
+          __builtin_amdgcn_sched_barrier(0);
+          const HFrag xf = plane_frag<SG>(xh, xl, 8 * s);
+          mfma_h3<SG>(qT0, f[0], xf);
+          mfma_h3<SG>(qT1, f[1], xf);
+          mfma_h3<SG>(kT0, f[2], xf);
+          mfma_h3<SG>(kT1, f[3], xf);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
+        qT0[r] += ib[h * 64 + f];
+        qT1[r] += ib[h * 64 + 32 + f];
+        kT0[r] += ib[kD + h * 64 + f];
+        kT1[r] += ib[kD + h * 64 + 32 + f];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kT0[r], qT0[r], st, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kT1[r], qT1[r], st, 0, 0, 0);
+      const int gi = grp[col];
+      float m = -__builtin_inff();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
+        st[r] = (grp[j] == gi) ? st[r] * 0.125f : -__builtin_inff();
+        m = fmaxf(m, st[r]);
+      }
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[r] = __expf(st[r] - m);
+        sum += st[r];
+      }
+      sum += __shfl_xor(sum, 32);
+      inv = 1.f / sum;
+    }
+    {
+      f32x16 v0, v1;  // v straight: lane = feature column, register = token row
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v0[r] = v1[r] = 0.f;
+      const uint4* hv0 = W.in_hp + ((size_t)(16 + 2 * h) * HS * 64 + lane) * 2;
+      const uint4* hv1 = W.in_hp + ((size_t)(17 + 2 * h) * HS * 64 + lane) * 2;
+      {
+        constexpr int D = 2 * kQkRing;
+        HFrag ring[D][2];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          ring[i][0] = load_h1<SG>(hv0 + T2L_WSTEP(i) * 128);
+          ring[i][1] = load_h1<SG>(hv1 + T2L_WSTEP(i) * 128);
+        }
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+          const HFrag f0 = ring[s % D][0], f1 = ring[s % D][1];
+          if (s + D < HS) {
+            ring[s % D][0] = load_h1<SG>(hv0 + T2L_WSTEP(s + D) * 128);
+            ring[s % D][1] = load_h1<SG>(hv1 + T2L_WSTEP(s + D) * 128);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const HFrag xf = plane_frag<SG>(xh, xl, 8 * s);
+          mfma_h3<SG>(v0, xf, f0);
+          mfma_h3<SG>(v1, xf, f1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      const float bv0 = ib[2 * kD + h * 64 + col], bv1 = ib[2 * kD + h * 64 + 32 + col];
+      // O^T[f][i] = sum_j v[j][f] P[i][j]: A = v registers (lane = feature, lane half = the key of register r), B = P registers (lane =
+      // query i, lane half = the same key) -> lane = query (token row), register quad = 4 consecutive features
+      f32x16 o0, o1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = st[r] * inv;
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[r] + bv0, p, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[r] + bv1, p, o1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const ti_f32x4 a = {o0[4 * q], o0[4 * q + 1], o0[4 * q + 2], o0[4 * q + 3]};
+        const ti_f32x4 b = {o1[4 * q], o1[4 * q + 1], o1[4 * q + 2], o1[4 * q + 3]};
+        watch4(a);
+        watch4(b);
+        plane_put4<SG>(BH(t), BL(t), col * kLdP + h * 64 + 8 * q + 4 * half, a);
+        plane_put4<SG>(BH(t), BL(t), col * kLdP + h * 64 + 32 + 8 * q + 4 * half, b);
+      }
+    }
+  }
+  __syncthreads();
+  // operand fragments of the row-wise products: token fragment of tile t at k-step s (this lane's row `col`, k half `half`)
+  const int frow = col * kLdP + half * 128;
+  {  // ---- x = x + o @ out_proj^T + b, transposed: wave w owns output features [32 w, 32 w + 32) for BOTH tiles
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const uint4* wp = W.out_hp + ((size_t)wave * (kD / 16) * 64 + lane) * 2;
+    stream_weights<SG, kD / 16, kRingDepth>(wp, [&](int s, const HFrag& wf) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) mfma_h3<SG>(acc[t], wf, plane_frag<SG>(BH(t) + frow, BL(t) + frow, 8 * s));
+    });
+    const float* b = W.out_b;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f0 = 32 * wave + 8 * q + 4 * half, off = col * kLdP + f0;
+        ti_f32x4 v = plane_get4<SG>(XH(t), XL(t), off);
+        const float4 bb = *reinterpret_cast<const float4*>(b + f0);
+        v += ti_f32x4{acc[t][4 * q] + bb.x, acc[t][4 * q + 1] + bb.y, acc[t][4 * q + 2] + bb.z, acc[t][4 * q + 3] + bb.w};
+        plane_put4<SG>(XH(t), XL(t), off, v);
+      }
+  }
+  __syncthreads();
+  // LayerNorm over the 64 rows, in place on the X planes (8 rows per wave, 4 columns per lane)
+  auto layer_norm_planes = [&](const float* __restrict__ g, const float* __restrict__ be, bool to_f32) {
+    const float4 wv = reinterpret_cast<const float4*>(g)[lane], bv = reinterpret_cast<const float4*>(be)[lane];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = wave * 8 + i, t = r >> 5, lr = r & 31, off = lr * kLdP + 4 * lane;
+      ti_f32x4 v = plane_get4<SG>(XH(t), XL(t), off);
+      const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / kD);
+      v -= mean;
+      const float var = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]) * (1.f / kD);
+      const float inv = 1.f / sqrtf(var + 1e-5f);
+      v = ti_f32x4{v[0] * inv * wv.x + bv.x, v[1] * inv * wv.y + bv.y, v[2] * inv * wv.z + bv.z, v[3] * inv * wv.w + bv.w};
+      if (to_f32) {  // (the last LayerNorm: the tile's B planes become one f32 [32][260] tile for the epilogue)
+        *reinterpret_cast<ti_f32x4*>(reinterpret_cast<float*>(BH(t)) + lr * kLdX + 4 * lane) = v;
+      } else {
+        watch4(v);
+        plane_put4<SG>(XH(t), XL(t), off, v);
+      }
+    }
+  };
+  layer_norm_planes(W.ln1_w, W.ln1_b, false);
+  __syncthreads();
+  {  // ---- feed-forward, four passes of 256 hidden units; wave w: one hidden tile per pass and one output tile, both token tiles
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const float* b1 = W.ff1_b;
+    constexpr int FS = 4 * kD / 16;
+    const int cbase = wave < 4 ? 32 * wave : 128 + 32 * (wave - 4);  // where this wave's hidden tile lives in the B planes
+    for (int c = 0; c < 4; ++c) {
+      const int tf = wave < 4 ? 4 * c + wave : 16 + 4 * c + (wave - 4);
+      f32x16 hT[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hT[t][r] = 0.f;
+      const uint4* w1 = W.ff1_hp + ((size_t)tf * (kD / 16) * 64 + lane) * 2;
+      stream_weights<SG, kD / 16, kRingDepth>(w1, [&](int s, const HFrag& wf) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) mfma_h3<SG>(hT[t], wf, plane_frag<SG>(XH(t) + frow, XL(t) + frow, 8 * s));
+      });
+      if (c) __syncthreads();  // every wave has consumed the previous pass from the B planes
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int u0 = 8 * q + 4 * half;
+          const float4 bb = *reinterpret_cast<const float4*>(b1 + tf * 32 + u0);
+          const ti_f32x4 v = {fmaxf(hT[t][4 * q] + bb.x, 0.f), fmaxf(hT[t][4 * q + 1] + bb.y, 0.f), fmaxf(hT[t][4 * q + 2] + bb.z, 0.f),
+                              fmaxf(hT[t][4 * q + 3] + bb.w, 0.f)};
+          watch4(v);
+          plane_put4<SG>(BH(t), BL(t), col * kLdP + cbase + u0, v);
+        }
+      __syncthreads();
+      const uint4* w2 = W.ff2_hp + (((size_t)wave * FS + 16 * c) * 64 + lane) * 2;
+      stream_weights<SG, kD / 16, kRingDepth>(w2, [&](int s, const HFrag& wf) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) mfma_h3<SG>(acc[t], wf, plane_frag<SG>(BH(t) + frow, BL(t) + frow, 8 * s));
+      });
+    }
+    const float* b2 = W.ff2_b;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f0 = 32 * wave + 8 * q + 4 * half, off = col * kLdP + f0;
+        ti_f32x4 v = plane_get4<SG>(XH(t), XL(t), off);
+        const float4 bb = *reinterpret_cast<const float4*>(b2 + f0);
+        v += ti_f32x4{acc[t][4 * q] + bb.x, acc[t][4 * q + 1] + bb.y, acc[t][4 * q + 2] + bb.z, acc[t][4 * q + 3] + bb.w};
+        plane_put4<SG>(XH(t), XL(t), off, v);
+      }
+  }
+  __syncthreads();  // (also: every wave is done reading the B planes — LayerNorm 2 overwrites them with the f32 tiles)
+  layer_norm_planes(W.ln2_w, W.ln2_b, true);
+  __syncthreads();
+  {  // x_in + layer(x_in), max over the description's S sentences: thread = (tile, column)
+    const int t = tid >> 8, c = tid & 255;
+    const float* y = reinterpret_cast<const float*>(BH(t));
+    const float* src = sent + (size_t)(d0 + t * dpt) * S * kD;
+    for (int d = 0; d < nd[t]; ++d) {
+      float m = -__builtin_inff();
+      for (int s_ = 0; s_ < S; ++s_) {
+        const int r = d * S + s_;
+        m = fmaxf(m, y[r * kLdX + c] + src[(size_t)r * kD + c]);
+      }
+      out[(size_t)(d0 + t * dpt + d) * kD + c] = m;
+    }
+  }
+  if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicOr(flag, 1);
+}
+
 int text_inter_fused_launch(t2l_ctx* ctx, const InterFusedW& W, bool single, const float* sent, int n_desc, int S, float* out, int* flag,
                             hipStream_t s) {
+  if (ctx->text_inter_fused == 2) {
+    const int dpt = kSP / S, tiles = (n_desc + 2 * dpt - 1) / (2 * dpt);
+    const size_t lds = (size_t)8 * kPlane * sizeof(_Float16) + kSP * sizeof(int);
+    static PerDeviceOnce once2;
+    if (once2.need(ctx->device)) {
+      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&text_inter_fused2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&text_inter_fused2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      once2.mark(ctx->device);
+    }
+    if (single)
+      hipLaunchKernelGGL(text_inter_fused2_kernel<2>, dim3(tiles), dim3(512), lds, s, W, sent, n_desc, S, dpt, out, flag);
+    else
+      hipLaunchKernelGGL(text_inter_fused2_kernel<1>, dim3(tiles), dim3(512), lds, s, W, sent, n_desc, S, dpt, out, flag);
+    T2L_HIP(ctx, hipGetLastError());
+    return T2L_OK;
+  }
   const int dpt = kSP / S, tiles = (n_desc + dpt - 1) / dpt;
   const size_t lds = (size_t)2 * kXFloats * sizeof(float) + kSP * sizeof(int);
   static PerDeviceOnce once;

@@ -10,7 +10,7 @@ x = torch.randn(4096 * 6, 256, device="cuda")
 a = torch.randn(4096, 4096, device="cuda")
 for _ in range(40):
     a @ a
-for fused in (1, 0, 1, 0):
+for fused in (1, 2, 0, 1, 2, 0):
     eng.set_option("text_inter_fused", fused)
     for _ in range(10):
         eng.text_inter(x, 4096, check=False)
