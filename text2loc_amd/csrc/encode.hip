@@ -930,50 +930,27 @@ __device__ __forceinline__ void stream_weights(const uint4* __restrict__ wp, F&&
   }
 }
 
-template <int H>
-__global__ __launch_bounds__(512, 1) void text_inter_fused2_kernel(InterFusedW W, const float* __restrict__ sent, int n_desc, int S, int dpt,
-                                                                   float* __restrict__ out, int* __restrict__ flag) {
-  static_assert(H == 1 || H == 2, "split-f16 or plain f16");
-  constexpr bool SG = H == 2;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  _Float16* base = reinterpret_cast<_Float16*>(smem);
-  // per tile t: X planes (token tile), B planes (attention output -> hidden pass; at the very end an f32 [32][260] tile)
-  auto XH = [&](int t) { return base + (size_t)(4 * t + 0) * kPlane; };
-  auto XL = [&](int t) { return base + (size_t)(4 * t + 1) * kPlane; };
-  auto BH = [&](int t) { return base + (size_t)(4 * t + 2) * kPlane; };
-  auto BL = [&](int t) { return base + (size_t)(4 * t + 3) * kPlane; };
-  int* grp = reinterpret_cast<int*>(base + (size_t)8 * kPlane);  // [32]: description of a tile-local row
+__device__ __forceinline__ _Float16* pl_xh(_Float16* base, int t) { return base + (size_t)(4 * t + 0) * kPlane; }
+__device__ __forceinline__ _Float16* pl_xl(_Float16* base, int t) { return base + (size_t)(4 * t + 1) * kPlane; }
+__device__ __forceinline__ _Float16* pl_bh(_Float16* base, int t) { return base + (size_t)(4 * t + 2) * kPlane; }
+__device__ __forceinline__ _Float16* pl_bl(_Float16* base, int t) { return base + (size_t)(4 * t + 3) * kPlane; }
+
+// One post-norm TransformerEncoderLayer (d_model 256, 4 heads, ReLU, feed-forward of 256 FFP units) over the TWO 32-row token tiles of an
+// eight-wave workgroup, in place on the tiles' X planes (B planes: scratch). mask(i, j): may query row i see key row j (tile-local)?
+// WATCH: run-time f16-range watch on everything that enters a split product (`bad`). last_to_f32: the final LayerNorm leaves f32
+// [32][260] tiles in the B-plane regions instead of planes (for an epilogue that needs full precision). Ends behind a barrier.
+template <bool SG, int FFP, bool WATCH, typename Mask>
+__device__ __forceinline__ void planes_layer(_Float16* base, const InterFusedW& W, Mask mask, bool& bad, bool last_to_f32) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
-  const int d0 = blockIdx.x * 2 * dpt;
-  bool bad = false;
   auto watch = [&](float v) { bad = bad || !(fabsf(v) < kSplitF16Safe); };
   auto watch4 = [&](ti_f32x4 v) { watch(v[0]); watch(v[1]); watch(v[2]); watch(v[3]); };
-  int nd[2], rows[2];
-  nd[0] = min(dpt, n_desc - d0);
-  nd[1] = max(0, min(dpt, n_desc - d0 - dpt));
-  rows[0] = nd[0] * S;
-  rows[1] = nd[1] * S;
-  // ---- the 64 rows -> planes (8 rows per wave, 4 columns per lane)
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int r = wave * 8 + i, t = r >> 5, lr = r & 31;
-    ti_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (lr < rows[t]) {
-      const float4 g = reinterpret_cast<const float4*>(sent + ((size_t)(d0 + t * dpt) * S + lr) * kD)[lane];
-      v = ti_f32x4{g.x, g.y, g.z, g.w};
-    }
-    watch4(v);
-    plane_put4<SG>(XH(t), XL(t), lr * kLdP + 4 * lane, v);
-  }
-  if (tid < kSP) grp[tid] = tid / S;
-  __syncthreads();
-
+  (void)watch4;
   {  // ---- self-attention: wave -> (tile t, head h); q^T, k^T, v from the tile's planes, scores / softmax / O^T from registers
     const int t = wave >> 2, h = wave & 3;
     constexpr int HS = kD / 16;
     const float* ib = W.in_b;
-    const _Float16 *xh = XH(t) + col * kLdP + half * 128, *xl = XL(t) + col * kLdP + half * 128;
+    const _Float16 *xh = pl_xh(base, t) + col * kLdP + half * 128, *xl = pl_xl(base, t) + col * kLdP + half * 128;
     f32x16 st;
     float inv;
     {
@@ -1024,12 +1001,11 @@ __global__ __launch_bounds__(512, 1) void text_inter_fused2_kernel(InterFusedW W
       for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kT0[r], qT0[r], st, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kT1[r], qT1[r], st, 0, 0, 0);
-      const int gi = grp[col];
       float m = -__builtin_inff();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
-        st[r] = (grp[j] == gi) ? st[r] * 0.125f : -__builtin_inff();
+        st[r] = mask(col, j) ? st[r] * 0.125f : -__builtin_inff();
         m = fmaxf(m, st[r]);
       }
       m = fmaxf(m, __shfl_xor(m, 32));
@@ -1086,10 +1062,10 @@ __global__ __launch_bounds__(512, 1) void text_inter_fused2_kernel(InterFusedW W
       for (int q = 0; q < 4; ++q) {
         const ti_f32x4 a = {o0[4 * q], o0[4 * q + 1], o0[4 * q + 2], o0[4 * q + 3]};
         const ti_f32x4 b = {o1[4 * q], o1[4 * q + 1], o1[4 * q + 2], o1[4 * q + 3]};
-        watch4(a);
-        watch4(b);
-        plane_put4<SG>(BH(t), BL(t), col * kLdP + h * 64 + 8 * q + 4 * half, a);
-        plane_put4<SG>(BH(t), BL(t), col * kLdP + h * 64 + 32 + 8 * q + 4 * half, b);
+        if constexpr (WATCH) watch4(a);
+        if constexpr (WATCH) watch4(b);
+        plane_put4<SG>(pl_bh(base, t), pl_bl(base, t), col * kLdP + h * 64 + 8 * q + 4 * half, a);
+        plane_put4<SG>(pl_bh(base, t), pl_bl(base, t), col * kLdP + h * 64 + 32 + 8 * q + 4 * half, b);
       }
     }
   }
@@ -1105,7 +1081,7 @@ __global__ __launch_bounds__(512, 1) void text_inter_fused2_kernel(InterFusedW W
     const uint4* wp = W.out_hp + ((size_t)wave * (kD / 16) * 64 + lane) * 2;
     stream_weights<SG, kD / 16, kRingDepth>(wp, [&](int s, const HFrag& wf) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) mfma_h3<SG>(acc[t], wf, plane_frag<SG>(BH(t) + frow, BL(t) + frow, 8 * s));
+      for (int t = 0; t < 2; ++t) mfma_h3<SG>(acc[t], wf, plane_frag<SG>(pl_bh(base, t) + frow, pl_bl(base, t) + frow, 8 * s));
     });
     const float* b = W.out_b;
 #pragma unroll
@@ -1113,10 +1089,10 @@ __global__ __launch_bounds__(512, 1) void text_inter_fused2_kernel(InterFusedW W
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int f0 = 32 * wave + 8 * q + 4 * half, off = col * kLdP + f0;
-        ti_f32x4 v = plane_get4<SG>(XH(t), XL(t), off);
+        ti_f32x4 v = plane_get4<SG>(pl_xh(base, t), pl_xl(base, t), off);
         const float4 bb = *reinterpret_cast<const float4*>(b + f0);
         v += ti_f32x4{acc[t][4 * q] + bb.x, acc[t][4 * q + 1] + bb.y, acc[t][4 * q + 2] + bb.z, acc[t][4 * q + 3] + bb.w};
-        plane_put4<SG>(XH(t), XL(t), off, v);
+        plane_put4<SG>(pl_xh(base, t), pl_xl(base, t), off, v);
       }
   }
   __syncthreads();
@@ -1126,17 +1102,17 @@ __global__ __launch_bounds__(512, 1) void text_inter_fused2_kernel(InterFusedW W
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = wave * 8 + i, t = r >> 5, lr = r & 31, off = lr * kLdP + 4 * lane;
-      ti_f32x4 v = plane_get4<SG>(XH(t), XL(t), off);
+      ti_f32x4 v = plane_get4<SG>(pl_xh(base, t), pl_xl(base, t), off);
       const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / kD);
       v -= mean;
       const float var = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]) * (1.f / kD);
       const float inv = 1.f / sqrtf(var + 1e-5f);
       v = ti_f32x4{v[0] * inv * wv.x + bv.x, v[1] * inv * wv.y + bv.y, v[2] * inv * wv.z + bv.z, v[3] * inv * wv.w + bv.w};
       if (to_f32) {  // (the last LayerNorm: the tile's B planes become one f32 [32][260] tile for the epilogue)
-        *reinterpret_cast<ti_f32x4*>(reinterpret_cast<float*>(BH(t)) + lr * kLdX + 4 * lane) = v;
+        *reinterpret_cast<ti_f32x4*>(reinterpret_cast<float*>(pl_bh(base, t)) + lr * kLdX + 4 * lane) = v;
       } else {
-        watch4(v);
-        plane_put4<SG>(XH(t), XL(t), off, v);
+        if constexpr (WATCH) watch4(v);
+        plane_put4<SG>(pl_xh(base, t), pl_xl(base, t), off, v);
       }
     }
   };
@@ -1149,10 +1125,10 @@ __global__ __launch_bounds__(512, 1) void text_inter_fused2_kernel(InterFusedW W
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const float* b1 = W.ff1_b;
-    constexpr int FS = 4 * kD / 16;
+    constexpr int FS = FFP * kD / 16;  // k-steps of one W2 tile
     const int cbase = wave < 4 ? 32 * wave : 128 + 32 * (wave - 4);  // where this wave's hidden tile lives in the B planes
-    for (int c = 0; c < 4; ++c) {
-      const int tf = wave < 4 ? 4 * c + wave : 16 + 4 * c + (wave - 4);
+    for (int c = 0; c < FFP; ++c) {
+      const int tf = wave < 4 ? 4 * c + wave : 4 * FFP + 4 * c + (wave - 4);
       f32x16 hT[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -1161,7 +1137,7 @@ __global__ __launch_bounds__(512, 1) void text_inter_fused2_kernel(InterFusedW W
       const uint4* w1 = W.ff1_hp + ((size_t)tf * (kD / 16) * 64 + lane) * 2;
       stream_weights<SG, kD / 16, kRingDepth>(w1, [&](int s, const HFrag& wf) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) mfma_h3<SG>(hT[t], wf, plane_frag<SG>(XH(t) + frow, XL(t) + frow, 8 * s));
+        for (int t = 0; t < 2; ++t) mfma_h3<SG>(hT[t], wf, plane_frag<SG>(pl_xh(base, t) + frow, pl_xl(base, t) + frow, 8 * s));
       });
       if (c) __syncthreads();  // every wave has consumed the previous pass from the B planes
 #pragma unroll
@@ -1172,14 +1148,14 @@ __global__ __launch_bounds__(512, 1) void text_inter_fused2_kernel(InterFusedW W
           const float4 bb = *reinterpret_cast<const float4*>(b1 + tf * 32 + u0);
           const ti_f32x4 v = {fmaxf(hT[t][4 * q] + bb.x, 0.f), fmaxf(hT[t][4 * q + 1] + bb.y, 0.f), fmaxf(hT[t][4 * q + 2] + bb.z, 0.f),
                               fmaxf(hT[t][4 * q + 3] + bb.w, 0.f)};
-          watch4(v);
-          plane_put4<SG>(BH(t), BL(t), col * kLdP + cbase + u0, v);
+          if constexpr (WATCH) watch4(v);
+          plane_put4<SG>(pl_bh(base, t), pl_bl(base, t), col * kLdP + cbase + u0, v);
         }
       __syncthreads();
       const uint4* w2 = W.ff2_hp + (((size_t)wave * FS + 16 * c) * 64 + lane) * 2;
       stream_weights<SG, kD / 16, kRingDepth>(w2, [&](int s, const HFrag& wf) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) mfma_h3<SG>(acc[t], wf, plane_frag<SG>(BH(t) + frow, BL(t) + frow, 8 * s));
+        for (int t = 0; t < 2; ++t) mfma_h3<SG>(acc[t], wf, plane_frag<SG>(pl_bh(base, t) + frow, pl_bl(base, t) + frow, 8 * s));
       });
     }
     const float* b2 = W.ff2_b;
@@ -1188,15 +1164,57 @@ __global__ __launch_bounds__(512, 1) void text_inter_fused2_kernel(InterFusedW W
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int f0 = 32 * wave + 8 * q + 4 * half, off = col * kLdP + f0;
-        ti_f32x4 v = plane_get4<SG>(XH(t), XL(t), off);
+        ti_f32x4 v = plane_get4<SG>(pl_xh(base, t), pl_xl(base, t), off);
         const float4 bb = *reinterpret_cast<const float4*>(b2 + f0);
         v += ti_f32x4{acc[t][4 * q] + bb.x, acc[t][4 * q + 1] + bb.y, acc[t][4 * q + 2] + bb.z, acc[t][4 * q + 3] + bb.w};
-        plane_put4<SG>(XH(t), XL(t), off, v);
+        plane_put4<SG>(pl_xh(base, t), pl_xl(base, t), off, v);
       }
   }
   __syncthreads();  // (also: every wave is done reading the B planes — LayerNorm 2 overwrites them with the f32 tiles)
-  layer_norm_planes(W.ln2_w, W.ln2_b, true);
+  layer_norm_planes(W.ln2_w, W.ln2_b, last_to_f32);
   __syncthreads();
+}
+
+template <int H>
+__global__ __launch_bounds__(512, 1) void text_inter_fused2_kernel(InterFusedW W, const float* __restrict__ sent, int n_desc, int S, int dpt,
+                                                                   float* __restrict__ out, int* __restrict__ flag) {
+  static_assert(H == 1 || H == 2, "split-f16 or plain f16");
+  constexpr bool SG = H == 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  _Float16* base = reinterpret_cast<_Float16*>(smem);
+  // per tile t: X planes (token tile), B planes (attention output -> hidden pass; at the very end an f32 [32][260] tile)
+  auto XH = [&](int t) { return base + (size_t)(4 * t + 0) * kPlane; };
+  auto XL = [&](int t) { return base + (size_t)(4 * t + 1) * kPlane; };
+  auto BH = [&](int t) { return base + (size_t)(4 * t + 2) * kPlane; };
+  auto BL = [&](int t) { return base + (size_t)(4 * t + 3) * kPlane; };
+  int* grp = reinterpret_cast<int*>(base + (size_t)8 * kPlane);  // [32]: description of a tile-local row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int d0 = blockIdx.x * 2 * dpt;
+  bool bad = false;
+  auto watch = [&](float v) { bad = bad || !(fabsf(v) < kSplitF16Safe); };
+  auto watch4 = [&](ti_f32x4 v) { watch(v[0]); watch(v[1]); watch(v[2]); watch(v[3]); };
+  int nd[2], rows[2];
+  nd[0] = min(dpt, n_desc - d0);
+  nd[1] = max(0, min(dpt, n_desc - d0 - dpt));
+  rows[0] = nd[0] * S;
+  rows[1] = nd[1] * S;
+  // ---- the 64 rows -> planes (8 rows per wave, 4 columns per lane)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = wave * 8 + i, t = r >> 5, lr = r & 31;
+    ti_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (lr < rows[t]) {
+      const float4 g = reinterpret_cast<const float4*>(sent + ((size_t)(d0 + t * dpt) * S + lr) * kD)[lane];
+      v = ti_f32x4{g.x, g.y, g.z, g.w};
+    }
+    watch4(v);
+    plane_put4<SG>(XH(t), XL(t), lr * kLdP + 4 * lane, v);
+  }
+  if (tid < kSP) grp[tid] = tid / S;
+  __syncthreads();
+
+  planes_layer<SG, 4, true>(base, W, [&](int i, int j) { return grp[i] == grp[j]; }, bad, true);
   {  // x_in + layer(x_in), max over the description's S sentences: thread = (tile, column)
     const int t = tid >> 8, c = tid & 255;
     const float* y = reinterpret_cast<const float*>(BH(t));
