@@ -557,6 +557,8 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
   } else if (!strcmp(name, "text_train_bf16")) {
     if (value != 0 && value != 1 && value != 2) return fail(ctx, T2L_EINVAL, "text_train_bf16: 0 (f32), 1 (bf16) or 2 (split-bf16)");
     ctx->text_train_bf16 = (int)value;
+  } else if (!strcmp(name, "encoder_two_cells")) {
+    ctx->encoder_two_cells = value != 0;
   } else if (!strcmp(name, "text_inter_fused")) {
     if (value != 0 && value != 1 && value != 2) return fail(ctx, T2L_EINVAL, "text_inter_fused: 0 (GEMM chain), 1 (one launch), 2 (one launch, two tiles per workgroup on LDS planes)");
     ctx->text_inter_fused = (int)value;

@@ -901,12 +901,13 @@ template <bool SG>
 __device__ __forceinline__ void plane_put4(_Float16* __restrict__ hi, _Float16* __restrict__ lo, int off, ti_f32x4 v) {
   const ti_f16x4 h = __builtin_convertvector(v, ti_f16x4);
   *reinterpret_cast<ti_f16x4*>(hi + off) = h;
-  if constexpr (!SG) *reinterpret_cast<ti_f16x4*>(lo + off) = __builtin_convertvector(v - __builtin_convertvector(h, ti_f32x4), ti_f16x4);
+  // (the plain-f16 option drops the low halves from the PRODUCTS only: the stored activations — the residual stream — keep both)
+  *reinterpret_cast<ti_f16x4*>(lo + off) = __builtin_convertvector(v - __builtin_convertvector(h, ti_f32x4), ti_f16x4);
 }
 template <bool SG>
 __device__ __forceinline__ ti_f32x4 plane_get4(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo, int off) {
   ti_f32x4 v = __builtin_convertvector(*reinterpret_cast<const ti_f16x4*>(hi + off), ti_f32x4);
-  if constexpr (!SG) v += __builtin_convertvector(*reinterpret_cast<const ti_f16x4*>(lo + off), ti_f32x4);
+  v += __builtin_convertvector(*reinterpret_cast<const ti_f16x4*>(lo + off), ti_f32x4);
   return v;
 }
 
@@ -1231,6 +1232,158 @@ __global__ __launch_bounds__(512, 1) void text_inter_fused2_kernel(InterFusedW W
   if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicOr(flag, 1);
 }
 
+// ------------------------------------------------------------------------------------------------
+// encode_cells, second form (option encoder_two_cells, split-f16 / plain-f16 arithmetic, at least two feature slots): the recipe that
+// t2l_text_inter's second form proved — TWO cells per workgroup of EIGHT waves, activations as split-f16 planes in LDS,
+// the weight fragments of the feature merge, out_proj and both feed-forward Linears loaded once for both cells and requested ahead of
+// the MFMAs, nothing split inside a GEMM loop. The feature stage keeps the first form's code: waves 4t .. 4t+3 build cell t's feature
+// slot as a normalised f32 tile (in the cell's X-plane region, not live before the merge epilogue), convert it to the cell's B planes,
+// and all eight waves contract both cells' slot with its slice of the merge weight.
+template <int H>
+__global__ __launch_bounds__(512, 1) void encode_cells2_kernel(EncParams P, t2l_packed_cells in, float* __restrict__ out) {
+  static_assert(H == 1 || H == 2, "split-f16 or plain f16 (the all-f32 encoder keeps the first form)");
+  constexpr bool SG = H == 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  _Float16* base = reinterpret_cast<_Float16*>(smem);
+  float* hb_all = reinterpret_cast<float*>(base + (size_t)8 * kPlane);  // [2][32][68]: hidden layer of the small MLPs
+  float* red = hb_all + 2 * kSP * kLdH;                                 // [8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int tc = wave >> 2, lw = wave & 3, ltid = tid & 255;  // the cell this wave builds features for, its wave / thread index there
+  int cell[2], obj0[2], nobj[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    cell[t] = min((int)blockIdx.x * 2 + t, in.n_cells - 1);  // an odd tail workgroup computes its last cell twice
+    obj0[t] = in.offsets[cell[t]];
+    nobj[t] = min(in.offsets[cell[t] + 1] - obj0[t], kS);
+  }
+  float* xf32 = reinterpret_cast<float*>(pl_xh(base, tc));  // this wave group's f32 [32][260] scratch tile (X-plane region of its cell)
+  float* bf32 = reinterpret_cast<float*>(pl_bh(base, tc));  // ... and the B-plane region as one (features2 staging only)
+  float* hb = hb_all + tc * kSP * kLdH;
+  const int my_nobj = nobj[tc], my_obj0 = obj0[tc];
+  const int frow = col * kLdP + half * 128;
+
+  f32x16 keep[2];  // merge accumulators, transposed: wave w = output features [32 w, 32 w + 32), lane = object slot
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) keep[t][r] = 0.f;
+  int slot = 0;
+  auto tile_to_planes = [&]() {  // the group's normalised f32 slot (X region) -> its cell's B planes
+    for (int i = lw; i < kSP; i += 4) {
+      const float4 g = *(reinterpret_cast<const float4*>(xf32 + i * kLdX) + lane);
+      plane_put4<SG>(pl_bh(base, tc), pl_bl(base, tc), i * kLdP + 4 * lane, ti_f32x4{g.x, g.y, g.z, g.w});
+    }
+  };
+  auto table_to_planes = [&](const float* __restrict__ tab, const int32_t* __restrict__ idx, int n_tab) {
+    for (int o = lw; o < kSP; o += 4) {
+      ti_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (o < my_nobj) {
+        const int ci = min(max(idx[my_obj0 + o], 0), n_tab - 1);
+        const float4 g = reinterpret_cast<const float4*>(tab + (size_t)ci * kD)[lane];
+        v = ti_f32x4{g.x, g.y, g.z, g.w};
+      }
+      plane_put4<SG>(pl_bh(base, tc), pl_bl(base, tc), o * kLdP + 4 * lane, v);
+    }
+  };
+  auto merge_slot = [&]() {  // both cells' B planes hold slot `slot`: keep += Wmerge[:, 256 slot : 256 slot + 256] @ slot^T
+    __syncthreads();
+    const uint4* wp = P.merge_hp + (size_t)slot * (kD * kD / 4) + ((size_t)wave * (kD / 16) * 64 + lane) * 2;
+    stream_weights<SG, kD / 16, kRingDepth>(wp, [&](int s, const HFrag& wf) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) mfma_h3<SG>(keep[t], wf, plane_frag<SG>(pl_bh(base, t) + frow, pl_bl(base, t) + frow, 8 * s));
+    });
+    ++slot;
+    __syncthreads();
+  };
+  if (P.use_class) {
+    if (P.class_embed) {
+      table_to_planes(P.class_tab, in.class_idx, P.n_class);
+    } else {  // features2 -> mlp_pointnet (f32: an input, not bounded by the weights) -> normalize
+      for (int o = lw; o < kSP; o += 4) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (o < my_nobj) v = reinterpret_cast<const float4*>(in.pn_feat + (size_t)(my_obj0 + o) * kD)[lane];
+        reinterpret_cast<float4*>(bf32 + o * kLdX)[lane] = v;
+      }
+      __syncthreads();
+      const float* pb = P.pn_b;
+      gemm32(bf32, kLdX, kD, P.pn_wp, kD, lw, lane, [&](int, int, int row, int cc, float v) { xf32[row * kLdX + cc] = fmaxf(v + pb[cc], 0.f); });
+      __syncthreads();
+      normalize_rows(xf32, kLdX, my_nobj, lw, lane);
+      __syncthreads();
+      tile_to_planes();
+    }
+    merge_slot();
+  }
+  if (P.use_color) {
+    if (P.color_embed) {
+      table_to_planes(P.color_tab, in.color_idx, P.n_color);
+    } else {
+      small_mlp<3>(P.color, in.rgb + (size_t)my_obj0 * 3, false, my_nobj, hb, xf32, ltid, lw, lane);
+      __syncthreads();
+      tile_to_planes();
+    }
+    merge_slot();
+  }
+  if (P.use_pos) {
+    small_mlp<3>(P.pos, in.center + (size_t)my_obj0 * 3, false, my_nobj, hb, xf32, ltid, lw, lane);
+    __syncthreads();
+    tile_to_planes();
+    merge_slot();
+  }
+  if (P.use_num) {
+    small_mlp<1>(P.num, in.n_pts + my_obj0, true, my_nobj, hb, xf32, ltid, lw, lane);
+    __syncthreads();
+    tile_to_planes();
+    merge_slot();
+  }
+  {  // merge epilogue: relu(keep + b) -> X planes (lane = object slot, register quad = 4 consecutive features)
+    const float* mb = P.merge_b;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f0 = 32 * wave + 8 * q + 4 * half;
+        const float4 bb = *reinterpret_cast<const float4*>(mb + f0);
+        const ti_f32x4 v = {fmaxf(keep[t][4 * q] + bb.x, 0.f), fmaxf(keep[t][4 * q + 1] + bb.y, 0.f), fmaxf(keep[t][4 * q + 2] + bb.z, 0.f),
+                            fmaxf(keep[t][4 * q + 3] + bb.w, 0.f)};
+        plane_put4<SG>(pl_xh(base, t), pl_xl(base, t), col * kLdP + f0, v);
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {  // F.normalize per object row; rows >= nobj are the zero pad slots (cell_retrieval.py:85,92)
+    const int r = wave * 8 + i, t = r >> 5, lr = r & 31, off = lr * kLdP + 4 * lane;
+    ti_f32x4 v = plane_get4<SG>(pl_xh(base, t), pl_xl(base, t), off);
+    const float ss = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+    const float inv = lr < nobj[t] ? 1.f / fmaxf(sqrtf(ss), 1e-12f) : 0.f;
+    v *= inv;
+    plane_put4<SG>(pl_xh(base, t), pl_xl(base, t), off, v);
+  }
+  __syncthreads();
+  bool bad = false;
+  for (int l = 0; l < P.num_layers; ++l) {
+    const LayerW& L = P.layer[l];
+    InterFusedW W;
+    W.in_hp = L.in_hp; W.out_hp = L.out_hp; W.ff1_hp = L.ff1_hp; W.ff2_hp = L.ff2_hp;
+    W.in_b = L.in_b; W.out_b = L.out_b; W.ff1_b = L.ff1_b; W.ff2_b = L.ff2_b;
+    W.ln1_w = L.ln1_w; W.ln1_b = L.ln1_b; W.ln2_w = L.ln2_w; W.ln2_b = L.ln2_b;
+    // no padding mask: the 28 slots, zero pads included, attend and are attended to; the 4 dead rows of the tile are no keys
+    planes_layer<SG, 2, false>(base, W, [](int, int j) { return j < kS; }, bad, l == P.num_layers - 1);
+  }
+  {  // max over ALL 28 slots, then normalize: thread = (cell, column)
+    const int t = tid >> 8, c = tid & 255;
+    const float* y = reinterpret_cast<const float*>(pl_bh(base, t));
+    float mx = y[c];
+    for (int i = 1; i < kS; ++i) mx = fmaxf(mx, y[i * kLdX + c]);
+    const float ss = wave_sum(mx * mx);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float nrm = sqrtf(red[4 * t] + red[4 * t + 1] + red[4 * t + 2] + red[4 * t + 3]);
+    if ((int)blockIdx.x * 2 + t < in.n_cells) out[(size_t)cell[t] * kD + c] = mx / fmaxf(nrm, 1e-12f);
+  }
+}
+
 int text_inter_fused_launch(t2l_ctx* ctx, const InterFusedW& W, bool single, const float* sent, int n_desc, int S, float* out, int* flag,
                             hipStream_t s) {
   if (ctx->text_inter_fused == 2) {
@@ -1548,6 +1701,22 @@ int encode_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float* out, hipStream_
     attr_done.mark(ctx->device);
   }
   event_begin(ctx, "encode_cells", s);
+  if (P.split_ok && !ctx->encoder_f32 && ctx->encoder_two_cells && P.nfeat > 1) {  // second form: two cells per eight-wave workgroup on planes
+    const size_t lds2 = (size_t)8 * kPlane * sizeof(_Float16) + (size_t)(2 * kSP * kLdH + 8) * sizeof(float);
+    static PerDeviceOnce attr2;
+    if (attr2.need(ctx->device)) {
+      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_cells2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_cells2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      attr2.mark(ctx->device);
+    }
+    if (ctx->encoder_f16)
+      hipLaunchKernelGGL(encode_cells2_kernel<2>, dim3((in->n_cells + 1) / 2), dim3(512), lds2, s, P, *in, out);
+    else
+      hipLaunchKernelGGL(encode_cells2_kernel<1>, dim3((in->n_cells + 1) / 2), dim3(512), lds2, s, P, *in, out);
+    event_end(ctx, "encode_cells", s);
+    T2L_HIP(ctx, hipGetLastError());
+    return T2L_OK;
+  }
   // encoder_f16 (option, off by default): ONE f16 product per operand pair instead of the three of the split form — embeddings
   // within ~1e-4 of the reference's (the north star asks for 1e-3) instead of 2e-7, 28 % less time
   if (P.split_ok && !ctx->encoder_f32 && ctx->encoder_f16)

@@ -108,6 +108,7 @@ struct t2l_ctx {
   int search_auto = 1;
   int pair_ll = 6;       // per-lane list length of the paired scan (5 or 6)
   int wide_repair = 512;  // rows a re-rank wave may re-score in a wide repair before the query goes to an exact scan (0: never)
+  int encoder_two_cells = 1;  // encode_cells: two cells per eight-wave workgroup on LDS planes (encode.hip: encode_cells2_kernel); 0: first form
   int text_inter_fused = 2;  // t2l_text_inter as one fused launch: 2 = two row tiles per 8-wave workgroup on LDS planes (default), 1 = one
                              // tile per 4-wave workgroup on f32 tiles, 0 = the nine-launch tiled-GEMM chain of text_head.hip
   int search_merge = 2;    // the paired scan merges a workgroup's four lists per query into one 32-byte record (search.hip: MERGE / MG):
