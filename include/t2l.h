@@ -462,6 +462,9 @@ int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step,
  * "search_wide_repair" (default 512, at most 1024): rows a re-rank wave may re-score in float64 to settle a query whose certificate failed
  *                     (every kept key that reaches the threshold + every row of a list whose floor does) before the query is
  *                     handed to an exact scan of the whole shard; 0 = off (tests of the exact stages).
+ * "encoder_two_cells" (default 1): t2l_encode_cells with two cells per eight-wave workgroup, activations as split-f16 planes in LDS and the
+ *                     merge / out_proj / feed-forward weight fragments shared by both cells (split-f16 and plain-f16 arithmetic, two or
+ *                     more feature slots); 0 = one cell per four-wave workgroup on f32 tiles. Same results to rounding (both meet the goldens).
  * "text_inter_fused"  (default 2): t2l_text_inter as ONE launch — 2: two tiles of floor(32 / S) descriptions per eight-wave workgroup, the
  *                     activations as split-f16 planes in LDS, every weight fragment of out_proj / linear1 / linear2 shared by both tiles;
  *                     1: one tile per four-wave workgroup on f32 tiles; 0 = the chain of tiled GEMM / attention / LayerNorm launches.

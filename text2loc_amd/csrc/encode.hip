@@ -880,7 +880,7 @@ __global__ __launch_bounds__(256, 2) void text_inter_fused_kernel(InterFusedW W,
 #define T2L_RING_DEPTH 3
 #endif
 #ifndef T2L_QK_RING
-#define T2L_QK_RING 3
+#define T2L_QK_RING 2
 #endif
 constexpr int kQkRing = T2L_QK_RING;  // the same for the q / k projection (four weight tiles = 32 VGPRs per step; v: twice as deep)
 constexpr int kRingDepth = T2L_RING_DEPTH;  // k-steps of weight fragments in flight per wave in the row-wise products (8 VGPRs per step)
