@@ -34,14 +34,16 @@ def _take(cells, n_cells=None, n_objects=None):
     return out
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["split-f16", "f32"])
+@pytest.fixture(scope="module", params=[(0, 1), (0, 0), (1, 0)], ids=["split-f16-two-cells", "split-f16-one-cell", "f32"])
 def eng(request):
-    """Both encoder kernels (split-f16 MFMAs for the big contractions / everything on the f32 MFMA) against the same bars."""
+    """All encoder kernels against the same bars: split-f16 MFMAs for the big contractions in both forms (two cells per eight-wave
+    workgroup on LDS planes — the default — and one cell per four-wave workgroup on f32 tiles), and everything on the f32 MFMA."""
     from text2loc_amd.engine import Engine
 
     e = Engine(0)
-    e.set_option("encoder_f32", request.param)
-    e.encoder_f32 = request.param
+    e.set_option("encoder_f32", request.param[0])
+    e.set_option("encoder_two_cells", request.param[1])
+    e.encoder_f32 = request.param[0]
     yield e
     e.close()
 
@@ -97,7 +99,7 @@ def test_e2e_golden_cells_then_ids(eng, golden):
 def test_feature_subsets_vs_oracle(eng, mode, feats):
     ce, co = {"embed": (True, True), "pn": (False, False), "mixed": (True, False)}[mode]
     sd = synth.make_object_branch_weights(3, use_features=feats)
-    cells = synth.make_cells(24, seed=12, min_obj=1, max_obj=40, with_pn_feat=True)
+    cells = synth.make_cells(25, seed=12, min_obj=1, max_obj=40, with_pn_feat=True)  # (odd: the two-cell form's tail workgroup)
     ref = O.encode_cells(cells, sd, ce, co, use_features=feats)
     eng.load_weights(sd, class_embed=ce, color_embed=co, use_features=feats)
     out = eng.encode_cells(_to_gpu(cells)).cpu().numpy()
