@@ -319,6 +319,8 @@ __device__ __forceinline__ void f_attention_regs(const float* __restrict__ x, Ti
     const uint4* hq = in_proj.h + ((size_t)h * HS * 64 + lane) * 2;
     const uint4* hk = in_proj.h + ((size_t)(4 + h) * HS * 64 + lane) * 2;
     const uint4* hv = in_proj.h + ((size_t)(8 + h) * HS * 64 + lane) * 2;
+    // (a pinned ring for these three fragments — as in mm32_dot_h — was measured SLOWER here: 5.98 ms against 5.66 ms, the kernel
+    // runs three workgroups per CU at <= 168 VGPRs)
 #pragma unroll 4
     for (int st = 0; st < HS; ++st) {
       const HFrag xf = split_h<H == 2>(xr + 8 * st), mf = split_h<H == 2>(mr + 8 * st);
