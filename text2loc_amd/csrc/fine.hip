@@ -324,9 +324,9 @@ __device__ __forceinline__ void f_attention_regs(const float* __restrict__ x, Ti
 #pragma unroll 4
     for (int st = 0; st < HS; ++st) {
       const HFrag xf = split_h<H == 2>(xr + 8 * st), mf = split_h<H == 2>(mr + 8 * st);
-      mfma_h3<H == 2>(qT, load_h1<H == 2>(hq + st * 128), xf);
-      mfma_h3<H == 2>(kT, load_h1<H == 2>(hk + st * 128), mf);
-      mfma_h3<H == 2>(v, mf, load_h1<H == 2>(hv + st * 128));
+      mfma_h3<H == 2>(qT, load_h1<H == 2>(hq + T2L_HOT(st) * 128), xf);
+      mfma_h3<H == 2>(kT, load_h1<H == 2>(hk + T2L_HOT(st) * 128), mf);
+      mfma_h3<H == 2>(v, mf, load_h1<H == 2>(hv + T2L_HOT(st) * 128));
     }
   } else {
 #pragma unroll 4

@@ -67,6 +67,13 @@ __device__ __forceinline__ HFrag load_h1(const uint4* __restrict__ wp) {  // SIN
 }
 // acc += A[32 x 16*STEPS] (this lane's LDS row half) * W^T (one packed weight tile, offset to its first step and to this
 // lane: 2 uint4 per lane and step, 128 uint4 per step)
+// dev experiment (make exp_fine / exp_enc EXPFLAG=-DT2L_EXP_HOTW; WRONG results, timing only): every weight fragment of a tile pass comes
+// from the pass's first two k-steps — the instruction stream stays, the packed-weight stream out of the L2 disappears
+#ifdef T2L_EXP_HOTW
+#define T2L_HOT(s) ((s) & 1)
+#else
+#define T2L_HOT(s) (s)
+#endif
 #ifndef T2L_DOT_RING
 #define T2L_DOT_RING 2
 #endif
@@ -79,11 +86,11 @@ __device__ __forceinline__ void mm32_dot_h(const float* __restrict__ arow, const
   constexpr int D = STEPS < kDotRing ? STEPS : kDotRing;
   HFrag ring[D];
 #pragma unroll
-  for (int i = 0; i < D; ++i) ring[i] = load_h1<SINGLE>(wp + i * 128);
+  for (int i = 0; i < D; ++i) ring[i] = load_h1<SINGLE>(wp + T2L_HOT(i) * 128);
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
     const HFrag wf = ring[s % D];
-    if (s + D < STEPS) ring[s % D] = load_h1<SINGLE>(wp + (s + D) * 128);
+    if (s + D < STEPS) ring[s % D] = load_h1<SINGLE>(wp + T2L_HOT(s + D) * 128);
     __builtin_amdgcn_sched_barrier(0);
     mfma_h3<SINGLE>(acc, split_h<SINGLE>(arow + 8 * s), wf);
     __builtin_amdgcn_sched_barrier(0);
