@@ -1016,33 +1016,109 @@ def secondary_measurements(eng):
     return out
 
 
-def roofline(kname, peak, mult, flops, time_ms, lanes, scan_ms, scan_n, span_ms, span_n, busy_ms, busy_n, serial):
-    achieved = flops / (time_ms * 1e-3) / 1e12 if time_ms > 0 else 0.0
-    out = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-           "executed": achieved * mult, "frac_executed": achieved * mult / peak,
-           "time_basis": ("timed-region wall clock per step (pipelined: kernel spans overlap)" if lanes > 1
-                          else "scan kernel average duration, HIP events on sampled launches of the timed region and of the 64 steps of the same loop behind it"),
-           "traffic": pmc_traffic("t2l::" + kname),
-           "traffic_source": ("measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --quick` as subprocesses "
-                              "outside the timed region, 2 x FETCH_SIZE + WRITE_SIZE" if ("t2l::" + kname) in _PMC_LIVE else PMC_SOURCE),
-           "traffic_detail": _PMC_LIVE.get("t2l::" + kname),
-           "kernel_ms": scan_ms, "launches_timed": scan_n,
-           "kernel_ms_in_kernel_span": span_ms, "launches_timed_in_kernel_span": span_n,
-           # sum of the launch's workgroup durations / grid (in-kernel stamps, every launch): the GPU time a launch used
-           "kernel_ms_gpu_time": busy_ms, "launches_timed_gpu_time": busy_n,
-           "flops_per_launch": flops,
-           # what the matrix pipe sustains on dense RANDOM f16 operands (power-limited clocks): measured by
-           # tools/pair_probe.hip on this part, bare v_mfma_f32_32x32x16_f16 stream, 1.45-1.53 PFLOP/s
-           "measured_random_data_mfma_ceiling_tflops": 1500.0,
-           "frac_of_measured_ceiling": achieved * mult / 1500.0}
-    if serial is not None:
-        s_scan, s_span, s_busy, s_step = serial
-        alone = flops / (s_scan * 1e-3) / 1e12 if s_scan else 0.0
-        out["kernel_alone"] = {"measured": "stream-ordered loop of this run (--lanes 1 behaviour), HIP events on every 4th launch",
-                               "kernel_ms": s_scan, "kernel_ms_in_kernel_span": s_span, "kernel_ms_gpu_time": s_busy,
-                               "achieved": alone, "frac": alone / peak, "frac_of_measured_ceiling": alone * mult / 1500.0,
-                               "ms_per_step": s_step}
-    return out
+def roofline(kname, peak, mult, flops, scan_ms, scan_n, span_ms, span_n, busy_ms, busy_n):
+    """achieved = ALGORITHMIC flops (2*Q*N*D) of one scan launch / the scan kernel's average duration (HIP events on sampled
+    launches of the timed region and of the same loop right behind it; rocprofv3 agrees, profiles/). `peak` is the dense MFMA
+    peak of the dtype the pipe runs in (f16 and bf16 share the 2.5 PF rate). In --mode 2 every product is 3 bf16 MFMA
+    products: `executed` / `frac_executed` give the matrix pipe's view."""
+    achieved = flops / (scan_ms * 1e-3) / 1e12 if scan_ms and scan_ms > 0 else 0.0
+    return {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "executed": achieved * mult, "frac_executed": achieved * mult / peak,
+            "time_basis": "scan kernel average duration, HIP events on sampled launches of the timed region and of the 64 steps of the same loop behind it",
+            "traffic": pmc_traffic("t2l::" + kname),
+            "traffic_source": ("measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --quick` as subprocesses "
+                               "outside the timed region, 2 x FETCH_SIZE + WRITE_SIZE" if ("t2l::" + kname) in _PMC_LIVE else PMC_SOURCE),
+            "traffic_detail": _PMC_LIVE.get("t2l::" + kname),
+            "kernel_ms": scan_ms, "launches_timed": scan_n,
+            "kernel_ms_in_kernel_span": span_ms, "launches_timed_in_kernel_span": span_n,
+            # sum of the launch's workgroup durations / grid (in-kernel stamps, every launch): the GPU time a launch used
+            "kernel_ms_gpu_time": busy_ms, "launches_timed_gpu_time": busy_n,
+            "flops_per_launch": flops,
+            # what the matrix pipe sustains on dense RANDOM f16 operands (power-limited clocks): measured by
+            # tools/pair_probe.hip on this part, bare v_mfma_f32_32x32x16_f16 stream, 1.45-1.53 PFLOP/s
+            "measured_random_data_mfma_ceiling_tflops": 1500.0,
+            "frac_of_measured_ceiling": achieved * mult / 1500.0}
+
+
+HEADLINE_MAX_BYTES = 4096
+
+
+def _r(x, nd=6):
+    """floats to `nd` significant digits (the line is read by a parser with a small buffer); everything else untouched"""
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}")
+    return x
+
+
+def format_headline(d):
+    """The ONE stdout JSON line of the contract, < 4 KB whatever the run measured: the contract's keys, `roofline` and
+    `cpu_baseline` ADJACENT, parity, ranks_seen and (N > 1) the other layout's rate — every list, note and side measurement of
+    the full record `d` stays in the detail file. Pure function of `d` (tests/test_bench_line.py feeds it canned numbers)."""
+    rl, cb, par, cfg = d.get("roofline") or {}, d.get("cpu_baseline"), d.get("parity") or {}, d.get("config") or {}
+    line = {k: _r(d.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                      "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {k: cfg.get(k) for k in ("workload", "n_cells", "queries_per_step", "embed_dim", "top_k", "parallelism", "layout")
+                      if cfg.get(k) is not None}
+    line["roofline"] = {k: _r(rl.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms",
+                                                   "launches_timed", "flops_per_launch")}
+    if cb is not None:
+        line["cpu_baseline"] = {k: _r(cb.get(k)) for k in ("value", "unit", "cores", "kind", "sample")}
+        line["cpu_baseline"]["sample"] = str(line["cpu_baseline"]["sample"])[:160]
+        line["speedup_vs_cpu_baseline"] = _r(d.get("speedup_vs_cpu_baseline"))
+    line["parity"] = {"ids_equal": par.get("ids_equal_float64_oracle"), "pairs_checked": par.get("pairs_checked"),
+                      "max_abs_score_err": _r(par.get("max_abs_score_err"))}
+    line["ranks_seen"] = d.get("ranks_seen")
+    km = d.get("kernels_ms") or {}
+    line["kernels_ms"] = {k: _r(v) for k, v in km.items()}
+    st = d.get("steady_state")
+    if st:
+        line["steady_state"] = {k: _r(st.get(k)) for k in ("steps", "untimed_ramp_steps", "ms_per_step", "queries_per_s")}
+    for key, keep in (("alt_query_sharded", ("queries_per_s", "ms_per_step", "ids_equal_row_sharded")),
+                      ("weak_scaling_point", ("rows_total", "queries_per_s", "ms_per_step", "error")),
+                      ("config5_coarse_plus_fine", ("queries_per_s", "ms_per_step", "error"))):
+        if d.get(key):
+            line[key] = {k: (_r(d[key][k]) if not isinstance(d[key][k], str) else d[key][k][:120]) for k in keep if k in d[key]}
+    if d.get("detail_file"):
+        line["detail_file"] = d["detail_file"]
+    txt = json.dumps(line)
+    if len(txt) >= HEADLINE_MAX_BYTES:  # cannot happen with the fields above; if a caller passes absurd strings, shed the optional ones
+        for key in ("config5_coarse_plus_fine", "weak_scaling_point", "steady_state", "kernels_ms", "detail_file"):
+            line.pop(key, None)
+        line["config"]["workload"] = str(line["config"].get("workload"))[:200]
+        txt = json.dumps(line)
+    assert len(txt) < HEADLINE_MAX_BYTES, len(txt)
+    return txt
+
+
+def format_secondary(sec, max_bytes=3500):
+    """One short NON-JSON stdout line (prefix `SECONDARY `, so that a line-wise JSON parser skips it) printed just before the headline:
+    the side measurements' key figures, for a reader who only has the tail of stdout. Scalars only, depth <= 2, largest groups dropped first."""
+    brief = {}
+    for name, grp in (sec or {}).items():
+        if not isinstance(grp, dict):
+            if isinstance(grp, (int, float, bool)):
+                brief[name] = _r(grp, 4)
+            continue
+        g = {}
+        for k, v in grp.items():
+            if isinstance(v, bool) or isinstance(v, (int, float)):
+                g[k] = _r(v, 4)
+            elif isinstance(v, dict):
+                for k2, v2 in v.items():
+                    if isinstance(v2, (int, float)) and not isinstance(v2, bool) and ("ms" in k2 or "frac" in k2 or "per_s" in k2 or "us" in k2):
+                        g[f"{k}.{k2}"] = _r(v2, 4)
+        if g:
+            brief[name] = g
+    txt = json.dumps(brief, separators=(",", ":"))
+    while len(txt) > max_bytes and brief:
+        biggest = max(brief, key=lambda n: len(json.dumps(brief[n])))
+        if isinstance(brief[biggest], dict) and len(brief[biggest]) > 4:  # keep the timing-like keys of the biggest group only
+            keep = {k: v for k, v in brief[biggest].items() if any(t in k for t in ("ms", "frac", "per_s", "us"))}
+            brief[biggest] = dict(list(keep.items())[:4])
+        else:
+            brief.pop(biggest)
+        txt = json.dumps(brief, separators=(",", ":"))
+    return "SECONDARY " + txt
 
 
 def main():
@@ -1063,10 +1139,8 @@ def main():
                     "overlapping launches would enter the per-kernel averages)")
     ap.add_argument("--quick", action="store_true", help="profiling runs (rocprofv3 --pmc slows every launch ~100x and does not "
                     "survive tens of thousands of them): no clock-ramp steps, short side loops, no pipelined measurement")
-    ap.add_argument("--lanes", type=int, default=1,
-                    help="1 (default): every step stream-ordered behind the previous one; the pipelined form of the same loop "
-                         "is measured beside it (`pipelined`). n > 1 (N=1 only): the TIMED steps themselves pipeline over n "
-                         "internal streams of the engine (t2l_search_join closes the timed region)")
+    ap.add_argument("--detail-out", default=os.path.join(REPO, "gpurun_out", "bench_detail.json"),
+                    help="where the full record (side measurements, distribution lists, notes) goes; the stdout line stays < 4 KB")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1131,78 +1205,31 @@ def main():
         eng.set_option("search_fused", args.fused)
     if args.nsplit:
         eng.set_option("search_nsplit", args.nsplit)
-    # N=1: the steps are independent jobs (a different query batch each) — they pipeline over `--lanes` internal streams of the
-    # engine (include/t2l.h: t2l_search only enqueues, t2l_search_join orders every result into the stream before the timed
-    # region closes). Output buffers rotate over 12 sets so that two calls sharing a set also share a lane (12 % lanes == 0).
-    lanes = args.lanes if world == 1 else 1
     N_OUT = 12
     outs = [(torch.empty((N_QUERIES, TOPK), dtype=torch.int32, device="cuda"),
              torch.empty((N_QUERIES, TOPK), dtype=torch.float64, device="cuda")) for _ in range(N_OUT)]
 
     def step(i):
-        if lanes > 1:
-            return eng.search(d_qs[i % N_BATCH], TOPK, out=outs[i % N_OUT], join=False)
         if world == 1:  # (ShardedSearcher.search is this call plus the exchange step that one rank does not have)
             return eng.search(d_qs[i % N_BATCH], TOPK, out=outs[i % N_OUT])
         return searcher.search(d_qs[i % N_BATCH], TOPK, out=outs[i % N_OUT])
 
-    # the same loop stream-ordered (lanes = 1), for the record: what one call costs when the next one waits for it
-    serial_ms = None
-    if lanes > 1:
-        for i in range(1500):
-            searcher.search(d_qs[i % N_BATCH], TOPK)
-        eng.set_option("profile_events", 4)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n_serial = max(20, args.steps)
-        for i in range(n_serial):
-            searcher.search(d_qs[i % N_BATCH], TOPK)
-        torch.cuda.synchronize()
-        serial_ms = 1e3 * (time.perf_counter() - t0) / n_serial
-        serial_scan_ms, _ = eng.kernel_stats("search_scan")
-        serial_span_ms, _ = eng.kernel_stats("search_scan_span")
-        serial_busy_ms, _ = eng.kernel_stats("search_scan_busy")
-        eng.kernel_stats("search_rerank")
-        eng.set_option("profile_events", 97)
-        eng.set_option("search_lanes", lanes)
-    # An idle MI355X needs ~40 ms of continuous load to reach its sustained clocks (measured: 56.6 -> 46.8 us per step over the
-    # first 40 ms of this very loop): untimed ramp steps first, so that a short run (--steps 20 is 1 ms of GPU time) measures the
-    # steady state and not the power-state ramp. Then the W warmup steps, then the timed K.
-    RAMP_STEPS = 0 if args.quick else max(0, 1500 - args.warmup)
-    # for the record, the same K steps WITHOUT the ramp (W warmup steps from an idle GPU, then K timed): what the workaround hides
-    unramped = None
-    if world == 1 and lanes == 1 and not args.quick:
-        torch.cuda.synchronize()
-        time.sleep(0.25)  # let the clocks fall back to idle
-        for i in range(args.warmup):
-            step(i)
-        torch.cuda.synchronize()
-        t0u = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
-        torch.cuda.synchronize()
-        tu = (time.perf_counter() - t0u) / args.steps
-        unramped = {"steps": args.steps, "warmup": args.warmup, "ms_per_step": tu * 1e3, "queries_per_s": N_QUERIES / tu,
-                    "note": "idle GPU -> W warmup steps -> K timed steps, no clock-ramp steps (the first ~40 ms of load run below the sustained clocks)"}
-    for i in range(RAMP_STEPS):
-        step(i)
+    # THE CONTRACT REGION (`value`): W warmup steps, then exactly K timed steps between barrier + synchronize on both sides.
+    # Nothing runs on the GPU before it but the set-up above — no clock-ramp steps: at the driver's --warmup 5 --steps 20 the
+    # GPU is still climbing from its idle clocks (it needs ~40 ms of load to reach the sustained ones), and that is what the
+    # headline reports. The sustained rate of the same loop is measured right behind it (`steady_state`, a side field).
     for i in range(args.warmup):
         step(i)
-    if lanes > 1:
-        eng.search_join()
-    # forget the samples so far and restart the sampling phase — host-only, the stream keeps running: the first timed step is a
-    # bracketed one (pipelined: sparse — the in-kernel stamps cover every launch)
+    # forget the samples so far and restart the sampling phase — host-only, the stream keeps running
     eng.set_option("stats_reset", 1)
     eng.set_option("profile_rerank", 0)  # timed region: sampled launches bracket the dominant kernel only; the re-rank is timed below
-    eng.set_option("profile_events", EVENT_EVERY if lanes == 1 else max(10, args.steps // 8))
+    eng.set_option("profile_events", EVENT_EVERY)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         idx, sc = step(i)
-    if lanes > 1:
-        eng.search_join()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -1211,43 +1238,44 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    scan_ms, scan_n = eng.kernel_stats("search_scan")
-    # more HIP-event samples of the same kernel than a K = 20 region can carry without paying for them (an event pair costs the stream
-    # ~6 us): the SAME loop continues right behind the timed region for 64 steps with every 4th launch bracketed -> 16 samples
+    scan_region_ms, scan_region_n = eng.kernel_stats("search_scan")
+    span_region_ms, span_region_n = eng.kernel_stats("search_scan_span")
+    fallbacks = eng.search_fallbacks()
+    rescored = eng.search_rescored()
+    counters = eng.search_counters()
+
+    # behind the contract region, N=1: the same stream-ordered loop at the sustained clocks — 1,500 untimed steps (~65 ms of load),
+    # then 400 timed steps without event pairs (`steady_state`), then 64 steps with every 4th launch bracketed by HIP events
+    # (an event pair costs the stream ~6 us, so the K = 20 region itself carries only 2-3 of them): the roofline's kernel
+    # duration averages the launches bracketed inside the timed region and these 16.
+    RAMP_STEPS = 0 if args.quick else 1500
+    steady = None
+    scan_ms, scan_n = scan_region_ms, scan_region_n
     scan_post_ms, scan_post_n = None, 0
-    scan_region_ms, scan_region_n = scan_ms, scan_n
-    if world == 1 and lanes == 1:
+    if world == 1:
+        eng.set_option("profile_events", 0)
+        for i in range(RAMP_STEPS):
+            step(i)
+        if not args.quick:
+            torch.cuda.synchronize()
+            t0s = time.perf_counter()
+            for i in range(400):
+                step(i)
+            torch.cuda.synchronize()
+            ts = (time.perf_counter() - t0s) / 400
+            steady = {"steps": 400, "untimed_ramp_steps": RAMP_STEPS, "ms_per_step": ts * 1e3, "queries_per_s": N_QUERIES / ts}
         eng.set_option("profile_events", 4)
         for i in range(16 if args.quick else 64):
             step(args.steps + i)
         torch.cuda.synchronize()
         scan_post_ms, scan_post_n = eng.kernel_stats("search_scan")
-        if scan_post_n:  # the roofline's basis: every bracketed launch of this loop — those inside the timed region and the 16 behind it
-            scan_region_ms, scan_region_n = scan_ms, scan_n
-            scan_ms = (scan_ms * scan_n + scan_post_ms * scan_post_n) / max(1, scan_n + scan_post_n)
-            scan_n = scan_n + scan_post_n
+        if scan_post_n:
+            scan_ms = (scan_region_ms * scan_region_n + scan_post_ms * scan_post_n) / max(1, scan_region_n + scan_post_n)
+            scan_n = scan_region_n + scan_post_n
     eng.set_option("profile_rerank", 1)
     span_ms, span_n = eng.kernel_stats("search_scan_span")
     busy_ms, busy_n = eng.kernel_stats("search_scan_busy")
-    fallbacks = eng.search_fallbacks()
-    rescored = eng.search_rescored()
-    counters = eng.search_counters()
-    # the same stream-ordered loop over 400 steps, no event pairs (the contract's K = 20 is a 1 ms region: it carries the first
-    # launch's latency, the closing synchronize and the sampled launches' event pairs; this is what the loop sustains)
-    steady = None
-    if world == 1 and lanes == 1 and not args.quick:
-        eng.set_option("profile_events", 0)
-        for i in range(200):
-            step(i)
-        torch.cuda.synchronize()
-        t0s = time.perf_counter()
-        for i in range(400):
-            step(i)
-        torch.cuda.synchronize()
-        ts = (time.perf_counter() - t0s) / 400
-        steady = {"steps": 400, "ms_per_step": ts * 1e3, "queries_per_s": N_QUERIES / ts}
-    # the re-rank kernel's duration: the same steps again right behind the timed region, every 4th launch bracketed
-    eng.set_option("search_lanes", 1)
+    # the re-rank kernel's duration: the same steps again, every 4th launch bracketed
     eng.set_option("profile_events", 4)
     for i in range(64):
         searcher.search(d_qs[i % N_BATCH], TOPK)
@@ -1256,15 +1284,8 @@ def main():
     eng.kernel_stats("search_scan")
     eng.set_option("profile_events", 1)  # the side measurements below bracket every launch
 
-    # what the last N_BATCH pipelined steps left in their output sets (compared with stream-ordered calls below)
-    timed_out = {}
-    if lanes > 1:
-        for i in range(max(0, args.steps - N_BATCH), args.steps):
-            timed_out[i % N_BATCH] = (outs[i % N_OUT][0].clone(), outs[i % N_OUT][1].clone())
-        eng.set_option("search_lanes", 1)
     # parity, outside the timed region: EVERY (id, score) of every rotated batch vs the float64 C oracle (all Q x K pairs)
     parity, max_score_err, recall1, n_checked = True, 0.0, [], 0
-    pipelined_equal = True
     serial_results = {}
     sharded_results = {}
     if world > 1:  # every rank takes part in the exchange of every rotated batch; rank 0 then checks all of them
@@ -1280,9 +1301,6 @@ def main():
             if world > 1:
                 gi, gs = sharded_results[bi]
             serial_results[bi] = (gi, gs)
-            if bi in timed_out:  # the timed (pipelined) loop's own results are the ones checked
-                pipelined_equal = pipelined_equal and bool(torch.equal(timed_out[bi][0], gi) and torch.equal(timed_out[bi][1], gs))
-                gi, gs = timed_out[bi]
             got_i, got_s = gi.cpu().numpy().astype(np.int64), gs.cpu().numpy()
             chunks = np.array_split(np.arange(N_QUERIES), nthr)
             with ThreadPoolExecutor(nthr) as ex:  # ctypes releases the GIL: the scalar oracle runs on nthr host cores
@@ -1298,7 +1316,7 @@ def main():
     # jobs, so step i runs its scan -> re-rank chain on internal stream i % 3 of the engine and the chains overlap. Reported
     # beside `value` (whose steps are stream-ordered, so that its kernel durations mean what rocprofv3 reports).
     pipelined = None
-    if world == 1 and lanes == 1 and rank == 0 and not args.no_pipelined and not args.quick:
+    if world == 1 and rank == 0 and not args.no_pipelined and not args.quick:
         P_LANES = 3
         eng.set_option("profile_events", 0)
         eng.set_option("search_lanes", P_LANES)
@@ -1457,36 +1475,23 @@ def main():
                                       2: "split-bf16 (3 MFMAs per product) candidate scan (f32 accumulate)"}[args.mode]
                                      + " -> float64 re-rank + certificate (ids and scores are the float64 ranking)",
                        "parallelism": f"db-row-shard x{world}" if world > 1 else "single-gpu",
-                       "untimed_ramp_steps_before_warmup": RAMP_STEPS,
-                       "pipelining": (f"{lanes} lanes: step i runs its scan -> re-rank chain on internal stream i % {lanes}; "
-                                      "one t2l_search_join before the closing synchronize") if lanes > 1 else "none (stream-ordered steps)"},
-            # achieved = ALGORITHMIC flops (2*Q*N*D) per launch / time. Stream-ordered steps: time = the scan kernel's average
-            # duration (HIP events on sampled launches of the timed region; rocprofv3 agrees, profiles/). PIPELINED steps
-            # (default): kernels of neighbouring steps share the chip, so a launch's start -> end span (what events and
-            # rocprofv3 report: `kernel_ms`) overlaps its neighbours' and no longer measures the kernel; `achieved` is then the
-            # conservative whole-job figure — scan flops of the timed region / its wall clock (the re-rank's share of the time
-            # included) — and `kernel_alone` carries the kernel by itself (stream-ordered loop of this same run: HIP events,
-            # in-kernel stamps), the number that compares with rocprofv3 of `bench.py --lanes 1`.
-            # `peak` is the dense MFMA peak of the dtype the pipe runs in (f16 and bf16 share the 2.5 PF rate). In --mode 2
-            # every product is 3 bf16 MFMA products: `executed` / `frac_executed` give the matrix pipe's view.
-            "roofline": roofline(kname, peak, mult, flops, ms if lanes > 1 else scan_ms, lanes, scan_ms, scan_n, span_ms, span_n,
-                                 busy_ms, busy_n,
-                                 None if serial_ms is None else (serial_scan_ms, serial_span_ms, serial_busy_ms, serial_ms)),
+                       "layout": (f"db-row-shard x{world}: shard search -> ONE all_gather of the per-shard top-k -> merge on every rank"
+                                  if world > 1 else "one resident DB, two launches per step (scan, re-rank)"),
+                       "pipelining": "none (stream-ordered steps)",
+                       "region": "set-up, then W warmup steps, then K timed steps: no clock-ramp steps before the region"},
+            "roofline": roofline(kname, peak, mult, flops, scan_ms, scan_n, span_ms, span_n, busy_ms, busy_n),
             "kernels_ms": {"search_scan": scan_ms, "search_rerank": rerank_ms},  # the whole step is these two launches
             "scan_kernel_event_samples": {"inside_the_timed_region": {"kernel_ms": scan_region_ms, "launches_timed": scan_region_n},
                                           "behind_the_timed_region": {"kernel_ms": scan_post_ms, "launches_timed": scan_post_n},
                                           "note": "roofline.kernel_ms averages both sets: an event pair costs the stream ~6 us, so the K = 20 "
                                                   "region carries 3 of them and the same loop continues for 64 steps with every 4th launch bracketed"},
-            # the same steps stream-ordered (lanes = 1): what one call costs when the next one waits for it
-            "stream_ordered": None if serial_ms is None else {"ms_per_step": serial_ms, "queries_per_s": N_QUERIES / (serial_ms * 1e-3)},
-            "steady_state_400_steps": steady,
-            "unramped_contract_region": unramped,
+            "scan_span_in_timed_region": {"kernel_ms_in_kernel_span": span_region_ms, "launches": span_region_n},
+            "steady_state": steady,
             "pipelined": pipelined,
             "secondary": secondary,
             "parity": {"ids_equal_float64_oracle": parity, "pairs_checked": n_checked,
                        "checked": f"all {N_QUERIES} x {TOPK} (id, score) pairs of {len(recall1)} query batch(es) vs the C oracle",
                        "max_abs_score_err": max_score_err, "recall_at_1_planted": recall1,
-                       "pipelined_results_equal_stream_ordered": pipelined_equal if lanes > 1 else None,
                        "exact_fallback_queries_last_step": fallbacks,
                        "first_certificate_failures_last_step": rescored, "counters_last_step": counters},
             "ranks_seen": ranks_seen, "query_batches_rotated": N_BATCH,
@@ -1513,7 +1518,19 @@ def main():
                 out["cpu_baseline"]["fair_cpu_torch_mm_topk_f32"] = {"queries_per_s": N_QUERIES / dt, "threads": torch.get_num_threads()}
             except Exception as e:
                 out["cpu_baseline"]["fair_cpu_torch_mm_topk_f32"] = {"error": repr(e)}
-        print(json.dumps(out))
+        # the full record goes to a file (and nowhere near stdout: 20 KB on one line once broke the driver's parser);
+        # stdout gets one short non-JSON line of side-measurement key figures, then THE line, last, < 4 KB
+        try:
+            os.makedirs(os.path.dirname(args.detail_out), exist_ok=True)
+            with open(args.detail_out, "w") as f:
+                json.dump(out, f, indent=1)
+            out["detail_file"] = os.path.relpath(args.detail_out, REPO)
+        except OSError as e:
+            print(f"bench.py: could not write {args.detail_out}: {e}", file=sys.stderr)
+        sys.stderr.flush()
+        if secondary:
+            print(format_secondary(secondary), flush=True)
+        print(format_headline(out), flush=True)
     if dist:
         dist.destroy_process_group()
 

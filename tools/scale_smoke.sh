@@ -12,15 +12,24 @@ mkdir -p "$OUT"
 export T2L_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0
 rc=0
 for N in ${SCALE_SMOKE_NS:-2 4 8}; do
-  timeout 900 python bench.py --gpus "$N" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_g$N.json" 2> "$OUT/bench_g$N.err"
+  timeout 900 python bench.py --gpus "$N" --steps 20 --warmup 5 --no-cpu-baseline --detail-out "$OUT/detail_g$N.json" > "$OUT/bench_g$N.json" 2> "$OUT/bench_g$N.err"
   st=$?
   if [ $st -ne 0 ]; then echo "scale_smoke: bench.py --gpus $N exited $st"; tail -20 "$OUT/bench_g$N.err"; rc=1; continue; fi
   python - "$OUT/bench_g$N.json" "$N" <<'EOF' || rc=1
 import json, sys
 path, n = sys.argv[1], int(sys.argv[2])
-line = [l for l in open(path).read().splitlines() if l.startswith("{")][-1]
+lines = open(path).read().splitlines()
+line = lines[-1]  # THE line is the last thing on stdout, and the only one that parses as JSON
 o = json.loads(line)
 bad = []
+if len(line) >= 4096: bad.append(f"headline is {len(line)} bytes (>= 4096)")
+if sum(1 for l in lines if l.startswith("{")) != 1: bad.append("more than one JSON line on stdout")
+for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline"):
+    if o.get(key) is None: bad.append(f"headline lacks {key}")
+if o["parity"]["ids_equal"] is not True: bad.append("headline parity.ids_equal is not true")
+for key in ("weak_scaling_point", "config5_coarse_plus_fine", "alt_query_sharded"):
+    if key not in o: bad.append(f"headline lacks {key}")
+o = json.load(open(path.replace("bench_g", "detail_g")))  # the full record: everything below reads it
 if o.get("n_gpus") != n: bad.append(f"n_gpus {o.get('n_gpus')} != {n}")
 if o.get("ranks_seen") != n: bad.append(f"ranks_seen {o.get('ranks_seen')} != {n}")
 if o["parity"]["ids_equal_float64_oracle"] is not True: bad.append("merged ids differ from the float64 oracle")
