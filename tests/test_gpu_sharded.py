@@ -163,8 +163,11 @@ def _fine_worker(rank, world, port, out_q):
     from text2loc_amd.cross_matcher import run_fine
 
     model, retr, dl, args = _fine_problem()
+    acc_local, off_local = run_fine(model, retr, dl, args, return_offsets=True)  # no shard_layout: an initialised group changes nothing
+    args.shard_layout = "auto"                                                   # opt-in: cells and pairs split over the ranks
     acc, offsets = run_fine(model, retr, dl, args, return_offsets=True)
     torch.cuda.synchronize()
+    assert acc_local == acc and np.array_equal(off_local, offsets)
     out_q.put((rank, acc, offsets))
     dist.barrier()
     dist.destroy_process_group()

@@ -324,3 +324,78 @@ def test_optimizer_routes_the_head_to_the_engine_and_steps_like_torch():
                 assert float(err.median()) < 2e-6, (n, float(err.median()))
     sd = oa.state_dict()
     assert sd["t2l_text_engine"]["step"] == 2 and sd["t2l_text_engine"]["exp_avg"].numel() > 13_000_000
+
+
+def test_optimizer_checkpoints_migrate_between_the_two_head_layouts():
+    """A checkpoint written with the head inside ``torch.optim.Adam`` (``text_engine=False`` — also the layout of every checkpoint older
+    than the engine-side head) resumes under ``text_engine=True`` with the head's moments and step moved into the engine, and the
+    other way round; the resumed optimizer takes the same next step as the one that wrote the checkpoint. A checkpoint of another
+    model raises instead of restarting Adam silently."""
+    from tests.test_gpu_train_loop import _args
+    from tests.test_host_logic import make_objects
+    from text2loc_amd.cell_retrieval import CellRetrievalNetwork
+    from text2loc_amd.losses import ContrastiveLoss
+    from text2loc_amd.optim import Adam
+
+    B, S, L = 16, 6, 8
+    objects = make_objects(synth.make_cells(B, seed=3), 3)
+    crit = ContrastiveLoss(0.1)
+
+    def build(text_engine):
+        enc = _encoder(7)
+        _no_dropout(enc)
+        model = CellRetrievalNetwork(synth.KNOWN_CLASS, synth.COLOR_NAMES, _args(), language_encoder=enc)
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_object_branch_weights(8).items()}, strict=False)
+        for layer in model.obj_inter_module:
+            layer.dropout.p = layer.dropout1.p = layer.dropout2.p = 0.0
+            layer.self_attn.dropout = 0.0
+        model = model.to("cuda").train()
+        return model, Adam(model, lr=2e-4, text_engine=text_engine)
+
+    def one_step(model, opt, seed):
+        hidden = torch.from_numpy(synth.make_t5_hidden(B * S, L, seed=seed)).cuda()
+        opt.zero_grad()
+        loss = crit(torch.nn.functional.normalize(model.language_encoder.head(hidden, B)), model.encode_objects(objects))
+        loss.backward()
+        opt.step()
+        return float(loss.detach())
+
+    for writer_engine in (False, True):
+        mw, ow = build(writer_engine)
+        for step in range(2):
+            one_step(mw, ow, 90 + step)
+        ckpt_model = {k: v.detach().clone() for k, v in mw.state_dict().items()}
+        ckpt_opt = ow.state_dict()
+        assert (ckpt_opt["t2l_text_engine"] is not None) == writer_engine
+        mr, orr = build(not writer_engine)
+        mr.load_state_dict(ckpt_model)
+        orr.load_state_dict(ckpt_opt)
+        # the head's moments arrived on the other side, element for element
+        head = [("language_encoder." + n, p) for n, p in mw.language_encoder.engine_optimizer_params()]
+        if writer_engine:  # engine -> torch state
+            flat_m = ckpt_opt["t2l_text_engine"]["exp_avg"]
+            rest_names = [n for n, _, k in orr._non_obj if k == "rest"]
+            off = 0
+            for n, p in head:
+                st = orr._torch.state[orr._torch.param_groups[0]["params"][rest_names.index(n)]]
+                assert float(st["step"]) == 2.0 and torch.equal(st["exp_avg"].reshape(-1).cpu(), flat_m[off:off + p.numel()].cpu()), n
+                off += p.numel()
+        else:              # torch state -> engine
+            m, v, st = mr.language_encoder._th_train_engine.text_adam_state()
+            assert st == 2
+            names_w = [n for n, _, _ in ow._non_obj]
+            want = torch.cat([ow._torch.state[ow._torch.param_groups[0]["params"][names_w.index(n)]]["exp_avg"].reshape(-1) for n, _ in head])
+            assert torch.equal(m.cpu(), want.cpu()) and float(m.abs().max()) > 0
+        # and the next step is the writer's next step
+        lw, lr_ = one_step(mw, ow, 99), one_step(mr, orr, 99)
+        torch.cuda.synchronize()
+        assert abs(lw - lr_) <= 1e-5 * max(1.0, abs(lw))
+        pr = dict(mr.named_parameters())
+        for n, p in mw.named_parameters():
+            if n.startswith("language_encoder.") and p.requires_grad and p.dim() == 2:
+                assert float((p.detach() - pr[n].detach()).abs().median()) < 2e-6, n
+    # a checkpoint that is not this model's: loud
+    bad = ow.state_dict()
+    bad["t2l_text_engine"] = dict(bad["t2l_text_engine"], exp_avg=bad["t2l_text_engine"]["exp_avg"][:-5], exp_avg_sq=bad["t2l_text_engine"]["exp_avg_sq"][:-5])
+    with pytest.raises(ValueError):
+        build(True)[1].load_state_dict(bad)

@@ -292,3 +292,79 @@ def test_auto_searcher_under_gloo(layout, expect):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok and lay == expect for _, ok, lay in res), res
+
+
+# ---- eval_epoch's retrieval under an initialised process group: local unless asked, and loud when the ranks' data differ -------------
+class _FakeEngine:
+    """db_set / search with the oracle's arithmetic (the collective plumbing is what is under test)"""
+
+    def db_set(self, emb, row_offset=0):
+        self.db, self.off = emb.numpy(), row_offset
+
+    def search(self, q, k):
+        i, s = O.retrieve_topk(self.db, q.numpy(), k)
+        return torch.from_numpy((i + self.off).astype(np.int32)), torch.from_numpy(s)
+
+
+class _FakeModel:
+    def __init__(self, layout):
+        import argparse
+
+        self.args = argparse.Namespace(shard_layout=layout) if layout != "absent" else argparse.Namespace()
+        self._eng = _FakeEngine()
+
+    def engine(self):
+        return self._eng
+
+
+def _rworker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from text2loc_amd.coarse import _engine_retrieve
+    from text2loc_amd.sharded import assert_replicated
+
+    db, qs, _ = synth.make_retrieval_problem(129, 12, seed=4, noise=2.0)
+    own_qs = qs if rank == 0 else np.ascontiguousarray(qs[::-1])  # what a DistributedSampler does: every rank its own queries
+    ridx, _ = O.retrieve_topk(db, own_qs, 5)
+    res = {}
+    # (1) no shard_layout (absent or None): an initialised group changes nothing — no collective, each rank's own answer
+    for layout in ("absent", None):
+        idx, _ = _engine_retrieve(_FakeModel(layout))(torch.from_numpy(db), torch.from_numpy(own_qs), 5)
+        res[f"local_{layout}"] = bool(np.array_equal(idx, ridx))
+    # (2) opted in with the SAME data on every rank: complete result on every rank, both layouts
+    full, _ = O.retrieve_topk(db, qs, 5)
+    for layout in ("query", "auto"):
+        idx, _ = _engine_retrieve(_FakeModel(layout))(torch.from_numpy(db), torch.from_numpy(qs), 5)
+        res[f"sharded_{layout}"] = bool(np.array_equal(idx, full))
+    # (3) opted in with rank-different queries: RuntimeError on EVERY rank, before any slice is stitched
+    try:
+        _engine_retrieve(_FakeModel("query"))(torch.from_numpy(db), torch.from_numpy(own_qs), 5)
+        res["differs_raises"] = False
+    except RuntimeError as e:
+        res["differs_raises"] = "differ across" in str(e)
+    # (4) differing SHAPES are caught too (fingerprints of equal length, different fields)
+    try:
+        assert_replicated([torch.zeros(3 + rank, 2)], None, "things")
+        res["shape_raises"] = False
+    except RuntimeError:
+        res["shape_raises"] = True
+    out_q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_eval_retrieval_is_local_unless_asked_and_checks_replication():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rworker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, r in res:
+        assert all(r.values()), (rank, r)

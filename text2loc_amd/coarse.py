@@ -63,18 +63,23 @@ def _engine_retrieve(model) -> Callable:
         if k > MAX_TOPK:
             raise ValueError(f"max(top_k)={k} exceeds the engine's T2L_MAX_TOPK={MAX_TOPK} (include/t2l.h)")
         eng = model.engine()
-        import torch.distributed as dist
+        layout = getattr(model.args, "shard_layout", None)
+        if layout not in (None, "", "none", "off"):
+            # OPT-IN (args.shard_layout = "auto" | "query" | "row"): N ranks, one per GPU, answer the search together — the database
+            # replicated and the QUERIES split while it fits a quarter of one GPU's HBM (KITTI360Pose: 11 k rows of ~28 M), row shards
+            # + top-k merge beyond; every rank gets the complete result. Collectives run inside: EVERY rank must call eval_epoch, with
+            # the same cells and the same queries (AutoSearcher proves that with one small all_reduce and raises on every rank
+            # otherwise). Without the option an initialised process group changes nothing: a DP training script that validates on
+            # rank 0 only, or feeds each rank its own DistributedSampler slice, searches locally.
+            import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            # N ranks (one per GPU): the layout sharded.choose_layout picks — the database replicated and the QUERIES split while it
-            # fits a quarter of one GPU's HBM (KITTI360Pose: 11 k rows of ~28 M), row shards + top-k merge beyond; every rank gets
-            # the complete result
-            from .sharded import AutoSearcher
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                from .sharded import AutoSearcher
 
-            srch = AutoSearcher(eng, layout=str(getattr(model.args, "shard_layout", "auto")))
-            srch.set_db(cell_enc.contiguous())
-            idx, sc = srch.search(text_enc.contiguous(), k)
-            return idx.cpu().numpy().astype(np.int64), sc.cpu().numpy()
+                srch = AutoSearcher(eng, layout=str(layout))
+                srch.set_db(cell_enc.contiguous())
+                idx, sc = srch.search(text_enc.contiguous(), k)
+                return idx.cpu().numpy().astype(np.int64), sc.cpu().numpy()
         eng.db_set(cell_enc.contiguous())
         idx, sc = eng.search(text_enc.contiguous(), k)
         return idx.cpu().numpy().astype(np.int64), sc.cpu().numpy()
@@ -87,7 +92,9 @@ def eval_epoch(model, dataloader, args, return_encodings: bool = False, return_d
                retrieve: Optional[Callable] = None):
     """Returns (accuracies{k: float}, accuracies_close{k: float}, top_retrievals{q: ndarray['<U32'][max(top_k)]})
     (+ encodings / dists / scores variants, training/coarse.py:152-157). ``retrieve`` replaces the search step
-    (tests of the host bookkeeping pass the oracle here); by default it is the model's HIP engine."""
+    (tests of the host bookkeeping pass the oracle here); by default it is the model's HIP engine on this process's GPU.
+    Multi-GPU retrieval is opt-in through ``model.args.shard_layout`` ("auto" | "query" | "row"): then every rank of the
+    default process group must call this function with the same dataset (see ``_engine_retrieve``)."""
     assert args.ranking_loss != "triplet"  # as the reference (training/coarse.py:65)
     model.eval()
     dataset = dataloader.dataset
@@ -104,13 +111,21 @@ def eval_epoch(model, dataloader, args, return_encodings: bool = False, return_d
     deferred = hasattr(le, "begin_deferred") and hasattr(le, "end_deferred")
     if deferred:  # no host sync per batch: the head's overflow flags are collected on the device and read ONCE behind the loop
         le.begin_deferred()
-    for batch in dataloader:
-        text_parts.append(model.encode_text(batch["texts"]).detach().float())
-        query_cell_ids.extend(batch["cell_ids"])
+    flagged = []
+    try:
+        for batch in dataloader:
+            text_parts.append(model.encode_text(batch["texts"]).detach().float())
+            query_cell_ids.extend(batch["cell_ids"])
+            if deferred:
+                text_batches.append(batch["texts"])
+    finally:  # whatever the loop raised, the head must leave deferred mode (or every later call skips its overflow check)
         if deferred:
-            text_batches.append(batch["texts"])
+            n_flags = len(getattr(le, "_deferred", None) or [])
+            flagged = le.end_deferred()
     if deferred:
-        for i in le.end_deferred():  # a batch whose activations left the f16 range: again, on the PyTorch modules
+        if flagged and n_flags != len(text_parts):  # (a custom encode_text that calls the head twice, or not at all: the flags no longer index batches)
+            raise RuntimeError(f"deferred overflow check: {n_flags} head calls for {len(text_parts)} text batches — cannot tell which batch overflowed")
+        for i in flagged:  # a batch whose activations left the f16 range: again, on the PyTorch modules
             keep, le.use_engine_head = le.use_engine_head, False
             try:
                 text_parts[i] = model.encode_text(text_batches[i]).detach().float()

@@ -215,11 +215,16 @@ def run_fine(model: CrossMatch, retrievals, dataloader, args, transform_fine=Non
     cells_dict = {c.id: c for c in cells}
     uniq = sorted({str(cid) for r in retrievals for cid in r})
     row = {cid: i for i, cid in enumerate(uniq)}
-    # more than one process (one per GPU, torch.distributed initialised): the distinct cells and the (pose, cell) pairs are
-    # split across the ranks in contiguous blocks — no exchange inside either stage — and all-gathered once each
-    from .sharded import gather_rows, shard_bounds, world_rank
+    # OPT-IN, like coarse.eval_epoch (args.shard_layout set to anything but None / "none"): with more than one process (one per GPU)
+    # the distinct cells and the (pose, cell) pairs are split across the ranks in contiguous blocks — no exchange inside either
+    # stage — and all-gathered once each. Every rank must then call run_fine with the same retrievals (proven by one small
+    # all_reduce); without the option an initialised process group changes nothing (rank-0-only validation stays local).
+    from .sharded import assert_replicated, gather_rows, shard_bounds, world_rank
 
-    world, rank = world_rank()
+    layout = getattr(args, "shard_layout", None) or getattr(a, "shard_layout", None)
+    world, rank = world_rank() if layout not in (None, "", "none", "off") else (1, 0)
+    if world > 1:
+        assert_replicated([torch.tensor([row[str(cid)] for r in retrievals for cid in r], dtype=torch.float64)], None, "retrievals")
     c_lo, c_hi = shard_bounds(len(uniq), world, rank)
     padded = [pad_objects(cells_dict[cid].objects) for cid in uniq[c_lo:c_hi]]
     descs = []
@@ -227,14 +232,14 @@ def run_fine(model: CrossMatch, retrievals, dataloader, args, transform_fine=Non
         chunk = padded[lo:lo + 2048]
         descs.append(model.encode_cells(chunk, object_points_fn(chunk) if object_points_fn is not None else None))
     cell_desc = torch.cat(descs) if descs else torch.zeros((0, PAD_SIZE, FINE_DIM), device=model.device)
-    cell_desc = gather_rows(cell_desc, len(uniq))
+    cell_desc = gather_rows(cell_desc, len(uniq)) if world > 1 else cell_desc
     hint_desc = encode_pose_hints(model.language_encoder, [" ".join(create_hint_description(p)) for p in poses])
     ci = np.array([row[str(cid)] for r in retrievals for cid in r], dtype=np.int32)
     hi = np.repeat(np.arange(len(poses), dtype=np.int32), K)
     p_lo, p_hi = shard_bounds(len(ci), world, rank)
     local = model.match(cell_desc, hint_desc, ci[p_lo:p_hi], hi[p_lo:p_hi]) if p_hi > p_lo else \
         torch.zeros((0, 2), device=model.device)
-    offsets = gather_rows(local, len(ci)).cpu().numpy().reshape(len(poses), K, 2)
+    offsets = (gather_rows(local, len(ci)) if world > 1 else local).cpu().numpy().reshape(len(poses), K, 2)
     from .coarse import _pose_cell_tables, sample_accuracies_batch
 
     pose_xy, pose_scene, bbox_xy, size, scene = _pose_cell_tables(poses, cells, retrievals)

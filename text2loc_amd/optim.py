@@ -59,6 +59,13 @@ class Adam(torch.optim.Optimizer):
                 obj.append(p)   # incl. the PointNet++ backbone unless --pointnet_freeze
             else:
                 rest.append(p)
+        # names in named_parameters order of everything the object-branch kernel does NOT step, and which optimizer steps each here:
+        # a checkpoint written under the other ``text_engine`` setting (or before the head moved into the engine) holds the same
+        # moments under the other layout — load_state_dict migrates by these names
+        text_set = {id(p) for p in text}
+        obj_set = {id(p) for p in obj}
+        self._non_obj = [(n, p, "text" if id(p) in text_set else "rest") for n, p in model.named_parameters()
+                         if p.requires_grad and id(p) not in obj_set]
         groups = [{"params": obj, "t2l_engine": True}]
         if rest:
             groups.append({"params": rest, "t2l_engine": False})
@@ -152,18 +159,79 @@ class Adam(torch.optim.Optimizer):
                 sd["t2l_text_engine"] = {"exp_avg": m.cpu(), "exp_avg_sq": v.cpu(), "step": int(step)}
         return sd
 
+    def _saved_moments(self, sd):
+        """{parameter name: (exp_avg, exp_avg_sq, step)} of every non-object-branch parameter a checkpoint holds moments for, whichever
+        layout wrote it: (i) head inside ``sd["torch"]`` (``text_engine=False``, CPU models, checkpoints older than the engine-side head);
+        (ii) head as the engine's flat moments ``sd["t2l_text_engine"]`` (bind order = named_parameters order) + the rest in ``sd["torch"]``.
+        A checkpoint that fits neither raises, naming the sizes — never a silent restart of Adam."""
+        names_all = [n for n, _, _ in self._non_obj]
+        names_rest = [n for n, _, k in self._non_obj if k == "rest"]
+        text = [(n, p) for n, p, k in self._non_obj if k == "text"]
+        ts, te = sd.get("torch"), sd.get("t2l_text_engine")
+        n_saved = sum(len(g["params"]) for g in ts["param_groups"]) if ts is not None else 0
+        out = {}
+        if te is None:
+            if n_saved == len(names_all):
+                order = names_all                      # layout (i): the head's moments sit in the torch optimizer's state
+            elif n_saved == len(names_rest) and not text:
+                order = names_rest
+            else:
+                raise ValueError(f"optimizer checkpoint holds {n_saved} torch-side parameters; this model has {len(names_all)} outside the "
+                                 f"object branch ({len(text)} of them in the text head): not a checkpoint of this model")
+        else:
+            head = [(n, p) for n, p in (self._model.language_encoder.engine_optimizer_params()
+                                        if hasattr(getattr(self._model, "language_encoder", None), "engine_optimizer_params") else [])]
+            head = [("language_encoder." + n, p) for n, p in head]
+            total = sum(p.numel() for _, p in head)
+            if int(te["exp_avg"].numel()) != total:
+                raise ValueError(f"optimizer checkpoint holds {int(te['exp_avg'].numel())} text-head moments; this model's engine head has {total}")
+            head_names = {n for n, _ in head}
+            order = [n for n in names_all if n not in head_names]
+            if n_saved != len(order):
+                raise ValueError(f"optimizer checkpoint holds {n_saved} torch-side parameters beside the engine's text head; this model has {len(order)}")
+            off = 0
+            for n, p_ in head:
+                k = p_.numel()
+                out[n] = (te["exp_avg"][off:off + k].view_as(p_), te["exp_avg_sq"][off:off + k].view_as(p_), int(te["step"]))
+                off += k
+        if ts is not None:
+            saved_ids = [i for g in ts["param_groups"] for i in g["params"]]
+            for i, n in zip(saved_ids, order):
+                st = ts["state"].get(i)
+                if st:
+                    out[n] = (st["exp_avg"], st["exp_avg_sq"], int(st["step"]))
+        return out
+
     def load_state_dict(self, sd):
         for g, saved in zip(self.param_groups, sd["param_groups"]):
             g.update({k: v for k, v in saved.items() if k != "params"})
-        if self._torch is not None and sd.get("torch") is not None:
-            self._torch.load_state_dict(sd["torch"])
+        saved = self._saved_moments(sd)
+        if self._torch is not None:
+            rest = [(n, p) for n, p, k in self._non_obj if k == "rest"]
+            ref_group = (sd.get("torch") or {}).get("param_groups", [None])[0] or self._torch.state_dict()["param_groups"][0]
+            state = {}
+            for i, (n, p) in enumerate(rest):
+                if n in saved:
+                    m, v, step = saved[n]
+                    state[i] = {"step": torch.tensor(float(step)), "exp_avg": m.detach().clone().view_as(p), "exp_avg_sq": v.detach().clone().view_as(p)}
+            self._torch.load_state_dict({"state": state, "param_groups": [dict(ref_group, params=list(range(len(rest))))]})
         e = sd.get("t2l_engine")
         if e is not None:
             step = int(e["step"])
             step_pn = int(e["step_pn"]) if "step_pn" in e else (step >> 32 if step >> 32 else step & 0xFFFFFFFF)  # older checkpoints:
             self._model.train_engine().set_adam_state(e["exp_avg"], e["exp_avg_sq"], (step & 0xFFFFFFFF) | (step_pn << 32))  # packed, or one step for both
-        t = sd.get("t2l_text_engine")
-        if t is not None and self._text:
+        if self._text:  # the head's moments go into the engine whichever layout the checkpoint used (flat, bind order)
             le = self._model.language_encoder
             le._bind_text_train(self._model.device)
-            le._th_train_engine.set_text_adam_state(t["exp_avg"], t["exp_avg_sq"], int(t["step"]))
+            text = [(n, p) for n, p, k in self._non_obj if k == "text"]
+            have = [n for n, _ in text if n in saved]
+            if have and len(have) != len(text):
+                raise ValueError(f"optimizer checkpoint holds moments for {len(have)} of the {len(text)} text-head tensors")
+            if have:
+                steps = {saved[n][2] for n, _ in text}
+                if len(steps) != 1:
+                    raise ValueError(f"text-head tensors of the checkpoint disagree on the Adam step ({sorted(steps)}): the engine keeps one")
+                dev = self._model.device
+                m = torch.cat([saved[n][0].detach().to(dev, torch.float32).reshape(-1) for n, _ in text])
+                v = torch.cat([saved[n][1].detach().to(dev, torch.float32).reshape(-1) for n, _ in text])
+                le._th_train_engine.set_text_adam_state(m, v, steps.pop())

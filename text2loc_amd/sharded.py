@@ -84,6 +84,38 @@ def gather_rows(local, n_total: int, group=None):
     return out[:n_total]
 
 
+def assert_replicated(tensors, group=None, what: str = "tensors"):
+    """Every rank must hold the SAME ``tensors`` (AutoSearcher's contract: same database, same queries). ONE small all_reduce
+    (MAX over [f, -f] of a fingerprint: shapes, a float64 sum and a position-weighted float64 sum per tensor) proves it, and a
+    rank whose data differs — e.g. a DistributedSampler'd dataloader feeding each rank its own queries — raises on EVERY rank
+    instead of returning slices of different query sets stitched together. No-op for a single process."""
+    import torch
+    import torch.distributed as dist
+
+    world, _ = world_rank(group)
+    if world == 1:
+        return
+    fp = []
+    for t in tensors:
+        x = t.detach().reshape(-1).to(torch.float64)
+        w = torch.arange(1, x.numel() + 1, dtype=torch.float64, device=x.device) % 8191.0 + 1.0
+        fp += [float(t.dim())] + [float(d) for d in t.shape] + [float(x.sum()), float((x * w).sum())]
+    f = torch.tensor(fp, dtype=torch.float64)
+    both = torch.cat([f, -f])
+    if dist.get_backend(group) == "nccl":
+        both = both.cuda()
+    try:
+        dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)
+    except RuntimeError as e:  # fingerprints of different LENGTH (different ranks of the tensors): the collective itself objects
+        raise RuntimeError(f"{what} differ across ranks (all_reduce of the fingerprints failed: {e})") from e
+    both = both.cpu()
+    hi, lo = both[: len(fp)], -both[len(fp):]
+    if not torch.equal(hi, lo):
+        raise RuntimeError(f"{what} differ across the {world} ranks (fingerprint max != min in {int((hi != lo).sum())} of {len(fp)} "
+                           "fields): sharded retrieval needs every rank to pass the same database and the same queries — evaluate "
+                           "the full query set on every rank (no DistributedSampler), or use retrieve= with your own layout")
+
+
 class ShardedSearcher:
     """search_fn(queries, k) -> (idx[Q,K] int32, score[Q,K] float64) on this rank's shard (global ids);
     merge_fn(idx[P,Q,K], score[P,Q,K]) -> (idx[Q,K], score[Q,K]). With an ``Engine`` both default to the
@@ -231,16 +263,21 @@ def choose_layout(n_rows: int, hbm_bytes: Optional[int] = None, replicate_fracti
 class AutoSearcher:
     """``set_db(all_rows)`` + ``search(queries, k)`` over N ranks with the layout ``choose_layout`` picks (or a forced one): every
     rank passes the SAME full [N,256] matrix and the SAME queries and gets the complete [Q,k] result back — what
-    ``coarse.eval_epoch`` calls when torch.distributed is initialised."""
+    ``coarse.eval_epoch`` calls when the caller asked for it (``args.shard_layout``); ``check_replicated`` (default on) proves the
+    "same" with one small all_reduce per set_db / search call."""
 
-    def __init__(self, engine=None, group=None, layout: str = "auto", search_fn: Optional[Callable] = None, merge_fn: Optional[Callable] = None):
+    def __init__(self, engine=None, group=None, layout: str = "auto", search_fn: Optional[Callable] = None, merge_fn: Optional[Callable] = None,
+                 check_replicated: bool = True):
         if layout not in ("auto", "query", "row"):
             raise ValueError("layout must be 'auto', 'query' or 'row'")
         self._args = (engine, group, search_fn, merge_fn)
+        self.check_replicated = bool(check_replicated)
         self.layout_request, self.layout, self.impl = layout, None, None
 
     def set_db(self, all_rows):
         engine, group, search_fn, merge_fn = self._args
+        if self.check_replicated:
+            assert_replicated([all_rows], group, "databases")
         self.layout = self.layout_request if self.layout_request != "auto" else choose_layout(int(all_rows.shape[0]))
         if self.layout == "query":
             self.impl = QueryShardedSearcher(engine, group, search_fn=search_fn)
@@ -249,4 +286,6 @@ class AutoSearcher:
         return self.impl.set_db_shard(all_rows)
 
     def search(self, queries, k: int):
+        if self.check_replicated:
+            assert_replicated([queries], self._args[1], "query sets")
         return self.impl.search(queries, k)
