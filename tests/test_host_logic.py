@@ -272,3 +272,80 @@ def test_other_ranking_losses_match_the_reference(golden, name):
     assert abs(float(loss) - float(g[name + "_loss"])) < 1e-5 * max(1.0, abs(float(g[name + "_loss"])))
     assert np.abs(a.grad.numpy() - g[name + "_grad_im"]).max() < 1e-6
     assert np.abs(b.grad.numpy() - g[name + "_grad_s"]).max() < 1e-6
+
+
+# ---- TextCache host behaviour (advisor, round 4): no pickle in the file, geometric growth, a cap, memos extended not cleared --------
+class _FakeTok:
+    def __call__(self, sentences, return_tensors=None, padding=None, max_length=None):
+        ids = [[1 + (sum(map(ord, w)) % 50) for w in s.split()] + [1] for s in sentences]
+        if return_tensors is None:
+            return {"input_ids": ids}
+        import torch
+
+        L = max_length
+        inp = torch.zeros((len(ids), L), dtype=torch.long)
+        att = torch.zeros((len(ids), L), dtype=torch.long)
+        for i, r in enumerate(ids):
+            inp[i, :len(r)] = torch.tensor(r)
+            att[i, :len(r)] = 1
+        return {"input_ids": inp, "attention_mask": att}
+
+
+class _FakeT5:
+    calls = 0
+
+    def __call__(self, input_ids, attention_mask, output_attentions=False):
+        import types
+
+        import torch
+
+        _FakeT5.calls += 1
+        h = torch.sin(input_ids.float()[..., None] * torch.arange(1, 9).float() + torch.arange(input_ids.shape[1]).float()[None, :, None])
+        return types.SimpleNamespace(last_hidden_state=h)
+
+
+class _FakeHead:
+    runs = []
+
+    def _head_first_half(self, hidden):
+        _FakeHead.runs.append(int(hidden.shape[0]))
+        return hidden.amax(dim=1)
+
+
+def test_text_cache_growth_cap_memo_and_pickle_free_file(tmp_path):
+    import torch
+
+    from text2loc_amd.text_cache import TextCache
+
+    c = TextCache(_FakeTok(), _FakeT5(), "cpu", max_tokens=6, dim=8, max_sentences=40)
+    first = [f"a b c{i}" for i in range(10)]
+    assert c.add(first) and c.hidden.shape == (10, 6, 8)
+    buf_ptr = c._buf.data_ptr()
+    keep = c.hidden.clone()
+    _FakeHead.runs.clear()
+    v1 = c.sentence_vectors(_FakeHead(), 4, version=1)
+    assert v1.shape == (10, 8) and _FakeHead.runs == [10]
+    # a miss appends into the same buffer (capacity 256 > 15): no copy of the cache, earlier rows untouched, memo EXTENDED by 5 rows
+    assert c.add([f"d e f{i}" for i in range(5)]) and c._buf.data_ptr() == buf_ptr and torch.equal(c.hidden[:10], keep)
+    v2 = c.sentence_vectors(_FakeHead(), 4, version=1)
+    assert v2.shape == (15, 8) and _FakeHead.runs == [10, 5] and torch.equal(v2[:10], v1)
+    assert c.sentence_vectors(_FakeHead(), 4, version=1) is v2 and _FakeHead.runs == [10, 5]
+    # the cap: refused (caller falls back to T5), nothing changed
+    assert not c.add([f"g h i{i}" for i in range(30)]) and len(c.index) == 15 and c.hidden.shape[0] == 15
+    assert not c.add(["one two three four five six seven"])  # longer than max_tokens
+    # lookup of a novel sentence adds exactly it
+    rows, L = c.lookup(["a b c3", "x y"])
+    assert rows.tolist() == [3, 15] and L == 4 and len(c.index) == 16
+    # persistence: a file np.load opens with allow_pickle=False, same content back
+    path = str(tmp_path / "cache.npz")
+    c.save(path)
+    z = np.load(path, allow_pickle=False)
+    assert z["sentences"].dtype.kind == "U" and list(z["sentences"])[:2] == ["a b c0", "a b c1"]
+    d = TextCache.load(path, device="cpu")
+    assert d.index == c.index and torch.equal(d.hidden, c.hidden) and np.array_equal(d.n_tok, c.n_tok)
+    # a round-4 style file (object array = pickle) is refused with an explanation, never unpickled
+    bad = str(tmp_path / "old.npz")
+    np.savez(bad, sentences=np.array(["a b"], dtype=object), n_tok=np.array([3], dtype=np.int32), hidden=np.zeros((1, 6, 8), np.float32),
+             max_tokens=np.int32(6), dim=np.int32(8))
+    with pytest.raises(ValueError, match="never unpickles"):
+        TextCache.load(bad, device="cpu")

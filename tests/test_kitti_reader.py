@@ -208,3 +208,57 @@ def test_point_transform_follows_no_pc_augment():
     rng = np.random.default_rng(5)
     sel = rng.integers(0, len(objs[0][0].xyz), size=256)
     assert np.array_equal(r0, np.asarray(objs[0][0].xyz, dtype=np.float32)[sel])
+
+
+class _Recorder:
+    """a 'model' that records what train_epoch feeds it (the augmentation draws are what is under test)"""
+
+    def __init__(self):
+        self.seen = []
+
+    def train(self):
+        return self
+
+    def encode_text(self, texts):
+        import torch
+
+        return torch.zeros(len(texts), 4, requires_grad=True)
+
+    def encode_objects(self, objects, object_points):
+        import torch
+
+        self.seen.append(np.concatenate([np.asarray(p["pos"]).reshape(-1) for p in object_points]))
+        return torch.zeros(len(objects), 4)
+
+
+class _NoOpt:
+    def zero_grad(self):
+        pass
+
+    def step(self):
+        pass
+
+
+def test_train_epoch_advances_the_augmentation_epoch_with_dataloader_workers():
+    """DataLoader workers (non-persistent) restart from a COPY of the dataset every epoch: without train_epoch telling the dataset that an
+    epoch has passed, the rotate_normalize draws of epoch 2 repeat epoch 1's exactly (advisor, round 4). Two epochs over two worker
+    processes: same items, different draws; and the epoch counter moved."""
+    import argparse
+
+    import torch
+
+    from text2loc_amd import kitti360pose as K
+    from text2loc_amd.coarse import train_epoch
+
+    ds = K.Kitti360PoseDataset(BASE, ["2013_05_28_drive_0010_sync"], object_points="sample", seed=1, transform="rotate_normalize")
+    dl = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False, num_workers=2, collate_fn=K.Kitti360PoseDataset.collate_fn)
+    rec = _Recorder()
+    args = argparse.Namespace(ranking_loss="contrastive")
+    crit = lambda a, p: (a.sum() + p.sum()) * 0.0  # noqa: E731
+    e0 = ds._epoch
+    train_epoch(rec, dl, args, _NoOpt(), crit)
+    n1 = len(rec.seen)
+    train_epoch(rec, dl, args, _NoOpt(), crit)
+    assert ds._epoch == e0 + 2 and n1 > 0 and len(rec.seen) == 2 * n1
+    for a, b in zip(rec.seen[:n1], rec.seen[n1:]):
+        assert a.shape == b.shape and not np.array_equal(a, b)

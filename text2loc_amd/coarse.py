@@ -39,6 +39,11 @@ def train_epoch(model, dataloader, args, optimizer, criterion):
         raise NotImplementedError("ranking_loss='triplet' is not runnable in the reference either (training/coarse.py:47-50)")
     model.train()
     losses = []
+    # one more epoch of augmentation draws: the dataset keys its per-item RNG on the epoch (kitti360pose.set_epoch), and DataLoader
+    # workers restart from a copy of the dataset every epoch — nobody else would tell them that an epoch has passed
+    ds = getattr(dataloader, "dataset", None)
+    if hasattr(ds, "set_epoch"):
+        ds.set_epoch(int(getattr(ds, "_epoch", 0)) + 1)
     for batch in dataloader:
         optimizer.zero_grad()
         anchor = model.encode_text(batch["texts"])

@@ -26,11 +26,14 @@ import torch
 
 
 class TextCache:
-    def __init__(self, tokenizer, llm_model, device, max_tokens: int = 32, dim: int = 1024):
+    def __init__(self, tokenizer, llm_model, device, max_tokens: int = 32, dim: int = 1024, max_sentences: int = 1 << 16):
         self.tokenizer, self.llm_model, self.device = tokenizer, llm_model, torch.device(device)
         self.max_tokens, self.dim = int(max_tokens), int(dim)
+        # cap: the template vocabulary is ~10^3 sentences; a stream of novel free-text queries must not grow HBM without bound
+        # (65,536 sentences x 32 tokens x 1024 x 4 B = 8.6 GB). Beyond it add() refuses and the batch takes the T5 path.
+        self.max_sentences = int(max_sentences)
         self.index: Dict[str, int] = {}
-        self.hidden = torch.empty((0, self.max_tokens, self.dim), dtype=torch.float32, device=self.device)
+        self.hidden = torch.empty((0, self.max_tokens, self.dim), dtype=torch.float32, device=self.device)  # rows [0, n) of the buffer
         self.n_tok = np.zeros((0,), dtype=np.int32)          # token count of every cached sentence (host: it sizes the batch)
         self._vec: Dict[tuple, torch.Tensor] = {}            # (L, weights version) -> f32[n, D] per-sentence vectors (eval mode)
         # description string -> slot of (_desc_rows, _desc_n): its sentences' rows (evaluation sets repeat). A batch of 4,096 known
@@ -79,7 +82,7 @@ class TextCache:
         if self.tokenizer is None or self.llm_model is None:
             return False  # (a cache loaded without its encoder: the caller's own T5 path serves the batch)
         lens = [len(ids) for ids in self.tokenizer(new)["input_ids"]]
-        if max(lens) > self.max_tokens:
+        if max(lens) > self.max_tokens or len(self.index) + len(new) > self.max_sentences:
             return False
         parts = []
         with torch.no_grad():
@@ -91,11 +94,23 @@ class TextCache:
         base = len(self.index)
         for i, s in enumerate(new):
             self.index[s] = base + i
-        self.hidden = torch.cat([self.hidden] + parts, dim=0).contiguous()
+        self._append(torch.cat(parts, dim=0))
         self.n_tok = np.concatenate([self.n_tok, np.asarray(lens, dtype=np.int32)])
         self.t5_sentences += len(new)
-        self._vec.clear()
-        return True
+        return True  # (the per-sentence memos stay: sentence_vectors extends them by the new rows)
+
+    def _append(self, rows: torch.Tensor):
+        """``hidden`` is a view of the first n rows of a buffer that grows geometrically: a miss costs the new rows, not a copy of
+        the whole cache (torch.cat of [n, 32, 1024] f32 per miss was 128 KB per cached sentence and twice the cache at its peak)."""
+        n, k = int(self.hidden.shape[0]), int(rows.shape[0])
+        buf = getattr(self, "_buf", None)
+        if buf is None or buf.data_ptr() != self.hidden.data_ptr() or buf.shape[0] < n + k or buf.shape[1:] != self.hidden.shape[1:]:
+            cap = min(max(self.max_sentences, n + k), max(n + k, 2 * n, 256))
+            new = torch.empty((cap,) + tuple(self.hidden.shape[1:]), dtype=torch.float32, device=self.device)
+            new[:n] = self.hidden
+            buf = self._buf = new
+        buf[n:n + k] = rows.to(self.device, torch.float32)
+        self.hidden = buf[:n + k]
 
     # ------------------------------------------------------------------ serving
     def lookup(self, sentences: List[str], add_missing: bool = True):
@@ -157,34 +172,44 @@ class TextCache:
         once per (L, head weights version) by the head's own first half (engine or PyTorch, whatever serves the model)."""
         key = (int(L), version)
         v = self._vec.get(key)
-        if v is None:
-            if len(self._vec) > 8:
+        have = 0 if v is None else int(v.shape[0])
+        if have < len(self.hidden):  # first use of this (L, version), or sentences were added since: the head runs over the NEW rows only
+            if v is None and len(self._vec) > 8:
                 self._vec.clear()
             with torch.no_grad():
-                parts = [language_encoder._head_first_half(self.hidden[lo:lo + 4096, :L].contiguous())
-                         for lo in range(0, len(self.hidden), 4096)]
-            v = self._vec[key] = torch.cat(parts, dim=0).contiguous()
+                parts = [language_encoder._head_first_half(self.hidden[lo:min(lo + 4096, len(self.hidden)), :L].contiguous())
+                         for lo in range(have, len(self.hidden), 4096)]
+            v = self._vec[key] = torch.cat(([v] if have else []) + parts, dim=0).contiguous()
         return v
 
     # ------------------------------------------------------------------ persistence ("T5-large embeddings precomputed", BASELINE config 2)
     def save(self, path: str):
         """One .npz: the sentences, their token counts and hidden states (f32) — what an evaluation run needs instead of T5-large."""
         order = sorted(self.index, key=self.index.get)
-        np.savez(path, sentences=np.array(order, dtype=object), n_tok=self.n_tok, hidden=self.hidden.cpu().numpy(),
-                 max_tokens=np.int32(self.max_tokens), dim=np.int32(self.dim), allow_pickle=True)
+        # sentences as a fixed-width unicode array: the file holds no pickled object, so loading one that came from elsewhere
+        # ("precomputed T5 embeddings" get shared) cannot execute code
+        np.savez(path, sentences=np.array(order, dtype=str), n_tok=self.n_tok, hidden=self.hidden.cpu().numpy(),
+                 max_tokens=np.int32(self.max_tokens), dim=np.int32(self.dim))
 
     @classmethod
     def load(cls, path: str, language_encoder=None, device=None) -> "TextCache":
         """``language_encoder`` (optional) supplies tokenizer + T5 for sentences the file does not hold; without it a miss sends the
         batch to the encoder's own T5 path."""
-        z = np.load(path, allow_pickle=True)
+        z = np.load(path, allow_pickle=False)
+        try:
+            sentences = z["sentences"]
+        except ValueError as e:  # an object array: written by round 4's save() (or by someone else's pickle)
+            raise ValueError(f"{path}: 'sentences' is a pickled object array; this loader never unpickles. Re-save the cache with "
+                             "TextCache.save (unicode array), or convert a file you trust: np.load(path, allow_pickle=True) -> "
+                             "np.savez(..., sentences=np.array(list(z['sentences']), dtype=str), ...)") from e
         dev = device if device is not None else (language_encoder.device if language_encoder is not None else "cuda")
         tok = getattr(language_encoder, "tokenizer", None)
         t5 = getattr(language_encoder, "llm_model", None)
         c = cls(tok, t5, dev, int(z["max_tokens"]), int(z["dim"]))
-        c.index = {str(sn): i for i, sn in enumerate(z["sentences"])}
+        c.index = {str(sn): i for i, sn in enumerate(sentences)}
         c.n_tok = np.asarray(z["n_tok"], dtype=np.int32)
         c.hidden = torch.from_numpy(np.ascontiguousarray(z["hidden"])).to(c.device)
+        c.max_sentences = max(c.max_sentences, len(c.index))
         return c
 
     def stats(self) -> dict:
