@@ -365,7 +365,8 @@ int t2l_zero_grad(t2l_ctx* ctx, void* stream);
  * bound buffers; `hidden` receives no gradient (T5 is frozen; a caller that trains T5 keeps the PyTorch path).
  * Arithmetic: option "text_train_bf16" (default 2): GEMM operands as split-bf16 (hi + lo bf16, three bf16 MFMAs per 16-step: products
  * within 2^-16 + 2^-18 relative, f32 accumulation, f32's exponent range — gradients need no loss scaling); 1: plain bf16 operands
- * (BASELINE config 4's arithmetic); 0: f32 MFMA. Everything else (softmax, LayerNorm, BatchNorm, pooling, dropout) is f32. */
+ * (BASELINE config 4's arithmetic). (An f32-MFMA operand form, 0, existed until round 5: it measured slower than PyTorch's f32 step
+ * and is rejected now.) Everything else (softmax, LayerNorm, BatchNorm, pooling, dropout) is f32. */
 int t2l_text_train_bind(t2l_ctx* ctx, const t2l_train_tensor* tensors, int32_t n, const char* prefix);
 int t2l_text_head_train(t2l_ctx* ctx, const float* hidden, int32_t n_sentences, int32_t n_tokens, int32_t n_descriptions, float dropout_p,
                         uint32_t seed, float* out, void* stream);
@@ -424,26 +425,13 @@ int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step,
  *     2 = split-bf16: every operand as hi + lo bf16, three MFMAs per 16-step (relative product error <= 2^-16 + 2^-18, f32's
  *     exponent range): the f32 goldens are met to 1e-4 at close to the bf16 variant's speed. Applies to the PointNet++
  *     training calls too.
- * "train_xcd_map"     (default 0): 1 = the training step's tile GEMMs walk their output tiles in per-XCD bands (an eighth of one operand
- *                      per L2). Measured slower with f32 operands (0.589 -> 0.630 ms per step), neutral with bf16; kept for A/B.
- * "loss_single_wg"    (default 0): 1 = t2l_contrastive_loss (batch <= 128) as ONE workgroup (round 1-2 kernel, kept for A/B); default:
- *                      4 * ceil(batch / 32) workgroups, every gradient tile on its own wave (38.6 -> 22.4 us per call at batch 64).
  * "train_gemm_block"  (default 0 = by measurement; 32, 64): output block of the training step's tile GEMMs. 64 = every wave holds
  *     2 x 2 accumulator tiles (half the L2 -> L1 operand traffic, a quarter of the workgroups): 4 % faster with bf16 / split-bf16
  *     operands, 3 % slower in f32 (the deeper operand ring of the 32 x 32 form does not fit beside 64 accumulators) — so 0 picks 64
  *     with train_bf16 != 0 and 32 otherwise. Results are identical up to float32 summation order.
- * "pointnet_train_v1" (default 0): 1 = t2l_pointnet_features_train / t2l_pointnet_backward on the first version's GEMM kernels
- *     (operands straight from L2, the first layer's post-ReLU activations stored) instead of the second version's (weights
- *     resident in LDS, BatchNorm sums in the GEMM epilogue, BatchNorm + ReLU fused into the operand load). Same results to
- *     float32 summation order; 26 ms against 17 ms per 64-cell step (22 against 13 with train_bf16 = 1). Kept for A/B runs.
- * "search_pair"       (default 1): mode 0 only — 1 = the paired scan (two waves per SIMD), 0 = one wave per SIMD.
  * "search_xcd_qgroups" (default 4; 1, 2, 4, 8): paired scan — the workgroups of one XCD form a rectangle of (query blocks) x
  *     (splits): with g groups an XCD's L2 pulls 1/g of the query batch in the prologue and g/8 of the f16 plane over the main
  *     loop (1 = all queries, 1/8 of the plane: round 2's mapping). Applies when the grid divides evenly, else 1.
- * "search_prep"       (default 0): paired scan — 1 = the queries' f16 fragment plane is built ONCE per call by a pre-pass launch
- *     (prep_queries_kernel) instead of by every workgroup's prologue. Measured at Q = 4096: the scan's span drops by 0.7 us, the
- *     extra dependent launch costs 2 us per stream-ordered step (the prologue is bound by the cold start behind a kernel
- *     boundary, not by the conversion); under "search_lanes" it is neutral. Results are bit-identical either way.
  * "search_heavy"      (set by the engine, see search_auto): 1 = queries no certificate settles go to the float64 MFMA exact
  *     stage instead of the fallback kernel's float64 VALU scan. With search_auto = 0 the caller may force it.
  * "train_keep_adam_state" (default 0): see t2l_adam_state.
@@ -464,11 +452,9 @@ int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step,
  *                     handed to an exact scan of the whole shard; 0 = off (tests of the exact stages).
  * "encoder_two_cells" (default 1): t2l_encode_cells with two cells per eight-wave workgroup, activations as split-f16 planes in LDS and the
  *                     merge / out_proj / feed-forward weight fragments shared by both cells (split-f16 and plain-f16 arithmetic, two or
- *                     more feature slots); 0 = one cell per four-wave workgroup on f32 tiles. Same results to rounding (both meet the goldens).
- * "text_inter_fused"  (default 2): t2l_text_inter as ONE launch — 2: two tiles of floor(32 / S) descriptions per eight-wave workgroup, the
- *                     activations as split-f16 planes in LDS, every weight fragment of out_proj / linear1 / linear2 shared by both tiles;
- *                     1: one tile per four-wave workgroup on f32 tiles; 0 = the chain of tiled GEMM / attention / LayerNorm launches.
- *                     Same results (all three are tested against the restatement).
+ *                     more feature slots). 0 = one cell per four-wave workgroup on f32 tiles — the kernel that serves models with ONE
+ *                     feature slot (and, in its f32 form, "encoder_f32"); the option exists so that the tests can hold that kernel
+ *                     to the reference goldens, which are four-feature models. Same results to rounding.
  * "search_merge_lists" (default 2): the paired scan's candidate hand-off to the re-rank. 0 = four 24-byte lists per (query, workgroup);
  *                     1 = ONE 32-byte record (the best 7 of their 24 keys, the source list in two more code bits, + a bound on every other
  *                     key): a third of the bytes written back at the end of the launch, -0.7 us per step at Q = 4096; 2 = records while the

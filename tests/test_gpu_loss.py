@@ -47,29 +47,18 @@ def test_batches_vs_oracle(eng, B):
 
 
 @pytest.mark.parametrize("B", [1, 31, 33, 64, 65, 100, 128])
-def test_single_workgroup_kernel_still_meets_the_oracle_and_the_default(eng, B):
-    """Option loss_single_wg (the kernel of rounds 1-2, kept for A/B): same bounds against the oracle, and within float32 rounding of
-    the default kernel (4 * ceil(B/32) workgroups, rowdot from the B x B matrices instead of the 256-wide rows); forward-only calls
-    (no gradient buffers) give the same loss on both."""
+def test_odd_batches_and_forward_only_calls(eng, B):
+    """Batches that are not a multiple of the 32-row tile, scaled inputs, and forward-only calls (no gradient buffers: one workgroup)
+    give the oracle's loss and gradients."""
     rng = np.random.default_rng(100 + B)
     a = (3.0 * rng.standard_normal((B, 256))).astype(np.float32)
     p = (0.5 * a + 0.4 * rng.standard_normal((B, 256))).astype(np.float32)
     rl, rga, rgp = O.contrastive_loss(a, p, 0.1, dtype=np.float64)
-    out = {}
-    for single in (1, 0):
-        eng.set_option("loss_single_wg", single)
-        try:
-            out[single] = _run(eng, a, p, 0.1)
-            lf, _, _ = eng.contrastive_loss(torch.from_numpy(a).cuda(), torch.from_numpy(p).cuda(), 0.1, need_grad=False)
-            assert abs(float(lf.item()) - out[single][0]) < 1e-6 * max(1.0, abs(rl))
-        finally:
-            eng.set_option("loss_single_wg", 0)
-        loss, ga, gp = out[single]
-        scale = np.abs(rga).max()
-        assert abs(loss - rl) < 3e-5 * max(1.0, abs(rl))
-        assert np.abs(ga - rga).max() < 1e-4 * scale + 3e-6 and np.abs(gp - rgp).max() < 1e-4 * np.abs(rgp).max() + 3e-6  # (B = 1: all gradients are 0)
-    assert abs(out[0][0] - out[1][0]) < 1e-5 * max(1.0, abs(rl))
-    assert np.abs(out[0][1] - out[1][1]).max() < 1e-4 * np.abs(rga).max() + 3e-6
+    loss, ga, gp = _run(eng, a, p, 0.1)
+    lf, _, _ = eng.contrastive_loss(torch.from_numpy(a).cuda(), torch.from_numpy(p).cuda(), 0.1, need_grad=False)
+    assert abs(float(lf.item()) - loss) < 1e-6 * max(1.0, abs(rl))
+    assert abs(loss - rl) < 3e-5 * max(1.0, abs(rl))
+    assert np.abs(ga - rga).max() < 1e-4 * np.abs(rga).max() + 3e-6 and np.abs(gp - rgp).max() < 1e-4 * np.abs(rgp).max() + 3e-6  # (B = 1: all gradients are 0)
 
 
 def test_autograd_function(eng):

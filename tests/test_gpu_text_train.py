@@ -49,7 +49,7 @@ def _check_grads(tensors, ref_grads, tol_rms, frac=0.97):
     return worst
 
 
-@pytest.mark.parametrize("arith", [2, 0, 1], ids=["split_bf16", "f32", "bf16"])
+@pytest.mark.parametrize("arith", [2, 1], ids=["split_bf16", "bf16"])
 @pytest.mark.parametrize("n_desc,S,L,p", [(4, 6, 7, 0.1), (3, 6, 16, 0.0), (2, 5, 32, 0.1), (9, 1, 1, 0.1), (16, 6, 12, 0.1)])
 def test_engine_text_train_matches_the_float64_oracle(n_desc, S, L, p, arith):
     from oracle import t2l_oracle_text_train as OTT
@@ -63,7 +63,7 @@ def test_engine_text_train_matches_the_float64_oracle(n_desc, S, L, p, arith):
     eng = Engine(0)
     try:
         tensors = _bind(eng, sd)
-        eng.set_option("text_train_bf16", arith)  # default 2 (split-bf16: f32-class); 0 = f32 MFMA; 1 = plain bf16 operands (config 4)
+        eng.set_option("text_train_bf16", arith)  # default 2 (split-bf16: f32-class); 1 = plain bf16 operands (config 4)
         out = eng.text_head_train(torch.from_numpy(hidden).cuda(), n_desc, dropout_p=p, seed=seed)
         eng.text_head_backward(torch.from_numpy(G).cuda())
         torch.cuda.synchronize()
@@ -77,7 +77,7 @@ def test_engine_text_train_matches_the_float64_oracle(n_desc, S, L, p, arith):
             return
         assert np.abs(out.cpu().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
         # float32 summation order under a BatchNorm over a few dozen rows and through two LayerNorm'd layers: median-tight, tails bounded
-        _check_grads(tensors, info["grads"], tol_rms=5e-3 if arith == 0 else 1e-2, frac=0.9)
+        _check_grads(tensors, info["grads"], tol_rms=1e-2, frac=0.9)
         new = __import__("oracle.t2l_oracle_train", fromlist=["x"]).bn_running_update(sd, info["bn_stats"])
         for k in (P + "inter_mlp.0.1.running_mean", P + "inter_mlp.0.1.running_var"):
             assert np.allclose(tensors[k][0].cpu().numpy(), new[k], rtol=2e-4, atol=2e-5), k

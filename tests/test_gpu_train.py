@@ -367,34 +367,3 @@ def test_gemm_block_64_equals_32(eng, golden, mode):
         if n.startswith("object_encoder.") and n.endswith(".0.bias"):
             continue  # in front of a BatchNorm: noise around a zero gradient
         assert float((a - b).norm()) <= 2e-4 * float(a.norm()) + 1e-9, n
-
-
-@pytest.mark.parametrize("mode", ["embed", "pn"])
-@pytest.mark.parametrize("blk", [32, 64])
-def test_xcd_band_order_of_the_tile_gemms_is_result_neutral(eng, golden, mode, blk):
-    """Option train_xcd_map = 1 walks the output tiles of every tile GEMM of the step in per-XCD bands (a bijection of the launch
-    order, for every grid shape of the step: plain, dW + dX pairs, the three-branch launches): the forward is bit-identical — every
-    output tile is computed by exactly one block with the same arithmetic — and the gradients agree to the order of the float atomics."""
-    g = golden(f"train_step_{mode}")
-    cells, sd, embed = load_case(g, mode)
-    res = {}
-    try:
-        eng.set_option("train_gemm_block", blk)
-        for xcd in (0, 1):
-            eng.set_option("train_xcd_map", xcd)
-            tensors = bind(eng, sd, embed)
-            positive = eng.encode_cells_train(to_dev(cells, embed), dropout_p=0.1, seed=5)
-            anchor = torch.from_numpy(g["anchor"]).cuda()
-            loss, ga, gp = eng.contrastive_loss(anchor, positive, float(g["temperature"]))
-            eng.encode_cells_backward(gp)
-            torch.cuda.synchronize()
-            res[xcd] = (positive.clone(), {n: t[1].clone() for n, t in tensors.items() if t[1] is not None})
-    finally:
-        eng.set_option("train_gemm_block", 0)
-        eng.set_option("train_xcd_map", 0)
-    assert torch.equal(res[0][0], res[1][0])
-    for n, a in res[0][1].items():
-        b = res[1][1][n]
-        if n.startswith("object_encoder.") and n.endswith(".0.bias"):
-            continue  # in front of a BatchNorm: noise around a zero gradient
-        assert float((a - b).norm()) <= 2e-5 * float(a.norm()) + 1e-9, n

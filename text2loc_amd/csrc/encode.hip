@@ -694,179 +694,11 @@ __global__ __launch_bounds__(256, NC == 1 ? 2 : 1) void encode_cells_kernel(EncP
 // K = 1,024 cover); and the inputs are not bounded by the weights (they come out of inter_mlp), so every value that enters a
 // split-f16 product is watched against the f16 range at run time: a tile that leaves it raises *flag and the caller redoes the batch
 // on the PyTorch modules (the protocol of t2l_text_head).
-template <int H>  // 1: split-f16, 2: plain f16 (option encoder_f16)
-__global__ __launch_bounds__(256, 2) void text_inter_fused_kernel(InterFusedW W, const float* __restrict__ sent, int n_desc, int S, int dpt,
-                                                                  float* __restrict__ out, int* __restrict__ flag) {
-  static_assert(H == 1 || H == 2, "split-f16 or plain f16");
-  constexpr bool SG = H == 2;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* x = smem;              // [32][260] token tile
-  float* buf = smem + kXFloats;  // [32][260] attention output -> feed-forward hidden pass
-  int* grp = reinterpret_cast<int*>(smem + 2 * kXFloats);  // [32] description of a tile row
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = lane & 31, half = lane >> 5;
-  const int d0 = blockIdx.x * dpt, nd = min(dpt, n_desc - d0), rows = nd * S;
-  const float* src = sent + (size_t)d0 * S * kD;
-  bool bad = false;
-  auto watch = [&](float v) { bad = bad || !(fabsf(v) < kSplitF16Safe); };
-  for (int i = wave; i < kSP; i += 4) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < rows) v = reinterpret_cast<const float4*>(src + (size_t)i * kD)[lane];
-    watch(v.x); watch(v.y); watch(v.z); watch(v.w);
-    *(reinterpret_cast<float4*>(x + i * kLdX) + lane) = v;
-  }
-  if (tid < kSP) grp[tid] = tid / S;
-  __syncthreads();
-
-  {  // ---- self-attention, head h = wave, registers only (the encoder's two passes)
-    const int h = wave;
-    constexpr int HS = kD / 16;
-    const float* ib = W.in_b;
-    f32x16 st;
-    float inv;
-    {
-      f32x16 qT0, qT1, kT0, kT1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) qT0[r] = qT1[r] = kT0[r] = kT1[r] = 0.f;
-      const uint4* hq0 = W.in_hp + ((size_t)(2 * h) * HS * 64 + lane) * 2;
-      const uint4* hq1 = W.in_hp + ((size_t)(2 * h + 1) * HS * 64 + lane) * 2;
-      const uint4* hk0 = W.in_hp + ((size_t)(8 + 2 * h) * HS * 64 + lane) * 2;
-      const uint4* hk1 = W.in_hp + ((size_t)(9 + 2 * h) * HS * 64 + lane) * 2;
-#pragma unroll 2
-      for (int s = 0; s < HS; ++s) {
-        const HFrag xf = split_h<SG>(x + col * kLdX + half * 128 + 8 * s);
-        mfma_h3<SG>(qT0, load_h1<SG>(hq0 + T2L_WSTEP(s) * 128), xf);
-        mfma_h3<SG>(qT1, load_h1<SG>(hq1 + T2L_WSTEP(s) * 128), xf);
-        mfma_h3<SG>(kT0, load_h1<SG>(hk0 + T2L_WSTEP(s) * 128), xf);
-        mfma_h3<SG>(kT1, load_h1<SG>(hk1 + T2L_WSTEP(s) * 128), xf);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
-        qT0[r] += ib[h * 64 + f];
-        qT1[r] += ib[h * 64 + 32 + f];
-        kT0[r] += ib[kD + h * 64 + f];
-        kT1[r] += ib[kD + h * 64 + 32 + f];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[r] = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kT0[r], qT0[r], st, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kT1[r], qT1[r], st, 0, 0, 0);
-      // lane: query i = col, keys j = (r&3) + 8*(r>>2) + 4*half; only the keys of the query's own description count
-      const int gi = grp[col];
-      float m = -__builtin_inff();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
-        st[r] = (grp[j] == gi) ? st[r] * 0.125f : -__builtin_inff();  // 1/sqrt(head_dim = 64)
-        m = fmaxf(m, st[r]);
-      }
-      m = fmaxf(m, __shfl_xor(m, 32));  // (the lane half that holds the query's own row makes this finite)
-      float sum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        st[r] = __expf(st[r] - m);
-        sum += st[r];
-      }
-      sum += __shfl_xor(sum, 32);
-      inv = 1.f / sum;
-    }
-    {
-      f32x16 v0, v1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v0[r] = v1[r] = 0.f;
-      const uint4* hv0 = W.in_hp + ((size_t)(16 + 2 * h) * HS * 64 + lane) * 2;
-      const uint4* hv1 = W.in_hp + ((size_t)(17 + 2 * h) * HS * 64 + lane) * 2;
-      mm_pair_h<SG>(x + col * kLdX + half * 128, HS, hv0, hv1, v0, v1);
-      const float bv0 = ib[2 * kD + h * 64 + col], bv1 = ib[2 * kD + h * 64 + 32 + col];
-      f32x16 o0, o1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = st[r] * inv;
-        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(p, v0[r] + bv0, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(p, v1[r] + bv1, o1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-        watch(o0[r]);
-        watch(o1[r]);
-        buf[i * kLdX + h * 64 + col] = o0[r];
-        buf[i * kLdX + h * 64 + 32 + col] = o1[r];
-      }
-    }
-  }
-  __syncthreads();
-  {  // x = LN1(x + o @ out_proj^T + b)
-    const float* b = W.out_b;
-    auto out_epi = [&](int, int, int row, int c, float v) { x[row * kLdX + c] += v + b[c]; };
-    gemm32_h<SG>(buf, kLdX, kD, W.out_hp, kD, wave, lane, out_epi);
-  }
-  __syncthreads();
-  layer_norm_rows(x, W.ln1_w, W.ln1_b, wave, lane);
-  __syncthreads();
-  for (int i = wave; i < kSP; i += 4) {  // (what LayerNorm hands to linear1)
-    const float4 v = *(reinterpret_cast<const float4*>(x + i * kLdX) + lane);
-    watch(v.x); watch(v.y); watch(v.z); watch(v.w);
-  }
-  {  // x = LN2(x + relu(x W1^T + b1) W2^T + b2), the 1,024 hidden units in four passes through buf
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-    const float* b1 = W.ff1_b;
-    constexpr int FS = 4 * kD / 16;  // k-steps of one W2 tile (K = 1,024)
-    for (int c = 0; c < 4; ++c) {
-      const int tA = 4 * c + wave, tB = 16 + 4 * c + wave;
-      f32x16 h0, h1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) h0[r] = h1[r] = 0.f;
-      mm_pair_h<SG>(x + col * kLdX + half * 128, kD / 16, W.ff1_hp + ((size_t)tA * (kD / 16) * 64 + lane) * 2,
-                    W.ff1_hp + ((size_t)tB * (kD / 16) * 64 + lane) * 2, h0, h1);
-      if (c) __syncthreads();  // every wave has consumed the previous pass from buf
-      const float bA = b1[tA * 32 + col], bB = b1[tB * 32 + col];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float a = fmaxf(h0[r] + bA, 0.f), bq = fmaxf(h1[r] + bB, 0.f);
-        watch(a);
-        watch(bq);
-        buf[row * kLdX + 32 * wave + col] = a;
-        buf[row * kLdX + 128 + 32 * wave + col] = bq;
-      }
-      __syncthreads();
-      mm_pair_h<SG>(buf + col * kLdX + half * 128, kD / 16, W.ff2_hp + (((size_t)wave * FS + 16 * c) * 64 + lane) * 2,
-                    W.ff2_hp + (((size_t)(wave + 4) * FS + 16 * c) * 64 + lane) * 2, acc0, acc1);
-    }
-    const float* b2 = W.ff2_b;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int c0 = wave * 32 + col, c1 = (wave + 4) * 32 + col;
-      x[row * kLdX + c0] += acc0[r] + b2[c0];
-      x[row * kLdX + c1] += acc1[r] + b2[c1];
-    }
-  }
-  __syncthreads();
-  layer_norm_rows(x, W.ln2_w, W.ln2_b, wave, lane);
-  __syncthreads();
-  // x_in + layer(x_in), max over the description's S sentences (thread = column)
-  for (int d = 0; d < nd; ++d) {
-    float m = -__builtin_inff();
-    for (int s_ = 0; s_ < S; ++s_) {
-      const int r = d * S + s_;
-      m = fmaxf(m, x[r * kLdX + tid] + src[(size_t)r * kD + tid]);
-    }
-    out[(size_t)(d0 + d) * kD + tid] = m;
-  }
-  if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicOr(flag, 1);
-}
+// (The kernel: text_inter_fused2_kernel below — two tiles per eight-wave workgroup on LDS planes. The one-tile form on f32 tiles that
+// this comment used to head was removed in round 5: 0.208 vs 0.179 ms for 4,096 descriptions x 6 sentences.)
 
 // ------------------------------------------------------------------------------------------------
-// Second form (option text_inter_fused = 2) — the testbed for the lever the encoder family is left with (the packed-weight
+// The launch — the testbed for the lever the encoder family is left with (the packed-weight
 // stream out of the L2 is worth 23-32 % of these kernels, the per-MFMA VALU work another third): TWO row tiles per workgroup of EIGHT
 // waves, every activation resident in LDS as split-f16 PLANES (hi | lo, rows of 264 halves), so that
 //  * out_proj, linear1 and linear2 (3/4 of the FLOPs) load each weight fragment ONCE for both tiles — wave w owns one 32-wide tile of
@@ -1386,7 +1218,7 @@ __global__ __launch_bounds__(512, 1) void encode_cells2_kernel(EncParams P, t2l_
 
 int text_inter_fused_launch(t2l_ctx* ctx, const InterFusedW& W, bool single, const float* sent, int n_desc, int S, float* out, int* flag,
                             hipStream_t s) {
-  if (ctx->text_inter_fused == 2) {
+  {
     const int dpt = kSP / S, tiles = (n_desc + 2 * dpt - 1) / (2 * dpt);
     const size_t lds = (size_t)8 * kPlane * sizeof(_Float16) + kSP * sizeof(int);
     static PerDeviceOnce once2;
@@ -1402,20 +1234,6 @@ int text_inter_fused_launch(t2l_ctx* ctx, const InterFusedW& W, bool single, con
     T2L_HIP(ctx, hipGetLastError());
     return T2L_OK;
   }
-  const int dpt = kSP / S, tiles = (n_desc + dpt - 1) / dpt;
-  const size_t lds = (size_t)2 * kXFloats * sizeof(float) + kSP * sizeof(int);
-  static PerDeviceOnce once;
-  if (once.need(ctx->device)) {
-    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&text_inter_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&text_inter_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    once.mark(ctx->device);
-  }
-  if (single)
-    hipLaunchKernelGGL(text_inter_fused_kernel<2>, dim3(tiles), dim3(256), lds, s, W, sent, n_desc, S, dpt, out, flag);
-  else
-    hipLaunchKernelGGL(text_inter_fused_kernel<1>, dim3(tiles), dim3(256), lds, s, W, sent, n_desc, S, dpt, out, flag);
-  T2L_HIP(ctx, hipGetLastError());
-  return T2L_OK;
 }
 
 // ---- host side: BN folding, fragment packing, upload -------------------------------------------

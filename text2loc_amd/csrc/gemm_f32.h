@@ -38,29 +38,12 @@ struct GemmArgs {
   uint32_t drop_key, drop_thr;  // counter-based dropout (train_kernels.h: keep_bit); drop_thr == 0: identity
   float drop_scale;
   int epi;
-  int xcd_bands;  // option train_xcd_map = 1: the XCD bands of xcd_logical below (measured SLOWER in f32, see there); default 0: launch order
 };
 
-// Workgroups are dealt to the 8 XCDs round robin in launch order, so neighbouring blocks land on eight different L2s. Launch position b
-// -> logical position: XCD x = b % 8 works through ONE contiguous band of the logical order (x fastest: a band of row blocks against
-// all column tiles, or a range of reduction chunks of a dW product), i.e. an eighth of one operand and all of the other. Bijective
-// for every block count (the first n % 8 XCDs take one block more).
-// MEASURED (round 3, training step at B = 64): 0.589 -> 0.630 ms per step with f32 operands, neutral (0.479 / 0.481) with bf16. The
-// launch order is not XCD-blind on these shapes: every product of the step has a multiple of 8 column tiles (N = 256 / 512 / 768), so
-// block b = bx + gx * by lands on XCD bx % 8 — each L2 already holds an eighth of the WEIGHT operand and streams the activations;
-// row bands trade that for an eighth of the activations against all of the weights, and lose. Kept as an option (default off).
-__device__ __forceinline__ int xcd_logical(int b, int n) {
-  const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
-  return x * q + min(x, r) + i;
-}
-__device__ __forceinline__ void xcd_remap3(int& bx, int& by, int& bz) {
-  const int gx = gridDim.x, gy = gridDim.y;
-  const int l = xcd_logical(bx + gx * (by + gy * bz), gx * gy * (int)gridDim.z);
-  bx = l % gx;
-  const int t = l / gx;
-  by = t % gy;
-  bz = t / gy;
-}
+// Workgroups are dealt to the 8 XCDs round robin in launch order, and that order is kept: every product of the step has a multiple of 8
+// column tiles (N = 256 / 512 / 768), so block b = bx + gx * by lands on XCD bx % 8 — each L2 holds an eighth of the WEIGHT operand and
+// streams the activations. (Round 3 measured the alternative — per-XCD row bands, option "train_xcd_map": 0.589 -> 0.630 ms per step
+// with f32 operands, neutral with bf16; removed in round 5)
 
 __device__ __forceinline__ bool gemm_keep_bit(uint32_t key, uint32_t idx, uint32_t thr) {  // == train_kernels.h: keep_bit
   uint32_t x = idx * 0x9E3779B1u + key;
@@ -216,7 +199,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   __shared__ float red[4 * 16 * 64];
   __shared__ float cred[4 * 64];
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (g.xcd_bands) xcd_remap3(bx, by, bz);
   gemm_body<A_KC, B_KC>(g, bx, by, bz, red, cred);
 }
 
@@ -376,7 +358,6 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmArgs g) {
   __shared__ float red[kGemm4RedFloats];
   __shared__ float cred[8 * 64];
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (g.xcd_bands) xcd_remap3(bx, by, bz);
   gemm_body4<A_KC, B_KC>(g, bx, by, bz, red, cred);
 }
 // Two products that depend on the same dY and on nothing of each other — dW += dY^T X (with the bias gradient) and
@@ -389,7 +370,7 @@ struct GemmPair {
 static __global__ __launch_bounds__(256) void gemm_pair_kernel(GemmPair p) {
   __shared__ float red[4 * 16 * 64];
   __shared__ float cred[4 * 64];
-  const int b = p.tn.xcd_bands ? xcd_logical(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int b = (int)blockIdx.x;
   if (b < p.tn_blocks) {
     const int bx = b % p.tn_gx, by = (b / p.tn_gx) % p.tn_gy, bz = b / (p.tn_gx * p.tn_gy);
     gemm_body<false, false>(p.tn, bx, by, bz, red, cred);
@@ -403,7 +384,7 @@ static __global__ __launch_bounds__(256) void gemm_pair_kernel(GemmPair p) {
 static __global__ __launch_bounds__(256, 2) void gemm4_pair_kernel(const GemmPair p) {
   __shared__ float red[kGemm4RedFloats];
   __shared__ float cred[8 * 64];
-  const int b = p.tn.xcd_bands ? xcd_logical(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int b = (int)blockIdx.x;
   if (b < p.tn_blocks) {
     const int bx = b % p.tn_gx, by = (b / p.tn_gx) % p.tn_gy, bz = b / (p.tn_gx * p.tn_gy);
     gemm_body4<false, false>(p.tn, bx, by, bz, red, cred);
@@ -423,7 +404,6 @@ __global__ __launch_bounds__(256) void gemm_multi_kernel(GemmMulti m) {
   __shared__ float red[4 * 16 * 64];
   __shared__ float cred[4 * 64];
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (m.j[0].xcd_bands) xcd_remap3(bx, by, bz);
   gemm_body<A_KC, B_KC>(m.j[bz], bx, by, 0, red, cred);
 }
 struct GemmPairMulti {
@@ -432,12 +412,7 @@ struct GemmPairMulti {
 static __global__ __launch_bounds__(256) void gemm_pair_multi_kernel(GemmPairMulti m) {
   __shared__ float red[4 * 16 * 64];
   __shared__ float cred[4 * 64];
-  int job = blockIdx.y, b = blockIdx.x;
-  if (m.p[0].tn.xcd_bands) {
-    const int l = xcd_logical(b + (int)gridDim.x * job, (int)(gridDim.x * gridDim.y));
-    job = l / (int)gridDim.x;
-    b = l % (int)gridDim.x;
-  }
+  const int job = blockIdx.y, b = blockIdx.x;
   const GemmPair& p = m.p[job];
   if (b < p.tn_blocks) {
     const int bx = b % p.tn_gx, by = (b / p.tn_gx) % p.tn_gy, bz = b / (p.tn_gx * p.tn_gy);
@@ -445,102 +420,6 @@ static __global__ __launch_bounds__(256) void gemm_pair_multi_kernel(GemmPairMul
   } else {
     const int c = b - p.tn_blocks;
     gemm_body<true, false>(p.nn, c % p.nn_gx, c / p.nn_gx, 0, red, cred);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Row-streaming GEMM for TALL problems (M = 10^5 .. 10^7 rows, N and K <= 1024: the edge MLPs of PointNet++ in training
-// mode): C[M,N] = A[M,K] B (+ bias[n]), A row-major (k contiguous), B_KC: B(k,n) = B[n*ldb + k] (Y = X W^T) else
-// B(k,n) = B[k*ldb + n] (dX = dY W). gemm_kernel gives every 32x32 output tile its own workgroup: on these shapes the rows are
-// re-read N/32 times and four waves split a reduction of 2-16 steps and meet in LDS. Here a wave owns 32 ROWS: one A
-// fragment per 16-step feeds up to four column tiles (128 columns of accumulators), no split-K, no LDS, no barrier; wider
-// outputs take another pass over the rows. B is small (<= 2 MB) and stays in L1 / L2. K must be a multiple of 16, N of 32.
-// ---------------------------------------------------------------------------------------------------------------
-template <bool B_KC>
-__global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i = lane & 31, kh = lane >> 5;
-  const int m0 = blockIdx.x * 128 + w * 32;
-  if (m0 >= g.M) return;
-  const int arow = min(m0 + i, g.M - 1);  // rows past the end repeat the last one (never stored)
-  const float* ap = g.A + (size_t)arow * g.lda + 8 * kh;
-  constexpr int kRing = 4;  // the rows stream from HBM (~2 us away): four 16-steps of them in flight per wave
-  for (int n0 = 0; n0 < g.N; n0 += 128) {
-    const int nt = min(4, (g.N - n0) >> 5);  // column tiles of this pass (workgroup-uniform)
-    f32x16 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    float a[kRing][8];
-    auto load_a = [&](int k0, float (&d)[8]) {
-      const float4 x = *reinterpret_cast<const float4*>(ap + k0), y = *reinterpret_cast<const float4*>(ap + k0 + 4);
-      d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w; d[4] = y.x; d[5] = y.y; d[6] = y.z; d[7] = y.w;
-    };
-#pragma unroll
-    for (int d = 0; d < kRing; ++d)
-      if (16 * d < g.K) load_a(16 * d, a[d]);
-    for (int kb = 0; kb < g.K; kb += 16 * kRing) {
-#pragma unroll
-      for (int d = 0; d < kRing; ++d) {
-        const int k0 = kb + 16 * d;
-        if (k0 < g.K) {
-          gemm_bf16x8 ah, al;
-          if (g.bf16 == 2) gemm_split_bf16(a[d], ah, al);
-          else if (g.bf16) ah = gemm_to_bf16(a[d]);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            if (t < nt) {
-              float b[8];
-              const int n = n0 + 32 * t + i;
-              if (B_KC) {
-                const float* bp = g.B + (size_t)n * g.ldb + k0 + 8 * kh;
-                const float4 x = *reinterpret_cast<const float4*>(bp), y = *reinterpret_cast<const float4*>(bp + 4);
-                b[0] = x.x; b[1] = x.y; b[2] = x.z; b[3] = x.w; b[4] = y.x; b[5] = y.y; b[6] = y.z; b[7] = y.w;
-              } else {
-                const float* bp = g.B + (size_t)(k0 + 8 * kh) * g.ldb + n;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) b[j] = bp[(size_t)j * g.ldb];
-              }
-              if (g.bf16 == 2) {
-                gemm_bf16x8 bh, bl;
-                gemm_split_bf16(b, bh, bl);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-              } else if (g.bf16) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, gemm_to_bf16(b), acc[t], 0, 0, 0);
-              } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][j], b[j], acc[t], 0, 0, 0);
-                // (tools/mfma_hazard_scan.py: the register allocator's accumulator copies behind this branch sat 12-17 wait states
-                //  after the last 16-pass MFMA — the recogniser padded for the 8-pass bf16 path that joins here; this kernel is the
-                //  first version's, kept for A/B runs: 16 idle cycles per 512 of MFMAs)
-                __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise hoists the wait in between the MFMAs)
-                asm volatile("s_nop 15" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-              }
-            }
-          }
-          if (k0 + 16 * kRing < g.K) load_a(k0 + 16 * kRing, a[d]);  // refill this slot with the step one ring ahead
-        }
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (t < nt) {
-        const int cg = n0 + 32 * t + i;
-        const float bv = g.bias ? g.bias[cg] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          if (row < g.M) {
-            float v = acc[t][r] + bv;
-            if (g.relu) v = fmaxf(v, 0.f);
-            g.C[(size_t)row * g.ldc + cg] = v;
-          }
-        }
-      }
-    }
   }
 }
 

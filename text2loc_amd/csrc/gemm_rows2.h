@@ -1,6 +1,6 @@
 // Row-streaming GEMMs of the PointNet++ training path, second version (pointnet_train.h). gfx950 only.
 //
-// The edge-MLP products are TALL: M = 10^5 .. 3*10^6 rows, N and K <= 1024. The first version (gemm_f32.h: gemm_rows_kernel,
+// The edge-MLP products are TALL: M = 10^5 .. 3*10^6 rows, N and K <= 1024. The first version (round 3's gemm_rows_kernel, removed in round 5,
 // gemm_kernel<false,false>) loaded every weight fragment from L2 right in front of the MFMAs that consume it — a dependent
 // ~1 us load per 8 MFMAs — and ran at 0.3-0.4 of the f32 MFMA peak whatever the operand type (rocprofv3, r03f: 50-63 TFLOP/s
 // in f32, the same wall time with bf16 operands). Here the SMALL operand lives in LDS:

@@ -1,5 +1,5 @@
 // Symmetric InfoNCE of training/losses.py:255-283 (ContrastiveLoss), forward + analytic backward, as ONE
-// single-workgroup launch (the op is latency bound: 2*B^2*D = 2.1 MFLOP at B = 64).
+// launch of 4 * ceil(B / 32) workgroups (the op is latency bound: 2*B^2*D = 2.1 MFLOP at B = 64).
 //
 //   ia_i = 1/|im_i|, ip_j = 1/|s_j|                                   losses.py:271-272
 //   sim  = (im @ s^T) * ia_i * ip_j            f32 MFMA 32x32x2      :274
@@ -114,109 +114,8 @@ __device__ __forceinline__ void grad_rowblock(const float* __restrict__ G, int l
   }
 }
 
-__global__ __launch_bounds__(256, 1) void contrastive_kernel(const float* __restrict__ im, const float* __restrict__ s,
-                                                             int B, float inv_t, float* __restrict__ loss,
-                                                             float* __restrict__ g_im, float* __restrict__ g_s) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int Bp = (B + 31) / 32 * 32;
-  const int ldg = Bp + 1;
-  float* E = smem;                // [Bp][ldg]
-  float* ia = E + Bp * ldg;       // [Bp]
-  float* ip = ia + Bp;            // [Bp]
-  float* diag = ip + Bp;          // [Bp] sim_ii
-  float* R = diag + Bp;           // [Bp]
-  float* C = R + Bp;              // [Bp]
-  float* red = C + Bp;            // [4]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = lane & 31, half = lane >> 5;
-
-  for (int i = tid; i < Bp * ldg; i += 256) E[i] = 0.f;
-#pragma unroll 4  // four rows' loads in flight per wave; the sums run on DPP (a __shfl_xor tree is 6 dependent LDS round trips)
-  for (int i = wave; i < Bp; i += 4) {  // inverse norms, one wave per row
-    float sa = 0.f, sp = 0.f;
-    if (i < B) {
-      const float4 a = reinterpret_cast<const float4*>(im + (size_t)i * kD)[lane];
-      const float4 p = reinterpret_cast<const float4*>(s + (size_t)i * kD)[lane];
-      sa = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
-      sp = p.x * p.x + p.y * p.y + p.z * p.z + p.w * p.w;
-    }
-    sa = wave_sum_f32(sa);
-    sp = wave_sum_f32(sp);
-    if (lane == 0) {
-      ia[i] = i < B ? 1.f / sqrtf(sa) : 0.f;
-      ip[i] = i < B ? 1.f / sqrtf(sp) : 0.f;
-    }
-  }
-  __syncthreads();
-
-  // sim tiles (32x32), k permuted so that each lane streams one contiguous half row of each operand
-  const int nb = Bp / 32;
-  for (int tile = wave; tile < nb * nb; tile += 4) {
-    const int i0 = (tile / nb) * 32, j0 = (tile % nb) * 32;
-    const float4* ap = reinterpret_cast<const float4*>(im + (size_t)min(i0 + col, B - 1) * kD + half * 128);
-    const float4* pp = reinterpret_cast<const float4*>(s + (size_t)min(j0 + col, B - 1) * kD + half * 128);
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 8
-    for (int q = 0; q < 32; ++q) {
-      const float4 a = ap[q], p = pp[q];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, p.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, p.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, p.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, p.w, acc, 0, 0, 0);
-    }
-    const int j = j0 + col;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (i < B && j < B) {
-        const float sim = acc[r] * ia[i] * ip[j];
-        E[i * ldg + j] = __expf(sim * inv_t);
-        if (i == j) diag[i] = sim;
-      }
-    }
-  }
-  __syncthreads();
-  if (tid < Bp) {
-    float r = 0.f, c = 0.f;
-    for (int j = 0; j < B; ++j) {
-      r += E[tid * ldg + j];
-      c += E[j * ldg + tid];
-    }
-    R[tid] = r;
-    C[tid] = c;
-  }
-  __syncthreads();
-  {
-    float v = 0.f;
-    for (int i = tid; i < B; i += 256) v += __logf(C[i]) + __logf(R[i]) - 2.f * diag[i] * inv_t;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    if (lane == 0) red[wave] = v;
-  }
-  __syncthreads();
-  if (tid == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) / (float)B;
-  if (!g_im) return;
-
-  const float sc = inv_t / (float)B;
-  for (int e = tid; e < B * B; e += 256) {
-    const int i = e / B, j = e % B;
-    const float v = E[i * ldg + j];
-    E[i * ldg + j] = (v / C[j] + v / R[i] - (i == j ? 2.f : 0.f)) * sc;
-  }
-  __syncthreads();
-  for (int task = wave; task < 2 * nb; task += 4) {
-    const int i0 = (task % nb) * 32;
-    if (task < nb)
-      grad_rowblock(E, ldg, false, B, i0, s, ip, im, ia, g_im, lane);
-    else
-      grad_rowblock(E, ldg, true, B, i0, im, ia, s, ip, g_s, lane);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// The same loss as 4*nb workgroups (default; `loss_single_wg` = 1 keeps the kernel above). The single workgroup spent half its time
+// The loss as 4*nb workgroups. (Rounds 1-2 ran ONE workgroup — 38.6 us per call at batch 64 against 22.4 us; removed in round 5.) The single workgroup spent half its time
 // in the two gradient products — 2*nb row blocks of 8 column tiles on 4 waves — and a quarter in load round trips ahead of the
 // similarity tiles. Here EVERY workgroup repeats the cheap part (similarity tiles, E, row / column sums, G: B^2 work, in its own LDS;
 // the inverse norms fall out of the operand loads of the similarity tiles, there is no norm pass), and the gradients' 2*nb*8 output
@@ -509,26 +408,15 @@ int loss_impl(t2l_ctx* ctx, const float* a, const float* p, int B, float temp, f
   if (B > T2L_MAX_LOSS_BATCH) return fail(ctx, T2L_EINVAL, "t2l_contrastive_loss: batch > 1024 not supported");
   if (B > 128) return loss_big_impl(ctx, a, p, B, temp, loss, ga, gp, s);
   const int Bp = (B + 31) / 32 * 32;
-  const size_t lds = ((size_t)Bp * (Bp + 1) + 5 * Bp + 4) * sizeof(float);
   static PerDeviceOnce attr_done;
   if (attr_done.need(ctx->device)) {
-    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&contrastive_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+    T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&contrastive_tiles_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     attr_done.mark(ctx->device);
   }
   event_begin(ctx, "contrastive_loss", s);
-  if (ctx->loss_single_wg) {
-    hipLaunchKernelGGL(contrastive_kernel, dim3(1), dim3(256), lds, s, a, p, B, 1.0f / temp, loss, ga, gp);
-  } else {
-    static PerDeviceOnce attr2_done;
-    if (attr2_done.need(ctx->device)) {
-      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&contrastive_tiles_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-      attr2_done.mark(ctx->device);
-    }
-    const size_t lds2 = (2 * (size_t)Bp * (Bp + 1) + 10 * Bp) * sizeof(float);
-    hipLaunchKernelGGL(contrastive_tiles_kernel, dim3(ga ? 4 * (Bp / 32) : 1), dim3(256), lds2, s, a, p, B, 1.0f / temp, loss, ga, gp);
-  }
+  const size_t lds = (2 * (size_t)Bp * (Bp + 1) + 10 * Bp) * sizeof(float);
+  hipLaunchKernelGGL(contrastive_tiles_kernel, dim3(ga ? 4 * (Bp / 32) : 1), dim3(256), lds, s, a, p, B, 1.0f / temp, loss, ga, gp);
   event_end(ctx, "contrastive_loss", s);
   T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;

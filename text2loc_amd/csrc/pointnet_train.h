@@ -32,12 +32,11 @@ struct PnLevel {
   float *mean1 = nullptr, *rstd1 = nullptr, *mean2 = nullptr, *rstd2 = nullptr;
   float* rg1 = nullptr;  // rstd1 * gamma1 per (cell, channel): the fused BatchNorm + ReLU operand loads of the second version
   float* ysel = nullptr;  // pre-BatchNorm value of the second layer at the arg-max row, per (group, channel)
-  float *xout = nullptr, *pos_out = nullptr, *w1p = nullptr, *dw1p = nullptr;
+  float *xout = nullptr, *pos_out = nullptr, *w1p = nullptr;
 };
 
 struct PnTrain {
   bool bound = false, trainable = false, have_forward = false;
-  bool v1 = false;  // the forward that is kept ran the first version's GEMM kernels (option pointnet_train_v1): a1 is stored
   char *ws = nullptr, *iws = nullptr;  // activations + scratch (sized exactly per call) / index tables (worst case, small)
   size_t ws_cap = 0, ws_off = 0, iws_cap = 0, scratch_off = 0, scratch_bytes = 0;
   int n_obj = 0, n_cells = 0;
@@ -193,10 +192,6 @@ __global__ __launch_bounds__(256) void pt_gather_kernel(const float* __restrict_
 __global__ void pt_pad_kernel(const float* __restrict__ W, int rows, int kin, int kp, float* __restrict__ Wp) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < rows * kp) Wp[i] = (i % kp) < kin ? W[(i / kp) * kin + (i % kp)] : 0.f;
-}
-__global__ void pt_unpad_add_kernel(const float* __restrict__ dWp, int rows, int kin, int kp, float* __restrict__ dW) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < rows * kin) dW[i] += dWp[(i / kin) * kp + (i % kin)];
 }
 
 // per-(cell, channel) sums over a block of kStatRows rows; grid (C/64, ceil(E/kStatRows)) (C = 32: grid.x = 1, half idle).
@@ -499,15 +494,6 @@ __global__ __launch_bounds__(256) void pt_segmax_kernel(const float* __restrict_
   *reinterpret_cast<int4*>(arg + i) = make_int4(br[0], br[1], br[2], br[3]);
   *reinterpret_cast<float4*>(ysel + i) = make_float4(ys[0], ys[1], ys[2], ys[3]);
 }
-// dx_src[src][0:cin] += dX[row][0:cin]
-__global__ __launch_bounds__(256) void pt_scatter_kernel(const float* __restrict__ dX, const int32_t* __restrict__ src, size_t E, int cin, int kp,
-                                                         float* __restrict__ dx_src) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= E * cin) return;
-  const size_t row = i / cin;
-  const int col = (int)(i % cin);
-  unsafeAtomicAdd(dx_src + (size_t)src[row] * cin + col, dX[row * kp + col]);
-}
 __global__ void pt_slice_kernel(const float* __restrict__ dX, size_t rows, int cin, int kp, float* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < rows * cin) out[i] = dX[(i / cin) * kp + (i % cin)];
@@ -529,24 +515,12 @@ static void pn_train_free(void* p) {
   delete pt;
 }
 
-// the tall GEMMs of the edge MLPs: row-streaming kernel (gemm_f32.h), one launch whatever M is
-static void launch_rows_nt(const train::GemmArgs& g, hipStream_t s) {
-  hipLaunchKernelGGL((train::gemm_rows_kernel<true>), dim3((unsigned)((g.M + 127) / 128)), dim3(256), 0, s, g);
-}
-static void gemm_nt_rows(const float* X, const float* W, const float* b, float* Y, size_t M, int N, int K, int relu, hipStream_t s) {
-  launch_rows_nt(train::GemmArgs{X, W, Y, b, (int)M, N, K, K, K, N, relu, 0, 0, nullptr, tl_gemm_bf16}, s);
-}
 // dX[M,Kp] = dY[M,N] W[N,Kp]: W is transposed once (<= 2 MB) so that the weight fragments are k-contiguous float4 loads too
 // (eight strided scalar loads per tile and step made this form 3 ms slower than the 32x32-tile kernel it replaces)
 __global__ void pt_transpose_kernel(const float* __restrict__ W, int N, int Kp, float* __restrict__ Wt) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < N * Kp) Wt[(size_t)(i % Kp) * N + i / Kp] = W[i];
 }
-static void gemm_nn_rows(const float* dY, const float* W, float* Wt, float* dX, size_t M, int N, int Kp, hipStream_t s) {
-  hipLaunchKernelGGL(pt_transpose_kernel, dim3((unsigned)((N * Kp + 255) / 256)), dim3(256), 0, s, W, N, Kp, Wt);
-  launch_rows_nt(train::GemmArgs{dY, Wt, dX, nullptr, (int)M, Kp, N, N, N, Kp, 0, 0, 0, nullptr, tl_gemm_bf16}, s);
-}
-
 // ---- second version: LDS-resident weights (gemm_rows2.h) ----------------------------------------------------------------
 static int pn_cu_count() {
   static int n_cu = 0;
@@ -742,11 +716,10 @@ static size_t pn_layout(PnTrain* pt) {
     L.row_cell = pn_bump<int32_t>(pt, L.E);
     L.X = pn_bump<float>(pt, L.E * L.kp);
     L.w1p = pn_bump<float>(pt, (size_t)L.h1 * L.kp);
-    L.dw1p = pn_bump<float>(pt, (size_t)L.h1 * L.kp);
     L.y1 = pn_bump<float>(pt, L.E * L.h1);
     // second version: a1 is recomputed from y1 wherever it is consumed — except in the global MLP (45 k rows x 512: 92 MB), whose
     // wide layers would pay the fused operand transform once per column pass (K = 512 leaves two column tiles per pass)
-    L.a1 = (pt->v1 || l == 3) ? pn_bump<float>(pt, L.E * L.h1) : nullptr;
+    L.a1 = l == 3 ? pn_bump<float>(pt, L.E * L.h1) : nullptr;
     L.rg1 = pn_bump<float>(pt, (size_t)n_cells * L.h1);
     L.y2 = pn_bump<float>(pt, L.E * L.h2);
     L.mean1 = pn_bump<float>(pt, (size_t)n_cells * L.h1);
@@ -776,16 +749,8 @@ static void pn_block_fwd(TrainState* st, PnTrain* pt, const PnLevel& L, int laye
   using namespace train;
   const std::string p = L.prefix + "." + std::to_string(layer);
   (void)hipMemsetAsync(pt->acc, 0, sizeof(double) * 2 * 1024 * pt->n_cells, s);
-  if (pt->v1) {
-    gemm_nt_rows(X, W, T_(st, p + ".0.bias").data, y, L.E, C, K, 0, s);
-    const dim3 sgrid((C + 63) / 64, (unsigned)((L.E + kStatRows - 1) / kStatRows));
-    hipLaunchKernelGGL((pt_bn_stats_kernel<0>), sgrid, dim3(256), 0, s, (const float*)y, (const float*)nullptr, (const float*)nullptr, C, L.E,
-                       (const int32_t*)L.row_cell, (const float*)nullptr, (const float*)nullptr, pt->acc, (const float*)nullptr,
-                       (const float*)nullptr);
-  } else {
-    gemm_rows2(X, W, T_(st, p + ".0.bias").data, y, L.E, C, K, x_fuse ? L.mean1 : nullptr, x_fuse ? L.rg1 : nullptr,
-               x_fuse ? T_(st, L.prefix + ".0.1.bias").data : nullptr, L.row_cell, pt->acc, s);
-  }
+  gemm_rows2(X, W, T_(st, p + ".0.bias").data, y, L.E, C, K, x_fuse ? L.mean1 : nullptr, x_fuse ? L.rg1 : nullptr,
+             x_fuse ? T_(st, L.prefix + ".0.1.bias").data : nullptr, L.row_cell, pt->acc, s);
   hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const double*)pt->acc, (const int32_t*)L.cnt, pt->n_cells, C,
                      mean, rstd, T_(st, p + ".1.running_mean").data, T_(st, p + ".1.running_var").data, 0.1f,
                      (const float*)T_(st, p + ".1.weight").data, rg);
@@ -839,7 +804,6 @@ int pn_train_forward_impl(t2l_ctx* ctx, const float* pos, const float* rgb, cons
   pt->pos0 = pos;
   pt->rgb0 = rgb;
   tl_gemm_bf16 = ctx->train_bf16;
-  tl_xcd_bands = ctx->train_xcd_map ? 1 : 0;
   const std::string P = "object_encoder.pointnet.";
   const int ns[3] = {256, 128, 64}, cin[3] = {3, 64, 128}, h1[4] = {32, 128, 256, 512}, h2[4] = {64, 128, 256, 1024};
   const float radius[3] = {0.2f, 0.3f, 0.4f};
@@ -941,7 +905,6 @@ int pn_train_forward_impl(t2l_ctx* ctx, const float* pos, const float* rgb, cons
   for (int c = 0; c < n_cells; ++c) h_cnt[3][c] = (cell_offsets[c + 1] - cell_offsets[c]) * 32;
 
   // ---- activations: exact sizes
-  pt->v1 = ctx->pn_train_v1 != 0;
   char* keep = pt->ws;
   pt->ws = nullptr;
   const size_t need = pn_layout(pt);
@@ -1011,7 +974,6 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
   if (!grad_f2) return fail(ctx, T2L_EINVAL, "t2l_pointnet_backward: null gradient");
   const int n_obj = pt->n_obj;
   tl_gemm_bf16 = ctx->train_bf16;
-  tl_xcd_bands = ctx->train_xcd_map ? 1 : 0;
   const std::string P = "object_encoder.pointnet.";
   event_begin(ctx, "pointnet_train_backward", s);
   pt->ws_off = pt->scratch_off;
@@ -1033,10 +995,7 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
     float* dA1 = pn_bump<float>(pt, L.E * L.h1);
     pn_block_bwd(st, pt, L, 1, dA2, L.y2, nullptr, L.h2, L.mean2, L.rstd2, nullptr, dx, s);
     const float* be1 = T_(st, L.prefix + ".0.1.bias").data;
-    if (pt->v1) {
-      gemm_tn(dA2, L.a1, T_(st, L.prefix + ".1.0.weight").grad, T_(st, L.prefix + ".1.0.bias").grad, (int)L.E, L.h2, L.h1, s);
-      gemm_nn_rows(dA2, T_(st, L.prefix + ".1.0.weight").data, pt->wt, dA1, L.E, L.h2, L.h1, s);
-    } else {  // a1 = relu(bn(y1)) is rebuilt while y1 is staged
+    {  // a1 = relu(bn(y1)) is rebuilt while y1 is staged
       if (!gemm_tn2(dA2, L.a1 ? L.a1 : L.y1, T_(st, L.prefix + ".1.0.weight").grad, T_(st, L.prefix + ".1.0.bias").grad, L.E, L.h2, L.h1, L.h1,
                     L.h1, L.a1 ? nullptr : L.mean1, L.a1 ? nullptr : L.rg1, L.a1 ? nullptr : be1, L.row_cell, s))
         return fail(ctx, T2L_EHIP, "t2l_pointnet_backward: no tn2_kernel instance for this layer shape (internal error)");
@@ -1045,12 +1004,7 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
       gemm_rows2(dA2, pt->wt, nullptr, dA1, L.E, L.h1, L.h2, nullptr, nullptr, nullptr, nullptr, nullptr, s);
     }
     pn_block_bwd(st, pt, L, 0, dA1, L.y1, L.a1, L.h1, L.mean1, L.rstd1, L.rg1, nullptr, s);
-    if (pt->v1) {
-      T2L_HIP(ctx, hipMemsetAsync(L.dw1p, 0, sizeof(float) * (size_t)L.h1 * L.kp, s));
-      gemm_tn(dA1, L.X, L.dw1p, T_(st, L.prefix + ".0.0.bias").grad, (int)L.E, L.h1, L.kp, s);
-      hipLaunchKernelGGL(pt_unpad_add_kernel, dim3(pn_blocks((size_t)L.h1 * L.kin)), dim3(256), 0, s, (const float*)L.dw1p, L.h1, L.kin, L.kp,
-                         T_(st, L.prefix + ".0.0.weight").grad);
-    } else {  // straight into the unpadded gradient: the padding columns of X are not written
+    {  // straight into the unpadded gradient: the padding columns of X are not written
       if (!gemm_tn2(dA1, L.X, T_(st, L.prefix + ".0.0.weight").grad, T_(st, L.prefix + ".0.0.bias").grad, L.E, L.h1, L.kp, L.kin, L.kin,
                     nullptr, nullptr, nullptr, nullptr, s))
         return fail(ctx, T2L_EHIP, "t2l_pointnet_backward: no tn2_kernel instance for this layer shape (internal error)");
@@ -1058,7 +1012,7 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
     if (l > 0) {  // the input gradient: features of the level below (positions are data)
       const PnLevel& Lb = pt->lv[l - 1];
       const size_t nprev = Lb.G * Lb.h2;
-      if (!pt->v1 && L.sa) {  // second version: the product's epilogue scatters (atomics through src): no [E, kp] gradient, no scatter launch
+      if (L.sa) {  // the product's epilogue scatters (atomics through src): no [E, kp] gradient, no scatter launch
         T2L_HIP(ctx, hipMemsetAsync(dx_next, 0, sizeof(float) * nprev, s));
         hipLaunchKernelGGL(pt_transpose_kernel, dim3((unsigned)((L.h1 * L.kp + 255) / 256)), dim3(256), 0, s, (const float*)L.w1p, L.h1, L.kp,
                            pt->wt);
@@ -1066,21 +1020,11 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
         gemm_rows2(dA1, pt->wt, nullptr, nullptr, L.E, (L.cin + 31) / 32 * 32, L.h1, nullptr, nullptr, nullptr, nullptr, nullptr, s,
                    (const int32_t*)L.src, dx_next, L.cin);
       } else {
-        float* dX = pn_bump<float>(pt, L.E * L.kp);
-        if (pt->v1) {
-          gemm_nn_rows(dA1, L.w1p, pt->wt, dX, L.E, L.h1, L.kp, s);
-        } else {
-          hipLaunchKernelGGL(pt_transpose_kernel, dim3((unsigned)((L.h1 * L.kp + 255) / 256)), dim3(256), 0, s, (const float*)L.w1p, L.h1, L.kp,
-                             pt->wt);
-          gemm_rows2(dA1, pt->wt, nullptr, dX, L.E, L.kp, L.h1, nullptr, nullptr, nullptr, nullptr, nullptr, s);
-        }
-        if (L.sa) {
-          T2L_HIP(ctx, hipMemsetAsync(dx_next, 0, sizeof(float) * nprev, s));
-          hipLaunchKernelGGL(pt_scatter_kernel, dim3(pn_blocks(L.E * L.cin)), dim3(256), 0, s, (const float*)dX, (const int32_t*)L.src, L.E, L.cin,
-                             L.kp, dx_next);
-        } else {
-          hipLaunchKernelGGL(pt_slice_kernel, dim3(pn_blocks(L.E * L.cin)), dim3(256), 0, s, (const float*)dX, L.E, L.cin, L.kp, dx_next);
-        }
+        float* dX = pn_bump<float>(pt, L.E * L.kp);  // (the global level: no sampling, the rows ARE the level below's)
+        hipLaunchKernelGGL(pt_transpose_kernel, dim3((unsigned)((L.h1 * L.kp + 255) / 256)), dim3(256), 0, s, (const float*)L.w1p, L.h1, L.kp,
+                           pt->wt);
+        gemm_rows2(dA1, pt->wt, nullptr, dX, L.E, L.kp, L.h1, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+        hipLaunchKernelGGL(pt_slice_kernel, dim3(pn_blocks(L.E * L.cin)), dim3(256), 0, s, (const float*)dX, L.E, L.cin, L.kp, dx_next);
       }
       std::swap(dx, dx_next);
     }

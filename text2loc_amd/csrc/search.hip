@@ -47,7 +47,7 @@ namespace t2l {
 // card — and clears the counters.
 // Two banks (round 4): a call counts in `fb_count`, which the call before it left zeroed; `fb_prev` is that earlier call's bank — its
 // final counts are parked at fb_count[64..79] (the report card) and it is cleared for the call after this one. The host swaps the two
-// per call. No workgroup of a call ever waits for this reset (a fused scan + re-rank launch counts from its first finished query
+// per call. No workgroup of a call ever waits for this reset (a launch may count from its first finished query
 // block on, whatever workgroup 0 is doing).
 __device__ __forceinline__ void reset_counts(int32_t* fb_count, int32_t* fb_prev, int zero_counts, int tid) {
   if (zero_counts && tid < 16) {
@@ -514,11 +514,7 @@ __device__ __forceinline__ float dpp_f(float v) {
   return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, true));
 }
 
-// PREP: the queries arrive as the f16 fragment plane of prep_queries_kernel ([query block][wave slot][group][k-step][lane] x 16 B:
-// a wave's fragment load is one contiguous 1 KiB) instead of being converted by every workgroup — the 16 splits of a query
-// block then read 128 KB of f16 each instead of converting 256 KB of f32 each (67 MB -> 33 MB through the L2s, no LDS exchange,
-// no barrier in the prologue).
-// The arguments of the re-rank (one struct: rerank_kernel and the fused scan + re-rank launch share the per-query routine below).
+// The arguments of the re-rank's per-query routine (rerank_query), as one struct.
 struct RerankArgs {
   const float* db;
   const float* q;
@@ -538,33 +534,18 @@ struct RerankArgs {
   int seq, wide_cap;
 };
 
-// FUSED (round 4): scan + re-rank in ONE launch. A workgroup publishes its candidate lists with write-through (sc1) stores, arrives on
-// its query block's counter, waits until the block's other splits have arrived (they are co-resident: a query block's workgroups
-// are consecutive in launch order) and then re-ranks its share of the block's queries (rerank_query, lists read with sc1 loads) —
-// no second dispatch, no kernel boundary between the two stages. The wait is bounded: a workgroup whose partners do not show up
-// (the chip shared with another process, fewer CUs than a block has splits) ranks its queries exactly instead (wg_exact_scan).
-struct FusedArgs {
-  RerankArgs rr;
-  int32_t* qb_cnt;  // [2][kFusedMaxQb] arrival counters, by call parity: a call counts in one half and zeroes the other for the next
-  int parity;
-};
-constexpr int kFusedMaxQb = 4096;
-constexpr int kFusedSpinMax = 1 << 15;  // x s_sleep(16) ~ 1 us each: ~30 ms, then the exact fallback
-template <int LL>
-__device__ void fused_rerank_tail(const FusedArgs& fa, float* smem, int qb, int sp, int nsplit, int Q);  // (defined behind rerank_query)
-
 // MERGE: the workgroup's four lists per query (two lane halves x two waves, 24 keys) leave as ONE record of 8 floats — the best 7 keys,
 // re-keyed so that the source list rides in two more code bits, + a bound on every key that did not make it (kMergedLL; the
 // re-rank's MG form reads it): a third of the bytes written back at the end of the launch and read by the re-rank.
 constexpr int kMergedLL = 8;
-template <int LL, int NS, bool PREP, bool FUSED = false, bool MERGE = false>
+template <int LL, int NS, bool MERGE = false>
 __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__ dbt, int n_rows, int n_tiles, int code_bits,
-                                                       const float* __restrict__ q, const uint4* __restrict__ qplane, int Q, int nsplit,
+                                                       const float* __restrict__ q, int Q, int nsplit,
                                                        float* __restrict__ cand, int32_t* __restrict__ fb_count, int32_t* __restrict__ fb_prev,
                                                        int zero_counts, float pinf, unsigned long long* __restrict__ span,
-                                                       unsigned span_seq, int xcd_qgroups, const FusedArgs fa = FusedArgs{}) {
+                                                       unsigned span_seq, int xcd_qgroups) {
   static_assert(NS == 4, "the step loop below is unrolled for a ring of 4 slots");
-  static_assert(!MERGE || (LL == 6 && !FUSED), "the in-workgroup list merge is written for the two-launch search with lists of 6");
+  static_assert(!MERGE || LL == 6, "the in-workgroup list merge is written for lists of 6");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kSlotBytes = 2 * kHalfTileBytes;
   constexpr unsigned kExchange = 2 * kSlotBytes;  // slots 2.. double as the query exchange area (64 KiB) in the prologue
@@ -576,14 +557,7 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
   // xcd_qgroups = GQ > 1: XCD x owns the RECTANGLE {query blocks = x % GQ (mod GQ)} x {splits = x / GQ (mod 8 / GQ)} instead: its
   // L2 pulls 1/GQ of the queries in the prologue (the burst every CU waits for) and GQ/8 of the plane over the main loop.
   int sp = blockIdx.x % nsplit, qb = blockIdx.x / nsplit;
-  if (xcd_qgroups < 0) {
-    // fused launch, 16 splits, query blocks in fours: WINDOWS of 64 consecutive workgroups = 4 query blocks x 16 splits, XCD x =
-    // blockIdx % 8 takes query block x % 4 of the window and splits (x / 4) * 8 + 0..7 — the same L2 footprint as the rectangle
-    // below (a quarter of the queries, half the plane per XCD) with every query block's workgroups inside one window
-    const int r = blockIdx.x & 63, x = r & 7;
-    qb = (blockIdx.x >> 6) * 4 + (x & 3);
-    sp = (x >> 2) * 8 + (r >> 3);
-  } else if (xcd_qgroups > 1) {
+  if (xcd_qgroups > 1) {
     const int GQ = xcd_qgroups, GS = 8 / GQ, nqb = gridDim.x / nsplit;
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3, per = nqb / GQ;
     qb = (j % per) * GQ + x % GQ;
@@ -602,9 +576,6 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
   int vmask = mask;
   asm volatile("" : "+v"(vmask));
   if (blockIdx.x == 0) reset_counts(fb_count, fb_prev, zero_counts, tid);
-  if constexpr (FUSED) {
-    if (sp == 0 && tid == 0) fa.qb_cnt[(fa.parity ^ 1) * kFusedMaxQb + qb] = 0;  // the next call's counter of this query block
-  }
   if (steps == 0) return;  // (the host never launches an empty split)
   // always-on stamps (t2l_kernel_stats "search_scan_span" / "search_scan_busy"): every workgroup stores its own start and end
   // (launch sequence << 40 | 100 MHz ticks) in its own slot of the launch's ring entry — plain stores, no packet on the stream
@@ -652,21 +623,6 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
   // qb*256 + slot*64 + g*32 + col; thread (ql, quarter) = (tid >> 2, tid & 3). LDS exchange rows are 512 B (one f16 query),
   // 16-byte chunk c of row ql at chunk c ^ (ql & 31): conflict-free for the quarter-row writers and the fragment readers.
   u32x4 q0[16], q1[16];  // 128 AGPRs
-  if constexpr (PREP) {
-    const uint4* pl = qplane + (size_t)((qb * 4 + wq) * 2) * 16 * 64 + lane;
-    uint4 v0[16], v1[16];  // all 32 loads in flight, then parked in the AGPRs
-#pragma unroll
-    for (int s_ = 0; s_ < 16; ++s_) {
-      v0[s_] = pl[s_ * 64];
-      v1[s_] = pl[(16 + s_) * 64];
-    }
-#pragma unroll
-    for (int s_ = 0; s_ < 16; ++s_) {
-      q0[s_] = pin_agpr(as_u32x4(v0[s_]));
-      q1[s_] = pin_agpr(as_u32x4(v1[s_]));
-    }
-    __syncthreads();  // (steps 0 and 1 of the tile ring have landed for every wave: vmcnt retired in order behind them)
-  } else
   {
     const int ql = tid >> 2, qt = tid & 3;
     char* ex_w = reinterpret_cast<char*>(smem) + kExchange + ql * 512;
@@ -788,12 +744,7 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
     if constexpr (LL % 2 == 0) {  // 24-byte lists: three 8-byte stores
 #pragma unroll
       for (int i = 0; i < LL / 2; ++i) {
-        if constexpr (FUSED)  // write-through: read by other workgroups of this launch
-          __hip_atomic_store(reinterpret_cast<unsigned long long*>(out) + i,
-                             (unsigned long long)__float_as_uint(ls[2 * i]) | ((unsigned long long)__float_as_uint(ls[2 * i + 1]) << 32),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else
-          reinterpret_cast<float2*>(out)[i] = make_float2(ls[2 * i], ls[2 * i + 1]);
+        reinterpret_cast<float2*>(out)[i] = make_float2(ls[2 * i], ls[2 * i + 1]);
       }
     } else {
 #pragma unroll
@@ -882,7 +833,6 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
     *reinterpret_cast<ulonglong2*>(span + 2 * blockIdx.x) = make_ulonglong2(tag | (wg_t0 & tm), tag | (t1 & tm));
   }
   T2L_STAMP(3);
-  if constexpr (FUSED) fused_rerank_tail<LL>(fa, smem, qb, sp, nsplit, Q);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -929,7 +879,7 @@ __device__ __forceinline__ void top32_insert(double& ts, int& tr, double cd, int
   }
 }
 
-template <int NW = 4>  // waves of the workgroup (4: rerank_kernel, 8: the fused scan + re-rank launch)
+template <int NW = 4>  // waves of the workgroup (4: rerank_kernel)
 __device__ __forceinline__ void wg_exact_scan(const float* __restrict__ db, int n_rows, const float* __restrict__ qrow, int K,
                                               int row_offset, int32_t* __restrict__ out_idx, double* __restrict__ out_score,
                                               WgExactSharedN<NW>& sh) {
@@ -1038,14 +988,12 @@ __device__ __forceinline__ void publish_report(const RerankArgs& a) {
 }
 
 // One query, one wave. `my_wg_flag`: this wave's slot of the workgroup's "rank exactly" flags; `wr_buf`: kWideCap ints of LDS.
-// SC1: the candidate lists are read with agent-scope (L1-bypassing) loads — the fused launch, where they were written by other
-// workgroups of the same launch.
 // MG: the lists are the MERGED records of scanp_kernel<..., MERGE> — `parts` = physical splits, one record of kMergedLL floats per
 // (query, split): 7 keys whose low bits are code << 2 | source list, then the bound on every key the record does not list (what
 // `lane_floor` is for a plain list: the floor of a full list).
-template <int LL, int L, bool SC1, bool MG = false>
+template <int LL, int L, bool MG = false>
 __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid, const int lane, int* my_wg_flag, int* wr_buf) {
-  static_assert(!MG || (LL == kMergedLL && !SC1), "merged records are 8 floats and belong to the two-launch search");
+  static_assert(!MG || LL == kMergedLL, "merged records are 8 floats");
   const float* __restrict__ db = a.db;
   const float* __restrict__ q = a.q;
   const int Q = a.Q, K = a.K, parts = a.parts, code_bits = a.code_bits, row_offset = a.row_offset, half_mode = a.half_mode;
@@ -1079,16 +1027,9 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
     } else if constexpr (LL % 2 == 0) {  // (LL = 6 lists are 24 bytes: 8-byte loads keep every list aligned)
 #pragma unroll
       for (int i = 0; i < LL / 2; ++i) {
-        if constexpr (SC1) {  // fused launch: the lists were published by OTHER workgroups of this launch (sc1 stores): L1-bypassing loads
-          const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(mine) + i, __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT);
-          lst[2 * i] = __uint_as_float((unsigned)u);
-          lst[2 * i + 1] = __uint_as_float((unsigned)(u >> 32));
-        } else {
-          const float2 v = reinterpret_cast<const float2*>(mine)[i];
-          lst[2 * i] = v.x;
-          lst[2 * i + 1] = v.y;
-        }
+        const float2 v = reinterpret_cast<const float2*>(mine)[i];
+        lst[2 * i] = v.x;
+        lst[2 * i + 1] = v.y;
       }
     } else {
 #pragma unroll
@@ -1448,55 +1389,6 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
   }  // !early
 }
 
-// The second half of the fused launch (scanp_kernel<..., FUSED>): publish is done (the caller's lists went out with sc1 stores).
-template <int LL>
-__device__ void fused_rerank_tail(const FusedArgs& fa, float* smem, int qb, int sp, int nsplit, int Q) {
-  static_assert(LL % 2 == 0, "the fused launch publishes 8-byte list pieces");
-  const int tid = threadIdx.x, lane = tid & 63, uwave = uniform_wave_id();
-  // ---- arrive, wait for the query block's other splits
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's list pieces have left (write-through)
-  __syncthreads();                                     // ... and every wave's; the tile ring is free from here on
-  int* wide_rows = reinterpret_cast<int*>(smem);                                        // [8][kWideCap]
-  WgExactSharedN<8>& exact_sh = *reinterpret_cast<WgExactSharedN<8>*>(smem + 8 * kWideCap);
-  int* wg_flag = reinterpret_cast<int*>(smem + 8 * kWideCap) + sizeof(WgExactSharedN<8>) / 4;  // [per_q <= 64] + [1]
-  const int per_q = kWideQPerBlock / nsplit;  // queries of the block this workgroup re-ranks
-  if (tid <= per_q) wg_flag[tid] = 0;
-  __syncthreads();
-  if (tid == 0) {
-    int32_t* c = fa.qb_cnt + fa.parity * kFusedMaxQb + qb;
-    __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int spins = 0;
-    bool ok;
-    while (!(ok = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nsplit) && ++spins < kFusedSpinMax)
-      __builtin_amdgcn_s_sleep(16);
-    wg_flag[per_q] = ok ? 1 : 0;
-  }
-  if (blockIdx.x == 0 && tid == 0) publish_report(fa.rr);  // (reset_counts parked the previous call's counters at the kernel's top)
-  __syncthreads();
-  const bool arrived = wg_flag[per_q] != 0;
-  const int q_base = qb * kWideQPerBlock + sp * per_q;
-  if (arrived) {
-    for (int i = uwave; i < per_q; i += 8) {
-      const int qid = q_base + i;
-      if (qid < Q) rerank_query<LL, 16, true>(fa.rr, qid, lane, &wg_flag[i], wide_rows + uwave * kWideCap);
-    }
-  } else if (tid < per_q && q_base + tid < Q) {
-    wg_flag[tid] = 3;  // the partners never showed up: these queries are ranked exactly, by this workgroup
-    fa.rr.flags[q_base + tid] = 3;
-    atomicAdd(&fa.rr.fb_count[1], 1);
-    atomicAdd(&fa.rr.fb_count[2], 1);
-  }
-  __syncthreads();
-#pragma unroll 1
-  for (int i = 0; i < per_q; ++i) {
-    if (!wg_flag[i]) continue;  // workgroup-uniform
-    const int fq = q_base + i;
-    if (tid == 0) atomicAdd(&fa.rr.fb_count[0], 1);
-    wg_exact_scan<8>(fa.rr.db, fa.rr.n_rows, fa.rr.q + (size_t)fq * kD, fa.rr.K, fa.rr.row_offset, fa.rr.out_idx + (size_t)fq * fa.rr.K,
-                     fa.rr.out_score ? fa.rr.out_score + (size_t)fq * fa.rr.K : nullptr, exact_sh);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // rerank (stage 1): one wave per query, 4 queries per 256-thread block.
 // ------------------------------------------------------------------------------------------------
@@ -1520,7 +1412,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
   if (threadIdx.x < 4) wg_flag[threadIdx.x] = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) publish_report(a);
   __syncthreads();
-  if (qid < Q) rerank_query<LL, L, false, MG>(a, qid, lane, &wg_flag[threadIdx.x >> 6], wide_rows[threadIdx.x >> 6]);
+  if (qid < Q) rerank_query<LL, L, MG>(a, qid, lane, &wg_flag[threadIdx.x >> 6], wide_rows[threadIdx.x >> 6]);
   // ---- unsettled queries of this workgroup: the exact float64 ranking, all 4 waves on one query at a time
   __syncthreads();
 #pragma unroll 1
@@ -1839,34 +1731,6 @@ int db_norm_impl(t2l_ctx* ctx, hipStream_t s) {
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// The queries of one search as the paired scan's f16 fragment plane, converted ONCE (option "search_prep"): per query the
-// power-of-two scale of half_shift_of(max |element|) and RNE to f16 — the arithmetic of the in-kernel prologue, bit for bit —
-// laid out [query block 256][wave slot 4][group 2][k-step 16][lane 64] x 16 B, lane (col, half) of k-step s holding chunk
-// half * 16 + s (k in [8 chunk, +8)) of query block*256 + slot*64 + group*32 + col. Rows beyond Q repeat row Q - 1 (as the
-// in-kernel prologue clamps). One workgroup per 32 queries: coalesced 1 KiB row reads, 512-byte contiguous plane writes.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void prep_queries_kernel(const float* __restrict__ q, int Q, uint4* __restrict__ plane) {
-  __shared__ uint4 tile[32][33];
-  const int t = threadIdx.x, ql = t >> 5, c = t & 31;
-  const int base = blockIdx.x * 32;
-  const int qrow = min(base + ql, Q - 1);
-  const float4* qp = reinterpret_cast<const float4*>(q + (size_t)qrow * kD + 8 * c);
-  const float4 a = qp[0], b = qp[1];
-  float m = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
-                  fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
-#pragma unroll
-  for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));  // the 32 lanes of the row
-  int shift;
-  half_shift_of(m, shift);
-  tile[c][ql] = make_uint4(pack_f16x2(a.x, a.y, shift), pack_f16x2(a.z, a.w, shift), pack_f16x2(b.x, b.y, shift), pack_f16x2(b.z, b.w, shift));
-  __syncthreads();
-  const int c2 = t >> 5, col = t & 31;  // chunk c2 of query base + col
-  const int qb = base >> 8, wq = (base & 255) >> 6, g = (base & 63) >> 5;
-  const int s_ = c2 & 15, half = c2 >> 4;
-  plane[((size_t)(((qb * 4 + wq) * 2 + g) * 16 + s_)) * 64 + half * 32 + col] = tile[c2][col];
-}
-
 static size_t scan_lds_bytes() { return (size_t)2 * kTileFloats * sizeof(float); }
 
 template <typename Kern>
@@ -1894,7 +1758,6 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
   const int stat_mode = probing ? 2 : (half_mode ? 1 : 0);
   const int seq = first ? ++ctx->stat_seq : 0;  // the report card goes out once per call
   const int defer = ctx->heavy ? 1 : 0;
-  bool fused = false;  // scan + re-rank went out as ONE launch (scanp_kernel<..., FUSED>)
   bool merged = false;  // the candidate lists are merged records (scanp_kernel<..., MERGE>)
   if constexpr (LL <= 6) {  // paired f16 MFMA scan (default): one 512-thread workgroup per CU, 256 queries each; `nsplit`
     // counts VIRTUAL splits here: the kernel takes physical ones (2 virtual splits per workgroup)
@@ -1902,16 +1765,9 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
     const size_t lds = (size_t)4 * 2 * kHalfTileBytes;
     static PerDeviceOnce once;
     if (once.need(ctx->device)) {
-      allow_lds(&scanp_kernel<LL, 4, false>, (size_t)4 * 2 * kHalfTileBytes);
-      allow_lds(&scanp_kernel<LL, 4, true>, (size_t)4 * 2 * kHalfTileBytes);
+      allow_lds(&scanp_kernel<LL, 4>, lds);
+      if constexpr (LL == 6) allow_lds(&scanp_kernel<LL, 4, true>, lds);
       once.mark(ctx->device);
-    }
-    const bool prep = ctx->search_prep != 0;
-    if (prep) {  // the f16 fragment plane of this call's queries, converted once (prep_queries_kernel) instead of by every workgroup
-      const int q_pad = (Q + kWideQPerBlock - 1) / kWideQPerBlock * kWideQPerBlock;
-      int rc_ = grow(ctx, (void**)&ctx->qplane, &ctx->qplane_cap, (size_t)q_pad * 512);
-      if (rc_ != T2L_OK) return rc_;
-      hipLaunchKernelGGL(prep_queries_kernel, dim3(q_pad / 32), dim3(1024), 0, s, q, Q, (uint4*)ctx->qplane);
     }
     const unsigned span_seq = ++ctx->span_seq;
     unsigned long long* span = ctx->scan_span && grid.x <= (unsigned)kSpanWgs ? ctx->scan_span + (size_t)2 * kSpanWgs * (span_seq % kSpanRing) : nullptr;
@@ -1922,80 +1778,25 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
       const int nqb = (Q + kWideQPerBlock - 1) / kWideQPerBlock, ns = nsplit / 2;
       if (xq < 2 || 8 % xq || nqb % xq || ns % (8 / xq) || (nqb * ns) % 8) xq = 1;
     }
-    FusedArgs fa{};
-    if constexpr (LL % 2 == 0 && L == 16) {
-      // one launch for scan + re-rank (option "search_fused"): every query block's workgroups must be co-resident — they are
-      // consecutive in launch order (windows of 64, or runs of `nsplit / 2`), one workgroup per CU
-      const int nqb = (Q + kWideQPerBlock - 1) / kWideQPerBlock, ns = nsplit / 2;
-      if (ctx->search_fused && !prep && ctx->n_lanes <= 1 && nqb <= kFusedMaxQb && kWideQPerBlock % ns == 0 && kWideQPerBlock / ns <= 64) {
-        if (!ctx->n_cu) {
-          int v = 0;
-          if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess) ctx->n_cu = v;
-        }
-        if (!ctx->qb_cnt && hipMalloc(&ctx->qb_cnt, sizeof(int32_t) * 2 * kFusedMaxQb) == hipSuccess)
-          (void)hipMemset(ctx->qb_cnt, 0, sizeof(int32_t) * 2 * kFusedMaxQb);
-        const bool window = ns == 16 && nqb % 4 == 0 && ctx->n_cu >= 128;
-        if (ctx->qb_cnt && (window || ctx->n_cu >= 2 * ns)) {
-          fused = true;
-          xq = window ? -1 : 1;
-          fa.rr = RerankArgs{db, q, Q, K, parts, code_bits, ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, half_mode, out_idx,
-                             out_score, ctx->flags, ctx->fb_count, eps_probe, __builtin_inff(), n_rows, defer, stat_mode, ctx->host_stat_dev,
-                             seq, min(ctx->wide_repair, kWideCap)};
-          fa.qb_cnt = ctx->qb_cnt;
-          fa.parity = (int)(ctx->fused_seq++ & 1u);
-        }
-      }
-    }
     hipEvent_t ea, eb;
     const bool ev = event_pair(ctx, "search_scan", &ea, &eb);  // sampled launch: the dispatch carries its own start / stop events
-    bool launched = false;
-    if constexpr (LL % 2 == 0 && L == 16) {
-      if (fused) {
-        static PerDeviceOnce once_f;
-        if (once_f.need(ctx->device)) {
-          allow_lds(&scanp_kernel<LL, 4, false, true>, (size_t)4 * 2 * kHalfTileBytes);
-          once_f.mark(ctx->device);
-        }
-        if (ev)
-          hipExtLaunchKernelGGL((scanp_kernel<LL, 4, false, true>), grid, dim3(512), (uint32_t)lds, s, ea, eb, 0u, dbh, n_rows, n_tiles, code_bits, q,
-                                (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, ctx->fb_prev, zero, __builtin_inff(), span,
-                                span_seq, xq, fa);
-        else
-          hipLaunchKernelGGL((scanp_kernel<LL, 4, false, true>), grid, dim3(512), lds, s, dbh, n_rows, n_tiles, code_bits, q,
-                             (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, ctx->fb_prev, zero, __builtin_inff(), span,
-                             span_seq, xq, fa);
-        launched = true;
-      }
-    }
+    auto launch = [&](auto kern) {
+      if (ev)
+        hipExtLaunchKernelGGL(kern, grid, dim3(512), (uint32_t)lds, s, ea, eb, 0u, dbh, n_rows, n_tiles, code_bits, q, Q, nsplit / 2, ctx->cand_score,
+                              ctx->fb_count, ctx->fb_prev, zero, __builtin_inff(), span, span_seq, xq);
+      else
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, dbh, n_rows, n_tiles, code_bits, q, Q, nsplit / 2, ctx->cand_score, ctx->fb_count,
+                           ctx->fb_prev, zero, __builtin_inff(), span, span_seq, xq);
+    };
     if constexpr (LL == 6 && L == 16) {
       // merged records (option "search_merge_lists"): the workgroup's four lists per query leave as one 32-byte record
       // (two more code bits come out of the key's score: kept to shards whose keys still hold 12 score bits below the exponent)
-      if (!launched && (ctx->search_merge == 1 || (ctx->search_merge == 2 && ctx->merge_live && !ctx->heavy)) && !prep && code_bits <= 9) {
-        static PerDeviceOnce once_m;
-        if (once_m.need(ctx->device)) {
-          allow_lds(&scanp_kernel<LL, 4, false, false, true>, (size_t)4 * 2 * kHalfTileBytes);
-          once_m.mark(ctx->device);
-        }
-        if (ev)
-          hipExtLaunchKernelGGL((scanp_kernel<LL, 4, false, false, true>), grid, dim3(512), (uint32_t)lds, s, ea, eb, 0u, dbh, n_rows, n_tiles,
-                                code_bits, q, (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, ctx->fb_prev, zero,
-                                __builtin_inff(), span, span_seq, xq, fa);
-        else
-          hipLaunchKernelGGL((scanp_kernel<LL, 4, false, false, true>), grid, dim3(512), lds, s, dbh, n_rows, n_tiles, code_bits, q,
-                             (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, ctx->fb_prev, zero, __builtin_inff(), span,
-                             span_seq, xq, fa);
-        launched = merged = true;
-      }
+      merged = (ctx->search_merge == 1 || (ctx->search_merge == 2 && ctx->merge_live && !ctx->heavy)) && code_bits <= 9;
     }
-    if (launched) {
-    } else if (ev)
-      hipExtLaunchKernelGGL(prep ? (scanp_kernel<LL, 4, true>) : (scanp_kernel<LL, 4, false>), grid, dim3(512), (uint32_t)lds, s, ea, eb, 0u,
-                            dbh, n_rows, n_tiles, code_bits, q, (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, ctx->fb_prev, zero,
-                            __builtin_inff(), span, span_seq, xq, fa);
-    else
-      hipLaunchKernelGGL(prep ? (scanp_kernel<LL, 4, true>) : (scanp_kernel<LL, 4, false>), grid, dim3(512), lds, s, dbh, n_rows, n_tiles,
-                         code_bits, q, (const uint4*)ctx->qplane, Q, nsplit / 2, ctx->cand_score, ctx->fb_count, ctx->fb_prev, zero, __builtin_inff(), span,
-                         span_seq, xq, fa);
+    if constexpr (LL == 6) {
+      if (merged) launch(scanp_kernel<LL, 4, true>);
+    }
+    if (!merged) launch(scanp_kernel<LL, 4>);
   } else {
   event_begin(ctx, "search_scan", s);
   if (ctx->eff_mode == 0) {  // f16 MFMA scan, one wave per SIMD (tiny shards, k > 10): 256 queries per workgroup
@@ -2032,11 +1833,6 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
   event_end(ctx, "search_scan", s);
   }
   T2L_HIP(ctx, hipGetLastError());
-  if (fused) {
-    T2L_HIP(ctx, hipGetLastError());
-    if (ctx->heavy) return exact_stage_impl(ctx, db, n_rows, row_offset, q, Q, K, out_idx, out_score, s);
-    return T2L_OK;
-  }
   // Two launches per search. Queries the certificate and the in-wave re-score leave unsettled are ranked exactly by
   // their own re-rank workgroup (wg_exact_scan) — there is no separate fallback launch to pay for when, as usual, there
   // are none. (Heavy mode: they are deferred to the float64 MFMA stage instead, search_exact.hip.)
@@ -2200,7 +1996,7 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     // the paired scan (two waves per SIMD, scanp_kernel) serves the f16 mode whenever the shard gives every query at least
     // 32 per-lane lists (>= 8 physical splits: 256+ rows); its splits below are VIRTUAL ones (two per workgroup)
     // (small batches keep the one-wave-per-SIMD kernel: twice the workgroups, and its prologue is the shorter one)
-    const bool pair_ok = ctx->eff_mode == 0 && ctx->search_pair && L == 16 && n_tiles >= 16 && Q >= 256;
+    const bool pair_ok = ctx->eff_mode == 0 && L == 16 && n_tiles >= 16 && Q >= 256;
     int nsplit = ctx->nsplit_override;
     if (nsplit <= 0) {
       // fill 256 CUs with one (wide scan) or two workgroups each; multiples of 8 keep a split on one XCD's L2
@@ -2262,8 +2058,6 @@ static void swap_lane(t2l_ctx* ctx, t2l_ctx::SearchLane& L) {
   std::swap(ctx->host_stat, L.host_stat);
   std::swap(ctx->host_stat_dev, L.host_stat_dev);
   std::swap(ctx->stat_seen, L.stat_seen);
-  std::swap(ctx->qplane, L.qplane);
-  std::swap(ctx->qplane_cap, L.qplane_cap);
 }
 
 int search_join_impl(t2l_ctx* ctx, hipStream_t s) {
@@ -2278,7 +2072,7 @@ int search_join_impl(t2l_ctx* ctx, hipStream_t s) {
 
 void free_lanes(t2l_ctx* ctx) {
   for (auto& L : ctx->lanes) {
-    for (void* p : {(void*)L.cand_score, (void*)L.flags, (void*)(L.fb_count < L.fb_prev ? L.fb_count : L.fb_prev), L.qplane})
+    for (void* p : {(void*)L.cand_score, (void*)L.flags, (void*)(L.fb_count < L.fb_prev ? L.fb_count : L.fb_prev)})
       if (p) (void)hipFree(p);
     if (L.host_stat) (void)hipHostFree(L.host_stat);
     if (L.stream) (void)hipStreamDestroy(L.stream);

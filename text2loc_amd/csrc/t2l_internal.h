@@ -109,32 +109,18 @@ struct t2l_ctx {
   int pair_ll = 6;       // per-lane list length of the paired scan (5 or 6)
   int wide_repair = 512;  // rows a re-rank wave may re-score in a wide repair before the query goes to an exact scan (0: never)
   int encoder_two_cells = 1;  // encode_cells: two cells per eight-wave workgroup on LDS planes (encode.hip: encode_cells2_kernel); 0: first form
-  int text_inter_fused = 2;  // t2l_text_inter as one fused launch: 2 = two row tiles per 8-wave workgroup on LDS planes (default), 1 = one
                              // tile per 4-wave workgroup on f32 tiles, 0 = the nine-launch tiled-GEMM chain of text_head.hip
   int search_merge = 2;    // the paired scan merges a workgroup's four lists per query into one 32-byte record (search.hip: MERGE / MG):
                            // 0 never, 1 always, 2 while the f16 report cards show next to no failed first certificates (a repair behind
                            // a merged record re-scores 4x the rows of a plain list's)
   bool merge_live = true;  // (search_merge == 2) what the report cards say right now
-  int search_fused = 0;    // 1: scan + re-rank as ONE launch where the shapes allow (search.hip: scanp_kernel<..., FUSED>)
-  int32_t* qb_cnt = nullptr;  // its per-query-block arrival counters [2][4096]
-  unsigned fused_seq = 0;
-  int n_cu = 0;
-  int search_prep = 0;   // paired scan: 1 = the queries' f16 fragment plane is built by a pre-pass launch, once per call
-  void* qplane = nullptr;  // ... that plane (q_pad x 512 B)
-  size_t qplane_cap = 0;
   int xcd_qgroups = 4;   // paired scan: query-block groups per XCD rectangle (1 = every XCD sees all queries and 1/8 of the splits;
                          // 4 = a quarter of the queries and half of the splits: -1.3 us of scan span at Q = 4096 x N = 11,259, measured)
-  int search_pair = 1;   // mode 0: 1 = the paired scan (two waves per SIMD, scanp_kernel), 0 = scanh_kernel (one wave per SIMD)
   int train_bf16 = 0;       // 1: the training step's GEMMs round their operands to bf16 (one bf16 MFMA per 16-step); 2: split-bf16 (three)
-  int fast_gemm_ksplit = 1;  // cut the contraction of few-tile training products into jobs (partial slabs + one reduction pass)
-  int text_train_fast = 1;  // its Linear products on the tiled bf16-plane GEMM of text_head.hip (0: the object branch's tile-per-workgroup products)
   int text_train_bf16 = 2;  // the same for the TEXT head's training GEMMs (d_model 1024: 466 GFLOP per step at B = 64): default split-bf16 —
                             // f32-class products (<= 2^-16 + 2^-18 relative, f32 accumulation, f32 exponent range) at 1.8x the f32 MFMA path's speed
-  int train_xcd_map = 0;      // 1 = the training step's tile GEMMs take their blocks in XCD bands (gemm_f32.h; measured slower in f32)
-  int loss_single_wg = 0;     // 1 = t2l_contrastive_loss (B <= 128) as the single-workgroup kernel (A/B; default: 4 * ceil(B/32) workgroups)
   int train_gemm_block = 0;   // output block of the training step's tile GEMMs: 64 (2 x 2 tiles per wave: half the operand traffic), 32, or
                               // 0 = by measurement: 64 with bf16 / split-bf16 operands (0.555 -> 0.533 ms per step), 32 in f32 (0.640 vs 0.660)
-  int pn_train_v1 = 0;      // 1: PointNet++ training on the first version's GEMM kernels (operands from L2, a1 stored) — for A/B measurements
   int train_keep_adam = 0;  // 1: t2l_train_bind keeps Adam moments + step when the parameter list is unchanged (a re-bind)
   int eff_mode = 0;           // the scan the current t2l_search call runs
   bool heavy = false;         // the database defeats the certificates: flagged queries go to the float64 MFMA stage
@@ -150,8 +136,7 @@ struct t2l_ctx {
   // into the caller's stream by t2l_search_join.
   struct SearchLane {
     float* cand_score = nullptr;
-    void* qplane = nullptr;
-    size_t cand_cap = 0, flag_cap = 0, qplane_cap = 0;
+    size_t cand_cap = 0, flag_cap = 0;
     int32_t *flags = nullptr, *fb_count = nullptr, *fb_prev = nullptr, *host_stat = nullptr, *host_stat_dev = nullptr;
     int stat_seen = 0;
     hipStream_t stream = nullptr;

@@ -689,13 +689,9 @@ struct Weights {
   int out_dim = 0;  // D of inter_mlp (256 coarse, 128 fine)
   // the inter-sentence layer (inter_module.0: d_model 256, 4 heads, dim_feedforward 1024) — coarse model only
   bool has_inter = false;
-  InterFusedW fused;  // the inter layer once more in the encoder's fragment packing (text_inter_fused_kernel, encode.hip)
-  char *i_qkv_h = nullptr, *i_qkv_l = nullptr, *i_out_h = nullptr, *i_out_l = nullptr, *i_ff1_h = nullptr, *i_ff1_l = nullptr, *i_ff2_h = nullptr,
-       *i_ff2_l = nullptr;
+  InterFusedW fused;  // the inter layer in the encoder's fragment packing (text_inter_fused2_kernel, encode.hip)
   float *i_qkv_b = nullptr, *i_out_b = nullptr, *i_ff1_b = nullptr, *i_ff2_b = nullptr, *i_ln1_g = nullptr, *i_ln1_b = nullptr, *i_ln2_g = nullptr,
         *i_ln2_b = nullptr;
-  char* ws2 = nullptr;  // workspace of t2l_text_inter
-  size_t ws2_cap = 0;
   // workspace
   char* ws = nullptr;
   size_t ws_cap = 0;
@@ -733,7 +729,6 @@ void free_text_head(t2l_ctx* ctx) {
   if (!W) return;
   for (void* p : W->owned) (void)hipFree(p);
   if (W->ws) (void)hipFree(W->ws);
-  if (W->ws2) (void)hipFree(W->ws2);
   if (W->flag) (void)hipFree(W->flag);
   if (W->flag_host) (void)hipHostFree(W->flag_host);
   delete W;
@@ -817,14 +812,12 @@ int text_head_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const cha
     bool all = D == ID && !th_find(w, n, P + "inter_module.1.linear1.weight", (int64_t)IF * ID);
     for (int i = 0; i < 12 && all; ++i) all = (it[i] = th_find(w, n, I0 + ireq[i].key, ireq[i].numel)) != nullptr;
     if (all) {
-      if ((rc = planes(it[0]->data, 3 * ID, ID, &W->i_qkv_h, &W->i_qkv_l)) || (rc = vec(it[1]->data, 3 * ID, 3 * ID, &W->i_qkv_b)) ||
-          (rc = planes(it[2]->data, ID, ID, &W->i_out_h, &W->i_out_l)) || (rc = vec(it[3]->data, ID, ID, &W->i_out_b)) ||
-          (rc = planes(it[4]->data, IF, ID, &W->i_ff1_h, &W->i_ff1_l)) || (rc = vec(it[5]->data, IF, IF, &W->i_ff1_b)) ||
-          (rc = planes(it[6]->data, ID, IF, &W->i_ff2_h, &W->i_ff2_l)) || (rc = vec(it[7]->data, ID, ID, &W->i_ff2_b)) ||
+      if ((rc = vec(it[1]->data, 3 * ID, 3 * ID, &W->i_qkv_b)) || (rc = vec(it[3]->data, ID, ID, &W->i_out_b)) ||
+          (rc = vec(it[5]->data, IF, IF, &W->i_ff1_b)) || (rc = vec(it[7]->data, ID, ID, &W->i_ff2_b)) ||
           (rc = vec(it[8]->data, ID, ID, &W->i_ln1_g)) || (rc = vec(it[9]->data, ID, ID, &W->i_ln1_b)) ||
           (rc = vec(it[10]->data, ID, ID, &W->i_ln2_g)) || (rc = vec(it[11]->data, ID, ID, &W->i_ln2_b)))
         return rc;
-      {  // the same four matrices as split-f16 MFMA fragments for the one-launch form (mfma_h3.h packing; 1.5 MB)
+      {  // the four matrices as split-f16 MFMA fragments (mfma_h3.h packing; 1.5 MB)
         auto frag = [&](const float* Wm, int rows, int cols, const uint4** dst) -> int {
           const std::vector<float> pk = pack_split_f16(Wm, nullptr, rows, cols, cols);
           void* d = nullptr;
@@ -974,70 +967,16 @@ int text_inter_impl(t2l_ctx* ctx, const float* sent, int n_desc, int S, float* o
   if (n_desc <= 0) return n_desc == 0 ? T2L_OK : fail(ctx, T2L_EINVAL, "t2l_text_inter: n_descriptions < 0");
   if (S < 1 || S > kMaxL) return fail(ctx, T2L_EINVAL, "t2l_text_inter: need 1 <= sentences per description <= 32");
   const bool single = ctx->encoder_f16 != 0;
-  if (ctx->text_inter_fused) {  // one launch: a tile of floor(32 / S) descriptions per workgroup, everything in LDS (encode.hip)
-    T2L_HIP(ctx, hipMemsetAsync(W->flag, 0, sizeof(int), s));
-    event_begin(ctx, "text_inter", s);
-    const int rc_ = text_inter_fused_launch(ctx, W->fused, single, sent, n_desc, S, out, W->flag, s);
-    event_end(ctx, "text_inter", s);
-    if (rc_ != T2L_OK) return rc_;
-    if (overflow) T2L_HIP(ctx, hipMemcpyAsync(overflow, W->flag, sizeof(int), hipMemcpyDeviceToDevice, s));
-    return T2L_OK;
-  }
-  const int rows_target = 65536;  // descriptions per pass: every intermediate of a pass (11.3 KB per row) stays inside the Infinity Cache
-  const int dpc = max(1, min(n_desc, rows_target / S));
-  const int m_cap = (dpc * S + kTile - 1) / kTile * kTile;
-  const int n_chunks = (n_desc + dpc - 1) / dpc;
-  size_t off = 0;
-  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-  const size_t plane = (size_t)m_cap * ID * 2;
-  const size_t o_xh = take(plane), o_xl = take(plane), o_qkv = take((size_t)m_cap * 3 * ID * 4), o_oh = take(plane), o_ol = take(plane),
-               o_y = take((size_t)m_cap * ID * 4), o_1h = take(plane), o_1l = take(plane), o_hh = take(plane * 4), o_hl = take(plane * 4);
-  if (W->ws2_cap < off) {
-    if (W->ws2) T2L_HIP(ctx, hipFree(W->ws2));
-    W->ws2 = nullptr;
-    W->ws2_cap = 0;
-    T2L_HIP(ctx, hipMalloc(&W->ws2, off));
-    W->ws2_cap = off;
-  }
-  char* ws = W->ws2;
+  // ONE launch: two tiles of floor(32 / S) descriptions per eight-wave workgroup, everything in LDS (encode.hip:
+  // text_inter_fused2_kernel). Rounds 3-4 also shipped a chain of tiled GEMM / attention / LayerNorm launches (0.208 ms for 4,096
+  // descriptions x 6 sentences) and a one-tile form of this launch; both measured slower than this one (0.179 ms) and were removed
+  // in round 5.
   T2L_HIP(ctx, hipMemsetAsync(W->flag, 0, sizeof(int), s));
-  T2L_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)out, (int)0xFF800000u, (size_t)n_desc * ID, s));  // -inf: straddling descriptions meet by atomic max
   event_begin(ctx, "text_inter", s);
-  for (int ch = 0; ch < n_chunks; ++ch) {
-    const int d0 = ch * dpc, nd = min(dpc, n_desc - d0);
-    const int M = nd * S, m_tiles = (M + kTile - 1) / kTile, m_pad = m_tiles * kTile;
-    const float* x = sent + (size_t)d0 * S * ID;
-    hipLaunchKernelGGL(th_split_kernel, dim3(m_pad / 32, 1), dim3(256), 0, s, x, M, ID, (_Float16*)(ws + o_xh), (_Float16*)(ws + o_xl), W->flag);
-    GemmArgs g{};
-    g.flag = W->flag;
-    g.m_tiles = m_tiles;
-    g.M = M;
-    g.wh = W->i_qkv_h; g.wl = W->i_qkv_l; g.xh = ws + o_xh; g.xl = ws + o_xl; g.bias = W->i_qkv_b; g.out0 = ws + o_qkv;
-    g.n_tiles = 3 * ID / kTile; g.K = ID; g.N = 3 * ID; g.n_real = 3 * ID;
-    th_launch_gemm<kEpiT32>(single, g, s);
-    {
-      const int G = 32 / S, n_groups = (nd + G - 1) / G;
-      hipLaunchKernelGGL(th_attn_kernel<256>, dim3(n_groups), dim3(256), 0, s, (const float*)(ws + o_qkv), nd, S, n_groups, (_Float16*)(ws + o_oh),
-                         (_Float16*)(ws + o_ol), W->flag);
-    }
-    g.wh = W->i_out_h; g.wl = W->i_out_l; g.xh = ws + o_oh; g.xl = ws + o_ol; g.bias = W->i_out_b; g.rh = ws + o_xh; g.rl = ws + o_xl; g.out0 = ws + o_y;
-    g.n_tiles = 1; g.K = ID; g.N = ID; g.n_real = ID;
-    th_launch_gemm<kEpiResidT32>(single, g, s);
-    hipLaunchKernelGGL((th_ln_kernel<false, 256>), dim3(m_pad / 32), dim3(256), 8 * 32 * 4, s, (const float*)(ws + o_y), W->i_ln1_g, W->i_ln1_b, M, S,
-                       (_Float16*)(ws + o_1h), (_Float16*)(ws + o_1l), (float*)nullptr, W->flag, (const float*)nullptr);
-    g.wh = W->i_ff1_h; g.wl = W->i_ff1_l; g.xh = ws + o_1h; g.xl = ws + o_1l; g.bias = W->i_ff1_b; g.out0 = ws + o_hh; g.out1 = ws + o_hl;
-    g.n_tiles = IF / kTile; g.K = ID; g.N = IF; g.n_real = IF;
-    th_launch_gemm<kEpiReluT16>(single, g, s);
-    g.wh = W->i_ff2_h; g.wl = W->i_ff2_l; g.xh = ws + o_hh; g.xl = ws + o_hl; g.bias = W->i_ff2_b; g.rh = ws + o_1h; g.rl = ws + o_1l; g.out0 = ws + o_y;
-    g.n_tiles = 1; g.K = IF; g.N = ID; g.n_real = ID;
-    th_launch_gemm<kEpiResidT32>(single, g, s);
-    // LayerNorm2, + x (the residual AROUND the layer), max over the description's S sentence rows
-    hipLaunchKernelGGL((th_ln_kernel<true, 256>), dim3(m_pad / 32), dim3(256), 32 * 260 * 4, s, (const float*)(ws + o_y), W->i_ln2_g, W->i_ln2_b, M, S,
-                       (_Float16*)nullptr, (_Float16*)nullptr, out + (size_t)d0 * ID, W->flag, x);
-  }
+  const int rc_ = text_inter_fused_launch(ctx, W->fused, single, sent, n_desc, S, out, W->flag, s);
   event_end(ctx, "text_inter", s);
+  if (rc_ != T2L_OK) return rc_;
   if (overflow) T2L_HIP(ctx, hipMemcpyAsync(overflow, W->flag, sizeof(int), hipMemcpyDeviceToDevice, s));
-  T2L_HIP(ctx, hipGetLastError());
   return T2L_OK;
 }
 
@@ -1059,7 +998,7 @@ int fast_gemm(t2l_ctx* ctx, const float* A, bool a_trans, const float* B, bool b
   // into the output were measured 2x SLOWER than no split at all) and one pass adds the slabs up (+ bias, ReLU, accumulate)
   const int m_tiles = m_pad / kTile, n_tiles = No / kTile, kt = k_pad >> 4;
   int ks = 1;
-  while (ctx->fast_gemm_ksplit && ks < 8 && m_tiles * n_tiles * ks < 192 && kt % (ks * 4) == 0 && kt / (ks * 2) >= 8) ks *= 2;
+  while (ks < 8 && m_tiles * n_tiles * ks < 192 && kt % (ks * 4) == 0 && kt / (ks * 2) >= 8) ks *= 2;
   const size_t part_bytes = ks > 1 ? sizeof(float) * (size_t)ks * Mo * No : 0;
   const size_t need = 2 * pa + 2 * pb + part_bytes + 256;
   if (ctx->fast_ws_cap < need) {  // (the context's own scratch: calls of one context are serialised by its caller)

@@ -127,12 +127,10 @@ static T* bump(TrainState* st, size_t count) {
 
 // ---- GEMM launchers -----------------------------------------------------------------------------------------
 static thread_local int tl_gemm_bf16 = 0;  // set from the context option "train_bf16" at the top of every forward / backward
-static thread_local int tl_xcd_bands = 0;  // option "train_xcd_map" = 1: the XCD bands of gemm_f32.h (A/B; measured slower in f32)
 static thread_local int tl_gemm_block64 = 0;  // option "train_gemm_block": 64 x 64 output blocks where the shape allows (default: with bf16 operands)
 static inline bool blk64(int rows_out_mult, int cols_out) { return tl_gemm_block64 && rows_out_mult % 64 == 0 && cols_out % 64 == 0; }
 // Y[M,N] = X[M,K] W[N,K]^T + b (relu)
 static void gemm_nt_args(GemmArgs g, hipStream_t s) {  // g.M rows (ragged allowed), g.N columns
-  g.xcd_bands = tl_xcd_bands;
   if (blk64(64, g.N))
     hipLaunchKernelGGL((gemm4_kernel<true, true>), dim3(g.N / 64, (g.M + 63) / 64, 1), dim3(256), 0, s, g);
   else
@@ -144,7 +142,6 @@ static void gemm_nt(const float* X, const float* W, const float* b, float* Y, in
 // dX[M,Kp] (+)= dY[M,N] W[N,Kp]
 static void gemm_nn(const float* dY, const float* W, float* dX, int M, int N, int Kp, int accumulate, hipStream_t s) {
   GemmArgs g{dY, W, dX, nullptr, M, Kp, N, N, Kp, Kp, 0, accumulate, N, nullptr, tl_gemm_bf16};
-  g.xcd_bands = tl_xcd_bands;
   if (blk64(64, Kp))
     hipLaunchKernelGGL((gemm4_kernel<true, false>), dim3(Kp / 64, (M + 63) / 64, 1), dim3(256), 0, s, g);
   else
@@ -163,7 +160,6 @@ static void gemm_tn(const float* dY, const float* X, float* dW, float* db, int M
   int ksplit, kchunk;
   tn_split(M, N, Kp, b64 ? 64 : 32, ksplit, kchunk);
   GemmArgs g{dY, X, dW, nullptr, N, Kp, M, N, Kp, Kp, 0, 1, kchunk, db, tl_gemm_bf16};
-  g.xcd_bands = tl_xcd_bands;
   if (b64)
     hipLaunchKernelGGL((gemm4_kernel<false, false>), dim3(Kp / 64, N / 64, ksplit), dim3(256), 0, s, g);
   else
@@ -180,7 +176,6 @@ static void gemm_tn_nn(const float* dY, const float* X, float* dW, float* db, co
   GemmPair p{};
   p.tn = GemmArgs{dY, X, dW, nullptr, N, Kp, M, N, Kp, Kp, 0, 1, kchunk, db, tl_gemm_bf16};
   p.nn = GemmArgs{dY, W, dX, nullptr, M, Kp, N, N, Kp, Kp, 0, accumulate, N, nullptr, tl_gemm_bf16};
-  p.tn.xcd_bands = p.nn.xcd_bands = tl_xcd_bands;
   if (mask_src) {
     p.nn.epi = 2;
     p.nn.mask_src = mask_src;
@@ -427,7 +422,6 @@ static void small_branches_fwd(TrainState* st, const std::vector<int>& which, in
   hipLaunchKernelGGL((bn_stats_multi_kernel<0>), dim3(1, (M + kBnRows - 1) / kBnRows, n), dim3(256), 0, s, b0);
   sync_slots(st->ctx, b0.j[0].acc, n, s);
   hipLaunchKernelGGL(bn_apply_fwd_multi_kernel, dim3((unsigned)(((size_t)M * 64 + 255) / 256), n), dim3(256), 0, s, b0);
-  gm.j[0].xcd_bands = tl_xcd_bands;
   hipLaunchKernelGGL((gemm_multi_kernel<true, true>), dim3(kTD / 32, (M + 31) / 32, n), dim3(256), 0, s, gm);
   hipLaunchKernelGGL((bn_stats_multi_kernel<0>), dim3(kTD / 64, (M + kBnRows - 1) / kBnRows, n), dim3(256), 0, s, b1);
   sync_slots(st->ctx, b1.j[0].acc, n, s);
@@ -488,7 +482,6 @@ static void small_branches_bwd(TrainState* st, const std::vector<int>& which, in
   hipLaunchKernelGGL((bn_stats_multi_kernel<1>), dim3(kTD / 64, (M + kBnRows - 1) / kBnRows, n), dim3(256), 0, s, b1);
   sync_slots(st->ctx, b1.j[0].acc, n, s);
   hipLaunchKernelGGL(bn_apply_bwd_multi_kernel, dim3((unsigned)(((size_t)M * kTD + 255) / 256), n), dim3(256), 0, s, b1);
-  gp.p[0].tn.xcd_bands = tl_xcd_bands;
   hipLaunchKernelGGL(gemm_pair_multi_kernel, dim3(pair_blocks, n), dim3(256), 0, s, gp);
   hipLaunchKernelGGL((bn_stats_multi_kernel<1>), dim3(1, (M + kBnRows - 1) / kBnRows, n), dim3(256), 0, s, b0);
   sync_slots(st->ctx, b0.j[0].acc, n, s);
@@ -521,7 +514,6 @@ int train_forward_impl(t2l_ctx* ctx, const t2l_packed_cells* in, float p, uint32
     st->ws_cap = need_bytes;
   }
   tl_gemm_bf16 = ctx->train_bf16;
-  tl_xcd_bands = ctx->train_xcd_map ? 1 : 0;
   tl_gemm_block64 = ctx->train_gemm_block == 64 || (ctx->train_gemm_block == 0 && ctx->train_bf16 != 0);
   st->ws_off = 0;
   st->have_forward = false;
@@ -686,7 +678,6 @@ int train_backward_impl(t2l_ctx* ctx, const float* grad_emb, float* grad_pn_feat
   if (!grad_emb) return fail(ctx, T2L_EINVAL, "t2l_encode_cells_backward: null gradient");
   const int M = st->M, B = st->B, T = st->T, Kc = st->n_feat * kTD;
   tl_gemm_bf16 = ctx->train_bf16;
-  tl_xcd_bands = ctx->train_xcd_map ? 1 : 0;
   tl_gemm_block64 = ctx->train_gemm_block == 64 || (ctx->train_gemm_block == 0 && ctx->train_bf16 != 0);
   const size_t mark = st->ws_off;
   event_begin(ctx, "train_backward", s);
@@ -1000,12 +991,12 @@ int text_train_bind_impl(t2l_ctx* ctx, const t2l_train_tensor* tensors, int n, c
   return T2L_OK;
 }
 
-// The head's Linear products. With bf16 / split-bf16 operands (option text_train_bf16 != 0, the default) they run on the tiled
-// LDS-ring GEMM of text_head.hip (fast_gemm: 256 x 256 tiles, bf16 planes — 466 GFLOP per step at B = 64 are GEMM-shaped work that
-// the object branch's tile-per-workgroup products, built for 1,792-row operands, serve at a third of its rate); f32 operands
-// (text_train_bf16 = 0) and shapes it does not take keep the f32-MFMA products of gemm_f32.h.
+// The head's Linear products run on the tiled LDS-ring GEMM of text_head.hip (fast_gemm: 256 x 256 tiles, bf16 planes, split-bf16 by
+// default — 466 GFLOP per step at B = 64 are GEMM-shaped work that the object branch's tile-per-workgroup products, built for
+// 1,792-row operands, serve at a third of its rate); shapes it does not take (fewer than 64 rows) keep the products of gemm_f32.h
+// with the same operand arithmetic. (An f32-MFMA operand option existed until round 5: 7.6 ms per step against PyTorch's 5.6; removed.)
 static bool t_fast(TextTrain* st, int M, int N, int K) {
-  return st->ctx->text_train_bf16 != 0 && st->ctx->text_train_fast && N % 256 == 0 && K % 32 == 0 && K % 4 == 0 && M >= 64;
+  return N % 256 == 0 && K % 32 == 0 && K % 4 == 0 && M >= 64;
 }
 static void t_gemm_nt(TextTrain* st, const float* X, const float* W, const float* b, float* Y, int M, int N, int K, int relu, hipStream_t s) {
   if (t_fast(st, M, N, K)) (void)fast_gemm(st->ctx, X, false, W, false, b, Y, M, N, K, relu, 0, st->ctx->text_train_bf16 == 1, s);
@@ -1124,7 +1115,6 @@ int text_train_forward_impl(t2l_ctx* ctx, const float* hidden, int n_sent, int L
   if (L < 1 || L > 32 || S > 32) return fail(ctx, T2L_EINVAL, "t2l_text_head_train: need 1 <= n_tokens <= 32 and <= 32 sentences per description");
   if (!(p >= 0.f && p < 1.f)) return fail(ctx, T2L_EINVAL, "t2l_text_head_train: dropout_p must be in [0, 1)");
   tl_gemm_bf16 = ctx->text_train_bf16;
-  tl_xcd_bands = 0;
   tl_gemm_block64 = ctx->train_gemm_block == 64 || (ctx->train_gemm_block == 0 && ctx->text_train_bf16 != 0);
   const size_t T1 = (size_t)n_sent * L;
   // saved activations + the backward's scratch: ~31 floats per (row, column) of each layer, see text_layer_alloc / text_layer_bwd
@@ -1193,7 +1183,6 @@ int text_train_backward_impl(t2l_ctx* ctx, const float* grad_out, hipStream_t s)
   if (!st || !st->have_forward) return fail(ctx, T2L_ESTATE, "t2l_text_head_backward: no forward pass to differentiate");
   if (!grad_out) return fail(ctx, T2L_EINVAL, "t2l_text_head_backward: null gradient");
   tl_gemm_bf16 = ctx->text_train_bf16;
-  tl_xcd_bands = 0;
   tl_gemm_block64 = ctx->train_gemm_block == 64 || (ctx->train_gemm_block == 0 && ctx->text_train_bf16 != 0);
   const size_t mark = st->ws_off;
   const int n_sent = st->n_sent, n_desc = st->n_desc, S = st->S, L = st->L;

@@ -9,7 +9,6 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 bf16 = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 0 f32, 1 bf16, 2 split-bf16
 eng = Engine(0)
 eng.set_option("train_bf16", bf16)
-if len(sys.argv) > 3: eng.set_option("pointnet_train_v1", int(sys.argv[3]))
 cells = synth.make_cells(B, seed=1)
 pos, rgb = synth.make_sampled_points(cells, 1)
 sd = dict(synth.make_object_branch_weights(2)); sd.update(synth.make_pointnet_weights(1))

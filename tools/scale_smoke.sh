@@ -29,7 +29,8 @@ for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype"
 if o["parity"]["ids_equal"] is not True: bad.append("headline parity.ids_equal is not true")
 for key in ("weak_scaling_point", "config5_coarse_plus_fine", "alt_query_sharded"):
     if key not in o: bad.append(f"headline lacks {key}")
-o = json.load(open(path.replace("bench_g", "detail_g")))  # the full record: everything below reads it
+import os
+o = json.load(open(os.path.join(os.path.dirname(path), os.path.basename(path).replace("bench_g", "detail_g"))))  # the full record: everything below reads it
 if o.get("n_gpus") != n: bad.append(f"n_gpus {o.get('n_gpus')} != {n}")
 if o.get("ranks_seen") != n: bad.append(f"ranks_seen {o.get('ranks_seen')} != {n}")
 if o["parity"]["ids_equal_float64_oracle"] is not True: bad.append("merged ids differ from the float64 oracle")

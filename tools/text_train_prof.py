@@ -1,10 +1,10 @@
-"""dev: the text head's training step alone (B=64 x 6 x 16), for rocprofv3 --kernel-trace --stats; argv: bf16 mode, fast (0/1)"""
+"""dev: the text head's training step alone (B=64 x 6 x 16), for rocprofv3 --kernel-trace --stats; argv: bf16 mode (1 | 2)"""
 import sys
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 from text2loc_amd.engine import Engine
 from text2loc_amd import synth
-mode, fast = int(sys.argv[1]), int(sys.argv[2])
+mode = int(sys.argv[1])
 eng = Engine(0)
 sd = synth.make_language_head_weights(0)
 P = "language_encoder."
@@ -16,7 +16,6 @@ for k, v in sd.items():
     tensors[k] = (t, None if "running_" in k else torch.zeros_like(t))
 eng.text_train_bind(tensors)
 eng.set_option("text_train_bf16", mode)
-eng.set_option("text_train_fast", fast)
 hidden = 0.2 * torch.randn(384, 16, 1024, device="cuda")
 g = torch.randn(64, 256, device="cuda")
 import time

@@ -9,7 +9,6 @@ def main(steps=30, B=64, streams=1, bf16=0, block=0, xcd=0):
     eng = Engine(0)
     eng.set_option("train_bf16", bf16)
     if block: eng.set_option("train_gemm_block", block)
-    eng.set_option("train_xcd_map", xcd)
     sd = synth.make_object_branch_weights(0)
     cells = synth.make_cells(B, seed=9)
     tens = {}

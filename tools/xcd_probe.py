@@ -13,9 +13,8 @@ eng.db_set(torch.from_numpy(db).cuda())
 dq = [torch.from_numpy(np.ascontiguousarray(b)).cuda() for b in batches]
 outs = [(torch.empty((Q, K), dtype=torch.int32, device="cuda"), torch.empty((Q, K), dtype=torch.float64, device="cuda")) for _ in range(12)]
 ref = None
-for gq, prep, lanes in ((1, 0, 1), (4, 0, 1), (4, 1, 1), (1, 1, 1), (4, 0, 3), (4, 1, 3), (4, 0, 1), (4, 1, 1)):
+for gq, lanes in ((1, 1), (4, 1), (2, 1), (8, 1), (4, 3), (1, 3), (4, 1)):
     eng.set_option("search_xcd_qgroups", gq)
-    eng.set_option("search_prep", prep)
     eng.set_option("search_lanes", lanes)
     for i in range(1500):
         eng.search(dq[i % 4], K, out=outs[i % 12], join=lanes == 1)
@@ -35,4 +34,4 @@ for gq, prep, lanes in ((1, 0, 1), (4, 0, 1), (4, 1, 1), (1, 1, 1), (4, 0, 3), (
     idx = eng.search(dq[0], K)[0].clone()
     if ref is None:
         ref = idx
-    print(f"xcd_qgroups={gq} prep={prep} lanes={lanes}: {dt * 1e6:.2f} us/step, scan span {span * 1e3:.2f} us, busy {busy * 1e3:.2f} us, ids equal {bool(torch.equal(idx, ref))}")
+    print(f"xcd_qgroups={gq} lanes={lanes}: {dt * 1e6:.2f} us/step, scan span {span * 1e3:.2f} us, busy {busy * 1e3:.2f} us, ids equal {bool(torch.equal(idx, ref))}")
