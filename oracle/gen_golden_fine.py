@@ -41,7 +41,7 @@ class HintTable(torch.nn.Module):
         return self.table[: len(hints)]
 
 
-def run(mode, hf_dir, pn_path):
+def run(mode, hf_dir, pn_path, n_layers=2):
     from datapreparation.kitti360pose.imports import Object3d
     from datapreparation.kitti360pose.utils import COLOR_NAMES, KNOWN_CLASS
     from models.cross_matcher import CrossMatch
@@ -49,10 +49,10 @@ def run(mode, hf_dir, pn_path):
     embed = mode == "embed"
     W_SEED, C_SEED, K, PAD, NH = 0, 21, 10, 16, 6
     args = H.make_args(hf_dir, pn_path, class_embed=embed, color_embed=embed, fine_embed_dim=128, fine_num_decoder_heads=4,
-                       fine_num_decoder_layers=2, fine_intra_module_num_layers=1, fine_intra_module_num_heads=4,
+                       fine_num_decoder_layers=n_layers, fine_intra_module_num_layers=1, fine_intra_module_num_heads=4,
                        pad_size=PAD, num_mentioned=NH)
     model = CrossMatch(KNOWN_CLASS, COLOR_NAMES, args)
-    sd = synth.make_fine_weights(W_SEED)
+    sd = synth.make_fine_weights(W_SEED, num_layers=n_layers)
     missing, unexpected = model.load_state_dict(to_torch_sd(sd), strict=False)
     assert not unexpected, unexpected
     assert all(k.startswith(("language_encoder.", "object_encoder.pointnet")) for k in missing), missing
@@ -83,10 +83,10 @@ def run(mode, hf_dir, pn_path):
         enc, _ = model.object_encoder(padded, toks)
         enc = torch.nn.functional.normalize(enc.reshape(K, PAD, 128), dim=-1)
         off = model(padded, ["h"] * K, toks)
-    out = {"weight_seed": W_SEED, "cell_seed": C_SEED, "n_cells": K, "pad_size": PAD, "n_hints": NH, "hint_encodings": hint_enc,
+    out = {"weight_seed": W_SEED, "cell_seed": C_SEED, "n_cells": K, "pad_size": PAD, "n_hints": NH, "n_layers": n_layers, "hint_encodings": hint_enc,
            "object_encodings": enc.numpy(), "offsets_out": off.numpy(), "in_pn_feat": pn_all}
     out.update({"in_" + k: v for k, v in packed.items()})
-    np.savez_compressed(osp.join(OUT, f"fine_{mode}.npz"), **out)
+    np.savez_compressed(osp.join(OUT, f"fine_{mode}.npz" if n_layers == 2 else f"fine_{mode}_l{n_layers}.npz"), **out)
     print(mode, "offsets", off.numpy()[:3].round(4).tolist(), "pad objects", int((packed["class_idx"] == 0).sum()))
 
 
@@ -97,6 +97,7 @@ def main():
     pn_path = H.make_pointnet_ckpt(osp.join(tmp, "pointnet.pth"))
     for mode in ("embed", "pn"):
         run(mode, hf_dir, pn_path)
+    run("embed", hf_dir, pn_path, n_layers=0)  # fine_num_decoder_layers == 0: the single cross_hints layer (cross_matcher.py:75-79, 119-120)
 
 
 if __name__ == "__main__":

@@ -57,9 +57,12 @@ def decoder_layer(x, mem, sd, prefix, n_heads):
 
 def cross_match(obj_enc: np.ndarray, hint_enc: np.ndarray, sd: dict, n_layers: int = 2, n_heads: int = 4) -> np.ndarray:
     """obj_enc [P,n_obj,D] (unit rows), hint_enc [P,n_hints,D] -> offsets [P,2] (cross_matcher.py:109-131, the
-    ``len(cross_hints) == len(cross_objects)`` branch the published configuration takes)."""
+    ``len(cross_hints) == len(cross_objects)`` branch the published configuration takes; ``n_layers == 0`` = the
+    ``fine_num_decoder_layers == 0`` construction, cross_matcher.py:75-79 / :119-120: one ``cross_hints`` layer, hints attend the raw objects)."""
     d0, d1 = obj_enc.astype(F32), hint_enc.astype(F32)
     sd = {k: np.asarray(v, dtype=F32) for k, v in sd.items() if np.asarray(v).dtype.kind == "f"}
+    if n_layers == 0:
+        d1 = decoder_layer(d1, d0, sd, "cross_hints", n_heads)
     for i in range(n_layers):
         d0 = decoder_layer(d0, d1, sd, f"cross_objects.{i}", n_heads)
         d1 = decoder_layer(d1, d0, sd, f"cross_hints.{i}", n_heads)

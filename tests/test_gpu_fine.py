@@ -42,6 +42,40 @@ def test_crossmatch_matches_the_reference_run(eng, golden, mode):
     assert np.abs(off.cpu().numpy() - g["offsets_out"]).max() < 5e-5
 
 
+def test_single_cross_hints_layer_matches_the_reference_run(eng, golden):
+    """fine_num_decoder_layers == 0 (cross_matcher.py:75-79, 119-120): one decoder layer under the keys "cross_hints.*", the hints attend
+    the raw object descriptors once. Engine (both arithmetics) vs the imported reference's own forward; then the drop-in module builds the
+    same state_dict layout as the reference's constructor and its forward() lands on the same offsets."""
+    import argparse
+
+    from text2loc_amd.cross_matcher import CrossMatch
+
+    g = golden("fine_embed_l0")
+    sd = synth.make_fine_weights(int(g["weight_seed"]), num_layers=0)
+    eng.fine_load_weights(sd, class_embed=True, color_embed=True, num_layers=0)
+    cells = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    desc = eng.fine_encode_objects(to_dev(cells, True))
+    assert np.abs(desc.cpu().numpy() - g["object_encodings"]).max() < 5e-6
+    off = eng.fine_match(desc, torch.from_numpy(g["hint_encodings"]).cuda())
+    torch.cuda.synchronize()
+    assert np.abs(off.cpu().numpy() - g["offsets_out"]).max() < 5e-5
+    ref2 = OF.cross_match(g["object_encodings"], g["hint_encodings"], synth.make_fine_weights(int(g["weight_seed"])), n_layers=2)
+    assert np.abs(off.cpu().numpy() - ref2[: len(off)]).max() > 1e-2  # (not the two-layer model by another name)
+    args = argparse.Namespace(fine_embed_dim=128, fine_num_decoder_heads=4, fine_num_decoder_layers=0, pad_size=16, num_mentioned=6,
+                              fine_intra_module_num_layers=1, fine_intra_module_num_heads=4, hungging_model=None, fixed_embedding=True,
+                              class_embed=True, color_embed=True, pointnet_freeze=True, use_features=["class", "color", "position", "num"])
+    model = CrossMatch(synth.KNOWN_CLASS, synth.COLOR_NAMES, args, language_encoder=torch.nn.Identity())
+    assert model.cross_objects is None and "cross_hints.self_attn.in_proj_weight" in model.state_dict()
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    assert not unexpected and not [k for k in missing if not k.startswith("language_encoder.")], (missing, unexpected)
+    model = model.to("cuda").eval()
+    model.engine().set_option("encoder_f32", eng.all_f32)
+    off_m = model.match(desc, torch.from_numpy(g["hint_encodings"]).cuda(), np.arange(len(off), dtype=np.int32), np.arange(len(off), dtype=np.int32))
+    assert np.abs(off_m.cpu().numpy() - g["offsets_out"]).max() < 5e-5
+    with pytest.raises(Exception, match="0..4 decoder layers"):
+        eng.fine_load_weights(sd, class_embed=True, color_embed=True, num_layers=5)
+
+
 def test_norm_guard_sends_large_rows_to_the_f32_kernel(eng):
     """Hint rows far above the guard (2-norm 64) in SOME pairs: those workgroups are served by the f32 launch that follows the
     split-f16 one, the others are not touched twice; every pair still matches the oracle."""

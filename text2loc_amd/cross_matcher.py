@@ -72,9 +72,9 @@ class CrossMatch(nn.Module):
             raise T2LError(f"the engine's fine stage is built for fine_embed_dim={FINE_DIM}, got {self.embed_dim}")
         if getattr(args, "pad_size", PAD_SIZE) != PAD_SIZE:
             raise T2LError(f"the engine's fine stage is built for pad_size={PAD_SIZE}")
-        n_layers = args.fine_num_decoder_layers
-        if n_layers < 1:
-            raise T2LError("fine_num_decoder_layers == 0 (single cross_hints layer) is not built")
+        n_layers = int(args.fine_num_decoder_layers)
+        if not 0 <= n_layers <= 4:
+            raise T2LError(f"the engine's fine stage holds 0..4 decoder layers, got fine_num_decoder_layers={n_layers}")
         self.object_encoder = ObjectEncoderParams(FINE_DIM, known_classes, args, known_colors)
         self.language_encoder = language_encoder if language_encoder is not None else LanguageEncoder(
             FINE_DIM, hungging_model=args.hungging_model, fixed_embedding=args.fixed_embedding,
@@ -82,8 +82,12 @@ class CrossMatch(nn.Module):
             is_fine=True)
         self.mlp_offsets = get_mlp_offset([FINE_DIM, FINE_DIM // 2, 2])
         mk = lambda: nn.TransformerDecoderLayer(d_model=FINE_DIM, nhead=args.fine_num_decoder_heads, dim_feedforward=4 * FINE_DIM)
-        self.cross_hints = nn.ModuleList([mk() for _ in range(n_layers)])
-        self.cross_objects = nn.ModuleList([mk() for _ in range(n_layers)])
+        if n_layers > 0:
+            self.cross_hints = nn.ModuleList([mk() for _ in range(n_layers)])
+            self.cross_objects = nn.ModuleList([mk() for _ in range(n_layers)])
+        else:  # cross_matcher.py:75-79: ONE layer (state_dict keys "cross_hints.*", no index), the hints attend the raw objects once
+            self.cross_hints = mk()
+            self.cross_objects = None
         self._engine: Optional[Engine] = None
         self._weights_version = None
 

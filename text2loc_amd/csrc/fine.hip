@@ -125,8 +125,8 @@ static int fraw(t2l_ctx* ctx, FineWeights* W, const WMap& m, const std::string& 
 
 int fine_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_model_config* cfg) {
   if (!w || n <= 0 || !cfg) return fail(ctx, T2L_EINVAL, "t2l_fine_load_weights: null argument");
-  if (cfg->num_heads != kFHeads || cfg->num_layers < 1 || cfg->num_layers > 4)
-    return fail(ctx, T2L_EINVAL, "t2l_fine_load_weights: built for 4 decoder heads and 1..4 decoder layers");
+  if (cfg->num_heads != kFHeads || cfg->num_layers < 0 || cfg->num_layers > 4)
+    return fail(ctx, T2L_EINVAL, "t2l_fine_load_weights: built for 4 decoder heads and 0..4 decoder layers (0 = the single cross_hints layer)");
   free_fine(ctx);
   FineWeights* W = new FineWeights();
   ctx->fine = W;
@@ -160,9 +160,11 @@ int fine_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_mode
   if (P.use_num && ((rc = flinear(ctx, W, m, oe + "num_encoder.0.0", oe + "num_encoder.0.1", 1, 64, &P.num1)) ||
                     (rc = flinear(ctx, W, m, oe + "num_encoder.1.0", oe + "num_encoder.1.1", 64, kFD, &P.num2)))) return rc;
   if ((rc = flinear(ctx, W, m, oe + "mlp_merge.0.0", oe + "mlp_merge.0.1", P.n_feat * kFD, kFD, &P.merge))) return rc;
-  for (int l = 0; l < P.n_layers; ++l)
-    for (int which = 0; which < 2; ++which) {
-      const std::string p = std::string(which ? "cross_hints." : "cross_objects.") + std::to_string(l);
+  // fine_num_decoder_layers == 0 (cross_matcher.py:75-79, 119-120): ONE decoder layer, keys "cross_hints.*" without an index, no
+  // cross_objects — the hints attend the raw object descriptors once. Loaded as hint[0]; the kernel branches on n_layers == 0.
+  for (int l = 0; l < std::max(1, P.n_layers); ++l)
+    for (int which = (P.n_layers == 0 ? 1 : 0); which < 2; ++which) {
+      const std::string p = P.n_layers == 0 ? std::string("cross_hints") : std::string(which ? "cross_hints." : "cross_objects.") + std::to_string(l);
       FDecoder& D = which ? P.hint[l] : P.obj[l];
       if ((rc = fpacked(ctx, W, m, p + ".self_attn.in_proj_weight", p + ".self_attn.in_proj_bias", kFD, 3 * kFD, &D.sa_in)) ||
           (rc = fpacked(ctx, W, m, p + ".self_attn.out_proj.weight", p + ".self_attn.out_proj.bias", kFD, kFD, &D.sa_out)) ||
@@ -205,6 +207,7 @@ int fine_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_mode
       n_obj = dec("cross_objects." + std::to_string(l), n_obj, n_hint);
       n_hint = dec("cross_hints." + std::to_string(l), n_hint, n_obj);
     }
+    if (P.n_layers == 0) n_hint = dec("cross_hints", n_hint, n_obj);
     P.split_ok = (wmax < kSplitF16Safe && amax < kSplitF16Safe) ? 1 : 0;
   }
   return T2L_OK;
@@ -562,6 +565,7 @@ __global__ __launch_bounds__(256, 3) void fine_match_kernel(FineParams P, const 
     f_decoder<H>(d0, gobj, d1, ghint, P.obj[l], buf);
     f_decoder<H>(d1, ghint, d0, gobj, P.hint[l], buf);
   }
+  if (P.n_layers == 0) f_decoder<H>(d1, ghint, d0, gobj, P.hint[0], buf);  // cross_matcher.py:119-120
   {  // desc1.max(dim=0) over the hints, then mlp_offsets (cross_matcher.py:128-131)
     const int p = tid >> 7, c = tid & 127;
     float m = d1[(8 * p) * kFS + c];

@@ -142,6 +142,8 @@ def make_fine_weights(seed: int = 0, embed_dim: int = 128, num_layers: int = 2) 
     for i in range(num_layers):
         _decoder_layer(rng, embed_dim, 4 * embed_dim, f"cross_hints.{i}", sd)
         _decoder_layer(rng, embed_dim, 4 * embed_dim, f"cross_objects.{i}", sd)
+    if num_layers == 0:  # fine_num_decoder_layers == 0: ONE cross_hints layer, no index in its keys, no cross_objects (cross_matcher.py:75-79)
+        _decoder_layer(rng, embed_dim, 4 * embed_dim, "cross_hints", sd)
     _linear(rng, embed_dim // 2, embed_dim, "mlp_offsets.0", sd)
     _linear(rng, 2, embed_dim // 2, "mlp_offsets.2", sd)
     return sd
