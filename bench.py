@@ -541,7 +541,7 @@ def secondary_measurements(eng):
         lat[f"q{qn}_us_per_call_synchronized"] = (time.perf_counter() - t0) / (20 if _QUICK else 200) * 1e6  # host-visible round trip of one call
     # the same single-query searches issued from C (t2l_search_many: 1,000 independent searches per call): what a search costs the
     # DEVICE back to back, without the ~14 us a Python ctypes call costs the host
-    for qn in (1, 64):
+    for qn in (1, 4, 16, 64):
         nb = 50 if _QUICK else 1000
         dqm = torch.from_numpy(np.ascontiguousarray(np.tile(_QS[:qn][None], (nb, 1, 1)))).cuda()
         om = (torch.empty((nb, qn, TOPK), dtype=torch.int32, device="cuda"), torch.empty((nb, qn, TOPK), dtype=torch.float64, device="cuda"))
@@ -556,7 +556,35 @@ def secondary_measurements(eng):
         lat[f"q{qn}_us_per_call_issued_from_c"] = (time.perf_counter() - t0) / (reps * nb) * 1e6
         one_i, _ = eng.search(dqm[0].contiguous(), TOPK)
         lat[f"q{qn}_search_many_equals_search"] = bool(torch.equal(om[0][nb - 1], one_i))
+        if qn <= 16:  # A/B, same box: the batched two-launch path these batches took until round 5 (option search_small = 0)
+            ids_small = om[0][nb - 1].clone()
+            eng.set_option("search_small", 0)
+            for _ in range(2):
+                eng.search_many(dqm, TOPK, out=om)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                eng.search_many(dqm, TOPK, out=om)
+            torch.cuda.synchronize()
+            lat[f"q{qn}_us_per_call_issued_from_c_two_launch_path"] = (time.perf_counter() - t0) / (reps * nb) * 1e6
+            lat[f"q{qn}_ids_equal_two_launch_path"] = bool(torch.equal(om[0][nb - 1], ids_small))
+            eng.set_option("search_small", 1)
     eng.set_option("profile_events", 1)
+    try:  # the one-launch kernel by itself (HIP events) and what that is against SURVEY 8d's per-query bound: 4 N D bytes per group of <= 4 queries
+        dq1 = torch.from_numpy(np.ascontiguousarray(_QS[:1])).cuda()
+        eng.kernel_stats("search_small")
+        for _ in range(50):
+            eng.search(dq1, TOPK)
+        torch.cuda.synchronize()
+        k_ms, k_n = eng.kernel_stats("search_small")
+        if k_n:
+            lat["q1_kernel_us"] = k_ms * 1e3
+            lat["q1_algorithmic_bytes"] = 4.0 * N_CELLS * DIM
+            lat["q1_kernel_GBps"] = 4.0 * N_CELLS * DIM / (k_ms * 1e-3) / 1e9
+            lat["q1_frac_of_8TBps"] = lat["q1_kernel_GBps"] / 8000.0
+            lat["q1_from_c_GBps"] = 4.0 * N_CELLS * DIM / (lat["q1_us_per_call_issued_from_c"] * 1e-6) / 1e9
+    except Exception as e:
+        lat["q1_kernel_error"] = repr(e)
     out["search_latency"] = lat
     # HBM-streaming regime (SURVEY.md §8d config 2'): 32 queries against N = 2,097,152 rows (1 GiB of f16 DB plane,
     # 4x the Infinity Cache): algorithmic bytes = that plane once per launch (512 B per row)

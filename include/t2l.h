@@ -435,6 +435,12 @@ int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step,
  * "search_heavy"      (set by the engine, see search_auto): 1 = queries no certificate settles go to the float64 MFMA exact
  *     stage instead of the fallback kernel's float64 VALU scan. With search_auto = 0 the caller may force it.
  * "train_keep_adam_state" (default 0): see t2l_adam_state.
+ * "search_small"      (default 1): batches of <= 16 queries against a shard of < stream_min_rows (and <= 65,536) rows, search_mode 0:
+ *     the whole search as ONE launch, exact float64 from the start (search_small.hip) — every workgroup scores its rows with the
+ *     re-rank's arithmetic, ranks them and publishes its best K write-through; the last workgroup to arrive merges the lists. Ids and
+ *     float64 scores are bit-identical to the batched path's. 10.8 us per single-query call issued from C at N = 11,259 against
+ *     21.2 us on the batched two-launch path (0: that path, kept for the A/B line of bench.py and for Q > 16).
+ * "search_small_wgs"  (default 0 = by query count, 128 or 192): its workgroups (published lists) per slice of 4 queries, <= 256.
  * "stream_min_rows"   (default 65536): batches of <= 64 queries against a shard of at least this many rows use the
  *     HBM-streaming scan (every CU streams a disjoint DB slice once) instead of the batched scan.
  * "search_nsplit"     (default 0 = auto): DB row splits per query block in the scan kernel.
@@ -471,7 +477,7 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value);
  * (no synchronisation while recording; enabled by option "profile_events" >= 1, off by default).
  * Returns the average duration (ms) and the number of launches recorded since the previous call for
  * name = "search_scan" | "search_rerank" | "encode_cells" | "contrastive_loss" | "reduce_objects" | "train_forward" |
- * "train_backward" | "adam_step" | "pointnet" | "fine_objects" | "fine_match" | "search_fallback" | "search_exact" (at most
+ * "train_backward" | "adam_step" | "pointnet" | "fine_objects" | "fine_match" | "search_fallback" | "search_exact" | "search_small" (at most
  * the last 512), "pointnet_train_index" | "pointnet_train_forward" | "pointnet_train_backward";
  * "search_scan_span" and "search_scan_busy" need no option: every workgroup of the paired scan stamps its own start and end
  * (100 MHz clock, the last 64 launches) — span = first workgroup start -> last workgroup end, busy = mean workgroup

@@ -368,6 +368,68 @@ def test_streaming_small_batch_path_vs_oracle(n, q, k):
         e.close()
 
 
+@pytest.mark.parametrize("n,q,k", [(1, 1, 1), (5, 3, 10), (31, 1, 26), (257, 4, 10), (700, 5, 10), (4097, 16, 26), (11259, 1, 10), (11259, 2, 10),
+                                   (11259, 13, 5), (65535, 1, 10), (60001, 7, 3)])
+def test_one_launch_exact_search_for_a_handful_of_queries(n, q, k):
+    """Q <= 16 against <= 65,536 rows (search_small.hip): ONE launch, float64 scores of every row, per-workgroup top-k published
+    write-through, merged by the last workgroup to arrive. Ids equal the oracle's float64 ranking, scores to 1e-12 — and they are
+    BIT-identical to what the batched two-launch path (option search_small = 0) reports for the same rows; exact ties go to the
+    lower row; a shard offset is applied; K > N leaves -1 / -inf; repeated calls with other query counts reuse the ticket counters."""
+    import torch
+    from oracle import c_oracle
+    from text2loc_amd.engine import Engine
+
+    e = Engine(0)
+    try:
+        e.set_option("profile_events", 1)
+        db, qs, _ = synth.make_retrieval_problem(n, q, seed=900 + n + q, noise=1.5)
+        e.db_set(torch.from_numpy(db).cuda(), 11)
+        dq = torch.from_numpy(qs).cuda()
+        e.kernel_stats("search_small")
+        idx, sc = e.search(dq, k)
+        torch.cuda.synchronize()
+        assert e.kernel_stats("search_small")[1] == 1 and e.search_fallbacks() == 0
+        ridx, rsc = c_oracle.retrieve_topk(db, qs, k)
+        kk = ridx.shape[1]
+        got_i, got_s = idx.cpu().numpy().astype(np.int64), sc.cpu().numpy()
+        assert np.array_equal(got_i[:, :kk], ridx + 11)
+        assert np.abs(got_s[:, :kk] - rsc).max() <= 1e-12 * max(1.0, float(np.abs(rsc).max()))
+        if kk < k:
+            assert (got_i[:, kk:] == -1).all() and np.isneginf(got_s[:, kk:]).all()
+        # the batched path on the same call: same ids, the SAME float64 bits
+        e.set_option("search_small", 0)
+        idx0, sc0 = e.search(dq, k)
+        torch.cuda.synchronize()
+        assert e.kernel_stats("search_small")[1] == 0
+        e.set_option("search_small", 1)
+        assert torch.equal(idx0, idx) and torch.equal(sc0, sc)
+        # other query counts right behind it (1, then 16, then 3: the slices' ticket bases diverge and are levelled again), every result checked
+        for q2 in (1, 16, 3, 16):
+            qs2 = synth.make_queries_for(db, q2, seed=q2 + n, noise=1.0)[0] if n > 1 else qs[:1].repeat(q2, axis=0)
+            i2, s2 = e.search(torch.from_numpy(np.ascontiguousarray(qs2)).cuda(), min(k, 10))
+            r2, _ = c_oracle.retrieve_topk(db, qs2, min(k, 10))
+            assert np.array_equal(i2.cpu().numpy().astype(np.int64)[:, : r2.shape[1]], r2 + 11), (n, q2)
+        # fewer workgroups per slice (option): same result
+        e.set_option("search_small_wgs", 8)
+        i3, s3 = e.search(dq, k)
+        e.set_option("search_small_wgs", 0)
+        assert torch.equal(i3, idx) and torch.equal(s3, sc)
+        # exact ties: every row twice (some three times) -> lower row first
+        m = min(n, 300)
+        db2 = np.concatenate([db[:m], db[:m], db[: m // 3]], axis=0)
+        e.db_set(torch.from_numpy(db2).cuda(), 0)
+        i4, s4 = e.search(dq, min(k, 10))
+        r4, rs4 = c_oracle.retrieve_topk(db2, qs, min(k, 10))
+        assert np.array_equal(i4.cpu().numpy().astype(np.int64)[:, : r4.shape[1]], r4)
+        # a zero query: all scores 0 (also -0.0 x row products): (score desc, row asc) = rows 0, 1, 2, ...
+        z = np.zeros((1, 256), dtype=np.float32)
+        i5, s5 = e.search(torch.from_numpy(z).cuda(), min(k, 10))
+        kk5 = min(min(k, 10), len(db2))
+        assert np.array_equal(i5.cpu().numpy()[0, :kk5], np.arange(kk5)) and (s5.cpu().numpy()[0, :kk5] == 0).all()
+    finally:
+        e.close()
+
+
 def _clustered_problem(n, q, spread, seed):
     """rows = one direction + `spread`-sized perturbations (score gaps far below every scan's error band), queries = rows +
     a quarter of that spread"""

@@ -107,7 +107,7 @@ void t2l_destroy(t2l_ctx* ctx) {
   free_fine(ctx);
   free_text_head(ctx);
   for (void* p : {(void*)ctx->db, (void*)ctx->db_split, (void*)ctx->db_half, (void*)ctx->db_norm_max, (void*)ctx->cand_score, (void*)ctx->seg_idx,
-                  (void*)ctx->seg_score, (void*)ctx->flags, (void*)(ctx->fb_count < ctx->fb_prev ? ctx->fb_count : ctx->fb_prev), ctx->fast_ws, (void*)ctx->fast_zero, ctx->reduce_ws, ctx->loss_ws, (void*)ctx->scan_span})
+                  (void*)ctx->seg_score, (void*)ctx->flags, (void*)(ctx->fb_count < ctx->fb_prev ? ctx->fb_count : ctx->fb_prev), ctx->fast_ws, (void*)ctx->fast_zero, ctx->reduce_ws, ctx->loss_ws, (void*)ctx->small_ticket, ctx->small_part, (void*)ctx->scan_span})
     if (p) (void)hipFree(p);
   delete[] ctx->span_grid;
   if (ctx->host_stat) (void)hipHostFree(ctx->host_stat);
@@ -545,6 +545,11 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     }
   } else if (!strcmp(name, "search_heavy")) {  // force (1) / release (0) the float64 MFMA exact stage (tests)
     ctx->heavy = value != 0;
+  } else if (!strcmp(name, "search_small")) {
+    ctx->search_small = value != 0;
+  } else if (!strcmp(name, "search_small_wgs")) {
+    if (value < 0 || value > 256) return fail(ctx, T2L_EINVAL, "search_small_wgs: 0 (default: 256) .. 256 workgroups per slice");
+    ctx->search_small_wgs = (int)value;
   } else if (!strcmp(name, "search_xcd_qgroups")) {
     if (value != 1 && value != 2 && value != 4 && value != 8) return fail(ctx, T2L_EINVAL, "search_xcd_qgroups must be 1, 2, 4 or 8");
     ctx->xcd_qgroups = (int)value;

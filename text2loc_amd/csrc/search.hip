@@ -1919,6 +1919,8 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
   // few queries against a large shard: stream the DB once through every CU (search_stream.hip)
   if (Q <= 64 && n_rows >= ctx->stream_min_rows && n_rows > 0 && ctx->search_mode == 0 && ctx->nsplit_override == 0)
     return search_stream_impl(ctx, q, Q, K, out_idx, out_score, s);
+  // a handful of queries against a shard that fits the caches: ONE launch, exact float64 from the start (search_small.hip)
+  if (search_small_applies(ctx, Q, K)) return search_small_impl(ctx, q, Q, K, out_idx, out_score, s);
   // the f16 scan's report card of an earlier call on this DB (see t2l_internal.h): more than 1 in 8 queries flagged ->
   // the split-bf16 scan from now on
   // ... and back when fewer than 1 in 16 would be (the stand-in counts them, rerank_kernel)

@@ -107,9 +107,14 @@ struct t2l_ctx {
   int encoder_f16 = 0;   // 1: plain-f16 products (one MFMA per operand pair) instead of split-f16: ~1e-4 instead of 2e-7, 28 % faster
   int search_auto = 1;
   int pair_ll = 6;       // per-lane list length of the paired scan (5 or 6)
+  int search_small = 1;      // batches of <= 16 queries against <= 65,536 rows: the one-launch exact float64 search (search_small.hip)
+  int search_small_wgs = 0;  // ... its workgroups per 4-query slice (0 = 256: one per CU)
+  unsigned* small_ticket = nullptr;       // dev u32[4]: arrival tickets per slice, running totals
+  unsigned small_ticket_base[4] = {0, 0, 0, 0};
+  void* small_part = nullptr;             // published per-workgroup top-K lists {f64 score | i32 row}
+  size_t small_part_cap = 0;
   int wide_repair = 512;  // rows a re-rank wave may re-score in a wide repair before the query goes to an exact scan (0: never)
   int encoder_two_cells = 1;  // encode_cells: two cells per eight-wave workgroup on LDS planes (encode.hip: encode_cells2_kernel); 0: first form
-                             // tile per 4-wave workgroup on f32 tiles, 0 = the nine-launch tiled-GEMM chain of text_head.hip
   int search_merge = 2;    // the paired scan merges a workgroup's four lists per query into one 32-byte record (search.hip: MERGE / MG):
                            // 0 never, 1 always, 2 while the f16 report cards show next to no failed first certificates (a repair behind
                            // a merged record re-scores 4x the rows of a plain list's)
@@ -178,6 +183,9 @@ int db_norm_impl(t2l_ctx* ctx, hipStream_t s);
 int merge_impl(t2l_ctx* ctx, const int32_t* idx, const double* score, int parts, int Q, int K, int32_t* out_idx,
                double* out_score, hipStream_t s);
 int search_stream_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s);
+// search_small.hip
+bool search_small_applies(const t2l_ctx* ctx, int Q, int K);
+int search_small_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, double* out_score, hipStream_t s);
 // search_exact.hip
 int exact_stage_impl(t2l_ctx* ctx, const float* db, int n_rows, int row_offset, const float* q, int Q, int K, int32_t* out_idx,
                      double* out_score, hipStream_t s);
