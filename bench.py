@@ -10,7 +10,7 @@ work fixed).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the fused MFMA
 candidate scan; algorithmic FLOPs = 2*Q*N*D per launch / its hipEvent-measured duration vs the dense MFMA peak of the
-dtype the scan multiplies in: 2.5 PF for the default f16 scan and for --mode 2 = split-bf16, 157.3 TF for --mode 1 = f32)
+dtype the scan multiplies in: 2.5 PF for the default f16 scan and for --mode 2 = split-bf16)
 and `cpu_baseline` (the numpy oracle of training/coarse.py:119-125 timed on this host).
 """
 import argparse
@@ -1157,8 +1157,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the encoder / loss side measurements")
     ap.add_argument("--cells", type=int, default=N_CELLS, help="dev: database rows (default = the BASELINE workload)")
     ap.add_argument("--queries", type=int, default=N_QUERIES, help="dev: queries per step")
-    ap.add_argument("--mode", type=int, default=0,
-                    help="search_mode: 0 = f16 scan (default), 1 = f32 scan, 2 = split-bf16 scan")
+    ap.add_argument("--mode", type=int, default=0, choices=[0, 2], help="search_mode: 0 = f16 scan (default), 2 = split-bf16 scan")
     ap.add_argument("--nsplit", type=int, default=0, help="override the scan kernel's DB split count (0 = auto)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the pipelined side measurement (profiling runs: its "
                     "overlapping launches would enter the per-kernel averages)")
@@ -1473,9 +1472,7 @@ def main():
         ms = 1e3 * elapsed / args.steps
         n_local = hi - lo
         flops = 2.0 * N_QUERIES * n_local * DIM  # algorithmic FLOPs of one scan launch on this rank's shard
-        if args.mode == 1:
-            kname, peak, dtype, mult = "scan_kernel<16>", F32_MFMA_PEAK_TFLOPS, "f32", 1
-        elif args.mode == 2:
+        if args.mode == 2:
             kname, peak, dtype, mult = "scanw_kernel<8, 4>", BF16_MFMA_PEAK_TFLOPS, "bf16x3", 3
         else:
             kname, peak, dtype, mult = "scanp_kernel<6, 4, false, false, true>", BF16_MFMA_PEAK_TFLOPS, "f16", 1  # (the merged-record form: the default on benign data)
@@ -1494,7 +1491,6 @@ def main():
                                    "precomputed text embeddings per step, top-10 (float64-exact ids)",
                        "n_cells": N_CELLS, "queries_per_step": N_QUERIES, "embed_dim": DIM, "top_k": TOPK,
                        "arithmetic": {0: "f16 MFMA candidate scan (power-of-two scaled operands, f32 accumulate)",
-                                      1: "f32 MFMA candidate scan",
                                       2: "split-bf16 (3 MFMAs per product) candidate scan (f32 accumulate)"}[args.mode]
                                      + " -> float64 re-rank + certificate (ids and scores are the float64 ranking)",
                        "parallelism": f"db-row-shard x{world}" if world > 1 else "single-gpu",

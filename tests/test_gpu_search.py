@@ -8,9 +8,11 @@ from text2loc_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1, 2], ids=["f16", "f32", "bf16x3"])
+@pytest.fixture(scope="module", params=[0, 2], ids=["f16", "bf16x3"])
 def eng(request):
-    """All scan kernels feed the same float64 re-rank + certificate: every test runs against each."""
+    """Both scan arithmetics (the f16 scan and the split-bf16 scan the auto mode escalates to) feed the same float64 re-rank +
+    certificate: every test runs against each. (A third, exact-f32 scan existed until round 5: 7x slower, same results by
+    construction; removed.)"""
     import torch
     from text2loc_amd.engine import Engine
 
@@ -114,7 +116,7 @@ def test_scale_invariance(eng, db_scale, q_scale):
     assert np.abs(sc - rsc).max() <= 1e-12 * max(1.0, float(np.abs(rsc).max()))
     if eng.scan_mode == 0 or max(abs(np.log10(db_scale)), abs(np.log10(q_scale))) < 11:
         assert eng.search_fallbacks() == 0  # representable: nobody needed the exact scan
-    else:  # the f32 / split-bf16 scans multiply the raw values and hand magnitudes beyond 2^+-40 to the exact scan
+    else:  # the split-bf16 scan multiplies the raw values and hand magnitudes beyond 2^+-40 to the exact scan
         assert eng.search_fallbacks() == len(qs)
 
 

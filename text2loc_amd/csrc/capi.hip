@@ -524,8 +524,8 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
     if (value < 0 || value > kMaxParts / 2) return fail(ctx, T2L_EINVAL, "search_nsplit out of range [0,32]");
     ctx->nsplit_override = (int)value;
   } else if (!strcmp(name, "search_mode")) {
-    if (value != 0 && value != 1 && value != 2)
-      return fail(ctx, T2L_EINVAL, "search_mode must be 0 (f16 scan), 1 (f32 scan) or 2 (split-bf16 scan)");
+    if (value != 0 && value != 2)
+      return fail(ctx, T2L_EINVAL, "search_mode must be 0 (f16 scan) or 2 (split-bf16 scan); 1 (the exact-f32 MFMA scan: 7x slower, same results) was removed in round 5");
     ctx->search_mode = (int)value;
   } else if (!strcmp(name, "encoder_f32")) {
     ctx->encoder_f32 = value != 0;

@@ -279,7 +279,7 @@ __device__ void f_normalize_rows(float* x, int ld, int T, int width = kFD) {
     for (int c = lane; c < width; c += 64) x[t * ld + c] /= n;
   }
 }
-constexpr int kPairs = 2;  // pairs per workgroup: their 2 x 16 object tokens fill one 32-row MFMA tile
+constexpr int kPairs = 4;  // pairs per workgroup: their 4 x 16 object tokens fill TWO 32-row MFMA tiles, their 4 x 8 hint slots ONE
 
 // x[t] = LayerNorm(x[t]) * g + b for t < T (in place; one wave per row)
 __device__ void f_ln_rows(float* x, int ld, int T, const float* __restrict__ g, const float* __restrict__ b) {
@@ -294,9 +294,10 @@ __device__ void f_ln_rows(float* x, int ld, int T, const float* __restrict__ g, 
   }
 }
 
-// Which rows of a 32-row token tile belong together: pair p owns rows (p << shift) .. + count - 1 of the first `rows` rows.
+// Which rows of a 32-row token tile belong together: the tile's g-th group (rows (g << shift) .. + count - 1 of the first `rows`
+// rows) belongs to pair base + g of the workgroup.
 struct TileGroups {
-  int shift, count, rows;
+  int shift, count, rows, base;
 };
 
 // One attention block of nn.TransformerDecoderLayer for the kPairs pairs of the tile, head h = wave, REGISTERS ONLY:
@@ -304,7 +305,9 @@ struct TileGroups {
 // v_h straight (A = mem token rows, B = packed rows); in those MFMA output layouts k_h^T / q_h^T are the A / B operands of
 // S^T = K Q^T and v_h is the B operand of P V (the trick of encode.hip). Keys of another pair (or padding rows) are masked.
 // Writes o_h (32 rows x 32 columns) into obuf[:, 32 h ..]. x == mem for self-attention.
-template <int H>
+// ACC: the output is ADDED to obuf (a query tile whose groups find their keys in different mem tiles attends each mem tile in turn;
+// a query row sees keys in exactly one of them and contributes zeros to the other pass).
+template <int H, bool ACC = false>
 __device__ __forceinline__ void f_attention_regs(const float* __restrict__ x, TileGroups gx, const float* __restrict__ mem, TileGroups gm,
                                                  const FPacked in_proj, float* __restrict__ obuf) {
   const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
@@ -362,7 +365,7 @@ __device__ __forceinline__ void f_attention_regs(const float* __restrict__ x, Ti
 #pragma unroll
   for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kT[r], qT[r], st, 0, 0, 0);
   // lane: query i = col, keys j = (r&3) + 8*(r>>2) + 4*half
-  const int gi = col >> gx.shift;
+  const int gi = gx.base + (col >> gx.shift) - gm.base;  // the mem tile's group that holds this query's pair (may be out of the tile)
   float m = -__builtin_inff();
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -387,7 +390,10 @@ __device__ __forceinline__ void f_attention_regs(const float* __restrict__ x, Ti
 #pragma unroll
   for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(st[r] * inv, v[r], o, 0, 0, 0);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) obuf[((r & 3) + 8 * (r >> 2) + 4 * half) * kFS + h * kFHd + col] = o[r];
+  for (int r = 0; r < 16; ++r) {
+    float* dst = obuf + ((r & 3) + 8 * (r >> 2) + 4 * half) * kFS + h * kFHd + col;
+    if constexpr (ACC) *dst += o[r]; else *dst = o[r];
+  }
 }
 
 // x += A @ W^T + b for a 128 -> 128 Linear (out_proj): one 32-column tile per wave
@@ -406,8 +412,10 @@ __device__ __forceinline__ void f_proj_add(const float* __restrict__ A, const FP
 
 // nn.TransformerDecoderLayer (post-norm, ReLU, eval, no masks) for the kPairs pairs of a workgroup. x / mem: 32-row token
 // tiles (LDS, stride kFS); buf: one more 32 x 128 tile (attention output, then the feed-forward hidden in four quarters).
+// mem2 != nullptr: the memory is TWO tiles (the hint tile of four pairs attends the pairs' two object tiles).
 template <int H>
-__device__ void f_decoder(float* x, TileGroups gx, const float* mem, TileGroups gm, const FDecoder D, float* buf) {
+__device__ void f_decoder(float* x, TileGroups gx, const float* mem, TileGroups gm, const FDecoder D, float* buf,
+                          const float* mem2 = nullptr, TileGroups gm2 = TileGroups{0, 0, 0, 0}) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
   f_attention_regs<H>(x, gx, x, gx, D.sa_in, buf);
   __syncthreads();
@@ -416,6 +424,7 @@ __device__ void f_decoder(float* x, TileGroups gx, const float* mem, TileGroups 
   f_ln_rows(x, kFS, gx.rows, D.g1, D.b1);
   __syncthreads();
   f_attention_regs<H>(x, gx, mem, gm, D.ca_in, buf);
+  if (mem2) f_attention_regs<H, true>(x, gx, mem2, gm2, D.ca_in, buf);  // (same wave, same obuf columns: ordered without a barrier)
   __syncthreads();
   f_proj_add<H>(buf, D.ca_out, x);
   __syncthreads();
@@ -450,6 +459,252 @@ __device__ void f_decoder(float* x, TileGroups gx, const float* mem, TileGroups 
   }
   __syncthreads();
   f_ln_rows(x, kFS, gx.rows, D.g3, D.b3);
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same decoder layer on split-f16 PLANES (round 5; the recipe of encode.hip's second form). In the f32-tile form above every
+// product splits its activation operand into hi + lo f16 on the fly — 20 VALU per 3 MFMAs, repeated by each of the four waves
+// (they multiply the same token rows into different output columns) and again for every use of the same rows (q, k, v, four
+// feed-forward quarters): ~2,200 of the ~2,800 VALU instructions a wave issued per tile pass were operand conversions (PMC, round 4:
+// 11.4 VALU per MFMA, MFMA pipe busy 0.19 by instruction count). Here every token tile lives in LDS as two f16 planes (hi | lo,
+// rows of 136 halves = 272 B: the 32 lanes of a fragment read are conflict-free 16-byte reads) and
+//  * a product's activation operand is two ds_read_b128, no conversion;
+//  * every product is computed TRANSPOSED (A = weight fragment, B = token fragment: D[feature][token]), so a lane ends up with 16
+//    features of ONE token, 4 consecutive ones per register quad: the epilogue splits each produced value ONCE and stores 8-byte
+//    plane pieces; the attention's P V product likewise as O^T = V^T P^T (the same registers with the operands swapped);
+//  * the residual stream is rebuilt from hi + lo (22 significand bits; the offsets stay within 5e-5 of the reference's).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kLdF = kFD + 8;                    // halves per plane row
+constexpr int kPlaneHalves = 32 * kLdF;          // one plane of a 32-row tile
+constexpr int kTileBytes = 2 * kPlaneHalves * 2; // hi + lo: 17,408 B (the f32 tile of the other form: 16,896 B)
+typedef _Float16 ff_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 ff_f16x2 __attribute__((ext_vector_type(2)));
+typedef float ff_f32x4 __attribute__((ext_vector_type(4)));
+typedef float ff_f32x2 __attribute__((ext_vector_type(2)));
+struct FP {
+  _Float16* hi;
+  _Float16* lo;
+};
+__device__ __forceinline__ FP fp_at(void* base) {
+  FP t;
+  t.hi = reinterpret_cast<_Float16*>(base);
+  t.lo = t.hi + kPlaneHalves;
+  return t;
+}
+template <bool SG>
+__device__ __forceinline__ HFrag fp_frag(const FP t, int off) {
+  HFrag f;
+  f.hi = *reinterpret_cast<const h3_f16x8*>(t.hi + off);
+  if constexpr (SG) f.lo = f.hi;
+  else f.lo = *reinterpret_cast<const h3_f16x8*>(t.lo + off);
+  return f;
+}
+__device__ __forceinline__ void fp_put4(const FP t, int off, ff_f32x4 v) {
+  const ff_f16x4 h = __builtin_convertvector(v, ff_f16x4);
+  *reinterpret_cast<ff_f16x4*>(t.hi + off) = h;
+  *reinterpret_cast<ff_f16x4*>(t.lo + off) = __builtin_convertvector(v - __builtin_convertvector(h, ff_f32x4), ff_f16x4);
+}
+__device__ __forceinline__ ff_f32x4 fp_get4(const FP t, int off) {
+  return __builtin_convertvector(*reinterpret_cast<const ff_f16x4*>(t.hi + off), ff_f32x4) +
+         __builtin_convertvector(*reinterpret_cast<const ff_f16x4*>(t.lo + off), ff_f32x4);
+}
+// acc (D[feature][token]) += W tile (STEPS k-steps of packed fragments at wp) x tokens (plane rows, this lane's half row at aoff)
+template <int STEPS, bool SG>
+__device__ __forceinline__ void fp_dot(const FP a, int aoff, const uint4* __restrict__ wp, f32x16& acc) {
+  constexpr int D = STEPS < kDotRing ? STEPS : kDotRing;
+  HFrag ring[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) ring[i] = load_h1<SG>(wp + T2L_HOT(i) * 128);
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    const HFrag wf = ring[st % D];
+    if (st + D < STEPS) ring[st % D] = load_h1<SG>(wp + T2L_HOT(st + D) * 128);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_h3<SG>(acc, wf, fp_frag<SG>(a, aoff + 8 * st));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// x[t][32 w + f] (+)= acc[f][t] + bias[32 w + f] for the wave's feature tile; RELU: buf = relu(acc + bias) (no accumulation)
+template <bool ADD, bool RELU>
+__device__ __forceinline__ void fp_epilogue(const FP dst, int dcol0, const f32x16& acc, const float* __restrict__ bias) {
+  const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int f = 8 * g + 4 * half, off = col * kLdF + dcol0 + f;
+    const float4 b = *reinterpret_cast<const float4*>(bias + f);
+    ff_f32x4 v = {acc[4 * g] + b.x, acc[4 * g + 1] + b.y, acc[4 * g + 2] + b.z, acc[4 * g + 3] + b.w};
+    if constexpr (RELU) v = ff_f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+    if constexpr (ADD) v += fp_get4(dst, off);
+    fp_put4(dst, off, v);
+  }
+}
+// x[t][32 w + f] = LayerNorm_t(x[t] + acc[.][t] + bias) * g + b — the residual epilogue and the LayerNorm behind it in one go. A lane
+// holds 16 of its token's 128 features (its partner lane ^ 32 another 16, the other three waves 32 each): the row sums meet in
+// 1 KB of LDS (two light barriers: mean, then the centred squares — the two-pass form, as nn.LayerNorm), the values stay in
+// registers in between, and the normalised row is written ONCE. (As a separate pass — one wave per row, two full-wave reductions per
+// row — the three LayerNorms were ~960 of a wave's VALU instructions per tile pass and a plane round trip each.)
+__device__ __forceinline__ void fp_epilogue_ln(const FP x, const f32x16& acc, const float* __restrict__ bias, const float* __restrict__ g,
+                                               const float* __restrict__ b, float* __restrict__ red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
+  ff_f32x4 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f = 32 * w + 8 * q + 4 * half;
+    const float4 bb = *reinterpret_cast<const float4*>(bias + f);
+    v[q] = fp_get4(x, col * kLdF + f) + ff_f32x4{acc[4 * q] + bb.x, acc[4 * q + 1] + bb.y, acc[4 * q + 2] + bb.z, acc[4 * q + 3] + bb.w};
+    s += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
+  }
+  s += __shfl_xor(s, 32);
+  if (half == 0) red[w * 32 + col] = s;
+  __syncthreads();
+  const float mu = ((red[col] + red[32 + col]) + (red[64 + col] + red[96 + col])) * (1.f / kFD);
+  float qs = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v[q] -= ff_f32x4{mu, mu, mu, mu};
+    qs += (v[q][0] * v[q][0] + v[q][1] * v[q][1]) + (v[q][2] * v[q][2] + v[q][3] * v[q][3]);
+  }
+  qs += __shfl_xor(qs, 32);
+  if (half == 0) red[128 + w * 32 + col] = qs;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf(((red[128 + col] + red[160 + col]) + (red[192 + col] + red[224 + col])) * (1.f / kFD) + 1e-5f);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f = 32 * w + 8 * q + 4 * half;
+    const float4 gg = *reinterpret_cast<const float4*>(g + f), bb = *reinterpret_cast<const float4*>(b + f);
+    fp_put4(x, col * kLdF + f, ff_f32x4{v[q][0] * rstd * gg.x + bb.x, v[q][1] * rstd * gg.y + bb.y, v[q][2] * rstd * gg.z + bb.z,
+                                         v[q][3] * rstd * gg.w + bb.w});
+  }
+}
+// x[t] = LayerNorm(x[t]) * g + b for t < T (in place; one wave per row, two consecutive features per lane)
+__device__ void fp_ln_rows(const FP x, int T, const float* __restrict__ g, const float* __restrict__ b) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float2 gv = *reinterpret_cast<const float2*>(g + 2 * lane), bv = *reinterpret_cast<const float2*>(b + 2 * lane);
+  for (int t = w; t < T; t += 4) {
+    const int off = t * kLdF + 2 * lane;
+    const ff_f32x2 v = __builtin_convertvector(*reinterpret_cast<const ff_f16x2*>(x.hi + off), ff_f32x2) +
+                       __builtin_convertvector(*reinterpret_cast<const ff_f16x2*>(x.lo + off), ff_f32x2);
+    const float mu = f_wsum(v[0] + v[1]) * (1.f / kFD);
+    const float d0 = v[0] - mu, d1 = v[1] - mu;
+    const float rstd = 1.0f / sqrtf(f_wsum(d0 * d0 + d1 * d1) * (1.f / kFD) + 1e-5f);
+    const ff_f32x2 o = {d0 * rstd * gv.x + bv.x, d1 * rstd * gv.y + bv.y};
+    const ff_f16x2 h = __builtin_convertvector(o, ff_f16x2);
+    *reinterpret_cast<ff_f16x2*>(x.hi + off) = h;
+    *reinterpret_cast<ff_f16x2*>(x.lo + off) = __builtin_convertvector(o - __builtin_convertvector(h, ff_f32x2), ff_f16x2);
+  }
+}
+// One attention block on planes, head h = wave (f_attention_regs with plane operands and the output transposed). ACC: added to obuf.
+template <int H, bool ACC>
+__device__ __forceinline__ void fp_attention(const FP x, TileGroups gx, const FP mem, TileGroups gm, bool self, const FPacked in_proj, const FP obuf) {
+  constexpr bool SG = H == 2;
+  const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
+  constexpr int HS = kFD / 16;  // 8 steps of 16
+  const uint4* hq = in_proj.h + ((size_t)h * HS * 64 + lane) * 2;
+  const uint4* hk = in_proj.h + ((size_t)(4 + h) * HS * 64 + lane) * 2;
+  const uint4* hv = in_proj.h + ((size_t)(8 + h) * HS * 64 + lane) * 2;
+  const int aoff = col * kLdF + half * (kFD / 2);
+  f32x16 qT, kT, v;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) qT[r] = kT[r] = v[r] = 0.f;
+#pragma unroll 4
+  for (int st = 0; st < HS; ++st) {
+    const HFrag xf = fp_frag<SG>(x, aoff + 8 * st);
+    const HFrag mf = self ? xf : fp_frag<SG>(mem, aoff + 8 * st);
+    mfma_h3<SG>(qT, load_h1<SG>(hq + T2L_HOT(st) * 128), xf);
+    mfma_h3<SG>(kT, load_h1<SG>(hk + T2L_HOT(st) * 128), mf);
+    mfma_h3<SG>(v, mf, load_h1<SG>(hv + T2L_HOT(st) * 128));
+  }
+  {
+    const float* ib = in_proj.b;
+    const float bv = ib[2 * kFD + h * kFHd + col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
+      qT[r] += ib[h * kFHd + f];
+      kT[r] += ib[kFD + h * kFHd + f];
+      v[r] += bv;
+    }
+  }
+  f32x16 st;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kT[r], qT[r], st, 0, 0, 0);
+  // lane: query i = col, keys j = (r&3) + 8*(r>>2) + 4*half
+  const int gi = gx.base + (col >> gx.shift) - gm.base;
+  float m = -__builtin_inff();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
+    const bool ok = (j >> gm.shift) == gi && (j & ((1 << gm.shift) - 1)) < gm.count && j < gm.rows;
+    st[r] = ok ? st[r] * 0.17677669529663687f : -__builtin_inff();  // 1/sqrt(32)
+    m = fmaxf(m, st[r]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 32));
+  const bool any = m > -__builtin_inff();
+  float sum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    st[r] = any ? __expf(st[r] - m) : 0.f;
+    sum += st[r];
+  }
+  sum += __shfl_xor(sum, 32);
+  const float inv = any ? 1.f / sum : 0.f;
+  // O^T = V^T P^T: A[feature c][key] = v (as it sits: lane (c, half) holds V[key(r, half)][c]), B[key][query] = P (lane (query, half))
+  f32x16 oT;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oT[r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oT = __builtin_amdgcn_mfma_f32_32x32x2f32(v[r], st[r] * inv, oT, 0, 0, 0);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {  // lane (query = col, half): features 8 g + 4 half + 0..3 of head h
+    const int off = col * kLdF + h * kFHd + 8 * g + 4 * half;
+    ff_f32x4 o4 = {oT[4 * g], oT[4 * g + 1], oT[4 * g + 2], oT[4 * g + 3]};
+    if constexpr (ACC) o4 += fp_get4(obuf, off);
+    fp_put4(obuf, off, o4);
+  }
+}
+template <int H>
+__device__ void fp_decoder(const FP x, TileGroups gx, const FP mem, TileGroups gm, const FDecoder D, const FP buf, float* red,
+                           const FP* mem2 = nullptr, TileGroups gm2 = TileGroups{0, 0, 0, 0}) {
+  constexpr bool SG = H == 2;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
+  const int aoff = col * kLdF + half * (kFD / 2);
+  auto proj_add_ln = [&](const FPacked& L, const float* g, const float* b) {  // x = LN(x + buf @ W^T + bias): the wave's 32 features
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    fp_dot<kFD / 16, SG>(buf, aoff, L.h + ((size_t)w * (kFD / 16) * 64 + lane) * 2, acc);
+    fp_epilogue_ln(x, acc, L.b, g, b, red);  // (nobody reads x here: the attention that did is behind a barrier)
+  };
+  fp_attention<H, false>(x, gx, x, gx, true, D.sa_in, buf);
+  __syncthreads();
+  proj_add_ln(D.sa_out, D.g1, D.b1);
+  __syncthreads();
+  fp_attention<H, false>(x, gx, mem, gm, false, D.ca_in, buf);
+  if (mem2) fp_attention<H, true>(x, gx, *mem2, gm2, false, D.ca_in, buf);  // (same wave, same obuf columns: ordered without a barrier)
+  __syncthreads();
+  proj_add_ln(D.ca_out, D.g2, D.b2);
+  __syncthreads();
+  {  // feed-forward 128 -> 512 -> 128, the hidden layer through buf in four quarters (see f_decoder)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int qtr = 0; qtr < 4; ++qtr) {
+      const int tile = (w < 2 ? 2 * qtr + w : 8 + 2 * qtr + (w - 2));
+      f32x16 hh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hh[r] = 0.f;
+      fp_dot<kFD / 16, SG>(x, aoff, D.l1.h + ((size_t)tile * (kFD / 16) * 64 + lane) * 2, hh);
+      if (qtr) __syncthreads();  // every wave has consumed the previous quarter
+      fp_epilogue<false, true>(buf, w * 32, hh, D.l1.b + tile * 32);
+      __syncthreads();
+      fp_dot<kFD / 16, SG>(buf, aoff, D.l2.h + (((size_t)w * (4 * kFD / 16) + 8 * qtr) * 64 + lane) * 2, acc);
+    }
+    fp_epilogue_ln(x, acc, D.l2.b, D.g3, D.b3, red);  // (the last read of x, linear1's, is behind the quarter's barriers)
+  }
   __syncthreads();
 }
 
@@ -512,69 +767,105 @@ __global__ __launch_bounds__(256) void fine_objects_kernel(FineParams P, t2l_pac
   for (int i = tid; i < kFObj * kFD; i += 256) out[(size_t)cell * kFObj * kFD + i] = res[(i / kFD) * kFS + (i % kFD)];
 }
 
-// One workgroup per kPairs = 2 (query, cell) pairs: the 2 x 16 object tokens fill one 32-row MFMA tile, the 2 x 6 hint tokens
-// sit at rows 8p..8p+5 of a second one (its other rows are zero / ignored). Three 32 x 128 LDS tiles (52 KB): three
-// workgroups per CU.
+// One workgroup per kPairs = 4 (query, cell) pairs: the 4 x 16 object tokens fill two 32-row MFMA tiles (pairs 0-1, pairs 2-3), the
+// 4 x <= 8 hint tokens ONE (pair p at rows 8p .. 8p + n_hints - 1, other rows zero / ignored). Until round 5 a workgroup held two
+// pairs: one object tile and a hint tile with only 16 of its 32 rows in use — every decoder layer over the hints streamed its
+// megabyte of weights and ran its ~450 MFMAs per wave for a tile that was 5/8 empty. With four pairs the hint layers are paid
+// once per four pairs instead of once per two: 3 tile passes per 4 pairs instead of 4 (+ the hint tile's second cross-attention
+// pass, its pairs' objects sitting in two tiles). Five 32 x 128 LDS tiles' worth (69 KB): two workgroups per CU.
 // H = split-f16 MFMAs: a workgroup whose raw descriptor rows exceed kFGuardNorm writes wg_flags[block] = 1 and leaves; the
 // !H launch that follows (all-f32 MFMA) serves exactly those workgroups (wg_flags == nullptr: every workgroup).
 template <int H>
-__global__ __launch_bounds__(256, 3) void fine_match_kernel(FineParams P, const float* __restrict__ cell_desc, const int32_t* __restrict__ cell_index,
+__global__ __launch_bounds__(256, 2) void fine_match_kernel(FineParams P, const float* __restrict__ cell_desc, const int32_t* __restrict__ cell_index,
                                                             const float* __restrict__ hint_desc, const int32_t* __restrict__ hint_index,
                                                             int n_pairs, int n_hints, float* __restrict__ out, int32_t* __restrict__ wg_flags) {
   if constexpr (!H) {
     if (wg_flags && !wg_flags[blockIdx.x]) return;
   }
-  extern __shared__ float sm[];
-  float* d0 = sm;                  // [32][kFS] objects: pair p at rows 16p..
-  float* d1 = d0 + 32 * kFS;       // [32][kFS] hints:   pair p at rows 8p..8p+n_hints-1
-  float* buf = d1 + 32 * kFS;      // [32][kFS]
-  float* pooled = buf + 32 * kFS;  // [kPairs][128]
-  float* h64 = pooled + kPairs * kFD;  // [kPairs][64]
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* pooled = sm + 4 * kTileBytes / 4;  // [kPairs][128] (behind the four tiles in either form)
+  float* h64 = pooled + kPairs * kFD;       // [kPairs][64]
+  float* red = h64 + kPairs * 64;           // [2][4][32]: row sums of the fused residual + LayerNorm epilogues
   const int tid = threadIdx.x, pair0 = blockIdx.x * kPairs;
-  for (int i = tid; i < 32 * kFD; i += 256) {
+  if constexpr (H != 0) {
+    // ---- split-f16 form: the four token tiles as f16 planes (objects A, objects B, hints, buf)
+    char* base = reinterpret_cast<char*>(sm);
+    const FP pa = fp_at(base), pb = fp_at(base + kTileBytes), ph = fp_at(base + 2 * kTileBytes), pbuf = fp_at(base + 3 * kTileBytes);
+    float worst = 0.f;  // guard: largest 2-norm of the 96 raw rows (NaN fails the comparison too); 32 threads cover a row
+    for (int i = tid; i < 96 * (kFD / 4); i += 256) {  // a float4 of a row per item: 32 items per row
+      const int row = i >> 5, c = 4 * (i & 31);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < 64) {
+        const int pair = min(pair0 + (row >> 4), n_pairs - 1);  // tail pairs are duplicated (their copies are not written back)
+        v = *reinterpret_cast<const float4*>(cell_desc + (size_t)(cell_index ? cell_index[pair] : pair) * kFObj * kFD + (row & 15) * kFD + c);
+      } else {
+        const int hrow = row - 64, hp = hrow >> 3, hr = hrow & 7;
+        if (hr < n_hints) {
+          const int hpair = min(pair0 + hp, n_pairs - 1);
+          v = *reinterpret_cast<const float4*>(hint_desc + ((size_t)(hint_index ? hint_index[hpair] : hpair) * n_hints + hr) * kFD + c);
+        }
+      }
+      const FP t = row < 32 ? pa : (row < 64 ? pb : ph);
+      fp_put4(t, (row & 31) * kLdF + c, ff_f32x4{v.x, v.y, v.z, v.w});
+      float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;  // the row's 32 quads sit in 32 consecutive lanes (half a wave)
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+      worst = (ss <= kFGuardNorm * kFGuardNorm) ? worst : 1.f;  // (NaN: the comparison fails)
+    }
+    const int unsafe = __syncthreads_or(worst != 0.f ? 1 : 0);
+    if (tid == 0) wg_flags[blockIdx.x] = unsafe ? 1 : 0;
+    if (unsafe) return;  // block-uniform: the f32 launch that follows serves this workgroup
+    const TileGroups gobjA{4, kFObj, 32, 0}, gobjB{4, kFObj, 32, 2}, ghint{3, n_hints, 32, 0};
+    for (int l = 0; l < P.n_layers; ++l) {  // cross_matcher.py:114-118
+      fp_decoder<H>(pa, gobjA, ph, ghint, P.obj[l], pbuf, red);
+      fp_decoder<H>(pb, gobjB, ph, ghint, P.obj[l], pbuf, red);
+      fp_decoder<H>(ph, ghint, pa, gobjA, P.hint[l], pbuf, red, &pb, gobjB);
+    }
+    if (P.n_layers == 0) fp_decoder<H>(ph, ghint, pa, gobjA, P.hint[0], pbuf, red, &pb, gobjB);  // cross_matcher.py:119-120
+    for (int i = tid; i < kPairs * kFD; i += 256) {  // desc1.max(dim=0) over the hints (cross_matcher.py:128)
+      const int p = i >> 7, c = i & 127;
+      auto at = [&](int t) { return (float)ph.hi[(8 * p + t) * kLdF + c] + (float)ph.lo[(8 * p + t) * kLdF + c]; };
+      float m = at(0);
+      for (int t = 1; t < n_hints; ++t) m = fmaxf(m, at(t));
+      pooled[p * kFD + c] = m;
+    }
+  } else {
+  float* d0 = sm;                  // [64][kFS] objects: pair p at rows 16p.. (tile A = pairs 0-1, tile B = pairs 2-3)
+  float* d1 = d0 + 64 * kFS;       // [32][kFS] hints:   pair p at rows 8p..8p+n_hints-1
+  float* buf = d1 + 32 * kFS;      // [32][kFS]
+  for (int i = tid; i < 64 * kFD; i += 256) {
     const int row = i / kFD, c = i % kFD, p = row >> 4;
-    const int pair = min(pair0 + p, n_pairs - 1);  // an odd tail pair is duplicated (its second copy is not written back)
+    const int pair = min(pair0 + p, n_pairs - 1);  // tail pairs are duplicated (their copies are not written back)
     d0[row * kFS + c] = cell_desc[(size_t)(cell_index ? cell_index[pair] : pair) * kFObj * kFD + (row & 15) * kFD + c];
-    const int hp = row >> 3, hr = row & 7;
+  }
+  for (int i = tid; i < 32 * kFD; i += 256) {
+    const int row = i / kFD, c = i % kFD, hp = row >> 3, hr = row & 7;
     float v = 0.f;
-    if (hp < kPairs && hr < n_hints) {
+    if (hr < n_hints) {
       const int hpair = min(pair0 + hp, n_pairs - 1);
       v = hint_desc[((size_t)(hint_index ? hint_index[hpair] : hpair) * n_hints + hr) * kFD + c];
     }
     d1[row * kFS + c] = v;
   }
   __syncthreads();
-  if constexpr (H != 0) {  // guard: largest 2-norm of the 64 raw rows (NaN fails the comparison too)
-    const int w = tid >> 6, lane = tid & 63;
-    float worst = 0.f;
-    for (int t = w; t < 64; t += 4) {
-      const float* row = (t < 32 ? d0 + t * kFS : d1 + (t - 32) * kFS);
-      const float a = row[lane], b = row[lane + 64];
-      worst = fmaxf(worst, f_wsum(a * a + b * b));
-    }
-    if (lane == 0) h64[w] = worst;
-    __syncthreads();
-    const float ss = fmaxf(fmaxf(h64[0], h64[1]), fmaxf(h64[2], h64[3]));
-    const bool safe = ss <= kFGuardNorm * kFGuardNorm;
-    if (tid == 0) wg_flags[blockIdx.x] = safe ? 0 : 1;
-    if (!safe) return;  // block-uniform
-    __syncthreads();
-  }
-  const TileGroups gobj{4, kFObj, 32}, ghint{3, n_hints, 16};
+  float* d0b = d0 + 32 * kFS;
+  const TileGroups gobjA{4, kFObj, 32, 0}, gobjB{4, kFObj, 32, 2}, ghint{3, n_hints, 32, 0};
   for (int l = 0; l < P.n_layers; ++l) {  // cross_matcher.py:114-118
-    f_decoder<H>(d0, gobj, d1, ghint, P.obj[l], buf);
-    f_decoder<H>(d1, ghint, d0, gobj, P.hint[l], buf);
+    f_decoder<H>(d0, gobjA, d1, ghint, P.obj[l], buf);
+    f_decoder<H>(d0b, gobjB, d1, ghint, P.obj[l], buf);
+    f_decoder<H>(d1, ghint, d0, gobjA, P.hint[l], buf, d0b, gobjB);
   }
-  if (P.n_layers == 0) f_decoder<H>(d1, ghint, d0, gobj, P.hint[0], buf);  // cross_matcher.py:119-120
-  {  // desc1.max(dim=0) over the hints, then mlp_offsets (cross_matcher.py:128-131)
-    const int p = tid >> 7, c = tid & 127;
+  if (P.n_layers == 0) f_decoder<H>(d1, ghint, d0, gobjA, P.hint[0], buf, d0b, gobjB);  // cross_matcher.py:119-120
+  for (int i = tid; i < kPairs * kFD; i += 256) {  // desc1.max(dim=0) over the hints (cross_matcher.py:128)
+    const int p = i >> 7, c = i & 127;
     float m = d1[(8 * p) * kFS + c];
     for (int t = 1; t < n_hints; ++t) m = fmaxf(m, d1[(8 * p + t) * kFS + c]);
     pooled[p * kFD + c] = m;
   }
-  __syncthreads();
-  if (tid < kPairs * 64) {
-    const int p = tid >> 6, n = tid & 63;
+  }  // f32 form
+  __syncthreads();  // mlp_offsets (cross_matcher.py:129-131)
+  {
+    const int p = tid >> 6, n = tid & 63;  // 4 pairs x 64 hidden units = the 256 threads
     float s = P.off0.b[n];
     for (int k = 0; k < kFD; ++k) s += pooled[p * kFD + k] * P.off0.wt[k * 64 + n];
     h64[p * 64 + n] = fmaxf(s, 0.f);
@@ -612,7 +903,7 @@ int fine_match_impl(t2l_ctx* ctx, const float* cell_desc, const int32_t* cell_in
   if (!cell_desc || !hint_desc || !out || n_pairs < 0) return fail(ctx, T2L_EINVAL, "t2l_fine_match: null argument");
   if (n_hints < 1 || n_hints > kFHintMax) return fail(ctx, T2L_EINVAL, "t2l_fine_match: 1 <= n_hints <= 8");
   if (n_pairs == 0) return T2L_OK;
-  const size_t lds = sizeof(float) * (3 * 32 * kFS + kPairs * kFD + kPairs * 64);  // 52 KB: three workgroups per CU
+  const size_t lds = (size_t)4 * kTileBytes + sizeof(float) * (kPairs * kFD + kPairs * 64 + 256);  // 73.7 KB: two workgroups per CU
   static PerDeviceOnce attr;
   if (attr.need(ctx->device)) {
     T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&fine_match_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

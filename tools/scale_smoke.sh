@@ -9,7 +9,8 @@ set -u
 cd "$(dirname "$0")/.."
 OUT=${1:-gpurun_out/scale_smoke}
 mkdir -p "$OUT"
-export T2L_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0
+# (on a node with >= N GPUs: T2L_DIST_BACKEND=nccl tools/scale_smoke.sh runs the SAME command over RCCL — exactly what the driver launches)
+export T2L_DIST_BACKEND=${T2L_DIST_BACKEND:-gloo} HSA_ENABLE_IPC_MODE_LEGACY=0
 rc=0
 for N in ${SCALE_SMOKE_NS:-2 4 8}; do
   timeout 900 python bench.py --gpus "$N" --steps 20 --warmup 5 --no-cpu-baseline --detail-out "$OUT/detail_g$N.json" > "$OUT/bench_g$N.json" 2> "$OUT/bench_g$N.err"
