@@ -76,6 +76,28 @@ def test_single_cross_hints_layer_matches_the_reference_run(eng, golden):
         eng.fine_load_weights(sd, class_embed=True, color_embed=True, num_layers=5)
 
 
+def test_a_pair_does_not_depend_on_its_place_in_the_workgroup(eng):
+    """Four pairs share a workgroup (two object tiles, one hint tile): a pair's offsets must not depend on which of the four places it
+    takes, nor on its neighbours — the property that keeps a sharded run_fine (which deals the pairs differently) bit-identical to the
+    single-process run. Shifting the pair list by 1, 2, 3 and 5 moves every pair to another place; twice the same call is the same bits."""
+    sd = synth.make_fine_weights(5)
+    eng.fine_load_weights(sd, class_embed=True, color_embed=True)
+    n_cells, Q = 37, 53
+    cells = synth.make_cells(n_cells, seed=77, min_obj=16, max_obj=16)
+    desc = eng.fine_encode_objects(to_dev(cells, True))
+    rng = np.random.default_rng(5)
+    hints = torch.from_numpy(rng.standard_normal((Q, 6, 128)).astype(np.float32)).cuda()
+    ci = torch.from_numpy(rng.integers(0, n_cells, size=Q * 10).astype(np.int32)).cuda()
+    hi = torch.arange(Q, dtype=torch.int32, device="cuda").repeat_interleave(10)
+    a = eng.fine_match(desc, hints, ci, hi).clone()
+    assert torch.equal(a, eng.fine_match(desc, hints, ci, hi))
+    for shift in (1, 2, 3, 5):
+        c = eng.fine_match(desc, hints, ci[shift:].contiguous(), hi[shift:].contiguous())
+        assert torch.equal(c, a[shift:]), shift
+    ref = OF.cross_match(OF.fine_object_encodings(cells, sd, True, True)[ci.cpu().numpy()[:64]], hints.cpu().numpy()[hi.cpu().numpy()[:64]], sd)
+    assert np.abs(a.cpu().numpy()[:64] - ref).max() < 5e-5
+
+
 def test_norm_guard_sends_large_rows_to_the_f32_kernel(eng):
     """Hint rows far above the guard (2-norm 64) in SOME pairs: those workgroups are served by the f32 launch that follows the
     split-f16 one, the others are not touched twice; every pair still matches the oracle."""

@@ -162,13 +162,16 @@ def _fine_worker(rank, world, port, out_q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from text2loc_amd.cross_matcher import run_fine
 
-    model, retr, dl, args = _fine_problem()
-    acc_local, off_local = run_fine(model, retr, dl, args, return_offsets=True)  # no shard_layout: an initialised group changes nothing
-    args.shard_layout = "auto"                                                   # opt-in: cells and pairs split over the ranks
-    acc, offsets = run_fine(model, retr, dl, args, return_offsets=True)
-    torch.cuda.synchronize()
-    assert acc_local == acc and np.array_equal(off_local, offsets)
-    out_q.put((rank, acc, offsets))
+    try:
+        model, retr, dl, args = _fine_problem()
+        acc_local, off_local = run_fine(model, retr, dl, args, return_offsets=True)  # no shard_layout: an initialised group changes nothing
+        args.shard_layout = "auto"                                                   # opt-in: cells and pairs split over the ranks
+        acc, offsets = run_fine(model, retr, dl, args, return_offsets=True)
+        torch.cuda.synchronize()
+        same = acc_local == acc and bool(np.array_equal(off_local, offsets))
+        out_q.put((rank, acc, offsets, "" if same else "the un-sharded call inside an initialised group differs from the sharded one"))
+    except Exception as e:  # (a worker that dies silently leaves the parent waiting for its timeout: report instead)
+        out_q.put((rank, None, None, repr(e)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -185,14 +188,18 @@ def test_run_fine_sharded_equals_single_process(world):
     procs = [ctx.Process(target=_fine_worker, args=(r, world, port, out_q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([out_q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    try:
+        res = sorted([out_q.get(timeout=240) for _ in range(world)], key=lambda r: r[0])
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs) and not [r[3] for r in res if r[3]], [r[3] for r in res]
     model, retr, dl, args = _fine_problem()
     acc1, off1 = run_fine(model, retr, dl, args, return_offsets=True)
     assert off1.shape == (53, 10, 2) and np.isfinite(off1).all()
-    for rank, acc, off in res:
+    for rank, acc, off, _ in res:
         assert acc == acc1, (rank, acc, acc1)
         assert np.array_equal(off, off1), f"rank {rank}: offsets differ from the single-process run"
 

@@ -595,8 +595,13 @@ __device__ void fp_ln_rows(const FP x, int T, const float* __restrict__ g, const
     *reinterpret_cast<ff_f16x2*>(x.lo + off) = __builtin_convertvector(o - __builtin_convertvector(h, ff_f32x2), ff_f16x2);
   }
 }
-// One attention block on planes, head h = wave (f_attention_regs with plane operands and the output transposed). ACC: added to obuf.
-template <int H, bool ACC>
+// One attention block on planes, head h = wave (f_attention_regs with plane operands and the output transposed). SHARED: the query tile's
+// groups find their keys in different mem tiles and attend each in turn — a query row sees keys in exactly ONE of the passes, and only
+// that pass writes its output row. (A first version added the passes up: the row's other pass read hi + lo back, added zero and split
+// the sum again — the same value, but where |lo| had been rounded up to exactly half an ulp of hi the re-split picks the other
+// neighbour as hi; the products drop lo * W_lo, so the offsets then depended, at 2e-7, on which tile of the workgroup a pair sat in —
+// and a sharded run_fine, which deals the pairs differently, was no longer bit-identical to the single-process run.)
+template <int H, bool SHARED>
 __device__ __forceinline__ void fp_attention(const FP x, TileGroups gx, const FP mem, TileGroups gm, bool self, const FPacked in_proj, const FP obuf) {
   constexpr bool SG = H == 2;
   const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
@@ -661,9 +666,8 @@ __device__ __forceinline__ void fp_attention(const FP x, TileGroups gx, const FP
 #pragma unroll
   for (int g = 0; g < 4; ++g) {  // lane (query = col, half): features 8 g + 4 half + 0..3 of head h
     const int off = col * kLdF + h * kFHd + 8 * g + 4 * half;
-    ff_f32x4 o4 = {oT[4 * g], oT[4 * g + 1], oT[4 * g + 2], oT[4 * g + 3]};
-    if constexpr (ACC) o4 += fp_get4(obuf, off);
-    fp_put4(obuf, off, o4);
+    const ff_f32x4 o4 = {oT[4 * g], oT[4 * g + 1], oT[4 * g + 2], oT[4 * g + 3]};
+    if (!SHARED || any) fp_put4(obuf, off, o4);
   }
 }
 template <int H>
@@ -683,8 +687,12 @@ __device__ void fp_decoder(const FP x, TileGroups gx, const FP mem, TileGroups g
   __syncthreads();
   proj_add_ln(D.sa_out, D.g1, D.b1);
   __syncthreads();
-  fp_attention<H, false>(x, gx, mem, gm, false, D.ca_in, buf);
-  if (mem2) fp_attention<H, true>(x, gx, *mem2, gm2, false, D.ca_in, buf);  // (same wave, same obuf columns: ordered without a barrier)
+  if (!mem2) {
+    fp_attention<H, false>(x, gx, mem, gm, false, D.ca_in, buf);
+  } else {  // (every query row has its keys in exactly one of the two tiles)
+    fp_attention<H, true>(x, gx, mem, gm, false, D.ca_in, buf);
+    fp_attention<H, true>(x, gx, *mem2, gm2, false, D.ca_in, buf);
+  }
   __syncthreads();
   proj_add_ln(D.ca_out, D.g2, D.b2);
   __syncthreads();
