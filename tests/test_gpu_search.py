@@ -510,7 +510,7 @@ def test_auto_mode_moves_a_clustered_database_to_the_exact_stage():
         e.close()
 
 
-@pytest.mark.parametrize("lanes", [2, 3, 4])
+@pytest.mark.parametrize("lanes", [2, 4])  # (3, the bench's side measurement, is checked there: results_equal_stream_ordered)
 def test_pipelined_searches_equal_stream_ordered_ones(lanes):
     """t2l_set_option("search_lanes", n) + t2l_search_join: consecutive calls run on internal streams and overlap; every call's
     (ids, scores) are those of the stream-ordered call, whatever mix of batch sizes (small batches and the streaming scan
