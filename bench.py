@@ -1475,7 +1475,7 @@ def main():
         if args.mode == 2:
             kname, peak, dtype, mult = "scanw_kernel<8, 4>", BF16_MFMA_PEAK_TFLOPS, "bf16x3", 3
         else:
-            kname, peak, dtype, mult = "scanp_kernel<6, 4, false, false, true>", BF16_MFMA_PEAK_TFLOPS, "f16", 1  # (the merged-record form: the default on benign data)
+            kname, peak, dtype, mult = "scanp_kernel<6, 4, true>", BF16_MFMA_PEAK_TFLOPS, "f16", 1  # (the merged-record form: the default on benign data)
         if world == 1 and args.mode == 0 and not args.quick and not os.environ.get("T2L_BENCH_CHILD"):
             live = measure_traffic_in_run("t2l::scanp_kernel")  # (outside every timed region; ~40 s; None without rocprofv3)
             if live is not None:
