@@ -202,7 +202,14 @@ def test_auto_mode_leaves_the_f16_scan_on_packed_scores_and_returns(eng):
         torch.cuda.synchronize()
         return i.cpu().numpy().astype(np.int64), s.cpu().numpy()
 
+    # t2l_db_set's prior (round 5): rows this parallel (mean pairwise cosine > 0.9 over a sample) start on the stand-in scan at once
     idx, sc = _search(eng, packed, q, 10)
+    assert np.array_equal(idx, ridx) and np.abs(sc - rsc).max() < 1e-12
+    assert eng.search_counters()["probe"] > len(q) // 8 and eng.search_fallbacks() == 0
+    # ... and WITHOUT the prior (forgotten: the report-card mechanism by itself, from the f16 scan)
+    eng.set_option("search_auto", 0)
+    eng.set_option("search_auto", 1)
+    idx, sc = again(q)
     assert np.array_equal(idx, ridx) and np.abs(sc - rsc).max() < 1e-12
     first = eng.search_rescored()
     assert first > len(q) // 8
@@ -219,7 +226,7 @@ def test_auto_mode_leaves_the_f16_scan_on_packed_scores_and_returns(eng):
     r2, _ = O.retrieve_topk(db, qs, 10)
     idx, _ = _search(eng, db, qs, 10)
     assert np.array_equal(idx, r2)
-    assert eng.search_counters()["probe"] == 0  # t2l_db_set voided the old database's report cards: the f16 scan is back
+    assert eng.search_counters()["probe"] == 0  # t2l_db_set voided the old database's report cards and the new rows are not parallel: the f16 scan is back
     for _ in range(3):
         idx, _ = again(qs)
         assert np.array_equal(idx, r2)

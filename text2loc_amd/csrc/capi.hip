@@ -74,12 +74,12 @@ int t2l_create(t2l_ctx** out, int device_id) {
   if (hipSetDevice(device_id) != hipSuccess) return T2L_EHIP;
   t2l_ctx* ctx = new t2l_ctx();
   ctx->device = device_id;
-  if (hipMalloc(&ctx->db_norm_max, 2 * sizeof(float)) != hipSuccess ||
+  if (hipMalloc(&ctx->db_norm_max, (2 + 256) * sizeof(float)) != hipSuccess ||
       hipMalloc(&ctx->fb_count, 256 * sizeof(int32_t)) != hipSuccess) {
     delete ctx;
     return T2L_ENOMEM;
   }
-  (void)hipMemset(ctx->db_norm_max, 0, 2 * sizeof(float));
+  (void)hipMemset(ctx->db_norm_max, 0, (2 + 256) * sizeof(float));
   if (hipHostMalloc((void**)&ctx->host_stat, 8 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess) {
     memset(ctx->host_stat, 0, 8 * sizeof(int32_t));
     if (hipHostGetDevicePointer((void**)&ctx->host_stat_dev, ctx->host_stat, 0) != hipSuccess) ctx->host_stat_dev = nullptr;
@@ -212,6 +212,26 @@ int t2l_db_set(t2l_ctx* ctx, const float* emb, int64_t n_rows, int64_t row_offse
   int rc = db_norm_impl(ctx, s);
   if (rc != T2L_OK) return rc;
   T2L_HIP(ctx, hipStreamSynchronize(s));
+  // A PRIOR for the first searches on this database (round 5). db_norm_impl left the sum S of up to 1,024 sampled rows, each
+  // normalised: (|S|^2 - n) / (n (n - 1)) is the sample's mean pairwise cosine. Above 0.9 the rows are nearly parallel — what an
+  // untrained encoder produces over overlapping cells, i.e. every validation pass of the first training epochs — and the f16
+  // certificates fail wholesale: without a prior the first call on such a database sends ~4,000 of 4,096 queries to the re-rank
+  // workgroups' own exact scans (3.3 ms; measured on bench.py's cold end-to-end line: 6.8 ms per encode + db_set + search against
+  // 3.4 with the prior), and t2l_db_set voids the report cards that would have said so. The prior only picks the starting MODE
+  // (split-bf16 stand-in scan, unsettled queries deferred to the float64 MFMA stage); results are exact in every mode and the first
+  // report cards correct a wrong guess within two calls (cost of a wrong guess: one near-empty launch per call).
+  if (ctx->search_auto && ctx->search_mode == 0 && n_rows >= 64) {
+    float cols[256];
+    T2L_HIP(ctx, hipMemcpy(cols, ctx->db_norm_max + 2, sizeof(cols), hipMemcpyDeviceToHost));
+    double ss = 0.0;
+    for (float c : cols) ss += (double)c * c;
+    const double n = (double)std::min<int64_t>(n_rows, 1024);
+    const double mean_cos = (ss - n) / (n * (n - 1.0));
+    if (mean_cos > 0.9) {  // (NaN compares false)
+      ctx->escalated = true;
+      ctx->heavy = true;
+    }
+  }
   return T2L_OK;
 }
 

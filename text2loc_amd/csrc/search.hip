@@ -1331,6 +1331,31 @@ __global__ __launch_bounds__(256) void db_norm_kernel(const float* __restrict__ 
   }
 }
 
+// out[0 .. 255] += sum over up to 1,024 sampled rows (every stride-th) of row / |row|: t2l_db_set turns |sum|^2 into the sample's mean
+// pairwise cosine (the prior for the first searches on a new database, capi.hip). 16 workgroups x 64 rows, one wave per row.
+__global__ __launch_bounds__(256) void db_cluster_kernel(const float* __restrict__ db, int n_rows, int stride, int n_sample, float* out) {
+  __shared__ float4 acc[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = blockIdx.x * 64 + wave; i < min(n_sample, (int)(blockIdx.x + 1) * 64); i += 4) {
+    const float4 v = reinterpret_cast<const float4*>(db + (size_t)min(i * stride, n_rows - 1) * kD)[lane];
+    float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    const float inv = s > 0.f ? 1.0f / sqrtf(s) : 0.f;
+    a.x += v.x * inv; a.y += v.y * inv; a.z += v.z * inv; a.w += v.w * inv;
+  }
+  acc[wave][lane] = a;
+  __syncthreads();
+  if (wave == 0) {
+    const float4 b = acc[1][lane], c = acc[2][lane], d = acc[3][lane];
+    atomicAdd(out + 4 * lane + 0, a.x + b.x + c.x + d.x);
+    atomicAdd(out + 4 * lane + 1, a.y + b.y + c.y + d.y);
+    atomicAdd(out + 4 * lane + 2, a.z + b.z + c.z + d.z);
+    atomicAdd(out + 4 * lane + 3, a.w + b.w + c.w + d.w);
+  }
+}
+
 static int grow(t2l_ctx* ctx, void** p, size_t* cap, size_t need_bytes) {
   if (need_bytes <= *cap) return T2L_OK;
   if (*p) (void)hipFree(*p);
@@ -1348,10 +1373,13 @@ int db_norm_impl(t2l_ctx* ctx, hipStream_t s) {
                        (int)ctx->db_pad);
     T2L_HIP(ctx, hipGetLastError());
   }
-  T2L_HIP(ctx, hipMemsetAsync(ctx->db_norm_max, 0, 2 * sizeof(float), s));
+  T2L_HIP(ctx, hipMemsetAsync(ctx->db_norm_max, 0, (2 + 256) * sizeof(float), s));
   if (ctx->db_rows > 0) {
     const int blocks = (int)min((int64_t)1024, (ctx->db_rows + 3) / 4);
     hipLaunchKernelGGL(db_norm_kernel, dim3(blocks), dim3(256), 0, s, ctx->db, (int)ctx->db_rows, ctx->db_norm_max);
+    const int n_sample = (int)min((int64_t)1024, ctx->db_rows), stride = (int)(ctx->db_rows / n_sample);
+    hipLaunchKernelGGL(db_cluster_kernel, dim3((n_sample + 63) / 64), dim3(256), 0, s, ctx->db, (int)ctx->db_rows, stride, n_sample,
+                       ctx->db_norm_max + 2);
     T2L_HIP(ctx, hipGetLastError());
   }
   if (ctx->db_pad > 0) {  // the scaled f16 plane of the default scan (needs the max |element| from above)

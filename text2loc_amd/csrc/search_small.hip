@@ -9,19 +9,20 @@
 // ranks them — no reduced-precision scan, no certificate, no candidate lists, no second launch:
 //
 //   phase 1 (every workgroup): rows [wg * R, wg * R + R) of the f32 DB against NQ <= 4 queries (blockIdx.y picks the group of 4):
-//            a 16-lane DPP row per DB row, four rows per wave pass, 256-byte coalesced loads; the scores meet in LDS and the
-//            workgroup ranks its R <= 256 rows by counting — (score desc, row asc), a strict total order — and PUBLISHES its best K
-//            as {float64 score, int32 row} with write-through (sc1) stores;
-//   phase 2 (the workgroup that arrives LAST on the group's ticket counter): reads the G published lists with sc1 loads, keeps what
-//            ranks at or above B = the best of the lists' K-th entries (that list alone holds K entries >= B, so nothing below B can
-//            be in the top K; every other list contributes at most K - 1 survivors), ranks the survivors by counting and writes the
-//            K ids / scores.
+//            a 16-lane DPP row per DB row, four rows per wave pass, 256-byte coalesced loads, three row groups in flight; the scores
+//            meet in LDS and the workgroup ranks its R <= 256 rows by counting — (score desc, row asc), a strict total order, one
+//            (row, query) pair per thread — and PUBLISHES its best K as 16-byte entries {float64 score bits, int32 row, 0} with
+//            write-through (sc1) buffer stores;
+//   phase 2 (the workgroup that arrives LAST on the slice's ticket counter): reads the G published lists' HEADS with sc1 loads (one
+//            query and K <= 16: the whole lists, same round trip), takes as bound T the K-th best head — K lists have a head at or
+//            ahead of T, so at least K entries are and nothing behind T can be in the top K —, compacts the entries at or ahead of T
+//            (typically K .. 2 K of the G * K) and ranks them by counting: one wave per query, the K ids / scores go out.
 //
-// Cross-workgroup visibility follows MI355X_MICROARCH.md / cdna_hip_programming.md (in-launch split-K reduction, the 4-8-byte store
-// form): relaxed agent-scope atomic stores (= `global_store ... sc1`) -> every wave `s_waitcnt vmcnt(0)` -> `__syncthreads()` ->
-// lane 0 relaxed agent `fetch_add` on the ticket; the last arriver reads with relaxed agent-scope atomic loads (sc1). No workgroup
-// ever waits for another one: nothing here depends on co-residency. The ticket is a running total (the host passes the value the
-// last arriver will draw), so no reset, no memset launch, and a grid of another size next call cannot be confused with this one.
+// Cross-workgroup visibility follows MI355X_MICROARCH.md / cdna_hip_programming.md (in-launch split-K reduction): 16-byte
+// `raw_buffer_store_b128 ... sc1` (write-through) -> every wave `s_waitcnt vmcnt(0)` -> `__syncthreads()` -> lane 0 relaxed agent
+// `fetch_add` on the ticket; the last arriver reads with sc1 buffer loads. No workgroup ever waits for another one: nothing here
+// depends on co-residency. The ticket is a running total (the host passes the value the last arriver will draw), so no reset, no
+// memset launch, and a grid of another size next call cannot be confused with this one.
 //
 // Roofline: the f32 rows once per group of 4 queries = 1 KiB per row (from L2 / Infinity Cache once resident). Measured: bench.py ->
 // search_latency.
