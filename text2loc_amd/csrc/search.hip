@@ -937,10 +937,11 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
   // ---- merge the `parts` lists into the top-L keys: L rounds of wave arg-max over the list heads. Round r leaves (key, part)
   // in lane r; the row is decoded from them ONCE after the loop (it was 12 instructions inside every round), and the loop is
   // unrolled so that popping the winner's head is 6 selects with no register copies behind them.
+  // Round 5: only the first L - 4 rounds run up front — they are all the early certificate below needs (9 queries in 10 stop there);
+  // the last four rounds run only on the way into the full path, in front of the four rows they select.
   float my_key = T2L_NEG_INF;
   int my_part = 0;
-#pragma unroll
-  for (int r = 0; r < L; ++r) {
+  auto merge_round = [&](int r) {
     const float bk = wave_max_f32(lst[0], pinf);
     const unsigned long long who = __ballot(lst[0] == bk);
     const int bl = __ffsll((long long)who) - 1;  // equal keys: lowest part first
@@ -952,11 +953,10 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
 #pragma unroll
     for (int i = 0; i < LL - 1; ++i) lst[i] = pop ? lst[i + 1] : lst[i];
     lst[LL - 1] = pop ? T2L_NEG_INF : lst[LL - 1];
-  }
-  int my_row = (lane < L && my_key != T2L_NEG_INF) ? krow(my_key, my_part) : INT_MAX;
-  // every row that is NOT re-scored has key <= g: kept rows lie at or below the L-th merged key, rows dropped inside a
-  // lane at or below that lane's floor (with LL == L a floor above the L-th key cannot happen; with LL < L it can)
-  const float g = fmaxf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_key), L - 1)), floor_max);
+  };
+#pragma unroll
+  for (int r = 0; r < L - 4; ++r) merge_round(r);
+  int my_row = (lane < L - 4 && my_key != T2L_NEG_INF) ? krow(my_key, my_part) : INT_MAX;
 
   // ---- certificate scale (keys of the f16 scan are true scores times 2^(shift_db + shift_q): undo that exactly)
   double kscale = 1.0;
@@ -1066,6 +1066,12 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
   if (early) {
     if (lane == 0) flags[qid] = 0;
   } else {
+#pragma unroll
+  for (int r = L - 4; r < L; ++r) merge_round(r);
+  if (lane >= L - 4 && lane < L && my_key != T2L_NEG_INF) my_row = krow(my_key, my_part);
+  // every row that is NOT re-scored has key <= g: kept rows lie at or below the L-th merged key, rows dropped inside a
+  // lane at or below that lane's floor (with LL == L a floor above the L-th key cannot happen; with LL < L it can)
+  const float g = fmaxf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_key), L - 1)), floor_max);
   gather(L / 4 - 1);
   score(L / 4 - 1);
   const int rank = rank_among(std::integral_constant<int, L>{});
