@@ -1,5 +1,6 @@
 """TEST INFRASTRUCTURE — ctypes loader of oracle/libt2l_oracle.so (the plain-C restatement)."""
 import ctypes as C
+import os
 import os.path as osp
 import subprocess
 
@@ -33,8 +34,22 @@ def retrieve_topk(cells, queries, k):
     k = min(k, n)
     idx = np.zeros((q, k), dtype=np.int64)
     sc = np.zeros((q, k), dtype=np.float64)
-    rc = lib().t2l_oracle_retrieve(cells.ctypes.data, n, queries.ctypes.data, q, d, k, idx.ctypes.data, sc.ctypes.data)
-    assert rc == 0
+    fn = lib().t2l_oracle_retrieve
+    n_thr = min(os.cpu_count() or 1, 32, max(1, q * n // 2_000_000))  # queries are independent: big checks use the host's cores
+    if n_thr <= 1:
+        assert fn(cells.ctypes.data, n, queries.ctypes.data, q, d, k, idx.ctypes.data, sc.ctypes.data) == 0
+        return idx, sc
+    from concurrent.futures import ThreadPoolExecutor
+
+    bounds = np.linspace(0, q, n_thr + 1).astype(int)
+
+    def part(i):  # (ctypes releases the GIL; every slice writes its own rows of idx / sc)
+        lo, hi = int(bounds[i]), int(bounds[i + 1])
+        if hi > lo:
+            assert fn(cells.ctypes.data, n, queries[lo:hi].ctypes.data, hi - lo, d, k, idx[lo:hi].ctypes.data, sc[lo:hi].ctypes.data) == 0
+
+    with ThreadPoolExecutor(n_thr) as ex:
+        list(ex.map(part, range(n_thr)))
     return idx, sc
 
 
