@@ -772,8 +772,9 @@ __device__ __forceinline__ _Float16* pl_bl(_Float16* base, int t) { return base 
 // eight-wave workgroup, in place on the tiles' X planes (B planes: scratch). mask(i, j): may query row i see key row j (tile-local)?
 // WATCH: run-time f16-range watch on everything that enters a split product (`bad`). last_to_f32: the final LayerNorm leaves f32
 // [32][260] tiles in the B-plane regions instead of planes (for an epilogue that needs full precision). Ends behind a barrier.
+// lnred: 1,024 floats of LDS scratch (the row sums of the fused residual + LayerNorm epilogues).
 template <bool SG, int FFP, bool WATCH, typename Mask>
-__device__ __forceinline__ void planes_layer(_Float16* base, const InterFusedW& W, Mask mask, bool& bad, bool last_to_f32) {
+__device__ __forceinline__ void planes_layer(_Float16* base, const InterFusedW& W, Mask mask, bool& bad, bool last_to_f32, float* lnred) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
   auto watch = [&](float v) { bad = bad || !(fabsf(v) < kSplitF16Safe); };
@@ -905,6 +906,67 @@ __device__ __forceinline__ void planes_layer(_Float16* base, const InterFusedW& 
   __syncthreads();
   // operand fragments of the row-wise products: token fragment of tile t at k-step s (this lane's row `col`, k half `half`)
   const int frow = col * kLdP + half * 128;
+  // x = LayerNorm(x + acc^T + bias) * g + be for both tiles — the residual epilogue and the LayerNorm behind it in one go (round 5; proven
+  // on fine.hip first). A lane holds 16 of a token's 256 features per tile (its partner lane ^ 32 another 16, the other seven waves 32
+  // each): the row sums meet in `lnred` behind two light barriers (mean, then centred squares: the two-pass form), the values stay in
+  // registers in between and the normalised rows are written once. As a separate pass (8 rows per wave, two full-wave reductions per
+  // row) the two LayerNorms of a layer were ~700 VALU instructions per wave and a plane round trip each.
+  auto resid_ln = [&](const f32x16 (&acc)[2], const float* __restrict__ bias, const float* __restrict__ g, const float* __restrict__ be,
+                      bool to_f32) {
+    ti_f32x4 v[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float sm = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f0 = 32 * wave + 8 * q + 4 * half;
+        const float4 bb = *reinterpret_cast<const float4*>(bias + f0);
+        v[t][q] = plane_get4<SG>(pl_xh(base, t), pl_xl(base, t), col * kLdP + f0) +
+                  ti_f32x4{acc[t][4 * q] + bb.x, acc[t][4 * q + 1] + bb.y, acc[t][4 * q + 2] + bb.z, acc[t][4 * q + 3] + bb.w};
+        sm += (v[t][q][0] + v[t][q][1]) + (v[t][q][2] + v[t][q][3]);
+      }
+      sm += __shfl_xor(sm, 32);
+      if (half == 0) lnred[(t * 8 + wave) * 32 + col] = sm;
+    }
+    __syncthreads();
+    float mean[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float m = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) m += lnred[(t * 8 + w) * 32 + col];
+      mean[t] = m * (1.f / kD);
+      float qs = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[t][q] -= mean[t];
+        qs += (v[t][q][0] * v[t][q][0] + v[t][q][1] * v[t][q][1]) + (v[t][q][2] * v[t][q][2] + v[t][q][3] * v[t][q][3]);
+      }
+      qs += __shfl_xor(qs, 32);
+      if (half == 0) lnred[512 + (t * 8 + wave) * 32 + col] = qs;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float var = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) var += lnred[512 + (t * 8 + w) * 32 + col];
+      const float inv = 1.f / sqrtf(var * (1.f / kD) + 1e-5f);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f0 = 32 * wave + 8 * q + 4 * half;
+        const float4 gg = *reinterpret_cast<const float4*>(g + f0), bb = *reinterpret_cast<const float4*>(be + f0);
+        const ti_f32x4 o = {v[t][q][0] * inv * gg.x + bb.x, v[t][q][1] * inv * gg.y + bb.y, v[t][q][2] * inv * gg.z + bb.z,
+                            v[t][q][3] * inv * gg.w + bb.w};
+        if (to_f32) {  // (the last LayerNorm: the tile's B planes become one f32 [32][260] tile for the epilogue)
+          *reinterpret_cast<ti_f32x4*>(reinterpret_cast<float*>(pl_bh(base, t)) + col * kLdX + f0) = o;
+        } else {
+          if constexpr (WATCH) watch4(o);
+          plane_put4<SG>(pl_xh(base, t), pl_xl(base, t), col * kLdP + f0, o);
+        }
+      }
+    }
+  };
   {  // ---- x = x + o @ out_proj^T + b, transposed: wave w owns output features [32 w, 32 w + 32) for BOTH tiles
     f32x16 acc[2];
 #pragma unroll
@@ -916,40 +978,8 @@ __device__ __forceinline__ void planes_layer(_Float16* base, const InterFusedW& 
 #pragma unroll
       for (int t = 0; t < 2; ++t) mfma_h3<SG>(acc[t], wf, plane_frag<SG>(pl_bh(base, t) + frow, pl_bl(base, t) + frow, 8 * s));
     });
-    const float* b = W.out_b;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int f0 = 32 * wave + 8 * q + 4 * half, off = col * kLdP + f0;
-        ti_f32x4 v = plane_get4<SG>(pl_xh(base, t), pl_xl(base, t), off);
-        const float4 bb = *reinterpret_cast<const float4*>(b + f0);
-        v += ti_f32x4{acc[t][4 * q] + bb.x, acc[t][4 * q + 1] + bb.y, acc[t][4 * q + 2] + bb.z, acc[t][4 * q + 3] + bb.w};
-        plane_put4<SG>(pl_xh(base, t), pl_xl(base, t), off, v);
-      }
+    resid_ln(acc, W.out_b, W.ln1_w, W.ln1_b, false);
   }
-  __syncthreads();
-  // LayerNorm over the 64 rows, in place on the X planes (8 rows per wave, 4 columns per lane)
-  auto layer_norm_planes = [&](const float* __restrict__ g, const float* __restrict__ be, bool to_f32) {
-    const float4 wv = reinterpret_cast<const float4*>(g)[lane], bv = reinterpret_cast<const float4*>(be)[lane];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = wave * 8 + i, t = r >> 5, lr = r & 31, off = lr * kLdP + 4 * lane;
-      ti_f32x4 v = plane_get4<SG>(pl_xh(base, t), pl_xl(base, t), off);
-      const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / kD);
-      v -= mean;
-      const float var = wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]) * (1.f / kD);
-      const float inv = 1.f / sqrtf(var + 1e-5f);
-      v = ti_f32x4{v[0] * inv * wv.x + bv.x, v[1] * inv * wv.y + bv.y, v[2] * inv * wv.z + bv.z, v[3] * inv * wv.w + bv.w};
-      if (to_f32) {  // (the last LayerNorm: the tile's B planes become one f32 [32][260] tile for the epilogue)
-        *reinterpret_cast<ti_f32x4*>(reinterpret_cast<float*>(pl_bh(base, t)) + lr * kLdX + 4 * lane) = v;
-      } else {
-        if constexpr (WATCH) watch4(v);
-        plane_put4<SG>(pl_xh(base, t), pl_xl(base, t), off, v);
-      }
-    }
-  };
-  layer_norm_planes(W.ln1_w, W.ln1_b, false);
   __syncthreads();
   {  // ---- feed-forward, four passes of 256 hidden units; wave w: one hidden tile per pass and one output tile, both token tiles
     f32x16 acc[2];
@@ -991,20 +1021,8 @@ __device__ __forceinline__ void planes_layer(_Float16* base, const InterFusedW& 
         for (int t = 0; t < 2; ++t) mfma_h3<SG>(acc[t], wf, plane_frag<SG>(pl_bh(base, t) + frow, pl_bl(base, t) + frow, 8 * s));
       });
     }
-    const float* b2 = W.ff2_b;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int f0 = 32 * wave + 8 * q + 4 * half, off = col * kLdP + f0;
-        ti_f32x4 v = plane_get4<SG>(pl_xh(base, t), pl_xl(base, t), off);
-        const float4 bb = *reinterpret_cast<const float4*>(b2 + f0);
-        v += ti_f32x4{acc[t][4 * q] + bb.x, acc[t][4 * q + 1] + bb.y, acc[t][4 * q + 2] + bb.z, acc[t][4 * q + 3] + bb.w};
-        plane_put4<SG>(pl_xh(base, t), pl_xl(base, t), off, v);
-      }
+    resid_ln(acc, W.ff2_b, W.ln2_w, W.ln2_b, last_to_f32);  // (every wave is past its reads of the B planes and of x at the first barrier inside)
   }
-  __syncthreads();  // (also: every wave is done reading the B planes — LayerNorm 2 overwrites them with the f32 tiles)
-  layer_norm_planes(W.ln2_w, W.ln2_b, last_to_f32);
   __syncthreads();
 }
 
@@ -1021,6 +1039,7 @@ __global__ __launch_bounds__(512, 1) void text_inter_fused2_kernel(InterFusedW W
   auto BH = [&](int t) { return base + (size_t)(4 * t + 2) * kPlane; };
   auto BL = [&](int t) { return base + (size_t)(4 * t + 3) * kPlane; };
   int* grp = reinterpret_cast<int*>(base + (size_t)8 * kPlane);  // [32]: description of a tile-local row
+  float* lnred = reinterpret_cast<float*>(grp + kSP);              // [1024]: row sums of the fused residual + LayerNorm epilogues
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
   const int d0 = blockIdx.x * 2 * dpt;
@@ -1047,7 +1066,7 @@ __global__ __launch_bounds__(512, 1) void text_inter_fused2_kernel(InterFusedW W
   if (tid < kSP) grp[tid] = tid / S;
   __syncthreads();
 
-  planes_layer<SG, 4, true>(base, W, [&](int i, int j) { return grp[i] == grp[j]; }, bad, true);
+  planes_layer<SG, 4, true>(base, W, [&](int i, int j) { return grp[i] == grp[j]; }, bad, true, lnred);
   {  // x_in + layer(x_in), max over the description's S sentences: thread = (tile, column)
     const int t = tid >> 8, c = tid & 255;
     const float* y = reinterpret_cast<const float*>(BH(t));
@@ -1201,7 +1220,7 @@ __global__ __launch_bounds__(512, 1) void encode_cells2_kernel(EncParams P, t2l_
     W.in_b = L.in_b; W.out_b = L.out_b; W.ff1_b = L.ff1_b; W.ff2_b = L.ff2_b;
     W.ln1_w = L.ln1_w; W.ln1_b = L.ln1_b; W.ln2_w = L.ln2_w; W.ln2_b = L.ln2_b;
     // no padding mask: the 28 slots, zero pads included, attend and are attended to; the 4 dead rows of the tile are no keys
-    planes_layer<SG, 2, false>(base, W, [](int, int j) { return j < kS; }, bad, l == P.num_layers - 1);
+    planes_layer<SG, 2, false>(base, W, [](int, int j) { return j < kS; }, bad, l == P.num_layers - 1, hb_all);  // (hb_all: dead behind the feature MLPs)
   }
   {  // max over ALL 28 slots, then normalize: thread = (cell, column)
     const int t = tid >> 8, c = tid & 255;
@@ -1220,7 +1239,7 @@ int text_inter_fused_launch(t2l_ctx* ctx, const InterFusedW& W, bool single, con
                             hipStream_t s) {
   {
     const int dpt = kSP / S, tiles = (n_desc + 2 * dpt - 1) / (2 * dpt);
-    const size_t lds = (size_t)8 * kPlane * sizeof(_Float16) + kSP * sizeof(int);
+    const size_t lds = (size_t)8 * kPlane * sizeof(_Float16) + kSP * sizeof(int) + 1024 * sizeof(float);
     static PerDeviceOnce once2;
     if (once2.need(ctx->device)) {
       T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&text_inter_fused2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
