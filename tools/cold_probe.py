@@ -1,23 +1,31 @@
-"""dev: where the cold end-to-end path (encode cells -> db_set -> search) spends its wall time."""
-import time
-import numpy as np, torch
+import sys, time, numpy as np, torch
+sys.path.insert(0, ".")
 from text2loc_amd import synth
 from text2loc_amd.engine import Engine
-eng = Engine(0)
-eng.load_weights({k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_object_branch_weights(0).items()}, class_embed=True, color_embed=True)
-cells = synth.make_cells(11259, seed=1)
-pc = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cells.items() if k != "counts"}
-q = torch.nn.functional.normalize(torch.randn(4096, 256, device="cuda"))
-def T(f, n=5):
+N, Q = 11259, 4096
+db, qs, _ = synth.make_retrieval_problem(N, Q, 256, seed=1, noise=0.5)
+sd = synth.make_object_branch_weights(0)
+cells = synth.make_cells(N, seed=0)
+packed = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cells.items() if k != "counts"}
+dq = torch.from_numpy(qs).cuda()
+e = Engine(0)
+e.load_weights(sd, class_embed=True, color_embed=True)
+def t(fn, n=5):
+    for _ in range(2): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(n): r = f()
-    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3, r
-for _ in range(2):
-    emb = eng.encode_cells(pc); eng.db_set(emb); eng.search(q, 10)
-t_enc, emb = T(lambda: eng.encode_cells(pc))
-t_db, _ = T(lambda: eng.db_set(emb))
-t_s, _ = T(lambda: eng.search(q, 10))
-def all3():
-    eng.db_set(eng.encode_cells(pc)); return eng.search(q, 10)
-t_all, _ = T(all3)
-print("encode %.3f ms  db_set %.3f ms  search %.3f ms  all %.3f ms" % (t_enc, t_db, t_s, t_all))
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+a = torch.randn(4096, 4096, device="cuda")
+for _ in range(30): a @ a
+emb = e.encode_cells(packed)
+print("encode_cells ms", t(lambda: e.encode_cells(packed)))
+print("db_set ms", t(lambda: e.db_set(emb)))
+print("search ms", t(lambda: e.search(dq, 10)))
+print("db_set+search ms", t(lambda: (e.db_set(emb), e.search(dq, 10))))
+print("all ms", t(lambda: (e.db_set(e.encode_cells(packed)), e.search(dq, 10))))
+e.set_option("profile_events", 1)
+for _ in range(3): e.db_set(emb); e.search(dq, 10)
+torch.cuda.synchronize()
+for k in ("search_scan", "search_rerank", "search_exact", "search_fallback"):
+    print(k, e.kernel_stats(k))
+print(e.search_counters())
