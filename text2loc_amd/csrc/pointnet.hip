@@ -31,6 +31,7 @@ using train::f32x16;
 
 struct PointNetWeights {
   uint4 *w1h[3] = {}, *w2h[3] = {}, *ga1h = nullptr, *ga2h = nullptr;  // split-f16 packings of the same matrices
+  uint4* wsh[3] = {};  // levels 2 and 3: the fragments of both layers in the order a tile consumes them (WStream, pack_sa_stream)
   float4 *w1[3] = {}, *w2[3] = {};  // SA levels, packed
   float* b2[3] = {};
   float4 *ga1 = nullptr, *ga2 = nullptr;
@@ -45,7 +46,7 @@ void free_pointnet(t2l_ctx* ctx) {
   PointNetWeights* P = reinterpret_cast<PointNetWeights*>(ctx->pn);
   if (!P) return;
   for (int l = 0; l < 3; ++l)
-    for (void* p : {(void*)P->w1[l], (void*)P->w2[l], (void*)P->b2[l], (void*)P->w1h[l], (void*)P->w2h[l]})
+    for (void* p : {(void*)P->w1[l], (void*)P->w2[l], (void*)P->b2[l], (void*)P->w1h[l], (void*)P->w2h[l], (void*)P->wsh[l]})
       if (p) (void)hipFree(p);
   for (void* p : {(void*)P->ga1h, (void*)P->ga2h, (void*)P->ga1, (void*)P->ga2, (void*)P->gab2, (void*)P->lin1w, (void*)P->lin1b, (void*)P->lin2w, (void*)P->lin2b, (void*)P->ws})
     if (p) (void)hipFree(p);
@@ -120,6 +121,23 @@ static int upload(t2l_ctx* ctx, T** dst, const std::vector<float>& v) {
 }
 
 constexpr int kCin[3] = {3, 64, 128}, kH1[3] = {32, 128, 256}, kH2[3] = {64, 128, 256};
+constexpr int kWsChunk = 8;  // WStream: packed-weight steps (64 lanes x [hi 16 B | lo 16 B] = 2 KiB) per chunk of the LDS ring
+
+// The stream of an SA level for WStream: layer 1 k-step major — step (st, ft) = fragment st of feature tile ft, so that one
+// input fragment feeds the FT feature tiles back to back — padded with zero steps to a whole chunk, then layer 2 as pack_sa_l2_h
+// has it ([output tile][feature tile][2]).
+static std::vector<float> pack_sa_stream(const std::vector<float>& l1h, const std::vector<float>& l2h, int ft_tiles, int steps) {
+  std::vector<float> out;
+  out.reserve(l1h.size() + l2h.size() + kWsChunk * 512);
+  for (int st = 0; st < steps; ++st)
+    for (int ft = 0; ft < ft_tiles; ++ft) {
+      const float* src = l1h.data() + ((size_t)ft * steps + st) * 512;  // one step = 512 floats
+      out.insert(out.end(), src, src + 512);
+    }
+  out.resize((out.size() / 512 + kWsChunk - 1) / kWsChunk * kWsChunk * 512, 0.f);
+  out.insert(out.end(), l2h.begin(), l2h.end());
+  return out;
+}
 constexpr int k1p(int cin) { return ((cin + 4 + 7) / 8) * 8; }  // [x | pos_j - pos_i | 1 | 0...] padded to 8
 constexpr int k1ph(int cin) { return ((cin + 4 + 15) / 16) * 16; }  // the same row padded to 16 (split-f16 steps of 16)
 
@@ -139,10 +157,13 @@ int pointnet_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n) {
     const std::string pre = p + "sa" + std::to_string(l + 1) + ".point_conv.local_nn";
     if (!fold_block(m, pre, 0, kCin[l] + 3, kH1[l], W, b)) return fail(ctx, T2L_EINVAL, "t2l_load_weights: incomplete " + pre + ".0");
     if ((rc = upload(ctx, &P->w1[l], pack_half_split(W, &b, kH1[l], kCin[l] + 3, k1p(kCin[l]))))) return rc;
-    if ((rc = upload(ctx, &P->w1h[l], pack_split_f16(W.data(), b.data(), kH1[l], kCin[l] + 3, k1ph(kCin[l]))))) return rc;
+    const std::vector<float> l1h = pack_split_f16(W.data(), b.data(), kH1[l], kCin[l] + 3, k1ph(kCin[l]));
+    if ((rc = upload(ctx, &P->w1h[l], l1h))) return rc;
     if (!fold_block(m, pre, 1, kH1[l], kH2[l], W, b)) return fail(ctx, T2L_EINVAL, "t2l_load_weights: incomplete " + pre + ".1");
     if ((rc = upload(ctx, &P->w2[l], pack_sa_l2(W, kH2[l], kH1[l])))) return rc;
-    if ((rc = upload(ctx, &P->w2h[l], pack_sa_l2_h(W, kH2[l], kH1[l])))) return rc;
+    const std::vector<float> l2h = pack_sa_l2_h(W, kH2[l], kH1[l]);
+    if ((rc = upload(ctx, &P->w2h[l], l2h))) return rc;
+    if (kCin[l] >= 64 && (rc = upload(ctx, &P->wsh[l], pack_sa_stream(l1h, l2h, kH1[l] / 32, k1ph(kCin[l]) / 16)))) return rc;
     if ((rc = upload(ctx, &P->b2[l], b))) return rc;
   }
   if (!fold_block(m, p + "ga.mlp", 0, 259, 512, W, b)) return fail(ctx, T2L_EINVAL, "t2l_load_weights: incomplete " + p + "ga.mlp.0");
@@ -395,6 +416,7 @@ struct SaParams {
   int self_loops;
   const uint4* w1h;
   const uint4* w2h;
+  const uint4* wsh;  // levels 2 and 3: the tile's stream for WStream
   int32_t* obj_flags;  // [n_obj]: 1 = this object's magnitudes left the split-f16 range (or were not finite): f32 launches only
 };
 
@@ -506,6 +528,377 @@ __global__ __launch_bounds__(256, 1) void pn_sa_kernel(SaParams P) {
   }
   if constexpr (H != 0) {  // anything at or beyond 3e4 (or NaN: the comparison fails) entered a split product: hand the object over
     if (!(amax < kSplitF16Safe)) P.obj_flags[o] = 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Levels 2 and 3 on split / plain f16: pn_sa_ws_kernel (the centres' tiles) + pn_self_ws_kernel (the self-loop tiles).
+//
+// What limited the one-wave-per-SIMD form above on these levels (r05, 10,698 objects, dev builds and per-workgroup stamps,
+// tools/pn_exp.sh / pn_stamps.py): (1) every wave pulled a tile's packed weights (104 KB / 400 KB) out of the L2 through a
+// 4-deep register ring — 384 cycles of look-ahead against an L2 round trip of 500+; (2) with one wave per SIMD the VALU work
+// of a tile (the compiler re-split the input row's fragments at every k-step to save registers: 24 VALU per 3 MFMAs, then the
+// ReLU / split of layer 1 and the max pooling of layer 2) and every stall sat in line with the MFMAs; (3) a ninth round of
+// four tiles per object for ONE self-loop tile. The chip is power-limited on dense split-f16 MFMAs (~21 ns per 32x32x16 MFMA
+// and SIMD, 0.6 of the nominal rate: tools/pair_probe.hip), so 19,800 MFMAs per SIMD-object of level 3 cannot take less than
+// 4.3 ms; they took 7.2.
+//
+// Here a workgroup has EIGHT waves, two per SIMD (<= 256 registers each), one tile each, and runs them in lock step over ONE
+// stream of packed weights in LDS: a ring of kWsBufs chunks of kWsChunk steps filled by LDS-DMA (each wave issues its
+// rows of a chunk in one burst behind the chunk's barrier — spreading them over the steps measured slower — no registers,
+// look-ahead two chunks), fragments read with immediate offsets through a kWsDepth-deep register ring. Layer 1 runs k-step
+// major: ONE input fragment (8 values of the lane's row half, read from LDS and split when its step comes: 9 / 5 splits per
+// tile instead of 72 / 20) feeds the FT feature tiles' accumulators back to back (FT independent MFMA chains); their
+// registers turn into the split A fragments of layer 2 in place. The self-loop messages are ordinary tiles of their own
+// launch (eight per workgroup round, any object), which also finishes the level's output: the centres' kernel leaves the raw
+// maxima, the self kernel applies max(self) + bias + ReLU. No ninth round, no 32 KB of self messages in LDS.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef T2L_WS_DEPTH
+#define T2L_WS_DEPTH 2
+#endif
+constexpr int kWsBufs = 4, kWsDepth = T2L_WS_DEPTH, kWsWaves = 8;
+typedef const __attribute__((address_space(3))) uint4* lds_u4;
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p; }
+__device__ __forceinline__ int uniform_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+// global_load_lds_dwordx4: 64 lanes x 16 B to M0 + 16 lane (search_dev.h: lds_dma_row — from inline asm, so that later LDS
+// reads do not wait for vmcnt(0); the stream orders DMA against its reads itself)
+__device__ __forceinline__ void ws_dma_row(unsigned lds_row_addr, unsigned lane_off, const void* row_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_row_addr), "v"(lane_off), "s"(row_base)
+               : "memory");
+}
+
+template <bool SG>
+struct WStream {
+  static constexpr int kStepB = SG ? 1024 : 2048;  // LDS bytes per step: [64 x hi 16 B][64 x lo 16 B] (plain f16: hi only)
+  static constexpr int kChunkB = kWsChunk * kStepB, kRpw = kWsChunk * (SG ? 1 : 2) / kWsWaves;  // DMA rows per wave and chunk
+  // this wave's rows of a chunk: rows wave + 8 i = (step, half) pairs in the split form, steps in the plain form
+  static constexpr int kRowDst = SG ? kWsWaves * 1024 : (kWsWaves / 2) * 2048, kRowSrc = SG ? kWsWaves * 2048 : (kWsWaves / 2) * 2048;
+  const char* src;     // wave-uniform: the level's packed stream (2 KiB per step: lane l at 32 l = [hi | lo])
+  unsigned ring_addr;  // LDS byte address of the ring
+  unsigned lane32;
+  int wave, cpr, total;   // chunks per round, chunks this workgroup consumes
+  int g, sc;              // chunk being consumed; source chunk (inside the round) of the next one to issue
+  lds_u4 ring, cur, nxt;  // lane-offset pointers: ring start, chunk g, chunk g + 1
+
+  __device__ __forceinline__ void issue(int c, int srcchunk) const {
+    const unsigned dst = ring_addr + (unsigned)(c & (kWsBufs - 1)) * kChunkB + (SG ? wave * 1024 : (wave >> 1) * 2048 + (wave & 1) * 1024);
+    const char* sp = src + (size_t)srcchunk * (kWsChunk * 2048) + (SG ? wave * 2048 : (wave >> 1) * 2048 + (wave & 1) * 16);
+#pragma unroll
+    for (int i = 0; i < kRpw; ++i) ws_dma_row(dst + i * kRowDst, lane32, sp + i * kRowSrc);
+  }
+  __device__ __forceinline__ lds_u4 buf(int c) const { return ring + (c & (kWsBufs - 1)) * (kChunkB / 16); }
+  // the first three chunks: as early in the kernel as possible
+  __device__ __forceinline__ void open(const void* stream, float* ring_lds, int lane, int rounds, int chunks_per_round) {
+    src = reinterpret_cast<const char*>(stream);
+    ring_addr = lds_addr_of(ring_lds);
+    ring = (lds_u4)(const __attribute__((address_space(3))) char*)reinterpret_cast<const char*>(ring_lds) + lane;
+    lane32 = lane * 32;
+    wave = uniform_wave_id();
+    cpr = chunks_per_round;
+    total = rounds * chunks_per_round;
+    g = -1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      if (c < total) issue(c, c);
+    sc = 3;  // (cpr > 3)
+    nxt = buf(0);
+    cur = nxt;
+  }
+  // chunk g is consumed (or nothing yet): chunk g + 1 becomes current. After it, chunks <= g + 1 (new g) have landed for EVERY
+  // wave (loads retire in order: all but the newest burst — anything else this wave has in flight is newer still and only
+  // makes the wait longer), and every wave is done with chunk g - 1, whose buffer takes chunk g + 3.
+  __device__ __forceinline__ void boundary() {
+    g += 1;
+    if (g + 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRpw) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (s_nop: the epilogue of a tile pass reads the last MFMA's accumulator right behind this block; on the short path
+    // through these branches the compiler's hazard padding came out one or two wait states short — tools/mfma_hazard_scan.py)
+    asm volatile("s_nop 3\n\ts_barrier" ::: "memory");
+    if (g + 3 < total) {
+      issue(g + 3, sc);
+      sc = sc + 1 == cpr ? 0 : sc + 1;
+    }
+    cur = nxt;
+    nxt = buf(g + 1);
+  }
+  template <bool NEXT, int OFF>
+  __device__ __forceinline__ HFrag read() const {
+    const lds_u4 p = NEXT ? nxt : cur;
+    HFrag f;
+    f.hi = __builtin_bit_cast(h3_f16x8, p[OFF * (kStepB / 16)]);
+    if constexpr (SG) f.lo = f.hi;
+    else f.lo = __builtin_bit_cast(h3_f16x8, p[OFF * (kStepB / 16) + 64]);
+    return f;
+  }
+  __device__ __forceinline__ void start(HFrag (&wr)[kWsDepth]) {  // chunks 0 and 1 in LDS, the register ring filled
+    boundary();
+    wr[0] = read<false, 0>();
+    wr[1] = read<false, 1>();
+    if constexpr (kWsDepth > 2) {
+      wr[2 % kWsDepth] = read<false, 2>();
+      wr[3 % kWsDepth] = read<false, 3>();
+    }
+    static_assert(kWsDepth == 2 || kWsDepth == 4, "cold start of the register ring");
+  }
+};
+
+template <int CIN, int H1, int H2>
+struct SaWs {  // the geometry of a tile's stream (pack_sa_stream)
+  static constexpr int S = k1ph(CIN) / 16, FT = H1 / 32, NT = H2 / 32, STEPS1 = FT * S;
+  static constexpr int L1P = (STEPS1 + kWsChunk - 1) / kWsChunk * kWsChunk, BODY = FT * 2, TOT = L1P + NT * BODY, CPR = TOT / kWsChunk;
+  static_assert(BODY % kWsChunk == 0 && BODY % kWsDepth == 0 && STEPS1 % kWsDepth == 0 && kWsDepth + (L1P - STEPS1) <= kWsChunk && CPR > 3,
+                "WStream: chunk boundaries and register-ring slots must sit at compile-time positions");
+  static constexpr int pos(int k) { return k < STEPS1 ? k : L1P + (k - STEPS1); }  // stream position of the k-th consumed step
+};
+
+// A tile's 32 input rows, one per lane & 31: the lane's half kh of [x(CIN) | pos_j - pos_i (3) | 1 | 0..] in pieces of 8.
+// load<ST> reads piece ST (LDS or global memory), split<ST> makes the fragment of k-step ST from it. The pieces of the kh = 1
+// half behind x are the tail [dx dy dz 1 0 0 0 0] and zeros: those lanes read piece 0 instead and drop it.
+template <int CIN>
+struct TileRows {
+  static constexpr int HALF = k1ph(CIN) / 2;
+  const float* row;  // the lane's row: x[0] (LDS: sx + nb * XS; global: src_x + node * CIN)
+  int kh;
+  float dx, dy, dz;
+  template <int ST>
+  __device__ __forceinline__ h3_f32x8 load() const {
+    constexpr bool kTailOrZero = HALF + 8 * ST >= CIN;  // for the kh = 1 half
+    const float* p = row + ((kTailOrZero && kh) ? 0 : kh * HALF + 8 * ST);
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    return h3_f32x8{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  }
+  template <int ST, bool SG>
+  __device__ __forceinline__ HFrag split(h3_f32x8 v, float& amax) const {
+    constexpr int k1 = HALF + 8 * ST;
+    static_assert(k1 < CIN || (k1 - CIN) % 8 == 0, "the tail starts a piece");
+    if constexpr (k1 >= CIN) {
+      const h3_f32x8 alt = k1 == CIN ? h3_f32x8{dx, dy, dz, 1.f, 0.f, 0.f, 0.f, 0.f} : h3_f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = kh ? alt[e] : v[e];
+    }
+    const HFrag f = split_vals<SG>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], amax);
+    asm volatile("" : "+v"(amax));  // (evaluated here: relu_split_in_place)
+    return f;
+  }
+};
+
+template <int K, typename G, bool SG, typename X>
+__device__ __forceinline__ void ws_l1_steps(WStream<SG>& ws, HFrag (&wr)[kWsDepth], f32x16 (&acc)[G::FT], const X& x, h3_f32x8& xraw, HFrag& xf,
+                                            float& amax) {
+  if constexpr (K < G::STEPS1) {
+    constexpr int st = K / G::FT, ft = K % G::FT, pk = G::pos(K), pn = G::pos(K + kWsDepth);
+    if constexpr (ft == 0) xf = x.template split<st, SG>(xraw, amax);
+    if constexpr (ft == (G::FT > 1 ? 1 : 0) && st + 1 < G::S) xraw = x.template load<st + 1>();  // the next k-step's piece, FT - 1 steps ahead
+    if constexpr (st == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ft][r] = 0.f;
+    }
+    const HFrag wf = wr[K % kWsDepth];
+    wr[K % kWsDepth] = ws.template read<(pn / kWsChunk != pk / kWsChunk), pn % kWsChunk>();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_h3<SG>(acc[ft], wf, xf);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (G::pos(K + 1) / kWsChunk != pk / kWsChunk) ws.boundary();
+    ws_l1_steps<K + 1, G, SG>(ws, wr, acc, x, xraw, xf, amax);
+  }
+}
+// layer 1's accumulator tile ft after ReLU + split, IN ITS OWN REGISTERS: elements 8 m .. 8 m + 3 = the hi halves, 8 m + 4 .. 8 m + 7
+// the lo halves of the A fragment m of feature tile ft (pack_sa_l2_h orders layer 2's weights to match)
+__device__ __forceinline__ HFrag frag_of(const f32x16& t, int m) {
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  const f32x4v h = {t[8 * m], t[8 * m + 1], t[8 * m + 2], t[8 * m + 3]}, l = {t[8 * m + 4], t[8 * m + 5], t[8 * m + 6], t[8 * m + 7]};
+  HFrag f;
+  f.hi = __builtin_bit_cast(h3_f16x8, h);
+  f.lo = __builtin_bit_cast(h3_f16x8, l);
+  return f;
+}
+template <bool SG>
+__device__ __forceinline__ void relu_split_in_place(f32x16& t, float& amax) {
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const HFrag f = split_vals<SG>(fmaxf(t[8 * m], 0.f), fmaxf(t[8 * m + 1], 0.f), fmaxf(t[8 * m + 2], 0.f), fmaxf(t[8 * m + 3], 0.f),
+                                   fmaxf(t[8 * m + 4], 0.f), fmaxf(t[8 * m + 5], 0.f), fmaxf(t[8 * m + 6], 0.f), fmaxf(t[8 * m + 7], 0.f), amax);
+    const f32x4v h = __builtin_bit_cast(f32x4v, f.hi), l = __builtin_bit_cast(f32x4v, f.lo);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      t[8 * m + e] = h[e];
+      t[8 * m + 4 + e] = l[e];
+    }
+  }
+  asm volatile("" : "+v"(amax));  // here, not where amax is read: the compiler otherwise keeps the 16 f32 values alive through layer 2
+}
+template <int SI, typename G, bool SG>
+__device__ __forceinline__ void ws_l2_steps(WStream<SG>& ws, HFrag (&wr)[kWsDepth], f32x16& acc, const f32x16 (&hf)[G::FT], bool stream_goes_on) {
+  if constexpr (SI < G::BODY) {
+    constexpr int slot = (G::STEPS1 + SI) % kWsDepth, sn = SI + kWsDepth;  // sn: the step fetched now (past BODY: the next tile pass / round)
+    const HFrag wf = wr[slot];
+    if (sn < G::BODY || stream_goes_on) wr[slot] = ws.template read<(sn / kWsChunk != SI / kWsChunk), sn % kWsChunk>();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_h3<SG>(acc, frag_of(hf[SI / 2], SI % 2), wf);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr ((SI + 1) % kWsChunk == 0) ws.boundary();
+    ws_l2_steps<SI + 1, G, SG>(ws, wr, acc, hf, stream_goes_on);
+  }
+}
+
+// The edge MLP of one tile with the weights out of the workgroup's LDS stream. ALL EIGHT waves call it the same number of
+// times (a wave without a tile runs a copy of another and drops the result). wr: the register ring, holding the fragments of
+// the first kWsDepth steps on entry and, when `more` rounds follow, of the next round's on exit. emit(nt, acc) as sa_mlp_tile.
+template <int CIN, int H1, int H2, bool SG, typename X, typename Emit>
+__device__ __forceinline__ void sa_mlp_tile_ws(const X& x, WStream<SG>& ws, HFrag (&wr)[kWsDepth], bool more, float& amax, Emit&& emit) {
+  using G = SaWs<CIN, H1, H2>;
+  f32x16 acc[G::FT];  // layer 1's accumulators, then layer 2's A fragments
+  {
+    h3_f32x8 xraw = x.template load<0>();
+    HFrag xf;
+    ws_l1_steps<0, G, SG>(ws, wr, acc, x, xraw, xf, amax);
+  }
+#pragma unroll
+  for (int ft = 0; ft < G::FT; ++ft) {  // BatchNorm + bias folded; ReLU
+    relu_split_in_place<SG>(acc[ft], amax);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll 1
+  for (int nt = 0; nt < G::NT; ++nt) {
+    f32x16 out;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[r] = 0.f;
+    ws_l2_steps<0, G, SG>(ws, wr, out, acc, more || nt + 1 < G::NT);
+    emit(nt, out);
+  }
+}
+
+// farthest point sampling of one object on the calling wave: selection order from point 0, lowest index on ties (as pn_sa_kernel)
+template <int NS>
+__device__ __forceinline__ void fps_wave(const float* spos, int* sel, int lane) {
+  constexpr int ND = NS / 2, PPL = NS / 64;
+  float mind[PPL], px[PPL], py[PPL], pz[PPL];
+#pragma unroll
+  for (int q = 0; q < PPL; ++q) {
+    const int p = lane + 64 * q;
+    px[q] = spos[p * 3]; py[q] = spos[p * 3 + 1]; pz[q] = spos[p * 3 + 2];
+    mind[q] = 3.0e38f;
+  }
+  int last = 0;
+  if (lane == 0) sel[0] = 0;
+  for (int t = 1; t < ND; ++t) {
+    const float cx = spos[last * 3], cy = spos[last * 3 + 1], cz = spos[last * 3 + 2];
+    float best = -1.f;
+    int bi = 0;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+      mind[q] = fminf(mind[q], d2_noFMA(px[q], py[q], pz[q], cx, cy, cz));
+      if (mind[q] > best) { best = mind[q]; bi = lane + 64 * q; }
+    }
+    const unsigned m = wave_umax(__float_as_uint(best));  // distances are >= 0: the bit pattern orders like the value
+    last = (int)wave_umin(__float_as_uint(best) == m ? (unsigned)bi : 0x7fffffffu);
+    if (lane == 0) sel[t] = last;
+  }
+}
+
+template <int CIN, int H1, int H2, int NS, bool SG>
+__global__ __launch_bounds__(64 * kWsWaves, 1) void pn_sa_ws_kernel(SaParams P) {
+  constexpr int ND = NS / 2, XS = CIN + 4, PPL = NS / 64, NTH = 64 * kWsWaves;
+  static_assert(ND % kWsWaves == 0, "whole rounds of tiles");
+  if (P.obj_flags[blockIdx.x]) return;  // left to the f32 launch
+  float amax = 0.f;
+  extern __shared__ float smem[];
+  float* spos = smem + kWsBufs * WStream<SG>::kChunkB / 4;  // [NS][3]   (the ring comes first)
+  float* sx = spos + NS * 3;                                 // [NS][XS]
+  float* dpos = sx + NS * XS;                                // [ND][3]
+  int* sel = reinterpret_cast<int*>(dpos + ND * 3);          // [ND]
+  int* nbr = sel + ND;                                       // [8 waves][32]
+  const int o = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, kh = lane >> 5;
+  WStream<SG> ws;
+  ws.open(P.wsh, smem, lane, ND / kWsWaves, SaWs<CIN, H1, H2>::CPR);
+  const float* gp = P.src_pos + (size_t)o * NS * 3;
+  const float* gx = P.src_x + (size_t)o * NS * CIN;
+  for (int i = tid; i < NS * 3; i += NTH) spos[i] = gp[i];
+  for (int i = tid; i < NS * CIN / 4; i += NTH) {  // rows of CIN floats -> rows of XS
+    const float4 v = reinterpret_cast<const float4*>(gx)[i];
+    *reinterpret_cast<float4*>(sx + (i / (CIN / 4)) * XS + (i % (CIN / 4)) * 4) = v;
+  }
+  __syncthreads();
+  if (w == 0) fps_wave<NS>(spos, sel, lane);
+  __syncthreads();
+  for (int i = tid; i < ND * 3; i += NTH) {
+    const float v = spos[sel[i / 3] * 3 + (i % 3)];
+    dpos[i] = v;
+    P.dst_pos[(size_t)o * ND * 3 + i] = v;
+  }
+  __syncthreads();
+  HFrag wr[kWsDepth];
+  ws.start(wr);
+  // ---- one 32-row tile per centre: ball query (first 32 in index order), edge MLP, max
+  for (int t = w; t < ND; t += kWsWaves) {
+    const float cx = dpos[t * 3], cy = dpos[t * 3 + 1], cz = dpos[t * 3 + 2];
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+      const int p = lane + 64 * q;
+      const bool in = d2_noFMA(spos[p * 3], spos[p * 3 + 1], spos[p * 3 + 2], cx, cy, cz) < P.r2;
+      const unsigned long long mask = __ballot(in);
+      const int rank = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+      if (in && rank < 32) nbr[w * 32 + rank] = p;
+      cnt += __popcll(mask);
+    }
+    cnt = min(cnt, 32);  // >= 1: the centre is one of the source points
+    const int nb = nbr[w * 32 + (j < cnt ? j : 0)];
+    const TileRows<CIN> rows{sx + nb * XS, kh, spos[nb * 3] - cx, spos[nb * 3 + 1] - cy, spos[nb * 3 + 2] - cz};
+    auto pool = [&](int nt, const f32x16& acc) {
+      float m = acc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+      m = fmaxf(m, __shfl_xor(m, 32));
+      const int c = nt * 32 + j;
+      // with self-loop messages the level's output is finished by pn_self_ws_kernel: max(self) + bias, ReLU
+      if (kh == 0) P.dst_x[((size_t)o * ND + t) * H2 + c] = P.self_loops ? m : fmaxf(m + P.b2[c], 0.f);
+    };
+    sa_mlp_tile_ws<CIN, H1, H2, SG>(rows, ws, wr, t + kWsWaves < ND, amax, pool);
+  }
+  if (!(amax < kSplitF16Safe)) P.obj_flags[o] = 1;  // anything at or beyond 3e4 (or NaN) entered a split product: hand the object over
+}
+
+// The extra (k -> k) messages of PyG's add_self_loops on the bipartite batch (centre k of the CELL's batch also hears source
+// node k of the cell's batch: oracle/t2l_oracle_pointnet.py) for all objects: tile (o, tt) = centres 32 tt.. of object o. A
+// workgroup takes eight tiles per round; a tile's pass over output tile nt turns the raw maxima pn_sa_ws_kernel left into the
+// level's output.
+template <int CIN, int H1, int H2, int NS, bool SG>
+__global__ __launch_bounds__(64 * kWsWaves, 1) void pn_self_ws_kernel(SaParams P, int n_obj) {
+  constexpr int ND = NS / 2, TPO = ND / 32;
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, kh = lane >> 5;
+  const int n_tiles = n_obj * TPO, per_round = kWsWaves * (int)gridDim.x, rounds = (n_tiles + per_round - 1) / per_round;
+  WStream<SG> ws;
+  ws.open(P.wsh, smem, lane, rounds, SaWs<CIN, H1, H2>::CPR);
+  HFrag wr[kWsDepth];
+  ws.start(wr);
+  for (int r = 0; r < rounds; ++r) {
+    const int id = (r * (int)gridDim.x + (int)blockIdx.x) * kWsWaves + w;
+    bool live = id < n_tiles;
+    const int o = live ? id / TPO : 0, tt = live ? id % TPO : 0;
+    live = live && !P.obj_flags[o];
+    const int cb = P.cell_base[o], t = tt * 32 + j;
+    const size_t node = (size_t)cb * NS + (size_t)(o - cb) * ND + t;  // source node k = (o - cb) ND + t of the cell's batch
+    const float* sp = P.src_pos + node * 3;
+    const float* dp = P.dst_pos + ((size_t)o * ND + t) * 3;
+    const TileRows<CIN> rows{P.src_x + node * CIN, kh, sp[0] - dp[0], sp[1] - dp[1], sp[2] - dp[2]};
+    float amax = 0.f;
+    auto finish = [&](int nt, const f32x16& acc) {
+      if (live) {
+        const int c = nt * 32 + j;
+        const float b = P.b2[c];
+        float* out = P.dst_x + ((size_t)o * ND + tt * 32 + 4 * kh) * H2 + c;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          float* pq = out + (size_t)((q & 3) + 8 * (q >> 2)) * H2;
+          *pq = fmaxf(fmaxf(*pq, acc[q]) + b, 0.f);
+        }
+      }
+    };
+    sa_mlp_tile_ws<CIN, H1, H2, SG>(rows, ws, wr, r + 1 < rounds, amax, finish);
+    if (live && !(amax < kSplitF16Safe)) P.obj_flags[o] = 1;
   }
 }
 
@@ -710,6 +1103,32 @@ static size_t sa_lds_bytes() {
   constexpr int ND = NS / 2, XS = CIN + 4;
   return sizeof(float) * (NS * 3 + NS * XS + ND * 3 + ND * H2) + sizeof(int) * (ND + 4 * 32);
 }
+template <int CIN, int NS, bool SG>
+static size_t sa_ws_lds_bytes() {
+  constexpr int ND = NS / 2, XS = CIN + 4;
+  return (size_t)kWsBufs * WStream<SG>::kChunkB + sizeof(float) * (NS * 3 + NS * XS + ND * 3) + sizeof(int) * (ND + kWsWaves * 32);
+}
+
+// levels 2 and 3, split or plain f16: the centres' tiles, then the self-loop tiles (which finish the output)
+template <int CIN, int H1, int H2, int NS, bool SG>
+static hipError_t launch_sa_ws(const SaParams& P, int n_obj, hipStream_t s) {
+  const size_t lds = sa_ws_lds_bytes<CIN, NS, SG>(), lds_self = (size_t)kWsBufs * WStream<SG>::kChunkB;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  static PerDeviceOnce attr;
+  if (attr.need(dev)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_ws_kernel<CIN, H1, H2, NS, SG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr.mark(dev);
+  }
+  hipLaunchKernelGGL((pn_sa_ws_kernel<CIN, H1, H2, NS, SG>), dim3(n_obj), dim3(64 * kWsWaves), lds, s, P);
+  if (P.self_loops) {
+    const int n_tiles = n_obj * (NS / 64), grid = std::min(256, (n_tiles + kWsWaves - 1) / kWsWaves);
+    hipLaunchKernelGGL((pn_self_ws_kernel<CIN, H1, H2, NS, SG>), dim3(grid), dim3(64 * kWsWaves), lds_self, s, P, n_obj);
+  }
+  return hipGetLastError();
+}
 
 // split = true: the split-f16 launch over all objects (it skips flagged ones and flags new ones) followed by the f32 launch
 // that serves exactly the flagged objects; split = false: one f32 launch over everything (P.obj_flags must be null)
@@ -720,19 +1139,28 @@ static hipError_t launch_sa(const SaParams& P, int n_obj, bool split, bool singl
   (void)hipGetDevice(&dev);
   static PerDeviceOnce attr;
   if (attr.need(dev)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_kernel<CIN, H1, H2, NS, 1>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_kernel<CIN, H1, H2, NS, 0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_kernel<CIN, H1, H2, NS, 2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_kernel<CIN, H1, H2, NS, 0>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if constexpr (CIN < 64) {
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_kernel<CIN, H1, H2, NS, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_sa_kernel<CIN, H1, H2, NS, 2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     if (e != hipSuccess) return e;
     attr.mark(dev);
   }
-  if (split && single) hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, 2>), dim3(n_obj), dim3(256), lds, s, P);  // option encoder_f16
-  else if (split) hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, 1>), dim3(n_obj), dim3(256), lds, s, P);
+  if constexpr (CIN >= 64) {
+    if (split) {
+      const hipError_t e = single ? launch_sa_ws<CIN, H1, H2, NS, true>(P, n_obj, s) : launch_sa_ws<CIN, H1, H2, NS, false>(P, n_obj, s);
+      if (e != hipSuccess) return e;
+    }
+  } else {
+    if (split && single) hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, 2>), dim3(n_obj), dim3(256), lds, s, P);  // option encoder_f16
+    else if (split) hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, 1>), dim3(n_obj), dim3(256), lds, s, P);
+  }
   hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, 0>), dim3(n_obj), dim3(256), lds, s, P);
   return hipGetLastError();
 }
@@ -775,11 +1203,11 @@ int pointnet_features_impl(t2l_ctx* ctx, const float* pos, const float* rgb, con
   T2L_HIP(ctx, hipStreamSynchronize(s));  // `base` is a host temporary
   event_begin(ctx, "pointnet", s);
   const float radii[3] = {0.2f, 0.3f, 0.4f};
-  SaParams P{pos, rgb, p1, x1, d_base, W->w1[0], W->w2[0], W->b2[0], radii[0] * radii[0], ctx->pn_self_loops, W->w1h[0], W->w2h[0], d_flags};
+  SaParams P{pos, rgb, p1, x1, d_base, W->w1[0], W->w2[0], W->b2[0], radii[0] * radii[0], ctx->pn_self_loops, W->w1h[0], W->w2h[0], W->wsh[0], d_flags};
   T2L_HIP(ctx, (launch_sa<3, 32, 64, 256>(P, n_obj, split, ctx->encoder_f16 != 0, s)));
-  P = SaParams{p1, x1, p2, x2, d_base, W->w1[1], W->w2[1], W->b2[1], radii[1] * radii[1], ctx->pn_self_loops, W->w1h[1], W->w2h[1], d_flags};
+  P = SaParams{p1, x1, p2, x2, d_base, W->w1[1], W->w2[1], W->b2[1], radii[1] * radii[1], ctx->pn_self_loops, W->w1h[1], W->w2h[1], W->wsh[1], d_flags};
   T2L_HIP(ctx, (launch_sa<64, 128, 128, 128>(P, n_obj, split, ctx->encoder_f16 != 0, s)));
-  P = SaParams{p2, x2, p3, x3, d_base, W->w1[2], W->w2[2], W->b2[2], radii[2] * radii[2], ctx->pn_self_loops, W->w1h[2], W->w2h[2], d_flags};
+  P = SaParams{p2, x2, p3, x3, d_base, W->w1[2], W->w2[2], W->b2[2], radii[2] * radii[2], ctx->pn_self_loops, W->w1h[2], W->w2h[2], W->wsh[2], d_flags};
   T2L_HIP(ctx, (launch_sa<128, 256, 256, 64>(P, n_obj, split, ctx->encoder_f16 != 0, s)));
   {
     const size_t lds_h = sizeof(float) * (32 * (ga_k(true) + 4) + 32 * kGaHS), lds_f = sizeof(float) * (32 * (ga_k(false) + 4) + 32 * kGaHS);
