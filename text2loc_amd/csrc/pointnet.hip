@@ -287,9 +287,31 @@ __device__ __forceinline__ HFrag split_vals(float v0, float v1, float v2, float 
   const h3_f32x8 v = {v0, v1, v2, v3, v4, v5, v6, v7};
   HFrag f;
   f.hi = __builtin_convertvector(v, h3_f16x8);
-  if constexpr (SG) f.lo = f.hi;  // (never read)
-  else f.lo = __builtin_convertvector(v - __builtin_convertvector(f.hi, h3_f32x8), h3_f16x8);
+  if constexpr (SG) {
+    f.lo = f.hi;  // (never read)
+  } else {  // v - hi (exact in f32) as ONE v_fma_mix_f32 per value, reading the packed half in place: no unpacking conversions
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    const u32x4v p = __builtin_bit_cast(u32x4v, f.hi);
+    h3_f32x8 d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d[2 * e]) : "v"(p[e]), "v"(v[2 * e]));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d[2 * e + 1]) : "v"(p[e]), "v"(v[2 * e + 1]));
+    }
+    f.lo = __builtin_convertvector(d, h3_f16x8);
+  }
   return f;
+}
+// max of the 16 accumulator registers of a lane: v_max3 from asm (fmaxf quiets every operand first: 31 VALU ops instead of 8)
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float max16(const f32x16& a) {
+  const float t0 = vmax3(a[0], a[1], a[2]), t1 = vmax3(a[3], a[4], a[5]), t2 = vmax3(a[6], a[7], a[8]), t3 = vmax3(a[9], a[10], a[11]),
+              t4 = vmax3(a[12], a[13], a[14]);
+  return vmax3(vmax3(t0, t1, t2), vmax3(t3, t4, a[15]), a[15]);
 }
 
 // The steps of the two layers as template recursions (the compiler does not unroll a 72-step loop with this body, and
@@ -516,9 +538,7 @@ __global__ __launch_bounds__(256, 1) void pn_sa_kernel(SaParams P) {
     float xrow[HALF];
     build_xrow<CIN, HALF>(sx + nb * XS, spos[nb * 3] - cx, spos[nb * 3 + 1] - cy, spos[nb * 3 + 2] - cz, kh, xrow);
     auto pool = [&](int nt, const f32x16& acc) {
-      float m = acc[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+      float m = max16(acc);
       m = fmaxf(m, __shfl_xor(m, 32));
       const int c = nt * 32 + j;
       if (kh == 0) P.dst_x[((size_t)o * ND + t) * H2 + c] = fmaxf(fmaxf(m, selfm[t * H2 + c]) + P.b2[c], 0.f);
@@ -797,6 +817,24 @@ __device__ __forceinline__ void fps_wave(const float* spos, int* sel, int lane) 
   }
 }
 
+// The centres of a level for all (unflagged) objects, one wave per object: inside pn_sa_ws_kernel the sampling loop (ND dependent
+// steps of two wave reductions) ran on one of eight waves while the CU's only workgroup waited — 8 of level 2's 84 us per object.
+template <int NS>
+__global__ __launch_bounds__(256) void pn_fps_kernel(const float* __restrict__ src_pos, float* __restrict__ dst_pos,
+                                                     const int32_t* __restrict__ obj_flags, int n_obj) {
+  constexpr int ND = NS / 2;
+  __shared__ float spos_all[4][NS * 3];
+  __shared__ int sel_all[4][ND];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, o = blockIdx.x * 4 + w;
+  if (o >= n_obj || obj_flags[o]) return;  // (no workgroup barrier below: the waves are independent)
+  float* spos = spos_all[w];
+  int* sel = sel_all[w];
+  const float* gp = src_pos + (size_t)o * NS * 3;
+  for (int i = lane; i < NS * 3; i += 64) spos[i] = gp[i];
+  fps_wave<NS>(spos, sel, lane);
+  for (int i = lane; i < ND * 3; i += 64) dst_pos[(size_t)o * ND * 3 + i] = spos[sel[i / 3] * 3 + (i % 3)];
+}
+
 template <int CIN, int H1, int H2, int NS, bool SG>
 __global__ __launch_bounds__(64 * kWsWaves, 1) void pn_sa_ws_kernel(SaParams P) {
   constexpr int ND = NS / 2, XS = CIN + 4, PPL = NS / 64, NTH = 64 * kWsWaves;
@@ -807,8 +845,7 @@ __global__ __launch_bounds__(64 * kWsWaves, 1) void pn_sa_ws_kernel(SaParams P) 
   float* spos = smem + kWsBufs * WStream<SG>::kChunkB / 4;  // [NS][3]   (the ring comes first)
   float* sx = spos + NS * 3;                                 // [NS][XS]
   float* dpos = sx + NS * XS;                                // [ND][3]
-  int* sel = reinterpret_cast<int*>(dpos + ND * 3);          // [ND]
-  int* nbr = sel + ND;                                       // [8 waves][32]
+  int* nbr = reinterpret_cast<int*>(dpos + ND * 3);          // [8 waves][32]
   const int o = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, kh = lane >> 5;
   WStream<SG> ws;
   ws.open(P.wsh, smem, lane, ND / kWsWaves, SaWs<CIN, H1, H2>::CPR);
@@ -819,17 +856,9 @@ __global__ __launch_bounds__(64 * kWsWaves, 1) void pn_sa_ws_kernel(SaParams P) 
     const float4 v = reinterpret_cast<const float4*>(gx)[i];
     *reinterpret_cast<float4*>(sx + (i / (CIN / 4)) * XS + (i % (CIN / 4)) * 4) = v;
   }
-  __syncthreads();
-  if (w == 0) fps_wave<NS>(spos, sel, lane);
-  __syncthreads();
-  for (int i = tid; i < ND * 3; i += NTH) {
-    const float v = spos[sel[i / 3] * 3 + (i % 3)];
-    dpos[i] = v;
-    P.dst_pos[(size_t)o * ND * 3 + i] = v;
-  }
-  __syncthreads();
+  for (int i = tid; i < ND * 3; i += NTH) dpos[i] = P.dst_pos[(size_t)o * ND * 3 + i];  // pn_fps_kernel
   HFrag wr[kWsDepth];
-  ws.start(wr);
+  ws.start(wr);  // (its barrier publishes the loads above)
   // ---- one 32-row tile per centre: ball query (first 32 in index order), edge MLP, max
   for (int t = w; t < ND; t += kWsWaves) {
     const float cx = dpos[t * 3], cy = dpos[t * 3 + 1], cz = dpos[t * 3 + 2];
@@ -847,9 +876,7 @@ __global__ __launch_bounds__(64 * kWsWaves, 1) void pn_sa_ws_kernel(SaParams P) 
     const int nb = nbr[w * 32 + (j < cnt ? j : 0)];
     const TileRows<CIN> rows{sx + nb * XS, kh, spos[nb * 3] - cx, spos[nb * 3 + 1] - cy, spos[nb * 3 + 2] - cz};
     auto pool = [&](int nt, const f32x16& acc) {
-      float m = acc[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+      float m = max16(acc);
       m = fmaxf(m, __shfl_xor(m, 32));
       const int c = nt * 32 + j;
       // with self-loop messages the level's output is finished by pn_self_ws_kernel: max(self) + bias, ReLU
@@ -1106,7 +1133,7 @@ static size_t sa_lds_bytes() {
 template <int CIN, int NS, bool SG>
 static size_t sa_ws_lds_bytes() {
   constexpr int ND = NS / 2, XS = CIN + 4;
-  return (size_t)kWsBufs * WStream<SG>::kChunkB + sizeof(float) * (NS * 3 + NS * XS + ND * 3) + sizeof(int) * (ND + kWsWaves * 32);
+  return (size_t)kWsBufs * WStream<SG>::kChunkB + sizeof(float) * (NS * 3 + NS * XS + ND * 3) + sizeof(int) * (kWsWaves * 32);
 }
 
 // levels 2 and 3, split or plain f16: the centres' tiles, then the self-loop tiles (which finish the output)
@@ -1122,6 +1149,7 @@ static hipError_t launch_sa_ws(const SaParams& P, int n_obj, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr.mark(dev);
   }
+  hipLaunchKernelGGL((pn_fps_kernel<NS>), dim3((n_obj + 3) / 4), dim3(256), 0, s, P.src_pos, P.dst_pos, P.obj_flags, n_obj);
   hipLaunchKernelGGL((pn_sa_ws_kernel<CIN, H1, H2, NS, SG>), dim3(n_obj), dim3(64 * kWsWaves), lds, s, P);
   if (P.self_loops) {
     const int n_tiles = n_obj * (NS / 64), grid = std::min(256, (n_tiles + kWsWaves - 1) / kWsWaves);
