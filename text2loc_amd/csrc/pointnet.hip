@@ -10,12 +10,16 @@
 // all-f32-MFMA launch that follows every split launch recomputes exactly the flagged objects (flags are sticky down the
 // levels). Option encoder_f32 forces the f32 kernels.
 //
-// One workgroup per object and level. FPS runs on one wave (DPP all-reduces, no LDS traffic in the loop). Every centre's
-// ball query is a wave-level ballot compaction ("first 32 in index order"). The two-layer edge MLP of a centre is one
-// 32-row tile (its <= 32 neighbours; empty slots repeat neighbour 0, harmless under max): layer 1 is computed TRANSPOSED
-// (features x neighbours) so that its MFMA output registers ARE the A operand of layer 2 — no LDS round trip between the
-// layers; BatchNorm and the Linear bias are folded on the host (bias rides on a constant-1 input column), weights are
-// pre-packed in operand order so every wave-level weight load is one coalesced 1 KiB line out of L2.
+// Level 1 (6 -> 32 -> 64 over 256 points) and the all-f32 kernels: one workgroup per object and level (pn_sa_kernel). FPS runs
+// on one wave (DPP all-reduces, no LDS traffic in the loop). Every centre's ball query is a wave-level ballot compaction
+// ("first 32 in index order"). The two-layer edge MLP of a centre is one 32-row tile (its <= 32 neighbours; empty slots repeat
+// neighbour 0, harmless under max): layer 1 is computed TRANSPOSED (features x neighbours) so that its MFMA output registers
+// ARE the A operand of layer 2 — no LDS round trip between the layers; BatchNorm and the Linear bias are folded on the host
+// (bias rides on a constant-1 input column), weights are pre-packed in operand order so every wave-level weight load is one
+// coalesced 1 KiB line out of L2.
+// Levels 2 and 3 and the global MLP on split / plain f16 (92 % of the arithmetic): pn_fps_kernel + pn_sa_ws_kernel +
+// pn_self_ws_kernel + pn_ga_ws_kernel — workgroups whose waves run their tiles in lock step over ONE stream of packed weights
+// in LDS (WStream, below).
 #include <math.h>
 #include <string.h>
 
@@ -30,7 +34,8 @@ using train::f32x16;
 
 
 struct PointNetWeights {
-  uint4 *w1h[3] = {}, *w2h[3] = {}, *ga1h = nullptr, *ga2h = nullptr;  // split-f16 packings of the same matrices
+  uint4 *w1h[3] = {}, *w2h[3] = {};  // split-f16 packings of the same matrices (level 1; the other levels read streams)
+  uint4* gash = nullptr;  // the global MLP's stream (same form)
   uint4* wsh[3] = {};  // levels 2 and 3: the fragments of both layers in the order a tile consumes them (WStream, pack_sa_stream)
   float4 *w1[3] = {}, *w2[3] = {};  // SA levels, packed
   float* b2[3] = {};
@@ -48,7 +53,7 @@ void free_pointnet(t2l_ctx* ctx) {
   for (int l = 0; l < 3; ++l)
     for (void* p : {(void*)P->w1[l], (void*)P->w2[l], (void*)P->b2[l], (void*)P->w1h[l], (void*)P->w2h[l], (void*)P->wsh[l]})
       if (p) (void)hipFree(p);
-  for (void* p : {(void*)P->ga1h, (void*)P->ga2h, (void*)P->ga1, (void*)P->ga2, (void*)P->gab2, (void*)P->lin1w, (void*)P->lin1b, (void*)P->lin2w, (void*)P->lin2b, (void*)P->ws})
+  for (void* p : {(void*)P->gash, (void*)P->ga1, (void*)P->ga2, (void*)P->gab2, (void*)P->lin1w, (void*)P->lin1b, (void*)P->lin2w, (void*)P->lin2b, (void*)P->ws})
     if (p) (void)hipFree(p);
   delete P;
   ctx->pn = nullptr;
@@ -158,20 +163,20 @@ int pointnet_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n) {
     if (!fold_block(m, pre, 0, kCin[l] + 3, kH1[l], W, b)) return fail(ctx, T2L_EINVAL, "t2l_load_weights: incomplete " + pre + ".0");
     if ((rc = upload(ctx, &P->w1[l], pack_half_split(W, &b, kH1[l], kCin[l] + 3, k1p(kCin[l]))))) return rc;
     const std::vector<float> l1h = pack_split_f16(W.data(), b.data(), kH1[l], kCin[l] + 3, k1ph(kCin[l]));
-    if ((rc = upload(ctx, &P->w1h[l], l1h))) return rc;
+    if (kCin[l] < 64 && (rc = upload(ctx, &P->w1h[l], l1h))) return rc;
     if (!fold_block(m, pre, 1, kH1[l], kH2[l], W, b)) return fail(ctx, T2L_EINVAL, "t2l_load_weights: incomplete " + pre + ".1");
     if ((rc = upload(ctx, &P->w2[l], pack_sa_l2(W, kH2[l], kH1[l])))) return rc;
     const std::vector<float> l2h = pack_sa_l2_h(W, kH2[l], kH1[l]);
-    if ((rc = upload(ctx, &P->w2h[l], l2h))) return rc;
+    if (kCin[l] < 64 && (rc = upload(ctx, &P->w2h[l], l2h))) return rc;
     if (kCin[l] >= 64 && (rc = upload(ctx, &P->wsh[l], pack_sa_stream(l1h, l2h, kH1[l] / 32, k1ph(kCin[l]) / 16)))) return rc;
     if ((rc = upload(ctx, &P->b2[l], b))) return rc;
   }
   if (!fold_block(m, p + "ga.mlp", 0, 259, 512, W, b)) return fail(ctx, T2L_EINVAL, "t2l_load_weights: incomplete " + p + "ga.mlp.0");
   if ((rc = upload(ctx, &P->ga1, pack_half_split(W, &b, 512, 259, 264)))) return rc;
-  if ((rc = upload(ctx, &P->ga1h, pack_split_f16(W.data(), b.data(), 512, 259, 272)))) return rc;
+  const std::vector<float> ga1h = pack_split_f16(W.data(), b.data(), 512, 259, 272);
   if (!fold_block(m, p + "ga.mlp", 1, 512, 1024, W, b)) return fail(ctx, T2L_EINVAL, "t2l_load_weights: incomplete " + p + "ga.mlp.1");
+  if ((rc = upload(ctx, &P->gash, pack_sa_stream(ga1h, pack_sa_l2_h(W, 1024, 512), 512 / 32, 272 / 16)))) return rc;
   if ((rc = upload(ctx, &P->ga2, pack_half_split(W, nullptr, 1024, 512, 512)))) return rc;
-  if ((rc = upload(ctx, &P->ga2h, pack_split_f16(W.data(), nullptr, 1024, 512, 512)))) return rc;
   if ((rc = upload(ctx, &P->gab2, b))) return rc;
   auto raw = [&](const char* name, int64_t numel, float** dst) -> int {
     auto it = m.find(p + name);
@@ -587,12 +592,12 @@ __device__ __forceinline__ void ws_dma_row(unsigned lds_row_addr, unsigned lane_
                : "memory");
 }
 
-template <bool SG>
+template <bool SG, int NW = kWsWaves>  // NW waves consume (and fetch) the stream
 struct WStream {
   static constexpr int kStepB = SG ? 1024 : 2048;  // LDS bytes per step: [64 x hi 16 B][64 x lo 16 B] (plain f16: hi only)
-  static constexpr int kChunkB = kWsChunk * kStepB, kRpw = kWsChunk * (SG ? 1 : 2) / kWsWaves;  // DMA rows per wave and chunk
-  // this wave's rows of a chunk: rows wave + 8 i = (step, half) pairs in the split form, steps in the plain form
-  static constexpr int kRowDst = SG ? kWsWaves * 1024 : (kWsWaves / 2) * 2048, kRowSrc = SG ? kWsWaves * 2048 : (kWsWaves / 2) * 2048;
+  static constexpr int kChunkB = kWsChunk * kStepB, kRpw = kWsChunk * (SG ? 1 : 2) / NW;  // DMA rows per wave and chunk
+  // this wave's rows of a chunk: rows wave + NW i = (step, half) pairs in the split form, steps in the plain form
+  static constexpr int kRowDst = SG ? NW * 1024 : (NW / 2) * 2048, kRowSrc = SG ? NW * 2048 : (NW / 2) * 2048;
   const char* src;     // wave-uniform: the level's packed stream (2 KiB per step: lane l at 32 l = [hi | lo])
   unsigned ring_addr;  // LDS byte address of the ring
   unsigned lane32;
@@ -702,8 +707,8 @@ struct TileRows {
   }
 };
 
-template <int K, typename G, bool SG, typename X>
-__device__ __forceinline__ void ws_l1_steps(WStream<SG>& ws, HFrag (&wr)[kWsDepth], f32x16 (&acc)[G::FT], const X& x, h3_f32x8& xraw, HFrag& xf,
+template <int K, typename G, bool SG, int NW, typename X>
+__device__ __forceinline__ void ws_l1_steps(WStream<SG, NW>& ws, HFrag (&wr)[kWsDepth], f32x16 (&acc)[G::FT], const X& x, h3_f32x8& xraw, HFrag& xf,
                                             float& amax) {
   if constexpr (K < G::STEPS1) {
     constexpr int st = K / G::FT, ft = K % G::FT, pk = G::pos(K), pn = G::pos(K + kWsDepth);
@@ -719,7 +724,7 @@ __device__ __forceinline__ void ws_l1_steps(WStream<SG>& ws, HFrag (&wr)[kWsDept
     mfma_h3<SG>(acc[ft], wf, xf);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (G::pos(K + 1) / kWsChunk != pk / kWsChunk) ws.boundary();
-    ws_l1_steps<K + 1, G, SG>(ws, wr, acc, x, xraw, xf, amax);
+    ws_l1_steps<K + 1, G, SG, NW>(ws, wr, acc, x, xraw, xf, amax);
   }
 }
 // layer 1's accumulator tile ft after ReLU + split, IN ITS OWN REGISTERS: elements 8 m .. 8 m + 3 = the hi halves, 8 m + 4 .. 8 m + 7
@@ -748,8 +753,8 @@ __device__ __forceinline__ void relu_split_in_place(f32x16& t, float& amax) {
   }
   asm volatile("" : "+v"(amax));  // here, not where amax is read: the compiler otherwise keeps the 16 f32 values alive through layer 2
 }
-template <int SI, typename G, bool SG>
-__device__ __forceinline__ void ws_l2_steps(WStream<SG>& ws, HFrag (&wr)[kWsDepth], f32x16& acc, const f32x16 (&hf)[G::FT], bool stream_goes_on) {
+template <int SI, typename G, bool SG, int NW>
+__device__ __forceinline__ void ws_l2_steps(WStream<SG, NW>& ws, HFrag (&wr)[kWsDepth], f32x16& acc, const f32x16 (&hf)[G::FT], bool stream_goes_on) {
   if constexpr (SI < G::BODY) {
     constexpr int slot = (G::STEPS1 + SI) % kWsDepth, sn = SI + kWsDepth;  // sn: the step fetched now (past BODY: the next tile pass / round)
     const HFrag wf = wr[slot];
@@ -758,21 +763,21 @@ __device__ __forceinline__ void ws_l2_steps(WStream<SG>& ws, HFrag (&wr)[kWsDept
     mfma_h3<SG>(acc, frag_of(hf[SI / 2], SI % 2), wf);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr ((SI + 1) % kWsChunk == 0) ws.boundary();
-    ws_l2_steps<SI + 1, G, SG>(ws, wr, acc, hf, stream_goes_on);
+    ws_l2_steps<SI + 1, G, SG, NW>(ws, wr, acc, hf, stream_goes_on);
   }
 }
 
 // The edge MLP of one tile with the weights out of the workgroup's LDS stream. ALL EIGHT waves call it the same number of
 // times (a wave without a tile runs a copy of another and drops the result). wr: the register ring, holding the fragments of
 // the first kWsDepth steps on entry and, when `more` rounds follow, of the next round's on exit. emit(nt, acc) as sa_mlp_tile.
-template <int CIN, int H1, int H2, bool SG, typename X, typename Emit>
-__device__ __forceinline__ void sa_mlp_tile_ws(const X& x, WStream<SG>& ws, HFrag (&wr)[kWsDepth], bool more, float& amax, Emit&& emit) {
+template <int CIN, int H1, int H2, bool SG, int NW, typename X, typename Emit>
+__device__ __forceinline__ void sa_mlp_tile_ws(const X& x, WStream<SG, NW>& ws, HFrag (&wr)[kWsDepth], bool more, float& amax, Emit&& emit) {
   using G = SaWs<CIN, H1, H2>;
   f32x16 acc[G::FT];  // layer 1's accumulators, then layer 2's A fragments
   {
     h3_f32x8 xraw = x.template load<0>();
     HFrag xf;
-    ws_l1_steps<0, G, SG>(ws, wr, acc, x, xraw, xf, amax);
+    ws_l1_steps<0, G, SG, NW>(ws, wr, acc, x, xraw, xf, amax);
   }
 #pragma unroll
   for (int ft = 0; ft < G::FT; ++ft) {  // BatchNorm + bias folded; ReLU
@@ -784,7 +789,7 @@ __device__ __forceinline__ void sa_mlp_tile_ws(const X& x, WStream<SG>& ws, HFra
     f32x16 out;
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[r] = 0.f;
-    ws_l2_steps<0, G, SG>(ws, wr, out, acc, more || nt + 1 < G::NT);
+    ws_l2_steps<0, G, SG, NW>(ws, wr, out, acc, more || nt + 1 < G::NT);
     emit(nt, out);
   }
 }
@@ -882,7 +887,7 @@ __global__ __launch_bounds__(64 * kWsWaves, 1) void pn_sa_ws_kernel(SaParams P) 
       // with self-loop messages the level's output is finished by pn_self_ws_kernel: max(self) + bias, ReLU
       if (kh == 0) P.dst_x[((size_t)o * ND + t) * H2 + c] = P.self_loops ? m : fmaxf(m + P.b2[c], 0.f);
     };
-    sa_mlp_tile_ws<CIN, H1, H2, SG>(rows, ws, wr, t + kWsWaves < ND, amax, pool);
+    sa_mlp_tile_ws<CIN, H1, H2, SG, kWsWaves>(rows, ws, wr, t + kWsWaves < ND, amax, pool);
   }
   if (!(amax < kSplitF16Safe)) P.obj_flags[o] = 1;  // anything at or beyond 3e4 (or NaN) entered a split product: hand the object over
 }
@@ -924,33 +929,58 @@ __global__ __launch_bounds__(64 * kWsWaves, 1) void pn_self_ws_kernel(SaParams P
         }
       }
     };
-    sa_mlp_tile_ws<CIN, H1, H2, SG>(rows, ws, wr, r + 1 < rounds, amax, finish);
+    sa_mlp_tile_ws<CIN, H1, H2, SG, kWsWaves>(rows, ws, wr, r + 1 < rounds, amax, finish);
     if (live && !(amax < kSplitF16Safe)) P.obj_flags[o] = 1;
   }
 }
 
-// GlobalAbstraction: get_mlp([259,512,1024]) over the 32 points of an object, max. One workgroup per object. The 512-wide
-// hidden layer passes through LDS in two halves of 256 units (the units k-steps [32 hf, 32 hf + 32) of the half-split
-// packing of the second Linear cover) while the 1024 outputs (8 column tiles per wave) accumulate in registers:
-// 68 KB of LDS instead of 100 KB, two objects per CU.
-constexpr int kGaH1 = 512, kGaHS = 256 + 4, kGaH2 = 1024;
-constexpr int ga_k(bool h) { return h ? 272 : 264; }  // [x(256) | pos(3) | 1 | 0..] padded to 8 (f32 steps) / 16 (split-f16 steps)
-template <int H>
+// GlobalAbstraction on split / plain f16 through the same machinery: an object's 32 points are one tile of get_mlp([259,512,1024])
+// ([x(256) | pos(3) | 1] rows straight from global memory, 16 feature tiles = 256 accumulator registers, so ONE wave per SIMD), four
+// objects per workgroup round share the 2.6 MB stream of packed weights that pn_ga_kernel below pulls out of the L2 once per object.
+constexpr int kGaWaves = 4;
+template <bool SG>
+__global__ __launch_bounds__(64 * kGaWaves, 1) void pn_ga_ws_kernel(const float* __restrict__ pos3, const float* __restrict__ x3,
+                                                                    const uint4* __restrict__ stream, const float* __restrict__ b2,
+                                                                    float* __restrict__ f0, int32_t* __restrict__ obj_flags, int n_obj) {
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, kh = lane >> 5;
+  const int per_round = kGaWaves * (int)gridDim.x, rounds = (n_obj + per_round - 1) / per_round;
+  WStream<SG, kGaWaves> ws;
+  ws.open(stream, smem, lane, rounds, SaWs<256, 512, 1024>::CPR);
+  HFrag wr[kWsDepth];
+  ws.start(wr);
+  for (int r = 0; r < rounds; ++r) {
+    const int id = (r * (int)gridDim.x + (int)blockIdx.x) * kGaWaves + w;
+    const bool live = id < n_obj && !obj_flags[id < n_obj ? id : 0];
+    const int o = live ? id : 0;
+    const float* pp = pos3 + ((size_t)o * 32 + j) * 3;
+    const TileRows<256> rows{x3 + ((size_t)o * 32 + j) * 256, kh, pp[0], pp[1], pp[2]};
+    float amax = 0.f;
+    auto pool = [&](int nt, const f32x16& acc) {
+      float m = max16(acc);
+      m = fmaxf(m, __shfl_xor(m, 32));
+      const int c = nt * 32 + j;
+      if (live && kh == 0) f0[(size_t)o * 1024 + c] = fmaxf(m + b2[c], 0.f);
+    };
+    sa_mlp_tile_ws<256, 512, 1024, SG, kGaWaves>(rows, ws, wr, r + 1 < rounds, amax, pool);
+    if (live && !(amax < kSplitF16Safe)) obj_flags[o] = 1;
+  }
+}
+
+// GlobalAbstraction on the f32 MFMA (option encoder_f32, and the objects the split launch flagged): get_mlp([259,512,1024]) over
+// the 32 points of an object, max. One workgroup per object. The 512-wide hidden layer passes through LDS in two halves of 256
+// units (the units k-steps [32 hf, 32 hf + 32) of the half-split packing of the second Linear cover) while the 1024 outputs
+// (8 column tiles per wave) accumulate in registers: 68 KB of LDS instead of 100 KB, two objects per CU.
+constexpr int kGaH1 = 512, kGaHS = 256 + 4, kGaH2 = 1024, kGaK = 264, kGaXS = kGaK + 4;  // [x(256) | pos(3) | 1 | 0..] padded to 8
 __global__ __launch_bounds__(256, 2) void pn_ga_kernel(const float* __restrict__ pos3, const float* __restrict__ x3,
                                                        const float4* __restrict__ w1, const float4* __restrict__ w2,
-                                                       const uint4* __restrict__ w1h, const uint4* __restrict__ w2h,
                                                        const float* __restrict__ b2, float* __restrict__ f0,
-                                                       int32_t* __restrict__ obj_flags) {
-  constexpr int kGaK = ga_k(H), kGaXS = kGaK + 4;
+                                                       const int32_t* __restrict__ obj_flags) {
   extern __shared__ float smem[];
   float* X = smem;                 // [32][kGaXS]  rows = [x(256) | pos(3) | 1 | 0..]
   float* Hd = X + 32 * kGaXS;      // [32][kGaHS]  one half of the hidden layer
   const int o = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, kh = lane >> 5;
-  if (obj_flags) {
-    const int flagged = obj_flags[o];
-    if (H ? flagged : !flagged) return;
-  }
-  float amax = 0.f;
+  if (obj_flags && !obj_flags[o]) return;  // behind a split launch: only the objects it flagged
   for (int i = tid; i < 32 * kGaK; i += 256) {
     const int r = i / kGaK, k = i % kGaK;
     float v = 0.f;
@@ -958,7 +988,6 @@ __global__ __launch_bounds__(256, 2) void pn_ga_kernel(const float* __restrict__
     else if (k < 259) v = pos3[((size_t)o * 32 + r) * 3 + (k - 256)];
     else if (k == 259) v = 1.f;
     X[r * kGaXS + k] = v;
-    amax = fmaxf(amax, fabsf(v));
   }
   __syncthreads();
   f32x16 acc[8];  // output column tiles w, w + 4, ..., w + 28
@@ -971,18 +1000,7 @@ __global__ __launch_bounds__(256, 2) void pn_ga_kernel(const float* __restrict__
     f32x16 h[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) h[0][r] = h[1][r] = 0.f;
-    if constexpr (H != 0) {  // the two tiles share every (split) A fragment
-      const float* xr = X + j * kGaXS + kh * (kGaK / 2);
-      constexpr int S = kGaK / 16;
-      const uint4* wa = w1h + ((size_t)(4 * hf + w) * S * 64 + lane) * 2;
-      const uint4* wb = w1h + ((size_t)(8 + 4 * hf + w) * S * 64 + lane) * 2;
-#pragma unroll 2
-      for (int st = 0; st < S; ++st) {
-        const HFrag a = split_h<H == 2>(xr + 8 * st);
-        mfma_h3<H == 2>(h[0], a, load_h1<H == 2>(wa + st * 128));
-        mfma_h3<H == 2>(h[1], a, load_h1<H == 2>(wb + st * 128));
-      }
-    } else {  // the two tiles share every A fragment
+    {  // the two tiles share every A fragment
       const float* xr = X + j * kGaXS + kh * (kGaK / 2);
       const float4* wa = w1 + (size_t)(4 * hf + w) * (kGaK / 8) * 64 + lane;
       const float4* wb = w1 + (size_t)(8 + 4 * hf + w) * (kGaK / 8) * 64 + lane;
@@ -1004,22 +1022,9 @@ __global__ __launch_bounds__(256, 2) void pn_ga_kernel(const float* __restrict__
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float hv = fmaxf(h[u][r], 0.f);
-        Hd[((r & 3) + 8 * (r >> 2) + 4 * kh) * kGaHS + 128 * u + 32 * w + j] = hv;
-        amax = fmaxf(amax, hv);
-      }
+      for (int r = 0; r < 16; ++r) Hd[((r & 3) + 8 * (r >> 2) + 4 * kh) * kGaHS + 128 * u + 32 * w + j] = fmaxf(h[u][r], 0.f);
     __syncthreads();
-    if constexpr (H != 0) {  // layer 2 partial: 8 column tiles share every split A fragment; K = 512: half hf = steps [16 hf, 16 hf + 16)
-      const float* hr = Hd + j * kGaHS + kh * 128;
-      const uint4* wp = w2h + (((size_t)w * (kGaH1 / 16) + 16 * hf) * 64 + lane) * 2;
-#pragma unroll 2
-      for (int st = 0; st < 16; ++st) {
-        const HFrag a = split_h<H == 2>(hr + 8 * st);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) mfma_h3<H == 2>(acc[t], a, load_h1<H == 2>(wp + ((size_t)4 * t * (kGaH1 / 16) + st) * 128));
-      }
-    } else {  // layer 2 partial: the 8 column tiles of this wave share every A fragment (one LDS read, 8 weight loads, 32 MFMAs)
+    {  // layer 2 partial: the 8 column tiles of this wave share every A fragment (one LDS read, 8 weight loads, 32 MFMAs)
       const float* hr = Hd + j * kGaHS + kh * 128;
       const float4* wp = w2 + ((size_t)w * (kGaH1 / 8) + 32 * hf) * 64 + lane;
 #pragma unroll 2
@@ -1038,15 +1043,10 @@ __global__ __launch_bounds__(256, 2) void pn_ga_kernel(const float* __restrict__
   }
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    float m = acc[t][0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[t][r]);
+    float m = max16(acc[t]);
     m = fmaxf(m, __shfl_xor(m, 32));
     const int c = (w + 4 * t) * 32 + j;
     if (kh == 0) f0[(size_t)o * kGaH2 + c] = fmaxf(m + b2[c], 0.f);
-  }
-  if constexpr (H != 0) {
-    if (!(amax < kSplitF16Safe)) obj_flags[o] = 1;
   }
 }
 
@@ -1238,19 +1238,23 @@ int pointnet_features_impl(t2l_ctx* ctx, const float* pos, const float* rgb, con
   P = SaParams{p2, x2, p3, x3, d_base, W->w1[2], W->w2[2], W->b2[2], radii[2] * radii[2], ctx->pn_self_loops, W->w1h[2], W->w2h[2], W->wsh[2], d_flags};
   T2L_HIP(ctx, (launch_sa<128, 256, 256, 64>(P, n_obj, split, ctx->encoder_f16 != 0, s)));
   {
-    const size_t lds_h = sizeof(float) * (32 * (ga_k(true) + 4) + 32 * kGaHS), lds_f = sizeof(float) * (32 * (ga_k(false) + 4) + 32 * kGaHS);
+    const size_t lds_f = sizeof(float) * (32 * kGaXS + 32 * kGaHS);
     static PerDeviceOnce attr;
     if (attr.need(ctx->device)) {
-      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
-      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h));
-      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+      T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
       attr.mark(ctx->device);
     }
-    if (split && ctx->encoder_f16)
-      hipLaunchKernelGGL(pn_ga_kernel<2>, dim3(n_obj), dim3(256), lds_h, s, p3, x3, W->ga1, W->ga2, W->ga1h, W->ga2h, W->gab2, f0, d_flags);
-    else if (split)
-      hipLaunchKernelGGL(pn_ga_kernel<1>, dim3(n_obj), dim3(256), lds_h, s, p3, x3, W->ga1, W->ga2, W->ga1h, W->ga2h, W->gab2, f0, d_flags);
-    hipLaunchKernelGGL(pn_ga_kernel<0>, dim3(n_obj), dim3(256), lds_f, s, p3, x3, W->ga1, W->ga2, W->ga1h, W->ga2h, W->gab2, f0, d_flags);
+    if (split) {
+      const int grid = std::min(256, (n_obj + kGaWaves - 1) / kGaWaves);
+      if (ctx->encoder_f16) {
+        const size_t ring = (size_t)kWsBufs * WStream<true, kGaWaves>::kChunkB;
+        hipLaunchKernelGGL(pn_ga_ws_kernel<true>, dim3(grid), dim3(64 * kGaWaves), ring, s, p3, x3, W->gash, W->gab2, f0, d_flags, n_obj);
+      } else {
+        const size_t ring = (size_t)kWsBufs * WStream<false, kGaWaves>::kChunkB;
+        hipLaunchKernelGGL(pn_ga_ws_kernel<false>, dim3(grid), dim3(64 * kGaWaves), ring, s, p3, x3, W->gash, W->gab2, f0, d_flags, n_obj);
+      }
+    }
+    hipLaunchKernelGGL(pn_ga_kernel, dim3(n_obj), dim3(256), lds_f, s, p3, x3, W->ga1, W->ga2, W->gab2, f0, d_flags);
   }
   {  // lin1 / lin2 + ReLU over all objects (pointnet2.py:86-89): plain GEMMs on the row-major torch weights
     train::GemmArgs g{f0, W->lin1w, f1, W->lin1b, n_obj, 512, 1024, 1024, 1024, 512, 1, 0, 1024, nullptr};
