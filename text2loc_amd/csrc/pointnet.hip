@@ -430,6 +430,54 @@ __device__ __forceinline__ void build_xrow(const float* __restrict__ x, float dx
   }
 }
 
+// farthest point sampling of one object on the calling wave: selection order from point 0, lowest index on ties 
+template <int NS>
+__device__ __forceinline__ void fps_wave(const float* spos, int* sel, int lane) {
+  constexpr int ND = NS / 2, PPL = NS / 64;
+  float mind[PPL], px[PPL], py[PPL], pz[PPL];
+#pragma unroll
+  for (int q = 0; q < PPL; ++q) {
+    const int p = lane + 64 * q;
+    px[q] = spos[p * 3]; py[q] = spos[p * 3 + 1]; pz[q] = spos[p * 3 + 2];
+    mind[q] = 3.0e38f;
+  }
+  int last = 0;
+  if (lane == 0) sel[0] = 0;
+  for (int t = 1; t < ND; ++t) {
+    const float cx = spos[last * 3], cy = spos[last * 3 + 1], cz = spos[last * 3 + 2];
+    float best = -1.f;
+    int bi = 0;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+      mind[q] = fminf(mind[q], d2_noFMA(px[q], py[q], pz[q], cx, cy, cz));
+      if (mind[q] > best) { best = mind[q]; bi = lane + 64 * q; }
+    }
+    const unsigned m = wave_umax(__float_as_uint(best));  // distances are >= 0: the bit pattern orders like the value
+    last = (int)wave_umin(__float_as_uint(best) == m ? (unsigned)bi : 0x7fffffffu);
+    if (lane == 0) sel[t] = last;
+  }
+}
+
+// The centres of a level for all (unflagged) objects, one wave per object. Inside the per-object kernels the sampling loop (ND
+// dependent steps of two wave reductions) runs on ONE wave: at level 1 (127 steps over 4 points per lane) that wave's SIMD carried
+// 25 us of sampling per object on top of its 18 us share of the tiles (three workgroups per CU, all sampling on their wave 0); at
+// level 2 the CU's only workgroup waited 8 of 84 us per object.
+template <int NS>
+__global__ __launch_bounds__(256) void pn_fps_kernel(const float* __restrict__ src_pos, float* __restrict__ dst_pos,
+                                                     const int32_t* __restrict__ obj_flags, int n_obj) {
+  constexpr int ND = NS / 2;
+  __shared__ float spos_all[4][NS * 3];
+  __shared__ int sel_all[4][ND];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, o = blockIdx.x * 4 + w;
+  if (o >= n_obj || (obj_flags && obj_flags[o])) return;  // (no workgroup barrier below: the waves are independent)
+  float* spos = spos_all[w];
+  int* sel = sel_all[w];
+  const float* gp = src_pos + (size_t)o * NS * 3;
+  for (int i = lane; i < NS * 3; i += 64) spos[i] = gp[i];
+  fps_wave<NS>(spos, sel, lane);
+  for (int i = lane; i < ND * 3; i += 64) dst_pos[(size_t)o * ND * 3 + i] = spos[sel[i / 3] * 3 + (i % 3)];
+}
+
 struct SaParams {
   const float* src_pos;  // [n_obj][NS][3]
   const float* src_x;    // [n_obj][NS][CIN]
@@ -444,7 +492,8 @@ struct SaParams {
   const uint4* w1h;
   const uint4* w2h;
   const uint4* wsh;  // levels 2 and 3: the tile's stream for WStream
-  int32_t* obj_flags;  // [n_obj]: 1 = this object's magnitudes left the split-f16 range (or were not finite): f32 launches only
+  int32_t* obj_flags;
+  int centres_given = 0;  // pn_sa_kernel: dst_pos already holds this level's centres (pn_fps_kernel)  // [n_obj]: 1 = this object's magnitudes left the split-f16 range (or were not finite): f32 launches only
 };
 
 template <int CIN, int H1, int H2, int NS, int H>
@@ -470,36 +519,17 @@ __global__ __launch_bounds__(256, 1) void pn_sa_kernel(SaParams P) {
   for (int i = tid; i < NS * CIN; i += 256) sx[(i / CIN) * XS + (i % CIN)] = gx[i];
   __syncthreads();
 
-  // ---- farthest point sampling, wave 0: selection order from point 0, lowest index on ties
-  if (w == 0) {
-    float mind[PPL], px[PPL], py[PPL], pz[PPL];
-#pragma unroll
-    for (int q = 0; q < PPL; ++q) {
-      const int p = lane + 64 * q;
-      px[q] = spos[p * 3]; py[q] = spos[p * 3 + 1]; pz[q] = spos[p * 3 + 2];
-      mind[q] = 3.0e38f;
+  // ---- farthest point sampling (wave 0) unless pn_fps_kernel ran
+  if (P.centres_given) {
+    for (int i = tid; i < ND * 3; i += 256) dpos[i] = P.dst_pos[(size_t)o * ND * 3 + i];
+  } else {
+    if (w == 0) fps_wave<NS>(spos, sel, lane);
+    __syncthreads();
+    for (int i = tid; i < ND * 3; i += 256) {
+      const float v = spos[sel[i / 3] * 3 + (i % 3)];
+      dpos[i] = v;
+      P.dst_pos[(size_t)o * ND * 3 + i] = v;
     }
-    int last = 0;
-    if (lane == 0) sel[0] = 0;
-    for (int t = 1; t < ND; ++t) {
-      const float cx = spos[last * 3], cy = spos[last * 3 + 1], cz = spos[last * 3 + 2];
-      float best = -1.f;
-      int bi = 0;
-#pragma unroll
-      for (int q = 0; q < PPL; ++q) {
-        mind[q] = fminf(mind[q], d2_noFMA(px[q], py[q], pz[q], cx, cy, cz));
-        if (mind[q] > best) { best = mind[q]; bi = lane + 64 * q; }
-      }
-      const unsigned m = wave_umax(__float_as_uint(best));  // distances are >= 0: the bit pattern orders like the value
-      last = (int)wave_umin(__float_as_uint(best) == m ? (unsigned)bi : 0x7fffffffu);
-      if (lane == 0) sel[t] = last;
-    }
-  }
-  __syncthreads();
-  for (int i = tid; i < ND * 3; i += 256) {
-    const float v = spos[sel[i / 3] * 3 + (i % 3)];
-    dpos[i] = v;
-    P.dst_pos[(size_t)o * ND * 3 + i] = v;
   }
   __syncthreads();
 
@@ -792,52 +822,6 @@ __device__ __forceinline__ void sa_mlp_tile_ws(const X& x, WStream<SG, NW>& ws, 
     ws_l2_steps<0, G, SG, NW>(ws, wr, out, acc, more || nt + 1 < G::NT);
     emit(nt, out);
   }
-}
-
-// farthest point sampling of one object on the calling wave: selection order from point 0, lowest index on ties (as pn_sa_kernel)
-template <int NS>
-__device__ __forceinline__ void fps_wave(const float* spos, int* sel, int lane) {
-  constexpr int ND = NS / 2, PPL = NS / 64;
-  float mind[PPL], px[PPL], py[PPL], pz[PPL];
-#pragma unroll
-  for (int q = 0; q < PPL; ++q) {
-    const int p = lane + 64 * q;
-    px[q] = spos[p * 3]; py[q] = spos[p * 3 + 1]; pz[q] = spos[p * 3 + 2];
-    mind[q] = 3.0e38f;
-  }
-  int last = 0;
-  if (lane == 0) sel[0] = 0;
-  for (int t = 1; t < ND; ++t) {
-    const float cx = spos[last * 3], cy = spos[last * 3 + 1], cz = spos[last * 3 + 2];
-    float best = -1.f;
-    int bi = 0;
-#pragma unroll
-    for (int q = 0; q < PPL; ++q) {
-      mind[q] = fminf(mind[q], d2_noFMA(px[q], py[q], pz[q], cx, cy, cz));
-      if (mind[q] > best) { best = mind[q]; bi = lane + 64 * q; }
-    }
-    const unsigned m = wave_umax(__float_as_uint(best));  // distances are >= 0: the bit pattern orders like the value
-    last = (int)wave_umin(__float_as_uint(best) == m ? (unsigned)bi : 0x7fffffffu);
-    if (lane == 0) sel[t] = last;
-  }
-}
-
-// The centres of a level for all (unflagged) objects, one wave per object: inside pn_sa_ws_kernel the sampling loop (ND dependent
-// steps of two wave reductions) ran on one of eight waves while the CU's only workgroup waited — 8 of level 2's 84 us per object.
-template <int NS>
-__global__ __launch_bounds__(256) void pn_fps_kernel(const float* __restrict__ src_pos, float* __restrict__ dst_pos,
-                                                     const int32_t* __restrict__ obj_flags, int n_obj) {
-  constexpr int ND = NS / 2;
-  __shared__ float spos_all[4][NS * 3];
-  __shared__ int sel_all[4][ND];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, o = blockIdx.x * 4 + w;
-  if (o >= n_obj || obj_flags[o]) return;  // (no workgroup barrier below: the waves are independent)
-  float* spos = spos_all[w];
-  int* sel = sel_all[w];
-  const float* gp = src_pos + (size_t)o * NS * 3;
-  for (int i = lane; i < NS * 3; i += 64) spos[i] = gp[i];
-  fps_wave<NS>(spos, sel, lane);
-  for (int i = lane; i < ND * 3; i += 64) dst_pos[(size_t)o * ND * 3 + i] = spos[sel[i / 3] * 3 + (i % 3)];
 }
 
 template <int CIN, int H1, int H2, int NS, bool SG>
@@ -1186,8 +1170,13 @@ static hipError_t launch_sa(const SaParams& P, int n_obj, bool split, bool singl
       if (e != hipSuccess) return e;
     }
   } else {
-    if (split && single) hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, 2>), dim3(n_obj), dim3(256), lds, s, P);  // option encoder_f16
-    else if (split) hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, 1>), dim3(n_obj), dim3(256), lds, s, P);
+    if (split) {
+      hipLaunchKernelGGL((pn_fps_kernel<NS>), dim3((n_obj + 3) / 4), dim3(256), 0, s, P.src_pos, P.dst_pos, P.obj_flags, n_obj);
+      SaParams Q = P;
+      Q.centres_given = 1;
+      if (single) hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, 2>), dim3(n_obj), dim3(256), lds, s, Q);  // option encoder_f16
+      else hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, 1>), dim3(n_obj), dim3(256), lds, s, Q);
+    }
   }
   hipLaunchKernelGGL((pn_sa_kernel<CIN, H1, H2, NS, 0>), dim3(n_obj), dim3(256), lds, s, P);
   return hipGetLastError();
