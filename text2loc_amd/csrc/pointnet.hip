@@ -307,18 +307,23 @@ __device__ __forceinline__ HFrag split_vals(float v0, float v1, float v2, float 
   }
   return f;
 }
-// max of the 16 accumulator registers of a lane: v_max3 from asm (fmaxf quiets every operand first: 31 VALU ops instead of 8)
+// max of the 16 accumulator registers of a lane in 12 VALU ops (fmaxf quiets every operand first: 31). The first level is
+// v_med3(a, b, +inf) from the builtin with an opaque +inf — the compiler sees these reads of the MFMA's result and pads the
+// hazard; instructions from inline asm it does not pad (tools/mfma_hazard_scan.py found v_max3 one wait state short) — the
+// rest is v_max3 from asm on those results.
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
   float d;
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
 __device__ __forceinline__ float max16(const f32x16& a) {
-  const float t0 = vmax3(a[0], a[1], a[2]), t1 = vmax3(a[3], a[4], a[5]), t2 = vmax3(a[6], a[7], a[8]), t3 = vmax3(a[9], a[10], a[11]),
-              t4 = vmax3(a[12], a[13], a[14]);
-  return vmax3(vmax3(t0, t1, t2), vmax3(t3, t4, a[15]), a[15]);
+  float pinf = __builtin_inff();
+  asm volatile("" : "+v"(pinf));
+  float t[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = __builtin_amdgcn_fmed3f(a[2 * i], a[2 * i + 1], pinf);
+  return vmax3(vmax3(t[0], t[1], t[2]), vmax3(t[3], t[4], t[5]), vmax3(t[6], t[7], t[7]));
 }
-
 // The steps of the two layers as template recursions (the compiler does not unroll a 72-step loop with this body, and
 // run-time indices would put the fragment arrays into scratch memory).
 template <int STEP, int STEPS, int S, int PF, int FT, bool SG>
@@ -809,8 +814,11 @@ __device__ __forceinline__ void sa_mlp_tile_ws(const X& x, WStream<SG, NW>& ws, 
     HFrag xf;
     ws_l1_steps<0, G, SG, NW>(ws, wr, acc, x, xraw, xf, amax);
   }
+  // BatchNorm + bias are folded; ReLU + split turn the accumulators into layer 2's fragments. (Measured and dropped: the second
+  // wave of each SIMD splitting a feature tile only when the first pass over layer 2 reaches it, so that the two waves' VALU
+  // bursts do not coincide — level 3 4.83 -> 4.94 ms, level 2 3.00 -> 3.10.)
 #pragma unroll
-  for (int ft = 0; ft < G::FT; ++ft) {  // BatchNorm + bias folded; ReLU
+  for (int ft = 0; ft < G::FT; ++ft) {
     relu_split_in_place<SG>(acc[ft], amax);
     __builtin_amdgcn_sched_barrier(0);
   }
