@@ -287,8 +287,14 @@ __device__ __forceinline__ void sa_mlp_tile(const float (&xrow)[k1p(CIN) / 2], c
 template <bool SG = false>  // SG: plain f16 (option encoder_f16): the high part only
 __device__ __forceinline__ HFrag split_vals(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
                                             float& amax) {
-  amax = fmaxf(fmaxf(fmaxf(amax, fabsf(v0)), fmaxf(fabsf(v1), fabsf(v2))), fmaxf(fmaxf(fabsf(v3), fabsf(v4)), fabsf(v5)));
-  amax = fmaxf(amax, fmaxf(fabsf(v6), fabsf(v7)));
+  // max(amax, |a|, |b|) as ONE v_max3 (fmaxf(fabsf()) chains quiet every operand first: 12 ops per 8 values instead of 4). The
+  // operands are VALU or load results at every call site, never an MFMA's destination (the compiler does not pad asm reads).
+  auto amax3 = [](float m, float a, float b) {
+    float d;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(d) : "v"(m), "v"(a), "v"(b));
+    return d;
+  };
+  amax = amax3(amax3(amax3(amax3(amax, v0, v1), v2, v3), v4, v5), v6, v7);
   const h3_f32x8 v = {v0, v1, v2, v3, v4, v5, v6, v7};
   HFrag f;
   f.hi = __builtin_convertvector(v, h3_f16x8);
