@@ -731,16 +731,16 @@ __device__ __forceinline__ HFrag plane_frag(const _Float16* __restrict__ hi, con
 }
 template <bool SG>
 __device__ __forceinline__ void plane_put4(_Float16* __restrict__ hi, _Float16* __restrict__ lo, int off, ti_f32x4 v) {
-  const ti_f16x4 h = __builtin_convertvector(v, ti_f16x4);
-  *reinterpret_cast<ti_f16x4*>(hi + off) = h;
+  h3_f16x4 h, l;
+  h3_split4(h3_f32x4{v[0], v[1], v[2], v[3]}, h, l);
+  *reinterpret_cast<h3_f16x4*>(hi + off) = h;
   // (the plain-f16 option drops the low halves from the PRODUCTS only: the stored activations — the residual stream — keep both)
-  *reinterpret_cast<ti_f16x4*>(lo + off) = __builtin_convertvector(v - __builtin_convertvector(h, ti_f32x4), ti_f16x4);
+  *reinterpret_cast<h3_f16x4*>(lo + off) = l;
 }
 template <bool SG>
 __device__ __forceinline__ ti_f32x4 plane_get4(const _Float16* __restrict__ hi, const _Float16* __restrict__ lo, int off) {
-  ti_f32x4 v = __builtin_convertvector(*reinterpret_cast<const ti_f16x4*>(hi + off), ti_f32x4);
-  v += __builtin_convertvector(*reinterpret_cast<const ti_f16x4*>(lo + off), ti_f32x4);
-  return v;
+  const h3_f32x4 v = h3_join4(*reinterpret_cast<const h3_f16x4*>(hi + off), *reinterpret_cast<const h3_f16x4*>(lo + off));
+  return ti_f32x4{v[0], v[1], v[2], v[3]};
 }
 
 // The weight fragments of one tile pass, STEPS k-steps, through a register ring D steps deep: the fragment of step s + D is requested

@@ -501,13 +501,14 @@ __device__ __forceinline__ HFrag fp_frag(const FP t, int off) {
   return f;
 }
 __device__ __forceinline__ void fp_put4(const FP t, int off, ff_f32x4 v) {
-  const ff_f16x4 h = __builtin_convertvector(v, ff_f16x4);
-  *reinterpret_cast<ff_f16x4*>(t.hi + off) = h;
-  *reinterpret_cast<ff_f16x4*>(t.lo + off) = __builtin_convertvector(v - __builtin_convertvector(h, ff_f32x4), ff_f16x4);
+  h3_f16x4 h, l;
+  h3_split4(h3_f32x4{v[0], v[1], v[2], v[3]}, h, l);
+  *reinterpret_cast<h3_f16x4*>(t.hi + off) = h;
+  *reinterpret_cast<h3_f16x4*>(t.lo + off) = l;
 }
 __device__ __forceinline__ ff_f32x4 fp_get4(const FP t, int off) {
-  return __builtin_convertvector(*reinterpret_cast<const ff_f16x4*>(t.hi + off), ff_f32x4) +
-         __builtin_convertvector(*reinterpret_cast<const ff_f16x4*>(t.lo + off), ff_f32x4);
+  const h3_f32x4 v = h3_join4(*reinterpret_cast<const h3_f16x4*>(t.hi + off), *reinterpret_cast<const h3_f16x4*>(t.lo + off));
+  return ff_f32x4{v[0], v[1], v[2], v[3]};
 }
 // acc (D[feature][token]) += W tile (STEPS k-steps of packed fragments at wp) x tokens (plane rows, this lane's half row at aoff)
 template <int STEPS, bool SG>
@@ -584,15 +585,15 @@ __device__ void fp_ln_rows(const FP x, int T, const float* __restrict__ g, const
   const float2 gv = *reinterpret_cast<const float2*>(g + 2 * lane), bv = *reinterpret_cast<const float2*>(b + 2 * lane);
   for (int t = w; t < T; t += 4) {
     const int off = t * kLdF + 2 * lane;
-    const ff_f32x2 v = __builtin_convertvector(*reinterpret_cast<const ff_f16x2*>(x.hi + off), ff_f32x2) +
-                       __builtin_convertvector(*reinterpret_cast<const ff_f16x2*>(x.lo + off), ff_f32x2);
+    const h3_f32x2 v = h3_join2(*reinterpret_cast<const h3_f16x2*>(x.hi + off), *reinterpret_cast<const h3_f16x2*>(x.lo + off));
     const float mu = f_wsum(v[0] + v[1]) * (1.f / kFD);
     const float d0 = v[0] - mu, d1 = v[1] - mu;
     const float rstd = 1.0f / sqrtf(f_wsum(d0 * d0 + d1 * d1) * (1.f / kFD) + 1e-5f);
     const ff_f32x2 o = {d0 * rstd * gv.x + bv.x, d1 * rstd * gv.y + bv.y};
-    const ff_f16x2 h = __builtin_convertvector(o, ff_f16x2);
-    *reinterpret_cast<ff_f16x2*>(x.hi + off) = h;
-    *reinterpret_cast<ff_f16x2*>(x.lo + off) = __builtin_convertvector(o - __builtin_convertvector(h, ff_f32x2), ff_f16x2);
+    h3_f16x2 h, l;
+    h3_split2(h3_f32x2{o[0], o[1]}, h, l);
+    *reinterpret_cast<h3_f16x2*>(x.hi + off) = h;
+    *reinterpret_cast<h3_f16x2*>(x.lo + off) = l;
   }
 }
 // One attention block on planes, head h = wave (f_attention_regs with plane operands and the output transposed). SHARED: the query tile's

@@ -28,6 +28,54 @@ constexpr float kSplitF16Safe = 3.0e4f;  // bound below which an operand may ent
 struct HFrag {
   h3_f16x8 hi, lo;
 };
+// v_fma_mix_f32 reads f16 operands out of either half of a packed register, so the two f32 <-> (hi, lo) conversions that every
+// split epilogue and every residual read-back is made of need no unpacking v_cvt_f32_f16 (this toolchain never selects the
+// instruction for these patterns). Both results are the exact f32 values the cvt + sub / cvt + cvt + add forms produce.
+//   h3_minus_half<HI>(x, p):  x - f16 half HI of p      (the low part of a split: x - hi is exact in f32)
+//   h3_sum_halves<HI>(h, l):  f16 half HI of h + f16 half HI of l  (hi + lo back to f32: one rounding, as the f32 add)
+// Inline asm: the compiler pads no MFMA hazard for these reads. x / p always come out of a compiler-visible VALU op on the
+// same registers (the v_cvt_pk that made p from x) or out of a load; tests/test_mfma_hazard_scan.py checks every kernel.
+template <int HI>
+__device__ __forceinline__ float h3_minus_half(float x, unsigned p) {
+  float d;
+  if constexpr (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(p), "v"(x));
+  else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(p), "v"(x));
+  return d;
+}
+template <int HI>
+__device__ __forceinline__ float h3_sum_halves(unsigned h, unsigned l) {
+  float d;
+  if constexpr (HI) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(h), "v"(l));
+  else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(h), "v"(l));
+  return d;
+}
+typedef _Float16 h3_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h3_f16x2 __attribute__((ext_vector_type(2)));
+typedef float h3_f32x4 __attribute__((ext_vector_type(4)));
+typedef float h3_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned h3_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned h3_u32x4 __attribute__((ext_vector_type(4)));
+// four / two f32 values -> packed hi halves and packed lo halves (lo of the split form)
+__device__ __forceinline__ void h3_split4(h3_f32x4 v, h3_f16x4& hi, h3_f16x4& lo) {
+  hi = __builtin_convertvector(v, h3_f16x4);
+  const h3_u32x2 p = __builtin_bit_cast(h3_u32x2, hi);
+  const h3_f32x4 d = {h3_minus_half<0>(v[0], p[0]), h3_minus_half<1>(v[1], p[0]), h3_minus_half<0>(v[2], p[1]), h3_minus_half<1>(v[3], p[1])};
+  lo = __builtin_convertvector(d, h3_f16x4);
+}
+__device__ __forceinline__ h3_f32x4 h3_join4(h3_f16x4 hi, h3_f16x4 lo) {
+  const h3_u32x2 h = __builtin_bit_cast(h3_u32x2, hi), l = __builtin_bit_cast(h3_u32x2, lo);
+  return h3_f32x4{h3_sum_halves<0>(h[0], l[0]), h3_sum_halves<1>(h[0], l[0]), h3_sum_halves<0>(h[1], l[1]), h3_sum_halves<1>(h[1], l[1])};
+}
+__device__ __forceinline__ void h3_split2(h3_f32x2 v, h3_f16x2& hi, h3_f16x2& lo) {
+  hi = __builtin_convertvector(v, h3_f16x2);
+  const unsigned p = __builtin_bit_cast(unsigned, hi);
+  const h3_f32x2 d = {h3_minus_half<0>(v[0], p), h3_minus_half<1>(v[1], p)};
+  lo = __builtin_convertvector(d, h3_f16x2);
+}
+__device__ __forceinline__ h3_f32x2 h3_join2(h3_f16x2 hi, h3_f16x2 lo) {
+  const unsigned h = __builtin_bit_cast(unsigned, hi), l = __builtin_bit_cast(unsigned, lo);
+  return h3_f32x2{h3_sum_halves<0>(h, l), h3_sum_halves<1>(h, l)};
+}
 // SINGLE: the plain-f16 variant (one product per pair of operands, |error| <= 2^-10 relative per product): no low part
 template <bool SINGLE = false>
 __device__ __forceinline__ HFrag split_h(const float* __restrict__ p) {  // 8 consecutive floats (16-byte aligned)
@@ -35,8 +83,14 @@ __device__ __forceinline__ HFrag split_h(const float* __restrict__ p) {  // 8 co
   const h3_f32x8 v = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   HFrag f;
   f.hi = __builtin_convertvector(v, h3_f16x8);
-  if constexpr (SINGLE) f.lo = f.hi;  // (never read)
-  else f.lo = __builtin_convertvector(v - __builtin_convertvector(f.hi, h3_f32x8), h3_f16x8);
+  if constexpr (SINGLE) {
+    f.lo = f.hi;  // (never read)
+  } else {
+    const h3_u32x4 p = __builtin_bit_cast(h3_u32x4, f.hi);
+    const h3_f32x8 d = {h3_minus_half<0>(v[0], p[0]), h3_minus_half<1>(v[1], p[0]), h3_minus_half<0>(v[2], p[1]), h3_minus_half<1>(v[3], p[1]),
+                        h3_minus_half<0>(v[4], p[2]), h3_minus_half<1>(v[5], p[2]), h3_minus_half<0>(v[6], p[3]), h3_minus_half<1>(v[7], p[3])};
+    f.lo = __builtin_convertvector(d, h3_f16x8);
+  }
   return f;
 }
 __device__ __forceinline__ HFrag load_h(const uint4* __restrict__ wp) {
