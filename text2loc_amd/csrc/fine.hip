@@ -194,10 +194,13 @@ int fine_load_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_mode
       }
       auto ln = [&](const char* g, const char* b) { return sq * h3_max_abs(W_(g, kFD), kFD) + h3_max_abs(W_(b, kFD), kFD); };
       amax = fmaxf(amax, fmaxf(xn, mn));                                                                          // q/k/v inputs
-      amax = fmaxf(amax, xn * h3_max_row_norm(sa + (size_t)2 * kFD * kFD, kFD, kFD) + h3_max_abs(sab + 2 * kFD, kFD));  // self out_proj input
+      amax = fmaxf(amax, xn * h3_max_row_norm(sa, 2 * kFD, kFD) + h3_max_abs(sab, 2 * kFD));                     // self q, k (S = K Q^T is a split product)
+      amax = fmaxf(amax, xn * h3_max_row_norm(sa + (size_t)2 * kFD * kFD, kFD, kFD) + h3_max_abs(sab + 2 * kFD, kFD));  // self v = P V operand, out_proj input
       const float e1 = ln(".norm1.weight", ".norm1.bias");
       amax = fmaxf(amax, e1);                                                                                     // cross-attention q input
-      amax = fmaxf(amax, mn * h3_max_row_norm(ca + (size_t)2 * kFD * kFD, kFD, kFD) + h3_max_abs(cab + 2 * kFD, kFD));  // cross out_proj input
+      amax = fmaxf(amax, sq * e1 * h3_max_row_norm(ca, kFD, kFD) + h3_max_abs(cab, kFD));                        // cross q
+      amax = fmaxf(amax, mn * h3_max_row_norm(ca + (size_t)kFD * kFD, kFD, kFD) + h3_max_abs(cab + kFD, kFD));   // cross k
+      amax = fmaxf(amax, mn * h3_max_row_norm(ca + (size_t)2 * kFD * kFD, kFD, kFD) + h3_max_abs(cab + 2 * kFD, kFD));  // cross v, out_proj input
       const float e2 = ln(".norm2.weight", ".norm2.bias");
       amax = fmaxf(amax, e2);                                                                                     // linear1 input
       amax = fmaxf(amax, sq * e2 * h3_max_row_norm(l1, 4 * kFD, kFD) + h3_max_abs(l1b, 4 * kFD));                // linear2 input
@@ -633,11 +636,15 @@ __device__ __forceinline__ void fp_attention(const FP x, TileGroups gx, const FP
       v[r] += bv;
     }
   }
+  // S^T = K Q^T and (below) O^T = V^T P^T as split-f16 products too: kT / qT (and v / P) sit in the same accumulator layout, so
+  // registers 0..7 and 8..15 of the two are matching k-halves of A and B — 6 MFMAs of 32 cycles per product instead of the 16
+  // f32 MFMAs of 64 (the attention core was 2,048 of a wave's ~4,350 matrix-pipe cycles per attention block). Always the
+  // three-product form, also under option encoder_f16: the logits carry the softmax. fine_load_weights bounds q, k, v.
   f32x16 st;
 #pragma unroll
   for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kT[r], qT[r], st, 0, 0, 0);
+  for (int m2 = 0; m2 < 2; ++m2) mfma_h3<false>(st, split_acc8<false>(kT, m2), split_acc8<false>(qT, m2));
   // lane: query i = col, keys j = (r&3) + 8*(r>>2) + 4*half
   const int gi = gx.base + (col >> gx.shift) - gm.base;
   float m = -__builtin_inff();
@@ -661,9 +668,12 @@ __device__ __forceinline__ void fp_attention(const FP x, TileGroups gx, const FP
   // O^T = V^T P^T: A[feature c][key] = v (as it sits: lane (c, half) holds V[key(r, half)][c]), B[key][query] = P (lane (query, half))
   f32x16 oT;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) oT[r] = 0.f;
+  for (int r = 0; r < 16; ++r) {
+    oT[r] = 0.f;
+    st[r] *= inv;
+  }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) oT = __builtin_amdgcn_mfma_f32_32x32x2f32(v[r], st[r] * inv, oT, 0, 0, 0);
+  for (int m2 = 0; m2 < 2; ++m2) mfma_h3<false>(oT, split_acc8<false>(v, m2), split_acc8<false>(st, m2));
 #pragma unroll
   for (int g = 0; g < 4; ++g) {  // lane (query = col, half): features 8 g + 4 half + 0..3 of head h
     const int off = col * kLdF + h * kFHd + 8 * g + 4 * half;

@@ -78,9 +78,7 @@ __device__ __forceinline__ h3_f32x2 h3_join2(h3_f16x2 hi, h3_f16x2 lo) {
 }
 // SINGLE: the plain-f16 variant (one product per pair of operands, |error| <= 2^-10 relative per product): no low part
 template <bool SINGLE = false>
-__device__ __forceinline__ HFrag split_h(const float* __restrict__ p) {  // 8 consecutive floats (16-byte aligned)
-  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-  const h3_f32x8 v = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+__device__ __forceinline__ HFrag split_v8(h3_f32x8 v) {  // 8 register values -> fragment
   HFrag f;
   f.hi = __builtin_convertvector(v, h3_f16x8);
   if constexpr (SINGLE) {
@@ -92,6 +90,17 @@ __device__ __forceinline__ HFrag split_h(const float* __restrict__ p) {  // 8 co
     f.lo = __builtin_convertvector(d, h3_f16x8);
   }
   return f;
+}
+// registers 8 m .. 8 m + 7 of an MFMA accumulator tile as a fragment: two tiles in the same layout, cut the same way, give
+// the two operands of a product the same k order (whatever rows of the tiles those registers are)
+template <bool SINGLE = false>
+__device__ __forceinline__ HFrag split_acc8(const h3_f32x16& t, int m) {
+  return split_v8<SINGLE>(h3_f32x8{t[8 * m], t[8 * m + 1], t[8 * m + 2], t[8 * m + 3], t[8 * m + 4], t[8 * m + 5], t[8 * m + 6], t[8 * m + 7]});
+}
+template <bool SINGLE = false>
+__device__ __forceinline__ HFrag split_h(const float* __restrict__ p) {  // 8 consecutive floats (16-byte aligned)
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  return split_v8<SINGLE>(h3_f32x8{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w});
 }
 __device__ __forceinline__ HFrag load_h(const uint4* __restrict__ wp) {
   // packed weights live in global memory: say so (a pointer that went through an opaque asm would otherwise load as flat_*)
