@@ -829,12 +829,29 @@ __device__ __forceinline__ void planes_layer(_Float16* base, const InterFusedW& 
         kT0[r] += ib[kD + h * 64 + f];
         kT1[r] += ib[kD + h * 64 + 32 + f];
       }
+      // S^T = K Q^T (and O^T = V^T P^T below) as split-f16 products on the accumulator registers: kT / qT (v / P) sit in the same
+      // MFMA output layout, so registers 0..7 and 8..15 of the two are matching k-halves of A and B — 12 MFMAs of 32 cycles here
+      // instead of 32 f32 MFMAs of 64 (the attention core was a third of a wave's matrix-pipe time in this layer). Always the
+      // three-product form (the logits carry the softmax); q, k, v are inside the load-time bound of the in_proj output (cell
+      // encoder) or watched here (WATCH).
+      if constexpr (WATCH) {
+        float wm = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wm = fmaxf(wm, fmaxf(fmaxf(fabsf(qT0[r]), fabsf(qT1[r])), fmaxf(fabsf(kT0[r]), fabsf(kT1[r]))));
+        watch(wm);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kT0[r], qT0[r], st, 0, 0, 0);
+      for (int m2 = 0; m2 < 2; ++m2) {  // (fenced: the compiler otherwise splits all eight fragments first — 64 registers of temporaries)
+        mfma_h3<false>(st, split_acc8<false>(kT0, m2), split_acc8<false>(qT0, m2));
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kT1[r], qT1[r], st, 0, 0, 0);
+      for (int m2 = 0; m2 < 2; ++m2) {
+        mfma_h3<false>(st, split_acc8<false>(kT1, m2), split_acc8<false>(qT1, m2));
+        __builtin_amdgcn_sched_barrier(0);
+      }
       float m = -__builtin_inff();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -888,9 +905,22 @@ __device__ __forceinline__ void planes_layer(_Float16* base, const InterFusedW& 
       for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = st[r] * inv;
-        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[r] + bv0, p, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[r] + bv1, p, o1, 0, 0, 0);
+        st[r] *= inv;
+        v0[r] += bv0;
+        v1[r] += bv1;
+      }
+      if constexpr (WATCH) {
+        float wm = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wm = fmaxf(wm, fmaxf(fabsf(v0[r]), fabsf(v1[r])));
+        watch(wm);
+      }
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2) {
+        const HFrag pf = split_acc8<false>(st, m2);
+        mfma_h3<false>(o0, split_acc8<false>(v0, m2), pf);
+        mfma_h3<false>(o1, split_acc8<false>(v1, m2), pf);
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -1463,7 +1493,8 @@ int load_weights_impl(t2l_ctx* ctx, const t2l_weight_desc* w, int n, const t2l_m
         return 16.f * max_abs(m.at(p + wn)->data, kD) + max_abs(m.at(p + bn)->data, kD);
       };
       act_bound = fmaxf(act_bound, x_norm);                                                                   // q/k/v input
-      act_bound = fmaxf(act_bound, x_norm * max_row_norm(Wi + (size_t)2 * kD * kD, kD, kD) + max_abs(bi + 2 * kD, kD));  // out_proj input: convex combinations of v
+      act_bound = fmaxf(act_bound, x_norm * max_row_norm(Wi, 2 * kD, kD) + max_abs(bi, 2 * kD));              // q, k: operands of the split S = K Q^T
+      act_bound = fmaxf(act_bound, x_norm * max_row_norm(Wi + (size_t)2 * kD * kD, kD, kD) + max_abs(bi + 2 * kD, kD));  // v (operand of P V) and out_proj input: convex combinations of v
       const float ln1 = ln_elem("norm1.weight", "norm1.bias");
       act_bound = fmaxf(act_bound, ln1);                                                                      // linear1 input (element bound)
       act_bound = fmaxf(act_bound, 16.f * ln1 * max_row_norm(W1, 2 * kD, kD) + max_abs(b1, 2 * kD));          // linear2 input
