@@ -14,7 +14,7 @@ def main(n_draws=150, seed=7):
     bad = 0
     for it in range(n_draws):
         n = int(rng.choice([1, 5, 31, 32, 33, 64, 100, 257, 511, 1000, 2049, 4097, 5000, 11259, 20000]))
-        q = int(rng.choice([1, 2, 31, 64, 65, 255, 256, 257, 700, 1024, 4096]))
+        q = int(rng.choice([1, 2, 3, 4, 7, 8, 12, 16, 17, 31, 64, 65, 255, 256, 257, 700, 1024, 4096]))
         k = int(rng.choice([1, 3, 5, 10, 11, 26]))
         kind = int(rng.integers(0, 4))
         lanes = int(rng.choice([1, 1, 2, 3, 4]))
