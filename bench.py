@@ -655,10 +655,10 @@ def secondary_measurements(eng):
         eng_p.set_option("profile_events", 1)
         eng_p.load_weights(sd_pn, class_embed=False, color_embed=False)
         d_pos, d_rgb = torch.from_numpy(pos_np).cuda(), torch.from_numpy(rgb_np).cuda()
-        for _ in range(2):
+        for _ in range(4):
             eng_p.pointnet_features(d_pos, d_rgb, cells_p["offsets"])
         eng_p.kernel_stats("pointnet")
-        for _ in range(3):
+        for _ in range(6):
             f2 = eng_p.pointnet_features(d_pos, d_rgb, cells_p["offsets"])
         torch.cuda.synchronize()
         ms, n = eng_p.kernel_stats("pointnet")
@@ -756,10 +756,10 @@ def secondary_measurements(eng):
         hints = torch.from_numpy(rs.standard_normal((N_QUERIES, 6, 128)).astype(np.float32)).cuda()
         ci = torch.from_numpy(rs.integers(0, N_CELLS, size=N_QUERIES * TOPK).astype(np.int32)).cuda()
         hi = torch.arange(N_QUERIES, dtype=torch.int32, device="cuda").repeat_interleave(TOPK).contiguous()
-        for _ in range(2):
+        for _ in range(8):  # (the host-side set-up above let the clocks drop: 40 ms of this kernel bring them back, README "clock ramp")
             eng_f.fine_match(desc, hints, ci, hi)
         eng_f.kernel_stats("fine_match")
-        for _ in range(3):
+        for _ in range(10):
             eng_f.fine_match(desc, hints, ci, hi)
         torch.cuda.synchronize()
         ms_m, _ = eng_f.kernel_stats("fine_match")
