@@ -224,7 +224,7 @@ def test_raw_cell_frame_coordinates_through_the_backbone(eng):
 
 def test_plain_f16_option_of_the_backbone(eng):
     """Option encoder_f16 on t2l_pointnet_features: one f16 product per operand pair in the edge MLPs and the global MLP
-    (14.8 -> 8.8 ms for 10.7 k objects); features2 within 1e-3 of the restatement's scale, the magnitude watch unchanged."""
+    (11.0 -> 5.9 ms for 10.7 k objects in round 5); features2 within 1e-3 of the restatement's scale, the magnitude watch unchanged."""
     cells = synth.make_cells(4, seed=12, min_obj=2, max_obj=6)
     pos, rgb = synth.make_sampled_points(cells, 12)
     ref = OP.pointnet_features(pos, rgb, cells["offsets"], eng._sd)
