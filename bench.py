@@ -1087,6 +1087,9 @@ def format_headline(d):
                       if cfg.get(k) is not None}
     line["roofline"] = {k: _r(rl.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms",
                                                    "launches_timed", "flops_per_launch")}
+    if rl.get("frac_of_measured_ceiling") is not None:  # `peak` is the nominal rate; dense random-data MFMAs are power-limited below it
+        line["roofline"]["measured_random_data_mfma_ceiling"] = _r(rl.get("measured_random_data_mfma_ceiling_tflops"))
+        line["roofline"]["frac_of_measured_ceiling"] = _r(rl.get("frac_of_measured_ceiling"))
     if cb is not None:
         line["cpu_baseline"] = {k: _r(cb.get(k)) for k in ("value", "unit", "cores", "kind", "sample")}
         line["cpu_baseline"]["sample"] = str(line["cpu_baseline"]["sample"])[:160]
