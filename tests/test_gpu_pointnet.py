@@ -61,6 +61,30 @@ def test_magnitude_watch_hands_large_objects_to_the_f32_kernels(eng):
     assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
 
 
+def test_a_batch_of_thousands_of_objects_matches_the_restatement_cell_by_cell(eng):
+    """The self-loop tiles and the global MLP run as PERSISTENT workgroups (eight / four tiles per round, the packed-weight stream
+    wrapping round after round): with ~3,000 objects every one of them goes through several rounds. Cells are independent (the
+    self-loop edges stay inside a cell), so the restatement is run on a few cells taken from the start, the middle and the end of
+    the batch — objects that sit in different rounds and workgroups — and on flagged objects in between."""
+    cells = synth.make_cells(150, seed=21)
+    off = cells["offsets"]
+    pos, rgb = synth.make_sampled_points(cells, 21)
+    assert int(off[-1]) > 2500
+    rgb = rgb.copy()
+    big = int(off[75])           # one object in the middle leaves the f16 range: the f32 kernels recompute it (and only it)
+    rgb[big] *= np.float32(2.0e5)
+    for self_loops in (1, 0):
+        eng.set_option("pointnet_pyg_self_loops", self_loops)
+        got = run(eng, cells, pos, rgb)
+        assert np.isfinite(got).all()
+        for c0, c1 in ((0, 2), (74, 77), (148, 150)):
+            lo, hi = int(off[c0]), int(off[c1])
+            ref = OP.pointnet_features(pos[lo:hi], rgb[lo:hi], off[c0:c1 + 1] - off[c0], eng._sd, pyg_self_loops=bool(self_loops))
+            err = np.abs(got[lo:hi] - ref).max()
+            assert err < 2e-4 * max(1.0, np.abs(ref).max()), (self_loops, c0, err)
+    eng.set_option("pointnet_pyg_self_loops", 1)
+
+
 def test_degenerate_objects(eng):
     """All points identical (every ball query saturates at 32, FPS ties everywhere) and a tiny cluster (1-neighbour balls)."""
     cells = synth.make_cells(1, seed=3, min_obj=3, max_obj=3)
