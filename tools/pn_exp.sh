@@ -1,5 +1,8 @@
 #!/bin/bash
-# dev: tools/pn_eval_probe.py under rocprofv3 for every experiment build text2loc_amd/libt2l_exp_*.so (timing only: their results are wrong)
+# dev: tools/pn_eval_probe.py under rocprofv3 for every experiment build text2loc_amd/libt2l_exp_*.so (timing only: their results are wrong).
+# The builds it compared in round 5 were the one-wave-per-SIMD SetAbstraction kernel (and its first LDS-stream form) with one piece
+# compiled out each (-DT2L_EXP_PN_NOSPLIT / NOX / NOPOOL / NOWAIT / NOBAR / NODMA): those hooks went with that kernel when the
+# eight-wave form replaced it (DESIGN 3.6 keeps the numbers); the script itself works for any set of libt2l_exp_*.so.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for lib in $ROOT/text2loc_amd/libt2l.so $ROOT/text2loc_amd/libt2l_exp_*.so; do

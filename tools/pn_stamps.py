@@ -1,4 +1,5 @@
-"""Dev tool: reads the per-workgroup stamp dump of an -DT2L_EXP_PN_STAMPS build (T2L_PN_STAMPS=<file>) of pn_sa_kernel<128,256,256,64>:
+"""Dev tool: reads the per-workgroup stamp dump of an -DT2L_EXP_PN_STAMPS build (T2L_PN_STAMPS=<file>) of pn_sa_kernel<128,256,256,64>
+(round 5's measurement of the one-wave-per-SIMD form; the stamp hooks went with that kernel, DESIGN 3.6 keeps the result):
 per workgroup [start, prologue end, self-round end, end, 4 round starts, hw id] in 10 ns ticks. Prints the phase durations and, per CU,
 how much of the launch the CU had a workgroup resident (gaps between consecutive workgroups on the same CU)."""
 import sys
