@@ -617,7 +617,10 @@ __global__ __launch_bounds__(256, 1) void pn_sa_kernel(SaParams P) {
 // tile instead of 72 / 20) feeds the FT feature tiles' accumulators back to back (FT independent MFMA chains); their
 // registers turn into the split A fragments of layer 2 in place. The self-loop messages are ordinary tiles of their own
 // launch (eight per workgroup round, any object), which also finishes the level's output: the centres' kernel leaves the raw
-// maxima, the self kernel applies max(self) + bias + ReLU. No ninth round, no 32 KB of self messages in LDS.
+// maxima, the self kernel applies max(self) + bias + ReLU. No ninth round, no 32 KB of self messages in LDS. (Measured and
+// dropped: the other order — self messages first, picked up by the centres' kernel through registers or through 32 KB of LDS —
+// saves 0.1 ms in the self kernels and costs the centres' kernels 0.15-0.6 ms: vector loads in flight behind a DMA burst make the
+// stream's `s_waitcnt vmcnt(rows)` wait for that burst too, and the LDS copy lengthens every object's prologue.)
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef T2L_WS_DEPTH
 #define T2L_WS_DEPTH 2
@@ -697,6 +700,9 @@ struct WStream {
     return f;
   }
   __device__ __forceinline__ void start(HFrag (&wr)[kWsDepth]) {  // chunks 0 and 1 in LDS, the register ring filled
+    // the kernels' prologues store their points / features to LDS right before this: the first barrier publishes them, so this
+    // wave's LDS stores have to be done when it arrives (the later boundaries are bare s_barriers: nothing is published there)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     boundary();
     wr[0] = read<false, 0>();
     wr[1] = read<false, 1>();
