@@ -754,6 +754,24 @@ struct TileRows {
   }
 };
 
+// TileRows whose pieces are all requested up front and kept in registers (rows in GLOBAL memory): a vector load behind one of the
+// stream's DMA bursts is waited for with s_waitcnt vmcnt(0) by the compiler — which waits for the burst as well; one such wait
+// per tile instead of one per k-step (the global MLP: 17 per object).
+template <int CIN>
+struct TileRowsHeld : TileRows<CIN> {
+  static constexpr int S = k1ph(CIN) / 16;
+  h3_f32x8 held[S];
+  template <int ST = 0>
+  __device__ __forceinline__ void fill() {
+    if constexpr (ST < S) {
+      held[ST] = TileRows<CIN>::template load<ST>();
+      fill<ST + 1>();
+    }
+  }
+  template <int ST>
+  __device__ __forceinline__ h3_f32x8 load() const { return held[ST]; }
+};
+
 template <int K, typename G, bool SG, int NW, typename X>
 __device__ __forceinline__ void ws_l1_steps(WStream<SG, NW>& ws, HFrag (&wr)[kWsDepth], f32x16 (&acc)[G::FT], const X& x, h3_f32x8& xraw, HFrag& xf,
                                             float& amax) {
@@ -854,7 +872,8 @@ __global__ __launch_bounds__(64 * kWsWaves, 1) void pn_sa_ws_kernel(SaParams P) 
   float* spos = smem + kWsBufs * WStream<SG>::kChunkB / 4;  // [NS][3]   (the ring comes first)
   float* sx = spos + NS * 3;                                 // [NS][XS]
   float* dpos = sx + NS * XS;                                // [ND][3]
-  int* nbr = reinterpret_cast<int*>(dpos + ND * 3);          // [8 waves][32]
+  float* sb2 = dpos + ND * 3;                                // [H2] the output bias (pn_ga_ws_kernel: why not a load in the pooling)
+  int* nbr = reinterpret_cast<int*>(sb2 + H2);               // [8 waves][32]
   const int o = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, kh = lane >> 5;
   WStream<SG> ws;
   ws.open(P.wsh, smem, lane, ND / kWsWaves, SaWs<CIN, H1, H2>::CPR);
@@ -866,6 +885,7 @@ __global__ __launch_bounds__(64 * kWsWaves, 1) void pn_sa_ws_kernel(SaParams P) 
     *reinterpret_cast<float4*>(sx + (i / (CIN / 4)) * XS + (i % (CIN / 4)) * 4) = v;
   }
   for (int i = tid; i < ND * 3; i += NTH) dpos[i] = P.dst_pos[(size_t)o * ND * 3 + i];  // pn_fps_kernel
+  for (int i = tid; i < H2; i += NTH) sb2[i] = P.b2[i];
   HFrag wr[kWsDepth];
   ws.start(wr);  // (its barrier publishes the loads above)
   // ---- one 32-row tile per centre: ball query (first 32 in index order), edge MLP, max
@@ -889,7 +909,7 @@ __global__ __launch_bounds__(64 * kWsWaves, 1) void pn_sa_ws_kernel(SaParams P) 
       m = fmaxf(m, __shfl_xor(m, 32));
       const int c = nt * 32 + j;
       // with self-loop messages the level's output is finished by pn_self_ws_kernel: max(self) + bias, ReLU
-      if (kh == 0) P.dst_x[((size_t)o * ND + t) * H2 + c] = P.self_loops ? m : fmaxf(m + P.b2[c], 0.f);
+      if (kh == 0) P.dst_x[((size_t)o * ND + t) * H2 + c] = P.self_loops ? m : fmaxf(m + sb2[c], 0.f);
     };
     sa_mlp_tile_ws<CIN, H1, H2, SG, kWsWaves>(rows, ws, wr, t + kWsWaves < ND, amax, pool);
   }
@@ -951,6 +971,10 @@ __global__ __launch_bounds__(64 * kGaWaves, 1) void pn_ga_ws_kernel(const float*
   const int per_round = kGaWaves * (int)gridDim.x, rounds = (n_obj + per_round - 1) / per_round;
   WStream<SG, kGaWaves> ws;
   ws.open(stream, smem, lane, rounds, SaWs<256, 512, 1024>::CPR);
+  // the output bias through LDS: a vector load inside the pooling makes the compiler wait for vmcnt(0) there — i.e. for the DMA burst
+  // the stream issued a moment earlier, one L2 round trip per output tile (32 per object)
+  float* sb2 = smem + kWsBufs * WStream<SG, kGaWaves>::kChunkB / 4;  // [1024]
+  for (int i = tid; i < 1024; i += 64 * kGaWaves) sb2[i] = b2[i];
   HFrag wr[kWsDepth];
   ws.start(wr);
   for (int r = 0; r < rounds; ++r) {
@@ -958,13 +982,17 @@ __global__ __launch_bounds__(64 * kGaWaves, 1) void pn_ga_ws_kernel(const float*
     const bool live = id < n_obj && !obj_flags[id < n_obj ? id : 0];
     const int o = live ? id : 0;
     const float* pp = pos3 + ((size_t)o * 32 + j) * 3;
-    const TileRows<256> rows{x3 + ((size_t)o * 32 + j) * 256, kh, pp[0], pp[1], pp[2]};
+    TileRowsHeld<256> rows;
+    rows.row = x3 + ((size_t)o * 32 + j) * 256;
+    rows.kh = kh;
+    rows.dx = pp[0]; rows.dy = pp[1]; rows.dz = pp[2];
+    rows.fill();
     float amax = 0.f;
     auto pool = [&](int nt, const f32x16& acc) {
       float m = max16(acc);
       m = fmaxf(m, __shfl_xor(m, 32));
       const int c = nt * 32 + j;
-      if (live && kh == 0) f0[(size_t)o * 1024 + c] = fmaxf(m + b2[c], 0.f);
+      if (live && kh == 0) f0[(size_t)o * 1024 + c] = fmaxf(m + sb2[c], 0.f);
     };
     sa_mlp_tile_ws<256, 512, 1024, SG, kGaWaves>(rows, ws, wr, r + 1 < rounds, amax, pool);
     if (live && !(amax < kSplitF16Safe)) obj_flags[o] = 1;
@@ -1137,7 +1165,7 @@ static size_t sa_lds_bytes() {
 template <int CIN, int NS, bool SG>
 static size_t sa_ws_lds_bytes() {
   constexpr int ND = NS / 2, XS = CIN + 4;
-  return (size_t)kWsBufs * WStream<SG>::kChunkB + sizeof(float) * (NS * 3 + NS * XS + ND * 3) + sizeof(int) * (kWsWaves * 32);
+  return (size_t)kWsBufs * WStream<SG>::kChunkB + sizeof(float) * (NS * 3 + NS * XS + ND * 3 + 256) + sizeof(int) * (kWsWaves * 32);  // (+ H2 <= 256 bias values)
 }
 
 // levels 2 and 3, split or plain f16: the centres' tiles, then the self-loop tiles (which finish the output)
@@ -1255,13 +1283,17 @@ int pointnet_features_impl(t2l_ctx* ctx, const float* pos, const float* rgb, con
     }
     if (split) {
       const int grid = std::min(256, (n_obj + kGaWaves - 1) / kGaWaves);
-      if (ctx->encoder_f16) {
-        const size_t ring = (size_t)kWsBufs * WStream<true, kGaWaves>::kChunkB;
-        hipLaunchKernelGGL(pn_ga_ws_kernel<true>, dim3(grid), dim3(64 * kGaWaves), ring, s, p3, x3, W->gash, W->gab2, f0, d_flags, n_obj);
-      } else {
-        const size_t ring = (size_t)kWsBufs * WStream<false, kGaWaves>::kChunkB;
-        hipLaunchKernelGGL(pn_ga_ws_kernel<false>, dim3(grid), dim3(64 * kGaWaves), ring, s, p3, x3, W->gash, W->gab2, f0, d_flags, n_obj);
+      static PerDeviceOnce ga_attr;
+      const size_t lds_sg = (size_t)kWsBufs * WStream<true, kGaWaves>::kChunkB + 4096, lds_sp = (size_t)kWsBufs * WStream<false, kGaWaves>::kChunkB + 4096;
+      if (ga_attr.need(ctx->device)) {
+        T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sg));
+        T2L_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_ga_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp));
+        ga_attr.mark(ctx->device);
       }
+      if (ctx->encoder_f16)
+        hipLaunchKernelGGL(pn_ga_ws_kernel<true>, dim3(grid), dim3(64 * kGaWaves), lds_sg, s, p3, x3, W->gash, W->gab2, f0, d_flags, n_obj);
+      else
+        hipLaunchKernelGGL(pn_ga_ws_kernel<false>, dim3(grid), dim3(64 * kGaWaves), lds_sp, s, p3, x3, W->gash, W->gab2, f0, d_flags, n_obj);
     }
     hipLaunchKernelGGL(pn_ga_kernel, dim3(n_obj), dim3(256), lds_f, s, p3, x3, W->ga1, W->ga2, W->gab2, f0, d_flags);
   }
