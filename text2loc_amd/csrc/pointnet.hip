@@ -754,22 +754,25 @@ struct TileRows {
   }
 };
 
-// TileRows whose pieces are all requested up front and kept in registers (rows in GLOBAL memory): a vector load behind one of the
-// stream's DMA bursts is waited for with s_waitcnt vmcnt(0) by the compiler — which waits for the burst as well; one such wait
-// per tile instead of one per k-step (the global MLP: 17 per object).
-template <int CIN>
+// TileRows over rows in GLOBAL memory whose pieces are requested BATCH at a time and kept in registers: a vector load behind one of
+// the stream's DMA bursts is waited for with s_waitcnt vmcnt(0) by the compiler — which waits for the burst as well. One such wait
+// per batch instead of one per k-step (the global MLP: all 17 pieces of an object at once; the self-loop tiles: 5 / 3 x 3).
+template <int CIN, int BATCH>
 struct TileRowsHeld : TileRows<CIN> {
   static constexpr int S = k1ph(CIN) / 16;
-  h3_f32x8 held[S];
-  template <int ST = 0>
-  __device__ __forceinline__ void fill() {
-    if constexpr (ST < S) {
-      held[ST] = TileRows<CIN>::template load<ST>();
-      fill<ST + 1>();
+  mutable h3_f32x8 held[BATCH];
+  template <int ST, int E = 0>
+  __device__ __forceinline__ void fill() const {
+    if constexpr (E < BATCH && ST + E < S) {
+      held[E] = TileRows<CIN>::template load<ST + E>();
+      fill<ST, E + 1>();
     }
   }
   template <int ST>
-  __device__ __forceinline__ h3_f32x8 load() const { return held[ST]; }
+  __device__ __forceinline__ h3_f32x8 load() const {
+    if constexpr (ST % BATCH == 0) fill<ST>();
+    return held[ST % BATCH];
+  }
 };
 
 template <int K, typename G, bool SG, int NW, typename X>
@@ -939,7 +942,10 @@ __global__ __launch_bounds__(64 * kWsWaves, 1) void pn_self_ws_kernel(SaParams P
     const size_t node = (size_t)cb * NS + (size_t)(o - cb) * ND + t;  // source node k = (o - cb) ND + t of the cell's batch
     const float* sp = P.src_pos + node * 3;
     const float* dp = P.dst_pos + ((size_t)o * ND + t) * 3;
-    const TileRows<CIN> rows{P.src_x + node * CIN, kh, sp[0] - dp[0], sp[1] - dp[1], sp[2] - dp[2]};
+    TileRowsHeld<CIN, (CIN > 64 ? 3 : 5)> rows;  // (level 3: 9 pieces would not fit the 256 registers of two waves per SIMD)
+    rows.row = P.src_x + node * CIN;
+    rows.kh = kh;
+    rows.dx = sp[0] - dp[0]; rows.dy = sp[1] - dp[1]; rows.dz = sp[2] - dp[2];
     float amax = 0.f;
     auto finish = [&](int nt, const f32x16& acc) {
       if (live) {
@@ -982,11 +988,10 @@ __global__ __launch_bounds__(64 * kGaWaves, 1) void pn_ga_ws_kernel(const float*
     const bool live = id < n_obj && !obj_flags[id < n_obj ? id : 0];
     const int o = live ? id : 0;
     const float* pp = pos3 + ((size_t)o * 32 + j) * 3;
-    TileRowsHeld<256> rows;
+    TileRowsHeld<256, 17> rows;
     rows.row = x3 + ((size_t)o * 32 + j) * 256;
     rows.kh = kh;
     rows.dx = pp[0]; rows.dy = pp[1]; rows.dz = pp[2];
-    rows.fill();
     float amax = 0.f;
     auto pool = [&](int nt, const f32x16& acc) {
       float m = max16(acc);
