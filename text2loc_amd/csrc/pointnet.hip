@@ -838,8 +838,10 @@ __device__ __forceinline__ void ws_l2_steps(WStream<SG, NW>& ws, HFrag (&wr)[kWs
 // The edge MLP of one tile with the weights out of the workgroup's LDS stream. ALL EIGHT waves call it the same number of
 // times (a wave without a tile runs a copy of another and drops the result). wr: the register ring, holding the fragments of
 // the first kWsDepth steps on entry and, when `more` rounds follow, of the next round's on exit. emit(nt, acc) as sa_mlp_tile.
-template <int CIN, int H1, int H2, bool SG, int NW, typename X, typename Emit>
-__device__ __forceinline__ void sa_mlp_tile_ws(const X& x, WStream<SG, NW>& ws, HFrag (&wr)[kWsDepth], bool more, float& amax, Emit&& emit) {
+// before(nt) runs in front of the products of output tile nt (a place to request what emit(nt) will need from global memory).
+template <int CIN, int H1, int H2, bool SG, int NW, typename X, typename Emit, typename Before>
+__device__ __forceinline__ void sa_mlp_tile_ws(const X& x, WStream<SG, NW>& ws, HFrag (&wr)[kWsDepth], bool more, float& amax, Emit&& emit,
+                                               Before&& before) {
   using G = SaWs<CIN, H1, H2>;
   f32x16 acc[G::FT];  // layer 1's accumulators, then layer 2's A fragments
   {
@@ -860,9 +862,14 @@ __device__ __forceinline__ void sa_mlp_tile_ws(const X& x, WStream<SG, NW>& ws, 
     f32x16 out;
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[r] = 0.f;
+    before(nt);
     ws_l2_steps<0, G, SG, NW>(ws, wr, out, acc, more || nt + 1 < G::NT);
     emit(nt, out);
   }
+}
+template <int CIN, int H1, int H2, bool SG, int NW, typename X, typename Emit>
+__device__ __forceinline__ void sa_mlp_tile_ws(const X& x, WStream<SG, NW>& ws, HFrag (&wr)[kWsDepth], bool more, float& amax, Emit&& emit) {
+  sa_mlp_tile_ws<CIN, H1, H2, SG, NW>(x, ws, wr, more, amax, emit, [](int) {});
 }
 
 template <int CIN, int H1, int H2, int NS, bool SG>
@@ -947,19 +954,24 @@ __global__ __launch_bounds__(64 * kWsWaves, 1) void pn_self_ws_kernel(SaParams P
     rows.kh = kh;
     rows.dx = sp[0] - dp[0]; rows.dy = sp[1] - dp[1]; rows.dz = sp[2] - dp[2];
     float amax = 0.f;
-    auto finish = [&](int nt, const f32x16& acc) {
+    // the raw maxima (and the bias) of an output tile are requested BEFORE its products: the compiler waits for them with vmcnt(0),
+    // and behind the products that wait no longer sits on the stream's latest DMA burst as well
+    float raw[16], bias = 0.f;
+    float* const out0 = P.dst_x + ((size_t)o * ND + tt * 32 + 4 * kh) * H2 + j;
+    auto request = [&](int nt) {
       if (live) {
-        const int c = nt * 32 + j;
-        const float b = P.b2[c];
-        float* out = P.dst_x + ((size_t)o * ND + tt * 32 + 4 * kh) * H2 + c;
+        bias = P.b2[nt * 32 + j];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          float* pq = out + (size_t)((q & 3) + 8 * (q >> 2)) * H2;
-          *pq = fmaxf(fmaxf(*pq, acc[q]) + b, 0.f);
-        }
+        for (int q = 0; q < 16; ++q) raw[q] = out0[(size_t)((q & 3) + 8 * (q >> 2)) * H2 + nt * 32];
       }
     };
-    sa_mlp_tile_ws<CIN, H1, H2, SG, kWsWaves>(rows, ws, wr, r + 1 < rounds, amax, finish);
+    auto finish = [&](int nt, const f32x16& acc) {
+      if (live) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) out0[(size_t)((q & 3) + 8 * (q >> 2)) * H2 + nt * 32] = fmaxf(fmaxf(raw[q], acc[q]) + bias, 0.f);
+      }
+    };
+    sa_mlp_tile_ws<CIN, H1, H2, SG, kWsWaves>(rows, ws, wr, r + 1 < rounds, amax, finish, request);
     if (live && !(amax < kSplitF16Safe)) P.obj_flags[o] = 1;
   }
 }
