@@ -516,7 +516,9 @@ __device__ __forceinline__ ff_f32x4 fp_get4(const FP t, int off) {
 // acc (D[feature][token]) += W tile (STEPS k-steps of packed fragments at wp) x tokens (plane rows, this lane's half row at aoff)
 template <int STEPS, bool SG>
 __device__ __forceinline__ void fp_dot(const FP a, int aoff, const uint4* __restrict__ wp, f32x16& acc) {
-  constexpr int D = STEPS < kDotRing ? STEPS : kDotRing;
+  // ring depth 3 (same-box A/B against 2 and 4, round 5: 4.35 / 4.28 / 4.31 ms, plain f16 3.44 / 3.31 / 3.36): the fragments' L2
+  // latency is this kernel's largest single cost now
+  constexpr int kRing = 3, D = STEPS < kRing ? STEPS : kRing;
   HFrag ring[D];
 #pragma unroll
   for (int i = 0; i < D; ++i) ring[i] = load_h1<SG>(wp + T2L_HOT(i) * 128);
@@ -617,13 +619,43 @@ __device__ __forceinline__ void fp_attention(const FP x, TileGroups gx, const FP
   f32x16 qT, kT, v;
 #pragma unroll
   for (int r = 0; r < 16; ++r) qT[r] = kT[r] = v[r] = 0.f;
-#pragma unroll 4
-  for (int st = 0; st < HS; ++st) {
-    const HFrag xf = fp_frag<SG>(x, aoff + 8 * st);
-    const HFrag mf = self ? xf : fp_frag<SG>(mem, aoff + 8 * st);
-    mfma_h3<SG>(qT, load_h1<SG>(hq + T2L_HOT(st) * 128), xf);
-    mfma_h3<SG>(kT, load_h1<SG>(hk + T2L_HOT(st) * 128), mf);
-    mfma_h3<SG>(v, mf, load_h1<SG>(hv + T2L_HOT(st) * 128));
+  {  // the three weight tiles of a k-step through a register ring, requested D steps ahead and pinned there (as fp_dot). The pointers
+     // RUN through opaque increments: with `base + constant` addressing the compiler materialises and hoists one 64-bit address per
+     // load (24 of them: 120+ spilled registers); as a partly unrolled loop without a ring (rounds 4-5) every body of four steps
+     // started with the L2 round trip of its twelve loads exposed. Same-box A/B: no ring 4.28 ms, D = 1 / 2 / 3: 3.75 / 3.83 / 4.04
+     // (251 registers and no spill at D = 1; 20 / 44 spilled registers at 2 / 3); plain f16 3.45 -> 2.94.
+#ifndef T2L_ATT_RING
+#define T2L_ATT_RING 1
+#endif
+    constexpr int D = T2L_ATT_RING;
+    const uint4 *pq = hq, *pk = hk, *pv = hv;
+    asm volatile("" : "+v"(pq), "+v"(pk), "+v"(pv));
+    HFrag ring[D][3];
+    auto load3 = [&](HFrag (&f)[3]) {
+      f[0] = load_h1<SG>(pq);
+      f[1] = load_h1<SG>(pk);
+      f[2] = load_h1<SG>(pv);
+#ifndef T2L_EXP_HOTW
+      pq += 128; pk += 128; pv += 128;
+#endif
+      asm volatile("" : "+v"(pq), "+v"(pk), "+v"(pv));
+    };
+#pragma unroll
+    for (int i = 0; i < D; ++i) load3(ring[i]);
+#pragma unroll
+    for (int st = 0; st < HS; ++st) {
+      HFrag f[3];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) f[e] = ring[st % D][e];
+      if (st + D < HS) load3(ring[st % D]);
+      __builtin_amdgcn_sched_barrier(0);
+      const HFrag xf = fp_frag<SG>(x, aoff + 8 * st);
+      const HFrag mf = self ? xf : fp_frag<SG>(mem, aoff + 8 * st);
+      mfma_h3<SG>(qT, f[0], xf);
+      mfma_h3<SG>(kT, f[1], mf);
+      mfma_h3<SG>(v, mf, f[2]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   {
     const float* ib = in_proj.b;
