@@ -14,7 +14,9 @@ REPO = osp.dirname(osp.dirname(osp.abspath(__file__)))
 
 
 def test_bench_gpus_8_plumbing_on_one_gpu(tmp_path):
-    env = dict(os.environ, SCALE_SMOKE_NS="8")
+    # (eight bench processes on one box: without a cap every one of them starts a torch / BLAS thread per core — on an 8-core GPU box this
+    # test took 65-145 s instead of 10)
+    env = dict(os.environ, SCALE_SMOKE_NS="8", OMP_NUM_THREADS="2", MKL_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2")
     r = subprocess.run([osp.join(REPO, "tools", "scale_smoke.sh"), str(tmp_path)], env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "scale_smoke N=8" in r.stdout and "-> OK" in r.stdout, r.stdout
