@@ -448,6 +448,55 @@ class LanguageEncoder(nn.Module):
             hidden = hidden.detach()
         return self.head(hidden, len(descriptions))
 
+    def forward_batches(self, descriptions: List[str], batch_size: int) -> torch.Tensor:
+        """``torch.cat([self(descriptions[i:i + batch_size]) for i in range(0, n, batch_size)])`` — the text loop of ``eval_epoch``
+        (training/coarse.py:88-97) — without one Python round per batch. The batching is part of the reference's RESULT: the
+        tokenizer pads to the longest sentence of the BATCH and the intra layer has no padding mask (language_encoder.py:113-131),
+        so a description's vector depends on L = the token count of its batch's longest sentence. Behind the sentence cache with
+        the eval-mode memo a per-sentence vector is a function of (sentence, L): the batches' L values come from the cached token
+        counts (numpy), every distinct L is one gather from its memo table, and the inter-sentence layer — independent per
+        description — runs ONCE over all descriptions. Anything else (no cache, training mode, unknown or over-long sentences)
+        takes the loop."""
+        n, batch_size = len(descriptions), max(1, int(batch_size))
+        fast = (n > 0 and self._cache_usable() and isinstance(descriptions[0], str) and not self.training and not torch.is_grad_enabled()
+                and self.memoise_sentence_vectors and not self.is_fine)
+        hit = None
+        if fast:
+            cache = self.text_cache
+            hit = cache.description_rows(descriptions)
+            if hit is None:  # first sight of (some of) these descriptions: split all of them once, T5 over the unseen sentences
+                sentences, per = [], set()
+                for d in descriptions:
+                    ss = self.split_sentences(d)
+                    per.add(len(ss))
+                    sentences.extend(ss)
+                if len(per) == 1 and cache.lookup(sentences) is not None:
+                    cache.remember(descriptions, sentences)
+                    hit = cache.description_rows(descriptions)
+        if hit is None:
+            return torch.cat([self(descriptions[i:i + batch_size]) for i in range(0, n, batch_size)], dim=0)
+        ia, n_per = hit
+        cache = self.text_cache
+        tok = cache.n_tok[ia].reshape(n, n_per).max(axis=1)
+        starts = np.arange(0, n, batch_size)
+        L_desc = np.repeat(np.maximum.reduceat(tok, starts), np.diff(np.append(starts, n)))
+        rows = torch.from_numpy(ia).to(cache.device)
+        version = (bool(self.use_engine_head), self._head_generation) + tuple((t.data_ptr(), t._version) for t in self._head_params())
+        x = None
+        deferred, self._deferred = getattr(self, "_deferred", None), None  # (the memos are checked synchronously, as in _from_cache)
+        try:
+            for L in np.unique(L_desc):
+                vec = cache.sentence_vectors(self, int(L), version)
+                if x is None:
+                    x = torch.empty((n * n_per, vec.shape[1]), dtype=vec.dtype, device=vec.device)
+                sel = torch.from_numpy(np.nonzero(np.repeat(L_desc == L, n_per))[0]).to(vec.device)
+                x.index_copy_(0, sel, vec.index_select(0, rows.index_select(0, sel)))
+        finally:
+            self._deferred = deferred
+        LanguageEncoder.cache_calls += len(starts)
+        self._open_call(x.device)
+        return self._head_second_half(x, n, self.use_engine_head and x.is_cuda)
+
     @property
     def device(self):
         return next(self.inter_mlp.parameters()).device
@@ -528,6 +577,14 @@ class CellRetrievalNetwork(nn.Module):
 
     def encode_text(self, descriptions):
         return F.normalize(self.language_encoder(descriptions))
+
+    def encode_text_batches(self, descriptions, batch_size: int):
+        """``cat(encode_text(batch) for batch in batches of batch_size)`` in one pass where the text branch can
+        (``LanguageEncoder.forward_batches``: the reference's batching is kept, its Python loop is not)."""
+        le = self.language_encoder
+        if hasattr(le, "forward_batches"):
+            return F.normalize(le.forward_batches(descriptions, batch_size))
+        return torch.cat([self.encode_text(descriptions[i:i + batch_size]) for i in range(0, len(descriptions), batch_size)], dim=0)
 
     def encode_objects(self, objects, object_points=None):
         if self.training and torch.is_grad_enabled():
@@ -720,8 +777,58 @@ class CellRetrievalNetwork(nn.Module):
             packed["pn_feat"] = pn.detach().contiguous()
         return eng.encode_cells(packed)
 
+    @torch.no_grad()
+    def encode_cell_set(self, cell_set, points: bool = False, transform: str = "fixed", seed: int = 0,
+                        chunk_cells: int = 4096) -> torch.Tensor:
+        """Eval-mode ``encode_objects`` over a whole ``packing.PackedCellSet`` -> f32[n_cells,256] unit rows on the GPU: what
+        ``eval_epoch``'s database loop (training/coarse.py:99-113) computes with one ``encode_objects`` call per ``args.batch_size``
+        cells (1 by default, evaluation/args.py:11), here from the flattened dataset in chunks of ``chunk_cells`` cells. In eval mode
+        a cell's embedding is a function of that cell alone (no batch statistics, no dropout), so the chunking cannot change it —
+        ``tests/test_gpu_pipeline.py::test_eval_epoch_is_independent_of_batching`` holds that bit for bit.
+        ``points``: the published feature mode (class_embed off) — per chunk, FixedPoints(256) under ``transform`` on the GPU
+        (t2l_sample_object_points, draws keyed on (seed, chunk, object, point)) -> PointNet++ (t2l_pointnet_features) ->
+        ``pn_feat``. The per-object reductions (a1) run once per dataset and device (``PackedCellSet.reduced``)."""
+        dev = self.device
+        if dev.type != "cuda":
+            raise T2LError("encode_cell_set runs on the MI355X only (model.to('cuda')); there is no CPU fallback")
+        a = self.args
+        eng = self.engine()
+        need_pn = "class" in a.use_features and not bool(getattr(a, "class_embed", False))
+        if need_pn and not points:
+            raise T2LError("class_embed is off: the cell dataset must deliver point batches (object_points='sample')")
+        oe = self.object_encoder
+        d = cell_set.on_device(dev)
+        red = cell_set.reduced(eng, dev, oe.known_colors)
+        cls = cell_set.class_idx_on(dev, oe.known_classes)
+        n_cells = cell_set.n_cells
+        out = torch.empty((n_cells, self.embed_dim), dtype=torch.float32, device=dev)
+        offs_h = cell_set.offsets
+        chunk_cells = max(1, int(chunk_cells))
+        for ci, lo in enumerate(range(0, n_cells, chunk_cells)):
+            hi = min(n_cells, lo + chunk_cells)
+            o_lo, o_hi = int(offs_h[lo]), int(offs_h[hi])
+            packed = {"offsets": (d["offsets"][lo:hi + 1] - o_lo) if o_lo else d["offsets"][lo:hi + 1],
+                      "class_idx": cls[o_lo:o_hi], "color_idx": red["color_idx"][o_lo:o_hi], "rgb": red["rgb"][o_lo:o_hi],
+                      "center": red["center"][o_lo:o_hi], "n_pts": red["n_pts"][o_lo:o_hi]}
+            if need_pn:
+                rgb_src = d["rgb"]
+                if "color" not in a.use_features:  # ablation of the reference: void all colours (object_encoder.py:87-90)
+                    rgb_src = d.get("rgb_zero")
+                    if rgb_src is None:
+                        rgb_src = d["rgb_zero"] = torch.zeros_like(d["rgb"])
+                pos, col = eng.sample_object_points(d["xyz"], rgb_src, d["point_offsets"][o_lo:o_hi + 1],
+                                                    (int(seed) + 0x9E3779B1 * ci) & 0xFFFFFFFF, transform=transform)
+                packed["pn_feat"] = eng.pointnet_features(pos, col, offs_h[lo:hi + 1] - o_lo)
+            out[lo:hi] = eng.encode_cells(packed)
+        return out
+
     # ---- engine plumbing --------------------------------------------------------------------------------
     def engine(self) -> Engine:
+        """The engine holding the CURRENT object-branch weights. Checked on every call — an optimizer steps parameters in place
+        behind the module's back — but against a cached parameter list: (data_ptr, _version) over it costs ~24 us where walking
+        ``state_dict(keep_vars=True)`` cost ~200 us per ``encode_objects`` call (as much host time as the GPU needs for eight
+        cells). The list is rebuilt whenever the module tree may have changed hands: ``train()/eval()``, ``load_state_dict``,
+        ``to()/cuda()/float()`` (``_apply``)."""
         dev = self.device
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
         if self._engine is None or self._engine.device != idx:
@@ -729,11 +836,28 @@ class CellRetrievalNetwork(nn.Module):
             self._weights_version = None
             self._pn_weights_version = None
             self._train_bound = None
-        version = (self._train_generation,) + tuple((p.data_ptr(), p._version) for p in self._object_params())
+        params = self._obj_param_list
+        if params is None:
+            params = self._obj_param_list = list(self._object_params())
+        version = (self._train_generation, tuple([(p.data_ptr(), p._version) for p in params]))
         if version != self._weights_version:
             self.sync_weights()
             self._weights_version = version
         return self._engine
+
+    _obj_param_list = None
+
+    def train(self, mode: bool = True):
+        self._obj_param_list = None
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._obj_param_list = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._obj_param_list = None
+        return super().load_state_dict(*args, **kwargs)
 
     def _object_params(self):
         for n, p in self.state_dict(keep_vars=True).items():

@@ -61,6 +61,16 @@ def _batches(dataset, batch_size):
         yield collate_fn([dataset[i] for i in range(lo, min(n, lo + batch_size))])
 
 
+def _is_plain_sequential(dataloader) -> bool:
+    """A torch DataLoader that walks its dataset front to back in fixed-size batches (the reference's evaluation loaders:
+    shuffle off, no sampler) — the only kind whose batches ``eval_epoch`` may rebuild from the dataset without iterating it."""
+    import torch.utils.data as tud
+
+    return (isinstance(dataloader, tud.DataLoader) and isinstance(getattr(dataloader, "sampler", None), tud.SequentialSampler)
+            and isinstance(getattr(dataloader, "batch_sampler", None), tud.BatchSampler) and dataloader.batch_size is not None
+            and not dataloader.drop_last)
+
+
 def _engine_retrieve(model) -> Callable:
     def retrieve(cell_enc: torch.Tensor, text_enc: torch.Tensor, k: int):
         from .engine import MAX_TOPK
@@ -109,20 +119,39 @@ def eval_epoch(model, dataloader, args, return_encodings: bool = False, return_d
     max_k = int(np.max(args.top_k))
     retrieve = retrieve or _engine_retrieve(model)
 
+    # Engine-sized batching (default; ``args.engine_batching = False`` restores one call per ``args.batch_size`` items). The
+    # reference encodes ``args.batch_size`` items per forward call — 1 by default in evaluation (evaluation/args.py:11) — which on
+    # this engine is 11,259 launches of a kernel that wants thousands of cells. In eval mode a cell's embedding depends on that
+    # cell alone, so the DATABASE side is re-batched freely (bit-identical rows). On the QUERY side the batching is part of the
+    # result (padding to the batch's longest sentence, no padding mask): the batches stay, the per-batch Python round does not
+    # (``encode_text_batches``).
+    rebatch = bool(getattr(args, "engine_batching", True))
+    chunk_cells = int(getattr(args, "engine_batch_cells", 4096))
+    timing = {}
+
     # ---- query side (text path stays on PyTorch)
     t0 = time.time()
-    text_parts, query_cell_ids, text_batches = [], [], []
+    text_parts, query_cell_ids, rerun = [], [], []
     le = getattr(model, "language_encoder", None)
     deferred = hasattr(le, "begin_deferred") and hasattr(le, "end_deferred")
+    texts = None
+    if rebatch and hasattr(dataset, "eval_texts") and hasattr(model, "encode_text_batches") and _is_plain_sequential(dataloader):
+        texts = dataset.eval_texts()  # item order == all_poses order: what a sequential DataLoader would have delivered
     if deferred:  # no host sync per batch: the head's overflow flags are collected on the device and read ONCE behind the loop
         le.begin_deferred()
     flagged = []
     try:
-        for batch in dataloader:
-            text_parts.append(model.encode_text(batch["texts"]).detach().float())
-            query_cell_ids.extend(batch["cell_ids"])
-            if deferred:
-                text_batches.append(batch["texts"])
+        if texts is not None:
+            bs = int(dataloader.batch_size)
+            text_parts.append(model.encode_text_batches(texts, bs).detach().float())
+            rerun.append(lambda: model.encode_text_batches(texts, bs))
+            query_cell_ids.extend(p.cell_id for p in dataset.all_poses)
+        else:
+            for batch in dataloader:
+                text_parts.append(model.encode_text(batch["texts"]).detach().float())
+                query_cell_ids.extend(batch["cell_ids"])
+                if deferred:
+                    rerun.append(lambda b=batch["texts"]: model.encode_text(b))
     finally:  # whatever the loop raised, the head must leave deferred mode (or every later call skips its overflow check)
         if deferred:
             n_flags = len(getattr(le, "_deferred", None) or [])
@@ -133,18 +162,30 @@ def eval_epoch(model, dataloader, args, return_encodings: bool = False, return_d
         for i in flagged:  # a batch whose activations left the f16 range: again, on the PyTorch modules
             keep, le.use_engine_head = le.use_engine_head, False
             try:
-                text_parts[i] = model.encode_text(text_batches[i]).detach().float()
+                text_parts[i] = rerun[i]().detach().float()
             finally:
                 le.use_engine_head = keep
     text_enc = torch.cat(text_parts, dim=0)
+    timing["encode_text_s"] = time.time() - t0
     print(f"Encoded {len(text_enc)} query texts in {time.time() - t0:0.2f}.")
 
     # ---- database side: every cell once, resident on the device
-    cell_parts, db_cell_ids = [], []
-    for batch in _batches(cells_dataset, args.batch_size):
-        cell_parts.append(model.encode_objects(batch["objects"], batch["object_points"]).detach().float())
-        db_cell_ids.extend(batch["cell_ids"])
-    cell_enc = torch.cat(cell_parts, dim=0)
+    t0 = time.time()
+    if rebatch and hasattr(cells_dataset, "packed") and hasattr(model, "encode_cell_set"):
+        t1 = time.time()
+        cell_set = cells_dataset.packed()  # flattened once per dataset (cached on it); the reductions once per dataset and GPU
+        timing["pack_s"] = time.time() - t1
+        cell_enc = model.encode_cell_set(cell_set, points=bool(getattr(cells_dataset, "wants_points", False)),
+                                         transform=getattr(cells_dataset, "point_transform", "fixed"),
+                                         seed=int(getattr(cells_dataset, "point_seed", 0)), chunk_cells=chunk_cells).float()
+        db_cell_ids = list(cell_set.cell_ids)
+    else:
+        cell_parts, db_cell_ids = [], []
+        for batch in _batches(cells_dataset, max(int(args.batch_size), chunk_cells) if rebatch else args.batch_size):
+            cell_parts.append(model.encode_objects(batch["objects"], batch["object_points"]).detach().float())
+            db_cell_ids.extend(batch["cell_ids"])
+        cell_enc = torch.cat(cell_parts, dim=0)
+    timing["encode_cells_s"] = time.time() - t0  # (host time of issuing the work: the device is read behind the search)
     assert len(cell_enc) == len(dataset.all_cells)  # training/coarse.py:122
     db_cell_ids = np.array(db_cell_ids, dtype="<U32")
     query_cell_ids = np.array(query_cell_ids, dtype="<U32")
@@ -153,7 +194,10 @@ def eval_epoch(model, dataloader, args, return_encodings: bool = False, return_d
     # (a database smaller than max(top_k) yields that many columns, like the reference's `sorted_indices[0:max_k]`;
     # the engine marks missing ranks with id -1, which must never be used as an index)
     k_eff = min(max_k, len(cell_enc))
+    t0 = time.time()
     top_idx, top_scores = retrieve(cell_enc, text_enc, k_eff)
+    timing["search_s"] = time.time() - t0  # (the first device read of the run: everything enqueued above drains here)
+    t0 = time.time()
     if (np.asarray(top_idx) < 0).any():
         raise RuntimeError("retrieval returned an empty rank although k <= number of cells")
 
@@ -166,6 +210,8 @@ def eval_epoch(model, dataloader, args, return_encodings: bool = False, return_d
     accuracies = {k: float(np.mean(hits[:, :k].any(axis=1))) for k in args.top_k}
     accuracies_close = {k: float(np.mean((dists[:, :k] <= cell_size / 2).any(axis=1))) for k in args.top_k}
     top_retrievals = {q: retrieved_ids[q] for q in range(len(retrieved_ids))}
+    timing["bookkeeping_s"] = time.time() - t0
+    eval_epoch.last_timing = timing  # breakdown of the most recent call (bench.py: run_coarse_e2e)
 
     if return_encodings or return_distance:
         ce = cell_enc.cpu().numpy().astype(np.float64)

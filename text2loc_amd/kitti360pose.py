@@ -174,14 +174,40 @@ class CellOnlyDataset:
     """cells.py:187-205 ``Kitti360CoarseCellOnlyDataset``: one item per database cell, in ``all_cells`` order (never flipped
     or shuffled, as in the reference)."""
 
-    def __init__(self, cells: Sequence[CellRecord], object_points: Optional[str] = None, seed: int = 0, transform: str = "fixed"):
+    def __init__(self, cells: Sequence[CellRecord], object_points: Optional[str] = None, seed: int = 0, transform: str = "fixed",
+                 packed_holder: Optional[dict] = None):
         self.cells = list(cells)
         self._points = object_points
         self._seed = seed
         self._transform = "normalize" if transform == "rotate_normalize" else transform  # val transform: no rotation
+        self._packed_holder = packed_holder if packed_holder is not None else {}
 
     def __len__(self):
         return len(self.cells)
+
+    # ---- the engine-sized path: every cell of the database flattened ONCE (packing.PackedCellSet) ---------------------------
+    # ``coarse.eval_epoch`` / ``CellDatabase.build`` encode through it when it is there (CellRetrievalNetwork.encode_cell_set):
+    # one host pass over the objects per DATASET instead of one per forward call, the per-object reductions, FixedPoints and
+    # PointNet++ on the GPU over chunks of thousands of cells whatever ``args.batch_size`` says. The holder is shared with the
+    # parent ``Kitti360PoseDataset`` (``get_cell_dataset`` builds a new CellOnlyDataset per call: the three validation passes per
+    # epoch of training/coarse.py:283-287 must not flatten the database three times).
+    @property
+    def wants_points(self) -> bool:
+        return self._points is not None
+
+    @property
+    def point_transform(self) -> str:
+        return self._transform
+
+    @property
+    def point_seed(self) -> int:
+        return int(self._seed)
+
+    def packed(self):
+        ps = self._packed_holder.get("set")
+        if ps is None:
+            ps = self._packed_holder["set"] = packing.PackedCellSet(self.cells)
+        return ps
 
     def _object_points(self, cell, idx):
         if self._points is None:
@@ -222,8 +248,9 @@ class Kitti360PoseDataset:
         self.all_cells: List[CellRecord] = []
         self.all_poses: List[PoseRecord] = []
         self._pose_scene: List[str] = []
+        self._packed_holder: dict = {}
         for s in self.scene_names:
-            cells, poses = load_scene(base_path, s)
+            cells, poses = base_path[s] if isinstance(base_path, dict) else load_scene(base_path, s)
             self.all_cells.extend(cells)
             self.all_poses.extend(poses)
             self._pose_scene.extend([s] * len(poses))
@@ -234,8 +261,22 @@ class Kitti360PoseDataset:
         self._cell_row = {c.id: i for i, c in enumerate(self.all_cells)}
         self.hint_descriptions = [hint_sentences(p) for p in self.all_poses]
 
+    @classmethod
+    def from_records(cls, cells: Sequence[CellRecord], poses: Sequence[PoseRecord], scene_name: str = "in_memory", **kw):
+        """The same dataset over records that are already in memory (one scene): what ``load_scene`` would have returned."""
+        return cls({scene_name: (list(cells), list(poses))}, [scene_name], **kw)
+
     def __len__(self):
         return len(self.all_poses)
+
+    def eval_texts(self) -> Optional[List[str]]:
+        """Every item's ``texts`` in item order WITHOUT building the items — None when items are augmented (then the texts are a
+        function of the draw and only ``__getitem__`` knows them). ``coarse.eval_epoch`` reads the queries from here instead of
+        iterating the DataLoader: an evaluation item also carries its cell's point batch (cells.py:91-107), which the query side
+        never looks at."""
+        if self.shuffle_hints or self.flip_poses:
+            return None
+        return [" ".join(h) for h in self.hint_descriptions]
 
     def __getitem__(self, idx):
         pose = self.all_poses[idx]
@@ -272,7 +313,7 @@ class Kitti360PoseDataset:
         return list(packing.KNOWN_CLASS)
 
     def get_cell_dataset(self) -> CellOnlyDataset:
-        return CellOnlyDataset(self.all_cells, self._points, self._seed, self._transform)
+        return CellOnlyDataset(self.all_cells, self._points, self._seed, self._transform, self._packed_holder)
 
     @staticmethod
     def collate_fn(data):

@@ -110,6 +110,96 @@ def pack_cells_gpu(engine, objects: List[List[object]], known_classes: Dict[str,
     return red
 
 
+class PackedCellSet:
+    """Every cell of a database flattened ONCE on the host: object counts, labels, and the raw points of all objects concatenated
+    (f32, 24 B/point) with per-object point offsets — the input of ``t2l_reduce_objects`` (a1) and ``t2l_sample_object_points``
+    (the dataloader's FixedPoints batches) for the WHOLE dataset. The reference walks the pickled objects again on every forward
+    call (models/object_encoder.py:74-84,121-145) and once more per item in the dataloader (dataloading/kitti360pose/utils.py:
+    91-147); here the walk happens once per dataset, the device copies and the (weight-independent) per-object reductions are
+    cached per GPU, and ``CellRetrievalNetwork.encode_cell_set`` encodes from them in chunks of thousands of cells.
+
+    ``cells``: anything with ``.objects`` (each ``.label``, ``.xyz [n,3]``, ``.rgb [n,3]``) and ``.id``."""
+
+    def __init__(self, cells):
+        flat = [o for c in cells for o in c.objects]
+        self.cell_ids = [c.id for c in cells]
+        self.counts = np.array([len(c.objects) for c in cells], dtype=np.int32)
+        self.offsets = np.zeros(len(self.counts) + 1, dtype=np.int32)
+        np.cumsum(self.counts, out=self.offsets[1:])
+        self.labels = [o.label for o in flat]
+        npts = np.fromiter((len(o.xyz) for o in flat), dtype=np.int64, count=len(flat))
+        self.point_offsets = np.zeros(len(flat) + 1, dtype=np.int64)
+        np.cumsum(npts, out=self.point_offsets[1:])
+        if flat:
+            self.xyz = np.concatenate([o.xyz for o in flat], axis=0, dtype=np.float32, casting="same_kind")
+            self.rgb = np.concatenate([o.rgb for o in flat], axis=0, dtype=np.float32, casting="same_kind")
+        else:
+            self.xyz = self.rgb = np.zeros((0, 3), np.float32)
+        self._class: Dict[tuple, np.ndarray] = {}
+        self._dev: Dict[str, dict] = {}
+
+    @property
+    def n_cells(self) -> int:
+        return int(len(self.counts))
+
+    @property
+    def n_objects(self) -> int:
+        return int(self.offsets[-1])
+
+    @property
+    def n_points(self) -> int:
+        return int(self.point_offsets[-1])
+
+    def class_idx(self, known_classes: Dict[str, int]) -> np.ndarray:
+        """known_classes.get(label, 0) per object (models/object_encoder.py:81), cached per class table."""
+        key = tuple(sorted(known_classes.items()))
+        out = self._class.get(key)
+        if out is None:
+            get = known_classes.get
+            out = self._class[key] = np.fromiter((get(lb, 0) for lb in self.labels), dtype=np.int32, count=len(self.labels))
+        return out
+
+    def on_device(self, device) -> Dict[str, "torch.Tensor"]:
+        """The points, offsets (and later the reductions) as tensors on ``device``, copied once."""
+        import torch
+
+        key = str(torch.device(device))
+        d = self._dev.get(key)
+        if d is None:
+            d = self._dev[key] = {"xyz": torch.from_numpy(self.xyz).to(device), "rgb": torch.from_numpy(self.rgb).to(device),
+                                  "point_offsets": torch.from_numpy(self.point_offsets).to(device),
+                                  "offsets": torch.from_numpy(self.offsets).to(device)}
+        return d
+
+    def reduced(self, engine, device, known_colors: Optional[Dict[str, int]] = None) -> Dict[str, "torch.Tensor"]:
+        """a1 for every object of the dataset in one launch pair (t2l_reduce_objects): mean rgb, nearest colour row, mean xyz,
+        point count — functions of the points alone, so cached beside the device copy."""
+        d = self.on_device(device)
+        if "red" not in d:
+            known_colors = known_colors or color_table()
+            rows = np.array([known_colors[c] for c in COLOR_NAMES], dtype=np.int32)
+            d["red"] = engine.reduce_objects(d["xyz"], d["rgb"], self.point_offsets, COLORS, rows)
+        return d["red"]
+
+    def class_idx_on(self, device, known_classes: Dict[str, int]):
+        import torch
+
+        d = self.on_device(device)
+        key = ("class", tuple(sorted(known_classes.items())))
+        if key not in d:
+            d[key] = torch.from_numpy(self.class_idx(known_classes)).to(device)
+        return d[key]
+
+    def release_device(self, device=None):
+        """Drop the device copies (all devices when ``device`` is None): the raw points are 24 B each."""
+        import torch
+
+        if device is None:
+            self._dev.clear()
+        else:
+            self._dev.pop(str(torch.device(device)), None)
+
+
 # transform name -> t2l_sample_object_points flags (include/t2l.h: T2L_SAMPLE_NORMALIZE = 1, T2L_SAMPLE_ROTATE = 2)
 POINT_TRANSFORMS = {"fixed": 0, "normalize": 1, "rotate_normalize": 3}
 
@@ -186,6 +276,6 @@ def to_device(packed: Dict[str, np.ndarray], device) -> Dict[str, "torch.Tensor"
             if k != "counts"}
 
 
-__all__ = ["KNOWN_CLASS", "COLOR_NAMES", "class_table", "color_table", "object_features", "pack_cells",
+__all__ = ["KNOWN_CLASS", "COLOR_NAMES", "class_table", "color_table", "object_features", "pack_cells", "PackedCellSet",
            "pack_cells_gpu", "sample_object_points", "sample_object_points_gpu", "to_device", "POINT_TRANSFORMS",
            "point_transform_from_args"]

@@ -261,3 +261,129 @@ def make_queries_for(db: np.ndarray, n_queries: int, seed: int = 0, noise: float
     nz = unit_rows(rng.standard_normal((n_queries, db.shape[1])))
     q = unit_rows(db[target].astype(np.float64) + noise * nz).astype(np.float32)
     return q, target.astype(np.int64)
+
+
+# ----------------------------------------------------------------------------------------------
+# a whole KITTI360Pose-shaped dataset in memory (cells with raw object points, poses with hints)
+# ----------------------------------------------------------------------------------------------
+HINT_DIRECTIONS = ("north", "south", "east", "west", "on-top")
+
+
+def make_k360_records(n_cells: int, n_poses: int, seed: int = 0, pts_per_obj=(24, 64), n_hints: int = 6,
+                      cell_size: float = 30.0, cell_dist: float = 10.0, scene: str = "0010"):
+    """(cells, poses): record objects shaped like the reference's pickled ``Cell`` / ``Object3d`` / ``Pose`` /
+    ``DescriptionBestCell`` (datapreparation/kitti360pose/imports.py:8-245) — ``text2loc_amd.kitti360pose``'s record types, the
+    same ones its reader returns — for ``Kitti360PoseDataset.from_records``. Cells follow ``make_cells`` (n_i ~ U{6..35}), every
+    object carries RAW points (``pts_per_obj`` = inclusive range of point counts; KITTI360Pose's mean is 1,827 — kept small here so
+    that 11,259 cells fit a bench host), cells sit on a square grid ``cell_dist`` apart (overlapping, as prepare.py lays them out),
+    every pose lies in a random cell and is described by ``n_hints`` of that cell's objects with the template fields
+    ``hint_sentences`` reads (direction, object_color_text, object_label)."""
+    from .kitti360pose import CellRecord, HintRecord, ObjectRecord, PoseRecord
+
+    cn = make_cells(n_cells, seed=seed)
+    rng = np.random.default_rng([seed, 0x360])
+    total = int(cn["offsets"][-1])
+    npts = rng.integers(int(pts_per_obj[0]), int(pts_per_obj[1]) + 1, size=total).astype(np.int64)
+    poff = np.zeros(total + 1, dtype=np.int64)
+    np.cumsum(npts, out=poff[1:])
+    P = int(poff[-1])
+    obj_of = np.repeat(np.arange(total), npts)
+    xyz_all = cn["center"].astype(np.float64)[obj_of] + 0.02 * rng.standard_normal((P, 3))
+    rgb_all = np.clip(cn["rgb"][obj_of] + (0.05 * rng.standard_normal((P, 3))).astype(np.float32), 0, 1).astype(np.float32)
+    labels = [KNOWN_CLASS[int(c) - 1] for c in cn["class_idx"]]
+    colors = [COLOR_NAMES[int(c)] for c in nearest_color_index(cn["rgb"])]
+    side = int(np.ceil(np.sqrt(n_cells)))
+    cells = []
+    for b in range(n_cells):
+        lo, hi = int(cn["offsets"][b]), int(cn["offsets"][b + 1])
+        objs = []
+        for o in range(lo, hi):
+            r = ObjectRecord()
+            r.__dict__.update(id=o, instance_id=o, xyz=xyz_all[poff[o]:poff[o + 1]], rgb=rgb_all[poff[o]:poff[o + 1]], label=labels[o])
+            objs.append(r)
+        x0, y0 = (b % side) * cell_dist, (b // side) * cell_dist
+        c = CellRecord()
+        c.__dict__.update(id=f"{scene}_{b:05d}", scene_name=scene, objects=objs, cell_size=float(cell_size),
+                          bbox_w=np.array([x0, y0, 0.0, x0 + cell_size, y0 + cell_size, cell_size], dtype=np.float64))
+        cells.append(c)
+    poses = []
+    target = rng.integers(0, n_cells, size=n_poses)
+    in_cell = rng.uniform(0.25, 0.75, size=(n_poses, 3))
+    for q in range(n_poses):
+        b = int(target[q])
+        lo, n_obj = int(cn["offsets"][b]), int(cn["counts"][b])
+        pick = lo + rng.choice(n_obj, size=n_hints, replace=n_obj < n_hints)
+        descs = []
+        for o in pick:
+            d = cn["center"][o][:2] - in_cell[q, :2]
+            if float(np.abs(d).max()) < 0.05:
+                direction = "on-top"
+            elif abs(d[0]) >= abs(d[1]):
+                direction = "east" if d[0] > 0 else "west"
+            else:
+                direction = "north" if d[1] > 0 else "south"
+            h = HintRecord()
+            h.__dict__.update(direction=direction, object_label=labels[o], object_color_text=colors[o], object_id=int(o),
+                              closest_point=cn["center"][o].astype(np.float64).copy())
+            descs.append(h)
+        p = PoseRecord()
+        bb = cells[b].bbox_w
+        p.__dict__.update(pose=in_cell[q].copy(), pose_w=bb[0:3] + in_cell[q] * cell_size, cell_id=cells[b].id, scene_name=scene,
+                          descriptions=descs)
+        poses.append(p)
+    return cells, poses
+
+
+def make_text_cache(sentences, device, seed: int = 0, tok_range=(9, 14), max_tokens: int = 16, dim: int = 1024):
+    """A ``TextCache`` over ``sentences`` whose "T5 hidden states" are seeded noise (the image holds no T5-large weights):
+    BASELINE config 2's "frozen T5-large embeddings precomputed", with per-sentence token counts drawn from ``tok_range`` so that
+    the batch-dependent padding length L of the reference's text path is exercised."""
+    import torch
+
+    from .text_cache import TextCache
+
+    sentences = list(sentences)
+    rng = np.random.default_rng([seed, 0x7C])
+    cache = TextCache(None, None, device, max_tokens=max_tokens, dim=dim)
+    g = torch.Generator(device="cpu").manual_seed(int(seed))
+    cache.hidden = (0.2 * torch.randn(len(sentences), max_tokens, dim, generator=g)).to(device)
+    cache.n_tok = rng.integers(int(tok_range[0]), int(tok_range[1]) + 1, size=len(sentences)).astype(np.int32)
+    cache.index = {s: i for i, s in enumerate(sentences)}
+    return cache
+
+
+def coarse_args(**kw):
+    """The published coarse configuration as the Namespace the reference's scripts hand the model (README.md:87-99,
+    evaluation/args.py) — ``class_embed`` / ``color_embed`` off = PointNet++ features, the published mode."""
+    import argparse
+
+    a = argparse.Namespace(coarse_embed_dim=256, object_size=28, object_inter_module_num_heads=4, object_inter_module_num_layers=2,
+                           hungging_model=None, fixed_embedding=True, intra_module_num_layers=1, intra_module_num_heads=4,
+                           inter_module_num_layers=1, inter_module_num_heads=4, class_embed=False, color_embed=False,
+                           use_features=["class", "color", "position", "num"], ranking_loss="contrastive", top_k=[1, 3, 5, 10],
+                           threshs=[5, 10, 15], batch_size=1, no_pc_augment=True, pointnet_freeze=True)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def make_coarse_model(args, device="cuda", seed: int = 0, sentences=None):
+    """``CellRetrievalNetwork`` with seeded weights for every branch (object branch, PointNet++, text head) in eval mode on
+    ``device``; T5 is absent (``llm_model`` is a placeholder) — with ``sentences`` the text branch sits behind a synthetic
+    ``TextCache`` over them (``make_text_cache``), i.e. BASELINE config 2's precomputed T5 embeddings."""
+    import torch
+
+    from .cell_retrieval import CellRetrievalNetwork, LanguageEncoder
+
+    le = LanguageEncoder(256, fixed_embedding=True, intra_module_num_layers=1, inter_module_num_layers=1, llm_model=object(),
+                         tokenizer=None, input_dim=1024)
+    model = CellRetrievalNetwork(list(KNOWN_CLASS), list(COLOR_NAMES), args, language_encoder=le)
+    sd = dict(make_object_branch_weights(seed))
+    sd.update(make_pointnet_weights(seed, n_classes=len(KNOWN_CLASS), n_colors=len(COLOR_NAMES)))
+    sd.update(make_language_head_weights(seed))
+    missing = model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=False)
+    assert not [k for k in missing.unexpected_keys], missing.unexpected_keys
+    model = model.to(device).eval()
+    if sentences is not None:
+        le.text_cache = make_text_cache(sentences, device, seed=seed)
+    return model

@@ -126,9 +126,9 @@ class TextCache:
         ia = np.asarray(idx, dtype=np.int64)
         return torch.from_numpy(ia).to(self.device), int(self.n_tok[ia].max())
 
-    def lookup_descriptions(self, descriptions: List[str]):
-        """The same for whole descriptions seen before (one dict probe per description instead of a regex split and one probe per
-        sentence: 4,096 descriptions cost ~1 ms of Python instead of ~15). -> (rows, L, sentences per description) or None."""
+    def description_rows(self, descriptions: List[str]):
+        """-> (cache rows of the descriptions' sentences i64[n * n_per] (HOST, description-major), n_per) when every description was
+        seen before and all hold the same number of sentences, else None."""
         if not descriptions:
             return None
         ids = list(map(self._desc.get, descriptions))
@@ -139,7 +139,15 @@ class TextCache:
         n_per = int(n[0])
         if n_per == 0 or (n != n_per).any():
             return None
-        ia = self._desc_rows[ids, :n_per].reshape(-1)
+        return self._desc_rows[ids, :n_per].reshape(-1), n_per
+
+    def lookup_descriptions(self, descriptions: List[str]):
+        """The same for whole descriptions seen before (one dict probe per description instead of a regex split and one probe per
+        sentence: 4,096 descriptions cost ~1 ms of Python instead of ~15). -> (rows, L, sentences per description) or None."""
+        hit = self.description_rows(descriptions)
+        if hit is None:
+            return None
+        ia, n_per = hit
         self.hits += 1
         return torch.from_numpy(ia).to(self.device), int(self.n_tok[ia].max()), n_per
 
