@@ -71,6 +71,40 @@ def _is_plain_sequential(dataloader) -> bool:
             and not dataloader.drop_last)
 
 
+class _StaticTables:
+    """What the bookkeeping reads from the duck-typed cell / pose objects, gathered ONCE per dataset: the reference walks
+    ``all_cells`` and ``all_poses`` with Python loops on every call (training/coarse.py:127-146, evaluation/pipeline.py:62-83) —
+    15k attribute reads + ``get_center`` calls cost more than the GPU spends on encoding and searching the whole database."""
+
+    def __init__(self, cells, poses):
+        self.n_cells, self.n_poses = len(cells), len(poses)
+        self.cell_ids = np.array([str(c.id) for c in cells], dtype="<U32")
+        self.centers_xy = np.array([np.asarray(c.get_center(), dtype=np.float64)[0:2] for c in cells]).reshape(-1, 2)
+        self.bbox_xy = np.array([np.asarray(c.bbox_w, dtype=np.float64)[0:2] for c in cells]).reshape(-1, 2)
+        self.cell_size = np.array([float(c.cell_size) for c in cells], dtype=np.float64)
+        self.cell_scene = np.array([str(c.id).split("_")[0] for c in cells])
+        self.pose_xy = np.array([np.asarray(p.pose_w, dtype=np.float64)[0:2] for p in poses]).reshape(-1, 2)
+        self.pose_cell_ids = np.array([str(p.cell_id) for p in poses], dtype="<U32")
+        self.pose_scene = np.array([str(p.cell_id).split("_")[0] for p in poses])
+        row = {cid: i for i, cid in enumerate(self.cell_ids.tolist())}
+        self.unique_ids = len(row) == self.n_cells
+        self.pose_rows = np.array([row.get(cid, -1) for cid in self.pose_cell_ids.tolist()], dtype=np.int64)  # -1: a cell outside the DB
+
+
+def _static_tables(dataset) -> "_StaticTables":
+    cells, poses = dataset.all_cells, dataset.all_poses
+    key = (id(cells), len(cells), id(poses), len(poses))
+    hit = getattr(dataset, "_t2l_static_tables", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    t = _StaticTables(cells, poses)
+    try:
+        dataset._t2l_static_tables = (key, t)
+    except Exception:  # (a dataset that refuses new attributes: gathered per call, as before)
+        pass
+    return t
+
+
 def _engine_retrieve(model) -> Callable:
     def retrieve(cell_enc: torch.Tensor, text_enc: torch.Tensor, k: int):
         from .engine import MAX_TOPK
@@ -104,7 +138,7 @@ def _engine_retrieve(model) -> Callable:
 
 @torch.no_grad()
 def eval_epoch(model, dataloader, args, return_encodings: bool = False, return_distance: bool = False,
-               retrieve: Optional[Callable] = None):
+               retrieve: Optional[Callable] = None, _extras: Optional[dict] = None):
     """Returns (accuracies{k: float}, accuracies_close{k: float}, top_retrievals{q: ndarray['<U32'][max(top_k)]})
     (+ encodings / dists / scores variants, training/coarse.py:152-157). ``retrieve`` replaces the search step
     (tests of the host bookkeeping pass the oracle here); by default it is the model's HIP engine on this process's GPU.
@@ -201,17 +235,27 @@ def eval_epoch(model, dataloader, args, return_encodings: bool = False, return_d
     if (np.asarray(top_idx) < 0).any():
         raise RuntimeError("retrieval returned an empty rank although k <= number of cells")
 
-    # ---- accuracies (host bookkeeping on [Q,K] arrays)
+    # ---- accuracies (host bookkeeping on [Q,K] arrays; the per-dataset tables are gathered once, _StaticTables)
+    tabs = _static_tables(dataset)
+    same_db = tabs.unique_ids and len(db_cell_ids) == tabs.n_cells and np.array_equal(db_cell_ids, tabs.cell_ids)
     retrieved_ids = db_cell_ids[top_idx]  # [Q,K]
-    hits = retrieved_ids == query_cell_ids[:, None]
-    centers = np.array([c.get_center()[0:2] for c in cells], dtype=np.float64)
-    query_poses_w = np.array([p.pose_w[0:2] for p in dataset.all_poses], dtype=np.float64)
+    if same_db and len(query_cell_ids) == tabs.n_poses and np.array_equal(query_cell_ids, tabs.pose_cell_ids):
+        hits = top_idx == tabs.pose_rows[:, None]  # ids are unique: equal ids <=> equal rows (integer compare instead of 41k strings)
+    else:
+        hits = retrieved_ids == query_cell_ids[:, None]
+    if same_db:
+        centers, query_poses_w = tabs.centers_xy, tabs.pose_xy
+    else:
+        centers = np.array([c.get_center()[0:2] for c in cells], dtype=np.float64)
+        query_poses_w = np.array([p.pose_w[0:2] for p in dataset.all_poses], dtype=np.float64)
     dists = np.linalg.norm(query_poses_w[:, None, :] - centers[top_idx], axis=2)  # [Q,K]
     accuracies = {k: float(np.mean(hits[:, :k].any(axis=1))) for k in args.top_k}
     accuracies_close = {k: float(np.mean((dists[:, :k] <= cell_size / 2).any(axis=1))) for k in args.top_k}
-    top_retrievals = {q: retrieved_ids[q] for q in range(len(retrieved_ids))}
+    top_retrievals = dict(enumerate(retrieved_ids))
     timing["bookkeeping_s"] = time.time() - t0
-    eval_epoch.last_timing = timing  # breakdown of the most recent call (bench.py: run_coarse_e2e)
+    eval_epoch.last_timing = timing  # breakdown of the most recent call (bench_e2e.py)
+    if _extras is not None:
+        _extras.update(top_idx=np.asarray(top_idx), same_db=same_db, tables=tabs, retrieved_ids=retrieved_ids)
 
     if return_encodings or return_distance:
         ce = cell_enc.cpu().numpy().astype(np.float64)
@@ -258,15 +302,20 @@ def _pose_cell_tables(poses, cells, retrievals):
 def run_coarse(model, dataloader, args, retrieve: Optional[Callable] = None):
     """Returns (retrievals: List[ndarray of cell ids], accuracies{k:{t: float}}) — the result contract of
     evaluation/pipeline.py:41-87, computed for all poses at once on [Q,K] arrays instead of per pose."""
-    acc, acc_close, top = eval_epoch(model, dataloader, args, retrieve=retrieve)
+    extras: dict = {}
+    acc, acc_close, top = eval_epoch(model, dataloader, args, retrieve=retrieve, _extras=extras)
     print("Retrieval Accs:")
     print(acc)
     print("Retrieval Accs Close:")
     print(acc_close)
     ds = dataloader.dataset
-    retrievals = [top[i] for i in range(len(top))]
+    retrievals = list(extras["retrieved_ids"])
     assert len(retrievals) == len(ds.all_poses)
-    pose_xy, pose_scene, bbox_xy, size, scene = _pose_cell_tables(ds.all_poses, ds.all_cells, retrievals)
+    if extras["same_db"]:  # the retrieved ROWS are at hand: no id -> row dictionary walk over [Q,K] strings
+        t, ridx = extras["tables"], extras["top_idx"]
+        pose_xy, pose_scene, bbox_xy, size, scene = t.pose_xy, t.pose_scene, t.bbox_xy[ridx], t.cell_size[ridx], t.cell_scene[ridx]
+    else:
+        pose_xy, pose_scene, bbox_xy, size, scene = _pose_cell_tables(ds.all_poses, ds.all_cells, retrievals)
     centre = np.full(bbox_xy.shape, 0.5)  # the coarse-only estimate is the cell centre (pipeline.py:72)
     ok = sample_accuracies_batch(pose_xy, pose_scene, bbox_xy, size, scene, centre, args.top_k, args.threshs)
     return retrievals, {k: {t: float(np.mean(ok[k][t])) for t in args.threshs} for k in args.top_k}
