@@ -168,7 +168,10 @@ int64_t t2l_db_rows(const t2l_ctx* ctx);
  *                                  -inf where idx == -1. May be NULL.
  * Result contract: identical to a float64 scan + stable descending sort (exact ties: lower row id
  * first). Internally: f32 MFMA candidate scan -> float64 re-rank -> per-query certificate; queries
- * whose certificate fails are re-done by an exact float64 scan on the device (no host round trip). */
+ * whose certificate fails are re-done by an exact float64 scan on the device (no host round trip).
+ * One stream at a time: a context's scratch (candidate lists, counters, the small-batch path's published lists and ticket
+ * counters) is per context, not per stream — calls on one context may be issued on different streams only when the caller
+ * orders them (events / synchronisation); concurrent searches need one context each, or t2l_search_lanes. */
 int t2l_search(t2l_ctx* ctx, const float* queries, int32_t n_queries, int32_t k, int32_t* out_idx,
                double* out_score, void* stream);
 /* n_batches independent searches of n_queries queries each, issued back to back from C: queries dev f32[n_batches, n_queries, 256],

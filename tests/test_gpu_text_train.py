@@ -364,12 +364,21 @@ def test_optimizer_checkpoints_migrate_between_the_two_head_layouts():
         mw, ow = build(writer_engine)
         for step in range(2):
             one_step(mw, ow, 90 + step)
+        # a decayed learning rate (the reference's ExponentialLR / StepLR, training/coarse.py:272-275): the resumed head must step at
+        # the DECAYED rate whichever group list the checkpoint had ([obj, rest] against [obj, rest, text] / [obj, text])
+        sched = torch.optim.lr_scheduler.ExponentialLR(ow, 0.5)
+        sched.step()
+        assert all(abs(g["lr"] - 1e-4) < 1e-12 for g in ow.param_groups)
         ckpt_model = {k: v.detach().clone() for k, v in mw.state_dict().items()}
         ckpt_opt = ow.state_dict()
         assert (ckpt_opt["t2l_text_engine"] is not None) == writer_engine
         mr, orr = build(not writer_engine)
+        kinds_before = [g["t2l_engine"] for g in orr.param_groups]
         mr.load_state_dict(ckpt_model)
         orr.load_state_dict(ckpt_opt)
+        assert [g["t2l_engine"] for g in orr.param_groups] == kinds_before          # markers are the reader's own
+        assert all(abs(g["lr"] - 1e-4) < 1e-12 for g in orr.param_groups), [g["lr"] for g in orr.param_groups]
+        assert [g["t2l_engine"] for g in orr.state_dict()["param_groups"]] == kinds_before
         # the head's moments arrived on the other side, element for element
         head = [("language_encoder." + n, p) for n, p in mw.language_encoder.engine_optimizer_params()]
         if writer_engine:  # engine -> torch state

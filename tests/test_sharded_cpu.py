@@ -350,6 +350,27 @@ def _rworker(rank, world, port, out_q):
         res["shape_raises"] = False
     except RuntimeError:
         res["shape_raises"] = True
+    # (5) identical data holding NaN / inf is NOT rank divergence (NaN != NaN): a warning that names the non-finite values
+    import warnings
+
+    bad = torch.from_numpy(db.copy())
+    bad[3, 7], bad[9, 0] = float("nan"), float("inf")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        try:
+            assert_replicated([bad], None, "databases")
+            res["nan_same_data_passes"] = any("non-finite" in str(x.message) for x in w)
+        except RuntimeError:
+            res["nan_same_data_passes"] = False
+    # ... and a NaN on ONE rank only still raises
+    one = torch.from_numpy(db.copy())
+    if rank == 1:
+        one[0, 0] = float("nan")
+    try:
+        assert_replicated([one], None, "databases")
+        res["nan_one_rank_raises"] = False
+    except RuntimeError:
+        res["nan_one_rank_raises"] = True
     out_q.put((rank, res))
     dist.destroy_process_group()
 

@@ -331,6 +331,10 @@ int t2l_merge_gathered(t2l_ctx* ctx, const void* blocks, int64_t block_bytes, in
 
 // counters of the last search of the context's own scratch set, or — with lanes — of the last search of EVERY lane, summed
 static hipError_t read_counters(t2l_ctx* ctx, int32_t* out8) {
+  if (ctx->last_search_small) {  // exact from the start: nothing failed a certificate, nothing fell back
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    return hipSuccess;
+  }
   hipError_t e = hipMemcpy(out8, ctx->fb_count, 8 * sizeof(int32_t), hipMemcpyDeviceToHost);
   if (e != hipSuccess || ctx->n_lanes <= 1) return e;
   for (int i = 0; i < 8; ++i) out8[i] = 0;
@@ -568,7 +572,7 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
   } else if (!strcmp(name, "search_small")) {
     ctx->search_small = value != 0;
   } else if (!strcmp(name, "search_small_wgs")) {
-    if (value < 0 || value > 256) return fail(ctx, T2L_EINVAL, "search_small_wgs: 0 (default: 256) .. 256 workgroups per slice");
+    if (value < 0 || value > 256) return fail(ctx, T2L_EINVAL, "search_small_wgs: 0 (default by query count: 128 or 192) .. 256 workgroups per slice");
     ctx->search_small_wgs = (int)value;
   } else if (!strcmp(name, "search_xcd_qgroups")) {
     if (value != 1 && value != 2 && value != 4 && value != 8) return fail(ctx, T2L_EINVAL, "search_xcd_qgroups must be 1, 2, 4 or 8");

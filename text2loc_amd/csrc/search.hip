@@ -1570,6 +1570,7 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
     T2L_HIP(ctx, hipGetLastError());
     return T2L_OK;
   }
+  ctx->last_search_small = false;
   // few queries against a large shard: stream the DB once through every CU (search_stream.hip)
   if (Q <= 64 && n_rows >= ctx->stream_min_rows && n_rows > 0 && ctx->search_mode == 0 && ctx->nsplit_override == 0)
     return search_stream_impl(ctx, q, Q, K, out_idx, out_score, s);
@@ -1629,6 +1630,7 @@ int search_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_idx, do
   // flags[Q] + f32 thresholds[Q] + flagged list[Q] + deferred list[Q] + uncertified list[Q] (search_exact.hip)
   if ((rc = grow(ctx, (void**)&ctx->flags, &ctx->flag_cap, (size_t)5 * Q * sizeof(int32_t))) != T2L_OK) return rc;
   std::swap(ctx->fb_count, ctx->fb_prev);  // this call counts in the bank the previous call cleared (reset_counts)
+  ctx->last_search_small = false;
   if (ctx->search_auto && ctx->heavy && ctx->all_exact && n_seg == 1 && (ctx->all_exact_calls++ & 7) != 7) {
     const int seq = ++ctx->stat_seq;
     // (block 0 parks the counters before any block's exactd successor reads them: the launches are stream-ordered)

@@ -220,7 +220,8 @@ __global__ __launch_bounds__(256) void smallq_kernel(const float* __restrict__ d
   // is a mediocre score that most published entries pass.) The phase is a chain of dependent memory round trips (~1 us each), so
   // every stage issues ALL its loads before it consumes one, the stages run for the slice's queries together, and the last two
   // stages give every query its own wave. One query and K <= 16: heads and lists arrive in ONE round trip (FUSE).
-  if (blockIdx.y == 0 && tid < 16 && fb_count) fb_count[tid] = 0;  // this call's counters: nothing failed, nothing fell back
+  // (the batched path's counters are left alone: a small call between two batched calls must not erase the earlier call's report
+  // card — the host answers t2l_search_fallbacks with zeros after a small call, ctx->last_search_small)
   const unsigned e0 = (unsigned)(blockIdx.y * kSmallNQ * G * K);  // first entry of this slice
   auto load_entry = [&](unsigned e) { return __builtin_amdgcn_raw_buffer_load_b128(rsrc, e * 16u, 0, 16); };  // (aux 16 = sc1: L1-bypassing)
   auto entry_bits = [](u32x4s v) { return (unsigned long long)v[0] | ((unsigned long long)v[1] << 32); };
@@ -461,13 +462,20 @@ int search_small_impl(t2l_ctx* ctx, const float* q, int Q, int K, int32_t* out_i
   const dim3 grid(G, slices);
 #define T2L_SMALL(NQv)                                                                                                                         \
   hipLaunchKernelGGL(smallq_kernel<NQv>, grid, dim3(256), 0, s, (const float*)ctx->db, n_rows, R, q, Q, K, (int)ctx->row_offset,               \
-                     reinterpret_cast<uint4*>(ctx->small_part), (unsigned)need, ctx->small_ticket, last_ticket, out_idx, out_score, ctx->fb_count)
+                     reinterpret_cast<uint4*>(ctx->small_part), (unsigned)need, ctx->small_ticket, last_ticket, out_idx, out_score, (int32_t*)nullptr)
   if (nq == 1) T2L_SMALL(1);
   else if (nq == 2) T2L_SMALL(2);
   else T2L_SMALL(4);
 #undef T2L_SMALL
   event_end(ctx, "search_small", s);
-  T2L_HIP(ctx, hipGetLastError());
+  if (const hipError_t le = hipGetLastError(); le != hipSuccess) {
+    // no workgroup drew a ticket, but the host bases are G ahead: bring both back to zero (stream-ordered) so that the next call's
+    // last arriver exists — otherwise every later call would return T2L_OK with unwritten outputs
+    (void)hipMemsetAsync(ctx->small_ticket, 0, sizeof(unsigned) * (kSmallMaxQ / kSmallNQ), s);
+    for (auto& b : ctx->small_ticket_base) b = 0u;
+    return fail(ctx, T2L_EHIP, std::string("smallq_kernel launch: ") + hipGetErrorString(le));
+  }
+  ctx->last_search_small = true;  // this call has no certificate and no fallback: its counters are all zero by construction
   return T2L_OK;
 }
 

@@ -108,7 +108,8 @@ struct t2l_ctx {
   int search_auto = 1;
   int pair_ll = 6;       // per-lane list length of the paired scan (5 or 6)
   int search_small = 1;      // batches of <= 16 queries against <= 65,536 rows: the one-launch exact float64 search (search_small.hip)
-  int search_small_wgs = 0;  // ... its workgroups per 4-query slice (0 = 256: one per CU)
+  int search_small_wgs = 0;  // ... its workgroups per 4-query slice (0 = by query count: 128 for Q <= 2 or Q > 8, else 192)
+  bool last_search_small = false;  // the last search ran the one-launch path: t2l_search_fallbacks answers 0 (it leaves the counters alone)
   unsigned* small_ticket = nullptr;       // dev u32[4]: arrival tickets per slice, running totals
   unsigned small_ticket_base[4] = {0, 0, 0, 0};
   void* small_part = nullptr;             // published per-workgroup top-K lists {f64 score | i32 row}

@@ -203,8 +203,23 @@ class Adam(torch.optim.Optimizer):
         return out
 
     def load_state_dict(self, sd):
-        for g, saved in zip(self.param_groups, sd["param_groups"]):
-            g.update({k: v for k, v in saved.items() if k != "params"})
+        # hyper-parameters go back by the group's MARKER, not its position: the two head layouts have different group lists
+        # ([obj, rest] against [obj, rest, text] or [obj, text]). A group with no counterpart in the checkpoint is the text head
+        # under the other layout: it takes lr / betas / eps of the group that held the head there (text <-> rest); the marker
+        # itself is never taken from the checkpoint.
+        by_kind = {}
+        for sg in sd["param_groups"]:
+            by_kind.setdefault(sg.get("t2l_engine", None), sg)
+        for g in self.param_groups:
+            kind = g["t2l_engine"]
+            src = by_kind.get(kind)
+            if src is None and kind == "text_head":
+                src = by_kind.get(False)
+            if src is None and kind is False:
+                src = by_kind.get("text_head")
+            if src is None:
+                continue
+            g.update({k: v for k, v in src.items() if k not in ("params", "t2l_engine")})
         saved = self._saved_moments(sd)
         if self._torch is not None:
             rest = [(n, p) for n, p, k in self._non_obj if k == "rest"]

@@ -95,11 +95,17 @@ def assert_replicated(tensors, group=None, what: str = "tensors"):
     world, _ = world_rank(group)
     if world == 1:
         return
-    fp = []
+    fp, n_bad = [], 0
     for t in tensors:
         x = t.detach().reshape(-1).to(torch.float64)
+        # non-finite values (an overflowed / untrained encoder) are counted and zeroed: NaN != NaN would otherwise read as "the
+        # ranks differ" on identical data; the count is part of the fingerprint and is reported as what it is
+        finite = torch.isfinite(x)
+        bad = int(x.numel() - int(finite.sum()))
+        n_bad += bad
+        x = torch.where(finite, x, torch.zeros_like(x))
         w = torch.arange(1, x.numel() + 1, dtype=torch.float64, device=x.device) % 8191.0 + 1.0
-        fp += [float(t.dim())] + [float(d) for d in t.shape] + [float(x.sum()), float((x * w).sum())]
+        fp += [float(t.dim())] + [float(d) for d in t.shape] + [float(bad), float(x.sum()), float((x * w).sum())]
     f = torch.tensor(fp, dtype=torch.float64)
     both = torch.cat([f, -f])
     if dist.get_backend(group) == "nccl":
@@ -110,6 +116,11 @@ def assert_replicated(tensors, group=None, what: str = "tensors"):
         raise RuntimeError(f"{what} differ across ranks (all_reduce of the fingerprints failed: {e})") from e
     both = both.cpu()
     hi, lo = both[: len(fp)], -both[len(fp):]
+    if n_bad and torch.equal(hi, lo):
+        import warnings
+
+        warnings.warn(f"{what}: {n_bad} non-finite values (the same on every rank) — the encoder overflowed or is untrained; "
+                      "retrieval over them is meaningless", RuntimeWarning, stacklevel=2)
     if not torch.equal(hi, lo):
         raise RuntimeError(f"{what} differ across the {world} ranks (fingerprint max != min in {int((hi != lo).sum())} of {len(fp)} "
                            "fields): sharded retrieval needs every rank to pass the same database and the same queries — evaluate "
