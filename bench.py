@@ -1228,6 +1228,8 @@ def main():
     lo, hi = searcher.set_db_shard(d_db)
     eng.set_option("profile_events", 97)  # outside the timed region: rare (the first samples create the event rings — not in the timed steps)
     eng.set_option("search_mode", args.mode)
+    if os.environ.get("T2L_BENCH_TILE_SEL") is not None:  # dev A/B: the paired scan's per-score insertion (0) against the tile-local selection (1, default)
+        eng.set_option("search_tile_sel", int(os.environ["T2L_BENCH_TILE_SEL"]))
     if args.nsplit:
         eng.set_option("search_nsplit", args.nsplit)
     N_OUT = 12
@@ -1478,7 +1480,7 @@ def main():
         if args.mode == 2:
             kname, peak, dtype, mult = "scanw_kernel<8, 4>", BF16_MFMA_PEAK_TFLOPS, "bf16x3", 3
         else:
-            kname, peak, dtype, mult = "scanp_kernel<6, 4, true>", BF16_MFMA_PEAK_TFLOPS, "f16", 1  # (the merged-record form: the default on benign data)
+            kname, peak, dtype, mult = ("scanp_kernel<6, 4, true, 1>" if os.environ.get("T2L_BENCH_TILE_SEL", "1") != "0" else "scanp_kernel<6, 4, true, 0>"), BF16_MFMA_PEAK_TFLOPS, "f16", 1  # (merged records + tile-local selection: the default on benign data)
         if world == 1 and args.mode == 0 and not args.quick and not os.environ.get("T2L_BENCH_CHILD"):
             live = measure_traffic_in_run("t2l::scanp_kernel")  # (outside every timed region; ~40 s; None without rocprofv3)
             if live is not None:

@@ -593,6 +593,8 @@ int t2l_set_option(t2l_ctx* ctx, const char* name, double value) {
   } else if (!strcmp(name, "search_wide_repair")) {
     if (value < 0 || value > 1024) return fail(ctx, T2L_EINVAL, "search_wide_repair: 0 (off) .. 1024 rows");
     ctx->wide_repair = (int)value;
+  } else if (!strcmp(name, "search_tile_sel")) {
+    ctx->search_tile_sel = value != 0;
   } else if (!strcmp(name, "search_pair_ll")) {
     if (value != 5 && value != 6) return fail(ctx, T2L_EINVAL, "search_pair_ll must be 5 or 6");
     ctx->pair_ll = (int)value;

@@ -229,13 +229,19 @@ __global__ __launch_bounds__(256, 1) void scanw_kernel(const uint4* __restrict__
 //   k-step then hits every bank group exactly 4 times = full LDS rate).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void half_db_kernel(const float* __restrict__ db, const float* __restrict__ norms,
-                                                      uint4* __restrict__ out, int rows) {
-  // one thread = 8 consecutive floats of one row -> one 16-byte f16 chunk; consecutive threads take consecutive ROWS of one
-  // chunk column, i.e. consecutive 16-byte units of the tile-chunk-major plane (search_dev.h): coalesced writes
+                                                      uint4* __restrict__ out, int rows_pad, int n_rows) {
+  // one thread = 8 consecutive floats of one row -> one 16-byte f16 chunk; consecutive threads take consecutive SLOTS of one
+  // chunk column, i.e. consecutive 16-byte units of the tile-chunk-major plane (search_dev.h): coalesced writes. The slots of a
+  // tile hold STRIDED rows (plane_row, search_dev.h): the reads are 32-byte pieces of rows n_rows / 32 apart — once per t2l_db_set.
   const int gid = blockIdx.x * 256 + threadIdx.x;
   const int r = gid & 31, c = (gid >> 5) & 31, tile = gid >> 10;
-  const int row = tile * kTileRows + r;
-  if (row >= rows) return;
+  const int pos = tile * kTileRows + r;
+  if (pos >= rows_pad) return;
+  const int row = plane_row(pos, n_rows);
+  if (row >= n_rows) {  // padding slots (only the partial last tile has them, and whole tiles behind it)
+    out[gid] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
   int shift;
   half_shift_of(norms[1], shift);
   const float4* src = reinterpret_cast<const float4*>(db + (size_t)row * kD + 8 * c);
@@ -404,13 +410,19 @@ struct RerankArgs {
   int n_rows, defer, stat_mode;
   int32_t* host_stat;
   int seq, wide_cap;
+  int rec6;  // merged records of the tile-local selection: 6 keys, B1 (a key: the largest third-best key of the record's lanes), B2
 };
 
 // MERGE: the workgroup's four lists per query (two lane halves x two waves, 24 keys) leave as ONE record of 8 floats — the best 7 keys,
 // re-keyed so that the source list rides in two more code bits, + a bound on every key that did not make it (kMergedLL; the
 // re-rank's MG form reads it): a third of the bytes written back at the end of the launch and read by the re-rank.
 constexpr int kMergedLL = 8;
-template <int LL, int NS, bool MERGE = false>
+// SEL = 1: the tile-local selection (search_dev.h, TileSelLists): 86 instead of 112 selection VALU per lane-tile and query group;
+// the third-best key of every group of 8 accumulator registers goes into the lane's (dA, dB), which leave in the record as B1 / B2.
+#ifndef T2L_SEL_RD
+#define T2L_SEL_RD 2  // fragment-ring depth of the SEL = 1 loop (the tile-local registers come out of the ring's)
+#endif
+template <int LL, int NS, bool MERGE = false, int SEL = 0>
 __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__ dbt, int n_rows, int n_tiles, int code_bits,
                                                        const float* __restrict__ q, int Q, int nsplit,
                                                        float* __restrict__ cand, int32_t* __restrict__ fb_count, int32_t* __restrict__ fb_prev,
@@ -418,6 +430,7 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
                                                        unsigned span_seq, int xcd_qgroups) {
   static_assert(NS == 4, "the step loop below is unrolled for a ring of 4 slots");
   static_assert(!MERGE || LL == 6, "the in-workgroup list merge is written for lists of 6");
+  static_assert(!SEL || MERGE, "the tile-local selection's dropped-bound leaves through the merged record's bound");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kSlotBytes = 2 * kHalfTileBytes;
   constexpr unsigned kExchange = 2 * kSlotBytes;  // slots 2.. double as the query exchange area (64 KiB) in the prologue
@@ -557,10 +570,11 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
     for (int e = 0; e < 4; ++e) d.piece(e);
   }
 
-  WideLists<LL> w;
+  std::conditional_t<SEL != 0, TileSelLists<LL>, WideLists<LL>> w;
 #pragma unroll
   for (int i = 0; i < LL; ++i) w.ls0[i] = w.ls1[i] = T2L_NEG_INF;
-  w.key0 = w.key1 = T2L_NEG_INF;
+  if constexpr (SEL) w.dA0 = w.dB0 = w.dA1 = w.dB1 = w.t0 = w.t1 = w.t2 = w.k = T2L_NEG_INF;
+  else w.key0 = w.key1 = T2L_NEG_INF;
   f32x16 accA0, accA1, accB0, accB1;  // step i / step i+1, per query group
 #pragma unroll
   for (int r = 0; r < 16; ++r) accA0[r] = accA1[r] = accB0[r] = accB1[r] = T2L_NEG_INF;
@@ -568,20 +582,23 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
   lds_cptr lb0 = (lds_cptr)smem + quad * kHalfTileBytes + half * 8192 + col * 16;
   lds_cptr lb1 = lb0 + 65536;
   asm volatile("" : "+v"(lb1));  // opaque: otherwise every slot-2/3 fragment address (> the 16-bit ds offset) gets its own register
-  u32x4 ring[4];
+  constexpr int RD = SEL ? T2L_SEL_RD : 4;
+  u32x4 ring[RD];
   // steps 0 and 1 landed for every wave before the query loads returned (vmcnt retires in order) and the barriers above
   // published that; only step 2's pieces may be in flight
 #pragma unroll
-  for (int i = 0; i < 4; ++i) ring[i] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(lb0 + i * 512);
+  for (int i = 0; i < RD; ++i) ring[i] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(lb0 + i * 512);
 
   auto step = [&](auto slot_tag, int i, f32x16& cur0, f32x16& cur1, const f32x16& prev0, const f32x16& prev1) {
     constexpr int SLOT = decltype(slot_tag)::value;
     const PairDma d = dma_of(i + NS - 1, (SLOT + NS - 1) % NS);
-    tilep_steps<LL, 0, 12, SLOT, NS, kCS>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, ((i - 1) << (4 + kCS)) | code_q, pinf, w, ring, d);
+    if constexpr (SEL) tilep3_steps<LL, 0, 12, SLOT, NS, kCS, RD>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, ((i - 1) << (4 + kCS)) | code_q, pinf, w, ring, d);
+    else tilep_steps<LL, 0, 12, SLOT, NS, kCS>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, ((i - 1) << (4 + kCS)) | code_q, pinf, w, ring, d);
     // step i+1 (issued two steps ago) has landed for this wave; after the barrier it has for every wave, and every wave
     // is past its last read of step i-1, whose slot the DMA below refills
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (NS - 3)) : "memory");
-    tilep_steps<LL, 12, 16, SLOT, NS, kCS>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, ((i - 1) << (4 + kCS)) | code_q, pinf, w, ring, d);
+    if constexpr (SEL) tilep3_steps<LL, 12, 16, SLOT, NS, kCS, RD>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, ((i - 1) << (4 + kCS)) | code_q, pinf, w, ring, d);
+    else tilep_steps<LL, 12, 16, SLOT, NS, kCS>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, ((i - 1) << (4 + kCS)) | code_q, pinf, w, ring, d);
   };
   for (int i = 0; i < steps; i += 4) {
     step(std::integral_constant<int, 0>{}, i, accA0, accA1, accB0, accB1);
@@ -651,6 +668,19 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
     float f0 = O0[LL - 1], f1 = O1[LL - 1];
     f0 = fmaxf(f0, __shfl_xor(f0, 32));
     f1 = fmaxf(f1, __shfl_xor(f1, 32));
+    // SEL: (dA >= dB) = the two largest third-best keys of the lane's tile-local groups — real keys whose code names their group. The four
+    // lanes of a query meet in (DA >= DB), the two largest of their eight: two sorted pairs -> top 2 = (max heads, max(min heads, max seconds))
+    auto top2 = [&](float& a, float& b, float oa, float ob) {
+      const float lo = __builtin_amdgcn_fmed3f(a, oa, ninf);
+      a = __builtin_amdgcn_fmed3f(a, oa, pinf);
+      b = __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(b, ob, pinf), lo, pinf);
+    };
+    float DA0 = T2L_NEG_INF, DB0 = T2L_NEG_INF, DA1 = T2L_NEG_INF, DB1 = T2L_NEG_INF;
+    if constexpr (SEL) {
+      DA0 = with_half(w.dA0); DB0 = with_half(w.dB0); DA1 = with_half(w.dA1); DB1 = with_half(w.dB1);
+      top2(DA0, DB0, __shfl_xor(DA0, 32), __shfl_xor(DB0, 32));
+      top2(DA1, DB1, __shfl_xor(DA1, 32), __shfl_xor(DB1, 32));
+    }
     {
       float B0[LL], B1[LL];
 #pragma unroll
@@ -674,12 +704,17 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
 #pragma unroll
     for (int i = 0; i < kMergedLL; ++i) M[i] = half ? A1[i] : A0[i];
     float fl = half ? f1 : f0;
-    float* xch = smem + ((size_t)wq * 64 + lane) * (kMergedLL + 1);  // 9-float records: conflict-free
+    float DA = half ? DA1 : DA0, DB = half ? DB1 : DB0;
+    float* xch = smem + ((size_t)wq * 64 + lane) * (kMergedLL + 3);  // 11-float records: conflict-free
     __syncthreads();  // every wave is done with the tile ring
     if (quad == 1) {
 #pragma unroll
       for (int i = 0; i < kMergedLL; ++i) xch[i] = M[i];
       xch[kMergedLL] = fl;
+      if constexpr (SEL) {
+        xch[kMergedLL + 1] = DA;
+        xch[kMergedLL + 2] = DB;
+      }
     }
     __syncthreads();
     if (quad == 0) {
@@ -689,6 +724,14 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
       fl = fmaxf(fl, xch[kMergedLL]);
       // everything evicted on the way lies at or below the 8th merged key; everything a lane dropped at or below its floor
       M[kMergedLL - 1] = fmaxf(M[kMergedLL - 1], fl);
+      if constexpr (SEL) {
+        // record of the tile-local selection: 6 keys, B1 = the largest third-best key of the four lanes (a KEY: the re-rank decodes
+        // its tile-local group and re-scores those 8 rows when B1 alone stands between a query and its certificate), B2 = the bound on
+        // everything else that is not listed: the 7th / 8th merged keys, the list floors, the other seven third-best keys
+        top2(DA, DB, xch[kMergedLL + 1], xch[kMergedLL + 2]);
+        M[kMergedLL - 1] = fmaxf(fmaxf(M[kMergedLL - 1], M[kMergedLL - 2]), DB);
+        M[kMergedLL - 2] = DA;
+      }
       const int qrow = qb * kWideQPerBlock + wq * kWideQPerWave + lane;
       if (qrow < Q) {
         float4* out = reinterpret_cast<float4*>(cand + ((size_t)qrow * nsplit + sp) * kMergedLL);
@@ -870,13 +913,14 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
   const float* __restrict__ q = a.q;
   const int Q = a.Q, K = a.K, parts = a.parts, code_bits = a.code_bits, row_offset = a.row_offset, half_mode = a.half_mode;
   const int slack_bits = MG ? code_bits + 2 : code_bits;  // score bits a key gave up for its code
+  const int strided_rows = half_mode ? a.n_rows : 0;       // keys of the f16 scans index the strided plane (plane_row)
   // row of a key held by list `part`
   auto krow = [&](float key, int part) {
     if constexpr (MG) {
       const int b = __float_as_int(key), src = b & 3;
-      return key_row(__int_as_float(b >> 2), 2 * (part + (src >> 1) * parts) + (src & 1), 2 * parts, code_bits);
+      return key_row(__int_as_float(b >> 2), 2 * (part + (src >> 1) * parts) + (src & 1), 2 * parts, code_bits, strided_rows);
     } else {
-      return key_row(key, part, parts >> 1, code_bits);
+      return key_row(key, part, parts >> 1, code_bits, strided_rows);
     }
   };
   const float* __restrict__ cand = a.cand;
@@ -915,7 +959,17 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
   // a FULL list dropped rows inside its lane: all of them have key <= its floor (-inf when nothing was dropped)
   const float lane_floor = lst[LL - 1];
   if constexpr (MG) lst[LL - 1] = T2L_NEG_INF;  // (the record's last slot is its bound, not a key)
-  const float floor_max = wave_max_f32(lane_floor, pinf);
+  // records of the tile-local selection (scanp_kernel<..., SEL = 1>): slot 6 is B1, the largest THIRD-best key of a tile-local group
+  // (8 rows) of the record's four lanes — everything those lanes dropped past their lists lies at or below it, and all of it except
+  // the other 5 rows of B1's own group at or below the record's bound B2 (slot 7, `lane_floor`)
+  float b1 = T2L_NEG_INF;
+  if constexpr (MG) {
+    if (a.rec6) {
+      b1 = lst[LL - 2];
+      lst[LL - 2] = T2L_NEG_INF;
+    }
+  }
+  const float floor_max = wave_max_f32(fmaxf(lane_floor, b1), pinf);
   // the query as float64, 16 elements per lane (dims 64 i + 4 seg + e: each load instruction reads 256 contiguous bytes
   // per 16-lane row); the lanes of one row cover the 256 dims, the 4 rows hold copies
   const int seg = lane & 15;
@@ -1071,9 +1125,99 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
   if (lane >= L - 4 && lane < L && my_key != T2L_NEG_INF) my_row = krow(my_key, my_part);
   // every row that is NOT re-scored has key <= g: kept rows lie at or below the L-th merged key, rows dropped inside a
   // lane at or below that lane's floor (with LL == L a floor above the L-th key cannot happen; with LL < L it can)
-  const float g = fmaxf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_key), L - 1)), floor_max);
+  const float key_L = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_key), L - 1));
+  const float g = fmaxf(key_L, floor_max);
   gather(L / 4 - 1);
-  score(L / 4 - 1);
+  // ---- the group repair, anticipated (records of the tile-local selection). Three of a query's best rows in the 8 rows of ONE
+  // tile-local group (1e-4 per query at N = 11 k: a query in every other batch of 4,096) leave the third as some record's B1 above
+  // everything the query can certify against. The first L - 4 scores already tell: with the K-th best of them as a provisional
+  // K-th score (the final one is no smaller) exactly one record's B1 reaches the threshold and no B2 does. Then the 8 rows of B1's
+  // group travel TOGETHER with the last four candidates (three row groups in flight, as in the first stage) — the query costs the
+  // round trips of any query that missed the early certificate (1 in 10) — and the certificate is taken against B2 in that
+  // record's place. Anything else (two such records, a B2 in reach, the certificate still failing) resets the extra lanes and
+  // takes the general path below.
+  bool fast_done = false;
+  if constexpr (MG && L == 16) {
+    int d_lane = -1;
+    // (cheap gate first: a B1 can only be what stands in the way when it lies above every B2 and above the L-th merged key)
+    const float b1_max = a.rec6 ? wave_max_f32(b1, pinf) : T2L_NEG_INF;
+    if (b1_max != T2L_NEG_INF && b1_max > fmaxf(key_L, wave_max_f32(lane_floor, pinf)) && representable && K <= LA && eps_rel_probe == 0.f) {
+      const int rA = rank_among(std::integral_constant<int, LA>{});
+      const unsigned long long kthA = __ballot(lane < LA && my_row != INT_MAX && rA == K - 1);
+      if (kthA != 0ull) {
+        const double dKA = __shfl(my_d, __ffsll((long long)kthA) - 1);
+        const double tA = (dKA - 2.0 * (fabs(dKA) * ldexp(1.0, slack_bits - 22) + eps32)) / kscale;
+        float thrA = (float)tA;
+        if ((double)thrA > tA) thrA = __uint_as_float(__float_as_uint(thrA) + (thrA > 0.f ? -1 : 1));  // round down
+        if (fabs(tA) < 3.0e38) {
+          const unsigned long long bm = __ballot(lane_floor != T2L_NEG_INF && lane_floor >= thrA);
+          const unsigned long long dm = __ballot(b1 != T2L_NEG_INF && b1 >= thrA);
+          if (bm == 0ull && __popcll(dm) == 1) d_lane = __ffsll((long long)dm) - 1;
+        }
+      }
+    }
+    if (d_lane >= 0) {  // wave-uniform
+      const int kb = __shfl(__float_as_int(b1), d_lane);
+      int cand_row = INT_MAX;
+      if (lane >= L && lane < L + kTileSelGroup) {  // key code: tile ordinal << 4 | accumulator register (its bit 3 = the group), << 2 | source
+        const int r = krow(__int_as_float((kb & ~((kTileSelGroup - 1) << 2)) | ((lane - L) << 2)), d_lane);
+        cand_row = r < n_rows ? r : INT_MAX;
+      }
+#pragma unroll
+      for (int j = 0; j < L; ++j) cand_row = __builtin_amdgcn_readlane(my_row, j) == cand_row ? INT_MAX : cand_row;  // a row enters once
+      if (lane >= L && lane < L + kTileSelGroup) my_row = cand_row;
+      auto gather_d = [&](int p, float4 (&rw)[4]) {
+        const int row = __shfl(my_row, L + 4 * p + (lane >> 4));
+        const float4* rp = reinterpret_cast<const float4*>(db + (size_t)(row == INT_MAX ? 0 : row) * kD) + seg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rw[i] = rp[16 * i];
+      };
+      auto score_d = [&](int p, const float4 (&rw)[4]) {
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          d0 += (double)rw[i].x * qd[4 * i];
+          d1 += (double)rw[i].y * qd[4 * i + 1];
+          d0 += (double)rw[i].z * qd[4 * i + 2];
+          d1 += (double)rw[i].w * qd[4 * i + 3];
+        }
+        const double d = row16_sum_f64(d0 + d1);
+        const double mine = __shfl(d, 16 * (lane & 3));
+        if ((lane >> 2) == L / 4 + p && my_row != INT_MAX) my_d = mine;
+      };
+      static_assert(kTileSelGroup == 8, "two row groups of four");
+      gather_d(0, rows[0]);
+      gather_d(1, rows[1]);
+      score(L / 4 - 1);
+      score_d(0, rows[0]);
+      score_d(1, rows[1]);
+      const int rank2 = rank_among(std::integral_constant<int, L + kTileSelGroup>{});
+      const bool valid2 = lane < L + kTileSelGroup && my_row != INT_MAX;
+      const unsigned long long kth2 = __ballot(valid2 && rank2 == K - 1);
+      // what is not re-scored now: kept keys at or below the L-th merged key, every record's B2, every OTHER record's B1
+      const float g2 = fmaxf(key_L, wave_max_f32(lane == d_lane ? lane_floor : fmaxf(lane_floor, b1), pinf));
+      if (kth2 != 0ull) {
+        const double dK2 = __shfl(my_d, __ffsll((long long)kth2) - 1);
+        if (dK2 > (double)g2 * kscale + key_slack(g2, slack_bits, eps32, kscale)) {
+          emit(valid2, rank2);
+          if (lane == 0) {
+            flags[qid] = 0;
+            atomicAdd(&fb_count[1], 1);  // re-scored beyond the first L candidates (the group repair)
+          }
+          fast_done = true;
+        }
+      }
+      if (!fast_done && lane >= L) {  // the general path starts from the L candidates
+        my_row = INT_MAX;
+        my_d = -__builtin_inf();
+      }
+    } else {
+      score(L / 4 - 1);
+    }
+  } else {
+    score(L / 4 - 1);
+  }
+  if (!fast_done) {
   const int rank = rank_among(std::integral_constant<int, L>{});
   const bool valid = lane < L && my_row != INT_MAX;
   emit(valid, rank);
@@ -1112,9 +1256,13 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
     int total = cnt;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off);
-    const bool bad = lane_floor != T2L_NEG_INF && lane_floor >= thr;  // this list dropped rows that could still matter
-    const unsigned long long bad_mask = __ballot(bad);
-    if (bad_mask == 0ull && total <= 16) {
+    bool bad = lane_floor != T2L_NEG_INF && lane_floor >= thr;  // this list dropped rows that could still matter
+    // ... or only B1 says so: then the rows that could are the 8 of B1's tile-local group (B2 bounds the rest of what the record dropped)
+    const bool dbad = !bad && b1 != T2L_NEG_INF && b1 >= thr;
+    unsigned long long bad_mask = __ballot(bad);
+    const unsigned long long d_mask = __ballot(dbad);
+    const int n_d = __popcll(d_mask);
+    if (bad_mask == 0ull && total <= 16 && total + kTileSelGroup * n_d <= 64 - L) {
       for (int e = 0; e < total; ++e) {  // the next best kept keys, in key order, into lanes L, L+1, ...
         const float bk = wave_max_f32(lst[0], pinf);
         const int bl = __ffsll((long long)__ballot(lst[0] == bk)) - 1;
@@ -1128,7 +1276,30 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
           lst[LL - 1] = T2L_NEG_INF;
         }
       }
-      for (int p = L / 4; p < (L + total + 3) / 4; ++p) {
+      int n_ent = L + total;
+      if constexpr (MG) {
+        // the tile-local groups behind the B1 keys that reach the threshold: all 8 rows of each (its two best are usually candidates
+        // already: a row enters once), compacted through this wave's LDS scratch into the lanes behind the kept keys
+        for (unsigned long long m = d_mask; m != 0ull; m &= m - 1ull) {
+          const int b = __ffsll((long long)m) - 1;
+          const int kb = __shfl(__float_as_int(b1), b);
+          int cand_row = INT_MAX;
+          if (lane < kTileSelGroup) {  // key code = tile ordinal << 4 | accumulator register (bit 3 = the group), << 2 | source
+            const int r = krow(__int_as_float((kb & ~((kTileSelGroup - 1) << 2)) | (lane << 2)), b);
+            cand_row = r < n_rows ? r : INT_MAX;
+          }
+          bool dup = cand_row == INT_MAX;
+          for (int j = 0; j < n_ent; ++j) dup = dup || __builtin_amdgcn_readlane(my_row, j) == cand_row;
+          const unsigned long long keep = __ballot(!dup);
+          if (!dup) wr_buf[__popcll(keep & ((1ull << lane) - 1ull))] = cand_row;
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (this wave's LDS writes are read back by its other lanes)
+          const int nk = __popcll(keep);
+          if (lane >= n_ent && lane < n_ent + nk) my_row = wr_buf[lane - n_ent];
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          n_ent += nk;
+        }
+      }
+      for (int p = L / 4; p < (n_ent + 3) / 4; ++p) {
         const int row = __shfl(my_row, 4 * p + (lane >> 4));
         const float4* rp = reinterpret_cast<const float4*>(db + (size_t)(row == INT_MAX ? 0 : row) * kD) + seg;
         double d0 = 0.0, d1 = 0.0;
@@ -1142,18 +1313,17 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
         }
         const double d = row16_sum_f64(d0 + d1);
         const double mine = __shfl(d, 16 * (lane & 3));
-        if ((lane >> 2) == p && lane < L + total && my_row != INT_MAX) my_d = mine;
+        if ((lane >> 2) == p && lane < n_ent && my_row != INT_MAX) my_d = mine;
       }
       int rank2 = 0;
-#pragma unroll
-      for (int j = 0; j < L + 16; ++j) {
+      for (int j = 0; j < n_ent; ++j) {
         const unsigned long long bj = __double_as_longlong(my_d);
         const double dj = __longlong_as_double(((unsigned long long)__builtin_amdgcn_readlane((unsigned)(bj >> 32), j) << 32) |
                                                (unsigned)__builtin_amdgcn_readlane((unsigned)bj, j));
         const int ij = __builtin_amdgcn_readlane(my_row, j);
         rank2 += (dj > my_d || (dj == my_d && ij < my_row)) ? 1 : 0;
       }
-      if (lane < L + total && my_row != INT_MAX && rank2 < K) {
+      if (lane < n_ent && my_row != INT_MAX && rank2 < K) {
         out_idx[(size_t)qid * K + rank2] = my_row + row_offset;
         if (out_score) out_score[(size_t)qid * K + rank2] = my_d;
       }
@@ -1169,12 +1339,13 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
       // a 0.7 ms step on clustered data, bench_distribution.py).
       // rows behind a list: a plain list covers the tiles of ONE virtual split at one lane half (16 rows per tile); a merged record the
       // two virtual splits of its workgroup at both halves (64 per tile ordinal; the second split may be one tile shorter: filtered below)
+      // (a record whose B1 alone reaches the threshold contributes its kept keys, like any good list, and the 8 rows of B1's group)
       const int vn_ = MG ? 2 * parts : parts >> 1;
       constexpr int kRowsPerTile = MG ? 64 : 16;
       const int n_tiles_ = (n_rows + kTileRows - 1) / kTileRows;
       const int my_vs = MG ? lane : lane >> 1;
       const int my_nt = (lane < parts && my_vs < n_tiles_) ? (n_tiles_ - my_vs + vn_ - 1) / vn_ : 0;
-      int work = bad ? my_nt * kRowsPerTile : cnt;
+      int work = bad ? my_nt * kRowsPerTile : cnt + (dbad ? kTileSelGroup : 0);
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) work += __shfl_xor(work, off);
       if (work <= wide_cap) {
@@ -1187,6 +1358,17 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
           const unsigned long long m = __ballot(pred);
           if (pred) wr[base + __popcll(m & lt_mask)] = krow(lst[i], lane);
           base += __popcll(m);
+        }
+        if constexpr (MG) {
+          for (unsigned long long m = d_mask; m != 0ull; m &= m - 1ull) {  // the tile-local groups behind the B1 keys in reach
+            const int b = __ffsll((long long)m) - 1;
+            const int kb = __shfl(__float_as_int(b1), b);
+            if (lane < kTileSelGroup) {
+              const int row = krow(__int_as_float((kb & ~((kTileSelGroup - 1) << 2)) | (lane << 2)), b);
+              wr[base + lane] = row < n_rows ? row : INT_MAX;
+            }
+            base += kTileSelGroup;
+          }
         }
         for (unsigned long long m = bad_mask; m != 0ull; m &= m - 1ull) {  // every row of the lists that did
           const int b = __ffsll((long long)m) - 1;
@@ -1264,6 +1446,7 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
       else flags[3 * Q + atomicAdd(&fb_count[4], 1)] = qid;                  //             -> exactd_kernel
     }
   }
+  }  // !fast_done
   }  // !early
 }
 
@@ -1272,19 +1455,19 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
 // ------------------------------------------------------------------------------------------------
 // LL = length of the per-lane lists the scan wrote, L = rows re-scored per query (LL <= L).
 template <int LL, int L, bool MG = false>
-__global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ db, const float* __restrict__ q, int Q,
+__global__ __launch_bounds__(256, 4) void rerank_kernel(const float* __restrict__ db, const float* __restrict__ q, int Q,
                                                      int K, int parts, int code_bits,
                                                      const float* __restrict__ cand, int row_offset, float eps_rel,
                                                      const float* __restrict__ db_norm_max, int half_mode,
                                                      int32_t* __restrict__ out_idx, double* __restrict__ out_score,
                                                      int32_t* __restrict__ flags, int32_t* __restrict__ fb_count,
                                                      float eps_rel_probe, float pinf, int n_rows, int defer, int stat_mode,
-                                                     int32_t* __restrict__ host_stat, int seq, int wide_cap) {
+                                                     int32_t* __restrict__ host_stat, int seq, int wide_cap, int rec6) {
   __shared__ WgExactShared exact_sh;
   __shared__ int wg_flag[4];
   __shared__ int wide_rows[4][kWideCap];  // per wave: the rows a wide repair re-scores
   const RerankArgs a{db, q, Q, K, parts, code_bits, cand, row_offset, eps_rel, db_norm_max, half_mode, out_idx, out_score, flags, fb_count,
-                     eps_rel_probe, pinf, n_rows, defer, stat_mode, host_stat, seq, wide_cap};
+                     eps_rel_probe, pinf, n_rows, defer, stat_mode, host_stat, seq, wide_cap, rec6};
   const int lane = threadIdx.x & 63;
   const int qid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (threadIdx.x < 4) wg_flag[threadIdx.x] = 0;
@@ -1390,7 +1573,7 @@ int db_norm_impl(t2l_ctx* ctx, hipStream_t s) {
   }
   if (ctx->db_pad > 0) {  // the scaled f16 plane of the default scan (needs the max |element| from above)
     hipLaunchKernelGGL(half_db_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, ctx->db, ctx->db_norm_max, ctx->db_half,
-                       (int)ctx->db_pad);
+                       (int)ctx->db_pad, (int)ctx->db_rows);
     T2L_HIP(ctx, hipGetLastError());
   }
   return T2L_OK;
@@ -1431,6 +1614,7 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
     if (once.need(ctx->device)) {
       allow_lds(&scanp_kernel<LL, 4>, lds);
       if constexpr (LL == 6) allow_lds(&scanp_kernel<LL, 4, true>, lds);
+      if constexpr (LL == 6) allow_lds(&scanp_kernel<LL, 4, true, 1>, lds);
       once.mark(ctx->device);
     }
     const unsigned span_seq = ++ctx->span_seq;
@@ -1458,7 +1642,8 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
       merged = (ctx->search_merge == 1 || (ctx->search_merge == 2 && ctx->merge_live && !ctx->heavy)) && code_bits <= 9;
     }
     if constexpr (LL == 6) {
-      if (merged) launch(scanp_kernel<LL, 4, true>);
+      if (merged && ctx->search_tile_sel) launch(scanp_kernel<LL, 4, true, 1>);
+      else if (merged) launch(scanp_kernel<LL, 4, true>);
     }
     if (!merged) launch(scanp_kernel<LL, 4>);
   } else {
@@ -1498,12 +1683,12 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
         hipExtLaunchKernelGGL((rerank_kernel<kMergedLL, L, true>), dim3((Q + 3) / 4), dim3(256), 0u, s, ea, eb, 0u, db, q, Q, K, nsplit / 2,
                               code_bits, (const float*)ctx->cand_score, row_offset, eps_rel, (const float*)ctx->db_norm_max, half_mode, out_idx,
                               out_score, ctx->flags, ctx->fb_count, eps_probe, __builtin_inff(), n_rows, defer, stat_mode,
-                              ctx->host_stat_dev, seq, min(ctx->wide_repair, kWideCap));
+                              ctx->host_stat_dev, seq, min(ctx->wide_repair, kWideCap), ctx->search_tile_sel ? 1 : 0);
       else
         hipLaunchKernelGGL((rerank_kernel<kMergedLL, L, true>), dim3((Q + 3) / 4), dim3(256), 0, s, db, q, Q, K, nsplit / 2, code_bits,
                            ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, half_mode, out_idx, out_score, ctx->flags,
                            ctx->fb_count, eps_probe, __builtin_inff(), n_rows, defer, stat_mode, ctx->host_stat_dev, seq,
-                           min(ctx->wide_repair, kWideCap));
+                           min(ctx->wide_repair, kWideCap), ctx->search_tile_sel ? 1 : 0);
       T2L_HIP(ctx, hipGetLastError());
       if (ctx->heavy) return exact_stage_impl(ctx, db, n_rows, row_offset, q, Q, K, out_idx, out_score, s);
       return T2L_OK;
@@ -1513,20 +1698,18 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
     hipExtLaunchKernelGGL((rerank_kernel<LL, L>), dim3((Q + 3) / 4), dim3(256), 0u, s, ea, eb, 0u, db, q, Q, K, parts, code_bits,
                           (const float*)ctx->cand_score, row_offset, eps_rel, (const float*)ctx->db_norm_max, half_mode, out_idx,
                           out_score, ctx->flags, ctx->fb_count, eps_probe, __builtin_inff(), n_rows, defer, stat_mode,
-                          ctx->host_stat_dev, seq, min(ctx->wide_repair, kWideCap));
+                          ctx->host_stat_dev, seq, min(ctx->wide_repair, kWideCap), 0);
   else
     hipLaunchKernelGGL((rerank_kernel<LL, L>), dim3((Q + 3) / 4), dim3(256), 0, s, db, q, Q, K, parts, code_bits,
                        ctx->cand_score, row_offset, eps_rel, ctx->db_norm_max, half_mode, out_idx, out_score, ctx->flags,
                        ctx->fb_count, eps_probe, __builtin_inff(), n_rows, defer, stat_mode, ctx->host_stat_dev, seq,
-                       min(ctx->wide_repair, kWideCap));
+                       min(ctx->wide_repair, kWideCap), 0);
   T2L_HIP(ctx, hipGetLastError());
   if (ctx->heavy) return exact_stage_impl(ctx, db, n_rows, row_offset, q, Q, K, out_idx, out_score, s);
   return T2L_OK;
 }
 
-// rows one scan launch can cover: 32 splits x 512 tiles (13 code bits) x 32 rows
-constexpr int kMaxPerTiles = 512;
-constexpr int kSegmentRows = (kMaxParts / 2) * kMaxPerTiles * kTileRows;
+// (rows one scan launch can cover — kSegmentRows = 32 splits x 512 tiles (13 code bits) x 32 rows — t2l_internal.h)
 
 // an empty shard (legal under ragged row-sharding: shard_bounds hands the tail ranks nothing) answers -1 / -inf everywhere
 __global__ __launch_bounds__(256) void empty_result_kernel(int n, int32_t* __restrict__ out_idx, double* __restrict__ out_score) {

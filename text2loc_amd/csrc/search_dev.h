@@ -312,6 +312,106 @@ __device__ __forceinline__ void tilep_steps(lds_cptr lb0, lds_cptr lb1, const u3
 }
 
 
+// ---- tile-local selection for the paired scan (round 6; scanp_kernel<..., SEL = 1>). Inserting every score into the lane's list
+// of LL = 6 costs 1 + LL = 7 VALU per score (112 per lane-tile and query group) beside MFMAs the wave can issue in 2 x 32 cycles per
+// k-step: the selection, not the matrix pipe, sets the loop's pace. A score enters a list of 6 that has seen 16 t scores with
+// probability 6 / (16 t): almost every one of those 6 med3 ops copies its own input. So the scores of a lane-tile first meet in
+// a LOCAL top 3 per GROUP of 8 accumulator registers (t0 >= t1 >= t2; key + 3 med3 = 4 VALU per score), the best two are inserted
+// into the list once per group (12 VALU) and the third goes into (dA >= dB), the two largest THIRD keys of the lane's groups
+// (2 VALU): 86 instead of 112 VALU per lane-tile and query group. Exactness is untouched: whatever the lane dropped without it
+// having passed through the list lies at or below dA, and dA is a real key — its code names the group it came from. The merged
+// record carries the largest dA of its four lanes as B1 and everything else (list floors, evicted keys, the other seven d values)
+// as B2 (search.hip): a certificate that fails on B1 alone is repaired by re-scoring the 8 rows of that ONE group, after which
+// B2 bounds all that is unseen. Groups of 8, not 16: three of a query's ~12 relevant rows in the same 16 of 11,259 rows is a 4e-4
+// event per query — more than one query per batch of 4,096, each 16 more rows for its re-rank wave (one more memory round trip
+// than any other wave of the launch: measured +1.7 us on the re-rank kernel, which ends with its slowest wave); the same in 8 rows
+// is a quarter as likely, and 8 rows travel in the registers of the round trip that wave makes anyway.
+// Neighbouring rows (overlapping cells share objects: a query's best rows come in runs) are kept out of one tile by the plane
+// itself (plane_row: row -> tile is strided, not blocked).
+// The two query groups take turns (group 0 in k-steps 0..7 of a tile, group 1 in 8..15), so ONE set of t0 / t1 / t2 / key
+// registers serves both. NaN keys (the -inf accumulators of the first step, OR-ed with a code) must stay no-ops: v_med3_f32 with a
+// NaN operand returns min3 of the others, so every op below keeps a finite-or-minus-infinity value when its key is NaN.
+template <int LL>
+struct TileSelLists {
+  float ls0[LL], ls1[LL];  // sorted key lists of the two query groups
+  float dA0, dB0, dA1, dB1;  // per group: the two largest third-best keys of the lane's tiles (dA >= dB): what it dropped past its list
+  float t0, t1, t2, k;     // tile-local top 3 of the group whose turn it is, key in flight
+};
+constexpr int kTileSelGroup = 8;                     // scores per tile-local group: the 16 accumulator registers of a lane-tile are two groups
+constexpr int kTileSelGroupOps = 43;                 // VALU ops per group: 29 selection + 12 list insertion + 2 for (dA, dB)
+constexpr int kTileSelOps = 2 * kTileSelGroupOps;    // per lane-tile and query group
+template <int LL, int O, int CS>
+__device__ __forceinline__ void tile_sel_op(float (&ls)[LL], float& dA, float& dB, TileSelLists<LL>& w, const f32x16& prev, int vmask,
+                                            int code0, float pinf) {
+  static_assert(LL == 6, "op table written for lists of 6");
+  constexpr int B = (O / kTileSelGroupOps) * kTileSelGroup, o = O % kTileSelGroupOps;  // first accumulator register of the group, op within it
+  auto key = [&](int i) { return __int_as_float((__float_as_int(prev[B + i]) & vmask) | __builtin_amdgcn_readfirstlane(code0 + ((B + i) << CS))); };
+  if constexpr (o == 0) w.k = key(0);
+  else if constexpr (o == 1) w.t0 = __builtin_amdgcn_fmed3f(w.k, -pinf, pinf);
+  else if constexpr (o == 2) w.k = key(1);
+  else if constexpr (o == 3) w.t1 = __builtin_amdgcn_fmed3f(w.t0, w.k, -pinf);
+  else if constexpr (o == 4) w.t0 = __builtin_amdgcn_fmed3f(w.t0, w.k, pinf);
+  else if constexpr (o == 5) w.k = key(2);
+  else if constexpr (o == 6) w.t2 = __builtin_amdgcn_fmed3f(w.t1, w.k, -pinf);
+  else if constexpr (o == 7) w.t1 = __builtin_amdgcn_fmed3f(w.t0, w.t1, w.k);
+  else if constexpr (o == 8) w.t0 = __builtin_amdgcn_fmed3f(w.t0, w.k, pinf);
+  else if constexpr (o < 29) {
+    constexpr int J = (o - 9) >> 2, P = (o - 9) & 3;
+    if constexpr (P == 0) w.k = key(3 + J);
+    else if constexpr (P == 1) w.t2 = __builtin_amdgcn_fmed3f(w.t1, w.t2, w.k);
+    else if constexpr (P == 2) w.t1 = __builtin_amdgcn_fmed3f(w.t0, w.t1, w.k);
+    else w.t0 = __builtin_amdgcn_fmed3f(w.t0, w.k, pinf);
+  } else if constexpr (o < 41) {  // t0, then t1, into the list: tail -> head, every element reads OLD neighbours only
+    constexpr int I = LL - 1 - (o - 29) % LL;
+    const float x = (o - 29) < LL ? w.t0 : w.t1;
+    if constexpr (I == 0) ls[0] = __builtin_amdgcn_fmed3f(ls[0], x, pinf);
+    else ls[I] = __builtin_amdgcn_fmed3f(ls[I - 1], ls[I], x);
+  } else if constexpr (o == 41) {
+    dB = __builtin_amdgcn_fmed3f(dA, dB, w.t2);
+  } else {
+    dA = __builtin_amdgcn_fmed3f(dA, w.t2, pinf);
+  }
+}
+template <int LL, int O, int O_END, int CS>
+__device__ __forceinline__ void tile_sel_ops(float (&ls)[LL], float& dA, float& dB, TileSelLists<LL>& w, const f32x16& prev, int vmask,
+                                             int code0, float pinf) {
+  if constexpr (O < O_END) {
+    tile_sel_op<LL, O, CS>(ls, dA, dB, w, prev, vmask, code0, pinf);
+    tile_sel_ops<LL, O + 1, O_END, CS>(ls, dA, dB, w, prev, vmask, code0, pinf);
+  }
+}
+// k-steps [S, S_END) of one step of the paired scan with the tile-local selection. RD: depth of the fragment ring (k-steps of
+// prefetch); the ring crosses into the next slot RD k-steps before the tile ends — behind the step's barrier at k-step 12.
+template <int LL, int S, int S_END, int SLOT, int NS, int CS, int RD>
+__device__ __forceinline__ void tilep3_steps(lds_cptr lb0, lds_cptr lb1, const u32x4 (&q0)[16], const u32x4 (&q1)[16],
+                                             f32x16& cur0, f32x16& cur1, const f32x16& prev0, const f32x16& prev1, int vmask,
+                                             int code0, float pinf, TileSelLists<LL>& w, u32x4 (&ring)[RD], const PairDma& dma) {
+  static_assert(RD == 2 || RD == 4, "ring depth");
+  static_assert(RD <= 4, "the ring may cross into the next slot only behind the barrier at k-step 12");
+  if constexpr (S < S_END) {
+    constexpr int NXT = (SLOT + 1) % NS;
+    constexpr int s8 = S & 7;
+    constexpr int O0 = kTileSelOps * s8 / 8, O2 = kTileSelOps * (s8 + 1) / 8, O1 = (O0 + O2) / 2;
+    const u32x4 a = ring[S & (RD - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S == 0) mfma_f16_first(cur0, a, q0[S]); else mfma_f16_acc(cur0, a, q0[S]);
+    if constexpr (S + RD < 16) ring[S & (RD - 1)] = pair_frag<SLOT, S + RD>(lb0, lb1);
+    else ring[S & (RD - 1)] = pair_frag<NXT, S + RD - 16>(lb0, lb1);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S < 8) tile_sel_ops<LL, O0, O1, CS>(w.ls0, w.dA0, w.dB0, w, prev0, vmask, code0, pinf);
+    else tile_sel_ops<LL, O0, O1, CS>(w.ls1, w.dA1, w.dB1, w, prev1, vmask, code0, pinf);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S == 0) mfma_f16_first(cur1, a, q1[S]); else mfma_f16_acc(cur1, a, q1[S]);
+    if constexpr (S >= 12) dma.piece(S - 12);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S < 8) tile_sel_ops<LL, O1, O2, CS>(w.ls0, w.dA0, w.dB0, w, prev0, vmask, code0, pinf);
+    else tile_sel_ops<LL, O1, O2, CS>(w.ls1, w.dA1, w.dB1, w, prev1, vmask, code0, pinf);
+    __builtin_amdgcn_sched_barrier(0);
+    tilep3_steps<LL, S + 1, S_END, SLOT, NS, CS, RD>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, code0, pinf, w, ring, dma);
+  }
+}
+
+
 // ---- wave-wide all-reduces on the VALU (DPP + v_permlane{16,32}_swap), no LDS traffic: __shfl_xor lowers to
 // ds_bpermute_b32, and the re-rank is shuffle-bound (hundreds of shuffles per query).
 template <int CTRL>
@@ -384,12 +484,28 @@ __device__ __forceinline__ float row16_max_f32(float v) {
   return v;
 }
 
+// The f16 plane deals rows to tiles STRIDED (round 6): inside a segment of the database (kSegmentRows rows; the whole shard when
+// it is smaller) with F = rows / 32 full tiles, slot j of tile t < F holds row j F + t; the partial last tile (rows % 32 of them)
+// stays blocked. Neighbouring rows — overlapping KITTI360Pose cells that share most of their objects, i.e. a query's best rows come
+// in runs — therefore never meet in one tile, let alone in the 16 rows of one lane-tile: the tile-local selection of the paired scan
+// (TileSelLists) keeps two rows per lane-tile, and every other list is spared runs too. A position is valid (< n_rows) exactly when
+// its row is: full tiles map onto [0, 32 F), the partial tile onto itself. `pos`: position in the plane; `n_rows`: rows of the
+// plane (all segments); returns the row.
+__device__ __forceinline__ int plane_row(int pos, int n_rows) {
+  const int seg0 = pos & ~(kSegmentRows - 1), p = pos - seg0;
+  const int full = min(kSegmentRows, n_rows - seg0) >> 5;
+  const int t = p >> 5, j = p & 31;
+  return seg0 + (t < full ? j * full + t : p);
+}
+
 // key -> local DB row. part = 2*split + half; split sp owns tiles sp, sp + nsplit, sp + 2*nsplit, ... (interleaved, so a
-// run of similar neighbouring rows spreads over all the per-lane lists instead of filling one).
-__device__ __forceinline__ int key_row(float key, int part, int nsplit, int code_bits) {
+// run of similar neighbouring rows spreads over all the per-lane lists instead of filling one). n_rows > 0: the key comes from the
+// f16 plane, whose tiles hold strided rows (plane_row); 0: from a blocked plane (the split-bf16 scan's).
+__device__ __forceinline__ int key_row(float key, int part, int nsplit, int code_bits, int n_rows_strided = 0) {
   const int code = __float_as_int(key) & ((1 << code_bits) - 1);
   const int r = code & 15;
-  return (((code >> 4) * nsplit + (part >> 1)) << 5) + (r & 3) + 8 * (r >> 2) + 4 * (part & 1);
+  const int pos = (((code >> 4) * nsplit + (part >> 1)) << 5) + (r & 3) + 8 * (r >> 2) + 4 * (part & 1);
+  return n_rows_strided > 0 ? plane_row(pos, n_rows_strided) : pos;
 }
 
 // float64 dot of DB row `row` with the query fragment held by the wave (lane owns dims 4*lane..4*lane+3)

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void scanq_kernel(const uint4* __restrict__
         if (bk != T2L_NEG_INF) {
           const int code = __float_as_int(bk) & ~mask;
           const int rr = code & 15;
-          row = ((wg * per + (code >> 4)) * 4 + jw) * kTileRows + (rr & 3) + 8 * (rr >> 2) + 4 * jh;
+          row = plane_row(((wg * per + (code >> 4)) * 4 + jw) * kTileRows + (rr & 3) + 8 * (rr >> 2) + 4 * jh, n_rows);
         }
         const size_t o = ((size_t)qi * G + wg) * L + r;
         cand_key[o] = bk;

@@ -27,6 +27,8 @@ constexpr int kScanWaves = 4;
 constexpr int kQPerBlock = kQPerWave * kScanWaves; // 128 queries per workgroup
 constexpr int kStageCap = 32;                      // staged (score,row) slots per lane between compactions
 constexpr int kMaxParts = 64;                      // per-query candidate partitions (= 2 * nsplit) the re-rank merges
+constexpr int kMaxPerTiles = 512;                  // tiles per split of one scan launch (13 key code bits)
+constexpr int kSegmentRows = (kMaxParts / 2) * kMaxPerTiles * 32;  // rows one scan launch covers (524,288); also the unit inside which the f16 plane deals rows to tiles strided
 
 // Per-kernel timing: a ring of hipEvent pairs recorded on the caller's stream (no sync when recording);
 // t2l_kernel_stats() reads them back after the caller's own synchronisation point.
@@ -107,6 +109,7 @@ struct t2l_ctx {
   int encoder_f16 = 0;   // 1: plain-f16 products (one MFMA per operand pair) instead of split-f16: ~1e-4 instead of 2e-7, 28 % faster
   int search_auto = 1;
   int pair_ll = 6;       // per-lane list length of the paired scan (5 or 6)
+  int search_tile_sel = 1;  // paired scan with the tile-local top-3 selection (scanp_kernel<..., SEL = 1>; merged records only)
   int search_small = 1;      // batches of <= 16 queries against <= 65,536 rows: the one-launch exact float64 search (search_small.hip)
   int search_small_wgs = 0;  // ... its workgroups per 4-query slice (0 = by query count: 128 for Q <= 2 or Q > 8, else 192)
   bool last_search_small = false;  // the last search ran the one-launch path: t2l_search_fallbacks answers 0 (it leaves the counters alone)
