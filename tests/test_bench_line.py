@@ -27,7 +27,7 @@ def canned(world=1, bloat=1):
                    "n_cells": 11259, "queries_per_step": 4096, "embed_dim": 256, "top_k": 10,
                    "arithmetic": "x" * 300 * bloat, "parallelism": "single-gpu" if world == 1 else f"db-row-shard x{world}",
                    "layout": "one resident DB, two launches per step (scan, re-rank)", "pipelining": "none", "region": "y" * 200},
-        "roofline": bench.roofline("scanp_kernel<6, 4, true>", 2500.0, 1, 2.0 * 4096 * 11259 * 256, 0.03073, 19,
+        "roofline": bench.roofline("scanp_kernel<6, 4, true, 1>", 2500.0, 1, 2.0 * 4096 * 11259 * 256, 0.03073, 19,
                                    0.0295, 84, 0.021, 84),
         "kernels_ms": {"search_scan": 0.030731234567, "search_rerank": 0.012345678},
         "scan_kernel_event_samples": {"note": "n" * 400 * bloat},

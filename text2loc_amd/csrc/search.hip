@@ -589,22 +589,30 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
 #pragma unroll
   for (int i = 0; i < RD; ++i) ring[i] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(lb0 + i * 512);
 
-  auto step = [&](auto slot_tag, int i, f32x16& cur0, f32x16& cur1, const f32x16& prev0, const f32x16& prev1) {
+  auto step = [&](auto slot_tag, auto first_tag, int i, f32x16& cur0, f32x16& cur1, const f32x16& prev0, const f32x16& prev1) {
     constexpr int SLOT = decltype(slot_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value && SEL;  // the launch's first step has no scores to select from yet
     const PairDma d = dma_of(i + NS - 1, (SLOT + NS - 1) % NS);
-    if constexpr (SEL) tilep3_steps<LL, 0, 12, SLOT, NS, kCS, RD>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, ((i - 1) << (4 + kCS)) | code_q, pinf, w, ring, d);
+    if constexpr (SEL) tilep3_steps<LL, 0, 12, SLOT, NS, kCS, RD, FIRST>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, ((i - 1) << (4 + kCS)) | code_q, pinf, w, ring, d);
     else tilep_steps<LL, 0, 12, SLOT, NS, kCS>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, ((i - 1) << (4 + kCS)) | code_q, pinf, w, ring, d);
     // step i+1 (issued two steps ago) has landed for this wave; after the barrier it has for every wave, and every wave
     // is past its last read of step i-1, whose slot the DMA below refills
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (NS - 3)) : "memory");
-    if constexpr (SEL) tilep3_steps<LL, 12, 16, SLOT, NS, kCS, RD>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, ((i - 1) << (4 + kCS)) | code_q, pinf, w, ring, d);
+    if constexpr (SEL) tilep3_steps<LL, 12, 16, SLOT, NS, kCS, RD, FIRST>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, ((i - 1) << (4 + kCS)) | code_q, pinf, w, ring, d);
     else tilep_steps<LL, 12, 16, SLOT, NS, kCS>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, ((i - 1) << (4 + kCS)) | code_q, pinf, w, ring, d);
   };
+  // SEL: the first step is peeled (it has nothing to select from: NOSEL). NOT for the per-score insertion: there the first step's keys
+  // are NaN (-inf accumulators OR-ed with a code) and stay out of the lists by the HARDWARE's med3 rule (a NaN operand -> min3 of the
+  // others); peeled, the compiler knows the lists are -inf there and folds med3(-inf, key, +inf) to min(key, +inf) = +inf for a NaN key
+  // — every list head +inf, every certificate failing (measured: all 4,096 queries in the exact scan). A loop it cannot see through
+  // leaves the rule to the hardware.
+  constexpr std::false_type later{};
+  if constexpr (SEL) step(std::integral_constant<int, 0>{}, std::true_type{}, 0, accA0, accA1, accB0, accB1);
   for (int i = 0; i < steps; i += 4) {
-    step(std::integral_constant<int, 0>{}, i, accA0, accA1, accB0, accB1);
-    if (i + 1 < steps) step(std::integral_constant<int, 1>{}, i + 1, accB0, accB1, accA0, accA1);
-    if (i + 2 < steps) step(std::integral_constant<int, 2>{}, i + 2, accA0, accA1, accB0, accB1);
-    if (i + 3 < steps) step(std::integral_constant<int, 3>{}, i + 3, accB0, accB1, accA0, accA1);
+    if (i || !SEL) step(std::integral_constant<int, 0>{}, later, i, accA0, accA1, accB0, accB1);
+    if (i + 1 < steps) step(std::integral_constant<int, 1>{}, later, i + 1, accB0, accB1, accA0, accA1);
+    if (i + 2 < steps) step(std::integral_constant<int, 2>{}, later, i + 2, accA0, accA1, accB0, accB1);
+    if (i + 3 < steps) step(std::integral_constant<int, 3>{}, later, i + 3, accB0, accB1, accA0, accA1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // over-issued DMA pieces must not land in LDS after the workgroup is gone
   T2L_STAMP(2);

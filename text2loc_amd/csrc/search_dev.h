@@ -382,7 +382,8 @@ __device__ __forceinline__ void tile_sel_ops(float (&ls)[LL], float& dA, float& 
 }
 // k-steps [S, S_END) of one step of the paired scan with the tile-local selection. RD: depth of the fragment ring (k-steps of
 // prefetch); the ring crosses into the next slot RD k-steps before the tile ends — behind the step's barrier at k-step 12.
-template <int LL, int S, int S_END, int SLOT, int NS, int CS, int RD>
+// NOSEL: the launch's first step — the accumulators of "the tile before" hold nothing yet: MFMAs, ring and DMA only.
+template <int LL, int S, int S_END, int SLOT, int NS, int CS, int RD, bool NOSEL = false>
 __device__ __forceinline__ void tilep3_steps(lds_cptr lb0, lds_cptr lb1, const u32x4 (&q0)[16], const u32x4 (&q1)[16],
                                              f32x16& cur0, f32x16& cur1, const f32x16& prev0, const f32x16& prev1, int vmask,
                                              int code0, float pinf, TileSelLists<LL>& w, u32x4 (&ring)[RD], const PairDma& dma) {
@@ -398,16 +399,18 @@ __device__ __forceinline__ void tilep3_steps(lds_cptr lb0, lds_cptr lb1, const u
     if constexpr (S + RD < 16) ring[S & (RD - 1)] = pair_frag<SLOT, S + RD>(lb0, lb1);
     else ring[S & (RD - 1)] = pair_frag<NXT, S + RD - 16>(lb0, lb1);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (S < 8) tile_sel_ops<LL, O0, O1, CS>(w.ls0, w.dA0, w.dB0, w, prev0, vmask, code0, pinf);
+    if constexpr (NOSEL) {
+    } else if constexpr (S < 8) tile_sel_ops<LL, O0, O1, CS>(w.ls0, w.dA0, w.dB0, w, prev0, vmask, code0, pinf);
     else tile_sel_ops<LL, O0, O1, CS>(w.ls1, w.dA1, w.dB1, w, prev1, vmask, code0, pinf);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (S == 0) mfma_f16_first(cur1, a, q1[S]); else mfma_f16_acc(cur1, a, q1[S]);
     if constexpr (S >= 12) dma.piece(S - 12);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (S < 8) tile_sel_ops<LL, O1, O2, CS>(w.ls0, w.dA0, w.dB0, w, prev0, vmask, code0, pinf);
+    if constexpr (NOSEL) {
+    } else if constexpr (S < 8) tile_sel_ops<LL, O1, O2, CS>(w.ls0, w.dA0, w.dB0, w, prev0, vmask, code0, pinf);
     else tile_sel_ops<LL, O1, O2, CS>(w.ls1, w.dA1, w.dB1, w, prev1, vmask, code0, pinf);
     __builtin_amdgcn_sched_barrier(0);
-    tilep3_steps<LL, S + 1, S_END, SLOT, NS, CS, RD>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, code0, pinf, w, ring, dma);
+    tilep3_steps<LL, S + 1, S_END, SLOT, NS, CS, RD, NOSEL>(lb0, lb1, q0, q1, cur0, cur1, prev0, prev1, vmask, code0, pinf, w, ring, dma);
   }
 }
 
