@@ -16,17 +16,48 @@
 //                  WHOLE N x K result in registers (<= 64 tiles of 32x32 over 8 waves); the rows of the chunk go through LDS
 //                  once per 32-row step (dY tile and X tile, transposed by the fragment reads), float atomics at the end.
 #pragma once
+#include <type_traits>
+
 #include "gemm_f32.h"
 
 namespace t2l {
 namespace train {
+
+// ---- storage type of the EDGE-ROW tensors (X, y1, a1, y2 and their gradients): float32, or bf16 when the GEMMs run on bf16 operands
+// (MODE 1, BASELINE config 4's arithmetic — what torch.autocast(bfloat16) stores between its Linear and BatchNorm modules too). With bf16
+// operands every product and every element-wise pass of the step is HBM-bound (round 3: 35 GB per step): halving the bytes of the
+// tensors that ARE the traffic is the lever. Accumulation, the BatchNorm sums (taken from the f32 accumulators in the product's
+// epilogue, before the rounding), the per-cell tables and every group-level tensor (xout, dxout, arg, ysel) stay float32. A value is
+// rounded ONCE, when it is stored (RNE, v_cvt_pk_bf16_f32); every consumer — forward and backward — reads the same rounded value,
+// so the ReLU signs and arg-max rows the backward replays are the forward's.
+typedef unsigned short pn_bf16;
+template <int MODE>
+using pn_store_t = std::conditional_t<MODE == 1, pn_bf16, float>;
+typedef __bf16 pn_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pn_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pn_pack2(float a, float b) {  // low half = a, high half = b, round to nearest even
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(pn_f32x2{a, b}, pn_bf16x2));
+}
+__device__ __forceinline__ float4 pn_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 pn_ld4(const pn_bf16* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ void pn_st4(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void pn_st4(pn_bf16* p, const float4 v) { *reinterpret_cast<uint2*>(p) = make_uint2(pn_pack2(v.x, v.y), pn_pack2(v.z, v.w)); }
+__device__ __forceinline__ float pn_ld1(const float* p) { return *p; }
+__device__ __forceinline__ float pn_ld1(const pn_bf16* p) { return __uint_as_float((unsigned)*p << 16); }
+__device__ __forceinline__ void pn_st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void pn_st1(pn_bf16* p, float v) { *p = (pn_bf16)(pn_pack2(v, 0.f) & 0xFFFFu); }
+__device__ __forceinline__ float pn_round(float v, const float*) { return v; }
+__device__ __forceinline__ float pn_round(float v, const pn_bf16*) { return __uint_as_float(pn_pack2(v, 0.f) << 16); }  // the value a bf16 store keeps
 
 constexpr int kRows2Lds = 128 * 1024;   // LDS bytes of the weight chunk
 constexpr int kRows2Threads = 512;
 constexpr int kRows2MaxT = 4;  // column tiles per pass (64 accumulator registers: two waves per SIMD without spills)
 constexpr int kTn2MaxT = 4;    // k tiles per workgroup of tn2_kernel
 
-struct Rows2Args {
+struct Rows2Args {  // (A and C are pn_store_t<MODE> arrays: float32, or bf16 in MODE 1 — the pointers are typed float for the host's sake)
   const float* A;      // [M][lda]
   const float* W;      // [N][ldw] (k contiguous)
   const float* bias;   // [N] or nullptr
@@ -93,6 +124,9 @@ __global__ __launch_bounds__(kRows2Threads) void rows2_kernel(const Rows2Args g)
   const long row_lo = gw * g.rows_per_wave, row_hi = min((long)g.M, row_lo + g.rows_per_wave);
   constexpr int kRing = 4;
   const int plane = TP * KS * 64 * 16;
+  typedef pn_store_t<MODE> ST;
+  const ST* __restrict__ gA = reinterpret_cast<const ST*>(g.A);
+  ST* __restrict__ gC = reinterpret_cast<ST*>(g.C);
   for (int n0 = 0; n0 < g.N; n0 += 32 * TP) {
     __syncthreads();  // the previous pass's readers are done
     rows2_fill<MODE>(r2_lds, g.W, g.ldw, n0, TP, g.K, g.N);
@@ -118,7 +152,7 @@ __global__ __launch_bounds__(kRows2Threads) void rows2_kernel(const Rows2Args g)
     };
     for (long m0 = row_lo; m0 < row_hi; m0 += 32) {
       const long arow = min(m0 + i, (long)g.M - 1);  // rows past the end repeat the last one (never stored, never counted)
-      const float* ap = g.A + (size_t)arow * g.lda + 8 * kh;
+      const ST* ap = gA + (size_t)arow * g.lda + 8 * kh;
       int acell = 0;
       if (AFUSE) acell = g.row_cell[arow];
       const float* mp = AFUSE ? g.a_mean + (size_t)acell * g.K + 8 * kh : nullptr;
@@ -132,8 +166,15 @@ __global__ __launch_bounds__(kRows2Threads) void rows2_kernel(const Rows2Args g)
       float a[kRing][8];
       auto load_a = [&](int ks, float (&d)[8]) {
         const int k0 = 16 * min(ks, KS - 1);
-        const float4 x = *reinterpret_cast<const float4*>(ap + k0), y = *reinterpret_cast<const float4*>(ap + k0 + 4);
-        d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w; d[4] = y.x; d[5] = y.y; d[6] = y.z; d[7] = y.w;
+        if constexpr (MODE == 1) {  // bf16 rows: the lane's 8 k values are ONE 16-byte load
+          const uint4 u = *reinterpret_cast<const uint4*>(ap + k0);
+          d[0] = __uint_as_float(u.x << 16); d[1] = __uint_as_float(u.x & 0xFFFF0000u); d[2] = __uint_as_float(u.y << 16);
+          d[3] = __uint_as_float(u.y & 0xFFFF0000u); d[4] = __uint_as_float(u.z << 16); d[5] = __uint_as_float(u.z & 0xFFFF0000u);
+          d[6] = __uint_as_float(u.w << 16); d[7] = __uint_as_float(u.w & 0xFFFF0000u);
+        } else {
+          const float4 x = pn_ld4(ap + k0), y = pn_ld4(ap + k0 + 4);
+          d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w; d[4] = y.x; d[5] = y.y; d[6] = y.z; d[7] = y.w;
+        }
         if (AFUSE) {
           const float4 m0v = *reinterpret_cast<const float4*>(mp + k0), m1v = *reinterpret_cast<const float4*>(mp + k0 + 4);
           const float4 r0v = *reinterpret_cast<const float4*>(rp + k0), r1v = *reinterpret_cast<const float4*>(rp + k0 + 4);
@@ -204,7 +245,7 @@ __global__ __launch_bounds__(kRows2Threads) void rows2_kernel(const Rows2Args g)
       for (int t = 0; t < TP; ++t) {
         const int cg = n0 + 32 * t + i;
         if (cg < g.N) {
-          float v[16];
+          float v[16];  // (the BatchNorm sums below take these float32 values: the statistics of the product, not of its rounded copy)
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = acc[t][r] + bv[t];
           if (g.scat_dst) {  // (workgroup-uniform)
@@ -217,14 +258,14 @@ __global__ __launch_bounds__(kRows2Threads) void rows2_kernel(const Rows2Args g)
             }
             continue;
           }
-          float* cp = g.C + (size_t)(m0 + 4 * kh) * g.ldc + cg;
+          ST* cp = gC + (size_t)(m0 + 4 * kh) * g.ldc + cg;
           if (full) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = v[r];
+            for (int r = 0; r < 16; ++r) pn_st1(cp + (size_t)((r & 3) + 8 * (r >> 2)) * g.ldc, v[r]);
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-              if (m0 + 4 * kh + (r & 3) + 8 * (r >> 2) < (long)g.M) cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = v[r];
+              if (m0 + 4 * kh + (r & 3) + 8 * (r >> 2) < (long)g.M) pn_st1(cp + (size_t)((r & 3) + 8 * (r >> 2)) * g.ldc, v[r]);
           }
           if (STATS) {
             if (uniform && full) {
@@ -266,7 +307,7 @@ __global__ __launch_bounds__(kRows2Threads) void rows2_kernel(const Rows2Args g)
 // barrier per step; f32 row-major, row stride = 4 mod 8 floats so the column-wise fragment reads of both lane halves are
 // conflict-free); XFUSE applies the BatchNorm + ReLU of the layer that produced X while staging (a1 is never stored).
 // ---------------------------------------------------------------------------------------------------------------
-struct Tn2Args {
+struct Tn2Args {   // (dY and X are pn_store_t<MODE> arrays, as Rows2Args' A and C)
   const float* dY;   // [M][ldy]
   const float* X;    // [M][ldx]
   float* dW;         // [N][ldw]
@@ -302,20 +343,23 @@ __global__ __launch_bounds__(kRows2Threads) void tn2_kernel(const Tn2Args g) {
   float csum = 0.f;
   const bool do_db = g.db && blockIdx.z == 0;
   float4 sy[UY], sx[UX];
+  typedef pn_store_t<MODE> ST;
+  const ST* __restrict__ gY = reinterpret_cast<const ST*>(g.dY);
+  const ST* __restrict__ gX = reinterpret_cast<const ST*>(g.X);
   auto load_regs = [&](int s) {
     const long m0 = m_lo + (long)s * SR;
 #pragma unroll
     for (int q = 0; q < UY; ++q) {
       const int u = tid + q * kRows2Threads, r = u / (NB / 4), c = (u % (NB / 4)) * 4;
       const long row = m0 + r;
-      const float4 v = *reinterpret_cast<const float4*>(g.dY + (size_t)min(row, m_hi - 1) * g.ldy + n_base + c);
+      const float4 v = pn_ld4(gY + (size_t)min(row, m_hi - 1) * g.ldy + n_base + c);
       sy[q] = row < m_hi ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int q = 0; q < UX; ++q) {
       const int u = min(tid + q * kRows2Threads, UXT - 1), r = u / (KB / 4), c = (u % (KB / 4)) * 4;
       const long row = m0 + r, rowc = min(row, m_hi - 1);
-      float4 v = *reinterpret_cast<const float4*>(g.X + (size_t)rowc * g.ldx + k_base + c);
+      float4 v = pn_ld4(gX + (size_t)rowc * g.ldx + k_base + c);
       if (XFUSE) {
         const size_t o = (size_t)g.row_cell[rowc] * g.K + k_base + c;
         const float4 mm = *reinterpret_cast<const float4*>(g.x_mean + o), rr = *reinterpret_cast<const float4*>(g.x_rg + o),

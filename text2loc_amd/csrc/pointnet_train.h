@@ -40,11 +40,13 @@ struct PnTrain {
   char *ws = nullptr, *iws = nullptr;  // activations + scratch (sized exactly per call) / index tables (worst case, small)
   size_t ws_cap = 0, ws_off = 0, iws_cap = 0, scratch_off = 0, scratch_bytes = 0;
   int n_obj = 0, n_cells = 0;
+  bool half = false;  // the edge-row tensors of the forward in memory are bf16 (train_bf16 == 1 at the forward; the backward must match)
   int32_t *cell_of_obj = nullptr, *cell_base = nullptr;  // device
   const float *pos0 = nullptr, *rgb0 = nullptr;
   PnLevel lv[4];
   float *f0 = nullptr, *f1 = nullptr, *f2 = nullptr;
   double* acc = nullptr;  // [n_cells][2][1024]
+  float *bk1 = nullptr, *bk2 = nullptr;  // [n_cells][1024]: the BatchNorm backward's per-(cell, channel) coefficients (pt_bn_bwd_finalize_kernel)
   float* wt = nullptr;    // [1024 x 512]: a weight matrix transposed for the input-gradient GEMM
 };
 
@@ -161,15 +163,25 @@ __global__ __launch_bounds__(256) void pt_iota_rows_kernel(size_t E, int per, co
 // edge inputs: X[row] = [x_src | pos_src - pos_centre | 0 pad] (SA), [x | pos | 0 pad] (global MLP: pos_ctr == nullptr).
 // One thread per 4 consecutive columns (kp is a multiple of 32): whole float4 loads of the source row where the 4 columns are
 // features and cin is a multiple of 4 (every level but the first, whose 3 + 3 real columns fit the scalar path).
+// ST: storage type of the edge-row tensors (float, or pn_bf16 with bf16 GEMM operands: gemm_rows2.h)
+template <typename ST>
 __global__ __launch_bounds__(256) void pt_gather_kernel(const float* __restrict__ x_src, const float* __restrict__ pos_src,
                                                         const float* __restrict__ pos_ctr, const int32_t* __restrict__ src,
                                                         const int32_t* __restrict__ row_group, size_t E, int cin, int kp,
-                                                        float* __restrict__ X) {
+                                                        ST* __restrict__ X) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int q = kp >> 2;
   if (i >= E * q) return;
-  const size_t row = i / q;
-  const int col = (int)(i % q) * 4;
+  size_t row;
+  int col;
+  if (E * q < 0x7fffffffull) {  // (a 64-bit division costs more than the rest of this thread's work)
+    const unsigned iu = (unsigned)i, ru = iu / (unsigned)q;
+    row = ru;
+    col = (int)(iu - ru * (unsigned)q) * 4;
+  } else {
+    row = i / q;
+    col = (int)(i % q) * 4;
+  }
   const size_t sr = (size_t)src[row];
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (col + 4 <= cin && (cin & 3) == 0) {
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(256) void pt_gather_kernel(const float* __restrict_
     }
     v = make_float4(e[0], e[1], e[2], e[3]);
   }
-  *reinterpret_cast<float4*>(X + row * kp + col) = v;
+  pn_st4(X + row * kp + col, v);
 }
 
 __global__ void pt_pad_kernel(const float* __restrict__ W, int rows, int kin, int kp, float* __restrict__ Wp) {
@@ -203,9 +215,9 @@ constexpr int kStatRows = 1024;
 // The post-ReLU activation of a block's first layer is not stored by the second version: a == nullptr -> its sign is recomputed
 // from y exactly as the fused operand loads compute it (pt_bn_relu: fma(y - mean, rg, beta)).
 __device__ __forceinline__ float pt_bn_relu(float y, float m, float rg, float be) { return fmaxf(__fmaf_rn(__fsub_rn(y, m), rg, be), 0.f); }
-template <int MODE>
-__global__ __launch_bounds__(256) void pt_bn_stats_kernel(const float* __restrict__ y, const float* __restrict__ d,
-                                                          const float* __restrict__ a, int C, size_t E,
+template <int MODE, typename ST>
+__global__ __launch_bounds__(256) void pt_bn_stats_kernel(const ST* __restrict__ y, const ST* __restrict__ d,
+                                                          const ST* __restrict__ a, int C, size_t E,
                                                           const int32_t* __restrict__ row_cell, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, double* __restrict__ acc,
                                                           const float* __restrict__ rg, const float* __restrict__ beta) {
@@ -245,13 +257,13 @@ __global__ __launch_bounds__(256) void pt_bn_stats_kernel(const float* __restric
         }
       }
       const size_t i = row * C + c;
-      const float4 v = *reinterpret_cast<const float4*>(y + i);
+      const float4 v = pn_ld4(y + i);
       if (MODE == 0) {
         s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
         s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
       } else {
-        const float4 dv = *reinterpret_cast<const float4*>(d + i);
-        const float4 av = a ? *reinterpret_cast<const float4*>(a + i)
+        const float4 dv = pn_ld4(d + i);
+        const float4 av = a ? pn_ld4(a + i)
                             : make_float4(pt_bn_relu(v.x, mu.x, rgv.x, bev.x), pt_bn_relu(v.y, mu.y, rgv.y, bev.y),
                                           pt_bn_relu(v.z, mu.z, rgv.z, bev.z), pt_bn_relu(v.w, mu.w, rgv.w, bev.w));
         const float e0 = av.x > 0.f ? dv.x : 0.f, e1 = av.y > 0.f ? dv.y : 0.f, e2 = av.z > 0.f ? dv.z : 0.f, e3 = av.w > 0.f ? dv.w : 0.f;
@@ -333,16 +345,18 @@ __global__ __launch_bounds__(256) void pt_bn_finalize_kernel(const double* __res
   }
 }
 
-__global__ __launch_bounds__(256) void pt_bn_apply_fwd_kernel(const float* __restrict__ y, size_t E, int C,
+template <typename ST>
+__global__ __launch_bounds__(256) void pt_bn_apply_fwd_kernel(const ST* __restrict__ y, size_t E, int C,
                                                               const int32_t* __restrict__ row_cell, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float* __restrict__ a) {
-  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;  // C is a multiple of 32: four channels of one row
+                                                              const float* __restrict__ beta, ST* __restrict__ a) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;  // C is a power of two >= 32: four channels of one row
   if (i >= E * C) return;
-  const size_t row = i / C;
-  const int c = (int)(i % C);
+  const int lg = __ffs(C) - 1;
+  const size_t row = i >> lg;
+  const int c = (int)(i & (size_t)(C - 1));
   const size_t sc = (size_t)row_cell[row] * C + c;
-  const float4 v = *reinterpret_cast<const float4*>(y + i), m = *reinterpret_cast<const float4*>(mean + sc),
+  const float4 v = pn_ld4(y + i), m = *reinterpret_cast<const float4*>(mean + sc),
                r = *reinterpret_cast<const float4*>(rstd + sc), ga = *reinterpret_cast<const float4*>(gamma + c),
                be = *reinterpret_cast<const float4*>(beta + c);
   float4 o;
@@ -350,62 +364,99 @@ __global__ __launch_bounds__(256) void pt_bn_apply_fwd_kernel(const float* __res
   o.y = fmaxf((v.y - m.y) * r.y * ga.y + be.y, 0.f);
   o.z = fmaxf((v.z - m.z) * r.z * ga.z + be.z, 0.f);
   o.w = fmaxf((v.w - m.w) * r.w * ga.w + be.w, 0.f);
-  *reinterpret_cast<float4*>(a + i) = o;
+  pn_st4(a + i, o);
 }
 
 // d (gradient w.r.t. the ReLU output) -> gradient w.r.t. the Linear output, in place. FROM_MAX (second layer of a block): the
 // incoming gradient is not read from d but rebuilt from the max aggregation — row `arg[group][c]` receives dxout[group][c],
 // every other row 0 — and the result is written to d.
-template <bool FROM_MAX>
-__global__ __launch_bounds__(256) void pt_bn_apply_bwd_kernel(float* __restrict__ d, const float* __restrict__ a, const float* __restrict__ y,
-                                                              size_t E, int C, const int32_t* __restrict__ row_cell,
-                                                              const int32_t* __restrict__ cnt, const double* __restrict__ acc,
+// The BatchNorm backward's closed form per element is  dx = k0 dv - k1 - (y - mean) k2  with per-(cell, channel) coefficients
+//   k0 = gamma rstd,  k1 = gamma rstd S1 / n,  k2 = gamma rstd^2 S2 / n   (S1 = sum dv, S2 = sum dv xhat over the cell's rows):
+// pt_bn_bwd_finalize_kernel turns the float64 sums into the k1 / k2 tables ONCE per (cell, channel) — the element-wise pass used to
+// read eight doubles and divide by n per thread — and adds the layer's gamma / beta gradients (sum over cells of S2 / S1) in the same
+// launch (it replaces pt_bn_param_grad_kernel: a serial walk over the cells per channel, 25 us x 8 launches per step).
+// Block = 32 channels x 8 cell lanes.
+__global__ __launch_bounds__(256) void pt_bn_bwd_finalize_kernel(const double* __restrict__ acc, const int32_t* __restrict__ cnt, int n_cells, int C,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                                                 float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta) {
+  __shared__ double r1[8][33], r2[8][33];
+  const int cl = threadIdx.x & 31, lane8 = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+  const bool cok = c < C;
+  const float ga = cok ? gamma[c] : 0.f;
+  double t1 = 0.0, t2 = 0.0;
+  if (cok)
+    for (int cell = lane8; cell < n_cells; cell += 8) {
+      const double s1 = acc[((size_t)cell * 2) * 1024 + c], s2 = acc[((size_t)cell * 2 + 1) * 1024 + c];
+      const float n = (float)max(cnt[cell], 1), r = rstd[(size_t)cell * C + c];
+      k1[(size_t)cell * C + c] = ga * r / n * (float)s1;
+      k2[(size_t)cell * C + c] = ga * r / n * r * (float)s2;
+      t1 += s1;
+      t2 += s2;
+    }
+  r1[lane8][cl] = t1;
+  r2[lane8][cl] = t2;
+  __syncthreads();
+  if (lane8 == 0 && cok) {
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      t1 += r1[j][cl];
+      t2 += r2[j][cl];
+    }
+    dbeta[c] += (float)t1;
+    dgamma[c] += (float)t2;
+  }
+}
+// d (gradient w.r.t. the ReLU output) -> gradient w.r.t. the Linear output, in place. FROM_MAX (second layer of a block): the
+// incoming gradient is not read from d but rebuilt from the max aggregation — row `arg[group][c]` receives dxout[group][c],
+// every other row 0 — and the result is written to d. C is a power of two (32 .. 1024): row / channel of an element by shift / mask.
+template <bool FROM_MAX, typename ST>
+__global__ __launch_bounds__(256) void pt_bn_apply_bwd_kernel(ST* __restrict__ d, const ST* __restrict__ a, const ST* __restrict__ y,
+                                                              size_t E, int C, int log2c, const int32_t* __restrict__ row_cell,
+                                                              const float* __restrict__ k1, const float* __restrict__ k2,
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, const int32_t* __restrict__ arg,
                                                               const float* __restrict__ dxout, const int32_t* __restrict__ row_group,
                                                               const float* __restrict__ beta, const float* __restrict__ rg) {
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= E * C) return;
-  const size_t row = i / C;
-  const int c = (int)(i % C);
-  const int cell = row_cell[row];
-  const size_t sc = (size_t)cell * C + c;
-  const float n = (float)max(cnt[cell], 1);
+  if (i >= E << log2c) return;
+  const size_t row = i >> log2c;
+  const int c = (int)(i & (size_t)(C - 1));
+  const size_t sc = ((size_t)row_cell[row] << log2c) + c;
   float4 dv4;
   if constexpr (FROM_MAX) {
-    const size_t gi = (size_t)row_group[row] * C + c;
+    const size_t gi = ((size_t)row_group[row] << log2c) + c;
     const int4 ar = *reinterpret_cast<const int4*>(arg + gi);
     const float4 dx = *reinterpret_cast<const float4*>(dxout + gi);
     const int r = (int)row;
     dv4 = make_float4(ar.x == r ? dx.x : 0.f, ar.y == r ? dx.y : 0.f, ar.z == r ? dx.z : 0.f, ar.w == r ? dx.w : 0.f);
   } else {
-    dv4 = *reinterpret_cast<const float4*>(d + i);
+    dv4 = pn_ld4(d + i);
   }
-  const float4 yv = *reinterpret_cast<const float4*>(y + i), m = *reinterpret_cast<const float4*>(mean + sc),
-               r = *reinterpret_cast<const float4*>(rstd + sc), ga = *reinterpret_cast<const float4*>(gamma + c);
-  float4 av;  // the ReLU output (its sign is what matters): stored for first layers, recomputed for second ones
+  const float4 yv = pn_ld4(y + i), m = *reinterpret_cast<const float4*>(mean + sc), r = *reinterpret_cast<const float4*>(rstd + sc),
+               ga = *reinterpret_cast<const float4*>(gamma + c), q1 = *reinterpret_cast<const float4*>(k1 + sc),
+               q2 = *reinterpret_cast<const float4*>(k2 + sc);
+  float4 av;  // the ReLU output (its sign is what matters): stored for the global MLP's first layer, recomputed otherwise
   if constexpr (FROM_MAX) {
     const float4 be = *reinterpret_cast<const float4*>(beta + c);
     av = make_float4((yv.x - m.x) * r.x * ga.x + be.x, (yv.y - m.y) * r.y * ga.y + be.y, (yv.z - m.z) * r.z * ga.z + be.z,
                      (yv.w - m.w) * r.w * ga.w + be.w);
   } else if (a) {
-    av = *reinterpret_cast<const float4*>(a + i);
+    av = pn_ld4(a + i);
   } else {  // second version: a1 is not stored
     const float4 be = *reinterpret_cast<const float4*>(beta + c), g4 = *reinterpret_cast<const float4*>(rg + sc);
     av = make_float4(pt_bn_relu(yv.x, m.x, g4.x, be.x), pt_bn_relu(yv.y, m.y, g4.y, be.y), pt_bn_relu(yv.z, m.z, g4.z, be.z),
                      pt_bn_relu(yv.w, m.w, g4.w, be.w));
   }
-  const double* a1 = acc + ((size_t)cell * 2) * 1024 + c;
-  const double* a2 = acc + ((size_t)cell * 2 + 1) * 1024 + c;
   float4 o;
-#define T2L_PT_BWD(X, K)                                                                                   \
-  {                                                                                                        \
-    const float dv = av.X > 0.f ? dv4.X : 0.f;                                                             \
-    o.X = ga.X * r.X / n * (n * dv - (float)a1[K] - (yv.X - m.X) * r.X * (float)a2[K]);                    \
+#define T2L_PT_BWD(X)                                                    \
+  {                                                                      \
+    const float dv = av.X > 0.f ? dv4.X : 0.f;                           \
+    o.X = ga.X * r.X * dv - q1.X - (yv.X - m.X) * q2.X;                  \
   }
-  T2L_PT_BWD(x, 0) T2L_PT_BWD(y, 1) T2L_PT_BWD(z, 2) T2L_PT_BWD(w, 3)
+  T2L_PT_BWD(x) T2L_PT_BWD(y) T2L_PT_BWD(z) T2L_PT_BWD(w)
 #undef T2L_PT_BWD
-  *reinterpret_cast<float4*>(d + i) = o;
+  pn_st4(d + i, o);
 }
 // BatchNorm-backward sums of a block's SECOND layer, straight from the max aggregation: only the arg-max row of every
 // (group, channel) carries a gradient, so sum dv and sum dv * xhat are sums over GROUPS (dv = dxout where the maximum is > 0;
@@ -444,33 +495,22 @@ __global__ __launch_bounds__(256) void pt_bn_stats_max_kernel(const float* __res
     atomicAdd(acc + ((size_t)cur * 2 + 1) * 1024 + c, (double)s2);
   }
 }
-__global__ void pt_bn_param_grad_kernel(const double* __restrict__ acc, int n_cells, int C, float* __restrict__ dgamma,
-                                        float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int cell = 0; cell < n_cells; ++cell) {
-    s1 += acc[((size_t)cell * 2) * 1024 + c];
-    s2 += acc[((size_t)cell * 2 + 1) * 1024 + c];
-  }
-  dbeta[c] += (float)s1;
-  dgamma[c] += (float)s2;
-}
-
 // second layer of a block: BatchNorm + ReLU applied on the fly, max over the rows of every group (first maximum wins, as
 // argmax) + the winning row and its pre-BatchNorm value (ysel: the backward's statistics need y at the arg-max row and read it
 // from here instead of gathering it) — the post-ReLU activations of the widest layer never exist in memory.
 // One thread per (group, 4 channels): float4 loads, a wave covers 1 KiB of a row.
-__global__ __launch_bounds__(256) void pt_segmax_kernel(const float* __restrict__ y, const int32_t* __restrict__ goff, size_t n_groups, int C,
+template <typename ST>
+__global__ __launch_bounds__(256) void pt_segmax_kernel(const ST* __restrict__ y, const int32_t* __restrict__ goff, size_t n_groups, int C,
                                                         int nd, const int32_t* __restrict__ cell_of_obj, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ xout, int32_t* __restrict__ arg,
                                                         float* __restrict__ ysel) {
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n_groups * C) return;
-  const size_t g = i / C;
-  const int c = (int)(i % C);
-  const size_t sc = (size_t)cell_of_obj[g / nd] * C + c;
+  const int lg = __ffs(C) - 1;  // (C is a power of two)
+  const size_t g = i >> lg;
+  const int c = (int)(i & (size_t)(C - 1));
+  const size_t sc = (size_t)cell_of_obj[(unsigned)g / (unsigned)nd] * C + c;
   const float4 m = *reinterpret_cast<const float4*>(mean + sc), r = *reinterpret_cast<const float4*>(rstd + sc),
                ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
   const int lo = goff[g], hi = goff[g + 1];
@@ -478,7 +518,7 @@ __global__ __launch_bounds__(256) void pt_segmax_kernel(const float* __restrict_
   int br[4] = {-1, -1, -1, -1};
 #pragma unroll 4
   for (int row = lo; row < hi; ++row) {
-    const float4 yv = *reinterpret_cast<const float4*>(y + (size_t)row * C + c);
+    const float4 yv = pn_ld4(y + (size_t)row * C + c);
     const float v[4] = {fmaxf((yv.x - m.x) * r.x * ga.x + be.x, 0.f), fmaxf((yv.y - m.y) * r.y * ga.y + be.y, 0.f),
                         fmaxf((yv.z - m.z) * r.z * ga.z + be.z, 0.f), fmaxf((yv.w - m.w) * r.w * ga.w + be.w, 0.f)};
     const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
@@ -494,9 +534,10 @@ __global__ __launch_bounds__(256) void pt_segmax_kernel(const float* __restrict_
   *reinterpret_cast<int4*>(arg + i) = make_int4(br[0], br[1], br[2], br[3]);
   *reinterpret_cast<float4*>(ysel + i) = make_float4(ys[0], ys[1], ys[2], ys[3]);
 }
-__global__ void pt_slice_kernel(const float* __restrict__ dX, size_t rows, int cin, int kp, float* __restrict__ out) {
+template <typename ST>
+__global__ void pt_slice_kernel(const ST* __restrict__ dX, size_t rows, int cin, int kp, float* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < rows * cin) out[i] = dX[(i / cin) * kp + (i % cin)];
+  if (i < rows * cin) out[i] = pn_ld1(dX + (i / cin) * kp + (i % cin));
 }
 __global__ void pt_relu_mask_kernel(float* __restrict__ d, const float* __restrict__ f, size_t n) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -626,7 +667,9 @@ static bool gemm_tn2(const float* dY, const float* X, float* dW, float* db, size
     const int rpw = (int)(((M + gx - 1) / gx + SR - 1) / SR * SR);
     // a narrower last block starts at column 32 * kb_tiles * nfull: shift the operand pointers, keep kb_tiles for the block stride
     const int k0 = part == 0 ? 0 : 32 * kb_tiles * nfull;
-    const train::Tn2Args a{dY, X + k0, dW + k0, part == 0 ? db : nullptr, (int)M, N, K, N, K, ldw, rpw, kb_tiles, k_real - k0,
+    // (X is an edge-row tensor: bf16 elements with bf16 operands — the column shift is in ITS elements)
+    const float* Xs = mode == 1 ? reinterpret_cast<const float*>(reinterpret_cast<const train::pn_bf16*>(X) + k0) : X + k0;
+    const train::Tn2Args a{dY, Xs, dW + k0, part == 0 ? db : nullptr, (int)M, N, K, N, K, ldw, rpw, kb_tiles, k_real - k0,
                            x_mean ? x_mean + k0 : nullptr, x_rg ? x_rg + k0 : nullptr, x_beta ? x_beta + k0 : nullptr, row_cell};
     const dim3 grid(gx, gy, gz);
     const bool xf = x_mean != nullptr;
@@ -705,8 +748,12 @@ static size_t pn_layout(PnTrain* pt) {
   pt->cell_of_obj = pn_bump<int32_t>(pt, n_obj);
   pt->cell_base = pn_bump<int32_t>(pt, n_obj);
   pt->acc = pn_bump<double>(pt, (size_t)n_cells * 2 * 1024);
+  pt->bk1 = pn_bump<float>(pt, (size_t)n_cells * 1024);
+  pt->bk2 = pn_bump<float>(pt, (size_t)n_cells * 1024);
   pt->wt = pn_bump<float>(pt, (size_t)1024 * 512);
   size_t scratch = 0;
+  const size_t es = pt->half ? 2 : 4;  // bytes per element of an edge-row tensor (gemm_rows2.h: pn_store_t)
+  auto edge = [&](size_t count) { return reinterpret_cast<float*>(pn_bump<char>(pt, count * es)); };
   for (int l = 0; l < 4; ++l) {
     PnLevel& L = pt->lv[l];
     L.cnt = pn_bump<int32_t>(pt, n_cells);
@@ -714,14 +761,14 @@ static size_t pn_layout(PnTrain* pt) {
     L.src = pn_bump<int32_t>(pt, L.E);
     L.row_group = pn_bump<int32_t>(pt, L.E);
     L.row_cell = pn_bump<int32_t>(pt, L.E);
-    L.X = pn_bump<float>(pt, L.E * L.kp);
+    L.X = edge(L.E * L.kp);
     L.w1p = pn_bump<float>(pt, (size_t)L.h1 * L.kp);
-    L.y1 = pn_bump<float>(pt, L.E * L.h1);
+    L.y1 = edge(L.E * L.h1);
     // second version: a1 is recomputed from y1 wherever it is consumed — except in the global MLP (45 k rows x 512: 92 MB), whose
     // wide layers would pay the fused operand transform once per column pass (K = 512 leaves two column tiles per pass)
-    L.a1 = l == 3 ? pn_bump<float>(pt, L.E * L.h1) : nullptr;
+    L.a1 = l == 3 ? edge(L.E * L.h1) : nullptr;
     L.rg1 = pn_bump<float>(pt, (size_t)n_cells * L.h1);
-    L.y2 = pn_bump<float>(pt, L.E * L.h2);
+    L.y2 = edge(L.E * L.h2);
     L.mean1 = pn_bump<float>(pt, (size_t)n_cells * L.h1);
     L.rstd1 = pn_bump<float>(pt, (size_t)n_cells * L.h1);
     L.mean2 = pn_bump<float>(pt, (size_t)n_cells * L.h2);
@@ -730,7 +777,7 @@ static size_t pn_layout(PnTrain* pt) {
     L.arg = pn_bump<int32_t>(pt, L.G * L.h2);
     L.ysel = pn_bump<float>(pt, L.G * L.h2);
     // backward scratch of this level: dA2, dA1, dX (+ 256-byte roundings)
-    scratch = std::max(scratch, L.E * (size_t)(L.h2 + L.h1 + L.kp) * sizeof(float) + 3 * 256);
+    scratch = std::max(scratch, L.E * (size_t)(L.h2 + L.h1 + L.kp) * es + 3 * 256);
   }
   pt->f1 = pn_bump<float>(pt, (size_t)n_obj * 512);
   pt->f2 = pn_bump<float>(pt, (size_t)n_obj * 256);
@@ -754,10 +801,16 @@ static void pn_block_fwd(TrainState* st, PnTrain* pt, const PnLevel& L, int laye
   hipLaunchKernelGGL(pt_bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const double*)pt->acc, (const int32_t*)L.cnt, pt->n_cells, C,
                      mean, rstd, T_(st, p + ".1.running_mean").data, T_(st, p + ".1.running_var").data, 0.1f,
                      (const float*)T_(st, p + ".1.weight").data, rg);
-  if (a)
-    hipLaunchKernelGGL(pt_bn_apply_fwd_kernel, dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, (const float*)y, L.E, C, (const int32_t*)L.row_cell,
-                       (const float*)mean, (const float*)rstd, (const float*)T_(st, p + ".1.weight").data,
-                       (const float*)T_(st, p + ".1.bias").data, a);
+  if (a) {
+    if (pt->half)
+      hipLaunchKernelGGL((pt_bn_apply_fwd_kernel<pn_bf16>), dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, reinterpret_cast<const pn_bf16*>(y), L.E, C,
+                         (const int32_t*)L.row_cell, (const float*)mean, (const float*)rstd, (const float*)T_(st, p + ".1.weight").data,
+                         (const float*)T_(st, p + ".1.bias").data, reinterpret_cast<pn_bf16*>(a));
+    else
+      hipLaunchKernelGGL((pt_bn_apply_fwd_kernel<float>), dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, (const float*)y, L.E, C,
+                         (const int32_t*)L.row_cell, (const float*)mean, (const float*)rstd, (const float*)T_(st, p + ".1.weight").data,
+                         (const float*)T_(st, p + ".1.bias").data, a);
+  }
 }
 
 // d: gradient w.r.t. the block's ReLU output [E, C] (overwritten with the gradient w.r.t. the Linear output). dxout != nullptr
@@ -767,23 +820,38 @@ static void pn_block_bwd(TrainState* st, PnTrain* pt, const PnLevel& L, int laye
   using namespace train;
   const std::string p = L.prefix + "." + std::to_string(layer);
   (void)hipMemsetAsync(pt->acc, 0, sizeof(double) * 2 * 1024 * pt->n_cells, s);
+  int log2c = 0;
+  while ((1 << log2c) < C) ++log2c;  // (C is 32 .. 1024, a power of two)
+  // sums -> coefficient tables + gamma / beta gradients -> element-wise closed form
   if (dxout) {
     hipLaunchKernelGGL(pt_bn_stats_max_kernel, dim3((C + 63) / 64, (unsigned)((L.G + 255) / 256)), dim3(256), 0, s, (const float*)L.ysel,
                        (const float*)L.xout, dxout, L.G, C, L.nd, (const int32_t*)pt->cell_of_obj, mean, rstd, pt->acc);
-    hipLaunchKernelGGL((pt_bn_apply_bwd_kernel<true>), dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, d, a, y, L.E, C,
-                       (const int32_t*)L.row_cell, (const int32_t*)L.cnt, (const double*)pt->acc, (const float*)T_(st, p + ".1.weight").data, mean,
-                       rstd, (const int32_t*)L.arg, dxout, (const int32_t*)L.row_group, (const float*)T_(st, p + ".1.bias").data,
-                       (const float*)nullptr);
   } else {
     const dim3 sgrid((C + 63) / 64, (unsigned)((L.E + kStatRows - 1) / kStatRows));
-    hipLaunchKernelGGL((pt_bn_stats_kernel<1>), sgrid, dim3(256), 0, s, y, (const float*)d, a, C, L.E, (const int32_t*)L.row_cell, mean, rstd,
-                       pt->acc, rg, (const float*)T_(st, p + ".1.bias").data);
-    hipLaunchKernelGGL((pt_bn_apply_bwd_kernel<false>), dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, d, a, y, L.E, C,
-                       (const int32_t*)L.row_cell, (const int32_t*)L.cnt, (const double*)pt->acc, (const float*)T_(st, p + ".1.weight").data, mean,
-                       rstd, (const int32_t*)nullptr, (const float*)nullptr, (const int32_t*)nullptr, (const float*)T_(st, p + ".1.bias").data, rg);
+    if (pt->half)
+      hipLaunchKernelGGL((pt_bn_stats_kernel<1, pn_bf16>), sgrid, dim3(256), 0, s, reinterpret_cast<const pn_bf16*>(y), reinterpret_cast<const pn_bf16*>(d),
+                         reinterpret_cast<const pn_bf16*>(a), C, L.E, (const int32_t*)L.row_cell, mean, rstd, pt->acc, rg,
+                         (const float*)T_(st, p + ".1.bias").data);
+    else
+      hipLaunchKernelGGL((pt_bn_stats_kernel<1, float>), sgrid, dim3(256), 0, s, y, (const float*)d, a, C, L.E, (const int32_t*)L.row_cell, mean, rstd,
+                         pt->acc, rg, (const float*)T_(st, p + ".1.bias").data);
   }
-  hipLaunchKernelGGL(pt_bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)pt->acc, pt->n_cells, C,
-                     T_(st, p + ".1.weight").grad, T_(st, p + ".1.bias").grad);
+  hipLaunchKernelGGL(pt_bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const double*)pt->acc, (const int32_t*)L.cnt, pt->n_cells, C,
+                     (const float*)T_(st, p + ".1.weight").data, rstd, pt->bk1, pt->bk2, T_(st, p + ".1.weight").grad, T_(st, p + ".1.bias").grad);
+#define T2L_PN_BWD_APPLY(FM, ST_)                                                                                                                   \
+  hipLaunchKernelGGL((pt_bn_apply_bwd_kernel<FM, ST_>), dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, reinterpret_cast<ST_*>(d),                   \
+                     reinterpret_cast<const ST_*>(a), reinterpret_cast<const ST_*>(y), L.E, C, log2c, (const int32_t*)L.row_cell,                    \
+                     (const float*)pt->bk1, (const float*)pt->bk2, (const float*)T_(st, p + ".1.weight").data, mean, rstd,                         \
+                     (const int32_t*)(FM ? L.arg : nullptr), (const float*)(FM ? dxout : nullptr), (const int32_t*)(FM ? L.row_group : nullptr),    \
+                     (const float*)T_(st, p + ".1.bias").data, (const float*)(FM ? nullptr : rg))
+  if (dxout) {
+    if (pt->half) T2L_PN_BWD_APPLY(true, pn_bf16);
+    else T2L_PN_BWD_APPLY(true, float);
+  } else {
+    if (pt->half) T2L_PN_BWD_APPLY(false, pn_bf16);
+    else T2L_PN_BWD_APPLY(false, float);
+  }
+#undef T2L_PN_BWD_APPLY
 }
 
 int pn_train_forward_impl(t2l_ctx* ctx, const float* pos, const float* rgb, const int32_t* cell_offsets, int n_cells, float* out_f2,
@@ -804,6 +872,7 @@ int pn_train_forward_impl(t2l_ctx* ctx, const float* pos, const float* rgb, cons
   pt->pos0 = pos;
   pt->rgb0 = rgb;
   tl_gemm_bf16 = ctx->train_bf16;
+  pt->half = ctx->train_bf16 == 1;  // bf16 operands -> the edge-row tensors live in memory as bf16 (gemm_rows2.h: pn_store_t)
   const std::string P = "object_encoder.pointnet.";
   const int ns[3] = {256, 128, 64}, cin[3] = {3, 64, 128}, h1[4] = {32, 128, 256, 512}, h2[4] = {64, 128, 256, 1024};
   const float radius[3] = {0.2f, 0.3f, 0.4f};
@@ -936,17 +1005,25 @@ int pn_train_forward_impl(t2l_ctx* ctx, const float* pos, const float* rgb, cons
     else
       hipLaunchKernelGGL(pt_iota_rows_kernel, dim3(pn_blocks(L.E + 1)), dim3(256), 0, s, L.E, 32, (const int32_t*)pt->cell_of_obj, L.src,
                          L.row_group, L.row_cell, L.goff);
-    hipLaunchKernelGGL(pt_gather_kernel, dim3(pn_blocks(L.E * (L.kp / 4))), dim3(256), 0, s, cur_x, cur_pos, L.sa ? (const float*)L.pos_out : nullptr,
-                       (const int32_t*)L.src, (const int32_t*)L.row_group, L.E, L.cin, L.kp, L.X);
+    if (pt->half)
+      hipLaunchKernelGGL((pt_gather_kernel<pn_bf16>), dim3(pn_blocks(L.E * (L.kp / 4))), dim3(256), 0, s, cur_x, cur_pos,
+                         L.sa ? (const float*)L.pos_out : nullptr, (const int32_t*)L.src, (const int32_t*)L.row_group, L.E, L.cin, L.kp,
+                         reinterpret_cast<pn_bf16*>(L.X));
+    else
+      hipLaunchKernelGGL((pt_gather_kernel<float>), dim3(pn_blocks(L.E * (L.kp / 4))), dim3(256), 0, s, cur_x, cur_pos,
+                         L.sa ? (const float*)L.pos_out : nullptr, (const int32_t*)L.src, (const int32_t*)L.row_group, L.E, L.cin, L.kp, L.X);
     hipLaunchKernelGGL(pt_pad_kernel, dim3(pn_blocks((size_t)L.h1 * L.kp)), dim3(256), 0, s, (const float*)T_(st, L.prefix + ".0.0.weight").data,
                        L.h1, L.kin, L.kp, L.w1p);
     pn_block_fwd(st, pt, L, 0, L.X, L.w1p, L.kp, L.h1, L.y1, L.a1, L.mean1, L.rstd1, L.rg1, false, s);
     pn_block_fwd(st, pt, L, 1, L.a1 ? L.a1 : L.y1, T_(st, L.prefix + ".1.0.weight").data, L.h1, L.h2, L.y2, nullptr, L.mean2, L.rstd2, nullptr,
                  L.a1 == nullptr, s);
-    hipLaunchKernelGGL(pt_segmax_kernel, dim3(pn_blocks(L.G * L.h2 / 4)), dim3(256), 0, s, (const float*)L.y2, (const int32_t*)L.goff, L.G, L.h2,
-                       L.nd, (const int32_t*)pt->cell_of_obj, (const float*)L.mean2, (const float*)L.rstd2,
-                       (const float*)T_(st, L.prefix + ".1.1.weight").data, (const float*)T_(st, L.prefix + ".1.1.bias").data, L.xout, L.arg,
-                       L.ysel);
+#define T2L_PN_SEGMAX(ST_)                                                                                                                        \
+  hipLaunchKernelGGL((pt_segmax_kernel<ST_>), dim3(pn_blocks(L.G * L.h2 / 4)), dim3(256), 0, s, reinterpret_cast<const ST_*>(L.y2),               \
+                     (const int32_t*)L.goff, L.G, L.h2, L.nd, (const int32_t*)pt->cell_of_obj, (const float*)L.mean2, (const float*)L.rstd2,       \
+                     (const float*)T_(st, L.prefix + ".1.1.weight").data, (const float*)T_(st, L.prefix + ".1.1.bias").data, L.xout, L.arg, L.ysel)
+    if (pt->half) T2L_PN_SEGMAX(pn_bf16);
+    else T2L_PN_SEGMAX(float);
+#undef T2L_PN_SEGMAX
     if (L.sa) {
       cur_pos = L.pos_out;
       cur_x = L.xout;
@@ -973,7 +1050,11 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
     return fail(ctx, T2L_ESTATE, "t2l_pointnet_backward: the backbone was bound without gradient buffers (frozen)");
   if (!grad_f2) return fail(ctx, T2L_EINVAL, "t2l_pointnet_backward: null gradient");
   const int n_obj = pt->n_obj;
+  if ((ctx->train_bf16 == 1) != pt->half)
+    return fail(ctx, T2L_ESTATE, "t2l_pointnet_backward: option train_bf16 changed between the forward and the backward (the saved edge rows are "
+                                 "bf16 exactly when the forward ran with train_bf16 = 1)");
   tl_gemm_bf16 = ctx->train_bf16;
+  const size_t es = pt->half ? 2 : 4;
   const std::string P = "object_encoder.pointnet.";
   event_begin(ctx, "pointnet_train_backward", s);
   pt->ws_off = pt->scratch_off;
@@ -991,8 +1072,8 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
   for (int l = 3; l >= 0; --l) {
     const PnLevel& L = pt->lv[l];
     const size_t lmark = pt->ws_off;
-    float* dA2 = pn_bump<float>(pt, L.E * L.h2);
-    float* dA1 = pn_bump<float>(pt, L.E * L.h1);
+    float* dA2 = reinterpret_cast<float*>(pn_bump<char>(pt, L.E * L.h2 * es));  // (edge-row tensors: pn_store_t)
+    float* dA1 = reinterpret_cast<float*>(pn_bump<char>(pt, L.E * L.h1 * es));
     pn_block_bwd(st, pt, L, 1, dA2, L.y2, nullptr, L.h2, L.mean2, L.rstd2, nullptr, dx, s);
     const float* be1 = T_(st, L.prefix + ".0.1.bias").data;
     {  // a1 = relu(bn(y1)) is rebuilt while y1 is staged
@@ -1020,11 +1101,15 @@ int pn_train_backward_impl(t2l_ctx* ctx, const float* grad_f2, hipStream_t s) {
         gemm_rows2(dA1, pt->wt, nullptr, nullptr, L.E, (L.cin + 31) / 32 * 32, L.h1, nullptr, nullptr, nullptr, nullptr, nullptr, s,
                    (const int32_t*)L.src, dx_next, L.cin);
       } else {
-        float* dX = pn_bump<float>(pt, L.E * L.kp);  // (the global level: no sampling, the rows ARE the level below's)
+        float* dX = reinterpret_cast<float*>(pn_bump<char>(pt, L.E * L.kp * es));  // (the global level: no sampling, the rows ARE the level below's)
         hipLaunchKernelGGL(pt_transpose_kernel, dim3((unsigned)((L.h1 * L.kp + 255) / 256)), dim3(256), 0, s, (const float*)L.w1p, L.h1, L.kp,
                            pt->wt);
         gemm_rows2(dA1, pt->wt, nullptr, dX, L.E, L.kp, L.h1, nullptr, nullptr, nullptr, nullptr, nullptr, s);
-        hipLaunchKernelGGL(pt_slice_kernel, dim3(pn_blocks(L.E * L.cin)), dim3(256), 0, s, (const float*)dX, L.E, L.cin, L.kp, dx_next);
+        if (pt->half)
+          hipLaunchKernelGGL((pt_slice_kernel<pn_bf16>), dim3(pn_blocks(L.E * L.cin)), dim3(256), 0, s, reinterpret_cast<const pn_bf16*>(dX), L.E, L.cin,
+                             L.kp, dx_next);
+        else
+          hipLaunchKernelGGL((pt_slice_kernel<float>), dim3(pn_blocks(L.E * L.cin)), dim3(256), 0, s, (const float*)dX, L.E, L.cin, L.kp, dx_next);
       }
       std::swap(dx, dx_next);
     }
