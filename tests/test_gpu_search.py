@@ -682,6 +682,52 @@ def _plane_rows(n):
     return np.where(t < full, j * full + t, p)
 
 
+def test_three_best_rows_in_one_tile_local_group_are_repaired_in_the_wave():
+    """The paired scan keeps the best TWO keys of every group of 8 accumulator registers (search_dev.h: TileSelLists) and hands the third
+    to the re-rank as the record's B1. Here every query's three best rows sit in ONE such group — plane slots 0, 1, 2 of one tile, i.e.
+    rows t, F + t, 2 F + t of the strided plane — so the third is dropped by construction: the re-rank must find it again by re-scoring
+    the 8 rows of B1's group (the 'group repair', counted as `rescored`), not by an exact scan of the shard and not by a wide repair;
+    ids and float64 scores equal the oracle's. The same database under the per-score insertion (search_tile_sel = 0) needs no repair."""
+    import torch
+    from oracle import c_oracle
+    from text2loc_amd.engine import Engine
+
+    rng = np.random.default_rng(77)
+    n, q = 11259, 320  # (>= 256 queries: the paired scan; one tile per query out of the 351 full tiles)
+    full = n // 32
+    db = synth.unit_rows(rng.standard_normal((n, 256))).astype(np.float32)
+    qs = synth.unit_rows(rng.standard_normal((q, 256))).astype(np.float32)
+    tiles = rng.choice(full, size=q, replace=False)
+    for i, t in enumerate(tiles):  # three near-copies of query i at plane slots 0, 1, 2 of tile t
+        for j, noise in enumerate((0.35, 0.45, 0.55)):
+            db[j * full + t] = synth.unit_rows((qs[i].astype(np.float64) + noise * synth.unit_rows(rng.standard_normal((1, 256)))[0])[None])[0]
+    rows = _plane_rows(n)
+    assert all(rows[32 * t + j] == j * full + t for t in tiles[:8] for j in range(3))
+    ridx, rsc = c_oracle.retrieve_topk(db, qs, 10)
+    assert all(set(ridx[i][:3]) == {tiles[i], full + tiles[i], 2 * full + tiles[i]} for i in range(q))
+    e = Engine(0)
+    try:
+        e.set_option("search_auto", 0)
+        e.set_option("search_merge_lists", 1)  # merged records whatever the report card says: the selection under test needs them
+        e.db_set(torch.from_numpy(db).cuda())
+        qd = torch.from_numpy(qs).cuda()
+        out = {}
+        for sel in (1, 0):
+            e.set_option("search_tile_sel", sel)
+            idx, sc = e.search(qd, 10)
+            torch.cuda.synchronize()
+            out[sel] = e.search_counters()
+            assert np.array_equal(idx.cpu().numpy().astype(np.int64), ridx), sel
+            assert np.abs(sc.cpu().numpy() - rsc).max() < 1e-12
+        # (measured: 294 of the 320 queries repaired in the wave, 1 in an exact scan, 25 certified without — their third row's key also
+        # reached the record through the other lane half's list)
+        assert out[1]["valu_exact_scans"] <= 2 and out[1]["wide_repairs"] <= 2, out
+        assert out[1]["rescored"] >= q * 8 // 10, out
+        assert out[0]["rescored"] <= 8 and out[0]["valu_exact_scans"] == 0, out
+    finally:
+        e.close()
+
+
 def test_merged_records_follow_the_report_card():
     """Default (``search_merge_lists = 2``): merged records while next to no query fails its first certificate; a clustered database moves
     the engine to plain lists within a few calls (a repair behind a merged record re-scores 4x the rows: the wide repair's cap sends those
