@@ -719,8 +719,8 @@ def test_three_best_rows_in_one_tile_local_group_are_repaired_in_the_wave():
             out[sel] = e.search_counters()
             assert np.array_equal(idx.cpu().numpy().astype(np.int64), ridx), sel
             assert np.abs(sc.cpu().numpy() - rsc).max() < 1e-12
-        # (measured: 294 of the 320 queries repaired in the wave, 1 in an exact scan, 25 certified without — their third row's key also
-        # reached the record through the other lane half's list)
+        # (measured: 294 of the 320 queries repaired in the wave, 1 in an exact scan, 25 certified without: a wave's LAST tile — one in
+        # eleven — is inserted score by score in the scan's epilogue, nothing of it is dropped)
         assert out[1]["valu_exact_scans"] <= 2 and out[1]["wide_repairs"] <= 2, out
         assert out[1]["rescored"] >= q * 8 // 10, out
         assert out[0]["rescored"] <= 8 and out[0]["valu_exact_scans"] == 0, out
