@@ -1463,7 +1463,9 @@ __device__ __forceinline__ void rerank_query(const RerankArgs& a, const int qid,
 // ------------------------------------------------------------------------------------------------
 // LL = length of the per-lane lists the scan wrote, L = rows re-scored per query (LL <= L).
 template <int LL, int L, bool MG = false>
-__global__ __launch_bounds__(256, 4) void rerank_kernel(const float* __restrict__ db, const float* __restrict__ q, int Q,
+// (the merged-record form holds its group-repair path inside 128 VGPRs: four waves per SIMD = all 4,096 query waves of a batch resident at once;
+//  the other forms keep the occupancy the compiler finds — L = 32 takes 139 VGPRs and would spill under the bound)
+__global__ __launch_bounds__(256, (MG ? 4 : 1)) void rerank_kernel(const float* __restrict__ db, const float* __restrict__ q, int Q,
                                                      int K, int parts, int code_bits,
                                                      const float* __restrict__ cand, int row_offset, float eps_rel,
                                                      const float* __restrict__ db_norm_max, int half_mode,
