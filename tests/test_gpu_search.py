@@ -139,6 +139,23 @@ def test_unrepresentable_inputs_take_the_exact_scan(eng):
     assert np.array_equal(idx, ridx)
 
 
+def test_narrower_embeddings_are_zero_padded(eng):
+    """``--coarse_embed_dim 128`` (models/cell_retrieval.py:22-49): the search takes rows narrower than its compiled 256 by zero padding —
+    ids and float64 scores are those of the narrow rows (the reference's loop on the same arrays)."""
+    rng = np.random.default_rng(128)
+    for d in (128, 64, 200):
+        db = synth.unit_rows(rng.standard_normal((3000, d))).astype(np.float32)
+        q = synth.unit_rows(db[rng.integers(0, 3000, 300)].astype(np.float64) + 0.5 * synth.unit_rows(rng.standard_normal((300, d)))).astype(np.float32)
+        idx, sc = _search(eng, db, q, 10)
+        ridx, rsc = O.retrieve_topk(db, q, 10)
+        assert np.array_equal(idx, ridx), d
+        assert np.abs(sc - rsc).max() < 1e-12
+    import torch
+
+    with pytest.raises(Exception, match="D <= 256"):
+        eng.db_set(torch.zeros(10, 300).cuda())
+
+
 def test_clustered_scores_use_the_second_stage(eng):
     """Scores packed ~1e-4 apart: more rows than the re-rank re-scores sit inside the scan's error band, so the
     certificate fails and the targeted float64 re-score (or the full one) decides — exactly."""

@@ -547,6 +547,17 @@ class Engine:
         torch.cuda.current_stream(self.device).synchronize()
 
     # ------------------------------------------------------------------ database + search
+    @staticmethod
+    def _pad_width(x: torch.Tensor, what: str) -> torch.Tensor:
+        """The search kernels are compiled for rows of EMBED_DIM = 256 floats. Narrower embeddings (``--coarse_embed_dim 128``: a model
+        whose encoders run elsewhere) are zero-padded: zeros add nothing to a dot product, so ids and float64 scores are exactly those of
+        the narrow rows (the certificate's norms and the f16 scaling see the same largest element). Wider ones have no kernel."""
+        if x.dim() != 2 or x.shape[1] > EMBED_DIM or x.shape[1] < 1:
+            raise T2LError(f"{what}: expected [N, D <= {EMBED_DIM}], got {tuple(x.shape)}")
+        if x.shape[1] < EMBED_DIM:
+            x = torch.nn.functional.pad(x.to(torch.float32), (0, EMBED_DIM - int(x.shape[1])))
+        return x
+
     def db_set(self, emb: torch.Tensor, row_offset: int = 0, owner=None):
         """Upload this rank's database shard. ``owner`` (any object) is remembered as ``db_owner`` so that callers sharing
         the engine can tell WHOSE rows are resident (row counts alone do not: db.CellDatabase.search); every call without
@@ -554,8 +565,7 @@ class Engine:
         self.db_owner = owner if owner is not None else object()
         self.db_generation = getattr(self, "db_generation", 0) + 1
         n = int(emb.shape[0])
-        if emb.dim() != 2 or emb.shape[1] != EMBED_DIM:
-            raise T2LError(f"db_set: expected [N,{EMBED_DIM}], got {tuple(emb.shape)}")
+        emb = self._pad_width(emb, "db_set")
         ptr = self._ptr(emb, torch.float32, "db") if n > 0 else None
         self._check(self.lib.t2l_db_set(self._h, ptr, n, int(row_offset), _stream_ptr(self.device)))
 
@@ -570,8 +580,7 @@ class Engine:
         cross-stream hop). With ``set_option("search_lanes", n)`` pass ``join=False`` for a stream of independent batches:
         consecutive calls pipeline on internal streams (t2l.h); call ``search_join()`` before touching any of their results
         or re-using their ``queries`` / ``out`` buffers (after 64 un-joined calls the engine joins by itself)."""
-        if queries.dim() != 2 or queries.shape[1] != EMBED_DIM:
-            raise T2LError(f"search: expected [Q,{EMBED_DIM}], got {tuple(queries.shape)}")
+        queries = self._pad_width(queries, "search")
         Q = int(queries.shape[0])
         if out is None:
             idx = torch.empty((Q, k), dtype=torch.int32, device=queries.device)
