@@ -165,7 +165,11 @@ __global__ __launch_bounds__(kRows2Threads) void rows2_kernel(const Rows2Args g)
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
       float a[kRing][8];
       auto load_a = [&](int ks, float (&d)[8]) {
+#ifdef T2L_EXP_R2_NOLOAD  // dev experiment (wrong results): every k-step re-reads the row's first 16 bytes (L1-hot): what does the A stream cost?
+        const int k0 = 0 * ks;
+#else
         const int k0 = 16 * min(ks, KS - 1);
+#endif
         if constexpr (MODE == 1) {  // bf16 rows: the lane's 8 k values are ONE 16-byte load
           const uint4 u = *reinterpret_cast<const uint4*>(ap + k0);
           d[0] = __uint_as_float(u.x << 16); d[1] = __uint_as_float(u.x & 0xFFFF0000u); d[2] = __uint_as_float(u.y << 16);
@@ -259,6 +263,9 @@ __global__ __launch_bounds__(kRows2Threads) void rows2_kernel(const Rows2Args g)
             continue;
           }
           ST* cp = gC + (size_t)(m0 + 4 * kh) * g.ldc + cg;
+#ifdef T2L_EXP_R2_NOSTORE  // dev experiment (wrong results): what do the epilogue's strided stores cost?
+          if (v[0] == 1.2345e30f)
+#endif
           if (full) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) pn_st1(cp + (size_t)((r & 3) + 8 * (r >> 2)) * g.ldc, v[r]);
