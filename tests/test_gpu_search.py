@@ -330,6 +330,28 @@ def test_full_size_properties(eng):
     assert np.abs(sc - rsc).max() < 1e-12
 
 
+def test_shard_of_two_scan_segments(eng):
+    """A shard beyond one scan launch's 524,288 rows is searched segment by segment and merged; the f16 plane deals rows to tiles strided
+    INSIDE each segment (plane_row: the second segment here has 156 full tiles and a partial one). Batched (paired scan) and streaming
+    (few queries) paths against the float64 ranking."""
+    rng = np.random.default_rng(19)
+    n = 524_288 + 5_000
+    db = rng.standard_normal((n, 256)).astype(np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    tgt = np.concatenate([rng.integers(0, n, 200), rng.integers(524_288, n, 56)])  # (some answers in the short second segment)
+    q = db[tgt].astype(np.float64) + 0.6 * rng.standard_normal((256, 256)) / 16.0
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    s = q.astype(np.float64) @ db.astype(np.float64).T
+    ridx = np.argsort(-s, axis=1, kind="stable")[:, :10]
+    rsc = np.take_along_axis(s, ridx, axis=1)
+    idx, sc = _search(eng, db, q, 10)
+    assert np.array_equal(idx, ridx)
+    assert np.abs(sc - rsc).max() < 1e-12
+    idx, sc = _search(eng, db, q[:8], 10)  # the streaming scan walks the whole plane in one launch
+    assert np.array_equal(idx, ridx[:8])
+    assert (ridx[200:, 0] >= 524_288).all()
+
+
 def test_hip_merge_kernel_vs_host_merge(eng):
     import torch
     from text2loc_amd.sharded import merge_topk_host
