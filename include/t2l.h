@@ -469,6 +469,10 @@ int t2l_adam_state(t2l_ctx* ctx, int32_t set, float* m, float* v, int64_t* step,
  *                     key): a third of the bytes written back at the end of the launch, -0.7 us per step at Q = 4096; 2 = records while the
  *                     report cards show fewer than 1 query in 64 failing its first certificate (a repair behind a record re-scores 4x the
  *                     rows of a plain list's), plain lists otherwise. Results are bit-identical in every setting.
+ * "search_tile_sel"   (default 1): with merged records, the paired scan selects through a local top 3 per group of 8 scores (the best two
+ *                     enter the lane's list, the third travels as the record's decodable bound B1; the re-rank re-scores that group's 8
+ *                     rows when a query's certificate fails on B1 alone). 0 = every score inserted into the list (round 5's form; A/B).
+ *                     Results are identical either way.
  * "search_pair_ll"    (default 6): per-lane list length of the paired scan (5: experiment, halves the certificate's margin).
  * "profile_events"    (default 0): n >= 1 records hipEvents around every n-th launch of each kernel (t2l_kernel_stats);
  *                     two records cost ~6 us of queue time per bracketed kernel, which matters beside a 30 us kernel.
