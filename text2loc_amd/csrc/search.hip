@@ -674,8 +674,8 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
     }
     // a lane's FLOOR (its 6th key: every row the lane saw and dropped lies at or below it) bounds what the record cannot list
     float f0 = O0[LL - 1], f1 = O1[LL - 1];
-    f0 = fmaxf(f0, __shfl_xor(f0, 32));
-    f1 = fmaxf(f1, __shfl_xor(f1, 32));
+    f0 = fmaxf(f0, xor32_f32(f0, half));
+    f1 = fmaxf(f1, xor32_f32(f1, half));
     // SEL: (dA >= dB) = the two largest third-best keys of the lane's tile-local groups — real keys whose code names their group. The four
     // lanes of a query meet in (DA >= DB), the two largest of their eight: two sorted pairs -> top 2 = (max heads, max(min heads, max seconds))
     auto top2 = [&](float& a, float& b, float oa, float ob) {
@@ -686,15 +686,15 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
     float DA0 = T2L_NEG_INF, DB0 = T2L_NEG_INF, DA1 = T2L_NEG_INF, DB1 = T2L_NEG_INF;
     if constexpr (SEL) {
       DA0 = with_half(w.dA0); DB0 = with_half(w.dB0); DA1 = with_half(w.dA1); DB1 = with_half(w.dB1);
-      top2(DA0, DB0, __shfl_xor(DA0, 32), __shfl_xor(DB0, 32));
-      top2(DA1, DB1, __shfl_xor(DA1, 32), __shfl_xor(DB1, 32));
+      top2(DA0, DB0, xor32_f32(DA0, half), xor32_f32(DB0, half));
+      top2(DA1, DB1, xor32_f32(DA1, half), xor32_f32(DB1, half));
     }
     {
       float B0[LL], B1[LL];
 #pragma unroll
       for (int i = 0; i < LL; ++i) {
-        B0[i] = __shfl_xor(O0[i], 32);
-        B1[i] = __shfl_xor(O1[i], 32);
+        B0[i] = xor32_f32(O0[i], half);
+        B1[i] = xor32_f32(O1[i], half);
       }
       static_assert(LL == 6 && kMergedLL == 8, "the half merge below is written out for 6 + 6 -> 8");
       A0[0] = O0[0]; A0[1] = O0[1]; A0[6] = B0[1]; A0[7] = B0[0];
@@ -713,8 +713,8 @@ __global__ __launch_bounds__(512, 1) void scanp_kernel(const uint4* __restrict__
     for (int i = 0; i < kMergedLL; ++i) M[i] = half ? A1[i] : A0[i];
     float fl = half ? f1 : f0;
     float DA = half ? DA1 : DA0, DB = half ? DB1 : DB0;
-    float* xch = smem + ((size_t)wq * 64 + lane) * (kMergedLL + 3);  // 11-float records: conflict-free
-    __syncthreads();  // every wave is done with the tile ring
+    // 11-float records (conflict-free) in their own 11 KB BEHIND the tile ring: no barrier between the last tile and the exchange
+    float* xch = smem + NS * kSlotBytes / sizeof(float) + ((size_t)wq * 64 + lane) * (kMergedLL + 3);
     if (quad == 1) {
 #pragma unroll
       for (int i = 0; i < kMergedLL; ++i) xch[i] = M[i];
@@ -1619,7 +1619,8 @@ static int launch_search(t2l_ctx* ctx, const float* db, const uint4* dbs, const 
   if constexpr (LL <= 6) {  // paired f16 MFMA scan (default): one 512-thread workgroup per CU, 256 queries each; `nsplit`
     // counts VIRTUAL splits here: the kernel takes physical ones (2 virtual splits per workgroup)
     const dim3 grid((Q + kWideQPerBlock - 1) / kWideQPerBlock * (nsplit / 2));
-    const size_t lds = (size_t)4 * 2 * kHalfTileBytes;
+    // (the tile ring + the merged records' exchange area: 256 records of 11 floats)
+    const size_t lds = (size_t)4 * 2 * kHalfTileBytes + (size_t)256 * (kMergedLL + 3) * sizeof(float);
     static PerDeviceOnce once;
     if (once.need(ctx->device)) {
       allow_lds(&scanp_kernel<LL, 4>, lds);

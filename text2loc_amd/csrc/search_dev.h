@@ -443,6 +443,12 @@ __device__ __forceinline__ float wave_max_f32(float v, float pinf) {  // every l
   return v;
 }
 
+// the value the lane 32 away holds (lane ^ 32) — v_permlane32_swap + a select instead of a ds_bpermute round trip through the LDS pipe
+__device__ __forceinline__ float xor32_f32(float v, int half) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(half ? r[0] : r[1]);
+}
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_d(double v) {
   const unsigned long long b = __double_as_longlong(v);
