@@ -412,7 +412,11 @@ __global__ __launch_bounds__(kRows2Threads) void tn2_kernel(const Tn2Args g) {
     for (int h = 0; h < 2; ++h) {
       float a[8];
 #pragma unroll
+#ifdef T2L_EXP_TN2_NOLDS  // dev experiment (wrong results): fragments from registers instead of the transposed LDS reads
+      for (int j = 0; j < 8; ++j) a[j] = csum + (float)j;
+#else
       for (int j = 0; j < 8; ++j) a[j] = ya[(16 * h + j) * ldyl];
+#endif
       gemm_bf16x8 ah, al;
       if (MODE == 2) gemm_split_bf16(a, ah, al);
       else if (MODE == 1) ah = gemm_to_bf16(a);
@@ -420,7 +424,11 @@ __global__ __launch_bounds__(kRows2Threads) void tn2_kernel(const Tn2Args g) {
       for (int t = 0; t < KT; ++t) {
         float b[8];
 #pragma unroll
+#ifdef T2L_EXP_TN2_NOLDS
+        for (int j = 0; j < 8; ++j) b[j] = csum + (float)(j + t);
+#else
         for (int j = 0; j < 8; ++j) b[j] = xa[(16 * h + j) * ldxl + t * 32];
+#endif
         if (MODE == 0) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[t], 0, 0, 0);
@@ -445,6 +453,9 @@ __global__ __launch_bounds__(kRows2Threads) void tn2_kernel(const Tn2Args g) {
     if (s + 1 < steps) write_lds((s + 1) & 1);
     __syncthreads();
   }
+#ifdef T2L_EXP_TN2_NOATOMIC  // dev experiment (wrong results): what do the final float atomics cost?
+  if (acc[0][0] != 1.2345e30f) return;
+#endif
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
     const int k = k_base + t * 32 + i;
