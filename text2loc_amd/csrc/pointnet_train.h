@@ -407,56 +407,96 @@ __global__ __launch_bounds__(256) void pt_bn_bwd_finalize_kernel(const double* _
     dgamma[c] += (float)t2;
   }
 }
-// d (gradient w.r.t. the ReLU output) -> gradient w.r.t. the Linear output, in place. FROM_MAX (second layer of a block): the
-// incoming gradient is not read from d but rebuilt from the max aggregation — row `arg[group][c]` receives dxout[group][c],
-// every other row 0 — and the result is written to d. C is a power of two (32 .. 1024): row / channel of an element by shift / mask.
-template <bool FROM_MAX, typename ST>
-__global__ __launch_bounds__(256) void pt_bn_apply_bwd_kernel(ST* __restrict__ d, const ST* __restrict__ a, const ST* __restrict__ y,
-                                                              size_t E, int C, int log2c, const int32_t* __restrict__ row_cell,
-                                                              const float* __restrict__ k1, const float* __restrict__ k2,
-                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                              const float* __restrict__ rstd, const int32_t* __restrict__ arg,
-                                                              const float* __restrict__ dxout, const int32_t* __restrict__ row_group,
-                                                              const float* __restrict__ beta, const float* __restrict__ rg) {
+// d (gradient w.r.t. the ReLU output) -> gradient w.r.t. the Linear output, in place: two forms. (The element-wise form of rounds 2-5 —
+// one thread per 4 elements, every table and the group's arg / dxout loaded beside each of them — took 214 / 168 us per launch with bf16
+// rows; the two below 110 / 158 us.)
+// First layers, strip-wise: the iteration of pt_bn_stats_kernel — thread = 4 channels x one of 16 row lanes of a block
+// of kStatRows rows; rows are sorted by cell, so the per-(cell, channel) tables are reloaded only when the cell changes (nearly all
+// blocks lie inside one cell) instead of beside every element. grid (C/64, ceil(E/kStatRows)).
+template <typename ST>
+__global__ __launch_bounds__(256) void pt_bn_apply_bwd_rows_kernel(ST* __restrict__ d, const ST* __restrict__ a, const ST* __restrict__ y, int C,
+                                                                   size_t E, const int32_t* __restrict__ row_cell, const float* __restrict__ k1,
+                                                                   const float* __restrict__ k2, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                   const float* __restrict__ beta, const float* __restrict__ rg) {
+  const int c = blockIdx.x * 64 + 4 * (threadIdx.x & 15), g = threadIdx.x >> 4;
+  if (c >= C) return;
+  const size_t lo = (size_t)blockIdx.y * kStatRows, hi = min(E, lo + kStatRows);
+  const bool one_cell = row_cell[lo] == row_cell[hi - 1];  // block-uniform
+  int cur = -1;
+  float4 m, k0, q1, q2, g4;
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+  auto tables = [&](int cell) {
+    const size_t sc = (size_t)cell * C + c;
+    m = *reinterpret_cast<const float4*>(mean + sc);
+    const float4 r = *reinterpret_cast<const float4*>(rstd + sc);
+    k0 = make_float4(ga.x * r.x, ga.y * r.y, ga.z * r.z, ga.w * r.w);
+    q1 = *reinterpret_cast<const float4*>(k1 + sc);
+    q2 = *reinterpret_cast<const float4*>(k2 + sc);
+    g4 = a ? k0 : *reinterpret_cast<const float4*>(rg + sc);
+    cur = cell;
+  };
+  tables(row_cell[lo]);
+#pragma unroll 2
+  for (size_t row = lo + g; row < hi; row += 16) {
+    if (!one_cell) {
+      const int cell = row_cell[row];
+      if (cell != cur) tables(cell);
+    }
+    const size_t i = row * C + c;
+    const float4 yv = pn_ld4(y + i), dv4 = pn_ld4(d + i);
+    const float4 av = a ? pn_ld4(a + i)
+                        : make_float4(pt_bn_relu(yv.x, m.x, g4.x, be.x), pt_bn_relu(yv.y, m.y, g4.y, be.y), pt_bn_relu(yv.z, m.z, g4.z, be.z),
+                                      pt_bn_relu(yv.w, m.w, g4.w, be.w));
+    float4 o;
+    o.x = k0.x * (av.x > 0.f ? dv4.x : 0.f) - q1.x - (yv.x - m.x) * q2.x;
+    o.y = k0.y * (av.y > 0.f ? dv4.y : 0.f) - q1.y - (yv.y - m.y) * q2.y;
+    o.z = k0.z * (av.z > 0.f ? dv4.z : 0.f) - q1.z - (yv.z - m.z) * q2.z;
+    o.w = k0.w * (av.w > 0.f ? dv4.w : 0.f) - q1.w - (yv.w - m.w) * q2.w;
+    pn_st4(d + i, o);
+  }
+}
+// Second layers (FROM the max aggregation: the incoming gradient is not read from d but rebuilt — row `arg[group][c]` receives
+// dxout[group][c], every other row 0 — and the result is written to d), group-wise: one thread per (group, 4 channels) walks the group's rows, as
+// pt_segmax_kernel does in the forward. Everything that is per GROUP — the arg-max rows, the gradient arriving at them — and per
+// (cell, channel) — a group lies inside one object, hence one cell — is loaded ONCE per thread instead of once per element (the
+// element-wise form above issued 32 bytes of arg / dxout loads and six table loads beside every 8 bytes of y): per row it reads y and
+// writes d. grid = ceil(G * C / 4 / 256).
+template <typename ST>
+__global__ __launch_bounds__(256) void pt_bn_apply_bwd_groups_kernel(ST* __restrict__ d, const ST* __restrict__ y, const int32_t* __restrict__ goff,
+                                                                     size_t n_groups, int C, int nd, const int32_t* __restrict__ cell_of_obj,
+                                                                     const float* __restrict__ k1, const float* __restrict__ k2,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                     const int32_t* __restrict__ arg, const float* __restrict__ dxout) {
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= E << log2c) return;
-  const size_t row = i >> log2c;
+  if (i >= n_groups * C) return;
+  const int lg = __ffs(C) - 1;  // (C is a power of two)
+  const size_t g = i >> lg;
   const int c = (int)(i & (size_t)(C - 1));
-  const size_t sc = ((size_t)row_cell[row] << log2c) + c;
-  float4 dv4;
-  if constexpr (FROM_MAX) {
-    const size_t gi = ((size_t)row_group[row] << log2c) + c;
-    const int4 ar = *reinterpret_cast<const int4*>(arg + gi);
-    const float4 dx = *reinterpret_cast<const float4*>(dxout + gi);
-    const int r = (int)row;
-    dv4 = make_float4(ar.x == r ? dx.x : 0.f, ar.y == r ? dx.y : 0.f, ar.z == r ? dx.z : 0.f, ar.w == r ? dx.w : 0.f);
-  } else {
-    dv4 = pn_ld4(d + i);
+  const size_t sc = (size_t)cell_of_obj[(unsigned)g / (unsigned)nd] * C + c;
+  const float4 m = *reinterpret_cast<const float4*>(mean + sc), r = *reinterpret_cast<const float4*>(rstd + sc),
+               ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c),
+               q1 = *reinterpret_cast<const float4*>(k1 + sc), q2 = *reinterpret_cast<const float4*>(k2 + sc);
+  const int4 ar = *reinterpret_cast<const int4*>(arg + i);
+  const float4 dx = *reinterpret_cast<const float4*>(dxout + i);
+  const float4 k0 = make_float4(ga.x * r.x, ga.y * r.y, ga.z * r.z, ga.w * r.w);
+  const int lo = goff[g], hi = goff[g + 1];
+#pragma unroll 4
+  for (int row = lo; row < hi; ++row) {
+    const size_t e = (size_t)row * C + c;
+    const float4 yv = pn_ld4(y + e);
+    float4 o;
+#define T2L_PT_BWDG(X)                                                                         \
+  {                                                                                            \
+    const float av = (yv.X - m.X) * r.X * ga.X + be.X; /* the sign of the ReLU input, as the forward's max saw it */ \
+    const float dv = (ar.X == row && av > 0.f) ? dx.X : 0.f;                                   \
+    o.X = k0.X * dv - q1.X - (yv.X - m.X) * q2.X;                                              \
   }
-  const float4 yv = pn_ld4(y + i), m = *reinterpret_cast<const float4*>(mean + sc), r = *reinterpret_cast<const float4*>(rstd + sc),
-               ga = *reinterpret_cast<const float4*>(gamma + c), q1 = *reinterpret_cast<const float4*>(k1 + sc),
-               q2 = *reinterpret_cast<const float4*>(k2 + sc);
-  float4 av;  // the ReLU output (its sign is what matters): stored for the global MLP's first layer, recomputed otherwise
-  if constexpr (FROM_MAX) {
-    const float4 be = *reinterpret_cast<const float4*>(beta + c);
-    av = make_float4((yv.x - m.x) * r.x * ga.x + be.x, (yv.y - m.y) * r.y * ga.y + be.y, (yv.z - m.z) * r.z * ga.z + be.z,
-                     (yv.w - m.w) * r.w * ga.w + be.w);
-  } else if (a) {
-    av = pn_ld4(a + i);
-  } else {  // second version: a1 is not stored
-    const float4 be = *reinterpret_cast<const float4*>(beta + c), g4 = *reinterpret_cast<const float4*>(rg + sc);
-    av = make_float4(pt_bn_relu(yv.x, m.x, g4.x, be.x), pt_bn_relu(yv.y, m.y, g4.y, be.y), pt_bn_relu(yv.z, m.z, g4.z, be.z),
-                     pt_bn_relu(yv.w, m.w, g4.w, be.w));
+    T2L_PT_BWDG(x) T2L_PT_BWDG(y) T2L_PT_BWDG(z) T2L_PT_BWDG(w)
+#undef T2L_PT_BWDG
+    pn_st4(d + e, o);
   }
-  float4 o;
-#define T2L_PT_BWD(X)                                                    \
-  {                                                                      \
-    const float dv = av.X > 0.f ? dv4.X : 0.f;                           \
-    o.X = ga.X * r.X * dv - q1.X - (yv.X - m.X) * q2.X;                  \
-  }
-  T2L_PT_BWD(x) T2L_PT_BWD(y) T2L_PT_BWD(z) T2L_PT_BWD(w)
-#undef T2L_PT_BWD
-  pn_st4(d + i, o);
 }
 // BatchNorm-backward sums of a block's SECOND layer, straight from the max aggregation: only the arg-max row of every
 // (group, channel) carries a gradient, so sum dv and sum dv * xhat are sums over GROUPS (dv = dxout where the maximum is > 0;
@@ -838,20 +878,25 @@ static void pn_block_bwd(TrainState* st, PnTrain* pt, const PnLevel& L, int laye
   }
   hipLaunchKernelGGL(pt_bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const double*)pt->acc, (const int32_t*)L.cnt, pt->n_cells, C,
                      (const float*)T_(st, p + ".1.weight").data, rstd, pt->bk1, pt->bk2, T_(st, p + ".1.weight").grad, T_(st, p + ".1.bias").grad);
-#define T2L_PN_BWD_APPLY(FM, ST_)                                                                                                                   \
-  hipLaunchKernelGGL((pt_bn_apply_bwd_kernel<FM, ST_>), dim3(pn_blocks(L.E * C / 4)), dim3(256), 0, s, reinterpret_cast<ST_*>(d),                   \
-                     reinterpret_cast<const ST_*>(a), reinterpret_cast<const ST_*>(y), L.E, C, log2c, (const int32_t*)L.row_cell,                    \
-                     (const float*)pt->bk1, (const float*)pt->bk2, (const float*)T_(st, p + ".1.weight").data, mean, rstd,                         \
-                     (const int32_t*)(FM ? L.arg : nullptr), (const float*)(FM ? dxout : nullptr), (const int32_t*)(FM ? L.row_group : nullptr),    \
-                     (const float*)T_(st, p + ".1.bias").data, (const float*)(FM ? nullptr : rg))
   if (dxout) {
-    if (pt->half) T2L_PN_BWD_APPLY(true, pn_bf16);
-    else T2L_PN_BWD_APPLY(true, float);
+#define T2L_PN_BWD_GROUPS(ST_)                                                                                                                          \
+  hipLaunchKernelGGL((pt_bn_apply_bwd_groups_kernel<ST_>), dim3(pn_blocks(L.G * C / 4)), dim3(256), 0, s, reinterpret_cast<ST_*>(d),                    \
+                     reinterpret_cast<const ST_*>(y), (const int32_t*)L.goff, L.G, C, L.nd, (const int32_t*)pt->cell_of_obj, (const float*)pt->bk1,     \
+                     (const float*)pt->bk2, (const float*)T_(st, p + ".1.weight").data, (const float*)T_(st, p + ".1.bias").data, mean, rstd,         \
+                     (const int32_t*)L.arg, dxout)
+    if (pt->half) T2L_PN_BWD_GROUPS(pn_bf16);
+    else T2L_PN_BWD_GROUPS(float);
+#undef T2L_PN_BWD_GROUPS
   } else {
-    if (pt->half) T2L_PN_BWD_APPLY(false, pn_bf16);
-    else T2L_PN_BWD_APPLY(false, float);
+    const dim3 agrid((C + 63) / 64, (unsigned)((L.E + kStatRows - 1) / kStatRows));
+#define T2L_PN_BWD_ROWS(ST_)                                                                                                                          \
+  hipLaunchKernelGGL((pt_bn_apply_bwd_rows_kernel<ST_>), agrid, dim3(256), 0, s, reinterpret_cast<ST_*>(d), reinterpret_cast<const ST_*>(a),        \
+                     reinterpret_cast<const ST_*>(y), C, L.E, (const int32_t*)L.row_cell, (const float*)pt->bk1, (const float*)pt->bk2,              \
+                     (const float*)T_(st, p + ".1.weight").data, mean, rstd, (const float*)T_(st, p + ".1.bias").data, rg)
+    if (pt->half) T2L_PN_BWD_ROWS(pn_bf16);
+    else T2L_PN_BWD_ROWS(float);
+#undef T2L_PN_BWD_ROWS
   }
-#undef T2L_PN_BWD_APPLY
 }
 
 int pn_train_forward_impl(t2l_ctx* ctx, const float* pos, const float* rgb, const int32_t* cell_offsets, int n_cells, float* out_f2,
