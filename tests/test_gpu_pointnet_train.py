@@ -320,6 +320,31 @@ def test_batch_of_64_cells_equals_its_parts(eng):
         assert float((tensors[k][0] - run_full[k]).abs().max()) < 1e-5 * max(1.0, float(run_full[k].abs().max())), k
 
 
+def test_bf16_rows_bind_the_backward_to_the_forwards_arithmetic(eng):
+    """With bf16 operands (``train_bf16 = 1``) the forward leaves its edge rows in memory as bf16; a backward under another setting would
+    read them as float32. The library refuses (T2L_ESTATE) instead of differentiating garbage; the matching pair runs."""
+    from text2loc_amd.engine import T2LError
+
+    cells = synth.make_cells(3, seed=4, min_obj=2, max_obj=5)
+    pos, rgb = synth.make_sampled_points(cells, 2)
+    offs = np.asarray(cells["offsets"], dtype=np.int32)
+    dpos, drgb = torch.from_numpy(pos).cuda(), torch.from_numpy(rgb).cuda()
+    g = torch.randn(pos.shape[0], 256, generator=torch.Generator().manual_seed(1)).cuda()
+    try:
+        for fwd, bwd in ((1, 0), (0, 1), (2, 1)):
+            bind_all(eng, synth.make_object_branch_weights(2), synth.make_pointnet_weights(3))
+            eng.set_option("train_bf16", fwd)
+            eng.pointnet_features_train(dpos, drgb, offs)
+            eng.set_option("train_bf16", bwd)
+            with pytest.raises(T2LError, match="train_bf16 changed"):
+                eng.pointnet_backward(g)
+            eng.set_option("train_bf16", fwd)
+            eng.pointnet_backward(g)  # the forward's own arithmetic: fine
+        torch.cuda.synchronize()
+    finally:
+        eng.set_option("train_bf16", 0)
+
+
 @pytest.mark.parametrize("mode,tol", [(2, 2e-3), (1, 6e-2)])
 def test_reduced_precision_gemms_track_the_f32_run_on_a_ragged_batch(eng, mode, tol):
     """The training GEMMs (weights resident in LDS, BatchNorm sums in the epilogue, the first layer's BatchNorm + ReLU applied by
