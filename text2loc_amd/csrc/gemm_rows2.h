@@ -456,6 +456,27 @@ __global__ __launch_bounds__(kRows2Threads) void tn2_kernel(const Tn2Args g) {
 #ifdef T2L_EXP_TN2_NOATOMIC  // dev experiment (wrong results): what do the final float atomics cost?
   if (acc[0][0] != 1.2345e30f) return;
 #endif
+  // The RG row groups of the workgroup hold partial sums of the SAME output tiles: they meet in LDS (the staging buffers are free
+  // now) and only the first group's waves go to memory — the float atomics of all 256 workgroups land on the same N x K addresses, and
+  // for the small first-level gradients (32 x 32: 1,024 addresses) 8 x as many of them cost 174 us of a 411 us launch (round 6).
+  if constexpr (RG >= 4) {  // (two row groups of a wide block: the LDS round costs more than the uncontended atomics it saves — measured)
+    static_assert((size_t)8 * KT * 16 * 64 <= (size_t)2 * buf_floats, "the partial tiles fit the staging buffers");
+    float* red = lds + (size_t)(w * KT) * 1024 + lane;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(t * 16 + r) * 64] = acc[t][r];
+    __syncthreads();
+    if (rg != 0) return;
+#pragma unroll
+    for (int q = 1; q < RG; ++q) {
+      const float* o = lds + (size_t)((q * NT + nt) * KT) * 1024 + lane;
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] += o[(t * 16 + r) * 64];
+    }
+  }
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
     const int k = k_base + t * 32 + i;
