@@ -161,3 +161,23 @@ def test_run_coarse_at_config2_size_in_the_published_mode():
     bbox = np.array([c.bbox_w[0:2] for c in ds.all_cells])
     rat = O.coarse_pose_accuracies(ridx, poses_xy, pose_scene, bbox, cell_scene, ds.all_cells[0].cell_size, args.top_k, args.threshs)
     assert at == rat
+
+
+def test_arithmetic_ab_tool_on_a_small_dataset():
+    """tools/arith_ab.py (bench.py's `arithmetic_ab` secondary) end to end at a size that takes seconds: the coarse
+    model trains on a synthetic dataset, the validation poses are searched with the database built in split-f16 and in plain f16 —
+    the exact run repeats bit for bit, the plain-f16 embeddings stay within the north star's 1e-3, and the report has its fields."""
+    import importlib.util
+    import os.path as osp
+
+    spec = importlib.util.spec_from_file_location("arith_ab", osp.join(osp.dirname(osp.dirname(osp.abspath(__file__))), "tools", "arith_ab.py"))
+    ab = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ab)
+    r = ab.measure(published=False, n_cells=512, n_train=512, n_eval=256, epochs=2)
+    assert r["exact_run_repeats_bit_for_bit"]
+    assert len(r["train_losses"]) == 2 and r["train_losses"][1] < r["train_losses"][0]
+    for name in ("db_f16_vs_exact", "all_f16_vs_exact"):
+        d = r[name]
+        assert 0.0 < d["max_abs_cell_embedding_diff"] < 1e-3, d
+        assert d["same_list_top1"] >= 0.95 and 0.0 <= d["same_list_top10"] <= 1.0
+    assert set(r["recall"]) == {"exact", "db_f16", "all_f16"}
